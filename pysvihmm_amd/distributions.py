@@ -1,0 +1,284 @@
+"""Emission-distribution plugins (the pybasicbayes duck type the reference uses).
+
+The reference imports ``Gaussian`` / ``Categorical`` from the un-vendored
+``pybasicbayes`` submodule (reference ``.gitmodules:1-3``; the directory is empty
+in the reference tree, no commit pin is recoverable).  These classes restate the
+published algorithm of that package (mattjj/pybasicbayes ``distributions.py``,
+NIW mean-field per Bishop PRML eqs. 10.59-10.65, 10.71, 10.74, 10.77) and expose
+exactly the members the reference touches:
+
+  ``Gaussian(mu=, sigma=, mu_0=, sigma_0=, kappa_0=, nu_0=)``
+        reference ``test_hmmsgd_metaobs.py:22-33,45-46``
+  ``.expected_log_likelihood(x)``   ``hmmbase.py:220``, ``hmmsgd_metaobs.py:509,686,816,1176``
+  ``.meanfieldupdate(data, w)``     ``hmmbatchcd.py:189``
+  ``._get_weighted_statistics`` / ``._posterior_hypparams``   ``util.py:69``
+  ``.get_vlb()``                    ``hmmbase.py:185``, ``hmmsgd_metaobs.py:294``
+  ``.rvs(size)``                    ``gen_synthetic.py:32,40``
+  ``.mu_mf .sigma_mf .kappa_mf .nu_mf .mu_0 .sigma_0 .kappa_0 .nu_0 .mu .sigma``
+        read and written by ``util.NIW_mf_moment_pars`` (``util.py:40-60``)
+
+Parity status: *unpinned* -- no reference test or fixture pins this arithmetic
+and the upstream source is absent; the device emission kernel is checked against
+this class (and the C oracle), everything downstream of ``lliks`` is checked
+against the reference's own code (tests/golden).
+"""
+
+import numpy as np
+import scipy.linalg as sla
+from scipy.special import digamma, gammaln
+
+__all__ = ["Gaussian", "Categorical", "sample_niw", "sample_invwishart",
+           "niw_quadratic_form"]
+
+
+# --------------------------------------------------------------------------- #
+#  samplers (pybasicbayes.util.stats)                                         #
+# --------------------------------------------------------------------------- #
+def sample_invwishart(lmbda, dof):
+    """Draw from an inverse-Wishart IW(lmbda, dof) (Bartlett decomposition).
+
+    Used by the reference harness only (``cluster/exper_run_simple.py:12,121``).
+    """
+    lmbda = np.asarray(lmbda, dtype=np.float64)
+    n = lmbda.shape[0]
+    chol = np.linalg.cholesky(lmbda)
+    if (dof <= 81 + n) and (dof == np.round(dof)):
+        x = np.random.randn(int(dof), n)
+    else:
+        x = np.diag(np.sqrt(np.atleast_1d(
+            np.random.chisquare(dof - np.arange(n)))))
+        x[np.triu_indices_from(x, 1)] = np.random.randn(n * (n - 1) // 2)
+    R = np.linalg.qr(x, 'r')
+    T = sla.solve_triangular(R.T, chol.T, lower=True).T
+    return T.dot(T.T)
+
+
+def sample_niw(mu, lmbda, kappa, nu):
+    """Draw (mu, Sigma) from a normal-inverse-Wishart."""
+    lmbda = sample_invwishart(lmbda, nu)
+    mu = np.random.multivariate_normal(mu, lmbda / kappa)
+    return mu, lmbda
+
+
+# --------------------------------------------------------------------------- #
+#  NIW mean-field Gaussian                                                    #
+# --------------------------------------------------------------------------- #
+def _loglmbdatilde(sigma_mf, nu_mf):
+    """E_q[log |Lambda|] for Lambda ~ Wishart, Bishop eq. 10.65."""
+    D = sigma_mf.shape[0]
+    chol = np.linalg.cholesky(sigma_mf)
+    return (digamma((nu_mf - np.arange(D)) / 2.).sum() + D * np.log(2.)
+            - 2. * np.log(chol.diagonal()).sum())
+
+
+def niw_quadratic_form(mu_mf, sigma_mf, kappa_mf, nu_mf):
+    """Canonical quadratic form of the NIW expected log-likelihood.
+
+    Returns ``(W[D,D], v[D], c)`` with
+    ``E_q[log N(x)] = c + v.x - x' W x``  where ``W = (nu/2) sigma_mf^-1``,
+    ``v = 2 W mu``, ``c = const - mu' W mu``.  This is the parameter block the
+    device emission kernel consumes ("emission feature GEMM").
+    """
+    D = len(mu_mf)
+    W = 0.5 * nu_mf * np.linalg.inv(sigma_mf)
+    W = 0.5 * (W + W.T)
+    v = 2. * W.dot(mu_mf)
+    const = (0.5 * _loglmbdatilde(sigma_mf, nu_mf) - D / (2. * kappa_mf)
+             - 0.5 * D * np.log(2. * np.pi))
+    c = const - mu_mf.dot(W).dot(mu_mf)
+    return W, v, c
+
+
+class Gaussian(object):
+    """Multivariate Gaussian with a normal-inverse-Wishart prior and an NIW
+    mean-field factor ``(mu_mf, sigma_mf, kappa_mf, nu_mf)``.
+    """
+
+    def __init__(self, mu=None, sigma=None, mu_0=None, sigma_0=None,
+                 kappa_0=None, nu_0=None, kappa_mf=None, nu_mf=None):
+        f = lambda a: None if a is None else np.array(a, dtype=np.float64)
+        self.mu = f(mu)
+        self.sigma = f(sigma)
+        self.mu_0 = f(mu_0)
+        self.sigma_0 = f(sigma_0)
+        self.kappa_0 = kappa_0
+        self.nu_0 = nu_0
+        self.kappa_mf = kappa_mf if kappa_mf is not None else kappa_0
+        self.nu_mf = nu_mf if nu_mf is not None else nu_0
+        self.mu_mf = self.mu
+        self.sigma_mf = self.sigma
+        have_prior = not any(a is None for a in (mu_0, sigma_0, kappa_0, nu_0))
+        if mu is None and sigma is None and have_prior:
+            self.resample()  # initialise from the prior, as upstream does
+
+    # -- sampling ------------------------------------------------------------
+    def resample(self, data=()):
+        D = len(self.mu_0)
+        if len(data) == 0:
+            hyp = (self.mu_0, self.sigma_0, self.kappa_0, self.nu_0)
+        else:
+            data = np.reshape(np.asarray(data, dtype=np.float64), (-1, D))
+            hyp = self._posterior_hypparams(
+                *self._get_weighted_statistics(data, np.ones(len(data)), D))
+        self.mu, self.sigma = sample_niw(*hyp)
+        self.mu_mf, self.sigma_mf = self.mu, self.sigma
+        return self
+
+    def rvs(self, size=None):
+        size = 1 if size is None else size
+        D = self.mu.shape[0]
+        shape = size + (D,) if isinstance(size, tuple) else (size, D)
+        chol = np.linalg.cholesky(self.sigma)
+        return self.mu + np.random.normal(size=shape).dot(chol.T)
+
+    def num_parameters(self):
+        D = len(self.mu_0 if self.mu_0 is not None else self.mu)
+        return D * (D + 1) / 2
+
+    # -- statistics / conjugate update --------------------------------------
+    def _get_weighted_statistics(self, data, weights, D=None):
+        D = len(self.mu_0) if D is None else D
+        data = np.reshape(data, (-1, D))
+        neff = weights.sum()
+        if neff > 0:
+            xbar = np.dot(weights, data) / neff
+            centered = data - xbar
+            sumsq = np.dot(centered.T, centered * weights[:, None])
+        else:
+            xbar, sumsq = None, None
+        return neff, xbar, sumsq
+
+    def _posterior_hypparams(self, n, xbar, sumsq):
+        mu_0, sigma_0, kappa_0, nu_0 = (self.mu_0, self.sigma_0, self.kappa_0,
+                                        self.nu_0)
+        if n > 0:
+            mu_n = kappa_0 / (kappa_0 + n) * mu_0 + n / (kappa_0 + n) * xbar
+            kappa_n = kappa_0 + n
+            nu_n = nu_0 + n
+            sigma_n = (sigma_0 + sumsq + kappa_0 * n / (kappa_0 + n)
+                       * np.outer(xbar - mu_0, xbar - mu_0))
+            return mu_n, sigma_n, kappa_n, nu_n
+        return mu_0, sigma_0, kappa_0, nu_0
+
+    def meanfieldupdate(self, data, weights):
+        D = len(self.mu_0)
+        self.mu_mf, self.sigma_mf, self.kappa_mf, self.nu_mf = \
+            self._posterior_hypparams(
+                *self._get_weighted_statistics(data, weights, D))
+        self.mu, self.sigma = self.mu_mf, self.sigma_mf / (self.nu_mf - D - 1)
+
+    # -- mean-field expectations ---------------------------------------------
+    def _loglmbdatilde(self):
+        return _loglmbdatilde(self.sigma_mf, self.nu_mf)
+
+    def expected_log_likelihood(self, x):
+        """E_q[log N(x | mu, Sigma)] under the NIW factor; NaN rows stay NaN
+        (callers apply ``np.nan_to_num``, reference ``hmmbase.py:220``)."""
+        mu_n, kappa_n, nu_n = self.mu_mf, self.kappa_mf, self.nu_mf
+        D = len(mu_n)
+        x = np.reshape(x, (-1, D)) - mu_n
+        chol = np.linalg.cholesky(self.sigma_mf)
+        xs = sla.solve_triangular(chol, x.T, lower=True, check_finite=False)
+        return (self._loglmbdatilde() / 2. - D / (2. * kappa_n)
+                - nu_n / 2. * np.einsum('ij,ij->j', xs, xs)
+                - D / 2. * np.log(2. * np.pi))
+
+    def quadratic_form(self):
+        return niw_quadratic_form(self.mu_mf, self.sigma_mf, self.kappa_mf,
+                                  self.nu_mf)
+
+    def get_vlb(self):
+        """E_q[log p(mu,Sigma)] + H[q] (Bishop eqs. 10.74 and 10.77)."""
+        D = len(self.mu_0)
+        llt = self._loglmbdatilde()
+        dmu = self.mu_mf - self.mu_0
+        q_entropy = (-0.5 * (llt + D * (np.log(self.kappa_mf / (2 * np.pi)) - 1))
+                     + _invwishart_entropy(self.sigma_mf, self.nu_mf))
+        p_avgengy = (0.5 * (D * np.log(self.kappa_0 / (2 * np.pi)) + llt
+                            - D * self.kappa_0 / self.kappa_mf
+                            - self.kappa_0 * self.nu_mf
+                            * np.dot(dmu, np.linalg.solve(self.sigma_mf, dmu)))
+                     + _invwishart_log_partitionfunction(self.sigma_0, self.nu_0)
+                     + (self.nu_0 - D - 1) / 2. * llt
+                     - 0.5 * self.nu_mf
+                     * np.linalg.solve(self.sigma_mf, self.sigma_0).trace())
+        return p_avgengy + q_entropy
+
+
+def _invwishart_log_partitionfunction(sigma, nu):
+    D = sigma.shape[0]
+    chol = np.linalg.cholesky(sigma)
+    return -1. * (nu * np.log(chol.diagonal()).sum()
+                  - (nu * D / 2. * np.log(2.) + D * (D - 1) / 4. * np.log(np.pi)
+                     + gammaln((nu - np.arange(D)) / 2.).sum()))
+
+
+def _invwishart_entropy(sigma, nu):
+    D = sigma.shape[0]
+    Elogdetlmbda = _loglmbdatilde(sigma, nu)
+    return (_invwishart_log_partitionfunction(sigma, nu)
+            - (nu - D - 1) / 2. * Elogdetlmbda + nu * D / 2.)
+
+
+# --------------------------------------------------------------------------- #
+#  Dirichlet-Categorical mean field                                           #
+# --------------------------------------------------------------------------- #
+class Categorical(object):
+    """Categorical emission with a Dirichlet prior ``alphav_0`` and Dirichlet
+    mean-field factor ``alpha_mf`` (reference use:
+    ``hmmsgd_metaobs.py:907-926,1071-1084``)."""
+
+    def __init__(self, weights=None, alpha_0=None, K=None, alphav_0=None,
+                 alpha_mf=None):
+        if alphav_0 is None and alpha_0 is not None and K is not None:
+            alphav_0 = np.repeat(alpha_0 / K, K)
+        self.alphav_0 = None if alphav_0 is None else np.array(alphav_0, float)
+        self.K = len(self.alphav_0) if self.alphav_0 is not None else K
+        self.weights = None if weights is None else np.array(weights, float)
+        if self.weights is None and self.alphav_0 is not None:
+            self.weights = np.random.dirichlet(self.alphav_0)
+        self._alpha_mf = (np.array(alpha_mf, float) if alpha_mf is not None
+                          else self.weights * self.alphav_0.sum()
+                          if self.alphav_0 is not None else None)
+
+    @property
+    def alpha_mf(self):
+        return self._alpha_mf
+
+    def num_parameters(self):
+        return len(self.weights)
+
+    def rvs(self, size=None):
+        return np.random.choice(len(self.weights), p=self.weights, size=size)
+
+    def _get_weighted_statistics(self, data, weights):
+        # ``weights`` is [N, C] already masked to the observed symbol
+        # (reference ``hmmsgd_metaobs.py:918-923``); data is ignored upstream
+        if np.ndim(weights) == 2:
+            return (weights.sum(0),)
+        counts = np.bincount(np.asarray(data, int), weights=weights,
+                             minlength=self.K)
+        return (counts,)
+
+    def _posterior_hypparams(self, counts):
+        return self.alphav_0 + counts
+
+    def meanfieldupdate(self, data, weights):
+        self._alpha_mf = self._posterior_hypparams(
+            *self._get_weighted_statistics(data, weights))
+        self.weights = self._alpha_mf / self._alpha_mf.sum()
+
+    def expected_log_likelihood(self, x):
+        x = np.asarray(x)
+        out = np.full(x.shape[0], np.nan)
+        ok = ~np.isnan(x.astype(float)).reshape(x.shape[0], -1).any(1)
+        el = digamma(self._alpha_mf) - digamma(self._alpha_mf.sum())
+        out[ok] = el[x[ok].astype(int).ravel()]
+        return out
+
+    def get_vlb(self):
+        a, a0 = self._alpha_mf, self.alphav_0
+        el = digamma(a) - digamma(a.sum())
+        logpi_p = gammaln(a0.sum()) - gammaln(a0).sum() + ((a0 - 1) * el).sum()
+        logpi_q = gammaln(a.sum()) - gammaln(a).sum() + ((a - 1) * el).sum()
+        return logpi_p - logpi_q
