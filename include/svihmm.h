@@ -1,0 +1,171 @@
+/* svihmm.h -- C ABI of the MI355X-native SVI-HMM E-step engine (libsvihmm_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of dillonalaird/pysvihmm:
+ *   emission expected log-likelihood -> log-domain forward/backward ->
+ *   posterior marginals -> expected sufficient statistics (natural-gradient
+ *   direction) -> (all-reduce) -> host global step.
+ * The reference has a single native boundary on this path, the Cython function
+ *   hmm_fast.FFBS(self, var_init, lalpha_init=None)          (hmm_fast.pyx:43-124)
+ * bound as VariationalHMMBase.ffbs_fast (hmmbase.py:409-411); everything else on
+ * the path is NumPy inside Python methods.  Each entry point below names the
+ * reference code (file:line under /root/reference) whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - Plain C: pointers + sizes, no C++/torch types.  All arrays are C-contiguous
+ *     row-major float64 unless stated; "host" pointers are borrowed for the call
+ *     only (caller keeps ownership); the library owns all device memory behind
+ *     the opaque handle.
+ *   - Every function returns 0 on success, non-zero on failure; the message of
+ *     the last failure on the calling thread is svihmm_last_error().  The Python
+ *     host raises RuntimeError (the reference's only exception type,
+ *     hmmbase.py:134, hmmsgd_metaobs.py:76,177,191,344).
+ *   - One thread per handle, one handle per device (the reference is
+ *     single-threaded and non-re-entrant).  Calls are synchronous with respect to
+ *     their host output buffers; device work runs on the handle's own HIP stream.
+ *   - A "window" is a meta-observation (hmmsgd_metaobs.py:42-45): Lm consecutive
+ *     rows of obs starting at starts[b] (inclusive bounds i1=starts[b],
+ *     i2=starts[b]+Lm-1).  A full-chain E-step is B=1, starts={0}, Lm=T.
+ */
+#ifndef SVIHMM_H
+#define SVIHMM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVIHMM_ABI_VERSION 1
+
+typedef struct svihmm_ctx svihmm_ctx;
+
+/* ---- flags ------------------------------------------------------------------ */
+/* Masked rows are treated as NaN rows when computing lliks (-> lliks row = 0):
+ * full_local_update semantics, hmmsgd_metaobs.py:1166-1168,1176.  Without it
+ * masked rows still contribute to lliks (infer() semantics, quirk Q9,
+ * hmmsgd_metaobs.py:314-315 commented out). */
+#define SVIHMM_MASK_AS_NAN 1u
+/* Transition statistic sum_{t=0}^{Lm-1} q[t-1] (x) q[t] with t-1 wrapping to the
+ * window's last row (quirk Q1, hmmsgd_metaobs.py:877-878).  Without it the batch
+ * form sum_{t=1}^{Lm-1} (hmmbatchcd.py:183-184, hmmbatchsgd.py:224-225). */
+#define SVIHMM_TRANS_WRAP 2u
+/* Use the lliks previously uploaded with svihmm_set_lliks (generic emission
+ * plugin route) instead of evaluating the NIW emission kernel. */
+#define SVIHMM_USE_HOST_LLIKS 4u
+
+/* ---- errors / lifecycle ------------------------------------------------------- */
+const char* svihmm_last_error(void);
+int svihmm_abi_version(void);
+int svihmm_device_count(int* n_out);
+int svihmm_create(int device_id, svihmm_ctx** out);
+int svihmm_destroy(svihmm_ctx* h);
+int svihmm_sync(svihmm_ctx* h);
+
+/* ---- inputs ----------------------------------------------------------------- */
+/* obs[T,D], mask[T] (1 = missing, may be NULL): hmmbase.py:60-65,122-123.
+ * Copied to HBM once; NaN entries are preserved. */
+int svihmm_set_obs(svihmm_ctx* h, const double* obs, int64_t T, int32_t D,
+                   const uint8_t* mask);
+
+/* mod_init[K], ltran[K,K] in the log domain: the psi-expectations of
+ * hmmbase.py:214-216 / hmmsgd_metaobs.py:502-504 (computed on the host with
+ * SciPy's digamma, uploaded once per minibatch).  The FFBS variant passes
+ * ltran = log(var_tran + DBL_EPSILON) instead (hmm_fast.pyx:91-93). */
+int svihmm_set_globals(svihmm_ctx* h, int32_t K, const double* mod_init,
+                       const double* ltran);
+
+/* NIW mean-field emission factors mu[K,D], sigma[K,D,D], kappa[K], nu[K]
+ * (pybasicbayes Gaussian.{mu_mf,sigma_mf,kappa_mf,nu_mf}); replaces the K calls
+ * odist.expected_log_likelihood(obs) at hmmbase.py:219-220,
+ * hmmsgd_metaobs.py:508-509,685-686,815-816,1175-1176, hmm_fast.pyx:84-85. */
+int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* mu,
+                            const double* sigma, const double* kappa,
+                            const double* nu);
+
+/* Generic plugin route: lliks[B,Lm,K] evaluated by an arbitrary emission object on
+ * the host (any object with expected_log_likelihood), already nan_to_num'ed. */
+int svihmm_set_lliks(svihmm_ctx* h, const double* lliks, int32_t B, int32_t Lm);
+
+/* ---- a3: emission expected log-likelihood ---------------------------------------- */
+/* out_lliks[B,Lm,K] = nan_to_num(E_q log p(obs[starts[b]+t] | theta_k)). */
+int svihmm_loglik(svihmm_ctx* h, const int64_t* starts, int32_t B, int32_t Lm,
+                  uint32_t flags, double* out_lliks);
+
+/* ---- a4..a7: messages, posterior, local bound ------------------------------------- */
+/* lalpha/lbeta/var_x [B,Lm,K], local_lb[B]; any output pointer may be NULL.
+ *   lalpha : hmmbase.py:292-295 == hmmsgd_metaobs.py:800-803
+ *   lbeta  : hmmbase.py:316-320 == hmmsgd_metaobs.py:851-855
+ *   var_x  : hmmbase.py:226-229 == hmmsgd_metaobs.py:516-519
+ *   local_lb[b] = sum_t LSE_k lalpha[b,t,k]  (hmmsgd_metaobs.py:271; quirk Q4) */
+int svihmm_forward_backward(svihmm_ctx* h, const int64_t* starts, int32_t B,
+                            int32_t Lm, uint32_t flags, double* out_lalpha,
+                            double* out_lbeta, double* out_var_x,
+                            double* out_local_lb);
+
+/* ---- a3..a9: whole minibatch E-step -> packed expected sufficient statistics --- */
+/* packed = [ A_raw(K*K) | xbar(K*D) | neff(K) | S(K*D*D) | lb(1) ], length
+ * svihmm_packed_size(K,D):
+ *   A_raw = sum_windows sum_t q[t-1] (x) q[t]       (hmmsgd_metaobs.py:876-878;
+ *           the caller adds B*(prior_tran-1), quirk Q2)
+ *   xbar_k, neff_k, S_k = sum over unmasked rows of q[t,k]*{x, 1, x x'}
+ *                                                    (util.py:73-83, :884-904)
+ *   lb    = sum_windows local_lb                     (hmmsgd_metaobs.py:436)
+ * out_packed may be NULL: the result then stays in HBM for
+ * svihmm_allreduce_packed / svihmm_read_packed. */
+int64_t svihmm_packed_size(int32_t K, int32_t D);
+int svihmm_estep_minibatch(svihmm_ctx* h, const int64_t* starts, int32_t B,
+                           int32_t Lm, uint32_t flags, double* out_packed);
+int svihmm_read_packed(svihmm_ctx* h, double* out_packed);
+
+/* Readback of the intermediates of the last estep/forward_backward call
+ * (what 0: lliks, 1: lalpha, 2: lbeta, 3: var_x; each [B,Lm,K]). */
+int svihmm_read_intermediate(svihmm_ctx* h, int32_t what, double* out);
+
+/* ---- a12: forward-filter backward-sample (hmm_fast.pyx:43-124) ---------------- */
+/* Forward filter over the whole chain with the globals currently set (the host
+ * passes the Cython variant's mod_init/ltran), then z[T-1] ~ softmax(lalpha[T-1]),
+ * z[t] ~ softmax_k(lalpha[t,k] + log_tran_col[k, z[t+1]]) by inverse CDF
+ * (rand_discrete, hmm_fast.pyx:29-36) with uniforms[t] in [0,1) supplied by the
+ * caller (libc rand() streams are not reproducible on a device).
+ * logA[K,K] = log(var_tran + DBL_EPSILON).  out_z[T] int64, out_lalpha[T,K] or NULL. */
+int svihmm_ffbs(svihmm_ctx* h, const double* logA, const double* uniforms,
+                uint32_t flags, int64_t* out_z, double* out_lalpha);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ----------------------------- */
+/* uid is a 128-byte ncclUniqueId produced on rank 0 and distributed by the host. */
+int svihmm_comm_unique_id(char uid_out[128]);
+int svihmm_comm_init(svihmm_ctx* h, const char uid[128], int32_t rank,
+                     int32_t nranks);
+int svihmm_comm_destroy(svihmm_ctx* h);
+/* In-place ncclAllReduce(sum, double) of the packed statistics in HBM: the
+ * "A_inter += A_i ; emit_inter[k] += e_i[k]" accumulation of
+ * hmmsgd_metaobs.py:430-436 extended across ranks. */
+int svihmm_allreduce_packed(svihmm_ctx* h);
+/* Generic all-reduce of a small host vector (op 0: sum, 1: max) through HBM;
+ * used for barriers and max-over-ranks timing. */
+int svihmm_allreduce_host(svihmm_ctx* h, double* buf, int64_t n, int32_t op);
+
+/* ---- measurement ------------------------------------------------------------------ */
+/* When enabled, every kernel launched by the handle is bracketed by HIP events on
+ * the handle's stream; svihmm_profile_read returns accumulated milliseconds and
+ * launch counts per kernel slot since the last reset. */
+#define SVIHMM_NKERN 12
+int svihmm_profile_enable(svihmm_ctx* h, int32_t on);
+int svihmm_profile_reset(svihmm_ctx* h);
+int svihmm_profile_read(svihmm_ctx* h, double ms_out[SVIHMM_NKERN],
+                        int64_t count_out[SVIHMM_NKERN]);
+const char* svihmm_kernel_name(int32_t slot);
+/* Selects the kernel generation for A/B measurement (0 = default/best). */
+int svihmm_set_variant(svihmm_ctx* h, int32_t which, int32_t value);
+
+/* ---- diagnostics ------------------------------------------------------------------- */
+/* One v_mfma_f64_16x16x4_f64 on A[16,4] x B[4,16] -> C[16,16] (operand-layout check). */
+int svihmm_selftest_mfma(svihmm_ctx* h, const double* A16x4, const double* B4x16,
+                         double* C16x16);
+/* fp64 throughput calibration: which 0 = v_mfma_f64_16x16x4_f64, 1 = v_fma_f64. */
+int svihmm_peak_fp64(svihmm_ctx* h, int32_t which, double* tflops_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVIHMM_H */

@@ -1,0 +1,112 @@
+"""ctypes binding of the C ABI in include/svihmm.h (libsvihmm_hip.so).
+
+There is no CPU fallback: if the shared library is missing or no HIP device is
+visible, using the engine raises ``RuntimeError``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsvihmm_hip.so")
+
+NKERN = 12
+MASK_AS_NAN = 1
+TRANS_WRAP = 2
+USE_HOST_LLIKS = 4
+
+_lib = None
+
+_c_double_p = C.POINTER(C.c_double)
+_c_int64_p = C.POINTER(C.c_int64)
+_c_uint8_p = C.POINTER(C.c_uint8)
+
+# name -> (restype, argtypes); mirrors include/svihmm.h one to one
+SIGNATURES = {
+    "svihmm_last_error": (C.c_char_p, []),
+    "svihmm_abi_version": (C.c_int, []),
+    "svihmm_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "svihmm_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "svihmm_destroy": (C.c_int, [C.c_void_p]),
+    "svihmm_sync": (C.c_int, [C.c_void_p]),
+    "svihmm_set_obs": (C.c_int, [C.c_void_p, _c_double_p, C.c_int64, C.c_int32, _c_uint8_p]),
+    "svihmm_set_globals": (C.c_int, [C.c_void_p, C.c_int32, _c_double_p, _c_double_p]),
+    "svihmm_set_emission_niw": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _c_double_p,
+                                          _c_double_p, _c_double_p, _c_double_p]),
+    "svihmm_set_lliks": (C.c_int, [C.c_void_p, _c_double_p, C.c_int32, C.c_int32]),
+    "svihmm_loglik": (C.c_int, [C.c_void_p, _c_int64_p, C.c_int32, C.c_int32, C.c_uint32,
+                                _c_double_p]),
+    "svihmm_forward_backward": (C.c_int, [C.c_void_p, _c_int64_p, C.c_int32, C.c_int32,
+                                          C.c_uint32, _c_double_p, _c_double_p, _c_double_p,
+                                          _c_double_p]),
+    "svihmm_packed_size": (C.c_int64, [C.c_int32, C.c_int32]),
+    "svihmm_estep_minibatch": (C.c_int, [C.c_void_p, _c_int64_p, C.c_int32, C.c_int32,
+                                         C.c_uint32, _c_double_p]),
+    "svihmm_read_packed": (C.c_int, [C.c_void_p, _c_double_p]),
+    "svihmm_read_intermediate": (C.c_int, [C.c_void_p, C.c_int32, _c_double_p]),
+    "svihmm_ffbs": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, C.c_uint32, _c_int64_p,
+                              _c_double_p]),
+    "svihmm_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "svihmm_comm_init": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32]),
+    "svihmm_comm_destroy": (C.c_int, [C.c_void_p]),
+    "svihmm_allreduce_packed": (C.c_int, [C.c_void_p]),
+    "svihmm_allreduce_host": (C.c_int, [C.c_void_p, _c_double_p, C.c_int64, C.c_int32]),
+    "svihmm_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
+    "svihmm_profile_reset": (C.c_int, [C.c_void_p]),
+    "svihmm_profile_read": (C.c_int, [C.c_void_p, _c_double_p, _c_int64_p]),
+    "svihmm_kernel_name": (C.c_char_p, [C.c_int32]),
+    "svihmm_set_variant": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "svihmm_selftest_mfma": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, _c_double_p]),
+    "svihmm_peak_fp64": (C.c_int, [C.c_void_p, C.c_int32, _c_double_p]),
+}
+
+
+def load():
+    """Load libsvihmm_hip.so (once) and attach the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "HIP extension not built: %s is missing. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C pysvihmm_amd/csrc` (there is no CPU fallback)." % LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    except OSError as e:
+        raise RuntimeError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().svihmm_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s" % (what or "svihmm call", last_error()))
+
+
+def dptr(a):
+    return None if a is None else a.ctypes.data_as(_c_double_p)
+
+
+def i64ptr(a):
+    return None if a is None else a.ctypes.data_as(_c_int64_p)
+
+
+def u8ptr(a):
+    return None if a is None else a.ctypes.data_as(_c_uint8_p)
+
+
+def as_f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise RuntimeError("expected array of shape %s, got %s" % (shape, a.shape))
+    return a

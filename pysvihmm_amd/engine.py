@@ -1,0 +1,225 @@
+"""HipEngine: thin object wrapper over the C ABI (one handle = one GPU).
+
+This is the E-step "operator" the host classes call; it mirrors the steps of the
+reference's ``local_update`` / ``intermediate_pars`` (hmmsgd_metaobs.py:487-519,
+857-928) but on whole minibatches of windows at once.  Device handles never live
+in a pickled ``__dict__`` (the reference pickles whole VBHMM objects,
+cluster/run_cluster_simple.py:32-37).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class PackedStats(object):
+    """View of the packed statistics buffer
+    ``[A_raw K*K | xbar K*D | neff K | S K*D*D | lb]``."""
+
+    def __init__(self, buf, K, D):
+        self.buf, self.K, self.D = buf, K, D
+        o = 0
+        self.A_raw = buf[o:o + K * K].reshape(K, K); o += K * K
+        self.xbar = buf[o:o + K * D].reshape(K, D); o += K * D
+        self.neff = buf[o:o + K]; o += K
+        self.S = buf[o:o + K * D * D].reshape(K, D, D); o += K * D * D
+        self.lb = buf[o:o + 1]
+
+    @staticmethod
+    def size(K, D):
+        return K * K + K * D + K + K * D * D + 1
+
+
+class HipEngine(object):
+    """E-step engine on one MI355X.  Raises RuntimeError when the HIP library or
+    a GPU is unavailable (no fallback)."""
+
+    name = "hip"
+
+    def __init__(self, device=0):
+        self._lib = L.load()
+        h = C.c_void_p()
+        L.check(self._lib.svihmm_create(int(device), C.byref(h)), "svihmm_create")
+        self._h = h
+        self.device = int(device)
+        self.T = self.D = self.K = 0
+        self._comm = False
+
+    # -- lifecycle ------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.svihmm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __getstate__(self):
+        raise RuntimeError("HipEngine holds device memory and cannot be pickled; "
+                           "VBHMM objects drop it in __getstate__")
+
+    def sync(self):
+        L.check(self._lib.svihmm_sync(self._h), "svihmm_sync")
+
+    # -- inputs ----------------------------------------------------------------------
+    def set_obs(self, obs, mask=None):
+        obs = np.asarray(obs, dtype=np.float64)
+        if obs.ndim == 1:
+            obs = obs[:, None]
+        obs = np.ascontiguousarray(obs)
+        T, D = obs.shape
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
+            if m.shape != (T,):
+                raise RuntimeError("mask must have shape (T,)")
+        L.check(self._lib.svihmm_set_obs(self._h, L.dptr(obs), T, D, L.u8ptr(m)), "svihmm_set_obs")
+        self.T, self.D = T, D
+
+    def set_globals(self, mod_init, ltran):
+        ltran = L.as_f64(ltran)
+        K = ltran.shape[0]
+        mod_init = L.as_f64(mod_init, (K,))
+        if ltran.shape != (K, K):
+            raise RuntimeError("ltran must be square")
+        L.check(self._lib.svihmm_set_globals(self._h, K, L.dptr(mod_init), L.dptr(ltran)),
+                "svihmm_set_globals")
+        self.K = K
+
+    def set_emission_niw(self, mu, sigma, kappa, nu):
+        mu = L.as_f64(mu)
+        K, D = mu.shape
+        sigma = L.as_f64(sigma, (K, D, D))
+        kappa = L.as_f64(kappa, (K,))
+        nu = L.as_f64(nu, (K,))
+        L.check(self._lib.svihmm_set_emission_niw(self._h, K, D, L.dptr(mu), L.dptr(sigma),
+                                                  L.dptr(kappa), L.dptr(nu)),
+                "svihmm_set_emission_niw")
+
+    def set_lliks(self, lliks):
+        lliks = L.as_f64(lliks)
+        B, Lm, K = lliks.shape
+        L.check(self._lib.svihmm_set_lliks(self._h, L.dptr(lliks), B, Lm), "svihmm_set_lliks")
+
+    # -- compute -----------------------------------------------------------------------
+    @staticmethod
+    def _starts(starts):
+        return np.ascontiguousarray(np.asarray(starts, dtype=np.int64).ravel())
+
+    def loglik(self, starts, Lm, flags=0):
+        st = self._starts(starts)
+        out = np.empty((len(st), Lm, self.K))
+        L.check(self._lib.svihmm_loglik(self._h, L.i64ptr(st), len(st), int(Lm), int(flags),
+                                        L.dptr(out)), "svihmm_loglik")
+        return out
+
+    def forward_backward(self, starts, Lm, flags=0, want=("lalpha", "lbeta", "var_x", "local_lb"),
+                         B=None):
+        st = None if starts is None else self._starts(starts)
+        B = len(st) if st is not None else int(B)
+        res = {}
+        bufs = {}
+        for name in ("lalpha", "lbeta", "var_x"):
+            bufs[name] = np.empty((B, Lm, self.K)) if name in want else None
+        bufs["local_lb"] = np.empty(B) if "local_lb" in want else None
+        L.check(self._lib.svihmm_forward_backward(
+            self._h, L.i64ptr(st), B, int(Lm), int(flags), L.dptr(bufs["lalpha"]),
+            L.dptr(bufs["lbeta"]), L.dptr(bufs["var_x"]), L.dptr(bufs["local_lb"])),
+            "svihmm_forward_backward")
+        for k, v in bufs.items():
+            if v is not None:
+                res[k] = v
+        return res
+
+    def estep(self, starts, Lm, flags=L.TRANS_WRAP, read=True):
+        """Whole-minibatch E-step -> PackedStats (or None with read=False: the
+        statistics stay in HBM for allreduce())."""
+        st = self._starts(starts)
+        out = np.empty(PackedStats.size(self.K, self.D)) if read else None
+        L.check(self._lib.svihmm_estep_minibatch(self._h, L.i64ptr(st), len(st), int(Lm),
+                                                 int(flags), L.dptr(out)),
+                "svihmm_estep_minibatch")
+        return PackedStats(out, self.K, self.D) if read else None
+
+    def read_packed(self):
+        out = np.empty(PackedStats.size(self.K, self.D))
+        L.check(self._lib.svihmm_read_packed(self._h, L.dptr(out)), "svihmm_read_packed")
+        return PackedStats(out, self.K, self.D)
+
+    def read_intermediate(self, what, B, Lm):
+        idx = {"lliks": 0, "lalpha": 1, "lbeta": 2, "var_x": 3}[what]
+        out = np.empty((B, Lm, self.K))
+        L.check(self._lib.svihmm_read_intermediate(self._h, idx, L.dptr(out)),
+                "svihmm_read_intermediate")
+        return out
+
+    def ffbs(self, logA, uniforms, flags=0, want_lalpha=True):
+        logA = L.as_f64(logA, (self.K, self.K))
+        u = L.as_f64(uniforms, (self.T,))
+        z = np.empty(self.T, dtype=np.int64)
+        la = np.empty((self.T, self.K)) if want_lalpha else None
+        L.check(self._lib.svihmm_ffbs(self._h, L.dptr(logA), L.dptr(u), int(flags),
+                                      L.i64ptr(z), L.dptr(la)), "svihmm_ffbs")
+        return z, la
+
+    # -- multi-GPU ------------------------------------------------------------------------
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(128)
+        L.check(self._lib.svihmm_comm_unique_id(buf), "svihmm_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, uid, rank, nranks):
+        L.check(self._lib.svihmm_comm_init(self._h, uid, int(rank), int(nranks)),
+                "svihmm_comm_init")
+        self._comm = True
+
+    def allreduce_packed(self):
+        L.check(self._lib.svihmm_allreduce_packed(self._h), "svihmm_allreduce_packed")
+
+    def allreduce_host(self, arr, op="sum"):
+        a = np.ascontiguousarray(np.asarray(arr, dtype=np.float64).ravel())
+        L.check(self._lib.svihmm_allreduce_host(self._h, L.dptr(a), a.size,
+                                                1 if op == "max" else 0),
+                "svihmm_allreduce_host")
+        return a.reshape(np.shape(arr))
+
+    # -- measurement ------------------------------------------------------------------------
+    def profile(self, on=True):
+        L.check(self._lib.svihmm_profile_enable(self._h, 1 if on else 0), "profile_enable")
+
+    def profile_reset(self):
+        L.check(self._lib.svihmm_profile_reset(self._h), "profile_reset")
+
+    def profile_read(self):
+        ms = np.zeros(L.NKERN)
+        cnt = np.zeros(L.NKERN, dtype=np.int64)
+        L.check(self._lib.svihmm_profile_read(self._h, L.dptr(ms), L.i64ptr(cnt)), "profile_read")
+        names = [self._lib.svihmm_kernel_name(i).decode() for i in range(L.NKERN)]
+        return {n: (float(m), int(c)) for n, m, c in zip(names, ms, cnt) if c > 0}
+
+    def set_variant(self, which, value):
+        idx = {"emission": 0, "stats": 1, "fb": 2}[which] if isinstance(which, str) else which
+        L.check(self._lib.svihmm_set_variant(self._h, idx, int(value)), "set_variant")
+
+    def selftest_mfma(self, A, B):
+        A = L.as_f64(A, (16, 4)); B = L.as_f64(B, (4, 16))
+        out = np.empty((16, 16))
+        L.check(self._lib.svihmm_selftest_mfma(self._h, L.dptr(A), L.dptr(B), L.dptr(out)),
+                "selftest_mfma")
+        return out
+
+    def peak_fp64(self, which):
+        v = C.c_double()
+        L.check(self._lib.svihmm_peak_fp64(self._h, int(which), C.byref(v)), "peak_fp64")
+        return v.value
+
+
+def device_count():
+    n = C.c_int()
+    lib = L.load()
+    rc = lib.svihmm_device_count(C.byref(n))
+    return n.value if rc == 0 else 0

@@ -1,0 +1,262 @@
+"""GPU parity tests: the HIP path (through the C ABI) against (a) golden vectors
+from the executed reference and (b) the oracle, on identical inputs.
+
+Tolerances (north_star): posteriors and natural-gradient statistics within 1e-6
+relative in fp64.  The observed errors are ~1e-12; the asserts use 1e-9 where the
+arithmetic is pure reference arithmetic so regressions show early.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from tests.helpers import make_problem, unpack, relerr
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+META = sorted(glob.glob(os.path.join(GOLDEN, "metaobs_*.npz")))
+RTOL = 1e-6  # contract
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from pysvihmm_amd.engine import HipEngine
+    e = HipEngine(0)
+    yield e
+    e.close()
+
+
+def test_mfma_f64_operand_layout(eng):
+    rng = np.random.default_rng(1)
+    A = rng.normal(size=(16, 4)); B = rng.normal(size=(4, 16))  # asymmetric
+    C = eng.selftest_mfma(A, B)
+    np.testing.assert_allclose(C, A.dot(B), rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("path", META, ids=[os.path.basename(p)[:-4] for p in META])
+@pytest.mark.parametrize("evar", [1, 2], ids=["em_outer", "em_mfma"])
+def test_golden_windows(eng, path, evar):
+    """Per-window intermediates vs the executed reference."""
+    from pysvihmm_amd import _lib as L
+    g = np.load(path)
+    K, Lm = int(g["K"]), 2 * int(g["L"]) + 1
+    eng.set_variant("emission", evar)
+    eng.set_obs(g["obs"], g["mask"])
+    wpi = int(g["windows_per_iter"])
+    for it in range(int(g["maxit"])):
+        w0 = it * wpi
+        sl = slice(w0, w0 + wpi)
+        eng.set_globals(g["w_mod_init"][w0], g["w_mod_tran"][w0])
+        eng.set_emission_niw(g["w_mu"][w0], g["w_sigma"][w0], g["w_kappa"][w0], g["w_nu"][w0])
+        starts = g["w_i1"][sl]
+        ll = eng.loglik(starts, Lm)
+        # a3: emission arithmetic is third-party (unpinned): same formula, 1e-9 rel on O(1e2) values
+        np.testing.assert_allclose(ll, g["w_lliks"][sl], rtol=1e-9, atol=1e-8)
+        # a4..a7 from the reference's own lliks: pure reference arithmetic
+        eng.set_lliks(g["w_lliks"][sl])
+        r = eng.forward_backward(None, Lm, flags=L.USE_HOST_LLIKS, B=wpi)
+        np.testing.assert_allclose(r["lalpha"], g["w_lalpha"][sl], rtol=1e-10, atol=1e-9)
+        np.testing.assert_allclose(r["lbeta"], g["w_lbeta"][sl], rtol=1e-10, atol=1e-9)
+        np.testing.assert_allclose(r["var_x"], g["w_var_x"][sl], rtol=RTOL, atol=1e-12)
+        np.testing.assert_allclose(r["local_lb"], g["w_local_lb"][sl], rtol=1e-12)
+    eng.set_variant("emission", 0)
+
+
+@pytest.mark.parametrize("path", META, ids=[os.path.basename(p)[:-4] for p in META])
+@pytest.mark.parametrize("svar", [1, 2], ids=["st_outer", "st_mfma"])
+def test_golden_minibatch_stats(eng, path, svar):
+    """a8/a9: natural-gradient statistics of each minibatch vs the reference's
+    A_inter / emit_inter (hmmsgd_metaobs.py:430-433)."""
+    from pysvihmm_amd import _lib as L
+    g = np.load(path)
+    K, D, Lm = int(g["K"]), int(g["D"]), 2 * int(g["L"]) + 1
+    eng.set_variant("stats", svar)
+    eng.set_obs(g["obs"], g["mask"])
+    wpi = int(g["windows_per_iter"])
+    for it in range(int(g["maxit"])):
+        w0 = it * wpi
+        sl = slice(w0, w0 + wpi)
+        eng.set_globals(g["w_mod_init"][w0], g["w_mod_tran"][w0])
+        eng.set_emission_niw(g["w_mu"][w0], g["w_sigma"][w0], g["w_kappa"][w0], g["w_nu"][w0])
+        st = eng.estep(g["w_i1"][sl], Lm, flags=L.TRANS_WRAP)
+        A = st.A_raw + wpi * (g["prior_tran"] - 1.0)  # quirk Q2: prior-1 once per window
+        np.testing.assert_allclose(A, g["it_A_inter"][it], rtol=RTOL, atol=1e-9)
+        np.testing.assert_allclose(st.xbar, g["it_E_xbar"][it], rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(st.neff, g["it_E_neff"][it], rtol=RTOL, atol=1e-9)
+        np.testing.assert_allclose(st.S, g["it_E_S"][it], rtol=RTOL, atol=1e-7)
+        np.testing.assert_allclose(st.lb[0], g["w_local_lb"][sl].sum(), rtol=1e-11)
+    eng.set_variant("stats", 0)
+
+
+@pytest.mark.parametrize("path", META[:3], ids=[os.path.basename(p)[:-4] for p in META[:3]])
+def test_golden_full_local_update(eng, path):
+    """hmmsgd_metaobs.py:1147-1205: full chain, masked rows NaN'd -> lliks 0."""
+    from pysvihmm_amd import _lib as L
+    from oracle import ref_numpy as R
+    g = np.load(path)
+    T = int(g["T"])
+    mi, mt = R.psi_expectations(g["full_var_init"], g["it_var_tran_new"][-1])
+    eng.set_obs(g["obs"], g["mask"])
+    eng.set_globals(mi, mt)
+    eng.set_emission_niw(g["it_new_mu"][-1], g["it_new_sigma"][-1], g["it_new_kappa"][-1],
+                         g["it_new_nu"][-1])
+    r = eng.forward_backward([0], T, flags=L.MASK_AS_NAN, want=("var_x",))
+    np.testing.assert_allclose(r["var_x"][0], g["full_var_x"], rtol=RTOL, atol=1e-10)
+
+
+@pytest.mark.parametrize("name", ["batchcd_K4_D2_T300", "batchsgd_K4_D3_T250"])
+def test_golden_batch(eng, name):
+    """hmmbase.local_update (hmmbase.py:201-229) + batch transition statistic."""
+    from pysvihmm_amd import _lib as L
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    T = int(g["T"])
+    for it in range(g["it_lliks"].shape[0]):
+        eng.set_globals(g["it_mod_init"][it], g["it_mod_tran"][it])
+        eng.set_lliks(g["it_lliks"][it][None])
+        r = eng.forward_backward(None, T, flags=L.USE_HOST_LLIKS, B=1)
+        np.testing.assert_allclose(r["lalpha"][0], g["it_lalpha"][it], rtol=1e-10, atol=1e-9)
+        np.testing.assert_allclose(r["lbeta"][0], g["it_lbeta"][it], rtol=1e-10, atol=1e-9)
+        np.testing.assert_allclose(r["var_x"][0], g["it_var_x"][it], rtol=RTOL, atol=1e-12)
+    # batch-form transition statistic (no wrap) on the last iteration, vs hmmbatchcd.py:183-184
+    if not int(g["sgd"]):
+        eng.set_obs(g["obs"], g["mask"])
+        st = eng.estep([0], T, flags=L.USE_HOST_LLIKS)
+        np.testing.assert_allclose(g["prior_tran"] + st.A_raw, g["it_var_tran_new"][-1],
+                                   rtol=RTOL, atol=1e-10)
+
+
+CASES = [  # K, D, T, Lm, B, miss
+    (2, 1, 300, 5, 7, 0.0),
+    (3, 3, 500, 1, 9, 0.2),      # Lm = 1: no recursion step, wrap term only
+    (5, 2, 400, 2, 33, 0.1),
+    (16, 8, 4000, 65, 40, 0.1),
+    (64, 32, 6000, 257, 20, 0.05),
+    (24, 5, 3000, 40, 17, 0.0),  # K, D not multiples of the tile sizes
+    (80, 6, 2000, 30, 6, 0.1),   # generic K > 64 (LDS transition matrix)
+    (150, 4, 1500, 20, 4, 0.0),  # generic K, transition matrix from HBM/L2
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=["K%d_D%d_T%d_Lm%d_B%d_m%g" % c for c in CASES])
+@pytest.mark.parametrize("var", [1, 2], ids=["outer", "mfma"])
+def test_random_vs_c_oracle(eng, case, var):
+    from pysvihmm_amd import _lib as L
+    from oracle import ref_c
+    K, D, T, Lm, B, miss = case
+    pb = make_problem(K, D, T, seed=100 + K + D, miss=miss)
+    rng = np.random.default_rng(K * 7 + D)
+    starts = rng.integers(0, T - Lm + 1, size=B)
+    eng.set_variant("emission", var); eng.set_variant("stats", var)
+    eng.set_obs(pb["obs"], pb["mask"])
+    eng.set_globals(pb["mod_init"], pb["ltran"])
+    eng.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    for flags in (L.TRANS_WRAP, L.TRANS_WRAP | L.MASK_AS_NAN, 0):
+        st = eng.estep(starts, Lm, flags=flags)
+        ref = ref_c.estep_minibatch(pb["obs"], pb["mask"], starts, Lm, pb["mod_init"],
+                                    pb["ltran"], pb["mu"], pb["sigma"], pb["kappa"], pb["nu"],
+                                    flags=flags)
+        A, xbar, neff, S, lb = unpack(ref, K, D)
+        scale = B * Lm
+        np.testing.assert_allclose(st.A_raw, A, rtol=RTOL, atol=1e-9 * scale)
+        np.testing.assert_allclose(st.neff, neff, rtol=RTOL, atol=1e-9 * scale)
+        np.testing.assert_allclose(st.xbar, xbar, rtol=RTOL, atol=1e-8 * scale)
+        np.testing.assert_allclose(st.S, S, rtol=RTOL, atol=1e-7 * scale)
+        np.testing.assert_allclose(st.lb[0], lb, rtol=1e-9)
+    eng.set_variant("emission", 0); eng.set_variant("stats", 0)
+
+
+def test_nan_rows_and_all_masked(eng):
+    """NaN observation rows give lliks 0 (np.nan_to_num, hmmbase.py:220); a fully
+    masked window contributes nothing to the emission statistics."""
+    from pysvihmm_amd import _lib as L
+    from oracle import ref_c
+    pb = make_problem(6, 3, 200, seed=5)
+    obs = pb["obs"].copy()
+    obs[10:14] = np.nan
+    obs[50, 1] = np.nan
+    mask = np.zeros(200, bool); mask[100:140] = True; mask[10:14] = True; mask[50] = True
+    eng.set_obs(obs, mask)
+    eng.set_globals(pb["mod_init"], pb["ltran"])
+    eng.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    ll = eng.loglik([0, 40], 30)
+    assert np.all(ll[0, 10:14] == 0.0) and np.all(ll[1, 10] == 0.0)
+    assert np.all(np.isfinite(ll))
+    st = eng.estep([100], 40, flags=L.TRANS_WRAP)
+    assert np.all(st.neff == 0) and np.all(st.S == 0) and np.all(st.xbar == 0)
+    np.testing.assert_allclose(st.A_raw.sum(), 40.0, rtol=1e-12)
+    st = eng.estep([0, 40], 30, flags=L.TRANS_WRAP)
+    ref = ref_c.estep_minibatch(obs, mask, [0, 40], 30, pb["mod_init"], pb["ltran"], pb["mu"],
+                                pb["sigma"], pb["kappa"], pb["nu"], flags=2)
+    np.testing.assert_allclose(st.buf, ref, rtol=RTOL, atol=1e-8)
+
+
+def test_error_paths(eng):
+    pb = make_problem(4, 2, 100, seed=3)
+    eng.set_obs(pb["obs"], None)
+    eng.set_globals(pb["mod_init"], pb["ltran"])
+    eng.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    with pytest.raises(RuntimeError):
+        eng.estep([90], 20)           # window runs off the end
+    with pytest.raises(RuntimeError):
+        eng.estep([-1], 5)
+    bad = pb["sigma"].copy(); bad[0] = -np.eye(2)
+    with pytest.raises(RuntimeError):
+        eng.set_emission_niw(pb["mu"], bad, pb["kappa"], pb["nu"])
+
+
+def test_ffbs(eng):
+    """hmm_fast.pyx:43-124: lalpha of the Cython variant exactly; z given a uniform stream."""
+    from oracle import ref_numpy as R
+    from scipy.special import digamma
+    g = np.load(os.path.join(GOLDEN, "ffbs_K5_D3_T120.npz"))
+    T, K = int(g["T"]), int(g["K"])
+    DE = np.finfo(np.float64).eps
+    mod_init = digamma(g["var_init"] + DE) - digamma(g["var_init"].sum() + DE)
+    logA = np.log(g["var_tran"] + DE)
+    eng.set_obs(g["obs"], None)
+    eng.set_globals(mod_init, logA)
+    eng.set_emission_niw(g["mu"], g["sigma"], g["kappa"], g["nu"])
+    u = np.random.default_rng(9).random(T)
+    z, la = eng.ffbs(logA, u)
+    np.testing.assert_allclose(la, g["lalpha"], rtol=1e-9, atol=1e-8)
+    zref = R.ffbs_backward_sample(g["lalpha"], g["var_tran"], u)
+    assert (z == zref).mean() > 0.98
+    assert z.min() >= 0 and z.max() < K
+
+
+def test_full_size_properties(eng):
+    """BASELINE config 3 shape (K=64, D=32, Lm=257) at a large batch: size-independent
+    properties of the statistics (the oracle would take minutes here)."""
+    from pysvihmm_amd import _lib as L
+    K, D, Lm = 64, 32, 257
+    T = 200000
+    pb = make_problem(K, D, T, seed=77, miss=0.1, sep=5.0)
+    B = T // Lm
+    starts = np.arange(B, dtype=np.int64) * Lm
+    eng.set_obs(pb["obs"], pb["mask"])
+    eng.set_globals(pb["mod_init"], pb["ltran"])
+    eng.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    st = eng.estep(starts, Lm, flags=L.TRANS_WRAP)
+    n = B * Lm
+    keep = ~pb["mask"][:n]
+    X = pb["obs"][:n][keep]
+    # posteriors sum to one => these identities hold for any correct E-step
+    np.testing.assert_allclose(st.A_raw.sum(), n, rtol=1e-10)
+    np.testing.assert_allclose(st.neff.sum(), keep.sum(), rtol=1e-10)
+    np.testing.assert_allclose(st.xbar.sum(0), X.sum(0), rtol=1e-8, atol=1e-6)
+    np.testing.assert_allclose(st.S.sum(0), X.T.dot(X), rtol=1e-8, atol=1e-5)
+    np.testing.assert_allclose(st.S, np.swapaxes(st.S, 1, 2), rtol=0, atol=0)
+    q = eng.read_intermediate("var_x", B, Lm)
+    np.testing.assert_allclose(q.sum(-1), 1.0, rtol=1e-12)
+    # marginal consistency: row sums of the transition statistic = sum_t q[t-1] (wrap => all t)
+    np.testing.assert_allclose(st.A_raw.sum(1), q.sum((0, 1)), rtol=1e-9)
+    np.testing.assert_allclose(st.A_raw.sum(0), q.sum((0, 1)), rtol=1e-9)
+    # a subset of windows against the C oracle
+    from oracle import ref_c
+    sub = starts[:3]
+    st2 = eng.estep(sub, Lm, flags=L.TRANS_WRAP)
+    ref = ref_c.estep_minibatch(pb["obs"], pb["mask"], sub, Lm, pb["mod_init"], pb["ltran"],
+                                pb["mu"], pb["sigma"], pb["kappa"], pb["nu"], flags=2)
+    np.testing.assert_allclose(st2.buf, ref, rtol=RTOL, atol=1e-6)
