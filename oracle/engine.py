@@ -1,0 +1,157 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+``OracleEngine`` exposes the same protocol as ``pysvihmm_amd.engine.HipEngine`` but
+evaluates every call with the reference restatement (oracle/ref_numpy.py, and the
+C port for speed).  Tests inject it into the host classes (``engine=``) to check
+the host logic on a machine without a GPU, and use it as the checker for the HIP
+engine.  The product never imports this module and has no CPU fallback.
+"""
+import numpy as np
+
+from . import ref_numpy as R
+from . import ref_c
+
+MASK_AS_NAN, TRANS_WRAP, USE_HOST_LLIKS = 1, 2, 4
+
+
+class _Packed(object):
+    def __init__(self, buf, K, D):
+        self.buf, self.K, self.D = buf, K, D
+        o = 0
+        self.A_raw = buf[o:o + K * K].reshape(K, K); o += K * K
+        self.xbar = buf[o:o + K * D].reshape(K, D); o += K * D
+        self.neff = buf[o:o + K]; o += K
+        self.S = buf[o:o + K * D * D].reshape(K, D, D); o += K * D * D
+        self.lb = buf[o:o + 1]
+
+
+class OracleEngine(object):
+    name = "oracle"
+
+    def __init__(self, device=0, use_c=True):
+        self.use_c = use_c
+        self.T = self.D = self.K = 0
+        self._host_ll = None
+        self._last = {}
+        self._packed = None
+        self._comm = None
+
+    def close(self):
+        pass
+
+    def sync(self):
+        pass
+
+    # -- inputs
+    def set_obs(self, obs, mask=None):
+        obs = np.array(obs, dtype=np.float64)
+        if obs.ndim == 1:
+            obs = obs[:, None]
+        self.obs = obs
+        self.T, self.D = obs.shape
+        self.mask = None if mask is None else np.asarray(mask).astype(bool).copy()
+
+    def set_globals(self, mod_init, ltran):
+        self.mod_init = np.array(mod_init, dtype=np.float64)
+        self.ltran = np.array(ltran, dtype=np.float64)
+        self.K = self.ltran.shape[0]
+
+    def set_emission_niw(self, mu, sigma, kappa, nu):
+        self.em = tuple(np.array(a, dtype=np.float64) for a in (mu, sigma, kappa, nu))
+        for k in range(len(self.em[2])):
+            np.linalg.cholesky(self.em[1][k])
+
+    def set_lliks(self, lliks):
+        self._host_ll = np.array(lliks, dtype=np.float64)
+
+    # -- compute
+    def _window_ll(self, s, Lm, flags):
+        x = self.obs[s:s + Lm]
+        if (flags & MASK_AS_NAN) and self.mask is not None:
+            x = x.copy()
+            x[self.mask[s:s + Lm]] = np.nan
+        f = ref_c.lliks_niw if self.use_c else R.lliks_niw
+        return f(x, *self.em)
+
+    def _check(self, starts, Lm):
+        for s in starts:
+            if s < 0 or s + Lm > self.T:
+                raise RuntimeError("window out of range")
+
+    def loglik(self, starts, Lm, flags=0):
+        starts = np.asarray(starts, dtype=np.int64).ravel()
+        self._check(starts, Lm)
+        return np.stack([self._window_ll(int(s), Lm, flags) for s in starts])
+
+    def _lls(self, starts, Lm, flags, B):
+        if flags & USE_HOST_LLIKS:
+            if self._host_ll is None or self._host_ll.shape[:2] != (B, Lm):
+                raise RuntimeError("no uploaded lliks of shape [B,Lm,K]")
+            return self._host_ll
+        return self.loglik(starts, Lm, flags)
+
+    def forward_backward(self, starts, Lm, flags=0,
+                         want=("lalpha", "lbeta", "var_x", "local_lb"), B=None):
+        st = None if starts is None else np.asarray(starts, dtype=np.int64).ravel()
+        B = len(st) if st is not None else int(B)
+        ll = self._lls(st, Lm, flags, B)
+        fw = ref_c.forward if self.use_c else R.forward_msgs
+        bw = ref_c.backward if self.use_c else R.backward_msgs
+        la = np.stack([fw(ll[b], self.mod_init, self.ltran) for b in range(B)])
+        lb = np.stack([bw(ll[b], self.ltran) for b in range(B)])
+        q = np.stack([R.posterior(la[b], lb[b]) for b in range(B)])
+        llb = np.array([R.local_lower_bound(la[b]) for b in range(B)])
+        self._last = dict(lliks=ll, lalpha=la, lbeta=lb, var_x=q, local_lb=llb)
+        return {k: self._last[k] for k in want}
+
+    def estep(self, starts, Lm, flags=TRANS_WRAP, read=True):
+        st = np.asarray(starts, dtype=np.int64).ravel()
+        self._check(st, Lm)
+        B = len(st)
+        self.forward_backward(st, Lm, flags)
+        K, D = self.K, self.D
+        buf = np.zeros(K * K + K * D + K + K * D * D + 1)
+        P = _Packed(buf, K, D)
+        q = self._last["var_x"]
+        for b in range(B):
+            s = int(st[b])
+            P.A_raw[:] += (R.transition_stat_wrap(q[b]) if flags & TRANS_WRAP
+                           else R.transition_stat_batch(q[b]))
+            inds = (np.ones(Lm, bool) if self.mask is None
+                    else np.logical_not(self.mask[s:s + Lm]))
+            x = self.obs[s:s + Lm][inds]
+            for k in range(K):
+                xb, ne, Sk = R.niw_suffstats(x, q[b][inds, k])
+                P.xbar[k] += xb; P.neff[k] += ne; P.S[k] += Sk
+        P.lb[0] = self._last["local_lb"].sum()
+        self._packed = P
+        return P if read else None
+
+    def read_packed(self):
+        return self._packed
+
+    def read_intermediate(self, what, B, Lm):
+        return self._last[what]
+
+    def read_rows(self, what, row0, nrows):
+        a = self._last[what]
+        return a.reshape(-1, a.shape[-1])[row0:row0 + nrows].copy()
+
+    def ffbs(self, logA, uniforms, flags=0, want_lalpha=True):
+        ll = self._window_ll(0, self.T, flags)
+        la = R.forward_msgs(ll, self.mod_init, self.ltran)
+        T, K = la.shape
+        z = np.empty(T, dtype=np.int64)
+        lp = la[T - 1]
+        p = np.exp(lp - lp.max()); p /= p.sum()
+        z[T - 1] = R.rand_discrete(p, uniforms[T - 1])
+        for t in range(T - 2, -1, -1):
+            lp = la[t] + logA[:, z[t + 1]]
+            p = np.exp(lp - lp.max()); p /= p.sum()
+            z[t] = R.rand_discrete(p, uniforms[t])
+        return z, la
+
+    # -- multi-process (host all-reduce through an injected communicator)
+    def allreduce_packed(self):
+        if self._comm is not None:
+            self._comm.allreduce_inplace(self._packed.buf)

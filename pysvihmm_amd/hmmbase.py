@@ -1,0 +1,354 @@
+"""VariationalHMMBase -- same class surface as the reference ``hmmbase.py``.
+
+The E-step methods (``local_update``, ``forward_msgs``, ``backward_msgs``,
+``full_local_update``, ``ffbs_fast``) run on the MI355X through the C ABI
+(``pysvihmm_amd.engine.HipEngine``); everything cheap and O(K^2 + K D^2) stays
+host-side NumPy with the reference's formulas: psi-expectations
+(reference hmmbase.py:214-216, SciPy digamma), ELBO (hmmbase.py:145-199), metrics
+(hmmbase.py:346-406).
+
+State flows through instance attributes exactly like the reference (``obs, mask,
+var_init, var_tran, var_emit, lliks, lalpha, lbeta, var_x, mod_init, mod_tran``).
+The engine handle is never pickled (``__getstate__``).
+
+``engine=`` lets a caller supply the engine object (tests inject the oracle to
+exercise the host logic without a GPU).  The default is the HIP engine; there is
+no CPU fallback: constructing it without the built library / a GPU raises.
+"""
+from __future__ import division
+
+import abc
+from copy import deepcopy
+
+import numpy as np
+import numpy.linalg as npl
+import scipy.spatial.distance as dist
+from numpy import newaxis as npa
+from scipy.special import digamma, gammaln
+
+from . import util
+from . import _lib as L
+from .distributions import Gaussian
+
+# This is for taking logs of things so we don't get -inf (reference hmmbase.py:30)
+eps = 1e-9
+DBL_EPSILON = float(np.finfo(np.float64).eps)
+
+
+def is_niw_gaussian(e):
+    """Device fast path is keyed on the concrete emission family, mirroring the
+    reference's ``type(self.var_emit[0]) is Gaussian`` dispatch
+    (hmmsgd_metaobs.py:887,1050)."""
+    return isinstance(e, Gaussian) or getattr(type(e), "svihmm_niw_fastpath", False)
+
+
+class VariationalHMMBase(object, metaclass=abc.ABCMeta):
+    """Abstract base class for finite variational HMMs."""
+
+    # Interface
+    @abc.abstractmethod
+    def global_update(self):
+        pass
+
+    @abc.abstractmethod
+    def infer(self):
+        """ Perform inference. """
+        pass
+
+    @staticmethod
+    def make_param_dict(prior_init, prior_tran, prior_emit, mask=None):
+        return {'prior_init': prior_init, 'prior_tran': prior_tran,
+                'prior_emit': prior_emit, 'mask': mask}
+
+    def set_mask(self, mask):
+        if mask is None:
+            self.mask = np.zeros(self.obs.shape[0], dtype='bool')
+        else:
+            self.mask = np.asarray(mask).astype('bool')
+        self._obs_dirty = True
+
+    def __init__(self, obs, prior_init, prior_tran, prior_emit, mask=None,
+                 init_init=None, init_tran=None, verbose=False, sts=None,
+                 engine=None, device=0):
+        self.verbose = verbose
+        self.sts = sts
+
+        # Save the hyperparameters
+        self.prior_init = deepcopy(np.asarray(prior_init)).astype('float64')
+        self.prior_tran = deepcopy(np.asarray(prior_tran)).astype('float64')
+        self.prior_emit = deepcopy(prior_emit)
+
+        # Initialize global variational distributions.
+        if init_init is None:
+            self.var_init = self.prior_init / np.sum(self.prior_init)
+        else:
+            self.var_init = np.array(init_init, dtype='float64')
+        if init_tran is None:
+            self.var_tran = self.prior_tran / np.sum(self.prior_tran, axis=1)[:, np.newaxis]
+        else:
+            self.var_tran = np.array(init_tran, dtype='float64')
+
+        # copy: mean and covariance of the prior objects are the (random) initial values
+        self.var_emit = deepcopy(prior_emit)
+
+        self.obs = obs
+        self.K = self.prior_tran.shape[0]
+        if obs.ndim == 1:
+            self.T = obs.shape[0]
+            self.D = 1
+        elif obs.ndim == 2:
+            self.T, self.D = obs.shape
+        else:
+            raise RuntimeError("obs must have 1 or 2 dimensions")
+        self.set_mask(mask)
+
+        self.elbo = -np.inf
+        self._engine = engine
+        self._device = device
+        self._obs_dirty = True
+        self._lZ = None
+
+    # -- engine plumbing -----------------------------------------------------------
+    @property
+    def engine(self):
+        if self._engine is None:
+            from .engine import HipEngine
+            self._engine = HipEngine(self._device)  # raises without library/GPU
+            self._obs_dirty = True
+        return self._engine
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d['_engine'] = None       # device handles are not picklable
+        d['_obs_dirty'] = True
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+
+    def set_data(self, obs, mask=None):
+        self.obs = obs
+        if mask is None:
+            self.mask = np.zeros(self.obs.shape[0], dtype='bool')
+        else:
+            self.mask = mask
+        self._obs_dirty = True
+
+    def _upload_obs(self, force=False):
+        """obs/mask -> HBM (once; again after set_data / in-place edits flagged by
+        ``_obs_dirty``)."""
+        if force or self._obs_dirty:
+            self.engine.set_obs(self.obs, self.mask)
+            self._obs_dirty = False
+
+    def _psi_expectations(self):
+        """reference hmmbase.py:214-216."""
+        self.mod_init = digamma(self.var_init + eps) - digamma(np.sum(self.var_init) + eps)
+        tran_sum = np.sum(self.var_tran, axis=1)
+        self.mod_tran = digamma(self.var_tran + eps) - digamma(tran_sum[:, npa] + eps)
+
+    def _emission_arrays(self):
+        ve = self.var_emit
+        return (np.array([g.mu_mf for g in ve], dtype=np.float64),
+                np.array([g.sigma_mf for g in ve], dtype=np.float64),
+                np.array([float(g.kappa_mf) for g in ve]),
+                np.array([float(g.nu_mf) for g in ve]))
+
+    def _niw_fastpath(self):
+        return all(is_niw_gaussian(e) for e in self.var_emit)
+
+    def _push_globals(self):
+        self.engine.set_globals(self.mod_init, self.mod_tran)
+
+    def _push_emission(self, windows=None, Lm=None, nan_mask=False):
+        """Make the emission log-likelihoods available on the device.
+
+        NIW Gaussians: upload the K mean-field factors, lliks are evaluated by the
+        emission kernel.  Any other plugin object: evaluate
+        ``expected_log_likelihood`` on the host (reference hmmbase.py:219-220) and
+        upload ``lliks``.  Returns the flag word for the engine calls."""
+        if self._niw_fastpath():
+            self.engine.set_emission_niw(*self._emission_arrays())
+            return L.MASK_AS_NAN if nan_mask else 0
+        obs = self.obs if self.obs.ndim == 2 else self.obs[:, None]
+        if windows is None:
+            windows, Lm = [0], self.T
+        ll = np.empty((len(windows), Lm, self.K))
+        for b, s in enumerate(windows):
+            x = obs[s:s + Lm]
+            if nan_mask:
+                x = x.copy()
+                x[self.mask[s:s + Lm]] = np.nan
+            for k, odist in enumerate(self.var_emit):
+                ll[b, :, k] = np.nan_to_num(odist.expected_log_likelihood(x))
+        self.engine.set_lliks(ll)
+        return L.USE_HOST_LLIKS
+
+    # -- ELBO ------------------------------------------------------------------------
+    def lower_bound(self):
+        """ Variational lower bound (reference hmmbase.py:145-199)."""
+        p_pi = self.prior_init
+        p_pisum = np.sum(p_pi)
+        q_pi = self.var_init
+        q_pidg = digamma(q_pi + eps)
+        q_pisum = np.sum(q_pi)
+        dg_q_pisum = digamma(q_pisum + eps)
+
+        pi_energy = (gammaln(p_pisum + eps) - np.sum(gammaln(p_pi + eps))
+                     + np.sum((p_pi - 1.) * (q_pidg - dg_q_pisum)))
+        pi_entropy = -(gammaln(q_pisum + eps) - np.sum(gammaln(q_pi + eps))
+                       + np.sum((q_pi - 1.) * (q_pidg - dg_q_pisum)))
+
+        p_A = self.prior_tran
+        p_Asum = np.sum(p_A, axis=1)
+        q_A = self.var_tran
+        q_Adg = digamma(q_A + eps)
+        q_Asum = np.sum(q_A, axis=1)
+        dg_q_Asum = digamma(q_Asum + eps)
+
+        A_energy = (gammaln(p_Asum + eps) - np.sum(gammaln(p_A + eps), axis=1)
+                    + np.sum((p_A - 1) * (q_Adg - dg_q_Asum[:, npa]), axis=1))
+        A_entropy = -(gammaln(q_Asum + eps) - np.sum(gammaln(q_A + eps), axis=1)
+                      + np.sum((q_A - 1) * (q_Adg - dg_q_Asum[:, npa]), axis=1))
+        A_energy = np.sum(A_energy)
+        A_entropy = np.sum(A_entropy)
+
+        emit_vlb = 0.
+        for k in range(self.K):
+            emit_vlb += self.var_emit[k].get_vlb()
+
+        # "log Z" = sum over ALL t of LSE_k lalpha[t,k] (quirk Q4, hmmbase.py:194);
+        # reduced on the device with the posterior kernel when available
+        if self._lZ is not None:
+            lZ = self._lZ
+        else:
+            lZ = np.sum(np.logaddexp.reduce(self.lalpha, axis=1))
+
+        return (pi_energy + pi_entropy + A_energy + A_entropy + emit_vlb + lZ)
+
+    # -- E-step ------------------------------------------------------------------------
+    def local_update(self, obs=None, mask=None):
+        """Batch local update (reference hmmbase.py:201-229) on the device.
+        Afterwards ``lliks, lalpha, lbeta, var_x, mod_init, mod_tran`` hold host
+        arrays of shape [T,K] / [K] / [K,K]."""
+        if obs is not None or mask is not None:
+            self.set_data(self.obs if obs is None else obs,
+                          self.mask if mask is None else mask)
+        self._psi_expectations()
+        self._upload_obs()
+        self._push_globals()
+        flags = self._push_emission()
+        r = self.engine.forward_backward([0], self.T, flags=flags)
+        self.lalpha = r["lalpha"][0]
+        self.lbeta = r["lbeta"][0]
+        self.var_x = r["var_x"][0]
+        self._lZ = float(r["local_lb"][0])
+        self.lliks = self.engine.read_intermediate("lliks", 1, self.T)[0]
+
+    def forward_msgs(self, obs=None, mask=None):
+        """lalpha from ``self.lliks, self.mod_init, self.mod_tran``
+        (reference hmmbase.py:266-295)."""
+        self.engine.set_globals(self.mod_init, self.mod_tran)
+        self.engine.set_lliks(np.ascontiguousarray(self.lliks)[None])
+        r = self.engine.forward_backward(None, self.lliks.shape[0], flags=L.USE_HOST_LLIKS,
+                                         want=("lalpha", "local_lb"), B=1)
+        self.lalpha = r["lalpha"][0]
+        self._lZ = float(r["local_lb"][0])
+
+    def backward_msgs(self, obs=None, mask=None):
+        """lbeta (reference hmmbase.py:297-320)."""
+        self.engine.set_globals(self.mod_init, self.mod_tran)
+        self.engine.set_lliks(np.ascontiguousarray(self.lliks)[None])
+        r = self.engine.forward_backward(None, self.lliks.shape[0], flags=L.USE_HOST_LLIKS,
+                                         want=("lbeta",), B=1)
+        self.lbeta = r["lbeta"][0]
+
+    def _batch_estep_stats(self):
+        """Whole-chain E-step + expected sufficient statistics on the device, batch
+        transition form (hmmbatchcd.py:182-184): used by the batch infer() loops so
+        that only O(K^2 + K D^2) numbers cross PCIe per iteration."""
+        self._psi_expectations()
+        self._upload_obs()
+        self._push_globals()
+        flags = self._push_emission()
+        st = self.engine.estep([0], self.T, flags=flags)  # no TRANS_WRAP: t=1..T-1
+        self._lZ = float(st.lb[0])
+        self._q0 = self.engine.read_rows("var_x", 0, 1)[0]
+        return st
+
+    def _fetch_local(self):
+        """Pull the per-time-step arrays of the last device E-step to the host
+        attributes (documented reference attributes)."""
+        T = self.T
+        self.lliks = self.engine.read_intermediate("lliks", 1, T)[0]
+        self.lalpha = self.engine.read_intermediate("lalpha", 1, T)[0]
+        self.lbeta = self.engine.read_intermediate("lbeta", 1, T)[0]
+        self.var_x = self.engine.read_intermediate("var_x", 1, T)[0]
+
+    def pred_logprob(self):
+        """Mean predictive log-probability of the masked data
+        (reference hmmbase.py:322-340)."""
+        K = self.K
+        obs = self.obs
+        mask = self.mask
+        nmiss = np.sum(mask)
+        if nmiss == 0:
+            return None
+        logprob = np.zeros((nmiss, K))
+        for k, odist in enumerate(self.var_emit):
+            logprob[:, k] = (np.log(self.var_x[mask, k] + eps)
+                             + odist.expected_log_likelihood(obs[mask, :]))
+        return np.mean(np.logaddexp.reduce(logprob, axis=1))
+
+    def full_local_update(self):
+        self.local_update()
+        return self.var_x
+
+    # -- FFBS (reference hmm_fast.pyx:43-124, bound at hmmbase.py:409-411) ---------------
+    def ffbs_fast(self, var_init, lalpha_init=None, uniforms=None):
+        """Forward-filter backward-sample.  Returns ``(z int64[T], lalpha[T,K])``.
+
+        Follows the Cython variant: ``DBL_EPSILON`` instead of 1e-9 and transitions
+        ``log(var_tran + DBL_EPSILON)`` (un-normalised; quirk Q6).  ``uniforms`` (one
+        per time step) replaces libc ``rand()``, which cannot be reproduced on a
+        device; default draws them from ``np.random``."""
+        var_init = np.asarray(var_init, dtype=np.float64)
+        A = self.var_tran
+        mod_init = digamma(var_init + DBL_EPSILON) - digamma(np.sum(var_init) + DBL_EPSILON)
+        logA = np.log(A + DBL_EPSILON)
+        if uniforms is None:
+            uniforms = np.random.random_sample(self.T)
+        self._upload_obs()
+        if lalpha_init is not None:
+            # backward sampling only, from the supplied messages
+            raise RuntimeError("lalpha_init is unusable in the reference on modern NumPy "
+                               "(hmm_fast.pyx:80); pass None")
+        self.engine.set_globals(mod_init, logA)
+        flags = self._push_emission()
+        z, lalpha = self.engine.ffbs(logA, uniforms, flags=flags)
+        return z, lalpha
+
+    # -- metrics (host) ----------------------------------------------------------------
+    def hamming_dist(self, full_var_x, true_sts):
+        state_sq = np.argmax(full_var_x, axis=1).astype(int)
+        best_match = util.munkres_match(true_sts, state_sq, self.K)
+        return dist.hamming(true_sts, best_match[state_sq]), best_match
+
+    def KL_L2_gaussian(self, emit_true, permutation):
+        KL = 0
+        distance_mus = 0
+        dim = len(self.var_emit[1].mu)
+        for k, k2 in enumerate(permutation):
+            k = permutation[k2]
+            diffmeans = emit_true[k].mu - self.var_emit[k2].mu
+            distance_mus += npl.norm(diffmeans)
+            sig_emit_inv = npl.inv(emit_true[k].sigma)
+            KL += .5 * (np.trace(np.dot(sig_emit_inv, self.var_emit[k2].sigma))
+                        + np.dot(diffmeans, np.dot(sig_emit_inv, diffmeans)) - dim
+                        - np.log(npl.det(self.var_emit[k2].sigma) / npl.det(emit_true[k].sigma)))
+        return KL, distance_mus
+
+    def A_dist(self, A_true, perm):
+        A = self.var_tran / np.sum(self.var_tran, axis=1)[:, np.newaxis]
+        A_true = A_true[np.ix_(perm, perm)]
+        return npl.norm(A_true - A)
