@@ -116,10 +116,21 @@ int64_t svihmm_packed_size(int32_t K, int32_t D);
 int svihmm_estep_minibatch(svihmm_ctx* h, const int64_t* starts, int32_t B,
                            int32_t Lm, uint32_t flags, double* out_packed);
 int svihmm_read_packed(svihmm_ctx* h, double* out_packed);
+/* Buffered meta-observations (growBuffer): the E-step runs on windows of length Lm,
+ * the statistics are taken over the inner segment [inner_off, inner_off+inner_len) of
+ * each window only, with the wrap-around term inside that segment
+ * (intermediate_pars_buffer, hmmsgd_metaobs.py:932-1008); lb still sums over the
+ * whole window (hmmsgd_metaobs.py:436). */
+int svihmm_estep_minibatch_ex(svihmm_ctx* h, const int64_t* starts, int32_t B,
+                              int32_t Lm, int32_t inner_off, int32_t inner_len,
+                              uint32_t flags, double* out_packed);
 
 /* Readback of the intermediates of the last estep/forward_backward call
  * (what 0: lliks, 1: lalpha, 2: lbeta, 3: var_x; each [B,Lm,K]). */
 int svihmm_read_intermediate(svihmm_ctx* h, int32_t what, double* out);
+/* nrows rows starting at flattened row row0 of the same [B*Lm, K] arrays. */
+int svihmm_read_rows(svihmm_ctx* h, int32_t what, int64_t row0, int64_t nrows,
+                     double* out);
 
 /* ---- a12: forward-filter backward-sample (hmm_fast.pyx:43-124) ---------------- */
 /* Forward filter over the whole chain with the globals currently set (the host

@@ -104,22 +104,26 @@ class OracleEngine(object):
         self._last = dict(lliks=ll, lalpha=la, lbeta=lb, var_x=q, local_lb=llb)
         return {k: self._last[k] for k in want}
 
-    def estep(self, starts, Lm, flags=TRANS_WRAP, read=True):
+    def estep(self, starts, Lm, flags=TRANS_WRAP, read=True, inner=None):
         st = np.asarray(starts, dtype=np.int64).ravel()
         self._check(st, Lm)
         B = len(st)
-        self.forward_backward(st, Lm, flags)
         K, D = self.K, self.D
         buf = np.zeros(K * K + K * D + K + K * D * D + 1)
         P = _Packed(buf, K, D)
-        q = self._last["var_x"]
+        if B == 0:
+            self._packed = P
+            return P if read else None
+        self.forward_backward(st, Lm, flags)
+        off, ln = (0, Lm) if inner is None else inner
+        q = self._last["var_x"][:, off:off + ln]
         for b in range(B):
-            s = int(st[b])
+            s = int(st[b]) + off
             P.A_raw[:] += (R.transition_stat_wrap(q[b]) if flags & TRANS_WRAP
                            else R.transition_stat_batch(q[b]))
-            inds = (np.ones(Lm, bool) if self.mask is None
-                    else np.logical_not(self.mask[s:s + Lm]))
-            x = self.obs[s:s + Lm][inds]
+            inds = (np.ones(ln, bool) if self.mask is None
+                    else np.logical_not(self.mask[s:s + ln]))
+            x = self.obs[s:s + ln][inds]
             for k in range(K):
                 xb, ne, Sk = R.niw_suffstats(x, q[b][inds, k])
                 P.xbar[k] += xb; P.neff[k] += ne; P.S[k] += Sk

@@ -437,7 +437,8 @@ __global__ __launch_bounds__(64) void k_stats_outer(
     const double* __restrict__ obs, const uint8_t* __restrict__ mask,
     const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K, int Kp,
     int Fp, int F, const int* __restrict__ fab, const double* __restrict__ q,
-    int64_t rows_per_chunk, uint32_t flags, double* __restrict__ part) {
+    int64_t rows_per_chunk, uint32_t flags, int Lq, int off, double* __restrict__ part) {
+  // rows g enumerate (window b, inner step t<Lm); q row = b*Lq+off+t, obs row = starts[b]+off+t
   const int lane = threadIdx.x;
   const int f0 = blockIdx.y * 16;
   const int k = blockIdx.z * 64 + lane;
@@ -449,9 +450,12 @@ __global__ __launch_bounds__(64) void k_stats_outer(
   for (int i = 0; i < 16; ++i) acc[i] = 0.0;
   const bool is_trans = f0 >= Fp;
   for (int64_t g = g0; g < g1; ++g) {
-    const double qk = (k < K) ? q[g * K + k] : 0.0;
+    const int64_t bwin = g / Lm;
+    const int64_t t = g - bwin * Lm;
+    const int64_t qrow = bwin * Lq + off + t;
+    const double qk = (k < K) ? q[qrow * K + k] : 0.0;
     if (!is_trans) {
-      const int64_t orow = obs_row(starts, Lm, g);
+      const int64_t orow = starts[bwin] + off + t;
       if (mask && mask[orow]) continue;
       const double* x = obs + orow * D;
 #pragma unroll
@@ -468,11 +472,9 @@ __global__ __launch_bounds__(64) void k_stats_outer(
         acc[i] = fma(phi, qk, acc[i]);
       }
     } else {
-      const int64_t bwin = g / Lm;
-      const int64_t t = g - bwin * Lm;
       int64_t gp;
-      if (t > 0) gp = g - 1;
-      else if (flags & SVIHMM_TRANS_WRAP) gp = bwin * Lm + Lm - 1;
+      if (t > 0) gp = qrow - 1;
+      else if (flags & SVIHMM_TRANS_WRAP) gp = qrow + Lm - 1;
       else continue;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -501,7 +503,7 @@ __global__ __launch_bounds__(256) void k_stats_mfma(
     const double* __restrict__ obs, const uint8_t* __restrict__ mask,
     const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K, int Kp,
     int Fp, int F, const int* __restrict__ fab, const double* __restrict__ q,
-    int64_t rows_per_chunk, uint32_t flags, double* __restrict__ part) {
+    int64_t rows_per_chunk, uint32_t flags, int Lq, int off, double* __restrict__ part) {
   extern __shared__ double smem[];
   const int DS = (D + 2) | 1;
   const int QS = 16 * NT + 1;  // padded q row stride
@@ -551,7 +553,8 @@ __global__ __launch_bounds__(256) void k_stats_mfma(
         const int64_t g = s0 + r;
         double v = 0.0;
         if (g < c1) {
-          const int64_t orow = obs_row(starts, Lm, g);
+          const int64_t bw = g / Lm;
+          const int64_t orow = starts[bw] + off + (g - bw * Lm);
           const bool msk = mask && mask[orow];
           if (!msk) v = (i < D) ? obs[orow * D + i] : (i == D ? 1.0 : 0.0);
         }
@@ -562,7 +565,12 @@ __global__ __launch_bounds__(256) void k_stats_mfma(
       const int r = e / (16 * NT), c = e - r * (16 * NT);
       const int64_t g = s0 + r;
       const int k = n0 + c;
-      qs[r * QS + c] = (g < c1 && k < K) ? q[g * K + k] : 0.0;
+      double v = 0.0;
+      if (g < c1 && k < K) {
+        const int64_t bw = g / Lm;
+        v = q[(bw * Lq + off + (g - bw * Lm)) * K + k];
+      }
+      qs[r * QS + c] = v;
     }
     if (need_qp) {
       for (int e = tid; e < ST_RB * (Kp + 1); e += 256) {
@@ -572,8 +580,9 @@ __global__ __launch_bounds__(256) void k_stats_mfma(
         if (g < c1 && c < K) {
           const int64_t bwin = g / Lm;
           const int64_t t = g - bwin * Lm;
-          if (t > 0) v = q[(g - 1) * K + c];
-          else if (flags & SVIHMM_TRANS_WRAP) v = q[(bwin * Lm + Lm - 1) * K + c];
+          const int64_t qrow = bwin * Lq + off + t;
+          if (t > 0) v = q[(qrow - 1) * K + c];
+          else if (flags & SVIHMM_TRANS_WRAP) v = q[(qrow + Lm - 1) * K + c];
         }
         qp[r * QPS + c] = v;
       }
@@ -1208,7 +1217,8 @@ static int launch_posterior(svihmm_ctx* h, int B, int Lm, bool total) {
   return 0;
 }
 
-static int launch_stats(svihmm_ctx* h, int B, int Lm, uint32_t flags) {
+static int launch_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags) {
+  // statistics over the inner segment [off, off+Lm) of each window of length Lq
   CK(ensure_feature_table(h));
   const int D = h->D, K = h->K, Kp = h->Kp, Fp = h->Fp, F = h->F;
   const int Ftot = Fp + Kp;
@@ -1243,7 +1253,7 @@ static int launch_stats(svihmm_ctx* h, int B, int Lm, uint32_t flags) {
     hipLaunchKernelGGL((k_stats_mfma<3, NTV>), grid, dim3(256), lds, h->stream,               \
                        (const double*)h->obs.p, mk, (const int64_t*)h->starts.p, n, Lm, D, K, \
                        Kp, Fp, F, (const int*)h->fab.p, (const double*)h->q.p, rpc, flags,    \
-                       (double*)h->part.p);                                                   \
+                       Lq, off, (double*)h->part.p);                                          \
   } while (0)
         if (NT == 4) ST_LAUNCH(4); else if (NT == 2) ST_LAUNCH(2); else ST_LAUNCH(1);
 #undef ST_LAUNCH
@@ -1253,7 +1263,7 @@ static int launch_stats(svihmm_ctx* h, int B, int Lm, uint32_t flags) {
       dim3 grid((unsigned)nchunk, Ftot / 16, (Kp + 63) / 64);
       hipLaunchKernelGGL(k_stats_outer, grid, dim3(64), 0, h->stream, (const double*)h->obs.p, mk,
                          (const int64_t*)h->starts.p, n, Lm, D, K, Kp, Fp, F,
-                         (const int*)h->fab.p, (const double*)h->q.p, rpc, flags,
+                         (const int*)h->fab.p, (const double*)h->q.p, rpc, flags, Lq, off,
                          (double*)h->part.p);
     }
     HIPCK(hipGetLastError());
@@ -1326,12 +1336,32 @@ int svihmm_forward_backward(svihmm_ctx* h, const int64_t* starts, int32_t B, int
 
 int svihmm_estep_minibatch(svihmm_ctx* h, const int64_t* starts, int32_t B, int32_t Lm,
                            uint32_t flags, double* out_packed) {
+  return svihmm_estep_minibatch_ex(h, starts, B, Lm, 0, Lm, flags, out_packed);
+}
+
+int svihmm_estep_minibatch_ex(svihmm_ctx* h, const int64_t* starts, int32_t B, int32_t Lm,
+                              int32_t inner_off, int32_t inner_len, uint32_t flags,
+                              double* out_packed) {
   if (!h) return fail("svihmm_estep_minibatch: NULL handle");
   CK(set_device(h));
+  if (B == 0) {  // empty shard of a multi-GPU minibatch: all-zero statistics
+    if (!h->have_globals || h->D <= 0) return fail("svihmm_estep_minibatch: set obs/globals first");
+    const size_t nb = (size_t)svihmm_packed_size(h->K, h->D) * sizeof(double);
+    CK(ensure(h->packed, nb));
+    HIPCK(hipMemsetAsync(h->packed.p, 0, nb, h->stream));
+    h->have_packed = true;
+    if (out_packed) {
+      CK(d2h(h, out_packed, h->packed.p, nb));
+      HIPCK(hipStreamSynchronize(h->stream));
+    }
+    return 0;
+  }
+  if (inner_off < 0 || inner_len <= 0 || inner_off + inner_len > Lm)
+    return fail("svihmm_estep_minibatch_ex: inner segment out of range");
   CK(prepare_ll(h, starts, B, Lm, flags, true));
   CK(launch_fb(h, B, Lm, 0, 2));
   CK(launch_posterior(h, B, Lm, true));
-  CK(launch_stats(h, B, Lm, flags));
+  CK(launch_stats(h, B, Lm, inner_off, inner_len, flags));
   h->have_packed = true;
   h->lastB = B; h->lastLm = Lm;
   if (out_packed) {
@@ -1359,6 +1389,19 @@ int svihmm_read_intermediate(svihmm_ctx* h, int32_t what, double* out) {
   const size_t n = (size_t)h->lastB * h->lastLm * h->K * sizeof(double);
   if (!src[what]->p || src[what]->cap < n) return fail("svihmm_read_intermediate: buffer not available");
   CK(d2h(h, out, src[what]->p, n));
+  HIPCK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int svihmm_read_rows(svihmm_ctx* h, int32_t what, int64_t row0, int64_t nrows, double* out) {
+  if (!h || !out || row0 < 0 || nrows <= 0) return fail("svihmm_read_rows: bad arguments");
+  if (h->lastB <= 0) return fail("svihmm_read_rows: nothing computed yet");
+  if (what < 0 || what > 3) return fail("svihmm_read_rows: bad selector");
+  if (row0 + nrows > (int64_t)h->lastB * h->lastLm) return fail("svihmm_read_rows: out of range");
+  CK(set_device(h));
+  Buf* src[] = {&h->ll, &h->la, &h->lb, &h->q};
+  if (!src[what]->p) return fail("svihmm_read_rows: buffer not available");
+  CK(d2h(h, out, (const double*)src[what]->p + (size_t)row0 * h->K, (size_t)nrows * h->K * sizeof(double)));
   HIPCK(hipStreamSynchronize(h->stream));
   return 0;
 }

@@ -135,13 +135,15 @@ class HipEngine(object):
                 res[k] = v
         return res
 
-    def estep(self, starts, Lm, flags=L.TRANS_WRAP, read=True):
+    def estep(self, starts, Lm, flags=L.TRANS_WRAP, read=True, inner=None):
         """Whole-minibatch E-step -> PackedStats (or None with read=False: the
-        statistics stay in HBM for allreduce())."""
+        statistics stay in HBM for allreduce()).  ``inner=(off, length)`` restricts
+        the statistics to that segment of every window (buffered meta-observations)."""
         st = self._starts(starts)
         out = np.empty(PackedStats.size(self.K, self.D)) if read else None
-        L.check(self._lib.svihmm_estep_minibatch(self._h, L.i64ptr(st), len(st), int(Lm),
-                                                 int(flags), L.dptr(out)),
+        off, ln = (0, int(Lm)) if inner is None else (int(inner[0]), int(inner[1]))
+        L.check(self._lib.svihmm_estep_minibatch_ex(self._h, L.i64ptr(st), len(st), int(Lm),
+                                                    off, ln, int(flags), L.dptr(out)),
                 "svihmm_estep_minibatch")
         return PackedStats(out, self.K, self.D) if read else None
 
@@ -155,6 +157,13 @@ class HipEngine(object):
         out = np.empty((B, Lm, self.K))
         L.check(self._lib.svihmm_read_intermediate(self._h, idx, L.dptr(out)),
                 "svihmm_read_intermediate")
+        return out
+
+    def read_rows(self, what, row0, nrows):
+        idx = {"lliks": 0, "lalpha": 1, "lbeta": 2, "var_x": 3}[what]
+        out = np.empty((int(nrows), self.K))
+        L.check(self._lib.svihmm_read_rows(self._h, idx, int(row0), int(nrows), L.dptr(out)),
+                "svihmm_read_rows")
         return out
 
     def ffbs(self, logA, uniforms, flags=0, want_lalpha=True):

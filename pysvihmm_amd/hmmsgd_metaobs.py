@@ -1,0 +1,616 @@
+"""SVI for HMMs with meta-observation minibatches -- class surface of the reference
+``hmmsgd_metaobs.py`` (the working SVI implementation).
+
+One SVI iteration (reference hmmsgd_metaobs.py:347-445):
+  host : learning rate, minibatch sampling, stationary init (eig, :413-418),
+         psi-expectations (:502-504)                      -- O(K^3), once per iteration
+  GPU  : for ALL windows of the minibatch at once: emission expected log-lik,
+         forward/backward, posteriors, expected sufficient statistics, local bound
+         (:487-519, :857-928, :271; the reference's serial ``for data in minibatch``)
+  RCCL : one all-reduce of the packed statistics when several GPUs share the minibatch
+  host : natural-gradient step (:1010-1084), identical on every rank
+
+Quirks reproduced on purpose: Q1 wrap-around product-of-
+marginals transition statistic, Q2 ``prior_tran-1`` once per window, Q3 batch factors
+from the constructor's L and S, Q4 local bound summed over all t, Q5 un-normalised
+eigenvector as ``var_init``, Q8 ``metaobs_noverlap`` returning S+1 windows, Q9 masked
+rows contribute to lliks but not to the emission statistics.
+"""
+from __future__ import division
+
+import sys
+import time
+
+import numpy as np
+import numpy.random as npr
+from numpy import newaxis as npa
+from scipy.special import digamma, gammaln
+
+from .hmmbase import VariationalHMMBase, is_niw_gaussian
+from .distributions import Gaussian, Categorical
+from . import util
+from . import _lib as L
+
+eps = 1e-9
+
+tau0 = 1.
+kappa0 = 0.7
+metaobs_half0 = 1
+mb_sz0 = 1
+
+
+class MetaObs(object):
+    """Inclusive index bounds of a meta-observation (reference :42-45)."""
+
+    def __init__(self, i1, i2):
+        self.i1 = i1
+        self.i2 = i2
+
+
+class VBHMM(VariationalHMMBase):
+    """ Stochastic variational inference for finite HMMs using natural gradients;
+    consecutive groups of nodes are sampled as a "meta-observation"."""
+
+    @staticmethod
+    def make_param_dict(prior_init, prior_tran, prior_emit, tau=tau0,
+                        kappa=kappa0, metaobs_half=metaobs_half0, mb_sz=mb_sz0,
+                        mask=None):
+        return {'prior_init': prior_init, 'prior_tran': prior_tran,
+                'prior_emit': prior_emit, 'mask': mask, 'tau': tau,
+                'kappa': kappa, 'metaobs_half': metaobs_half, 'mb_sz': mb_sz}
+
+    def set_metaobs_fun(self):
+        if self.metaobs_fun_name == 'unif':
+            self.metaobs_fun = self.metaobs_unif
+        elif self.metaobs_fun_name == 'noverlap':
+            self.metaobs_fun = self.metaobs_noverlap
+        else:
+            raise RuntimeError("Unknown value for metaobs_fun: %s" % (self.metaobs_fun_name,))
+
+    def __init__(self, obs, prior_init, prior_tran,
+                 prior_emit, tau=tau0, kappa=kappa0,
+                 metaobs_half=metaobs_half0, mb_sz=mb_sz0, mask=None,
+                 full_predprob=False, init_init=None, init_tran=None,
+                 maxit=100, verbose=False, adagrad=False, metaobs_fun='unif',
+                 seed=None, sts=None, fullpred_freq=10, fullpred_sched=None,
+                 growBuffer=False, bufferBudget=False, engine=None, device=0, comm=None):
+        np.random.seed(seed)
+        self.seed = seed
+
+        super(VBHMM, self).__init__(obs, prior_init, prior_tran,
+                                    prior_emit, mask=mask, init_init=init_init,
+                                    init_tran=init_tran, verbose=verbose,
+                                    sts=sts, engine=engine, device=device)
+
+        self.elbo = -np.inf
+        self.tau = tau
+        self.kappa = kappa
+        self.lrate = tau ** (-kappa)
+        self.full_predprob = full_predprob
+        self.fullpred_freq = fullpred_freq
+        if fullpred_sched is not None:
+            self.fullpred_sched = fullpred_sched
+        else:
+            self.fullpred_sched = np.arange(0, maxit, 10)
+
+        self.mataobs_fun_name = metaobs_fun  # (sic) reference typo kept, quirk Q10
+        if metaobs_fun == 'unif':
+            self.metaobs_fun = self.metaobs_unif
+            self.metaobs_fun_name = 'unif'
+        elif metaobs_fun == 'noverlap':
+            self.metaobs_fun = self.metaobs_noverlap
+            self.metaobs_fun_name = 'noverlap'
+        else:
+            raise RuntimeError("Unknown value for metaobs_fun: %s" % (metaobs_fun,))
+
+        self.adagrad = adagrad
+        if adagrad:
+            self.ada_G = 1.0 * np.ones(self.prior_tran.shape)
+
+        self.maxit = maxit
+        self.growBuffer = growBuffer
+        self.bufferBudget = bufferBudget
+
+        if metaobs_half < 1:
+            raise RuntimeError("metaobs (%d) must be >= 1." % (metaobs_half,))
+        self.metaobs_half = metaobs_half
+        self.mb_sz = mb_sz
+        self.cur_mo = None
+        self.batchfactor = 1.
+        self.comm = comm
+
+        metaobs_sz = 2 * metaobs_half + 1
+        self.var_x = np.random.rand(metaobs_sz, self.K)
+        self.var_x /= np.sum(self.var_x, axis=1)[:, np.newaxis]
+        self.lalpha = np.empty((metaobs_sz, self.K))
+        self.lbeta = np.empty((metaobs_sz, self.K))
+        self.lliks = np.empty((metaobs_sz, self.K))
+
+    def __getstate__(self):
+        d = super(VBHMM, self).__getstate__()
+        d['comm'] = None
+        return d
+
+    # -- minibatch samplers (reference :210-255) ----------------------------------------
+    def metaobs_unif(self, N, L_, n):
+        ll = L_
+        uu = N - 1 - L_
+        c_vec = npr.randint(ll, uu + 1, n)
+        return [MetaObs(c - L_, c + L_) for c in c_vec]
+
+    def metaobs_noverlap(self, N, L_, n):
+        """Returns n+1 windows and rejects only |dc| <= L (quirk Q8, reference :229-255)."""
+        ll = L_
+        uu = N - 1 - L_
+        c_vec = np.inf * np.ones(n)
+        minibatch = list()
+        c = npr.randint(ll, uu + 1, 1)[0]
+        minibatch.append(MetaObs(c - L_, c + L_))
+        for i in range(n):
+            c = npr.randint(ll, uu + 1, 1)[0]
+            while np.any(np.abs(c_vec - c) <= L_):
+                c = npr.randint(ll, uu + 1, 1)[0]
+            c_vec[i] = c
+            minibatch.append(MetaObs(c - L_, c + L_))
+        return minibatch
+
+    # -- bounds ---------------------------------------------------------------------------
+    def local_lower_bound(self):
+        """sum_t LSE_k lalpha[t,k] of the current meta-observation (reference :257-271)."""
+        if self._lZ is not None:
+            return self._lZ
+        return np.sum(np.logaddexp.reduce(self.lalpha, axis=1))
+
+    def global_lower_bound(self):
+        """reference :273-296."""
+        p_A = self.prior_tran
+        p_Asum = np.sum(p_A, axis=1)
+        q_A = self.var_tran
+        q_Adg = digamma(q_A + eps)
+        q_Asum = np.sum(q_A, axis=1)
+        dg_q_Asum = digamma(q_Asum + eps)
+        A_energy = (gammaln(p_Asum + eps) - np.sum(gammaln(p_A + eps), axis=1)
+                    + np.sum((p_A - 1) * (q_Adg - dg_q_Asum[:, npa]), axis=1))
+        A_entropy = -(gammaln(q_Asum + eps) - np.sum(gammaln(q_A + eps), axis=1)
+                      + np.sum((q_A - 1) * (q_Adg - dg_q_Asum[:, npa]), axis=1))
+        emit_vlb = 0.
+        for k in range(self.K):
+            emit_vlb += self.var_emit[k].get_vlb()
+        return np.sum(A_energy) + np.sum(A_entropy) + emit_vlb
+
+    # -- the SVI loop -----------------------------------------------------------------------
+    def _stationary_init(self):
+        """reference :413-418 (same for every window of a minibatch: computed once)."""
+        A_mean = self.var_tran / np.sum(self.var_tran, axis=1)[:, npa]
+        ew, ev = np.linalg.eig(A_mean.T)
+        ew_dec = np.argsort(ew)[::-1]
+        self.var_init = np.abs(ev[:, ew_dec[0]])
+
+    def _alloc_local(self, halfL):
+        metaobs_sz = 2 * halfL + 1
+        self.var_x = np.random.rand(metaobs_sz, self.K)
+        self.var_x /= np.sum(self.var_x, axis=1)[:, np.newaxis]
+        self.lalpha = np.empty((metaobs_sz, self.K))
+        self.lbeta = np.empty((metaobs_sz, self.K))
+        self.lliks = np.empty((metaobs_sz, self.K))
+
+    def infer(self, adaptive=False, perIter=10, epsilon=1e-6, minHalfL=1,
+              avgResidual=False, Lincrement=1, Lcutoff=1000, fused=True):
+        """ Runs stochastic variational inference (reference :298-485)."""
+        np.random.seed(self.seed)
+        if (type(self).local_update is not VBHMM.local_update
+                or type(self).intermediate_pars is not VBHMM.intermediate_pars
+                or not self._niw_fastpath()):
+            # subclass overrides, or an emission family the device statistics kernels
+            # do not know (the reference dispatches on the type too, :887,907):
+            # follow the reference loop literally, E-step recursions still on the device
+            fused = False
+
+        growBuffer = self.growBuffer
+        bufferBudget = self.bufferBudget
+        maxit = self.maxit
+        if self.metaobs_fun is None:
+            self.set_metaobs_fun()
+
+        self.elbo_vec = np.inf * np.ones(maxit)
+        K = self.K
+        self.iter_time = np.inf * np.ones(maxit)
+
+        mb_sz = self.mb_sz
+        L_ = self.metaobs_half
+        miniL = L_
+        bufferL = L_
+        if (L_ is None or adaptive) and growBuffer:
+            raise RuntimeError("Cannot specify both adaptive and buffer simultaneously!")
+
+        self._obs_dirty = True
+        self._upload_obs()
+
+        for it in range(maxit):
+            start_time = time.time()
+            self.lrate = (it + self.tau) ** (-self.kappa)
+
+            if L_ is None or (adaptive and it % perIter == 0):
+                L_ = self.select_L(mb_sz, epsilon=epsilon, minHalfL=minHalfL,
+                                   avgResidual=avgResidual, Lincrement=Lincrement,
+                                   Lcutoff=Lcutoff)
+                self._alloc_local(L_)
+                miniL = L_
+
+            if growBuffer and it % perIter == 0:
+                bufferL = self.select_buffer(self.mb_sz, epsilon=epsilon, halfL=L_,
+                                             avgResidual=avgResidual,
+                                             Lincrement=Lincrement, Lcutoff=Lcutoff)
+                self._alloc_local(bufferL)
+                miniL = bufferL
+                if bufferBudget:
+                    mb_sz = self.buffer_budget(bufferL)
+
+            minibatch = self.metaobs_fun(self.T, miniL, mb_sz)
+
+            if fused:
+                A_inter, emit_inter, lb = self._minibatch_estep(
+                    minibatch, miniL, (bufferL, L_) if growBuffer else None)
+            else:
+                lb = 0.
+                A_inter = np.zeros_like(self.var_tran)
+                emit_inter = [util.NIW_zero_nat_pars(self.var_emit[0]) for k in range(K)]
+                for data in minibatch:
+                    self.cur_mo = data
+                    self._stationary_init()
+                    self.local_update(metaobs=data)
+                    if growBuffer:
+                        A_i, e_i = self.intermediate_pars_buffer(data, bufferL, L_)
+                    else:
+                        A_i, e_i = self.intermediate_pars(data)
+                    A_inter += A_i
+                    for k in range(K):
+                        emit_inter[k] += e_i[k]
+                    lb += self.local_lower_bound()
+
+            self.global_update(A_inter, emit_inter)
+            self.iter_time[it] = time.time() - start_time
+
+            lb += self.global_lower_bound()
+            self.elbo_vec[it] = lb
+            if self.verbose:
+                print("iter: %d, ELBO: %.2f" % (it, lb))
+                sys.stdout.flush()
+
+            if self.full_predprob and it in self.fullpred_sched:
+                # the reference writes into arrays whose allocation is commented out
+                # (quirk Q11); allocate them lazily instead of raising AttributeError
+                if not hasattr(self, 'pred_logprob_full_mean'):
+                    self.pred_logprob_full_mean = np.inf * np.ones(maxit)
+                    self.pred_logprob_full_std = np.inf * np.ones(maxit)
+                tmp = self.pred_logprob_full()
+                self.pred_logprob_full_mean[it] = np.nanmean(tmp)
+                self.pred_logprob_full_std[it] = np.nanstd(tmp)
+
+        # So that the hmm object can be pickled
+        self.metaobs_fun = None
+
+    def _minibatch_estep(self, minibatch, miniL, buffer=None):
+        """All windows of the minibatch in one device E-step; returns
+        ``(A_inter, emit_inter, lb)`` exactly as the serial accumulation of the
+        reference (:398-436) would.  With a communicator the windows are sharded
+        round-robin over the ranks and the packed statistics are all-reduced."""
+        K, D = self.K, self.D
+        Lm = 2 * miniL + 1
+        self._stationary_init()
+        self._psi_expectations()
+        self._push_globals()
+        comm = self.comm
+        mine = minibatch if comm is None else minibatch[comm.rank::comm.size]
+        starts = np.array([mo.i1 for mo in mine], dtype=np.int64)
+        nwin = len(minibatch)
+        inner = None
+        if buffer is not None:
+            bufferL, L_ = buffer
+            inner = (bufferL - L_, 2 * L_ + 1)
+        if len(starts):
+            flags = self._push_emission(windows=list(starts), Lm=Lm) | L.TRANS_WRAP
+        else:
+            flags = L.TRANS_WRAP
+        # an empty shard still produces (zero) statistics so every rank joins the all-reduce
+        st = self.engine.estep(starts, Lm, flags=flags, read=(comm is None), inner=inner)
+        if comm is not None:
+            st = comm.allreduce_stats(self.engine, K, D)
+        # quirk Q2: prior_tran - 1 is part of every window's A_i
+        A_inter = st.A_raw + nwin * (self.prior_tran - 1.)
+        emit_inter = [util._obj(st.xbar[k].copy(), float(st.neff[k]), st.S[k].copy(),
+                                float(st.neff[k])) for k in range(K)]
+        lb = float(st.lb[0])
+        # leave the object as the reference does after the loop: state of the last window
+        self.cur_mo = minibatch[-1]
+        if len(starts):
+            b = len(starts) - 1
+            for name in ("lliks", "lalpha", "lbeta", "var_x"):
+                setattr(self, name, self.engine.read_rows(name, b * Lm, Lm))
+            self._lZ = None
+        return A_inter, emit_inter, lb
+
+    # -- single meta-observation local update (reference :487-519) ----------------------------
+    def local_update(self, metaobs=None):
+        if metaobs is None:
+            loff, uoff = 0, self.T - 1
+        else:
+            loff, uoff = metaobs.i1, metaobs.i2
+        Lm = uoff - loff + 1
+        self._psi_expectations()
+        self._upload_obs()
+        self._push_globals()
+        flags = self._push_emission(windows=[loff], Lm=Lm)
+        r = self.engine.forward_backward([loff], Lm, flags=flags)
+        self.lalpha = r["lalpha"][0]
+        self.lbeta = r["lbeta"][0]
+        self.var_x = r["var_x"][0]
+        self._lZ = float(r["local_lb"][0])
+        self.lliks = self.engine.read_intermediate("lliks", 1, Lm)[0]
+
+    # -- adaptive window length (reference :521-661) --------------------------------------------
+    def _local_messages_batch(self, centers, halflength):
+        """var_x of the windows centred at ``centers`` (all of half-width
+        ``halflength``) in one device call; what ``get_local_messages`` returns, batched."""
+        Lm = 2 * halflength + 1
+        starts = np.asarray(centers, dtype=np.int64) - halflength
+        self._upload_obs()
+        flags = self._push_emission(windows=list(starts), Lm=Lm)
+        r = self.engine.forward_backward(starts, Lm, flags=flags, want=("var_x",))
+        return r["var_x"]
+
+    def _prepare_messages(self):
+        # reference get_local_messages recomputes these every call (:675-677)
+        self._psi_expectations()
+        self._push_globals()
+
+    def select_L(self, numIndices=1, epsilon=1e-5, minHalfL=1, avgResidual=False,
+                 Lincrement=1, Lcutoff=1000):
+        """reference :521-569; the per-index growth loops run in lock-step so every
+        candidate L is one batched device E-step over the still-active indices."""
+        indices = npr.choice(self.T - 2 * minHalfL - 1, size=numIndices) + minHalfL
+        self._prepare_messages()
+        n = len(indices)
+        Lcur = np.full(n, minHalfL, dtype=int)
+        q_old = self._local_messages_batch(indices, minHalfL)[:, minHalfL, :]
+        q_diff = np.full(n, np.finfo(np.float64).max)
+        count = np.zeros(n, dtype=int)
+        run_av = np.zeros(n); run_old = np.zeros(n)
+        active = np.ones(n, dtype=bool)
+        while True:
+            for i in np.where(active)[0]:
+                ind, Li = indices[i], Lcur[i]
+                if ind - Li < 1 + Lincrement or ind + Li + Lincrement + 1 > self.T or Li > Lcutoff:
+                    active[i] = False
+                    continue
+                if not avgResidual:
+                    if q_diff[i] < epsilon:
+                        active[i] = False
+                else:
+                    count[i] += 1
+                    if count[i] > 1 and (run_av[i] - run_old[i]) / (count[i] - 1) < epsilon:
+                        active[i] = False
+            if not active.any():
+                break
+            # all active indices share the same L (they start together, grow together)
+            idx = np.where(active)[0]
+            Lnew = Lcur[idx[0]] + Lincrement
+            q_new = self._local_messages_batch(indices[idx], Lnew)[:, Lnew, :]
+            d = np.sum(np.abs(q_new - q_old[idx]), axis=1)
+            if not avgResidual:
+                q_diff[idx] = d
+            else:
+                run_old[idx] = run_av[idx]
+                run_av[idx] += d
+            q_old[idx] = q_new
+            Lcur[idx] = Lnew
+        return int(np.max(Lcur)) if n else -1
+
+    def buffer_budget(self, halfL, budget=400):
+        return int(np.ceil(budget / (2 * halfL + 1)))
+
+    def select_buffer(self, numIndices=1, epsilon=1e-5, halfL=10,
+                      avgResidual=False, Lincrement=1, Lcutoff=1000):
+        """reference :579-661 (non-avgResidual branch; the avgResidual branch of the
+        reference uses ``var_new`` before assignment, :648, and cannot run)."""
+        if avgResidual:
+            raise RuntimeError("select_buffer(avgResidual=True) is broken in the reference "
+                               "(hmmsgd_metaobs.py:648 uses var_new before assignment)")
+        indices = npr.choice(self.T - 2 * halfL - 1, size=numIndices) + halfL
+        self._prepare_messages()
+        n = len(indices)
+        bufL = np.full(n, halfL, dtype=int)
+        v0 = self._local_messages_batch(indices, halfL)
+        q_old_left = v0[:, 0, :].copy()
+        q_old_right = v0[:, 2 * halfL, :].copy()
+        dl = np.full(n, np.finfo(np.float64).max)
+        dr = dl.copy()
+        active = np.ones(n, dtype=bool)
+        while True:
+            for i in np.where(active)[0]:
+                ind, b = indices[i], bufL[i]
+                if ind - b < 1 + Lincrement or ind + b + Lincrement + 1 > self.T or b > Lcutoff:
+                    active[i] = False
+                elif dl[i] < epsilon and dr[i] < epsilon:
+                    active[i] = False
+            if not active.any():
+                break
+            idx = np.where(active)[0]
+            bnew = bufL[idx[0]] + Lincrement
+            v = self._local_messages_batch(indices[idx], bnew)
+            ql = v[:, bnew - halfL, :]
+            qr = v[:, bnew + halfL, :]
+            dl[idx] = np.sum(np.abs(ql - q_old_left[idx]), axis=1)
+            dr[idx] = np.sum(np.abs(qr - q_old_right[idx]), axis=1)
+            q_old_left[idx] = ql
+            q_old_right[idx] = qr
+            bufL[idx] = bnew
+        return int(np.max(bufL)) if n else -1
+
+    def get_local_messages(self, ind, halflength):
+        """reference :663-700: var_x of the window centred at ``ind``."""
+        self._prepare_messages()
+        return self._local_messages_batch([ind], halflength)[0]
+
+    def get_marginal(self, var_over_x, index):
+        return np.squeeze(var_over_x[index, :])
+
+    def _messages(self, metaobs, lliks, mod_tran, mod_init, want):
+        self.engine.set_globals(mod_init, mod_tran)
+        self.engine.set_lliks(np.ascontiguousarray(lliks)[None])
+        r = self.engine.forward_backward(None, lliks.shape[0], flags=L.USE_HOST_LLIKS,
+                                         want=(want,), B=1)
+        return r[want][0]
+
+    def get_forward(self, metaobs, lliks, mod_tran, mod_init):
+        """reference :711-740."""
+        return self._messages(metaobs, lliks, mod_tran, mod_init, "lalpha")
+
+    def get_backward(self, metaobs, lliks, mod_tran):
+        """reference :742-771."""
+        return self._messages(metaobs, lliks, mod_tran, np.zeros(self.K), "lbeta")
+
+    def forward_msgs(self, metaobs=None):
+        """reference :775-803."""
+        self.lalpha = self._messages(metaobs, self.lliks, self.mod_tran, self.mod_init, "lalpha")
+        self._lZ = None
+
+    def backward_msgs(self, metaobs=None):
+        """reference :828-855."""
+        self.lbeta = self._messages(metaobs, self.lliks, self.mod_tran, self.mod_init, "lbeta")
+
+    def forward_msgs_real_data(self, lalpha_init=None):
+        """reference :805-826 (whole chain)."""
+        if lalpha_init is not None:
+            raise RuntimeError("lalpha_init override is not supported on the device path")
+        self._upload_obs()
+        self._push_globals()
+        flags = self._push_emission()
+        r = self.engine.forward_backward([0], self.T, flags=flags, want=("lalpha",))
+        return r["lalpha"][0]
+
+    # -- natural-gradient direction of ONE window from host arrays (reference :857-1008) -------
+    def intermediate_pars(self, metaobs=None):
+        if metaobs is None:
+            loff, uoff = 0, self.T
+        else:
+            loff, uoff = metaobs.i1, metaobs.i2
+        return self._intermediate(self.var_x, loff, uoff)
+
+    def intermediate_pars_buffer(self, metaobs, bufferL, L_):
+        if metaobs is None:
+            loff, uoff = 0, self.T
+        else:
+            loff, uoff = metaobs.i1 + bufferL - L_, metaobs.i2 - bufferL + L_
+        return self._intermediate(self.var_x[bufferL - L_:bufferL + L_ + 1, :], loff, uoff)
+
+    def _intermediate(self, var_x, loff, uoff):
+        obs = self.obs
+        mask = self.mask
+        tran_mf = self.prior_tran.copy()
+        for t in range(loff, uoff + 1):
+            tran_mf += np.outer(var_x[t - loff - 1, :], var_x[t - loff, :])
+        A_inter = tran_mf - 1.
+        inds = np.logical_not(mask[loff:(uoff + 1)])
+        emit_inter = list()
+        if is_niw_gaussian(self.var_emit[0]):
+            for k in range(self.K):
+                G = self.var_emit[k]
+                weights = var_x[inds, k]
+                emit_inter.append(util.NIW_suffstats(G, obs[loff:(uoff + 1), :][inds, :], weights))
+        elif type(self.var_emit[0]) is Categorical:
+            for k in range(self.K):
+                G = self.var_emit[k]
+                w = var_x[inds, k]
+                data = np.asarray(obs[loff:(uoff + 1)][inds]).astype(int).ravel()
+                C = G.num_parameters()
+                z = np.zeros((data.shape[0], C))
+                z[np.arange(data.shape[0]), data] = 1
+                wz = w[:, None] * z
+                alpha_mf = G._posterior_hypparams(*G._get_weighted_statistics(data, wz))
+                emit_inter.append(alpha_mf - 1.)
+        return A_inter, emit_inter
+
+    # -- global natural-gradient step (reference :1010-1084) -------------------------------------
+    def global_update(self, A_inter, emit_inter):
+        lrate = self.lrate
+        L_ = self.metaobs_half
+        S = self.mb_sz
+        T = self.T
+
+        nats_old = self.var_tran - 1.
+        bfact = (T - 2 * L_ - 1) / (2. * L_ * S)
+        A_up = bfact * A_inter
+        if self.adagrad:
+            self.ada_G += nats_old ** 2
+            adaMatrix = self.ada_G ** .25
+            nats_new = (1. - 1.0 / adaMatrix) * nats_old + A_up / adaMatrix
+        else:
+            nats_new = (1. - lrate) * nats_old + lrate * A_up
+        self.var_tran = nats_new + 1.
+
+        bfact = (T - 2 * L_ - 1) / ((2. * L_ + 1.) * S)
+        if is_niw_gaussian(self.var_emit[0]):
+            for k in range(self.K):
+                G = self.var_emit[k]
+                nats_old = util.NIW_mf_natural_pars(G.mu_mf, G.sigma_mf, G.kappa_mf, G.nu_mf)
+                prior_hypparam = util.NIW_mf_natural_pars(G.mu_0, G.sigma_0, G.kappa_0, G.nu_0)
+                nats_new = (1. - lrate) * nats_old \
+                    + lrate * (prior_hypparam + bfact * emit_inter[k])
+                util.NIW_mf_moment_pars(G, *nats_new)
+        elif type(self.var_emit[0]) is Categorical:
+            for k in range(self.K):
+                G = self.var_emit[k]
+                nats_old = G.alpha_mf - 1.
+                nats_new = (1. - lrate) * nats_old + lrate * bfact * emit_inter[k]
+                G._alpha_mf = nats_new + 1.
+                G.weights = G._alpha_mf / G._alpha_mf.sum()
+
+    # -- predictive log-probabilities (reference :1086-1145) ----------------------------------------
+    def pred_logprob(self, metaobs=None):
+        cur_mo = self.cur_mo
+        if metaobs is None:
+            metaobs = cur_mo
+        if ((metaobs is not cur_mo) and
+                (metaobs.i1 != cur_mo.i1 and metaobs.i2 != cur_mo.i2)):  # quirk Q14 ("and")
+            self.local_update(metaobs=metaobs)
+        K = self.K
+        loff, uoff = metaobs.i1, metaobs.i2
+        obs_full = getattr(self, 'obs_full', self.obs)   # infer never sets obs_full (Q14)
+        obs = obs_full[loff:(uoff + 1), :]
+        mask = self.mask[loff:(uoff + 1)]
+        nmiss = np.sum(mask)
+        if nmiss == 0:
+            return None
+        logprob = np.zeros((nmiss, K))
+        for k, odist in enumerate(self.var_emit):
+            logprob[:, k] = np.log(self.var_x[mask, k] + eps) \
+                + odist.expected_log_likelihood(obs[mask, :])
+        return np.mean(np.logaddexp.reduce(logprob, axis=1))
+
+    def pred_logprob_full(self):
+        full_var_x = self.full_local_update()
+        K = self.K
+        obs = getattr(self, 'obs_full', self.obs)
+        mask = self.mask
+        nmiss = np.sum(mask)
+        if nmiss == 0:
+            return None
+        logprob = np.zeros((nmiss, K))
+        for k, odist in enumerate(self.var_emit):
+            logprob[:, k] = np.log(full_var_x[mask, k] + eps) \
+                + odist.expected_log_likelihood(obs[mask, :])
+        return np.mean(np.logaddexp.reduce(logprob, axis=1))
+
+    def full_local_update(self):
+        """Whole-chain E-step with missing rows treated as NaN (lliks row = 0),
+        reference :1147-1205.  obs is not mutated (the reference NaN-masks it in place
+        and restores it); returns var_x[T,K]."""
+        mod_init = digamma(self.var_init + eps) - digamma(np.sum(self.var_init) + eps)
+        tran_sum = np.sum(self.var_tran, axis=1)
+        mod_tran = digamma(self.var_tran + eps) - digamma(tran_sum[:, npa] + eps)
+        self._upload_obs()
+        self.engine.set_globals(mod_init, mod_tran)
+        flags = self._push_emission(nan_mask=True)
+        r = self.engine.forward_backward([0], self.T, flags=flags, want=("var_x",))
+        return r["var_x"][0]

@@ -1,0 +1,172 @@
+"""Host logic of the reference-compatible classes, on CPU: the oracle engine is
+injected (``engine=``) so that everything except the device kernels is exercised
+-- minibatch sampling, stationary init, psi-expectations, accumulation quirks,
+natural-gradient global step, ELBO bookkeeping, pickling -- and compared with the
+trace of the executed reference (tests/golden)."""
+import glob
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from oracle.engine import OracleEngine
+from pysvihmm_amd import hmmbatchcd, hmmbatchsgd, hmmsgd_metaobs, hmmsvi
+from pysvihmm_amd.distributions import Gaussian
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+META = sorted(glob.glob(os.path.join(GOLDEN, "metaobs_*.npz")))
+
+
+def emit_from_fixture(g, K):
+    out = []
+    for k in range(K):
+        e = Gaussian(mu=g["init_mu"][k], sigma=np.eye(len(g["init_mu"][k])),
+                     mu_0=g["prior_mu0"][k], sigma_0=g["prior_sigma0"][k],
+                     kappa_0=float(g["prior_kappa0"][k]), nu_0=float(g["prior_nu0"][k]))
+        e.mu_mf = g["init_mu"][k].copy()
+        e.sigma_mf = g["init_sigma"][k].copy()
+        e.kappa_mf = float(g["init_kappa"][k])
+        e.nu_mf = float(g["init_nu"][k])
+        out.append(e)
+    return np.array(out)
+
+
+@pytest.mark.parametrize("path", META[:3], ids=[os.path.basename(p)[:-4] for p in META[:3]])
+def test_metaobs_infer_matches_reference_trace(path):
+    g = np.load(path)
+    K = int(g["K"])
+    hmm = hmmsgd_metaobs.VBHMM(
+        g["obs"].copy(), np.ones(K), g["prior_tran"], emit_from_fixture(g, K),
+        tau=float(g["tau"]), kappa=float(g["kappa"]), metaobs_half=int(g["L"]),
+        mb_sz=int(g["S"]), mask=g["mask"], init_tran=g["init_tran"], maxit=int(g["maxit"]),
+        seed=int(g["seed"]), engine=OracleEngine())
+    hmm.infer()
+    np.testing.assert_allclose(hmm.var_tran, g["it_var_tran_new"][-1], rtol=1e-10, atol=1e-10)
+    for k in range(K):
+        np.testing.assert_allclose(hmm.var_emit[k].mu_mf, g["it_new_mu"][-1][k], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(hmm.var_emit[k].sigma_mf, g["it_new_sigma"][-1][k], rtol=1e-9, atol=1e-8)
+        np.testing.assert_allclose(hmm.var_emit[k].kappa_mf, g["it_new_kappa"][-1][k], rtol=1e-11)
+        np.testing.assert_allclose(hmm.var_emit[k].nu_mf, g["it_new_nu"][-1][k], rtol=1e-11)
+    np.testing.assert_allclose(hmm.elbo_vec, g["elbo_vec"], rtol=1e-9)
+    # state left on the object = last window of the last minibatch (reference behaviour)
+    np.testing.assert_allclose(hmm.var_x, g["w_var_x"][-1], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(hmm.lalpha, g["w_lalpha"][-1], rtol=1e-10, atol=1e-9)
+    assert hmm.cur_mo.i1 == int(g["w_i1"][-1]) and hmm.cur_mo.i2 == int(g["w_i2"][-1])
+    assert hmm.metaobs_fun is None            # so that the object can be pickled
+    full = hmm.full_local_update()
+    np.testing.assert_allclose(full, g["full_var_x"], rtol=1e-8, atol=1e-11)
+    blob = pickle.dumps(hmm)                  # cluster/run_cluster_simple.py:32-37
+    h2 = pickle.loads(blob)
+    assert h2._engine is None
+    np.testing.assert_array_equal(h2.var_tran, hmm.var_tran)
+
+
+def test_metaobs_unfused_path_equals_fused():
+    """The literal reference loop (local_update + intermediate_pars per window) and the
+    fused minibatch E-step give the same updates."""
+    g = np.load(META[1])
+    K = int(g["K"])
+    res = []
+    for fused in (True, False):
+        hmm = hmmsgd_metaobs.VBHMM(
+            g["obs"].copy(), np.ones(K), g["prior_tran"], emit_from_fixture(g, K),
+            tau=1.0, kappa=0.7, metaobs_half=int(g["L"]), mb_sz=int(g["S"]), mask=g["mask"],
+            init_tran=g["init_tran"], maxit=2, seed=11, engine=OracleEngine())
+        hmm.infer(fused=fused)
+        res.append((hmm.var_tran.copy(), hmm.var_emit[0].sigma_mf.copy(), hmm.elbo_vec.copy()))
+    for a, b in zip(res[0], res[1]):
+        np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("name,mod", [("batchcd_K4_D2_T300", hmmbatchcd),
+                                      ("batchsgd_K4_D3_T250", hmmbatchsgd)])
+@pytest.mark.parametrize("fused", [True, False])
+def test_batch_infer_matches_reference_trace(name, mod, fused):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    K = int(g["K"])
+    kw = dict(mask=g["mask"], init_tran=g["init_tran"], maxit=int(g["maxit"]),
+              engine=OracleEngine())
+    if int(g["sgd"]):
+        kw.update(tau=1.0, kappa=0.7)
+    hmm = mod.VBHMM(g["obs"].copy(), g["prior_init"], g["prior_tran"], emit_from_fixture(g, K), **kw)
+    hmm.infer(fused=fused)
+    np.testing.assert_allclose(hmm.var_tran, g["it_var_tran_new"][-1], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(hmm.var_init, g["it_var_init_new"][-1], rtol=1e-9, atol=1e-12)
+    for k in range(K):
+        np.testing.assert_allclose(hmm.var_emit[k].mu_mf, g["it_new_mu"][-1][k], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(hmm.var_emit[k].sigma_mf, g["it_new_sigma"][-1][k], rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(hmm.elbo_vec, g["elbo_vec"][:len(hmm.elbo_vec)], rtol=1e-8)
+    np.testing.assert_allclose(hmm.var_x, g["it_var_x"][-1], rtol=1e-8, atol=1e-11)
+    assert not np.isnan(hmm.obs).any()       # data restored after infer
+    pickle.loads(pickle.dumps(hmm))
+
+
+def test_two_blob_demo_acceptance():
+    """The reference's demo (test_hmmbatchcd.py / test_hmmsgd_metaobs.py:13-65):
+    2 states, 2-D, first half N(0,I), second half N((5,5),I); Hamming distance 0."""
+    # the emission factors are initialised by a random draw from the (vague) prior, as in
+    # pybasicbayes, so like the reference's unseeded demos the outcome depends on the
+    # draw (cf. the failure recorded in reference test_hmmbatchsgd.py:52); seed 5 converges
+    rng = np.random.RandomState(5)
+    np.random.seed(5)
+    N, K, D = 600, 2, 2
+    sts = (np.arange(N) >= N // 2).astype(int)
+    obs = rng.randn(N, D) + 5.0 * sts[:, None]
+    mu_0 = np.zeros(D); sigma_0 = 0.75 * np.cov(obs.T)
+    prior_emit = np.array([Gaussian(mu_0=mu_0, sigma_0=sigma_0, kappa_0=0.01, nu_0=4)
+                           for _ in range(K)])
+    hmm = hmmbatchcd.VBHMM(obs, np.ones(K), np.ones((K, K)), prior_emit, maxit=15,
+                           sts=sts, engine=OracleEngine())
+    hmm.infer()
+    assert hmm.hamming == 0.0
+    assert np.all(np.diff(hmm.elbo_vec) > -1e-6)       # batch CD: monotone ELBO
+    svi = hmmsgd_metaobs.VBHMM(obs, np.ones(K), np.ones((K, K)), prior_emit, metaobs_half=10,
+                               mb_sz=8, maxit=60, seed=3, engine=OracleEngine())
+    svi.infer()
+    hd, _ = svi.hamming_dist(svi.full_local_update(), sts)
+    assert hd < 0.02
+
+
+def test_adaptive_and_buffer_paths_run():
+    g = np.load(META[0])
+    K = int(g["K"])
+    hmm = hmmsgd_metaobs.VBHMM(g["obs"].copy(), np.ones(K), g["prior_tran"], emit_from_fixture(g, K),
+                               metaobs_half=3, mb_sz=2, maxit=3, seed=5, engine=OracleEngine())
+    hmm.infer(adaptive=True, perIter=2, epsilon=1e-3, Lcutoff=12)
+    assert np.all(np.isfinite(hmm.elbo_vec))
+    hb = hmmsgd_metaobs.VBHMM(g["obs"].copy(), np.ones(K), g["prior_tran"], emit_from_fixture(g, K),
+                              metaobs_half=3, mb_sz=2, maxit=3, seed=5, growBuffer=True,
+                              engine=OracleEngine())
+    hb.infer(perIter=2, epsilon=1e-3, Lcutoff=12)
+    assert np.all(np.isfinite(hb.elbo_vec))
+    # buffered statistics == reference's intermediate_pars_buffer on the same posteriors
+    L_, bufL = 3, 5
+    mo = hmmsgd_metaobs.MetaObs(40 - bufL, 40 + bufL)
+    hb._stationary_init(); hb.local_update(metaobs=mo)
+    A_i, e_i = hb.intermediate_pars_buffer(mo, bufL, L_)
+    st = hb.engine.estep([mo.i1], 2 * bufL + 1, flags=2, inner=(bufL - L_, 2 * L_ + 1))
+    np.testing.assert_allclose(st.A_raw + (hb.prior_tran - 1.0), A_i, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(st.S[1], e_i[1][2], rtol=1e-10, atol=1e-10)
+
+
+def test_names_and_param_dicts():
+    assert hmmsvi.SVIHMM is hmmsgd_metaobs.VBHMM and hmmsvi.HMMSVI is hmmsgd_metaobs.VBHMM
+    d = hmmsgd_metaobs.VBHMM.make_param_dict(1, 2, 3)
+    assert set(d) == {'prior_init', 'prior_tran', 'prior_emit', 'mask', 'tau', 'kappa',
+                      'metaobs_half', 'mb_sz'}
+    with pytest.raises(RuntimeError):
+        hmmsgd_metaobs.VBHMM(np.zeros((10, 2)), np.ones(2), np.ones((2, 2)),
+                             np.array([Gaussian(mu_0=np.zeros(2), sigma_0=np.eye(2), kappa_0=1, nu_0=4)] * 2),
+                             metaobs_half=0, engine=OracleEngine())
+
+
+def test_product_has_no_cpu_fallback():
+    """Without a GPU the default engine must fail loudly, never fall back."""
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("GPU present")
+    obs = np.random.RandomState(0).randn(50, 2)
+    pe = np.array([Gaussian(mu_0=np.zeros(2), sigma_0=np.eye(2), kappa_0=1, nu_0=4) for _ in range(2)])
+    hmm = hmmbatchcd.VBHMM(obs, np.ones(2), np.ones((2, 2)), pe, maxit=1)
+    with pytest.raises(RuntimeError):
+        hmm.infer()
