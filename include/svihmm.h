@@ -52,6 +52,9 @@ typedef struct svihmm_ctx svihmm_ctx;
 /* Use the lliks previously uploaded with svihmm_set_lliks (generic emission
  * plugin route) instead of evaluating the NIW emission kernel. */
 #define SVIHMM_USE_HOST_LLIKS 4u
+/* svihmm_estep_minibatch only: also materialise lbeta in HBM so that it can be read
+ * back (the fused backward sweep otherwise keeps it in registers). */
+#define SVIHMM_KEEP_LBETA 8u
 
 /* ---- errors / lifecycle ------------------------------------------------------- */
 const char* svihmm_last_error(void);

@@ -15,6 +15,7 @@ NKERN = 12
 MASK_AS_NAN = 1
 TRANS_WRAP = 2
 USE_HOST_LLIKS = 4
+KEEP_LBETA = 8
 
 _lib = None
 

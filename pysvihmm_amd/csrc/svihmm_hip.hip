@@ -371,6 +371,369 @@ __global__ void k_fb_generic(const double* __restrict__ ll, const double* __rest
 }
 
 // ------------------------------------------------------------------------------------
+//  K2c/K2d: forward and backward(+posterior) sweeps as batched fp64 MFMA mat-mats.
+//  A workgroup owns 16 windows (the M dimension of v_mfma_f64_16x16x4_f64); wave s owns
+//  the 16-state tile n0=16*s (K <= 64 -> NW = Kp/16 waves).  Per time step
+//      out[w][j] = sum_i P[w][i] * M[i][j],   P = exp(prev message - shift[w]) via LDS,
+//  M = exp(ltran) (forward) / its transpose (backward) held in registers as the B operand.
+//  The per-window shift is c_t = c_{t-1} + ln2*frexp_exp(sum_i P_{t-1}[i]) + max_j ll_t[j]:
+//  an upper bound of max_j message_t[j] that is at most ~|min ltran| above it, built only
+//  from tile reductions of the PREVIOUS step, so there is one barrier per step and no
+//  reduction on the critical path.  sum_t LSE_j lalpha (quirk Q4) is accumulated as a
+//  running (mantissa, exponent) product of the per-step sums.
+// ------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// all-lanes reductions over each row of 16 lanes (quad_perm xor1, xor2, row_half_mirror, row_mirror)
+__device__ __forceinline__ double row16_sum(double v) {
+  v += dpp_mov_f64<0xB1>(v);
+  v += dpp_mov_f64<0x4E>(v);
+  v += dpp_mov_f64<0x141>(v);
+  v += dpp_mov_f64<0x140>(v);
+  return v;
+}
+__device__ __forceinline__ double row16_max(double v) {
+  v = fmax(v, dpp_mov_f64<0xB1>(v));
+  v = fmax(v, dpp_mov_f64<0x4E>(v));
+  v = fmax(v, dpp_mov_f64<0x141>(v));
+  v = fmax(v, dpp_mov_f64<0x140>(v));
+  return v;
+}
+#define LN2_D 0.69314718055994530942
+
+template <int NW>
+struct FbShared {
+  static constexpr int Kp = 16 * NW;
+  static constexpr int PS = Kp + 2;
+  double __attribute__((aligned(16))) P[2][16][PS];
+  // tile reductions: every lane of a 16-lane row holds the same value after the DPP
+  // reduction and writes its own slot (branch-free, conflict-free); readers use slot 0
+  double tsum[2][16][NW][16];
+  double tmll[2][16][NW][16];
+  double tq[2][16][NW][16];
+};
+
+template <int NW>
+__device__ __forceinline__ double4_t fb_matmul(const FbShared<NW>& sh, int cur, int li, int lg,
+                                               const double (&Bv)[4 * NW]) {
+  constexpr int KS = 4 * NW;
+  double4_t a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+  const double* prow = &sh.P[cur][li][2 * lg];
+#pragma unroll
+  for (int c = 0; c < KS / 2; c += 2) {
+    const double2 x = *reinterpret_cast<const double2*>(prow + 8 * c);
+    const double2 y = *reinterpret_cast<const double2*>(prow + 8 * (c + 1));
+    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, Bv[2 * c], a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, Bv[2 * c + 1], a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(y.x, Bv[2 * c + 2], a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(y.y, Bv[2 * c + 3], a3, 0, 0, 0);
+  }
+  return (a0 + a1) + (a2 + a3);
+}
+
+// FULL: K == 16*NW (no padded states).  Windows beyond B are clamped to B-1 (they redo the
+// last window and rewrite identical values), so the time loop has no per-lane predicate
+// and compiles to a single basic block: loads issued two steps ahead are waited for with a
+// counted vmcnt instead of a full drain.
+template <int NW, bool FULL>
+__global__ __launch_bounds__(64 * NW) void k_fwd_mfma(
+    const double* __restrict__ ll, const double* __restrict__ Aexp,
+    const double* __restrict__ mod_init, int B, int Lm, int K, double* __restrict__ la_out,
+    double* __restrict__ local_lb, double* __restrict__ logz) {
+  // Critical path per step: LDS read -> MFMA -> p = acc * w -> LDS write -> row sum -> barrier.
+  // w = exp(ll_t - d) (d = shift increment) does not depend on the MFMA result and the
+  // lalpha store (log) of step t is issued during step t+1, so every transcendental runs
+  // in the shadow of the matrix pipe.
+  constexpr int KS = 4 * NW;
+  __shared__ FbShared<NW> sh;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int j = wave * 16 + li;
+  const bool vj = FULL || (j < K);
+  const int jc = vj ? j : 0;
+  const int b0 = blockIdx.x * 16;
+  double Bv[KS];
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+    const int k = 8 * (kk >> 1) + 2 * lg + (kk & 1);
+    Bv[kk] = (k < K && vj) ? Aexp[(size_t)k * K + jc] : 0.0;
+  }
+  size_t base[4];
+  int gwc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int gw = b0 + lg + 4 * r;
+    gwc[r] = gw < B ? gw : B - 1;
+    base[r] = (size_t)gwc[r] * Lm * K + jc;
+  }
+  const double NEG_INF = -INFINITY;
+  double c[4], csum[4], mant[4], lln[4], ll2[4];  // ll_{t+1}, ll_{t+2}: two steps in flight
+  double pacc[4], pc[4], pll[4];                  // delayed lalpha store of the previous step
+  int ex[4];
+  const size_t K1 = (size_t)K * (Lm > 1 ? 1 : 0), K2 = (size_t)K * (Lm > 2 ? 2 : (Lm > 1 ? 1 : 0));
+  // ---- t = 0
+  {
+    double tm[4], la0[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double x0 = mod_init[jc] + ll[base[r]];
+      la0[r] = vj ? x0 : NEG_INF;
+      if (vj) la_out[base[r]] = la0[r];
+      tm[r] = row16_max(la0[r]);
+      const double x1 = ll[base[r] + K1], x2 = ll[base[r] + K2];
+      lln[r] = vj ? x1 : NEG_INF;
+      ll2[r] = vj ? x2 : NEG_INF;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sh.tq[0][lg + 4 * r][wave][li] = tm[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int w = lg + 4 * r;
+      double m = sh.tq[0][w][0][0];
+#pragma unroll
+      for (int s2 = 1; s2 < NW; ++s2) m = fmax(m, sh.tq[0][w][s2][0]);
+      c[r] = m;
+      csum[r] = m;
+      mant[r] = 1.0;
+      ex[r] = 0;
+      const double pv = vj ? exp(la0[r] - m) : 0.0;
+      sh.P[0][w][j] = pv;
+      sh.tsum[0][w][wave][li] = row16_sum(pv);
+      sh.tmll[1][w][wave][li] = row16_max(lln[r]);
+      pacc[r] = 1.0; pc[r] = 0.0; pll[r] = la0[r];   // re-stores lalpha[0] at t = 1
+    }
+    __syncthreads();
+  }
+  for (int t = 1; t < Lm; ++t) {
+    const int cur = (t - 1) & 1, nxt = t & 1;
+    const size_t o2 = (size_t)(t + 2 < Lm ? t + 2 : Lm - 1) * K;
+    double llv[4], wgt[4], cn[4];
+    // (a) everything that does not need the MFMA result
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int w = lg + 4 * r;
+      llv[r] = lln[r];
+      lln[r] = ll2[r];   // loaded one step ago: its row max below does not wait on HBM
+      const double x2 = ll[base[r] + o2];
+      ll2[r] = vj ? x2 : NEG_INF;
+      double tot = sh.tsum[cur][w][0][0], mll = sh.tmll[nxt][w][0][0];
+#pragma unroll
+      for (int s2 = 1; s2 < NW; ++s2) {
+        tot += sh.tsum[cur][w][s2][0];
+        mll = fmax(mll, sh.tmll[nxt][w][s2][0]);
+      }
+      int e1, e2;
+      mant[r] = frexp(mant[r] * tot, &e1);
+      ex[r] += e1;
+      (void)frexp(tot, &e2);
+      const double d = (double)e2 * LN2_D + mll;
+      cn[r] = c[r] + d;
+      wgt[r] = vj ? exp(llv[r] - d) : 0.0;
+    }
+    // (b) matrix pipe
+    const double4_t acc = fb_matmul<NW>(sh, cur, li, lg, Bv);
+    // (c) delayed lalpha store of step t-1 (independent of acc: overlaps the MFMAs)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double lav = log(pacc[r]) + pc[r] + pll[r];
+      if (FULL || vj) la_out[base[r] + (size_t)(t - 1) * K] = lav;
+    }
+    // (d) critical tail
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int w = lg + 4 * r;
+      const double pv = acc[r] * wgt[r];
+      sh.P[nxt][w][j] = pv;
+      sh.tsum[nxt][w][wave][li] = row16_sum(pv);
+      sh.tmll[cur][w][wave][li] = row16_max(lln[r]);
+      pacc[r] = acc[r]; pc[r] = c[r]; pll[r] = llv[r];
+      c[r] = cn[r];
+      csum[r] += cn[r];
+    }
+    __syncthreads();
+  }
+  if (Lm > 1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (vj) la_out[base[r] + (size_t)(Lm - 1) * K] = log(pacc[r]) + pc[r] + pll[r];
+  }
+  // ---- epilogue: LSE of the last step, per-window totals
+  if (wave == 0 && li == 0) {
+    const int last = (Lm - 1) & 1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int w = lg + 4 * r;
+      double tot = sh.tsum[last][w][0][0];
+#pragma unroll
+      for (int s2 = 1; s2 < NW; ++s2) tot += sh.tsum[last][w][s2][0];
+      const double lz = c[r] + log(tot);
+      int e1;
+      const double mm = frexp(mant[r] * tot, &e1);
+      local_lb[gwc[r]] = csum[r] + log(mm) + (double)(ex[r] + e1) * LN2_D;
+      logz[gwc[r]] = lz;
+    }
+  }
+}
+
+template <int NW, bool FULL, bool WANT_LB>
+__global__ __launch_bounds__(64 * NW) void k_bwd_mfma(
+    const double* __restrict__ ll, const double* __restrict__ AexpT,
+    const double* __restrict__ la_in, const double* __restrict__ logz, int B, int Lm, int K,
+    double* __restrict__ lb_out, double* __restrict__ q_out) {
+  constexpr int KS = 4 * NW;
+  __shared__ FbShared<NW> sh;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int j = wave * 16 + li;
+  const bool vj = FULL || (j < K);
+  const int jc = vj ? j : 0;
+  const int b0 = blockIdx.x * 16;
+  double Bv[KS];
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+    const int k = 8 * (kk >> 1) + 2 * lg + (kk & 1);
+    Bv[kk] = (k < K && vj) ? AexpT[(size_t)k * K + jc] : 0.0;
+  }
+  size_t base[4];
+  double sz[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int gw = b0 + lg + 4 * r;
+    const int g = gw < B ? gw : B - 1;
+    base[r] = (size_t)g * Lm * K + jc;
+    sz[r] = logz[g];
+  }
+  const double NEG_INF = -INFINITY;
+  double c[4], eprev[4], lln[4], lan[4], ll2[4];
+  const size_t top = (size_t)(Lm - 1) * K;
+  const size_t K1 = (size_t)K * (Lm > 1 ? 1 : 0), K2 = (size_t)K * (Lm > 2 ? 2 : (Lm > 1 ? 1 : 0));
+  // ---- t = Lm-1: lbeta = 0
+  {
+    double tm[4], u[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double x0 = ll[base[r] + top], a0 = la_in[base[r] + top];
+      const double x1 = ll[base[r] + top - K1], x2 = ll[base[r] + top - K2];
+      const double a1 = la_in[base[r] + top - K1];
+      if (WANT_LB && vj) lb_out[base[r] + top] = 0.0;
+      u[r] = vj ? x0 : NEG_INF;
+      tm[r] = row16_max(u[r]);
+      eprev[r] = vj ? exp(a0 - sz[r]) : 0.0;
+      lln[r] = vj ? x1 : NEG_INF;
+      ll2[r] = vj ? x2 : NEG_INF;
+      lan[r] = a1;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sh.tq[1][lg + 4 * r][wave][li] = tm[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int w = lg + 4 * r;
+      double m = sh.tq[1][w][0][0];
+#pragma unroll
+      for (int s2 = 1; s2 < NW; ++s2) m = fmax(m, sh.tq[1][w][s2][0]);
+      c[r] = m;
+      const double pv = vj ? exp(u[r] - m) : 0.0;
+      sh.P[0][w][j] = pv;
+      sh.tsum[0][w][wave][li] = row16_sum(pv);
+      sh.tmll[1][w][wave][li] = row16_max(lln[r]);
+      sh.tq[0][w][wave][li] = row16_sum(eprev[r]);
+    }
+    __syncthreads();
+  }
+  int step = 1;
+  for (int t = Lm - 2; t >= 0; --t, ++step) {
+    const int cur = (step - 1) & 1, nxt = step & 1;
+    const size_t o1 = (size_t)(t >= 1 ? t - 1 : 0) * K, o2 = (size_t)(t >= 2 ? t - 2 : 0) * K;
+    double wp[4], we[4], cn[4], rq[4];
+    // (a) independent of the MFMA result
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int w = lg + 4 * r;
+      const double llv = lln[r], lav = lan[r];
+      lln[r] = ll2[r];
+      const double x2 = ll[base[r] + o2];
+      ll2[r] = vj ? x2 : NEG_INF;
+      lan[r] = la_in[base[r] + o1];
+      double tot = sh.tsum[cur][w][0][0], mll = sh.tmll[nxt][w][0][0], totq = sh.tq[cur][w][0][0];
+#pragma unroll
+      for (int s2 = 1; s2 < NW; ++s2) {
+        tot += sh.tsum[cur][w][s2][0];
+        mll = fmax(mll, sh.tmll[nxt][w][s2][0]);
+        totq += sh.tq[cur][w][s2][0];
+      }
+      rq[r] = 1.0 / totq;
+      int e2;
+      (void)frexp(tot, &e2);
+      const double d = (double)e2 * LN2_D + mll;
+      cn[r] = c[r] + d;
+      wp[r] = vj ? exp(llv - d) : 0.0;                          // P'_t = acc * wp
+      we[r] = vj ? exp(fmin(lav + c[r] - sz[r], 700.0)) : 0.0;  // e_t  = acc * we
+    }
+    // (b) matrix pipe
+    const double4_t acc = fb_matmul<NW>(sh, cur, li, lg, Bv);
+    // (c) posterior of row t+1, normalised like hmmbase.py:226-229 (overlaps the MFMAs)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double qv = eprev[r] * rq[r];
+      if (FULL || vj) q_out[base[r] + (size_t)(t + 1) * K] = qv;
+    }
+    // (d) critical tail
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int w = lg + 4 * r;
+      const double pv = acc[r] * wp[r];
+      sh.P[nxt][w][j] = pv;
+      eprev[r] = acc[r] * we[r];
+      sh.tsum[nxt][w][wave][li] = row16_sum(pv);
+      sh.tq[nxt][w][wave][li] = row16_sum(eprev[r]);
+      sh.tmll[cur][w][wave][li] = row16_max(lln[r]);
+    }
+    if (WANT_LB) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double lbv = log(acc[r]) + c[r];
+        if (FULL || vj) lb_out[base[r] + (size_t)t * K] = lbv;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[r] = cn[r];
+    __syncthreads();
+  }
+  // ---- flush the posterior of row 0
+  {
+    const int last = (step - 1) & 1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int w = lg + 4 * r;
+      double totq = sh.tq[last][w][0][0];
+#pragma unroll
+      for (int s2 = 1; s2 < NW; ++s2) totq += sh.tq[last][w][s2][0];
+      if (vj) q_out[base[r]] = eprev[r] / totq;
+    }
+  }
+}
+
+__global__ void k_sum_lb(const double* __restrict__ local_lb, int B, double* __restrict__ lb_total) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) acc += local_lb[b];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *lb_total = red[0];
+}
+
+// ------------------------------------------------------------------------------------
 //  K3: posterior marginals q = softmax_k(la+lb) and per-row LSE_k(la) partial sums.
 //      grid (B*nseg), block 256 = 4 waves, one wave per row; seg = PS_ROWS rows.
 // ------------------------------------------------------------------------------------
@@ -624,6 +987,165 @@ __global__ __launch_bounds__(256) void k_stats_mfma(
 }
 
 // ------------------------------------------------------------------------------------
+//  K4c: statistics GEMM, software-pipelined (K <= 64).  Same math as K4b; differences:
+//   * the next 32-row stage is fetched from HBM into registers while the current stage
+//     runs on the matrix pipe (global -> reg early, reg -> LDS after the compute);
+//   * row bookkeeping (obs row, q row, wrap predecessor, mask) is computed once per stage
+//     by 32 lanes instead of per element (no integer divisions in the copy loops);
+//   * MT = 5 m-tiles per wave: the 36 emission + 4 transition tiles of K=64, D=32 split
+//     into two balanced workgroup passes, so q is read twice instead of four times.
+//  grid (nchunk, ceil(Ftot/16 / (4*MT))), block 256.
+// ------------------------------------------------------------------------------------
+struct StRow {
+  long long orow;   // obs row, -1: out of range or masked (x~ = 0)
+  long long qrow;   // q row, -1: out of range
+  long long prow;   // predecessor q row, -1: none
+};
+
+template <int MT, int NT, int XK>
+__global__ __launch_bounds__(256) void k_stats_mfma2(
+    const double* __restrict__ obs, const uint8_t* __restrict__ mask,
+    const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K, int Fp, int F,
+    const int* __restrict__ fab, const double* __restrict__ q, int64_t rows_per_chunk,
+    uint32_t flags, int Lq, int off, double* __restrict__ part) {
+  constexpr int Kp = 16 * NT;
+  constexpr int QS = Kp + 1;
+  extern __shared__ double smem[];
+  const int DS = (D + 2) | 1;
+  double* xs = smem;               // [32][DS]
+  double* qs = xs + ST_RB * DS;    // [32][QS]
+  double* qp = qs + ST_RB * QS;    // [32][QS]  (column Kp is a zero column)
+  StRow* rinfo = reinterpret_cast<StRow*>(qp + ST_RB * QS);  // [2][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int Ftot = Fp + Kp;
+  const int mt0 = (blockIdx.y * 4 + wave) * MT;
+  const int wg_m0 = blockIdx.y * 4 * MT * 16, wg_m1 = wg_m0 + 4 * MT * 16;
+  const bool need_x = wg_m0 < Fp;
+  const bool need_qp = wg_m1 > Fp;
+  const int sr = tid >> 3, sc = tid & 7;   // staging role: row sr, columns sc + 8k
+
+  int fa[MT], fb[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int f = (mt0 + m) * 16 + li;
+    if (f < F) { const int ab = fab[f]; fa[m] = ab & 0xffff; fb[m] = ab >> 16; }
+    else if (f >= Fp) { fa[m] = (f - Fp < K) ? f - Fp : Kp; fb[m] = 0; }
+    else { fa[m] = D + 1; fb[m] = D + 1; }
+  }
+  double4_t acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  const int64_t c0 = (int64_t)blockIdx.x * rows_per_chunk;
+  const int64_t c1 = imin64(nrows, c0 + rows_per_chunk);
+  const int nstage = (int)((c1 - c0 + ST_RB - 1) / ST_RB);
+
+  auto row_info = [&](int64_t s0, int buf) {
+    if (tid < ST_RB) {
+      const int64_t g = s0 + tid;
+      StRow ri; ri.orow = -1; ri.qrow = -1; ri.prow = -1;
+      if (g < c1) {
+        const int64_t bw = g / Lm;
+        const int64_t t = g - bw * Lm;
+        ri.qrow = bw * Lq + off + t;
+        const int64_t orow = starts[bw] + off + t;
+        ri.orow = (mask && mask[orow]) ? -1 : orow;
+        if (t > 0) ri.prow = ri.qrow - 1;
+        else if (flags & SVIHMM_TRANS_WRAP) ri.prow = ri.qrow + Lm - 1;
+      }
+      rinfo[buf * ST_RB + tid] = ri;
+    }
+  };
+  double rx[XK], rq[2 * NT], rp[2 * NT];
+  auto fetch = [&](int buf) {
+    const StRow ri = rinfo[buf * ST_RB + sr];
+    if (need_x) {
+#pragma unroll
+      for (int k = 0; k < XK; ++k) {
+        const int c = sc + 8 * k;
+        double v = 0.0;
+        if (ri.orow >= 0) {
+          if (c < D) v = obs[ri.orow * D + c];
+          else if (c == D) v = 1.0;
+        }
+        rx[k] = v;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * NT; ++k) {
+      const int c = sc + 8 * k;
+      rq[k] = (ri.qrow >= 0 && c < K) ? q[ri.qrow * K + c] : 0.0;
+    }
+    if (need_qp) {
+#pragma unroll
+      for (int k = 0; k < 2 * NT; ++k) {
+        const int c = sc + 8 * k;
+        rp[k] = (ri.prow >= 0 && c < K) ? q[ri.prow * K + c] : 0.0;
+      }
+    }
+  };
+  auto commit = [&]() {
+    if (need_x) {
+#pragma unroll
+      for (int k = 0; k < XK; ++k) {
+        const int c = sc + 8 * k;
+        if (c < D + 2) xs[sr * DS + c] = rx[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * NT; ++k) qs[sr * QS + sc + 8 * k] = rq[k];
+    if (need_qp) {
+#pragma unroll
+      for (int k = 0; k < 2 * NT; ++k) qp[sr * QS + sc + 8 * k] = rp[k];
+      if (sc == 0) qp[sr * QS + Kp] = 0.0;
+    }
+  };
+
+  row_info(c0, 0);
+  __syncthreads();
+  fetch(0);
+  for (int st = 0; st < nstage; ++st) {
+    const int64_t s0 = c0 + (int64_t)st * ST_RB;
+    __syncthreads();            // previous compute finished reading LDS
+    commit();
+    row_info(s0 + ST_RB, (st + 1) & 1);
+    __syncthreads();
+    if (st + 1 < nstage) fetch((st + 1) & 1);   // in flight during the MFMAs below
+#pragma unroll 2
+    for (int ks = 0; ks < ST_RB / 4; ++ks) {
+      const int r = ks * 4 + lg;
+      double Bv[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) Bv[n] = qs[r * QS + n * 16 + li];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        double A;
+        if ((mt0 + m) * 16 < Fp) A = xs[r * DS + fa[m]] * xs[r * DS + fb[m]];  // wave-uniform
+        else A = qp[r * QS + fa[m]];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(A, Bv[n], acc[m][n], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = (mt0 + m) * 16 + lg + 4 * r;
+      if (f < Ftot) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          part[((size_t)blockIdx.x * Ftot + f) * Kp + n * 16 + li] = acc[m][n][r];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 //  K5: deterministic reduction of the per-chunk partials + scatter into the packed layout
 //      packed = [A_raw K*K | xbar K*D | neff K | S K*D*D | lb]
 // ------------------------------------------------------------------------------------
@@ -744,6 +1266,109 @@ __global__ __launch_bounds__(64) void k_ffbs_sample(const double* __restrict__ l
   }
 }
 
+// ------------------------------------------------------------------------------------
+//  K0: NIW mean-field factors -> theta (one workgroup per state).  Cholesky of sigma_mf,
+//      W = (nu/2) sigma^-1 = (nu/2) L^-T L^-1, E log|Lambda| (digamma), linear and constant
+//      terms of the quadratic form.  status[0] = 1 + k if sigma_k is not positive definite.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ double digamma_d(double x) {
+  double r = 0.0;
+  while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
+  const double f = 1.0 / (x * x);
+  const double t = f * (-1.0 / 12 + f * (1.0 / 120 + f * (-1.0 / 252 + f * (1.0 / 240 +
+                   f * (-1.0 / 132 + f * (691.0 / 32760 + f * (-1.0 / 12)))))));
+  return r + log(x) - 0.5 / x + t;
+}
+__device__ __forceinline__ int feat_index_d(int a, int b, int D) {
+  return a * (D + 1) - a * (a - 1) / 2 + (b - a);
+}
+__global__ __launch_bounds__(256) void k_niw_to_theta(
+    const double* __restrict__ mu, const double* __restrict__ sigma,
+    const double* __restrict__ kappa, const double* __restrict__ nu, int K, int D, int Kp,
+    double* __restrict__ theta, int* __restrict__ status) {
+  extern __shared__ double sm[];
+  const int S = D + 1;
+  double* Lm_ = sm;            // [D][S] Cholesky factor (lower)
+  double* Li = Lm_ + D * S;    // [D][S] its inverse (lower)
+  double* W = Li + D * S;      // [D][S]
+  double* wm = W + D * S;      // [D]
+  __shared__ int bad;
+  const int k = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const double* Sg = sigma + (size_t)k * D * D;
+  const double* m = mu + (size_t)k * D;
+  for (int e = tid; e < D * D; e += nt) {
+    const int i = e / D, j = e - i * D;
+    Lm_[i * S + j] = Sg[e];
+    Li[i * S + j] = 0.0;
+  }
+  if (tid == 0) bad = 0;
+  __syncthreads();
+  // right-looking Cholesky
+  for (int j = 0; j < D; ++j) {
+    const double djj = Lm_[j * S + j];
+    if (!(djj > 0.0)) { if (tid == 0) bad = 1; }
+    __syncthreads();
+    if (bad) break;
+    const double d = sqrt(djj);
+    for (int i = j + 1 + tid; i < D; i += nt) Lm_[i * S + j] /= d;
+    __syncthreads();
+    if (tid == 0) Lm_[j * S + j] = d;
+    const int n = D - 1 - j;
+    for (int e = tid; e < n * n; e += nt) {
+      const int a = j + 1 + e / n, b = j + 1 + e % n;
+      if (b <= a) Lm_[a * S + b] -= Lm_[a * S + j] * Lm_[b * S + j];
+    }
+    __syncthreads();
+  }
+  if (bad) {
+    if (tid == 0) atomicMax(status, 1 + k);
+    return;
+  }
+  // Li = L^-1, one column per thread
+  for (int c = tid; c < D; c += nt) {
+    Li[c * S + c] = 1.0 / Lm_[c * S + c];
+    for (int r = c + 1; r < D; ++r) {
+      double s = 0.0;
+      for (int jj = c; jj < r; ++jj) s -= Lm_[r * S + jj] * Li[jj * S + c];
+      Li[r * S + c] = s / Lm_[r * S + r];
+    }
+  }
+  __syncthreads();
+  const double hn = 0.5 * nu[k];
+  for (int e = tid; e < D * D; e += nt) {
+    const int i = e / D, j = e - i * D;
+    if (j < i) continue;
+    double s = 0.0;
+    for (int r = j; r < D; ++r) s += Li[r * S + i] * Li[r * S + j];
+    W[i * S + j] = hn * s;
+    W[j * S + i] = hn * s;
+  }
+  __syncthreads();
+  for (int i = tid; i < D; i += nt) {
+    double s = 0.0;
+    for (int j = 0; j < D; ++j) s += W[i * S + j] * m[j];
+    wm[i] = s;
+    theta[(size_t)feat_index_d(i, D, D) * Kp + k] = 2.0 * s;
+  }
+  for (int e = tid; e < D * D; e += nt) {
+    const int i = e / D, j = e - i * D;
+    if (j < i) continue;
+    theta[(size_t)feat_index_d(i, j, D) * Kp + k] = (i == j) ? -W[i * S + i] : -2.0 * W[i * S + j];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double logdet = 0.0, llt = D * log(2.0), mWm = 0.0;
+    for (int i = 0; i < D; ++i) {
+      logdet += log(Lm_[i * S + i]);
+      llt += digamma_d(0.5 * (nu[k] - i));
+      mWm += m[i] * wm[i];
+    }
+    llt -= 2.0 * logdet;
+    const double cst = 0.5 * llt - D / (2.0 * kappa[k]) - 0.5 * D * 1.8378770664093454835606594728112;
+    theta[(size_t)feat_index_d(D, D, D) * Kp + k] = cst - mWm;
+  }
+}
+
 // small utility kernels
 __global__ void k_exp_transpose(const double* __restrict__ ltran, int K, double* __restrict__ A,
                                 double* __restrict__ AT) {
@@ -833,14 +1458,16 @@ struct svihmm_ctx {
   bool have_globals = false;
   // emission
   int eK = 0, eD = 0, Kp = 0, F = 0, Fp = 0;
-  Buf theta, fab;
+  Buf theta, fab, niw;
+  int tabD = -1;
   bool have_emission = false;
   // work
-  Buf starts, ll, la, lb, q, lse_part, local_lb, part, packed, scratch;
+  Buf starts, ll, la, lb, q, lse_part, local_lb, logz, part, packed, scratch;
   int lastB = 0, lastLm = 0;       // shape of the intermediates currently held
   int hostB = 0, hostLm = 0;       // shape of host-uploaded lliks
   bool have_host_ll = false;
   bool have_packed = false;
+  bool have_lb = false;           // lbeta materialised by the last call
   // variants: [0] emission (0 auto,1 outer,2 mfma) [1] stats (0 auto,1 outer,2 mfma)
   int variant[4] = {0, 0, 0, 0};
   // profiling
@@ -916,9 +1543,9 @@ int svihmm_destroy(svihmm_ctx* h) {
   if (h->comm) { ncclCommDestroy(h->comm); h->comm = nullptr; }
   for (auto& p : h->pending) { hipEventDestroy(p.e0); hipEventDestroy(p.e1); }
   for (auto e : h->pool) hipEventDestroy(e);
-  Buf* bufs[] = {&h->obs, &h->mask, &h->mod_init, &h->ltran, &h->Aexp, &h->AexpT, &h->theta,
+  Buf* bufs[] = {&h->obs, &h->mask, &h->mod_init, &h->ltran, &h->Aexp, &h->AexpT, &h->theta, &h->niw,
                  &h->fab, &h->starts, &h->ll, &h->la, &h->lb, &h->q, &h->lse_part,
-                 &h->local_lb, &h->part, &h->packed, &h->scratch};
+                 &h->local_lb, &h->logz, &h->part, &h->packed, &h->scratch};
   for (Buf* b : bufs) release(*b);
   hipStreamDestroy(h->stream);
   delete h;
@@ -971,116 +1598,72 @@ int svihmm_set_globals(svihmm_ctx* h, int32_t K, const double* mod_init, const d
   return 0;
 }
 
-// ---- host NIW -> theta ------------------------------------------------------------
-static double digamma_h(double x) {
-  double r = 0.0;
-  while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
-  const double f = 1.0 / (x * x);
-  // asymptotic series: ln x - 1/2x - sum B_2n / (2n x^2n)
-  const double t = f * (-1.0 / 12 + f * (1.0 / 120 + f * (-1.0 / 252 + f * (1.0 / 240 +
-                   f * (-1.0 / 132 + f * (691.0 / 32760 + f * (-1.0 / 12)))))));
-  return r + std::log(x) - 0.5 / x + t;
-}
-
-static int cholesky_lower(std::vector<double>& a, int n) {
-  for (int j = 0; j < n; ++j) {
-    double d = a[j * n + j];
-    for (int k = 0; k < j; ++k) d -= a[j * n + k] * a[j * n + k];
-    if (!(d > 0.0)) return 1;
-    d = std::sqrt(d);
-    a[j * n + j] = d;
-    for (int i = j + 1; i < n; ++i) {
-      double s = a[i * n + j];
-      for (int k = 0; k < j; ++k) s -= a[i * n + k] * a[j * n + k];
-      a[i * n + j] = s / d;
-    }
-    for (int i = 0; i < j; ++i) a[i * n + j] = 0.0;
-  }
-  return 0;
-}
-
+// ---- NIW -> theta on the device (k_niw_to_theta) -------------------------------------
 static inline int feat_index(int a, int b, int D) {  // 0 <= a <= b <= D
   return a * (D + 1) - a * (a - 1) / 2 + (b - a);
+}
+
+static int upload_feature_table(svihmm_ctx* h, int D, int K) {
+  const int F = (D + 1) * (D + 2) / 2, Fp = (F + 15) / 16 * 16, Kp = (K + 15) / 16 * 16;
+  if (h->tabD == D && h->Fp == Fp) { h->F = F; h->Kp = Kp; return 0; }
+  std::vector<int> fab(Fp, (D + 1) | ((D + 1) << 16));  // padding -> zero slot
+  for (int a = 0; a <= D; ++a)
+    for (int b = a; b <= D; ++b) fab[feat_index(a, b, D)] = a | (b << 16);
+  CK(ensure(h->fab, fab.size() * sizeof(int)));
+  HIPCK(hipMemcpyAsync(h->fab.p, fab.data(), fab.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  h->tabD = D; h->F = F; h->Fp = Fp; h->Kp = Kp;
+  return 0;
 }
 
 int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* mu,
                             const double* sigma, const double* kappa, const double* nu) {
   if (!h || K <= 0 || D <= 0 || !mu || !sigma || !kappa || !nu)
     return fail("svihmm_set_emission_niw: bad arguments");
+  if ((size_t)(3 * D * (D + 1) + D) * 8 > 150 * 1024)
+    return fail("svihmm_set_emission_niw: D too large");
   CK(set_device(h));
-  const int F = (D + 1) * (D + 2) / 2;
-  const int Fp = (F + 15) / 16 * 16;
-  const int Kp = (K + 15) / 16 * 16;
-  std::vector<double> theta((size_t)Fp * Kp, 0.0);
-  std::vector<int> fab(Fp, (D << 16) | D);
-  for (int a = 0; a <= D; ++a)
-    for (int b = a; b <= D; ++b) fab[feat_index(a, b, D)] = a | (b << 16);
-  for (int f = F; f < Fp; ++f) fab[f] = (D + 1) | ((D + 1) << 16);  // padding -> zero slot
-  std::vector<double> L((size_t)D * D), Li((size_t)D * D), W((size_t)D * D);
-  const double LOG2PI = 1.8378770664093454835606594728112;
-  for (int k = 0; k < K; ++k) {
-    const double* S = sigma + (size_t)k * D * D;
-    const double* m = mu + (size_t)k * D;
-    for (int i = 0; i < D * D; ++i) L[i] = S[i];
-    if (cholesky_lower(L, D))
-      return fail("svihmm_set_emission_niw: sigma_mf[" + std::to_string(k) + "] is not positive definite");
-    // Li = L^-1 (lower)
-    std::fill(Li.begin(), Li.end(), 0.0);
-    for (int c = 0; c < D; ++c) {
-      Li[c * D + c] = 1.0 / L[c * D + c];
-      for (int r = c + 1; r < D; ++r) {
-        double s = 0.0;
-        for (int j = c; j < r; ++j) s -= L[r * D + j] * Li[j * D + c];
-        Li[r * D + c] = s / L[r * D + r];
-      }
-    }
-    // W = (nu/2) * Li^T Li
-    const double hn = 0.5 * nu[k];
-    for (int i = 0; i < D; ++i)
-      for (int j = i; j < D; ++j) {
-        double s = 0.0;
-        for (int r = j; r < D; ++r) s += Li[r * D + i] * Li[r * D + j];
-        W[i * D + j] = W[j * D + i] = hn * s;
-      }
-    double logdet = 0.0;
-    for (int i = 0; i < D; ++i) logdet += std::log(L[i * D + i]);
-    double llt = D * std::log(2.0) - 2.0 * logdet;
-    for (int i = 0; i < D; ++i) llt += digamma_h(0.5 * (nu[k] - i));
-    const double cst = 0.5 * llt - D / (2.0 * kappa[k]) - 0.5 * D * LOG2PI;
-    double mWm = 0.0;
-    for (int i = 0; i < D; ++i) {
-      double wm = 0.0;
-      for (int j = 0; j < D; ++j) wm += W[i * D + j] * m[j];
-      theta[(size_t)feat_index(i, D, D) * Kp + k] = 2.0 * wm;  // linear term v_i
-      mWm += m[i] * wm;
-    }
-    theta[(size_t)feat_index(D, D, D) * Kp + k] = cst - mWm;  // constant
-    for (int i = 0; i < D; ++i)
-      for (int j = i; j < D; ++j)
-        theta[(size_t)feat_index(i, j, D) * Kp + k] = (i == j) ? -W[i * D + i] : -2.0 * W[i * D + j];
+  CK(upload_feature_table(h, D, K));
+  const int Fp = h->Fp, Kp = h->Kp;
+  const size_t nmu = (size_t)K * D, nsg = (size_t)K * D * D;
+  const size_t nin = nmu + nsg + 2 * (size_t)K;
+  CK(ensure(h->niw, nin * sizeof(double) + 64));
+  CK(ensure(h->theta, (size_t)Fp * Kp * sizeof(double)));
+  double* dmu = (double*)h->niw.p;
+  double* dsg = dmu + nmu;
+  double* dka = dsg + nsg;
+  double* dnu = dka + K;
+  int* dstatus = (int*)(dnu + K);
+  HIPCK(hipMemcpyAsync(dmu, mu, nmu * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemcpyAsync(dsg, sigma, nsg * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemcpyAsync(dka, kappa, K * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemcpyAsync(dnu, nu, K * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemsetAsync(dstatus, 0, sizeof(int), h->stream));
+  HIPCK(hipMemsetAsync(h->theta.p, 0, (size_t)Fp * Kp * sizeof(double), h->stream));
+  {
+    ProfScope ps(h, KS_MISC);
+    const size_t lds = (size_t)(3 * D * (D + 1) + D) * sizeof(double);
+    if (lds > 64 * 1024)
+      hipFuncSetAttribute((const void*)k_niw_to_theta, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_niw_to_theta, dim3(K), dim3(256), lds, h->stream, (const double*)dmu,
+                       (const double*)dsg, (const double*)dka, (const double*)dnu, K, D, Kp,
+                       (double*)h->theta.p, dstatus);
+    HIPCK(hipGetLastError());
   }
-  CK(ensure(h->theta, theta.size() * sizeof(double)));
-  CK(ensure(h->fab, fab.size() * sizeof(int)));
-  HIPCK(hipMemcpyAsync(h->theta.p, theta.data(), theta.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIPCK(hipMemcpyAsync(h->fab.p, fab.data(), fab.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  int status = 0;
+  HIPCK(hipMemcpyAsync(&status, dstatus, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCK(hipStreamSynchronize(h->stream));
-  h->eK = K; h->eD = D; h->Kp = Kp; h->F = F; h->Fp = Fp; h->have_emission = true;
+  if (status != 0) {
+    h->have_emission = false;
+    return fail("svihmm_set_emission_niw: sigma_mf[" + std::to_string(status - 1) + "] is not positive definite");
+  }
+  h->eK = K; h->eD = D; h->have_emission = true;
   return 0;
 }
 
 // feature table is also needed by the statistics kernels when only host lliks are used
 static int ensure_feature_table(svihmm_ctx* h) {
-  if (h->have_emission && h->eD == h->D && h->eK == h->K) return 0;
-  const int D = h->D, K = h->K;
-  const int F = (D + 1) * (D + 2) / 2, Fp = (F + 15) / 16 * 16, Kp = (K + 15) / 16 * 16;
-  std::vector<int> fab(Fp, (D + 1) | ((D + 1) << 16));
-  for (int a = 0; a <= D; ++a)
-    for (int b = a; b <= D; ++b) fab[feat_index(a, b, D)] = a | (b << 16);
-  CK(ensure(h->fab, fab.size() * sizeof(int)));
-  HIPCK(hipMemcpyAsync(h->fab.p, fab.data(), fab.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  HIPCK(hipStreamSynchronize(h->stream));
-  h->F = F; h->Fp = Fp; h->Kp = Kp;
-  return 0;
+  return upload_feature_table(h, h->D, h->K);
 }
 
 int svihmm_set_lliks(svihmm_ctx* h, const double* lliks, int32_t B, int32_t Lm) {
@@ -1217,6 +1800,69 @@ static int launch_posterior(svihmm_ctx* h, int B, int Lm, bool total) {
   return 0;
 }
 
+// forward sweep, then backward sweep with the posterior fused (K <= 64).  want_lb: also
+// materialise lbeta (API readback); total: write sum_b local_lb into packed[last].
+static int launch_fb_fused(svihmm_ctx* h, int B, int Lm, bool want_lb, bool total) {
+  if (!h->have_globals) return fail("no globals: call svihmm_set_globals");
+  const int K = h->K;
+  const size_t n = (size_t)B * Lm * K * sizeof(double);
+  CK(ensure(h->la, n));
+  CK(ensure(h->q, n));
+  if (want_lb) CK(ensure(h->lb, n));
+  CK(ensure(h->local_lb, (size_t)B * sizeof(double)));
+  CK(ensure(h->logz, (size_t)B * sizeof(double)));
+  CK(ensure(h->packed, (size_t)svihmm_packed_size(K, h->D > 0 ? h->D : 1) * sizeof(double)));
+  const int NW = (K + 15) / 16;
+  dim3 grid((B + 15) / 16);
+  const double* ll = (const double*)h->ll.p;
+  double* la = (double*)h->la.p;
+  double* lb = want_lb ? (double*)h->lb.p : nullptr;
+  double* q = (double*)h->q.p;
+  double* llb = (double*)h->local_lb.p;
+  double* lz = (double*)h->logz.p;
+  {
+    ProfScope ps(h, KS_FB);
+#define FWD(NWV, F) hipLaunchKernelGGL((k_fwd_mfma<NWV, F>), grid, dim3(64 * NWV), 0, h->stream, ll, \
+                                       (const double*)h->Aexp.p, (const double*)h->mod_init.p, B, Lm, K, la, llb, lz)
+    const bool full = (K == 16 * NW);
+    if (NW == 1) { if (full) FWD(1, true); else FWD(1, false); }
+    else if (NW == 2) { if (full) FWD(2, true); else FWD(2, false); }
+    else if (NW == 3) { if (full) FWD(3, true); else FWD(3, false); }
+    else { if (full) FWD(4, true); else FWD(4, false); }
+#undef FWD
+    HIPCK(hipGetLastError());
+  }
+  {
+    ProfScope ps(h, KS_POSTERIOR);
+    const bool full = (K == 16 * NW);
+#define BWD(NWV, F, W) hipLaunchKernelGGL((k_bwd_mfma<NWV, F, W>), grid, dim3(64 * NWV), 0, h->stream, ll, \
+                                          (const double*)h->AexpT.p, (const double*)la, (const double*)lz, B, Lm, K, lb, q)
+#define BWD2(NWV) do { if (full) { if (want_lb) BWD(NWV, true, true); else BWD(NWV, true, false); } \
+                       else { if (want_lb) BWD(NWV, false, true); else BWD(NWV, false, false); } } while (0)
+    if (NW == 1) BWD2(1); else if (NW == 2) BWD2(2); else if (NW == 3) BWD2(3); else BWD2(4);
+#undef BWD2
+#undef BWD
+    if (total) {
+      double* lbtot = (double*)h->packed.p + (svihmm_packed_size(K, h->D) - 1);
+      hipLaunchKernelGGL(k_sum_lb, dim3(1), dim3(256), 0, h->stream, (const double*)llb, B, lbtot);
+    }
+    HIPCK(hipGetLastError());
+  }
+  return 0;
+}
+
+// messages + posterior for a window batch: picks the fused MFMA sweeps or the
+// wave-per-window kernels (concurrent directions; better latency for small batches)
+static int run_fb(svihmm_ctx* h, int B, int Lm, bool want_lb, bool total) {
+  int var = h->variant[2];
+  if (h->K > 64) var = 1;
+  if (var == 0) var = (B >= 192) ? 2 : 1;
+  h->have_lb = (var != 2) || want_lb;
+  if (var == 2) return launch_fb_fused(h, B, Lm, want_lb, total);
+  CK(launch_fb(h, B, Lm, 0, 2));
+  return launch_posterior(h, B, Lm, total);
+}
+
 static int launch_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags) {
   // statistics over the inner segment [off, off+Lm) of each window of length Lq
   CK(ensure_feature_table(h));
@@ -1232,9 +1878,34 @@ static int launch_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t 
   CK(ensure(h->packed, (size_t)svihmm_packed_size(K, D) * sizeof(double)));
   const uint8_t* mk = h->have_mask ? (const uint8_t*)h->mask.p : nullptr;
   int var = h->variant[1];
-  if (var == 0) var = 2;
+  if (var == 0) var = 3;
   {
     ProfScope ps(h, KS_STATS);
+    if (var == 3 && (Kp > 64 || D + 2 > 72)) var = 2;
+    if (var == 3) {
+      const int NT = Kp / 16;
+      const int MT = 5;
+      const int DS = (D + 2) | 1;
+      const size_t lds = ((size_t)ST_RB * DS + 2 * (size_t)ST_RB * (Kp + 1)) * 8 + 2 * ST_RB * sizeof(StRow);
+      const int mtiles = Ftot / 16;
+      dim3 grid((unsigned)nchunk, (mtiles + 4 * MT - 1) / (4 * MT));
+      const int xk = (D + 2 + 7) / 8;   // <= 9
+#define ST2(NTV, XKV)                                                                              \
+  do {                                                                                             \
+    if (lds > 64 * 1024)                                                                           \
+      hipFuncSetAttribute((const void*)k_stats_mfma2<5, NTV, XKV>,                                 \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+    hipLaunchKernelGGL((k_stats_mfma2<5, NTV, XKV>), grid, dim3(256), lds, h->stream,              \
+                       (const double*)h->obs.p, mk, (const int64_t*)h->starts.p, n, Lm, D, K, Fp,  \
+                       F, (const int*)h->fab.p, (const double*)h->q.p, rpc, flags, Lq, off,        \
+                       (double*)h->part.p);                                                        \
+  } while (0)
+#define ST2X(NTV) do { if (xk <= 2) ST2(NTV, 2); else if (xk <= 5) ST2(NTV, 5); else ST2(NTV, 9); } while (0)
+      if (NT == 1) ST2X(1); else if (NT == 2) ST2X(2); else if (NT == 3) ST2X(3); else ST2X(4);
+#undef ST2X
+#undef ST2
+      (void)MT;
+    }
     if (var == 2) {
       const int ntile = Kp / 16;
       const int NT = (ntile % 4 == 0) ? 4 : (ntile % 2 == 0) ? 2 : 1;
@@ -1322,8 +1993,7 @@ int svihmm_forward_backward(svihmm_ctx* h, const int64_t* starts, int32_t B, int
   if (!h) return fail("svihmm_forward_backward: NULL handle");
   CK(set_device(h));
   CK(prepare_ll(h, starts, B, Lm, flags, false));
-  CK(launch_fb(h, B, Lm, 0, 2));
-  CK(launch_posterior(h, B, Lm, false));
+  CK(run_fb(h, B, Lm, out_lbeta != nullptr, false));
   const size_t n = (size_t)B * Lm * h->K * sizeof(double);
   if (out_lalpha) CK(d2h(h, out_lalpha, h->la.p, n));
   if (out_lbeta) CK(d2h(h, out_lbeta, h->lb.p, n));
@@ -1359,8 +2029,7 @@ int svihmm_estep_minibatch_ex(svihmm_ctx* h, const int64_t* starts, int32_t B, i
   if (inner_off < 0 || inner_len <= 0 || inner_off + inner_len > Lm)
     return fail("svihmm_estep_minibatch_ex: inner segment out of range");
   CK(prepare_ll(h, starts, B, Lm, flags, true));
-  CK(launch_fb(h, B, Lm, 0, 2));
-  CK(launch_posterior(h, B, Lm, true));
+  CK(run_fb(h, B, Lm, (flags & SVIHMM_KEEP_LBETA) != 0, true));
   CK(launch_stats(h, B, Lm, inner_off, inner_len, flags));
   h->have_packed = true;
   h->lastB = B; h->lastLm = Lm;
@@ -1386,6 +2055,8 @@ int svihmm_read_intermediate(svihmm_ctx* h, int32_t what, double* out) {
   CK(set_device(h));
   Buf* src[] = {&h->ll, &h->la, &h->lb, &h->q};
   if (what < 0 || what > 3) return fail("svihmm_read_intermediate: bad selector");
+  if (what == 2 && !h->have_lb)
+    return fail("svihmm_read_intermediate: lbeta was not materialised (pass SVIHMM_KEEP_LBETA)");
   const size_t n = (size_t)h->lastB * h->lastLm * h->K * sizeof(double);
   if (!src[what]->p || src[what]->cap < n) return fail("svihmm_read_intermediate: buffer not available");
   CK(d2h(h, out, src[what]->p, n));
@@ -1397,6 +2068,8 @@ int svihmm_read_rows(svihmm_ctx* h, int32_t what, int64_t row0, int64_t nrows, d
   if (!h || !out || row0 < 0 || nrows <= 0) return fail("svihmm_read_rows: bad arguments");
   if (h->lastB <= 0) return fail("svihmm_read_rows: nothing computed yet");
   if (what < 0 || what > 3) return fail("svihmm_read_rows: bad selector");
+  if (what == 2 && !h->have_lb)
+    return fail("svihmm_read_rows: lbeta was not materialised (pass SVIHMM_KEEP_LBETA)");
   if (row0 + nrows > (int64_t)h->lastB * h->lastLm) return fail("svihmm_read_rows: out of range");
   CK(set_device(h));
   Buf* src[] = {&h->ll, &h->la, &h->lb, &h->q};

@@ -309,7 +309,8 @@ class VBHMM(VariationalHMMBase):
             bufferL, L_ = buffer
             inner = (bufferL - L_, 2 * L_ + 1)
         if len(starts):
-            flags = self._push_emission(windows=list(starts), Lm=Lm) | L.TRANS_WRAP
+            # KEEP_LBETA: the reference leaves lbeta of the last window on the object
+            flags = self._push_emission(windows=list(starts), Lm=Lm) | L.TRANS_WRAP | L.KEEP_LBETA
         else:
             flags = L.TRANS_WRAP
         # an empty shard still produces (zero) statistics so every rank joins the all-reduce

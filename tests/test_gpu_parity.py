@@ -56,16 +56,18 @@ def test_golden_windows(eng, path, evar):
         np.testing.assert_allclose(ll, g["w_lliks"][sl], rtol=1e-9, atol=1e-8)
         # a4..a7 from the reference's own lliks: pure reference arithmetic
         eng.set_lliks(g["w_lliks"][sl])
-        r = eng.forward_backward(None, Lm, flags=L.USE_HOST_LLIKS, B=wpi)
-        np.testing.assert_allclose(r["lalpha"], g["w_lalpha"][sl], rtol=1e-10, atol=1e-9)
-        np.testing.assert_allclose(r["lbeta"], g["w_lbeta"][sl], rtol=1e-10, atol=1e-9)
-        np.testing.assert_allclose(r["var_x"], g["w_var_x"][sl], rtol=RTOL, atol=1e-12)
-        np.testing.assert_allclose(r["local_lb"], g["w_local_lb"][sl], rtol=1e-12)
-    eng.set_variant("emission", 0)
+        for fv in (1, 2):                    # wave-per-window and fused MFMA sweeps
+            eng.set_variant("fb", fv)
+            r = eng.forward_backward(None, Lm, flags=L.USE_HOST_LLIKS, B=wpi)
+            np.testing.assert_allclose(r["lalpha"], g["w_lalpha"][sl], rtol=1e-10, atol=1e-9)
+            np.testing.assert_allclose(r["lbeta"], g["w_lbeta"][sl], rtol=1e-10, atol=1e-9)
+            np.testing.assert_allclose(r["var_x"], g["w_var_x"][sl], rtol=RTOL, atol=1e-12)
+            np.testing.assert_allclose(r["local_lb"], g["w_local_lb"][sl], rtol=1e-12)
+    eng.set_variant("emission", 0); eng.set_variant("fb", 0)
 
 
 @pytest.mark.parametrize("path", META, ids=[os.path.basename(p)[:-4] for p in META])
-@pytest.mark.parametrize("svar", [1, 2], ids=["st_outer", "st_mfma"])
+@pytest.mark.parametrize("svar", [1, 2, 3], ids=["st_outer", "st_mfma", "st_mfma_pipelined"])
 def test_golden_minibatch_stats(eng, path, svar):
     """a8/a9: natural-gradient statistics of each minibatch vs the reference's
     A_inter / emit_inter (hmmsgd_metaobs.py:430-433)."""
@@ -140,18 +142,32 @@ CASES = [  # K, D, T, Lm, B, miss
 
 
 @pytest.mark.parametrize("case", CASES, ids=["K%d_D%d_T%d_Lm%d_B%d_m%g" % c for c in CASES])
-@pytest.mark.parametrize("var", [1, 2], ids=["outer", "mfma"])
+@pytest.mark.parametrize("var", [1, 2, 3], ids=["outer", "mfma", "mfma_pipelined"])
 def test_random_vs_c_oracle(eng, case, var):
+    """var 1: VALU kernels + wave-per-window recursions; var 2: fp64 MFMA emission/statistics
+    + fused MFMA forward / backward+posterior sweeps (K <= 64)."""
     from pysvihmm_amd import _lib as L
     from oracle import ref_c
     K, D, T, Lm, B, miss = case
     pb = make_problem(K, D, T, seed=100 + K + D, miss=miss)
     rng = np.random.default_rng(K * 7 + D)
     starts = rng.integers(0, T - Lm + 1, size=B)
-    eng.set_variant("emission", var); eng.set_variant("stats", var)
+    eng.set_variant("emission", min(var, 2)); eng.set_variant("stats", var); eng.set_variant("fb", min(var, 2))
     eng.set_obs(pb["obs"], pb["mask"])
     eng.set_globals(pb["mod_init"], pb["ltran"])
     eng.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    # messages and posteriors of every window against the C oracle
+    r = eng.forward_backward(starts, Lm)
+    for b in range(0, B, max(1, B // 5)):
+        s0 = int(starts[b])
+        ll = ref_c.lliks_niw(pb["obs"][s0:s0 + Lm], pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+        la = ref_c.forward(ll, pb["mod_init"], pb["ltran"])
+        lb_ = ref_c.backward(ll, pb["ltran"])
+        q, lz = ref_c.posterior(la, lb_)
+        np.testing.assert_allclose(r["lalpha"][b], la, rtol=1e-9, atol=1e-8)
+        np.testing.assert_allclose(r["lbeta"][b], lb_, rtol=1e-9, atol=1e-8)
+        np.testing.assert_allclose(r["var_x"][b], q, rtol=RTOL, atol=1e-12)
+        np.testing.assert_allclose(r["local_lb"][b], lz, rtol=1e-11)
     for flags in (L.TRANS_WRAP, L.TRANS_WRAP | L.MASK_AS_NAN, 0):
         st = eng.estep(starts, Lm, flags=flags)
         ref = ref_c.estep_minibatch(pb["obs"], pb["mask"], starts, Lm, pb["mod_init"],
@@ -164,7 +180,7 @@ def test_random_vs_c_oracle(eng, case, var):
         np.testing.assert_allclose(st.xbar, xbar, rtol=RTOL, atol=1e-8 * scale)
         np.testing.assert_allclose(st.S, S, rtol=RTOL, atol=1e-7 * scale)
         np.testing.assert_allclose(st.lb[0], lb, rtol=1e-9)
-    eng.set_variant("emission", 0); eng.set_variant("stats", 0)
+    eng.set_variant("emission", 0); eng.set_variant("stats", 0); eng.set_variant("fb", 0)
 
 
 def test_nan_rows_and_all_masked(eng):
@@ -250,6 +266,8 @@ def test_full_size_properties(eng):
     np.testing.assert_allclose(st.S, np.swapaxes(st.S, 1, 2), rtol=0, atol=0)
     q = eng.read_intermediate("var_x", B, Lm)
     np.testing.assert_allclose(q.sum(-1), 1.0, rtol=1e-12)
+    with pytest.raises(RuntimeError):           # fused sweep keeps lbeta in registers
+        eng.read_intermediate("lbeta", B, Lm)
     # marginal consistency: row sums of the transition statistic = sum_t q[t-1] (wrap => all t)
     np.testing.assert_allclose(st.A_raw.sum(1), q.sum((0, 1)), rtol=1e-9)
     np.testing.assert_allclose(st.A_raw.sum(0), q.sum((0, 1)), rtol=1e-9)

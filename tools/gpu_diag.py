@@ -60,7 +60,7 @@ def main():
             print("  var_x err %.3g  local_lb rel %.3g" % (np.abs(r["var_x"] - q).max(), relerr(r["local_lb"], lbs)))
             ref = ref_c.estep_minibatch(pb["obs"], pb["mask"], starts, Lm, pb["mod_init"], pb["ltran"], pb["mu"], pb["sigma"], pb["kappa"], pb["nu"], flags=2)
             A, xbar, neff, S, lbt = unpack(ref, K, D)
-            for sv in (1, 2):
+            for sv in (1, 2, 3):
                 eng.set_variant("stats", sv)
                 st = eng.estep(starts, Lm, flags=L.TRANS_WRAP)
                 print("  stats var %d: A %.3g xbar %.3g neff %.3g S %.3g lb %.3g (abs, scale %d)" % (
@@ -82,8 +82,8 @@ def main():
         eng.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
         for B in (64, 3891):
             starts = (np.arange(B, dtype=np.int64) * Lm) % (T - Lm)
-            for ev, sv in ((2, 2), (1, 1)):
-                eng.set_variant("emission", ev); eng.set_variant("stats", sv)
+            for ev, sv, fv in ((2, 3, 2), (2, 2, 2), (2, 2, 1)):
+                eng.set_variant("emission", ev); eng.set_variant("stats", sv); eng.set_variant("fb", fv)
                 eng.estep(starts, Lm, read=False); eng.sync()
                 eng.profile(True); eng.profile_reset()
                 t0 = time.time()
@@ -93,7 +93,7 @@ def main():
                 eng.sync()
                 dt = (time.time() - t0) / reps
                 prof = eng.profile_read(); eng.profile(False)
-                print("  B=%d variants(em=%d,st=%d): %.3f ms/step -> %.3g upd/s" % (B, ev, sv, dt * 1e3, B * Lm * K / dt))
+                print("  B=%d variants(em=%d,st=%d,fb=%d): %.3f ms/step -> %.3g upd/s" % (B, ev, sv, fv, dt * 1e3, B * Lm * K / dt))
                 for k, (ms, c) in prof.items():
                     print("      %-18s %8.3f ms/launch (%d launches)" % (k, ms / c, c))
     except Exception:
