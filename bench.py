@@ -98,14 +98,16 @@ def main():
     from pysvihmm_amd import _lib as L
     eng = HipEngine(local_rank)
 
-    dist = None
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        import torch.distributed as dist  # gloo: rendezvous, barrier only
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        uid = [eng.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        eng.comm_init(uid[0], rank, world)
+    # N>1: one process per GPU, RCCL over xGMI through the C ABI.  No torch in the
+    # process: the ncclUniqueId is exchanged through a file keyed by the launcher's pid,
+    # barriers and the max-over-ranks timing are RCCL all-reduces on the handle's stream
+    # (+ hipStreamSynchronize) -- the same bracket as dist.barrier()+cuda.synchronize().
+    use_comm = world > 1 or os.environ.get("SVIHMM_FORCE_COMM") == "1"  # (world-1 rehearsal)
+    comm = None
+    if use_comm:
+        from pysvihmm_amd.comm import RcclComm, file_uid_exchange
+        ex = file_uid_exchange(rank)
+        comm = RcclComm(eng, rank, world, ex)
 
     pb = synth(rank)
     eng.set_obs(pb["obs"], None)            # resident in HBM before the timed region
@@ -117,14 +119,14 @@ def main():
         eng.set_globals(pb["mod_init"], pb["ltran"])
         eng.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
         eng.estep(st, LM, flags=L.TRANS_WRAP, read=False)
-        if world > 1:
+        if use_comm:
             eng.allreduce_packed()
         return eng.read_packed()
 
     def barrier():
         eng.sync()
-        if dist is not None:
-            dist.barrier()
+        if comm is not None:
+            comm.barrier(eng)
         eng.sync()
 
     for _ in range(args.warmup):
@@ -139,11 +141,8 @@ def main():
     dt = time.perf_counter() - t0
     prof = eng.profile_read()
     eng.profile(False)
-    if dist is not None:
-        import torch
-        tt = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt[0])
+    if comm is not None:
+        dt = float(eng.allreduce_host(np.array([dt]), "max")[0])   # MAX over ranks
     assert np.all(np.isfinite(out.buf)), "non-finite statistics"
     # sanity: posteriors sum to one => wrap transition statistic sums to the row count
     tot_rows = rows * world
@@ -227,9 +226,14 @@ def main():
                 err = np.max(np.abs(chk.buf - ref) / (1e-9 + np.abs(ref)))
                 res["cpu_baseline"]["gpu_vs_port_max_rel_err"] = float(err)
         print(json.dumps(res))
+    if comm is not None:
+        comm.barrier(eng)
+        if rank == 0:
+            try:
+                os.remove(ex.path)
+            except OSError:
+                pass
     eng.close()
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -55,6 +55,44 @@ class TorchDistComm(object):
         self._dist.barrier(group=self.group)
 
 
+def file_uid_exchange(rank, tag=None, timeout=300.0, directory=None):
+    """Single-node rendezvous without torch: rank 0 publishes the 128-byte ncclUniqueId
+    in a file named after the launcher's pid (all workers of one ``torch.distributed.run``
+    share the parent pid) and MASTER_PORT; the other ranks poll for it.  Returns a
+    function suitable as ``exchange_uid`` of ``RcclComm``."""
+    import os
+    import tempfile
+    import time
+    if tag is None:
+        tag = "%s_%s_%s" % (os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid(),
+                            os.environ.get("MASTER_PORT", "0"))
+    directory = directory or tempfile.gettempdir()
+    path = os.path.join(directory, "svihmm_uid_%s.bin" % tag)
+
+    def exchange(uid):
+        if rank == 0:
+            tmp = path + ".tmp%d" % os.getpid()
+            with open(tmp, "wb") as f:
+                f.write(uid)
+            os.replace(tmp, path)          # atomic publish
+            return uid
+        t0 = time.time()
+        while True:
+            try:
+                with open(path, "rb") as f:
+                    data = f.read()
+                if len(data) == 128:
+                    return data
+            except OSError:
+                pass
+            if time.time() - t0 > timeout:
+                raise RuntimeError("rendezvous timeout waiting for %s" % path)
+            time.sleep(0.01)
+
+    exchange.path = path
+    return exchange
+
+
 def torch_uid_exchange(uid):
     """broadcast the ncclUniqueId over an initialised torch.distributed group."""
     import torch.distributed as dist

@@ -141,34 +141,35 @@ __global__ __launch_bounds__(EM_R) void k_emission_outer(
 //       Workgroup = 4 waves x (MT=2 row tiles) = 128 rows; NT n-tiles of 16 states.
 //       grid (ceil(n/128), Kp/(16*NT)), block 256.
 // ------------------------------------------------------------------------------------
-#define EMM_ROWS 128
-template <int NT>
+template <int NT, int MT>
 __global__ __launch_bounds__(256) void k_emission_mfma(
     const double* __restrict__ obs, const uint8_t* __restrict__ mask,
     const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K, int Kp,
     int Fp, const double* __restrict__ theta, const int* __restrict__ fab,
     uint32_t flags, double* __restrict__ ll) {
+  // workgroup = 4 waves x MT row tiles of 16 rows
+  constexpr int ROWS = 64 * MT;
   extern __shared__ double smem[];
   const int DS = (D + 2) | 1;  // odd row stride (doubles); slot D = 1.0, slot D+1 = 0.0
-  double* xs = smem;                              // [EMM_ROWS][DS]
-  int* fabs_ = (int*)(xs + EMM_ROWS * DS);        // [Fp] packed (a | b<<16)
-  unsigned char* bad_s = (unsigned char*)(fabs_ + Fp);  // [EMM_ROWS]
+  double* xs = smem;                              // [ROWS][DS]
+  int* fabs_ = (int*)(xs + ROWS * DS);            // [Fp] packed (a | b<<16)
+  unsigned char* bad_s = (unsigned char*)(fabs_ + Fp);  // [ROWS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t g0 = (int64_t)blockIdx.x * EMM_ROWS;
+  const int64_t g0 = (int64_t)blockIdx.x * ROWS;
   const int n0 = blockIdx.y * (16 * NT);
 
-  if (tid < EMM_ROWS) {
-    int64_t g = g0 + tid;
+  for (int r = tid; r < ROWS; r += 256) {
+    int64_t g = g0 + r;
     unsigned char bd = 0;
     if (g < nrows && (flags & SVIHMM_MASK_AS_NAN) && mask)
       bd = mask[obs_row(starts, Lm, g)] != 0;
-    bad_s[tid] = bd;
-    xs[tid * DS + D] = 1.0;
-    xs[tid * DS + D + 1] = 0.0;
+    bad_s[r] = bd;
+    xs[r * DS + D] = 1.0;
+    xs[r * DS + D + 1] = 0.0;
   }
   for (int e = tid; e < Fp; e += 256) fabs_[e] = fab[e];
   __syncthreads();
-  for (int e = tid; e < EMM_ROWS * D; e += 256) {
+  for (int e = tid; e < ROWS * D; e += 256) {
     int r = e / D, i = e - r * D;
     int64_t g = g0 + r;
     double v = 0.0;
@@ -179,15 +180,14 @@ __global__ __launch_bounds__(256) void k_emission_mfma(
   __syncthreads();
 
   const int li = lane & 15, lg = lane >> 4;
-  const int r0 = wave * 32 + li;  // row of m-tile 0 for this lane; m-tile 1 = +16
-  double4_t acc[2][NT];
+  const int r0 = wave * 16 * MT + li;  // row of m-tile 0 for this lane; m-tile m = +16m
+  double4_t acc[MT][NT];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
-  const double* xr0 = xs + r0 * DS;
-  const double* xr1 = xs + (r0 + 16) * DS;
+  const double* xr = xs + r0 * DS;
   const double* thl = theta + n0 + li;
   const int nks = Fp >> 2;
 #pragma unroll 2
@@ -195,23 +195,23 @@ __global__ __launch_bounds__(256) void k_emission_mfma(
     const int f = (s << 2) + lg;
     const int ab = fabs_[f];
     const int a = ab & 0xffff, b = ab >> 16;
-    const double A0 = xr0[a] * xr0[b];
-    const double A1 = xr1[a] * xr1[b];
     const double* trow = thl + (size_t)f * Kp;
-    double Bv[NT];
+    double Bv[NT], Av[MT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) Bv[n] = trow[n * 16];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      acc[0][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, Bv[n], acc[0][n], 0, 0, 0);
-      acc[1][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, Bv[n], acc[1][n], 0, 0, 0);
-    }
+    for (int m = 0; m < MT; ++m) Av[m] = xr[m * 16 * DS + a] * xr[m * 16 * DS + b];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(Av[m], Bv[n], acc[m][n], 0, 0, 0);
   }
 #pragma unroll
-  for (int m = 0; m < 2; ++m) {
+  for (int m = 0; m < MT; ++m) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int rl = wave * 32 + m * 16 + lg + 4 * r;
+      const int rl = wave * 16 * MT + m * 16 + lg + 4 * r;
       const int64_t g = g0 + rl;
       if (g < nrows) {
         const bool bd = bad_s[rl] != 0;
@@ -1754,23 +1754,28 @@ static int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags) {
   if (var == 0) var = 2;
   if (var == 2) {
     const int DS = (D + 2) | 1;
-    const size_t lds = (size_t)EMM_ROWS * DS * 8 + (size_t)h->Fp * 4 + EMM_ROWS;
-    if (lds > 160 * 1024) var = 1;
+    int MT = h->variant[3] > 0 ? h->variant[3] : 2;
+    if (MT != 2 && MT != 4) MT = 2;
+    size_t lds = (size_t)(64 * MT) * DS * 8 + (size_t)h->Fp * 4 + 64 * MT;
+    if (lds > 150 * 1024 && MT == 4) { MT = 2; lds = (size_t)128 * DS * 8 + (size_t)h->Fp * 4 + 128; }
+    if (lds > 150 * 1024) var = 1;
     else {
       const int ntile = Kp / 16;
       const int NT = (ntile % 4 == 0) ? 4 : (ntile % 2 == 0) ? 2 : 1;
-      dim3 grid((unsigned)((n + EMM_ROWS - 1) / EMM_ROWS), ntile / NT);
-#define EMM_LAUNCH(NTV)                                                                     \
-  hipLaunchKernelGGL(k_emission_mfma<NTV>, grid, dim3(256), lds, h->stream,                 \
-                     (const double*)h->obs.p, mk, (const int64_t*)h->starts.p, n, Lm, D, K, \
-                     Kp, h->Fp, (const double*)h->theta.p, (const int*)h->fab.p, flags,     \
-                     (double*)h->ll.p)
-      if (lds > 64 * 1024) {
-        hipFuncSetAttribute((const void*)k_emission_mfma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)k_emission_mfma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)k_emission_mfma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      }
-      if (NT == 4) EMM_LAUNCH(4); else if (NT == 2) EMM_LAUNCH(2); else EMM_LAUNCH(1);
+      const int rows = 64 * MT;
+      dim3 grid((unsigned)((n + rows - 1) / rows), ntile / NT);
+#define EMM_LAUNCH(NTV, MTV)                                                                 \
+  do {                                                                                        \
+    if (lds > 64 * 1024)                                                                      \
+      hipFuncSetAttribute((const void*)k_emission_mfma<NTV, MTV>,                             \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+    hipLaunchKernelGGL((k_emission_mfma<NTV, MTV>), grid, dim3(256), lds, h->stream,          \
+                       (const double*)h->obs.p, mk, (const int64_t*)h->starts.p, n, Lm, D, K, \
+                       Kp, h->Fp, (const double*)h->theta.p, (const int*)h->fab.p, flags,     \
+                       (double*)h->ll.p);                                                     \
+  } while (0)
+      if (MT == 4) { if (NT == 4) EMM_LAUNCH(4, 4); else if (NT == 2) EMM_LAUNCH(2, 4); else EMM_LAUNCH(1, 4); }
+      else { if (NT == 4) EMM_LAUNCH(4, 2); else if (NT == 2) EMM_LAUNCH(2, 2); else EMM_LAUNCH(1, 2); }
 #undef EMM_LAUNCH
     }
   }

@@ -42,3 +42,29 @@ def test_sharded_minibatch_allreduce(tmp_path, world):
     for o in outs[1:]:                      # replicas stay in lock-step bit for bit
         np.testing.assert_array_equal(o["var_tran"], outs[0]["var_tran"])
         np.testing.assert_array_equal(o["sigma"], outs[0]["sigma"])
+
+
+def _uid_worker(rank, tag, directory, q):
+    from pysvihmm_amd.comm import file_uid_exchange
+    ex = file_uid_exchange(rank, tag=tag, directory=directory, timeout=30)
+    uid = bytes(range(128)) if rank == 0 else None
+    if rank == 0:
+        import time
+        time.sleep(0.3)                      # late publisher: the others must poll
+    q.put((rank, ex(uid)))
+
+
+def test_file_rendezvous_of_unique_id(tmp_path):
+    """bench.py's torch-free rendezvous: rank 0 publishes the 128-byte ncclUniqueId
+    atomically, the other ranks poll for it."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_uid_worker, args=(r, "t%d" % os.getpid(), str(tmp_path), q))
+          for r in range(4)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=60) for _ in ps)
+    for p in ps:
+        p.join(30)
+    assert all(got[r] == bytes(range(128)) for r in range(4))
