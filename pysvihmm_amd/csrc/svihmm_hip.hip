@@ -382,6 +382,62 @@ __global__ void k_fb_generic(const double* __restrict__ ll, const double* __rest
 //  reduction on the critical path.  sum_t LSE_j lalpha (quirk Q4) is accumulated as a
 //  running (mantissa, exponent) product of the per-step sums.
 // ------------------------------------------------------------------------------------
+// fp64 transcendentals for the fused sweeps.  On gfx950 fp64 MFMA and fp64 VALU share one
+// pipe (tools/peak_probe.py: their times add), so every fp64 VALU instruction in the time
+// loop costs matrix throughput; ocml's log() alone is ~90 of them.  These are plain
+// range-reduction + Horner versions, accurate to ~2 ulp (tests compare against the oracle).
+__device__ __forceinline__ double fmax_raw(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));  // no NaN canonicalisation pair
+  return r;
+}
+__device__ __forceinline__ double fast_exp(double x) {
+  x = fmax_raw(x, -800.0);                       // also maps -inf to exp -> 0
+  const double k = __builtin_rint(x * 1.4426950408889634074);
+  double r = fma(k, -6.93147180369123816490e-01, x);
+  r = fma(k, -1.90821492927058770002e-10, r);
+  double p = 1.0 / 479001600.0;                  // Taylor to r^12: |r| <= 0.3466 -> 1.7e-16
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)k);
+}
+__device__ __forceinline__ double fast_log(double x) {   // x > 0, finite, normal
+  int e;
+  double m = frexp(x, &e);                       // m in [0.5, 1)
+  const bool lo = m < 0.70710678118654752440;
+  m = lo ? m + m : m;
+  e = lo ? e - 1 : e;
+  const double f = m - 1.0;
+  const double s = f / (2.0 + f);
+  const double z = s * s;                        // z <= 0.0295
+  double p = 1.0 / 23.0;
+  p = fma(p, z, 1.0 / 21.0);
+  p = fma(p, z, 1.0 / 19.0);
+  p = fma(p, z, 1.0 / 17.0);
+  p = fma(p, z, 1.0 / 15.0);
+  p = fma(p, z, 1.0 / 13.0);
+  p = fma(p, z, 1.0 / 11.0);
+  p = fma(p, z, 1.0 / 9.0);
+  p = fma(p, z, 1.0 / 7.0);
+  p = fma(p, z, 1.0 / 5.0);
+  p = fma(p, z, 1.0 / 3.0);
+  // log(m) = 2s + 2s*z*p ; log(x) = e*ln2_hi + (log(m) + e*ln2_lo)
+  const double two_s = s + s;
+  const double ed = (double)e;
+  const double t = fma(two_s * z, p, fma(ed, 1.90821492927058770002e-10, two_s));
+  return fma(ed, 6.93147180369123816490e-01, t);
+}
+
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov_f64(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -398,10 +454,10 @@ __device__ __forceinline__ double row16_sum(double v) {
   return v;
 }
 __device__ __forceinline__ double row16_max(double v) {
-  v = fmax(v, dpp_mov_f64<0xB1>(v));
-  v = fmax(v, dpp_mov_f64<0x4E>(v));
-  v = fmax(v, dpp_mov_f64<0x141>(v));
-  v = fmax(v, dpp_mov_f64<0x140>(v));
+  v = fmax_raw(v, dpp_mov_f64<0xB1>(v));
+  v = fmax_raw(v, dpp_mov_f64<0x4E>(v));
+  v = fmax_raw(v, dpp_mov_f64<0x141>(v));
+  v = fmax_raw(v, dpp_mov_f64<0x140>(v));
   return v;
 }
 #define LN2_D 0.69314718055994530942
@@ -526,7 +582,7 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_mfma(
 #pragma unroll
       for (int s2 = 1; s2 < NW; ++s2) {
         tot += sh.tsum[cur][w][s2][0];
-        mll = fmax(mll, sh.tmll[nxt][w][s2][0]);
+        mll = fmax_raw(mll, sh.tmll[nxt][w][s2][0]);
       }
       int e1, e2;
       mant[r] = frexp(mant[r] * tot, &e1);
@@ -534,14 +590,14 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_mfma(
       (void)frexp(tot, &e2);
       const double d = (double)e2 * LN2_D + mll;
       cn[r] = c[r] + d;
-      wgt[r] = vj ? exp(llv[r] - d) : 0.0;
+      wgt[r] = vj ? fast_exp(llv[r] - d) : 0.0;
     }
     // (b) matrix pipe
     const double4_t acc = fb_matmul<NW>(sh, cur, li, lg, Bv);
     // (c) delayed lalpha store of step t-1 (independent of acc: overlaps the MFMAs)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const double lav = log(pacc[r]) + pc[r] + pll[r];
+      const double lav = fast_log(pacc[r]) + pc[r] + pll[r];
       if (FULL || vj) la_out[base[r] + (size_t)(t - 1) * K] = lav;
     }
     // (d) critical tail
@@ -561,7 +617,7 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_mfma(
   if (Lm > 1) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (vj) la_out[base[r] + (size_t)(Lm - 1) * K] = log(pacc[r]) + pc[r] + pll[r];
+      if (vj) la_out[base[r] + (size_t)(Lm - 1) * K] = fast_log(pacc[r]) + pc[r] + pll[r];
   }
   // ---- epilogue: LSE of the last step, per-window totals
   if (wave == 0 && li == 0) {
@@ -610,7 +666,7 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_mfma(
     sz[r] = logz[g];
   }
   const double NEG_INF = -INFINITY;
-  double c[4], eprev[4], lln[4], lan[4], ll2[4];
+  double c[4], eprev[4], lln[4], lan[4], ll2[4], la2[4];
   const size_t top = (size_t)(Lm - 1) * K;
   const size_t K1 = (size_t)K * (Lm > 1 ? 1 : 0), K2 = (size_t)K * (Lm > 2 ? 2 : (Lm > 1 ? 1 : 0));
   // ---- t = Lm-1: lbeta = 0
@@ -621,6 +677,7 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_mfma(
       const double x0 = ll[base[r] + top], a0 = la_in[base[r] + top];
       const double x1 = ll[base[r] + top - K1], x2 = ll[base[r] + top - K2];
       const double a1 = la_in[base[r] + top - K1];
+      la2[r] = la_in[base[r] + top - K2];
       if (WANT_LB && vj) lb_out[base[r] + top] = 0.0;
       u[r] = vj ? x0 : NEG_INF;
       tm[r] = row16_max(u[r]);
@@ -650,7 +707,7 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_mfma(
   int step = 1;
   for (int t = Lm - 2; t >= 0; --t, ++step) {
     const int cur = (step - 1) & 1, nxt = step & 1;
-    const size_t o1 = (size_t)(t >= 1 ? t - 1 : 0) * K, o2 = (size_t)(t >= 2 ? t - 2 : 0) * K;
+    const size_t o2 = (size_t)(t >= 2 ? t - 2 : 0) * K;
     double wp[4], we[4], cn[4], rq[4];
     // (a) independent of the MFMA result
 #pragma unroll
@@ -660,12 +717,13 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_mfma(
       lln[r] = ll2[r];
       const double x2 = ll[base[r] + o2];
       ll2[r] = vj ? x2 : NEG_INF;
-      lan[r] = la_in[base[r] + o1];
+      lan[r] = la2[r];
+      la2[r] = la_in[base[r] + o2];
       double tot = sh.tsum[cur][w][0][0], mll = sh.tmll[nxt][w][0][0], totq = sh.tq[cur][w][0][0];
 #pragma unroll
       for (int s2 = 1; s2 < NW; ++s2) {
         tot += sh.tsum[cur][w][s2][0];
-        mll = fmax(mll, sh.tmll[nxt][w][s2][0]);
+        mll = fmax_raw(mll, sh.tmll[nxt][w][s2][0]);
         totq += sh.tq[cur][w][s2][0];
       }
       rq[r] = 1.0 / totq;
@@ -673,8 +731,8 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_mfma(
       (void)frexp(tot, &e2);
       const double d = (double)e2 * LN2_D + mll;
       cn[r] = c[r] + d;
-      wp[r] = vj ? exp(llv - d) : 0.0;                          // P'_t = acc * wp
-      we[r] = vj ? exp(fmin(lav + c[r] - sz[r], 700.0)) : 0.0;  // e_t  = acc * we
+      wp[r] = vj ? fast_exp(llv - d) : 0.0;                          // P'_t = acc * wp
+      we[r] = vj ? fast_exp(fmin(lav + c[r] - sz[r], 700.0)) : 0.0;  // e_t  = acc * we
     }
     // (b) matrix pipe
     const double4_t acc = fb_matmul<NW>(sh, cur, li, lg, Bv);
@@ -698,7 +756,7 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_mfma(
     if (WANT_LB) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const double lbv = log(acc[r]) + c[r];
+        const double lbv = fast_log(acc[r]) + c[r];
         if (FULL || vj) lb_out[base[r] + (size_t)t * K] = lbv;
       }
     }
