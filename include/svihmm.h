@@ -80,7 +80,11 @@ int svihmm_set_globals(svihmm_ctx* h, int32_t K, const double* mod_init,
 /* NIW mean-field emission factors mu[K,D], sigma[K,D,D], kappa[K], nu[K]
  * (pybasicbayes Gaussian.{mu_mf,sigma_mf,kappa_mf,nu_mf}); replaces the K calls
  * odist.expected_log_likelihood(obs) at hmmbase.py:219-220,
- * hmmsgd_metaobs.py:508-509,685-686,815-816,1175-1176, hmm_fast.pyx:84-85. */
+ * hmmsgd_metaobs.py:508-509,685-686,815-816,1175-1176, hmm_fast.pyx:84-85.
+ * The Cholesky factorisation runs on the device and the call does not wait for it: a
+ * sigma that is not positive definite is reported by the next synchronising call
+ * (svihmm_sync, svihmm_loglik, svihmm_forward_backward, svihmm_estep_minibatch with an
+ * output buffer, svihmm_read_packed). */
 int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* mu,
                             const double* sigma, const double* kappa,
                             const double* nu);

@@ -1215,8 +1215,19 @@ __global__ void k_finalize(const double* __restrict__ part, int nchunk, int D, i
   if (idx >= (int64_t)Ftot * Kp) return;
   const int f = idx / Kp, k = idx - (int64_t)f * Kp;
   if (k >= K) return;
-  double s = 0.0;
-  for (int c = 0; c < nchunk; ++c) s += part[((size_t)c * Ftot + f) * Kp + k];
+  // fixed summation order (4 interleaved partial sums) -> bit-reproducible
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  const size_t stride = (size_t)Ftot * Kp;
+  const double* pp = part + (size_t)f * Kp + k;
+  int c = 0;
+  for (; c + 4 <= nchunk; c += 4) {
+    s0 += pp[(size_t)c * stride];
+    s1 += pp[(size_t)(c + 1) * stride];
+    s2 += pp[(size_t)(c + 2) * stride];
+    s3 += pp[(size_t)(c + 3) * stride];
+  }
+  for (; c < nchunk; ++c) s0 += pp[(size_t)c * stride];
+  const double s = (s0 + s1) + (s2 + s3);
   double* A = packed;
   double* xbar = A + (size_t)K * K;
   double* neff = xbar + (size_t)K * D;
@@ -1562,6 +1573,9 @@ struct svihmm_ctx {
   int eK = 0, eD = 0, Kp = 0, F = 0, Fp = 0;
   Buf theta, fab, niw;
   int tabD = -1;
+  void* pin = nullptr; size_t pin_cap = 0;   // pinned host staging for parameter uploads
+  int* pin_status = nullptr;                 // pinned: NIW factorisation status (lazy check)
+  bool status_pending = false;
   bool have_emission = false;
   // work
   Buf starts, ll, la, lb, q, lse_part, local_lb, logz, part, packed, scratch;
@@ -1649,15 +1663,19 @@ int svihmm_destroy(svihmm_ctx* h) {
                  &h->fab, &h->starts, &h->ll, &h->la, &h->lb, &h->q, &h->lse_part,
                  &h->local_lb, &h->logz, &h->part, &h->packed, &h->scratch};
   for (Buf* b : bufs) release(*b);
+  if (h->pin) hipHostFree(h->pin);
+  if (h->pin_status) hipHostFree(h->pin_status);
   hipStreamDestroy(h->stream);
   delete h;
   return 0;
 }
 
+static int check_emission_status(svihmm_ctx* h);
+static int pinned(svihmm_ctx* h, size_t bytes, void** out);
 int svihmm_sync(svihmm_ctx* h) {
   CK(set_device(h));
   HIPCK(hipStreamSynchronize(h->stream));
-  return 0;
+  return check_emission_status(h);
 }
 
 int svihmm_set_obs(svihmm_ctx* h, const double* obs, int64_t T, int32_t D,
@@ -1687,16 +1705,45 @@ int svihmm_set_globals(svihmm_ctx* h, int32_t K, const double* mod_init, const d
   CK(ensure(h->ltran, kk));
   CK(ensure(h->Aexp, kk));
   CK(ensure(h->AexpT, kk));
-  HIPCK(hipMemcpyAsync(h->mod_init.p, mod_init, K * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIPCK(hipMemcpyAsync(h->ltran.p, ltran, kk, hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));   // staging buffer free again
+  CK(check_emission_status(h));
+  void* pin = nullptr;
+  CK(pinned(h, kk + K * sizeof(double), &pin));
+  std::memcpy(pin, ltran, kk);
+  std::memcpy((char*)pin + kk, mod_init, K * sizeof(double));
+  HIPCK(hipMemcpyAsync(h->ltran.p, pin, kk, hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemcpyAsync(h->mod_init.p, (char*)pin + kk, K * sizeof(double), hipMemcpyHostToDevice, h->stream));
   {
     ProfScope ps(h, KS_MISC);
     hipLaunchKernelGGL(k_exp_transpose, dim3((K * K + 255) / 256), dim3(256), 0, h->stream,
                        (const double*)h->ltran.p, K, (double*)h->Aexp.p, (double*)h->AexpT.p);
   }
   HIPCK(hipGetLastError());
-  HIPCK(hipStreamSynchronize(h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));   // both setters share the staging buffer
   h->K = K; h->have_globals = true;
+  return 0;
+}
+
+static int pinned(svihmm_ctx* h, size_t bytes, void** out) {
+  if (bytes > h->pin_cap) {
+    if (h->pin) hipHostFree(h->pin);
+    h->pin = nullptr; h->pin_cap = 0;
+    HIPCK(hipHostMalloc(&h->pin, bytes + 4096, hipHostMallocDefault));
+    h->pin_cap = bytes + 4096;
+  }
+  *out = h->pin;
+  return 0;
+}
+// call after a stream synchronisation: reports a failed NIW factorisation of the last
+// svihmm_set_emission_niw (which itself returns without waiting for the device)
+static int check_emission_status(svihmm_ctx* h) {
+  if (!h->status_pending) return 0;
+  h->status_pending = false;
+  const int st = h->pin_status ? *h->pin_status : 0;
+  if (st != 0) {
+    h->have_emission = false;
+    return fail("svihmm_set_emission_niw: sigma_mf[" + std::to_string(st - 1) + "] is not positive definite");
+  }
   return 0;
 }
 
@@ -1736,10 +1783,19 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
   double* dka = dsg + nsg;
   double* dnu = dka + K;
   int* dstatus = (int*)(dnu + K);
-  HIPCK(hipMemcpyAsync(dmu, mu, nmu * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIPCK(hipMemcpyAsync(dsg, sigma, nsg * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIPCK(hipMemcpyAsync(dka, kappa, K * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIPCK(hipMemcpyAsync(dnu, nu, K * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  // one pinned staging buffer, one H2D copy; the previous upload must have left it
+  HIPCK(hipStreamSynchronize(h->stream));
+  CK(check_emission_status(h));
+  void* pin = nullptr;
+  CK(pinned(h, nin * sizeof(double), &pin));
+  double* hp = (double*)pin;
+  std::memcpy(hp, mu, nmu * sizeof(double));
+  std::memcpy(hp + nmu, sigma, nsg * sizeof(double));
+  std::memcpy(hp + nmu + nsg, kappa, K * sizeof(double));
+  std::memcpy(hp + nmu + nsg + K, nu, K * sizeof(double));
+  if (!h->pin_status) HIPCK(hipHostMalloc((void**)&h->pin_status, 64, hipHostMallocDefault));
+  *h->pin_status = 0;
+  HIPCK(hipMemcpyAsync(dmu, hp, nin * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCK(hipMemsetAsync(dstatus, 0, sizeof(int), h->stream));
   HIPCK(hipMemsetAsync(h->theta.p, 0, (size_t)Fp * Kp * sizeof(double), h->stream));
   {
@@ -1752,13 +1808,9 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
                        (double*)h->theta.p, dstatus);
     HIPCK(hipGetLastError());
   }
-  int status = 0;
-  HIPCK(hipMemcpyAsync(&status, dstatus, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIPCK(hipStreamSynchronize(h->stream));
-  if (status != 0) {
-    h->have_emission = false;
-    return fail("svihmm_set_emission_niw: sigma_mf[" + std::to_string(status - 1) + "] is not positive definite");
-  }
+  // status comes back asynchronously; it is examined at the next synchronising call
+  HIPCK(hipMemcpyAsync(h->pin_status, dstatus, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  h->status_pending = true;
   h->eK = K; h->eD = D; h->have_emission = true;
   return 0;
 }
@@ -1978,7 +2030,9 @@ static int launch_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t 
   const int64_t n = (int64_t)B * Lm;
   // row chunking: ~256 row chunks (x feature/state tiles => >= 1024 workgroups at D=32)
   // so that small minibatches still spread over the 256 CUs; chunk = multiple of ST_RB
-  int64_t rpc = (n + 255) / 256;
+  // (one resident workgroup per CU for the pipelined kernel: 128 chunks x 2 passes = 256)
+  const int target_chunks = (Kp <= 64 && n >= 128 * 1024) ? 128 : 256;
+  int64_t rpc = (n + target_chunks - 1) / target_chunks;
   rpc = (rpc + ST_RB - 1) / ST_RB * ST_RB;
   int64_t nchunk = (n + rpc - 1) / rpc;
   CK(ensure(h->part, (size_t)nchunk * Ftot * Kp * sizeof(double)));
@@ -2090,6 +2144,7 @@ int svihmm_loglik(svihmm_ctx* h, const int64_t* starts, int32_t B, int32_t Lm, u
   CK(prepare_ll(h, starts, B, Lm, flags & ~SVIHMM_USE_HOST_LLIKS, false));
   CK(d2h(h, out_lliks, h->ll.p, (size_t)B * Lm * h->K * sizeof(double)));
   HIPCK(hipStreamSynchronize(h->stream));
+  CK(check_emission_status(h));
   h->lastB = B; h->lastLm = Lm;
   return 0;
 }
@@ -2107,6 +2162,7 @@ int svihmm_forward_backward(svihmm_ctx* h, const int64_t* starts, int32_t B, int
   if (out_var_x) CK(d2h(h, out_var_x, h->q.p, n));
   if (out_local_lb) CK(d2h(h, out_local_lb, h->local_lb.p, (size_t)B * sizeof(double)));
   HIPCK(hipStreamSynchronize(h->stream));
+  CK(check_emission_status(h));
   h->lastB = B; h->lastLm = Lm;
   return 0;
 }
@@ -2143,6 +2199,7 @@ int svihmm_estep_minibatch_ex(svihmm_ctx* h, const int64_t* starts, int32_t B, i
   if (out_packed) {
     CK(d2h(h, out_packed, h->packed.p, (size_t)svihmm_packed_size(h->K, h->D) * sizeof(double)));
     HIPCK(hipStreamSynchronize(h->stream));
+    CK(check_emission_status(h));
   }
   return 0;
 }
@@ -2153,6 +2210,7 @@ int svihmm_read_packed(svihmm_ctx* h, double* out_packed) {
   CK(set_device(h));
   CK(d2h(h, out_packed, h->packed.p, (size_t)svihmm_packed_size(h->K, h->D) * sizeof(double)));
   HIPCK(hipStreamSynchronize(h->stream));
+  CK(check_emission_status(h));
   return 0;
 }
 
