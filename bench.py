@@ -117,7 +117,7 @@ def main():
 
     def step(st=starts):
         eng.set_globals(pb["mod_init"], pb["ltran"])
-        eng.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+        eng.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"], check=False)
         eng.estep(st, LM, flags=L.TRANS_WRAP, read=False)
         if use_comm:
             eng.allreduce_packed()

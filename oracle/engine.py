@@ -56,7 +56,7 @@ class OracleEngine(object):
         self.ltran = np.array(ltran, dtype=np.float64)
         self.K = self.ltran.shape[0]
 
-    def set_emission_niw(self, mu, sigma, kappa, nu):
+    def set_emission_niw(self, mu, sigma, kappa, nu, check=True):
         self.em = tuple(np.array(a, dtype=np.float64) for a in (mu, sigma, kappa, nu))
         for k in range(len(self.em[2])):
             np.linalg.cholesky(self.em[1][k])

@@ -90,7 +90,11 @@ class HipEngine(object):
                 "svihmm_set_globals")
         self.K = K
 
-    def set_emission_niw(self, mu, sigma, kappa, nu):
+    def set_emission_niw(self, mu, sigma, kappa, nu, check=True):
+        """Upload the K NIW mean-field factors; the quadratic-form parameters are built on
+        the device.  ``check=True`` waits for the factorisation so that a sigma that is
+        not positive definite raises here; ``check=False`` returns immediately (the error
+        then surfaces at the next synchronising call -- used in hot loops)."""
         mu = L.as_f64(mu)
         K, D = mu.shape
         sigma = L.as_f64(sigma, (K, D, D))
@@ -99,6 +103,8 @@ class HipEngine(object):
         L.check(self._lib.svihmm_set_emission_niw(self._h, K, D, L.dptr(mu), L.dptr(sigma),
                                                   L.dptr(kappa), L.dptr(nu)),
                 "svihmm_set_emission_niw")
+        if check:
+            L.check(self._lib.svihmm_sync(self._h), "svihmm_set_emission_niw")
 
     def set_lliks(self, lliks):
         lliks = L.as_f64(lliks)
