@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "../../include/svihmm.h"
+#include "svihmm_common.h"
 
 // ------------------------------------------------------------------------------------
 //  error handling
@@ -54,7 +55,6 @@ static int fail(const std::string& m) { g_err = m; return 1; }
     if (int r__ = (x)) return r__; \
   } while (0)
 
-typedef double double4_t __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------
 //  device helpers
@@ -75,7 +75,6 @@ __device__ __forceinline__ double nan_to_num(double v) {
   if (isinf(v)) return v > 0 ? 1.7976931348623157e308 : -1.7976931348623157e308;
   return v;
 }
-__device__ __forceinline__ int64_t imin64(int64_t a, int64_t b) { return a < b ? a : b; }
 // global row g=(b,t) of the flattened window batch -> obs row
 __device__ __forceinline__ int64_t obs_row(const int64_t* __restrict__ starts, int Lm,
                                            int64_t g) {
@@ -189,24 +188,44 @@ __global__ __launch_bounds__(256) void k_emission_mfma(
 
   const double* xr = xs + r0 * DS;
   const double* thl = theta + n0 + li;
+  // Fp is a multiple of 16 -> the k-step count is a multiple of 4: the loop is unrolled by
+  // hand so that the theta (B operand) loads of four k-steps are in flight together
   const int nks = Fp >> 2;
-#pragma unroll 2
-  for (int s = 0; s < nks; ++s) {
-    const int f = (s << 2) + lg;
-    const int ab = fabs_[f];
-    const int a = ab & 0xffff, b = ab >> 16;
-    const double* trow = thl + (size_t)f * Kp;
-    double Bv[NT], Av[MT];
+  for (int s = 0; s < nks; s += 4) {
+    double Bv[4][NT], Av[4][MT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) Bv[n] = trow[n * 16];
+    for (int u = 0; u < 4; ++u) {
+      const int f = ((s + u) << 2) + lg;
+      const double* trow = thl + (size_t)f * Kp;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) Av[m] = xr[m * 16 * DS + a] * xr[m * 16 * DS + b];
+      for (int n = 0; n < NT; ++n) Bv[u][n] = trow[n * 16];
+    }
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int u = 0; u < 4; ++u) {
+      const int f = ((s + u) << 2) + lg;
+      const int ab = fabs_[f];
+      const int a = ab & 0xffff, b = ab >> 16;
 #pragma unroll
-      for (int n = 0; n < NT; ++n)
-        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(Av[m], Bv[n], acc[m][n], 0, 0, 0);
+      for (int m = 0; m < MT; ++m) Av[u][m] = xr[m * 16 * DS + a] * xr[m * 16 * DS + b];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(Av[u][m], Bv[u][n], acc[m][n], 0, 0, 0);
   }
+  // epilogue on plain VGPR copies: keeps the loop-carried accumulators in AGPRs (otherwise
+  // hipcc shuttles all of them VGPR<->AGPR around every k-step)
+  double outv[MT][NT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) outv[m][n][r] = acc[m][n][r];
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -218,7 +237,7 @@ __global__ __launch_bounds__(256) void k_emission_mfma(
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           const int k = n0 + n * 16 + li;
-          if (k < K) ll[g * K + k] = bd ? 0.0 : nan_to_num(acc[m][n][r]);
+          if (k < K) ll[g * K + k] = bd ? 0.0 : nan_to_num(outv[m][n][r]);
         }
       }
     }
@@ -909,297 +928,6 @@ __global__ __launch_bounds__(64) void k_stats_outer(
 #pragma unroll
     for (int i = 0; i < 16; ++i)
       part[((size_t)blockIdx.x * Ftot + f0 + i) * Kp + k] = acc[i];
-  }
-}
-
-// ------------------------------------------------------------------------------------
-//  K4b: statistics as an fp64 MFMA GEMM  out[Ftot x Kp] = Phi^T[Ftot x rows] * q[rows x Kp]
-//       Per workgroup: 4 waves, each MT m-tiles (16 features) x NT n-tiles (16 states);
-//       rows of the chunk staged through LDS in blocks of ST_RB.
-//       grid (nchunk, ceil(Ftot/16 / (4*MT)), Kp/(16*NT)), block 256.
-// ------------------------------------------------------------------------------------
-#define ST_RB 32
-template <int MT, int NT>
-__global__ __launch_bounds__(256) void k_stats_mfma(
-    const double* __restrict__ obs, const uint8_t* __restrict__ mask,
-    const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K, int Kp,
-    int Fp, int F, const int* __restrict__ fab, const double* __restrict__ q,
-    int64_t rows_per_chunk, uint32_t flags, int Lq, int off, double* __restrict__ part) {
-  extern __shared__ double smem[];
-  const int DS = (D + 2) | 1;
-  const int QS = 16 * NT + 1;  // padded q row stride
-  double* xs = smem;                  // [ST_RB][DS]   augmented, masked rows zeroed
-  double* qs = xs + ST_RB * DS;       // [ST_RB][QS]   q[t][n0..]
-  double* qp = qs + ST_RB * QS;       // [ST_RB][Kp+1] q[prev(t)][all states] (transition tiles)
-  const int QPS = Kp + 1;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, lg = lane >> 4;
-  const int Ftot = Fp + Kp;
-  const int mt0 = (blockIdx.y * 4 + wave) * MT;  // first m-tile of this wave
-  const int n0 = blockIdx.z * 16 * NT;
-  const int wg_m0 = blockIdx.y * 4 * MT * 16, wg_m1 = wg_m0 + 4 * MT * 16;
-  const bool need_x = wg_m0 < Fp;
-  const bool need_qp = wg_m1 > Fp;
-
-  // per-lane feature descriptors for each m-tile (constant for the whole kernel)
-  int fa[MT], fb[MT], ftype[MT];  // ftype 0: emission feature, 1: transition
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const int f = (mt0 + m) * 16 + li;
-    if (f < F) {
-      const int ab = fab[f];
-      fa[m] = ab & 0xffff; fb[m] = ab >> 16; ftype[m] = 0;
-    } else if (f >= Fp && f < Fp + K) {
-      fa[m] = f - Fp; fb[m] = 0; ftype[m] = 1;
-    } else if (f >= Fp) {
-      fa[m] = Kp; fb[m] = 0; ftype[m] = 1;   // qp[r][Kp] is a zero column
-    } else {
-      fa[m] = D + 1; fb[m] = D + 1; ftype[m] = 0;  // zero slot
-    }
-  }
-  double4_t acc[MT][NT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int n = 0; n < NT; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
-
-  const int64_t c0 = (int64_t)blockIdx.x * rows_per_chunk;
-  const int64_t c1 = imin64(nrows, c0 + rows_per_chunk);
-  for (int64_t s0 = c0; s0 < c1; s0 += ST_RB) {
-    __syncthreads();
-    // ---- stage ST_RB rows
-    if (need_x) {
-      for (int e = tid; e < ST_RB * (D + 2); e += 256) {
-        const int r = e / (D + 2), i = e - r * (D + 2);
-        const int64_t g = s0 + r;
-        double v = 0.0;
-        if (g < c1) {
-          const int64_t bw = g / Lm;
-          const int64_t orow = starts[bw] + off + (g - bw * Lm);
-          const bool msk = mask && mask[orow];
-          if (!msk) v = (i < D) ? obs[orow * D + i] : (i == D ? 1.0 : 0.0);
-        }
-        xs[r * DS + i] = v;
-      }
-    }
-    for (int e = tid; e < ST_RB * 16 * NT; e += 256) {
-      const int r = e / (16 * NT), c = e - r * (16 * NT);
-      const int64_t g = s0 + r;
-      const int k = n0 + c;
-      double v = 0.0;
-      if (g < c1 && k < K) {
-        const int64_t bw = g / Lm;
-        v = q[(bw * Lq + off + (g - bw * Lm)) * K + k];
-      }
-      qs[r * QS + c] = v;
-    }
-    if (need_qp) {
-      for (int e = tid; e < ST_RB * (Kp + 1); e += 256) {
-        const int r = e / (Kp + 1), c = e - r * (Kp + 1);
-        const int64_t g = s0 + r;
-        double v = 0.0;
-        if (g < c1 && c < K) {
-          const int64_t bwin = g / Lm;
-          const int64_t t = g - bwin * Lm;
-          const int64_t qrow = bwin * Lq + off + t;
-          if (t > 0) v = q[(qrow - 1) * K + c];
-          else if (flags & SVIHMM_TRANS_WRAP) v = q[(qrow + Lm - 1) * K + c];
-        }
-        qp[r * QPS + c] = v;
-      }
-    }
-    __syncthreads();
-    // ---- ST_RB/4 k-steps of 4 rows
-#pragma unroll 2
-    for (int ks = 0; ks < ST_RB / 4; ++ks) {
-      const int r = ks * 4 + lg;
-      double Bv[NT];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) Bv[n] = qs[r * QS + n * 16 + li];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        double A;
-        if ((mt0 + m) * 16 < Fp) A = xs[r * DS + fa[m]] * xs[r * DS + fb[m]];  // wave-uniform
-        else A = qp[r * QPS + fa[m]];
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(A, Bv[n], acc[m][n], 0, 0, 0);
-      }
-    }
-  }
-  // ---- write partials: C[row=(l>>4)+4r -> feature][col=l&15 -> state]
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int f = (mt0 + m) * 16 + lg + 4 * r;
-      if (f < Ftot) {
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const int k = n0 + n * 16 + li;
-          part[((size_t)blockIdx.x * Ftot + f) * Kp + k] = acc[m][n][r];
-        }
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------
-//  K4c: statistics GEMM, software-pipelined (K <= 64).  Same math as K4b; differences:
-//   * the next 32-row stage is fetched from HBM into registers while the current stage
-//     runs on the matrix pipe (global -> reg early, reg -> LDS after the compute);
-//   * row bookkeeping (obs row, q row, wrap predecessor, mask) is computed once per stage
-//     by 32 lanes instead of per element (no integer divisions in the copy loops);
-//   * MT = 5 m-tiles per wave: the 36 emission + 4 transition tiles of K=64, D=32 split
-//     into two balanced workgroup passes, so q is read twice instead of four times.
-//  grid (nchunk, ceil(Ftot/16 / (4*MT))), block 256.
-// ------------------------------------------------------------------------------------
-struct StRow {
-  long long orow;   // obs row, -1: out of range or masked (x~ = 0)
-  long long qrow;   // q row, -1: out of range
-  long long prow;   // predecessor q row, -1: none
-};
-
-template <int MT, int NT, int XK>
-__global__ __launch_bounds__(256) void k_stats_mfma2(
-    const double* __restrict__ obs, const uint8_t* __restrict__ mask,
-    const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K, int Fp, int F,
-    const int* __restrict__ fab, const double* __restrict__ q, int64_t rows_per_chunk,
-    uint32_t flags, int Lq, int off, double* __restrict__ part) {
-  constexpr int Kp = 16 * NT;
-  constexpr int QS = Kp + 1;
-  extern __shared__ double smem[];
-  const int DS = (D + 2) | 1;
-  double* xs = smem;               // [32][DS]
-  double* qs = xs + ST_RB * DS;    // [32][QS]
-  double* qp = qs + ST_RB * QS;    // [32][QS]  (column Kp is a zero column)
-  StRow* rinfo = reinterpret_cast<StRow*>(qp + ST_RB * QS);  // [2][32]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, lg = lane >> 4;
-  const int Ftot = Fp + Kp;
-  const int mt0 = (blockIdx.y * 4 + wave) * MT;
-  const int wg_m0 = blockIdx.y * 4 * MT * 16, wg_m1 = wg_m0 + 4 * MT * 16;
-  const bool need_x = wg_m0 < Fp;
-  const bool need_qp = wg_m1 > Fp;
-  const int sr = tid >> 3, sc = tid & 7;   // staging role: row sr, columns sc + 8k
-
-  int fa[MT], fb[MT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const int f = (mt0 + m) * 16 + li;
-    if (f < F) { const int ab = fab[f]; fa[m] = ab & 0xffff; fb[m] = ab >> 16; }
-    else if (f >= Fp) { fa[m] = (f - Fp < K) ? f - Fp : Kp; fb[m] = 0; }
-    else { fa[m] = D + 1; fb[m] = D + 1; }
-  }
-  double4_t acc[MT][NT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int n = 0; n < NT; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
-
-  const int64_t c0 = (int64_t)blockIdx.x * rows_per_chunk;
-  const int64_t c1 = imin64(nrows, c0 + rows_per_chunk);
-  const int nstage = (int)((c1 - c0 + ST_RB - 1) / ST_RB);
-
-  auto row_info = [&](int64_t s0, int buf) {
-    if (tid < ST_RB) {
-      const int64_t g = s0 + tid;
-      StRow ri; ri.orow = -1; ri.qrow = -1; ri.prow = -1;
-      if (g < c1) {
-        const int64_t bw = g / Lm;
-        const int64_t t = g - bw * Lm;
-        ri.qrow = bw * Lq + off + t;
-        const int64_t orow = starts[bw] + off + t;
-        ri.orow = (mask && mask[orow]) ? -1 : orow;
-        if (t > 0) ri.prow = ri.qrow - 1;
-        else if (flags & SVIHMM_TRANS_WRAP) ri.prow = ri.qrow + Lm - 1;
-      }
-      rinfo[buf * ST_RB + tid] = ri;
-    }
-  };
-  double rx[XK], rq[2 * NT], rp[2 * NT];
-  auto fetch = [&](int buf) {
-    const StRow ri = rinfo[buf * ST_RB + sr];
-    if (need_x) {
-#pragma unroll
-      for (int k = 0; k < XK; ++k) {
-        const int c = sc + 8 * k;
-        double v = 0.0;
-        if (ri.orow >= 0) {
-          if (c < D) v = obs[ri.orow * D + c];
-          else if (c == D) v = 1.0;
-        }
-        rx[k] = v;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 2 * NT; ++k) {
-      const int c = sc + 8 * k;
-      rq[k] = (ri.qrow >= 0 && c < K) ? q[ri.qrow * K + c] : 0.0;
-    }
-    if (need_qp) {
-#pragma unroll
-      for (int k = 0; k < 2 * NT; ++k) {
-        const int c = sc + 8 * k;
-        rp[k] = (ri.prow >= 0 && c < K) ? q[ri.prow * K + c] : 0.0;
-      }
-    }
-  };
-  auto commit = [&]() {
-    if (need_x) {
-#pragma unroll
-      for (int k = 0; k < XK; ++k) {
-        const int c = sc + 8 * k;
-        if (c < D + 2) xs[sr * DS + c] = rx[k];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 2 * NT; ++k) qs[sr * QS + sc + 8 * k] = rq[k];
-    if (need_qp) {
-#pragma unroll
-      for (int k = 0; k < 2 * NT; ++k) qp[sr * QS + sc + 8 * k] = rp[k];
-      if (sc == 0) qp[sr * QS + Kp] = 0.0;
-    }
-  };
-
-  row_info(c0, 0);
-  __syncthreads();
-  fetch(0);
-  for (int st = 0; st < nstage; ++st) {
-    const int64_t s0 = c0 + (int64_t)st * ST_RB;
-    __syncthreads();            // previous compute finished reading LDS
-    commit();
-    row_info(s0 + ST_RB, (st + 1) & 1);
-    __syncthreads();
-    if (st + 1 < nstage) fetch((st + 1) & 1);   // in flight during the MFMAs below
-#pragma unroll 2
-    for (int ks = 0; ks < ST_RB / 4; ++ks) {
-      const int r = ks * 4 + lg;
-      double Bv[NT];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) Bv[n] = qs[r * QS + n * 16 + li];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        double A;
-        if ((mt0 + m) * 16 < Fp) A = xs[r * DS + fa[m]] * xs[r * DS + fb[m]];  // wave-uniform
-        else A = qp[r * QS + fa[m]];
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(A, Bv[n], acc[m][n], 0, 0, 0);
-      }
-    }
-  }
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int f = (mt0 + m) * 16 + lg + 4 * r;
-      if (f < Ftot) {
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          part[((size_t)blockIdx.x * Ftot + f) * Kp + n * 16 + li] = acc[m][n][r];
-      }
-    }
   }
 }
 
@@ -2043,53 +1771,17 @@ static int launch_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t 
   {
     ProfScope ps(h, KS_STATS);
     if (var == 3 && (Kp > 64 || D + 2 > 72)) var = 2;
-    if (var == 3) {
-      const int NT = Kp / 16;
-      const int MT = 5;
-      const int DS = (D + 2) | 1;
-      const size_t lds = ((size_t)ST_RB * DS + 2 * (size_t)ST_RB * (Kp + 1)) * 8 + 2 * ST_RB * sizeof(StRow);
-      const int mtiles = Ftot / 16;
-      dim3 grid((unsigned)nchunk, (mtiles + 4 * MT - 1) / (4 * MT));
-      const int xk = (D + 2 + 7) / 8;   // <= 9
-#define ST2(NTV, XKV)                                                                              \
-  do {                                                                                             \
-    if (lds > 64 * 1024)                                                                           \
-      hipFuncSetAttribute((const void*)k_stats_mfma2<5, NTV, XKV>,                                 \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
-    hipLaunchKernelGGL((k_stats_mfma2<5, NTV, XKV>), grid, dim3(256), lds, h->stream,              \
-                       (const double*)h->obs.p, mk, (const int64_t*)h->starts.p, n, Lm, D, K, Fp,  \
-                       F, (const int*)h->fab.p, (const double*)h->q.p, rpc, flags, Lq, off,        \
-                       (double*)h->part.p);                                                        \
-  } while (0)
-#define ST2X(NTV) do { if (xk <= 2) ST2(NTV, 2); else if (xk <= 5) ST2(NTV, 5); else ST2(NTV, 9); } while (0)
-      if (NT == 1) ST2X(1); else if (NT == 2) ST2X(2); else if (NT == 3) ST2X(3); else ST2X(4);
-#undef ST2X
-#undef ST2
-      (void)MT;
-    }
-    if (var == 2) {
-      const int ntile = Kp / 16;
-      const int NT = (ntile % 4 == 0) ? 4 : (ntile % 2 == 0) ? 2 : 1;
-      const int MT = 3;
-      const int DS = (D + 2) | 1;
-      const size_t lds = ((size_t)ST_RB * DS + (size_t)ST_RB * (16 * NT + 1) + (size_t)ST_RB * (Kp + 1)) * 8;
-      if (lds > 160 * 1024) var = 1;
-      else {
-        const int mtiles = Ftot / 16;
-        dim3 grid((unsigned)nchunk, (mtiles + 4 * MT - 1) / (4 * MT), ntile / NT);
-#define ST_LAUNCH(NTV)                                                                        \
-  do {                                                                                        \
-    if (lds > 64 * 1024)                                                                      \
-      hipFuncSetAttribute((const void*)k_stats_mfma<3, NTV>,                                  \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
-    hipLaunchKernelGGL((k_stats_mfma<3, NTV>), grid, dim3(256), lds, h->stream,               \
-                       (const double*)h->obs.p, mk, (const int64_t*)h->starts.p, n, Lm, D, K, \
-                       Kp, Fp, F, (const int*)h->fab.p, (const double*)h->q.p, rpc, flags,    \
-                       Lq, off, (double*)h->part.p);                                          \
-  } while (0)
-        if (NT == 4) ST_LAUNCH(4); else if (NT == 2) ST_LAUNCH(2); else ST_LAUNCH(1);
-#undef ST_LAUNCH
-      }
+    if (var == 3 || var == 2) {
+      // the MFMA statistics kernels live in svihmm_stats.hip (own translation unit: they
+      // are register-heavy and must be compiled WITHOUT -amdgpu-mfma-vgpr-form)
+      StatsLaunch a;
+      a.stream = h->stream; a.obs = (const double*)h->obs.p; a.mask = mk;
+      a.starts = (const int64_t*)h->starts.p; a.n = n; a.Lm = Lm; a.D = D; a.K = K; a.Kp = Kp;
+      a.Fp = Fp; a.F = F; a.fab = (const int*)h->fab.p; a.q = (const double*)h->q.p; a.rpc = rpc;
+      a.flags = flags; a.Lq = Lq; a.off = off; a.part = (double*)h->part.p; a.nchunk = (int)nchunk;
+      const int rc = svihmm_launch_stats_mfma(&a, var == 3 ? 1 : 0);
+      if (rc == 2) var = 1;                       // does not fit in LDS: VALU fallback
+      else if (rc != 0) return fail("statistics kernel launch failed");
     }
     if (var == 1) {
       dim3 grid((unsigned)nchunk, Ftot / 16, (Kp + 63) / 64);
