@@ -26,6 +26,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -1103,9 +1104,9 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma3(
   //   QP0 + i     q[prev(t), i], i < Kp  (transition features: row[QP0+i] * row[ONE])
   const int ZERO = D + 1, ONE = D + 2, QP0 = D + 3;
   const int RS = (QP0 + Kp) | 1;   // odd stride
-  double* rb = smem;                // [32][RS]
-  double* qs = rb + ST_RB * RS;     // [32][QS]
-  StRow* rinfo = reinterpret_cast<StRow*>(qs + ST_RB * QS);  // [2][32]
+  double* rb0 = smem;                    // [2][32][RS]
+  double* qs0 = rb0 + 2 * ST_RB * RS;    // [2][32][QS]
+  StRow* rinfo = reinterpret_cast<StRow*>(qs0 + 2 * ST_RB * QS);  // [4][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int mg = wave & 3, ng = wave >> 2;
@@ -1179,7 +1180,9 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma3(
       }
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](int bufi) {
+    double* rb = rb0 + bufi * ST_RB * RS;
+    double* qs = qs0 + bufi * ST_RB * QS;
     if (need_x) {
 #pragma unroll
       for (int k = 0; k < XK; ++k) {
@@ -1200,33 +1203,75 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma3(
       }
     }
   };
-  if (sc == 0) { rb[sr * RS + ZERO] = 0.0; rb[sr * RS + ONE] = 1.0; }
-
+  if (sc == 0) {
+    rb0[sr * RS + ZERO] = 0.0; rb0[sr * RS + ONE] = 1.0;
+    rb0[(ST_RB + sr) * RS + ZERO] = 0.0; rb0[(ST_RB + sr) * RS + ONE] = 1.0;
+  }
+  // Pipeline: LDS tiles are double buffered and there is ONE barrier per 32-row stage.
+  // During stage st every wave also writes stage st+1 (held in registers) into the other
+  // buffer and fetches stage st+2 from HBM; the two waves that share a SIMD do this at
+  // opposite ends of the stage (role B first, role A last), so one of them always feeds
+  // the matrix pipe.  Row bookkeeping runs three stages ahead.
+  const bool roleB = (NSPLIT == 2) && (ng == 1);
   row_info(c0, 0);
+  row_info(c0 + ST_RB, 1);
+  row_info(c0 + 2 * ST_RB, 2);
   __syncthreads();
   fetch(0);
+  commit(0);
+  if (nstage > 1) fetch(1);
+  __syncthreads();
   for (int st = 0; st < nstage; ++st) {
-    const int64_t s0 = c0 + (int64_t)st * ST_RB;
-    __syncthreads();            // previous compute finished reading LDS
-    commit();
-    row_info(s0 + ST_RB, (st + 1) & 1);
-    __syncthreads();
-    if (st + 1 < nstage) fetch((st + 1) & 1);   // in flight during the MFMAs below
-#pragma unroll 2
+    const int cur = st & 1;
+    if (roleB) {
+      if (st + 1 < nstage) commit(cur ^ 1);
+      if (st + 2 < nstage) fetch((st + 2) & 3);
+    }
+    const double* rb = rb0 + cur * ST_RB * RS;
+    const double* qs = qs0 + cur * ST_RB * QS;
+    // k-steps, software pipelined by hand: the LDS reads of k-step ks+1 are issued before
+    // the MFMAs of k-step ks, so their latency is covered by this wave's own matrix work
+    double Bv[NTW], Ax[MT], Ay[MT];
+    {
+      const double* row = rb + lg * RS;
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) Bv[n] = qs[lg * QS + (nt0 + n) * 16 + li];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) { Ax[m] = row[fa[m]]; Ay[m] = row[fb[m]]; }
+    }
+#pragma unroll
     for (int ks = 0; ks < ST_RB / 4; ++ks) {
-      const int r = ks * 4 + lg;
-      const double* row = rb + r * RS;
-      double Bv[NTW], Av[MT];
+      double Bn[NTW], Axn[MT], Ayn[MT];
+      if (ks + 1 < ST_RB / 4) {
+        const int r = (ks + 1) * 4 + lg;
+        const double* row = rb + r * RS;
 #pragma unroll
-      for (int n = 0; n < NTW; ++n) Bv[n] = qs[r * QS + (nt0 + n) * 16 + li];
+        for (int n = 0; n < NTW; ++n) Bn[n] = qs[r * QS + (nt0 + n) * 16 + li];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) Av[m] = row[fa[m]] * row[fb[m]];
+        for (int m = 0; m < MT; ++m) { Axn[m] = row[fa[m]]; Ayn[m] = row[fb[m]]; }
+      }
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+      for (int m = 0; m < MT; ++m) {
+        const double A = Ax[m] * Ay[m];
 #pragma unroll
         for (int n = 0; n < NTW; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(Av[m], Bv[n], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(A, Bv[n], acc[m][n], 0, 0, 0);
+      }
+      if (ks + 1 < ST_RB / 4) {
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) Bv[n] = Bn[n];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { Ax[m] = Axn[m]; Ay[m] = Ayn[m]; }
+      }
+      // role A stages in the middle of its compute phase (role B did it before), so that
+      // at the end of the stage both waves of a SIMD are still feeding the matrix pipe
+      if (ks == ST_RB / 8 - 1 && !roleB) {
+        if (st + 1 < nstage) commit(cur ^ 1);
+        if (st + 2 < nstage) fetch((st + 2) & 3);
+      }
     }
+    row_info(c0 + (int64_t)(st + 3) * ST_RB, (st + 3) & 3);
+    __syncthreads();
   }
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
@@ -2088,7 +2133,7 @@ static int launch_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t 
       const int TPR = 8 * NSPLIT;
       const int DS = (D + 2) | 1;
       const int RS = (D + 3 + Kp) | 1;
-      const size_t lds = ((size_t)ST_RB * RS + (size_t)ST_RB * (Kp + 1)) * 8 + 2 * ST_RB * sizeof(StRow);
+      const size_t lds = 2 * ((size_t)ST_RB * RS + (size_t)ST_RB * (Kp + 1)) * 8 + 4 * ST_RB * sizeof(StRow);
       const int mtiles = Ftot / 16;
       const int xk = (D + 1 + TPR - 1) / TPR;
       (void)DS;
