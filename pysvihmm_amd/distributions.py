@@ -28,7 +28,7 @@ import scipy.linalg as sla
 from scipy.special import digamma, gammaln
 
 __all__ = ["Gaussian", "Categorical", "sample_niw", "sample_invwishart",
-           "niw_quadratic_form"]
+           "niw_quadratic_form", "niw_vlb_batch"]
 
 
 # --------------------------------------------------------------------------- #
@@ -203,6 +203,40 @@ class Gaussian(object):
                      - 0.5 * self.nu_mf
                      * np.linalg.solve(self.sigma_mf, self.sigma_0).trace())
         return p_avgengy + q_entropy
+
+
+def niw_vlb_batch(mu_mf, sigma_mf, kappa_mf, nu_mf, mu_0, sigma_0, kappa_0, nu_0):
+    """``Gaussian.get_vlb()`` for K NIW factors at once (stacked arrays [K,D], [K,D,D], [K]):
+    same formulas (Bishop 10.74, 10.77), one batched Cholesky / solve instead of 4K small
+    ones -- the ELBO bookkeeping of the SVI loop is otherwise slower than the device E-step."""
+    mu_mf = np.asarray(mu_mf, float); sigma_mf = np.asarray(sigma_mf, float)
+    K, D = mu_mf.shape
+    kappa_mf = np.asarray(kappa_mf, float); nu_mf = np.asarray(nu_mf, float)
+    kappa_0 = np.asarray(kappa_0, float); nu_0 = np.asarray(nu_0, float)
+    ar = np.arange(D)
+
+    def llt(chol, nu):
+        return (digamma((nu[:, None] - ar) / 2.).sum(1) + D * np.log(2.)
+                - 2. * np.log(np.diagonal(chol, axis1=1, axis2=2)).sum(1))
+
+    def logpart(chol, nu):
+        return -1. * (nu * np.log(np.diagonal(chol, axis1=1, axis2=2)).sum(1)
+                      - (nu * D / 2. * np.log(2.) + D * (D - 1) / 4. * np.log(np.pi)
+                         + gammaln((nu[:, None] - ar) / 2.).sum(1)))
+
+    chol_mf = np.linalg.cholesky(sigma_mf)
+    chol_0 = np.linalg.cholesky(np.asarray(sigma_0, float))
+    l_mf = llt(chol_mf, nu_mf)
+    dmu = mu_mf - np.asarray(mu_0, float)
+    sol_dmu = np.linalg.solve(sigma_mf, dmu[:, :, None])[:, :, 0]
+    sol_s0 = np.linalg.solve(sigma_mf, np.asarray(sigma_0, float))
+    iw_entropy = logpart(chol_mf, nu_mf) - (nu_mf - D - 1) / 2. * l_mf + nu_mf * D / 2.
+    q_entropy = -0.5 * (l_mf + D * (np.log(kappa_mf / (2 * np.pi)) - 1)) + iw_entropy
+    p_avgengy = (0.5 * (D * np.log(kappa_0 / (2 * np.pi)) + l_mf - D * kappa_0 / kappa_mf
+                        - kappa_0 * nu_mf * np.einsum('kd,kd->k', dmu, sol_dmu))
+                 + logpart(chol_0, nu_0) + (nu_0 - D - 1) / 2. * l_mf
+                 - 0.5 * nu_mf * np.trace(sol_s0, axis1=1, axis2=2))
+    return p_avgengy + q_entropy
 
 
 def _invwishart_log_partitionfunction(sigma, nu):

@@ -157,6 +157,21 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
     def _niw_fastpath(self):
         return all(is_niw_gaussian(e) for e in self.var_emit)
 
+    def _emit_vlb(self):
+        """sum_k var_emit[k].get_vlb() (reference hmmbase.py:183-185), batched for NIW
+        Gaussians."""
+        ve = self.var_emit
+        if self._niw_fastpath() and all(type(e).get_vlb is Gaussian.get_vlb for e in ve):
+            from .distributions import niw_vlb_batch
+            mu, sg, ka, nu = self._emission_arrays()
+            return float(np.sum(niw_vlb_batch(
+                mu, sg, ka, nu, np.array([g.mu_0 for g in ve]), np.array([g.sigma_0 for g in ve]),
+                np.array([float(g.kappa_0) for g in ve]), np.array([float(g.nu_0) for g in ve]))))
+        tot = 0.
+        for k in range(self.K):
+            tot += ve[k].get_vlb()
+        return tot
+
     def _push_globals(self):
         self.engine.set_globals(self.mod_init, self.mod_tran)
 
@@ -213,9 +228,7 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
         A_energy = np.sum(A_energy)
         A_entropy = np.sum(A_entropy)
 
-        emit_vlb = 0.
-        for k in range(self.K):
-            emit_vlb += self.var_emit[k].get_vlb()
+        emit_vlb = self._emit_vlb()
 
         # "log Z" = sum over ALL t of LSE_k lalpha[t,k] (quirk Q4, hmmbase.py:194);
         # reduced on the device with the posterior kernel when available

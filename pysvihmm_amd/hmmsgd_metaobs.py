@@ -39,6 +39,16 @@ metaobs_half0 = 1
 mb_sz0 = 1
 
 
+class _StackedStats(list):
+    """``emit_inter`` of a fused minibatch E-step: behaves like the reference's list of K
+    ``[xbar, neff, S, neff]`` items and also carries the stacked arrays."""
+
+    def __init__(self, xbar, neff, S):
+        super(_StackedStats, self).__init__(
+            util._obj(xbar[k], float(neff[k]), S[k], float(neff[k])) for k in range(len(neff)))
+        self.xbar, self.neff, self.S = xbar, neff, S
+
+
 class MetaObs(object):
     """Inclusive index bounds of a meta-observation (reference :42-45)."""
 
@@ -173,10 +183,7 @@ class VBHMM(VariationalHMMBase):
                     + np.sum((p_A - 1) * (q_Adg - dg_q_Asum[:, npa]), axis=1))
         A_entropy = -(gammaln(q_Asum + eps) - np.sum(gammaln(q_A + eps), axis=1)
                       + np.sum((q_A - 1) * (q_Adg - dg_q_Asum[:, npa]), axis=1))
-        emit_vlb = 0.
-        for k in range(self.K):
-            emit_vlb += self.var_emit[k].get_vlb()
-        return np.sum(A_energy) + np.sum(A_entropy) + emit_vlb
+        return np.sum(A_energy) + np.sum(A_entropy) + self._emit_vlb()
 
     # -- the SVI loop -----------------------------------------------------------------------
     def _stationary_init(self):
@@ -319,8 +326,7 @@ class VBHMM(VariationalHMMBase):
             st = comm.allreduce_stats(self.engine, K, D)
         # quirk Q2: prior_tran - 1 is part of every window's A_i
         A_inter = st.A_raw + nwin * (self.prior_tran - 1.)
-        emit_inter = [util._obj(st.xbar[k].copy(), float(st.neff[k]), st.S[k].copy(),
-                                float(st.neff[k])) for k in range(K)]
+        emit_inter = _StackedStats(st.xbar.copy(), st.neff.copy(), st.S.copy())
         lb = float(st.lb[0])
         # leave the object as the reference does after the loop: state of the last window
         self.cur_mo = minibatch[-1]
@@ -551,7 +557,9 @@ class VBHMM(VariationalHMMBase):
         self.var_tran = nats_new + 1.
 
         bfact = (T - 2 * L_ - 1) / ((2. * L_ + 1.) * S)
-        if is_niw_gaussian(self.var_emit[0]):
+        if self._niw_fastpath() and isinstance(emit_inter, _StackedStats):
+            self._global_update_niw_stacked(lrate, bfact, emit_inter)
+        elif is_niw_gaussian(self.var_emit[0]):
             for k in range(self.K):
                 G = self.var_emit[k]
                 nats_old = util.NIW_mf_natural_pars(G.mu_mf, G.sigma_mf, G.kappa_mf, G.nu_mf)
@@ -566,6 +574,33 @@ class VBHMM(VariationalHMMBase):
                 nats_new = (1. - lrate) * nats_old + lrate * bfact * emit_inter[k]
                 G._alpha_mf = nats_new + 1.
                 G.weights = G._alpha_mf / G._alpha_mf.sum()
+
+    def _global_update_niw_stacked(self, lrate, bfact, E):
+        """The K-loop of reference :1050-1069 + util.py:28-60 on stacked arrays: the same
+        element-wise arithmetic (so the same floating-point results), without 4K small
+        NumPy object-array operations per iteration."""
+        ve = self.var_emit
+        D = self.D
+        mu, sg, ka, nu = self._emission_arrays()
+        mu0 = np.array([g.mu_0 for g in ve]); sg0 = np.array([g.sigma_0 for g in ve])
+        ka0 = np.array([float(g.kappa_0) for g in ve]); nu0 = np.array([float(g.nu_0) for g in ve])
+
+        def nat(m, s_, k_, n_):          # util.NIW_mf_natural_pars
+            return (k_[:, None] * m, k_, s_ + np.einsum('ki,kj->kij', m, m) * k_[:, None, None],
+                    n_ + 2 + D)
+        o = nat(mu, sg, ka, nu)
+        p0 = nat(mu0, sg0, ka0, nu0)
+        e = (E.xbar, E.neff, E.S, E.neff)
+        new = [(1. - lrate) * o[i] + lrate * (p0[i] + bfact * e[i]) for i in range(4)]
+        m_new = new[0] / new[1][:, None]                       # util.NIW_mf_moment_pars
+        k_new = new[1]
+        s_new = new[2] - np.einsum('ki,kj->kij', m_new, m_new) * k_new[:, None, None]
+        n_new = new[3] - 2 - D
+        for k, G in enumerate(ve):
+            G.mu_mf = m_new[k]; G.sigma_mf = s_new[k]
+            G.kappa_mf = k_new[k]; G.nu_mf = n_new[k]
+            G.mu = G.mu_mf
+            G.sigma = G.sigma_mf / (G.nu_mf - D - 1)
 
     # -- predictive log-probabilities (reference :1086-1145) ----------------------------------------
     def pred_logprob(self, metaobs=None):

@@ -1,0 +1,24 @@
+"""End-to-end SVI (hmmsgd_metaobs.VBHMM.infer) at BASELINE configs[2] on one GPU:
+per-iteration wall time and where the host time goes."""
+import cProfile, os, pstats, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from pysvihmm_amd import hmmsgd_metaobs
+from pysvihmm_amd.distributions import Gaussian
+
+K, D, T = 64, 32, 1000000
+rng = np.random.default_rng(8675309)
+means = rng.normal(0, 5, size=(K, D))
+sts = np.empty(T, dtype=np.int64); t = 0; cur = 0
+while t < T:
+    d = rng.geometric(0.1); sts[t:t + d] = cur; t += d; cur = (cur + 1 + rng.integers(0, K - 1)) % K
+obs = means[sts] + rng.normal(size=(T, D))
+np.random.seed(0)
+prior = np.array([Gaussian(mu_0=obs[:20000].mean(0), sigma_0=0.75 * np.cov(obs[:20000].T), kappa_0=0.01, nu_0=D + 2) for _ in range(K)])
+for mb, L_ in ((64, 128), (3891, 128)):
+    hmm = hmmsgd_metaobs.VBHMM(obs, np.ones(K), np.ones((K, K)), prior, tau=1.0, kappa=0.7, metaobs_half=L_,
+                               mb_sz=mb, maxit=12, seed=1, metaobs_fun='unif')
+    pr = cProfile.Profile(); t0 = time.time(); pr.enable(); hmm.infer(); pr.disable(); dt = time.time() - t0
+    print("mb_sz=%d: %.1f ms/iteration wall (iter_time mean %.2f ms = E-step + global step), elbo[-1]=%.4g" % (
+        mb, dt / 12 * 1e3, hmm.iter_time[2:].mean() * 1e3, hmm.elbo_vec[-1]))
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
