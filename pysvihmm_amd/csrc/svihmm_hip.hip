@@ -944,7 +944,8 @@ __global__ __launch_bounds__(256) void k_stats_mfma(
     const double* __restrict__ obs, const uint8_t* __restrict__ mask,
     const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K, int Kp,
     int Fp, int F, const int* __restrict__ fab, const double* __restrict__ q,
-    int64_t rows_per_chunk, uint32_t flags, int Lq, int off, double* __restrict__ part) {
+    int64_t rows_per_chunk, uint32_t flags, int Lq, int off, double* __restrict__ part,
+    int mt_base) {
   extern __shared__ double smem[];
   const int DS = (D + 2) | 1;
   const int QS = 16 * NT + 1;  // padded q row stride
@@ -955,9 +956,9 @@ __global__ __launch_bounds__(256) void k_stats_mfma(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int Ftot = Fp + Kp;
-  const int mt0 = (blockIdx.y * 4 + wave) * MT;  // first m-tile of this wave
+  const int mt0 = mt_base + (blockIdx.y * 4 + wave) * MT;  // first m-tile of this wave
   const int n0 = blockIdx.z * 16 * NT;
-  const int wg_m0 = blockIdx.y * 4 * MT * 16, wg_m1 = wg_m0 + 4 * MT * 16;
+  const int wg_m0 = (mt_base + blockIdx.y * 4 * MT) * 16, wg_m1 = wg_m0 + 4 * MT * 16;
   const bool need_x = wg_m0 < Fp;
   const bool need_qp = wg_m1 > Fp;
 
@@ -1090,7 +1091,10 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma3(
     const double* __restrict__ obs, const uint8_t* __restrict__ mask,
     const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K, int Fp, int F,
     const int* __restrict__ fab, const double* __restrict__ q, int64_t rows_per_chunk,
-    uint32_t flags, int Lq, int off, double* __restrict__ part) {
+    uint32_t flags, int Lq, int off, double* __restrict__ part, int KpTot, int mt_limit) {
+  // KpTot: padded state count of the whole problem (partials stride); this workgroup covers
+  // states [blockIdx.z*Kp, +Kp); only m-tiles < mt_limit are produced (K > 64: the
+  // transition tiles are left to k_stats_mfma)
   constexpr int NT = NTW * NSPLIT;
   constexpr int Kp = 16 * NT;
   constexpr int QS = Kp + 1;
@@ -1110,12 +1114,13 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma3(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int mg = wave & 3, ng = wave >> 2;
-  const int Ftot = Fp + Kp;
+  const int Ftot = Fp + KpTot;
+  const int kbase = blockIdx.z * Kp;
   const int mt0 = (blockIdx.y * 4 + mg) * MT;
   const int nt0 = ng * NTW;
   const int wg_m0 = blockIdx.y * 4 * MT * 16, wg_m1 = wg_m0 + 4 * MT * 16;
   const bool need_x = wg_m0 < Fp;
-  const bool need_qp = wg_m1 > Fp;
+  const bool need_qp = wg_m1 > Fp && mt_limit * 16 > Fp;
   const int sr = tid / TPR, sc = tid % TPR;   // staging role: row sr, columns sc + TPR*k
 
   int fa[MT], fb[MT];
@@ -1124,7 +1129,7 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma3(
     const int f = (mt0 + m) * 16 + li;
     fa[m] = ZERO; fb[m] = ZERO;
     if (f < F) { const int ab = fab[f]; fa[m] = ab & 0xffff; fb[m] = ab >> 16; }
-    else if (f >= Fp && f - Fp < K) { fa[m] = QP0 + (f - Fp); fb[m] = ONE; }
+    else if (f >= Fp && f - Fp < K && mt_limit * 16 > Fp) { fa[m] = QP0 + (f - Fp); fb[m] = ONE; }
   }
   double4_t acc[MT][NTW];
 #pragma unroll
@@ -1170,7 +1175,7 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma3(
 #pragma unroll
     for (int k = 0; k < QK; ++k) {
       const int c = sc + TPR * k;
-      rq[k] = (ri.qrow >= 0 && c < K) ? q[ri.qrow * K + c] : 0.0;
+      rq[k] = (ri.qrow >= 0 && kbase + c < K) ? q[ri.qrow * K + kbase + c] : 0.0;
     }
     if (need_qp) {
 #pragma unroll
@@ -1278,10 +1283,10 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma3(
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int f = (mt0 + m) * 16 + lg + 4 * r;
-      if (f < Ftot) {
+      if (f < Ftot && (mt0 + m) < mt_limit) {
 #pragma unroll
         for (int n = 0; n < NTW; ++n)
-          part[((size_t)blockIdx.x * Ftot + f) * Kp + (nt0 + n) * 16 + li] = acc[m][n][r];
+          part[((size_t)blockIdx.x * Ftot + f) * KpTot + kbase + (nt0 + n) * 16 + li] = acc[m][n][r];
       }
     }
   }
@@ -2115,7 +2120,7 @@ static int launch_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t 
   // row chunking: ~256 row chunks (x feature/state tiles => >= 1024 workgroups at D=32)
   // so that small minibatches still spread over the 256 CUs; chunk = multiple of ST_RB
   // (one resident workgroup per CU for the pipelined kernel: 128 chunks x 2 passes = 256)
-  const int target_chunks = (Kp <= 64 && n >= 128 * 1024) ? 128 : 256;
+  const int target_chunks = (n >= 128 * 1024) ? 128 : 256;
   int64_t rpc = (n + target_chunks - 1) / target_chunks;
   rpc = (rpc + ST_RB - 1) / ST_RB * ST_RB;
   int64_t nchunk = (n + rpc - 1) / rpc;
@@ -2126,20 +2131,23 @@ static int launch_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t 
   if (var == 0) var = 3;
   {
     ProfScope ps(h, KS_STATS);
-    if (var == 3 && Kp > 64) var = 2;
     if (var == 3) {
-      const int NTt = Kp / 16;                       // 1..4
+      // pipelined VGPR-form GEMM.  K <= 64: all tiles (statistics + transition) in one launch.
+      // K > 64: state groups of 64 in grid.z for the emission-statistics tiles; the K x K
+      // transition tiles (which need q[t-1] of ALL states as operand rows) go to k_stats_mfma.
+      const bool big = Kp > 64;
+      const int NTt = big ? 4 : Kp / 16;                // n-tiles per workgroup
+      const int KpW = 16 * NTt;
       const int NSPLIT = (NTt == 4) ? 2 : 1;
       const int TPR = 8 * NSPLIT;
-      const int DS = (D + 2) | 1;
-      const int RS = (D + 3 + Kp) | 1;
-      const size_t lds = 2 * ((size_t)ST_RB * RS + (size_t)ST_RB * (Kp + 1)) * 8 + 4 * ST_RB * sizeof(StRow);
+      const int RS = (D + 3 + KpW) | 1;
+      const size_t lds = 2 * ((size_t)ST_RB * RS + (size_t)ST_RB * (KpW + 1)) * 8 + 4 * ST_RB * sizeof(StRow);
       const int mtiles = Ftot / 16;
+      const int mt_limit = big ? Fp / 16 : mtiles;
       const int xk = (D + 1 + TPR - 1) / TPR;
-      (void)DS;
-      if (lds > 150 * 1024 || xk > 9) var = 2;
+      if (lds > 150 * 1024 || xk > 9 || (big && Kp % 64 != 0)) var = 2;
       else {
-        dim3 grid((unsigned)nchunk, (mtiles + 4 * 5 - 1) / (4 * 5));
+        dim3 grid((unsigned)nchunk, (mt_limit + 4 * 5 - 1) / (4 * 5), big ? Kp / 64 : 1);
 #define ST3(NTW, NS, XKV)                                                                        \
   do {                                                                                           \
     if (lds > 64 * 1024)                                                                         \
@@ -2148,12 +2156,26 @@ static int launch_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t 
     hipLaunchKernelGGL((k_stats_mfma3<5, NTW, NS, XKV>), grid, dim3(256 * NS), lds, h->stream,   \
                        (const double*)h->obs.p, mk, (const int64_t*)h->starts.p, n, Lm, D, K, Fp, \
                        F, (const int*)h->fab.p, (const double*)h->q.p, rpc, flags, Lq, off,       \
-                       (double*)h->part.p);                                                       \
+                       (double*)h->part.p, Kp, mt_limit);                                         \
   } while (0)
 #define ST3X(NTW, NS) do { if (xk <= 1) ST3(NTW, NS, 1); else if (xk <= 3) ST3(NTW, NS, 3); else if (xk <= 5) ST3(NTW, NS, 5); else ST3(NTW, NS, 9); } while (0)
         if (NTt == 4) ST3X(2, 2); else if (NTt == 3) ST3X(3, 1); else if (NTt == 2) ST3X(2, 1); else ST3X(1, 1);
 #undef ST3X
 #undef ST3
+        if (big) {   // transition tiles [Fp/16, Ftot/16)
+          const int NT = 4, MT = 3;
+          const int DS = (D + 2) | 1;
+          const size_t lds2 = ((size_t)ST_RB * DS + (size_t)ST_RB * (16 * NT + 1) + (size_t)ST_RB * (Kp + 1)) * 8;
+          if (lds2 > 150 * 1024) return fail("statistics: K too large for the LDS-staged transition kernel");
+          if (lds2 > 64 * 1024)
+            hipFuncSetAttribute((const void*)k_stats_mfma<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+          const int ttiles = Kp / 16;
+          dim3 g2((unsigned)nchunk, (ttiles + 4 * MT - 1) / (4 * MT), Kp / 64);
+          hipLaunchKernelGGL((k_stats_mfma<3, 4>), g2, dim3(256), lds2, h->stream,
+                             (const double*)h->obs.p, mk, (const int64_t*)h->starts.p, n, Lm, D, K,
+                             Kp, Fp, F, (const int*)h->fab.p, (const double*)h->q.p, rpc, flags,
+                             Lq, off, (double*)h->part.p, Fp / 16);
+        }
       }
     }
     if (var == 2) {
@@ -2174,7 +2196,7 @@ static int launch_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t 
     hipLaunchKernelGGL((k_stats_mfma<3, NTV>), grid, dim3(256), lds, h->stream,               \
                        (const double*)h->obs.p, mk, (const int64_t*)h->starts.p, n, Lm, D, K, \
                        Kp, Fp, F, (const int*)h->fab.p, (const double*)h->q.p, rpc, flags,    \
-                       Lq, off, (double*)h->part.p);                                          \
+                       Lq, off, (double*)h->part.p, 0);                                       \
   } while (0)
         if (NT == 4) ST_LAUNCH(4); else if (NT == 2) ST_LAUNCH(2); else ST_LAUNCH(1);
 #undef ST_LAUNCH
