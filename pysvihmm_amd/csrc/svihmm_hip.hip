@@ -245,6 +245,92 @@ __global__ __launch_bounds__(256) void k_emission_mfma(
   }
 }
 
+// fp64 transcendentals for the fused sweeps.  On gfx950 fp64 MFMA and fp64 VALU share one
+// pipe (tools/peak_probe.py: their times add), so every fp64 VALU instruction in the time
+// loop costs matrix throughput; ocml's log() alone is ~90 of them.  These are plain
+// range-reduction + Horner versions, accurate to ~2 ulp (tests compare against the oracle).
+__device__ __forceinline__ double fmax_raw(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));  // no NaN canonicalisation pair
+  return r;
+}
+__device__ __forceinline__ double fast_exp(double x) {
+  x = fmax_raw(x, -800.0);                       // also maps -inf to exp -> 0
+  const double k = __builtin_rint(x * 1.4426950408889634074);
+  double r = fma(k, -6.93147180369123816490e-01, x);
+  r = fma(k, -1.90821492927058770002e-10, r);
+  double p = 1.0 / 479001600.0;                  // Taylor to r^12: |r| <= 0.3466 -> 1.7e-16
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)k);
+}
+__device__ __forceinline__ double fast_log(double x) {   // x >= 0, finite
+  int e;
+  double m = frexp(x, &e);                       // m in [0.5, 1)
+  const bool lo = m < 0.70710678118654752440;
+  m = lo ? m + m : m;
+  e = lo ? e - 1 : e;
+  const double f = m - 1.0;
+  const double s = f / (2.0 + f);
+  const double z = s * s;                        // z <= 0.0295
+  double p = 1.0 / 23.0;
+  p = fma(p, z, 1.0 / 21.0);
+  p = fma(p, z, 1.0 / 19.0);
+  p = fma(p, z, 1.0 / 17.0);
+  p = fma(p, z, 1.0 / 15.0);
+  p = fma(p, z, 1.0 / 13.0);
+  p = fma(p, z, 1.0 / 11.0);
+  p = fma(p, z, 1.0 / 9.0);
+  p = fma(p, z, 1.0 / 7.0);
+  p = fma(p, z, 1.0 / 5.0);
+  p = fma(p, z, 1.0 / 3.0);
+  // log(m) = 2s + 2s*z*p ; log(x) = e*ln2_hi + (log(m) + e*ln2_lo)
+  const double two_s = s + s;
+  const double ed = (double)e;
+  const double t = fma(two_s * z, p, fma(ed, 1.90821492927058770002e-10, two_s));
+  const double r = fma(ed, 6.93147180369123816490e-01, t);
+  return x > 0.0 ? r : -INFINITY;               // log(0) = -inf (an unreachable state)
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// all-lanes reductions over each row of 16 lanes (quad_perm xor1, xor2, row_half_mirror, row_mirror)
+__device__ __forceinline__ double row16_sum(double v) {
+  v += dpp_mov_f64<0xB1>(v);
+  v += dpp_mov_f64<0x4E>(v);
+  v += dpp_mov_f64<0x141>(v);
+  v += dpp_mov_f64<0x140>(v);
+  return v;
+}
+__device__ __forceinline__ double row16_max(double v) {
+  v = fmax_raw(v, dpp_mov_f64<0xB1>(v));
+  v = fmax_raw(v, dpp_mov_f64<0x4E>(v));
+  v = fmax_raw(v, dpp_mov_f64<0x141>(v));
+  v = fmax_raw(v, dpp_mov_f64<0x140>(v));
+  return v;
+}
+__device__ __forceinline__ double wave64_max_fast(double v) {
+  v = row16_max(v);
+  v = fmax_raw(v, __shfl_xor(v, 16, 64));
+  v = fmax_raw(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+
 // ------------------------------------------------------------------------------------
 //  K2a: forward / backward messages, one wavefront per (window, direction), K <= KMAX<=64.
 //       The transition column (fwd) / row (bwd) of exp(ltran) lives in registers,
@@ -277,8 +363,8 @@ __global__ __launch_bounds__(64) void k_fb_wave(
     for (int t = 1; t < Lm; ++t) {
       const double llt = llnext;
       if (valid && t + 1 < Lm) llnext = llb[(size_t)(t + 1) * K + j];
-      const double m = wave_max(la);
-      const double p = valid ? exp(la - m) : 0.0;
+      const double m = wave64_max_fast(la);
+      const double p = valid ? fast_exp(la - m) : 0.0;
       if (j < KMAX) p_s[cur][j] = p;
       __syncthreads();
       double s0 = 0.0, s1 = 0.0;
@@ -288,7 +374,7 @@ __global__ __launch_bounds__(64) void k_fb_wave(
         s1 = fma(p_s[cur][i + 1], a[i + 1], s1);
       }
       cur ^= 1;
-      la = valid ? log(s0 + s1) + m + llt : NEG_INF;
+      la = valid ? fast_log(s0 + s1) + m + llt : NEG_INF;
       if (valid) out[(size_t)t * K + j] = la;
     }
   } else {
@@ -299,8 +385,8 @@ __global__ __launch_bounds__(64) void k_fb_wave(
     for (int t = Lm - 2; t >= 0; --t) {
       const double u = valid ? lb + llnext : NEG_INF;
       if (valid && t >= 1) llnext = llb[(size_t)t * K + j];
-      const double m = wave_max(u);
-      const double p = valid ? exp(u - m) : 0.0;
+      const double m = wave64_max_fast(u);
+      const double p = valid ? fast_exp(u - m) : 0.0;
       if (j < KMAX) p_s[cur][j] = p;
       __syncthreads();
       double s0 = 0.0, s1 = 0.0;
@@ -310,7 +396,7 @@ __global__ __launch_bounds__(64) void k_fb_wave(
         s1 = fma(p_s[cur][i + 1], a[i + 1], s1);
       }
       cur ^= 1;
-      lb = log(s0 + s1) + m;
+      lb = fast_log(s0 + s1) + m;
       if (valid) out[(size_t)t * K + j] = lb;
     }
   }
@@ -402,84 +488,6 @@ __global__ void k_fb_generic(const double* __restrict__ ll, const double* __rest
 //  reduction on the critical path.  sum_t LSE_j lalpha (quirk Q4) is accumulated as a
 //  running (mantissa, exponent) product of the per-step sums.
 // ------------------------------------------------------------------------------------
-// fp64 transcendentals for the fused sweeps.  On gfx950 fp64 MFMA and fp64 VALU share one
-// pipe (tools/peak_probe.py: their times add), so every fp64 VALU instruction in the time
-// loop costs matrix throughput; ocml's log() alone is ~90 of them.  These are plain
-// range-reduction + Horner versions, accurate to ~2 ulp (tests compare against the oracle).
-__device__ __forceinline__ double fmax_raw(double a, double b) {
-  double r;
-  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));  // no NaN canonicalisation pair
-  return r;
-}
-__device__ __forceinline__ double fast_exp(double x) {
-  x = fmax_raw(x, -800.0);                       // also maps -inf to exp -> 0
-  const double k = __builtin_rint(x * 1.4426950408889634074);
-  double r = fma(k, -6.93147180369123816490e-01, x);
-  r = fma(k, -1.90821492927058770002e-10, r);
-  double p = 1.0 / 479001600.0;                  // Taylor to r^12: |r| <= 0.3466 -> 1.7e-16
-  p = fma(p, r, 1.0 / 39916800.0);
-  p = fma(p, r, 1.0 / 3628800.0);
-  p = fma(p, r, 1.0 / 362880.0);
-  p = fma(p, r, 1.0 / 40320.0);
-  p = fma(p, r, 1.0 / 5040.0);
-  p = fma(p, r, 1.0 / 720.0);
-  p = fma(p, r, 1.0 / 120.0);
-  p = fma(p, r, 1.0 / 24.0);
-  p = fma(p, r, 1.0 / 6.0);
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
-  return ldexp(p, (int)k);
-}
-__device__ __forceinline__ double fast_log(double x) {   // x > 0, finite, normal
-  int e;
-  double m = frexp(x, &e);                       // m in [0.5, 1)
-  const bool lo = m < 0.70710678118654752440;
-  m = lo ? m + m : m;
-  e = lo ? e - 1 : e;
-  const double f = m - 1.0;
-  const double s = f / (2.0 + f);
-  const double z = s * s;                        // z <= 0.0295
-  double p = 1.0 / 23.0;
-  p = fma(p, z, 1.0 / 21.0);
-  p = fma(p, z, 1.0 / 19.0);
-  p = fma(p, z, 1.0 / 17.0);
-  p = fma(p, z, 1.0 / 15.0);
-  p = fma(p, z, 1.0 / 13.0);
-  p = fma(p, z, 1.0 / 11.0);
-  p = fma(p, z, 1.0 / 9.0);
-  p = fma(p, z, 1.0 / 7.0);
-  p = fma(p, z, 1.0 / 5.0);
-  p = fma(p, z, 1.0 / 3.0);
-  // log(m) = 2s + 2s*z*p ; log(x) = e*ln2_hi + (log(m) + e*ln2_lo)
-  const double two_s = s + s;
-  const double ed = (double)e;
-  const double t = fma(two_s * z, p, fma(ed, 1.90821492927058770002e-10, two_s));
-  return fma(ed, 6.93147180369123816490e-01, t);
-}
-
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov_f64(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
-// all-lanes reductions over each row of 16 lanes (quad_perm xor1, xor2, row_half_mirror, row_mirror)
-__device__ __forceinline__ double row16_sum(double v) {
-  v += dpp_mov_f64<0xB1>(v);
-  v += dpp_mov_f64<0x4E>(v);
-  v += dpp_mov_f64<0x141>(v);
-  v += dpp_mov_f64<0x140>(v);
-  return v;
-}
-__device__ __forceinline__ double row16_max(double v) {
-  v = fmax_raw(v, dpp_mov_f64<0xB1>(v));
-  v = fmax_raw(v, dpp_mov_f64<0x4E>(v));
-  v = fmax_raw(v, dpp_mov_f64<0x141>(v));
-  v = fmax_raw(v, dpp_mov_f64<0x140>(v));
-  return v;
-}
 #define LN2_D 0.69314718055994530942
 
 template <int NW>

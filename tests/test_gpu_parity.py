@@ -278,3 +278,29 @@ def test_full_size_properties(eng):
     ref = ref_c.estep_minibatch(pb["obs"], pb["mask"], sub, Lm, pb["mod_init"], pb["ltran"],
                                 pb["mu"], pb["sigma"], pb["kappa"], pb["nu"], flags=2)
     np.testing.assert_allclose(st2.buf, ref, rtol=RTOL, atol=1e-6)
+
+
+@pytest.mark.parametrize("fbv", [1, 2], ids=["wave", "mfma"])
+def test_unreachable_state(eng, fbv):
+    """A state nobody can transition into (ltran column ~ -1e9, i.e. var_tran ~ 0): the
+    linear-domain recursion sees exactly zero weight; posteriors and statistics must still
+    agree with the reference's log-domain arithmetic (which carries e^-1e9 ~ 0)."""
+    from pysvihmm_amd import _lib as L
+    from oracle import ref_c
+    from scipy.special import digamma
+    K, D, T, Lm, B = 5, 2, 400, 25, 12
+    pb = make_problem(K, D, T, seed=9)
+    vt = pb["var_tran"].copy()
+    vt[:, 3] = 0.0                               # psi(1e-9) ~ -1e9
+    ltran = digamma(vt + 1e-9) - digamma(vt.sum(1)[:, None] + 1e-9)
+    starts = np.arange(B) * 30
+    eng.set_variant("fb", fbv)
+    eng.set_obs(pb["obs"], None)
+    eng.set_globals(pb["mod_init"], ltran)
+    eng.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    st = eng.estep(starts, Lm, flags=L.TRANS_WRAP)
+    ref = ref_c.estep_minibatch(pb["obs"], None, starts, Lm, pb["mod_init"], ltran, pb["mu"],
+                                pb["sigma"], pb["kappa"], pb["nu"], flags=2)
+    assert np.all(np.isfinite(st.buf))
+    np.testing.assert_allclose(st.buf, ref, rtol=RTOL, atol=1e-9)
+    eng.set_variant("fb", 0)
