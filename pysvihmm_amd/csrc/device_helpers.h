@@ -1,0 +1,115 @@
+// device_helpers.h -- wave / row reductions, fp64 exp/log, DPP helpers shared by the kernels.
+// Part of libsvihmm_hip.so; included by svihmm_hip.hip (single translation unit).
+#pragma once
+
+// ------------------------------------------------------------------------------------
+//  device helpers
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double nan_to_num(double v) {
+  // np.nan_to_num: NaN -> 0, +-inf -> +-DBL_MAX  (hmmbase.py:220)
+  if (v != v) return 0.0;
+  if (isinf(v)) return v > 0 ? 1.7976931348623157e308 : -1.7976931348623157e308;
+  return v;
+}
+// global row g=(b,t) of the flattened window batch -> obs row
+__device__ __forceinline__ int64_t obs_row(const int64_t* __restrict__ starts, int Lm,
+                                           int64_t g) {
+  int64_t b = g / Lm;
+  return starts[b] + (g - b * Lm);
+}
+
+// fp64 transcendentals for the fused sweeps.  On gfx950 fp64 MFMA and fp64 VALU share one
+// pipe (tools/peak_probe.py: their times add), so every fp64 VALU instruction in the time
+// loop costs matrix throughput; ocml's log() alone is ~90 of them.  These are plain
+// range-reduction + Horner versions, accurate to ~2 ulp (tests compare against the oracle).
+__device__ __forceinline__ double fmax_raw(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));  // no NaN canonicalisation pair
+  return r;
+}
+__device__ __forceinline__ double fast_exp(double x) {
+  x = fmax_raw(x, -800.0);                       // also maps -inf to exp -> 0
+  const double k = __builtin_rint(x * 1.4426950408889634074);
+  double r = fma(k, -6.93147180369123816490e-01, x);
+  r = fma(k, -1.90821492927058770002e-10, r);
+  double p = 1.0 / 479001600.0;                  // Taylor to r^12: |r| <= 0.3466 -> 1.7e-16
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)k);
+}
+__device__ __forceinline__ double fast_log(double x) {   // x >= 0, finite
+  int e;
+  double m = frexp(x, &e);                       // m in [0.5, 1)
+  const bool lo = m < 0.70710678118654752440;
+  m = lo ? m + m : m;
+  e = lo ? e - 1 : e;
+  const double f = m - 1.0;
+  const double s = f / (2.0 + f);
+  const double z = s * s;                        // z <= 0.0295
+  double p = 1.0 / 23.0;
+  p = fma(p, z, 1.0 / 21.0);
+  p = fma(p, z, 1.0 / 19.0);
+  p = fma(p, z, 1.0 / 17.0);
+  p = fma(p, z, 1.0 / 15.0);
+  p = fma(p, z, 1.0 / 13.0);
+  p = fma(p, z, 1.0 / 11.0);
+  p = fma(p, z, 1.0 / 9.0);
+  p = fma(p, z, 1.0 / 7.0);
+  p = fma(p, z, 1.0 / 5.0);
+  p = fma(p, z, 1.0 / 3.0);
+  // log(m) = 2s + 2s*z*p ; log(x) = e*ln2_hi + (log(m) + e*ln2_lo)
+  const double two_s = s + s;
+  const double ed = (double)e;
+  const double t = fma(two_s * z, p, fma(ed, 1.90821492927058770002e-10, two_s));
+  const double r = fma(ed, 6.93147180369123816490e-01, t);
+  return x > 0.0 ? r : -INFINITY;               // log(0) = -inf (an unreachable state)
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// all-lanes reductions over each row of 16 lanes (quad_perm xor1, xor2, row_half_mirror, row_mirror)
+__device__ __forceinline__ double row16_sum(double v) {
+  v += dpp_mov_f64<0xB1>(v);
+  v += dpp_mov_f64<0x4E>(v);
+  v += dpp_mov_f64<0x141>(v);
+  v += dpp_mov_f64<0x140>(v);
+  return v;
+}
+__device__ __forceinline__ double row16_max(double v) {
+  v = fmax_raw(v, dpp_mov_f64<0xB1>(v));
+  v = fmax_raw(v, dpp_mov_f64<0x4E>(v));
+  v = fmax_raw(v, dpp_mov_f64<0x141>(v));
+  v = fmax_raw(v, dpp_mov_f64<0x140>(v));
+  return v;
+}
+__device__ __forceinline__ double wave64_max_fast(double v) {
+  v = row16_max(v);
+  v = fmax_raw(v, __shfl_xor(v, 16, 64));
+  v = fmax_raw(v, __shfl_xor(v, 32, 64));
+  return v;
+}

@@ -1,0 +1,268 @@
+// kernels_emission.h -- K0 NIW -> theta, K1 emission expected log-likelihood (VALU fallback + fp64 MFMA GEMM).
+// Part of libsvihmm_hip.so; included by svihmm_hip.hip (single translation unit).
+#pragma once
+
+// ------------------------------------------------------------------------------------
+//  K1a: emission, VALU outer-product form (generic fallback).  lane = row.
+//       grid (ceil(n/128), Kp/16), block 128, LDS (D+1)*129*8 bytes.
+// ------------------------------------------------------------------------------------
+#define EM_R 128
+__global__ __launch_bounds__(EM_R) void k_emission_outer(
+    const double* __restrict__ obs, const uint8_t* __restrict__ mask,
+    const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K, int Kp,
+    const double* __restrict__ theta, uint32_t flags, double* __restrict__ ll) {
+  extern __shared__ double xs[];  // [(D+1)][EM_R+1], transposed
+  const int S = EM_R + 1;
+  const int tid = threadIdx.x;
+  const int64_t g0 = (int64_t)blockIdx.x * EM_R;
+  const int k0 = blockIdx.y * 16;
+  for (int e = tid; e < EM_R * D; e += EM_R) {
+    int r = e / D, i = e - r * D;
+    int64_t g = g0 + r;
+    double v = 0.0;
+    if (g < nrows) v = obs[obs_row(starts, Lm, g) * D + i];
+    xs[i * S + r] = v;
+  }
+  xs[D * S + tid] = 1.0;
+  __syncthreads();
+  const int64_t g = g0 + tid;
+  bool bad = false;
+  if (g < nrows && (flags & SVIHMM_MASK_AS_NAN) && mask)
+    bad = mask[obs_row(starts, Lm, g)] != 0;
+  double acc[16];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) acc[kk] = 0.0;
+  const double* th = theta + k0;
+  int f = 0;
+  for (int a = 0; a <= D; ++a) {
+    const double xa = xs[a * S + tid];
+    bad |= (xa != xa);
+    for (int b = a; b <= D; ++b) {
+      const double phi = xa * xs[b * S + tid];
+      const double* row = th + (size_t)f * Kp;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) acc[kk] = fma(phi, row[kk], acc[kk]);
+      ++f;
+    }
+  }
+  if (g < nrows) {
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+      if (k0 + kk < K) ll[g * K + k0 + kk] = bad ? 0.0 : nan_to_num(acc[kk]);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+//  K1b: emission as an fp64 MFMA GEMM  ll[rows x K] = Phi[rows x Fp] * theta[Fp x Kp]
+//       with Phi generated on the fly from x rows staged in LDS.
+//       v_mfma_f64_16x16x4_f64: A lane l -> A[i=l&15][k=l>>4]; B lane l -> B[k=l>>4][j=l&15];
+//       C/D lane l reg r -> C[row=(l>>4)+4r][col=l&15].
+//       Workgroup = 4 waves x (MT=2 row tiles) = 128 rows; NT n-tiles of 16 states.
+//       grid (ceil(n/128), Kp/(16*NT)), block 256.
+// ------------------------------------------------------------------------------------
+template <int NT, int MT>
+__global__ __launch_bounds__(256) void k_emission_mfma(
+    const double* __restrict__ obs, const uint8_t* __restrict__ mask,
+    const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K, int Kp,
+    int Fp, const double* __restrict__ theta, const int* __restrict__ fab,
+    uint32_t flags, double* __restrict__ ll) {
+  // workgroup = 4 waves x MT row tiles of 16 rows
+  constexpr int ROWS = 64 * MT;
+  extern __shared__ double smem[];
+  const int DS = (D + 2) | 1;  // odd row stride (doubles); slot D = 1.0, slot D+1 = 0.0
+  double* xs = smem;                              // [ROWS][DS]
+  int* fabs_ = (int*)(xs + ROWS * DS);            // [Fp] packed (a | b<<16)
+  unsigned char* bad_s = (unsigned char*)(fabs_ + Fp);  // [ROWS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t g0 = (int64_t)blockIdx.x * ROWS;
+  const int n0 = blockIdx.y * (16 * NT);
+
+  for (int r = tid; r < ROWS; r += 256) {
+    int64_t g = g0 + r;
+    unsigned char bd = 0;
+    if (g < nrows && (flags & SVIHMM_MASK_AS_NAN) && mask)
+      bd = mask[obs_row(starts, Lm, g)] != 0;
+    bad_s[r] = bd;
+    xs[r * DS + D] = 1.0;
+    xs[r * DS + D + 1] = 0.0;
+  }
+  for (int e = tid; e < Fp; e += 256) fabs_[e] = fab[e];
+  __syncthreads();
+  for (int e = tid; e < ROWS * D; e += 256) {
+    int r = e / D, i = e - r * D;
+    int64_t g = g0 + r;
+    double v = 0.0;
+    if (g < nrows) v = obs[obs_row(starts, Lm, g) * D + i];
+    if (v != v) { bad_s[r] = 1; v = 0.0; }
+    xs[r * DS + i] = v;
+  }
+  __syncthreads();
+
+  const int li = lane & 15, lg = lane >> 4;
+  const int r0 = wave * 16 * MT + li;  // row of m-tile 0 for this lane; m-tile m = +16m
+  double4_t acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  const double* xr = xs + r0 * DS;
+  const double* thl = theta + n0 + li;
+  // Fp is a multiple of 16 -> the k-step count is a multiple of 4: the loop is unrolled by
+  // hand so that the theta (B operand) loads of four k-steps are in flight together
+  const int nks = Fp >> 2;
+  for (int s = 0; s < nks; s += 4) {
+    double Bv[4][NT], Av[4][MT];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int f = ((s + u) << 2) + lg;
+      const double* trow = thl + (size_t)f * Kp;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) Bv[u][n] = trow[n * 16];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int f = ((s + u) << 2) + lg;
+      const int ab = fabs_[f];
+      const int a = ab & 0xffff, b = ab >> 16;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) Av[u][m] = xr[m * 16 * DS + a] * xr[m * 16 * DS + b];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(Av[u][m], Bv[u][n], acc[m][n], 0, 0, 0);
+  }
+  // epilogue on plain VGPR copies: keeps the loop-carried accumulators in AGPRs (otherwise
+  // hipcc shuttles all of them VGPR<->AGPR around every k-step)
+  double outv[MT][NT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) outv[m][n][r] = acc[m][n][r];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rl = wave * 16 * MT + m * 16 + lg + 4 * r;
+      const int64_t g = g0 + rl;
+      if (g < nrows) {
+        const bool bd = bad_s[rl] != 0;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int k = n0 + n * 16 + li;
+          if (k < K) ll[g * K + k] = bd ? 0.0 : nan_to_num(outv[m][n][r]);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+//  K0: NIW mean-field factors -> theta (one workgroup per state).  Cholesky of sigma_mf,
+//      W = (nu/2) sigma^-1 = (nu/2) L^-T L^-1, E log|Lambda| (digamma), linear and constant
+//      terms of the quadratic form.  status[0] = 1 + k if sigma_k is not positive definite.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ double digamma_d(double x) {
+  double r = 0.0;
+  while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
+  const double f = 1.0 / (x * x);
+  const double t = f * (-1.0 / 12 + f * (1.0 / 120 + f * (-1.0 / 252 + f * (1.0 / 240 +
+                   f * (-1.0 / 132 + f * (691.0 / 32760 + f * (-1.0 / 12)))))));
+  return r + log(x) - 0.5 / x + t;
+}
+__device__ __forceinline__ int feat_index_d(int a, int b, int D) {
+  return a * (D + 1) - a * (a - 1) / 2 + (b - a);
+}
+__global__ __launch_bounds__(256) void k_niw_to_theta(
+    const double* __restrict__ mu, const double* __restrict__ sigma,
+    const double* __restrict__ kappa, const double* __restrict__ nu, int K, int D, int Kp,
+    double* __restrict__ theta, int* __restrict__ status) {
+  extern __shared__ double sm[];
+  const int S = D + 1;
+  double* Lm_ = sm;            // [D][S] Cholesky factor (lower)
+  double* Li = Lm_ + D * S;    // [D][S] its inverse (lower)
+  double* W = Li + D * S;      // [D][S]
+  double* wm = W + D * S;      // [D]
+  __shared__ int bad;
+  const int k = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const double* Sg = sigma + (size_t)k * D * D;
+  const double* m = mu + (size_t)k * D;
+  for (int e = tid; e < D * D; e += nt) {
+    const int i = e / D, j = e - i * D;
+    Lm_[i * S + j] = Sg[e];
+    Li[i * S + j] = 0.0;
+  }
+  if (tid == 0) bad = 0;
+  __syncthreads();
+  // right-looking Cholesky
+  for (int j = 0; j < D; ++j) {
+    const double djj = Lm_[j * S + j];
+    if (!(djj > 0.0)) { if (tid == 0) bad = 1; }
+    __syncthreads();
+    if (bad) break;
+    const double d = sqrt(djj);
+    for (int i = j + 1 + tid; i < D; i += nt) Lm_[i * S + j] /= d;
+    __syncthreads();
+    if (tid == 0) Lm_[j * S + j] = d;
+    const int n = D - 1 - j;
+    for (int e = tid; e < n * n; e += nt) {
+      const int a = j + 1 + e / n, b = j + 1 + e % n;
+      if (b <= a) Lm_[a * S + b] -= Lm_[a * S + j] * Lm_[b * S + j];
+    }
+    __syncthreads();
+  }
+  if (bad) {
+    if (tid == 0) atomicMax(status, 1 + k);
+    return;
+  }
+  // Li = L^-1, one column per thread
+  for (int c = tid; c < D; c += nt) {
+    Li[c * S + c] = 1.0 / Lm_[c * S + c];
+    for (int r = c + 1; r < D; ++r) {
+      double s = 0.0;
+      for (int jj = c; jj < r; ++jj) s -= Lm_[r * S + jj] * Li[jj * S + c];
+      Li[r * S + c] = s / Lm_[r * S + r];
+    }
+  }
+  __syncthreads();
+  const double hn = 0.5 * nu[k];
+  for (int e = tid; e < D * D; e += nt) {
+    const int i = e / D, j = e - i * D;
+    if (j < i) continue;
+    double s = 0.0;
+    for (int r = j; r < D; ++r) s += Li[r * S + i] * Li[r * S + j];
+    W[i * S + j] = hn * s;
+    W[j * S + i] = hn * s;
+  }
+  __syncthreads();
+  for (int i = tid; i < D; i += nt) {
+    double s = 0.0;
+    for (int j = 0; j < D; ++j) s += W[i * S + j] * m[j];
+    wm[i] = s;
+    theta[(size_t)feat_index_d(i, D, D) * Kp + k] = 2.0 * s;
+  }
+  for (int e = tid; e < D * D; e += nt) {
+    const int i = e / D, j = e - i * D;
+    if (j < i) continue;
+    theta[(size_t)feat_index_d(i, j, D) * Kp + k] = (i == j) ? -W[i * S + i] : -2.0 * W[i * S + j];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double logdet = 0.0, llt = D * log(2.0), mWm = 0.0;
+    for (int i = 0; i < D; ++i) {
+      logdet += log(Lm_[i * S + i]);
+      llt += digamma_d(0.5 * (nu[k] - i));
+      mWm += m[i] * wm[i];
+    }
+    llt -= 2.0 * logdet;
+    const double cst = 0.5 * llt - D / (2.0 * kappa[k]) - 0.5 * D * 1.8378770664093454835606594728112;
+    theta[(size_t)feat_index_d(D, D, D) * Kp + k] = cst - mWm;
+  }
+}

@@ -1,0 +1,616 @@
+// kernels_recursion.h -- K2 forward/backward sweeps (wave-per-window, generic, batched fp64 MFMA), K3 posterior, K6 FFBS sampling.
+// Part of libsvihmm_hip.so; included by svihmm_hip.hip (single translation unit).
+#pragma once
+
+// ------------------------------------------------------------------------------------
+//  K2a: forward / backward messages, one wavefront per (window, direction), K <= KMAX<=64.
+//       The transition column (fwd) / row (bwd) of exp(ltran) lives in registers,
+//       the shifted probabilities p_i are exchanged through LDS.
+//       grid (B, ndir), block 64.
+// ------------------------------------------------------------------------------------
+template <int KMAX>
+__global__ __launch_bounds__(64) void k_fb_wave(
+    const double* __restrict__ ll, const double* __restrict__ Aexp,
+    const double* __restrict__ mod_init, int Lm, int K, int dir0,
+    double* __restrict__ la_out, double* __restrict__ lb_out) {
+  __shared__ double p_s[2][KMAX];
+  const int b = blockIdx.x, dir = dir0 + blockIdx.y, j = threadIdx.x;
+  const bool valid = j < K;
+  double a[KMAX];
+#pragma unroll
+  for (int i = 0; i < KMAX; ++i) {
+    double v = 0.0;
+    if (valid && i < K) v = (dir == 0) ? Aexp[i * K + j] : Aexp[j * K + i];
+    a[i] = v;
+  }
+  const double* llb = ll + (size_t)b * Lm * K;
+  const double NEG_INF = -INFINITY;
+  int cur = 0;
+  if (dir == 0) {
+    double* out = la_out + (size_t)b * Lm * K;
+    double la = valid ? mod_init[j] + llb[j] : NEG_INF;
+    if (valid) out[j] = la;
+    double llnext = (valid && Lm > 1) ? llb[K + j] : 0.0;
+    for (int t = 1; t < Lm; ++t) {
+      const double llt = llnext;
+      if (valid && t + 1 < Lm) llnext = llb[(size_t)(t + 1) * K + j];
+      const double m = wave64_max_fast(la);
+      const double p = valid ? fast_exp(la - m) : 0.0;
+      if (j < KMAX) p_s[cur][j] = p;
+      __syncthreads();
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int i = 0; i < KMAX; i += 2) {
+        s0 = fma(p_s[cur][i], a[i], s0);
+        s1 = fma(p_s[cur][i + 1], a[i + 1], s1);
+      }
+      cur ^= 1;
+      la = valid ? fast_log(s0 + s1) + m + llt : NEG_INF;
+      if (valid) out[(size_t)t * K + j] = la;
+    }
+  } else {
+    double* out = lb_out + (size_t)b * Lm * K;
+    double lb = 0.0;
+    if (valid) out[(size_t)(Lm - 1) * K + j] = 0.0;
+    double llnext = valid ? llb[(size_t)(Lm - 1) * K + j] : 0.0;
+    for (int t = Lm - 2; t >= 0; --t) {
+      const double u = valid ? lb + llnext : NEG_INF;
+      if (valid && t >= 1) llnext = llb[(size_t)t * K + j];
+      const double m = wave64_max_fast(u);
+      const double p = valid ? fast_exp(u - m) : 0.0;
+      if (j < KMAX) p_s[cur][j] = p;
+      __syncthreads();
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int i = 0; i < KMAX; i += 2) {
+        s0 = fma(p_s[cur][i], a[i], s0);
+        s1 = fma(p_s[cur][i + 1], a[i + 1], s1);
+      }
+      cur ^= 1;
+      lb = fast_log(s0 + s1) + m;
+      if (valid) out[(size_t)t * K + j] = lb;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+//  K2b: forward / backward, generic K (block = roundup(K,64) threads, thread = state).
+//       Transition matrix (fwd: A, bwd: A^T) is read from LDS when it fits, else HBM/L2.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_max(double v, double* red, int nw) {
+  v = wave_max(v);
+  if (nw == 1) return v;
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  double m = red[0];
+  for (int i = 1; i < nw; ++i) m = fmax(m, red[i]);
+  return m;
+}
+
+__global__ void k_fb_generic(const double* __restrict__ ll, const double* __restrict__ Aexp,
+                             const double* __restrict__ AexpT,
+                             const double* __restrict__ mod_init, int Lm, int K, int dir0,
+                             int m_in_lds, double* __restrict__ la_out,
+                             double* __restrict__ lb_out) {
+  extern __shared__ double sm[];
+  double* p_s = sm;            // [2][K]
+  double* red = sm + 2 * K;    // [16]
+  double* M_s = red + 16;      // [K][K] if m_in_lds
+  const int b = blockIdx.x, dir = dir0 + blockIdx.y, j = threadIdx.x;
+  const int nw = (blockDim.x + 63) >> 6;
+  const bool valid = j < K;
+  // M[i][j] such that out_j = sum_i p_i M[i][j]:  fwd M = A ; bwd M[jj][i] = A[i][jj] = A^T
+  const double* Mg = (dir == 0) ? Aexp : AexpT;
+  const double* M = Mg;
+  if (m_in_lds) {
+    for (int e = threadIdx.x; e < K * K; e += blockDim.x) M_s[e] = Mg[e];
+    M = M_s;
+  }
+  __syncthreads();
+  const double* llb = ll + (size_t)b * Lm * K;
+  const double NEG_INF = -INFINITY;
+  int cur = 0;
+  if (dir == 0) {
+    double* out = la_out + (size_t)b * Lm * K;
+    double la = valid ? mod_init[j] + llb[j] : NEG_INF;
+    if (valid) out[j] = la;
+    for (int t = 1; t < Lm; ++t) {
+      const double llt = valid ? llb[(size_t)t * K + j] : 0.0;
+      const double m = block_max(la, red, nw);
+      if (valid) p_s[cur * K + j] = exp(la - m);
+      __syncthreads();
+      double s = 0.0;
+      if (valid)
+        for (int i = 0; i < K; ++i) s = fma(p_s[cur * K + i], M[(size_t)i * K + j], s);
+      cur ^= 1;
+      la = valid ? log(s) + m + llt : NEG_INF;
+      if (valid) out[(size_t)t * K + j] = la;
+    }
+  } else {
+    double* out = lb_out + (size_t)b * Lm * K;
+    double lb = 0.0;
+    if (valid) out[(size_t)(Lm - 1) * K + j] = 0.0;
+    for (int t = Lm - 2; t >= 0; --t) {
+      const double u = valid ? lb + llb[(size_t)(t + 1) * K + j] : NEG_INF;
+      const double m = block_max(u, red, nw);
+      if (valid) p_s[cur * K + j] = exp(u - m);
+      __syncthreads();
+      double s = 0.0;
+      if (valid)
+        for (int i = 0; i < K; ++i) s = fma(p_s[cur * K + i], M[(size_t)i * K + j], s);
+      cur ^= 1;
+      lb = log(s) + m;
+      if (valid) out[(size_t)t * K + j] = lb;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+//  K2c/K2d: forward and backward(+posterior) sweeps as batched fp64 MFMA mat-mats.
+//  A workgroup owns 16 windows (the M dimension of v_mfma_f64_16x16x4_f64); wave s owns
+//  the 16-state tile n0=16*s (K <= 64 -> NW = Kp/16 waves).  Per time step
+//      out[w][j] = sum_i P[w][i] * M[i][j],   P = exp(prev message - shift[w]) via LDS,
+//  M = exp(ltran) (forward) / its transpose (backward) held in registers as the B operand.
+//  The per-window shift is c_t = c_{t-1} + ln2*frexp_exp(sum_i P_{t-1}[i]) + max_j ll_t[j]:
+//  an upper bound of max_j message_t[j] that is at most ~|min ltran| above it, built only
+//  from tile reductions of the PREVIOUS step, so there is one barrier per step and no
+//  reduction on the critical path.  sum_t LSE_j lalpha (quirk Q4) is accumulated as a
+//  running (mantissa, exponent) product of the per-step sums.
+// ------------------------------------------------------------------------------------
+#define LN2_D 0.69314718055994530942
+
+template <int NW>
+struct FbShared {
+  static constexpr int Kp = 16 * NW;
+  static constexpr int PS = Kp + 2;
+  double __attribute__((aligned(16))) P[2][16][PS];
+  // tile reductions: every lane of a 16-lane row holds the same value after the DPP
+  // reduction and writes its own slot (branch-free, conflict-free); readers use slot 0
+  double tsum[2][16][NW][16];
+  double tmll[2][16][NW][16];
+  double tq[2][16][NW][16];
+};
+
+template <int NW>
+__device__ __forceinline__ double4_t fb_matmul(const FbShared<NW>& sh, int cur, int li, int lg,
+                                               const double (&Bv)[4 * NW]) {
+  constexpr int KS = 4 * NW;
+  double4_t a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+  const double* prow = &sh.P[cur][li][2 * lg];
+#pragma unroll
+  for (int c = 0; c < KS / 2; c += 2) {
+    const double2 x = *reinterpret_cast<const double2*>(prow + 8 * c);
+    const double2 y = *reinterpret_cast<const double2*>(prow + 8 * (c + 1));
+    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, Bv[2 * c], a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, Bv[2 * c + 1], a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(y.x, Bv[2 * c + 2], a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(y.y, Bv[2 * c + 3], a3, 0, 0, 0);
+  }
+  return (a0 + a1) + (a2 + a3);
+}
+
+// FULL: K == 16*NW (no padded states).  Windows beyond B are clamped to B-1 (they redo the
+// last window and rewrite identical values), so the time loop has no per-lane predicate
+// and compiles to a single basic block: loads issued two steps ahead are waited for with a
+// counted vmcnt instead of a full drain.
+template <int NW, bool FULL>
+__global__ __launch_bounds__(64 * NW) void k_fwd_mfma(
+    const double* __restrict__ ll, const double* __restrict__ Aexp,
+    const double* __restrict__ mod_init, int B, int Lm, int K, double* __restrict__ la_out,
+    double* __restrict__ local_lb, double* __restrict__ logz) {
+  // Critical path per step: LDS read -> MFMA -> p = acc * w -> LDS write -> row sum -> barrier.
+  // w = exp(ll_t - d) (d = shift increment) does not depend on the MFMA result and the
+  // lalpha store (log) of step t is issued during step t+1, so every transcendental runs
+  // in the shadow of the matrix pipe.
+  constexpr int KS = 4 * NW;
+  __shared__ FbShared<NW> sh;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int j = wave * 16 + li;
+  const bool vj = FULL || (j < K);
+  const int jc = vj ? j : 0;
+  const int b0 = blockIdx.x * 16;
+  double Bv[KS];
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+    const int k = 8 * (kk >> 1) + 2 * lg + (kk & 1);
+    Bv[kk] = (k < K && vj) ? Aexp[(size_t)k * K + jc] : 0.0;
+  }
+  size_t base[4];
+  int gwc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int gw = b0 + lg + 4 * r;
+    gwc[r] = gw < B ? gw : B - 1;
+    base[r] = (size_t)gwc[r] * Lm * K + jc;
+  }
+  const double NEG_INF = -INFINITY;
+  double c[4], csum[4], mant[4], lln[4], ll2[4];  // ll_{t+1}, ll_{t+2}: two steps in flight
+  double pacc[4], pc[4], pll[4];                  // delayed lalpha store of the previous step
+  int ex[4];
+  const size_t K1 = (size_t)K * (Lm > 1 ? 1 : 0), K2 = (size_t)K * (Lm > 2 ? 2 : (Lm > 1 ? 1 : 0));
+  // ---- t = 0
+  {
+    double tm[4], la0[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double x0 = mod_init[jc] + ll[base[r]];
+      la0[r] = vj ? x0 : NEG_INF;
+      if (vj) la_out[base[r]] = la0[r];
+      tm[r] = row16_max(la0[r]);
+      const double x1 = ll[base[r] + K1], x2 = ll[base[r] + K2];
+      lln[r] = vj ? x1 : NEG_INF;
+      ll2[r] = vj ? x2 : NEG_INF;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sh.tq[0][lg + 4 * r][wave][li] = tm[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int w = lg + 4 * r;
+      double m = sh.tq[0][w][0][0];
+#pragma unroll
+      for (int s2 = 1; s2 < NW; ++s2) m = fmax(m, sh.tq[0][w][s2][0]);
+      c[r] = m;
+      csum[r] = m;
+      mant[r] = 1.0;
+      ex[r] = 0;
+      const double pv = vj ? exp(la0[r] - m) : 0.0;
+      sh.P[0][w][j] = pv;
+      sh.tsum[0][w][wave][li] = row16_sum(pv);
+      sh.tmll[1][w][wave][li] = row16_max(lln[r]);
+      pacc[r] = 1.0; pc[r] = 0.0; pll[r] = la0[r];   // re-stores lalpha[0] at t = 1
+    }
+    __syncthreads();
+  }
+  for (int t = 1; t < Lm; ++t) {
+    const int cur = (t - 1) & 1, nxt = t & 1;
+    const size_t o2 = (size_t)(t + 2 < Lm ? t + 2 : Lm - 1) * K;
+    double llv[4], wgt[4], cn[4];
+    // (a) everything that does not need the MFMA result
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int w = lg + 4 * r;
+      llv[r] = lln[r];
+      lln[r] = ll2[r];   // loaded one step ago: its row max below does not wait on HBM
+      const double x2 = ll[base[r] + o2];
+      ll2[r] = vj ? x2 : NEG_INF;
+      double tot = sh.tsum[cur][w][0][0], mll = sh.tmll[nxt][w][0][0];
+#pragma unroll
+      for (int s2 = 1; s2 < NW; ++s2) {
+        tot += sh.tsum[cur][w][s2][0];
+        mll = fmax_raw(mll, sh.tmll[nxt][w][s2][0]);
+      }
+      int e1, e2;
+      mant[r] = frexp(mant[r] * tot, &e1);
+      ex[r] += e1;
+      (void)frexp(tot, &e2);
+      const double d = (double)e2 * LN2_D + mll;
+      cn[r] = c[r] + d;
+      wgt[r] = vj ? fast_exp(llv[r] - d) : 0.0;
+    }
+    // (b) matrix pipe
+    const double4_t acc = fb_matmul<NW>(sh, cur, li, lg, Bv);
+    // (c) delayed lalpha store of step t-1 (independent of acc: overlaps the MFMAs)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double lav = fast_log(pacc[r]) + pc[r] + pll[r];
+      if (FULL || vj) la_out[base[r] + (size_t)(t - 1) * K] = lav;
+    }
+    // (d) critical tail
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int w = lg + 4 * r;
+      const double pv = acc[r] * wgt[r];
+      sh.P[nxt][w][j] = pv;
+      sh.tsum[nxt][w][wave][li] = row16_sum(pv);
+      sh.tmll[cur][w][wave][li] = row16_max(lln[r]);
+      pacc[r] = acc[r]; pc[r] = c[r]; pll[r] = llv[r];
+      c[r] = cn[r];
+      csum[r] += cn[r];
+    }
+    __syncthreads();
+  }
+  if (Lm > 1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (vj) la_out[base[r] + (size_t)(Lm - 1) * K] = fast_log(pacc[r]) + pc[r] + pll[r];
+  }
+  // ---- epilogue: LSE of the last step, per-window totals
+  if (wave == 0 && li == 0) {
+    const int last = (Lm - 1) & 1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int w = lg + 4 * r;
+      double tot = sh.tsum[last][w][0][0];
+#pragma unroll
+      for (int s2 = 1; s2 < NW; ++s2) tot += sh.tsum[last][w][s2][0];
+      const double lz = c[r] + log(tot);
+      int e1;
+      const double mm = frexp(mant[r] * tot, &e1);
+      local_lb[gwc[r]] = csum[r] + log(mm) + (double)(ex[r] + e1) * LN2_D;
+      logz[gwc[r]] = lz;
+    }
+  }
+}
+
+template <int NW, bool FULL, bool WANT_LB>
+__global__ __launch_bounds__(64 * NW) void k_bwd_mfma(
+    const double* __restrict__ ll, const double* __restrict__ AexpT,
+    const double* __restrict__ la_in, const double* __restrict__ logz, int B, int Lm, int K,
+    double* __restrict__ lb_out, double* __restrict__ q_out) {
+  constexpr int KS = 4 * NW;
+  __shared__ FbShared<NW> sh;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int j = wave * 16 + li;
+  const bool vj = FULL || (j < K);
+  const int jc = vj ? j : 0;
+  const int b0 = blockIdx.x * 16;
+  double Bv[KS];
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+    const int k = 8 * (kk >> 1) + 2 * lg + (kk & 1);
+    Bv[kk] = (k < K && vj) ? AexpT[(size_t)k * K + jc] : 0.0;
+  }
+  size_t base[4];
+  double sz[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int gw = b0 + lg + 4 * r;
+    const int g = gw < B ? gw : B - 1;
+    base[r] = (size_t)g * Lm * K + jc;
+    sz[r] = logz[g];
+  }
+  const double NEG_INF = -INFINITY;
+  double c[4], eprev[4], lln[4], lan[4], ll2[4], la2[4];
+  const size_t top = (size_t)(Lm - 1) * K;
+  const size_t K1 = (size_t)K * (Lm > 1 ? 1 : 0), K2 = (size_t)K * (Lm > 2 ? 2 : (Lm > 1 ? 1 : 0));
+  // ---- t = Lm-1: lbeta = 0
+  {
+    double tm[4], u[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double x0 = ll[base[r] + top], a0 = la_in[base[r] + top];
+      const double x1 = ll[base[r] + top - K1], x2 = ll[base[r] + top - K2];
+      const double a1 = la_in[base[r] + top - K1];
+      la2[r] = la_in[base[r] + top - K2];
+      if (WANT_LB && vj) lb_out[base[r] + top] = 0.0;
+      u[r] = vj ? x0 : NEG_INF;
+      tm[r] = row16_max(u[r]);
+      eprev[r] = vj ? exp(a0 - sz[r]) : 0.0;
+      lln[r] = vj ? x1 : NEG_INF;
+      ll2[r] = vj ? x2 : NEG_INF;
+      lan[r] = a1;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sh.tq[1][lg + 4 * r][wave][li] = tm[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int w = lg + 4 * r;
+      double m = sh.tq[1][w][0][0];
+#pragma unroll
+      for (int s2 = 1; s2 < NW; ++s2) m = fmax(m, sh.tq[1][w][s2][0]);
+      c[r] = m;
+      const double pv = vj ? exp(u[r] - m) : 0.0;
+      sh.P[0][w][j] = pv;
+      sh.tsum[0][w][wave][li] = row16_sum(pv);
+      sh.tmll[1][w][wave][li] = row16_max(lln[r]);
+      sh.tq[0][w][wave][li] = row16_sum(eprev[r]);
+    }
+    __syncthreads();
+  }
+  int step = 1;
+  for (int t = Lm - 2; t >= 0; --t, ++step) {
+    const int cur = (step - 1) & 1, nxt = step & 1;
+    const size_t o2 = (size_t)(t >= 2 ? t - 2 : 0) * K;
+    double wp[4], we[4], cn[4], rq[4];
+    // (a) independent of the MFMA result
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int w = lg + 4 * r;
+      const double llv = lln[r], lav = lan[r];
+      lln[r] = ll2[r];
+      const double x2 = ll[base[r] + o2];
+      ll2[r] = vj ? x2 : NEG_INF;
+      lan[r] = la2[r];
+      la2[r] = la_in[base[r] + o2];
+      double tot = sh.tsum[cur][w][0][0], mll = sh.tmll[nxt][w][0][0], totq = sh.tq[cur][w][0][0];
+#pragma unroll
+      for (int s2 = 1; s2 < NW; ++s2) {
+        tot += sh.tsum[cur][w][s2][0];
+        mll = fmax_raw(mll, sh.tmll[nxt][w][s2][0]);
+        totq += sh.tq[cur][w][s2][0];
+      }
+      rq[r] = 1.0 / totq;
+      int e2;
+      (void)frexp(tot, &e2);
+      const double d = (double)e2 * LN2_D + mll;
+      cn[r] = c[r] + d;
+      wp[r] = vj ? fast_exp(llv - d) : 0.0;                          // P'_t = acc * wp
+      we[r] = vj ? fast_exp(fmin(lav + c[r] - sz[r], 700.0)) : 0.0;  // e_t  = acc * we
+    }
+    // (b) matrix pipe
+    const double4_t acc = fb_matmul<NW>(sh, cur, li, lg, Bv);
+    // (c) posterior of row t+1, normalised like hmmbase.py:226-229 (overlaps the MFMAs)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double qv = eprev[r] * rq[r];
+      if (FULL || vj) q_out[base[r] + (size_t)(t + 1) * K] = qv;
+    }
+    // (d) critical tail
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int w = lg + 4 * r;
+      const double pv = acc[r] * wp[r];
+      sh.P[nxt][w][j] = pv;
+      eprev[r] = acc[r] * we[r];
+      sh.tsum[nxt][w][wave][li] = row16_sum(pv);
+      sh.tq[nxt][w][wave][li] = row16_sum(eprev[r]);
+      sh.tmll[cur][w][wave][li] = row16_max(lln[r]);
+    }
+    if (WANT_LB) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double lbv = fast_log(acc[r]) + c[r];
+        if (FULL || vj) lb_out[base[r] + (size_t)t * K] = lbv;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[r] = cn[r];
+    __syncthreads();
+  }
+  // ---- flush the posterior of row 0
+  {
+    const int last = (step - 1) & 1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int w = lg + 4 * r;
+      double totq = sh.tq[last][w][0][0];
+#pragma unroll
+      for (int s2 = 1; s2 < NW; ++s2) totq += sh.tq[last][w][s2][0];
+      if (vj) q_out[base[r]] = eprev[r] / totq;
+    }
+  }
+}
+
+__global__ void k_sum_lb(const double* __restrict__ local_lb, int B, double* __restrict__ lb_total) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) acc += local_lb[b];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *lb_total = red[0];
+}
+
+// ------------------------------------------------------------------------------------
+//  K3: posterior marginals q = softmax_k(la+lb) and per-row LSE_k(la) partial sums.
+//      grid (B*nseg), block 256 = 4 waves, one wave per row; seg = PS_ROWS rows.
+// ------------------------------------------------------------------------------------
+#define PS_ROWS 256
+template <int KPL>  // states per lane (K <= 64*KPL)
+__global__ __launch_bounds__(256) void k_posterior(const double* __restrict__ la,
+                                                   const double* __restrict__ lb, int Lm,
+                                                   int K, int nseg,
+                                                   double* __restrict__ q,
+                                                   double* __restrict__ lse_part) {
+  __shared__ double wsum[4];
+  const int b = blockIdx.x / nseg, seg = blockIdx.x - b * nseg;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t0 = seg * PS_ROWS;
+  const int t1 = min(Lm, t0 + PS_ROWS);
+  double lse_acc = 0.0;
+  for (int t = t0 + wave; t < t1; t += 4) {
+    const size_t base = ((size_t)b * Lm + t) * K;
+    double u[KPL], a[KPL];
+    double mu = -INFINITY, ma = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < KPL; ++c) {
+      const int k = lane + 64 * c;
+      if (k < K) {
+        a[c] = la[base + k];
+        u[c] = a[c] + lb[base + k];
+      } else {
+        a[c] = -INFINITY;
+        u[c] = -INFINITY;
+      }
+      mu = fmax(mu, u[c]);
+      ma = fmax(ma, a[c]);
+    }
+    mu = wave_max(mu);
+    ma = wave_max(ma);
+    double su = 0.0, sa = 0.0;
+#pragma unroll
+    for (int c = 0; c < KPL; ++c) {
+      u[c] = exp(u[c] - mu);
+      su += u[c];
+      sa += exp(a[c] - ma);
+    }
+    su = wave_sum(su);
+    sa = wave_sum(sa);
+#pragma unroll
+    for (int c = 0; c < KPL; ++c) {
+      const int k = lane + 64 * c;
+      if (k < K) q[base + k] = u[c] / su;
+    }
+    lse_acc += ma + log(sa);
+  }
+  if (lane == 0) wsum[wave] = lse_acc;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    lse_part[(size_t)b * nseg + seg] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+// ------------------------------------------------------------------------------------
+//  K6: FFBS backward sampling (hmm_fast.pyx:97-122), one wavefront, K <= 64 in-lane,
+//      larger K through a serial tail in lane 0.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_ffbs_sample(const double* __restrict__ la,
+                                                    const double* __restrict__ logA,
+                                                    const double* __restrict__ unif, int64_t T,
+                                                    int K, int64_t* __restrict__ z) {
+  const int lane = threadIdx.x;
+  extern __shared__ double ps[];  // [K] for K > 64
+  int64_t znext = 0;
+  for (int64_t t = T - 1; t >= 0; --t) {
+    if (K <= 64) {
+      double lp = -INFINITY;
+      if (lane < K) {
+        lp = la[t * K + lane];
+        if (t < T - 1) lp += logA[(size_t)lane * K + znext];
+      }
+      const double m = wave_max(lp);
+      double p = (lane < K) ? exp(lp - m) : 0.0;
+      const double tot = wave_sum(p);
+      p /= tot;
+      // inclusive scan in lane order
+      double c = p;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const double v = __shfl_up(c, o, 64);
+        if (lane >= o) c += v;
+      }
+      const double r = unif[t];
+      const unsigned long long bal = __ballot(lane < K && r <= c);
+      int zz = bal ? (__ffsll((long long)bal) - 1) : (K - 1);
+      znext = zz;
+    } else {
+      double mloc = -INFINITY;
+      for (int k = lane; k < K; k += 64) {
+        double lp = la[t * K + k];
+        if (t < T - 1) lp += logA[(size_t)k * K + znext];
+        ps[k] = lp;
+        mloc = fmax(mloc, lp);
+      }
+      const double m = wave_max(mloc);
+      double sl = 0.0;
+      for (int k = lane; k < K; k += 64) {
+        const double e = exp(ps[k] - m);
+        ps[k] = e;
+        sl += e;
+      }
+      const double tot = wave_sum(sl);
+      __syncthreads();
+      int zz = K - 1;
+      if (lane == 0) {
+        const double r = unif[t];
+        double rs = 0.0;
+        for (int k = 0; k < K; ++k) {
+          rs += ps[k] / tot;
+          if (r <= rs) { zz = k; break; }
+        }
+      }
+      zz = __shfl(zz, 0, 64);
+      znext = zz;
+      __syncthreads();
+    }
+    if (lane == 0) z[t] = znext;
+  }
+}

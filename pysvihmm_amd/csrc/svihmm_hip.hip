@@ -57,1576 +57,11 @@ static int fail(const std::string& m) { g_err = m; return 1; }
   } while (0)
 
 
-// ------------------------------------------------------------------------------------
-//  device helpers
-// ------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-  return v;
-}
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ double nan_to_num(double v) {
-  // np.nan_to_num: NaN -> 0, +-inf -> +-DBL_MAX  (hmmbase.py:220)
-  if (v != v) return 0.0;
-  if (isinf(v)) return v > 0 ? 1.7976931348623157e308 : -1.7976931348623157e308;
-  return v;
-}
-// global row g=(b,t) of the flattened window batch -> obs row
-__device__ __forceinline__ int64_t obs_row(const int64_t* __restrict__ starts, int Lm,
-                                           int64_t g) {
-  int64_t b = g / Lm;
-  return starts[b] + (g - b * Lm);
-}
-
-// ------------------------------------------------------------------------------------
-//  K1a: emission, VALU outer-product form (generic fallback).  lane = row.
-//       grid (ceil(n/128), Kp/16), block 128, LDS (D+1)*129*8 bytes.
-// ------------------------------------------------------------------------------------
-#define EM_R 128
-__global__ __launch_bounds__(EM_R) void k_emission_outer(
-    const double* __restrict__ obs, const uint8_t* __restrict__ mask,
-    const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K, int Kp,
-    const double* __restrict__ theta, uint32_t flags, double* __restrict__ ll) {
-  extern __shared__ double xs[];  // [(D+1)][EM_R+1], transposed
-  const int S = EM_R + 1;
-  const int tid = threadIdx.x;
-  const int64_t g0 = (int64_t)blockIdx.x * EM_R;
-  const int k0 = blockIdx.y * 16;
-  for (int e = tid; e < EM_R * D; e += EM_R) {
-    int r = e / D, i = e - r * D;
-    int64_t g = g0 + r;
-    double v = 0.0;
-    if (g < nrows) v = obs[obs_row(starts, Lm, g) * D + i];
-    xs[i * S + r] = v;
-  }
-  xs[D * S + tid] = 1.0;
-  __syncthreads();
-  const int64_t g = g0 + tid;
-  bool bad = false;
-  if (g < nrows && (flags & SVIHMM_MASK_AS_NAN) && mask)
-    bad = mask[obs_row(starts, Lm, g)] != 0;
-  double acc[16];
-#pragma unroll
-  for (int kk = 0; kk < 16; ++kk) acc[kk] = 0.0;
-  const double* th = theta + k0;
-  int f = 0;
-  for (int a = 0; a <= D; ++a) {
-    const double xa = xs[a * S + tid];
-    bad |= (xa != xa);
-    for (int b = a; b <= D; ++b) {
-      const double phi = xa * xs[b * S + tid];
-      const double* row = th + (size_t)f * Kp;
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) acc[kk] = fma(phi, row[kk], acc[kk]);
-      ++f;
-    }
-  }
-  if (g < nrows) {
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk)
-      if (k0 + kk < K) ll[g * K + k0 + kk] = bad ? 0.0 : nan_to_num(acc[kk]);
-  }
-}
-
-// ------------------------------------------------------------------------------------
-//  K1b: emission as an fp64 MFMA GEMM  ll[rows x K] = Phi[rows x Fp] * theta[Fp x Kp]
-//       with Phi generated on the fly from x rows staged in LDS.
-//       v_mfma_f64_16x16x4_f64: A lane l -> A[i=l&15][k=l>>4]; B lane l -> B[k=l>>4][j=l&15];
-//       C/D lane l reg r -> C[row=(l>>4)+4r][col=l&15].
-//       Workgroup = 4 waves x (MT=2 row tiles) = 128 rows; NT n-tiles of 16 states.
-//       grid (ceil(n/128), Kp/(16*NT)), block 256.
-// ------------------------------------------------------------------------------------
-template <int NT, int MT>
-__global__ __launch_bounds__(256) void k_emission_mfma(
-    const double* __restrict__ obs, const uint8_t* __restrict__ mask,
-    const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K, int Kp,
-    int Fp, const double* __restrict__ theta, const int* __restrict__ fab,
-    uint32_t flags, double* __restrict__ ll) {
-  // workgroup = 4 waves x MT row tiles of 16 rows
-  constexpr int ROWS = 64 * MT;
-  extern __shared__ double smem[];
-  const int DS = (D + 2) | 1;  // odd row stride (doubles); slot D = 1.0, slot D+1 = 0.0
-  double* xs = smem;                              // [ROWS][DS]
-  int* fabs_ = (int*)(xs + ROWS * DS);            // [Fp] packed (a | b<<16)
-  unsigned char* bad_s = (unsigned char*)(fabs_ + Fp);  // [ROWS]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t g0 = (int64_t)blockIdx.x * ROWS;
-  const int n0 = blockIdx.y * (16 * NT);
-
-  for (int r = tid; r < ROWS; r += 256) {
-    int64_t g = g0 + r;
-    unsigned char bd = 0;
-    if (g < nrows && (flags & SVIHMM_MASK_AS_NAN) && mask)
-      bd = mask[obs_row(starts, Lm, g)] != 0;
-    bad_s[r] = bd;
-    xs[r * DS + D] = 1.0;
-    xs[r * DS + D + 1] = 0.0;
-  }
-  for (int e = tid; e < Fp; e += 256) fabs_[e] = fab[e];
-  __syncthreads();
-  for (int e = tid; e < ROWS * D; e += 256) {
-    int r = e / D, i = e - r * D;
-    int64_t g = g0 + r;
-    double v = 0.0;
-    if (g < nrows) v = obs[obs_row(starts, Lm, g) * D + i];
-    if (v != v) { bad_s[r] = 1; v = 0.0; }
-    xs[r * DS + i] = v;
-  }
-  __syncthreads();
-
-  const int li = lane & 15, lg = lane >> 4;
-  const int r0 = wave * 16 * MT + li;  // row of m-tile 0 for this lane; m-tile m = +16m
-  double4_t acc[MT][NT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int n = 0; n < NT; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
-
-  const double* xr = xs + r0 * DS;
-  const double* thl = theta + n0 + li;
-  // Fp is a multiple of 16 -> the k-step count is a multiple of 4: the loop is unrolled by
-  // hand so that the theta (B operand) loads of four k-steps are in flight together
-  const int nks = Fp >> 2;
-  for (int s = 0; s < nks; s += 4) {
-    double Bv[4][NT], Av[4][MT];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int f = ((s + u) << 2) + lg;
-      const double* trow = thl + (size_t)f * Kp;
-#pragma unroll
-      for (int n = 0; n < NT; ++n) Bv[u][n] = trow[n * 16];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int f = ((s + u) << 2) + lg;
-      const int ab = fabs_[f];
-      const int a = ab & 0xffff, b = ab >> 16;
-#pragma unroll
-      for (int m = 0; m < MT; ++m) Av[u][m] = xr[m * 16 * DS + a] * xr[m * 16 * DS + b];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(Av[u][m], Bv[u][n], acc[m][n], 0, 0, 0);
-  }
-  // epilogue on plain VGPR copies: keeps the loop-carried accumulators in AGPRs (otherwise
-  // hipcc shuttles all of them VGPR<->AGPR around every k-step)
-  double outv[MT][NT][4];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) outv[m][n][r] = acc[m][n][r];
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int rl = wave * 16 * MT + m * 16 + lg + 4 * r;
-      const int64_t g = g0 + rl;
-      if (g < nrows) {
-        const bool bd = bad_s[rl] != 0;
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const int k = n0 + n * 16 + li;
-          if (k < K) ll[g * K + k] = bd ? 0.0 : nan_to_num(outv[m][n][r]);
-        }
-      }
-    }
-  }
-}
-
-// fp64 transcendentals for the fused sweeps.  On gfx950 fp64 MFMA and fp64 VALU share one
-// pipe (tools/peak_probe.py: their times add), so every fp64 VALU instruction in the time
-// loop costs matrix throughput; ocml's log() alone is ~90 of them.  These are plain
-// range-reduction + Horner versions, accurate to ~2 ulp (tests compare against the oracle).
-__device__ __forceinline__ double fmax_raw(double a, double b) {
-  double r;
-  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));  // no NaN canonicalisation pair
-  return r;
-}
-__device__ __forceinline__ double fast_exp(double x) {
-  x = fmax_raw(x, -800.0);                       // also maps -inf to exp -> 0
-  const double k = __builtin_rint(x * 1.4426950408889634074);
-  double r = fma(k, -6.93147180369123816490e-01, x);
-  r = fma(k, -1.90821492927058770002e-10, r);
-  double p = 1.0 / 479001600.0;                  // Taylor to r^12: |r| <= 0.3466 -> 1.7e-16
-  p = fma(p, r, 1.0 / 39916800.0);
-  p = fma(p, r, 1.0 / 3628800.0);
-  p = fma(p, r, 1.0 / 362880.0);
-  p = fma(p, r, 1.0 / 40320.0);
-  p = fma(p, r, 1.0 / 5040.0);
-  p = fma(p, r, 1.0 / 720.0);
-  p = fma(p, r, 1.0 / 120.0);
-  p = fma(p, r, 1.0 / 24.0);
-  p = fma(p, r, 1.0 / 6.0);
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
-  return ldexp(p, (int)k);
-}
-__device__ __forceinline__ double fast_log(double x) {   // x >= 0, finite
-  int e;
-  double m = frexp(x, &e);                       // m in [0.5, 1)
-  const bool lo = m < 0.70710678118654752440;
-  m = lo ? m + m : m;
-  e = lo ? e - 1 : e;
-  const double f = m - 1.0;
-  const double s = f / (2.0 + f);
-  const double z = s * s;                        // z <= 0.0295
-  double p = 1.0 / 23.0;
-  p = fma(p, z, 1.0 / 21.0);
-  p = fma(p, z, 1.0 / 19.0);
-  p = fma(p, z, 1.0 / 17.0);
-  p = fma(p, z, 1.0 / 15.0);
-  p = fma(p, z, 1.0 / 13.0);
-  p = fma(p, z, 1.0 / 11.0);
-  p = fma(p, z, 1.0 / 9.0);
-  p = fma(p, z, 1.0 / 7.0);
-  p = fma(p, z, 1.0 / 5.0);
-  p = fma(p, z, 1.0 / 3.0);
-  // log(m) = 2s + 2s*z*p ; log(x) = e*ln2_hi + (log(m) + e*ln2_lo)
-  const double two_s = s + s;
-  const double ed = (double)e;
-  const double t = fma(two_s * z, p, fma(ed, 1.90821492927058770002e-10, two_s));
-  const double r = fma(ed, 6.93147180369123816490e-01, t);
-  return x > 0.0 ? r : -INFINITY;               // log(0) = -inf (an unreachable state)
-}
-
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov_f64(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
-// all-lanes reductions over each row of 16 lanes (quad_perm xor1, xor2, row_half_mirror, row_mirror)
-__device__ __forceinline__ double row16_sum(double v) {
-  v += dpp_mov_f64<0xB1>(v);
-  v += dpp_mov_f64<0x4E>(v);
-  v += dpp_mov_f64<0x141>(v);
-  v += dpp_mov_f64<0x140>(v);
-  return v;
-}
-__device__ __forceinline__ double row16_max(double v) {
-  v = fmax_raw(v, dpp_mov_f64<0xB1>(v));
-  v = fmax_raw(v, dpp_mov_f64<0x4E>(v));
-  v = fmax_raw(v, dpp_mov_f64<0x141>(v));
-  v = fmax_raw(v, dpp_mov_f64<0x140>(v));
-  return v;
-}
-__device__ __forceinline__ double wave64_max_fast(double v) {
-  v = row16_max(v);
-  v = fmax_raw(v, __shfl_xor(v, 16, 64));
-  v = fmax_raw(v, __shfl_xor(v, 32, 64));
-  return v;
-}
-
-// ------------------------------------------------------------------------------------
-//  K2a: forward / backward messages, one wavefront per (window, direction), K <= KMAX<=64.
-//       The transition column (fwd) / row (bwd) of exp(ltran) lives in registers,
-//       the shifted probabilities p_i are exchanged through LDS.
-//       grid (B, ndir), block 64.
-// ------------------------------------------------------------------------------------
-template <int KMAX>
-__global__ __launch_bounds__(64) void k_fb_wave(
-    const double* __restrict__ ll, const double* __restrict__ Aexp,
-    const double* __restrict__ mod_init, int Lm, int K, int dir0,
-    double* __restrict__ la_out, double* __restrict__ lb_out) {
-  __shared__ double p_s[2][KMAX];
-  const int b = blockIdx.x, dir = dir0 + blockIdx.y, j = threadIdx.x;
-  const bool valid = j < K;
-  double a[KMAX];
-#pragma unroll
-  for (int i = 0; i < KMAX; ++i) {
-    double v = 0.0;
-    if (valid && i < K) v = (dir == 0) ? Aexp[i * K + j] : Aexp[j * K + i];
-    a[i] = v;
-  }
-  const double* llb = ll + (size_t)b * Lm * K;
-  const double NEG_INF = -INFINITY;
-  int cur = 0;
-  if (dir == 0) {
-    double* out = la_out + (size_t)b * Lm * K;
-    double la = valid ? mod_init[j] + llb[j] : NEG_INF;
-    if (valid) out[j] = la;
-    double llnext = (valid && Lm > 1) ? llb[K + j] : 0.0;
-    for (int t = 1; t < Lm; ++t) {
-      const double llt = llnext;
-      if (valid && t + 1 < Lm) llnext = llb[(size_t)(t + 1) * K + j];
-      const double m = wave64_max_fast(la);
-      const double p = valid ? fast_exp(la - m) : 0.0;
-      if (j < KMAX) p_s[cur][j] = p;
-      __syncthreads();
-      double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-      for (int i = 0; i < KMAX; i += 2) {
-        s0 = fma(p_s[cur][i], a[i], s0);
-        s1 = fma(p_s[cur][i + 1], a[i + 1], s1);
-      }
-      cur ^= 1;
-      la = valid ? fast_log(s0 + s1) + m + llt : NEG_INF;
-      if (valid) out[(size_t)t * K + j] = la;
-    }
-  } else {
-    double* out = lb_out + (size_t)b * Lm * K;
-    double lb = 0.0;
-    if (valid) out[(size_t)(Lm - 1) * K + j] = 0.0;
-    double llnext = valid ? llb[(size_t)(Lm - 1) * K + j] : 0.0;
-    for (int t = Lm - 2; t >= 0; --t) {
-      const double u = valid ? lb + llnext : NEG_INF;
-      if (valid && t >= 1) llnext = llb[(size_t)t * K + j];
-      const double m = wave64_max_fast(u);
-      const double p = valid ? fast_exp(u - m) : 0.0;
-      if (j < KMAX) p_s[cur][j] = p;
-      __syncthreads();
-      double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-      for (int i = 0; i < KMAX; i += 2) {
-        s0 = fma(p_s[cur][i], a[i], s0);
-        s1 = fma(p_s[cur][i + 1], a[i + 1], s1);
-      }
-      cur ^= 1;
-      lb = fast_log(s0 + s1) + m;
-      if (valid) out[(size_t)t * K + j] = lb;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------
-//  K2b: forward / backward, generic K (block = roundup(K,64) threads, thread = state).
-//       Transition matrix (fwd: A, bwd: A^T) is read from LDS when it fits, else HBM/L2.
-// ------------------------------------------------------------------------------------
-__device__ __forceinline__ double block_max(double v, double* red, int nw) {
-  v = wave_max(v);
-  if (nw == 1) return v;
-  const int w = threadIdx.x >> 6;
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[w] = v;
-  __syncthreads();
-  double m = red[0];
-  for (int i = 1; i < nw; ++i) m = fmax(m, red[i]);
-  return m;
-}
-
-__global__ void k_fb_generic(const double* __restrict__ ll, const double* __restrict__ Aexp,
-                             const double* __restrict__ AexpT,
-                             const double* __restrict__ mod_init, int Lm, int K, int dir0,
-                             int m_in_lds, double* __restrict__ la_out,
-                             double* __restrict__ lb_out) {
-  extern __shared__ double sm[];
-  double* p_s = sm;            // [2][K]
-  double* red = sm + 2 * K;    // [16]
-  double* M_s = red + 16;      // [K][K] if m_in_lds
-  const int b = blockIdx.x, dir = dir0 + blockIdx.y, j = threadIdx.x;
-  const int nw = (blockDim.x + 63) >> 6;
-  const bool valid = j < K;
-  // M[i][j] such that out_j = sum_i p_i M[i][j]:  fwd M = A ; bwd M[jj][i] = A[i][jj] = A^T
-  const double* Mg = (dir == 0) ? Aexp : AexpT;
-  const double* M = Mg;
-  if (m_in_lds) {
-    for (int e = threadIdx.x; e < K * K; e += blockDim.x) M_s[e] = Mg[e];
-    M = M_s;
-  }
-  __syncthreads();
-  const double* llb = ll + (size_t)b * Lm * K;
-  const double NEG_INF = -INFINITY;
-  int cur = 0;
-  if (dir == 0) {
-    double* out = la_out + (size_t)b * Lm * K;
-    double la = valid ? mod_init[j] + llb[j] : NEG_INF;
-    if (valid) out[j] = la;
-    for (int t = 1; t < Lm; ++t) {
-      const double llt = valid ? llb[(size_t)t * K + j] : 0.0;
-      const double m = block_max(la, red, nw);
-      if (valid) p_s[cur * K + j] = exp(la - m);
-      __syncthreads();
-      double s = 0.0;
-      if (valid)
-        for (int i = 0; i < K; ++i) s = fma(p_s[cur * K + i], M[(size_t)i * K + j], s);
-      cur ^= 1;
-      la = valid ? log(s) + m + llt : NEG_INF;
-      if (valid) out[(size_t)t * K + j] = la;
-    }
-  } else {
-    double* out = lb_out + (size_t)b * Lm * K;
-    double lb = 0.0;
-    if (valid) out[(size_t)(Lm - 1) * K + j] = 0.0;
-    for (int t = Lm - 2; t >= 0; --t) {
-      const double u = valid ? lb + llb[(size_t)(t + 1) * K + j] : NEG_INF;
-      const double m = block_max(u, red, nw);
-      if (valid) p_s[cur * K + j] = exp(u - m);
-      __syncthreads();
-      double s = 0.0;
-      if (valid)
-        for (int i = 0; i < K; ++i) s = fma(p_s[cur * K + i], M[(size_t)i * K + j], s);
-      cur ^= 1;
-      lb = log(s) + m;
-      if (valid) out[(size_t)t * K + j] = lb;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------
-//  K2c/K2d: forward and backward(+posterior) sweeps as batched fp64 MFMA mat-mats.
-//  A workgroup owns 16 windows (the M dimension of v_mfma_f64_16x16x4_f64); wave s owns
-//  the 16-state tile n0=16*s (K <= 64 -> NW = Kp/16 waves).  Per time step
-//      out[w][j] = sum_i P[w][i] * M[i][j],   P = exp(prev message - shift[w]) via LDS,
-//  M = exp(ltran) (forward) / its transpose (backward) held in registers as the B operand.
-//  The per-window shift is c_t = c_{t-1} + ln2*frexp_exp(sum_i P_{t-1}[i]) + max_j ll_t[j]:
-//  an upper bound of max_j message_t[j] that is at most ~|min ltran| above it, built only
-//  from tile reductions of the PREVIOUS step, so there is one barrier per step and no
-//  reduction on the critical path.  sum_t LSE_j lalpha (quirk Q4) is accumulated as a
-//  running (mantissa, exponent) product of the per-step sums.
-// ------------------------------------------------------------------------------------
-#define LN2_D 0.69314718055994530942
-
-template <int NW>
-struct FbShared {
-  static constexpr int Kp = 16 * NW;
-  static constexpr int PS = Kp + 2;
-  double __attribute__((aligned(16))) P[2][16][PS];
-  // tile reductions: every lane of a 16-lane row holds the same value after the DPP
-  // reduction and writes its own slot (branch-free, conflict-free); readers use slot 0
-  double tsum[2][16][NW][16];
-  double tmll[2][16][NW][16];
-  double tq[2][16][NW][16];
-};
-
-template <int NW>
-__device__ __forceinline__ double4_t fb_matmul(const FbShared<NW>& sh, int cur, int li, int lg,
-                                               const double (&Bv)[4 * NW]) {
-  constexpr int KS = 4 * NW;
-  double4_t a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
-  const double* prow = &sh.P[cur][li][2 * lg];
-#pragma unroll
-  for (int c = 0; c < KS / 2; c += 2) {
-    const double2 x = *reinterpret_cast<const double2*>(prow + 8 * c);
-    const double2 y = *reinterpret_cast<const double2*>(prow + 8 * (c + 1));
-    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, Bv[2 * c], a0, 0, 0, 0);
-    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, Bv[2 * c + 1], a1, 0, 0, 0);
-    a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(y.x, Bv[2 * c + 2], a2, 0, 0, 0);
-    a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(y.y, Bv[2 * c + 3], a3, 0, 0, 0);
-  }
-  return (a0 + a1) + (a2 + a3);
-}
-
-// FULL: K == 16*NW (no padded states).  Windows beyond B are clamped to B-1 (they redo the
-// last window and rewrite identical values), so the time loop has no per-lane predicate
-// and compiles to a single basic block: loads issued two steps ahead are waited for with a
-// counted vmcnt instead of a full drain.
-template <int NW, bool FULL>
-__global__ __launch_bounds__(64 * NW) void k_fwd_mfma(
-    const double* __restrict__ ll, const double* __restrict__ Aexp,
-    const double* __restrict__ mod_init, int B, int Lm, int K, double* __restrict__ la_out,
-    double* __restrict__ local_lb, double* __restrict__ logz) {
-  // Critical path per step: LDS read -> MFMA -> p = acc * w -> LDS write -> row sum -> barrier.
-  // w = exp(ll_t - d) (d = shift increment) does not depend on the MFMA result and the
-  // lalpha store (log) of step t is issued during step t+1, so every transcendental runs
-  // in the shadow of the matrix pipe.
-  constexpr int KS = 4 * NW;
-  __shared__ FbShared<NW> sh;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int li = lane & 15, lg = lane >> 4;
-  const int j = wave * 16 + li;
-  const bool vj = FULL || (j < K);
-  const int jc = vj ? j : 0;
-  const int b0 = blockIdx.x * 16;
-  double Bv[KS];
-#pragma unroll
-  for (int kk = 0; kk < KS; ++kk) {
-    const int k = 8 * (kk >> 1) + 2 * lg + (kk & 1);
-    Bv[kk] = (k < K && vj) ? Aexp[(size_t)k * K + jc] : 0.0;
-  }
-  size_t base[4];
-  int gwc[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int gw = b0 + lg + 4 * r;
-    gwc[r] = gw < B ? gw : B - 1;
-    base[r] = (size_t)gwc[r] * Lm * K + jc;
-  }
-  const double NEG_INF = -INFINITY;
-  double c[4], csum[4], mant[4], lln[4], ll2[4];  // ll_{t+1}, ll_{t+2}: two steps in flight
-  double pacc[4], pc[4], pll[4];                  // delayed lalpha store of the previous step
-  int ex[4];
-  const size_t K1 = (size_t)K * (Lm > 1 ? 1 : 0), K2 = (size_t)K * (Lm > 2 ? 2 : (Lm > 1 ? 1 : 0));
-  // ---- t = 0
-  {
-    double tm[4], la0[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const double x0 = mod_init[jc] + ll[base[r]];
-      la0[r] = vj ? x0 : NEG_INF;
-      if (vj) la_out[base[r]] = la0[r];
-      tm[r] = row16_max(la0[r]);
-      const double x1 = ll[base[r] + K1], x2 = ll[base[r] + K2];
-      lln[r] = vj ? x1 : NEG_INF;
-      ll2[r] = vj ? x2 : NEG_INF;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sh.tq[0][lg + 4 * r][wave][li] = tm[r];
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int w = lg + 4 * r;
-      double m = sh.tq[0][w][0][0];
-#pragma unroll
-      for (int s2 = 1; s2 < NW; ++s2) m = fmax(m, sh.tq[0][w][s2][0]);
-      c[r] = m;
-      csum[r] = m;
-      mant[r] = 1.0;
-      ex[r] = 0;
-      const double pv = vj ? exp(la0[r] - m) : 0.0;
-      sh.P[0][w][j] = pv;
-      sh.tsum[0][w][wave][li] = row16_sum(pv);
-      sh.tmll[1][w][wave][li] = row16_max(lln[r]);
-      pacc[r] = 1.0; pc[r] = 0.0; pll[r] = la0[r];   // re-stores lalpha[0] at t = 1
-    }
-    __syncthreads();
-  }
-  for (int t = 1; t < Lm; ++t) {
-    const int cur = (t - 1) & 1, nxt = t & 1;
-    const size_t o2 = (size_t)(t + 2 < Lm ? t + 2 : Lm - 1) * K;
-    double llv[4], wgt[4], cn[4];
-    // (a) everything that does not need the MFMA result
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int w = lg + 4 * r;
-      llv[r] = lln[r];
-      lln[r] = ll2[r];   // loaded one step ago: its row max below does not wait on HBM
-      const double x2 = ll[base[r] + o2];
-      ll2[r] = vj ? x2 : NEG_INF;
-      double tot = sh.tsum[cur][w][0][0], mll = sh.tmll[nxt][w][0][0];
-#pragma unroll
-      for (int s2 = 1; s2 < NW; ++s2) {
-        tot += sh.tsum[cur][w][s2][0];
-        mll = fmax_raw(mll, sh.tmll[nxt][w][s2][0]);
-      }
-      int e1, e2;
-      mant[r] = frexp(mant[r] * tot, &e1);
-      ex[r] += e1;
-      (void)frexp(tot, &e2);
-      const double d = (double)e2 * LN2_D + mll;
-      cn[r] = c[r] + d;
-      wgt[r] = vj ? fast_exp(llv[r] - d) : 0.0;
-    }
-    // (b) matrix pipe
-    const double4_t acc = fb_matmul<NW>(sh, cur, li, lg, Bv);
-    // (c) delayed lalpha store of step t-1 (independent of acc: overlaps the MFMAs)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const double lav = fast_log(pacc[r]) + pc[r] + pll[r];
-      if (FULL || vj) la_out[base[r] + (size_t)(t - 1) * K] = lav;
-    }
-    // (d) critical tail
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int w = lg + 4 * r;
-      const double pv = acc[r] * wgt[r];
-      sh.P[nxt][w][j] = pv;
-      sh.tsum[nxt][w][wave][li] = row16_sum(pv);
-      sh.tmll[cur][w][wave][li] = row16_max(lln[r]);
-      pacc[r] = acc[r]; pc[r] = c[r]; pll[r] = llv[r];
-      c[r] = cn[r];
-      csum[r] += cn[r];
-    }
-    __syncthreads();
-  }
-  if (Lm > 1) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (vj) la_out[base[r] + (size_t)(Lm - 1) * K] = fast_log(pacc[r]) + pc[r] + pll[r];
-  }
-  // ---- epilogue: LSE of the last step, per-window totals
-  if (wave == 0 && li == 0) {
-    const int last = (Lm - 1) & 1;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int w = lg + 4 * r;
-      double tot = sh.tsum[last][w][0][0];
-#pragma unroll
-      for (int s2 = 1; s2 < NW; ++s2) tot += sh.tsum[last][w][s2][0];
-      const double lz = c[r] + log(tot);
-      int e1;
-      const double mm = frexp(mant[r] * tot, &e1);
-      local_lb[gwc[r]] = csum[r] + log(mm) + (double)(ex[r] + e1) * LN2_D;
-      logz[gwc[r]] = lz;
-    }
-  }
-}
-
-template <int NW, bool FULL, bool WANT_LB>
-__global__ __launch_bounds__(64 * NW) void k_bwd_mfma(
-    const double* __restrict__ ll, const double* __restrict__ AexpT,
-    const double* __restrict__ la_in, const double* __restrict__ logz, int B, int Lm, int K,
-    double* __restrict__ lb_out, double* __restrict__ q_out) {
-  constexpr int KS = 4 * NW;
-  __shared__ FbShared<NW> sh;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int li = lane & 15, lg = lane >> 4;
-  const int j = wave * 16 + li;
-  const bool vj = FULL || (j < K);
-  const int jc = vj ? j : 0;
-  const int b0 = blockIdx.x * 16;
-  double Bv[KS];
-#pragma unroll
-  for (int kk = 0; kk < KS; ++kk) {
-    const int k = 8 * (kk >> 1) + 2 * lg + (kk & 1);
-    Bv[kk] = (k < K && vj) ? AexpT[(size_t)k * K + jc] : 0.0;
-  }
-  size_t base[4];
-  double sz[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int gw = b0 + lg + 4 * r;
-    const int g = gw < B ? gw : B - 1;
-    base[r] = (size_t)g * Lm * K + jc;
-    sz[r] = logz[g];
-  }
-  const double NEG_INF = -INFINITY;
-  double c[4], eprev[4], lln[4], lan[4], ll2[4], la2[4];
-  const size_t top = (size_t)(Lm - 1) * K;
-  const size_t K1 = (size_t)K * (Lm > 1 ? 1 : 0), K2 = (size_t)K * (Lm > 2 ? 2 : (Lm > 1 ? 1 : 0));
-  // ---- t = Lm-1: lbeta = 0
-  {
-    double tm[4], u[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const double x0 = ll[base[r] + top], a0 = la_in[base[r] + top];
-      const double x1 = ll[base[r] + top - K1], x2 = ll[base[r] + top - K2];
-      const double a1 = la_in[base[r] + top - K1];
-      la2[r] = la_in[base[r] + top - K2];
-      if (WANT_LB && vj) lb_out[base[r] + top] = 0.0;
-      u[r] = vj ? x0 : NEG_INF;
-      tm[r] = row16_max(u[r]);
-      eprev[r] = vj ? exp(a0 - sz[r]) : 0.0;
-      lln[r] = vj ? x1 : NEG_INF;
-      ll2[r] = vj ? x2 : NEG_INF;
-      lan[r] = a1;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sh.tq[1][lg + 4 * r][wave][li] = tm[r];
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int w = lg + 4 * r;
-      double m = sh.tq[1][w][0][0];
-#pragma unroll
-      for (int s2 = 1; s2 < NW; ++s2) m = fmax(m, sh.tq[1][w][s2][0]);
-      c[r] = m;
-      const double pv = vj ? exp(u[r] - m) : 0.0;
-      sh.P[0][w][j] = pv;
-      sh.tsum[0][w][wave][li] = row16_sum(pv);
-      sh.tmll[1][w][wave][li] = row16_max(lln[r]);
-      sh.tq[0][w][wave][li] = row16_sum(eprev[r]);
-    }
-    __syncthreads();
-  }
-  int step = 1;
-  for (int t = Lm - 2; t >= 0; --t, ++step) {
-    const int cur = (step - 1) & 1, nxt = step & 1;
-    const size_t o2 = (size_t)(t >= 2 ? t - 2 : 0) * K;
-    double wp[4], we[4], cn[4], rq[4];
-    // (a) independent of the MFMA result
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int w = lg + 4 * r;
-      const double llv = lln[r], lav = lan[r];
-      lln[r] = ll2[r];
-      const double x2 = ll[base[r] + o2];
-      ll2[r] = vj ? x2 : NEG_INF;
-      lan[r] = la2[r];
-      la2[r] = la_in[base[r] + o2];
-      double tot = sh.tsum[cur][w][0][0], mll = sh.tmll[nxt][w][0][0], totq = sh.tq[cur][w][0][0];
-#pragma unroll
-      for (int s2 = 1; s2 < NW; ++s2) {
-        tot += sh.tsum[cur][w][s2][0];
-        mll = fmax_raw(mll, sh.tmll[nxt][w][s2][0]);
-        totq += sh.tq[cur][w][s2][0];
-      }
-      rq[r] = 1.0 / totq;
-      int e2;
-      (void)frexp(tot, &e2);
-      const double d = (double)e2 * LN2_D + mll;
-      cn[r] = c[r] + d;
-      wp[r] = vj ? fast_exp(llv - d) : 0.0;                          // P'_t = acc * wp
-      we[r] = vj ? fast_exp(fmin(lav + c[r] - sz[r], 700.0)) : 0.0;  // e_t  = acc * we
-    }
-    // (b) matrix pipe
-    const double4_t acc = fb_matmul<NW>(sh, cur, li, lg, Bv);
-    // (c) posterior of row t+1, normalised like hmmbase.py:226-229 (overlaps the MFMAs)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const double qv = eprev[r] * rq[r];
-      if (FULL || vj) q_out[base[r] + (size_t)(t + 1) * K] = qv;
-    }
-    // (d) critical tail
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int w = lg + 4 * r;
-      const double pv = acc[r] * wp[r];
-      sh.P[nxt][w][j] = pv;
-      eprev[r] = acc[r] * we[r];
-      sh.tsum[nxt][w][wave][li] = row16_sum(pv);
-      sh.tq[nxt][w][wave][li] = row16_sum(eprev[r]);
-      sh.tmll[cur][w][wave][li] = row16_max(lln[r]);
-    }
-    if (WANT_LB) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double lbv = fast_log(acc[r]) + c[r];
-        if (FULL || vj) lb_out[base[r] + (size_t)t * K] = lbv;
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) c[r] = cn[r];
-    __syncthreads();
-  }
-  // ---- flush the posterior of row 0
-  {
-    const int last = (step - 1) & 1;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int w = lg + 4 * r;
-      double totq = sh.tq[last][w][0][0];
-#pragma unroll
-      for (int s2 = 1; s2 < NW; ++s2) totq += sh.tq[last][w][s2][0];
-      if (vj) q_out[base[r]] = eprev[r] / totq;
-    }
-  }
-}
-
-__global__ void k_sum_lb(const double* __restrict__ local_lb, int B, double* __restrict__ lb_total) {
-  __shared__ double red[256];
-  double acc = 0.0;
-  for (int b = threadIdx.x; b < B; b += blockDim.x) acc += local_lb[b];
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int o = 128; o >= 1; o >>= 1) {
-    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *lb_total = red[0];
-}
-
-// ------------------------------------------------------------------------------------
-//  K3: posterior marginals q = softmax_k(la+lb) and per-row LSE_k(la) partial sums.
-//      grid (B*nseg), block 256 = 4 waves, one wave per row; seg = PS_ROWS rows.
-// ------------------------------------------------------------------------------------
-#define PS_ROWS 256
-template <int KPL>  // states per lane (K <= 64*KPL)
-__global__ __launch_bounds__(256) void k_posterior(const double* __restrict__ la,
-                                                   const double* __restrict__ lb, int Lm,
-                                                   int K, int nseg,
-                                                   double* __restrict__ q,
-                                                   double* __restrict__ lse_part) {
-  __shared__ double wsum[4];
-  const int b = blockIdx.x / nseg, seg = blockIdx.x - b * nseg;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int t0 = seg * PS_ROWS;
-  const int t1 = min(Lm, t0 + PS_ROWS);
-  double lse_acc = 0.0;
-  for (int t = t0 + wave; t < t1; t += 4) {
-    const size_t base = ((size_t)b * Lm + t) * K;
-    double u[KPL], a[KPL];
-    double mu = -INFINITY, ma = -INFINITY;
-#pragma unroll
-    for (int c = 0; c < KPL; ++c) {
-      const int k = lane + 64 * c;
-      if (k < K) {
-        a[c] = la[base + k];
-        u[c] = a[c] + lb[base + k];
-      } else {
-        a[c] = -INFINITY;
-        u[c] = -INFINITY;
-      }
-      mu = fmax(mu, u[c]);
-      ma = fmax(ma, a[c]);
-    }
-    mu = wave_max(mu);
-    ma = wave_max(ma);
-    double su = 0.0, sa = 0.0;
-#pragma unroll
-    for (int c = 0; c < KPL; ++c) {
-      u[c] = exp(u[c] - mu);
-      su += u[c];
-      sa += exp(a[c] - ma);
-    }
-    su = wave_sum(su);
-    sa = wave_sum(sa);
-#pragma unroll
-    for (int c = 0; c < KPL; ++c) {
-      const int k = lane + 64 * c;
-      if (k < K) q[base + k] = u[c] / su;
-    }
-    lse_acc += ma + log(sa);
-  }
-  if (lane == 0) wsum[wave] = lse_acc;
-  __syncthreads();
-  if (threadIdx.x == 0)
-    lse_part[(size_t)b * nseg + seg] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-}
-
-// ------------------------------------------------------------------------------------
-//  K4a: statistics, VALU outer-product form (generic fallback).  One wave per
-//       (row chunk, 16-feature chunk, 64-state chunk); lane = state.
-//       feature f < Fp : phi = x~_a x~_b (0 on masked rows);  f >= Fp : phi = q[prev][f-Fp]
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_stats_outer(
-    const double* __restrict__ obs, const uint8_t* __restrict__ mask,
-    const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K, int Kp,
-    int Fp, int F, const int* __restrict__ fab, const double* __restrict__ q,
-    int64_t rows_per_chunk, uint32_t flags, int Lq, int off, double* __restrict__ part) {
-  // rows g enumerate (window b, inner step t<Lm); q row = b*Lq+off+t, obs row = starts[b]+off+t
-  const int lane = threadIdx.x;
-  const int f0 = blockIdx.y * 16;
-  const int k = blockIdx.z * 64 + lane;
-  const int Ftot = Fp + Kp;
-  const int64_t g0 = (int64_t)blockIdx.x * rows_per_chunk;
-  const int64_t g1 = imin64(nrows, g0 + rows_per_chunk);
-  double acc[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.0;
-  const bool is_trans = f0 >= Fp;
-  for (int64_t g = g0; g < g1; ++g) {
-    const int64_t bwin = g / Lm;
-    const int64_t t = g - bwin * Lm;
-    const int64_t qrow = bwin * Lq + off + t;
-    const double qk = (k < K) ? q[qrow * K + k] : 0.0;
-    if (!is_trans) {
-      const int64_t orow = starts[bwin] + off + t;
-      if (mask && mask[orow]) continue;
-      const double* x = obs + orow * D;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int f = f0 + i;
-        double phi = 0.0;
-        if (f < F) {
-          const int ab = fab[f];
-          const int a = ab & 0xffff, b = ab >> 16;
-          const double xa = (a < D) ? x[a] : 1.0;
-          const double xb = (b < D) ? x[b] : 1.0;
-          phi = xa * xb;
-        }
-        acc[i] = fma(phi, qk, acc[i]);
-      }
-    } else {
-      int64_t gp;
-      if (t > 0) gp = qrow - 1;
-      else if (flags & SVIHMM_TRANS_WRAP) gp = qrow + Lm - 1;
-      else continue;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int ii = f0 - Fp + i;
-        const double phi = (ii < K) ? q[gp * K + ii] : 0.0;
-        acc[i] = fma(phi, qk, acc[i]);
-      }
-    }
-  }
-  if (k < Kp) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-      part[((size_t)blockIdx.x * Ftot + f0 + i) * Kp + k] = acc[i];
-  }
-}
-
-// ------------------------------------------------------------------------------------
-//  K4b: statistics as an fp64 MFMA GEMM  out[Ftot x Kp] = Phi^T[Ftot x rows] * q[rows x Kp]
-//       Per workgroup: 4 waves, each MT m-tiles (16 features) x NT n-tiles (16 states);
-//       rows of the chunk staged through LDS in blocks of ST_RB.
-//       grid (nchunk, ceil(Ftot/16 / (4*MT)), Kp/(16*NT)), block 256.
-// ------------------------------------------------------------------------------------
-#define ST_RB 32
-template <int MT, int NT>
-__global__ __launch_bounds__(256) void k_stats_mfma(
-    const double* __restrict__ obs, const uint8_t* __restrict__ mask,
-    const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K, int Kp,
-    int Fp, int F, const int* __restrict__ fab, const double* __restrict__ q,
-    int64_t rows_per_chunk, uint32_t flags, int Lq, int off, double* __restrict__ part,
-    int mt_base) {
-  extern __shared__ double smem[];
-  const int DS = (D + 2) | 1;
-  const int QS = 16 * NT + 1;  // padded q row stride
-  double* xs = smem;                  // [ST_RB][DS]   augmented, masked rows zeroed
-  double* qs = xs + ST_RB * DS;       // [ST_RB][QS]   q[t][n0..]
-  double* qp = qs + ST_RB * QS;       // [ST_RB][Kp+1] q[prev(t)][all states] (transition tiles)
-  const int QPS = Kp + 1;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, lg = lane >> 4;
-  const int Ftot = Fp + Kp;
-  const int mt0 = mt_base + (blockIdx.y * 4 + wave) * MT;  // first m-tile of this wave
-  const int n0 = blockIdx.z * 16 * NT;
-  const int wg_m0 = (mt_base + blockIdx.y * 4 * MT) * 16, wg_m1 = wg_m0 + 4 * MT * 16;
-  const bool need_x = wg_m0 < Fp;
-  const bool need_qp = wg_m1 > Fp;
-
-  // per-lane feature descriptors for each m-tile (constant for the whole kernel)
-  int fa[MT], fb[MT], ftype[MT];  // ftype 0: emission feature, 1: transition
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const int f = (mt0 + m) * 16 + li;
-    if (f < F) {
-      const int ab = fab[f];
-      fa[m] = ab & 0xffff; fb[m] = ab >> 16; ftype[m] = 0;
-    } else if (f >= Fp && f < Fp + K) {
-      fa[m] = f - Fp; fb[m] = 0; ftype[m] = 1;
-    } else if (f >= Fp) {
-      fa[m] = Kp; fb[m] = 0; ftype[m] = 1;   // qp[r][Kp] is a zero column
-    } else {
-      fa[m] = D + 1; fb[m] = D + 1; ftype[m] = 0;  // zero slot
-    }
-  }
-  double4_t acc[MT][NT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int n = 0; n < NT; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
-
-  const int64_t c0 = (int64_t)blockIdx.x * rows_per_chunk;
-  const int64_t c1 = imin64(nrows, c0 + rows_per_chunk);
-  for (int64_t s0 = c0; s0 < c1; s0 += ST_RB) {
-    __syncthreads();
-    // ---- stage ST_RB rows
-    if (need_x) {
-      for (int e = tid; e < ST_RB * (D + 2); e += 256) {
-        const int r = e / (D + 2), i = e - r * (D + 2);
-        const int64_t g = s0 + r;
-        double v = 0.0;
-        if (g < c1) {
-          const int64_t bw = g / Lm;
-          const int64_t orow = starts[bw] + off + (g - bw * Lm);
-          const bool msk = mask && mask[orow];
-          if (!msk) v = (i < D) ? obs[orow * D + i] : (i == D ? 1.0 : 0.0);
-        }
-        xs[r * DS + i] = v;
-      }
-    }
-    for (int e = tid; e < ST_RB * 16 * NT; e += 256) {
-      const int r = e / (16 * NT), c = e - r * (16 * NT);
-      const int64_t g = s0 + r;
-      const int k = n0 + c;
-      double v = 0.0;
-      if (g < c1 && k < K) {
-        const int64_t bw = g / Lm;
-        v = q[(bw * Lq + off + (g - bw * Lm)) * K + k];
-      }
-      qs[r * QS + c] = v;
-    }
-    if (need_qp) {
-      for (int e = tid; e < ST_RB * (Kp + 1); e += 256) {
-        const int r = e / (Kp + 1), c = e - r * (Kp + 1);
-        const int64_t g = s0 + r;
-        double v = 0.0;
-        if (g < c1 && c < K) {
-          const int64_t bwin = g / Lm;
-          const int64_t t = g - bwin * Lm;
-          const int64_t qrow = bwin * Lq + off + t;
-          if (t > 0) v = q[(qrow - 1) * K + c];
-          else if (flags & SVIHMM_TRANS_WRAP) v = q[(qrow + Lm - 1) * K + c];
-        }
-        qp[r * QPS + c] = v;
-      }
-    }
-    __syncthreads();
-    // ---- ST_RB/4 k-steps of 4 rows
-#pragma unroll 2
-    for (int ks = 0; ks < ST_RB / 4; ++ks) {
-      const int r = ks * 4 + lg;
-      double Bv[NT];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) Bv[n] = qs[r * QS + n * 16 + li];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        double A;
-        if ((mt0 + m) * 16 < Fp) A = xs[r * DS + fa[m]] * xs[r * DS + fb[m]];  // wave-uniform
-        else A = qp[r * QPS + fa[m]];
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(A, Bv[n], acc[m][n], 0, 0, 0);
-      }
-    }
-  }
-  // ---- write partials: C[row=(l>>4)+4r -> feature][col=l&15 -> state]
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int f = (mt0 + m) * 16 + lg + 4 * r;
-      if (f < Ftot) {
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const int k = n0 + n * 16 + li;
-          part[((size_t)blockIdx.x * Ftot + f) * Kp + k] = acc[m][n][r];
-        }
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------
-//  K4c: statistics GEMM, software-pipelined, VGPR-form accumulators (K <= 64).
-//  Same math as K4b.  Design points:
-//   * fp64 MFMA with AGPR accumulators runs at ~63 % of the VGPR-form rate on gfx950
-//     (tools/peak_probe.py: 49 vs 77.6 TF/s), so the accumulators must fit the 256
-//     architected VGPRs: a workgroup is 4 m-groups x NSPLIT n-groups of waves, each wave
-//     MT x NTW tiles (5 x 2 x 8 = 80 accumulator registers at K = 64);
-//   * the next 32-row stage is fetched from HBM into registers while the current stage
-//     runs on the matrix pipe (global -> reg early, reg -> LDS after the compute);
-//   * row bookkeeping (obs row, q row, wrap predecessor, mask) is computed once per stage
-//     by 32 lanes instead of per element (no integer divisions in the copy loops);
-//   * the 36 emission + 4 transition tiles of K=64, D=32 split into two balanced
-//     workgroup passes, so q is read twice.
-//  grid (nchunk, ceil(Ftot/16 / (4*MT))), block 256*NSPLIT.
-// ------------------------------------------------------------------------------------
-struct StRow {
-  long long orow;   // obs row, -1: out of range or masked (x~ = 0)
-  long long qrow;   // q row, -1: out of range
-  long long prow;   // predecessor q row, -1: none
-};
-
-template <int MT, int NTW, int NSPLIT, int XK>
-__global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma3(
-    const double* __restrict__ obs, const uint8_t* __restrict__ mask,
-    const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K, int Fp, int F,
-    const int* __restrict__ fab, const double* __restrict__ q, int64_t rows_per_chunk,
-    uint32_t flags, int Lq, int off, double* __restrict__ part, int KpTot, int mt_limit) {
-  // KpTot: padded state count of the whole problem (partials stride); this workgroup covers
-  // states [blockIdx.z*Kp, +Kp); only m-tiles < mt_limit are produced (K > 64: the
-  // transition tiles are left to k_stats_mfma)
-  constexpr int NT = NTW * NSPLIT;
-  constexpr int Kp = 16 * NT;
-  constexpr int QS = Kp + 1;
-  constexpr int TPR = 8 * NSPLIT;          // staging threads per row
-  constexpr int QK = (Kp + TPR - 1) / TPR;  // q columns per staging thread
-  extern __shared__ double smem[];
-  // One LDS row per time step holds every A-operand source, so that each operand is the
-  // branch-free product row[fa] * row[fb]:
-  //   [0, D)      x (0 on masked rows)        D        1.0 (0 on masked rows)
-  //   D+1  ZERO   0.0                          D+2      ONE = 1.0 (always)
-  //   QP0 + i     q[prev(t), i], i < Kp  (transition features: row[QP0+i] * row[ONE])
-  const int ZERO = D + 1, ONE = D + 2, QP0 = D + 3;
-  const int RS = (QP0 + Kp) | 1;   // odd stride
-  double* rb0 = smem;                    // [2][32][RS]
-  double* qs0 = rb0 + 2 * ST_RB * RS;    // [2][32][QS]
-  StRow* rinfo = reinterpret_cast<StRow*>(qs0 + 2 * ST_RB * QS);  // [4][32]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, lg = lane >> 4;
-  const int mg = wave & 3, ng = wave >> 2;
-  const int Ftot = Fp + KpTot;
-  const int kbase = blockIdx.z * Kp;
-  const int mt0 = (blockIdx.y * 4 + mg) * MT;
-  const int nt0 = ng * NTW;
-  const int wg_m0 = blockIdx.y * 4 * MT * 16, wg_m1 = wg_m0 + 4 * MT * 16;
-  const bool need_x = wg_m0 < Fp;
-  const bool need_qp = wg_m1 > Fp && mt_limit * 16 > Fp;
-  const int sr = tid / TPR, sc = tid % TPR;   // staging role: row sr, columns sc + TPR*k
-
-  int fa[MT], fb[MT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const int f = (mt0 + m) * 16 + li;
-    fa[m] = ZERO; fb[m] = ZERO;
-    if (f < F) { const int ab = fab[f]; fa[m] = ab & 0xffff; fb[m] = ab >> 16; }
-    else if (f >= Fp && f - Fp < K && mt_limit * 16 > Fp) { fa[m] = QP0 + (f - Fp); fb[m] = ONE; }
-  }
-  double4_t acc[MT][NTW];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int n = 0; n < NTW; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
-
-  const int64_t c0 = (int64_t)blockIdx.x * rows_per_chunk;
-  const int64_t c1 = imin64(nrows, c0 + rows_per_chunk);
-  const int nstage = (int)((c1 - c0 + ST_RB - 1) / ST_RB);
-
-  auto row_info = [&](int64_t s0, int buf) {
-    if (tid < ST_RB) {
-      const int64_t g = s0 + tid;
-      StRow ri; ri.orow = -1; ri.qrow = -1; ri.prow = -1;
-      if (g < c1) {
-        const int64_t bw = g / Lm;
-        const int64_t t = g - bw * Lm;
-        ri.qrow = bw * Lq + off + t;
-        const int64_t orow = starts[bw] + off + t;
-        ri.orow = (mask && mask[orow]) ? -1 : orow;
-        if (t > 0) ri.prow = ri.qrow - 1;
-        else if (flags & SVIHMM_TRANS_WRAP) ri.prow = ri.qrow + Lm - 1;
-      }
-      rinfo[buf * ST_RB + tid] = ri;
-    }
-  };
-  double rx[XK], rq[QK], rp[QK];
-  auto fetch = [&](int buf) {
-    const StRow ri = rinfo[buf * ST_RB + sr];
-    if (need_x) {
-#pragma unroll
-      for (int k = 0; k < XK; ++k) {
-        const int c = sc + TPR * k;
-        double v = 0.0;
-        if (ri.orow >= 0) {
-          if (c < D) v = obs[ri.orow * D + c];
-          else if (c == D) v = 1.0;
-        }
-        rx[k] = v;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < QK; ++k) {
-      const int c = sc + TPR * k;
-      rq[k] = (ri.qrow >= 0 && kbase + c < K) ? q[ri.qrow * K + kbase + c] : 0.0;
-    }
-    if (need_qp) {
-#pragma unroll
-      for (int k = 0; k < QK; ++k) {
-        const int c = sc + TPR * k;
-        rp[k] = (ri.prow >= 0 && c < K) ? q[ri.prow * K + c] : 0.0;
-      }
-    }
-  };
-  auto commit = [&](int bufi) {
-    double* rb = rb0 + bufi * ST_RB * RS;
-    double* qs = qs0 + bufi * ST_RB * QS;
-    if (need_x) {
-#pragma unroll
-      for (int k = 0; k < XK; ++k) {
-        const int c = sc + TPR * k;
-        if (c <= D) rb[sr * RS + c] = rx[k];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < QK; ++k) {
-      const int c = sc + TPR * k;
-      if (c < Kp) qs[sr * QS + c] = rq[k];
-    }
-    if (need_qp) {
-#pragma unroll
-      for (int k = 0; k < QK; ++k) {
-        const int c = sc + TPR * k;
-        if (c < Kp) rb[sr * RS + QP0 + c] = rp[k];
-      }
-    }
-  };
-  if (sc == 0) {
-    rb0[sr * RS + ZERO] = 0.0; rb0[sr * RS + ONE] = 1.0;
-    rb0[(ST_RB + sr) * RS + ZERO] = 0.0; rb0[(ST_RB + sr) * RS + ONE] = 1.0;
-  }
-  // Pipeline: LDS tiles are double buffered and there is ONE barrier per 32-row stage.
-  // During stage st every wave also writes stage st+1 (held in registers) into the other
-  // buffer and fetches stage st+2 from HBM; the two waves that share a SIMD do this at
-  // opposite ends of the stage (role B first, role A last), so one of them always feeds
-  // the matrix pipe.  Row bookkeeping runs three stages ahead.
-  const bool roleB = (NSPLIT == 2) && (ng == 1);
-  row_info(c0, 0);
-  row_info(c0 + ST_RB, 1);
-  row_info(c0 + 2 * ST_RB, 2);
-  __syncthreads();
-  fetch(0);
-  commit(0);
-  if (nstage > 1) fetch(1);
-  __syncthreads();
-  for (int st = 0; st < nstage; ++st) {
-    const int cur = st & 1;
-    if (roleB) {
-      if (st + 1 < nstage) commit(cur ^ 1);
-      if (st + 2 < nstage) fetch((st + 2) & 3);
-    }
-    const double* rb = rb0 + cur * ST_RB * RS;
-    const double* qs = qs0 + cur * ST_RB * QS;
-    // k-steps, software pipelined by hand: the LDS reads of k-step ks+1 are issued before
-    // the MFMAs of k-step ks, so their latency is covered by this wave's own matrix work
-    double Bv[NTW], Ax[MT], Ay[MT];
-    {
-      const double* row = rb + lg * RS;
-#pragma unroll
-      for (int n = 0; n < NTW; ++n) Bv[n] = qs[lg * QS + (nt0 + n) * 16 + li];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) { Ax[m] = row[fa[m]]; Ay[m] = row[fb[m]]; }
-    }
-#pragma unroll
-    for (int ks = 0; ks < ST_RB / 4; ++ks) {
-      double Bn[NTW], Axn[MT], Ayn[MT];
-      if (ks + 1 < ST_RB / 4) {
-        const int r = (ks + 1) * 4 + lg;
-        const double* row = rb + r * RS;
-#pragma unroll
-        for (int n = 0; n < NTW; ++n) Bn[n] = qs[r * QS + (nt0 + n) * 16 + li];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) { Axn[m] = row[fa[m]]; Ayn[m] = row[fb[m]]; }
-      }
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const double A = Ax[m] * Ay[m];
-#pragma unroll
-        for (int n = 0; n < NTW; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(A, Bv[n], acc[m][n], 0, 0, 0);
-      }
-      if (ks + 1 < ST_RB / 4) {
-#pragma unroll
-        for (int n = 0; n < NTW; ++n) Bv[n] = Bn[n];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) { Ax[m] = Axn[m]; Ay[m] = Ayn[m]; }
-      }
-      // role A stages in the middle of its compute phase (role B did it before), so that
-      // at the end of the stage both waves of a SIMD are still feeding the matrix pipe
-      if (ks == ST_RB / 8 - 1 && !roleB) {
-        if (st + 1 < nstage) commit(cur ^ 1);
-        if (st + 2 < nstage) fetch((st + 2) & 3);
-      }
-    }
-    row_info(c0 + (int64_t)(st + 3) * ST_RB, (st + 3) & 3);
-    __syncthreads();
-  }
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int f = (mt0 + m) * 16 + lg + 4 * r;
-      if (f < Ftot && (mt0 + m) < mt_limit) {
-#pragma unroll
-        for (int n = 0; n < NTW; ++n)
-          part[((size_t)blockIdx.x * Ftot + f) * KpTot + kbase + (nt0 + n) * 16 + li] = acc[m][n][r];
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------
-//  K5: deterministic reduction of the per-chunk partials + scatter into the packed layout
-//      packed = [A_raw K*K | xbar K*D | neff K | S K*D*D | lb]
-// ------------------------------------------------------------------------------------
-__global__ void k_finalize(const double* __restrict__ part, int nchunk, int D, int K,
-                           int Kp, int Fp, int F, const int* __restrict__ fab,
-                           double* __restrict__ packed) {
-  const int Ftot = Fp + Kp;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)Ftot * Kp) return;
-  const int f = idx / Kp, k = idx - (int64_t)f * Kp;
-  if (k >= K) return;
-  // fixed summation order (4 interleaved partial sums) -> bit-reproducible
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  const size_t stride = (size_t)Ftot * Kp;
-  const double* pp = part + (size_t)f * Kp + k;
-  int c = 0;
-  for (; c + 4 <= nchunk; c += 4) {
-    s0 += pp[(size_t)c * stride];
-    s1 += pp[(size_t)(c + 1) * stride];
-    s2 += pp[(size_t)(c + 2) * stride];
-    s3 += pp[(size_t)(c + 3) * stride];
-  }
-  for (; c < nchunk; ++c) s0 += pp[(size_t)c * stride];
-  const double s = (s0 + s1) + (s2 + s3);
-  double* A = packed;
-  double* xbar = A + (size_t)K * K;
-  double* neff = xbar + (size_t)K * D;
-  double* S = neff + K;
-  if (f < F) {
-    const int ab = fab[f];
-    const int a = ab & 0xffff, b = ab >> 16;
-    if (b < D) {  // a <= b < D
-      S[((size_t)k * D + a) * D + b] = s;
-      S[((size_t)k * D + b) * D + a] = s;
-    } else if (a < D) {
-      xbar[(size_t)k * D + a] = s;
-    } else {
-      neff[k] = s;
-    }
-  } else if (f >= Fp && f - Fp < K) {
-    A[(size_t)(f - Fp) * K + k] = s;
-  }
-}
-
-__global__ void k_reduce_lb(const double* __restrict__ lse_part, int B, int nseg,
-                            double* __restrict__ local_lb, double* __restrict__ lb_total) {
-  // single block; deterministic order
-  __shared__ double red[256];
-  double acc = 0.0;
-  for (int b = threadIdx.x; b < B; b += blockDim.x) {
-    double s = 0.0;
-    for (int i = 0; i < nseg; ++i) s += lse_part[(size_t)b * nseg + i];
-    local_lb[b] = s;
-    acc += s;
-  }
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int o = 128; o >= 1; o >>= 1) {
-    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0 && lb_total) *lb_total = red[0];
-}
-
-// ------------------------------------------------------------------------------------
-//  K6: FFBS backward sampling (hmm_fast.pyx:97-122), one wavefront, K <= 64 in-lane,
-//      larger K through a serial tail in lane 0.
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_ffbs_sample(const double* __restrict__ la,
-                                                    const double* __restrict__ logA,
-                                                    const double* __restrict__ unif, int64_t T,
-                                                    int K, int64_t* __restrict__ z) {
-  const int lane = threadIdx.x;
-  extern __shared__ double ps[];  // [K] for K > 64
-  int64_t znext = 0;
-  for (int64_t t = T - 1; t >= 0; --t) {
-    if (K <= 64) {
-      double lp = -INFINITY;
-      if (lane < K) {
-        lp = la[t * K + lane];
-        if (t < T - 1) lp += logA[(size_t)lane * K + znext];
-      }
-      const double m = wave_max(lp);
-      double p = (lane < K) ? exp(lp - m) : 0.0;
-      const double tot = wave_sum(p);
-      p /= tot;
-      // inclusive scan in lane order
-      double c = p;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const double v = __shfl_up(c, o, 64);
-        if (lane >= o) c += v;
-      }
-      const double r = unif[t];
-      const unsigned long long bal = __ballot(lane < K && r <= c);
-      int zz = bal ? (__ffsll((long long)bal) - 1) : (K - 1);
-      znext = zz;
-    } else {
-      double mloc = -INFINITY;
-      for (int k = lane; k < K; k += 64) {
-        double lp = la[t * K + k];
-        if (t < T - 1) lp += logA[(size_t)k * K + znext];
-        ps[k] = lp;
-        mloc = fmax(mloc, lp);
-      }
-      const double m = wave_max(mloc);
-      double sl = 0.0;
-      for (int k = lane; k < K; k += 64) {
-        const double e = exp(ps[k] - m);
-        ps[k] = e;
-        sl += e;
-      }
-      const double tot = wave_sum(sl);
-      __syncthreads();
-      int zz = K - 1;
-      if (lane == 0) {
-        const double r = unif[t];
-        double rs = 0.0;
-        for (int k = 0; k < K; ++k) {
-          rs += ps[k] / tot;
-          if (r <= rs) { zz = k; break; }
-        }
-      }
-      zz = __shfl(zz, 0, 64);
-      znext = zz;
-      __syncthreads();
-    }
-    if (lane == 0) z[t] = znext;
-  }
-}
-
-// ------------------------------------------------------------------------------------
-//  K0: NIW mean-field factors -> theta (one workgroup per state).  Cholesky of sigma_mf,
-//      W = (nu/2) sigma^-1 = (nu/2) L^-T L^-1, E log|Lambda| (digamma), linear and constant
-//      terms of the quadratic form.  status[0] = 1 + k if sigma_k is not positive definite.
-// ------------------------------------------------------------------------------------
-__device__ __forceinline__ double digamma_d(double x) {
-  double r = 0.0;
-  while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
-  const double f = 1.0 / (x * x);
-  const double t = f * (-1.0 / 12 + f * (1.0 / 120 + f * (-1.0 / 252 + f * (1.0 / 240 +
-                   f * (-1.0 / 132 + f * (691.0 / 32760 + f * (-1.0 / 12)))))));
-  return r + log(x) - 0.5 / x + t;
-}
-__device__ __forceinline__ int feat_index_d(int a, int b, int D) {
-  return a * (D + 1) - a * (a - 1) / 2 + (b - a);
-}
-__global__ __launch_bounds__(256) void k_niw_to_theta(
-    const double* __restrict__ mu, const double* __restrict__ sigma,
-    const double* __restrict__ kappa, const double* __restrict__ nu, int K, int D, int Kp,
-    double* __restrict__ theta, int* __restrict__ status) {
-  extern __shared__ double sm[];
-  const int S = D + 1;
-  double* Lm_ = sm;            // [D][S] Cholesky factor (lower)
-  double* Li = Lm_ + D * S;    // [D][S] its inverse (lower)
-  double* W = Li + D * S;      // [D][S]
-  double* wm = W + D * S;      // [D]
-  __shared__ int bad;
-  const int k = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-  const double* Sg = sigma + (size_t)k * D * D;
-  const double* m = mu + (size_t)k * D;
-  for (int e = tid; e < D * D; e += nt) {
-    const int i = e / D, j = e - i * D;
-    Lm_[i * S + j] = Sg[e];
-    Li[i * S + j] = 0.0;
-  }
-  if (tid == 0) bad = 0;
-  __syncthreads();
-  // right-looking Cholesky
-  for (int j = 0; j < D; ++j) {
-    const double djj = Lm_[j * S + j];
-    if (!(djj > 0.0)) { if (tid == 0) bad = 1; }
-    __syncthreads();
-    if (bad) break;
-    const double d = sqrt(djj);
-    for (int i = j + 1 + tid; i < D; i += nt) Lm_[i * S + j] /= d;
-    __syncthreads();
-    if (tid == 0) Lm_[j * S + j] = d;
-    const int n = D - 1 - j;
-    for (int e = tid; e < n * n; e += nt) {
-      const int a = j + 1 + e / n, b = j + 1 + e % n;
-      if (b <= a) Lm_[a * S + b] -= Lm_[a * S + j] * Lm_[b * S + j];
-    }
-    __syncthreads();
-  }
-  if (bad) {
-    if (tid == 0) atomicMax(status, 1 + k);
-    return;
-  }
-  // Li = L^-1, one column per thread
-  for (int c = tid; c < D; c += nt) {
-    Li[c * S + c] = 1.0 / Lm_[c * S + c];
-    for (int r = c + 1; r < D; ++r) {
-      double s = 0.0;
-      for (int jj = c; jj < r; ++jj) s -= Lm_[r * S + jj] * Li[jj * S + c];
-      Li[r * S + c] = s / Lm_[r * S + r];
-    }
-  }
-  __syncthreads();
-  const double hn = 0.5 * nu[k];
-  for (int e = tid; e < D * D; e += nt) {
-    const int i = e / D, j = e - i * D;
-    if (j < i) continue;
-    double s = 0.0;
-    for (int r = j; r < D; ++r) s += Li[r * S + i] * Li[r * S + j];
-    W[i * S + j] = hn * s;
-    W[j * S + i] = hn * s;
-  }
-  __syncthreads();
-  for (int i = tid; i < D; i += nt) {
-    double s = 0.0;
-    for (int j = 0; j < D; ++j) s += W[i * S + j] * m[j];
-    wm[i] = s;
-    theta[(size_t)feat_index_d(i, D, D) * Kp + k] = 2.0 * s;
-  }
-  for (int e = tid; e < D * D; e += nt) {
-    const int i = e / D, j = e - i * D;
-    if (j < i) continue;
-    theta[(size_t)feat_index_d(i, j, D) * Kp + k] = (i == j) ? -W[i * S + i] : -2.0 * W[i * S + j];
-  }
-  __syncthreads();
-  if (tid == 0) {
-    double logdet = 0.0, llt = D * log(2.0), mWm = 0.0;
-    for (int i = 0; i < D; ++i) {
-      logdet += log(Lm_[i * S + i]);
-      llt += digamma_d(0.5 * (nu[k] - i));
-      mWm += m[i] * wm[i];
-    }
-    llt -= 2.0 * logdet;
-    const double cst = 0.5 * llt - D / (2.0 * kappa[k]) - 0.5 * D * 1.8378770664093454835606594728112;
-    theta[(size_t)feat_index_d(D, D, D) * Kp + k] = cst - mWm;
-  }
-}
-
-// small utility kernels
-__global__ void k_exp_transpose(const double* __restrict__ ltran, int K, double* __restrict__ A,
-                                double* __restrict__ AT) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= K * K) return;
-  const int i = idx / K, j = idx - i * K;
-  const double v = exp(ltran[idx]);
-  A[idx] = v;
-  AT[(size_t)j * K + i] = v;
-}
-
-__global__ void k_selftest_mfma(const double* __restrict__ A, const double* __restrict__ Bm,
-                                double* __restrict__ C) {
-  // A[16][4], B[4][16] row-major -> C[16][16]
-  const int l = threadIdx.x;
-  const double a = A[(l & 15) * 4 + (l >> 4)];
-  const double b = Bm[(l >> 4) * 16 + (l & 15)];
-  double4_t c = {0.0, 0.0, 0.0, 0.0};
-  c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-  for (int r = 0; r < 4; ++r) C[((l >> 4) + 4 * r) * 16 + (l & 15)] = c[r];
-}
-
-// fp64 throughput micro-benchmarks (peak calibration for the roofline)
-__global__ __launch_bounds__(256) void k_peak_mfma_f64(double* out, int iters) {
-  double4_t c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
-  const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
-  const long long t0 = clock64();
-  for (int i = 0; i < iters; ++i) {
-    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1, 0, 0, 0);
-    c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2, 0, 0, 0);
-    c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3, 0, 0, 0);
-  }
-  const long long t1 = clock64();
-  out[blockIdx.x * blockDim.x + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
-  if (blockIdx.x == 0 && threadIdx.x == 0) out[(size_t)gridDim.x * blockDim.x] = (double)(t1 - t0);
-}
-template <int NACC>
-__global__ __launch_bounds__(256) void k_peak_mfma_chain(double* out, int iters) {
-  double4_t c[NACC];
-#pragma unroll
-  for (int i = 0; i < NACC; ++i) c[i] = (double4_t){0, 0, 0, 0};
-  const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
-  const long long t0 = clock64();
-  for (int it = 0; it < iters; ++it) {
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) c[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c[i], 0, 0, 0);
-  }
-  const long long t1 = clock64();
-  double s = 0;
-#pragma unroll
-  for (int i = 0; i < NACC; ++i) s += c[i][i & 3];
-  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-  if (blockIdx.x == 0 && threadIdx.x == 0) out[(size_t)gridDim.x * blockDim.x] = (double)(t1 - t0);
-}
-// MFMA + fp64 VALU overlap probe: per iteration 8 MFMAs and NF*8 independent v_fma_f64
-template <int NF, bool MF>
-__global__ __launch_bounds__(256) void k_peak_mix(double* out, int iters) {
-  double4_t c[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) c[i] = (double4_t){0, 0, 0, 0};
-  double f[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) f[i] = i;
-  const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
-  for (int it = 0; it < iters; ++it) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if (MF) c[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c[i], 0, 0, 0);
-#pragma unroll
-      for (int k = 0; k < NF; ++k) f[(i + k) & 7] = fma(f[(i + k) & 7], a, b);
-    }
-  }
-  double s = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) s += c[i][i & 3] + f[i];
-  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-}
-__global__ __launch_bounds__(256) void k_peak_fma_f64(double* out, int iters) {
-  double c[8];
-  const double a = 1.0 + threadIdx.x * 1e-9, b = 1e-9 * threadIdx.x;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) c[i] = i;
-  for (int it = 0; it < iters; ++it) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) c[i] = fma(c[i], a, b);
-  }
-  double s = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) s += c[i];
-  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-}
+#include "device_helpers.h"
+#include "kernels_emission.h"
+#include "kernels_recursion.h"
+#include "kernels_stats.h"
+#include "kernels_misc.h"
 
 // ------------------------------------------------------------------------------------
 //  host side
