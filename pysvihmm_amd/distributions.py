@@ -188,7 +188,12 @@ class Gaussian(object):
                                   self.nu_mf)
 
     def get_vlb(self):
-        """E_q[log p(mu,Sigma)] + H[q] (Bishop eqs. 10.74 and 10.77)."""
+        """E_q[log p(mu,Sigma)] + H[q] = -KL(q || prior) (Bishop eqs. 10.74 and 10.77).
+
+        The prior's Wishart normaliser enters as ``log B(W0, nu0) = -log Z`` (10.74), so the
+        term is exactly zero when q equals the prior (tests/test_emission_formula.py).  Some
+        pybasicbayes revisions carry that term with the opposite sign, which shifts the ELBO
+        by the constant ``2 log Z(sigma_0, nu_0)`` per state and changes nothing else."""
         D = len(self.mu_0)
         llt = self._loglmbdatilde()
         dmu = self.mu_mf - self.mu_0
@@ -198,7 +203,7 @@ class Gaussian(object):
                             - D * self.kappa_0 / self.kappa_mf
                             - self.kappa_0 * self.nu_mf
                             * np.dot(dmu, np.linalg.solve(self.sigma_mf, dmu)))
-                     + _invwishart_log_partitionfunction(self.sigma_0, self.nu_0)
+                     - _invwishart_log_partitionfunction(self.sigma_0, self.nu_0)
                      + (self.nu_0 - D - 1) / 2. * llt
                      - 0.5 * self.nu_mf
                      * np.linalg.solve(self.sigma_mf, self.sigma_0).trace())
@@ -234,7 +239,7 @@ def niw_vlb_batch(mu_mf, sigma_mf, kappa_mf, nu_mf, mu_0, sigma_0, kappa_0, nu_0
     q_entropy = -0.5 * (l_mf + D * (np.log(kappa_mf / (2 * np.pi)) - 1)) + iw_entropy
     p_avgengy = (0.5 * (D * np.log(kappa_0 / (2 * np.pi)) + l_mf - D * kappa_0 / kappa_mf
                         - kappa_0 * nu_mf * np.einsum('kd,kd->k', dmu, sol_dmu))
-                 + logpart(chol_0, nu_0) + (nu_0 - D - 1) / 2. * l_mf
+                 - logpart(chol_0, nu_0) + (nu_0 - D - 1) / 2. * l_mf
                  - 0.5 * nu_mf * np.trace(sol_s0, axis1=1, axis2=2))
     return p_avgengy + q_entropy
 

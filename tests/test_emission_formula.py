@@ -1,0 +1,90 @@
+"""Independent check of the (unpinned, third-party) emission arithmetic: the closed-form
+NIW mean-field expected log-likelihood restated from pybasicbayes / Bishop 10.64-10.71 must
+equal a Monte-Carlo estimate of E_q[log N(x | mu, Sigma)] with (mu, Sigma) drawn from the NIW
+factor by SciPy's own samplers.  Also: the quadratic-form parameters the device kernel consumes
+reproduce the class, and the conjugate update / ELBO term are self-consistent."""
+import numpy as np
+import scipy.stats as st
+
+from pysvihmm_amd.distributions import Gaussian, niw_quadratic_form, niw_vlb_batch
+from oracle import ref_numpy as R
+
+
+def _factor(D, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.normal(size=(D, D))
+    g = Gaussian(mu=rng.normal(size=D), sigma=np.eye(D), mu_0=np.zeros(D), sigma_0=np.eye(D),
+                 kappa_0=0.5, nu_0=D + 2)
+    g.mu_mf = rng.normal(size=D)
+    g.sigma_mf = 2.0 * np.eye(D) + a.dot(a.T)
+    g.kappa_mf = 3.7
+    g.nu_mf = D + 6.5
+    return g, rng
+
+
+def test_expected_log_likelihood_matches_monte_carlo():
+    D, n = 3, 60000
+    g, rng = _factor(D, 1)
+    x = rng.normal(size=(4, D)) * 2.0
+    sig = st.invwishart.rvs(df=g.nu_mf, scale=g.sigma_mf, size=n, random_state=7)
+    z = rng.normal(size=(n, D))
+    chol = np.linalg.cholesky(sig / g.kappa_mf)
+    mu = g.mu_mf + np.einsum('nij,nj->ni', chol, z)
+    acc = np.zeros((n, len(x)))
+    sinv = np.linalg.inv(sig)
+    _, logdet = np.linalg.slogdet(sig)
+    for i, xi in enumerate(x):
+        d = xi - mu
+        acc[:, i] = -0.5 * (D * np.log(2 * np.pi) + logdet + np.einsum('ni,nij,nj->n', d, sinv, d))
+    mc = acc.mean(0)
+    se = acc.std(0) / np.sqrt(n)
+    cf = g.expected_log_likelihood(x)
+    assert np.all(np.abs(mc - cf) < 5 * se + 1e-3), (mc, cf, se)
+
+
+def test_quadratic_form_and_oracle_agree_with_class():
+    D = 6
+    g, rng = _factor(D, 2)
+    x = rng.normal(size=(50, D)) * 3.0
+    W, v, c = niw_quadratic_form(g.mu_mf, g.sigma_mf, g.kappa_mf, g.nu_mf)
+    q = c + x.dot(v) - np.einsum('ti,ij,tj->t', x, W, x)
+    ref = g.expected_log_likelihood(x)
+    np.testing.assert_allclose(q, ref, rtol=1e-11, atol=1e-10)
+    np.testing.assert_allclose(
+        R.niw_expected_log_likelihood(x, g.mu_mf, g.sigma_mf, g.kappa_mf, g.nu_mf), ref,
+        rtol=1e-12, atol=1e-11)
+    xn = x.copy(); xn[3, 1] = np.nan
+    out = g.expected_log_likelihood(xn)
+    assert np.isnan(out[3]) and np.all(np.isfinite(np.delete(out, 3)))
+
+
+def test_meanfield_update_is_the_conjugate_posterior():
+    """weights = 1: the mean-field update equals the textbook NIW posterior."""
+    D, n = 4, 300
+    g, rng = _factor(D, 3)
+    data = rng.normal(size=(n, D)) + 1.5
+    g.meanfieldupdate(data, np.ones(n))
+    xbar = data.mean(0)
+    S = (data - xbar).T.dot(data - xbar)
+    k0, n0 = 0.5, D + 2
+    np.testing.assert_allclose(g.kappa_mf, k0 + n)
+    np.testing.assert_allclose(g.nu_mf, n0 + n)
+    np.testing.assert_allclose(g.mu_mf, n * xbar / (k0 + n), rtol=1e-12)
+    np.testing.assert_allclose(g.sigma_mf, np.eye(D) + S + k0 * n / (k0 + n) * np.outer(xbar, xbar),
+                               rtol=1e-12)
+
+
+def test_vlb_is_minus_kl_and_zero_at_the_prior():
+    """get_vlb = E_q[log p] + H[q] = -KL(q || p): zero when q equals the prior, negative
+    otherwise; the batched version equals the per-object one."""
+    D = 3
+    g, rng = _factor(D, 4)
+    p = Gaussian(mu=np.zeros(D), sigma=np.eye(D), mu_0=np.zeros(D), sigma_0=np.eye(D) * 1.3,
+                 kappa_0=0.5, nu_0=D + 2)
+    p.mu_mf, p.sigma_mf, p.kappa_mf, p.nu_mf = p.mu_0.copy(), p.sigma_0.copy(), p.kappa_0, p.nu_0
+    assert abs(p.get_vlb()) < 1e-9
+    assert g.get_vlb() < 0
+    b = niw_vlb_batch(np.array([g.mu_mf, p.mu_mf]), np.array([g.sigma_mf, p.sigma_mf]),
+                      [g.kappa_mf, p.kappa_mf], [g.nu_mf, p.nu_mf], np.array([g.mu_0, p.mu_0]),
+                      np.array([g.sigma_0, p.sigma_0]), [g.kappa_0, p.kappa_0], [g.nu_0, p.nu_0])
+    np.testing.assert_allclose(b, [g.get_vlb(), p.get_vlb()], rtol=1e-11, atol=1e-10)
