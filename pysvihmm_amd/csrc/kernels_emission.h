@@ -60,12 +60,16 @@ __global__ __launch_bounds__(EM_R) void k_emission_outer(
 //       Workgroup = 4 waves x (MT=2 row tiles) = 128 rows; NT n-tiles of 16 states.
 //       grid (ceil(n/128), Kp/(16*NT)), block 256.
 // ------------------------------------------------------------------------------------
-template <int NT, int MT>
+//       SCALED (grid.y == 1, the workgroup owns whole rows): instead of ll the kernel
+//       writes Eh = exp(ll) * 2^-k with k = ceil(max_j ll / ln 2) and the per-row k
+//       (kexp) -- the input format of the scaled linear-domain sweeps K2e/K2f, so that
+//       no exp is left in their time loops.
+template <int NT, int MT, bool SCALED>
 __global__ __launch_bounds__(256) void k_emission_mfma(
     const double* __restrict__ obs, const uint8_t* __restrict__ mask,
     const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K, int Kp,
     int Fp, const double* __restrict__ theta, const int* __restrict__ fab,
-    uint32_t flags, double* __restrict__ ll) {
+    uint32_t flags, double* __restrict__ ll, double* __restrict__ kexp) {
   // workgroup = 4 waves x MT row tiles of 16 rows
   constexpr int ROWS = 64 * MT;
   extern __shared__ double smem[];
@@ -152,8 +156,26 @@ __global__ __launch_bounds__(256) void k_emission_mfma(
     for (int r = 0; r < 4; ++r) {
       const int rl = wave * 16 * MT + m * 16 + lg + 4 * r;
       const int64_t g = g0 + rl;
-      if (g < nrows) {
-        const bool bd = bad_s[rl] != 0;
+      const bool bd = bad_s[rl] != 0;
+      if (SCALED) {
+        double v[NT], mx = -INFINITY;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int k = n0 + n * 16 + li;
+          v[n] = k < K ? (bd ? 0.0 : nan_to_num(outv[m][n][r])) : -INFINITY;
+          mx = fmax_raw(mx, v[n]);
+        }
+        mx = row16_max(mx);   // all lanes: the DPP reduction stays outside the store guards
+        const double kx = (mx > -1e300 && mx < 1e300) ? ceil(mx * 1.4426950408889634074) : 0.0;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int k = n0 + n * 16 + li;
+          const double e = fast_exp(fma(-kx, 1.90821492927058770002e-10,
+                                        fma(-kx, 6.93147180369123816490e-01, v[n])));
+          if (g < nrows && k < K) ll[g * K + k] = e;
+        }
+        if (li == 0 && g < nrows) kexp[g] = kx;
+      } else if (g < nrows) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           const int k = n0 + n * 16 + li;

@@ -477,6 +477,275 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_mfma(
   }
 }
 
+// ------------------------------------------------------------------------------------
+//  K2e/K2f: scaled linear-domain sweeps -- the E-step fast path (K <= 64, B >= 192).
+//  Same batching as K2c/K2d (16 windows per workgroup, wave s owns state tile 16*s), but
+//  nothing in the time loop is a transcendental: the emission kernel hands over
+//      Eh[t][j] = exp(ll[t][j]) * 2^-k_t,   k_t = ceil(max_j ll[t][j] / ln 2)  (integer),
+//  and the messages are carried as (mantissa-like vector, integer binary exponent):
+//      alpha_t[j] = ah_t[j] * 2^na_t,       beta_t[j] = bh_t[j] * 2^nb_t.
+//  Forward:  ah_t = (ah_{t-1} . A) * Eh_t * 2^-e,  na_t = na_{t-1} + k_t + e,
+//            e = frexp exponent of sum_i ah_{t-1}[i]  (keeps sum ah in [2^-?, 1)).
+//  Backward: v_{t+1} = Eh_{t+1} * bh_{t+1};  bh_t = (A . v_{t+1}) * 2^-e,
+//            nb_t = nb_{t+1} + k_{t+1} + e,  e = frexp exponent of sum_j v_{t+1}[j];
+//  posterior q_t[j] = ah_t[j] * bh_t[j] * 2^(na_t + nb_t - ze) / zm with Z = zm * 2^ze from
+//  the forward sweep (hmmbase.py:226-229 normalises by the row sum, which equals Z).
+//  The row sum needed for e costs one extra MFMA: lane (li, lg) adds up the 16 A-operand
+//  values it loads anyway (row li, k = 2lg, 2lg+1 mod 8) and multiplies against a ones
+//  operand, so every accumulator register r holds the sum of window lg + 4r -- exactly the
+//  layout the per-window scalars live in.  One barrier per step, no reduction through LDS.
+//  local_lb = sum_t LSE_j lalpha_t[j] (quirk Q4) is a running (mantissa, exponent) product.
+//  Log-domain lalpha / lbeta / lliks are materialised on demand by the log kernels above.
+// ------------------------------------------------------------------------------------
+#define LOG2E_D 1.4426950408889634074
+#define LN2_HI_D 6.93147180369123816490e-01
+#define LN2_LO_D 1.90821492927058770002e-10
+
+template <int NW>
+struct LinShared {
+  static constexpr int PS = 16 * NW + 2;
+  double __attribute__((aligned(16))) P[2][16][PS];
+};
+
+template <int NW>
+__device__ __forceinline__ void lin_matmul(const LinShared<NW>& sh, int cur, int li, int lg,
+                                           const double (&Bv)[4 * NW], double4_t& acc,
+                                           double4_t& tot) {
+  constexpr int KS = 4 * NW;
+  double4_t a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+  const double* prow = &sh.P[cur][li][2 * lg];
+  double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+  for (int c = 0; c < KS / 2; c += 2) {
+    const double2 x = *reinterpret_cast<const double2*>(prow + 8 * c);
+    const double2 y = *reinterpret_cast<const double2*>(prow + 8 * (c + 1));
+    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, Bv[2 * c], a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, Bv[2 * c + 1], a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(y.x, Bv[2 * c + 2], a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(y.y, Bv[2 * c + 3], a3, 0, 0, 0);
+    s0 += x.x + y.x;
+    s1 += x.y + y.y;
+  }
+  const double4_t z = {0, 0, 0, 0};
+  tot = __builtin_amdgcn_mfma_f64_16x16x4f64(s0 + s1, 1.0, z, 0, 0, 0);
+  acc = (a0 + a1) + (a2 + a3);
+}
+template <int NW>
+__device__ __forceinline__ double4_t lin_rowsum(const LinShared<NW>& sh, int cur, int li, int lg) {
+  const double* prow = &sh.P[cur][li][2 * lg];
+  double s = 0.0;
+#pragma unroll
+  for (int c = 0; c < 2 * NW; ++c) {
+    const double2 x = *reinterpret_cast<const double2*>(prow + 8 * c);
+    s += x.x + x.y;
+  }
+  const double4_t z = {0, 0, 0, 0};
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(s, 1.0, z, 0, 0, 0);
+}
+
+template <int NW, bool FULL>
+__global__ __launch_bounds__(64 * NW) void k_fwd_lin(
+    const double* __restrict__ Eh, const double* __restrict__ kexp,
+    const double* __restrict__ Aexp, const double* __restrict__ mod_init, int B, int Lm, int K,
+    double* __restrict__ ah, double2* __restrict__ nak, double* __restrict__ local_lb,
+    double* __restrict__ logz, double2* __restrict__ zfac) {
+  constexpr int KS = 4 * NW;
+  __shared__ LinShared<NW> sh;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int j = wave * 16 + li;
+  const bool vj = FULL || (j < K);
+  const int jc = vj ? j : 0;
+  const int b0 = blockIdx.x * 16;
+  double Bv[KS];
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+    const int k = 8 * (kk >> 1) + 2 * lg + (kk & 1);
+    Bv[kk] = (k < K && vj) ? Aexp[(size_t)k * K + jc] : 0.0;
+  }
+  size_t base[4], rowb[4];
+  int gwc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int gw = b0 + lg + 4 * r;
+    gwc[r] = gw < B ? gw : B - 1;
+    rowb[r] = (size_t)gwc[r] * Lm;
+    base[r] = rowb[r] * K + jc;
+  }
+  // common binary exponent of the initial distribution
+  double mi_max = -INFINITY;
+  for (int k = 0; k < K; ++k) mi_max = fmax(mi_max, mod_init[k]);
+  const double s0 = (mi_max > -1e300 && mi_max < 1e300) ? ceil(mi_max * LOG2E_D) : 0.0;
+  const double pij = vj ? exp(fma(-s0, LN2_LO_D, fma(-s0, LN2_HI_D, mod_init[jc]))) : 0.0;
+  const int i1 = Lm > 1 ? 1 : 0, i2 = Lm > 2 ? 2 : i1;
+  double na[4], mant[4], nsum[4], en1[4], en2[4], kn1[4], kn2[4];
+  int ex[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const double e0 = Eh[base[r]];
+    const double k0 = kexp[rowb[r]];
+    const double a0 = vj ? pij * e0 : 0.0;
+    na[r] = s0 + k0;
+    if (vj) ah[base[r]] = a0;
+    nak[rowb[r]] = make_double2(na[r], k0);
+    sh.P[0][lg + 4 * r][j] = a0;
+    en1[r] = Eh[base[r] + (size_t)i1 * K];
+    en2[r] = Eh[base[r] + (size_t)i2 * K];
+    kn1[r] = kexp[rowb[r] + i1];
+    kn2[r] = kexp[rowb[r] + i2];
+    mant[r] = 1.0; ex[r] = 0; nsum[r] = 0.0;
+  }
+  __syncthreads();
+  for (int t = 1; t < Lm; ++t) {
+    const int cur = (t - 1) & 1, nxt = t & 1;
+    const int t2 = t + 2 < Lm ? t + 2 : Lm - 1;
+    double ev[4], kv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      ev[r] = en1[r]; en1[r] = en2[r]; en2[r] = Eh[base[r] + (size_t)t2 * K];
+      kv[r] = kn1[r]; kn1[r] = kn2[r]; kn2[r] = kexp[rowb[r] + t2];
+    }
+    double4_t acc, tot;
+    lin_matmul<NW>(sh, cur, li, lg, Bv, acc, tot);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e2 = __builtin_amdgcn_frexp_exp(tot[r]);
+      const double av = ldexp(acc[r] * ev[r], -e2);
+      sh.P[nxt][lg + 4 * r][j] = av;
+      if (FULL || vj) ah[base[r] + (size_t)t * K] = av;
+      // LSE of step t-1: log(tot) + na_{t-1} ln 2, accumulated as a product
+      const double mm = mant[r] * tot[r];
+      ex[r] += __builtin_amdgcn_frexp_exp(mm);
+      mant[r] = __builtin_amdgcn_frexp_mant(mm);
+      nsum[r] += na[r];
+      na[r] += kv[r] + (double)e2;
+      nak[rowb[r] + t] = make_double2(na[r], kv[r]);
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: Z = sum_j alpha_{Lm-1}[j], local_lb
+  {
+    const double4_t tot = lin_rowsum<NW>(sh, (Lm - 1) & 1, li, lg);
+    if (wave == 0 && li == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double mm = mant[r] * tot[r];
+        const int exf = ex[r] + __builtin_amdgcn_frexp_exp(mm);
+        const double mf = __builtin_amdgcn_frexp_mant(mm);
+        const double zm = __builtin_amdgcn_frexp_mant(tot[r]);
+        const double ze = na[r] + (double)__builtin_amdgcn_frexp_exp(tot[r]);
+        local_lb[gwc[r]] = log(mf) + ((double)exf + nsum[r] + na[r]) * LN2_D;
+        logz[gwc[r]] = log(zm) + ze * LN2_D;
+        zfac[gwc[r]] = make_double2(1.0 / zm, ze);
+      }
+    }
+  }
+}
+
+template <int NW, bool FULL>
+__global__ __launch_bounds__(64 * NW) void k_bwd_lin(
+    const double* __restrict__ Eh, const double2* __restrict__ nak,
+    const double* __restrict__ AexpT, const double* __restrict__ ah,
+    const double2* __restrict__ zfac, int B, int Lm, int K, double* __restrict__ q_out) {
+  constexpr int KS = 4 * NW;
+  __shared__ LinShared<NW> sh;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int j = wave * 16 + li;
+  const bool vj = FULL || (j < K);
+  const int jc = vj ? j : 0;
+  const int b0 = blockIdx.x * 16;
+  double Bv[KS];
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+    const int k = 8 * (kk >> 1) + 2 * lg + (kk & 1);
+    Bv[kk] = (k < K && vj) ? AexpT[(size_t)k * K + jc] : 0.0;
+  }
+  size_t base[4], rowb[4];
+  double zinv[4], ze[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int gw = b0 + lg + 4 * r;
+    const int g = gw < B ? gw : B - 1;
+    rowb[r] = (size_t)g * Lm;
+    base[r] = rowb[r] * K + jc;
+    const double2 z = zfac[g];
+    zinv[r] = z.x; ze[r] = z.y;
+  }
+  const int top = Lm - 1;
+  const int i1 = Lm > 1 ? top - 1 : top, i2 = Lm > 2 ? top - 2 : i1;
+  double nb[4], kprev[4], en1[4], en2[4], an1[4], an2[4];
+  double2 nn1[4], nn2[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const double e0 = Eh[base[r] + (size_t)top * K];
+    const double a0 = ah[base[r] + (size_t)top * K];
+    const double2 n0 = nak[rowb[r] + top];
+    nb[r] = 0.0;
+    kprev[r] = n0.y;
+    if (vj) q_out[base[r] + (size_t)top * K] = a0 * ldexp(zinv[r], (int)(n0.x - ze[r]));
+    sh.P[0][lg + 4 * r][j] = vj ? e0 : 0.0;
+    en1[r] = Eh[base[r] + (size_t)i1 * K]; en2[r] = Eh[base[r] + (size_t)i2 * K];
+    an1[r] = ah[base[r] + (size_t)i1 * K]; an2[r] = ah[base[r] + (size_t)i2 * K];
+    nn1[r] = nak[rowb[r] + i1]; nn2[r] = nak[rowb[r] + i2];
+  }
+  __syncthreads();
+  int step = 1;
+  for (int t = Lm - 2; t >= 0; --t, ++step) {
+    const int cur = (step - 1) & 1, nxt = step & 1;
+    const int t2 = t >= 2 ? t - 2 : 0;
+    double ev[4], av[4];
+    double2 nv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      ev[r] = en1[r]; en1[r] = en2[r]; en2[r] = Eh[base[r] + (size_t)t2 * K];
+      av[r] = an1[r]; an1[r] = an2[r]; an2[r] = ah[base[r] + (size_t)t2 * K];
+      nv[r] = nn1[r]; nn1[r] = nn2[r]; nn2[r] = nak[rowb[r] + t2];
+    }
+    double4_t acc, tot;
+    lin_matmul<NW>(sh, cur, li, lg, Bv, acc, tot);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e2 = __builtin_amdgcn_frexp_exp(tot[r]);
+      const double bh = ldexp(acc[r], -e2);
+      sh.P[nxt][lg + 4 * r][j] = ev[r] * bh;
+      nb[r] += kprev[r] + (double)e2;
+      kprev[r] = nv[r].y;
+      const double f = ldexp(zinv[r], (int)(nv[r].x + nb[r] - ze[r]));
+      const double qv = (av[r] * bh) * f;
+      if (FULL || vj) q_out[base[r] + (size_t)t * K] = qv;
+    }
+    __syncthreads();
+  }
+}
+
+// host-supplied lliks (generic emission plugins) -> (Eh, kexp) for the scaled sweeps.
+// One 16-lane row per (window, t) row, KT = ceil(K/16) values per lane.
+template <int KT>
+__global__ __launch_bounds__(256) void k_scale_ll(const double* __restrict__ ll, int64_t nrows,
+                                                  int K, double* __restrict__ Eh,
+                                                  double* __restrict__ kexp) {
+  const int li = threadIdx.x & 15;
+  const int64_t g = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int64_t gc = g < nrows ? g : nrows - 1;
+  double v[KT], mx = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < KT; ++c) {
+    const int k = li + 16 * c;
+    v[c] = k < K ? ll[gc * K + k] : -INFINITY;
+    mx = fmax_raw(mx, v[c]);
+  }
+  mx = row16_max(mx);
+  const double kx = (mx > -1e300 && mx < 1e300) ? ceil(mx * LOG2E_D) : 0.0;
+#pragma unroll
+  for (int c = 0; c < KT; ++c) {
+    const int k = li + 16 * c;
+    if (k < K && g < nrows)
+      Eh[g * K + k] = fast_exp(fma(-kx, LN2_LO_D, fma(-kx, LN2_HI_D, v[c])));
+  }
+  if (li == 0 && g < nrows) kexp[g] = kx;
+}
+
 __global__ void k_sum_lb(const double* __restrict__ local_lb, int B, double* __restrict__ lb_total) {
   __shared__ double red[256];
   double acc = 0.0;

@@ -111,6 +111,14 @@ struct svihmm_ctx {
   bool have_emission = false;
   // work
   Buf starts, ll, la, lb, q, lse_part, local_lb, logz, part, packed, scratch;
+  // scaled linear-domain sweeps: per-row binary exponents, (na, k) records, 1/Z factors,
+  // Eh of host-supplied lliks; log-domain intermediates materialised on demand (m_*)
+  Buf kexp, nak, zfac, llE, m_ll, m_la, m_lb;
+  bool lin_mode = false;           // ll/la hold Eh / ah of the last sweep (not logs)
+  bool lin_stale = false;          // parameters changed since: logs can no longer be rebuilt
+  bool last_host_ll = false;       // the last sweep ran on host-supplied lliks
+  uint32_t last_flags = 0;
+  int m_b0 = 0, m_nb = 0;          // window range currently materialised in m_*
   int lastB = 0, lastLm = 0;       // shape of the intermediates currently held
   int hostB = 0, hostLm = 0;       // shape of host-uploaded lliks
   bool have_host_ll = false;
@@ -193,7 +201,8 @@ int svihmm_destroy(svihmm_ctx* h) {
   for (auto e : h->pool) hipEventDestroy(e);
   Buf* bufs[] = {&h->obs, &h->mask, &h->mod_init, &h->ltran, &h->Aexp, &h->AexpT, &h->theta, &h->niw,
                  &h->fab, &h->starts, &h->ll, &h->la, &h->lb, &h->q, &h->lse_part,
-                 &h->local_lb, &h->logz, &h->part, &h->packed, &h->scratch};
+                 &h->local_lb, &h->logz, &h->part, &h->packed, &h->scratch, &h->kexp, &h->nak,
+                 &h->zfac, &h->llE, &h->m_ll, &h->m_la, &h->m_lb};
   for (Buf* b : bufs) release(*b);
   if (h->pin) hipHostFree(h->pin);
   if (h->pin_status) hipHostFree(h->pin_status);
@@ -215,6 +224,7 @@ int svihmm_set_obs(svihmm_ctx* h, const double* obs, int64_t T, int32_t D,
   if (!h || !obs || T <= 0 || D <= 0) return fail("svihmm_set_obs: bad arguments");
   if (D > 4095) return fail("svihmm_set_obs: D too large");
   CK(set_device(h));
+  h->lin_stale = true;
   ProfScope ps(h, KS_H2D);
   CK(ensure(h->obs, (size_t)T * D * sizeof(double)));
   HIPCK(hipMemcpyAsync(h->obs.p, obs, (size_t)T * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -232,6 +242,7 @@ int svihmm_set_globals(svihmm_ctx* h, int32_t K, const double* mod_init, const d
   if (!h || K <= 0 || !mod_init || !ltran) return fail("svihmm_set_globals: bad arguments");
   if (K > 1024) return fail("svihmm_set_globals: K > 1024 unsupported");
   CK(set_device(h));
+  h->lin_stale = true;
   const size_t kk = (size_t)K * K * sizeof(double);
   CK(ensure(h->mod_init, K * sizeof(double)));
   CK(ensure(h->ltran, kk));
@@ -304,6 +315,7 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
   if ((size_t)(3 * D * (D + 1) + D) * 8 > 150 * 1024)
     return fail("svihmm_set_emission_niw: D too large");
   CK(set_device(h));
+  h->lin_stale = true;
   CK(upload_feature_table(h, D, K));
   const int Fp = h->Fp, Kp = h->Kp;
   const size_t nmu = (size_t)K * D, nsg = (size_t)K * D * D;
@@ -356,6 +368,7 @@ int svihmm_set_lliks(svihmm_ctx* h, const double* lliks, int32_t B, int32_t Lm) 
   if (!h || !lliks || B <= 0 || Lm <= 0) return fail("svihmm_set_lliks: bad arguments");
   if (!h->have_globals) return fail("svihmm_set_lliks: call svihmm_set_globals first (K unknown)");
   CK(set_device(h));
+  h->lin_stale = true;
   const size_t n = (size_t)B * Lm * h->K * sizeof(double);
   CK(ensure(h->ll, n));
   HIPCK(hipMemcpyAsync(h->ll.p, lliks, n, hipMemcpyHostToDevice, h->stream));
@@ -383,41 +396,57 @@ static int upload_starts(svihmm_ctx* h, const int64_t* starts, int B) {
   return 0;
 }
 
-static int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags) {
+// scaled: write (Eh, kexp) for the linear-domain sweeps instead of ll (K <= 64 only).
+// starts_dev / out: window starts and destination (default: the handle's buffers).
+static int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled = false,
+                           const int64_t* starts_dev = nullptr, double* out = nullptr) {
   if (!h->have_emission) return fail("no emission parameters: call svihmm_set_emission_niw");
   if (h->eD != h->D) return fail("emission D does not match obs D");
   if (!h->have_globals || h->eK != h->K) return fail("emission K does not match globals K");
   const int64_t n = (int64_t)B * Lm;
   const int D = h->D, K = h->K, Kp = h->Kp;
-  CK(ensure(h->ll, (size_t)n * K * sizeof(double)));
+  if (!out) {
+    CK(ensure(h->ll, (size_t)n * K * sizeof(double)));
+    out = (double*)h->ll.p;
+  }
+  if (!starts_dev) starts_dev = (const int64_t*)h->starts.p;
+  if (scaled) CK(ensure(h->kexp, (size_t)n * sizeof(double)));
   const uint8_t* mk = h->have_mask ? (const uint8_t*)h->mask.p : nullptr;
   ProfScope ps(h, KS_EMISSION);
   int var = h->variant[0];
-  if (var == 0) var = 2;
+  if (var == 0 || scaled) var = 2;
   if (var == 2) {
     const int DS = (D + 2) | 1;
     int MT = h->variant[3] > 0 ? h->variant[3] : 2;
     if (MT != 2 && MT != 4) MT = 2;
     size_t lds = (size_t)(64 * MT) * DS * 8 + (size_t)h->Fp * 4 + 64 * MT;
     if (lds > 150 * 1024 && MT == 4) { MT = 2; lds = (size_t)128 * DS * 8 + (size_t)h->Fp * 4 + 128; }
+    if (lds > 150 * 1024 && scaled) return fail("emission: D too large for the scaled sweeps");
     if (lds > 150 * 1024) var = 1;
     else {
       const int ntile = Kp / 16;
-      const int NT = (ntile % 4 == 0) ? 4 : (ntile % 2 == 0) ? 2 : 1;
+      int NT = (ntile % 4 == 0) ? 4 : (ntile % 2 == 0) ? 2 : 1;
+      if (scaled) { NT = ntile; MT = 2; }   // the workgroup must own whole rows (K <= 64)
       const int rows = 64 * MT;
       dim3 grid((unsigned)((n + rows - 1) / rows), ntile / NT);
-#define EMM_LAUNCH(NTV, MTV)                                                                 \
+#define EMM_LAUNCH(NTV, MTV, SC)                                                             \
   do {                                                                                        \
     if (lds > 64 * 1024)                                                                      \
-      hipFuncSetAttribute((const void*)k_emission_mfma<NTV, MTV>,                             \
+      hipFuncSetAttribute((const void*)k_emission_mfma<NTV, MTV, SC>,                         \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
-    hipLaunchKernelGGL((k_emission_mfma<NTV, MTV>), grid, dim3(256), lds, h->stream,          \
-                       (const double*)h->obs.p, mk, (const int64_t*)h->starts.p, n, Lm, D, K, \
+    hipLaunchKernelGGL((k_emission_mfma<NTV, MTV, SC>), grid, dim3(256), lds, h->stream,      \
+                       (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K,                  \
                        Kp, h->Fp, (const double*)h->theta.p, (const int*)h->fab.p, flags,     \
-                       (double*)h->ll.p);                                                     \
+                       out, (double*)h->kexp.p);                                              \
   } while (0)
-      if (MT == 4) { if (NT == 4) EMM_LAUNCH(4, 4); else if (NT == 2) EMM_LAUNCH(2, 4); else EMM_LAUNCH(1, 4); }
-      else { if (NT == 4) EMM_LAUNCH(4, 2); else if (NT == 2) EMM_LAUNCH(2, 2); else EMM_LAUNCH(1, 2); }
+      if (scaled) {
+        if (NT == 4) EMM_LAUNCH(4, 2, true); else if (NT == 3) EMM_LAUNCH(3, 2, true);
+        else if (NT == 2) EMM_LAUNCH(2, 2, true); else EMM_LAUNCH(1, 2, true);
+      } else if (MT == 4) {
+        if (NT == 4) EMM_LAUNCH(4, 4, false); else if (NT == 2) EMM_LAUNCH(2, 4, false); else EMM_LAUNCH(1, 4, false);
+      } else {
+        if (NT == 4) EMM_LAUNCH(4, 2, false); else if (NT == 2) EMM_LAUNCH(2, 2, false); else EMM_LAUNCH(1, 2, false);
+      }
 #undef EMM_LAUNCH
     }
   }
@@ -428,26 +457,29 @@ static int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags) {
       hipFuncSetAttribute((const void*)k_emission_outer, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid((unsigned)((n + EM_R - 1) / EM_R), Kp / 16);
     hipLaunchKernelGGL(k_emission_outer, grid, dim3(EM_R), lds, h->stream,
-                       (const double*)h->obs.p, mk, (const int64_t*)h->starts.p, n, Lm, D, K,
-                       Kp, (const double*)h->theta.p, flags, (double*)h->ll.p);
+                       (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K,
+                       Kp, (const double*)h->theta.p, flags, out);
   }
   HIPCK(hipGetLastError());
   return 0;
 }
 
-static int launch_fb(svihmm_ctx* h, int B, int Lm, int dir0, int ndir) {
+static int launch_fb(svihmm_ctx* h, int B, int Lm, int dir0, int ndir,
+                     const double* ll = nullptr, double* la = nullptr, double* lb = nullptr) {
   if (!h->have_globals) return fail("no globals: call svihmm_set_globals");
   const int K = h->K;
   const size_t n = (size_t)B * Lm * K * sizeof(double);
-  if (dir0 == 0) CK(ensure(h->la, n));
-  if (dir0 + ndir > 1) CK(ensure(h->lb, n));
+  if (!ll) {
+    if (dir0 == 0) CK(ensure(h->la, n));
+    if (dir0 + ndir > 1) CK(ensure(h->lb, n));
+    ll = (const double*)h->ll.p;
+    la = (double*)h->la.p;
+    lb = (double*)h->lb.p;
+  }
   ProfScope ps(h, KS_FB);
   dim3 grid(B, ndir);
-  const double* ll = (const double*)h->ll.p;
   const double* A = (const double*)h->Aexp.p;
   const double* mi = (const double*)h->mod_init.p;
-  double* la = (double*)h->la.p;
-  double* lb = (double*)h->lb.p;
   if (K <= 16)
     hipLaunchKernelGGL(k_fb_wave<16>, grid, dim3(64), 0, h->stream, ll, A, mi, Lm, K, dir0, la, lb);
   else if (K <= 32)
@@ -542,12 +574,75 @@ static int launch_fb_fused(svihmm_ctx* h, int B, int Lm, bool want_lb, bool tota
   return 0;
 }
 
-// messages + posterior for a window batch: picks the fused MFMA sweeps or the
-// wave-per-window kernels (concurrent directions; better latency for small batches)
-static int run_fb(svihmm_ctx* h, int B, int Lm, bool want_lb, bool total) {
+// scaled linear-domain sweeps (K <= 64): Eh / kexp -> ah, (na, k), Z -> var_x
+static int launch_fb_lin(svihmm_ctx* h, int B, int Lm, bool total) {
+  if (!h->have_globals) return fail("no globals: call svihmm_set_globals");
+  const int K = h->K;
+  const size_t n = (size_t)B * Lm * K * sizeof(double);
+  CK(ensure(h->la, n));
+  CK(ensure(h->q, n));
+  CK(ensure(h->nak, (size_t)B * Lm * sizeof(double2)));
+  CK(ensure(h->zfac, (size_t)B * sizeof(double2)));
+  CK(ensure(h->local_lb, (size_t)B * sizeof(double)));
+  CK(ensure(h->logz, (size_t)B * sizeof(double)));
+  CK(ensure(h->packed, (size_t)svihmm_packed_size(K, h->D > 0 ? h->D : 1) * sizeof(double)));
+  const int NW = (K + 15) / 16;
+  const bool full = (K == 16 * NW);
+  dim3 grid((B + 15) / 16);
+  const double* Eh = (const double*)(h->last_host_ll ? h->llE.p : h->ll.p);
+  const double* kx = (const double*)h->kexp.p;
+  double* ah = (double*)h->la.p;
+  double2* nak = (double2*)h->nak.p;
+  double2* zf = (double2*)h->zfac.p;
+  double* llb = (double*)h->local_lb.p;
+  {
+    ProfScope ps(h, KS_FB);
+#define FWD(NWV, F) hipLaunchKernelGGL((k_fwd_lin<NWV, F>), grid, dim3(64 * NWV), 0, h->stream, Eh, kx, \
+                                       (const double*)h->Aexp.p, (const double*)h->mod_init.p, B, Lm, K, \
+                                       ah, nak, llb, (double*)h->logz.p, zf)
+    if (NW == 1) { if (full) FWD(1, true); else FWD(1, false); }
+    else if (NW == 2) { if (full) FWD(2, true); else FWD(2, false); }
+    else if (NW == 3) { if (full) FWD(3, true); else FWD(3, false); }
+    else { if (full) FWD(4, true); else FWD(4, false); }
+#undef FWD
+    HIPCK(hipGetLastError());
+  }
+  {
+    ProfScope ps(h, KS_POSTERIOR);
+#define BWD(NWV, F) hipLaunchKernelGGL((k_bwd_lin<NWV, F>), grid, dim3(64 * NWV), 0, h->stream, Eh, \
+                                       (const double2*)nak, (const double*)h->AexpT.p, (const double*)ah, \
+                                       (const double2*)zf, B, Lm, K, (double*)h->q.p)
+    if (NW == 1) { if (full) BWD(1, true); else BWD(1, false); }
+    else if (NW == 2) { if (full) BWD(2, true); else BWD(2, false); }
+    else if (NW == 3) { if (full) BWD(3, true); else BWD(3, false); }
+    else { if (full) BWD(4, true); else BWD(4, false); }
+#undef BWD
+    if (total) {
+      double* lbtot = (double*)h->packed.p + (svihmm_packed_size(K, h->D) - 1);
+      hipLaunchKernelGGL(k_sum_lb, dim3(1), dim3(256), 0, h->stream, (const double*)llb, B, lbtot);
+    }
+    HIPCK(hipGetLastError());
+  }
+  return 0;
+}
+
+// Which sweep implementation a batch uses: 1 wave-per-window (log domain; small batches,
+// K > 64), 2 log-domain MFMA (callers that want lalpha / lbeta back), 3 scaled
+// linear-domain MFMA (the E-step fast path; logs are materialised on demand).
+static int pick_fb(const svihmm_ctx* h, int B, bool want_logs) {
   int var = h->variant[2];
-  if (h->K > 64) var = 1;
-  if (var == 0) var = (B >= 192) ? 2 : 1;
+  if (h->K > 64) return 1;
+  if (var == 0) var = (B >= 192) ? (want_logs ? 2 : 3) : 1;
+  return var;
+}
+
+// messages + posterior for a window batch (mode from pick_fb, fixed before the emission ran)
+static int run_fb(svihmm_ctx* h, int B, int Lm, int var, bool want_lb, bool total) {
+  h->m_nb = 0;
+  if (var == 3) {
+    h->have_lb = true;   // materialised lazily
+    return launch_fb_lin(h, B, Lm, total);
+  }
   h->have_lb = (var != 2) || want_lb;
   if (var == 2) return launch_fb_fused(h, B, Lm, want_lb, total);
   CK(launch_fb(h, B, Lm, 0, 2));
@@ -675,8 +770,24 @@ int64_t svihmm_packed_size(int32_t K, int32_t D) {
   return (int64_t)K * K + (int64_t)K * D + K + (int64_t)K * D * D + 1;
 }
 
+static int launch_scale_ll(svihmm_ctx* h, int B, int Lm) {
+  const int64_t n = (int64_t)B * Lm;
+  const int K = h->K;
+  CK(ensure(h->llE, (size_t)n * K * sizeof(double)));
+  CK(ensure(h->kexp, (size_t)n * sizeof(double)));
+  ProfScope ps(h, KS_EMISSION);
+  dim3 grid((unsigned)((n + 15) / 16));
+#define SC(KT) hipLaunchKernelGGL(k_scale_ll<KT>, grid, dim3(256), 0, h->stream, (const double*)h->ll.p, \
+                                  n, K, (double*)h->llE.p, (double*)h->kexp.p)
+  if (K <= 16) SC(1); else if (K <= 32) SC(2); else if (K <= 48) SC(3); else SC(4);
+#undef SC
+  HIPCK(hipGetLastError());
+  return 0;
+}
+
+// lin: the batch goes through the scaled linear-domain sweeps (pick_fb == 3)
 static int prepare_ll(svihmm_ctx* h, const int64_t* starts, int B, int Lm, uint32_t flags,
-                      bool need_obs_for_stats) {
+                      bool need_obs_for_stats, bool lin = false) {
   if (!h->have_globals) return fail("no globals: call svihmm_set_globals");
   const bool host_ll = flags & SVIHMM_USE_HOST_LLIKS;
   CK(check_windows(h, starts, B, Lm, !host_ll || need_obs_for_stats));
@@ -684,10 +795,57 @@ static int prepare_ll(svihmm_ctx* h, const int64_t* starts, int B, int Lm, uint3
   if (host_ll) {
     if (!h->have_host_ll || h->hostB != B || h->hostLm != Lm)
       return fail("SVIHMM_USE_HOST_LLIKS: no uploaded lliks of shape [B,Lm,K]");
+    if (lin) CK(launch_scale_ll(h, B, Lm));
   } else {
-    CK(launch_emission(h, B, Lm, flags));
+    CK(launch_emission(h, B, Lm, flags, lin));
     h->have_host_ll = false;
   }
+  h->lin_mode = lin;
+  h->lin_stale = false;
+  h->last_host_ll = host_ll;
+  h->last_flags = flags;
+  h->m_nb = 0;
+  return 0;
+}
+
+// Log-domain lliks / lalpha / lbeta of windows [b0, b0+nb) of the last (scaled) sweep,
+// recomputed by the log-domain kernels into the m_* side buffers.
+static int materialise(svihmm_ctx* h, int b0, int nb) {
+  if (h->m_nb > 0 && b0 >= h->m_b0 && b0 + nb <= h->m_b0 + h->m_nb) return 0;
+  if (h->lin_stale)
+    return fail("log-domain intermediates of the last E-step are rebuilt on demand and the "
+                "observations / globals / emission parameters have changed since: read them "
+                "before the next parameter upload");
+  const int Lm = h->lastLm, K = h->K;
+  const size_t n = (size_t)nb * Lm * K * sizeof(double);
+  CK(ensure(h->m_la, n));
+  CK(ensure(h->m_lb, n));
+  const double* ll;
+  if (h->last_host_ll) {
+    ll = (const double*)h->ll.p + (size_t)b0 * Lm * K;
+  } else {
+    CK(ensure(h->m_ll, n));
+    CK(launch_emission(h, nb, Lm, h->last_flags, false, (const int64_t*)h->starts.p + b0,
+                       (double*)h->m_ll.p));
+    ll = (const double*)h->m_ll.p;
+  }
+  CK(launch_fb(h, nb, Lm, 0, 2, ll, (double*)h->m_la.p, (double*)h->m_lb.p));
+  h->m_b0 = b0; h->m_nb = nb;
+  return 0;
+}
+// device pointer of row `row0` of intermediate `what` (0 lliks, 1 lalpha, 2 lbeta, 3 var_x)
+static int intermediate_ptr(svihmm_ctx* h, int what, int64_t row0, int64_t nrows, const double** out) {
+  const int K = h->K, Lm = h->lastLm;
+  Buf* src[] = {&h->ll, &h->la, &h->lb, &h->q};
+  if (!h->lin_mode || what == 3 || (what == 0 && h->last_host_ll)) {
+    if (!src[what]->p) return fail("intermediate buffer not available");
+    *out = (const double*)src[what]->p + (size_t)row0 * K;
+    return 0;
+  }
+  const int b0 = (int)(row0 / Lm), b1 = (int)((row0 + nrows - 1) / Lm) + 1;
+  CK(materialise(h, b0, b1 - b0));
+  Buf* ms[] = {&h->m_ll, &h->m_la, &h->m_lb};
+  *out = (const double*)ms[what]->p + ((size_t)row0 - (size_t)h->m_b0 * Lm) * K;
   return 0;
 }
 
@@ -708,11 +866,14 @@ int svihmm_forward_backward(svihmm_ctx* h, const int64_t* starts, int32_t B, int
                             double* out_var_x, double* out_local_lb) {
   if (!h) return fail("svihmm_forward_backward: NULL handle");
   CK(set_device(h));
-  CK(prepare_ll(h, starts, B, Lm, flags, false));
-  CK(run_fb(h, B, Lm, out_lbeta != nullptr, false));
+  const int var = pick_fb(h, B, out_lalpha != nullptr || out_lbeta != nullptr);
+  CK(prepare_ll(h, starts, B, Lm, flags, false, var == 3));
+  CK(run_fb(h, B, Lm, var, out_lbeta != nullptr, false));
+  h->lastB = B; h->lastLm = Lm;
+  if (var == 3 && (out_lalpha || out_lbeta)) CK(materialise(h, 0, B));   // forced variant
   const size_t n = (size_t)B * Lm * h->K * sizeof(double);
-  if (out_lalpha) CK(d2h(h, out_lalpha, h->la.p, n));
-  if (out_lbeta) CK(d2h(h, out_lbeta, h->lb.p, n));
+  if (out_lalpha) CK(d2h(h, out_lalpha, var == 3 ? h->m_la.p : h->la.p, n));
+  if (out_lbeta) CK(d2h(h, out_lbeta, var == 3 ? h->m_lb.p : h->lb.p, n));
   if (out_var_x) CK(d2h(h, out_var_x, h->q.p, n));
   if (out_local_lb) CK(d2h(h, out_local_lb, h->local_lb.p, (size_t)B * sizeof(double)));
   HIPCK(hipStreamSynchronize(h->stream));
@@ -745,8 +906,9 @@ int svihmm_estep_minibatch_ex(svihmm_ctx* h, const int64_t* starts, int32_t B, i
   }
   if (inner_off < 0 || inner_len <= 0 || inner_off + inner_len > Lm)
     return fail("svihmm_estep_minibatch_ex: inner segment out of range");
-  CK(prepare_ll(h, starts, B, Lm, flags, true));
-  CK(run_fb(h, B, Lm, (flags & SVIHMM_KEEP_LBETA) != 0, true));
+  const int var = pick_fb(h, B, false);
+  CK(prepare_ll(h, starts, B, Lm, flags, true, var == 3));
+  CK(run_fb(h, B, Lm, var, (flags & SVIHMM_KEEP_LBETA) != 0, true));
   CK(launch_stats(h, B, Lm, inner_off, inner_len, flags));
   h->have_packed = true;
   h->lastB = B; h->lastLm = Lm;
@@ -772,13 +934,13 @@ int svihmm_read_intermediate(svihmm_ctx* h, int32_t what, double* out) {
   if (!h || !out) return fail("svihmm_read_intermediate: bad arguments");
   if (h->lastB <= 0) return fail("svihmm_read_intermediate: nothing computed yet");
   CK(set_device(h));
-  Buf* src[] = {&h->ll, &h->la, &h->lb, &h->q};
   if (what < 0 || what > 3) return fail("svihmm_read_intermediate: bad selector");
   if (what == 2 && !h->have_lb)
     return fail("svihmm_read_intermediate: lbeta was not materialised (pass SVIHMM_KEEP_LBETA)");
-  const size_t n = (size_t)h->lastB * h->lastLm * h->K * sizeof(double);
-  if (!src[what]->p || src[what]->cap < n) return fail("svihmm_read_intermediate: buffer not available");
-  CK(d2h(h, out, src[what]->p, n));
+  const int64_t rows = (int64_t)h->lastB * h->lastLm;
+  const double* src = nullptr;
+  CK(intermediate_ptr(h, what, 0, rows, &src));
+  CK(d2h(h, out, src, (size_t)rows * h->K * sizeof(double)));
   HIPCK(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -791,9 +953,9 @@ int svihmm_read_rows(svihmm_ctx* h, int32_t what, int64_t row0, int64_t nrows, d
     return fail("svihmm_read_rows: lbeta was not materialised (pass SVIHMM_KEEP_LBETA)");
   if (row0 + nrows > (int64_t)h->lastB * h->lastLm) return fail("svihmm_read_rows: out of range");
   CK(set_device(h));
-  Buf* src[] = {&h->ll, &h->la, &h->lb, &h->q};
-  if (!src[what]->p) return fail("svihmm_read_rows: buffer not available");
-  CK(d2h(h, out, (const double*)src[what]->p + (size_t)row0 * h->K, (size_t)nrows * h->K * sizeof(double)));
+  const double* src = nullptr;
+  CK(intermediate_ptr(h, what, row0, nrows, &src));
+  CK(d2h(h, out, src, (size_t)nrows * h->K * sizeof(double)));
   HIPCK(hipStreamSynchronize(h->stream));
   return 0;
 }

@@ -56,7 +56,7 @@ def test_golden_windows(eng, path, evar):
         np.testing.assert_allclose(ll, g["w_lliks"][sl], rtol=1e-9, atol=1e-8)
         # a4..a7 from the reference's own lliks: pure reference arithmetic
         eng.set_lliks(g["w_lliks"][sl])
-        for fv in (1, 2):                    # wave-per-window and fused MFMA sweeps
+        for fv in (1, 2, 3):                 # wave-per-window, log-MFMA, scaled linear-domain sweeps
             eng.set_variant("fb", fv)
             r = eng.forward_backward(None, Lm, flags=L.USE_HOST_LLIKS, B=wpi)
             np.testing.assert_allclose(r["lalpha"], g["w_lalpha"][sl], rtol=1e-10, atol=1e-9)
@@ -145,14 +145,15 @@ CASES = [  # K, D, T, Lm, B, miss
 @pytest.mark.parametrize("var", [1, 2, 3], ids=["outer", "mfma", "mfma_pipelined"])
 def test_random_vs_c_oracle(eng, case, var):
     """var 1: VALU kernels + wave-per-window recursions; var 2: fp64 MFMA emission/statistics
-    + fused MFMA forward / backward+posterior sweeps (K <= 64)."""
+    + log-domain MFMA forward / backward+posterior sweeps (K <= 64); var 3: pipelined
+    statistics + scaled linear-domain sweeps (logs rebuilt on demand)."""
     from pysvihmm_amd import _lib as L
     from oracle import ref_c
     K, D, T, Lm, B, miss = case
     pb = make_problem(K, D, T, seed=100 + K + D, miss=miss)
     rng = np.random.default_rng(K * 7 + D)
     starts = rng.integers(0, T - Lm + 1, size=B)
-    eng.set_variant("emission", min(var, 2)); eng.set_variant("stats", var); eng.set_variant("fb", min(var, 2))
+    eng.set_variant("emission", min(var, 2)); eng.set_variant("stats", var); eng.set_variant("fb", var)
     eng.set_obs(pb["obs"], pb["mask"])
     eng.set_globals(pb["mod_init"], pb["ltran"])
     eng.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
@@ -266,8 +267,19 @@ def test_full_size_properties(eng):
     np.testing.assert_allclose(st.S, np.swapaxes(st.S, 1, 2), rtol=0, atol=0)
     q = eng.read_intermediate("var_x", B, Lm)
     np.testing.assert_allclose(q.sum(-1), 1.0, rtol=1e-12)
-    with pytest.raises(RuntimeError):           # fused sweep keeps lbeta in registers
-        eng.read_intermediate("lbeta", B, Lm)
+    # the scaled sweeps keep no log-domain messages: a window's lalpha / lbeta / lliks are
+    # rebuilt on demand by the log-domain kernels and must match the oracle
+    from oracle import ref_numpy as R
+    b = B - 2
+    rows = {w: eng.read_rows(w, b * Lm, Lm) for w in ("lliks", "lalpha", "lbeta", "var_x")}
+    x = pb["obs"][starts[b]:starts[b] + Lm]
+    ll_ref = R.lliks_niw(x, pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    np.testing.assert_allclose(rows["lliks"], ll_ref, rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(rows["lalpha"], R.forward_msgs(ll_ref, pb["mod_init"], pb["ltran"]),
+                               rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(rows["lbeta"], R.backward_msgs(ll_ref, pb["ltran"]),
+                               rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(rows["var_x"], q[b], rtol=0, atol=0)
     # marginal consistency: row sums of the transition statistic = sum_t q[t-1] (wrap => all t)
     np.testing.assert_allclose(st.A_raw.sum(1), q.sum((0, 1)), rtol=1e-9)
     np.testing.assert_allclose(st.A_raw.sum(0), q.sum((0, 1)), rtol=1e-9)
@@ -280,7 +292,7 @@ def test_full_size_properties(eng):
     np.testing.assert_allclose(st2.buf, ref, rtol=RTOL, atol=1e-6)
 
 
-@pytest.mark.parametrize("fbv", [1, 2], ids=["wave", "mfma"])
+@pytest.mark.parametrize("fbv", [1, 2, 3], ids=["wave", "mfma", "lin"])
 def test_unreachable_state(eng, fbv):
     """A state nobody can transition into (ltran column ~ -1e9, i.e. var_tran ~ 0): the
     linear-domain recursion sees exactly zero weight; posteriors and statistics must still
