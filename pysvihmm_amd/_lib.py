@@ -71,6 +71,8 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # developer override for A/B runs of differently built HIP libraries (still the HIP path)
+    LIB_PATH = os.environ.get("SVIHMM_HIP_LIB", globals()["LIB_PATH"])
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             "HIP extension not built: %s is missing. Build it with "

@@ -478,24 +478,34 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_mfma(
 }
 
 // ------------------------------------------------------------------------------------
-//  K2e/K2f: scaled linear-domain sweeps -- the E-step fast path (K <= 64, B >= 192).
+//  K2e: scaled linear-domain sweeps -- the E-step fast path (K <= 64, B >= 192).
 //  Same batching as K2c/K2d (16 windows per workgroup, wave s owns state tile 16*s), but
 //  nothing in the time loop is a transcendental: the emission kernel hands over
 //      Eh[t][j] = exp(ll[t][j]) * 2^-k_t,   k_t = ceil(max_j ll[t][j] / ln 2)  (integer),
-//  and the messages are carried as (mantissa-like vector, integer binary exponent):
-//      alpha_t[j] = ah_t[j] * 2^na_t,       beta_t[j] = bh_t[j] * 2^nb_t.
-//  Forward:  ah_t = (ah_{t-1} . A) * Eh_t * 2^-e,  na_t = na_{t-1} + k_t + e,
-//            e = frexp exponent of sum_i ah_{t-1}[i]  (keeps sum ah in [2^-?, 1)).
-//  Backward: v_{t+1} = Eh_{t+1} * bh_{t+1};  bh_t = (A . v_{t+1}) * 2^-e,
-//            nb_t = nb_{t+1} + k_{t+1} + e,  e = frexp exponent of sum_j v_{t+1}[j];
-//  posterior q_t[j] = ah_t[j] * bh_t[j] * 2^(na_t + nb_t - ze) / zm with Z = zm * 2^ze from
-//  the forward sweep (hmmbase.py:226-229 normalises by the row sum, which equals Z).
+//  and the messages are carried as (vector, integer binary exponent):
+//      alpha_t[j] = ah_t[j] * 2^(h_t + K_t),   beta_t[j] = bh_t[j] * 2^(g_t + K_top - K_t),
+//  K_t = k_0 + .. + k_t.  Forward:  ah_t = (ah_{t-1} . A) * Eh_t * 2^-e,  h_t = h_{t-1} + e,
+//  e = frexp exponent of sum_i ah_{t-1}[i].  Backward: v_{t+1} = Eh_{t+1} * bh_{t+1},
+//  bh_t = (A . v_{t+1}) * 2^-e,  g_t = g_{t+1} + e,  e = frexp exponent of sum_j v_{t+1}[j].
+//  The posterior needs no k at all:
+//      q_t[j] = ah_t[j] * bh_t[j] * 2^(h_t + g_t - h_top - zexp) / zm,   Z = zm * 2^(..+zexp)
+//  (hmmbase.py:226-229 normalises by the row sum, which equals Z); it is formed by its
+//  consumers (the statistics GEMM's staging threads, or k_lin_posterior for API reads).
+//  The two directions are independent, so ONE launch runs both (blockIdx.y = direction):
+//  a forward and a backward workgroup share each CU, two waves per SIMD, and one direction's
+//  matrix work fills the other's LDS / barrier / memory-issue gaps.
 //  The row sum needed for e costs one extra MFMA: lane (li, lg) adds up the 16 A-operand
-//  values it loads anyway (row li, k = 2lg, 2lg+1 mod 8) and multiplies against a ones
-//  operand, so every accumulator register r holds the sum of window lg + 4r -- exactly the
-//  layout the per-window scalars live in.  One barrier per step, no reduction through LDS.
-//  local_lb = sum_t LSE_j lalpha_t[j] (quirk Q4) is a running (mantissa, exponent) product.
-//  Log-domain lalpha / lbeta / lliks are materialised on demand by the log kernels above.
+//  values it loads anyway and multiplies against a ones operand, so every accumulator
+//  register r holds the sum of window lg + 4r -- the layout the per-window scalars live in.
+//  One barrier per step, no reduction through LDS.  local_lb = sum_t LSE_j lalpha_t[j]
+//  (quirk Q4) is a running (mantissa, exponent) product.  Log-domain lalpha / lbeta / lliks
+//  are materialised on demand by the log-domain kernels above.
+//  Addressing: the workgroup's 16 windows are contiguous rows [b0*Lm, (b0+16)*Lm), so every
+//  access is (uniform base advanced by t) + (32-bit per-lane offset fixed for the kernel) --
+//  no 64-bit vector address arithmetic in the loop (host guarantees 16*Lm*K*8 < 2^32).
+//  The time loop is unrolled by two with one register set per parity: a value loaded at step
+//  t is first touched at step t+2, so its wait is a counted vmcnt a full step behind the
+//  stores (gfx9 counts loads and stores in one in-order counter).
 // ------------------------------------------------------------------------------------
 #define LOG2E_D 1.4426950408889634074
 #define LN2_HI_D 6.93147180369123816490e-01
@@ -523,8 +533,8 @@ __device__ __forceinline__ void lin_matmul(const LinShared<NW>& sh, int cur, int
     a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, Bv[2 * c + 1], a1, 0, 0, 0);
     a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(y.x, Bv[2 * c + 2], a2, 0, 0, 0);
     a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(y.y, Bv[2 * c + 3], a3, 0, 0, 0);
-    s0 += x.x + y.x;
-    s1 += x.y + y.y;
+    s0 = (c == 0) ? x.x + y.x : s0 + (x.x + y.x);
+    s1 = (c == 0) ? x.y + y.y : s1 + (x.y + y.y);
   }
   const double4_t z = {0, 0, 0, 0};
   tot = __builtin_amdgcn_mfma_f64_16x16x4f64(s0 + s1, 1.0, z, 0, 0, 0);
@@ -543,179 +553,265 @@ __device__ __forceinline__ double4_t lin_rowsum(const LinShared<NW>& sh, int cur
   return __builtin_amdgcn_mfma_f64_16x16x4f64(s, 1.0, z, 0, 0, 0);
 }
 
+// per-lane state shared by both directions
 template <int NW, bool FULL>
-__global__ __launch_bounds__(64 * NW) void k_fwd_lin(
-    const double* __restrict__ Eh, const double* __restrict__ kexp,
+struct LinLane {
+  int lane, wave, li, lg, j, jc, b0;
+  bool vj;
+  unsigned oE[4], oR[4], oRw;   // 32-bit element offsets of (window lg+4r, state j) / row; oRw: window lg+4*wave
+  int gwc[4];
+  __device__ __forceinline__ void init(int B, int Lm, int K) {
+    lane = threadIdx.x & 63; wave = threadIdx.x >> 6;
+    li = lane & 15; lg = lane >> 4;
+    j = wave * 16 + li;
+    vj = FULL || (j < K);
+    jc = vj ? j : 0;
+    b0 = blockIdx.x * 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gw = b0 + lg + 4 * r;
+      gwc[r] = gw < B ? gw : B - 1;
+      oR[r] = (unsigned)(gwc[r] - b0) * (unsigned)Lm;
+      oE[r] = oR[r] * (unsigned)K + (unsigned)jc;
+    }
+    const int gww = b0 + lg + 4 * (wave & 3);
+    oRw = (unsigned)((gww < B ? gww : B - 1) - b0) * (unsigned)Lm;
+  }
+};
+// value of register array v[r] for r == wave (wave-uniform select; NW == 4 only)
+__device__ __forceinline__ double sel4(const double (&v)[4], int w) {
+  return w == 0 ? v[0] : (w == 1 ? v[1] : (w == 2 ? v[2] : v[3]));
+}
+
+template <int NW, bool FULL>
+__device__ __forceinline__ void fwd_lin_body(
+    LinShared<NW>& sh, const double* __restrict__ Eh, const double* __restrict__ kexp,
     const double* __restrict__ Aexp, const double* __restrict__ mod_init, int B, int Lm, int K,
-    double* __restrict__ ah, double2* __restrict__ nak, double* __restrict__ local_lb,
+    double* __restrict__ ah, double* __restrict__ hx, double* __restrict__ local_lb,
     double* __restrict__ logz, double2* __restrict__ zfac) {
   constexpr int KS = 4 * NW;
-  __shared__ LinShared<NW> sh;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int li = lane & 15, lg = lane >> 4;
-  const int j = wave * 16 + li;
-  const bool vj = FULL || (j < K);
-  const int jc = vj ? j : 0;
-  const int b0 = blockIdx.x * 16;
+  LinLane<NW, FULL> L;
+  L.init(B, Lm, K);
+  const int li = L.li, lg = L.lg, j = L.j, jc = L.jc, wave = L.wave;
+  const bool vj = L.vj;
   double Bv[KS];
 #pragma unroll
   for (int kk = 0; kk < KS; ++kk) {
     const int k = 8 * (kk >> 1) + 2 * lg + (kk & 1);
     Bv[kk] = (k < K && vj) ? Aexp[(size_t)k * K + jc] : 0.0;
   }
-  size_t base[4], rowb[4];
-  int gwc[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int gw = b0 + lg + 4 * r;
-    gwc[r] = gw < B ? gw : B - 1;
-    rowb[r] = (size_t)gwc[r] * Lm;
-    base[r] = rowb[r] * K + jc;
-  }
+  const size_t wrow = (size_t)L.b0 * Lm;
+  const double* __restrict__ Eb = Eh + wrow * K;
+  double* __restrict__ ab = ah + wrow * K;
+  double* __restrict__ hb = hx + wrow;
   // common binary exponent of the initial distribution
   double mi_max = -INFINITY;
   for (int k = 0; k < K; ++k) mi_max = fmax(mi_max, mod_init[k]);
   const double s0 = (mi_max > -1e300 && mi_max < 1e300) ? ceil(mi_max * LOG2E_D) : 0.0;
   const double pij = vj ? exp(fma(-s0, LN2_LO_D, fma(-s0, LN2_HI_D, mod_init[jc]))) : 0.0;
   const int i1 = Lm > 1 ? 1 : 0, i2 = Lm > 2 ? 2 : i1;
-  double na[4], mant[4], nsum[4], en1[4], en2[4], kn1[4], kn2[4];
+  double h[4], mant[4], hsum[4], ea[4], eb[4];
   int ex[4];
+  {
+    double e0[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const double e0 = Eh[base[r]];
-    const double k0 = kexp[rowb[r]];
-    const double a0 = vj ? pij * e0 : 0.0;
-    na[r] = s0 + k0;
-    if (vj) ah[base[r]] = a0;
-    nak[rowb[r]] = make_double2(na[r], k0);
-    sh.P[0][lg + 4 * r][j] = a0;
-    en1[r] = Eh[base[r] + (size_t)i1 * K];
-    en2[r] = Eh[base[r] + (size_t)i2 * K];
-    kn1[r] = kexp[rowb[r] + i1];
-    kn2[r] = kexp[rowb[r] + i2];
-    mant[r] = 1.0; ex[r] = 0; nsum[r] = 0.0;
-  }
-  __syncthreads();
-  for (int t = 1; t < Lm; ++t) {
-    const int cur = (t - 1) & 1, nxt = t & 1;
-    const int t2 = t + 2 < Lm ? t + 2 : Lm - 1;
-    double ev[4], kv[4];
+    for (int r = 0; r < 4; ++r) e0[r] = Eb[L.oE[r]];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ea[r] = (Eb + (size_t)i1 * K)[L.oE[r]];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) eb[r] = (Eb + (size_t)i2 * K)[L.oE[r]];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      ev[r] = en1[r]; en1[r] = en2[r]; en2[r] = Eh[base[r] + (size_t)t2 * K];
-      kv[r] = kn1[r]; kn1[r] = kn2[r]; kn2[r] = kexp[rowb[r] + t2];
+      const double a0 = vj ? pij * e0[r] : 0.0;
+      h[r] = s0;
+      if (NW != 4) hb[L.oR[r]] = s0;
+      if (FULL || vj) ab[L.oE[r]] = a0;
+      sh.P[0][lg + 4 * r][j] = a0;
+      mant[r] = 1.0; ex[r] = 0; hsum[r] = 0.0;
     }
+    if (NW == 4) hb[L.oRw] = s0;
+  }
+  __syncthreads();
+  // one time step: reads P[CUR], writes P[1-CUR]; er holds Eh_t, refilled with step t+2
+  auto step = [&](const int t, auto curc, double (&er)[4]) {
+    constexpr int CUR = decltype(curc)::value, NXT = 1 - CUR;
+    const int t2 = t + 2 < Lm ? t + 2 : Lm - 1;
     double4_t acc, tot;
-    lin_matmul<NW>(sh, cur, li, lg, Bv, acc, tot);
+    lin_matmul<NW>(sh, CUR, li, lg, Bv, acc, tot);
+    double* __restrict__ at = ab + (size_t)t * K;
+    double* __restrict__ ht = hb + t;
+    const double* __restrict__ E2 = Eb + (size_t)t2 * K;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int e2 = __builtin_amdgcn_frexp_exp(tot[r]);
-      const double av = ldexp(acc[r] * ev[r], -e2);
-      sh.P[nxt][lg + 4 * r][j] = av;
-      if (FULL || vj) ah[base[r] + (size_t)t * K] = av;
-      // LSE of step t-1: log(tot) + na_{t-1} ln 2, accumulated as a product
+      const double av = ldexp(acc[r] * er[r], -e2);
+      sh.P[NXT][lg + 4 * r][j] = av;
+      if (FULL || vj) at[L.oE[r]] = av;
+      // LSE of step t-1: log(tot) + (h_{t-1} + K_{t-1}) ln 2, accumulated as a product
       const double mm = mant[r] * tot[r];
       ex[r] += __builtin_amdgcn_frexp_exp(mm);
       mant[r] = __builtin_amdgcn_frexp_mant(mm);
-      nsum[r] += na[r];
-      na[r] += kv[r] + (double)e2;
-      nak[rowb[r] + t] = make_double2(na[r], kv[r]);
+      hsum[r] += h[r];
+      h[r] += (double)e2;
+      if (NW != 4) ht[L.oR[r]] = h[r];
+    }
+    if (NW == 4) ht[L.oRw] = sel4(h, wave);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) er[r] = E2[L.oE[r]];
+    __syncthreads();
+  };
+  {
+    int t = 1;
+    for (; t + 1 < Lm; t += 2) {
+      step(t, std::integral_constant<int, 0>{}, ea);
+      step(t + 1, std::integral_constant<int, 1>{}, eb);
+    }
+    if (t < Lm) step(t, std::integral_constant<int, 0>{}, ea);
+  }
+  // ---- epilogue: K_top = sum_t k_t and sum_t K_t = sum_t (Lm - t) k_t per window (the only
+  // place the emission exponents enter), Z = sum_j alpha_{Lm-1}[j], local_lb
+  {
+    const int last = (Lm - 1) & 1;
+    double* scr = &sh.P[1 - last][0][0];     // free buffer: [0,16) K_top, [16,32) sum_t K_t
+    const double* __restrict__ kbw = kexp + wrow;
+    for (int w = threadIdx.x >> 4; w < 16; w += 4 * NW) {
+      const int gw = L.b0 + w;
+      const unsigned o = (unsigned)((gw < B ? gw : B - 1) - L.b0) * (unsigned)Lm;
+      double a = 0.0, c = 0.0;
+      for (int t = li; t < Lm; t += 16) {
+        const double kv = kbw[o + t];
+        a += kv;
+        c += kv * (double)(Lm - t);
+      }
+      a = row16_sum(a);
+      c = row16_sum(c);
+      if (li == 0) { scr[w] = a; scr[16 + w] = c; }
     }
     __syncthreads();
-  }
-  // ---- epilogue: Z = sum_j alpha_{Lm-1}[j], local_lb
-  {
-    const double4_t tot = lin_rowsum<NW>(sh, (Lm - 1) & 1, li, lg);
+    const double4_t tot = lin_rowsum<NW>(sh, last, li, lg);
     if (wave == 0 && li == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
+        const int w = lg + 4 * r;
+        const double Ktop = scr[w], KK = scr[16 + w];
         const double mm = mant[r] * tot[r];
         const int exf = ex[r] + __builtin_amdgcn_frexp_exp(mm);
         const double mf = __builtin_amdgcn_frexp_mant(mm);
         const double zm = __builtin_amdgcn_frexp_mant(tot[r]);
-        const double ze = na[r] + (double)__builtin_amdgcn_frexp_exp(tot[r]);
-        local_lb[gwc[r]] = log(mf) + ((double)exf + nsum[r] + na[r]) * LN2_D;
-        logz[gwc[r]] = log(zm) + ze * LN2_D;
-        zfac[gwc[r]] = make_double2(1.0 / zm, ze);
+        const double zexp = (double)__builtin_amdgcn_frexp_exp(tot[r]);
+        local_lb[L.gwc[r]] = log(mf) + ((double)exf + hsum[r] + h[r] + KK) * LN2_D;
+        logz[L.gwc[r]] = log(zm) + (h[r] + Ktop + zexp) * LN2_D;
+        zfac[L.gwc[r]] = make_double2(1.0 / zm, h[r] + zexp);
       }
     }
   }
 }
 
 template <int NW, bool FULL>
-__global__ __launch_bounds__(64 * NW) void k_bwd_lin(
-    const double* __restrict__ Eh, const double2* __restrict__ nak,
-    const double* __restrict__ AexpT, const double* __restrict__ ah,
-    const double2* __restrict__ zfac, int B, int Lm, int K, double* __restrict__ q_out) {
+__device__ __forceinline__ void bwd_lin_body(
+    LinShared<NW>& sh, const double* __restrict__ Eh, const double* __restrict__ AexpT, int B,
+    int Lm, int K, double* __restrict__ bh, double* __restrict__ gx) {
   constexpr int KS = 4 * NW;
-  __shared__ LinShared<NW> sh;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int li = lane & 15, lg = lane >> 4;
-  const int j = wave * 16 + li;
-  const bool vj = FULL || (j < K);
-  const int jc = vj ? j : 0;
-  const int b0 = blockIdx.x * 16;
+  LinLane<NW, FULL> L;
+  L.init(B, Lm, K);
+  const int li = L.li, lg = L.lg, j = L.j, jc = L.jc, wave = L.wave;
+  const bool vj = L.vj;
   double Bv[KS];
 #pragma unroll
   for (int kk = 0; kk < KS; ++kk) {
     const int k = 8 * (kk >> 1) + 2 * lg + (kk & 1);
     Bv[kk] = (k < K && vj) ? AexpT[(size_t)k * K + jc] : 0.0;
   }
-  size_t base[4], rowb[4];
-  double zinv[4], ze[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int gw = b0 + lg + 4 * r;
-    const int g = gw < B ? gw : B - 1;
-    rowb[r] = (size_t)g * Lm;
-    base[r] = rowb[r] * K + jc;
-    const double2 z = zfac[g];
-    zinv[r] = z.x; ze[r] = z.y;
-  }
+  const size_t wrow = (size_t)L.b0 * Lm;
+  const double* __restrict__ Eb = Eh + wrow * K;
+  double* __restrict__ bb = bh + wrow * K;
+  double* __restrict__ gb = gx + wrow;
   const int top = Lm - 1;
   const int i1 = Lm > 1 ? top - 1 : top, i2 = Lm > 2 ? top - 2 : i1;
-  double nb[4], kprev[4], en1[4], en2[4], an1[4], an2[4];
-  double2 nn1[4], nn2[4];
+  double g[4], ea[4], eb[4];
+  {
+    double e0[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const double e0 = Eh[base[r] + (size_t)top * K];
-    const double a0 = ah[base[r] + (size_t)top * K];
-    const double2 n0 = nak[rowb[r] + top];
-    nb[r] = 0.0;
-    kprev[r] = n0.y;
-    if (vj) q_out[base[r] + (size_t)top * K] = a0 * ldexp(zinv[r], (int)(n0.x - ze[r]));
-    sh.P[0][lg + 4 * r][j] = vj ? e0 : 0.0;
-    en1[r] = Eh[base[r] + (size_t)i1 * K]; en2[r] = Eh[base[r] + (size_t)i2 * K];
-    an1[r] = ah[base[r] + (size_t)i1 * K]; an2[r] = ah[base[r] + (size_t)i2 * K];
-    nn1[r] = nak[rowb[r] + i1]; nn2[r] = nak[rowb[r] + i2];
-  }
-  __syncthreads();
-  int step = 1;
-  for (int t = Lm - 2; t >= 0; --t, ++step) {
-    const int cur = (step - 1) & 1, nxt = step & 1;
-    const int t2 = t >= 2 ? t - 2 : 0;
-    double ev[4], av[4];
-    double2 nv[4];
+    for (int r = 0; r < 4; ++r) e0[r] = (Eb + (size_t)top * K)[L.oE[r]];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ea[r] = (Eb + (size_t)i1 * K)[L.oE[r]];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) eb[r] = (Eb + (size_t)i2 * K)[L.oE[r]];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      ev[r] = en1[r]; en1[r] = en2[r]; en2[r] = Eh[base[r] + (size_t)t2 * K];
-      av[r] = an1[r]; an1[r] = an2[r]; an2[r] = ah[base[r] + (size_t)t2 * K];
-      nv[r] = nn1[r]; nn1[r] = nn2[r]; nn2[r] = nak[rowb[r] + t2];
+      g[r] = 0.0;
+      if (NW != 4) (gb + top)[L.oR[r]] = 0.0;
+      if (FULL || vj) (bb + (size_t)top * K)[L.oE[r]] = 1.0;
+      sh.P[0][lg + 4 * r][j] = vj ? e0[r] : 0.0;
     }
+    if (NW == 4) (gb + top)[L.oRw] = 0.0;
+  }
+  __syncthreads();
+  // one step: bh of row t from P[CUR] = Eh_{t+1} * bh_{t+1}; er holds Eh_t
+  auto step = [&](const int t, auto curc, double (&er)[4]) {
+    constexpr int CUR = decltype(curc)::value, NXT = 1 - CUR;
+    const int t2 = t >= 2 ? t - 2 : 0;
     double4_t acc, tot;
-    lin_matmul<NW>(sh, cur, li, lg, Bv, acc, tot);
+    lin_matmul<NW>(sh, CUR, li, lg, Bv, acc, tot);
+    double* __restrict__ bt = bb + (size_t)t * K;
+    double* __restrict__ gt = gb + t;
+    const double* __restrict__ E2 = Eb + (size_t)t2 * K;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int e2 = __builtin_amdgcn_frexp_exp(tot[r]);
-      const double bh = ldexp(acc[r], -e2);
-      sh.P[nxt][lg + 4 * r][j] = ev[r] * bh;
-      nb[r] += kprev[r] + (double)e2;
-      kprev[r] = nv[r].y;
-      const double f = ldexp(zinv[r], (int)(nv[r].x + nb[r] - ze[r]));
-      const double qv = (av[r] * bh) * f;
-      if (FULL || vj) q_out[base[r] + (size_t)t * K] = qv;
+      const double bv = ldexp(acc[r], -e2);
+      sh.P[NXT][lg + 4 * r][j] = er[r] * bv;
+      if (FULL || vj) bt[L.oE[r]] = bv;
+      g[r] += (double)e2;
+      if (NW != 4) gt[L.oR[r]] = g[r];
     }
+    if (NW == 4) gt[L.oRw] = sel4(g, wave);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) er[r] = E2[L.oE[r]];
     __syncthreads();
+  };
+  {
+    int t = Lm - 2;
+    for (; t >= 1; t -= 2) {
+      step(t, std::integral_constant<int, 0>{}, ea);
+      step(t - 1, std::integral_constant<int, 1>{}, eb);
+    }
+    if (t == 0) step(0, std::integral_constant<int, 0>{}, ea);
+  }
+}
+
+// grid (ceil(B/16), 2): blockIdx.y = 0 forward, 1 backward
+template <int NW, bool FULL>
+__global__ __launch_bounds__(64 * NW) void k_sweeps_lin(
+    const double* __restrict__ Eh, const double* __restrict__ kexp,
+    const double* __restrict__ Aexp, const double* __restrict__ AexpT,
+    const double* __restrict__ mod_init, int B, int Lm, int K, double* __restrict__ ah,
+    double* __restrict__ bh, double* __restrict__ hx, double* __restrict__ gx,
+    double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac) {
+  __shared__ LinShared<NW> sh;
+  if (blockIdx.y == 0)
+    fwd_lin_body<NW, FULL>(sh, Eh, kexp, Aexp, mod_init, B, Lm, K, ah, hx, local_lb, logz, zfac);
+  else
+    bwd_lin_body<NW, FULL>(sh, Eh, AexpT, B, Lm, K, bh, gx);
+}
+
+// posterior marginals from the scaled messages (API reads of var_x; the statistics GEMM
+// forms the same product in its staging threads and never needs this array).
+// One 16-lane row per (window, t) row.
+template <int KT>
+__global__ __launch_bounds__(256) void k_lin_posterior(
+    const double* __restrict__ ah, const double* __restrict__ bh, const double* __restrict__ hx,
+    const double* __restrict__ gx, const double2* __restrict__ zfac, int64_t nrows, int Lm,
+    int K, double* __restrict__ q) {
+  const int li = threadIdx.x & 15;
+  const int64_t g = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (g >= nrows) return;
+  const double2 zf = zfac[g / Lm];
+  const double s = ldexp(zf.x, (int)(hx[g] + gx[g] - zf.y));
+#pragma unroll
+  for (int c = 0; c < KT; ++c) {
+    const int k = li + 16 * c;
+    if (k < K) q[g * K + k] = (ah[g * K + k] * bh[g * K + k]) * s;
   }
 }
 

@@ -217,14 +217,19 @@ struct StRow {
   long long orow;   // obs row, -1: out of range or masked (x~ = 0)
   long long qrow;   // q row, -1: out of range
   long long prow;   // predecessor q row, -1: none
+  double sq, sp;    // LIN: posterior scale 2^(h+g-zexp)/zm of rows qrow / prow
 };
 
-template <int MT, int NTW, int NSPLIT, int XK>
+// LIN: the posteriors are not read but formed by the staging threads from the scaled
+// messages of K2e: q = ah * bh * 2^(hx + gx - zfac.y) * zfac.x (q points at ah).
+template <int MT, int NTW, int NSPLIT, int XK, bool LIN>
 __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma3(
     const double* __restrict__ obs, const uint8_t* __restrict__ mask,
     const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K, int Fp, int F,
     const int* __restrict__ fab, const double* __restrict__ q, int64_t rows_per_chunk,
-    uint32_t flags, int Lq, int off, double* __restrict__ part, int KpTot, int mt_limit) {
+    uint32_t flags, int Lq, int off, double* __restrict__ part, int KpTot, int mt_limit,
+    const double* __restrict__ bh, const double* __restrict__ hx, const double* __restrict__ gx,
+    const double2* __restrict__ zfac) {
   // KpTot: padded state count of the whole problem (partials stride); this workgroup covers
   // states [blockIdx.z*Kp, +Kp); only m-tiles < mt_limit are produced (K > 64: the
   // transition tiles are left to k_stats_mfma)
@@ -274,25 +279,60 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma3(
   const int64_t c1 = imin64(nrows, c0 + rows_per_chunk);
   const int nstage = (int)((c1 - c0 + ST_RB - 1) / ST_RB);
 
-  auto row_info = [&](int64_t s0, int buf) {
+  // Row bookkeeping (threads 0..31, one row each) runs three stages ahead and is split in
+  // phases so that its dependent global loads (starts -> mask, exponents) never sit in front
+  // of the stage barrier: phase 1 at the top of a stage issues the first-level loads, phase 2
+  // in the middle the mask load that needs starts[], commit writes the LDS record at the end.
+  int64_t ri_g = 0, ri_bw = 0, ri_t = 0, ri_q = -1, ri_p = -1, ri_start = 0, ri_o = -1;
+  uint8_t ri_m = 0;
+  double2 ri_zf = make_double2(0.0, 0.0);
+  double ri_hq = 0.0, ri_gq = 0.0, ri_hp = 0.0, ri_gp = 0.0;
+  bool ri_ok = false;
+  auto ri_phase1 = [&](int64_t s0) {
     if (tid < ST_RB) {
-      const int64_t g = s0 + tid;
-      StRow ri; ri.orow = -1; ri.qrow = -1; ri.prow = -1;
-      if (g < c1) {
-        const int64_t bw = g / Lm;
-        const int64_t t = g - bw * Lm;
-        ri.qrow = bw * Lq + off + t;
-        const int64_t orow = starts[bw] + off + t;
-        ri.orow = (mask && mask[orow]) ? -1 : orow;
-        if (t > 0) ri.prow = ri.qrow - 1;
-        else if (flags & SVIHMM_TRANS_WRAP) ri.prow = ri.qrow + Lm - 1;
+      ri_g = s0 + tid;
+      ri_ok = ri_g < c1;
+      ri_q = -1; ri_p = -1;
+      if (ri_ok) {
+        ri_bw = ri_g / Lm;
+        ri_t = ri_g - ri_bw * Lm;
+        ri_q = ri_bw * Lq + off + ri_t;
+        if (ri_t > 0) ri_p = ri_q - 1;
+        else if (flags & SVIHMM_TRANS_WRAP) ri_p = ri_q + Lm - 1;
+        ri_start = starts[ri_bw];
+        if (LIN) {
+          ri_zf = zfac[ri_bw];
+          ri_hq = hx[ri_q]; ri_gq = gx[ri_q];
+          if (ri_p >= 0) { ri_hp = hx[ri_p]; ri_gp = gx[ri_p]; }
+        }
+      }
+    }
+  };
+  auto ri_phase2 = [&]() {
+    if (tid < ST_RB && ri_ok) {
+      ri_o = ri_start + off + ri_t;
+      ri_m = mask ? mask[ri_o] : (uint8_t)0;
+    }
+  };
+  auto ri_commit = [&](int buf) {
+    if (tid < ST_RB) {
+      StRow ri; ri.orow = -1; ri.qrow = ri_q; ri.prow = ri_p; ri.sq = 0.0; ri.sp = 0.0;
+      if (ri_ok) {
+        ri.orow = ri_m ? -1 : ri_o;
+        if (LIN) {
+          ri.sq = ldexp(ri_zf.x, (int)(ri_hq + ri_gq - ri_zf.y));
+          if (ri_p >= 0) ri.sp = ldexp(ri_zf.x, (int)(ri_hp + ri_gp - ri_zf.y));
+        }
       }
       rinfo[buf * ST_RB + tid] = ri;
     }
   };
+  auto row_info = [&](int64_t s0, int buf) { ri_phase1(s0); ri_phase2(); ri_commit(buf); };
   double rx[XK], rq[QK], rp[QK];
+  double rq2[LIN ? QK : 1], rp2[LIN ? QK : 1], rsq = 0.0, rsp = 0.0;
   auto fetch = [&](int buf) {
     const StRow ri = rinfo[buf * ST_RB + sr];
+    if (LIN) { rsq = ri.sq; rsp = ri.sp; }
     if (need_x) {
 #pragma unroll
       for (int k = 0; k < XK; ++k) {
@@ -309,12 +349,14 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma3(
     for (int k = 0; k < QK; ++k) {
       const int c = sc + TPR * k;
       rq[k] = (ri.qrow >= 0 && kbase + c < K) ? q[ri.qrow * K + kbase + c] : 0.0;
+      if (LIN) rq2[k] = (ri.qrow >= 0 && kbase + c < K) ? bh[ri.qrow * K + kbase + c] : 0.0;
     }
     if (need_qp) {
 #pragma unroll
       for (int k = 0; k < QK; ++k) {
         const int c = sc + TPR * k;
         rp[k] = (ri.prow >= 0 && c < K) ? q[ri.prow * K + c] : 0.0;
+        if (LIN) rp2[k] = (ri.prow >= 0 && c < K) ? bh[ri.prow * K + c] : 0.0;
       }
     }
   };
@@ -331,13 +373,13 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma3(
 #pragma unroll
     for (int k = 0; k < QK; ++k) {
       const int c = sc + TPR * k;
-      if (c < Kp) qs[sr * QS + c] = rq[k];
+      if (c < Kp) qs[sr * QS + c] = LIN ? (rq[k] * rq2[k]) * rsq : rq[k];
     }
     if (need_qp) {
 #pragma unroll
       for (int k = 0; k < QK; ++k) {
         const int c = sc + TPR * k;
-        if (c < Kp) rb[sr * RS + QP0 + c] = rp[k];
+        if (c < Kp) rb[sr * RS + QP0 + c] = LIN ? (rp[k] * rp2[k]) * rsp : rp[k];
       }
     }
   };
@@ -361,6 +403,7 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma3(
   __syncthreads();
   for (int st = 0; st < nstage; ++st) {
     const int cur = st & 1;
+    ri_phase1(c0 + (int64_t)(st + 3) * ST_RB);
     if (roleB) {
       if (st + 1 < nstage) commit(cur ^ 1);
       if (st + 2 < nstage) fetch((st + 2) & 3);
@@ -403,13 +446,314 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma3(
       }
       // role A stages in the middle of its compute phase (role B did it before), so that
       // at the end of the stage both waves of a SIMD are still feeding the matrix pipe
+      if (ks == ST_RB / 8 - 1) ri_phase2();
       if (ks == ST_RB / 8 - 1 && !roleB) {
         if (st + 1 < nstage) commit(cur ^ 1);
         if (st + 2 < nstage) fetch((st + 2) & 3);
       }
     }
-    row_info(c0 + (int64_t)(st + 3) * ST_RB, (st + 3) & 3);
+    ri_commit((st + 3) & 3);
     __syncthreads();
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = (mt0 + m) * 16 + lg + 4 * r;
+      if (f < Ftot && (mt0 + m) < mt_limit) {
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+          part[((size_t)blockIdx.x * Ftot + f) * KpTot + kbase + (nt0 + n) * 16 + li] = acc[m][n][r];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+//  K4d: K4c with branch-free staging and compile-time operand offsets.
+//  On gfx950 every VALU instruction a wave issues competes with the fp64 MFMAs of the SIMD
+//  (tools/peak_probe.py: the times add), and K4c spent ~600 VALU instructions per 80-MFMA
+//  stage on address arithmetic, 64-bit divisions and predicated copies.  Here:
+//   * the A-operand tile is stored column-major, both LDS buffers interleaved, the 32 stage
+//     rows permuted:  element (buffer u, row r, column c) at  c*67 + u*33 + (r&3)*8 + (r>>2),
+//     so the operand of k-step ks for lane (li, lg) is  base(lane, m) + [u*33 + ks]  -- one
+//     VGPR per (m-tile, factor) computed once per kernel, everything else an immediate, and
+//     a wave's 64 reads spread over all banks (column stride 67 = 3 mod 32, lg stride 8);
+//   * row bookkeeping is 32-bit arithmetic relative to the chunk start (one unsigned
+//     division per row instead of a 64-bit one); q rows become 32-bit element offsets
+//     from a per-thread base pointer;
+//   * staging threads copy with unconditional loads from clamped addresses and value
+//     selects (no exec-mask branches, so waits stay counted);
+//   * the stage loop is unrolled by two so that the LDS buffer is a compile-time choice.
+//  Same pipeline as K4c: double-buffered LDS, one barrier per stage, role-split staging.
+//  Host guarantees rows_per_chunk * max(K, Lq/Lm * K) < 2^31.
+// ------------------------------------------------------------------------------------
+struct StRow4 {
+  long long ooff;   // obs element offset (row * D), -1: out of range or masked
+  int qoff;         // q element offset relative to the chunk's first q row, -1: out of range
+  int poff;         // predecessor q element offset (may be negative: see pok), validity in pok
+  int pok, pad_;
+  double sq, sp;    // LIN: posterior scale of the two rows
+};
+#define ST_CS 33            // row slots per buffer per column (32 + 1 pad)
+#define ST_CC (2 * ST_CS + 1)  // column stride (both buffers + 1 pad): 67
+
+template <int MT, int NTW, int NSPLIT, int XK, bool LIN>
+__global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
+    const double* __restrict__ obs, const uint8_t* __restrict__ mask,
+    const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K, int Fp, int F,
+    const int* __restrict__ fab, const double* __restrict__ q, int64_t rows_per_chunk,
+    uint32_t flags, int Lq, int off, double* __restrict__ part, int KpTot, int mt_limit,
+    const double* __restrict__ bh, const double* __restrict__ hx, const double* __restrict__ gx,
+    const double2* __restrict__ zfac) {
+  static_assert(ST_RB == 32, "row permutation assumes 32-row stages");
+  constexpr int NT = NTW * NSPLIT;
+  constexpr int Kp = 16 * NT;
+  constexpr int QS = Kp + 1;
+  constexpr int TPR = 8 * NSPLIT;          // staging threads per row
+  constexpr int QK = Kp / TPR;             // q columns per staging thread (exact)
+  static_assert(QK * TPR == Kp, "staging split");
+  extern __shared__ double smem[];
+  // columns of the A-operand tile: [0,D) x | D: 1 (0 on masked rows) | D+1 ZERO | D+2 ONE | QP0+i: q[prev][i]
+  const int ZERO = D + 1, ONE = D + 2, QP0 = D + 3;
+  const int C = QP0 + Kp;
+  double* rb0 = smem;                      // [C][67]
+  double* qs0 = rb0 + C * ST_CC;           // [2][32][QS]
+  StRow4* rinfo = reinterpret_cast<StRow4*>(qs0 + 2 * ST_RB * QS);  // [4][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int mg = wave & 3, ng = wave >> 2;
+  const int Ftot = Fp + KpTot;
+  const int kbase = blockIdx.z * Kp;
+  const int mt0 = (blockIdx.y * 4 + mg) * MT;
+  const int nt0 = ng * NTW;
+  const int wg_m0 = blockIdx.y * 4 * MT * 16, wg_m1 = wg_m0 + 4 * MT * 16;
+  const bool need_x = wg_m0 < Fp;
+  const bool need_qp = wg_m1 > Fp && mt_limit * 16 > Fp;
+  const int sr = tid / TPR, sc = tid % TPR;   // staging role: row sr, columns sc + TPR*k
+  const int psr = (sr & 3) * 8 + (sr >> 2);   // permuted row slot
+
+  // A-operand element index of buffer 0, k-step 0 (buffer u, k-step ks: + u*33 + ks)
+  int oa[MT], ob[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int f = (mt0 + m) * 16 + li;
+    int fa = ZERO, fb = ZERO;
+    if (f < F) { const int ab = fab[f]; fa = ab & 0xffff; fb = ab >> 16; }
+    else if (f >= Fp && f - Fp < K && mt_limit * 16 > Fp) { fa = QP0 + (f - Fp); fb = ONE; }
+    oa[m] = fa * ST_CC + lg * 8; ob[m] = fb * ST_CC + lg * 8;
+  }
+  const int obq = lg * QS + nt0 * 16 + li;   // B operand: qs[(4ks+lg)*QS + (nt0+n)*16 + li]
+  double4_t acc[MT][NTW];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  const int64_t c0 = (int64_t)blockIdx.x * rows_per_chunk;
+  const int64_t c1 = imin64(nrows, c0 + rows_per_chunk);
+  const int nrow = (int)(c1 - c0);
+  const int nstage = (nrow + ST_RB - 1) / ST_RB;
+  // chunk origin: window bw0, step t0, q row Q0 (all uniform)
+  const int64_t bw0 = c0 / Lm;
+  const unsigned t0 = (unsigned)(c0 - bw0 * Lm);
+  const int64_t Q0 = bw0 * Lq + off;
+  const double* __restrict__ qthr = q + Q0 * K + kbase + sc;   // per-thread bases
+  const double* __restrict__ bthr = LIN ? bh + Q0 * K + kbase + sc : nullptr;
+  const double* __restrict__ pthr = q + Q0 * K + sc;
+  const double* __restrict__ bpthr = LIN ? bh + Q0 * K + sc : nullptr;
+
+  // ---- row bookkeeping, three stages ahead, in phases (see K4c); threads 0..31
+  unsigned ri_bwr = 0, ri_t = 0;
+  int ri_qr = 0, ri_pr = 0, ri_pok = 0;
+  int64_t ri_start = 0, ri_o = -1;
+  uint8_t ri_m = 0;
+  double2 ri_zf = make_double2(0.0, 0.0);
+  double ri_hq = 0.0, ri_gq = 0.0, ri_hp = 0.0, ri_gp = 0.0;
+  bool ri_ok = false;
+  auto ri_phase1 = [&](int s0) {        // s0: first row of the stage relative to c0
+    if (tid < ST_RB) {
+      const int jrow = s0 + tid;
+      ri_ok = jrow < nrow;
+      const unsigned x = t0 + (unsigned)(ri_ok ? jrow : 0);
+      ri_bwr = x / (unsigned)Lm;
+      ri_t = x - ri_bwr * (unsigned)Lm;
+      ri_qr = (int)(ri_bwr * (unsigned)Lq + ri_t);          // q row relative to Q0
+      ri_pok = (ri_t > 0 || (flags & SVIHMM_TRANS_WRAP)) ? 1 : 0;
+      ri_pr = ri_t > 0 ? ri_qr - 1 : ri_qr + Lm - 1;
+      const int64_t bw = bw0 + ri_bwr;
+      ri_start = starts[bw];
+      if (LIN) {
+        ri_zf = zfac[bw];
+        ri_hq = hx[Q0 + ri_qr]; ri_gq = gx[Q0 + ri_qr];
+        const int pr = ri_pok ? ri_pr : ri_qr;
+        ri_hp = hx[Q0 + pr]; ri_gp = gx[Q0 + pr];
+      }
+    }
+  };
+  auto ri_phase2 = [&]() {
+    if (tid < ST_RB) {
+      ri_o = ri_start + off + ri_t;
+      ri_m = mask ? mask[ri_o] : (uint8_t)0;
+    }
+  };
+  auto ri_commit = [&](int buf) {
+    if (tid < ST_RB) {
+      StRow4 ri;
+      ri.ooff = (ri_ok && !ri_m) ? ri_o * D : -1;
+      ri.qoff = ri_ok ? ri_qr * K : -1;
+      ri.poff = ri_pr * K;
+      ri.pok = (ri_ok && ri_pok) ? 1 : 0;
+      ri.pad_ = 0;
+      ri.sq = 0.0; ri.sp = 0.0;
+      if (LIN) {
+        ri.sq = ldexp(ri_zf.x, (int)(ri_hq + ri_gq - ri_zf.y));
+        ri.sp = ldexp(ri_zf.x, (int)(ri_hp + ri_gp - ri_zf.y));
+      }
+      rinfo[buf * ST_RB + tid] = ri;
+    }
+  };
+  auto row_info = [&](int s0, int buf) { ri_phase1(s0); ri_phase2(); ri_commit(buf); };
+
+  // ---- staging: unconditional loads from clamped addresses, selects at commit time
+  int xcc[XK], xwi[XK];  // clamped obs column; LDS index (buffer 0) of the column this thread writes
+#pragma unroll
+  for (int k = 0; k < XK; ++k) {
+    const int c = sc + TPR * k;
+    xcc[k] = c < D ? c : D - 1;
+    xwi[k] = (c <= D ? c : ZERO) * ST_CC + psr;   // beyond the ones slot: rewrite ZERO with 0.0
+  }
+  const int qwi = sr * QS + sc;                 // q tile element of this thread (column 0)
+  const int pwi = (QP0 + sc) * ST_CC + psr;     // q[prev] column of this thread (buffer 0)
+  double rx[XK], rq[QK], rp[QK];
+  double rq2[LIN ? QK : 1], rp2[LIN ? QK : 1], rsq = 0.0, rsp = 0.0;
+  bool okx = false, okq = false, okp = false;
+  auto fetch = [&](int buf) {
+    const StRow4 ri = rinfo[buf * ST_RB + sr];
+    okx = ri.ooff >= 0; okq = ri.qoff >= 0; okp = ri.pok != 0;
+    if (LIN) { rsq = ri.sq; rsp = ri.sp; }
+    if (need_x) {
+      const double* __restrict__ xo = obs + (okx ? ri.ooff : 0);
+#pragma unroll
+      for (int k = 0; k < XK; ++k) rx[k] = xo[xcc[k]];
+    }
+    {
+      const int o = okq ? ri.qoff : 0;
+#pragma unroll
+      for (int k = 0; k < QK; ++k) rq[k] = qthr[o + TPR * k];
+      if (LIN) {
+#pragma unroll
+        for (int k = 0; k < QK; ++k) rq2[k] = bthr[o + TPR * k];
+      }
+    }
+    if (need_qp) {
+      const int o = okp ? ri.poff : 0;
+#pragma unroll
+      for (int k = 0; k < QK; ++k) rp[k] = pthr[o + TPR * k];
+      if (LIN) {
+#pragma unroll
+        for (int k = 0; k < QK; ++k) rp2[k] = bpthr[o + TPR * k];
+      }
+    }
+  };
+  auto commit = [&](auto bufc) {
+    constexpr int U = decltype(bufc)::value;
+    if (need_x) {
+#pragma unroll
+      for (int k = 0; k < XK; ++k) {
+        const int c = sc + TPR * k;
+        const double v = c < D ? rx[k] : (c == D ? 1.0 : 0.0);
+        rb0[xwi[k] + U * ST_CS] = okx ? v : 0.0;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < QK; ++k) {
+      const bool okc = okq && (kbase + sc + TPR * k < K);
+      const double v = LIN ? (rq[k] * rq2[k]) * rsq : rq[k];
+      qs0[U * ST_RB * QS + qwi + TPR * k] = okc ? v : 0.0;
+    }
+    if (need_qp) {
+#pragma unroll
+      for (int k = 0; k < QK; ++k) {
+        const bool okc = okp && (sc + TPR * k < K);
+        const double v = LIN ? (rp[k] * rp2[k]) * rsp : rp[k];
+        rb0[pwi + U * ST_CS + TPR * k * ST_CC] = okc ? v : 0.0;
+      }
+    }
+  };
+  // constant columns of both buffers
+  if (sc == 0) {
+    rb0[ZERO * ST_CC + psr] = 0.0; rb0[ONE * ST_CC + psr] = 1.0;
+    rb0[ZERO * ST_CC + ST_CS + psr] = 0.0; rb0[ONE * ST_CC + ST_CS + psr] = 1.0;
+  }
+  const bool roleB = (NSPLIT == 2) && (ng == 1);
+  row_info(0, 0);
+  row_info(ST_RB, 1);
+  row_info(2 * ST_RB, 2);
+  __syncthreads();
+  fetch(0);
+  commit(std::integral_constant<int, 0>{});
+  if (nstage > 1) fetch(1);
+  __syncthreads();
+  // one 32-row stage on LDS buffer CUR: 8 k-steps, software pipelined by hand (the LDS
+  // reads of k-step ks+1 are issued before the MFMAs of k-step ks)
+  auto stage = [&](const int st, auto curc) {
+    constexpr int CUR = decltype(curc)::value;
+    constexpr int UO = CUR * ST_CS;
+    ri_phase1((st + 3) * ST_RB);
+    if (roleB) {
+      if (st + 1 < nstage) commit(std::integral_constant<int, 1 - CUR>{});
+      if (st + 2 < nstage) fetch((st + 2) & 3);
+    }
+    const double* qs = qs0 + CUR * ST_RB * QS + obq;
+    double Bv[NTW], Ax[MT], Ay[MT];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) Bv[n] = qs[n * 16];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { Ax[m] = rb0[oa[m] + UO]; Ay[m] = rb0[ob[m] + UO]; }
+#pragma unroll
+    for (int ks = 0; ks < ST_RB / 4; ++ks) {
+      double Bn[NTW], Axn[MT], Ayn[MT];
+      if (ks + 1 < ST_RB / 4) {
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) Bn[n] = qs[(ks + 1) * 4 * QS + n * 16];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { Axn[m] = rb0[oa[m] + UO + ks + 1]; Ayn[m] = rb0[ob[m] + UO + ks + 1]; }
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const double A = Ax[m] * Ay[m];
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(A, Bv[n], acc[m][n], 0, 0, 0);
+      }
+      if (ks + 1 < ST_RB / 4) {
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) Bv[n] = Bn[n];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { Ax[m] = Axn[m]; Ay[m] = Ayn[m]; }
+      }
+      // the operand addresses are immediates: without a fence the scheduler hoists the
+      // LDS reads of all eight k-steps to the top of the stage and spills
+      __builtin_amdgcn_sched_barrier(0);
+      // role A stages in the middle of its compute phase (role B did it before), so that
+      // at the end of the stage both waves of a SIMD are still feeding the matrix pipe
+      if (ks == ST_RB / 8 - 1) ri_phase2();
+      if (ks == ST_RB / 8 - 1 && !roleB) {
+        if (st + 1 < nstage) commit(std::integral_constant<int, 1 - CUR>{});
+        if (st + 2 < nstage) fetch((st + 2) & 3);
+      }
+    }
+    ri_commit((st + 3) & 3);
+    __syncthreads();
+  };
+  {
+    int st = 0;
+    for (; st + 1 < nstage; st += 2) {
+      stage(st, std::integral_constant<int, 0>{});
+      stage(st + 1, std::integral_constant<int, 1>{});
+    }
+    if (st < nstage) stage(st, std::integral_constant<int, 0>{});
   }
 #pragma unroll
   for (int m = 0; m < MT; ++m) {

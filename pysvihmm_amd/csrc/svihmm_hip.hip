@@ -28,6 +28,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/svihmm.h"
@@ -113,19 +114,26 @@ struct svihmm_ctx {
   Buf starts, ll, la, lb, q, lse_part, local_lb, logz, part, packed, scratch;
   // scaled linear-domain sweeps: per-row binary exponents, (na, k) records, 1/Z factors,
   // Eh of host-supplied lliks; log-domain intermediates materialised on demand (m_*)
-  Buf kexp, nak, zfac, llE, m_ll, m_la, m_lb;
-  bool lin_mode = false;           // ll/la hold Eh / ah of the last sweep (not logs)
+  Buf kexp, hx, gx, zfac, llE, m_ll, m_la, m_lb;
+  bool lin_mode = false;           // ll/la/lb hold Eh / ah / bh of the last sweep (not logs)
+  bool q_valid = false;            // lin_mode: var_x has been formed from ah, bh (k_lin_posterior)
   bool lin_stale = false;          // parameters changed since: logs can no longer be rebuilt
   bool last_host_ll = false;       // the last sweep ran on host-supplied lliks
   uint32_t last_flags = 0;
   int m_b0 = 0, m_nb = 0;          // window range currently materialised in m_*
   int lastB = 0, lastLm = 0;       // shape of the intermediates currently held
+  int curB = 0;                    // windows of the batch being processed
   int hostB = 0, hostLm = 0;       // shape of host-uploaded lliks
   bool have_host_ll = false;
   bool have_packed = false;
   bool have_lb = false;           // lbeta materialised by the last call
-  // variants: [0] emission (0 auto,1 outer,2 mfma) [1] stats (0 auto,1 outer,2 mfma)
-  int variant[4] = {0, 0, 0, 0};
+  // variants: [0] emission (0 auto,1 outer,2 mfma) [1] stats (0 auto,1 outer,2 mfma,3 pipelined)
+  // [2] sweeps (0 auto,1 wave,2 log-MFMA,3 scaled) [3] emission row tiles
+  // [4] two-stream E-step pipeline (0 auto,1 off,2 on)
+  int variant[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // second stream + events of the pipelined E-step (created on first use)
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_em[2] = {nullptr, nullptr}, ev_sw[2] = {nullptr, nullptr};
   // profiling
   bool prof = false;
   std::vector<Pending> pending;
@@ -138,8 +146,9 @@ struct svihmm_ctx {
 };
 
 struct ProfScope {
-  svihmm_ctx* h; int slot; hipEvent_t e0 = nullptr, e1 = nullptr; bool on;
-  ProfScope(svihmm_ctx* h_, int slot_) : h(h_), slot(slot_), on(h_->prof) {
+  svihmm_ctx* h; int slot; hipEvent_t e0 = nullptr, e1 = nullptr; bool on; hipStream_t st;
+  ProfScope(svihmm_ctx* h_, int slot_, hipStream_t st_ = nullptr)
+      : h(h_), slot(slot_), on(h_->prof), st(st_ ? st_ : h_->stream) {
     if (!on) return;
     auto get = [&]() {
       hipEvent_t e;
@@ -148,11 +157,11 @@ struct ProfScope {
       return e;
     };
     e0 = get(); e1 = get();
-    hipEventRecord(e0, h->stream);
+    hipEventRecord(e0, st);
   }
   ~ProfScope() {
     if (!on) return;
-    hipEventRecord(e1, h->stream);
+    hipEventRecord(e1, st);
     h->pending.push_back({slot, e0, e1});
   }
 };
@@ -201,9 +210,14 @@ int svihmm_destroy(svihmm_ctx* h) {
   for (auto e : h->pool) hipEventDestroy(e);
   Buf* bufs[] = {&h->obs, &h->mask, &h->mod_init, &h->ltran, &h->Aexp, &h->AexpT, &h->theta, &h->niw,
                  &h->fab, &h->starts, &h->ll, &h->la, &h->lb, &h->q, &h->lse_part,
-                 &h->local_lb, &h->logz, &h->part, &h->packed, &h->scratch, &h->kexp, &h->nak,
+                 &h->local_lb, &h->logz, &h->part, &h->packed, &h->scratch, &h->kexp, &h->hx, &h->gx,
                  &h->zfac, &h->llE, &h->m_ll, &h->m_la, &h->m_lb};
   for (Buf* b : bufs) release(*b);
+  for (int i = 0; i < 2; ++i) {
+    if (h->ev_em[i]) hipEventDestroy(h->ev_em[i]);
+    if (h->ev_sw[i]) hipEventDestroy(h->ev_sw[i]);
+  }
+  if (h->stream2) hipStreamDestroy(h->stream2);
   if (h->pin) hipHostFree(h->pin);
   if (h->pin_status) hipHostFree(h->pin_status);
   hipStreamDestroy(h->stream);
@@ -399,7 +413,9 @@ static int upload_starts(svihmm_ctx* h, const int64_t* starts, int B) {
 // scaled: write (Eh, kexp) for the linear-domain sweeps instead of ll (K <= 64 only).
 // starts_dev / out: window starts and destination (default: the handle's buffers).
 static int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled = false,
-                           const int64_t* starts_dev = nullptr, double* out = nullptr) {
+                           const int64_t* starts_dev = nullptr, double* out = nullptr,
+                           double* kexp_out = nullptr, hipStream_t stream = nullptr,
+                           size_t min_lds = 0) {
   if (!h->have_emission) return fail("no emission parameters: call svihmm_set_emission_niw");
   if (h->eD != h->D) return fail("emission D does not match obs D");
   if (!h->have_globals || h->eK != h->K) return fail("emission K does not match globals K");
@@ -410,9 +426,13 @@ static int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool sc
     out = (double*)h->ll.p;
   }
   if (!starts_dev) starts_dev = (const int64_t*)h->starts.p;
-  if (scaled) CK(ensure(h->kexp, (size_t)n * sizeof(double)));
+  if (scaled && !kexp_out) {
+    CK(ensure(h->kexp, (size_t)n * sizeof(double)));
+    kexp_out = (double*)h->kexp.p;
+  }
+  if (!stream) stream = h->stream;
   const uint8_t* mk = h->have_mask ? (const uint8_t*)h->mask.p : nullptr;
-  ProfScope ps(h, KS_EMISSION);
+  ProfScope ps(h, KS_EMISSION, stream);
   int var = h->variant[0];
   if (var == 0 || scaled) var = 2;
   if (var == 2) {
@@ -421,6 +441,7 @@ static int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool sc
     if (MT != 2 && MT != 4) MT = 2;
     size_t lds = (size_t)(64 * MT) * DS * 8 + (size_t)h->Fp * 4 + 64 * MT;
     if (lds > 150 * 1024 && MT == 4) { MT = 2; lds = (size_t)128 * DS * 8 + (size_t)h->Fp * 4 + 128; }
+    if (lds < min_lds) lds = min_lds;   // occupancy cap: leave LDS for co-resident sweep workgroups
     if (lds > 150 * 1024 && scaled) return fail("emission: D too large for the scaled sweeps");
     if (lds > 150 * 1024) var = 1;
     else {
@@ -434,10 +455,10 @@ static int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool sc
     if (lds > 64 * 1024)                                                                      \
       hipFuncSetAttribute((const void*)k_emission_mfma<NTV, MTV, SC>,                         \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
-    hipLaunchKernelGGL((k_emission_mfma<NTV, MTV, SC>), grid, dim3(256), lds, h->stream,      \
+    hipLaunchKernelGGL((k_emission_mfma<NTV, MTV, SC>), grid, dim3(256), lds, stream,         \
                        (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K,                  \
                        Kp, h->Fp, (const double*)h->theta.p, (const int*)h->fab.p, flags,     \
-                       out, (double*)h->kexp.p);                                              \
+                       out, kexp_out);                                                        \
   } while (0)
       if (scaled) {
         if (NT == 4) EMM_LAUNCH(4, 2, true); else if (NT == 3) EMM_LAUNCH(3, 2, true);
@@ -456,7 +477,7 @@ static int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool sc
     if (lds > 64 * 1024)
       hipFuncSetAttribute((const void*)k_emission_outer, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid((unsigned)((n + EM_R - 1) / EM_R), Kp / 16);
-    hipLaunchKernelGGL(k_emission_outer, grid, dim3(EM_R), lds, h->stream,
+    hipLaunchKernelGGL(k_emission_outer, grid, dim3(EM_R), lds, stream,
                        (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K,
                        Kp, (const double*)h->theta.p, flags, out);
   }
@@ -575,64 +596,88 @@ static int launch_fb_fused(svihmm_ctx* h, int B, int Lm, bool want_lb, bool tota
 }
 
 // scaled linear-domain sweeps (K <= 64): Eh / kexp -> ah, (na, k), Z -> var_x
-static int launch_fb_lin(svihmm_ctx* h, int B, int Lm, bool total) {
-  if (!h->have_globals) return fail("no globals: call svihmm_set_globals");
+static int ensure_fb_lin(svihmm_ctx* h, int B, int Lm) {
   const int K = h->K;
   const size_t n = (size_t)B * Lm * K * sizeof(double);
   CK(ensure(h->la, n));
-  CK(ensure(h->q, n));
-  CK(ensure(h->nak, (size_t)B * Lm * sizeof(double2)));
+  CK(ensure(h->lb, n));
+  CK(ensure(h->hx, (size_t)B * Lm * sizeof(double)));
+  CK(ensure(h->gx, (size_t)B * Lm * sizeof(double)));
   CK(ensure(h->zfac, (size_t)B * sizeof(double2)));
   CK(ensure(h->local_lb, (size_t)B * sizeof(double)));
   CK(ensure(h->logz, (size_t)B * sizeof(double)));
   CK(ensure(h->packed, (size_t)svihmm_packed_size(K, h->D > 0 ? h->D : 1) * sizeof(double)));
+  return 0;
+}
+// both sweeps over windows [b0, b0+nb) of the current batch on `stream` (buffers ensured):
+// one launch, blockIdx.y = direction
+static int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_t stream) {
+  const int K = h->K;
   const int NW = (K + 15) / 16;
   const bool full = (K == 16 * NW);
-  dim3 grid((B + 15) / 16);
-  const double* Eh = (const double*)(h->last_host_ll ? h->llE.p : h->ll.p);
-  const double* kx = (const double*)h->kexp.p;
-  double* ah = (double*)h->la.p;
-  double2* nak = (double2*)h->nak.p;
-  double2* zf = (double2*)h->zfac.p;
-  double* llb = (double*)h->local_lb.p;
-  {
-    ProfScope ps(h, KS_FB);
-#define FWD(NWV, F) hipLaunchKernelGGL((k_fwd_lin<NWV, F>), grid, dim3(64 * NWV), 0, h->stream, Eh, kx, \
-                                       (const double*)h->Aexp.p, (const double*)h->mod_init.p, B, Lm, K, \
-                                       ah, nak, llb, (double*)h->logz.p, zf)
-    if (NW == 1) { if (full) FWD(1, true); else FWD(1, false); }
-    else if (NW == 2) { if (full) FWD(2, true); else FWD(2, false); }
-    else if (NW == 3) { if (full) FWD(3, true); else FWD(3, false); }
-    else { if (full) FWD(4, true); else FWD(4, false); }
-#undef FWD
-    HIPCK(hipGetLastError());
-  }
-  {
-    ProfScope ps(h, KS_POSTERIOR);
-#define BWD(NWV, F) hipLaunchKernelGGL((k_bwd_lin<NWV, F>), grid, dim3(64 * NWV), 0, h->stream, Eh, \
-                                       (const double2*)nak, (const double*)h->AexpT.p, (const double*)ah, \
-                                       (const double2*)zf, B, Lm, K, (double*)h->q.p)
-    if (NW == 1) { if (full) BWD(1, true); else BWD(1, false); }
-    else if (NW == 2) { if (full) BWD(2, true); else BWD(2, false); }
-    else if (NW == 3) { if (full) BWD(3, true); else BWD(3, false); }
-    else { if (full) BWD(4, true); else BWD(4, false); }
-#undef BWD
-    if (total) {
-      double* lbtot = (double*)h->packed.p + (svihmm_packed_size(K, h->D) - 1);
-      hipLaunchKernelGGL(k_sum_lb, dim3(1), dim3(256), 0, h->stream, (const double*)llb, B, lbtot);
-    }
-    HIPCK(hipGetLastError());
-  }
+  dim3 grid((nb + 15) / 16, 2);
+  const size_t ro = (size_t)b0 * Lm;
+  const double* Eh = (const double*)(h->last_host_ll ? h->llE.p : h->ll.p) + ro * K;
+  const double* kx = (const double*)h->kexp.p + ro;
+  double* ah = (double*)h->la.p + ro * K;
+  double* bh = (double*)h->lb.p + ro * K;
+  double* hx = (double*)h->hx.p + ro;
+  double* gx = (double*)h->gx.p + ro;
+  double2* zf = (double2*)h->zfac.p + b0;
+  double* llb = (double*)h->local_lb.p + b0;
+  double* lz = (double*)h->logz.p + b0;
+  ProfScope ps(h, KS_FB, stream);
+#define SWP(NWV, F) hipLaunchKernelGGL((k_sweeps_lin<NWV, F>), grid, dim3(64 * NWV), 0, stream, Eh, kx, \
+                                       (const double*)h->Aexp.p, (const double*)h->AexpT.p,             \
+                                       (const double*)h->mod_init.p, nb, Lm, K, ah, bh, hx, gx, llb, lz, zf)
+  if (NW == 1) { if (full) SWP(1, true); else SWP(1, false); }
+  else if (NW == 2) { if (full) SWP(2, true); else SWP(2, false); }
+  else if (NW == 3) { if (full) SWP(3, true); else SWP(3, false); }
+  else { if (full) SWP(4, true); else SWP(4, false); }
+#undef SWP
+  HIPCK(hipGetLastError());
+  return 0;
+}
+// var_x of the last scaled sweep (B windows of length Lm), formed on first use
+static int ensure_q(svihmm_ctx* h, int B, int Lm, hipStream_t stream) {
+  if (!h->lin_mode || h->q_valid) return 0;
+  const int K = h->K;
+  const int64_t n = (int64_t)B * Lm;
+  CK(ensure(h->q, (size_t)n * K * sizeof(double)));
+  ProfScope ps(h, KS_POSTERIOR, stream);
+  dim3 grid((unsigned)((n + 15) / 16));
+#define PQ(KT) hipLaunchKernelGGL(k_lin_posterior<KT>, grid, dim3(256), 0, stream, (const double*)h->la.p, \
+                                  (const double*)h->lb.p, (const double*)h->hx.p, (const double*)h->gx.p,   \
+                                  (const double2*)h->zfac.p, n, Lm, K, (double*)h->q.p)
+  if (K <= 16) PQ(1); else if (K <= 32) PQ(2); else if (K <= 48) PQ(3); else PQ(4);
+#undef PQ
+  HIPCK(hipGetLastError());
+  h->q_valid = true;
+  return 0;
+}
+static int launch_sum_lb(svihmm_ctx* h, int B, hipStream_t stream) {
+  double* lbtot = (double*)h->packed.p + (svihmm_packed_size(h->K, h->D) - 1);
+  hipLaunchKernelGGL(k_sum_lb, dim3(1), dim3(256), 0, stream, (const double*)h->local_lb.p, B, lbtot);
+  HIPCK(hipGetLastError());
+  return 0;
+}
+static int launch_fb_lin(svihmm_ctx* h, int B, int Lm, bool total) {
+  if (!h->have_globals) return fail("no globals: call svihmm_set_globals");
+  CK(ensure_fb_lin(h, B, Lm));
+  CK(launch_fb_lin_range(h, 0, B, Lm, h->stream));
+  if (total) CK(launch_sum_lb(h, B, h->stream));
   return 0;
 }
 
 // Which sweep implementation a batch uses: 1 wave-per-window (log domain; small batches,
 // K > 64), 2 log-domain MFMA (callers that want lalpha / lbeta back), 3 scaled
 // linear-domain MFMA (the E-step fast path; logs are materialised on demand).
-static int pick_fb(const svihmm_ctx* h, int B, bool want_logs) {
+static int pick_fb(const svihmm_ctx* h, int B, int Lm, bool want_logs) {
   int var = h->variant[2];
   if (h->K > 64) return 1;
   if (var == 0) var = (B >= 192) ? (want_logs ? 2 : 3) : 1;
+  // the scaled sweeps address a workgroup's 16 windows with 32-bit byte offsets
+  if (var == 3 && (size_t)16 * Lm * h->K * sizeof(double) >= ((size_t)1 << 32)) var = 2;
   return var;
 }
 
@@ -649,26 +694,47 @@ static int run_fb(svihmm_ctx* h, int B, int Lm, int var, bool want_lb, bool tota
   return launch_posterior(h, B, Lm, total);
 }
 
-static int launch_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags) {
-  // statistics over the inner segment [off, off+Lm) of each window of length Lq
-  CK(ensure_feature_table(h));
-  const int D = h->D, K = h->K, Kp = h->Kp, Fp = h->Fp, F = h->F;
-  const int Ftot = Fp + Kp;
-  const int64_t n = (int64_t)B * Lm;
-  // row chunking: ~256 row chunks (x feature/state tiles => >= 1024 workgroups at D=32)
-  // so that small minibatches still spread over the 256 CUs; chunk = multiple of ST_RB
-  // (one resident workgroup per CU for the pipelined kernel: 128 chunks x 2 passes = 256)
+// row chunking of the statistics GEMM: ~256 row chunks (x feature/state tiles => >= 1024
+// workgroups at D=32) so that small minibatches still spread over the 256 CUs; chunk =
+// multiple of ST_RB (one resident workgroup per CU for the pipelined kernel: 128 chunks x 2
+// passes = 256)
+struct StatsPlan { int64_t rpc, nchunk; };
+static StatsPlan stats_plan(int64_t n) {
   const int target_chunks = (n >= 128 * 1024) ? 128 : 256;
   int64_t rpc = (n + target_chunks - 1) / target_chunks;
   rpc = (rpc + ST_RB - 1) / ST_RB * ST_RB;
-  int64_t nchunk = (n + rpc - 1) / rpc;
-  CK(ensure(h->part, (size_t)nchunk * Ftot * Kp * sizeof(double)));
-  CK(ensure(h->packed, (size_t)svihmm_packed_size(K, D) * sizeof(double)));
+  return {rpc, (n + rpc - 1) / rpc};
+}
+// partial statistics of windows [b0, b0+nb) (inner segment [off, off+Lm) of each window of
+// length Lq) into partial slots [chunk_base, chunk_base + plan.nchunk) on `stream`
+static int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, int Lm, uint32_t flags,
+                              StatsPlan plan, int64_t chunk_base, hipStream_t stream) {
+  const int D = h->D, K = h->K, Kp = h->Kp, Fp = h->Fp, F = h->F;
+  const int Ftot = Fp + Kp;
+  const int64_t n = (int64_t)nb * Lm;
+  const int64_t rpc = plan.rpc, nchunk = plan.nchunk;
   const uint8_t* mk = h->have_mask ? (const uint8_t*)h->mask.p : nullptr;
+  const int64_t* starts_dev = (const int64_t*)h->starts.p + b0;
   int var = h->variant[1];
   if (var == 0) var = 3;
+  if (var == 3) {   // feasibility of the pipelined kernel (same test as below)
+    const int KpW = Kp > 64 ? 64 : Kp;
+    const int TPR = 8 * ((KpW / 16 == 4) ? 2 : 1);
+    const size_t lds = ((size_t)(D + 3 + KpW) * ST_CC + 2 * (size_t)ST_RB * (KpW + 1)) * 8 + 4 * ST_RB * sizeof(StRow4);
+    if (lds > 150 * 1024 || (D + 1 + TPR - 1) / TPR > 9 || (Kp > 64 && Kp % 64 != 0)) var = 2;
+  }
+  // scaled sweeps: the pipelined kernel forms q = ah * bh * scale itself; the others read var_x
+  const bool lin = h->lin_mode && !h->q_valid && var == 3 && Kp <= 64;
+  if (h->lin_mode && !lin) CK(ensure_q(h, h->curB, Lq, stream));
+  const size_t qo = (size_t)b0 * Lq * K;
+  const double* qv = (const double*)(lin ? h->la.p : h->q.p) + qo;
+  const double* bhv = lin ? (const double*)h->lb.p + qo : nullptr;
+  const double* hxv = lin ? (const double*)h->hx.p + (size_t)b0 * Lq : nullptr;
+  const double* gxv = lin ? (const double*)h->gx.p + (size_t)b0 * Lq : nullptr;
+  const double2* zfv = lin ? (const double2*)h->zfac.p + b0 : nullptr;
+  double* partv = (double*)h->part.p + (size_t)chunk_base * Ftot * Kp;
   {
-    ProfScope ps(h, KS_STATS);
+    ProfScope ps(h, KS_STATS, stream);
     if (var == 3) {
       // pipelined VGPR-form GEMM.  K <= 64: all tiles (statistics + transition) in one launch.
       // K > 64: state groups of 64 in grid.z for the emission-statistics tiles; the K x K
@@ -678,28 +744,29 @@ static int launch_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t 
       const int KpW = 16 * NTt;
       const int NSPLIT = (NTt == 4) ? 2 : 1;
       const int TPR = 8 * NSPLIT;
-      const int RS = (D + 3 + KpW) | 1;
-      const size_t lds = 2 * ((size_t)ST_RB * RS + (size_t)ST_RB * (KpW + 1)) * 8 + 4 * ST_RB * sizeof(StRow);
+      const size_t lds = ((size_t)(D + 3 + KpW) * ST_CC + 2 * (size_t)ST_RB * (KpW + 1)) * 8 + 4 * ST_RB * sizeof(StRow4);
       const int mtiles = Ftot / 16;
       const int mt_limit = big ? Fp / 16 : mtiles;
       const int xk = (D + 1 + TPR - 1) / TPR;
       if (lds > 150 * 1024 || xk > 9 || (big && Kp % 64 != 0)) var = 2;
       else {
         dim3 grid((unsigned)nchunk, (mt_limit + 4 * 5 - 1) / (4 * 5), big ? Kp / 64 : 1);
-#define ST3(NTW, NS, XKV)                                                                        \
+#define ST3L(NTW, NS, XKV, LN)                                                                    \
   do {                                                                                           \
     if (lds > 64 * 1024)                                                                         \
-      hipFuncSetAttribute((const void*)k_stats_mfma3<5, NTW, NS, XKV>,                           \
+      hipFuncSetAttribute((const void*)k_stats_mfma4<5, NTW, NS, XKV, LN>,                       \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
-    hipLaunchKernelGGL((k_stats_mfma3<5, NTW, NS, XKV>), grid, dim3(256 * NS), lds, h->stream,   \
-                       (const double*)h->obs.p, mk, (const int64_t*)h->starts.p, n, Lm, D, K, Fp, \
-                       F, (const int*)h->fab.p, (const double*)h->q.p, rpc, flags, Lq, off,       \
-                       (double*)h->part.p, Kp, mt_limit);                                         \
+    hipLaunchKernelGGL((k_stats_mfma4<5, NTW, NS, XKV, LN>), grid, dim3(256 * NS), lds, stream,  \
+                       (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, Fp,                  \
+                       F, (const int*)h->fab.p, qv, rpc, flags, Lq, off,                          \
+                       partv, Kp, mt_limit, bhv, hxv, gxv, zfv);                                  \
   } while (0)
+#define ST3(NTW, NS, XKV) do { if (lin) ST3L(NTW, NS, XKV, true); else ST3L(NTW, NS, XKV, false); } while (0)
 #define ST3X(NTW, NS) do { if (xk <= 1) ST3(NTW, NS, 1); else if (xk <= 3) ST3(NTW, NS, 3); else if (xk <= 5) ST3(NTW, NS, 5); else ST3(NTW, NS, 9); } while (0)
         if (NTt == 4) ST3X(2, 2); else if (NTt == 3) ST3X(3, 1); else if (NTt == 2) ST3X(2, 1); else ST3X(1, 1);
 #undef ST3X
 #undef ST3
+#undef ST3L
         if (big) {   // transition tiles [Fp/16, Ftot/16)
           const int NT = 4, MT = 3;
           const int DS = (D + 2) | 1;
@@ -709,10 +776,10 @@ static int launch_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t 
             hipFuncSetAttribute((const void*)k_stats_mfma<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
           const int ttiles = Kp / 16;
           dim3 g2((unsigned)nchunk, (ttiles + 4 * MT - 1) / (4 * MT), Kp / 64);
-          hipLaunchKernelGGL((k_stats_mfma<3, 4>), g2, dim3(256), lds2, h->stream,
-                             (const double*)h->obs.p, mk, (const int64_t*)h->starts.p, n, Lm, D, K,
-                             Kp, Fp, F, (const int*)h->fab.p, (const double*)h->q.p, rpc, flags,
-                             Lq, off, (double*)h->part.p, Fp / 16);
+          hipLaunchKernelGGL((k_stats_mfma<3, 4>), g2, dim3(256), lds2, stream,
+                             (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K,
+                             Kp, Fp, F, (const int*)h->fab.p, qv, rpc, flags,
+                             Lq, off, partv, Fp / 16);
         }
       }
     }
@@ -731,10 +798,10 @@ static int launch_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t 
     if (lds > 64 * 1024)                                                                      \
       hipFuncSetAttribute((const void*)k_stats_mfma<3, NTV>,                                  \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
-    hipLaunchKernelGGL((k_stats_mfma<3, NTV>), grid, dim3(256), lds, h->stream,               \
-                       (const double*)h->obs.p, mk, (const int64_t*)h->starts.p, n, Lm, D, K, \
-                       Kp, Fp, F, (const int*)h->fab.p, (const double*)h->q.p, rpc, flags,    \
-                       Lq, off, (double*)h->part.p, 0);                                       \
+    hipLaunchKernelGGL((k_stats_mfma<3, NTV>), grid, dim3(256), lds, stream,                  \
+                       (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K,                  \
+                       Kp, Fp, F, (const int*)h->fab.p, qv, rpc, flags,                       \
+                       Lq, off, partv, 0);                                                    \
   } while (0)
         if (NT == 4) ST_LAUNCH(4); else if (NT == 2) ST_LAUNCH(2); else ST_LAUNCH(1);
 #undef ST_LAUNCH
@@ -742,22 +809,35 @@ static int launch_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t 
     }
     if (var == 1) {
       dim3 grid((unsigned)nchunk, Ftot / 16, (Kp + 63) / 64);
-      hipLaunchKernelGGL(k_stats_outer, grid, dim3(64), 0, h->stream, (const double*)h->obs.p, mk,
-                         (const int64_t*)h->starts.p, n, Lm, D, K, Kp, Fp, F,
-                         (const int*)h->fab.p, (const double*)h->q.p, rpc, flags, Lq, off,
-                         (double*)h->part.p);
+      hipLaunchKernelGGL(k_stats_outer, grid, dim3(64), 0, stream, (const double*)h->obs.p, mk,
+                         starts_dev, n, Lm, D, K, Kp, Fp, F,
+                         (const int*)h->fab.p, qv, rpc, flags, Lq, off, partv);
     }
     HIPCK(hipGetLastError());
   }
-  {
-    ProfScope ps(h, KS_FINALIZE);
-    const int64_t tot = (int64_t)Ftot * Kp;
-    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream,
-                       (const double*)h->part.p, (int)nchunk, D, K, Kp, Fp, F,
-                       (const int*)h->fab.p, (double*)h->packed.p);
-    HIPCK(hipGetLastError());
-  }
   return 0;
+}
+static int launch_stats_finalize(svihmm_ctx* h, int64_t nchunk, hipStream_t stream) {
+  const int D = h->D, K = h->K, Kp = h->Kp, Fp = h->Fp, F = h->F;
+  ProfScope ps(h, KS_FINALIZE, stream);
+  const int64_t tot = (int64_t)(Fp + Kp) * Kp;
+  hipLaunchKernelGGL(k_finalize, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream,
+                     (const double*)h->part.p, (int)nchunk, D, K, Kp, Fp, F,
+                     (const int*)h->fab.p, (double*)h->packed.p);
+  HIPCK(hipGetLastError());
+  return 0;
+}
+static int ensure_stats(svihmm_ctx* h, int64_t nchunk_total) {
+  CK(ensure_feature_table(h));
+  CK(ensure(h->part, (size_t)nchunk_total * (h->Fp + h->Kp) * h->Kp * sizeof(double)));
+  CK(ensure(h->packed, (size_t)svihmm_packed_size(h->K, h->D) * sizeof(double)));
+  return 0;
+}
+static int launch_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags) {
+  const StatsPlan plan = stats_plan((int64_t)B * Lm);
+  CK(ensure_stats(h, plan.nchunk));
+  CK(launch_stats_range(h, 0, B, Lq, off, Lm, flags, plan, 0, h->stream));
+  return launch_stats_finalize(h, plan.nchunk, h->stream);
 }
 
 static int d2h(svihmm_ctx* h, void* dst, const void* src, size_t bytes) {
@@ -802,6 +882,8 @@ static int prepare_ll(svihmm_ctx* h, const int64_t* starts, int B, int Lm, uint3
   }
   h->lin_mode = lin;
   h->lin_stale = false;
+  h->q_valid = false;
+  h->curB = B;
   h->last_host_ll = host_ll;
   h->last_flags = flags;
   h->m_nb = 0;
@@ -838,6 +920,7 @@ static int intermediate_ptr(svihmm_ctx* h, int what, int64_t row0, int64_t nrows
   const int K = h->K, Lm = h->lastLm;
   Buf* src[] = {&h->ll, &h->la, &h->lb, &h->q};
   if (!h->lin_mode || what == 3 || (what == 0 && h->last_host_ll)) {
+    if (what == 3) CK(ensure_q(h, h->lastB, Lm, h->stream));
     if (!src[what]->p) return fail("intermediate buffer not available");
     *out = (const double*)src[what]->p + (size_t)row0 * K;
     return 0;
@@ -846,6 +929,79 @@ static int intermediate_ptr(svihmm_ctx* h, int what, int64_t row0, int64_t nrows
   CK(materialise(h, b0, b1 - b0));
   Buf* ms[] = {&h->m_ll, &h->m_la, &h->m_lb};
   *out = (const double*)ms[what]->p + ((size_t)row0 - (size_t)h->m_b0 * Lm) * K;
+  return 0;
+}
+
+// ---- two-stream E-step pipeline -------------------------------------------------------------
+// The scaled sweeps are latency-bound (one 4-wave workgroup per 16 windows, a serial chain
+// of Lm steps that keeps the matrix pipe ~45 % busy) while emission and statistics are
+// throughput-bound GEMMs.  For large batches the windows are split in two halves:
+//   stream A:  emission(h1)  emission(h2)        statistics(h1)  statistics(h2)  finalize
+//   stream B:               sweeps(h1)      sweeps(h2)
+// so that the sweeps of one half share the CUs with a GEMM of the other half.  The emission
+// kernel's LDS request is padded so that three of its workgroups plus one sweep workgroup fit
+// a CU; the sweep kernels raise their wave priority.  Partials stay deterministic (fixed
+// chunking per half, one finalize over all slots).
+static bool use_pipeline(const svihmm_ctx* h, int B, int Lm, int fbvar, uint32_t flags) {
+  const int v = h->variant[4];
+  if (v == 1 || fbvar != 3 || (flags & SVIHMM_USE_HOST_LLIKS)) return false;
+  if (h->Kp > 64 || h->D > 64) return false;
+  const int sv = h->variant[1];
+  if (sv != 0 && sv != 3) return false;
+  // opt-in only: on MI355X the sweeps' fp64 VALU work queues behind the GEMMs' MFMAs on a
+  // shared SIMD and both sides lose more than the overlap wins (experiments)
+  return v == 2 && B >= 32;
+}
+static int estep_pipelined(svihmm_ctx* h, const int64_t* starts, int B, int Lm, int inner_off,
+                           int inner_len, uint32_t flags) {
+  if (!h->have_globals) return fail("no globals: call svihmm_set_globals");
+  CK(check_windows(h, starts, B, Lm, true));
+  CK(upload_starts(h, starts, B));
+  if (!h->have_emission) return fail("no emission parameters: call svihmm_set_emission_niw");
+  if (h->eD != h->D) return fail("emission D does not match obs D");
+  if (h->eK != h->K) return fail("emission K does not match globals K");
+  if (!h->stream2) {
+    HIPCK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      HIPCK(hipEventCreateWithFlags(&h->ev_em[i], hipEventDisableTiming));
+      HIPCK(hipEventCreateWithFlags(&h->ev_sw[i], hipEventDisableTiming));
+    }
+  }
+  const int K = h->K;
+  const int64_t n = (int64_t)B * Lm;
+  // all buffers first: ensure() may reallocate
+  CK(ensure(h->ll, (size_t)n * K * sizeof(double)));
+  CK(ensure(h->kexp, (size_t)n * sizeof(double)));
+  CK(ensure_fb_lin(h, B, Lm));
+  int b0[2], nb[2];
+  b0[0] = 0; nb[0] = ((B / 2 + 15) / 16) * 16; b0[1] = nb[0]; nb[1] = B - nb[0];
+  StatsPlan plan[2] = {stats_plan((int64_t)nb[0] * inner_len), stats_plan((int64_t)nb[1] * inner_len)};
+  CK(ensure_stats(h, plan[0].nchunk + plan[1].nchunk));
+  h->have_host_ll = false;
+  h->lin_mode = true; h->lin_stale = false; h->last_host_ll = false; h->last_flags = flags;
+  h->q_valid = false; h->curB = B;
+  h->m_nb = 0; h->have_lb = true;
+  hipStream_t A = h->stream, Bs = h->stream2;
+  // stream B must not start before earlier work of stream A (parameter uploads) is done
+  HIPCK(hipEventRecord(h->ev_sw[1], A));
+  HIPCK(hipStreamWaitEvent(Bs, h->ev_sw[1], 0));
+  const size_t em_lds = 41 * 1024;   // 3 emission workgroups + 1 sweep workgroup per CU
+  for (int c = 0; c < 2; ++c) {
+    const size_t ro = (size_t)b0[c] * Lm;
+    CK(launch_emission(h, nb[c], Lm, flags, true, (const int64_t*)h->starts.p + b0[c],
+                       (double*)h->ll.p + ro * K, (double*)h->kexp.p + ro, A, em_lds));
+    HIPCK(hipEventRecord(h->ev_em[c], A));
+    HIPCK(hipStreamWaitEvent(Bs, h->ev_em[c], 0));
+    CK(launch_fb_lin_range(h, b0[c], nb[c], Lm, Bs));
+    HIPCK(hipEventRecord(h->ev_sw[c], Bs));
+  }
+  for (int c = 0; c < 2; ++c) {
+    HIPCK(hipStreamWaitEvent(A, h->ev_sw[c], 0));
+    CK(launch_stats_range(h, b0[c], nb[c], Lm, inner_off, inner_len, flags, plan[c],
+                          c == 0 ? 0 : plan[0].nchunk, A));
+  }
+  CK(launch_stats_finalize(h, plan[0].nchunk + plan[1].nchunk, A));
+  CK(launch_sum_lb(h, B, A));
   return 0;
 }
 
@@ -866,11 +1022,12 @@ int svihmm_forward_backward(svihmm_ctx* h, const int64_t* starts, int32_t B, int
                             double* out_var_x, double* out_local_lb) {
   if (!h) return fail("svihmm_forward_backward: NULL handle");
   CK(set_device(h));
-  const int var = pick_fb(h, B, out_lalpha != nullptr || out_lbeta != nullptr);
+  const int var = pick_fb(h, B, Lm, out_lalpha != nullptr || out_lbeta != nullptr);
   CK(prepare_ll(h, starts, B, Lm, flags, false, var == 3));
   CK(run_fb(h, B, Lm, var, out_lbeta != nullptr, false));
   h->lastB = B; h->lastLm = Lm;
   if (var == 3 && (out_lalpha || out_lbeta)) CK(materialise(h, 0, B));   // forced variant
+  if (var == 3 && out_var_x) CK(ensure_q(h, B, Lm, h->stream));
   const size_t n = (size_t)B * Lm * h->K * sizeof(double);
   if (out_lalpha) CK(d2h(h, out_lalpha, var == 3 ? h->m_la.p : h->la.p, n));
   if (out_lbeta) CK(d2h(h, out_lbeta, var == 3 ? h->m_lb.p : h->lb.p, n));
@@ -906,10 +1063,14 @@ int svihmm_estep_minibatch_ex(svihmm_ctx* h, const int64_t* starts, int32_t B, i
   }
   if (inner_off < 0 || inner_len <= 0 || inner_off + inner_len > Lm)
     return fail("svihmm_estep_minibatch_ex: inner segment out of range");
-  const int var = pick_fb(h, B, false);
-  CK(prepare_ll(h, starts, B, Lm, flags, true, var == 3));
-  CK(run_fb(h, B, Lm, var, (flags & SVIHMM_KEEP_LBETA) != 0, true));
-  CK(launch_stats(h, B, Lm, inner_off, inner_len, flags));
+  const int var = pick_fb(h, B, Lm, false);
+  if (use_pipeline(h, B, Lm, var, flags)) {
+    CK(estep_pipelined(h, starts, B, Lm, inner_off, inner_len, flags));
+  } else {
+    CK(prepare_ll(h, starts, B, Lm, flags, true, var == 3));
+    CK(run_fb(h, B, Lm, var, (flags & SVIHMM_KEEP_LBETA) != 0, true));
+    CK(launch_stats(h, B, Lm, inner_off, inner_len, flags));
+  }
   h->have_packed = true;
   h->lastB = B; h->lastLm = Lm;
   if (out_packed) {
@@ -1085,7 +1246,7 @@ int svihmm_profile_read(svihmm_ctx* h, double ms_out[SVIHMM_NKERN], int64_t coun
   return 0;
 }
 int svihmm_set_variant(svihmm_ctx* h, int32_t which, int32_t value) {
-  if (!h || which < 0 || which >= 4) return fail("svihmm_set_variant: bad arguments");
+  if (!h || which < 0 || which >= 8) return fail("svihmm_set_variant: bad arguments");
   h->variant[which] = value;
   return 0;
 }

@@ -142,3 +142,46 @@ def test_logs_on_demand_and_staleness(eng):
     with pytest.raises(RuntimeError, match="rebuilt on demand"):
         eng.read_rows("lalpha", 0, Lm)
     eng.read_rows("var_x", 0, Lm)            # posteriors are always resident
+
+
+@pytest.mark.parametrize("K,B,inner", [(64, 203, None), (20, 75, (3, 5)), (33, 1000, None)])
+def test_two_stream_pipeline_vs_oracle(eng, K, B, inner):
+    """Forced two-stream E-step (emission/statistics of one half overlap the sweeps of the
+    other): same statistics as the oracle, bit-identical when repeated (deterministic
+    partials), and identical posteriors to the single-stream path."""
+    from pysvihmm_amd import _lib as L
+    from oracle import ref_c
+    D, T, Lm = 3, 9000, 11
+    pb = make_problem(K, D, T, seed=500 + K, miss=0.05)
+    rng = np.random.default_rng(K + B)
+    starts = rng.integers(0, T - Lm + 1, size=B)
+    _push(eng, pb)
+    flags = L.TRANS_WRAP | L.MASK_AS_NAN
+    eng.set_variant("fb", 3)
+    eng.set_variant("pipeline", 1)
+    st0 = eng.estep(starts, Lm, flags=flags, inner=inner)
+    q0 = eng.read_intermediate("var_x", B, Lm)
+    eng.set_variant("pipeline", 2)
+    st1 = eng.estep(starts, Lm, flags=flags, inner=inner)
+    q1 = eng.read_intermediate("var_x", B, Lm)
+    st2 = eng.estep(starts, Lm, flags=flags, inner=inner)
+    la = eng.read_rows("lalpha", (B - 1) * Lm, Lm)     # logs on demand after the pipeline
+    eng.set_variant("pipeline", 0); eng.set_variant("fb", 0)
+    np.testing.assert_array_equal(st1.buf, st2.buf)
+    np.testing.assert_array_equal(q0, q1)
+    np.testing.assert_allclose(st1.buf, st0.buf, rtol=1e-12, atol=1e-12 * B * Lm)
+    if inner is None:
+        ref = ref_c.estep_minibatch(pb["obs"], pb["mask"], starts, Lm, pb["mod_init"], pb["ltran"],
+                                    pb["mu"], pb["sigma"], pb["kappa"], pb["nu"], flags=flags)
+        A, xbar, neff, S, lb = unpack(ref, K, D)
+        sc = B * Lm
+        np.testing.assert_allclose(st1.A_raw, A, rtol=RTOL, atol=1e-9 * sc)
+        np.testing.assert_allclose(st1.neff, neff, rtol=RTOL, atol=1e-9 * sc)
+        np.testing.assert_allclose(st1.xbar, xbar, rtol=RTOL, atol=1e-8 * sc)
+        np.testing.assert_allclose(st1.S, S, rtol=RTOL, atol=1e-7 * sc)
+        np.testing.assert_allclose(st1.lb[0], lb, rtol=1e-10)
+    s0 = int(starts[B - 1])
+    x = pb["obs"][s0:s0 + Lm].copy()
+    x[pb["mask"][s0:s0 + Lm]] = np.nan
+    ll = ref_c.lliks_niw(x, pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    np.testing.assert_allclose(la, ref_c.forward(ll, pb["mod_init"], pb["ltran"]), rtol=1e-9, atol=1e-8)
