@@ -199,281 +199,26 @@ __global__ __launch_bounds__(256) void k_stats_mfma(
 }
 
 // ------------------------------------------------------------------------------------
-//  K4c: statistics GEMM, software-pipelined, VGPR-form accumulators (K <= 64).
-//  Same math as K4b.  Design points:
+//  K4d: statistics GEMM, software-pipelined, VGPR-form accumulators (K <= 64 per state
+//  group).  Same math as K4b.  Design points:
 //   * fp64 MFMA with AGPR accumulators runs at ~63 % of the VGPR-form rate on gfx950
 //     (tools/peak_probe.py: 49 vs 77.6 TF/s), so the accumulators must fit the 256
 //     architected VGPRs: a workgroup is 4 m-groups x NSPLIT n-groups of waves, each wave
 //     MT x NTW tiles (5 x 2 x 8 = 80 accumulator registers at K = 64);
 //   * the next 32-row stage is fetched from HBM into registers while the current stage
-//     runs on the matrix pipe (global -> reg early, reg -> LDS after the compute);
+//     runs on the matrix pipe (global -> reg early, reg -> LDS after the compute); LDS tiles
+//     are double buffered with ONE barrier per stage; the two waves that share a SIMD stage
+//     at opposite ends of the stage (role B first, role A in the middle), so one of them
+//     always feeds the matrix pipe;
 //   * row bookkeeping (obs row, q row, wrap predecessor, mask) is computed once per stage
-//     by 32 lanes instead of per element (no integer divisions in the copy loops);
+//     by 32 lanes, three stages ahead, in phases so that its dependent global loads never
+//     sit in front of the stage barrier;
 //   * the 36 emission + 4 transition tiles of K=64, D=32 split into two balanced
 //     workgroup passes, so q is read twice.
-//  grid (nchunk, ceil(Ftot/16 / (4*MT))), block 256*NSPLIT.
-// ------------------------------------------------------------------------------------
-struct StRow {
-  long long orow;   // obs row, -1: out of range or masked (x~ = 0)
-  long long qrow;   // q row, -1: out of range
-  long long prow;   // predecessor q row, -1: none
-  double sq, sp;    // LIN: posterior scale 2^(h+g-zexp)/zm of rows qrow / prow
-};
-
-// LIN: the posteriors are not read but formed by the staging threads from the scaled
-// messages of K2e: q = ah * bh * 2^(hx + gx - zfac.y) * zfac.x (q points at ah).
-template <int MT, int NTW, int NSPLIT, int XK, bool LIN>
-__global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma3(
-    const double* __restrict__ obs, const uint8_t* __restrict__ mask,
-    const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K, int Fp, int F,
-    const int* __restrict__ fab, const double* __restrict__ q, int64_t rows_per_chunk,
-    uint32_t flags, int Lq, int off, double* __restrict__ part, int KpTot, int mt_limit,
-    const double* __restrict__ bh, const double* __restrict__ hx, const double* __restrict__ gx,
-    const double2* __restrict__ zfac) {
-  // KpTot: padded state count of the whole problem (partials stride); this workgroup covers
-  // states [blockIdx.z*Kp, +Kp); only m-tiles < mt_limit are produced (K > 64: the
-  // transition tiles are left to k_stats_mfma)
-  constexpr int NT = NTW * NSPLIT;
-  constexpr int Kp = 16 * NT;
-  constexpr int QS = Kp + 1;
-  constexpr int TPR = 8 * NSPLIT;          // staging threads per row
-  constexpr int QK = (Kp + TPR - 1) / TPR;  // q columns per staging thread
-  extern __shared__ double smem[];
-  // One LDS row per time step holds every A-operand source, so that each operand is the
-  // branch-free product row[fa] * row[fb]:
-  //   [0, D)      x (0 on masked rows)        D        1.0 (0 on masked rows)
-  //   D+1  ZERO   0.0                          D+2      ONE = 1.0 (always)
-  //   QP0 + i     q[prev(t), i], i < Kp  (transition features: row[QP0+i] * row[ONE])
-  const int ZERO = D + 1, ONE = D + 2, QP0 = D + 3;
-  const int RS = (QP0 + Kp) | 1;   // odd stride
-  double* rb0 = smem;                    // [2][32][RS]
-  double* qs0 = rb0 + 2 * ST_RB * RS;    // [2][32][QS]
-  StRow* rinfo = reinterpret_cast<StRow*>(qs0 + 2 * ST_RB * QS);  // [4][32]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, lg = lane >> 4;
-  const int mg = wave & 3, ng = wave >> 2;
-  const int Ftot = Fp + KpTot;
-  const int kbase = blockIdx.z * Kp;
-  const int mt0 = (blockIdx.y * 4 + mg) * MT;
-  const int nt0 = ng * NTW;
-  const int wg_m0 = blockIdx.y * 4 * MT * 16, wg_m1 = wg_m0 + 4 * MT * 16;
-  const bool need_x = wg_m0 < Fp;
-  const bool need_qp = wg_m1 > Fp && mt_limit * 16 > Fp;
-  const int sr = tid / TPR, sc = tid % TPR;   // staging role: row sr, columns sc + TPR*k
-
-  int fa[MT], fb[MT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const int f = (mt0 + m) * 16 + li;
-    fa[m] = ZERO; fb[m] = ZERO;
-    if (f < F) { const int ab = fab[f]; fa[m] = ab & 0xffff; fb[m] = ab >> 16; }
-    else if (f >= Fp && f - Fp < K && mt_limit * 16 > Fp) { fa[m] = QP0 + (f - Fp); fb[m] = ONE; }
-  }
-  double4_t acc[MT][NTW];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int n = 0; n < NTW; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
-
-  const int64_t c0 = (int64_t)blockIdx.x * rows_per_chunk;
-  const int64_t c1 = imin64(nrows, c0 + rows_per_chunk);
-  const int nstage = (int)((c1 - c0 + ST_RB - 1) / ST_RB);
-
-  // Row bookkeeping (threads 0..31, one row each) runs three stages ahead and is split in
-  // phases so that its dependent global loads (starts -> mask, exponents) never sit in front
-  // of the stage barrier: phase 1 at the top of a stage issues the first-level loads, phase 2
-  // in the middle the mask load that needs starts[], commit writes the LDS record at the end.
-  int64_t ri_g = 0, ri_bw = 0, ri_t = 0, ri_q = -1, ri_p = -1, ri_start = 0, ri_o = -1;
-  uint8_t ri_m = 0;
-  double2 ri_zf = make_double2(0.0, 0.0);
-  double ri_hq = 0.0, ri_gq = 0.0, ri_hp = 0.0, ri_gp = 0.0;
-  bool ri_ok = false;
-  auto ri_phase1 = [&](int64_t s0) {
-    if (tid < ST_RB) {
-      ri_g = s0 + tid;
-      ri_ok = ri_g < c1;
-      ri_q = -1; ri_p = -1;
-      if (ri_ok) {
-        ri_bw = ri_g / Lm;
-        ri_t = ri_g - ri_bw * Lm;
-        ri_q = ri_bw * Lq + off + ri_t;
-        if (ri_t > 0) ri_p = ri_q - 1;
-        else if (flags & SVIHMM_TRANS_WRAP) ri_p = ri_q + Lm - 1;
-        ri_start = starts[ri_bw];
-        if (LIN) {
-          ri_zf = zfac[ri_bw];
-          ri_hq = hx[ri_q]; ri_gq = gx[ri_q];
-          if (ri_p >= 0) { ri_hp = hx[ri_p]; ri_gp = gx[ri_p]; }
-        }
-      }
-    }
-  };
-  auto ri_phase2 = [&]() {
-    if (tid < ST_RB && ri_ok) {
-      ri_o = ri_start + off + ri_t;
-      ri_m = mask ? mask[ri_o] : (uint8_t)0;
-    }
-  };
-  auto ri_commit = [&](int buf) {
-    if (tid < ST_RB) {
-      StRow ri; ri.orow = -1; ri.qrow = ri_q; ri.prow = ri_p; ri.sq = 0.0; ri.sp = 0.0;
-      if (ri_ok) {
-        ri.orow = ri_m ? -1 : ri_o;
-        if (LIN) {
-          ri.sq = ldexp(ri_zf.x, (int)(ri_hq + ri_gq - ri_zf.y));
-          if (ri_p >= 0) ri.sp = ldexp(ri_zf.x, (int)(ri_hp + ri_gp - ri_zf.y));
-        }
-      }
-      rinfo[buf * ST_RB + tid] = ri;
-    }
-  };
-  auto row_info = [&](int64_t s0, int buf) { ri_phase1(s0); ri_phase2(); ri_commit(buf); };
-  double rx[XK], rq[QK], rp[QK];
-  double rq2[LIN ? QK : 1], rp2[LIN ? QK : 1], rsq = 0.0, rsp = 0.0;
-  auto fetch = [&](int buf) {
-    const StRow ri = rinfo[buf * ST_RB + sr];
-    if (LIN) { rsq = ri.sq; rsp = ri.sp; }
-    if (need_x) {
-#pragma unroll
-      for (int k = 0; k < XK; ++k) {
-        const int c = sc + TPR * k;
-        double v = 0.0;
-        if (ri.orow >= 0) {
-          if (c < D) v = obs[ri.orow * D + c];
-          else if (c == D) v = 1.0;
-        }
-        rx[k] = v;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < QK; ++k) {
-      const int c = sc + TPR * k;
-      rq[k] = (ri.qrow >= 0 && kbase + c < K) ? q[ri.qrow * K + kbase + c] : 0.0;
-      if (LIN) rq2[k] = (ri.qrow >= 0 && kbase + c < K) ? bh[ri.qrow * K + kbase + c] : 0.0;
-    }
-    if (need_qp) {
-#pragma unroll
-      for (int k = 0; k < QK; ++k) {
-        const int c = sc + TPR * k;
-        rp[k] = (ri.prow >= 0 && c < K) ? q[ri.prow * K + c] : 0.0;
-        if (LIN) rp2[k] = (ri.prow >= 0 && c < K) ? bh[ri.prow * K + c] : 0.0;
-      }
-    }
-  };
-  auto commit = [&](int bufi) {
-    double* rb = rb0 + bufi * ST_RB * RS;
-    double* qs = qs0 + bufi * ST_RB * QS;
-    if (need_x) {
-#pragma unroll
-      for (int k = 0; k < XK; ++k) {
-        const int c = sc + TPR * k;
-        if (c <= D) rb[sr * RS + c] = rx[k];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < QK; ++k) {
-      const int c = sc + TPR * k;
-      if (c < Kp) qs[sr * QS + c] = LIN ? (rq[k] * rq2[k]) * rsq : rq[k];
-    }
-    if (need_qp) {
-#pragma unroll
-      for (int k = 0; k < QK; ++k) {
-        const int c = sc + TPR * k;
-        if (c < Kp) rb[sr * RS + QP0 + c] = LIN ? (rp[k] * rp2[k]) * rsp : rp[k];
-      }
-    }
-  };
-  if (sc == 0) {
-    rb0[sr * RS + ZERO] = 0.0; rb0[sr * RS + ONE] = 1.0;
-    rb0[(ST_RB + sr) * RS + ZERO] = 0.0; rb0[(ST_RB + sr) * RS + ONE] = 1.0;
-  }
-  // Pipeline: LDS tiles are double buffered and there is ONE barrier per 32-row stage.
-  // During stage st every wave also writes stage st+1 (held in registers) into the other
-  // buffer and fetches stage st+2 from HBM; the two waves that share a SIMD do this at
-  // opposite ends of the stage (role B first, role A last), so one of them always feeds
-  // the matrix pipe.  Row bookkeeping runs three stages ahead.
-  const bool roleB = (NSPLIT == 2) && (ng == 1);
-  row_info(c0, 0);
-  row_info(c0 + ST_RB, 1);
-  row_info(c0 + 2 * ST_RB, 2);
-  __syncthreads();
-  fetch(0);
-  commit(0);
-  if (nstage > 1) fetch(1);
-  __syncthreads();
-  for (int st = 0; st < nstage; ++st) {
-    const int cur = st & 1;
-    ri_phase1(c0 + (int64_t)(st + 3) * ST_RB);
-    if (roleB) {
-      if (st + 1 < nstage) commit(cur ^ 1);
-      if (st + 2 < nstage) fetch((st + 2) & 3);
-    }
-    const double* rb = rb0 + cur * ST_RB * RS;
-    const double* qs = qs0 + cur * ST_RB * QS;
-    // k-steps, software pipelined by hand: the LDS reads of k-step ks+1 are issued before
-    // the MFMAs of k-step ks, so their latency is covered by this wave's own matrix work
-    double Bv[NTW], Ax[MT], Ay[MT];
-    {
-      const double* row = rb + lg * RS;
-#pragma unroll
-      for (int n = 0; n < NTW; ++n) Bv[n] = qs[lg * QS + (nt0 + n) * 16 + li];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) { Ax[m] = row[fa[m]]; Ay[m] = row[fb[m]]; }
-    }
-#pragma unroll
-    for (int ks = 0; ks < ST_RB / 4; ++ks) {
-      double Bn[NTW], Axn[MT], Ayn[MT];
-      if (ks + 1 < ST_RB / 4) {
-        const int r = (ks + 1) * 4 + lg;
-        const double* row = rb + r * RS;
-#pragma unroll
-        for (int n = 0; n < NTW; ++n) Bn[n] = qs[r * QS + (nt0 + n) * 16 + li];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) { Axn[m] = row[fa[m]]; Ayn[m] = row[fb[m]]; }
-      }
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const double A = Ax[m] * Ay[m];
-#pragma unroll
-        for (int n = 0; n < NTW; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(A, Bv[n], acc[m][n], 0, 0, 0);
-      }
-      if (ks + 1 < ST_RB / 4) {
-#pragma unroll
-        for (int n = 0; n < NTW; ++n) Bv[n] = Bn[n];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) { Ax[m] = Axn[m]; Ay[m] = Ayn[m]; }
-      }
-      // role A stages in the middle of its compute phase (role B did it before), so that
-      // at the end of the stage both waves of a SIMD are still feeding the matrix pipe
-      if (ks == ST_RB / 8 - 1) ri_phase2();
-      if (ks == ST_RB / 8 - 1 && !roleB) {
-        if (st + 1 < nstage) commit(cur ^ 1);
-        if (st + 2 < nstage) fetch((st + 2) & 3);
-      }
-    }
-    ri_commit((st + 3) & 3);
-    __syncthreads();
-  }
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int f = (mt0 + m) * 16 + lg + 4 * r;
-      if (f < Ftot && (mt0 + m) < mt_limit) {
-#pragma unroll
-        for (int n = 0; n < NTW; ++n)
-          part[((size_t)blockIdx.x * Ftot + f) * KpTot + kbase + (nt0 + n) * 16 + li] = acc[m][n][r];
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------
-//  K4d: K4c with branch-free staging and compile-time operand offsets.
 //  On gfx950 every VALU instruction a wave issues competes with the fp64 MFMAs of the SIMD
-//  (tools/peak_probe.py: the times add), and K4c spent ~600 VALU instructions per 80-MFMA
-//  stage on address arithmetic, 64-bit divisions and predicated copies.  Here:
+//  (tools/peak_probe.py: the times add); an earlier version (K4c) spent ~600 VALU
+//  instructions per 80-MFMA stage on address arithmetic, 64-bit divisions and predicated
+//  copies.  Here (~170 per stage):
 //   * the A-operand tile is stored column-major, both LDS buffers interleaved, the 32 stage
 //     rows permuted:  element (buffer u, row r, column c) at  c*67 + u*33 + (r&3)*8 + (r>>2),
 //     so the operand of k-step ks for lane (li, lg) is  base(lane, m) + [u*33 + ks]  -- one
@@ -485,7 +230,7 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma3(
 //   * staging threads copy with unconditional loads from clamped addresses and value
 //     selects (no exec-mask branches, so waits stay counted);
 //   * the stage loop is unrolled by two so that the LDS buffer is a compile-time choice.
-//  Same pipeline as K4c: double-buffered LDS, one barrier per stage, role-split staging.
+//  grid (nchunk, ceil(Ftot/16 / (4*MT)), state groups), block 256*NSPLIT.
 //  Host guarantees rows_per_chunk * max(K, Lq/Lm * K) < 2^31.
 // ------------------------------------------------------------------------------------
 struct StRow4 {
@@ -510,7 +255,7 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
   constexpr int NT = NTW * NSPLIT;
   constexpr int Kp = 16 * NT;
   constexpr int QS = Kp + 1;
-  constexpr int TPR = 8 * NSPLIT;          // staging threads per row
+  constexpr int TPR = 8 * NSPLIT;          // staging threads per row (block / 32)
   constexpr int QK = Kp / TPR;             // q columns per staging thread (exact)
   static_assert(QK * TPR == Kp, "staging split");
   extern __shared__ double smem[];
@@ -563,7 +308,7 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
   const double* __restrict__ pthr = q + Q0 * K + sc;
   const double* __restrict__ bpthr = LIN ? bh + Q0 * K + sc : nullptr;
 
-  // ---- row bookkeeping, three stages ahead, in phases (see K4c); threads 0..31
+  // ---- row bookkeeping, three stages ahead, in phases; threads 0..31
   unsigned ri_bwr = 0, ri_t = 0;
   int ri_qr = 0, ri_pr = 0, ri_pok = 0;
   int64_t ri_start = 0, ri_o = -1;
@@ -606,9 +351,9 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
       ri.pok = (ri_ok && ri_pok) ? 1 : 0;
       ri.pad_ = 0;
       ri.sq = 0.0; ri.sp = 0.0;
-      if (LIN) {
-        ri.sq = ldexp(ri_zf.x, (int)(ri_hq + ri_gq - ri_zf.y));
-        ri.sp = ldexp(ri_zf.x, (int)(ri_hp + ri_gp - ri_zf.y));
+      if (LIN) {   // invalid rows: scale 0 (their loads come from a clamped, finite row)
+        ri.sq = ri_ok ? ldexp(ri_zf.x, (int)(ri_hq + ri_gq - ri_zf.y)) : 0.0;
+        ri.sp = ri.pok ? ldexp(ri_zf.x, (int)(ri_hp + ri_gp - ri_zf.y)) : 0.0;
       }
       rinfo[buf * ST_RB + tid] = ri;
     }
@@ -666,18 +411,19 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
         rb0[xwi[k] + U * ST_CS] = okx ? v : 0.0;
       }
     }
+    // Padded state columns (k >= K) are not masked: they read finite neighbours (the
+    // buffers carry slack past the last row) and only feed output columns / transition
+    // features that nothing reads (k_finalize drops k >= K, features >= Fp + K are (0, 0)).
 #pragma unroll
     for (int k = 0; k < QK; ++k) {
-      const bool okc = okq && (kbase + sc + TPR * k < K);
-      const double v = LIN ? (rq[k] * rq2[k]) * rsq : rq[k];
-      qs0[U * ST_RB * QS + qwi + TPR * k] = okc ? v : 0.0;
+      const double v = LIN ? (rq[k] * rq2[k]) * rsq : (okq ? rq[k] : 0.0);
+      qs0[U * ST_RB * QS + qwi + TPR * k] = v;
     }
     if (need_qp) {
 #pragma unroll
       for (int k = 0; k < QK; ++k) {
-        const bool okc = okp && (sc + TPR * k < K);
-        const double v = LIN ? (rp[k] * rp2[k]) * rsp : rp[k];
-        rb0[pwi + U * ST_CS + TPR * k * ST_CC] = okc ? v : 0.0;
+        const double v = LIN ? (rp[k] * rp2[k]) * rsp : (okp ? rp[k] : 0.0);
+        rb0[pwi + U * ST_CS + TPR * k * ST_CC] = v;
       }
     }
   };
@@ -686,7 +432,7 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
     rb0[ZERO * ST_CC + psr] = 0.0; rb0[ONE * ST_CC + psr] = 1.0;
     rb0[ZERO * ST_CC + ST_CS + psr] = 0.0; rb0[ONE * ST_CC + ST_CS + psr] = 1.0;
   }
-  const bool roleB = (NSPLIT == 2) && (ng == 1);
+  const bool roleB = wave >= 4;   // the second wave of each SIMD
   row_info(0, 0);
   row_info(ST_RB, 1);
   row_info(2 * ST_RB, 2);

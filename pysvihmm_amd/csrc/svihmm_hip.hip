@@ -74,8 +74,10 @@ struct Buf {
 static int ensure(Buf& b, size_t bytes) {
   if (bytes <= b.cap && b.p) return 0;
   if (b.p) { hipFree(b.p); b.p = nullptr; b.cap = 0; }
+  // 256 bytes past `cap` always belong to the allocation: kernels that stage padded state
+  // columns read up to 15 doubles beyond the last row
   size_t want = bytes + bytes / 8 + 256;
-  HIPCK(hipMalloc(&b.p, want));
+  HIPCK(hipMalloc(&b.p, want + 256));
   b.cap = want;
   return 0;
 }
