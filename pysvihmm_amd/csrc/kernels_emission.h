@@ -202,7 +202,8 @@ __device__ __forceinline__ double digamma_d(double x) {
 __device__ __forceinline__ int feat_index_d(int a, int b, int D) {
   return a * (D + 1) - a * (a - 1) / 2 + (b - a);
 }
-__global__ __launch_bounds__(256) void k_niw_to_theta(
+// generic D (workgroup per state, matrices in LDS): used for D > 64 only
+__global__ __launch_bounds__(256) void k_niw_to_theta_generic(
     const double* __restrict__ mu, const double* __restrict__ sigma,
     const double* __restrict__ kappa, const double* __restrict__ nu, int K, int D, int Kp,
     double* __restrict__ theta, int* __restrict__ status) {
@@ -284,6 +285,100 @@ __global__ __launch_bounds__(256) void k_niw_to_theta(
       mWm += m[i] * wm[i];
     }
     llt -= 2.0 * logdet;
+    const double cst = 0.5 * llt - D / (2.0 * kappa[k]) - 0.5 * D * 1.8378770664093454835606594728112;
+    theta[(size_t)feat_index_d(D, D, D) * Kp + k] = cst - mWm;
+  }
+}
+
+// D <= DMAX <= 64: one wavefront per state, lane a owns row a of sigma / column a of L^-1 in
+// registers (loops fully unrolled, so all register indices are static).  Cross-lane data
+// moves as LDS broadcasts (every lane reads the same address): the D dependent Cholesky
+// columns cost one v_readlane + one LDS round trip each instead of workgroup barriers, and
+// the triangular inverse / Gram product stream independent broadcast reads.  ~10x faster
+// than the generic kernel at D = 32; it sits on the E-step's critical path every iteration.
+template <int DMAX>
+__global__ __launch_bounds__(64) void k_niw_to_theta_wave(
+    const double* __restrict__ mu, const double* __restrict__ sigma,
+    const double* __restrict__ kappa, const double* __restrict__ nu, int K, int D, int Kp,
+    double* __restrict__ theta, int* __restrict__ status) {
+  __shared__ double col[64];
+  __shared__ double Ls[DMAX][DMAX + 1];    // L (row-major), later X = L^-1 stored as Ls[c][r]
+  __shared__ double ms[DMAX];
+  const int k = blockIdx.x, a = threadIdx.x;
+  const bool va = a < D;
+  const double* Sg = sigma + (size_t)k * D * D;
+  double A[DMAX];
+#pragma unroll
+  for (int j = 0; j < DMAX; ++j) A[j] = (va && j < D) ? Sg[(size_t)a * D + j] : (a == j ? 1.0 : 0.0);
+  if (a < DMAX) ms[a] = va ? mu[(size_t)k * D + a] : 0.0;
+  // ---- right-looking Cholesky; padded rows/columns form an identity block
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < DMAX; ++j) {
+    const double djj = __shfl(A[j], j, 64);
+    bad |= !(djj > 0.0);
+    const double d = sqrt(djj), rd = 1.0 / d;
+    const double l = (a == j) ? d : A[j] * rd;
+    A[j] = l;
+    col[a] = l;
+    __syncthreads();
+#pragma unroll
+    for (int b = j + 1; b < DMAX; ++b) A[b] = fma(-l, col[b], A[b]);   // upper part: unused garbage
+    __syncthreads();
+  }
+  if (bad) {   // uniform: djj is a broadcast value
+    if (a == 0) atomicMax(status, 1 + k);
+    return;
+  }
+  double logdet;
+  {   // the lane's diagonal element through a select chain (no dynamic register index)
+    double dg = 1.0;
+#pragma unroll
+    for (int j = 0; j < DMAX; ++j) dg = (a == j) ? A[j] : dg;
+    logdet = va ? log(dg) : 0.0;
+  }
+  if (a < DMAX) {
+#pragma unroll
+    for (int j = 0; j < DMAX; ++j) Ls[a][j] = A[j];
+  }
+  __syncthreads();
+  // ---- X = L^-1, lane c owns column c: X[r][c] = -(sum_{j=c}^{r-1} L[r][j] X[j][c]) / L[r][r]
+  double X[DMAX];
+  const int c = a;
+#pragma unroll
+  for (int r = 0; r < DMAX; ++r) {
+    double s = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int j = 0; j < r; ++j) s = fma(-Ls[r][j], X[j], s);   // X[j] = 0 for j < c
+    X[r] = (r >= c) ? s / Ls[r][r] : 0.0;
+  }
+  __syncthreads();
+  if (a < DMAX) {
+#pragma unroll
+    for (int r = 0; r < DMAX; ++r) Ls[a][r] = X[r];            // Ls[c][r] = X[r][c]
+  }
+  __syncthreads();
+  // ---- W = (nu/2) X^T X, lane i owns row i; theta entries
+  const double hn = 0.5 * nu[k];
+  double wmi = 0.0;
+  const int i = a;
+#pragma unroll
+  for (int j = 0; j < DMAX; ++j) {
+    double s = 0.0;
+#pragma unroll
+    for (int r = j; r < DMAX; ++r) s = fma(X[r], Ls[j][r], s);  // X[r][i] * X[r][j]; zero for r < max(i,j)
+    const double w = hn * s;
+    wmi = fma(w, ms[j], wmi);
+    if (va && j >= i && j < D)
+      theta[(size_t)feat_index_d(i, j, D) * Kp + k] = (i == j) ? -w : -2.0 * w;
+  }
+  if (va) theta[(size_t)feat_index_d(i, D, D) * Kp + k] = 2.0 * wmi;
+  // ---- constant term
+  double dgm = va ? digamma_d(0.5 * (nu[k] - a)) : 0.0;
+  double mWm = va ? ms[a < DMAX ? a : 0] * wmi : 0.0;
+  logdet = wave_sum(logdet); dgm = wave_sum(dgm); mWm = wave_sum(mWm);
+  if (a == 0) {
+    const double llt = D * log(2.0) + dgm - 2.0 * logdet;
     const double cst = 0.5 * llt - D / (2.0 * kappa[k]) - 0.5 * D * 1.8378770664093454835606594728112;
     theta[(size_t)feat_index_d(D, D, D) * Kp + k] = cst - mWm;
   }

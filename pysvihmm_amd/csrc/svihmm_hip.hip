@@ -107,6 +107,7 @@ struct svihmm_ctx {
   // emission
   int eK = 0, eD = 0, Kp = 0, F = 0, Fp = 0;
   Buf theta, fab, niw;
+  void* theta_zero_p = nullptr; size_t theta_zero_n = 0;   // what the last theta memset covered
   int tabD = -1;
   void* pin = nullptr; size_t pin_cap = 0;   // pinned host staging for parameter uploads
   int* pin_status = nullptr;                 // pinned: NIW factorisation status (lazy check)
@@ -347,7 +348,7 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
   HIPCK(hipStreamSynchronize(h->stream));
   CK(check_emission_status(h));
   void* pin = nullptr;
-  CK(pinned(h, nin * sizeof(double), &pin));
+  CK(pinned(h, (nin + 1) * sizeof(double), &pin));
   double* hp = (double*)pin;
   std::memcpy(hp, mu, nmu * sizeof(double));
   std::memcpy(hp + nmu, sigma, nsg * sizeof(double));
@@ -355,17 +356,32 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
   std::memcpy(hp + nmu + nsg + K, nu, K * sizeof(double));
   if (!h->pin_status) HIPCK(hipHostMalloc((void**)&h->pin_status, 64, hipHostMallocDefault));
   *h->pin_status = 0;
-  HIPCK(hipMemcpyAsync(dmu, hp, nin * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIPCK(hipMemsetAsync(dstatus, 0, sizeof(int), h->stream));
-  HIPCK(hipMemsetAsync(h->theta.p, 0, (size_t)Fp * Kp * sizeof(double), h->stream));
+  hp[nin] = 0.0;   // the status word travels with the parameters: one H2D copy
+  HIPCK(hipMemcpyAsync(dmu, hp, (nin + 1) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  // theta's padded rows / columns are zeroed once per (buffer, shape); k_niw_to_theta
+  // rewrites every live entry on each call
+  if (h->theta_zero_p != h->theta.p || h->theta_zero_n != (size_t)Fp * Kp) {
+    HIPCK(hipMemsetAsync(h->theta.p, 0, (size_t)Fp * Kp * sizeof(double), h->stream));
+    h->theta_zero_p = h->theta.p; h->theta_zero_n = (size_t)Fp * Kp;
+  }
   {
     ProfScope ps(h, KS_MISC);
-    const size_t lds = (size_t)(3 * D * (D + 1) + D) * sizeof(double);
-    if (lds > 64 * 1024)
-      hipFuncSetAttribute((const void*)k_niw_to_theta, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_niw_to_theta, dim3(K), dim3(256), lds, h->stream, (const double*)dmu,
-                       (const double*)dsg, (const double*)dka, (const double*)dnu, K, D, Kp,
-                       (double*)h->theta.p, dstatus);
+#define NIWW(DM) hipLaunchKernelGGL(k_niw_to_theta_wave<DM>, dim3(K), dim3(64), 0, h->stream, (const double*)dmu, \
+                                    (const double*)dsg, (const double*)dka, (const double*)dnu, K, D, Kp,   \
+                                    (double*)h->theta.p, dstatus)
+    if (D <= 8) NIWW(8);
+    else if (D <= 16) NIWW(16);
+    else if (D <= 32) NIWW(32);
+    else if (D <= 64) NIWW(64);
+    else {
+      const size_t lds = (size_t)(3 * D * (D + 1) + D) * sizeof(double);
+      if (lds > 64 * 1024)
+        hipFuncSetAttribute((const void*)k_niw_to_theta_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(k_niw_to_theta_generic, dim3(K), dim3(256), lds, h->stream, (const double*)dmu,
+                         (const double*)dsg, (const double*)dka, (const double*)dnu, K, D, Kp,
+                         (double*)h->theta.p, dstatus);
+    }
+#undef NIWW
     HIPCK(hipGetLastError());
   }
   // status comes back asynchronously; it is examined at the next synchronising call
