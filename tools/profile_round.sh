@@ -1,0 +1,24 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence for one profile set (run on the GPU box through gpurun):
+#   tools/profile_round.sh r01e
+# kernel trace + stats, FETCH_SIZE / WRITE_SIZE in separate PMC passes, SQ counters, bench line.
+# Output: gpurun_out/<tag>_*.txt / .json (copy what should be judged into profiles/).
+set -u
+TAG=${1:-rXX}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+run() {  # name, rocprof args...
+  local name=$1; shift
+  rm -rf /tmp/prof_$name
+  rocprofv3 "$@" -d /tmp/prof_$name -o $TAG -- $BENCH > /tmp/prof_$name.log 2>&1
+  local db=$(find /tmp/prof_$name -name "*.db" | head -1)
+  python $ROOT/tools/rocpd_summary.py $db
+}
+run kt --kernel-trace --stats > $OUT/${TAG}_kernel_stats.txt
+{ run fetch --kernel-trace --pmc FETCH_SIZE; run write --kernel-trace --pmc WRITE_SIZE; } > $OUT/${TAG}_pmc_hbm.txt
+run sq --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS > $OUT/${TAG}_sq_counters.txt
+cd $ROOT && python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > $OUT/${TAG}_bench.json
+tail -c 600 $OUT/${TAG}_bench.json
