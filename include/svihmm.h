@@ -53,7 +53,8 @@ typedef struct svihmm_ctx svihmm_ctx;
  * plugin route) instead of evaluating the NIW emission kernel. */
 #define SVIHMM_USE_HOST_LLIKS 4u
 /* svihmm_estep_minibatch only: also materialise lbeta in HBM so that it can be read
- * back (the fused backward sweep otherwise keeps it in registers). */
+ * back (the log-domain fused backward sweep otherwise keeps it in registers; the scaled
+ * sweeps of large batches rebuild lbeta on demand and ignore the flag). */
 #define SVIHMM_KEEP_LBETA 8u
 
 /* ---- errors / lifecycle ------------------------------------------------------- */
@@ -133,7 +134,14 @@ int svihmm_estep_minibatch_ex(svihmm_ctx* h, const int64_t* starts, int32_t B,
                               uint32_t flags, double* out_packed);
 
 /* Readback of the intermediates of the last estep/forward_backward call
- * (what 0: lliks, 1: lalpha, 2: lbeta, 3: var_x; each [B,Lm,K]). */
+ * (what 0: lliks, 1: lalpha, 2: lbeta, 3: var_x; each [B,Lm,K]).
+ * Large batches (B >= 192, K <= 64) run scaled linear-domain sweeps that never write a
+ * logarithm: var_x is formed on first read, and the log-domain lliks / lalpha / lbeta of the
+ * requested windows are recomputed by the log-domain kernels (exact, same values as a
+ * svihmm_forward_backward call on those windows).  That recomputation uses the CURRENT
+ * observations / globals / emission parameters: read log-domain intermediates before the
+ * next svihmm_set_* call (a read after one fails with an explicit error; ranges already
+ * rebuilt stay readable). */
 int svihmm_read_intermediate(svihmm_ctx* h, int32_t what, double* out);
 /* nrows rows starting at flattened row row0 of the same [B*Lm, K] arrays. */
 int svihmm_read_rows(svihmm_ctx* h, int32_t what, int64_t row0, int64_t nrows,
@@ -173,7 +181,10 @@ int svihmm_profile_reset(svihmm_ctx* h);
 int svihmm_profile_read(svihmm_ctx* h, double ms_out[SVIHMM_NKERN],
                         int64_t count_out[SVIHMM_NKERN]);
 const char* svihmm_kernel_name(int32_t slot);
-/* Selects the kernel generation for A/B measurement (0 = default/best). */
+/* Selects the kernel generation for A/B measurement (0 = default/best).
+ * which 0 emission (1 VALU, 2 MFMA) | 1 statistics (1 VALU, 2 MFMA, 3 pipelined MFMA)
+ * | 2 sweeps (1 wave-per-window, 2 log-domain MFMA, 3 scaled linear-domain MFMA)
+ * | 3 emission row tiles per wave | 4 two-stream E-step pipeline (1 off, 2 on; default off) */
 int svihmm_set_variant(svihmm_ctx* h, int32_t which, int32_t value);
 
 /* ---- diagnostics ------------------------------------------------------------------- */
