@@ -76,29 +76,47 @@ __global__ __launch_bounds__(256) void k_emission_mfma(
   const int DS = (D + 2) | 1;  // odd row stride (doubles); slot D = 1.0, slot D+1 = 0.0
   double* xs = smem;                              // [ROWS][DS]
   int* fabs_ = (int*)(xs + ROWS * DS);            // [Fp] packed (a | b<<16)
-  unsigned char* bad_s = (unsigned char*)(fabs_ + Fp);  // [ROWS]
+  long long* rowoff = (long long*)(fabs_ + Fp);   // [ROWS] obs element offset of the row, -1: none (Fp is even)
+  unsigned char* bad_s = (unsigned char*)(rowoff + ROWS);  // [ROWS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t g0 = (int64_t)blockIdx.x * ROWS;
   const int n0 = blockIdx.y * (16 * NT);
 
-  for (int r = tid; r < ROWS; r += 256) {
-    int64_t g = g0 + r;
-    unsigned char bd = 0;
-    if (g < nrows && (flags & SVIHMM_MASK_AS_NAN) && mask)
-      bd = mask[obs_row(starts, Lm, g)] != 0;
-    bad_s[r] = bd;
-    xs[r * DS + D] = 1.0;
-    xs[r * DS + D + 1] = 0.0;
+  // Row bookkeeping once per row, in 32-bit arithmetic relative to the tile's first row (the
+  // copy loop below used to pay a 64-bit division per ELEMENT; VALU work of a prologue wave
+  // blocks the MFMAs of the three waves it shares the SIMD with).
+  {
+    const int64_t bw0 = g0 / Lm;
+    const unsigned t0 = (unsigned)(g0 - bw0 * Lm);
+    for (int r = tid; r < ROWS; r += 256) {
+      const bool valid = g0 + r < nrows;
+      const unsigned x = t0 + (unsigned)(valid ? r : 0);
+      const unsigned bwr = x / (unsigned)Lm;
+      const int64_t orow = starts[bw0 + bwr] + (x - bwr * (unsigned)Lm);
+      unsigned char bd = 0;
+      if (valid && (flags & SVIHMM_MASK_AS_NAN) && mask) bd = mask[orow] != 0;
+      rowoff[r] = valid ? orow * D : -1;
+      bad_s[r] = bd;
+      xs[r * DS + D] = 1.0;
+      xs[r * DS + D + 1] = 0.0;
+    }
   }
   for (int e = tid; e < Fp; e += 256) fabs_[e] = fab[e];
   __syncthreads();
-  for (int e = tid; e < ROWS * D; e += 256) {
-    int r = e / D, i = e - r * D;
-    int64_t g = g0 + r;
-    double v = 0.0;
-    if (g < nrows) v = obs[obs_row(starts, Lm, g) * D + i];
-    if (v != v) { bad_s[r] = 1; v = 0.0; }
-    xs[r * DS + i] = v;
+  {
+    // (row, column) from shifts: DP = D rounded up to a power of two (<= 256, since the tile
+    // must fit LDS), 256 / DP rows per pass, consecutive lanes read consecutive doubles
+    const int sh = 32 - __builtin_clz((unsigned)(D > 1 ? D - 1 : 1));
+    const int rpp = 256 >> sh, i = tid & ((1 << sh) - 1), rr = tid >> sh;
+    for (int rb = 0; rb < ROWS; rb += rpp) {
+      const int r = rb + rr;
+      if (i < D) {
+        const long long o = rowoff[r];
+        double v = o >= 0 ? obs[o + i] : 0.0;
+        if (v != v) { bad_s[r] = 1; v = 0.0; }
+        xs[r * DS + i] = v;
+      }
+    }
   }
   __syncthreads();
 

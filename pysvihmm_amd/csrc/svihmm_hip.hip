@@ -457,8 +457,8 @@ static int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool sc
     const int DS = (D + 2) | 1;
     int MT = h->variant[3] > 0 ? h->variant[3] : 2;
     if (MT != 2 && MT != 4) MT = 2;
-    size_t lds = (size_t)(64 * MT) * DS * 8 + (size_t)h->Fp * 4 + 64 * MT;
-    if (lds > 150 * 1024 && MT == 4) { MT = 2; lds = (size_t)128 * DS * 8 + (size_t)h->Fp * 4 + 128; }
+    size_t lds = (size_t)(64 * MT) * DS * 8 + (size_t)h->Fp * 4 + (size_t)(64 * MT) * 9;
+    if (lds > 150 * 1024 && MT == 4) { MT = 2; lds = (size_t)128 * DS * 8 + (size_t)h->Fp * 4 + 128 * 9; }
     if (lds < min_lds) lds = min_lds;   // occupancy cap: leave LDS for co-resident sweep workgroups
     if (lds > 150 * 1024 && scaled) return fail("emission: D too large for the scaled sweeps");
     if (lds > 150 * 1024) var = 1;
