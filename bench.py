@@ -29,6 +29,11 @@ import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+# RCCL prints a version banner to stdout under NCCL_DEBUG=VERSION (set on the GPU boxes);
+# the contract is ONE JSON line, so quieten it before librccl is loaded with the HIP library.
+if os.environ.get("NCCL_DEBUG", "").upper() in ("VERSION", "INFO"):
+    del os.environ["NCCL_DEBUG"]
+os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")   # whatever RCCL still says: not on stdout
 
 K, D, T, LHALF = 64, 32, 1000000, 128
 LM = 2 * LHALF + 1

@@ -57,6 +57,29 @@ __device__ __forceinline__ double fast_exp(double x) {
   p = fma(p, r, 1.0);
   return ldexp(p, (int)k);
 }
+// fast_exp with its constants held in caller-provided VGPRs.  hipcc otherwise rematerialises
+// every fp64 literal (two v_mov_b32 each) at each use: in a 32-exp epilogue that is ~800 moves.
+struct ExpConsts { double c[15]; };
+__device__ __forceinline__ void exp_consts_init(ExpConsts& k) {
+  const double v[15] = {1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0,
+                        1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0,
+                        1.0 / 6.0, 0.5, 1.4426950408889634074, -6.93147180369123816490e-01,
+                        -1.90821492927058770002e-10, -800.0};
+#pragma unroll
+  for (int i = 0; i < 15; ++i) { k.c[i] = v[i]; asm volatile("" : "+v"(k.c[i])); }
+}
+__device__ __forceinline__ double fast_exp_k(double x, const ExpConsts& k) {
+  x = fmax_raw(x, k.c[14]);
+  const double n = __builtin_rint(x * k.c[11]);
+  double r = fma(n, k.c[12], x);
+  r = fma(n, k.c[13], r);
+  double p = k.c[0];
+#pragma unroll
+  for (int i = 1; i <= 10; ++i) p = fma(p, r, k.c[i]);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)n);
+}
 __device__ __forceinline__ double fast_log(double x) {   // x >= 0, finite
   int e;
   double m = frexp(x, &e);                       // m in [0.5, 1)

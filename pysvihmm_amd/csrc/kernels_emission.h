@@ -168,36 +168,57 @@ __global__ __launch_bounds__(256) void k_emission_mfma(
 #pragma unroll
       for (int r = 0; r < 4; ++r) outv[m][n][r] = acc[m][n][r];
   __builtin_amdgcn_sched_barrier(0);
+  if (SCALED) {
+    // One exp per (row, state) is the algorithmic minimum of transcendental work on the
+    // whole E-step; keep it lean: constants pinned in VGPRs, branch-free NaN/inf handling.
+    ExpConsts ek;
+    exp_consts_init(ek);
+    double big = 1.7976931348623157e308, l2e = 1.4426950408889634074;
+    asm volatile("" : "+v"(big));
+    asm volatile("" : "+v"(l2e));
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
+    for (int m = 0; m < MT; ++m) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int rl = wave * 16 * MT + m * 16 + lg + 4 * r;
-      const int64_t g = g0 + rl;
-      const bool bd = bad_s[rl] != 0;
-      if (SCALED) {
+      for (int r = 0; r < 4; ++r) {
+        const int rl = wave * 16 * MT + m * 16 + lg + 4 * r;
+        const int64_t g = g0 + rl;
+        const bool bd = bad_s[rl] != 0;
         double v[NT], mx = -INFINITY;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           const int k = n0 + n * 16 + li;
-          v[n] = k < K ? (bd ? 0.0 : nan_to_num(outv[m][n][r])) : -INFINITY;
+          double x = outv[m][n][r];
+          x = fmax_raw(-big, x);                 // -inf -> -DBL_MAX, NaN -> -DBL_MAX ...
+          x = -fmax_raw(-big, -x);               // +inf -> DBL_MAX
+          x = (outv[m][n][r] != outv[m][n][r] || bd) ? 0.0 : x;   // ... NaN and masked rows -> 0
+          v[n] = k < K ? x : -INFINITY;
           mx = fmax_raw(mx, v[n]);
         }
         mx = row16_max(mx);   // all lanes: the DPP reduction stays outside the store guards
-        const double kx = (mx > -1e300 && mx < 1e300) ? ceil(mx * 1.4426950408889634074) : 0.0;
+        const double kx = (mx > -1e300 && mx < 1e300) ? ceil(mx * l2e) : 0.0;
+        double* orow = ll + g * K + n0 + li;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-          const int k = n0 + n * 16 + li;
-          const double e = fast_exp(fma(-kx, 1.90821492927058770002e-10,
-                                        fma(-kx, 6.93147180369123816490e-01, v[n])));
-          if (g < nrows && k < K) ll[g * K + k] = e;
+          const double e = fast_exp_k(fma(kx, ek.c[13], fma(kx, ek.c[12], v[n])), ek);
+          if (g < nrows && n0 + n * 16 + li < K) orow[n * 16] = e;
         }
         if (li == 0 && g < nrows) kexp[g] = kx;
-      } else if (g < nrows) {
+      }
+    }
+  } else {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const int k = n0 + n * 16 + li;
-          if (k < K) ll[g * K + k] = bd ? 0.0 : nan_to_num(outv[m][n][r]);
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rl = wave * 16 * MT + m * 16 + lg + 4 * r;
+        const int64_t g = g0 + rl;
+        const bool bd = bad_s[rl] != 0;
+        if (g < nrows) {
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            const int k = n0 + n * 16 + li;
+            if (k < K) ll[g * K + k] = bd ? 0.0 : nan_to_num(outv[m][n][r]);
+          }
         }
       }
     }
