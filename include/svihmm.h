@@ -184,7 +184,8 @@ const char* svihmm_kernel_name(int32_t slot);
 /* Selects the kernel generation for A/B measurement (0 = default/best).
  * which 0 emission (1 VALU, 2 MFMA) | 1 statistics (1 VALU, 2 MFMA, 3 pipelined MFMA)
  * | 2 sweeps (1 wave-per-window, 2 log-domain MFMA, 3 scaled linear-domain MFMA)
- * | 3 emission row tiles per wave | 4 two-stream E-step pipeline (1 off, 2 on; default off) */
+ * | 3 emission row tiles per wave | 4 two-stream E-step pipeline (1 off, 2 on; default off)
+ * | 6 blocked scan for one long window (B = 1, Lm >= 2048, K <= 64; 1 = off) */
 int svihmm_set_variant(svihmm_ctx* h, int32_t which, int32_t value);
 
 /* ---- diagnostics ------------------------------------------------------------------- */

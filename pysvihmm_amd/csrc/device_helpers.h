@@ -130,6 +130,20 @@ __device__ __forceinline__ double row16_max(double v) {
   v = fmax_raw(v, dpp_mov_f64<0x140>(v));
   return v;
 }
+// wave-wide reductions without LDS round trips: DPP within rows of 16, v_readlane across rows
+// (result uniform).  ~25 instructions instead of six ds_bpermute round trips.
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                          __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v = row16_sum(v);
+  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+__device__ __forceinline__ double wave_max_dpp(double v) {
+  v = row16_max(v);
+  return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
 __device__ __forceinline__ double wave64_max_fast(double v) {
   v = row16_max(v);
   v = fmax_raw(v, __shfl_xor(v, 16, 64));

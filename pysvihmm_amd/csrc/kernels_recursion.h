@@ -553,45 +553,72 @@ __device__ __forceinline__ double4_t lin_rowsum(const LinShared<NW>& sh, int cur
   return __builtin_amdgcn_mfma_f64_16x16x4f64(s, 1.0, z, 0, 0, 0);
 }
 
-// per-lane state shared by both directions
+// per-lane state shared by both directions.  Windows of a launch start `wstride` rows apart
+// (normal batches: wstride = Lm; chain chunks overlap their terminal row: wstride = Lm - 1).
 template <int NW, bool FULL>
 struct LinLane {
   int lane, wave, li, lg, j, jc, b0;
   bool vj;
   unsigned oE[4], oR[4], oRw;   // 32-bit element offsets of (window lg+4r, state j) / row; oRw: window lg+4*wave
   int gwc[4];
-  __device__ __forceinline__ void init(int B, int Lm, int K) {
+  __device__ __forceinline__ void init(int bfirst, int B, int wstride, int K, bool shared_rows) {
     lane = threadIdx.x & 63; wave = threadIdx.x >> 6;
     li = lane & 15; lg = lane >> 4;
     j = wave * 16 + li;
     vj = FULL || (j < K);
     jc = vj ? j : 0;
-    b0 = blockIdx.x * 16;
+    b0 = bfirst;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int gw = b0 + lg + 4 * r;
       gwc[r] = gw < B ? gw : B - 1;
-      oR[r] = (unsigned)(gwc[r] - b0) * (unsigned)Lm;
+      oR[r] = shared_rows ? 0u : (unsigned)(gwc[r] - b0) * (unsigned)wstride;
       oE[r] = oR[r] * (unsigned)K + (unsigned)jc;
     }
     const int gww = b0 + lg + 4 * (wave & 3);
-    oRw = (unsigned)((gww < B ? gww : B - 1) - b0) * (unsigned)Lm;
+    oRw = shared_rows ? 0u : (unsigned)((gww < B ? gww : B - 1) - b0) * (unsigned)wstride;
   }
 };
-// value of register array v[r] for r == wave (wave-uniform select; NW == 4 only)
+// value of register array v[r] for r == w (wave-uniform select)
 __device__ __forceinline__ double sel4(const double (&v)[4], int w) {
   return w == 0 ? v[0] : (w == 1 ? v[1] : (w == 2 ? v[2] : v[3]));
 }
 
-template <int NW, bool FULL>
+// Chain extension (one window = the whole sequence, "100 % sequential in t").
+// The scaled recursion is a product of K x K matrices G_s = A diag(Eh_s), so a long chain is
+// cut into chunks of L steps and processed as an exact blocked scan:
+//   S1  per chunk, M_c = G_{cL+1} ... G_{cL+L} by the forward sweep itself run on 64 unit
+//       vectors (MODE 2: four workgroups of 16 pseudo-windows share the chunk's rows);
+//   S2  k_chunk_scan: alpha at the chunk starts (alpha_{b+1} = alpha_b M_c) and beta at the
+//       chunk ends (beta_b = M_c beta_{b+1}) -- the same matrices serve both directions;
+//   S3  the sweeps below with the boundary vectors as initial / terminal condition (MODE 1):
+//       every chunk is then an independent window, all of them run concurrently.
+// Same arithmetic as the sequential sweep up to the association order of the products.
+struct LinChain {
+  const double* init_vec;   // MODE 1 fwd: [B][K] initial ah of each window, init_exp[B] its exponent
+  const double* init_exp;
+  const double* term_vec;   // MODE 1 bwd: [B][K] bh at the (virtual) top row, term_exp[B]
+  const double* term_exp;
+  const double* kbefore;    // [B] sum of the emission row exponents before the window (local_lb, logz)
+  double* Mout;             // MODE 2: [chunks][16*NW][K] chunk matrix, MoutT its transpose
+  double* MoutT;
+  double* Mh;               // MODE 2: [chunks][16*NW] per-row exponents
+};
+
+// MODE 0: windows start from the initial distribution.  MODE 1: from chain.init_vec.
+// MODE 2: chunk matrices (unit initial vectors, all pseudo-windows read the chunk's rows,
+// nothing but the final matrix is stored; blockIdx.x = chunk * NW + row group).
+template <int NW, bool FULL, int MODE>
 __device__ __forceinline__ void fwd_lin_body(
     LinShared<NW>& sh, const double* __restrict__ Eh, const double* __restrict__ kexp,
-    const double* __restrict__ Aexp, const double* __restrict__ mod_init, int B, int Lm, int K,
-    double* __restrict__ ah, double* __restrict__ hx, double* __restrict__ local_lb,
-    double* __restrict__ logz, double2* __restrict__ zfac) {
+    const double* __restrict__ Aexp, const double* __restrict__ mod_init, int B, int Lm,
+    int wstride, int K, double* __restrict__ ah, double* __restrict__ hx,
+    double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac,
+    const LinChain& ch) {
   constexpr int KS = 4 * NW;
   LinLane<NW, FULL> L;
-  L.init(B, Lm, K);
+  const int chunk = MODE == 2 ? blockIdx.x / NW : 0, rgrp = MODE == 2 ? blockIdx.x % NW : 0;
+  L.init(MODE == 2 ? chunk : blockIdx.x * 16, MODE == 2 ? chunk + 1 : B, wstride, K, MODE == 2);
   const int li = L.li, lg = L.lg, j = L.j, jc = L.jc, wave = L.wave;
   const bool vj = L.vj;
   double Bv[KS];
@@ -600,36 +627,47 @@ __device__ __forceinline__ void fwd_lin_body(
     const int k = 8 * (kk >> 1) + 2 * lg + (kk & 1);
     Bv[kk] = (k < K && vj) ? Aexp[(size_t)k * K + jc] : 0.0;
   }
-  const size_t wrow = (size_t)L.b0 * Lm;
+  const size_t wrow = (size_t)L.b0 * wstride;
   const double* __restrict__ Eb = Eh + wrow * K;
   double* __restrict__ ab = ah + wrow * K;
   double* __restrict__ hb = hx + wrow;
-  // common binary exponent of the initial distribution
-  double mi_max = -INFINITY;
-  for (int k = 0; k < K; ++k) mi_max = fmax(mi_max, mod_init[k]);
-  const double s0 = (mi_max > -1e300 && mi_max < 1e300) ? ceil(mi_max * LOG2E_D) : 0.0;
-  const double pij = vj ? exp(fma(-s0, LN2_LO_D, fma(-s0, LN2_HI_D, mod_init[jc]))) : 0.0;
   const int i1 = Lm > 1 ? 1 : 0, i2 = Lm > 2 ? 2 : i1;
   double h[4], mant[4], hsum[4], ea[4], eb[4];
   int ex[4];
   {
-    double e0[4];
+    double a0[4];
+    if (MODE == 0) {
+      // common binary exponent of the initial distribution
+      double mi_max = -INFINITY;
+      for (int k = 0; k < K; ++k) mi_max = fmax(mi_max, mod_init[k]);
+      const double s0 = (mi_max > -1e300 && mi_max < 1e300) ? ceil(mi_max * LOG2E_D) : 0.0;
+      const double pij = vj ? exp(fma(-s0, LN2_LO_D, fma(-s0, LN2_HI_D, mod_init[jc]))) : 0.0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) e0[r] = Eb[L.oE[r]];
+      for (int r = 0; r < 4; ++r) { a0[r] = vj ? pij * Eb[L.oE[r]] : 0.0; h[r] = s0; }
+    } else if (MODE == 1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        a0[r] = vj ? ch.init_vec[(size_t)L.gwc[r] * K + jc] : 0.0;
+        h[r] = ch.init_exp[L.gwc[r]];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { a0[r] = (vj && j == rgrp * 16 + lg + 4 * r) ? 1.0 : 0.0; h[r] = 0.0; }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) ea[r] = (Eb + (size_t)i1 * K)[L.oE[r]];
 #pragma unroll
     for (int r = 0; r < 4; ++r) eb[r] = (Eb + (size_t)i2 * K)[L.oE[r]];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const double a0 = vj ? pij * e0[r] : 0.0;
-      h[r] = s0;
-      if (NW != 4) hb[L.oR[r]] = s0;
-      if (FULL || vj) ab[L.oE[r]] = a0;
-      sh.P[0][lg + 4 * r][j] = a0;
+      if (MODE != 2) {
+        if (NW != 4) hb[L.oR[r]] = h[r];
+        if (FULL || vj) ab[L.oE[r]] = a0[r];
+      }
+      sh.P[0][lg + 4 * r][j] = a0[r];
       mant[r] = 1.0; ex[r] = 0; hsum[r] = 0.0;
     }
-    if (NW == 4) hb[L.oRw] = s0;
+    if (MODE != 2 && NW == 4) hb[L.oRw] = sel4(h, wave);
   }
   __syncthreads();
   // one time step: reads P[CUR], writes P[1-CUR]; er holds Eh_t, refilled with step t+2
@@ -646,16 +684,18 @@ __device__ __forceinline__ void fwd_lin_body(
       const int e2 = __builtin_amdgcn_frexp_exp(tot[r]);
       const double av = ldexp(acc[r] * er[r], -e2);
       sh.P[NXT][lg + 4 * r][j] = av;
-      if (FULL || vj) at[L.oE[r]] = av;
-      // LSE of step t-1: log(tot) + (h_{t-1} + K_{t-1}) ln 2, accumulated as a product
-      const double mm = mant[r] * tot[r];
-      ex[r] += __builtin_amdgcn_frexp_exp(mm);
-      mant[r] = __builtin_amdgcn_frexp_mant(mm);
-      hsum[r] += h[r];
+      if (MODE != 2) {
+        if (FULL || vj) at[L.oE[r]] = av;
+        // LSE of step t-1: log(tot) + (h_{t-1} + K_{t-1}) ln 2, accumulated as a product
+        const double mm = mant[r] * tot[r];
+        ex[r] += __builtin_amdgcn_frexp_exp(mm);
+        mant[r] = __builtin_amdgcn_frexp_mant(mm);
+        hsum[r] += h[r];
+      }
       h[r] += (double)e2;
-      if (NW != 4) ht[L.oR[r]] = h[r];
+      if (MODE != 2 && NW != 4) ht[L.oR[r]] = h[r];
     }
-    if (NW == 4) ht[L.oRw] = sel4(h, wave);
+    if (MODE != 2 && NW == 4) ht[L.oRw] = sel4(h, wave);
 #pragma unroll
     for (int r = 0; r < 4; ++r) er[r] = E2[L.oE[r]];
     __syncthreads();
@@ -668,15 +708,29 @@ __device__ __forceinline__ void fwd_lin_body(
     }
     if (t < Lm) step(t, std::integral_constant<int, 0>{}, ea);
   }
+  const int last = (Lm - 1) & 1;
+  if (MODE == 2) {
+    // the chunk matrix row group: M[i][j] = P[last][i - 16*rgrp][j], and its transpose
+    const int Kp = 16 * NW;
+    double* __restrict__ Mo = ch.Mout + (size_t)chunk * Kp * K;
+    double* __restrict__ Mt = ch.MoutT + (size_t)chunk * Kp * K;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = rgrp * 16 + lg + 4 * r;
+      const double v = sh.P[last][lg + 4 * r][j];
+      if (vj && i < K) { Mo[(size_t)i * K + j] = v; Mt[(size_t)j * K + i] = v; }
+      if (wave == 0 && li == 0 && i < K) ch.Mh[(size_t)chunk * Kp + i] = h[r];
+    }
+    return;
+  }
   // ---- epilogue: K_top = sum_t k_t and sum_t K_t = sum_t (Lm - t) k_t per window (the only
   // place the emission exponents enter), Z = sum_j alpha_{Lm-1}[j], local_lb
   {
-    const int last = (Lm - 1) & 1;
     double* scr = &sh.P[1 - last][0][0];     // free buffer: [0,16) K_top, [16,32) sum_t K_t
     const double* __restrict__ kbw = kexp + wrow;
     for (int w = threadIdx.x >> 4; w < 16; w += 4 * NW) {
       const int gw = L.b0 + w;
-      const unsigned o = (unsigned)((gw < B ? gw : B - 1) - L.b0) * (unsigned)Lm;
+      const unsigned o = (unsigned)((gw < B ? gw : B - 1) - L.b0) * (unsigned)wstride;
       double a = 0.0, c = 0.0;
       for (int t = li; t < Lm; t += 16) {
         const double kv = kbw[o + t];
@@ -693,7 +747,8 @@ __device__ __forceinline__ void fwd_lin_body(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int w = lg + 4 * r;
-        const double Ktop = scr[w], KK = scr[16 + w];
+        const double kb4 = (MODE == 1 && ch.kbefore) ? ch.kbefore[L.gwc[r]] : 0.0;
+        const double Ktop = scr[w] + kb4, KK = scr[16 + w] + kb4 * (double)Lm;
         const double mm = mant[r] * tot[r];
         const int exf = ex[r] + __builtin_amdgcn_frexp_exp(mm);
         const double mf = __builtin_amdgcn_frexp_mant(mm);
@@ -707,13 +762,17 @@ __device__ __forceinline__ void fwd_lin_body(
   }
 }
 
-template <int NW, bool FULL>
+// MODE 0: beta = 1 at the window's last row.  MODE 1 (chain chunks): the window has Lm rows
+// of which the top one is virtual -- it belongs to the next chunk and only supplies Eh and the
+// boundary vector chain.term_vec; nothing is stored for it.
+template <int NW, bool FULL, int MODE>
 __device__ __forceinline__ void bwd_lin_body(
     LinShared<NW>& sh, const double* __restrict__ Eh, const double* __restrict__ AexpT, int B,
-    int Lm, int K, double* __restrict__ bh, double* __restrict__ gx) {
+    int Lm, int wstride, int K, double* __restrict__ bh, double* __restrict__ gx,
+    const LinChain& ch) {
   constexpr int KS = 4 * NW;
   LinLane<NW, FULL> L;
-  L.init(B, Lm, K);
+  L.init(blockIdx.x * 16, B, wstride, K, false);
   const int li = L.li, lg = L.lg, j = L.j, jc = L.jc, wave = L.wave;
   const bool vj = L.vj;
   double Bv[KS];
@@ -722,7 +781,7 @@ __device__ __forceinline__ void bwd_lin_body(
     const int k = 8 * (kk >> 1) + 2 * lg + (kk & 1);
     Bv[kk] = (k < K && vj) ? AexpT[(size_t)k * K + jc] : 0.0;
   }
-  const size_t wrow = (size_t)L.b0 * Lm;
+  const size_t wrow = (size_t)L.b0 * wstride;
   const double* __restrict__ Eb = Eh + wrow * K;
   double* __restrict__ bb = bh + wrow * K;
   double* __restrict__ gb = gx + wrow;
@@ -730,7 +789,7 @@ __device__ __forceinline__ void bwd_lin_body(
   const int i1 = Lm > 1 ? top - 1 : top, i2 = Lm > 2 ? top - 2 : i1;
   double g[4], ea[4], eb[4];
   {
-    double e0[4];
+    double e0[4], b0v[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) e0[r] = (Eb + (size_t)top * K)[L.oE[r]];
 #pragma unroll
@@ -739,12 +798,18 @@ __device__ __forceinline__ void bwd_lin_body(
     for (int r = 0; r < 4; ++r) eb[r] = (Eb + (size_t)i2 * K)[L.oE[r]];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      g[r] = 0.0;
-      if (NW != 4) (gb + top)[L.oR[r]] = 0.0;
-      if (FULL || vj) (bb + (size_t)top * K)[L.oE[r]] = 1.0;
-      sh.P[0][lg + 4 * r][j] = vj ? e0[r] : 0.0;
+      if (MODE == 1) {
+        b0v[r] = vj ? ch.term_vec[(size_t)L.gwc[r] * K + jc] : 0.0;
+        g[r] = ch.term_exp[L.gwc[r]];
+      } else {
+        b0v[r] = 1.0;
+        g[r] = 0.0;
+        if (NW != 4) (gb + top)[L.oR[r]] = 0.0;
+        if (FULL || vj) (bb + (size_t)top * K)[L.oE[r]] = 1.0;
+      }
+      sh.P[0][lg + 4 * r][j] = vj ? e0[r] * b0v[r] : 0.0;
     }
-    if (NW == 4) (gb + top)[L.oRw] = 0.0;
+    if (MODE != 1 && NW == 4) (gb + top)[L.oRw] = 0.0;
   }
   __syncthreads();
   // one step: bh of row t from P[CUR] = Eh_{t+1} * bh_{t+1}; er holds Eh_t
@@ -780,19 +845,174 @@ __device__ __forceinline__ void bwd_lin_body(
   }
 }
 
-// grid (ceil(B/16), 2): blockIdx.y = 0 forward, 1 backward
-template <int NW, bool FULL>
+// grid (ceil(B/16), 2): blockIdx.y = 0 forward, 1 backward.  MODE 1: interior chain chunks,
+// forward windows have Lm - 1 rows (the top row is the next chunk's), backward ones Lm with a
+// virtual top row.  MODE 3: the chain's last chunk (boundary initial vector, ordinary end).
+// MODE 2: grid (chunks * NW, 1), forward only (chunk matrices).
+template <int NW, bool FULL, int MODE>
 __global__ __launch_bounds__(64 * NW) void k_sweeps_lin(
     const double* __restrict__ Eh, const double* __restrict__ kexp,
     const double* __restrict__ Aexp, const double* __restrict__ AexpT,
-    const double* __restrict__ mod_init, int B, int Lm, int K, double* __restrict__ ah,
-    double* __restrict__ bh, double* __restrict__ hx, double* __restrict__ gx,
-    double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac) {
+    const double* __restrict__ mod_init, int B, int Lm, int wstride, int K,
+    double* __restrict__ ah, double* __restrict__ bh, double* __restrict__ hx,
+    double* __restrict__ gx, double* __restrict__ local_lb, double* __restrict__ logz,
+    double2* __restrict__ zfac, LinChain ch) {
   __shared__ LinShared<NW> sh;
   if (blockIdx.y == 0)
-    fwd_lin_body<NW, FULL>(sh, Eh, kexp, Aexp, mod_init, B, Lm, K, ah, hx, local_lb, logz, zfac);
+    fwd_lin_body<NW, FULL, (MODE == 3 ? 1 : MODE)>(sh, Eh, kexp, Aexp, mod_init, B,
+                                                   MODE == 1 ? Lm - 1 : Lm, wstride, K, ah, hx,
+                                                   local_lb, logz, zfac, ch);
   else
-    bwd_lin_body<NW, FULL>(sh, Eh, AexpT, B, Lm, K, bh, gx);
+    bwd_lin_body<NW, FULL, (MODE == 1 ? 1 : 0)>(sh, Eh, AexpT, B, Lm, wstride, K, bh, gx, ch);
+}
+
+// S2 of the chain scan: boundary vectors.  grid 2 (0: alpha at chunk starts, 1: beta at chunk
+// ends), one wavefront each, lane = state.  Chunk c spans rows [c*L, (c+1)*L] (the last one up
+// to T-1); bnd row b of the outputs belongs to chain row min(b*L, T-1).
+//   forward:  a_{c+1} = a_c M_c          a_0 = pi * Eh_0
+//   backward: b_c = M_c b_{c+1}          b_C = 1
+// with M_c[i][j] = Mm[c][i][j] * 2^Mh[c][i]; vectors renormalised to sum in [1/2, 1) with their
+// own binary exponent.  Also: kbefore[c] = sum of kexp over rows < c*L, and Z / logZ.
+// The dependent chain per chunk is kept short: the row exponents / their maximum are taken
+// one chunk ahead, four partial accumulators, DPP + readlane reductions (no LDS), and the
+// renormalisation exponent comes from the PREVIOUS vector's sum (any integer keeps the
+// bookkeeping exact; the sum only has to stay in range), so no reduction sits between two
+// mat-vecs.
+// Workgroup = 4 waves.  Wave 0 runs the chain; waves 1..3 stream the chunk matrices from HBM
+// into a 4-slot LDS ring three chunks ahead (each helper owns every third chunk: it issues
+// the loads on its turn and writes them to LDS two iterations later), so the HBM latency of
+// a 32 KB matrix is off the sequential path.  One barrier per chunk.
+template <int KMAX>
+__device__ __forceinline__ double scan_matvec(const double* __restrict__ ms, int K, int lane, double w) {
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+  for (int i = 0; i < KMAX; i += 4) {
+    a0 = fma(readlane_f64(w, i), ms[(i) * 64 + lane], a0);
+    a1 = fma(readlane_f64(w, i + 1), ms[(i + 1) * 64 + lane], a1);
+    a2 = fma(readlane_f64(w, i + 2), ms[(i + 2) * 64 + lane], a2);
+    a3 = fma(readlane_f64(w, i + 3), ms[(i + 3) * 64 + lane], a3);
+  }
+  return (a0 + a1) + (a2 + a3);
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void k_chunk_scan(
+    const double* __restrict__ Mm, const double* __restrict__ MmT, const double* __restrict__ Mh,
+    int C, int Kp, int K, const double* __restrict__ Eh, const double* __restrict__ ksum,
+    const double* __restrict__ mod_init, double* __restrict__ abnd, double* __restrict__ aexp,
+    double* __restrict__ bbnd, double* __restrict__ bexp, double* __restrict__ kbefore,
+    double2* __restrict__ zfac, double* __restrict__ logz) {
+  extern __shared__ double ring[];            // [4][KMAX][64]
+  constexpr int SLOT = KMAX * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool vl = lane < K;
+  const int lc = vl ? lane : 0;
+  const size_t MS = (size_t)Kp * K;
+  const bool fwd = blockIdx.x == 0;
+  const double* __restrict__ Msrc = fwd ? Mm : MmT;
+  // position p = 0..C-1 in processing order -> chunk index
+  auto chunk_of = [&](int p) { return fwd ? p : C - 1 - p; };
+  // helper: load chunk at position p into registers / write registers to its ring slot
+  double hr[KMAX];
+  auto h_load = [&](int p) {
+    const double* __restrict__ M = Msrc + (size_t)chunk_of(p < C ? p : C - 1) * MS;
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i) hr[i] = M[(size_t)(i < K ? i : K - 1) * K + lc];
+  };
+  auto h_store = [&](int p) {
+    double* __restrict__ dst = ring + (p & 3) * SLOT;
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i) dst[i * 64 + lane] = hr[i];
+  };
+  // prologue: helper h brings in position h-1 (slots 0..2)
+  if (wave >= 1) { h_load(wave - 1); h_store(wave - 1); }
+  double a = 0.0, Hx = 0.0, mh = 0.0, hmax = 0.0;
+  int e_lag = 0;
+  if (wave == 0) {
+    if (fwd) {
+      double mi_max = -INFINITY;
+      for (int k = 0; k < K; ++k) mi_max = fmax(mi_max, mod_init[k]);
+      const double s0 = (mi_max > -1e300 && mi_max < 1e300) ? ceil(mi_max * LOG2E_D) : 0.0;
+      a = vl ? exp(fma(-s0, LN2_LO_D, fma(-s0, LN2_HI_D, mod_init[lc]))) * Eh[lc] : 0.0;
+      Hx = s0;
+      if (vl) abnd[lane] = a;
+      if (lane == 0) aexp[0] = Hx;
+      mh = vl ? Mh[lane] : -INFINITY;
+      hmax = wave_max_dpp(mh);
+    } else {
+      a = vl ? 1.0 : 0.0;
+      if (vl) bbnd[(size_t)C * K + lane] = a;
+      if (lane == 0) bexp[C] = 0.0;
+    }
+    e_lag = __builtin_amdgcn_frexp_exp(wave_sum_dpp(a));
+  }
+  // helper turn bookkeeping: helper h loads positions p = h-1+3, h-1+6, ... ; the load for
+  // position p is issued at iteration p-3 and written at iteration p-1
+  if (wave >= 1) h_load(wave - 1 + 3);
+  __syncthreads();
+  for (int p = 0; p < C; ++p) {
+    if (wave == 0) {
+      const double* __restrict__ ms = ring + (p & 3) * SLOT;
+      const int c = chunk_of(p);
+      if (fwd) {
+        // a <- a M_c
+        const double w = vl ? ldexp(a, (int)(mh - hmax) - e_lag) : 0.0;
+        const double acc = scan_matvec<KMAX>(ms, K, lane, w);
+        Hx += hmax + (double)e_lag;
+        a = vl ? acc : 0.0;
+        if (vl) abnd[(size_t)(c + 1) * K + lane] = a;
+        if (lane == 0) aexp[c + 1] = Hx;
+        e_lag = __builtin_amdgcn_frexp_exp(wave_sum_dpp(a));
+        mh = vl ? Mh[(size_t)(c + 1 < C ? c + 1 : c) * Kp + lane] : -INFINITY;
+        hmax = wave_max_dpp(mh);
+      } else {
+        // b <- M_c b = 2^Mh[i] * sum_j M[i][j] b[j]  (rows of the transposed copy)
+        const double w = vl ? ldexp(a, -e_lag) : 0.0;
+        const double acc = scan_matvec<KMAX>(ms, K, lane, w);
+        const double mhc = vl ? Mh[(size_t)c * Kp + lane] : -INFINITY;
+        const double hm = wave_max_dpp(mhc);
+        a = vl ? ldexp(acc, (int)(mhc - hm)) : 0.0;
+        Hx += hm + (double)e_lag;
+        if (vl) bbnd[(size_t)c * K + lane] = a;
+        if (lane == 0) bexp[c] = Hx;
+        e_lag = __builtin_amdgcn_frexp_exp(wave_sum_dpp(a));
+      }
+    } else {
+      // position q = p + 2 is written now by its owner (slot (p+2)&3 was freed at iteration
+      // p - 2), then the owner issues the loads of q + 3
+      const int q = p + 2;
+      if ((q % 3) == wave - 1 && q >= 3) {
+        if (q < C) h_store(q);
+        h_load(q + 3);
+      }
+    }
+    __syncthreads();
+  }
+  if (wave == 0 && fwd) {
+    // emission exponents before each chunk (prefix sums of the per-chunk sums)
+    double kb = 0.0;
+    if (lane == 0)
+      for (int cc = 0; cc < C; ++cc) { kbefore[cc] = kb; kb += ksum[cc]; }
+    kb = readlane_f64(kb, 0);
+    const double tot = wave_sum_dpp(vl ? a : 0.0);   // a is alpha at the last row: Z
+    if (lane == 0) {
+      const double zm = __builtin_amdgcn_frexp_mant(tot);
+      const double zexp = (double)__builtin_amdgcn_frexp_exp(tot);
+      zfac[0] = make_double2(1.0 / zm, Hx + zexp);
+      logz[0] = log(zm) + (Hx + zexp + kb) * LN2_D;
+    }
+  }
+}
+
+// sum of the emission row exponents of each chunk's own rows [c*Lc, (c+1)*Lc) (last: up to T)
+__global__ __launch_bounds__(64) void k_chunk_ksum(const double* __restrict__ kexp, int C, int Lc,
+                                                  int64_t T, double* __restrict__ ksum) {
+  const int c = blockIdx.x;
+  const int64_t r0 = (int64_t)c * Lc, r1 = (c == C - 1) ? T : r0 + Lc;
+  double ks = 0.0;
+  for (int64_t r = r0 + threadIdx.x; r < r1; r += 64) ks += kexp[r];
+  ks = wave_sum_dpp(ks);
+  if (threadIdx.x == 0) ksum[c] = ks;
 }
 
 // posterior marginals from the scaled messages (API reads of var_x; the statistics GEMM

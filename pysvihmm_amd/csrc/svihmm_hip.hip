@@ -117,7 +117,7 @@ struct svihmm_ctx {
   Buf starts, ll, la, lb, q, lse_part, local_lb, logz, part, packed, scratch;
   // scaled linear-domain sweeps: per-row binary exponents, (na, k) records, 1/Z factors,
   // Eh of host-supplied lliks; log-domain intermediates materialised on demand (m_*)
-  Buf kexp, hx, gx, zfac, llE, m_ll, m_la, m_lb;
+  Buf kexp, hx, gx, zfac, llE, m_ll, m_la, m_lb, chain, chain2;
   bool lin_mode = false;           // ll/la/lb hold Eh / ah / bh of the last sweep (not logs)
   bool q_valid = false;            // lin_mode: var_x has been formed from ah, bh (k_lin_posterior)
   bool lin_stale = false;          // parameters changed since: logs can no longer be rebuilt
@@ -214,7 +214,7 @@ int svihmm_destroy(svihmm_ctx* h) {
   Buf* bufs[] = {&h->obs, &h->mask, &h->mod_init, &h->ltran, &h->Aexp, &h->AexpT, &h->theta, &h->niw,
                  &h->fab, &h->starts, &h->ll, &h->la, &h->lb, &h->q, &h->lse_part,
                  &h->local_lb, &h->logz, &h->part, &h->packed, &h->scratch, &h->kexp, &h->hx, &h->gx,
-                 &h->zfac, &h->llE, &h->m_ll, &h->m_la, &h->m_lb};
+                 &h->zfac, &h->llE, &h->m_ll, &h->m_la, &h->m_lb, &h->chain, &h->chain2};
   for (Buf* b : bufs) release(*b);
   for (int i = 0; i < 2; ++i) {
     if (h->ev_em[i]) hipEventDestroy(h->ev_em[i]);
@@ -645,9 +645,11 @@ static int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_
   double* llb = (double*)h->local_lb.p + b0;
   double* lz = (double*)h->logz.p + b0;
   ProfScope ps(h, KS_FB, stream);
-#define SWP(NWV, F) hipLaunchKernelGGL((k_sweeps_lin<NWV, F>), grid, dim3(64 * NWV), 0, stream, Eh, kx, \
-                                       (const double*)h->Aexp.p, (const double*)h->AexpT.p,             \
-                                       (const double*)h->mod_init.p, nb, Lm, K, ah, bh, hx, gx, llb, lz, zf)
+  const LinChain none = {};
+#define SWP(NWV, F) hipLaunchKernelGGL((k_sweeps_lin<NWV, F, 0>), grid, dim3(64 * NWV), 0, stream, Eh, kx, \
+                                       (const double*)h->Aexp.p, (const double*)h->AexpT.p,                \
+                                       (const double*)h->mod_init.p, nb, Lm, Lm, K, ah, bh, hx, gx, llb,   \
+                                       lz, zf, none)
   if (NW == 1) { if (full) SWP(1, true); else SWP(1, false); }
   else if (NW == 2) { if (full) SWP(2, true); else SWP(2, false); }
   else if (NW == 3) { if (full) SWP(3, true); else SWP(3, false); }
@@ -679,8 +681,113 @@ static int launch_sum_lb(svihmm_ctx* h, int B, hipStream_t stream) {
   HIPCK(hipGetLastError());
   return 0;
 }
+// One long window (B = 1, the full-chain E-step) as an exact blocked scan over chunks of
+// CHAIN_L steps: chunk matrices (S1), boundary vectors (S2), all chunks as concurrent windows
+// with boundary conditions (S3).  See the comment above LinChain in kernels_recursion.h.
+// chunk length: 256 steps give the most concurrent windows in S3; very long chains use 1024 so
+// that the sequential boundary scan (S2) stays short (S1's work does not depend on it)
+static int chain_len(int Lm) { return Lm >= 512 * 1024 ? 1024 : 256; }
+static bool use_chain(const svihmm_ctx* h, int B, int Lm) {
+  return B == 1 && h->K <= 64 && Lm >= 2048 && h->variant[6] != 1;
+}
+static int launch_fb_chain(svihmm_ctx* h, int Lm, bool total) {
+  const int K = h->K, T = Lm, L = chain_len(Lm);
+  const int NW = (K + 15) / 16, Kp = 16 * NW;
+  const bool full = (K == Kp);
+  const int Cfull = (T - 2) / L;            // interior chunks; the tail chunk has 1..L steps
+  const int C = Cfull + 1;
+  const int ltail = T - 1 - Cfull * L;      // steps of the tail chunk (rows Cfull*L .. T-1)
+  CK(ensure_fb_lin(h, 1, Lm));
+  // chunk matrices + transposes + row exponents | boundary vectors and exponents | per-chunk scalars
+  const size_t nM = (size_t)C * Kp * K;
+  CK(ensure(h->chain, (2 * nM + (size_t)C * Kp + 2 * (size_t)(C + 1) * K + 7 * (size_t)(C + 1) + 8) * sizeof(double)));
+  double* Mm = (double*)h->chain.p;
+  double* MmT = Mm + nM;
+  double* Mh = MmT + nM;
+  double* abnd = Mh + (size_t)C * Kp;
+  double* bbnd = abnd + (size_t)(C + 1) * K;
+  double* aexp = bbnd + (size_t)(C + 1) * K;
+  double* bexp = aexp + (C + 1);
+  double* kbef = bexp + (C + 1);
+  double* lbw = kbef + (C + 1);             // per-chunk local_lb
+  double* lzw = lbw + (C + 1);              // scratch logz of the S3 windows
+  double* ksum = lzw + (C + 1);             // per-chunk sums of the emission row exponents
+  CK(ensure(h->chain2, (size_t)(C + 1) * sizeof(double2)));
+  double2* zfw = (double2*)h->chain2.p;     // scratch zfac of the S3 windows (the global one comes from S2)
+  const double* Eh = (const double*)(h->last_host_ll ? h->llE.p : h->ll.p);
+  const double* kx = (const double*)h->kexp.p;
+  double* ah = (double*)h->la.p; double* bh = (double*)h->lb.p;
+  double* hx = (double*)h->hx.p; double* gx = (double*)h->gx.p;
+  const double* A = (const double*)h->Aexp.p; const double* At = (const double*)h->AexpT.p;
+  const double* mi = (const double*)h->mod_init.p;
+  hipStream_t st = h->stream;
+  ProfScope ps(h, KS_FB, st);
+#define SWPM(NWV, F, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH)                       \
+  hipLaunchKernelGGL((k_sweeps_lin<NWV, F, MD>), GRID, dim3(64 * NWV), 0, st, EHP, KXP, A, At, mi, BB, LL, \
+                     WS, K, AH, BH, HX, GX, LB, LZ, ZF, CH)
+#define SWPD(MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH)                                \
+  do {                                                                                                      \
+    if (NW == 1) { if (full) SWPM(1, true, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH); \
+                   else SWPM(1, false, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH); }   \
+    else if (NW == 2) { if (full) SWPM(2, true, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH); \
+                        else SWPM(2, false, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH); } \
+    else if (NW == 3) { if (full) SWPM(3, true, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH); \
+                        else SWPM(3, false, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH); } \
+    else { if (full) SWPM(4, true, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH);         \
+           else SWPM(4, false, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH); }           \
+  } while (0)
+  LinChain ch = {};
+  ch.Mout = Mm; ch.MoutT = MmT; ch.Mh = Mh;
+  // S1: chunk matrices.  Interior chunks: L steps (rows c*L .. c*L+L); tail: ltail steps.
+  if (Cfull > 0)
+    SWPD(2, dim3((unsigned)(Cfull * NW), 1), Cfull, L + 1, L, Eh, kx, ah, bh, hx, gx, lbw, lzw, zfw, ch);
+  {
+    LinChain ct = ch;
+    ct.Mout = Mm + (size_t)Cfull * Kp * K; ct.MoutT = MmT + (size_t)Cfull * Kp * K; ct.Mh = Mh + (size_t)Cfull * Kp;
+    const size_t ro = (size_t)Cfull * L;
+    SWPD(2, dim3((unsigned)NW, 1), 1, ltail + 1, L, Eh + ro * K, kx + ro, ah, bh, hx, gx, lbw, lzw, zfw, ct);
+  }
+  // S2: boundary vectors, Z
+  hipLaunchKernelGGL(k_chunk_ksum, dim3(C), dim3(64), 0, st, kx, C, L, (int64_t)T, ksum);
+#define SCAN(KM)                                                                                                   \
+  do {                                                                                                             \
+    const size_t lds = (size_t)4 * KM * 64 * sizeof(double);                                                       \
+    if (lds > 64 * 1024)                                                                                           \
+      hipFuncSetAttribute((const void*)k_chunk_scan<KM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
+    hipLaunchKernelGGL(k_chunk_scan<KM>, dim3(2), dim3(256), lds, st, (const double*)Mm, (const double*)MmT,       \
+                       (const double*)Mh, C, Kp, K, Eh, (const double*)ksum, mi, abnd, aexp, bbnd, bexp, kbef,     \
+                       (double2*)h->zfac.p, (double*)h->logz.p);                                                   \
+  } while (0)
+  if (K <= 16) SCAN(16); else if (K <= 32) SCAN(32); else SCAN(64);
+#undef SCAN
+  // S3: every chunk as a window with boundary conditions
+  ch.init_vec = abnd; ch.init_exp = aexp; ch.kbefore = kbef;
+  ch.term_vec = bbnd + K; ch.term_exp = bexp + 1;       // window c ends at boundary c + 1
+  if (Cfull > 0)
+    SWPD(1, dim3((unsigned)((Cfull + 15) / 16), 2), Cfull, L + 1, L, Eh, kx, ah, bh, hx, gx, lbw, lzw, zfw, ch);
+  {
+    LinChain ct = ch;
+    ct.init_vec = abnd + (size_t)Cfull * K; ct.init_exp = aexp + Cfull; ct.kbefore = kbef + Cfull;
+    const size_t ro = (size_t)Cfull * L;
+    SWPD(3, dim3(1, 2), 1, ltail + 1, L, Eh + ro * K, kx + ro, ah + ro * K, bh + ro * K, hx + ro, gx + ro,
+         lbw + Cfull, lzw + Cfull, zfw + Cfull, ct);
+  }
+#undef SWPD
+#undef SWPM
+  HIPCK(hipGetLastError());
+  // local_lb[0] = sum of the chunks' parts (fixed order)
+  hipLaunchKernelGGL(k_sum_lb, dim3(1), dim3(256), 0, st, (const double*)lbw, C, (double*)h->local_lb.p);
+  if (total) {
+    double* lbtot = (double*)h->packed.p + (svihmm_packed_size(K, h->D) - 1);
+    hipLaunchKernelGGL(k_sum_lb, dim3(1), dim3(256), 0, st, (const double*)lbw, C, lbtot);
+  }
+  HIPCK(hipGetLastError());
+  return 0;
+}
+
 static int launch_fb_lin(svihmm_ctx* h, int B, int Lm, bool total) {
   if (!h->have_globals) return fail("no globals: call svihmm_set_globals");
+  if (use_chain(h, B, Lm)) return launch_fb_chain(h, Lm, total);
   CK(ensure_fb_lin(h, B, Lm));
   CK(launch_fb_lin_range(h, 0, B, Lm, h->stream));
   if (total) CK(launch_sum_lb(h, B, h->stream));
@@ -694,8 +801,9 @@ static int pick_fb(const svihmm_ctx* h, int B, int Lm, bool want_logs) {
   int var = h->variant[2];
   if (h->K > 64) return 1;
   if (var == 0) var = (B >= 192) ? (want_logs ? 2 : 3) : 1;
+  if (h->variant[2] == 0 && !want_logs && use_chain(h, B, Lm)) var = 3;   // long single chain: blocked scan
   // the scaled sweeps address a workgroup's 16 windows with 32-bit byte offsets
-  if (var == 3 && (size_t)16 * Lm * h->K * sizeof(double) >= ((size_t)1 << 32)) var = 2;
+  if (var == 3 && !use_chain(h, B, Lm) && (size_t)16 * Lm * h->K * sizeof(double) >= ((size_t)1 << 32)) var = 2;
   return var;
 }
 
