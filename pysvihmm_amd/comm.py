@@ -79,10 +79,13 @@ def file_uid_exchange(rank, tag=None, timeout=300.0, directory=None):
         t0 = time.time()
         while True:
             try:
-                with open(path, "rb") as f:
-                    data = f.read()
-                if len(data) == 128:
-                    return data
+                # a file left behind by a crashed earlier job with the same tag is older than
+                # this job's workers (which all start within seconds of each other)
+                if os.path.getmtime(path) >= t0 - 120.0:
+                    with open(path, "rb") as f:
+                        data = f.read()
+                    if len(data) == 128:
+                        return data
             except OSError:
                 pass
             if time.time() - t0 > timeout:
