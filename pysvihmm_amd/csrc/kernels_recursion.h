@@ -553,6 +553,41 @@ __device__ __forceinline__ double4_t lin_rowsum(const LinShared<NW>& sh, int cur
   return __builtin_amdgcn_mfma_f64_16x16x4f64(s, 1.0, z, 0, 0, 0);
 }
 
+// K > 64: the B operand (the transition matrix tile of this wave, K x 16 doubles) no longer
+// fits the register budget of 16 waves per workgroup, so it is streamed from L2 every step
+// (A + jc points at column jc; rows beyond K are clamped -- their P entries are zero).
+template <int NW, bool FULL>
+__device__ __forceinline__ void lin_matmul_stream(const LinShared<NW>& sh, int cur, int li, int lg,
+                                                  const double* __restrict__ Bcol, int K,
+                                                  double4_t& acc, double4_t& tot) {
+  // 16 waves per workgroup leave 128 VGPRs per wave: deeper explicit prefetch of the B values
+  // (register sets of 8, two or three deep) spills and is slower than this plain form, in
+  // which the other three waves of the SIMD cover the L2 latency.
+  constexpr int KS = 4 * NW;
+  double4_t a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+  const double* prow = &sh.P[cur][li][2 * lg];
+  double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+  for (int c = 0; c < KS / 2; c += 2) {
+    const int k0 = 8 * c + 2 * lg, k2 = 8 * (c + 1) + 2 * lg;
+    const int r0 = FULL ? k0 : min(k0, K - 1), r1 = FULL ? k0 + 1 : min(k0 + 1, K - 1);
+    const int r2 = FULL ? k2 : min(k2, K - 1), r3 = FULL ? k2 + 1 : min(k2 + 1, K - 1);
+    const double b0 = Bcol[(size_t)r0 * K], b1 = Bcol[(size_t)r1 * K];
+    const double b2 = Bcol[(size_t)r2 * K], b3 = Bcol[(size_t)r3 * K];
+    const double2 x = *reinterpret_cast<const double2*>(prow + 8 * c);
+    const double2 y = *reinterpret_cast<const double2*>(prow + 8 * (c + 1));
+    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, b0, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, b1, a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(y.x, b2, a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(y.y, b3, a3, 0, 0, 0);
+    s0 = (c == 0) ? x.x + y.x : s0 + (x.x + y.x);
+    s1 = (c == 0) ? x.y + y.y : s1 + (x.y + y.y);
+  }
+  const double4_t z = {0, 0, 0, 0};
+  tot = __builtin_amdgcn_mfma_f64_16x16x4f64(s0 + s1, 1.0, z, 0, 0, 0);
+  acc = (a0 + a1) + (a2 + a3);
+}
+
 // per-lane state shared by both directions.  Windows of a launch start `wstride` rows apart
 // (normal batches: wstride = Lm; chain chunks overlap their terminal row: wstride = Lm - 1).
 template <int NW, bool FULL>
@@ -608,7 +643,7 @@ struct LinChain {
 // MODE 0: windows start from the initial distribution.  MODE 1: from chain.init_vec.
 // MODE 2: chunk matrices (unit initial vectors, all pseudo-windows read the chunk's rows,
 // nothing but the final matrix is stored; blockIdx.x = chunk * NW + row group).
-template <int NW, bool FULL, int MODE>
+template <int NW, bool FULL, int MODE, bool BS = false>
 __device__ __forceinline__ void fwd_lin_body(
     LinShared<NW>& sh, const double* __restrict__ Eh, const double* __restrict__ kexp,
     const double* __restrict__ Aexp, const double* __restrict__ mod_init, int B, int Lm,
@@ -621,12 +656,15 @@ __device__ __forceinline__ void fwd_lin_body(
   L.init(MODE == 2 ? chunk : blockIdx.x * 16, MODE == 2 ? chunk + 1 : B, wstride, K, MODE == 2);
   const int li = L.li, lg = L.lg, j = L.j, jc = L.jc, wave = L.wave;
   const bool vj = L.vj;
-  double Bv[KS];
+  double Bv[BS ? 1 : KS];
+  if (!BS) {
 #pragma unroll
-  for (int kk = 0; kk < KS; ++kk) {
-    const int k = 8 * (kk >> 1) + 2 * lg + (kk & 1);
-    Bv[kk] = (k < K && vj) ? Aexp[(size_t)k * K + jc] : 0.0;
+    for (int kk = 0; kk < KS; ++kk) {
+      const int k = 8 * (kk >> 1) + 2 * lg + (kk & 1);
+      Bv[BS ? 0 : kk] = (k < K && vj) ? Aexp[(size_t)k * K + jc] : 0.0;
+    }
   }
+  const double* __restrict__ Bcol = Aexp + jc;
   const size_t wrow = (size_t)L.b0 * wstride;
   const double* __restrict__ Eb = Eh + wrow * K;
   double* __restrict__ ab = ah + wrow * K;
@@ -661,13 +699,13 @@ __device__ __forceinline__ void fwd_lin_body(
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       if (MODE != 2) {
-        if (NW != 4) hb[L.oR[r]] = h[r];
+        if (NW % 4 != 0) hb[L.oR[r]] = h[r];
         if (FULL || vj) ab[L.oE[r]] = a0[r];
       }
       sh.P[0][lg + 4 * r][j] = a0[r];
       mant[r] = 1.0; ex[r] = 0; hsum[r] = 0.0;
     }
-    if (MODE != 2 && NW == 4) hb[L.oRw] = sel4(h, wave);
+    if (MODE != 2 && NW % 4 == 0) hb[L.oRw] = sel4(h, wave & 3);
   }
   __syncthreads();
   // one time step: reads P[CUR], writes P[1-CUR]; er holds Eh_t, refilled with step t+2
@@ -675,14 +713,16 @@ __device__ __forceinline__ void fwd_lin_body(
     constexpr int CUR = decltype(curc)::value, NXT = 1 - CUR;
     const int t2 = t + 2 < Lm ? t + 2 : Lm - 1;
     double4_t acc, tot;
-    lin_matmul<NW>(sh, CUR, li, lg, Bv, acc, tot);
+    if constexpr (BS) lin_matmul_stream<NW, FULL>(sh, CUR, li, lg, Bcol, K, acc, tot);
+    else lin_matmul<NW>(sh, CUR, li, lg, Bv, acc, tot);
     double* __restrict__ at = ab + (size_t)t * K;
     double* __restrict__ ht = hb + t;
     const double* __restrict__ E2 = Eb + (size_t)t2 * K;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int e2 = __builtin_amdgcn_frexp_exp(tot[r]);
-      const double av = ldexp(acc[r] * er[r], -e2);
+      double av = ldexp(acc[r] * er[r], -e2);
+      if (BS && !FULL) av = vj ? av : 0.0;   // streamed B has no zero columns for padded states
       sh.P[NXT][lg + 4 * r][j] = av;
       if (MODE != 2) {
         if (FULL || vj) at[L.oE[r]] = av;
@@ -693,9 +733,9 @@ __device__ __forceinline__ void fwd_lin_body(
         hsum[r] += h[r];
       }
       h[r] += (double)e2;
-      if (MODE != 2 && NW != 4) ht[L.oR[r]] = h[r];
+      if (MODE != 2 && NW % 4 != 0) ht[L.oR[r]] = h[r];
     }
-    if (MODE != 2 && NW == 4) ht[L.oRw] = sel4(h, wave);
+    if (MODE != 2 && NW % 4 == 0) ht[L.oRw] = sel4(h, wave & 3);
 #pragma unroll
     for (int r = 0; r < 4; ++r) er[r] = E2[L.oE[r]];
     __syncthreads();
@@ -765,7 +805,7 @@ __device__ __forceinline__ void fwd_lin_body(
 // MODE 0: beta = 1 at the window's last row.  MODE 1 (chain chunks): the window has Lm rows
 // of which the top one is virtual -- it belongs to the next chunk and only supplies Eh and the
 // boundary vector chain.term_vec; nothing is stored for it.
-template <int NW, bool FULL, int MODE>
+template <int NW, bool FULL, int MODE, bool BS = false>
 __device__ __forceinline__ void bwd_lin_body(
     LinShared<NW>& sh, const double* __restrict__ Eh, const double* __restrict__ AexpT, int B,
     int Lm, int wstride, int K, double* __restrict__ bh, double* __restrict__ gx,
@@ -775,12 +815,15 @@ __device__ __forceinline__ void bwd_lin_body(
   L.init(blockIdx.x * 16, B, wstride, K, false);
   const int li = L.li, lg = L.lg, j = L.j, jc = L.jc, wave = L.wave;
   const bool vj = L.vj;
-  double Bv[KS];
+  double Bv[BS ? 1 : KS];
+  if (!BS) {
 #pragma unroll
-  for (int kk = 0; kk < KS; ++kk) {
-    const int k = 8 * (kk >> 1) + 2 * lg + (kk & 1);
-    Bv[kk] = (k < K && vj) ? AexpT[(size_t)k * K + jc] : 0.0;
+    for (int kk = 0; kk < KS; ++kk) {
+      const int k = 8 * (kk >> 1) + 2 * lg + (kk & 1);
+      Bv[BS ? 0 : kk] = (k < K && vj) ? AexpT[(size_t)k * K + jc] : 0.0;
+    }
   }
+  const double* __restrict__ Bcol = AexpT + jc;
   const size_t wrow = (size_t)L.b0 * wstride;
   const double* __restrict__ Eb = Eh + wrow * K;
   double* __restrict__ bb = bh + wrow * K;
@@ -804,12 +847,12 @@ __device__ __forceinline__ void bwd_lin_body(
       } else {
         b0v[r] = 1.0;
         g[r] = 0.0;
-        if (NW != 4) (gb + top)[L.oR[r]] = 0.0;
+        if (NW % 4 != 0) (gb + top)[L.oR[r]] = 0.0;
         if (FULL || vj) (bb + (size_t)top * K)[L.oE[r]] = 1.0;
       }
       sh.P[0][lg + 4 * r][j] = vj ? e0[r] * b0v[r] : 0.0;
     }
-    if (MODE != 1 && NW == 4) (gb + top)[L.oRw] = 0.0;
+    if (MODE != 1 && NW % 4 == 0) (gb + top)[L.oRw] = 0.0;
   }
   __syncthreads();
   // one step: bh of row t from P[CUR] = Eh_{t+1} * bh_{t+1}; er holds Eh_t
@@ -817,20 +860,22 @@ __device__ __forceinline__ void bwd_lin_body(
     constexpr int CUR = decltype(curc)::value, NXT = 1 - CUR;
     const int t2 = t >= 2 ? t - 2 : 0;
     double4_t acc, tot;
-    lin_matmul<NW>(sh, CUR, li, lg, Bv, acc, tot);
+    if constexpr (BS) lin_matmul_stream<NW, FULL>(sh, CUR, li, lg, Bcol, K, acc, tot);
+    else lin_matmul<NW>(sh, CUR, li, lg, Bv, acc, tot);
     double* __restrict__ bt = bb + (size_t)t * K;
     double* __restrict__ gt = gb + t;
     const double* __restrict__ E2 = Eb + (size_t)t2 * K;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int e2 = __builtin_amdgcn_frexp_exp(tot[r]);
-      const double bv = ldexp(acc[r], -e2);
+      double bv = ldexp(acc[r], -e2);
+      if (BS && !FULL) bv = vj ? bv : 0.0;
       sh.P[NXT][lg + 4 * r][j] = er[r] * bv;
       if (FULL || vj) bt[L.oE[r]] = bv;
       g[r] += (double)e2;
-      if (NW != 4) gt[L.oR[r]] = g[r];
+      if (NW % 4 != 0) gt[L.oR[r]] = g[r];
     }
-    if (NW == 4) gt[L.oRw] = sel4(g, wave);
+    if (NW % 4 == 0) gt[L.oRw] = sel4(g, wave & 3);
 #pragma unroll
     for (int r = 0; r < 4; ++r) er[r] = E2[L.oE[r]];
     __syncthreads();
@@ -849,7 +894,7 @@ __device__ __forceinline__ void bwd_lin_body(
 // forward windows have Lm - 1 rows (the top row is the next chunk's), backward ones Lm with a
 // virtual top row.  MODE 3: the chain's last chunk (boundary initial vector, ordinary end).
 // MODE 2: grid (chunks * NW, 1), forward only (chunk matrices).
-template <int NW, bool FULL, int MODE>
+template <int NW, bool FULL, int MODE, bool BS = false>
 __global__ __launch_bounds__(64 * NW) void k_sweeps_lin(
     const double* __restrict__ Eh, const double* __restrict__ kexp,
     const double* __restrict__ Aexp, const double* __restrict__ AexpT,
@@ -857,13 +902,14 @@ __global__ __launch_bounds__(64 * NW) void k_sweeps_lin(
     double* __restrict__ ah, double* __restrict__ bh, double* __restrict__ hx,
     double* __restrict__ gx, double* __restrict__ local_lb, double* __restrict__ logz,
     double2* __restrict__ zfac, LinChain ch) {
-  __shared__ LinShared<NW> sh;
+  extern __shared__ double __attribute__((aligned(16))) lin_smem[];   // sizeof(LinShared<NW>)
+  LinShared<NW>& sh = *reinterpret_cast<LinShared<NW>*>(lin_smem);
   if (blockIdx.y == 0)
-    fwd_lin_body<NW, FULL, (MODE == 3 ? 1 : MODE)>(sh, Eh, kexp, Aexp, mod_init, B,
+    fwd_lin_body<NW, FULL, (MODE == 3 ? 1 : MODE), BS>(sh, Eh, kexp, Aexp, mod_init, B,
                                                    MODE == 1 ? Lm - 1 : Lm, wstride, K, ah, hx,
                                                    local_lb, logz, zfac, ch);
   else
-    bwd_lin_body<NW, FULL, (MODE == 1 ? 1 : 0)>(sh, Eh, AexpT, B, Lm, wstride, K, bh, gx, ch);
+    bwd_lin_body<NW, FULL, (MODE == 1 ? 1 : 0), BS>(sh, Eh, AexpT, B, Lm, wstride, K, bh, gx, ch);
 }
 
 // S2 of the chain scan: boundary vectors.  grid 2 (0: alpha at chunk starts, 1: beta at chunk

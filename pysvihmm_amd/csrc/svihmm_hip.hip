@@ -122,6 +122,7 @@ struct svihmm_ctx {
   bool q_valid = false;            // lin_mode: var_x has been formed from ah, bh (k_lin_posterior)
   bool lin_stale = false;          // parameters changed since: logs can no longer be rebuilt
   bool last_host_ll = false;       // the last sweep ran on host-supplied lliks
+  bool eh_in_llE = false;          // scaled emission lives in llE (h->ll holds the plain lliks)
   uint32_t last_flags = 0;
   int m_b0 = 0, m_nb = 0;          // window range currently materialised in m_*
   int lastB = 0, lastLm = 0;       // shape of the intermediates currently held
@@ -635,7 +636,7 @@ static int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_
   const bool full = (K == 16 * NW);
   dim3 grid((nb + 15) / 16, 2);
   const size_t ro = (size_t)b0 * Lm;
-  const double* Eh = (const double*)(h->last_host_ll ? h->llE.p : h->ll.p) + ro * K;
+  const double* Eh = (const double*)(h->eh_in_llE ? h->llE.p : h->ll.p) + ro * K;
   const double* kx = (const double*)h->kexp.p + ro;
   double* ah = (double*)h->la.p + ro * K;
   double* bh = (double*)h->lb.p + ro * K;
@@ -646,15 +647,26 @@ static int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_
   double* lz = (double*)h->logz.p + b0;
   ProfScope ps(h, KS_FB, stream);
   const LinChain none = {};
-#define SWP(NWV, F) hipLaunchKernelGGL((k_sweeps_lin<NWV, F, 0>), grid, dim3(64 * NWV), 0, stream, Eh, kx, \
-                                       (const double*)h->Aexp.p, (const double*)h->AexpT.p,                \
-                                       (const double*)h->mod_init.p, nb, Lm, Lm, K, ah, bh, hx, gx, llb,   \
-                                       lz, zf, none)
+#define SWPX(NWV, F, BSV)                                                                                  \
+  do {                                                                                                     \
+    const size_t lds = sizeof(LinShared<NWV>);                                                             \
+    if (lds > 64 * 1024)                                                                                   \
+      hipFuncSetAttribute((const void*)k_sweeps_lin<NWV, F, 0, BSV>,                                       \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+    hipLaunchKernelGGL((k_sweeps_lin<NWV, F, 0, BSV>), grid, dim3(64 * NWV), lds, stream, Eh, kx,          \
+                       (const double*)h->Aexp.p, (const double*)h->AexpT.p,                                \
+                       (const double*)h->mod_init.p, nb, Lm, Lm, K, ah, bh, hx, gx, llb, lz, zf, none);    \
+  } while (0)
+#define SWP(NWV, F) SWPX(NWV, F, false)
   if (NW == 1) { if (full) SWP(1, true); else SWP(1, false); }
   else if (NW == 2) { if (full) SWP(2, true); else SWP(2, false); }
   else if (NW == 3) { if (full) SWP(3, true); else SWP(3, false); }
-  else { if (full) SWP(4, true); else SWP(4, false); }
+  else if (NW == 4) { if (full) SWP(4, true); else SWP(4, false); }
+  else if (NW <= 8) { if (K == 128) SWPX(8, true, true); else SWPX(8, false, true); }      // K > 64: B streamed
+  else if (NW <= 12) { if (K == 192) SWPX(12, true, true); else SWPX(12, false, true); }
+  else { if (K == 256) SWPX(16, true, true); else SWPX(16, false, true); }
 #undef SWP
+#undef SWPX
   HIPCK(hipGetLastError());
   return 0;
 }
@@ -669,7 +681,8 @@ static int ensure_q(svihmm_ctx* h, int B, int Lm, hipStream_t stream) {
 #define PQ(KT) hipLaunchKernelGGL(k_lin_posterior<KT>, grid, dim3(256), 0, stream, (const double*)h->la.p, \
                                   (const double*)h->lb.p, (const double*)h->hx.p, (const double*)h->gx.p,   \
                                   (const double2*)h->zfac.p, n, Lm, K, (double*)h->q.p)
-  if (K <= 16) PQ(1); else if (K <= 32) PQ(2); else if (K <= 48) PQ(3); else PQ(4);
+  if (K <= 16) PQ(1); else if (K <= 32) PQ(2); else if (K <= 48) PQ(3); else if (K <= 64) PQ(4);
+  else if (K <= 128) PQ(8); else if (K <= 192) PQ(12); else PQ(16);
 #undef PQ
   HIPCK(hipGetLastError());
   h->q_valid = true;
@@ -714,7 +727,7 @@ static int launch_fb_chain(svihmm_ctx* h, int Lm, bool total) {
   double* ksum = lzw + (C + 1);             // per-chunk sums of the emission row exponents
   CK(ensure(h->chain2, (size_t)(C + 1) * sizeof(double2)));
   double2* zfw = (double2*)h->chain2.p;     // scratch zfac of the S3 windows (the global one comes from S2)
-  const double* Eh = (const double*)(h->last_host_ll ? h->llE.p : h->ll.p);
+  const double* Eh = (const double*)(h->eh_in_llE ? h->llE.p : h->ll.p);
   const double* kx = (const double*)h->kexp.p;
   double* ah = (double*)h->la.p; double* bh = (double*)h->lb.p;
   double* hx = (double*)h->hx.p; double* gx = (double*)h->gx.p;
@@ -723,8 +736,8 @@ static int launch_fb_chain(svihmm_ctx* h, int Lm, bool total) {
   hipStream_t st = h->stream;
   ProfScope ps(h, KS_FB, st);
 #define SWPM(NWV, F, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH)                       \
-  hipLaunchKernelGGL((k_sweeps_lin<NWV, F, MD>), GRID, dim3(64 * NWV), 0, st, EHP, KXP, A, At, mi, BB, LL, \
-                     WS, K, AH, BH, HX, GX, LB, LZ, ZF, CH)
+  hipLaunchKernelGGL((k_sweeps_lin<NWV, F, MD>), GRID, dim3(64 * NWV), sizeof(LinShared<NWV>), st, EHP, KXP, A, At, \
+                     mi, BB, LL, WS, K, AH, BH, HX, GX, LB, LZ, ZF, CH)
 #define SWPD(MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH)                                \
   do {                                                                                                      \
     if (NW == 1) { if (full) SWPM(1, true, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH); \
@@ -799,7 +812,13 @@ static int launch_fb_lin(svihmm_ctx* h, int B, int Lm, bool total) {
 // linear-domain MFMA (the E-step fast path; logs are materialised on demand).
 static int pick_fb(const svihmm_ctx* h, int B, int Lm, bool want_logs) {
   int var = h->variant[2];
-  if (h->K > 64) return 1;
+  if (h->K > 256) return 1;
+  if (h->K > 64) {   // no log-domain MFMA sweep beyond 64 states: scaled (streamed B) or per-window
+    if (var == 2) var = 1;
+    if (var == 0) var = (B >= 192 && !want_logs) ? 3 : 1;
+    if (var == 3 && (size_t)16 * Lm * h->K * sizeof(double) >= ((size_t)1 << 32)) var = 1;
+    return var;
+  }
   if (var == 0) var = (B >= 192) ? (want_logs ? 2 : 3) : 1;
   if (h->variant[2] == 0 && !want_logs && use_chain(h, B, Lm)) var = 3;   // long single chain: blocked scan
   // the scaled sweeps address a workgroup's 16 windows with 32-bit byte offsets
@@ -985,7 +1004,8 @@ static int launch_scale_ll(svihmm_ctx* h, int B, int Lm) {
   dim3 grid((unsigned)((n + 15) / 16));
 #define SC(KT) hipLaunchKernelGGL(k_scale_ll<KT>, grid, dim3(256), 0, h->stream, (const double*)h->ll.p, \
                                   n, K, (double*)h->llE.p, (double*)h->kexp.p)
-  if (K <= 16) SC(1); else if (K <= 32) SC(2); else if (K <= 48) SC(3); else SC(4);
+  if (K <= 16) SC(1); else if (K <= 32) SC(2); else if (K <= 48) SC(3); else if (K <= 64) SC(4);
+  else if (K <= 128) SC(8); else if (K <= 192) SC(12); else SC(16);
 #undef SC
   HIPCK(hipGetLastError());
   return 0;
@@ -1003,9 +1023,14 @@ static int prepare_ll(svihmm_ctx* h, const int64_t* starts, int B, int Lm, uint3
       return fail("SVIHMM_USE_HOST_LLIKS: no uploaded lliks of shape [B,Lm,K]");
     if (lin) CK(launch_scale_ll(h, B, Lm));
   } else {
-    CK(launch_emission(h, B, Lm, flags, lin));
+    // K <= 64: the emission kernel owns whole rows and writes (Eh, kexp) itself; wider
+    // models take the plain kernel plus one scaling pass
+    const bool two_pass = lin && h->Kp > 64;
+    CK(launch_emission(h, B, Lm, flags, lin && !two_pass));
+    if (two_pass) CK(launch_scale_ll(h, B, Lm));
     h->have_host_ll = false;
   }
+  h->eh_in_llE = lin && (host_ll || h->Kp > 64);
   h->lin_mode = lin;
   h->lin_stale = false;
   h->q_valid = false;
@@ -1029,7 +1054,7 @@ static int materialise(svihmm_ctx* h, int b0, int nb) {
   CK(ensure(h->m_la, n));
   CK(ensure(h->m_lb, n));
   const double* ll;
-  if (h->last_host_ll) {
+  if (h->eh_in_llE) {   // the plain lliks are still in h->ll
     ll = (const double*)h->ll.p + (size_t)b0 * Lm * K;
   } else {
     CK(ensure(h->m_ll, n));
@@ -1045,7 +1070,7 @@ static int materialise(svihmm_ctx* h, int b0, int nb) {
 static int intermediate_ptr(svihmm_ctx* h, int what, int64_t row0, int64_t nrows, const double** out) {
   const int K = h->K, Lm = h->lastLm;
   Buf* src[] = {&h->ll, &h->la, &h->lb, &h->q};
-  if (!h->lin_mode || what == 3 || (what == 0 && h->last_host_ll)) {
+  if (!h->lin_mode || what == 3 || (what == 0 && h->eh_in_llE)) {
     if (what == 3) CK(ensure_q(h, h->lastB, Lm, h->stream));
     if (!src[what]->p) return fail("intermediate buffer not available");
     *out = (const double*)src[what]->p + (size_t)row0 * K;
@@ -1104,7 +1129,7 @@ static int estep_pipelined(svihmm_ctx* h, const int64_t* starts, int B, int Lm, 
   StatsPlan plan[2] = {stats_plan((int64_t)nb[0] * inner_len), stats_plan((int64_t)nb[1] * inner_len)};
   CK(ensure_stats(h, plan[0].nchunk + plan[1].nchunk));
   h->have_host_ll = false;
-  h->lin_mode = true; h->lin_stale = false; h->last_host_ll = false; h->last_flags = flags;
+  h->lin_mode = true; h->lin_stale = false; h->last_host_ll = false; h->eh_in_llE = false; h->last_flags = flags;
   h->q_valid = false; h->curB = B;
   h->m_nb = 0; h->have_lb = true;
   hipStream_t A = h->stream, Bs = h->stream2;

@@ -24,9 +24,10 @@ def _push(eng, pb, mask=True):
     eng.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
 
 
-@pytest.mark.parametrize("K", [3, 16, 17, 33, 48, 50, 64])
+@pytest.mark.parametrize("K", [3, 16, 17, 33, 48, 50, 64, 65, 100, 128, 200, 256])
 def test_auto_path_vs_oracle(eng, K):
-    """B >= 192 -> the automatic choice is the scaled sweep; statistics vs the C oracle."""
+    """B >= 192 -> the automatic choice is the scaled sweep (K > 64: transition tile streamed
+    from L2, emission scaled in a second pass); statistics vs the C oracle."""
     from pysvihmm_amd import _lib as L
     from oracle import ref_c
     D, T, Lm, B = 3, 6000, 11, 203            # B not a multiple of 16
