@@ -243,7 +243,10 @@ struct StRow4 {
 #define ST_CS 33            // row slots per buffer per column (32 + 1 pad)
 #define ST_CC (2 * ST_CS + 1)  // column stride (both buffers + 1 pad): 67
 
-template <int MT, int NTW, int NSPLIT, int XK, bool LIN>
+// TRONLY (K > 64): only the transition statistic sum_t q[t-1, pbase + i] q[t, kbase + j] of
+// one 64 x 64 block of (previous state, state) pairs: blockIdx.y = previous-state group,
+// blockIdx.z = state group, the m-tiles are the 64 q[prev] columns, no obs staging.
+template <int MT, int NTW, int NSPLIT, int XK, bool LIN, bool TRONLY = false>
 __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
     const double* __restrict__ obs, const uint8_t* __restrict__ mask,
     const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K, int Fp, int F,
@@ -270,11 +273,12 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
   const int mg = wave & 3, ng = wave >> 2;
   const int Ftot = Fp + KpTot;
   const int kbase = blockIdx.z * Kp;
-  const int mt0 = (blockIdx.y * 4 + mg) * MT;
+  const int pbase = TRONLY ? blockIdx.y * 64 : 0;     // first previous state of this block
+  const int mt0 = TRONLY ? mg * MT : (blockIdx.y * 4 + mg) * MT;
   const int nt0 = ng * NTW;
   const int wg_m0 = blockIdx.y * 4 * MT * 16, wg_m1 = wg_m0 + 4 * MT * 16;
-  const bool need_x = wg_m0 < Fp;
-  const bool need_qp = wg_m1 > Fp && mt_limit * 16 > Fp;
+  const bool need_x = !TRONLY && wg_m0 < Fp;
+  const bool need_qp = TRONLY || (wg_m1 > Fp && mt_limit * 16 > Fp);
   const int sr = tid / TPR, sc = tid % TPR;   // staging role: row sr, columns sc + TPR*k
   const int psr = (sr & 3) * 8 + (sr >> 2);   // permuted row slot
 
@@ -284,7 +288,8 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
   for (int m = 0; m < MT; ++m) {
     const int f = (mt0 + m) * 16 + li;
     int fa = ZERO, fb = ZERO;
-    if (f < F) { const int ab = fab[f]; fa = ab & 0xffff; fb = ab >> 16; }
+    if (TRONLY) { if (f < 64 && pbase + f < K) { fa = QP0 + f; fb = ONE; } }
+    else if (f < F) { const int ab = fab[f]; fa = ab & 0xffff; fb = ab >> 16; }
     else if (f >= Fp && f - Fp < K && mt_limit * 16 > Fp) { fa = QP0 + (f - Fp); fb = ONE; }
     oa[m] = fa * ST_CC + lg * 8; ob[m] = fb * ST_CC + lg * 8;
   }
@@ -305,8 +310,8 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
   const int64_t Q0 = bw0 * Lq + off;
   const double* __restrict__ qthr = q + Q0 * K + kbase + sc;   // per-thread bases
   const double* __restrict__ bthr = LIN ? bh + Q0 * K + kbase + sc : nullptr;
-  const double* __restrict__ pthr = q + Q0 * K + sc;
-  const double* __restrict__ bpthr = LIN ? bh + Q0 * K + sc : nullptr;
+  const double* __restrict__ pthr = q + Q0 * K + pbase + sc;
+  const double* __restrict__ bpthr = LIN ? bh + Q0 * K + pbase + sc : nullptr;
 
   // ---- row bookkeeping, three stages ahead, in phases; threads 0..31
   unsigned ri_bwr = 0, ri_t = 0;
@@ -505,8 +510,9 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
   for (int m = 0; m < MT; ++m) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int f = (mt0 + m) * 16 + lg + 4 * r;
-      if (f < Ftot && (mt0 + m) < mt_limit) {
+      const int fl = (mt0 + m) * 16 + lg + 4 * r;
+      const int f = TRONLY ? Fp + pbase + fl : fl;
+      if (TRONLY ? (fl < 64 && pbase + fl < KpTot) : (f < Ftot && (mt0 + m) < mt_limit)) {
 #pragma unroll
         for (int n = 0; n < NTW; ++n)
           part[((size_t)blockIdx.x * Ftot + f) * KpTot + kbase + (nt0 + n) * 16 + li] = acc[m][n][r];

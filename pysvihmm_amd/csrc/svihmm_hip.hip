@@ -912,19 +912,20 @@ static int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, in
 #undef ST3X
 #undef ST3
 #undef ST3L
-        if (big) {   // transition tiles [Fp/16, Ftot/16)
-          const int NT = 4, MT = 3;
-          const int DS = (D + 2) | 1;
-          const size_t lds2 = ((size_t)ST_RB * DS + (size_t)ST_RB * (16 * NT + 1) + (size_t)ST_RB * (Kp + 1)) * 8;
-          if (lds2 > 150 * 1024) return fail("statistics: K too large for the LDS-staged transition kernel");
-          if (lds2 > 64 * 1024)
-            hipFuncSetAttribute((const void*)k_stats_mfma<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-          const int ttiles = Kp / 16;
-          dim3 g2((unsigned)nchunk, (ttiles + 4 * MT - 1) / (4 * MT), Kp / 64);
-          hipLaunchKernelGGL((k_stats_mfma<3, 4>), g2, dim3(256), lds2, stream,
-                             (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K,
-                             Kp, Fp, F, (const int*)h->fab.p, qv, rpc, flags,
-                             Lq, off, partv, Fp / 16);
+        if (big) {   // transition tiles: one 64 x 64 (previous state, state) block per workgroup
+          dim3 g2((unsigned)nchunk, Kp / 64, Kp / 64);
+#define STT(XKV)                                                                                  \
+  do {                                                                                           \
+    if (lds > 64 * 1024)                                                                         \
+      hipFuncSetAttribute((const void*)k_stats_mfma4<1, 2, 2, XKV, false, true>,                 \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
+    hipLaunchKernelGGL((k_stats_mfma4<1, 2, 2, XKV, false, true>), g2, dim3(512), lds, stream,   \
+                       (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, Fp,                  \
+                       F, (const int*)h->fab.p, qv, rpc, flags, Lq, off,                          \
+                       partv, Kp, mt_limit, bhv, hxv, gxv, zfv);                                  \
+  } while (0)
+          if (xk <= 1) STT(1); else if (xk <= 3) STT(3); else if (xk <= 5) STT(5); else STT(9);
+#undef STT
         }
       }
     }
