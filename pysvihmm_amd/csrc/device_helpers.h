@@ -136,11 +136,19 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
                           __builtin_amdgcn_readlane(__double2loint(v), l));
 }
+// Reading a lane that is inactive where the value was produced is undefined, and the compiler
+// is free to sink "x = valid ? f(..) : 0" plus everything that consumes x only in valid lanes
+// into the divergent region -- a v_readlane of x then sees garbage in the other lanes (seen
+// with ragged K in k_fb_wave).  pin_all_lanes() is an opaque volatile no-op: the value must
+// exist in every lane at this point of the (uniform) control flow.
+__device__ __forceinline__ void pin_all_lanes(double& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ double wave_sum_dpp(double v) {
+  pin_all_lanes(v);
   v = row16_sum(v);
   return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 __device__ __forceinline__ double wave_max_dpp(double v) {
+  pin_all_lanes(v);
   v = row16_max(v);
   return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }

@@ -930,6 +930,7 @@ __global__ __launch_bounds__(64 * NW) void k_sweeps_lin(
 // a 32 KB matrix is off the sequential path.  One barrier per chunk.
 template <int KMAX>
 __device__ __forceinline__ double scan_matvec(const double* __restrict__ ms, int K, int lane, double w) {
+  pin_all_lanes(w);
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
   for (int i = 0; i < KMAX; i += 4) {
@@ -938,7 +939,9 @@ __device__ __forceinline__ double scan_matvec(const double* __restrict__ ms, int
     a2 = fma(readlane_f64(w, i + 2), ms[(i + 2) * 64 + lane], a2);
     a3 = fma(readlane_f64(w, i + 3), ms[(i + 3) * 64 + lane], a3);
   }
-  return (a0 + a1) + (a2 + a3);
+  double r = (a0 + a1) + (a2 + a3);
+  pin_all_lanes(r);
+  return r;
 }
 
 template <int KMAX>
