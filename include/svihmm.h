@@ -133,6 +133,16 @@ int svihmm_estep_minibatch_ex(svihmm_ctx* h, const int64_t* starts, int32_t B,
                               int32_t Lm, int32_t inner_off, int32_t inner_len,
                               uint32_t flags, double* out_packed);
 
+/* Mean predictive log-probability of the held-out (masked) rows of the given windows
+ * (hmmsgd_metaobs.py:1086-1145 pred_logprob / pred_logprob_full, hmmbase.py:322-340):
+ * E-step with `flags` (SVIHMM_MASK_AS_NAN: the masked rows are missing), then the mean over
+ * the masked rows of LSE_k( log(var_x[t,k] + 1e-9) + E_q log p(x_t | k) ) with the emission
+ * term evaluated on the true observations.  out2[0] = mean (NaN if nothing is masked),
+ * out2[1] = number of masked rows.  NIW emission only (a host-supplied lliks batch has no
+ * "true observation" term). */
+int svihmm_pred_logprob(svihmm_ctx* h, const int64_t* starts, int32_t B, int32_t Lm,
+                        uint32_t flags, double out2[2]);
+
 /* Readback of the intermediates of the last estep/forward_backward call
  * (what 0: lliks, 1: lalpha, 2: lbeta, 3: var_x; each [B,Lm,K]).
  * Large batches (B >= 192, K <= 64) run scaled linear-domain sweeps that never write a

@@ -131,6 +131,22 @@ class OracleEngine(object):
         self._packed = P
         return P if read else None
 
+    def pred_logprob(self, starts, Lm, flags=MASK_AS_NAN):
+        st = np.asarray(starts, dtype=np.int64).ravel()
+        if self.mask is None:
+            return None, 0
+        r = self.forward_backward(st, Lm, flags, want=("var_x",))
+        tot, n = 0.0, 0
+        for b, s in enumerate(st):
+            m = self.mask[s:s + Lm]
+            if not m.any():
+                continue
+            ll = R.lliks_niw(self.obs[s:s + Lm][m], *self.em)
+            v = np.log(r["var_x"][b][m] + 1e-9) + ll
+            tot += np.sum(np.logaddexp.reduce(v, axis=1))
+            n += int(m.sum())
+        return (tot / n if n else None), n
+
     def read_packed(self):
         return self._packed
 

@@ -94,3 +94,57 @@ __global__ __launch_bounds__(256) void k_peak_fma_f64(double* out, int iters) {
   for (int i = 0; i < 8; ++i) s += c[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
+
+// ------------------------------------------------------------------------------------
+//  K7: predictive log-probability of the held-out rows (hmmsgd_metaobs.py:1086-1145,
+//      hmmbase.py:322-340):  sum over masked rows of LSE_k( log(var_x[t,k] + 1e-9) + ll[t,k] )
+//      with ll evaluated on the TRUE observations.  One 16-lane row per (window, t) row,
+//      fixed row -> block assignment and per-block partials: deterministic.
+//      grid (nblk), block 256; part[2*b] = sum, part[2*b+1] = count.
+// ------------------------------------------------------------------------------------
+#define PRED_ROWS_PER_BLOCK 2048
+template <int KT>
+__global__ __launch_bounds__(256) void k_pred_logprob(
+    const double* __restrict__ q, const double* __restrict__ ll, const uint8_t* __restrict__ mask,
+    const int64_t* __restrict__ starts, int64_t nrows, int Lm, int K, double* __restrict__ part) {
+  __shared__ double red[2][16];
+  const int li = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int64_t r0 = (int64_t)blockIdx.x * PRED_ROWS_PER_BLOCK;
+  const int64_t r1 = imin64(nrows, r0 + PRED_ROWS_PER_BLOCK);
+  double acc = 0.0, cnt = 0.0;
+  for (int64_t g = r0 + rg; g < r1; g += 16) {
+    const int64_t b = g / Lm;
+    const int64_t orow = starts[b] + (g - b * Lm);
+    if (!mask[orow]) continue;             // uniform within the 16-lane row
+    double v[KT], mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      const int k = li + 16 * c;
+      v[c] = k < K ? log(q[g * K + k] + 1e-9) + ll[g * K + k] : -INFINITY;
+      mx = fmax(mx, v[c]);
+    }
+    mx = row16_max(mx);
+    double sm = 0.0;
+#pragma unroll
+    for (int c = 0; c < KT; ++c) sm += (li + 16 * c < K) ? exp(v[c] - mx) : 0.0;
+    sm = row16_sum(sm);
+    acc += mx + log(sm);
+    cnt += 1.0;
+  }
+  if (li == 0) { red[0][rg] = acc; red[1][rg] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, c = 0.0;
+    for (int i = 0; i < 16; ++i) { a += red[0][i]; c += red[1][i]; }
+    part[2 * blockIdx.x] = a;
+    part[2 * blockIdx.x + 1] = c;
+  }
+}
+__global__ void k_pred_final(const double* __restrict__ part, int nblk, double* __restrict__ out2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double a = 0.0, c = 0.0;
+    for (int i = 0; i < nblk; ++i) { a += part[2 * i]; c += part[2 * i + 1]; }
+    out2[0] = c > 0.0 ? a / c : NAN;
+    out2[1] = c;
+  }
+}

@@ -1191,6 +1191,44 @@ int svihmm_forward_backward(svihmm_ctx* h, const int64_t* starts, int32_t B, int
   return 0;
 }
 
+int svihmm_pred_logprob(svihmm_ctx* h, const int64_t* starts, int32_t B, int32_t Lm,
+                        uint32_t flags, double out2[2]) {
+  if (!h || !starts || !out2) return fail("svihmm_pred_logprob: bad arguments");
+  if (flags & SVIHMM_USE_HOST_LLIKS) return fail("svihmm_pred_logprob: NIW emission only");
+  CK(set_device(h));
+  if (!h->have_mask) { out2[0] = NAN; out2[1] = 0.0; return 0; }
+  const int var = pick_fb(h, B, Lm, false);
+  CK(prepare_ll(h, starts, B, Lm, flags, false, var == 3));
+  CK(run_fb(h, B, Lm, var, false, false));
+  h->lastB = B; h->lastLm = Lm;
+  CK(ensure_q(h, B, Lm, h->stream));
+  // emission term on the true observations (no masking), into the side buffer
+  const int K = h->K;
+  const int64_t n = (int64_t)B * Lm;
+  CK(ensure(h->m_ll, (size_t)n * K * sizeof(double)));
+  h->m_nb = 0;
+  CK(launch_emission(h, B, Lm, flags & ~(uint32_t)SVIHMM_MASK_AS_NAN, false, nullptr, (double*)h->m_ll.p));
+  const int nblk = (int)((n + PRED_ROWS_PER_BLOCK - 1) / PRED_ROWS_PER_BLOCK);
+  CK(ensure(h->scratch, ((size_t)2 * nblk + 2) * sizeof(double)));
+  double* part = (double*)h->scratch.p;
+  {
+    ProfScope ps(h, KS_MISC);
+#define PL(KT) hipLaunchKernelGGL(k_pred_logprob<KT>, dim3(nblk), dim3(256), 0, h->stream, (const double*)h->q.p, \
+                                  (const double*)h->m_ll.p, (const uint8_t*)h->mask.p,                            \
+                                  (const int64_t*)h->starts.p, n, Lm, K, part)
+    if (K <= 16) PL(1); else if (K <= 32) PL(2); else if (K <= 48) PL(3); else if (K <= 64) PL(4);
+    else if (K <= 128) PL(8); else if (K <= 256) PL(16);
+    else return fail("svihmm_pred_logprob: K > 256 not supported");
+#undef PL
+    hipLaunchKernelGGL(k_pred_final, dim3(1), dim3(64), 0, h->stream, (const double*)part, nblk, part + 2 * nblk);
+    HIPCK(hipGetLastError());
+  }
+  CK(d2h(h, out2, part + 2 * nblk, 2 * sizeof(double)));
+  HIPCK(hipStreamSynchronize(h->stream));
+  CK(check_emission_status(h));
+  return 0;
+}
+
 int svihmm_estep_minibatch(svihmm_ctx* h, const int64_t* starts, int32_t B, int32_t Lm,
                            uint32_t flags, double* out_packed) {
   return svihmm_estep_minibatch_ex(h, starts, B, Lm, 0, Lm, flags, out_packed);

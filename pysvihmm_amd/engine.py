@@ -153,6 +153,16 @@ class HipEngine(object):
                 "svihmm_estep_minibatch")
         return PackedStats(out, self.K, self.D) if read else None
 
+    def pred_logprob(self, starts, Lm, flags=L.MASK_AS_NAN):
+        """Mean predictive log-probability of the masked rows of the windows and their number
+        (reference pred_logprob / pred_logprob_full); ``(None, 0)`` when nothing is masked."""
+        st = self._starts(starts)
+        out = np.empty(2)
+        L.check(self._lib.svihmm_pred_logprob(self._h, L.i64ptr(st), len(st), int(Lm), int(flags),
+                                              L.dptr(out)), "svihmm_pred_logprob")
+        n = int(out[1])
+        return (float(out[0]) if n > 0 else None), n
+
     def read_packed(self):
         out = np.empty(PackedStats.size(self.K, self.D))
         L.check(self._lib.svihmm_read_packed(self._h, L.dptr(out)), "svihmm_read_packed")

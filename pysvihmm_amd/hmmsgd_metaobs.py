@@ -625,6 +625,18 @@ class VBHMM(VariationalHMMBase):
         return np.mean(np.logaddexp.reduce(logprob, axis=1))
 
     def pred_logprob_full(self):
+        obs_full = getattr(self, 'obs_full', self.obs)
+        if self._niw_fastpath() and obs_full is self.obs:
+            # whole computation on the device (chain E-step as a blocked scan, emission term of
+            # the held-out rows, reduction): two doubles come back instead of var_x[T,K]
+            mod_init = digamma(self.var_init + eps) - digamma(np.sum(self.var_init) + eps)
+            tran_sum = np.sum(self.var_tran, axis=1)
+            mod_tran = digamma(self.var_tran + eps) - digamma(tran_sum[:, npa] + eps)
+            self._upload_obs()
+            self.engine.set_globals(mod_init, mod_tran)
+            flags = self._push_emission(nan_mask=True)
+            val, _ = self.engine.pred_logprob([0], self.T, flags=flags)
+            return val
         full_var_x = self.full_local_update()
         K = self.K
         obs = getattr(self, 'obs_full', self.obs)

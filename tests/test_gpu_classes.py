@@ -123,3 +123,20 @@ def test_rccl_world_size_one():
     zero = e.estep([], 50)                      # empty shard -> zero statistics
     assert np.all(zero.buf == 0)
     e.close()
+
+
+def test_pred_logprob_full_device_equals_host_route():
+    """Held-out predictive log-probability computed entirely on the device
+    (svihmm_pred_logprob) vs the literal host formula on full_local_update's var_x."""
+    from pysvihmm_amd import hmmsgd_metaobs
+    g = np.load(os.path.join(GOLDEN, "metaobs_K4_D2_L10_mask.npz"))
+    K = int(g["K"])
+    hmm = hmmsgd_metaobs.VBHMM(
+        g["obs"].copy(), np.ones(K), g["prior_tran"], emit_from_fixture(g, K),
+        tau=float(g["tau"]), kappa=float(g["kappa"]), metaobs_half=int(g["L"]),
+        mb_sz=int(g["S"]), mask=g["mask"], init_tran=g["init_tran"], maxit=2, seed=int(g["seed"]))
+    hmm.infer()
+    fast = hmm.pred_logprob_full()
+    hmm.obs_full = hmm.obs.copy()
+    slow = hmm.pred_logprob_full()
+    np.testing.assert_allclose(fast, slow, rtol=1e-9)

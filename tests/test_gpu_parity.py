@@ -316,3 +316,34 @@ def test_unreachable_state(eng, fbv):
     assert np.all(np.isfinite(st.buf))
     np.testing.assert_allclose(st.buf, ref, rtol=RTOL, atol=1e-9)
     eng.set_variant("fb", 0)
+
+
+@pytest.mark.parametrize("B,Lm", [(5, 40), (1, 3000), (230, 12)])
+def test_pred_logprob_vs_numpy(eng, B, Lm):
+    """svihmm_pred_logprob: mean over the masked rows of
+    LSE_k(log(var_x + 1e-9) + E log p(x_t | k)), E-step with the masked rows missing.
+    Covers the per-window path, the chain scan and the scaled batch sweeps."""
+    from pysvihmm_amd import _lib as L
+    from oracle import ref_numpy as R
+    K, D, T = 9, 3, 4000
+    pb = make_problem(K, D, T, seed=66, miss=0.15)
+    starts = (np.arange(B) * 17) % (T - Lm + 1)
+    eng.set_obs(pb["obs"], pb["mask"])
+    eng.set_globals(pb["mod_init"], pb["ltran"])
+    eng.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    val, n = eng.pred_logprob(starts, Lm, flags=L.MASK_AS_NAN)
+    tot, cnt = 0.0, 0
+    for s0 in starts:
+        m = pb["mask"][s0:s0 + Lm]
+        x = pb["obs"][s0:s0 + Lm].copy()
+        xm = x.copy(); xm[m] = np.nan
+        ll = R.lliks_niw(xm, pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+        q = R.posterior(R.forward_msgs(ll, pb["mod_init"], pb["ltran"]), R.backward_msgs(ll, pb["ltran"]))
+        if m.any():
+            lt = R.lliks_niw(x[m], pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+            tot += np.sum(np.logaddexp.reduce(np.log(q[m] + 1e-9) + lt, axis=1))
+            cnt += int(m.sum())
+    assert n == cnt
+    np.testing.assert_allclose(val, tot / cnt, rtol=1e-9)
+    eng.set_obs(pb["obs"], None)
+    assert eng.pred_logprob(starts, Lm) == (None, 0)

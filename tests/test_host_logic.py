@@ -170,3 +170,22 @@ def test_product_has_no_cpu_fallback():
     hmm = hmmbatchcd.VBHMM(obs, np.ones(2), np.ones((2, 2)), pe, maxit=1)
     with pytest.raises(RuntimeError):
         hmm.infer()
+
+
+def test_pred_logprob_full_engine_path_equals_host_formula():
+    """pred_logprob_full (reference hmmsgd_metaobs.py:1121-1145): the engine route (one call,
+    two doubles back) equals the literal host formula on full_local_update's var_x."""
+    g = np.load(os.path.join(GOLDEN, "metaobs_K4_D2_L10_mask.npz"))
+    K = int(g["K"])
+    hmm = hmmsgd_metaobs.VBHMM(
+        g["obs"].copy(), np.ones(K), g["prior_tran"], emit_from_fixture(g, K),
+        tau=float(g["tau"]), kappa=float(g["kappa"]), metaobs_half=int(g["L"]),
+        mb_sz=int(g["S"]), mask=g["mask"], init_tran=g["init_tran"], maxit=2,
+        seed=int(g["seed"]), engine=OracleEngine())
+    hmm.infer()
+    assert g["mask"].any()
+    fast = hmm.pred_logprob_full()
+    hmm.obs_full = hmm.obs.copy()          # a distinct obs_full forces the literal host route
+    slow = hmm.pred_logprob_full()
+    assert fast is not None and np.isfinite(fast)
+    np.testing.assert_allclose(fast, slow, rtol=1e-12)

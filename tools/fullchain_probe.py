@@ -22,4 +22,7 @@ for K, D, T in ((16, 8, 100000), (64, 32, 1000000)):
         print("K=%d D=%d T=%d full chain (%s): %.1f ms wall without var_x D2H (%.3g upd/s)  lb=%.9e" % (
             K, D, T, mode, dt * 1e3, T * K / dt, r["local_lb"][0]))
         print("    kernels:", {k: round(v[0], 3) for k, v in pr.items()})
+        if mode == "scan":
+            t0 = time.time(); v = e.pred_logprob([0], T, flags=1); dt = time.time() - t0
+            print("    pred_logprob (E-step + held-out term + reduction): %.1f ms -> %r" % (dt * 1e3, v))
     e.close()
