@@ -109,8 +109,14 @@ struct svihmm_ctx {
   Buf theta, fab, niw;
   void* theta_zero_p = nullptr; size_t theta_zero_n = 0;   // what the last theta memset covered
   int tabD = -1;
-  void* pin = nullptr; size_t pin_cap = 0;   // pinned host staging for parameter uploads
+  // pinned host staging: a ring of slots, each guarded by an event recorded after the copy
+  // that uses it, so that parameter uploads and small readbacks never synchronise the stream
+  struct PinSlot { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool busy = false; };
+  PinSlot pins[6];
+  int pin_next = 0;
   int* pin_status = nullptr;                 // pinned: NIW factorisation status (lazy check)
+  double* mirror = nullptr; size_t mirror_cap = 0;   // pinned + mapped copy of `packed`
+  bool mirror_valid = false;
   bool status_pending = false;
   bool have_emission = false;
   // work
@@ -222,15 +228,17 @@ int svihmm_destroy(svihmm_ctx* h) {
     if (h->ev_sw[i]) hipEventDestroy(h->ev_sw[i]);
   }
   if (h->stream2) hipStreamDestroy(h->stream2);
-  if (h->pin) hipHostFree(h->pin);
+  for (auto& ps : h->pins) { if (ps.p) hipHostFree(ps.p); if (ps.ev) hipEventDestroy(ps.ev); }
   if (h->pin_status) hipHostFree(h->pin_status);
+  if (h->mirror) hipHostFree(h->mirror);
   hipStreamDestroy(h->stream);
   delete h;
   return 0;
 }
 
 static int check_emission_status(svihmm_ctx* h);
-static int pinned(svihmm_ctx* h, size_t bytes, void** out);
+static int pinned(svihmm_ctx* h, size_t bytes, void** out, int* slot_out);
+static int pin_release(svihmm_ctx* h, int slot);
 int svihmm_sync(svihmm_ctx* h) {
   CK(set_device(h));
   HIPCK(hipStreamSynchronize(h->stream));
@@ -266,33 +274,45 @@ int svihmm_set_globals(svihmm_ctx* h, int32_t K, const double* mod_init, const d
   CK(ensure(h->ltran, kk));
   CK(ensure(h->Aexp, kk));
   CK(ensure(h->AexpT, kk));
-  HIPCK(hipStreamSynchronize(h->stream));   // staging buffer free again
-  CK(check_emission_status(h));
   void* pin = nullptr;
-  CK(pinned(h, kk + K * sizeof(double), &pin));
+  int slot = 0;
+  CK(pinned(h, kk + K * sizeof(double), &pin, &slot));
   std::memcpy(pin, ltran, kk);
   std::memcpy((char*)pin + kk, mod_init, K * sizeof(double));
   HIPCK(hipMemcpyAsync(h->ltran.p, pin, kk, hipMemcpyHostToDevice, h->stream));
   HIPCK(hipMemcpyAsync(h->mod_init.p, (char*)pin + kk, K * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  CK(pin_release(h, slot));
   {
     ProfScope ps(h, KS_MISC);
     hipLaunchKernelGGL(k_exp_transpose, dim3((K * K + 255) / 256), dim3(256), 0, h->stream,
                        (const double*)h->ltran.p, K, (double*)h->Aexp.p, (double*)h->AexpT.p);
   }
   HIPCK(hipGetLastError());
-  HIPCK(hipStreamSynchronize(h->stream));   // both setters share the staging buffer
   h->K = K; h->have_globals = true;
   return 0;
 }
 
-static int pinned(svihmm_ctx* h, size_t bytes, void** out) {
-  if (bytes > h->pin_cap) {
-    if (h->pin) hipHostFree(h->pin);
-    h->pin = nullptr; h->pin_cap = 0;
-    HIPCK(hipHostMalloc(&h->pin, bytes + 4096, hipHostMallocDefault));
-    h->pin_cap = bytes + 4096;
+// acquire the next staging slot (waits only if the copy that last used it is still in flight,
+// i.e. six uploads ago); pin_release() records the guard event after the copy is enqueued
+static int pinned(svihmm_ctx* h, size_t bytes, void** out, int* slot_out) {
+  svihmm_ctx::PinSlot& ps = h->pins[h->pin_next];
+  *slot_out = h->pin_next;
+  h->pin_next = (h->pin_next + 1) % 6;
+  if (ps.busy) { HIPCK(hipEventSynchronize(ps.ev)); ps.busy = false; }
+  if (bytes > ps.cap) {
+    if (ps.p) hipHostFree(ps.p);
+    ps.p = nullptr; ps.cap = 0;
+    HIPCK(hipHostMalloc(&ps.p, bytes + 4096, hipHostMallocDefault));
+    ps.cap = bytes + 4096;
   }
-  *out = h->pin;
+  if (!ps.ev) HIPCK(hipEventCreateWithFlags(&ps.ev, hipEventDisableTiming));
+  *out = ps.p;
+  return 0;
+}
+static int pin_release(svihmm_ctx* h, int slot) {
+  svihmm_ctx::PinSlot& ps = h->pins[slot];
+  HIPCK(hipEventRecord(ps.ev, h->stream));
+  ps.busy = true;
   return 0;
 }
 // call after a stream synchronisation: reports a failed NIW factorisation of the last
@@ -301,6 +321,7 @@ static int check_emission_status(svihmm_ctx* h) {
   if (!h->status_pending) return 0;
   h->status_pending = false;
   const int st = h->pin_status ? *h->pin_status : 0;
+  if (h->pin_status) *h->pin_status = 0;   // sticky until read: reset only here (stream idle)
   if (st != 0) {
     h->have_emission = false;
     return fail("svihmm_set_emission_niw: sigma_mf[" + std::to_string(st - 1) + "] is not positive definite");
@@ -344,21 +365,25 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
   double* dsg = dmu + nmu;
   double* dka = dsg + nsg;
   double* dnu = dka + K;
-  int* dstatus = (int*)(dnu + K);
-  // one pinned staging buffer, one H2D copy; the previous upload must have left it
-  HIPCK(hipStreamSynchronize(h->stream));
-  CK(check_emission_status(h));
+  // status word: pinned + mapped host memory, written (atomicMax) by the kernel only when a
+  // factor is not positive definite -- no device-to-host copy on the critical path
+  if (!h->pin_status) {
+    HIPCK(hipHostMalloc((void**)&h->pin_status, 64, hipHostMallocMapped));
+    *h->pin_status = 0;
+  }
+  int* dstatus = nullptr;
+  HIPCK(hipHostGetDevicePointer((void**)&dstatus, h->pin_status, 0));
+  // one pinned staging slot, one H2D copy, no stream synchronisation
   void* pin = nullptr;
-  CK(pinned(h, (nin + 1) * sizeof(double), &pin));
+  int slot = 0;
+  CK(pinned(h, (nin + 1) * sizeof(double), &pin, &slot));
   double* hp = (double*)pin;
   std::memcpy(hp, mu, nmu * sizeof(double));
   std::memcpy(hp + nmu, sigma, nsg * sizeof(double));
   std::memcpy(hp + nmu + nsg, kappa, K * sizeof(double));
   std::memcpy(hp + nmu + nsg + K, nu, K * sizeof(double));
-  if (!h->pin_status) HIPCK(hipHostMalloc((void**)&h->pin_status, 64, hipHostMallocDefault));
-  *h->pin_status = 0;
-  hp[nin] = 0.0;   // the status word travels with the parameters: one H2D copy
-  HIPCK(hipMemcpyAsync(dmu, hp, (nin + 1) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemcpyAsync(dmu, hp, nin * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  CK(pin_release(h, slot));
   // theta's padded rows / columns are zeroed once per (buffer, shape); k_niw_to_theta
   // rewrites every live entry on each call
   if (h->theta_zero_p != h->theta.p || h->theta_zero_n != (size_t)Fp * Kp) {
@@ -386,7 +411,6 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
     HIPCK(hipGetLastError());
   }
   // status comes back asynchronously; it is examined at the next synchronising call
-  HIPCK(hipMemcpyAsync(h->pin_status, dstatus, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   h->status_pending = true;
   h->eK = K; h->eD = D; h->have_emission = true;
   return 0;
@@ -425,7 +449,17 @@ static int check_windows(svihmm_ctx* h, const int64_t* starts, int B, int Lm, bo
 
 static int upload_starts(svihmm_ctx* h, const int64_t* starts, int B) {
   CK(ensure(h->starts, (size_t)B * sizeof(int64_t)));
-  HIPCK(hipMemcpyAsync(h->starts.p, starts, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+  const size_t nb = (size_t)B * sizeof(int64_t);
+  if (nb <= (size_t)4 << 20) {   // through a pinned slot: no host-side wait for the stream
+    void* pin = nullptr;
+    int slot = 0;
+    CK(pinned(h, nb, &pin, &slot));
+    std::memcpy(pin, starts, nb);
+    HIPCK(hipMemcpyAsync(h->starts.p, pin, nb, hipMemcpyHostToDevice, h->stream));
+    CK(pin_release(h, slot));
+  } else {
+    HIPCK(hipMemcpyAsync(h->starts.p, starts, nb, hipMemcpyHostToDevice, h->stream));
+  }
   return 0;
 }
 
@@ -991,6 +1025,22 @@ static int d2h(svihmm_ctx* h, void* dst, const void* src, size_t bytes) {
   HIPCK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
   return 0;
 }
+// small result readback: DMA into a pinned slot queued right behind the producing kernel,
+// one stream synchronisation, host copy to the caller's (pageable) buffer.  A direct async
+// copy to pageable memory makes the runtime wait for the stream on the host first (~0.1 ms
+// of GPU idle per E-step in the kernel trace).
+static int d2h_sync_small(svihmm_ctx* h, void* dst, const void* src, size_t bytes) {
+  void* pin = nullptr;
+  int slot = 0;
+  CK(pinned(h, bytes, &pin, &slot));
+  {
+    ProfScope ps(h, KS_D2H);
+    HIPCK(hipMemcpyAsync(pin, src, bytes, hipMemcpyDeviceToHost, h->stream));
+  }
+  HIPCK(hipStreamSynchronize(h->stream));
+  std::memcpy(dst, pin, bytes);
+  return 0;
+}
 
 int64_t svihmm_packed_size(int32_t K, int32_t D) {
   return (int64_t)K * K + (int64_t)K * D + K + (int64_t)K * D * D + 1;
@@ -1082,6 +1132,34 @@ static int intermediate_ptr(svihmm_ctx* h, int what, int64_t row0, int64_t nrows
   Buf* ms[] = {&h->m_ll, &h->m_la, &h->m_lb};
   *out = (const double*)ms[what]->p + ((size_t)row0 - (size_t)h->m_b0 * Lm) * K;
   return 0;
+}
+
+// copy `packed` into the host-visible mirror on the handle's stream
+static int launch_mirror(svihmm_ctx* h) {
+  const size_t n = (size_t)svihmm_packed_size(h->K, h->D);
+  if (n * sizeof(double) > h->mirror_cap) {
+    if (h->mirror) hipHostFree(h->mirror);
+    h->mirror = nullptr; h->mirror_cap = 0;
+    HIPCK(hipHostMalloc((void**)&h->mirror, n * sizeof(double) + 256, hipHostMallocMapped));
+    h->mirror_cap = n * sizeof(double) + 256;
+  }
+  double* dev = nullptr;
+  HIPCK(hipHostGetDevicePointer((void**)&dev, h->mirror, 0));
+  ProfScope ps(h, KS_D2H);
+  hipLaunchKernelGGL(k_mirror, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream,
+                     (const double*)h->packed.p, dev, (int)n);
+  HIPCK(hipGetLastError());
+  h->mirror_valid = true;
+  return 0;
+}
+static int read_packed_host(svihmm_ctx* h, double* out) {
+  const size_t nb = (size_t)svihmm_packed_size(h->K, h->D) * sizeof(double);
+  if (h->mirror_valid) {
+    HIPCK(hipStreamSynchronize(h->stream));
+    std::memcpy(out, h->mirror, nb);
+    return 0;
+  }
+  return d2h_sync_small(h, out, h->packed.p, nb);
 }
 
 // ---- two-stream E-step pipeline -------------------------------------------------------------
@@ -1245,6 +1323,7 @@ int svihmm_estep_minibatch_ex(svihmm_ctx* h, const int64_t* starts, int32_t B, i
     CK(ensure(h->packed, nb));
     HIPCK(hipMemsetAsync(h->packed.p, 0, nb, h->stream));
     h->have_packed = true;
+    h->mirror_valid = false;
     if (out_packed) {
       CK(d2h(h, out_packed, h->packed.p, nb));
       HIPCK(hipStreamSynchronize(h->stream));
@@ -1263,9 +1342,9 @@ int svihmm_estep_minibatch_ex(svihmm_ctx* h, const int64_t* starts, int32_t B, i
   }
   h->have_packed = true;
   h->lastB = B; h->lastLm = Lm;
+  CK(launch_mirror(h));
   if (out_packed) {
-    CK(d2h(h, out_packed, h->packed.p, (size_t)svihmm_packed_size(h->K, h->D) * sizeof(double)));
-    HIPCK(hipStreamSynchronize(h->stream));
+    CK(read_packed_host(h, out_packed));
     CK(check_emission_status(h));
   }
   return 0;
@@ -1275,8 +1354,7 @@ int svihmm_read_packed(svihmm_ctx* h, double* out_packed) {
   if (!h || !out_packed) return fail("svihmm_read_packed: bad arguments");
   if (!h->have_packed) return fail("svihmm_read_packed: no statistics computed yet");
   CK(set_device(h));
-  CK(d2h(h, out_packed, h->packed.p, (size_t)svihmm_packed_size(h->K, h->D) * sizeof(double)));
-  HIPCK(hipStreamSynchronize(h->stream));
+  CK(read_packed_host(h, out_packed));
   CK(check_emission_status(h));
   return 0;
 }
@@ -1377,7 +1455,8 @@ int svihmm_allreduce_packed(svihmm_ctx* h) {
   ProfScope ps(h, KS_ALLREDUCE);
   const size_t n = (size_t)svihmm_packed_size(h->K, h->D);
   NCCLCK(ncclAllReduce(h->packed.p, h->packed.p, n, ncclDouble, ncclSum, h->comm, h->stream));
-  return 0;
+  h->mirror_valid = false;
+  return launch_mirror(h);   // the host-visible copy follows the reduced statistics
 }
 
 int svihmm_allreduce_host(svihmm_ctx* h, double* buf, int64_t n, int32_t op) {
