@@ -133,6 +133,15 @@ int svihmm_estep_minibatch_ex(svihmm_ctx* h, const int64_t* starts, int32_t B,
                               int32_t Lm, int32_t inner_off, int32_t inner_len,
                               uint32_t flags, double* out_packed);
 
+/* Categorical emissions (hmmsgd_metaobs.py:907-926, 1071-1084; pybasicbayes Categorical):
+ * obs must be [T][1] holding the symbol index 0..V-1 as a double; logp[k][v] =
+ * E_q log theta_k[v] = psi(alpha_mf[k][v]) - psi(sum_v alpha_mf[k][v]) (host, SciPy digamma).
+ * Afterwards the E-step entry points use the table instead of the NIW kernel and the packed
+ * statistics have the layout [A_raw K*K | counts K*V | lb] (counts[k][v] = sum of var_x[t,k]
+ * over unmasked rows with symbol v); svihmm_packed_len gives the current length. */
+int svihmm_set_emission_cat(svihmm_ctx* h, int32_t K, int32_t V, const double* logp);
+int64_t svihmm_packed_len(svihmm_ctx* h);
+
 /* Mean predictive log-probability of the held-out (masked) rows of the given windows
  * (hmmsgd_metaobs.py:1086-1145 pred_logprob / pred_logprob_full, hmmbase.py:322-340):
  * E-step with `flags` (SVIHMM_MASK_AS_NAN: the masked rows are missing), then the mean over

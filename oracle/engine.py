@@ -25,6 +25,14 @@ class _Packed(object):
         self.lb = buf[o:o + 1]
 
 
+class _PackedCat(object):
+    def __init__(self, buf, K, V):
+        self.buf, self.K, self.V = buf, K, V
+        self.A_raw = buf[:K * K].reshape(K, K)
+        self.counts = buf[K * K:K * K + K * V].reshape(K, V)
+        self.lb = buf[K * K + K * V:]
+
+
 class OracleEngine(object):
     name = "oracle"
 
@@ -57,9 +65,14 @@ class OracleEngine(object):
         self.K = self.ltran.shape[0]
 
     def set_emission_niw(self, mu, sigma, kappa, nu, check=True):
+        self.V = 0
         self.em = tuple(np.array(a, dtype=np.float64) for a in (mu, sigma, kappa, nu))
         for k in range(len(self.em[2])):
             np.linalg.cholesky(self.em[1][k])
+
+    def set_emission_cat(self, logp):
+        self.cat = np.array(logp, dtype=np.float64)
+        self.V = self.cat.shape[1]
 
     def set_lliks(self, lliks):
         self._host_ll = np.array(lliks, dtype=np.float64)
@@ -70,6 +83,12 @@ class OracleEngine(object):
         if (flags & MASK_AS_NAN) and self.mask is not None:
             x = x.copy()
             x[self.mask[s:s + Lm]] = np.nan
+        if getattr(self, "V", 0):
+            xv = x[:, 0]
+            ok = ~np.isnan(xv)
+            ll = np.zeros((len(xv), self.K))
+            ll[ok] = self.cat[:, xv[ok].astype(int)].T
+            return ll
         f = ref_c.lliks_niw if self.use_c else R.lliks_niw
         return f(x, *self.em)
 
@@ -109,6 +128,8 @@ class OracleEngine(object):
         self._check(st, Lm)
         B = len(st)
         K, D = self.K, self.D
+        if getattr(self, "V", 0):
+            return self._estep_cat(st, Lm, flags, read, inner)
         buf = np.zeros(K * K + K * D + K + K * D * D + 1)
         P = _Packed(buf, K, D)
         if B == 0:
@@ -141,11 +162,35 @@ class OracleEngine(object):
             m = self.mask[s:s + Lm]
             if not m.any():
                 continue
-            ll = R.lliks_niw(self.obs[s:s + Lm][m], *self.em)
+            xm = self.obs[s:s + Lm][m]
+            ll = (self.cat[:, xm[:, 0].astype(int)].T if getattr(self, "V", 0)
+                  else R.lliks_niw(xm, *self.em))
             v = np.log(r["var_x"][b][m] + 1e-9) + ll
             tot += np.sum(np.logaddexp.reduce(v, axis=1))
             n += int(m.sum())
         return (tot / n if n else None), n
+
+    def _estep_cat(self, st, Lm, flags, read, inner):
+        K, V, B = self.K, self.V, len(st)
+        buf = np.zeros(K * K + K * V + 1)
+        P = _PackedCat(buf, K, V)
+        if B:
+            self.forward_backward(st, Lm, flags)
+            off, ln = (0, Lm) if inner is None else inner
+            q = self._last["var_x"][:, off:off + ln]
+            for b in range(B):
+                s = int(st[b]) + off
+                P.A_raw[:] += (R.transition_stat_wrap(q[b]) if flags & TRANS_WRAP
+                               else R.transition_stat_batch(q[b]))
+                x = self.obs[s:s + ln, 0]
+                ok = ~np.isnan(x)
+                if self.mask is not None:
+                    ok &= ~self.mask[s:s + ln]
+                for v in range(V):
+                    P.counts[:, v] += q[b][ok & (x == v)].sum(0)
+            P.lb[0] = self._last["local_lb"].sum()
+        self._packed = P
+        return P if read else None
 
     def read_packed(self):
         return self._packed

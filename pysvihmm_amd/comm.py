@@ -49,7 +49,7 @@ class TorchDistComm(object):
         st = engine.read_packed()
         buf = np.ascontiguousarray(st.buf)
         self.allreduce_inplace(buf)
-        return PackedStats(buf, K, D)
+        return type(st)(buf, K, getattr(st, "V", D))
 
     def barrier(self, engine=None):
         self._dist.barrier(group=self.group)

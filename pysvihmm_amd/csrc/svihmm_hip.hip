@@ -106,7 +106,8 @@ struct svihmm_ctx {
   bool have_globals = false;
   // emission
   int eK = 0, eD = 0, Kp = 0, F = 0, Fp = 0;
-  Buf theta, fab, niw;
+  Buf theta, fab, niw, cat_table, partc;
+  bool emis_cat = false; int V = 0;          // Categorical emission: table [V][K] = E log theta
   void* theta_zero_p = nullptr; size_t theta_zero_n = 0;   // what the last theta memset covered
   int tabD = -1;
   // pinned host staging: a ring of slots, each guarded by an event recorded after the copy
@@ -154,6 +155,14 @@ struct svihmm_ctx {
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
 };
+
+// length of the packed statistics in the layout of the current emission family:
+// NIW  [A_raw K*K | xbar K*D | neff K | S K*D*D | lb],  Categorical  [A_raw K*K | counts K*V | lb]
+static size_t packed_len(const svihmm_ctx* h) {
+  if (h->emis_cat) return (size_t)h->K * h->K + (size_t)h->K * h->V + 1;
+  const size_t D = h->D > 0 ? h->D : 1;
+  return (size_t)h->K * h->K + (size_t)h->K * D + h->K + (size_t)h->K * D * D + 1;
+}
 
 struct ProfScope {
   svihmm_ctx* h; int slot; hipEvent_t e0 = nullptr, e1 = nullptr; bool on; hipStream_t st;
@@ -221,7 +230,7 @@ int svihmm_destroy(svihmm_ctx* h) {
   Buf* bufs[] = {&h->obs, &h->mask, &h->mod_init, &h->ltran, &h->Aexp, &h->AexpT, &h->theta, &h->niw,
                  &h->fab, &h->starts, &h->ll, &h->la, &h->lb, &h->q, &h->lse_part,
                  &h->local_lb, &h->logz, &h->part, &h->packed, &h->scratch, &h->kexp, &h->hx, &h->gx,
-                 &h->zfac, &h->llE, &h->m_ll, &h->m_la, &h->m_lb, &h->chain, &h->chain2};
+                 &h->zfac, &h->llE, &h->m_ll, &h->m_la, &h->m_lb, &h->chain, &h->chain2, &h->cat_table, &h->partc};
   for (Buf* b : bufs) release(*b);
   for (int i = 0; i < 2; ++i) {
     if (h->ev_em[i]) hipEventDestroy(h->ev_em[i]);
@@ -412,11 +421,30 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
   }
   // status comes back asynchronously; it is examined at the next synchronising call
   h->status_pending = true;
-  h->eK = K; h->eD = D; h->have_emission = true;
+  h->eK = K; h->eD = D; h->have_emission = true; h->emis_cat = false;
   return 0;
 }
 
 // feature table is also needed by the statistics kernels when only host lliks are used
+int svihmm_set_emission_cat(svihmm_ctx* h, int32_t K, int32_t V, const double* logp) {
+  if (!h || K <= 0 || V <= 0 || !logp) return fail("svihmm_set_emission_cat: bad arguments");
+  CK(set_device(h));
+  h->lin_stale = true;
+  const size_t n = (size_t)K * V;
+  CK(ensure(h->cat_table, n * sizeof(double)));
+  void* pin = nullptr;
+  int slot = 0;
+  CK(pinned(h, n * sizeof(double), &pin, &slot));
+  double* hp = (double*)pin;
+  for (int k = 0; k < K; ++k)              // transpose to [V][K]: a row's states are contiguous
+    for (int v = 0; v < V; ++v) hp[(size_t)v * K + k] = logp[(size_t)k * V + v];
+  HIPCK(hipMemcpyAsync(h->cat_table.p, hp, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  CK(pin_release(h, slot));
+  h->eK = K; h->eD = 1; h->V = V; h->Kp = (K + 15) / 16 * 16; h->have_emission = true; h->emis_cat = true;
+  return 0;
+}
+int64_t svihmm_packed_len(svihmm_ctx* h) { return h ? (int64_t)packed_len(h) : 0; }
+
 static int ensure_feature_table(svihmm_ctx* h) {
   return upload_feature_table(h, h->D, h->K);
 }
@@ -486,6 +514,14 @@ static int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool sc
   if (!stream) stream = h->stream;
   const uint8_t* mk = h->have_mask ? (const uint8_t*)h->mask.p : nullptr;
   ProfScope ps(h, KS_EMISSION, stream);
+  if (h->emis_cat) {   // table lookup (scaled output: the caller adds the k_scale_ll pass)
+    if (scaled) return fail("internal: Categorical emission has no fused scaled output");
+    hipLaunchKernelGGL(k_emission_cat, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream,
+                       (const double*)h->obs.p, mk, starts_dev, n, Lm, K, h->V,
+                       (const double*)h->cat_table.p, flags, out);
+    HIPCK(hipGetLastError());
+    return 0;
+  }
   int var = h->variant[0];
   if (var == 0 || scaled) var = 2;
   if (var == 2) {
@@ -579,7 +615,7 @@ static int launch_posterior(svihmm_ctx* h, int B, int Lm, bool total) {
   CK(ensure(h->q, (size_t)B * Lm * K * sizeof(double)));
   CK(ensure(h->lse_part, (size_t)B * nseg * sizeof(double)));
   CK(ensure(h->local_lb, (size_t)B * sizeof(double)));
-  CK(ensure(h->packed, (size_t)svihmm_packed_size(K, h->D > 0 ? h->D : 1) * sizeof(double)));
+  CK(ensure(h->packed, (size_t)packed_len(h) * sizeof(double)));
   ProfScope ps(h, KS_POSTERIOR);
   dim3 grid((unsigned)((size_t)B * nseg));
 #define POST_LAUNCH(KPL)                                                                  \
@@ -590,7 +626,7 @@ static int launch_posterior(svihmm_ctx* h, int B, int Lm, bool total) {
   else POST_LAUNCH(16);
 #undef POST_LAUNCH
   double* lbtot = nullptr;
-  if (total) lbtot = (double*)h->packed.p + (svihmm_packed_size(K, h->D) - 1);
+  if (total) lbtot = (double*)h->packed.p + (packed_len(h) - 1);
   hipLaunchKernelGGL(k_reduce_lb, dim3(1), dim3(256), 0, h->stream, (const double*)h->lse_part.p,
                      B, nseg, (double*)h->local_lb.p, lbtot);
   HIPCK(hipGetLastError());
@@ -608,7 +644,7 @@ static int launch_fb_fused(svihmm_ctx* h, int B, int Lm, bool want_lb, bool tota
   if (want_lb) CK(ensure(h->lb, n));
   CK(ensure(h->local_lb, (size_t)B * sizeof(double)));
   CK(ensure(h->logz, (size_t)B * sizeof(double)));
-  CK(ensure(h->packed, (size_t)svihmm_packed_size(K, h->D > 0 ? h->D : 1) * sizeof(double)));
+  CK(ensure(h->packed, (size_t)packed_len(h) * sizeof(double)));
   const int NW = (K + 15) / 16;
   dim3 grid((B + 15) / 16);
   const double* ll = (const double*)h->ll.p;
@@ -640,7 +676,7 @@ static int launch_fb_fused(svihmm_ctx* h, int B, int Lm, bool want_lb, bool tota
 #undef BWD2
 #undef BWD
     if (total) {
-      double* lbtot = (double*)h->packed.p + (svihmm_packed_size(K, h->D) - 1);
+      double* lbtot = (double*)h->packed.p + (packed_len(h) - 1);
       hipLaunchKernelGGL(k_sum_lb, dim3(1), dim3(256), 0, h->stream, (const double*)llb, B, lbtot);
     }
     HIPCK(hipGetLastError());
@@ -659,7 +695,7 @@ static int ensure_fb_lin(svihmm_ctx* h, int B, int Lm) {
   CK(ensure(h->zfac, (size_t)B * sizeof(double2)));
   CK(ensure(h->local_lb, (size_t)B * sizeof(double)));
   CK(ensure(h->logz, (size_t)B * sizeof(double)));
-  CK(ensure(h->packed, (size_t)svihmm_packed_size(K, h->D > 0 ? h->D : 1) * sizeof(double)));
+  CK(ensure(h->packed, (size_t)packed_len(h) * sizeof(double)));
   return 0;
 }
 // both sweeps over windows [b0, b0+nb) of the current batch on `stream` (buffers ensured):
@@ -723,7 +759,7 @@ static int ensure_q(svihmm_ctx* h, int B, int Lm, hipStream_t stream) {
   return 0;
 }
 static int launch_sum_lb(svihmm_ctx* h, int B, hipStream_t stream) {
-  double* lbtot = (double*)h->packed.p + (svihmm_packed_size(h->K, h->D) - 1);
+  double* lbtot = (double*)h->packed.p + (packed_len(h) - 1);
   hipLaunchKernelGGL(k_sum_lb, dim3(1), dim3(256), 0, stream, (const double*)h->local_lb.p, B, lbtot);
   HIPCK(hipGetLastError());
   return 0;
@@ -825,7 +861,7 @@ static int launch_fb_chain(svihmm_ctx* h, int Lm, bool total) {
   // local_lb[0] = sum of the chunks' parts (fixed order)
   hipLaunchKernelGGL(k_sum_lb, dim3(1), dim3(256), 0, st, (const double*)lbw, C, (double*)h->local_lb.p);
   if (total) {
-    double* lbtot = (double*)h->packed.p + (svihmm_packed_size(K, h->D) - 1);
+    double* lbtot = (double*)h->packed.p + (packed_len(h) - 1);
     hipLaunchKernelGGL(k_sum_lb, dim3(1), dim3(256), 0, st, (const double*)lbw, C, lbtot);
   }
   HIPCK(hipGetLastError());
@@ -1010,10 +1046,58 @@ static int launch_stats_finalize(svihmm_ctx* h, int64_t nchunk, hipStream_t stre
 static int ensure_stats(svihmm_ctx* h, int64_t nchunk_total) {
   CK(ensure_feature_table(h));
   CK(ensure(h->part, (size_t)nchunk_total * (h->Fp + h->Kp) * h->Kp * sizeof(double)));
-  CK(ensure(h->packed, (size_t)svihmm_packed_size(h->K, h->D) * sizeof(double)));
+  CK(ensure(h->packed, (size_t)packed_len(h) * sizeof(double)));
   return 0;
 }
+// Categorical statistics: transition block on the pipelined GEMM (transition-only mode),
+// symbol counts by k_stats_cat, both reduced by k_finalize_cat into [A_raw | counts | lb]
+static int launch_stats_cat(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags) {
+  const int K = h->K, Kp = h->Kp, V = h->V, D = h->D;
+  if (K > 256) return fail("Categorical statistics: K > 256 unsupported");
+  const int KpT = (K + 63) / 64 * 64;
+  const int64_t n = (int64_t)B * Lm;
+  hipStream_t stream = h->stream;
+  CK(ensure_q(h, h->curB, Lq, stream));
+  const StatsPlan plan = stats_plan(n);
+  const int64_t rpcc = (n + 1023) / 1024 > 64 ? (n + 1023) / 1024 : 64;
+  const int nchunkc = (int)((n + rpcc - 1) / rpcc);
+  CK(ensure(h->part, (size_t)plan.nchunk * KpT * KpT * sizeof(double)));
+  CK(ensure(h->partc, (size_t)nchunkc * V * Kp * sizeof(double)));
+  CK(ensure(h->packed, packed_len(h) * sizeof(double)));
+  const uint8_t* mk = h->have_mask ? (const uint8_t*)h->mask.p : nullptr;
+  {
+    ProfScope ps(h, KS_STATS, stream);
+    const size_t lds = ((size_t)(D + 3 + 64) * ST_CC + 2 * (size_t)ST_RB * 65) * 8 + 4 * ST_RB * sizeof(StRow4);
+    hipFuncSetAttribute((const void*)k_stats_mfma4<1, 2, 2, 1, false, true>,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 g2((unsigned)plan.nchunk, KpT / 64, KpT / 64);
+    hipLaunchKernelGGL((k_stats_mfma4<1, 2, 2, 1, false, true>), g2, dim3(512), lds, stream,
+                       (const double*)h->obs.p, mk, (const int64_t*)h->starts.p, n, Lm, D, K, 0, 0,
+                       (const int*)nullptr, (const double*)h->q.p, plan.rpc, flags, Lq, off,
+                       (double*)h->part.p, KpT, 0, (const double*)nullptr, (const double*)nullptr,
+                       (const double*)nullptr, (const double2*)nullptr);
+    const size_t ldsc = (size_t)V * Kp * sizeof(double);
+    if (ldsc > 150 * 1024) return fail("Categorical statistics: V * K too large for the LDS table");
+    if (ldsc > 64 * 1024)
+      hipFuncSetAttribute((const void*)k_stats_cat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc);
+    hipLaunchKernelGGL(k_stats_cat, dim3((unsigned)nchunkc), dim3(64), ldsc, stream, (const double*)h->obs.p, mk,
+                       (const int64_t*)h->starts.p, n, Lm, K, Kp, V, (const double*)h->q.p, rpcc, Lq, off,
+                       (double*)h->partc.p);
+    HIPCK(hipGetLastError());
+  }
+  {
+    ProfScope ps(h, KS_FINALIZE, stream);
+    const int64_t tot = (int64_t)K * K + (int64_t)K * V;
+    hipLaunchKernelGGL(k_finalize_cat, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream,
+                       (const double*)h->part.p, (int)plan.nchunk, KpT, (const double*)h->partc.p, nchunkc,
+                       K, Kp, V, (double*)h->packed.p);
+    HIPCK(hipGetLastError());
+  }
+  return 0;
+}
+
 static int launch_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags) {
+  if (h->emis_cat) return launch_stats_cat(h, B, Lq, off, Lm, flags);
   const StatsPlan plan = stats_plan((int64_t)B * Lm);
   CK(ensure_stats(h, plan.nchunk));
   CK(launch_stats_range(h, 0, B, Lq, off, Lm, flags, plan, 0, h->stream));
@@ -1076,12 +1160,12 @@ static int prepare_ll(svihmm_ctx* h, const int64_t* starts, int B, int Lm, uint3
   } else {
     // K <= 64: the emission kernel owns whole rows and writes (Eh, kexp) itself; wider
     // models take the plain kernel plus one scaling pass
-    const bool two_pass = lin && h->Kp > 64;
+    const bool two_pass = lin && (h->Kp > 64 || h->emis_cat);
     CK(launch_emission(h, B, Lm, flags, lin && !two_pass));
     if (two_pass) CK(launch_scale_ll(h, B, Lm));
     h->have_host_ll = false;
   }
-  h->eh_in_llE = lin && (host_ll || h->Kp > 64);
+  h->eh_in_llE = lin && (host_ll || h->Kp > 64 || h->emis_cat);
   h->lin_mode = lin;
   h->lin_stale = false;
   h->q_valid = false;
@@ -1136,7 +1220,7 @@ static int intermediate_ptr(svihmm_ctx* h, int what, int64_t row0, int64_t nrows
 
 // copy `packed` into the host-visible mirror on the handle's stream
 static int launch_mirror(svihmm_ctx* h) {
-  const size_t n = (size_t)svihmm_packed_size(h->K, h->D);
+  const size_t n = (size_t)packed_len(h);
   if (n * sizeof(double) > h->mirror_cap) {
     if (h->mirror) hipHostFree(h->mirror);
     h->mirror = nullptr; h->mirror_cap = 0;
@@ -1153,7 +1237,7 @@ static int launch_mirror(svihmm_ctx* h) {
   return 0;
 }
 static int read_packed_host(svihmm_ctx* h, double* out) {
-  const size_t nb = (size_t)svihmm_packed_size(h->K, h->D) * sizeof(double);
+  const size_t nb = (size_t)packed_len(h) * sizeof(double);
   if (h->mirror_valid) {
     HIPCK(hipStreamSynchronize(h->stream));
     std::memcpy(out, h->mirror, nb);
@@ -1175,7 +1259,7 @@ static int read_packed_host(svihmm_ctx* h, double* out) {
 static bool use_pipeline(const svihmm_ctx* h, int B, int Lm, int fbvar, uint32_t flags) {
   const int v = h->variant[4];
   if (v == 1 || fbvar != 3 || (flags & SVIHMM_USE_HOST_LLIKS)) return false;
-  if (h->Kp > 64 || h->D > 64) return false;
+  if (h->Kp > 64 || h->D > 64 || h->emis_cat) return false;
   const int sv = h->variant[1];
   if (sv != 0 && sv != 3) return false;
   // opt-in only: on MI355X the sweeps' fp64 VALU work queues behind the GEMMs' MFMAs on a
@@ -1319,7 +1403,7 @@ int svihmm_estep_minibatch_ex(svihmm_ctx* h, const int64_t* starts, int32_t B, i
   CK(set_device(h));
   if (B == 0) {  // empty shard of a multi-GPU minibatch: all-zero statistics
     if (!h->have_globals || h->D <= 0) return fail("svihmm_estep_minibatch: set obs/globals first");
-    const size_t nb = (size_t)svihmm_packed_size(h->K, h->D) * sizeof(double);
+    const size_t nb = (size_t)packed_len(h) * sizeof(double);
     CK(ensure(h->packed, nb));
     HIPCK(hipMemsetAsync(h->packed.p, 0, nb, h->stream));
     h->have_packed = true;
@@ -1453,7 +1537,7 @@ int svihmm_allreduce_packed(svihmm_ctx* h) {
   if (!h->comm) return fail("svihmm_allreduce_packed: communicator not initialised");
   CK(set_device(h));
   ProfScope ps(h, KS_ALLREDUCE);
-  const size_t n = (size_t)svihmm_packed_size(h->K, h->D);
+  const size_t n = (size_t)packed_len(h);
   NCCLCK(ncclAllReduce(h->packed.p, h->packed.p, n, ncclDouble, ncclSum, h->comm, h->stream));
   h->mirror_valid = false;
   return launch_mirror(h);   // the host-visible copy follows the reduced statistics

@@ -31,6 +31,22 @@ class PackedStats(object):
         return K * K + K * D + K + K * D * D + 1
 
 
+class PackedCatStats(object):
+    """View of the packed statistics of a Categorical-emission E-step
+    ``[A_raw K*K | counts K*V | lb]`` (counts[k, v] = sum of var_x[t, k] over unmasked rows
+    with symbol v)."""
+
+    def __init__(self, buf, K, V):
+        self.buf, self.K, self.V = buf, K, V
+        self.A_raw = buf[:K * K].reshape(K, K)
+        self.counts = buf[K * K:K * K + K * V].reshape(K, V)
+        self.lb = buf[K * K + K * V:K * K + K * V + 1]
+
+    @staticmethod
+    def size(K, V):
+        return K * K + K * V + 1
+
+
 class HipEngine(object):
     """E-step engine on one MI355X.  Raises RuntimeError when the HIP library or
     a GPU is unavailable (no fallback)."""
@@ -44,6 +60,7 @@ class HipEngine(object):
         self._h = h
         self.device = int(device)
         self.T = self.D = self.K = 0
+        self.V = 0            # > 0: Categorical emission with V symbols is active
         self._comm = False
 
     # -- lifecycle ------------------------------------------------------------------
@@ -103,6 +120,7 @@ class HipEngine(object):
         L.check(self._lib.svihmm_set_emission_niw(self._h, K, D, L.dptr(mu), L.dptr(sigma),
                                                   L.dptr(kappa), L.dptr(nu)),
                 "svihmm_set_emission_niw")
+        self.V = 0
         if check:
             L.check(self._lib.svihmm_sync(self._h), "svihmm_set_emission_niw")
 
@@ -146,12 +164,25 @@ class HipEngine(object):
         statistics stay in HBM for allreduce()).  ``inner=(off, length)`` restricts
         the statistics to that segment of every window (buffered meta-observations)."""
         st = self._starts(starts)
-        out = np.empty(PackedStats.size(self.K, self.D)) if read else None
+        out = np.empty(self._packed_len()) if read else None
         off, ln = (0, int(Lm)) if inner is None else (int(inner[0]), int(inner[1]))
         L.check(self._lib.svihmm_estep_minibatch_ex(self._h, L.i64ptr(st), len(st), int(Lm),
                                                     off, ln, int(flags), L.dptr(out)),
                 "svihmm_estep_minibatch")
-        return PackedStats(out, self.K, self.D) if read else None
+        return self._wrap_packed(out) if read else None
+
+    def _packed_len(self):
+        return PackedCatStats.size(self.K, self.V) if self.V else PackedStats.size(self.K, self.D)
+
+    def _wrap_packed(self, buf):
+        return PackedCatStats(buf, self.K, self.V) if self.V else PackedStats(buf, self.K, self.D)
+
+    def set_emission_cat(self, logp):
+        """Categorical emissions: ``logp[k, v] = E_q log theta_k[v]`` (obs = symbol indices)."""
+        logp = L.as_f64(logp)
+        K, V = logp.shape
+        L.check(self._lib.svihmm_set_emission_cat(self._h, K, V, L.dptr(logp)), "svihmm_set_emission_cat")
+        self.V = V
 
     def pred_logprob(self, starts, Lm, flags=L.MASK_AS_NAN):
         """Mean predictive log-probability of the masked rows of the windows and their number
@@ -164,9 +195,9 @@ class HipEngine(object):
         return (float(out[0]) if n > 0 else None), n
 
     def read_packed(self):
-        out = np.empty(PackedStats.size(self.K, self.D))
+        out = np.empty(self._packed_len())
         L.check(self._lib.svihmm_read_packed(self._h, L.dptr(out)), "svihmm_read_packed")
-        return PackedStats(out, self.K, self.D)
+        return self._wrap_packed(out)
 
     def read_intermediate(self, what, B, Lm):
         idx = {"lliks": 0, "lalpha": 1, "lbeta": 2, "var_x": 3}[what]

@@ -157,6 +157,15 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
     def _niw_fastpath(self):
         return all(is_niw_gaussian(e) for e in self.var_emit)
 
+    def _cat_fastpath(self):
+        """Categorical emissions over one integer-valued observation column (the device keeps
+        the E log theta table and counts symbols; reference hmmsgd_metaobs.py:907-926)."""
+        from .distributions import Categorical
+        ve = self.var_emit
+        return (all(type(e) is Categorical for e in ve)
+                and len({e.num_parameters() for e in ve}) == 1
+                and (self.obs.ndim == 1 or self.obs.shape[1] == 1))
+
     def _emit_vlb(self):
         """sum_k var_emit[k].get_vlb() (reference hmmbase.py:183-185), batched for NIW
         Gaussians."""
@@ -184,6 +193,12 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
         upload ``lliks``.  Returns the flag word for the engine calls."""
         if self._niw_fastpath():
             self.engine.set_emission_niw(*self._emission_arrays())
+            return L.MASK_AS_NAN if nan_mask else 0
+        if self._cat_fastpath():
+            # Categorical: E log theta table (pybasicbayes Categorical.expected_log_likelihood),
+            # looked up on the device
+            table = np.stack([digamma(e.alpha_mf) - digamma(np.sum(e.alpha_mf)) for e in self.var_emit])
+            self.engine.set_emission_cat(table)
             return L.MASK_AS_NAN if nan_mask else 0
         obs = self.obs if self.obs.ndim == 2 else self.obs[:, None]
         if windows is None:

@@ -207,7 +207,7 @@ class VBHMM(VariationalHMMBase):
         np.random.seed(self.seed)
         if (type(self).local_update is not VBHMM.local_update
                 or type(self).intermediate_pars is not VBHMM.intermediate_pars
-                or not self._niw_fastpath()):
+                or not (self._niw_fastpath() or self._cat_fastpath())):
             # subclass overrides, or an emission family the device statistics kernels
             # do not know (the reference dispatches on the type too, :887,907):
             # follow the reference loop literally, E-step recursions still on the device
@@ -261,7 +261,12 @@ class VBHMM(VariationalHMMBase):
             else:
                 lb = 0.
                 A_inter = np.zeros_like(self.var_tran)
-                emit_inter = [util.NIW_zero_nat_pars(self.var_emit[0]) for k in range(K)]
+                if type(self.var_emit[0]) is Categorical:
+                    # the reference calls util.NIW_zero_nat_pars here for every family
+                    # (:399), which raises for a Categorical; zeros of the right shape instead
+                    emit_inter = [np.zeros(self.var_emit[0].num_parameters()) for k in range(K)]
+                else:
+                    emit_inter = [util.NIW_zero_nat_pars(self.var_emit[0]) for k in range(K)]
                 for data in minibatch:
                     self.cur_mo = data
                     self._stationary_init()
@@ -326,7 +331,11 @@ class VBHMM(VariationalHMMBase):
             st = comm.allreduce_stats(self.engine, K, D)
         # quirk Q2: prior_tran - 1 is part of every window's A_i
         A_inter = st.A_raw + nwin * (self.prior_tran - 1.)
-        emit_inter = _StackedStats(st.xbar.copy(), st.neff.copy(), st.S.copy())
+        if hasattr(st, "counts"):
+            # Categorical (reference :907-926): every window contributes alpha_0 + counts - 1
+            emit_inter = [nwin * (G.alphav_0 - 1.) + st.counts[k] for k, G in enumerate(self.var_emit)]
+        else:
+            emit_inter = _StackedStats(st.xbar.copy(), st.neff.copy(), st.S.copy())
         lb = float(st.lb[0])
         # leave the object as the reference does after the loop: state of the last window
         self.cur_mo = minibatch[-1]
