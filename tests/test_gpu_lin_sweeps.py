@@ -186,3 +186,30 @@ def test_two_stream_pipeline_vs_oracle(eng, K, B, inner):
     x[pb["mask"][s0:s0 + Lm]] = np.nan
     ll = ref_c.lliks_niw(x, pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
     np.testing.assert_allclose(la, ref_c.forward(ll, pb["mod_init"], pb["ltran"]), rtol=1e-9, atol=1e-8)
+
+
+@pytest.mark.parametrize("K,Lm,B", [(1, 7, 200), (2, 3000, 192), (64, 1500, 193)])
+def test_extreme_shapes(eng, K, Lm, B):
+    """Degenerate state counts and long windows on the scaled sweeps: exponents accumulate over
+    thousands of steps (|log-likelihood| ~ 1e4 per window) without losing the statistics."""
+    from pysvihmm_amd import _lib as L
+    from oracle import ref_c
+    D = 2
+    T = Lm * 4 + 50
+    pb = make_problem(K, D, T, seed=900 + K, miss=0.05, sep=4.0)
+    rng = np.random.default_rng(K + Lm)
+    starts = rng.integers(0, T - Lm + 1, size=B)
+    _push(eng, pb)
+    st = eng.estep(starts, Lm, flags=L.TRANS_WRAP)
+    sub = np.unique(rng.integers(0, B, size=6))
+    st2 = eng.estep(starts[sub], Lm, flags=L.TRANS_WRAP)      # same windows on the per-window path
+    ref = ref_c.estep_minibatch(pb["obs"], pb["mask"], starts[sub], Lm, pb["mod_init"], pb["ltran"],
+                                pb["mu"], pb["sigma"], pb["kappa"], pb["nu"], flags=2)
+    np.testing.assert_allclose(st2.buf, ref, rtol=RTOL, atol=1e-7 * len(sub) * Lm)
+    assert np.all(np.isfinite(st.buf))
+    np.testing.assert_allclose(st.A_raw.sum(), B * Lm, rtol=1e-10)
+    # the scaled path on those windows alone (forced) equals the per-window path
+    eng.set_variant("fb", 3)
+    st3 = eng.estep(starts[sub], Lm, flags=L.TRANS_WRAP)
+    eng.set_variant("fb", 0)
+    np.testing.assert_allclose(st3.buf, st2.buf, rtol=1e-8, atol=1e-9 * len(sub) * Lm)
