@@ -560,28 +560,28 @@ template <int NW, bool FULL>
 __device__ __forceinline__ void lin_matmul_stream(const LinShared<NW>& sh, int cur, int li, int lg,
                                                   const double* __restrict__ Bcol, int K,
                                                   double4_t& acc, double4_t& tot) {
-  // 16 waves per workgroup leave 128 VGPRs per wave: deeper explicit prefetch of the B values
-  // (register sets of 8, two or three deep) spills and is slower than this plain form, in
-  // which the other three waves of the SIMD cover the L2 latency.
+  // A rolled loop with running pointers (unroll 4): fully unrolled, the compiler turns the
+  // lane addresses of the streamed tile into loop invariants of the time loop and spills
+  // them.  Rows beyond K come from the zeroed slack behind the matrices.
   constexpr int KS = 4 * NW;
   double4_t a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
-  const double* prow = &sh.P[cur][li][2 * lg];
+  const double* pr = &sh.P[cur][li][2 * lg];
+  const double* __restrict__ pb = Bcol + (size_t)(2 * lg) * K;
+  const size_t K1 = (size_t)K, K8 = (size_t)8 * K, K9 = (size_t)9 * K, K16 = (size_t)16 * K;
   double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-  for (int c = 0; c < KS / 2; c += 2) {
-    const int k0 = 8 * c + 2 * lg, k2 = 8 * (c + 1) + 2 * lg;
-    const int r0 = FULL ? k0 : min(k0, K - 1), r1 = FULL ? k0 + 1 : min(k0 + 1, K - 1);
-    const int r2 = FULL ? k2 : min(k2, K - 1), r3 = FULL ? k2 + 1 : min(k2 + 1, K - 1);
-    const double b0 = Bcol[(size_t)r0 * K], b1 = Bcol[(size_t)r1 * K];
-    const double b2 = Bcol[(size_t)r2 * K], b3 = Bcol[(size_t)r3 * K];
-    const double2 x = *reinterpret_cast<const double2*>(prow + 8 * c);
-    const double2 y = *reinterpret_cast<const double2*>(prow + 8 * (c + 1));
+#pragma unroll 4
+  for (int c = 0; c < KS / 4; ++c) {
+    const double b0 = pb[0], b1 = pb[K1], b2 = pb[K8], b3 = pb[K9];
+    pb += K16;
+    const double2 x = *reinterpret_cast<const double2*>(pr);
+    const double2 y = *reinterpret_cast<const double2*>(pr + 8);
+    pr += 16;
     a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, b0, a0, 0, 0, 0);
     a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, b1, a1, 0, 0, 0);
     a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(y.x, b2, a2, 0, 0, 0);
     a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(y.y, b3, a3, 0, 0, 0);
-    s0 = (c == 0) ? x.x + y.x : s0 + (x.x + y.x);
-    s1 = (c == 0) ? x.y + y.y : s1 + (x.y + y.y);
+    s0 += x.x + y.x;
+    s1 += x.y + y.y;
   }
   const double4_t z = {0, 0, 0, 0};
   tot = __builtin_amdgcn_mfma_f64_16x16x4f64(s0 + s1, 1.0, z, 0, 0, 0);
@@ -910,6 +910,181 @@ __global__ __launch_bounds__(64 * NW) void k_sweeps_lin(
                                                    local_lb, logz, zfac, ch);
   else
     bwd_lin_body<NW, FULL, (MODE == 1 ? 1 : 0), BS>(sh, Eh, AexpT, B, Lm, wstride, K, bh, gx, ch);
+}
+
+// ------------------------------------------------------------------------------------
+//  K2e', wide models (128 < K <= 256): the same scaled sweeps with TWO state tiles per wave.
+//  With one tile per wave a K = 256 workgroup needs 16 waves, i.e. four per SIMD and only
+//  128 VGPRs each -- no room to prefetch the streamed transition tile, the kernel is then
+//  bound by L2 round trips (23 us per step).  Eight waves of two tiles get 256 VGPRs, share
+//  every A operand between their two MFMAs, and the compiler can keep a whole group of B
+//  values in flight.  Ordinary windows only (no chain modes); both directions in one launch.
+// ------------------------------------------------------------------------------------
+template <int NW, bool FULL>
+__global__ __launch_bounds__(64 * NW) void k_sweeps_lin2(
+    const double* __restrict__ Eh, const double* __restrict__ kexp,
+    const double* __restrict__ Aexp, const double* __restrict__ AexpT,
+    const double* __restrict__ mod_init, int B, int Lm, int K, double* __restrict__ ah,
+    double* __restrict__ bh, double* __restrict__ hx, double* __restrict__ gx,
+    double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac) {
+  constexpr int NT = 2 * NW, KS = 4 * NT;
+  extern __shared__ double __attribute__((aligned(16))) lin_smem[];
+  LinShared<NT>& sh = *reinterpret_cast<LinShared<NT>*>(lin_smem);
+  const bool fwd = blockIdx.y == 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int j0 = wave * 32 + li, j1 = j0 + 16;
+  const bool v0 = FULL || j0 < K, v1 = FULL || j1 < K;
+  const int jc0 = v0 ? j0 : 0, jc1 = v1 ? j1 : 0;
+  const int b0 = blockIdx.x * 16;
+  const size_t wrow = (size_t)b0 * Lm;
+  const double* __restrict__ Eb = Eh + wrow * K;
+  double* __restrict__ ob = (fwd ? ah : bh) + wrow * K;      // stored vector: ah (fwd) / bh (bwd)
+  double* __restrict__ xb = (fwd ? hx : gx) + wrow;          // its exponent stream
+  // B operand addressing: uniform row base (scalar registers) + one 32-bit lane offset per
+  // tile; rows beyond K are read from the zeroed slack the host keeps behind the matrices
+  const double* __restrict__ Bm = fwd ? Aexp : AexpT;
+  const int lo0 = 2 * lg * K + jc0, lo1 = 2 * lg * K + jc1;
+  unsigned oR[4], oE[4], oRw;
+  int gwc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int gw = b0 + lg + 4 * r;
+    gwc[r] = gw < B ? gw : B - 1;
+    oR[r] = (unsigned)(gwc[r] - b0) * (unsigned)Lm;
+    oE[r] = oR[r] * (unsigned)K;
+  }
+  {
+    const int gww = b0 + lg + 4 * (wave & 3);
+    oRw = (unsigned)((gww < B ? gww : B - 1) - b0) * (unsigned)Lm;
+  }
+  // row touched by sweep step s (s = 0: the initial row)
+  auto rowof = [&](int s) { return fwd ? s : Lm - 1 - s; };
+  double h[4], mant[4], hsum[4];
+  int ex[4];
+  {
+    double s0 = 0.0, p0 = 1.0, p1 = 1.0;
+    if (fwd) {
+      double mi_max = -INFINITY;
+      for (int k = 0; k < K; ++k) mi_max = fmax(mi_max, mod_init[k]);
+      s0 = (mi_max > -1e300 && mi_max < 1e300) ? ceil(mi_max * LOG2E_D) : 0.0;
+      p0 = v0 ? exp(fma(-s0, LN2_LO_D, fma(-s0, LN2_HI_D, mod_init[jc0]))) : 0.0;
+      p1 = v1 ? exp(fma(-s0, LN2_LO_D, fma(-s0, LN2_HI_D, mod_init[jc1]))) : 0.0;
+    }
+    const size_t ro = (size_t)rowof(0) * K;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double e0 = (Eb + ro)[oE[r] + jc0], e1 = (Eb + ro)[oE[r] + jc1];
+      // forward: ah_0 = pi * Eh_0 (stored), P = ah_0;  backward: bh_top = 1 (stored), P = Eh_top
+      const double s0v = fwd ? p0 * e0 : 1.0, s1v = fwd ? p1 * e1 : 1.0;
+      if (v0) (ob + ro)[oE[r] + jc0] = s0v;
+      if (v1) (ob + ro)[oE[r] + jc1] = s1v;
+      sh.P[0][lg + 4 * r][j0] = v0 ? (fwd ? s0v : e0) : 0.0;
+      sh.P[0][lg + 4 * r][j1] = v1 ? (fwd ? s1v : e1) : 0.0;
+      h[r] = s0; mant[r] = 1.0; ex[r] = 0; hsum[r] = 0.0;
+    }
+    (xb + rowof(0))[oRw] = s0;
+  }
+  __syncthreads();
+  for (int s = 1; s < Lm; ++s) {
+    const int cur = (s - 1) & 1, nxt = s & 1;
+    const int t = rowof(s);
+    const size_t ro = (size_t)t * K;
+    double e0[4], e1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { e0[r] = (Eb + ro)[oE[r] + jc0]; e1[r] = (Eb + ro)[oE[r] + jc1]; }
+    // out[w][j] = sum_i P[w][i] M[i][j] for this wave's two tiles; tot[w] = sum_i P[w][i]
+    double4_t p0 = {0, 0, 0, 0}, p1 = p0, q0 = p0, q1 = p0;
+    const double* pr = &sh.P[cur][li][2 * lg];
+    // A rolled loop with running pointers: fully unrolled, the compiler materialises all 256
+    // lane addresses of the streamed tile as loop invariants of the time loop and spills them.
+    const double* __restrict__ pb0 = Bm + lo0;
+    const double* __restrict__ pb1 = Bm + lo1;
+    const size_t K1 = (size_t)K, K8 = (size_t)8 * K, K9 = (size_t)9 * K, K16 = (size_t)16 * K;
+    double sa = 0.0, sb = 0.0;
+#pragma unroll 4
+    for (int c = 0; c < KS / 4; ++c) {        // 4 k-steps (16 transition rows) per trip
+      const double b00 = pb0[0], b01 = pb0[K1], b02 = pb0[K8], b03 = pb0[K9];
+      const double b10 = pb1[0], b11 = pb1[K1], b12 = pb1[K8], b13 = pb1[K9];
+      pb0 += K16; pb1 += K16;
+      const double2 x = *reinterpret_cast<const double2*>(pr);
+      const double2 y = *reinterpret_cast<const double2*>(pr + 8);
+      pr += 16;
+      p0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, b00, p0, 0, 0, 0);
+      q0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, b10, q0, 0, 0, 0);
+      p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, b01, p1, 0, 0, 0);
+      q1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, b11, q1, 0, 0, 0);
+      p0 = __builtin_amdgcn_mfma_f64_16x16x4f64(y.x, b02, p0, 0, 0, 0);
+      q0 = __builtin_amdgcn_mfma_f64_16x16x4f64(y.x, b12, q0, 0, 0, 0);
+      p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y.y, b03, p1, 0, 0, 0);
+      q1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y.y, b13, q1, 0, 0, 0);
+      sa += x.x + y.x;
+      sb += x.y + y.y;
+    }
+    const double4_t z = {0, 0, 0, 0};
+    const double4_t tot = __builtin_amdgcn_mfma_f64_16x16x4f64(sa + sb, 1.0, z, 0, 0, 0);
+    const double4_t acc0 = p0 + p1, acc1 = q0 + q1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e2 = __builtin_amdgcn_frexp_exp(tot[r]);
+      double o0, o1, n0, n1;      // stored value, next P value
+      if (fwd) {
+        o0 = v0 ? ldexp(acc0[r] * e0[r], -e2) : 0.0; o1 = v1 ? ldexp(acc1[r] * e1[r], -e2) : 0.0;
+        n0 = o0; n1 = o1;
+        const double mm = mant[r] * tot[r];
+        ex[r] += __builtin_amdgcn_frexp_exp(mm);
+        mant[r] = __builtin_amdgcn_frexp_mant(mm);
+        hsum[r] += h[r];
+      } else {
+        o0 = v0 ? ldexp(acc0[r], -e2) : 0.0; o1 = v1 ? ldexp(acc1[r], -e2) : 0.0;
+        n0 = e0[r] * o0; n1 = e1[r] * o1;
+      }
+      sh.P[nxt][lg + 4 * r][j0] = n0;
+      sh.P[nxt][lg + 4 * r][j1] = n1;
+      if (v0) (ob + ro)[oE[r] + jc0] = o0;
+      if (v1) (ob + ro)[oE[r] + jc1] = o1;
+      h[r] += (double)e2;
+    }
+    (xb + t)[oRw] = sel4(h, wave & 3);
+    __syncthreads();
+  }
+  if (!fwd) return;
+  // ---- forward epilogue: K sums, Z, local_lb (as in fwd_lin_body)
+  {
+    const int last = (Lm - 1) & 1;
+    double* scr = &sh.P[1 - last][0][0];
+    const double* __restrict__ kbw = kexp + wrow;
+    for (int w = threadIdx.x >> 4; w < 16; w += 4 * NW) {
+      const int gw = b0 + w;
+      const unsigned o = (unsigned)((gw < B ? gw : B - 1) - b0) * (unsigned)Lm;
+      double a = 0.0, c = 0.0;
+      for (int t = li; t < Lm; t += 16) {
+        const double kv = kbw[o + t];
+        a += kv;
+        c += kv * (double)(Lm - t);
+      }
+      a = row16_sum(a);
+      c = row16_sum(c);
+      if (li == 0) { scr[w] = a; scr[16 + w] = c; }
+    }
+    __syncthreads();
+    const double4_t tot = lin_rowsum<NT>(sh, last, li, lg);
+    if (wave == 0 && li == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int w = lg + 4 * r;
+        const double Ktop = scr[w], KK = scr[16 + w];
+        const double mm = mant[r] * tot[r];
+        const int exf = ex[r] + __builtin_amdgcn_frexp_exp(mm);
+        const double mf = __builtin_amdgcn_frexp_mant(mm);
+        const double zm = __builtin_amdgcn_frexp_mant(tot[r]);
+        const double zexp = (double)__builtin_amdgcn_frexp_exp(tot[r]);
+        local_lb[gwc[r]] = log(mf) + ((double)exf + hsum[r] + h[r] + KK) * LN2_D;
+        logz[gwc[r]] = log(zm) + (h[r] + Ktop + zexp) * LN2_D;
+        zfac[gwc[r]] = make_double2(1.0 / zm, h[r] + zexp);
+      }
+    }
+  }
 }
 
 // S2 of the chain scan: boundary vectors.  grid 2 (0: alpha at chunk starts, 1: beta at chunk

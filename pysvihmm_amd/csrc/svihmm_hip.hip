@@ -281,8 +281,12 @@ int svihmm_set_globals(svihmm_ctx* h, int32_t K, const double* mod_init, const d
   const size_t kk = (size_t)K * K * sizeof(double);
   CK(ensure(h->mod_init, K * sizeof(double)));
   CK(ensure(h->ltran, kk));
-  CK(ensure(h->Aexp, kk));
-  CK(ensure(h->AexpT, kk));
+  // 16 zero rows behind each matrix: the wide-model sweeps read whole 16-state tiles of rows
+  const size_t slack = (size_t)16 * K * sizeof(double);
+  CK(ensure(h->Aexp, kk + slack));
+  CK(ensure(h->AexpT, kk + slack));
+  HIPCK(hipMemsetAsync((char*)h->Aexp.p + kk, 0, slack, h->stream));
+  HIPCK(hipMemsetAsync((char*)h->AexpT.p + kk, 0, slack, h->stream));
   void* pin = nullptr;
   int slot = 0;
   CK(pinned(h, kk + K * sizeof(double), &pin, &slot));
@@ -733,8 +737,22 @@ static int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_
   else if (NW == 3) { if (full) SWP(3, true); else SWP(3, false); }
   else if (NW == 4) { if (full) SWP(4, true); else SWP(4, false); }
   else if (NW <= 8) { if (K == 128) SWPX(8, true, true); else SWPX(8, false, true); }      // K > 64: B streamed
-  else if (NW <= 12) { if (K == 192) SWPX(12, true, true); else SWPX(12, false, true); }
-  else { if (K == 256) SWPX(16, true, true); else SWPX(16, false, true); }
+  else {
+    // 128 < K <= 256: eight waves of two state tiles (256 VGPRs each) instead of 16 x 1
+#define SWP2(F)                                                                                            \
+  do {                                                                                                     \
+    const size_t lds = sizeof(LinShared<16>);                                                              \
+    hipFuncSetAttribute((const void*)k_sweeps_lin2<8, F>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                        (int)lds);                                                                         \
+    hipLaunchKernelGGL((k_sweeps_lin2<8, F>), grid, dim3(512), lds, stream, Eh, kx,                        \
+                       (const double*)h->Aexp.p, (const double*)h->AexpT.p, (const double*)h->mod_init.p,  \
+                       nb, Lm, K, ah, bh, hx, gx, llb, lz, zf);                                            \
+  } while (0)
+    if (h->variant[7] == 1) { if (NW <= 12) { if (K == 192) SWPX(12, true, true); else SWPX(12, false, true); }
+                              else { if (K == 256) SWPX(16, true, true); else SWPX(16, false, true); } }
+    else if (K == 256) SWP2(true); else SWP2(false);
+#undef SWP2
+  }
 #undef SWP
 #undef SWPX
   HIPCK(hipGetLastError());
