@@ -1301,20 +1301,20 @@ __global__ void k_sum_lb(const double* __restrict__ local_lb, int B, double* __r
 
 // ------------------------------------------------------------------------------------
 //  K3: posterior marginals q = softmax_k(la+lb) and per-row LSE_k(la) partial sums.
-//      grid (B*nseg), block 256 = 4 waves, one wave per row; seg = PS_ROWS rows.
+//      grid (B*nseg), block 256 = 4 waves, one wave per row; seg = rps rows (the host picks
+//      short segments for small batches so that a 64-window minibatch still fills the chip).
 // ------------------------------------------------------------------------------------
-#define PS_ROWS 256
 template <int KPL>  // states per lane (K <= 64*KPL)
 __global__ __launch_bounds__(256) void k_posterior(const double* __restrict__ la,
                                                    const double* __restrict__ lb, int Lm,
-                                                   int K, int nseg,
+                                                   int K, int nseg, int rps,
                                                    double* __restrict__ q,
                                                    double* __restrict__ lse_part) {
   __shared__ double wsum[4];
   const int b = blockIdx.x / nseg, seg = blockIdx.x - b * nseg;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int t0 = seg * PS_ROWS;
-  const int t1 = min(Lm, t0 + PS_ROWS);
+  const int t0 = seg * rps;
+  const int t1 = min(Lm, t0 + rps);
   double lse_acc = 0.0;
   for (int t = t0 + wave; t < t1; t += 4) {
     const size_t base = ((size_t)b * Lm + t) * K;

@@ -615,7 +615,10 @@ static int launch_fb(svihmm_ctx* h, int B, int Lm, int dir0, int ndir,
 
 static int launch_posterior(svihmm_ctx* h, int B, int Lm, bool total) {
   const int K = h->K;
-  const int nseg = (Lm + PS_ROWS - 1) / PS_ROWS;
+  // rows per workgroup: 256 for big batches, down to 16 so that small ones give >= ~2048 workgroups
+  int rps = 256;
+  while (rps > 16 && (int64_t)B * ((Lm + rps - 1) / rps) < 2048) rps >>= 1;
+  const int nseg = (Lm + rps - 1) / rps;
   CK(ensure(h->q, (size_t)B * Lm * K * sizeof(double)));
   CK(ensure(h->lse_part, (size_t)B * nseg * sizeof(double)));
   CK(ensure(h->local_lb, (size_t)B * sizeof(double)));
@@ -624,7 +627,7 @@ static int launch_posterior(svihmm_ctx* h, int B, int Lm, bool total) {
   dim3 grid((unsigned)((size_t)B * nseg));
 #define POST_LAUNCH(KPL)                                                                  \
   hipLaunchKernelGGL(k_posterior<KPL>, grid, dim3(256), 0, h->stream, (const double*)h->la.p, \
-                     (const double*)h->lb.p, Lm, K, nseg, (double*)h->q.p, (double*)h->lse_part.p)
+                     (const double*)h->lb.p, Lm, K, nseg, rps, (double*)h->q.p, (double*)h->lse_part.p)
   if (K <= 64) POST_LAUNCH(1);
   else if (K <= 256) POST_LAUNCH(4);
   else POST_LAUNCH(16);
