@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_emission_mfma(
     const int rpp = 256 >> sh, i = tid & ((1 << sh) - 1), rr = tid >> sh;
     for (int rb = 0; rb < ROWS; rb += rpp) {
       const int r = rb + rr;
-      if (i < D) {
+      if (i < D && r < ROWS) {   // (256 >> sh rows per pass can exceed a 64-row tile)
         const long long o = rowoff[r];
         double v = o >= 0 ? obs[o + i] : 0.0;
         if (v != v) { bad_s[r] = 1; v = 0.0; }
