@@ -118,7 +118,12 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
         return self._engine
 
     def __getstate__(self):
+        pend = self.__dict__.get("_pending_rows")
+        if pend is not None:      # resolve device-resident attributes before the handle goes
+            for name in list(pend[2]):
+                getattr(self, name)
         d = dict(self.__dict__)
+        d.pop('_pending_rows', None)
         d['_engine'] = None       # device handles are not picklable
         d['_obs_dirty'] = True
         return d

@@ -57,9 +57,38 @@ class MetaObs(object):
         self.i2 = i2
 
 
+def _lazy_window_attr(name):
+    """``lliks / lalpha / lbeta / var_x`` of the last window of a fused minibatch: the reference
+    leaves them on the object after every iteration (:396-436); here they are fetched from the
+    device on first access instead of every iteration (the large-batch device path does not
+    even materialise logarithms unless asked).  Assigning the attribute works as usual."""
+    key = "_val_" + name
+
+    def get(self):
+        pend = self.__dict__.get("_pending_rows")
+        if pend is not None and name in pend[2]:
+            row0, nrows, names = pend
+            names.discard(name)
+            self.__dict__[key] = self.engine.read_rows(name, row0, nrows)
+        return self.__dict__[key]
+
+    def set_(self, value):
+        pend = self.__dict__.get("_pending_rows")
+        if pend is not None:
+            pend[2].discard(name)
+        self.__dict__[key] = value
+
+    return property(get, set_)
+
+
 class VBHMM(VariationalHMMBase):
     """ Stochastic variational inference for finite HMMs using natural gradients;
     consecutive groups of nodes are sampled as a "meta-observation"."""
+
+    lliks = _lazy_window_attr("lliks")
+    lalpha = _lazy_window_attr("lalpha")
+    lbeta = _lazy_window_attr("lbeta")
+    var_x = _lazy_window_attr("var_x")
 
     @staticmethod
     def make_param_dict(prior_init, prior_tran, prior_emit, tau=tau0,
@@ -299,8 +328,19 @@ class VBHMM(VariationalHMMBase):
                 self.pred_logprob_full_mean[it] = np.nanmean(tmp)
                 self.pred_logprob_full_std[it] = np.nanstd(tmp)
 
+        # the last window's lliks / lalpha / lbeta / var_x now (no lazy state survives infer:
+        # a later call that uploads new parameters could no longer rebuild them)
+        self._resolve_pending()
+
         # So that the hmm object can be pickled
         self.metaobs_fun = None
+
+    def _resolve_pending(self):
+        pend = self.__dict__.get("_pending_rows")
+        if pend is not None:
+            for name in list(pend[2]):
+                getattr(self, name)
+            self.__dict__.pop("_pending_rows", None)
 
     def _minibatch_estep(self, minibatch, miniL, buffer=None):
         """All windows of the minibatch in one device E-step; returns
@@ -341,8 +381,8 @@ class VBHMM(VariationalHMMBase):
         self.cur_mo = minibatch[-1]
         if len(starts):
             b = len(starts) - 1
-            for name in ("lliks", "lalpha", "lbeta", "var_x"):
-                setattr(self, name, self.engine.read_rows(name, b * Lm, Lm))
+            # state of the last window, fetched on first access (valid until the next upload)
+            self._pending_rows = (b * Lm, Lm, {"lliks", "lalpha", "lbeta", "var_x"})
             self._lZ = None
         return A_inter, emit_inter, lb
 
