@@ -1087,6 +1087,142 @@ __global__ __launch_bounds__(64 * NW) void k_sweeps_lin2(
   }
 }
 
+// ------------------------------------------------------------------------------------
+//  K2e'', small batches (K <= 64): the scaled recursion with one wavefront per (window,
+//  direction), lane = state.  Same inputs / outputs as k_sweeps_lin (Eh, kexp -> ah, hx / bh,
+//  gx, local_lb, logz, zfac), so the consumers (statistics GEMM, k_lin_posterior) do not care
+//  which of the two produced them.  The MFMA kernel needs >= 16 windows per workgroup and
+//  ~0.9 us per step; this one has no exp / log / max on the step's critical path either
+//  (LDS broadcast of the previous vector, 64 FMAs in four chains against the transition
+//  column held in registers, exponent from the previous vector's sum) and takes 0.56 us per
+//  step (0.6 - 0.7 with 64 - 512 windows x 2 directions in flight) -- the 64-window minibatch of
+//  configs[2] and every short single chain.
+// ------------------------------------------------------------------------------------
+// FULLK (K == 64: every lane is a state): no per-lane predicates in the time loop, which then
+// is a single basic block -- stores and the prefetched Eh load are waited for with counted
+// vmcnt instead of a full drain per step.  The exponent stream is written 64 steps at a time
+// (lane s & 63 keeps h_s; one coalesced store per 64 steps): 64 lanes storing one address
+// every step serialise in the memory pipeline.
+template <int KMAX, bool FULLK>
+__global__ __launch_bounds__(64) void k_wave_lin(
+    const double* __restrict__ Eh, const double* __restrict__ kexp,
+    const double* __restrict__ Aexp, const double* __restrict__ AexpT,
+    const double* __restrict__ mod_init, int Lm, int K, double* __restrict__ ah,
+    double* __restrict__ bh, double* __restrict__ hx, double* __restrict__ gx,
+    double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac) {
+  __shared__ double p_s[2][64];
+  const int b = blockIdx.x, j = threadIdx.x;
+  const bool fwd = blockIdx.y == 0;
+  static_assert(!FULLK || KMAX == 64, "FULLK: all 64 lanes are states");
+  const bool valid = FULLK || j < K;
+  const int jc = valid ? j : 0;
+  // fwd: a[i] = A[i][j] (column j);  bwd: a[i] = A[j][i] = AexpT[i][j]
+  const double* __restrict__ Am = fwd ? Aexp : AexpT;
+  double a[KMAX];
+#pragma unroll
+  for (int i = 0; i < KMAX; ++i) a[i] = (valid && i < K) ? Am[(size_t)i * K + jc] : 0.0;
+  const size_t wrow = (size_t)b * Lm;
+  const double* __restrict__ Eb = Eh + wrow * K + jc;
+  double* __restrict__ ob = (fwd ? ah : bh) + wrow * K + jc;
+  double* __restrict__ xb = (fwd ? hx : gx) + wrow;
+  auto rowof = [&](int s) { return fwd ? s : Lm - 1 - s; };
+  double h = 0.0, mant = 1.0, hsum = 0.0;
+  int ex = 0;
+  double pcur;      // the vector entering the next mat-vec: ah_{t-1} (fwd) / Eh_{t+1} bh_{t+1} (bwd)
+  {
+    const int t = rowof(0);
+    const double e0 = Eb[(size_t)t * K];
+    double o;
+    if (fwd) {
+      double mi_max = -INFINITY;
+      for (int k = 0; k < K; ++k) mi_max = fmax(mi_max, mod_init[k]);
+      h = (mi_max > -1e300 && mi_max < 1e300) ? ceil(mi_max * LOG2E_D) : 0.0;
+      o = valid ? exp(fma(-h, LN2_LO_D, fma(-h, LN2_HI_D, mod_init[jc]))) * e0 : 0.0;
+      pcur = o;
+    } else {
+      o = valid ? 1.0 : 0.0;
+      pcur = valid ? e0 : 0.0;
+    }
+    if (valid) ob[(size_t)t * K] = o;
+  }
+  double hkeep = h;     // lane (s & 63) keeps the exponent of sweep step s
+  // Eh rows are fetched PD steps ahead (one register each): a single window has nothing else
+  // to hide the HBM latency of a long chain behind
+  constexpr int PD = 4;
+  auto eload = [&](int s) { return Eb[(size_t)rowof(s < Lm ? s : Lm - 1) * K]; };
+  double eq[PD];
+#pragma unroll
+  for (int u = 0; u < PD; ++u) eq[u] = eload(1 + u);
+  auto step = [&](int s, double et) {
+    const int cur = s & 1;
+    const int t = rowof(s);
+    p_s[cur][j] = pcur;
+    __syncthreads();
+    // exponent and bookkeeping from the entering vector (off the mat-vec's dependency chain)
+    const double tot = wave_sum_dpp(pcur);
+    const int e2 = __builtin_amdgcn_frexp_exp(tot);
+    if (fwd) {
+      const double mm = mant * tot;
+      ex += __builtin_amdgcn_frexp_exp(mm);
+      mant = __builtin_amdgcn_frexp_mant(mm);
+      hsum += h;
+    }
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+    for (int i = 0; i < KMAX; i += 4) {
+      s0 = fma(p_s[cur][i], a[i], s0);
+      s1 = fma(p_s[cur][i + 1], a[i + 1], s1);
+      s2 = fma(p_s[cur][i + 2], a[i + 2], s2);
+      s3 = fma(p_s[cur][i + 3], a[i + 3], s3);
+    }
+    const double acc = (s0 + s1) + (s2 + s3);
+    double o;
+    if (fwd) { o = valid ? ldexp(acc * et, -e2) : 0.0; pcur = o; }
+    else { o = valid ? ldexp(acc, -e2) : 0.0; pcur = et * o; }
+    h += (double)e2;
+    if (FULLK || valid) ob[(size_t)t * K] = o;
+    hkeep = (j == (s & 63)) ? h : hkeep;
+    if ((s & 63) == 63) xb[rowof(s - 63 + j)] = hkeep;      // uniform branch, coalesced store
+  };
+  int s = 1;
+  for (; s + PD <= Lm; s += PD) {
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+      const double et = eq[u];
+      eq[u] = eload(s + u + PD);
+      step(s + u, et);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < PD; ++u)
+    if (s + u < Lm) step(s + u, eq[u]);
+  {   // remaining exponents of the last partial group (and step 0 when Lm < 64)
+    const int sl = Lm - 1, s0 = sl & ~63;
+    if ((sl & 63) != 63 && s0 + j <= sl) xb[rowof(s0 + j)] = hkeep;
+  }
+  if (!fwd) return;
+  // ---- forward epilogue: K sums over the window's rows, Z, local_lb
+  double ks = 0.0, kk = 0.0;
+  for (int t = j; t < Lm; t += 64) {
+    const double kv = kexp[wrow + t];
+    ks += kv;
+    kk += kv * (double)(Lm - t);
+  }
+  ks = wave_sum_dpp(ks);
+  kk = wave_sum_dpp(kk);
+  const double tot = wave_sum_dpp(pcur);
+  if (j == 0) {
+    const double mm = mant * tot;
+    const int exf = ex + __builtin_amdgcn_frexp_exp(mm);
+    const double mf = __builtin_amdgcn_frexp_mant(mm);
+    const double zm = __builtin_amdgcn_frexp_mant(tot);
+    const double zexp = (double)__builtin_amdgcn_frexp_exp(tot);
+    local_lb[b] = log(mf) + ((double)exf + hsum + h + kk) * LN2_D;
+    logz[b] = log(zm) + (h + ks + zexp) * LN2_D;
+    zfac[b] = make_double2(1.0 / zm, h + zexp);
+  }
+}
+
 // S2 of the chain scan: boundary vectors.  grid 2 (0: alpha at chunk starts, 1: beta at chunk
 // ends), one wavefront each, lane = state.  Chunk c spans rows [c*L, (c+1)*L] (the last one up
 // to T-1); bnd row b of the outputs belongs to chain row min(b*L, T-1).

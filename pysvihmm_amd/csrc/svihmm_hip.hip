@@ -705,6 +705,9 @@ static int ensure_fb_lin(svihmm_ctx* h, int B, int Lm) {
   CK(ensure(h->packed, (size_t)packed_len(h) * sizeof(double)));
   return 0;
 }
+// below this many windows the wave-per-window scaled sweep beats the MFMA one (which is
+// latency-bound at ~0.9 us per step however few windows it gets)
+#define LIN_WAVE_MAX 1400
 // both sweeps over windows [b0, b0+nb) of the current batch on `stream` (buffers ensured):
 // one launch, blockIdx.y = direction
 static int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_t stream) {
@@ -723,6 +726,18 @@ static int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_
   double* llb = (double*)h->local_lb.p + b0;
   double* lz = (double*)h->logz.p + b0;
   ProfScope ps(h, KS_FB, stream);
+  if (K <= 64 && nb < LIN_WAVE_MAX && h->variant[7] != 2) {
+    // small batches: one wavefront per (window, direction)
+    dim3 gw((unsigned)nb, 2);
+#define WL(KM, FK) hipLaunchKernelGGL((k_wave_lin<KM, FK>), gw, dim3(64), 0, stream, Eh, kx, (const double*)h->Aexp.p, \
+                                      (const double*)h->AexpT.p, (const double*)h->mod_init.p, Lm, K, ah, bh, hx,  \
+                                      gx, llb, lz, zf)
+    if (K <= 16) WL(16, false); else if (K <= 32) WL(32, false);
+    else if (K == 64) WL(64, true); else WL(64, false);
+#undef WL
+    HIPCK(hipGetLastError());
+    return 0;
+  }
   const LinChain none = {};
 #define SWPX(NWV, F, BSV)                                                                                  \
   do {                                                                                                     \
@@ -910,10 +925,11 @@ static int pick_fb(const svihmm_ctx* h, int B, int Lm, bool want_logs) {
     if (var == 3 && (size_t)16 * Lm * h->K * sizeof(double) >= ((size_t)1 << 32)) var = 1;
     return var;
   }
-  if (var == 0) var = (B >= 192) ? (want_logs ? 2 : 3) : 1;
-  if (h->variant[2] == 0 && !want_logs && use_chain(h, B, Lm)) var = 3;   // long single chain: blocked scan
+  if (var == 0) var = want_logs ? (B >= 192 ? 2 : 1) : 3;   // no logs wanted: scaled sweeps at any batch size
   // the scaled sweeps address a workgroup's 16 windows with 32-bit byte offsets
-  if (var == 3 && !use_chain(h, B, Lm) && (size_t)16 * Lm * h->K * sizeof(double) >= ((size_t)1 << 32)) var = 2;
+  // (the wave-per-window kernel of small batches uses 64-bit row offsets)
+  if (var == 3 && !use_chain(h, B, Lm) && !(B < LIN_WAVE_MAX && h->variant[7] != 2) &&
+      (size_t)16 * Lm * h->K * sizeof(double) >= ((size_t)1 << 32)) var = 2;
   return var;
 }
 

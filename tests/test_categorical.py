@@ -90,6 +90,6 @@ def test_class_categorical_on_gpu_equals_literal_loop():
     a = _make(K, V, obs, mask, None); a.infer()
     assert a.engine.name == "hip"
     b = _make(K, V, obs, mask, None); b.infer(fused=False)
-    np.testing.assert_allclose(a.var_tran, b.var_tran, rtol=1e-8)
+    np.testing.assert_allclose(a.var_tran, b.var_tran, rtol=1e-6, atol=1e-7)
     for k in range(K):
-        np.testing.assert_allclose(a.var_emit[k].alpha_mf, b.var_emit[k].alpha_mf, rtol=1e-8)
+        np.testing.assert_allclose(a.var_emit[k].alpha_mf, b.var_emit[k].alpha_mf, rtol=1e-6, atol=1e-7)
