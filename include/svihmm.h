@@ -152,6 +152,15 @@ int64_t svihmm_packed_len(svihmm_ctx* h);
 int svihmm_pred_logprob(svihmm_ctx* h, const int64_t* starts, int32_t B, int32_t Lm,
                         uint32_t flags, double out2[2]);
 
+/* State decoding of the last estep/forward_backward call for the evaluation metrics
+ * (hmmbase.py:346-355 hamming_dist; util.py:236-277 munkres_match's count matrix):
+ * z[r] = argmax_k var_x[r, k] for the n = B*Lm rows (window-major; the first maximum wins like
+ * np.argmax) and, when true_sts (host, int32[n], same row order) is given,
+ * conf[pred*K + true] = number of rows decoded as `pred` whose label is `true` (labels outside
+ * [0, K) are skipped).  out_z (host int32[n]) and out_conf (host int64[K*K]) are optional. */
+int svihmm_state_argmax(svihmm_ctx* h, const int32_t* true_sts, int32_t* out_z,
+                        int64_t* out_conf);
+
 /* Readback of the intermediates of the last estep/forward_backward call
  * (what 0: lliks, 1: lalpha, 2: lbeta, 3: var_x; each [B,Lm,K]).
  * Large batches (B >= 192, K <= 64) run scaled linear-domain sweeps that never write a

@@ -152,6 +152,19 @@ class OracleEngine(object):
         self._packed = P
         return P if read else None
 
+    def state_argmax(self, true_sts=None, want_z=True):
+        """hmmbase.py:346-355 (np.argmax(full_var_x, axis=1)) + the count matrix of
+        util.py:236-277 (DM[pred, true])."""
+        q = self._last["var_x"].reshape(-1, self.K)
+        z = np.argmax(q, axis=1).astype(np.int32)
+        conf = None
+        if true_sts is not None:
+            ts = np.asarray(true_sts).ravel().astype(np.int64)
+            ok = (ts >= 0) & (ts < self.K)
+            conf = np.zeros((self.K, self.K), dtype=np.int64)
+            np.add.at(conf, (z[ok], ts[ok]), 1)
+        return (z if want_z else None), conf
+
     def pred_logprob(self, starts, Lm, flags=MASK_AS_NAN):
         st = np.asarray(starts, dtype=np.int64).ravel()
         if self.mask is None:

@@ -149,6 +149,63 @@ __global__ void k_pred_final(const double* __restrict__ part, int nblk, double* 
   }
 }
 
+// ------------------------------------------------------------------------------------
+//  State decoding for the evaluation metrics (hmmbase.py:346-355 hamming_dist:
+//  np.argmax(full_var_x, axis=1) -> util.munkres_match's K x K count matrix, util.py:236-277).
+//  One wave per row, lane = state (strided by 64 above 64 states); the first maximum wins like
+//  np.argmax.  With true labels: conf[pred * K + true] += 1, counted in an LDS table per
+//  workgroup (K <= 64) and flushed with one atomic per touched cell -- T = 1e6 rows move
+//  4 MB of labels instead of the 512 MB of var_x the host route reads back.
+// ------------------------------------------------------------------------------------
+#define ARGMAX_ROWS_PER_BLOCK 1024
+__global__ __launch_bounds__(256) void k_state_argmax(
+    const double* __restrict__ q, int64_t nrows, int K, const int32_t* __restrict__ true_sts,
+    int32_t* __restrict__ z, unsigned long long* __restrict__ conf) {
+  extern __shared__ unsigned int ctab[];         // [K*K] when K <= 64 and labels are given
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool lds_tab = true_sts != nullptr && K <= 64;
+  if (lds_tab) {
+    for (int i = threadIdx.x; i < K * K; i += 256) ctab[i] = 0u;
+    __syncthreads();
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * ARGMAX_ROWS_PER_BLOCK;
+  const int64_t r1 = imin64(nrows, r0 + ARGMAX_ROWS_PER_BLOCK);
+  for (int64_t g = r0 + wave; g < r1; g += 4) {
+    const double* __restrict__ row = q + g * K;
+    double best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int k = lane; k < K; k += 64) {
+      const double v = row[k];
+      if (v > best || bi == 0x7fffffff) { best = v; bi = k; }   // strictly greater: first maximum
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double ov = __shfl_xor(best, off, 64);
+      const int oi = __shfl_xor(bi, off, 64);
+      const bool take = (oi != 0x7fffffff) && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi));
+      best = take ? ov : best;
+      bi = take ? oi : bi;
+    }
+    if (lane == 0) {
+      if (z) z[g] = bi;
+      if (true_sts) {
+        const int tr = true_sts[g];
+        if (tr >= 0 && tr < K) {
+          if (lds_tab) atomicAdd(&ctab[bi * K + tr], 1u);
+          else atomicAdd(&conf[(size_t)bi * K + tr], 1ull);
+        }
+      }
+    }
+  }
+  if (lds_tab) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * K; i += 256) {
+      const unsigned int c = ctab[i];
+      if (c) atomicAdd(&conf[i], (unsigned long long)c);
+    }
+  }
+}
+
 // packed statistics -> host-visible (pinned, mapped) mirror.  An ordinary kernel launch right
 // behind k_finalize / the all-reduce: the runtime's D2H copy command starts ~0.1 ms after its
 // producer in the kernel trace, this one after the usual ~6 us.

@@ -1510,6 +1510,40 @@ int svihmm_read_rows(svihmm_ctx* h, int32_t what, int64_t row0, int64_t nrows, d
   return 0;
 }
 
+int svihmm_state_argmax(svihmm_ctx* h, const int32_t* true_sts, int32_t* out_z,
+                        int64_t* out_conf) {
+  if (!h || (!out_z && !out_conf)) return fail("svihmm_state_argmax: bad arguments");
+  if (out_conf && !true_sts) return fail("svihmm_state_argmax: the count matrix needs true_sts");
+  if (h->lastB <= 0) return fail("svihmm_state_argmax: nothing computed yet");
+  CK(set_device(h));
+  const int K = h->K;
+  const int64_t n = (int64_t)h->lastB * h->lastLm;
+  const double* q = nullptr;
+  CK(intermediate_ptr(h, 3, 0, n, &q));
+  const size_t zb = ((size_t)n * sizeof(int32_t) + 15) & ~(size_t)15;
+  const size_t cb = (size_t)K * K * sizeof(unsigned long long);
+  CK(ensure(h->scratch, 2 * zb + cb));
+  int32_t* dz = (int32_t*)h->scratch.p;
+  int32_t* dtrue = (int32_t*)((char*)h->scratch.p + zb);
+  unsigned long long* dconf = (unsigned long long*)((char*)h->scratch.p + 2 * zb);
+  if (true_sts) {
+    HIPCK(hipMemcpyAsync(dtrue, true_sts, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIPCK(hipMemsetAsync(dconf, 0, cb, h->stream));
+  }
+  {
+    ProfScope ps(h, KS_MISC);
+    const int nblk = (int)((n + ARGMAX_ROWS_PER_BLOCK - 1) / ARGMAX_ROWS_PER_BLOCK);
+    const size_t lds = (true_sts && K <= 64) ? (size_t)K * K * sizeof(unsigned int) : 0;
+    hipLaunchKernelGGL(k_state_argmax, dim3(nblk), dim3(256), lds, h->stream, q, n, K,
+                       (const int32_t*)(true_sts ? dtrue : nullptr), dz, dconf);
+    HIPCK(hipGetLastError());
+  }
+  if (out_z) CK(d2h(h, out_z, dz, (size_t)n * sizeof(int32_t)));
+  if (out_conf) CK(d2h(h, out_conf, dconf, cb));
+  HIPCK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 int svihmm_ffbs(svihmm_ctx* h, const double* logA, const double* uniforms, uint32_t flags,
                 int64_t* out_z, double* out_lalpha) {
   if (!h || !logA || !uniforms || !out_z) return fail("svihmm_ffbs: bad arguments");

@@ -145,6 +145,7 @@ class HipEngine(object):
                          B=None):
         st = None if starts is None else self._starts(starts)
         B = len(st) if st is not None else int(B)
+        self._rows = B * int(Lm)
         res = {}
         bufs = {}
         for name in ("lalpha", "lbeta", "var_x"):
@@ -166,6 +167,7 @@ class HipEngine(object):
         st = self._starts(starts)
         out = np.empty(self._packed_len()) if read else None
         off, ln = (0, int(Lm)) if inner is None else (int(inner[0]), int(inner[1]))
+        self._rows = len(st) * int(Lm)
         L.check(self._lib.svihmm_estep_minibatch_ex(self._h, L.i64ptr(st), len(st), int(Lm),
                                                     off, ln, int(flags), L.dptr(out)),
                 "svihmm_estep_minibatch")
@@ -188,11 +190,31 @@ class HipEngine(object):
         """Mean predictive log-probability of the masked rows of the windows and their number
         (reference pred_logprob / pred_logprob_full); ``(None, 0)`` when nothing is masked."""
         st = self._starts(starts)
+        self._rows = len(st) * int(Lm)
         out = np.empty(2)
         L.check(self._lib.svihmm_pred_logprob(self._h, L.i64ptr(st), len(st), int(Lm), int(flags),
                                               L.dptr(out)), "svihmm_pred_logprob")
         n = int(out[1])
         return (float(out[0]) if n > 0 else None), n
+
+    def state_argmax(self, true_sts=None, want_z=True):
+        """``np.argmax(var_x, axis=1)`` over the rows of the last E-step (window-major) and, with
+        labels, the count matrix ``DM[pred, true]`` of ``util.munkres_match`` (reference
+        ``hmmbase.py:346-355``, ``util.py:236-277``) -- decoded on the device, so only the
+        int32 labels cross the bus.  Returns ``(z or None, DM or None)``."""
+        n = getattr(self, "_rows", 0)
+        if n <= 0:
+            raise RuntimeError("state_argmax: no E-step has run on this engine")
+        z = np.empty(n, dtype=np.int32) if want_z else None
+        ts = conf = None
+        if true_sts is not None:
+            ts = np.ascontiguousarray(np.asarray(true_sts).ravel(), dtype=np.int32)
+            if ts.size != n:
+                raise ValueError("true_sts has %d labels for %d decoded rows" % (ts.size, n))
+            conf = np.zeros((self.K, self.K), dtype=np.int64)
+        vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        L.check(self._lib.svihmm_state_argmax(self._h, vp(ts), vp(z), vp(conf)), "svihmm_state_argmax")
+        return z, conf
 
     def read_packed(self):
         out = np.empty(self._packed_len())

@@ -699,6 +699,16 @@ class VBHMM(VariationalHMMBase):
                 + odist.expected_log_likelihood(obs[mask, :])
         return np.mean(np.logaddexp.reduce(logprob, axis=1))
 
+    def _full_estep_device(self):
+        """full_local_update without the var_x readback (hamming_dist(None, true_sts))."""
+        mod_init = digamma(self.var_init + eps) - digamma(np.sum(self.var_init) + eps)
+        tran_sum = np.sum(self.var_tran, axis=1)
+        mod_tran = digamma(self.var_tran + eps) - digamma(tran_sum[:, npa] + eps)
+        self._upload_obs()
+        self.engine.set_globals(mod_init, mod_tran)
+        flags = self._push_emission(nan_mask=True)
+        self.engine.forward_backward([0], self.T, flags=flags, want=())
+
     def full_local_update(self):
         """Whole-chain E-step with missing rows treated as NaN (lliks row = 0),
         reference :1147-1205.  obs is not mutated (the reference NaN-masks it in place

@@ -144,9 +144,17 @@ def munkres_match(sts_true, sts_pred, K):
     sts_pred = np.asarray(sts_pred).astype('int')
     DM = np.zeros((K, K))
     np.add.at(DM, (sts_pred, sts_true), 1.)
+    return match_from_counts(DM)
+
+
+def match_from_counts(DM):
+    """The assignment step of ``munkres_match`` on a ready count matrix ``DM[pred, true]``
+    (``util.py:262-277``; the device builds the counts, ``svihmm_state_argmax``)."""
+    from scipy.optimize import linear_sum_assignment
+    DM = np.asarray(DM, dtype=np.float64)
     cost_mat = 1 - (DM / np.sum(DM))
     rows, cols = linear_sum_assignment(cost_mat)
-    out = np.empty(K, dtype=int)
+    out = np.empty(DM.shape[0], dtype=int)
     out[rows] = cols
     return out
 

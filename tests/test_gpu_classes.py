@@ -140,3 +140,30 @@ def test_pred_logprob_full_device_equals_host_route():
     hmm.obs_full = hmm.obs.copy()
     slow = hmm.pred_logprob_full()
     np.testing.assert_allclose(fast, slow, rtol=1e-9)
+
+
+def test_hamming_dist_device_equals_host_route():
+    """hamming_dist(None, true_sts): arg-max + count matrix on the device == the reference
+    route (full_local_update -> np.argmax -> munkres_match -> scipy hamming)."""
+    from pysvihmm_amd import hmmsgd_metaobs, hmmbatchcd
+    from pysvihmm_amd.distributions import Gaussian
+    rng = np.random.RandomState(2)
+    np.random.seed(2)
+    N, K, D = 5000, 3, 2
+    sts = rng.randint(0, K, size=N // 50).repeat(50)
+    obs = rng.randn(N, D) + 3.0 * np.stack([sts, -sts], axis=1)
+    mask = rng.rand(N) < 0.1
+    prior_emit = np.array([Gaussian(mu_0=np.zeros(D), sigma_0=0.75 * np.cov(obs.T), kappa_0=0.01, nu_0=4)
+                           for _ in range(K)])
+    svi = hmmsgd_metaobs.VBHMM(obs, np.ones(K), np.ones((K, K)), prior_emit, mask=mask,
+                               metaobs_half=10, mb_sz=16, maxit=40, seed=3)
+    svi.infer()
+    hd, bm = svi.hamming_dist(svi.full_local_update(), sts)
+    hd2, bm2 = svi.hamming_dist(None, sts)
+    assert svi.engine.name == "hip"
+    assert abs(hd - hd2) < 1e-12 and np.array_equal(bm, bm2)
+    cd = hmmbatchcd.VBHMM(obs, np.ones(K), np.ones((K, K)), prior_emit, maxit=5)
+    cd.infer()
+    hd, bm = cd.hamming_dist(cd.full_local_update(), sts)
+    hd2, bm2 = cd.hamming_dist(None, sts)
+    assert abs(hd - hd2) < 1e-12 and np.array_equal(bm, bm2)

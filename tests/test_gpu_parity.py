@@ -347,3 +347,61 @@ def test_pred_logprob_vs_numpy(eng, B, Lm):
     np.testing.assert_allclose(val, tot / cnt, rtol=1e-9)
     eng.set_obs(pb["obs"], None)
     assert eng.pred_logprob(starts, Lm) == (None, 0)
+
+
+@pytest.mark.parametrize("K,B,Lm", [(5, 1, 3000), (16, 7, 65), (64, 300, 33), (100, 3, 257), (256, 2, 40)])
+def test_state_argmax_vs_oracle(eng, K, B, Lm):
+    """svihmm_state_argmax: np.argmax(var_x, axis=1) per row + the count matrix
+    DM[pred, true] of util.munkres_match.  Integer outputs: exact wherever the two largest
+    posteriors of a row differ by more than rounding noise; DM must equal the counts of the
+    returned labels exactly."""
+    from oracle.engine import OracleEngine
+    D = 3
+    T = max(4000, B * 7 + Lm + 1)
+    pb = make_problem(K, D, T, seed=K + Lm, miss=0.1, sep=2.0)
+    starts = (np.arange(B) * 7) % (T - Lm + 1)
+    rng = np.random.default_rng(5)
+    true = rng.integers(-1, K + 1, size=B * Lm)       # includes labels outside [0, K): skipped
+    orc = OracleEngine()
+    for e in (eng, orc):
+        e.set_obs(pb["obs"], pb["mask"])
+        e.set_globals(pb["mod_init"], pb["ltran"])
+        e.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    ro = orc.forward_backward(starts, Lm, want=("var_x",))
+    eng.forward_backward(starts, Lm, want=())
+    z, dm = eng.state_argmax(true)
+    zo, dmo = orc.state_argmax(true)
+    q = ro["var_x"].reshape(-1, K)
+    top2 = np.sort(q, axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 1e-9
+    assert clear.mean() > 0.9
+    assert np.array_equal(z[clear], zo[clear])
+    assert np.all(q[np.arange(len(z)), z] >= top2[:, 1] - 1e-9)     # near-ties: still a maximiser
+    ok = (true >= 0) & (true < K)
+    ref = np.zeros((K, K), dtype=np.int64)
+    np.add.at(ref, (z[ok], true[ok]), 1)
+    assert np.array_equal(dm, ref)
+    if clear.all():
+        assert np.array_equal(dm, dmo)
+    # labels only / counts only
+    z2, none = eng.state_argmax()
+    assert none is None and np.array_equal(z2, z)
+    none, dm2 = eng.state_argmax(true, want_z=False)
+    assert none is None and np.array_equal(dm2, dm)
+
+
+def test_state_argmax_first_maximum_and_errors(eng):
+    """Ties: the first maximum wins like np.argmax (a host-supplied flat lliks batch with
+    uniform transitions gives exactly equal posteriors)."""
+    from pysvihmm_amd import _lib as L
+    K, Lm = 70, 9
+    eng.set_globals(np.full(K, -np.log(K)), np.full((K, K), -np.log(K)))
+    ll = np.zeros((2, Lm, K))
+    ll[1, :, 40] = 1.0; ll[1, :, 69] = 1.0                 # two equal maxima: 40 wins
+    eng.set_lliks(ll)
+    r = eng.forward_backward(None, Lm, flags=L.USE_HOST_LLIKS, want=("var_x",), B=2)
+    z, _ = eng.state_argmax()
+    assert np.array_equal(z, np.argmax(r["var_x"].reshape(-1, K), axis=1))
+    assert np.all(z[:Lm] == 0) and np.all(z[Lm:] == 40)
+    with pytest.raises(ValueError):
+        eng.state_argmax(np.zeros(3, dtype=np.int32))

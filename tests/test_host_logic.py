@@ -124,8 +124,11 @@ def test_two_blob_demo_acceptance():
     svi = hmmsgd_metaobs.VBHMM(obs, np.ones(K), np.ones((K, K)), prior_emit, metaobs_half=10,
                                mb_sz=8, maxit=60, seed=3, engine=OracleEngine())
     svi.infer()
-    hd, _ = svi.hamming_dist(svi.full_local_update(), sts)
+    hd, bm = svi.hamming_dist(svi.full_local_update(), sts)
     assert hd < 0.02
+    # device-decoded route (arg-max + count matrix on the engine): same distance and matching
+    hd2, bm2 = svi.hamming_dist(None, sts)
+    assert hd2 == pytest.approx(hd, abs=1e-15) and np.array_equal(bm, bm2)
 
 
 def test_adaptive_and_buffer_paths_run():

@@ -25,4 +25,10 @@ for K, D, T in ((16, 8, 100000), (64, 32, 1000000)):
         if mode == "scan":
             t0 = time.time(); v = e.pred_logprob([0], T, flags=1); dt = time.time() - t0
             print("    pred_logprob (E-step + held-out term + reduction): %.1f ms -> %r" % (dt * 1e3, v))
+            sts = np.asarray(pb.get('sts', np.zeros(T)), dtype=np.int32)
+            e.forward_backward([0], T, flags=1, want=())
+            t0 = time.time(); _, dm = e.state_argmax(sts, want_z=False); dt = time.time() - t0
+            print("    state_argmax + K x K counts (labels in, counts out): %.1f ms, %d rows counted" % (dt * 1e3, dm.sum()))
+            t0 = time.time(); q = e.read_intermediate("var_x", 1, T)[0]; zz = np.argmax(q, axis=1); dt = time.time() - t0
+            print("    host route (var_x D2H + np.argmax): %.1f ms" % (dt * 1e3))
     e.close()
