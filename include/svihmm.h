@@ -71,6 +71,14 @@ int svihmm_sync(svihmm_ctx* h);
 int svihmm_set_obs(svihmm_ctx* h, const double* obs, int64_t T, int32_t D,
                    const uint8_t* mask);
 
+/* The same resident copy filled in pieces (gen_synthetic.py:188-191 read_data_mmap streams
+ * [size, D] blocks of the on-disk float64 array): svihmm_alloc_obs sizes it (mask zeroed when
+ * with_mask), svihmm_set_obs_rows uploads rows [row0, row0+nrows) and returns when the block
+ * is on the device.  Rows never written are undefined. */
+int svihmm_alloc_obs(svihmm_ctx* h, int64_t T, int32_t D, int32_t with_mask);
+int svihmm_set_obs_rows(svihmm_ctx* h, int64_t row0, int64_t nrows, const double* obs,
+                        const uint8_t* mask);
+
 /* mod_init[K], ltran[K,K] in the log domain: the psi-expectations of
  * hmmbase.py:214-216 / hmmsgd_metaobs.py:502-504 (computed on the host with
  * SciPy's digamma, uploaded once per minibatch).  The FFBS variant passes

@@ -59,6 +59,16 @@ class OracleEngine(object):
         self.T, self.D = obs.shape
         self.mask = None if mask is None else np.asarray(mask).astype(bool).copy()
 
+    def set_obs_blocks(self, blocks, T, D, mask=None):
+        obs = np.zeros((int(T), int(D)))
+        row = 0
+        for blk in blocks:
+            blk = np.asarray(blk, dtype=np.float64).reshape(-1, int(D))
+            obs[row:row + blk.shape[0]] = blk
+            row += blk.shape[0]
+        self.set_obs(obs, mask)
+        return row
+
     def set_globals(self, mod_init, ltran):
         self.mod_init = np.array(mod_init, dtype=np.float64)
         self.ltran = np.array(ltran, dtype=np.float64)

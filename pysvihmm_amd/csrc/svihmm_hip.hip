@@ -273,6 +273,41 @@ int svihmm_set_obs(svihmm_ctx* h, const double* obs, int64_t T, int32_t D,
   return 0;
 }
 
+// Chunked upload for sequences that arrive in pieces (gen_synthetic.py:188-191 read_data_mmap
+// yields [size, D] blocks of the on-disk float64 array): svihmm_alloc_obs sizes the resident
+// copy, svihmm_set_obs_rows fills rows [row0, row0 + nrows).  Each call returns once its
+// block is on the device (the caller may reuse the block).
+int svihmm_alloc_obs(svihmm_ctx* h, int64_t T, int32_t D, int32_t with_mask) {
+  if (!h || T <= 0 || D <= 0) return fail("svihmm_alloc_obs: bad arguments");
+  if (D > 4095) return fail("svihmm_alloc_obs: D too large");
+  CK(set_device(h));
+  h->lin_stale = true;
+  CK(ensure(h->obs, (size_t)T * D * sizeof(double)));
+  h->have_mask = with_mask != 0;
+  if (with_mask) {
+    CK(ensure(h->mask, (size_t)T));
+    HIPCK(hipMemsetAsync(h->mask.p, 0, (size_t)T, h->stream));
+  }
+  h->T = T; h->D = D;
+  return 0;
+}
+int svihmm_set_obs_rows(svihmm_ctx* h, int64_t row0, int64_t nrows, const double* obs,
+                        const uint8_t* mask) {
+  if (!h || !obs || row0 < 0 || nrows <= 0) return fail("svihmm_set_obs_rows: bad arguments");
+  if (h->T <= 0 || row0 + nrows > h->T) return fail("svihmm_set_obs_rows: rows outside the allocated sequence");
+  if (mask && !h->have_mask) return fail("svihmm_set_obs_rows: sequence was allocated without a mask");
+  CK(set_device(h));
+  h->lin_stale = true;
+  ProfScope ps(h, KS_H2D);
+  const size_t D = (size_t)h->D;
+  HIPCK(hipMemcpyAsync((double*)h->obs.p + (size_t)row0 * D, obs, (size_t)nrows * D * sizeof(double),
+                       hipMemcpyHostToDevice, h->stream));
+  if (mask)
+    HIPCK(hipMemcpyAsync((uint8_t*)h->mask.p + row0, mask, (size_t)nrows, hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 int svihmm_set_globals(svihmm_ctx* h, int32_t K, const double* mod_init, const double* ltran) {
   if (!h || K <= 0 || !mod_init || !ltran) return fail("svihmm_set_globals: bad arguments");
   if (K > 1024) return fail("svihmm_set_globals: K > 1024 unsupported");

@@ -97,6 +97,29 @@ class HipEngine(object):
         L.check(self._lib.svihmm_set_obs(self._h, L.dptr(obs), T, D, L.u8ptr(m)), "svihmm_set_obs")
         self.T, self.D = T, D
 
+    def set_obs_blocks(self, blocks, T, D, mask=None):
+        """Upload a sequence that arrives in row blocks (``gen_synthetic.read_data_mmap``,
+        reference ``gen_synthetic.py:188-191``): ``blocks`` yields ``[n_i, D]`` arrays in
+        order; rows beyond the last block keep whatever the allocation held."""
+        T, D = int(T), int(D)
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
+            if m.shape != (T,):
+                raise RuntimeError("mask must have shape (T,)")
+        L.check(self._lib.svihmm_alloc_obs(self._h, T, D, int(m is not None)), "svihmm_alloc_obs")
+        self.T, self.D = T, D
+        row = 0
+        for blk in blocks:
+            blk = np.ascontiguousarray(np.asarray(blk, dtype=np.float64).reshape(-1, D))
+            n = blk.shape[0]
+            if n == 0:
+                continue
+            mp = None if m is None else m[row:row + n].ctypes.data_as(C.c_void_p)
+            L.check(self._lib.svihmm_set_obs_rows(self._h, row, n, L.dptr(blk), mp), "svihmm_set_obs_rows")
+            row += n
+        return row
+
     def set_globals(self, mod_init, ltran):
         ltran = L.as_f64(ltran)
         K = ltran.shape[0]

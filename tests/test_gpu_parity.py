@@ -405,3 +405,29 @@ def test_state_argmax_first_maximum_and_errors(eng):
     assert np.all(z[:Lm] == 0) and np.all(z[Lm:] == 40)
     with pytest.raises(ValueError):
         eng.state_argmax(np.zeros(3, dtype=np.int32))
+
+
+def test_obs_uploaded_in_blocks_equals_whole(eng, tmp_path):
+    """svihmm_alloc_obs / svihmm_set_obs_rows: the sequence streamed from the
+    reference's on-disk float64 layout in row blocks gives the same E-step as one upload."""
+    from pysvihmm_amd import gen_synthetic
+    K, D, T, Lm = 6, 4, 5000, 101
+    pb = make_problem(K, D, T, seed=12, miss=0.1)
+    path = str(tmp_path / "obs.dat")
+    fp = np.memmap(path, dtype="float64", mode="w+", shape=(T, D)); fp[:] = pb["obs"]; fp.flush(); del fp
+    starts = np.arange(0, T - Lm, 97)
+    eng.set_obs(pb["obs"], pb["mask"])
+    eng.set_globals(pb["mod_init"], pb["ltran"])
+    eng.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    a = eng.estep(starts, Lm).buf.copy()
+    n = eng.set_obs_blocks(gen_synthetic.read_data_mmap(D, T, 768, path), T, D, pb["mask"])
+    assert n == (T // 768) * 768                       # the reference's reader drops the tail block
+    tail = pb["obs"][n:]
+    from pysvihmm_amd import _lib as L
+    tm = np.ascontiguousarray(pb["mask"][n:].astype(np.uint8))
+    L.check(eng._lib.svihmm_set_obs_rows(eng._h, n, T - n, L.dptr(np.ascontiguousarray(tail)),
+                                         tm.ctypes.data), "rows")
+    b = eng.estep(starts, Lm).buf.copy()
+    assert np.array_equal(a, b)
+    with pytest.raises(RuntimeError):
+        L.check(eng._lib.svihmm_set_obs_rows(eng._h, T - 1, 2, L.dptr(np.zeros((2, D))), None), "rows")
