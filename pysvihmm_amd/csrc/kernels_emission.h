@@ -64,6 +64,49 @@ __global__ __launch_bounds__(EM_R) void k_emission_outer(
 //       writes Eh = exp(ll) * 2^-k with k = ceil(max_j ll / ln 2) and the per-row k
 //       (kexp) -- the input format of the scaled linear-domain sweeps K2e/K2f, so that
 //       no exp is left in their time loops.
+// Scaled epilogue of the emission GEMMs: Eh = exp(ll) * 2^-k, k = ceil(max_j ll / ln 2) per row.
+template <int NT, int MT>
+__device__ __forceinline__ void emission_scaled_epilogue(
+    const double (&outv)[MT][NT][4], const unsigned char* bad_s, int wave, int li, int lg,
+    int64_t g0, int64_t nrows, int K, int n0, double* __restrict__ ll, double* __restrict__ kexp) {
+    // One exp per (row, state) is the algorithmic minimum of transcendental work on the
+    // whole E-step; keep it lean: constants pinned in VGPRs, branch-free NaN/inf handling.
+    ExpConsts ek;
+    exp_consts_init(ek);
+    double big = 1.7976931348623157e308, l2e = 1.4426950408889634074;
+    asm volatile("" : "+v"(big));
+    asm volatile("" : "+v"(l2e));
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rl = wave * 16 * MT + m * 16 + lg + 4 * r;
+        const int64_t g = g0 + rl;
+        const bool bd = bad_s[rl] != 0;
+        double v[NT], mx = -INFINITY;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int k = n0 + n * 16 + li;
+          double x = outv[m][n][r];
+          x = fmax_raw(-big, x);                 // -inf -> -DBL_MAX, NaN -> -DBL_MAX ...
+          x = -fmax_raw(-big, -x);               // +inf -> DBL_MAX
+          x = (outv[m][n][r] != outv[m][n][r] || bd) ? 0.0 : x;   // ... NaN and masked rows -> 0
+          v[n] = k < K ? x : -INFINITY;
+          mx = fmax_raw(mx, v[n]);
+        }
+        mx = row16_max(mx);   // all lanes: the DPP reduction stays outside the store guards
+        const double kx = (mx > -1e300 && mx < 1e300) ? ceil(mx * l2e) : 0.0;
+        double* orow = ll + g * K + n0 + li;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const double e = fast_exp_k(fma(kx, ek.c[13], fma(kx, ek.c[12], v[n])), ek);
+          if (g < nrows && n0 + n * 16 + li < K) orow[n * 16] = e;
+        }
+        if (li == 0 && g < nrows) kexp[g] = kx;
+      }
+    }
+}
+
 template <int NT, int MT, bool SCALED>
 __global__ __launch_bounds__(256) void k_emission_mfma(
     const double* __restrict__ obs, const uint8_t* __restrict__ mask,
@@ -108,13 +151,27 @@ __global__ __launch_bounds__(256) void k_emission_mfma(
     // must fit LDS), 256 / DP rows per pass, consecutive lanes read consecutive doubles
     const int sh = 32 - __builtin_clz((unsigned)(D > 1 ? D - 1 : 1));
     const int rpp = 256 >> sh, i = tid & ((1 << sh) - 1), rr = tid >> sh;
-    for (int rb = 0; rb < ROWS; rb += rpp) {
-      const int r = rb + rr;
-      if (i < D && r < ROWS) {   // (256 >> sh rows per pass can exceed a 64-row tile)
-        const long long o = rowoff[r];
-        double v = o >= 0 ? obs[o + i] : 0.0;
-        if (v != v) { bad_s[r] = 1; v = 0.0; }
-        xs[r * DS + i] = v;
+    // all of a thread's loads are issued before the first LDS write (branch-free, clamped
+    // addresses): written as load -> wait -> store per row the compiler serialises 16 HBM
+    // round trips per workgroup, 9 % of the kernel on the bench shape
+    constexpr int CH = 16;
+    for (int rb = 0; rb < ROWS; rb += rpp * CH) {
+      double v[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int r = rb + j * rpp + rr;
+        const long long o = r < ROWS ? rowoff[r] : -1;
+        const bool ok = i < D && o >= 0;
+        const double t = obs[ok ? o + i : 0];
+        v[j] = ok ? t : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int r = rb + j * rpp + rr;
+        if (i < D && r < ROWS) {   // (256 >> sh rows per pass can exceed a 64-row tile)
+          if (v[j] != v[j]) { bad_s[r] = 1; v[j] = 0.0; }
+          xs[r * DS + i] = v[j];
+        }
       }
     }
   }
@@ -169,42 +226,7 @@ __global__ __launch_bounds__(256) void k_emission_mfma(
       for (int r = 0; r < 4; ++r) outv[m][n][r] = acc[m][n][r];
   __builtin_amdgcn_sched_barrier(0);
   if (SCALED) {
-    // One exp per (row, state) is the algorithmic minimum of transcendental work on the
-    // whole E-step; keep it lean: constants pinned in VGPRs, branch-free NaN/inf handling.
-    ExpConsts ek;
-    exp_consts_init(ek);
-    double big = 1.7976931348623157e308, l2e = 1.4426950408889634074;
-    asm volatile("" : "+v"(big));
-    asm volatile("" : "+v"(l2e));
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rl = wave * 16 * MT + m * 16 + lg + 4 * r;
-        const int64_t g = g0 + rl;
-        const bool bd = bad_s[rl] != 0;
-        double v[NT], mx = -INFINITY;
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const int k = n0 + n * 16 + li;
-          double x = outv[m][n][r];
-          x = fmax_raw(-big, x);                 // -inf -> -DBL_MAX, NaN -> -DBL_MAX ...
-          x = -fmax_raw(-big, -x);               // +inf -> DBL_MAX
-          x = (outv[m][n][r] != outv[m][n][r] || bd) ? 0.0 : x;   // ... NaN and masked rows -> 0
-          v[n] = k < K ? x : -INFINITY;
-          mx = fmax_raw(mx, v[n]);
-        }
-        mx = row16_max(mx);   // all lanes: the DPP reduction stays outside the store guards
-        const double kx = (mx > -1e300 && mx < 1e300) ? ceil(mx * l2e) : 0.0;
-        double* orow = ll + g * K + n0 + li;
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const double e = fast_exp_k(fma(kx, ek.c[13], fma(kx, ek.c[12], v[n])), ek);
-          if (g < nrows && n0 + n * 16 + li < K) orow[n * 16] = e;
-        }
-        if (li == 0 && g < nrows) kexp[g] = kx;
-      }
-    }
+    emission_scaled_epilogue<NT, MT>(outv, bad_s, wave, li, lg, g0, nrows, K, n0, ll, kexp);
   } else {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -223,6 +245,188 @@ __global__ __launch_bounds__(256) void k_emission_mfma(
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------
+//  K1c: the scaled emission GEMM with an address-free feature schedule (D % 8 == 0, K <= 64).
+//  Measured on K1b (bench shape): every non-MFMA instruction a SIMD issues costs MFMA issue
+//  slots -- generating the A operands (table lookup, unpacking, four LDS addresses per k-step)
+//  took 8.5 % of the kernel, the 16 B-operand loads per four k-steps 5 %.  Here the features
+//  are ordered along orbits of the index shift: with N = D + 1 (odd), c = D / 4 and
+//  delta = 0 .. D/2, k-step s = delta * c + a0 gives lane group lg the product
+//       x[a] * x[(a + delta) mod N],      a = a0 + c * lg        (a0 = 0 .. c-1)
+//  -- every unordered pair {a, b}, a, b < N - 1 or not, exactly once, the leftover a = N - 1
+//  of each delta in ceil((D/2+1)/4) extra k-steps (group lg: delta = 4j + lg).  The row is
+//  stored in LDS as x[-1 .. 3D/2 - 1] with x[i] = x[i mod N] (slot N-1 = 1.0), so "mod N" and
+//  the per-group shift c * lg are part of a per-lane constant base and each operand is ONE
+//  ds_read_b128 at base + immediate (the two row tiles of the wave are interleaved: the
+//  b128 holds the same column of rows r and r + 16).  theta is re-laid for it by
+//  k_theta_orbit: rows in schedule order, the NT state tiles of a lane adjacent (b128 loads).
+//  Per k-step: 2 LDS reads, 2 v_mul_f64, NT/2 global loads, 2 NT MFMAs; no table, no
+//  unpacking, two address adds per U k-steps.  141 k-steps at D = 32 instead of 144.
+// ------------------------------------------------------------------------------------
+__global__ void k_theta_orbit(const double* __restrict__ theta, int D, int Kp, int NT,
+                              double* __restrict__ orb) {
+  const int fo = blockIdx.x, s = fo >> 2, lg = fo & 3, k = threadIdx.x;
+  const int N = D + 1, c = D >> 2, nd = (D >> 1) + 1;
+  int a, b;
+  bool valid = true;
+  if (s < c * nd) {
+    const int d = s / c, a0 = s - d * c;
+    a = a0 + c * lg;
+    b = (a + d) % N;
+  } else {
+    const int d = 4 * (s - c * nd) + lg;
+    valid = d < nd;
+    a = N - 1;
+    b = (N - 1 + d) % N;
+  }
+  const int lo = a < b ? a : b, hi = a < b ? b : a;
+  const int f = lo * (D + 1) - lo * (lo - 1) / 2 + (hi - lo);
+  if (k < Kp) orb[(size_t)fo * Kp + (k & 15) * NT + (k >> 4)] = valid ? theta[(size_t)f * Kp + k] : 0.0;
+}
+
+template <int NT, int U>
+__global__ __launch_bounds__(256) void k_emission_orbit(
+    const double* __restrict__ obs, const uint8_t* __restrict__ mask,
+    const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K,
+    const double* __restrict__ orb, uint32_t flags, double* __restrict__ ll,
+    double* __restrict__ kexp) {
+  constexpr int MT = 2, ROWS = 128, KP = 16 * NT;
+  extern __shared__ double smem[];
+  const int N = D + 1, c = D >> 2, nd = (D >> 1) + 1, nleft = (nd + 3) >> 2;
+  const int LEN = D + (D >> 1) + 1;                 // slots -1 .. 3D/2 - 1 (odd count)
+  double2* xs2 = (double2*)smem;                    // [64 row pairs][LEN] (row r, row r + 16)
+  long long* rowoff = (long long*)(xs2 + 64 * LEN);
+  unsigned char* bad_s = (unsigned char*)(rowoff + ROWS);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t g0 = (int64_t)blockIdx.x * ROWS;
+  double* xs1 = (double*)xs2;
+  // row r of the tile -> wave r >> 5, row tile (r >> 4) & 1, lane row r & 15
+  auto slot = [&](int r, int idx) { return ((((r >> 5) * 16 + (r & 15)) * LEN + idx + 1) << 1) + ((r >> 4) & 1); };
+  {
+    const int64_t bw0 = g0 / Lm;
+    const unsigned t0 = (unsigned)(g0 - bw0 * Lm);
+    for (int r = tid; r < ROWS; r += 256) {
+      const bool valid = g0 + r < nrows;
+      const unsigned x = t0 + (unsigned)(valid ? r : 0);
+      const unsigned bwr = x / (unsigned)Lm;
+      const int64_t orow = starts[bw0 + bwr] + (x - bwr * (unsigned)Lm);
+      unsigned char bd = 0;
+      if (valid && (flags & SVIHMM_MASK_AS_NAN) && mask) bd = mask[orow] != 0;
+      rowoff[r] = valid ? orow * D : -1;
+      bad_s[r] = bd;
+      xs1[slot(r, -1)] = 1.0;
+      xs1[slot(r, D)] = 1.0;
+    }
+  }
+  __syncthreads();
+  {
+    const int sh = 32 - __builtin_clz((unsigned)(D - 1));
+    const int rpp = 256 >> sh, i = tid & ((1 << sh) - 1), rr = tid >> sh;
+    constexpr int CH = 16;      // loads first, LDS writes after (see K1b)
+    for (int rb = 0; rb < ROWS; rb += rpp * CH) {
+      double v[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int r = rb + j * rpp + rr;
+        const long long o = r < ROWS ? rowoff[r] : -1;
+        const bool ok = i < D && o >= 0;
+        const double t = obs[ok ? o + i : 0];
+        v[j] = ok ? t : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int r = rb + j * rpp + rr;
+        if (i < D && r < ROWS) {
+          if (v[j] != v[j]) { bad_s[r] = 1; v[j] = 0.0; }
+          xs1[slot(r, i)] = v[j];
+          if (i + N <= LEN - 2) xs1[slot(r, i + N)] = v[j];
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  const int li = lane & 15, lg = lane >> 4;
+  double4_t acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  const double2* rowp = xs2 + (wave * 16 + li) * LEN + 1;      // slot 0 of this lane's row pair
+  const double2* pa0 = rowp + c * lg;
+  const unsigned loff = (unsigned)(lg * KP + li * NT);         // lane part of the theta address
+  auto kstep = [&](const double2 xa, const double2 xb, const double (&Bv)[NT]) {
+    const double A0 = xa.x * xb.x, A1 = xa.y * xb.y;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[0][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, Bv[n], acc[0][n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[1][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, Bv[n], acc[1][n], 0, 0, 0);
+  };
+  auto loadB = [&](const double* trow, double (&Bv)[NT]) {
+    if constexpr (NT % 2 == 0) {
+#pragma unroll
+      for (int n = 0; n < NT; n += 2) {
+        const double2 t = *reinterpret_cast<const double2*>(trow + loff + n);
+        Bv[n] = t.x; Bv[n + 1] = t.y;
+      }
+    } else {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) Bv[n] = trow[loff + n];
+    }
+  };
+  // blocks of U k-steps, (delta, a0) in schedule order; the B operands of block i + 1 are
+  // requested before the MFMAs of block i (two register sets, loop unrolled by two blocks)
+  const int nblk = nd * (c / U);
+  int bd = 0, ba = 0;                                // (delta, a0) of the next block to compute
+  auto block = [&](const double (&Bv)[U][NT]) {
+    const double2* pa = pa0 + ba;
+    const double2* pb = pa + bd;
+    double2 xa[U], xb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { xa[u] = pa[u]; xb[u] = pb[u]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) kstep(xa[u], xb[u], Bv[u]);
+    ba += U;
+    if (ba == c) { ba = 0; ++bd; }
+  };
+  auto loadblk = [&](int bi, double (&Bv)[U][NT]) {
+    const double* t = orb + (size_t)(bi < nblk ? bi : nblk - 1) * (U * 4 * KP);
+#pragma unroll
+    for (int u = 0; u < U; ++u) loadB(t + (size_t)u * 4 * KP, Bv[u]);
+  };
+  {
+    double B0[U][NT], B1[U][NT];
+    loadblk(0, B0);
+    for (int bi = 0; bi < nblk; bi += 2) {
+      loadblk(bi + 1, B1);
+      block(B0);
+      loadblk(bi + 2, B0);
+      if (bi + 1 < nblk) block(B1);
+    }
+  }
+  const double* tbs = orb + (size_t)nblk * (U * 4 * KP);
+  {
+    const double2 xl = rowp[N - 1];
+    const double2* p2 = rowp + lg - 1;
+    for (int j = 0; j < nleft; ++j) {
+      double Bv[NT];
+      loadB(tbs, Bv);
+      kstep(xl, p2[4 * j], Bv);
+      tbs += (size_t)4 * KP;
+    }
+  }
+  double outv[MT][NT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) outv[m][n][r] = acc[m][n][r];
+  __builtin_amdgcn_sched_barrier(0);
+  emission_scaled_epilogue<NT, MT>(outv, bad_s, wave, li, lg, g0, nrows, K, 0, ll, kexp);
 }
 
 // ------------------------------------------------------------------------------------

@@ -106,7 +106,8 @@ struct svihmm_ctx {
   bool have_globals = false;
   // emission
   int eK = 0, eD = 0, Kp = 0, F = 0, Fp = 0;
-  Buf theta, fab, niw, cat_table, partc;
+  Buf theta, theta_orb, fab, niw, cat_table, partc;
+  bool orb_valid = false;   // theta_orb matches theta (k_theta_orbit ran since the last parameter upload)
   bool emis_cat = false; int V = 0;          // Categorical emission: table [V][K] = E log theta
   void* theta_zero_p = nullptr; size_t theta_zero_n = 0;   // what the last theta memset covered
   int tabD = -1;
@@ -461,6 +462,7 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
   // status comes back asynchronously; it is examined at the next synchronising call
   h->status_pending = true;
   h->eK = K; h->eD = D; h->have_emission = true; h->emis_cat = false;
+  h->orb_valid = false;
   return 0;
 }
 
@@ -563,6 +565,28 @@ static int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool sc
   }
   int var = h->variant[0];
   if (var == 0 || scaled) var = 2;
+  // scaled output, D % 8 == 0: the address-free orbit schedule (variant[5] = 1 keeps K1b)
+  if (scaled && K <= 64 && D >= 8 && D <= 40 && D % 8 == 0 && h->variant[5] != 1 && min_lds == 0) {
+    const int NT = Kp / 16, LEN = D + D / 2 + 1;
+    const int nks = (D / 4) * (D / 2 + 1) + (D / 2 + 1 + 3) / 4;
+    if (!h->orb_valid) {
+      CK(ensure(h->theta_orb, (size_t)nks * 4 * Kp * sizeof(double)));
+      hipLaunchKernelGGL(k_theta_orbit, dim3(nks * 4), dim3(64), 0, stream, (const double*)h->theta.p,
+                         D, Kp, NT, (double*)h->theta_orb.p);
+      HIPCK(hipGetLastError());
+      h->orb_valid = true;
+    }
+    const size_t lds = (size_t)128 * LEN * 8 + 128 * 9;
+    dim3 grid((unsigned)((n + 127) / 128));
+#define EMO(NTV, UV) hipLaunchKernelGGL((k_emission_orbit<NTV, UV>), grid, dim3(256), lds, stream,           \
+                                        (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K,               \
+                                        (const double*)h->theta_orb.p, flags, out, kexp_out)
+    if (D % 16 == 0) { if (NT == 4) EMO(4, 4); else if (NT == 3) EMO(3, 4); else if (NT == 2) EMO(2, 4); else EMO(1, 4); }
+    else             { if (NT == 4) EMO(4, 2); else if (NT == 3) EMO(3, 2); else if (NT == 2) EMO(2, 2); else EMO(1, 2); }
+#undef EMO
+    HIPCK(hipGetLastError());
+    return 0;
+  }
   if (var == 2) {
     const int DS = (D + 2) | 1;
     int MT = h->variant[3] > 0 ? h->variant[3] : 2;

@@ -303,7 +303,7 @@ class HipEngine(object):
         return {n: (float(m), int(c)) for n, m, c in zip(names, ms, cnt) if c > 0}
 
     def set_variant(self, which, value):
-        idx = {"emission": 0, "stats": 1, "fb": 2, "emission_mt": 3, "pipeline": 4, "chain": 6}[which] if isinstance(which, str) else which
+        idx = {"emission": 0, "stats": 1, "fb": 2, "emission_mt": 3, "pipeline": 4, "emission_orbit": 5, "chain": 6}[which] if isinstance(which, str) else which
         L.check(self._lib.svihmm_set_variant(self._h, idx, int(value)), "set_variant")
 
     def selftest_mfma(self, A, B):

@@ -1,19 +1,26 @@
-import sys,time; sys.path.insert(0,'.')
+"""A/B of the two scaled emission GEMMs on the bench shape (same process, same box):
+variant emission_orbit = 1 keeps K1b (table-driven features), 0 = K1c (orbit schedule)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import bench
 from pysvihmm_amd.engine import HipEngine
-from tests.helpers import make_problem
-from oracle import ref_c
-K,D,Lm,T=64,32,257,1000000
-pb=make_problem(K,D,T,seed=1,sep=5.0)
-e=HipEngine(0); e.set_obs(pb['obs'],None); e.set_globals(pb['mod_init'],pb['ltran']); e.set_emission_niw(pb['mu'],pb['sigma'],pb['kappa'],pb['nu'])
-B=3891; starts=np.arange(B,dtype=np.int64)*Lm
-ref=ref_c.lliks_niw(pb['obs'][:Lm],pb['mu'],pb['sigma'],pb['kappa'],pb['nu'])
+from pysvihmm_amd import _lib as L
+pb = bench.synth(0)
+e = HipEngine(0)
+e.set_obs(pb["obs"], None)
+B = bench.T // bench.LM
+st = np.arange(B, dtype=np.int64) * bench.LM
+e.set_globals(pb["mod_init"], pb["ltran"]); e.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+res = {}
 for rnd in range(3):
-  for mt in (2,4):
-    e.set_variant('emission_mt',mt)
-    e.estep(starts,Lm,read=False); e.sync()
-    e.profile(True); e.profile_reset()
-    for _ in range(5): e.estep(starts,Lm,read=False)
-    p=e.profile_read(); e.profile(False)
-    ll=e.read_rows('lliks',0,Lm)
-    print(rnd,'MT',mt,'emission %.3f ms'%(p['emission'][0]/p['emission'][1]),'err',np.abs(ll-ref).max())
+    for v in (1, 0):
+        e.set_variant("emission_orbit", v)
+        for _ in range(2): e.estep(st, bench.LM, flags=L.TRANS_WRAP, read=False)
+        e.sync(); e.profile(True); e.profile_reset()
+        for _ in range(10): e.estep(st, bench.LM, flags=L.TRANS_WRAP, read=False)
+        p = e.profile_read(); e.profile(False)
+        res[v] = e.read_packed().buf.copy()
+        print(rnd, "orbit" if v == 0 else "table", {k: round(x[0] / max(x[1], 1), 4) for k, x in p.items() if x[1]})
+d = np.abs(res[0] - res[1]) / (np.abs(res[1]) + 1e-300)
+print("packed statistics, orbit vs table: max rel diff %.3g" % d.max())
