@@ -265,6 +265,21 @@ __global__ __launch_bounds__(256) void k_emission_mfma(
 //  Per k-step: 2 LDS reads, 2 v_mul_f64, NT/2 global loads, 2 NT MFMAs; no table, no
 //  unpacking, two address adds per U k-steps.  141 k-steps at D = 32 instead of 144.
 // ------------------------------------------------------------------------------------
+// theta entry of the feature pair (i <= j <= D) for state k, in both layouts: the canonical
+// row feat_index(i, j) and -- when `orb` is given -- its place in the orbit schedule
+__device__ __forceinline__ void theta_store(double* __restrict__ theta, double* __restrict__ orb,
+                                            int i, int j, int D, int Kp, int k, double v) {
+  theta[(size_t)(i * (D + 1) - i * (i - 1) / 2 + (j - i)) * Kp + k] = v;
+  if (orb) {
+    const int N = D + 1, c = D >> 2, nd = (D >> 1) + 1, NT = Kp >> 4;
+    const int d = j - i;
+    const int a = d <= (D >> 1) ? i : j, dl = d <= (D >> 1) ? d : N - d;
+    int lg, st;
+    if (a < N - 1) { lg = a / c; st = dl * c + (a - lg * c); }
+    else { lg = dl & 3; st = c * nd + (dl >> 2); }
+    orb[(size_t)(4 * st + lg) * Kp + (k & 15) * NT + (k >> 4)] = v;
+  }
+}
 __global__ void k_theta_orbit(const double* __restrict__ theta, int D, int Kp, int NT,
                               double* __restrict__ orb) {
   const int fo = blockIdx.x, s = fo >> 2, lg = fo & 3, k = threadIdx.x;
@@ -449,7 +464,7 @@ __device__ __forceinline__ int feat_index_d(int a, int b, int D) {
 __global__ __launch_bounds__(256) void k_niw_to_theta_generic(
     const double* __restrict__ mu, const double* __restrict__ sigma,
     const double* __restrict__ kappa, const double* __restrict__ nu, int K, int D, int Kp,
-    double* __restrict__ theta, int* __restrict__ status) {
+    double* __restrict__ theta, int* __restrict__ status, double* __restrict__ orb) {
   extern __shared__ double sm[];
   const int S = D + 1;
   double* Lm_ = sm;            // [D][S] Cholesky factor (lower)
@@ -512,12 +527,12 @@ __global__ __launch_bounds__(256) void k_niw_to_theta_generic(
     double s = 0.0;
     for (int j = 0; j < D; ++j) s += W[i * S + j] * m[j];
     wm[i] = s;
-    theta[(size_t)feat_index_d(i, D, D) * Kp + k] = 2.0 * s;
+    theta_store(theta, orb, i, D, D, Kp, k, 2.0 * s);
   }
   for (int e = tid; e < D * D; e += nt) {
     const int i = e / D, j = e - i * D;
     if (j < i) continue;
-    theta[(size_t)feat_index_d(i, j, D) * Kp + k] = (i == j) ? -W[i * S + i] : -2.0 * W[i * S + j];
+    theta_store(theta, orb, i, j, D, Kp, k, (i == j) ? -W[i * S + i] : -2.0 * W[i * S + j]);
   }
   __syncthreads();
   if (tid == 0) {
@@ -529,7 +544,7 @@ __global__ __launch_bounds__(256) void k_niw_to_theta_generic(
     }
     llt -= 2.0 * logdet;
     const double cst = 0.5 * llt - D / (2.0 * kappa[k]) - 0.5 * D * 1.8378770664093454835606594728112;
-    theta[(size_t)feat_index_d(D, D, D) * Kp + k] = cst - mWm;
+    theta_store(theta, orb, D, D, D, Kp, k, cst - mWm);
   }
 }
 
@@ -543,7 +558,7 @@ template <int DMAX>
 __global__ __launch_bounds__(64) void k_niw_to_theta_wave(
     const double* __restrict__ mu, const double* __restrict__ sigma,
     const double* __restrict__ kappa, const double* __restrict__ nu, int K, int D, int Kp,
-    double* __restrict__ theta, int* __restrict__ status) {
+    double* __restrict__ theta, int* __restrict__ status, double* __restrict__ orb) {
   __shared__ double col[64];
   __shared__ double Ls[DMAX][DMAX + 1];    // L (row-major), later X = L^-1 stored as Ls[c][r]
   __shared__ double ms[DMAX];
@@ -613,9 +628,9 @@ __global__ __launch_bounds__(64) void k_niw_to_theta_wave(
     const double w = hn * s;
     wmi = fma(w, ms[j], wmi);
     if (va && j >= i && j < D)
-      theta[(size_t)feat_index_d(i, j, D) * Kp + k] = (i == j) ? -w : -2.0 * w;
+      theta_store(theta, orb, i, j, D, Kp, k, (i == j) ? -w : -2.0 * w);
   }
-  if (va) theta[(size_t)feat_index_d(i, D, D) * Kp + k] = 2.0 * wmi;
+  if (va) theta_store(theta, orb, i, D, D, Kp, k, 2.0 * wmi);
   // ---- constant term
   double dgm = va ? digamma_d(0.5 * (nu[k] - a)) : 0.0;
   double mWm = va ? ms[a < DMAX ? a : 0] * wmi : 0.0;
@@ -623,6 +638,6 @@ __global__ __launch_bounds__(64) void k_niw_to_theta_wave(
   if (a == 0) {
     const double llt = D * log(2.0) + dgm - 2.0 * logdet;
     const double cst = 0.5 * llt - D / (2.0 * kappa[k]) - 0.5 * D * 1.8378770664093454835606594728112;
-    theta[(size_t)feat_index_d(D, D, D) * Kp + k] = cst - mWm;
+    theta_store(theta, orb, D, D, D, Kp, k, cst - mWm);
   }
 }

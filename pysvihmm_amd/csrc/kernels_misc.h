@@ -3,14 +3,29 @@
 #pragma once
 
 // small utility kernels
-__global__ void k_exp_transpose(const double* __restrict__ ltran, int K, double* __restrict__ A,
+// `src` = [ltran K*K | mod_init K] in a pinned host slot (device-visible): the kernel pulls the
+// globals over PCIe itself (device copies of both + exp(ltran) and its transpose).  A kernel
+// reading mapped host memory starts ~8 us after its predecessor; a hipMemcpyAsync of the same
+// few KB took 20-40 us of stream time on this stack (kernel trace, tools/trace_gaps.py).
+__global__ void k_exp_transpose(const double* __restrict__ src, int K, double* __restrict__ ltran,
+                                double* __restrict__ mod_init, double* __restrict__ A,
                                 double* __restrict__ AT) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < K) mod_init[idx] = src[(size_t)K * K + idx];
   if (idx >= K * K) return;
   const int i = idx / K, j = idx - i * K;
-  const double v = exp(ltran[idx]);
+  const double l = src[idx];
+  const double v = exp(l);
+  ltran[idx] = l;
   A[idx] = v;
   AT[(size_t)j * K + i] = v;
+}
+// small host -> device upload as a kernel: dst[i] = src[i], src in a pinned (device-visible)
+// host slot, 8-byte words
+__global__ __launch_bounds__(256) void k_pull(const unsigned long long* __restrict__ src,
+                                              unsigned long long* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    dst[i] = src[i];
 }
 
 __global__ void k_selftest_mfma(const double* __restrict__ A, const double* __restrict__ Bm,

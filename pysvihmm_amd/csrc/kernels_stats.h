@@ -525,10 +525,25 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
 //  K5: deterministic reduction of the per-chunk partials + scatter into the packed layout
 //      packed = [A_raw K*K | xbar K*D | neff K | S K*D*D | lb]
 // ------------------------------------------------------------------------------------
+// With `local_lb` the launch carries one extra workgroup that adds up the B per-window ELBO
+// terms into the last packed slot (fixed order; saves a kernel on the E-step's critical path).
 __global__ void k_finalize(const double* __restrict__ part, int nchunk, int D, int K,
                            int Kp, int Fp, int F, const int* __restrict__ fab,
-                           double* __restrict__ packed) {
+                           double* __restrict__ packed, const double* __restrict__ local_lb, int B) {
   const int Ftot = Fp + Kp;
+  if (local_lb && blockIdx.x == gridDim.x - 1) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < B; b += 256) acc += local_lb[b];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) packed[(size_t)K * K + (size_t)K * D + K + (size_t)K * D * D] = red[0];
+    return;
+  }
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)Ftot * Kp) return;
   const int f = idx / Kp, k = idx - (int64_t)f * Kp;

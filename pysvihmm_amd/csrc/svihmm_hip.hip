@@ -107,6 +107,10 @@ struct svihmm_ctx {
   // emission
   int eK = 0, eD = 0, Kp = 0, F = 0, Fp = 0;
   Buf theta, theta_orb, fab, niw, cat_table, partc;
+  void *slack_a = nullptr, *slack_t = nullptr;   // Aexp / AexpT whose slack rows are zeroed
+  int slack_k = 0;
+  void* orb_zero_p = nullptr; size_t orb_zero_n = 0;
+  int lb_pending = 0;       // windows whose local_lb sum has not been written to packed yet
   bool orb_valid = false;   // theta_orb matches theta (k_theta_orbit ran since the last parameter upload)
   bool emis_cat = false; int V = 0;          // Categorical emission: table [V][K] = E log theta
   void* theta_zero_p = nullptr; size_t theta_zero_n = 0;   // what the last theta memset covered
@@ -248,6 +252,7 @@ int svihmm_destroy(svihmm_ctx* h) {
 
 static int check_emission_status(svihmm_ctx* h);
 static int pinned(svihmm_ctx* h, size_t bytes, void** out, int* slot_out);
+static int pull_small(svihmm_ctx* h, void* dst, const void* pin, size_t bytes);
 static int pin_release(svihmm_ctx* h, int slot);
 int svihmm_sync(svihmm_ctx* h) {
   CK(set_device(h));
@@ -321,22 +326,26 @@ int svihmm_set_globals(svihmm_ctx* h, int32_t K, const double* mod_init, const d
   const size_t slack = (size_t)16 * K * sizeof(double);
   CK(ensure(h->Aexp, kk + slack));
   CK(ensure(h->AexpT, kk + slack));
-  HIPCK(hipMemsetAsync((char*)h->Aexp.p + kk, 0, slack, h->stream));
-  HIPCK(hipMemsetAsync((char*)h->AexpT.p + kk, 0, slack, h->stream));
+  if (h->slack_a != h->Aexp.p || h->slack_t != h->AexpT.p || h->slack_k != K) {   // once per (buffers, K)
+    HIPCK(hipMemsetAsync((char*)h->Aexp.p + kk, 0, slack, h->stream));
+    HIPCK(hipMemsetAsync((char*)h->AexpT.p + kk, 0, slack, h->stream));
+    h->slack_a = h->Aexp.p; h->slack_t = h->AexpT.p; h->slack_k = K;
+  }
   void* pin = nullptr;
   int slot = 0;
   CK(pinned(h, kk + K * sizeof(double), &pin, &slot));
   std::memcpy(pin, ltran, kk);
   std::memcpy((char*)pin + kk, mod_init, K * sizeof(double));
-  HIPCK(hipMemcpyAsync(h->ltran.p, pin, kk, hipMemcpyHostToDevice, h->stream));
-  HIPCK(hipMemcpyAsync(h->mod_init.p, (char*)pin + kk, K * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  CK(pin_release(h, slot));
   {
     ProfScope ps(h, KS_MISC);
+    void* dpin = nullptr;
+    HIPCK(hipHostGetDevicePointer(&dpin, pin, 0));
     hipLaunchKernelGGL(k_exp_transpose, dim3((K * K + 255) / 256), dim3(256), 0, h->stream,
-                       (const double*)h->ltran.p, K, (double*)h->Aexp.p, (double*)h->AexpT.p);
+                       (const double*)dpin, K, (double*)h->ltran.p, (double*)h->mod_init.p,
+                       (double*)h->Aexp.p, (double*)h->AexpT.p);
   }
   HIPCK(hipGetLastError());
+  CK(pin_release(h, slot));   // guards the slot until the kernel has read it
   h->K = K; h->have_globals = true;
   return 0;
 }
@@ -351,7 +360,7 @@ static int pinned(svihmm_ctx* h, size_t bytes, void** out, int* slot_out) {
   if (bytes > ps.cap) {
     if (ps.p) hipHostFree(ps.p);
     ps.p = nullptr; ps.cap = 0;
-    HIPCK(hipHostMalloc(&ps.p, bytes + 4096, hipHostMallocDefault));
+    HIPCK(hipHostMalloc(&ps.p, bytes + 4096, hipHostMallocMapped));   // kernels pull from the slots
     ps.cap = bytes + 4096;
   }
   if (!ps.ev) HIPCK(hipEventCreateWithFlags(&ps.ev, hipEventDisableTiming));
@@ -431,7 +440,7 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
   std::memcpy(hp + nmu, sigma, nsg * sizeof(double));
   std::memcpy(hp + nmu + nsg, kappa, K * sizeof(double));
   std::memcpy(hp + nmu + nsg + K, nu, K * sizeof(double));
-  HIPCK(hipMemcpyAsync(dmu, hp, nin * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  CK(pull_small(h, dmu, hp, nin * sizeof(double)));
   CK(pin_release(h, slot));
   // theta's padded rows / columns are zeroed once per (buffer, shape); k_niw_to_theta
   // rewrites every live entry on each call
@@ -439,11 +448,23 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
     HIPCK(hipMemsetAsync(h->theta.p, 0, (size_t)Fp * Kp * sizeof(double), h->stream));
     h->theta_zero_p = h->theta.p; h->theta_zero_n = (size_t)Fp * Kp;
   }
+  // shapes the orbit-schedule emission kernel takes: theta is written in its layout as well
+  double* orbp = nullptr;
+  if (K <= 64 && D >= 8 && D <= 40 && D % 8 == 0) {
+    const size_t nks = (size_t)(D / 4) * (D / 2 + 1) + (D / 2 + 1 + 3) / 4;
+    const size_t nb = nks * 4 * Kp * sizeof(double);
+    CK(ensure(h->theta_orb, nb));
+    if (h->orb_zero_p != h->theta_orb.p || h->orb_zero_n != nb) {   // padding rows / columns: once
+      HIPCK(hipMemsetAsync(h->theta_orb.p, 0, nb, h->stream));
+      h->orb_zero_p = h->theta_orb.p; h->orb_zero_n = nb;
+    }
+    orbp = (double*)h->theta_orb.p;
+  }
   {
     ProfScope ps(h, KS_MISC);
 #define NIWW(DM) hipLaunchKernelGGL(k_niw_to_theta_wave<DM>, dim3(K), dim3(64), 0, h->stream, (const double*)dmu, \
                                     (const double*)dsg, (const double*)dka, (const double*)dnu, K, D, Kp,   \
-                                    (double*)h->theta.p, dstatus)
+                                    (double*)h->theta.p, dstatus, orbp)
     if (D <= 8) NIWW(8);
     else if (D <= 16) NIWW(16);
     else if (D <= 32) NIWW(32);
@@ -454,7 +475,7 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
         hipFuncSetAttribute((const void*)k_niw_to_theta_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(k_niw_to_theta_generic, dim3(K), dim3(256), lds, h->stream, (const double*)dmu,
                          (const double*)dsg, (const double*)dka, (const double*)dnu, K, D, Kp,
-                         (double*)h->theta.p, dstatus);
+                         (double*)h->theta.p, dstatus, orbp);
     }
 #undef NIWW
     HIPCK(hipGetLastError());
@@ -462,7 +483,7 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
   // status comes back asynchronously; it is examined at the next synchronising call
   h->status_pending = true;
   h->eK = K; h->eD = D; h->have_emission = true; h->emis_cat = false;
-  h->orb_valid = false;
+  h->orb_valid = orbp != nullptr;
   return 0;
 }
 
@@ -516,6 +537,20 @@ static int check_windows(svihmm_ctx* h, const int64_t* starts, int B, int Lm, bo
   return 0;
 }
 
+// small upload through a pinned slot, pulled by a kernel (see k_exp_transpose)
+static int pull_small(svihmm_ctx* h, void* dst, const void* pin, size_t bytes) {
+  const size_t n = bytes / 8;
+  unsigned blocks = (unsigned)((n + 1023) / 1024);
+  if (blocks > 512) blocks = 512;
+  if (blocks < 1) blocks = 1;
+  void* dpin = nullptr;
+  HIPCK(hipHostGetDevicePointer(&dpin, const_cast<void*>(pin), 0));
+  hipLaunchKernelGGL(k_pull, dim3(blocks), dim3(256), 0, h->stream, (const unsigned long long*)dpin,
+                     (unsigned long long*)dst, n);
+  HIPCK(hipGetLastError());
+  return 0;
+}
+
 static int upload_starts(svihmm_ctx* h, const int64_t* starts, int B) {
   CK(ensure(h->starts, (size_t)B * sizeof(int64_t)));
   const size_t nb = (size_t)B * sizeof(int64_t);
@@ -524,7 +559,7 @@ static int upload_starts(svihmm_ctx* h, const int64_t* starts, int B) {
     int slot = 0;
     CK(pinned(h, nb, &pin, &slot));
     std::memcpy(pin, starts, nb);
-    HIPCK(hipMemcpyAsync(h->starts.p, pin, nb, hipMemcpyHostToDevice, h->stream));
+    CK(pull_small(h, h->starts.p, pin, nb));
     CK(pin_release(h, slot));
   } else {
     HIPCK(hipMemcpyAsync(h->starts.p, starts, nb, hipMemcpyHostToDevice, h->stream));
@@ -853,6 +888,8 @@ static int ensure_q(svihmm_ctx* h, int B, int Lm, hipStream_t stream) {
   h->q_valid = true;
   return 0;
 }
+// ELBO total still owed to packed[last] (set by the scaled sweeps, paid by k_finalize or here)
+static int flush_lb(svihmm_ctx* h, hipStream_t stream);
 static int launch_sum_lb(svihmm_ctx* h, int B, hipStream_t stream) {
   double* lbtot = (double*)h->packed.p + (packed_len(h) - 1);
   hipLaunchKernelGGL(k_sum_lb, dim3(1), dim3(256), 0, stream, (const double*)h->local_lb.p, B, lbtot);
@@ -968,8 +1005,14 @@ static int launch_fb_lin(svihmm_ctx* h, int B, int Lm, bool total) {
   if (use_chain(h, B, Lm)) return launch_fb_chain(h, Lm, total);
   CK(ensure_fb_lin(h, B, Lm));
   CK(launch_fb_lin_range(h, 0, B, Lm, h->stream));
-  if (total) CK(launch_sum_lb(h, B, h->stream));
+  if (total) h->lb_pending = B;   // summed by k_finalize's extra workgroup (or flush_lb)
   return 0;
+}
+static int flush_lb(svihmm_ctx* h, hipStream_t stream) {
+  if (!h->lb_pending) return 0;
+  const int B = h->lb_pending;
+  h->lb_pending = 0;
+  return launch_sum_lb(h, B, stream);
 }
 
 // Which sweep implementation a batch uses: 1 wave-per-window (log domain; small batches,
@@ -1133,9 +1176,12 @@ static int launch_stats_finalize(svihmm_ctx* h, int64_t nchunk, hipStream_t stre
   const int D = h->D, K = h->K, Kp = h->Kp, Fp = h->Fp, F = h->F;
   ProfScope ps(h, KS_FINALIZE, stream);
   const int64_t tot = (int64_t)(Fp + Kp) * Kp;
-  hipLaunchKernelGGL(k_finalize, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream,
+  const int lbB = h->lb_pending;     // deferred ELBO total of the scaled sweeps rides along
+  h->lb_pending = 0;
+  hipLaunchKernelGGL(k_finalize, dim3((unsigned)((tot + 255) / 256) + (lbB ? 1 : 0)), dim3(256), 0, stream,
                      (const double*)h->part.p, (int)nchunk, D, K, Kp, Fp, F,
-                     (const int*)h->fab.p, (double*)h->packed.p);
+                     (const int*)h->fab.p, (double*)h->packed.p,
+                     (const double*)(lbB ? h->local_lb.p : nullptr), lbB);
   HIPCK(hipGetLastError());
   return 0;
 }
@@ -1189,7 +1235,7 @@ static int launch_stats_cat(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint3
                        K, Kp, V, (double*)h->packed.p);
     HIPCK(hipGetLastError());
   }
-  return 0;
+  return flush_lb(h, stream);
 }
 
 static int launch_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags) {
@@ -1519,6 +1565,7 @@ int svihmm_estep_minibatch_ex(svihmm_ctx* h, const int64_t* starts, int32_t B, i
     CK(prepare_ll(h, starts, B, Lm, flags, true, var == 3));
     CK(run_fb(h, B, Lm, var, (flags & SVIHMM_KEEP_LBETA) != 0, true));
     CK(launch_stats(h, B, Lm, inner_off, inner_len, flags));
+    CK(flush_lb(h, h->stream));   // no-op when k_finalize carried the ELBO total
   }
   h->have_packed = true;
   h->lastB = B; h->lastLm = Lm;

@@ -10,7 +10,7 @@ rows = list(c.execute("select name, start, end, grid_x*grid_y*grid_z/(workgroup_
                       "from kernels order by start"))
 # one bench step = from a k_exp_transpose to the next one, taken near the end of the run
 idx = [i for i, r in enumerate(rows) if "k_exp_transpose" in r[0]]
-sel = [i for i in idx if rows[i + 3][3] > 1000 if i + 8 < len(rows)]
+sel = [i for i in idx if i + 8 < len(rows) and any(r[3] > 1000 for r in rows[i + 1:i + 7])]
 i0 = sel[-3]
 i1 = [i for i in idx if i > i0][0]
 t0 = rows[i0][1]
