@@ -221,6 +221,36 @@ __global__ __launch_bounds__(256) void k_state_argmax(
   }
 }
 
+// HBM access-pattern probe for the sweeps: every workgroup walks 16 windows in time, reading
+// two [16 x 64] fp64 row sets per step and writing two (the traffic of a forward + backward
+// pair), PERM 0: window-major rows (16 pieces of 512 B, Lm * 512 B apart), PERM 1: the 16
+// windows' rows of a step adjacent (one 8 KB piece).
+template <int PERM>
+__global__ __launch_bounds__(256) void k_probe_pattern(const double* __restrict__ src,
+                                                       double* __restrict__ dst, int Lm) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t gbase = (size_t)blockIdx.x * 16 * Lm * 64;
+  double acc = 0.0;
+  for (int t = 0; t < Lm; ++t) {
+    double v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int w = wave * 4 + r;
+      const size_t o = PERM ? gbase + ((size_t)t * 16 + w) * 64 + lane
+                            : gbase + ((size_t)w * Lm + t) * 64 + lane;
+      v[r] = src[o];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int w = wave * 4 + r;
+      const size_t o = PERM ? gbase + ((size_t)t * 16 + w) * 64 + lane
+                            : gbase + ((size_t)w * Lm + t) * 64 + lane;
+      dst[o] = v[r] + acc;
+      acc += 1e-300;
+    }
+  }
+}
+
 // packed statistics -> host-visible (pinned, mapped) mirror.  An ordinary kernel launch right
 // behind k_finalize / the all-reduce: the runtime's D2H copy command starts ~0.1 ms after its
 // producer in the kernel trace, this one after the usual ~6 us.

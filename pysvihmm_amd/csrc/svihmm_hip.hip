@@ -1803,6 +1803,28 @@ int svihmm_peak_fp64(svihmm_ctx* h, int32_t which, double* tflops_out) {
   // which: 0 mfma (8 blocks/CU), 1 fma, 2 mfma 1 block/CU (1 wave/SIMD), 3 mfma 2 blocks/CU;
   // +16: return s_memtime ticks per loop iteration of block 0 instead of TFLOP/s
   const bool ticks = (which & 16) != 0;
+  if (which >= 400 && which <= 401) {   // sweep access-pattern probe: returns TB/s (read + write)
+    const int Lm = 257, groups = 488;
+    const size_t n = (size_t)groups * 16 * Lm * 64;
+    CK(ensure(h->scratch, 2 * n * sizeof(double)));
+    double* src = (double*)h->scratch.p;
+    double* dst = src + n;
+    HIPCK(hipMemsetAsync(src, 0, n * sizeof(double), h->stream));
+    hipEvent_t e0, e1;
+    HIPCK(hipEventCreate(&e0)); HIPCK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 3; ++rep) {
+      HIPCK(hipEventRecord(e0, h->stream));
+      if (which == 400) hipLaunchKernelGGL(k_probe_pattern<0>, dim3(groups), dim3(256), 0, h->stream, (const double*)src, dst, Lm);
+      else hipLaunchKernelGGL(k_probe_pattern<1>, dim3(groups), dim3(256), 0, h->stream, (const double*)src, dst, Lm);
+      HIPCK(hipEventRecord(e1, h->stream));
+      HIPCK(hipEventSynchronize(e1));
+    }
+    float ms = 0.f;
+    HIPCK(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *tflops_out = 2.0 * n * sizeof(double) / (ms * 1e-3) / 1e12;
+    return 0;
+  }
   if (which >= 200) {   // 200 + 10*nf + mf : mix probe, 2 blocks/CU; returns ns per loop iteration
     const int nf = (which - 200) / 10, mf = (which - 200) % 10;
     const int blocks = 512, threads = 256, iters = 4000;
