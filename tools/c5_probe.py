@@ -16,4 +16,7 @@ t0 = time.time()
 for _ in range(3): e.estep(starts, Lm, read=False)
 e.sync(); dt = (time.time() - t0) / 3
 print("K=%d D=%d T=%d B=%d: %.2f ms/step -> %.3g upd/s" % (K, D, T, B, dt * 1e3, B * Lm * K / dt))
-for k, (ms, c) in e.profile_read().items(): print("   %-18s %9.3f ms" % (k, ms / c))
+for k, (ms, c) in e.profile_read().items(): print("   %-18s %9.3f ms per step (%d launches)" % (k, ms / 3, c // 3))
+F = (D + 1) * (D + 2) // 2
+fl = B * Lm * (2.0 * F * K + 2.0 * (F + K) * K + 2 * 2.0 * K * K * 17 / 16)
+print("   algorithmic MFMA flops per step %.3g -> %.1f TF/s end to end (fp64 peak 78.6)" % (fl, fl / dt / 1e12))
