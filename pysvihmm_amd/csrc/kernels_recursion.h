@@ -1559,3 +1559,154 @@ __global__ __launch_bounds__(64) void k_ffbs_sample(const double* __restrict__ l
     if (lane == 0) z[t] = znext;
   }
 }
+
+// ------------------------------------------------------------------------------------
+//  K6b: FFBS for long chains (hmm_fast.pyx:43-124) without a sequential pass over T.
+//  Forward filter: the exact blocked scan of the scaled sweeps (launch_fb_chain), turned into
+//  lalpha by k_chain_lalpha:  lalpha_t[j] = log(ah_t[j]) + (h_t + K_t) ln 2,  K_t the running
+//  sum of the emission row exponents (integers, so any summation order is exact).
+//  Backward sampling: z_t = F_t(z_{t+1}) with F_t the inverse-CDF draw of
+//  softmax_k(lalpha[t,k] + logA[k, z_{t+1}]) at the recorded uniform u_t -- a composition of
+//  maps {0..K-1} -> {0..K-1}, which is associative:
+//    P1 k_ffbs_paths: one wave per chunk of rows, lane = the chunk's entry state (the state
+//       at the first row of the next chunk); every lane walks its own path down the chunk
+//       and records it, path[t][entry] (one byte).  As soon as all lanes agree (the paths
+//       couple, after a few rows on peaked posteriors) the wave switches to one cooperative
+//       draw per row (lane = state, as K6); coupled paths stay coupled.
+//    P2 k_ffbs_compose: suffix scan of the chunk maps G_c = path[first row of c][.]
+//       (Hillis-Steele, log2 C rounds) -> the entry state of every chunk.
+//    P3 k_ffbs_gather: z[t] = path[t][entry of t's chunk].
+//  The draws use  u_t * sum_k p_k <= cumsum_k p_k  (no division); within 1 ulp of a CDF
+//  boundary the state can differ from K6's -- as it can between K6 and NumPy's summation.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_chain_lalpha(
+    const double* __restrict__ ah, const double* __restrict__ hx, const double* __restrict__ kexp,
+    const double* __restrict__ kbefore, int L, int C, int64_t T, int K, double* __restrict__ out) {
+  __shared__ double kc[1025];
+  __shared__ double part[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int64_t r0 = (int64_t)c * L;
+  const int n = (int)((c == C - 1 ? T : r0 + L) - r0);       // <= L + 1 <= 1025
+  const int per = (n + 255) / 256;
+  const int i0 = tid * per, i1 = i0 + per < n ? i0 + per : n;
+  double s = 0.0;
+  for (int i = i0; i < i1; ++i) s += kexp[r0 + i];
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    double run = kbefore[c];
+    for (int i = 0; i < 256; ++i) { const double v = part[i]; part[i] = run; run += v; }
+  }
+  __syncthreads();
+  s = part[tid];
+  for (int i = i0; i < i1; ++i) { s += kexp[r0 + i]; kc[i] = s; }
+  __syncthreads();
+  for (int64_t e = tid; e < (int64_t)n * K; e += 256) {
+    const int i = (int)(e / K);
+    const double hk = hx[r0 + i] + kc[i];
+    out[r0 * K + e] = fma(hk, LN2_HI_D, fma(hk, LN2_LO_D, log(ah[r0 * K + e])));
+  }
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(64) void k_ffbs_paths(
+    const double* __restrict__ la, const double* __restrict__ logA, const double* __restrict__ unif,
+    int64_t T, int K, int Ls, unsigned char* __restrict__ path) {
+  extern __shared__ double fsm[];
+  double* lAT = fsm;                       // [K][KMAX + 1]: lAT[s][k] = logA[k][s]
+  double* row = lAT + K * (KMAX + 1);      // [2][KMAX] the lalpha row of the step
+  const int lane = threadIdx.x;
+  for (int e = lane; e < K * K; e += 64) {
+    const int k = e / K, sidx = e - k * K;
+    lAT[sidx * (KMAX + 1) + k] = logA[e];
+  }
+  const int64_t lo = (int64_t)blockIdx.x * Ls;
+  const int64_t hi = lo + Ls < T ? lo + Ls : T;
+  int cur = lane < K ? lane : 0;           // lane s: the state at row t+1 on the path entered at s
+  bool coupled = false;
+  __syncthreads();
+  for (int64_t t = hi - 1; t >= lo; --t) {
+    const bool first = t == T - 1;         // no transition term: every entry state draws alike
+    const double r = unif[t];
+    double* rw = row + (t & 1) * KMAX;
+    if (lane < KMAX) rw[lane] = lane < K ? la[t * K + lane] : -INFINITY;
+    if (!coupled) {
+      const double* tr = lAT + cur * (KMAX + 1);
+      double lp[KMAX], m = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        lp[k] = rw[k] + ((first || k >= K) ? 0.0 : tr[k]);
+        m = fmax(m, lp[k]);
+      }
+      double tot = 0.0;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) { lp[k] = k < K ? exp(lp[k] - m) : 0.0; tot += lp[k]; }
+      const double thr = r * tot;
+      double c = 0.0;
+      int zz = K - 1;
+      bool found = false;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        c += lp[k];
+        const bool hit = !found && k < K && thr <= c;
+        zz = hit ? k : zz;
+        found = found || hit;
+      }
+      cur = zz;
+      const int c0 = __builtin_amdgcn_readfirstlane(cur);
+      coupled = __ballot(lane < K && cur != c0) == 0ull;
+    } else {
+      // cooperative draw, lane = state k
+      double lp = -INFINITY;
+      if (lane < K) lp = rw[lane] + (first ? 0.0 : lAT[cur * (KMAX + 1) + lane]);
+      const double m = wave_max(lp);
+      const double pk = lane < K ? exp(lp - m) : 0.0;
+      const double tot = wave_sum(pk);
+      double c = pk;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const double v = __shfl_up(c, o, 64);
+        if (lane >= o) c += v;
+      }
+      const unsigned long long bal = __ballot(lane < K && r * tot <= c);
+      cur = bal ? (__ffsll((long long)bal) - 1) : (K - 1);
+    }
+    if (lane < KMAX) path[t * KMAX + lane] = (unsigned char)cur;
+  }
+}
+
+// P2: maps[c][s] = state at the first row of chunk c given entry state s (= path row lo_c);
+// suffix composition H_c = G_c o G_{c+1} o ... ; entry[c] = H_{c+1}(0) (last chunk: 0, unused).
+__global__ __launch_bounds__(1024) void k_ffbs_compose(const unsigned char* __restrict__ path, int64_t T,
+                                                       int KS, int Ls, int C, unsigned char* __restrict__ mA,
+                                                       unsigned char* __restrict__ mB,
+                                                       unsigned char* __restrict__ entry) {
+  const int n = C * KS;
+  for (int e = threadIdx.x; e < n; e += 1024) {
+    const int c = e / KS, x = e - c * KS;
+    mA[e] = path[(int64_t)c * Ls * KS + x];
+  }
+  __threadfence_block();
+  __syncthreads();
+  unsigned char* src = mA;
+  unsigned char* dst = mB;
+  for (int d = 1; d < C; d <<= 1) {
+    for (int e = threadIdx.x; e < n; e += 1024) {
+      const int c = e / KS, x = e - c * KS;
+      dst[e] = (c + d < C) ? src[c * KS + src[(c + d) * KS + x]] : src[e];
+    }
+    __threadfence_block();
+    __syncthreads();
+    unsigned char* t = src; src = dst; dst = t;
+  }
+  for (int c = threadIdx.x; c < C; c += 1024) entry[c] = (c + 1 < C) ? src[(c + 1) * KS] : 0;
+}
+
+__global__ __launch_bounds__(256) void k_ffbs_gather(const unsigned char* __restrict__ path,
+                                                     const unsigned char* __restrict__ entry, int64_t T,
+                                                     int KS, int Ls, int64_t* __restrict__ z) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  z[t] = path[t * KS + entry[t / Ls]];
+}
+

@@ -110,6 +110,7 @@ struct svihmm_ctx {
   void *slack_a = nullptr, *slack_t = nullptr;   // Aexp / AexpT whose slack rows are zeroed
   int slack_k = 0;
   void* orb_zero_p = nullptr; size_t orb_zero_n = 0;
+  const double* chain_kbef = nullptr; int chain_C = 0, chain_L = 0;   // of the last launch_fb_chain
   int lb_pending = 0;       // windows whose local_lb sum has not been written to packed yet
   bool orb_valid = false;   // theta_orb matches theta (k_theta_orbit ran since the last parameter upload)
   bool emis_cat = false; int V = 0;          // Categorical emission: table [V][K] = E log theta
@@ -235,7 +236,7 @@ int svihmm_destroy(svihmm_ctx* h) {
   Buf* bufs[] = {&h->obs, &h->mask, &h->mod_init, &h->ltran, &h->Aexp, &h->AexpT, &h->theta, &h->niw,
                  &h->fab, &h->starts, &h->ll, &h->la, &h->lb, &h->q, &h->lse_part,
                  &h->local_lb, &h->logz, &h->part, &h->packed, &h->scratch, &h->kexp, &h->hx, &h->gx,
-                 &h->zfac, &h->llE, &h->m_ll, &h->m_la, &h->m_lb, &h->chain, &h->chain2, &h->cat_table, &h->partc};
+                 &h->zfac, &h->llE, &h->m_ll, &h->m_la, &h->m_lb, &h->chain, &h->chain2, &h->cat_table, &h->partc, &h->theta_orb};
   for (Buf* b : bufs) release(*b);
   for (int i = 0; i < 2; ++i) {
     if (h->ev_em[i]) hipEventDestroy(h->ev_em[i]);
@@ -322,8 +323,11 @@ int svihmm_set_globals(svihmm_ctx* h, int32_t K, const double* mod_init, const d
   const size_t kk = (size_t)K * K * sizeof(double);
   CK(ensure(h->mod_init, K * sizeof(double)));
   CK(ensure(h->ltran, kk));
-  // 16 zero rows behind each matrix: the wide-model sweeps read whole 16-state tiles of rows
-  const size_t slack = (size_t)16 * K * sizeof(double);
+  // zero rows behind each matrix: the wide-model sweeps stream whole row tiles of the transition
+  // matrix up to the width they are instantiated for (128 rows for 64 < K <= 128, 256 beyond),
+  // not just up to K rounded to a tile
+  const int reach = K <= 64 ? (K + 15) / 16 * 16 : K <= 128 ? 128 : K <= 256 ? 256 : K;
+  const size_t slack = (size_t)(reach - K + 16) * K * sizeof(double);
   CK(ensure(h->Aexp, kk + slack));
   CK(ensure(h->AexpT, kk + slack));
   if (h->slack_a != h->Aexp.p || h->slack_t != h->AexpT.p || h->slack_k != K) {   // once per (buffers, K)
@@ -927,6 +931,7 @@ static int launch_fb_chain(svihmm_ctx* h, int Lm, bool total) {
   double* lbw = kbef + (C + 1);             // per-chunk local_lb
   double* lzw = lbw + (C + 1);              // scratch logz of the S3 windows
   double* ksum = lzw + (C + 1);             // per-chunk sums of the emission row exponents
+  h->chain_kbef = kbef; h->chain_C = C; h->chain_L = L;
   CK(ensure(h->chain2, (size_t)(C + 1) * sizeof(double2)));
   double2* zfw = (double2*)h->chain2.p;     // scratch zfac of the S3 windows (the global one comes from S2)
   const double* Eh = (const double*)(h->eh_in_llE ? h->llE.p : h->ll.p);
@@ -1658,23 +1663,65 @@ int svihmm_ffbs(svihmm_ctx* h, const double* logA, const double* uniforms, uint3
   if (T <= 0) return fail("svihmm_ffbs: no observations");
   if (T > 2147483647LL) return fail("svihmm_ffbs: T too large");
   int64_t st0 = 0;
-  CK(prepare_ll(h, &st0, 1, (int)T, flags, false));
-  CK(launch_fb(h, 1, (int)T, 0, 1));
   const int K = h->K;
-  CK(ensure(h->scratch, ((size_t)K * K + (size_t)T) * sizeof(double) + (size_t)T * sizeof(int64_t)));
+  if (!h->have_globals) return fail("no globals: call svihmm_set_globals");
+  // forward filter: long chains through the exact blocked scan (scaled sweeps), then lalpha
+  // from (ah, h, K); short ones with the per-window log-domain kernel
+  const double* la = nullptr;
+  if (use_chain(h, 1, (int)T)) {
+    CK(prepare_ll(h, &st0, 1, (int)T, flags, false, true));
+    CK(launch_fb_chain(h, (int)T, false));
+    CK(ensure(h->m_la, (size_t)T * K * sizeof(double)));
+    h->m_nb = 0;
+    ProfScope ps(h, KS_FB);
+    hipLaunchKernelGGL(k_chain_lalpha, dim3(h->chain_C), dim3(256), 0, h->stream, (const double*)h->la.p,
+                       (const double*)h->hx.p, (const double*)h->kexp.p, h->chain_kbef, h->chain_L,
+                       h->chain_C, T, K, (double*)h->m_la.p);
+    HIPCK(hipGetLastError());
+    la = (const double*)h->m_la.p;
+  } else {
+    CK(prepare_ll(h, &st0, 1, (int)T, flags, false));
+    CK(launch_fb(h, 1, (int)T, 0, 1));
+    la = (const double*)h->la.p;
+  }
+  // backward sampling: blocked composition of the per-row draw maps (K <= 64, T >= 1024),
+  // else the sequential single-wave sampler
+  const bool blocked = K <= 64 && T >= 1024 && h->variant[6] != 1;
+  const int KS = K <= 16 ? 16 : K <= 32 ? 32 : 64;
+  const int Ls = T >= 65536 ? 512 : 256;
+  const int Cs = (int)((T + Ls - 1) / Ls);
+  const size_t base = ((size_t)K * K + (size_t)T) * sizeof(double) + (size_t)T * sizeof(int64_t);
+  const size_t extra = blocked ? (size_t)T * KS + 2 * (size_t)Cs * KS + (size_t)Cs + 64 : 0;
+  CK(ensure(h->scratch, base + extra));
   double* dlogA = (double*)h->scratch.p;
   double* dun = dlogA + (size_t)K * K;
   int64_t* dz = (int64_t*)(dun + T);
+  unsigned char* path = (unsigned char*)(dz + T);
+  unsigned char* mA = path + (size_t)T * KS;
+  unsigned char* mB = mA + (size_t)Cs * KS;
+  unsigned char* entry = mB + (size_t)Cs * KS;
   HIPCK(hipMemcpyAsync(dlogA, logA, (size_t)K * K * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCK(hipMemcpyAsync(dun, uniforms, (size_t)T * sizeof(double), hipMemcpyHostToDevice, h->stream));
   {
     ProfScope ps(h, KS_FFBS);
-    hipLaunchKernelGGL(k_ffbs_sample, dim3(1), dim3(64), K > 64 ? (size_t)K * 8 : 0, h->stream,
-                       (const double*)h->la.p, (const double*)dlogA, (const double*)dun, T, K, dz);
+    if (blocked) {
+#define FPATH(KM)                                                                                          \
+  hipLaunchKernelGGL(k_ffbs_paths<KM>, dim3(Cs), dim3(64), ((size_t)K * (KM + 1) + 2 * KM) * sizeof(double), \
+                     h->stream, la, (const double*)dlogA, (const double*)dun, T, K, Ls, path)
+      if (KS == 16) FPATH(16); else if (KS == 32) FPATH(32); else FPATH(64);
+#undef FPATH
+      hipLaunchKernelGGL(k_ffbs_compose, dim3(1), dim3(1024), 0, h->stream, (const unsigned char*)path, T, KS,
+                         Ls, Cs, mA, mB, entry);
+      hipLaunchKernelGGL(k_ffbs_gather, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, h->stream,
+                         (const unsigned char*)path, (const unsigned char*)entry, T, KS, Ls, dz);
+    } else {
+      hipLaunchKernelGGL(k_ffbs_sample, dim3(1), dim3(64), K > 64 ? (size_t)K * 8 : 0, h->stream,
+                         la, (const double*)dlogA, (const double*)dun, T, K, dz);
+    }
     HIPCK(hipGetLastError());
   }
   CK(d2h(h, out_z, dz, (size_t)T * sizeof(int64_t)));
-  if (out_lalpha) CK(d2h(h, out_lalpha, h->la.p, (size_t)T * K * sizeof(double)));
+  if (out_lalpha) CK(d2h(h, out_lalpha, la, (size_t)T * K * sizeof(double)));
   HIPCK(hipStreamSynchronize(h->stream));
   h->lastB = 1; h->lastLm = (int)T;
   return 0;

@@ -74,3 +74,41 @@ def test_chain_batch_statistics_vs_oracle(eng):
         np.testing.assert_allclose(st.xbar, xbar, rtol=RTOL, atol=1e-8 * T)
         np.testing.assert_allclose(st.S, S, rtol=RTOL, atol=1e-7 * T)
         np.testing.assert_allclose(st.lb[0], lb, rtol=1e-10)
+
+
+@pytest.mark.parametrize("K,T", [(5, 5000), (16, 3000), (40, 70001), (64, 9000)])
+def test_ffbs_long_chain_blocked(K, T):
+    """FFBS of a long chain (hmm_fast.pyx:43-124): forward filter through the blocked scan
+    (lalpha from the scaled messages) and backward sampling by composition of the per-row draw
+    maps, against the C oracle's forward pass and a row-by-row check of every draw:
+    z[t] must be the inverse-CDF draw of softmax(lalpha[t] + logA[:, z[t+1]]) at u[t]."""
+    from pysvihmm_amd.engine import HipEngine
+    from oracle import ref_c
+    D = 3
+    pb = make_problem(K, D, T, seed=K + 11, sep=1.5, miss=0.0)     # weakly separated: slow coupling
+    DE = np.finfo(np.float64).eps
+    logA = np.log(pb["var_tran"] + DE)
+    u = np.random.default_rng(K).random(T)
+    e = HipEngine(0)
+    e.set_obs(pb["obs"], None)
+    e.set_globals(pb["mod_init"], logA)
+    e.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    z, la = e.ffbs(logA, u)
+    ll = ref_c.lliks_niw(pb["obs"], pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    ref = ref_c.forward(ll, pb["mod_init"], logA)
+    np.testing.assert_allclose(la, ref, rtol=1e-9, atol=1e-6)
+    assert z.min() >= 0 and z.max() < K
+    # every draw, vectorised: p = softmax(lalpha[t] + logA[:, z[t+1]]), first k with u <= cumsum
+    lp = ref.copy()
+    lp[:-1] += logA[:, z[1:]].T
+    p = np.exp(lp - lp.max(axis=1, keepdims=True))
+    p /= p.sum(axis=1, keepdims=True)
+    c = np.cumsum(p, axis=1)
+    want = np.minimum((c < u[:, None]).sum(axis=1), K - 1)
+    assert (want == z).mean() > 0.9999          # a mismatch needs u within rounding of a CDF step
+    # the sequential sampler (chain off) follows the same path
+    e.set_variant("chain", 1)
+    z2, la2 = e.ffbs(logA, u)
+    np.testing.assert_allclose(la2, ref, rtol=1e-9, atol=1e-6)
+    assert (z2 == z).mean() > 0.999
+    e.close()
