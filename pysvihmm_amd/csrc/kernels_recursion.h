@@ -1582,6 +1582,8 @@ __global__ __launch_bounds__(64) void k_ffbs_sample(const double* __restrict__ l
 __global__ __launch_bounds__(256) void k_chain_lalpha(
     const double* __restrict__ ah, const double* __restrict__ hx, const double* __restrict__ kexp,
     const double* __restrict__ kbefore, int L, int C, int64_t T, int K, double* __restrict__ out) {
+  // entries whose scaled message underflowed (ah = 0 or denormal: more than ~460 nats below the
+  // row's total) come out as -inf / imprecise here; k_lalpha_fix recomputes exactly those
   __shared__ double kc[1025];
   __shared__ double part[256];
   const int c = blockIdx.x, tid = threadIdx.x;
@@ -1605,6 +1607,49 @@ __global__ __launch_bounds__(256) void k_chain_lalpha(
     const int i = (int)(e / K);
     const double hk = hx[r0 + i] + kc[i];
     out[r0 * K + e] = fma(hk, LN2_HI_D, fma(hk, LN2_LO_D, log(ah[r0 * K + e])));
+  }
+}
+
+// lalpha entries the scaled messages cannot represent (ah < 1e-200 relative to a row total of
+// order one) recomputed in the log domain from the previous row:
+//   lalpha_t[j] = LSE_i(lalpha_{t-1}[i] + ltran[i,j]) + ll_t[j]       (hmmbase.py:292-295)
+// The LSE is carried by the row's large entries, which `src` (k_chain_lalpha's output) has to
+// full precision; what the underflowed entries of row t-1 would add is below e^-460 relative.
+// Every row independently: one wave per row, lane = state j, ltran column in registers.
+// dst = src where no fix is needed (separate buffers: no read/write overlap between rows).
+template <int KMAX>
+__global__ __launch_bounds__(256) void k_lalpha_fix(
+    const double* __restrict__ src, const double* __restrict__ ah, const double* __restrict__ ll,
+    const double* __restrict__ ltran, const double* __restrict__ mod_init, int64_t T, int K,
+    double* __restrict__ dst) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool vj = lane < K;
+  const int jc = vj ? lane : 0;
+  double lt[KMAX];
+#pragma unroll
+  for (int i = 0; i < KMAX; ++i) lt[i] = (i < K && vj) ? ltran[(size_t)i * K + jc] : -INFINITY;
+  const int64_t rows_per_block = 64;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  for (int64_t t = r0 + wave; t < r0 + rows_per_block && t < T; t += 4) {
+    const double a = vj ? ah[t * K + lane] : 1.0;
+    double v = vj ? src[t * K + lane] : 0.0;
+    const bool need = vj && a < 1e-200;
+    if (__ballot(need) != 0ull) {
+      if (t == 0) {
+        if (need) v = mod_init[lane] + ll[lane];
+      } else {
+        const double* __restrict__ pr = src + (t - 1) * K;     // uniform row: scalar loads
+        double m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) m = fmax(m, (i < K ? pr[i] : -INFINITY) + lt[i]);
+        double sm = 0.0;
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) sm += exp((i < K ? pr[i] : -INFINITY) + lt[i] - m);
+        const double fixed = (m > -INFINITY ? m + log(sm) : -INFINITY) + ll[t * K + jc];
+        if (need) v = fixed;
+      }
+    }
+    if (vj) dst[t * K + lane] = v;
   }
 }
 

@@ -1679,6 +1679,21 @@ int svihmm_ffbs(svihmm_ctx* h, const double* logA, const double* uniforms, uint3
                        h->chain_C, T, K, (double*)h->m_la.p);
     HIPCK(hipGetLastError());
     la = (const double*)h->m_la.p;
+    if (out_lalpha) {
+      // the caller wants lalpha itself: entries the scaled messages lost to underflow are
+      // recomputed in the log domain (plain lliks into m_ll, corrected copy into m_lb)
+      CK(ensure(h->m_ll, (size_t)T * K * sizeof(double)));
+      CK(ensure(h->m_lb, (size_t)T * K * sizeof(double)));
+      CK(launch_emission(h, 1, (int)T, flags, false, nullptr, (double*)h->m_ll.p));
+      const unsigned nblk = (unsigned)((T + 63) / 64);
+#define LFIX(KM) hipLaunchKernelGGL(k_lalpha_fix<KM>, dim3(nblk), dim3(256), 0, h->stream, la, (const double*)h->la.p, \
+                                    (const double*)h->m_ll.p, (const double*)h->ltran.p,                         \
+                                    (const double*)h->mod_init.p, T, K, (double*)h->m_lb.p)
+      if (K <= 16) LFIX(16); else if (K <= 32) LFIX(32); else LFIX(64);
+#undef LFIX
+      HIPCK(hipGetLastError());
+      la = (const double*)h->m_lb.p;
+    }
   } else {
     CK(prepare_ll(h, &st0, 1, (int)T, flags, false));
     CK(launch_fb(h, 1, (int)T, 0, 1));

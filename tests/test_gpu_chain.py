@@ -76,16 +76,19 @@ def test_chain_batch_statistics_vs_oracle(eng):
         np.testing.assert_allclose(st.lb[0], lb, rtol=1e-10)
 
 
-@pytest.mark.parametrize("K,T", [(5, 5000), (16, 3000), (40, 70001), (64, 9000)])
-def test_ffbs_long_chain_blocked(K, T):
+@pytest.mark.parametrize("K,T,D,sep", [(5, 5000, 3, 1.5), (16, 3000, 3, 1.5), (40, 70001, 3, 1.5),
+                                       (64, 9000, 3, 1.5), (16, 6000, 8, 14.0), (33, 4000, 16, 9.0)])
+def test_ffbs_long_chain_blocked(K, T, D, sep):
     """FFBS of a long chain (hmm_fast.pyx:43-124): forward filter through the blocked scan
     (lalpha from the scaled messages) and backward sampling by composition of the per-row draw
     maps, against the C oracle's forward pass and a row-by-row check of every draw:
     z[t] must be the inverse-CDF draw of softmax(lalpha[t] + logA[:, z[t+1]]) at u[t]."""
     from pysvihmm_amd.engine import HipEngine
     from oracle import ref_c
-    D = 3
-    pb = make_problem(K, D, T, seed=K + 11, sep=1.5, miss=0.0)     # weakly separated: slow coupling
+    # sep 1.5: weakly separated, slow coupling of the sampled paths; sep >= 9 with D >= 8: states
+    # hundreds of nats apart, the scaled forward messages underflow and lalpha needs the
+    # log-domain fix-up to stay finite like the reference's
+    pb = make_problem(K, D, T, seed=K + 11, sep=sep, miss=0.0)
     DE = np.finfo(np.float64).eps
     logA = np.log(pb["var_tran"] + DE)
     u = np.random.default_rng(K).random(T)
@@ -96,6 +99,9 @@ def test_ffbs_long_chain_blocked(K, T):
     z, la = e.ffbs(logA, u)
     ll = ref_c.lliks_niw(pb["obs"], pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
     ref = ref_c.forward(ll, pb["mod_init"], logA)
+    assert np.isfinite(ref).all() and np.isfinite(la).all()
+    if sep > 5:
+        assert (ref.max(axis=1) - ref.min(axis=1)).max() > 800      # beyond what exp() can span
     np.testing.assert_allclose(la, ref, rtol=1e-9, atol=1e-6)
     assert z.min() >= 0 and z.max() < K
     # every draw, vectorised: p = softmax(lalpha[t] + logA[:, z[t+1]]), first k with u <= cumsum
