@@ -1579,9 +1579,24 @@ __global__ __launch_bounds__(64) void k_ffbs_sample(const double* __restrict__ l
 //  The draws use  u_t * sum_k p_k <= cumsum_k p_k  (no division); within 1 ulp of a CDF
 //  boundary the state can differ from K6's -- as it can between K6 and NumPy's summation.
 // ------------------------------------------------------------------------------------
+// ktop != nullptr: the backward messages instead,  lbeta_t[i] = log(bh_t[i]) + (g_t + K_top - K_t) ln 2
+// (ah = bh, hx = gx).
+__global__ void k_ksum_all(const double* __restrict__ kexp, int64_t T, double* __restrict__ ktop) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int64_t t = threadIdx.x; t < T; t += 256) acc += kexp[t];     // integers: exact in any order
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *ktop = red[0];
+}
 __global__ __launch_bounds__(256) void k_chain_lalpha(
     const double* __restrict__ ah, const double* __restrict__ hx, const double* __restrict__ kexp,
-    const double* __restrict__ kbefore, int L, int C, int64_t T, int K, double* __restrict__ out) {
+    const double* __restrict__ kbefore, int L, int C, int64_t T, int K, double* __restrict__ out,
+    const double* __restrict__ ktop = nullptr) {
   // entries whose scaled message underflowed (ah = 0 or denormal: more than ~460 nats below the
   // row's total) come out as -inf / imprecise here; k_lalpha_fix recomputes exactly those
   __shared__ double kc[1025];
@@ -1605,7 +1620,7 @@ __global__ __launch_bounds__(256) void k_chain_lalpha(
   __syncthreads();
   for (int64_t e = tid; e < (int64_t)n * K; e += 256) {
     const int i = (int)(e / K);
-    const double hk = hx[r0 + i] + kc[i];
+    const double hk = hx[r0 + i] + (ktop ? *ktop - kc[i] : kc[i]);
     out[r0 * K + e] = fma(hk, LN2_HI_D, fma(hk, LN2_LO_D, log(ah[r0 * K + e])));
   }
 }
@@ -1650,6 +1665,43 @@ __global__ __launch_bounds__(256) void k_lalpha_fix(
       }
     }
     if (vj) dst[t * K + lane] = v;
+  }
+}
+
+// the backward counterpart:  lbeta_t[i] = LSE_j(ltran[i,j] + lbeta_{t+1}[j] + ll_{t+1}[j])
+// (hmmbase.py:316-320), lbeta_{T-1} = 0; lane = state i, ltran row in registers.
+template <int KMAX>
+__global__ __launch_bounds__(256) void k_lbeta_fix(
+    const double* __restrict__ src, const double* __restrict__ bh, const double* __restrict__ ll,
+    const double* __restrict__ ltran, int64_t T, int K, double* __restrict__ dst) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool vi = lane < K;
+  const int ic = vi ? lane : 0;
+  double lt[KMAX];
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) lt[j] = (j < K && vi) ? ltran[(size_t)ic * K + j] : -INFINITY;
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  for (int64_t t = r0 + wave; t < r0 + 64 && t < T; t += 4) {
+    const double b = vi ? bh[t * K + lane] : 1.0;
+    double v = vi ? src[t * K + lane] : 0.0;
+    const bool need = vi && b < 1e-200;
+    if (__ballot(need) != 0ull) {
+      if (t == T - 1) {
+        if (need) v = 0.0;
+      } else {
+        const double* __restrict__ pr = src + (t + 1) * K;
+        const double* __restrict__ pl = ll + (t + 1) * K;
+        double m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) m = fmax(m, (j < K ? pr[j] + pl[j] : -INFINITY) + lt[j]);
+        double sm = 0.0;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) sm += exp((j < K ? pr[j] + pl[j] : -INFINITY) + lt[j] - m);
+        const double fixed = m > -INFINITY ? m + log(sm) : -INFINITY;
+        if (need) v = fixed;
+      }
+    }
+    if (vi) dst[t * K + lane] = v;
   }
 }
 

@@ -110,7 +110,7 @@ struct svihmm_ctx {
   void *slack_a = nullptr, *slack_t = nullptr;   // Aexp / AexpT whose slack rows are zeroed
   int slack_k = 0;
   void* orb_zero_p = nullptr; size_t orb_zero_n = 0;
-  const double* chain_kbef = nullptr; int chain_C = 0, chain_L = 0;   // of the last launch_fb_chain
+  const double* chain_kbef = nullptr; int chain_C = 0, chain_L = 0, chain_T = 0;   // of the last launch_fb_chain
   int lb_pending = 0;       // windows whose local_lb sum has not been written to packed yet
   bool orb_valid = false;   // theta_orb matches theta (k_theta_orbit ran since the last parameter upload)
   bool emis_cat = false; int V = 0;          // Categorical emission: table [V][K] = E log theta
@@ -931,7 +931,7 @@ static int launch_fb_chain(svihmm_ctx* h, int Lm, bool total) {
   double* lbw = kbef + (C + 1);             // per-chunk local_lb
   double* lzw = lbw + (C + 1);              // scratch logz of the S3 windows
   double* ksum = lzw + (C + 1);             // per-chunk sums of the emission row exponents
-  h->chain_kbef = kbef; h->chain_C = C; h->chain_L = L;
+  h->chain_kbef = kbef; h->chain_C = C; h->chain_L = L; h->chain_T = T;
   CK(ensure(h->chain2, (size_t)(C + 1) * sizeof(double2)));
   double2* zfw = (double2*)h->chain2.p;     // scratch zfac of the S3 windows (the global one comes from S2)
   const double* Eh = (const double*)(h->eh_in_llE ? h->llE.p : h->ll.p);
@@ -1032,7 +1032,7 @@ static int pick_fb(const svihmm_ctx* h, int B, int Lm, bool want_logs) {
     if (var == 3 && (size_t)16 * Lm * h->K * sizeof(double) >= ((size_t)1 << 32)) var = 1;
     return var;
   }
-  if (var == 0) var = want_logs ? (B >= 192 ? 2 : 1) : 3;   // no logs wanted: scaled sweeps at any batch size
+  if (var == 0) var = want_logs ? (use_chain(h, B, Lm) ? 3 : B >= 192 ? 2 : 1) : 3;   // no logs wanted: scaled sweeps at any batch size; logs of one long chain: blocked scan + conversion
   // the scaled sweeps address a workgroup's 16 windows with 32-bit byte offsets
   // (the wave-per-window kernel of small batches uses 64-bit row offsets)
   if (var == 3 && !use_chain(h, B, Lm) && !(B < LIN_WAVE_MAX && h->variant[7] != 2) &&
@@ -1344,7 +1344,38 @@ static int materialise(svihmm_ctx* h, int b0, int nb) {
                        (double*)h->m_ll.p));
     ll = (const double*)h->m_ll.p;
   }
-  CK(launch_fb(h, nb, Lm, 0, 2, ll, (double*)h->m_la.p, (double*)h->m_lb.p));
+  if (h->lastB == 1 && h->chain_T == Lm && h->chain_kbef && use_chain(h, 1, Lm)) {
+    // the blocked scan's messages -> logs (k_chain_lalpha both ways), entries lost to underflow
+    // recomputed in the log domain row by row (k_lalpha_fix / k_lbeta_fix): no sequential pass
+    const size_t ne = (size_t)Lm * K;
+    CK(ensure(h->scratch, (2 * ne + 8) * sizeof(double)));
+    double* ta = (double*)h->scratch.p;
+    double* tb = ta + ne;
+    double* ktop = tb + ne;
+    const int64_t T = Lm;
+    ProfScope ps(h, KS_FB);
+    hipLaunchKernelGGL(k_ksum_all, dim3(1), dim3(256), 0, h->stream, (const double*)h->kexp.p, T, ktop);
+    hipLaunchKernelGGL(k_chain_lalpha, dim3(h->chain_C), dim3(256), 0, h->stream, (const double*)h->la.p,
+                       (const double*)h->hx.p, (const double*)h->kexp.p, h->chain_kbef, h->chain_L,
+                       h->chain_C, T, K, ta, (const double*)nullptr);
+    hipLaunchKernelGGL(k_chain_lalpha, dim3(h->chain_C), dim3(256), 0, h->stream, (const double*)h->lb.p,
+                       (const double*)h->gx.p, (const double*)h->kexp.p, h->chain_kbef, h->chain_L,
+                       h->chain_C, T, K, tb, (const double*)ktop);
+    const unsigned nblk = (unsigned)((T + 63) / 64);
+#define LFIX(KM)                                                                                                  \
+  do {                                                                                                            \
+    hipLaunchKernelGGL(k_lalpha_fix<KM>, dim3(nblk), dim3(256), 0, h->stream, (const double*)ta,                  \
+                       (const double*)h->la.p, ll, (const double*)h->ltran.p, (const double*)h->mod_init.p, T, K, \
+                       (double*)h->m_la.p);                                                                       \
+    hipLaunchKernelGGL(k_lbeta_fix<KM>, dim3(nblk), dim3(256), 0, h->stream, (const double*)tb,                   \
+                       (const double*)h->lb.p, ll, (const double*)h->ltran.p, T, K, (double*)h->m_lb.p);          \
+  } while (0)
+    if (K <= 16) LFIX(16); else if (K <= 32) LFIX(32); else LFIX(64);
+#undef LFIX
+    HIPCK(hipGetLastError());
+  } else {
+    CK(launch_fb(h, nb, Lm, 0, 2, ll, (double*)h->m_la.p, (double*)h->m_lb.p));
+  }
   h->m_b0 = b0; h->m_nb = nb;
   return 0;
 }

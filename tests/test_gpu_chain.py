@@ -118,3 +118,34 @@ def test_ffbs_long_chain_blocked(K, T, D, sep):
     np.testing.assert_allclose(la2, ref, rtol=1e-9, atol=1e-6)
     assert (z2 == z).mean() > 0.999
     e.close()
+
+
+@pytest.mark.parametrize("K,T,D,sep", [(7, 4100, 3, 2.0), (16, 6000, 8, 14.0), (64, 5000, 16, 9.0)])
+def test_chain_logs_from_scaled_messages(K, T, D, sep):
+    """lalpha / lbeta of one long chain (hmmbase.local_update's attributes) come from the blocked
+    scan's scaled messages plus a row-parallel log-domain fix-up of underflowed entries -- no
+    sequential pass -- and match the log-domain C oracle also where states are > 800 nats apart."""
+    from pysvihmm_amd.engine import HipEngine
+    from oracle import ref_c
+    pb = make_problem(K, D, T, seed=K + 3, sep=sep, miss=0.05)
+    e = HipEngine(0)
+    e.set_obs(pb["obs"], pb["mask"])
+    e.set_globals(pb["mod_init"], pb["ltran"])
+    e.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    r = e.forward_backward([0], T)
+    ll = ref_c.lliks_niw(pb["obs"], pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    la = ref_c.forward(ll, pb["mod_init"], pb["ltran"])
+    lb = ref_c.backward(ll, pb["ltran"])
+    q, lz = ref_c.posterior(la, lb)
+    assert np.isfinite(r["lalpha"]).all() and np.isfinite(r["lbeta"]).all()
+    np.testing.assert_allclose(r["lalpha"][0], la, rtol=1e-9, atol=1e-6)
+    np.testing.assert_allclose(r["lbeta"][0], lb, rtol=1e-9, atol=1e-6)
+    np.testing.assert_allclose(r["var_x"][0], q, rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(r["local_lb"][0], lz, rtol=1e-10)
+    np.testing.assert_allclose(e.read_intermediate("lliks", 1, T)[0], ll, rtol=1e-9, atol=1e-8)
+    # the sequential log-domain kernels give the same thing
+    e.set_variant("chain", 1)
+    r2 = e.forward_backward([0], T)
+    np.testing.assert_allclose(r2["lalpha"][0], r["lalpha"][0], rtol=1e-9, atol=1e-6)
+    np.testing.assert_allclose(r2["lbeta"][0], r["lbeta"][0], rtol=1e-9, atol=1e-6)
+    e.close()
