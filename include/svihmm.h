@@ -189,7 +189,11 @@ int svihmm_read_rows(svihmm_ctx* h, int32_t what, int64_t row0, int64_t nrows,
  * z[t] ~ softmax_k(lalpha[t,k] + log_tran_col[k, z[t+1]]) by inverse CDF
  * (rand_discrete, hmm_fast.pyx:29-36) with uniforms[t] in [0,1) supplied by the
  * caller (libc rand() streams are not reproducible on a device).
- * logA[K,K] = log(var_tran + DBL_EPSILON).  out_z[T] int64, out_lalpha[T,K] or NULL. */
+ * logA[K,K] = log(var_tran + DBL_EPSILON).  out_z[T] int64, out_lalpha[T,K] or NULL.
+ * Long chains (K <= 64, T >= 2048) take no sequential pass over T: the forward filter runs as
+ * the blocked scan of the full-chain E-step, the draws z[t] = F_t(z[t+1]) are composed as maps
+ * over row chunks (same path as the sequential sampler unless a uniform lies within rounding of
+ * a CDF step); out_lalpha is exact also for entries the scaled scan loses to underflow. */
 int svihmm_ffbs(svihmm_ctx* h, const double* logA, const double* uniforms,
                 uint32_t flags, int64_t* out_z, double* out_lalpha);
 
