@@ -168,6 +168,32 @@ def main():
     barrier()
     dt64 = (time.perf_counter() - t0) / n64
 
+    # whole-chain paths on the same resident sequence (world size 1 only: side figures, outside
+    # the timed region above): the full-sequence E-step (one window of T rows) and FFBS
+    chain = None
+    if world == 1:
+        DE = np.finfo(np.float64).eps
+        t_fc = t_ff = 1e9
+        for rep in range(3):
+            eng.set_globals(pb["mod_init"], pb["ltran"])
+            eng.sync(); t0 = time.perf_counter()
+            eng.estep([0], T, flags=0, read=False); eng.read_packed()
+            t_fc = min(t_fc, time.perf_counter() - t0)
+        logA = np.log(np.exp(pb["ltran"]) + DE)
+        u = np.random.default_rng(1).random(T)
+        eng.set_globals(pb["mod_init"], logA)
+        for rep in range(3):
+            eng.sync(); t0 = time.perf_counter()
+            eng.ffbs(logA, u, want_lalpha=False)
+            t_ff = min(t_ff, time.perf_counter() - t0)
+        chain = {"full_chain_estep": {"T": T, "ms": t_fc * 1e3, "value": T * K / t_fc, "unit": "updates/s",
+                                      "note": "one window = the whole sequence (exact blocked scan), "
+                                              "E-step + statistics"},
+                 "ffbs": {"T": T, "ms": t_ff * 1e3, "value": T * K / t_ff, "unit": "updates/s",
+                          "note": "forward filter (blocked scan) + backward sampling (composed "
+                                  "draw maps), z[T] back on the host"}}
+        eng.set_globals(pb["mod_init"], pb["ltran"])
+
     if rank == 0:
         flops = algorithmic_flops(rows)
         kern = {}
@@ -211,6 +237,8 @@ def main():
             "minibatch_s64": {"windows": 64, "ms_per_step": dt64 * 1e3,
                               "value": 64 * LM * K / dt64, "unit": "updates/s"},
         }
+        if chain:
+            res["whole_chain"] = chain
         if not args.no_cpu_baseline:
             # the reference algorithm restated in C (oracle/ref_c.c), 1 core, bounded sample
             from oracle import ref_c
