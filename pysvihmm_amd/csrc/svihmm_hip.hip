@@ -1713,12 +1713,16 @@ int svihmm_ffbs(svihmm_ctx* h, const double* logA, const double* uniforms, uint3
     if (out_lalpha) {
       // the caller wants lalpha itself: entries the scaled messages lost to underflow are
       // recomputed in the log domain (plain lliks into m_ll, corrected copy into m_lb)
-      CK(ensure(h->m_ll, (size_t)T * K * sizeof(double)));
       CK(ensure(h->m_lb, (size_t)T * K * sizeof(double)));
-      CK(launch_emission(h, 1, (int)T, flags, false, nullptr, (double*)h->m_ll.p));
+      const double* llp = (const double*)h->ll.p;     // host-supplied / two-pass lliks are still there
+      if (!h->eh_in_llE) {
+        CK(ensure(h->m_ll, (size_t)T * K * sizeof(double)));
+        CK(launch_emission(h, 1, (int)T, flags, false, nullptr, (double*)h->m_ll.p));
+        llp = (const double*)h->m_ll.p;
+      }
       const unsigned nblk = (unsigned)((T + 63) / 64);
 #define LFIX(KM) hipLaunchKernelGGL(k_lalpha_fix<KM>, dim3(nblk), dim3(256), 0, h->stream, la, (const double*)h->la.p, \
-                                    (const double*)h->m_ll.p, (const double*)h->ltran.p,                         \
+                                    llp, (const double*)h->ltran.p,                                              \
                                     (const double*)h->mod_init.p, T, K, (double*)h->m_lb.p)
       if (K <= 16) LFIX(16); else if (K <= 32) LFIX(32); else LFIX(64);
 #undef LFIX

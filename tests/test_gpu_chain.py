@@ -149,3 +149,29 @@ def test_chain_logs_from_scaled_messages(K, T, D, sep):
     np.testing.assert_allclose(r2["lalpha"][0], r["lalpha"][0], rtol=1e-9, atol=1e-6)
     np.testing.assert_allclose(r2["lbeta"][0], r["lbeta"][0], rtol=1e-9, atol=1e-6)
     e.close()
+
+
+def test_ffbs_long_chain_host_lliks():
+    """The same path fed with host-evaluated lliks (generic emission plugins,
+    SVIHMM_USE_HOST_LLIKS): the log-domain fix-up reads the uploaded lliks, not an NIW kernel."""
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    from oracle import ref_c
+    K, T = 12, 4500
+    rng = np.random.default_rng(4)
+    ll = rng.normal(size=(T, K)) * 3.0
+    ll[np.arange(T), rng.integers(0, K, size=T)] += 900.0        # one state dominates by 900 nats
+    vt = 1.0 + rng.random((K, K)) * 5
+    logA = np.log(vt + np.finfo(np.float64).eps)
+    mod_init = np.log(rng.dirichlet(np.ones(K)))
+    u = rng.random(T)
+    e = HipEngine(0)
+    e.set_obs(np.zeros((T, 1)), None)
+    e.set_globals(mod_init, logA)
+    e.set_lliks(ll[None])
+    z, la = e.ffbs(logA, u, flags=L.USE_HOST_LLIKS)
+    ref = ref_c.forward(ll, mod_init, logA)
+    assert np.isfinite(la).all()
+    np.testing.assert_allclose(la, ref, rtol=1e-9, atol=1e-6)
+    assert z.min() >= 0 and z.max() < K
+    e.close()
