@@ -1365,6 +1365,110 @@ __global__ __launch_bounds__(256) void k_chunk_scan(
 }
 
 // sum of the emission row exponents of each chunk's own rows [c*Lc, (c+1)*Lc) (last: up to T)
+// S2 for 64 < K <= 256: same recurrences and outputs as k_chunk_scan, thread = state, the chunk
+// matrix streamed straight from HBM / L2 (512 KB per chunk at K = 256: ~10 us per chunk, a few
+// ms per million rows -- S1's T K^3 flops dominate the wide scan by two orders of magnitude,
+// so no ring, no helper waves).  grid 2 (forward / backward), block 256.
+__device__ __forceinline__ double block256_sum(double v, double* red) {
+  v = wave_sum_dpp(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ double block256_max(double v, double* red) {
+  v = wave_max_dpp(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+__global__ __launch_bounds__(256) void k_chunk_scan_wide(
+    const double* __restrict__ Mm, const double* __restrict__ MmT, const double* __restrict__ Mh,
+    int C, int Kp, int K, const double* __restrict__ Eh, const double* __restrict__ ksum,
+    const double* __restrict__ mod_init, double* __restrict__ abnd, double* __restrict__ aexp,
+    double* __restrict__ bbnd, double* __restrict__ bexp, double* __restrict__ kbefore,
+    double2* __restrict__ zfac, double* __restrict__ logz) {
+  __shared__ double ws[256];
+  __shared__ double red[4];
+  const int j = threadIdx.x;
+  const bool vl = j < K;
+  const int jc = vl ? j : 0;
+  const size_t MS = (size_t)Kp * K;
+  const bool fwd = blockIdx.x == 0;
+  const double* __restrict__ Msrc = fwd ? Mm : MmT;
+  auto matvec = [&](const double* __restrict__ M, double w) {
+    __syncthreads();
+    ws[j] = w;
+    __syncthreads();
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    const double* __restrict__ col = M + jc;
+    int i = 0;
+    for (; i + 16 <= K; i += 16) {
+      double m[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) m[u] = col[(size_t)(i + u) * K];
+#pragma unroll
+      for (int u = 0; u < 16; u += 4) {
+        a0 = fma(ws[i + u], m[u], a0);
+        a1 = fma(ws[i + u + 1], m[u + 1], a1);
+        a2 = fma(ws[i + u + 2], m[u + 2], a2);
+        a3 = fma(ws[i + u + 3], m[u + 3], a3);
+      }
+    }
+    for (; i < K; ++i) a0 = fma(ws[i], col[(size_t)i * K], a0);
+    return (a0 + a1) + (a2 + a3);
+  };
+  double a, Hx = 0.0;
+  int e_lag;
+  if (fwd) {
+    double mi_max = -INFINITY;
+    for (int k = 0; k < K; ++k) mi_max = fmax(mi_max, mod_init[k]);
+    const double s0 = (mi_max > -1e300 && mi_max < 1e300) ? ceil(mi_max * LOG2E_D) : 0.0;
+    a = vl ? exp(fma(-s0, LN2_LO_D, fma(-s0, LN2_HI_D, mod_init[jc]))) * Eh[jc] : 0.0;
+    Hx = s0;
+    if (vl) abnd[j] = a;
+    if (j == 0) aexp[0] = Hx;
+  } else {
+    a = vl ? 1.0 : 0.0;
+    if (vl) bbnd[(size_t)C * K + j] = a;
+    if (j == 0) bexp[C] = 0.0;
+  }
+  e_lag = __builtin_amdgcn_frexp_exp(block256_sum(a, red));
+  for (int p = 0; p < C; ++p) {
+    const int c = fwd ? p : C - 1 - p;
+    const double mh = vl ? Mh[(size_t)c * Kp + j] : -INFINITY;
+    const double hm = block256_max(mh, red);
+    if (fwd) {       // a <- a M_c, rows of M_c carry their own exponents
+      const double w = vl ? ldexp(a, (int)(mh - hm) - e_lag) : 0.0;
+      const double acc = matvec(Msrc + (size_t)c * MS, w);
+      Hx += hm + (double)e_lag;
+      a = vl ? acc : 0.0;
+      if (vl) abnd[(size_t)(c + 1) * K + j] = a;
+      if (j == 0) aexp[c + 1] = Hx;
+    } else {         // b <- M_c b (rows of the transposed copy)
+      const double w = vl ? ldexp(a, -e_lag) : 0.0;
+      const double acc = matvec(Msrc + (size_t)c * MS, w);
+      a = vl ? ldexp(acc, (int)(mh - hm)) : 0.0;
+      Hx += hm + (double)e_lag;
+      if (vl) bbnd[(size_t)c * K + j] = a;
+      if (j == 0) bexp[c] = Hx;
+    }
+    e_lag = __builtin_amdgcn_frexp_exp(block256_sum(a, red));
+  }
+  if (fwd) {
+    const double tot = block256_sum(vl ? a : 0.0, red);
+    if (j == 0) {
+      double kb = 0.0;
+      for (int cc = 0; cc < C; ++cc) { kbefore[cc] = kb; kb += ksum[cc]; }
+      const double zm = __builtin_amdgcn_frexp_mant(tot);
+      const double zexp = (double)__builtin_amdgcn_frexp_exp(tot);
+      zfac[0] = make_double2(1.0 / zm, Hx + zexp);
+      logz[0] = log(zm) + (Hx + zexp + kb) * LN2_D;
+    }
+  }
+}
+
 __global__ __launch_bounds__(64) void k_chunk_ksum(const double* __restrict__ kexp, int C, int Lc,
                                                   int64_t T, double* __restrict__ ksum) {
   const int c = blockIdx.x;

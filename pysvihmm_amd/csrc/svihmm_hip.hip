@@ -907,11 +907,14 @@ static int launch_sum_lb(svihmm_ctx* h, int B, hipStream_t stream) {
 // that the sequential boundary scan (S2) stays short (S1's work does not depend on it)
 static int chain_len(int Lm) { return Lm >= 512 * 1024 ? 1024 : 256; }
 static bool use_chain(const svihmm_ctx* h, int B, int Lm) {
-  return B == 1 && h->K <= 64 && Lm >= 2048 && h->variant[6] != 1;
+  return B == 1 && h->K <= 256 && Lm >= 2048 && h->variant[6] != 1;
 }
 static int launch_fb_chain(svihmm_ctx* h, int Lm, bool total) {
   const int K = h->K, T = Lm, L = chain_len(Lm);
-  const int NW = (K + 15) / 16, Kp = 16 * NW;
+  // state tiles the sweep kernels are instantiated for: exact up to 64 states, 8 / 16 tiles with
+  // the transition tile streamed beyond (the chunk matrices are laid out for that width)
+  const int NWt = (K + 15) / 16;
+  const int NW = NWt <= 4 ? NWt : NWt <= 8 ? 8 : 16, Kp = 16 * NW;
   const bool full = (K == Kp);
   const int Cfull = (T - 2) / L;            // interior chunks; the tail chunk has 1..L steps
   const int C = Cfull + 1;
@@ -945,9 +948,20 @@ static int launch_fb_chain(svihmm_ctx* h, int Lm, bool total) {
 #define SWPM(NWV, F, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH)                       \
   hipLaunchKernelGGL((k_sweeps_lin<NWV, F, MD>), GRID, dim3(64 * NWV), sizeof(LinShared<NWV>), st, EHP, KXP, A, At, \
                      mi, BB, LL, WS, K, AH, BH, HX, GX, LB, LZ, ZF, CH)
+#define SWPB(NWV, F, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH)                       \
+  do {                                                                                                      \
+    hipFuncSetAttribute((const void*)k_sweeps_lin<NWV, F, MD, true>,                                        \
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LinShared<NWV>));           \
+    hipLaunchKernelGGL((k_sweeps_lin<NWV, F, MD, true>), GRID, dim3(64 * NWV), sizeof(LinShared<NWV>), st,  \
+                       EHP, KXP, A, At, mi, BB, LL, WS, K, AH, BH, HX, GX, LB, LZ, ZF, CH);                 \
+  } while (0)
 #define SWPD(MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH)                                \
   do {                                                                                                      \
-    if (NW == 1) { if (full) SWPM(1, true, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH); \
+    if (NW == 8) { if (full) SWPB(8, true, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH); \
+                   else SWPB(8, false, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH); }   \
+    else if (NW == 16) { if (full) SWPB(16, true, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH); \
+                         else SWPB(16, false, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH); } \
+    else if (NW == 1) { if (full) SWPM(1, true, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH); \
                    else SWPM(1, false, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH); }   \
     else if (NW == 2) { if (full) SWPM(2, true, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH); \
                         else SWPM(2, false, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH); } \
@@ -978,7 +992,11 @@ static int launch_fb_chain(svihmm_ctx* h, int Lm, bool total) {
                        (const double*)Mh, C, Kp, K, Eh, (const double*)ksum, mi, abnd, aexp, bbnd, bexp, kbef,     \
                        (double2*)h->zfac.p, (double*)h->logz.p);                                                   \
   } while (0)
-  if (K <= 16) SCAN(16); else if (K <= 32) SCAN(32); else SCAN(64);
+  if (K <= 16) SCAN(16); else if (K <= 32) SCAN(32); else if (K <= 64) SCAN(64);
+  else
+    hipLaunchKernelGGL(k_chunk_scan_wide, dim3(2), dim3(256), 0, st, (const double*)Mm, (const double*)MmT,
+                       (const double*)Mh, C, Kp, K, Eh, (const double*)ksum, mi, abnd, aexp, bbnd, bexp, kbef,
+                       (double2*)h->zfac.p, (double*)h->logz.p);
 #undef SCAN
   // S3: every chunk as a window with boundary conditions
   ch.init_vec = abnd; ch.init_exp = aexp; ch.kbefore = kbef;
@@ -993,6 +1011,7 @@ static int launch_fb_chain(svihmm_ctx* h, int Lm, bool total) {
          lbw + Cfull, lzw + Cfull, zfw + Cfull, ct);
   }
 #undef SWPD
+#undef SWPB
 #undef SWPM
   HIPCK(hipGetLastError());
   // local_lb[0] = sum of the chunks' parts (fixed order)
@@ -1028,8 +1047,8 @@ static int pick_fb(const svihmm_ctx* h, int B, int Lm, bool want_logs) {
   if (h->K > 256) return 1;
   if (h->K > 64) {   // no log-domain MFMA sweep beyond 64 states: scaled (streamed B) or per-window
     if (var == 2) var = 1;
-    if (var == 0) var = (B >= 192 && !want_logs) ? 3 : 1;
-    if (var == 3 && (size_t)16 * Lm * h->K * sizeof(double) >= ((size_t)1 << 32)) var = 1;
+    if (var == 0) var = ((B >= 192 || use_chain(h, B, Lm)) && !want_logs) ? 3 : 1;   // one long chain: blocked scan
+    if (var == 3 && !use_chain(h, B, Lm) && (size_t)16 * Lm * h->K * sizeof(double) >= ((size_t)1 << 32)) var = 1;
     return var;
   }
   if (var == 0) var = want_logs ? (use_chain(h, B, Lm) ? 3 : B >= 192 ? 2 : 1) : 3;   // no logs wanted: scaled sweeps at any batch size; logs of one long chain: blocked scan + conversion
@@ -1344,7 +1363,7 @@ static int materialise(svihmm_ctx* h, int b0, int nb) {
                        (double*)h->m_ll.p));
     ll = (const double*)h->m_ll.p;
   }
-  if (h->lastB == 1 && h->chain_T == Lm && h->chain_kbef && use_chain(h, 1, Lm)) {
+  if (h->lastB == 1 && K <= 64 && h->chain_T == Lm && h->chain_kbef && use_chain(h, 1, Lm)) {
     // the blocked scan's messages -> logs (k_chain_lalpha both ways), entries lost to underflow
     // recomputed in the log domain row by row (k_lalpha_fix / k_lbeta_fix): no sequential pass
     const size_t ne = (size_t)Lm * K;
@@ -1699,7 +1718,7 @@ int svihmm_ffbs(svihmm_ctx* h, const double* logA, const double* uniforms, uint3
   // forward filter: long chains through the exact blocked scan (scaled sweeps), then lalpha
   // from (ah, h, K); short ones with the per-window log-domain kernel
   const double* la = nullptr;
-  if (use_chain(h, 1, (int)T)) {
+  if (K <= 64 && use_chain(h, 1, (int)T)) {
     CK(prepare_ll(h, &st0, 1, (int)T, flags, false, true));
     CK(launch_fb_chain(h, (int)T, false));
     CK(ensure(h->m_la, (size_t)T * K * sizeof(double)));

@@ -32,7 +32,9 @@ def _oracle(pb, T, masked):
 
 # T - 1 = 9 * 256 + tail steps: tail of 1, 6 and 256 (the maximum) steps
 # ... and one chain long enough for the 1024-step chunks
-@pytest.mark.parametrize("K,T", [(5, 2306), (16, 2311), (40, 2561), (64, 2311), (64, 4100), (4, 530000)])
+# ... and wide models: transition tile streamed, 8 / 16 state tiles, thread-per-state boundary scan
+@pytest.mark.parametrize("K,T", [(5, 2306), (16, 2311), (40, 2561), (64, 2311), (64, 4100), (4, 530000),
+                                 (80, 2311), (128, 2561), (150, 2306), (256, 2400)])
 def test_chain_posteriors_vs_oracle(eng, K, T):
     from pysvihmm_amd import _lib as L
     D = 3
@@ -56,10 +58,10 @@ def test_chain_posteriors_vs_oracle(eng, K, T):
     np.testing.assert_allclose(got, la[T - 5:], rtol=1e-9, atol=1e-8)
 
 
-def test_chain_batch_statistics_vs_oracle(eng):
+@pytest.mark.parametrize("K,D,T", [(12, 4, 3000), (100, 4, 2500), (200, 3, 2100)])
+def test_chain_batch_statistics_vs_oracle(eng, K, D, T):
     """hmmbase batch E-step on one long chain (no wrap): statistics + lower bound."""
     from oracle import ref_c
-    K, D, T = 12, 4, 3000
     pb = make_problem(K, D, T, seed=21, miss=0.05)
     eng.set_obs(pb["obs"], pb["mask"])
     eng.set_globals(pb["mod_init"], pb["ltran"])
