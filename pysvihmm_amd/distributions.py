@@ -233,8 +233,9 @@ def niw_vlb_batch(mu_mf, sigma_mf, kappa_mf, nu_mf, mu_0, sigma_0, kappa_0, nu_0
     chol_0 = np.linalg.cholesky(np.asarray(sigma_0, float))
     l_mf = llt(chol_mf, nu_mf)
     dmu = mu_mf - np.asarray(mu_0, float)
-    sol_dmu = np.linalg.solve(sigma_mf, dmu[:, :, None])[:, :, 0]
-    sol_s0 = np.linalg.solve(sigma_mf, np.asarray(sigma_0, float))
+    # one factorisation per state for both right-hand sides
+    sol = np.linalg.solve(sigma_mf, np.concatenate([dmu[:, :, None], np.asarray(sigma_0, float)], axis=2))
+    sol_dmu, sol_s0 = sol[:, :, 0], sol[:, :, 1:]
     iw_entropy = logpart(chol_mf, nu_mf) - (nu_mf - D - 1) / 2. * l_mf + nu_mf * D / 2.
     q_entropy = -0.5 * (l_mf + D * (np.log(kappa_mf / (2 * np.pi)) - 1)) + iw_entropy
     p_avgengy = (0.5 * (D * np.log(kappa_0 / (2 * np.pi)) + l_mf - D * kappa_0 / kappa_mf
