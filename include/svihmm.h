@@ -150,6 +150,20 @@ int svihmm_estep_minibatch_ex(svihmm_ctx* h, const int64_t* starts, int32_t B,
 int svihmm_set_emission_cat(svihmm_ctx* h, int32_t K, int32_t V, const double* logp);
 int64_t svihmm_packed_len(svihmm_ctx* h);
 
+/* ELBO bookkeeping of the SVI loop (hmmsgd_metaobs.py:273-296 global_lower_bound,
+ * hmmbase.py:183-185: sum_k var_emit[k].get_vlb()): the data-dependent scalars of the NIW
+ * factors' term for the given mean-field parameters (D <= 64) --
+ * out[k] = log det sigma_mf[k], out[K+k] = tr(sigma_mf[k]^-1 sigma_0[k]),
+ * out[2K+k] = (mu_mf[k]-mu_0[k])' sigma_mf[k]^-1 (mu_mf[k]-mu_0[k]); the host adds the
+ * closed-form parts (digamma / gammaln of nu, kappa).  The prior (mu_0[K,D], sigma_0[K,D,D])
+ * is uploaded once with svihmm_set_emission_prior.  A pure function of its arguments: the
+ * E-step's own parameter set and the intermediates of the last E-step are not touched. */
+int svihmm_set_emission_prior(svihmm_ctx* h, int32_t K, int32_t D, const double* mu0,
+                              const double* sigma0);
+int svihmm_niw_vlb_terms(svihmm_ctx* h, int32_t K, int32_t D, const double* mu,
+                         const double* sigma, const double* kappa, const double* nu,
+                         double* out3K);
+
 /* Mean predictive log-probability of the held-out (masked) rows of the given windows
  * (hmmsgd_metaobs.py:1086-1145 pred_logprob / pred_logprob_full, hmmbase.py:322-340):
  * E-step with `flags` (SVIHMM_MASK_AS_NAN: the masked rows are missing), then the mean over

@@ -464,7 +464,8 @@ __device__ __forceinline__ int feat_index_d(int a, int b, int D) {
 __global__ __launch_bounds__(256) void k_niw_to_theta_generic(
     const double* __restrict__ mu, const double* __restrict__ sigma,
     const double* __restrict__ kappa, const double* __restrict__ nu, int K, int D, int Kp,
-    double* __restrict__ theta, int* __restrict__ status, double* __restrict__ orb) {
+    double* __restrict__ theta, int* __restrict__ status, double* __restrict__ orb,
+    double* __restrict__ logdet_out) {
   extern __shared__ double sm[];
   const int S = D + 1;
   double* Lm_ = sm;            // [D][S] Cholesky factor (lower)
@@ -545,6 +546,7 @@ __global__ __launch_bounds__(256) void k_niw_to_theta_generic(
     llt -= 2.0 * logdet;
     const double cst = 0.5 * llt - D / (2.0 * kappa[k]) - 0.5 * D * 1.8378770664093454835606594728112;
     theta_store(theta, orb, D, D, D, Kp, k, cst - mWm);
+    if (logdet_out) logdet_out[k] = 2.0 * logdet;     // log det sigma_mf (ELBO terms)
   }
 }
 
@@ -558,7 +560,8 @@ template <int DMAX>
 __global__ __launch_bounds__(64) void k_niw_to_theta_wave(
     const double* __restrict__ mu, const double* __restrict__ sigma,
     const double* __restrict__ kappa, const double* __restrict__ nu, int K, int D, int Kp,
-    double* __restrict__ theta, int* __restrict__ status, double* __restrict__ orb) {
+    double* __restrict__ theta, int* __restrict__ status, double* __restrict__ orb,
+    double* __restrict__ logdet_out) {
   __shared__ double col[64];
   __shared__ double Ls[DMAX][DMAX + 1];    // L (row-major), later X = L^-1 stored as Ls[c][r]
   __shared__ double ms[DMAX];
@@ -639,5 +642,39 @@ __global__ __launch_bounds__(64) void k_niw_to_theta_wave(
     const double llt = D * log(2.0) + dgm - 2.0 * logdet;
     const double cst = 0.5 * llt - D / (2.0 * kappa[k]) - 0.5 * D * 1.8378770664093454835606594728112;
     theta_store(theta, orb, D, D, D, Kp, k, cst - mWm);
+    if (logdet_out) logdet_out[k] = 2.0 * logdet;
+  }
+}
+
+// The three data-dependent scalars of the NIW factor's ELBO term (Gaussian.get_vlb, Bishop
+// 10.74 / 10.77) per state, from what the E-step already keeps on the device:
+//   out[k] = log det sigma_mf,  out[K+k] = tr(sigma_mf^-1 sigma_0),
+//   out[2K+k] = (mu_mf - mu_0)' sigma_mf^-1 (mu_mf - mu_0).
+// theta holds W = (nu/2) sigma_mf^-1 in feature form (-W_aa, -2 W_ab), so both contractions are
+// sums over the quadratic features.  One wave per state; `out` is host-visible pinned memory.
+__global__ __launch_bounds__(64) void k_niw_vlb_terms(
+    const double* __restrict__ theta, const int* __restrict__ fab, int F, int D, int Kp,
+    const double* __restrict__ mu, const double* __restrict__ nu, const double* __restrict__ logdet,
+    const double* __restrict__ mu0, const double* __restrict__ sigma0, int K,
+    double* __restrict__ out) {
+  const int k = blockIdx.x, lane = threadIdx.x;
+  const double* __restrict__ m = mu + (size_t)k * D;
+  const double* __restrict__ m0 = mu0 + (size_t)k * D;
+  const double* __restrict__ s0 = sigma0 + (size_t)k * D * D;
+  double tr = 0.0, qd = 0.0;
+  for (int f = lane; f < F; f += 64) {
+    const int ab = fab[f], a = ab & 0xffff, b = ab >> 16;
+    if (b >= D) continue;                    // linear and constant features
+    const double t = theta[(size_t)f * Kp + k];
+    tr = fma(t, s0[a * D + b], tr);
+    qd = fma(t, (m[a] - m0[a]) * (m[b] - m0[b]), qd);
+  }
+  tr = wave_sum(tr);
+  qd = wave_sum(qd);
+  if (lane == 0) {
+    const double c = -2.0 / nu[k];
+    out[k] = logdet[k];
+    out[K + k] = c * tr;
+    out[2 * K + k] = c * qd;
   }
 }

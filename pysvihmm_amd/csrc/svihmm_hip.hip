@@ -106,7 +106,9 @@ struct svihmm_ctx {
   bool have_globals = false;
   // emission
   int eK = 0, eD = 0, Kp = 0, F = 0, Fp = 0;
-  Buf theta, theta_orb, fab, niw, cat_table, partc;
+  Buf theta, theta_orb, fab, niw, cat_table, partc, prior, vlb_aux;
+  double* vlb_host = nullptr;   // pinned + mapped: [3][K] ELBO terms
+  int prior_K = 0, prior_D = 0, vlb_host_K = 0;
   void *slack_a = nullptr, *slack_t = nullptr;   // Aexp / AexpT whose slack rows are zeroed
   int slack_k = 0;
   void* orb_zero_p = nullptr; size_t orb_zero_n = 0;
@@ -236,8 +238,9 @@ int svihmm_destroy(svihmm_ctx* h) {
   Buf* bufs[] = {&h->obs, &h->mask, &h->mod_init, &h->ltran, &h->Aexp, &h->AexpT, &h->theta, &h->niw,
                  &h->fab, &h->starts, &h->ll, &h->la, &h->lb, &h->q, &h->lse_part,
                  &h->local_lb, &h->logz, &h->part, &h->packed, &h->scratch, &h->kexp, &h->hx, &h->gx,
-                 &h->zfac, &h->llE, &h->m_ll, &h->m_la, &h->m_lb, &h->chain, &h->chain2, &h->cat_table, &h->partc, &h->theta_orb};
+                 &h->zfac, &h->llE, &h->m_ll, &h->m_la, &h->m_lb, &h->chain, &h->chain2, &h->cat_table, &h->partc, &h->theta_orb, &h->prior, &h->vlb_aux};
   for (Buf* b : bufs) release(*b);
+  if (h->vlb_host) { hipHostFree(h->vlb_host); h->vlb_host = nullptr; }
   for (int i = 0; i < 2; ++i) {
     if (h->ev_em[i]) hipEventDestroy(h->ev_em[i]);
     if (h->ev_sw[i]) hipEventDestroy(h->ev_sw[i]);
@@ -468,7 +471,7 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
     ProfScope ps(h, KS_MISC);
 #define NIWW(DM) hipLaunchKernelGGL(k_niw_to_theta_wave<DM>, dim3(K), dim3(64), 0, h->stream, (const double*)dmu, \
                                     (const double*)dsg, (const double*)dka, (const double*)dnu, K, D, Kp,   \
-                                    (double*)h->theta.p, dstatus, orbp)
+                                    (double*)h->theta.p, dstatus, orbp, (double*)nullptr)
     if (D <= 8) NIWW(8);
     else if (D <= 16) NIWW(16);
     else if (D <= 32) NIWW(32);
@@ -479,7 +482,7 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
         hipFuncSetAttribute((const void*)k_niw_to_theta_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(k_niw_to_theta_generic, dim3(K), dim3(256), lds, h->stream, (const double*)dmu,
                          (const double*)dsg, (const double*)dka, (const double*)dnu, K, D, Kp,
-                         (double*)h->theta.p, dstatus, orbp);
+                         (double*)h->theta.p, dstatus, orbp, (double*)nullptr);
     }
 #undef NIWW
     HIPCK(hipGetLastError());
@@ -488,6 +491,79 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
   h->status_pending = true;
   h->eK = K; h->eD = D; h->have_emission = true; h->emis_cat = false;
   h->orb_valid = orbp != nullptr;
+  return 0;
+}
+
+// ---- ELBO terms of the NIW factors from the device-resident parameters --------------------
+int svihmm_set_emission_prior(svihmm_ctx* h, int32_t K, int32_t D, const double* mu0, const double* sigma0) {
+  if (!h || K <= 0 || D <= 0 || !mu0 || !sigma0) return fail("svihmm_set_emission_prior: bad arguments");
+  CK(set_device(h));
+  const size_t nmu = (size_t)K * D, nsg = (size_t)K * D * D;
+  CK(ensure(h->prior, (nmu + nsg) * sizeof(double)));
+  void* pin = nullptr;
+  int slot = 0;
+  CK(pinned(h, (nmu + nsg) * sizeof(double), &pin, &slot));
+  std::memcpy(pin, mu0, nmu * sizeof(double));
+  std::memcpy((double*)pin + nmu, sigma0, nsg * sizeof(double));
+  CK(pull_small(h, h->prior.p, pin, (nmu + nsg) * sizeof(double)));
+  CK(pin_release(h, slot));
+  h->prior_K = K; h->prior_D = D;
+  return 0;
+}
+int svihmm_niw_vlb_terms(svihmm_ctx* h, int32_t K, int32_t D, const double* mu, const double* sigma,
+                         const double* kappa, const double* nu, double* out3K) {
+  if (!h || K <= 0 || D <= 0 || !mu || !sigma || !kappa || !nu || !out3K)
+    return fail("svihmm_niw_vlb_terms: bad arguments");
+  if (h->prior_K != K || h->prior_D != D) return fail("svihmm_niw_vlb_terms: call svihmm_set_emission_prior first");
+  if (D > 64) return fail("svihmm_niw_vlb_terms: D > 64 not supported");
+  CK(set_device(h));
+  CK(upload_feature_table(h, D, K));
+  const int Fp = h->Fp, Kp = h->Kp;
+  if (h->vlb_host_K < K) {
+    if (h->vlb_host) hipHostFree(h->vlb_host);
+    h->vlb_host = nullptr; h->vlb_host_K = 0;
+    HIPCK(hipHostMalloc((void**)&h->vlb_host, (size_t)3 * K * sizeof(double), hipHostMallocMapped));
+    h->vlb_host_K = K;
+  }
+  double* dout = nullptr;
+  HIPCK(hipHostGetDevicePointer((void**)&dout, h->vlb_host, 0));
+  // a private parameter / theta set: the E-step's own (h->niw, h->theta) stay untouched, so the
+  // intermediates of the last E-step remain readable after the ELBO has been evaluated
+  const size_t nmu = (size_t)K * D, nsg = (size_t)K * D * D, nin = nmu + nsg + 2 * (size_t)K;
+  const size_t nth = (size_t)Fp * Kp;
+  CK(ensure(h->vlb_aux, (nin + nth + K + 8) * sizeof(double)));
+  double* dmu = (double*)h->vlb_aux.p;
+  double* dsg = dmu + nmu;
+  double* dka = dsg + nsg;
+  double* dnu = dka + K;
+  double* th2 = dnu + K;
+  double* ld = th2 + nth;
+  int* dstat = (int*)(ld + K);
+  void* pin = nullptr;
+  int slot = 0;
+  CK(pinned(h, nin * sizeof(double), &pin, &slot));
+  double* hp = (double*)pin;
+  std::memcpy(hp, mu, nmu * sizeof(double));
+  std::memcpy(hp + nmu, sigma, nsg * sizeof(double));
+  std::memcpy(hp + nmu + nsg, kappa, K * sizeof(double));
+  std::memcpy(hp + nmu + nsg + K, nu, K * sizeof(double));
+  CK(pull_small(h, dmu, hp, nin * sizeof(double)));
+  CK(pin_release(h, slot));
+  const double* p0 = (const double*)h->prior.p;
+  {
+    ProfScope ps(h, KS_MISC);
+#define NIWV(DM) hipLaunchKernelGGL(k_niw_to_theta_wave<DM>, dim3(K), dim3(64), 0, h->stream, (const double*)dmu, \
+                                    (const double*)dsg, (const double*)dka, (const double*)dnu, K, D, Kp, th2,    \
+                                    dstat, (double*)nullptr, ld)
+    if (D <= 8) NIWV(8); else if (D <= 16) NIWV(16); else if (D <= 32) NIWV(32); else NIWV(64);
+#undef NIWV
+    hipLaunchKernelGGL(k_niw_vlb_terms, dim3(K), dim3(64), 0, h->stream, (const double*)th2,
+                       (const int*)h->fab.p, h->F, D, Kp, (const double*)dmu, (const double*)dnu,
+                       (const double*)ld, p0, p0 + nmu, K, dout);
+    HIPCK(hipGetLastError());
+  }
+  HIPCK(hipStreamSynchronize(h->stream));
+  std::memcpy(out3K, h->vlb_host, (size_t)3 * K * sizeof(double));
   return 0;
 }
 

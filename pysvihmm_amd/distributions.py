@@ -210,7 +210,7 @@ class Gaussian(object):
         return p_avgengy + q_entropy
 
 
-def niw_vlb_batch(mu_mf, sigma_mf, kappa_mf, nu_mf, mu_0, sigma_0, kappa_0, nu_0):
+def niw_vlb_batch(mu_mf, sigma_mf, kappa_mf, nu_mf, mu_0, sigma_0, kappa_0, nu_0, terms=None):
     """``Gaussian.get_vlb()`` for K NIW factors at once (stacked arrays [K,D], [K,D,D], [K]):
     same formulas (Bishop 10.74, 10.77), one batched Cholesky / solve instead of 4K small
     ones -- the ELBO bookkeeping of the SVI loop is otherwise slower than the device E-step."""
@@ -229,19 +229,35 @@ def niw_vlb_batch(mu_mf, sigma_mf, kappa_mf, nu_mf, mu_0, sigma_0, kappa_0, nu_0
                       - (nu * D / 2. * np.log(2.) + D * (D - 1) / 4. * np.log(np.pi)
                          + gammaln((nu[:, None] - ar) / 2.).sum(1)))
 
-    chol_mf = np.linalg.cholesky(sigma_mf)
     chol_0 = np.linalg.cholesky(np.asarray(sigma_0, float))
-    l_mf = llt(chol_mf, nu_mf)
-    dmu = mu_mf - np.asarray(mu_0, float)
-    # one factorisation per state for both right-hand sides
-    sol = np.linalg.solve(sigma_mf, np.concatenate([dmu[:, :, None], np.asarray(sigma_0, float)], axis=2))
-    sol_dmu, sol_s0 = sol[:, :, 0], sol[:, :, 1:]
-    iw_entropy = logpart(chol_mf, nu_mf) - (nu_mf - D - 1) / 2. * l_mf + nu_mf * D / 2.
+    if terms is not None:
+        # (log det sigma_mf, tr(sigma_mf^-1 sigma_0), dmu' sigma_mf^-1 dmu) from the device
+        # (HipEngine.emission_vlb_terms): no factorisation of sigma_mf on the host
+        logdet_mf, tr_s0, quad = (np.asarray(t, float) for t in terms)
+        half_ld = 0.5 * logdet_mf
+    else:
+        chol_mf = np.linalg.cholesky(sigma_mf)
+        half_ld = np.log(np.diagonal(chol_mf, axis1=1, axis2=2)).sum(1)
+        dmu = mu_mf - np.asarray(mu_0, float)
+        # one factorisation per state for both right-hand sides
+        sol = np.linalg.solve(sigma_mf, np.concatenate([dmu[:, :, None], np.asarray(sigma_0, float)], axis=2))
+        quad = np.einsum('kd,kd->k', dmu, sol[:, :, 0])
+        tr_s0 = np.trace(sol[:, :, 1:], axis1=1, axis2=2)
+
+    def llt_h(hl, nu):
+        return digamma((nu[:, None] - ar) / 2.).sum(1) + D * np.log(2.) - 2. * hl
+
+    def logpart_h(hl, nu):
+        return -1. * (nu * hl - (nu * D / 2. * np.log(2.) + D * (D - 1) / 4. * np.log(np.pi)
+                                 + gammaln((nu[:, None] - ar) / 2.).sum(1)))
+
+    l_mf = llt_h(half_ld, nu_mf)
+    iw_entropy = logpart_h(half_ld, nu_mf) - (nu_mf - D - 1) / 2. * l_mf + nu_mf * D / 2.
     q_entropy = -0.5 * (l_mf + D * (np.log(kappa_mf / (2 * np.pi)) - 1)) + iw_entropy
     p_avgengy = (0.5 * (D * np.log(kappa_0 / (2 * np.pi)) + l_mf - D * kappa_0 / kappa_mf
-                        - kappa_0 * nu_mf * np.einsum('kd,kd->k', dmu, sol_dmu))
+                        - kappa_0 * nu_mf * quad)
                  - logpart(chol_0, nu_0) + (nu_0 - D - 1) / 2. * l_mf
-                 - 0.5 * nu_mf * np.trace(sol_s0, axis1=1, axis2=2))
+                 - 0.5 * nu_mf * tr_s0)
     return p_avgengy + q_entropy
 
 

@@ -147,6 +147,25 @@ class HipEngine(object):
         if check:
             L.check(self._lib.svihmm_sync(self._h), "svihmm_set_emission_niw")
 
+    def set_emission_prior(self, mu0, sigma0):
+        mu0 = L.as_f64(mu0)
+        K, D = mu0.shape
+        sigma0 = L.as_f64(sigma0, (K, D, D))
+        L.check(self._lib.svihmm_set_emission_prior(self._h, K, D, L.dptr(mu0), L.dptr(sigma0)),
+                "svihmm_set_emission_prior")
+
+    def niw_vlb_terms(self, mu, sigma, kappa, nu):
+        """(log det sigma_mf, tr(sigma_mf^-1 sigma_0), (mu_mf-mu_0)' sigma_mf^-1 (mu_mf-mu_0)), each
+        [K], for the given NIW mean-field parameters (prior from set_emission_prior); does not
+        disturb the E-step's parameter set."""
+        mu = L.as_f64(mu)
+        K, D = mu.shape
+        sigma = L.as_f64(sigma, (K, D, D)); kappa = L.as_f64(kappa, (K,)); nu = L.as_f64(nu, (K,))
+        out = np.empty((3, K))
+        L.check(self._lib.svihmm_niw_vlb_terms(self._h, K, D, L.dptr(mu), L.dptr(sigma), L.dptr(kappa),
+                                               L.dptr(nu), L.dptr(out)), "svihmm_niw_vlb_terms")
+        return out[0], out[1], out[2]
+
     def set_lliks(self, lliks):
         lliks = L.as_f64(lliks)
         B, Lm, K = lliks.shape

@@ -124,6 +124,7 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
                 getattr(self, name)
         d = dict(self.__dict__)
         d.pop('_pending_rows', None)
+        d.pop('_prior_on_device', None)
         d['_engine'] = None       # device handles are not picklable
         d['_obs_dirty'] = True
         return d
@@ -178,9 +179,22 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
         if self._niw_fastpath() and all(type(e).get_vlb is Gaussian.get_vlb for e in ve):
             from .distributions import niw_vlb_batch
             mu, sg, ka, nu = self._emission_arrays()
+            mu0 = np.array([g.mu_0 for g in ve]); sg0 = np.array([g.sigma_0 for g in ve])
+            terms = None
+            eng = self.engine
+            if hasattr(eng, "niw_vlb_terms") and mu.shape[1] <= 64:
+                # log det / trace / quadratic form of sigma_mf from the device (it factorises
+                # sigma_mf for the E-step anyway): the host-side batched solve of K D x D systems
+                # costs more than the device E-step of a 64-window minibatch
+                key = (id(eng), mu0.shape)
+                if getattr(self, "_prior_on_device", None) != key:
+                    eng.set_emission_prior(mu0, sg0)
+                    self._prior_on_device = key
+                terms = eng.niw_vlb_terms(mu, sg, ka, nu)
             return float(np.sum(niw_vlb_batch(
-                mu, sg, ka, nu, np.array([g.mu_0 for g in ve]), np.array([g.sigma_0 for g in ve]),
-                np.array([float(g.kappa_0) for g in ve]), np.array([float(g.nu_0) for g in ve]))))
+                mu, sg, ka, nu, mu0, sg0,
+                np.array([float(g.kappa_0) for g in ve]), np.array([float(g.nu_0) for g in ve]),
+                terms=terms)))
         tot = 0.
         for k in range(self.K):
             tot += ve[k].get_vlb()

@@ -431,3 +431,36 @@ def test_obs_uploaded_in_blocks_equals_whole(eng, tmp_path):
     assert np.array_equal(a, b)
     with pytest.raises(RuntimeError):
         L.check(eng._lib.svihmm_set_obs_rows(eng._h, T - 1, 2, L.dptr(np.zeros((2, D))), None), "rows")
+
+
+@pytest.mark.parametrize("K,D", [(3, 2), (16, 8), (64, 32), (20, 64)])
+def test_niw_vlb_terms_device_vs_host(eng, K, D):
+    """svihmm_niw_vlb_terms: log det sigma_mf, tr(sigma_mf^-1 sigma_0) and the prior-mean quadratic
+    form from the device's own factorisation; the ELBO term built from them equals the host
+    formula (one batched solve), and the E-step's parameter set is left alone."""
+    from pysvihmm_amd.distributions import niw_vlb_batch
+    rng = np.random.default_rng(K * 3 + D)
+    def spd(n):
+        a = rng.normal(size=(n, D, D + 3))
+        return np.einsum('kij,klj->kil', a, a) / D + 0.1 * np.eye(D)
+    mu, sg = rng.normal(size=(K, D)) * 3, spd(K)
+    ka, nu = rng.random(K) * 50 + 0.1, D + 2 + rng.random(K) * 100
+    mu0, sg0 = rng.normal(size=(K, D)), spd(K)
+    ka0, nu0 = np.full(K, 0.01), np.full(K, D + 2.0)
+    pb = make_problem(K, D, 600, seed=1)
+    eng.set_obs(pb["obs"], None)
+    eng.set_globals(pb["mod_init"], pb["ltran"])
+    eng.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    before = eng.estep([0, 100], 50).buf.copy()
+    eng.set_emission_prior(mu0, sg0)
+    ld, tr, qd = eng.niw_vlb_terms(mu, sg, ka, nu)
+    np.testing.assert_allclose(ld, np.linalg.slogdet(sg)[1], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(tr, np.trace(np.linalg.solve(sg, sg0), axis1=1, axis2=2), rtol=1e-10)
+    dm = mu - mu0
+    np.testing.assert_allclose(qd, np.einsum('kd,kd->k', dm, np.linalg.solve(sg, dm[:, :, None])[:, :, 0]), rtol=1e-10)
+    host = niw_vlb_batch(mu, sg, ka, nu, mu0, sg0, ka0, nu0)
+    dev = niw_vlb_batch(mu, sg, ka, nu, mu0, sg0, ka0, nu0, terms=(ld, tr, qd))
+    np.testing.assert_allclose(dev, host, rtol=1e-10, atol=1e-9)
+    # the E-step parameters were not disturbed
+    after = eng.estep([0, 100], 50).buf
+    assert np.array_equal(before, after)
