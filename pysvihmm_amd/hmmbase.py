@@ -125,6 +125,7 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
         d = dict(self.__dict__)
         d.pop('_pending_rows', None)
         d.pop('_prior_on_device', None)
+        d.pop('_prior_stack', None)
         d['_engine'] = None       # device handles are not picklable
         d['_obs_dirty'] = True
         return d
@@ -172,6 +173,19 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
                 and len({e.num_parameters() for e in ve}) == 1
                 and (self.obs.ndim == 1 or self.obs.shape[1] == 1))
 
+    def _prior_arrays(self):
+        """Stacked NIW prior hyperparameters (mu_0 [K,D], sigma_0 [K,D,D], kappa_0 [K], nu_0 [K]).
+        The priors of a model do not change after construction (the reference never writes
+        them either), so they are stacked once per emitter array."""
+        ve = self.var_emit
+        key = (id(ve), len(ve))
+        c = self.__dict__.get("_prior_stack")
+        if c is None or c[0] != key:
+            c = (key, np.array([g.mu_0 for g in ve]), np.array([g.sigma_0 for g in ve]),
+                 np.array([float(g.kappa_0) for g in ve]), np.array([float(g.nu_0) for g in ve]))
+            self._prior_stack = c
+        return c[1:]
+
     def _emit_vlb(self):
         """sum_k var_emit[k].get_vlb() (reference hmmbase.py:183-185), batched for NIW
         Gaussians."""
@@ -179,7 +193,7 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
         if self._niw_fastpath() and all(type(e).get_vlb is Gaussian.get_vlb for e in ve):
             from .distributions import niw_vlb_batch
             mu, sg, ka, nu = self._emission_arrays()
-            mu0 = np.array([g.mu_0 for g in ve]); sg0 = np.array([g.sigma_0 for g in ve])
+            mu0, sg0, ka0, nu0 = self._prior_arrays()
             terms = None
             eng = self.engine
             if hasattr(eng, "niw_vlb_terms") and mu.shape[1] <= 64:
@@ -192,9 +206,7 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
                     self._prior_on_device = key
                 terms = eng.niw_vlb_terms(mu, sg, ka, nu)
             return float(np.sum(niw_vlb_batch(
-                mu, sg, ka, nu, mu0, sg0,
-                np.array([float(g.kappa_0) for g in ve]), np.array([float(g.nu_0) for g in ve]),
-                terms=terms)))
+                mu, sg, ka, nu, mu0, sg0, ka0, nu0, terms=terms)))
         tot = 0.
         for k in range(self.K):
             tot += ve[k].get_vlb()

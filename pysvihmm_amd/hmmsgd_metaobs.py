@@ -644,8 +644,7 @@ class VBHMM(VariationalHMMBase):
         ve = self.var_emit
         D = self.D
         mu, sg, ka, nu = self._emission_arrays()
-        mu0 = np.array([g.mu_0 for g in ve]); sg0 = np.array([g.sigma_0 for g in ve])
-        ka0 = np.array([float(g.kappa_0) for g in ve]); nu0 = np.array([float(g.nu_0) for g in ve])
+        mu0, sg0, ka0, nu0 = self._prior_arrays()
 
         def nat(m, s_, k_, n_):          # util.NIW_mf_natural_pars
             return (k_[:, None] * m, k_, s_ + np.einsum('ki,kj->kij', m, m) * k_[:, None, None],
