@@ -312,7 +312,7 @@ class Categorical(object):
         # (reference ``hmmsgd_metaobs.py:918-923``); data is ignored upstream
         if np.ndim(weights) == 2:
             return (weights.sum(0),)
-        counts = np.bincount(np.asarray(data, int), weights=weights,
+        counts = np.bincount(np.asarray(data, int).ravel(), weights=np.asarray(weights, float).ravel(),
                              minlength=self.K)
         return (counts,)
 

@@ -113,6 +113,14 @@ class VBHMM(VariationalHMMBase):
         ``(neff, xbar/neff, S - neff xbar xbar')``."""
         self.var_init = self.prior_init + self._q0
         self.var_tran = self.prior_tran + st.A_raw
+        if hasattr(st, "counts"):
+            # Categorical emitters (the engine counted symbols): meanfieldupdate(obs[inds],
+            # q[inds, k]) is alpha_mf = alphav_0 + sum_t q[t, k] [x_t = v] over unmasked rows
+            for k in range(self.K):
+                G = self.var_emit[k]
+                G._alpha_mf = G._posterior_hypparams(st.counts[k])
+                G.weights = G._alpha_mf / G._alpha_mf.sum()
+            return
         for k in range(self.K):
             G = self.var_emit[k]
             if not is_niw_gaussian(G):

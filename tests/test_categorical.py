@@ -93,3 +93,40 @@ def test_class_categorical_on_gpu_equals_literal_loop():
     np.testing.assert_allclose(a.var_tran, b.var_tran, rtol=1e-6, atol=1e-7)
     for k in range(K):
         np.testing.assert_allclose(a.var_emit[k].alpha_mf, b.var_emit[k].alpha_mf, rtol=1e-6, atol=1e-7)
+
+
+def _batchcd(K, V, obs, mask, engine, maxit=4):
+    from pysvihmm_amd import hmmbatchcd
+    np.random.seed(3)
+    emit = np.array([Categorical(alphav_0=np.ones(V) * 0.5) for _ in range(K)])
+    return hmmbatchcd.VBHMM(obs.copy()[:, None], np.ones(K), np.ones((K, K)), emit, mask=mask,
+                            maxit=maxit, engine=engine)
+
+
+def test_batchcd_categorical_fused_equals_literal_on_the_oracle_engine():
+    """hmmbatchcd coordinate ascent with Categorical emitters: the fused M-step from the
+    engine's symbol counts equals the literal local_update() / global_update() loop
+    (reference hmmbatchcd.py:172-189 with the plugin's meanfieldupdate)."""
+    K, V, T = 3, 6, 500
+    obs, mask, _ = _cat_problem(K, V, T, 5)
+    a = _batchcd(K, V, obs, mask, OracleEngine()); a.infer()
+    b = _batchcd(K, V, obs, mask, OracleEngine()); b.infer(fused=False)
+    np.testing.assert_allclose(a.var_tran, b.var_tran, rtol=1e-9)
+    np.testing.assert_allclose(a.var_init, b.var_init, rtol=1e-9)
+    for k in range(K):
+        np.testing.assert_allclose(a.var_emit[k].alpha_mf, b.var_emit[k].alpha_mf, rtol=1e-9)
+    np.testing.assert_allclose(a.elbo_vec, b.elbo_vec, rtol=1e-9)
+    assert np.all(np.diff(a.elbo_vec) > -1e-7)           # coordinate ascent: monotone ELBO
+
+
+@pytest.mark.gpu
+def test_batchcd_categorical_on_gpu():
+    K, V, T = 4, 7, 3000                                  # T >= 2048: the chain scan path
+    obs, mask, _ = _cat_problem(K, V, T, 6)
+    a = _batchcd(K, V, obs, mask, None); a.infer()
+    b = _batchcd(K, V, obs, mask, OracleEngine()); b.infer()
+    assert a.engine.name == "hip"
+    np.testing.assert_allclose(a.var_tran, b.var_tran, rtol=1e-6, atol=1e-9)
+    for k in range(K):
+        np.testing.assert_allclose(a.var_emit[k].alpha_mf, b.var_emit[k].alpha_mf, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(a.elbo_vec, b.elbo_vec, rtol=1e-8)
