@@ -879,9 +879,11 @@ static int ensure_fb_lin(svihmm_ctx* h, int B, int Lm) {
   CK(ensure(h->packed, (size_t)packed_len(h) * sizeof(double)));
   return 0;
 }
-// below this many windows the wave-per-window scaled sweep beats the MFMA one (which is
-// latency-bound at ~0.9 us per step however few windows it gets)
-#define LIN_WAVE_MAX 1400
+// up to this many windows the wave-per-window scaled sweep beats the MFMA one (which is
+// latency-bound at ~0.9 us per step however few windows it gets): 2 x 1024 waves are resident
+// at once (190 VGPRs: two per SIMD); measured (tools/sweep_crossover.py, K = 64, Lm = 257)
+// 0.16 ms at 64 .. 0.19 ms at 1024 windows against 0.23 .. 0.25 ms, 0.33 against 0.26 ms at 1399
+#define LIN_WAVE_MAX 1025
 // both sweeps over windows [b0, b0+nb) of the current batch on `stream` (buffers ensured):
 // one launch, blockIdx.y = direction
 static int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_t stream) {
