@@ -197,6 +197,19 @@ int svihmm_read_intermediate(svihmm_ctx* h, int32_t what, double* out);
 int svihmm_read_rows(svihmm_ctx* h, int32_t what, int64_t row0, int64_t nrows,
                      double* out);
 
+/* ---- synthetic sequences generated in HBM (gen_synthetic.py:27-44 generate_data) ---------- */
+/* Start in state 0; z_t drawn from row z_{t-1} of the transition matrix by np.random.choice's
+ * inverse CDF (cdf[K,K] = cumsum(tran, axis=1) / cumsum[:, -1], searchsorted side='right');
+ * x_t = means[z_t] + chols[z_t] n_t with n_t ~ N(0, I) (chols: lower Cholesky factors [K,D,D]).
+ * Counter-based randomness (Philox4x32-10 keyed by `seed`; row t: stream 0 = transition uniform,
+ * stream 1 + p = Box-Muller pair for components 2p, 2p+1), so a run is reproducible and the
+ * state chain needs no sequential pass (composition of per-row maps).  The sequence becomes
+ * the resident observation copy (no mask); K <= 64.  svihmm_read_generated copies the states
+ * (int32[T]) and / or the observations ([T,D]) to the host. */
+int svihmm_generate(svihmm_ctx* h, int64_t T, int32_t K, int32_t D, const double* cdf,
+                    const double* means, const double* chols, uint64_t seed);
+int svihmm_read_generated(svihmm_ctx* h, int32_t* sts_out, double* obs_out);
+
 /* ---- a12: forward-filter backward-sample (hmm_fast.pyx:43-124) ---------------- */
 /* Forward filter over the whole chain with the globals currently set (the host
  * passes the Cython variant's mod_init/ltran), then z[T-1] ~ softmax(lalpha[T-1]),

@@ -263,3 +263,57 @@ def ffbs_backward_sample(lalpha, var_tran, uniforms):
         p = np.exp(lp - lp.max()); p /= p.sum()
         z[t] = rand_discrete(p, uniforms[t])
     return z
+
+
+# ---- device generator restated (pysvihmm_amd/csrc/kernels_misc.h k_gen_*): Philox4x32-10 ----
+def philox4x32_10(seed, rows, stream):
+    """Four uint32 words per row for counter (row_lo, row_hi, stream, 0), key = seed."""
+    M32 = np.uint64(0xFFFFFFFF)
+    rows = np.asarray(rows, dtype=np.uint64)
+    c0 = rows & M32
+    c1 = rows >> np.uint64(32)
+    c2 = np.full(rows.shape, stream, dtype=np.uint64)
+    c3 = np.zeros(rows.shape, dtype=np.uint64)
+    k0 = np.uint64(seed & 0xFFFFFFFF)
+    k1 = np.uint64((seed >> 32) & 0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c0
+        p1 = np.uint64(0xCD9E8D57) * c2
+        n0 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & M32
+        n1 = p1 & M32
+        n2 = ((p0 >> np.uint64(32)) ^ c3 ^ k1) & M32
+        n3 = p0 & M32
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0 = (k0 + np.uint64(0x9E3779B9)) & M32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & M32
+    return c0, c1, c2, c3
+
+
+def _u53(hi, lo):
+    return ((hi >> np.uint64(5)).astype(np.float64) * 67108864.0
+            + (lo >> np.uint64(6)).astype(np.float64)) / 9007199254740992.0
+
+
+def generate_counter_based(tran, means, chols, T, seed):
+    """gen_synthetic.py:27-44 semantics (start in state 0, np.random.choice's inverse CDF,
+    mean + chol n) on the device generator's random stream: states exactly, obs to rounding."""
+    tran = np.asarray(tran, float)
+    K = tran.shape[0]
+    D = means.shape[1]
+    cdf = np.cumsum(tran, axis=1)
+    cdf = cdf / cdf[:, -1:]
+    rows = np.arange(T, dtype=np.uint64)
+    w = philox4x32_10(seed, rows, 0)
+    u = _u53(w[0], w[1])
+    z = np.zeros(T, dtype=np.int32)
+    for t in range(1, T):
+        z[t] = min(int(np.searchsorted(cdf[z[t - 1]], u[t], side='right')), K - 1)
+    n = np.empty((T, D + 1))
+    for p in range((D + 1) // 2):
+        w = philox4x32_10(seed, rows, 1 + p)
+        u1, u2 = _u53(w[0], w[1]), _u53(w[2], w[3])
+        r = np.sqrt(-2.0 * np.log(1.0 - u1))
+        n[:, 2 * p] = r * np.cos(2 * np.pi * u2)
+        n[:, 2 * p + 1] = r * np.sin(2 * np.pi * u2)
+    obs = means[z] + np.einsum('tij,tj->ti', np.tril(chols)[z], n[:, :D])
+    return obs, z

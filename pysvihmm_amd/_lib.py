@@ -55,6 +55,9 @@ SIGNATURES = {
     "svihmm_set_emission_prior": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _c_double_p, _c_double_p]),
     "svihmm_niw_vlb_terms": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _c_double_p, _c_double_p, _c_double_p,
                                        _c_double_p, _c_double_p]),
+    "svihmm_generate": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, _c_double_p, _c_double_p,
+                                  _c_double_p, C.c_uint64]),
+    "svihmm_read_generated": (C.c_int, [C.c_void_p, C.c_void_p, _c_double_p]),
     "svihmm_state_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "svihmm_read_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, _c_double_p]),
     "svihmm_read_intermediate": (C.c_int, [C.c_void_p, C.c_int32, _c_double_p]),

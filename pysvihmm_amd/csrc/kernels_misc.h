@@ -251,6 +251,125 @@ __global__ __launch_bounds__(256) void k_probe_pattern(const double* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------
+//  Synthetic sequences on the device (gen_synthetic.py:27-44 generate_data: start in state 0,
+//  z_t ~ tran[z_{t-1}] by np.random.choice's inverse CDF -- cdf = cumsum(p) / cumsum(p)[-1],
+//  searchsorted(cdf, u, side='right') -- and x_t = mean[z_t] + chol[z_t] n_t, n_t ~ N(0, I)).
+//  Randomness is counter based (Philox4x32-10, key = seed, counter = (row, stream)): row t
+//  draws its transition uniform from stream 0 and its normals, two per call by Box-Muller,
+//  from streams 1 + j/2 -- any thread can recompute any draw, and the NumPy oracle does the
+//  same.  The state chain is a composition of per-row maps z_t = F_t(z_{t-1}) like the FFBS
+//  sampler: k_gen_paths (one wave per chunk, lane = state before the chunk, binary search in
+//  the CDF row), k_gen_compose (prefix composition of the chunk maps), k_gen_gather.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned long long seed, unsigned long long row,
+                                              unsigned stream, unsigned (&o)[4]) {
+  unsigned c0 = (unsigned)row, c1 = (unsigned)(row >> 32), c2 = stream, c3 = 0u;
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+__device__ __forceinline__ double u53(unsigned hi, unsigned lo) {   // [0, 1), 53 bits
+  return ((double)(hi >> 5) * 67108864.0 + (double)(lo >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(64) void k_gen_paths(const double* __restrict__ cdf, unsigned long long seed,
+                                                  int64_t T, int K, int Ls,
+                                                  unsigned char* __restrict__ path) {
+  extern __shared__ double gcdf[];          // [K][KMAX + 1]
+  const int lane = threadIdx.x;
+  for (int e = lane; e < K * K; e += 64) gcdf[(e / K) * (KMAX + 1) + (e % K)] = cdf[e];
+  __syncthreads();
+  const int64_t lo = (int64_t)blockIdx.x * Ls;
+  const int64_t hi = lo + Ls < T ? lo + Ls : T;
+  int cur = lane < K ? lane : 0;
+  for (int64_t t = lo; t < hi; ++t) {
+    unsigned w[4];
+    philox4x32_10(seed, (unsigned long long)t, 0u, w);
+    const double u = u53(w[0], w[1]);
+    // number of CDF entries <= u (searchsorted side='right'), clipped to K - 1
+    const double* __restrict__ row = gcdf + cur * (KMAX + 1);
+    int a = 0, b = K;                       // answer in [a, b]
+#pragma unroll
+    for (int it = 0; it < 7; ++it) {
+      const int mid = (a + b) >> 1;
+      const bool le = (a < b) && row[mid < K ? mid : K - 1] <= u;
+      a = le ? mid + 1 : a;
+      b = ((a < b) && !le) ? mid : b;
+    }
+    cur = t == 0 ? 0 : (a < K ? a : K - 1);
+    if (lane < KMAX) path[t * KMAX + lane] = (unsigned char)cur;
+  }
+}
+// maps[c][s] = state at the LAST row of chunk c given the state s before its first row;
+// prefix composition; entry[c] = state before chunk c (chunk 0: 0, unused -- row 0 is state 0)
+__global__ __launch_bounds__(1024) void k_gen_compose(const unsigned char* __restrict__ path, int64_t T,
+                                                      int KS, int Ls, int C, unsigned char* __restrict__ mA,
+                                                      unsigned char* __restrict__ mB,
+                                                      unsigned char* __restrict__ entry) {
+  const int n = C * KS;
+  for (int e = threadIdx.x; e < n; e += 1024) {
+    const int c = e / KS, x = e - c * KS;
+    const int64_t last = ((int64_t)(c + 1) * Ls < T ? (int64_t)(c + 1) * Ls : T) - 1;
+    mA[e] = path[last * KS + x];
+  }
+  __threadfence_block();
+  __syncthreads();
+  unsigned char* src = mA;
+  unsigned char* dst = mB;
+  for (int d = 1; d < C; d <<= 1) {
+    for (int e = threadIdx.x; e < n; e += 1024) {
+      const int c = e / KS, x = e - c * KS;
+      dst[e] = (c - d >= 0) ? src[c * KS + src[(c - d) * KS + x]] : src[e];
+    }
+    __threadfence_block();
+    __syncthreads();
+    unsigned char* t = src; src = dst; dst = t;
+  }
+  for (int c = threadIdx.x; c < C; c += 1024) entry[c] = c > 0 ? src[(c - 1) * KS] : 0;
+}
+__global__ __launch_bounds__(256) void k_gen_gather(const unsigned char* __restrict__ path,
+                                                    const unsigned char* __restrict__ entry, int64_t T,
+                                                    int KS, int Ls, int32_t* __restrict__ z) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  z[t] = path[t * KS + entry[t / Ls]];
+}
+// x_t = mean[z_t] + chol[z_t] n_t (lower triangular), one thread per row
+__global__ __launch_bounds__(256) void k_gen_obs(const int32_t* __restrict__ z, const double* __restrict__ means,
+                                                 const double* __restrict__ chols, unsigned long long seed,
+                                                 int64_t T, int D, double* __restrict__ obs) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const int s = z[t];
+  const double* __restrict__ m = means + (size_t)s * D;
+  const double* __restrict__ Lc = chols + (size_t)s * D * D;
+  double* __restrict__ x = obs + t * D;
+  for (int i = 0; i < D; ++i) x[i] = m[i];
+  for (int p = 0; 2 * p < D; ++p) {
+    unsigned w[4];
+    philox4x32_10(seed, (unsigned long long)t, 1u + (unsigned)p, w);
+    const double u1 = u53(w[0], w[1]), u2 = u53(w[2], w[3]);
+    const double r = sqrt(-2.0 * log(1.0 - u1));
+    double sn, cs;
+    sincos(6.283185307179586476925286766559 * u2, &sn, &cs);
+    const double n0 = r * cs, n1 = r * sn;
+    const int j0 = 2 * p, j1 = 2 * p + 1;
+    for (int i = j0; i < D; ++i) x[i] = fma(Lc[i * D + j0], n0, x[i]);
+    if (j1 < D)
+      for (int i = j1; i < D; ++i) x[i] = fma(Lc[i * D + j1], n1, x[i]);
+  }
+}
+
 // packed statistics -> host-visible (pinned, mapped) mirror.  An ordinary kernel launch right
 // behind k_finalize / the all-reduce: the runtime's D2H copy command starts ~0.1 ms after its
 // producer in the kernel trace, this one after the usual ~6 us.

@@ -106,7 +106,8 @@ struct svihmm_ctx {
   bool have_globals = false;
   // emission
   int eK = 0, eD = 0, Kp = 0, F = 0, Fp = 0;
-  Buf theta, theta_orb, fab, niw, cat_table, partc, prior, vlb_aux;
+  Buf theta, theta_orb, fab, niw, cat_table, partc, prior, vlb_aux, gen_z;
+  int64_t gen_T = 0;
   double* vlb_host = nullptr;   // pinned + mapped: [3][K] ELBO terms
   int prior_K = 0, prior_D = 0, vlb_host_K = 0;
   void *slack_a = nullptr, *slack_t = nullptr;   // Aexp / AexpT whose slack rows are zeroed
@@ -238,7 +239,7 @@ int svihmm_destroy(svihmm_ctx* h) {
   Buf* bufs[] = {&h->obs, &h->mask, &h->mod_init, &h->ltran, &h->Aexp, &h->AexpT, &h->theta, &h->niw,
                  &h->fab, &h->starts, &h->ll, &h->la, &h->lb, &h->q, &h->lse_part,
                  &h->local_lb, &h->logz, &h->part, &h->packed, &h->scratch, &h->kexp, &h->hx, &h->gx,
-                 &h->zfac, &h->llE, &h->m_ll, &h->m_la, &h->m_lb, &h->chain, &h->chain2, &h->cat_table, &h->partc, &h->theta_orb, &h->prior, &h->vlb_aux};
+                 &h->zfac, &h->llE, &h->m_ll, &h->m_la, &h->m_lb, &h->chain, &h->chain2, &h->cat_table, &h->partc, &h->theta_orb, &h->prior, &h->vlb_aux, &h->gen_z};
   for (Buf* b : bufs) release(*b);
   if (h->vlb_host) { hipHostFree(h->vlb_host); h->vlb_host = nullptr; }
   for (int i = 0; i < 2; ++i) {
@@ -279,7 +280,7 @@ int svihmm_set_obs(svihmm_ctx* h, const double* obs, int64_t T, int32_t D,
     HIPCK(hipMemcpyAsync(h->mask.p, mask, (size_t)T, hipMemcpyHostToDevice, h->stream));
   }
   HIPCK(hipStreamSynchronize(h->stream));
-  h->T = T; h->D = D;
+  h->T = T; h->D = D; h->gen_T = 0;
   return 0;
 }
 
@@ -1871,6 +1872,63 @@ int svihmm_ffbs(svihmm_ctx* h, const double* logA, const double* uniforms, uint3
   if (out_lalpha) CK(d2h(h, out_lalpha, la, (size_t)T * K * sizeof(double)));
   HIPCK(hipStreamSynchronize(h->stream));
   h->lastB = 1; h->lastLm = (int)T;
+  return 0;
+}
+
+// ---- synthetic sequences generated in HBM (gen_synthetic.py:27-44) --------------------------
+int svihmm_generate(svihmm_ctx* h, int64_t T, int32_t K, int32_t D, const double* cdf,
+                    const double* means, const double* chols, uint64_t seed) {
+  if (!h || T <= 0 || K <= 0 || D <= 0 || !cdf || !means || !chols) return fail("svihmm_generate: bad arguments");
+  if (K > 64) return fail("svihmm_generate: K > 64 not supported");
+  if (D > 4095) return fail("svihmm_generate: D too large");
+  CK(set_device(h));
+  h->lin_stale = true;
+  CK(ensure(h->obs, (size_t)T * D * sizeof(double)));
+  CK(ensure(h->gen_z, (size_t)T * sizeof(int32_t)));
+  h->have_mask = false;
+  const int KS = K <= 16 ? 16 : K <= 32 ? 32 : 64;
+  const int Ls = T >= 65536 ? 512 : 256;
+  const int Cs = (int)((T + Ls - 1) / Ls);
+  const size_t npar = (size_t)K * K + (size_t)K * D + (size_t)K * D * D;
+  const size_t bytes = npar * sizeof(double) + (size_t)T * KS + 2 * (size_t)Cs * KS + (size_t)Cs + 64;
+  CK(ensure(h->scratch, bytes));
+  double* dcdf = (double*)h->scratch.p;
+  double* dmean = dcdf + (size_t)K * K;
+  double* dchol = dmean + (size_t)K * D;
+  unsigned char* path = (unsigned char*)(dchol + (size_t)K * D * D);
+  unsigned char* mA = path + (size_t)T * KS;
+  unsigned char* mB = mA + (size_t)Cs * KS;
+  unsigned char* entry = mB + (size_t)Cs * KS;
+  HIPCK(hipMemcpyAsync(dcdf, cdf, (size_t)K * K * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemcpyAsync(dmean, means, (size_t)K * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemcpyAsync(dchol, chols, (size_t)K * D * D * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  {
+    ProfScope ps(h, KS_MISC);
+#define GPATH(KM)                                                                                        \
+  hipLaunchKernelGGL(k_gen_paths<KM>, dim3(Cs), dim3(64), (size_t)K * (KM + 1) * sizeof(double), h->stream, \
+                     (const double*)dcdf, (unsigned long long)seed, T, K, Ls, path)
+    if (KS == 16) GPATH(16); else if (KS == 32) GPATH(32); else GPATH(64);
+#undef GPATH
+    hipLaunchKernelGGL(k_gen_compose, dim3(1), dim3(1024), 0, h->stream, (const unsigned char*)path, T, KS, Ls,
+                       Cs, mA, mB, entry);
+    hipLaunchKernelGGL(k_gen_gather, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, h->stream,
+                       (const unsigned char*)path, (const unsigned char*)entry, T, KS, Ls, (int32_t*)h->gen_z.p);
+    hipLaunchKernelGGL(k_gen_obs, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, h->stream,
+                       (const int32_t*)h->gen_z.p, (const double*)dmean, (const double*)dchol,
+                       (unsigned long long)seed, T, D, (double*)h->obs.p);
+    HIPCK(hipGetLastError());
+  }
+  HIPCK(hipStreamSynchronize(h->stream));
+  h->T = T; h->D = D; h->gen_T = T;
+  return 0;
+}
+int svihmm_read_generated(svihmm_ctx* h, int32_t* sts_out, double* obs_out) {
+  if (!h || (!sts_out && !obs_out)) return fail("svihmm_read_generated: bad arguments");
+  if (h->gen_T <= 0 || h->gen_T != h->T) return fail("svihmm_read_generated: no generated sequence is resident");
+  CK(set_device(h));
+  if (sts_out) CK(d2h(h, sts_out, h->gen_z.p, (size_t)h->T * sizeof(int32_t)));
+  if (obs_out) CK(d2h(h, obs_out, h->obs.p, (size_t)h->T * h->D * sizeof(double)));
+  HIPCK(hipStreamSynchronize(h->stream));
   return 0;
 }
 

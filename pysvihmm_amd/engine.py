@@ -97,6 +97,29 @@ class HipEngine(object):
         L.check(self._lib.svihmm_set_obs(self._h, L.dptr(obs), T, D, L.u8ptr(m)), "svihmm_set_obs")
         self.T, self.D = T, D
 
+    def generate(self, tran, means, chols, T, seed=0):
+        """Generate a synthetic sequence directly in HBM (reference ``gen_synthetic.generate_data``
+        semantics; counter-based randomness, see ``include/svihmm.h``): it becomes the resident
+        observation copy.  ``chols`` are lower Cholesky factors of the emission covariances."""
+        tran = L.as_f64(tran)
+        K = tran.shape[0]
+        cdf = np.cumsum(tran, axis=1)
+        cdf = np.ascontiguousarray(cdf / cdf[:, -1:])
+        means = L.as_f64(means)
+        D = means.shape[1]
+        chols = L.as_f64(chols, (K, D, D))
+        L.check(self._lib.svihmm_generate(self._h, int(T), K, D, L.dptr(cdf), L.dptr(means), L.dptr(chols),
+                                          int(seed) & 0xFFFFFFFFFFFFFFFF), "svihmm_generate")
+        self.T, self.D = int(T), D
+
+    def read_generated(self, want_obs=True, want_sts=True):
+        sts = np.empty(self.T, dtype=np.int32) if want_sts else None
+        obs = np.empty((self.T, self.D)) if want_obs else None
+        L.check(self._lib.svihmm_read_generated(
+            self._h, None if sts is None else sts.ctypes.data_as(C.c_void_p), L.dptr(obs)),
+            "svihmm_read_generated")
+        return obs, sts
+
     def set_obs_blocks(self, blocks, T, D, mask=None):
         """Upload a sequence that arrives in row blocks (``gen_synthetic.read_data_mmap``,
         reference ``gen_synthetic.py:188-191``): ``blocks`` yields ``[n_i, D]`` arrays in

@@ -76,6 +76,20 @@ def generate_data_fast(tran, means, chols, T, rng=None):
     return obs, sts
 
 
+def generate_data_device(tran, means, chols, T, seed=0, engine=None, want_obs=False):
+    """The same process generated in HBM by the engine (``svihmm_generate``): the sequence stays
+    resident as the engine's observation copy -- T = 1e8 x D = 32 is 25.6 GB that never exists on
+    the host -- and only the states (and the observations if asked) come back.
+    ``chols``: lower Cholesky factors of the emission covariances [K,D,D].
+    Returns ``(obs or None, sts int32[T], engine)``."""
+    if engine is None:
+        from .engine import HipEngine
+        engine = HipEngine(0)
+    engine.generate(tran, means, chols, T, seed)
+    obs, sts = engine.read_generated(want_obs=want_obs, want_sts=True)
+    return obs, sts, engine
+
+
 def generate_data_mmap(tran, emit, T, obs_path='obs.dat', sts_path='sts.dat'):
     """Write a long sequence to disk with np.memmap (float64 obs [T,D], int32 sts [T,1])."""
     D = len(emit[0].rvs()[0])
