@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """First-contact GPU diagnostics: layout self-test, fp64 peaks, per-kernel
 errors vs the oracle for every variant, and a kernel-time breakdown at the bench
-shape.  Prints everything; never stops at the first failure."""
+shape.  Prints everything; never stops at the first failure.  (A checker script: it lives
+under tests/ because it imports the oracle; run it as `python tests/gpu_diag.py`.)"""
 import os
 import sys
 import time
