@@ -192,3 +192,34 @@ def test_pred_logprob_full_engine_path_equals_host_formula():
     slow = hmm.pred_logprob_full()
     assert fast is not None and np.isfinite(fast)
     np.testing.assert_allclose(fast, slow, rtol=1e-12)
+
+
+def test_oracle_is_confined_to_tests_smoke_and_bench_baseline():
+    """The oracle is test infrastructure: nothing under pysvihmm_amd/ or tools/ imports it,
+    bench.py only inside its cpu_baseline leg, __graft_entry__ only inside smoke()."""
+    import ast
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def oracle_imports(path):
+        tree = ast.parse(open(path).read())
+        hits = []
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in node.names):
+                hits.append(node.lineno)
+            if isinstance(node, ast.ImportFrom) and (node.module or "").split(".")[0] == "oracle":
+                hits.append(node.lineno)
+        return hits
+
+    for path in glob.glob(os.path.join(root, "pysvihmm_amd", "*.py")) + glob.glob(os.path.join(root, "tools", "*.py")):
+        assert not oracle_imports(path), path
+    src = open(os.path.join(root, "bench.py")).read().splitlines()
+    for ln in oracle_imports(os.path.join(root, "bench.py")):
+        assert any("no_cpu_baseline" in l for l in src[max(0, ln - 6):ln]), ln
+    tree = ast.parse(open(os.path.join(root, "__graft_entry__.py")).read())
+    for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
+        uses = any(isinstance(n, (ast.Import, ast.ImportFrom)) and
+                   ((getattr(n, "module", None) or "").startswith("oracle") or
+                    any(a.name.startswith("oracle") for a in getattr(n, "names", [])))
+                   for n in ast.walk(fn))
+        assert not uses or fn.name == "smoke", fn.name
