@@ -224,12 +224,21 @@ int svihmm_read_generated(svihmm_ctx* h, int32_t* sts_out, double* obs_out);
 int svihmm_ffbs(svihmm_ctx* h, const double* logA, const double* uniforms,
                 uint32_t flags, int64_t* out_z, double* out_lalpha);
 
+/* Backward sampling only, from forward messages the caller supplies: the `lalpha_init` branch of
+ * FFBS (hmm_fast.pyx:80-95 skips the likelihoods and the filter, :97-122 samples).  lalpha[T,K]
+ * host; logA / uniforms / out_z as svihmm_ffbs.  The resident observations are not used. */
+int svihmm_ffbs_sample(svihmm_ctx* h, int64_t T, int32_t K, const double* lalpha,
+                       const double* logA, const double* uniforms, int64_t* out_z);
+
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ----------------------------- */
 /* uid is a 128-byte ncclUniqueId produced on rank 0 and distributed by the host. */
 int svihmm_comm_unique_id(char uid_out[128]);
 int svihmm_comm_init(svihmm_ctx* h, const char uid[128], int32_t rank,
                      int32_t nranks);
 int svihmm_comm_destroy(svihmm_ctx* h);
+/* ncclCommCount of the handle's communicator (0 when none): the number of ranks RCCL itself
+ * sees, reported by bench.py so that an N-GPU line can be told from N independent replicas. */
+int svihmm_comm_count(svihmm_ctx* h, int32_t* nranks_out);
 /* In-place ncclAllReduce(sum, double) of the packed statistics in HBM: the
  * "A_inter += A_i ; emit_inter[k] += e_i[k]" accumulation of
  * hmmsgd_metaobs.py:430-436 extended across ranks. */
@@ -259,8 +268,6 @@ int svihmm_set_variant(svihmm_ctx* h, int32_t which, int32_t value);
 /* One v_mfma_f64_16x16x4_f64 on A[16,4] x B[4,16] -> C[16,16] (operand-layout check). */
 int svihmm_selftest_mfma(svihmm_ctx* h, const double* A16x4, const double* B4x16,
                          double* C16x16);
-/* fp64 throughput calibration: which 0 = v_mfma_f64_16x16x4_f64, 1 = v_fma_f64. */
-int svihmm_peak_fp64(svihmm_ctx* h, int32_t which, double* tflops_out);
 
 #ifdef __cplusplus
 }

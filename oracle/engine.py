@@ -50,8 +50,17 @@ class OracleEngine(object):
     def sync(self):
         pass
 
+    def on_next_mutation(self, callback):
+        self._on_mutate = callback
+
+    def _pre_mutate(self):
+        cb, self._on_mutate = getattr(self, "_on_mutate", None), None
+        if cb is not None:
+            cb()
+
     # -- inputs
     def set_obs(self, obs, mask=None):
+        self._pre_mutate()
         obs = np.array(obs, dtype=np.float64)
         if obs.ndim == 1:
             obs = obs[:, None]
@@ -70,21 +79,25 @@ class OracleEngine(object):
         return row
 
     def set_globals(self, mod_init, ltran):
+        self._pre_mutate()
         self.mod_init = np.array(mod_init, dtype=np.float64)
         self.ltran = np.array(ltran, dtype=np.float64)
         self.K = self.ltran.shape[0]
 
     def set_emission_niw(self, mu, sigma, kappa, nu, check=True):
+        self._pre_mutate()
         self.V = 0
         self.em = tuple(np.array(a, dtype=np.float64) for a in (mu, sigma, kappa, nu))
         for k in range(len(self.em[2])):
             np.linalg.cholesky(self.em[1][k])
 
     def set_emission_cat(self, logp):
+        self._pre_mutate()
         self.cat = np.array(logp, dtype=np.float64)
         self.V = self.cat.shape[1]
 
     def set_lliks(self, lliks):
+        self._pre_mutate()
         self._host_ll = np.array(lliks, dtype=np.float64)
 
     # -- compute
@@ -108,6 +121,7 @@ class OracleEngine(object):
                 raise RuntimeError("window out of range")
 
     def loglik(self, starts, Lm, flags=0):
+        self._pre_mutate()
         starts = np.asarray(starts, dtype=np.int64).ravel()
         self._check(starts, Lm)
         return np.stack([self._window_ll(int(s), Lm, flags) for s in starts])
@@ -121,6 +135,7 @@ class OracleEngine(object):
 
     def forward_backward(self, starts, Lm, flags=0,
                          want=("lalpha", "lbeta", "var_x", "local_lb"), B=None):
+        self._pre_mutate()
         st = None if starts is None else np.asarray(starts, dtype=np.int64).ravel()
         B = len(st) if st is not None else int(B)
         ll = self._lls(st, Lm, flags, B)
@@ -134,6 +149,7 @@ class OracleEngine(object):
         return {k: self._last[k] for k in want}
 
     def estep(self, starts, Lm, flags=TRANS_WRAP, read=True, inner=None):
+        self._pre_mutate()
         st = np.asarray(starts, dtype=np.int64).ravel()
         self._check(st, Lm)
         B = len(st)
@@ -176,6 +192,7 @@ class OracleEngine(object):
         return (z if want_z else None), conf
 
     def pred_logprob(self, starts, Lm, flags=MASK_AS_NAN):
+        self._pre_mutate()
         st = np.asarray(starts, dtype=np.int64).ravel()
         if self.mask is None:
             return None, 0
@@ -226,8 +243,13 @@ class OracleEngine(object):
         return a.reshape(-1, a.shape[-1])[row0:row0 + nrows].copy()
 
     def ffbs(self, logA, uniforms, flags=0, want_lalpha=True):
+        self._pre_mutate()
         ll = self._window_ll(0, self.T, flags)
         la = R.forward_msgs(ll, self.mod_init, self.ltran)
+        return self.ffbs_sample(la, logA, uniforms), la
+
+    def ffbs_sample(self, la, logA, uniforms):
+        """hmm_fast.pyx:97-122 (backward sampling from given forward messages)."""
         T, K = la.shape
         z = np.empty(T, dtype=np.int64)
         lp = la[T - 1]
@@ -237,7 +259,7 @@ class OracleEngine(object):
             lp = la[t] + logA[:, z[t + 1]]
             p = np.exp(lp - lp.max()); p /= p.sum()
             z[t] = R.rand_discrete(p, uniforms[t])
-        return z, la
+        return z
 
     # -- multi-process (host all-reduce through an injected communicator)
     def allreduce_packed(self):

@@ -63,6 +63,9 @@ SIGNATURES = {
     "svihmm_read_intermediate": (C.c_int, [C.c_void_p, C.c_int32, _c_double_p]),
     "svihmm_ffbs": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, C.c_uint32, _c_int64_p,
                               _c_double_p]),
+    "svihmm_ffbs_sample": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, _c_double_p, _c_double_p,
+                                     _c_double_p, _c_int64_p]),
+    "svihmm_comm_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "svihmm_comm_unique_id": (C.c_int, [C.c_char_p]),
     "svihmm_comm_init": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32]),
     "svihmm_comm_destroy": (C.c_int, [C.c_void_p]),
@@ -74,7 +77,6 @@ SIGNATURES = {
     "svihmm_kernel_name": (C.c_char_p, [C.c_int32]),
     "svihmm_set_variant": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "svihmm_selftest_mfma": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, _c_double_p]),
-    "svihmm_peak_fp64": (C.c_int, [C.c_void_p, C.c_int32, _c_double_p]),
 }
 
 

@@ -3,22 +3,21 @@ expected sufficient statistics ``[A_raw | xbar | neff | S | lb]`` before the glo
 natural-gradient step (the ``A_inter += A_i ; emit_inter[k] += e_i[k]`` accumulation
 of reference hmmsgd_metaobs.py:430-436 extended across GPUs).
 
-* ``RcclComm``  -- production: ncclAllReduce(sum, fp64) on the device buffer over
-  RCCL/xGMI through the C ABI (``svihmm_allreduce_packed``); one process per GPU.
-* ``TorchDistComm`` -- host all-reduce through an initialised ``torch.distributed``
-  process group (gloo); used by the CPU multi-process tests of the sharding logic.
-Both give every rank bit-identical statistics, so the deterministic host global step
-keeps the replicas in lock-step without a parameter broadcast.
+``RcclComm``: ncclAllReduce(sum, fp64) on the device buffer over RCCL/xGMI through the C ABI
+(``svihmm_allreduce_packed``); one process per GPU, no PyTorch in the process.  Every rank
+ends up with bit-identical statistics, so the deterministic host global step keeps the
+replicas in lock-step without a parameter broadcast.  The ncclUniqueId travels through a
+file (``file_uid_exchange``) or any callable the caller supplies.  (The CPU multi-process
+tests of the sharding logic use a gloo communicator with the same protocol; it lives with
+the tests, ``tests/dist_helpers.py``.)
 """
 import numpy as np
-
-from .engine import PackedStats
 
 
 class RcclComm(object):
     def __init__(self, engine, rank, size, exchange_uid):
         """``exchange_uid(uid_or_None) -> uid``: host-side broadcast of the 128-byte
-        ncclUniqueId from rank 0 (e.g. via torch.distributed gloo or a TCP store)."""
+        ncclUniqueId from rank 0 (``file_uid_exchange``, a TCP store, ...)."""
         self.rank, self.size = int(rank), int(size)
         uid = exchange_uid(engine.comm_unique_id() if self.rank == 0 else None)
         engine.comm_init(uid, self.rank, self.size)
@@ -29,30 +28,6 @@ class RcclComm(object):
 
     def barrier(self, engine):
         engine.allreduce_host(np.zeros(1))
-
-
-class TorchDistComm(object):
-    def __init__(self, group=None):
-        import torch.distributed as dist
-        self._dist = dist
-        self.group = group
-        self.rank = dist.get_rank(group)
-        self.size = dist.get_world_size(group)
-
-    def allreduce_inplace(self, buf):
-        import torch
-        t = torch.from_numpy(buf)
-        self._dist.all_reduce(t, group=self.group)
-        return buf
-
-    def allreduce_stats(self, engine, K, D):
-        st = engine.read_packed()
-        buf = np.ascontiguousarray(st.buf)
-        self.allreduce_inplace(buf)
-        return type(st)(buf, K, getattr(st, "V", D))
-
-    def barrier(self, engine=None):
-        self._dist.barrier(group=self.group)
 
 
 def file_uid_exchange(rank, tag=None, timeout=300.0, directory=None):
@@ -94,11 +69,3 @@ def file_uid_exchange(rank, tag=None, timeout=300.0, directory=None):
 
     exchange.path = path
     return exchange
-
-
-def torch_uid_exchange(uid):
-    """broadcast the ncclUniqueId over an initialised torch.distributed group."""
-    import torch.distributed as dist
-    box = [uid]
-    dist.broadcast_object_list(box, src=0)
-    return box[0]

@@ -1,4 +1,4 @@
-// kernels_misc.h -- exp/transpose of ltran, MFMA layout self-test, fp64 peak probes.
+// kernels_misc.h -- exp/transpose of ltran, MFMA layout self-test, small utility kernels.
 // Part of libsvihmm_hip.so; included by svihmm_hip.hip (single translation unit).
 #pragma once
 
@@ -37,77 +37,6 @@ __global__ void k_selftest_mfma(const double* __restrict__ A, const double* __re
   double4_t c = {0.0, 0.0, 0.0, 0.0};
   c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
   for (int r = 0; r < 4; ++r) C[((l >> 4) + 4 * r) * 16 + (l & 15)] = c[r];
-}
-
-// fp64 throughput micro-benchmarks (peak calibration for the roofline)
-__global__ __launch_bounds__(256) void k_peak_mfma_f64(double* out, int iters) {
-  double4_t c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
-  const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
-  const long long t0 = clock64();
-  for (int i = 0; i < iters; ++i) {
-    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1, 0, 0, 0);
-    c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2, 0, 0, 0);
-    c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3, 0, 0, 0);
-  }
-  const long long t1 = clock64();
-  out[blockIdx.x * blockDim.x + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
-  if (blockIdx.x == 0 && threadIdx.x == 0) out[(size_t)gridDim.x * blockDim.x] = (double)(t1 - t0);
-}
-template <int NACC>
-__global__ __launch_bounds__(256) void k_peak_mfma_chain(double* out, int iters) {
-  double4_t c[NACC];
-#pragma unroll
-  for (int i = 0; i < NACC; ++i) c[i] = (double4_t){0, 0, 0, 0};
-  const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
-  const long long t0 = clock64();
-  for (int it = 0; it < iters; ++it) {
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) c[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c[i], 0, 0, 0);
-  }
-  const long long t1 = clock64();
-  double s = 0;
-#pragma unroll
-  for (int i = 0; i < NACC; ++i) s += c[i][i & 3];
-  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-  if (blockIdx.x == 0 && threadIdx.x == 0) out[(size_t)gridDim.x * blockDim.x] = (double)(t1 - t0);
-}
-// MFMA + fp64 VALU overlap probe: per iteration 8 MFMAs and NF*8 independent v_fma_f64
-template <int NF, bool MF>
-__global__ __launch_bounds__(256) void k_peak_mix(double* out, int iters) {
-  double4_t c[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) c[i] = (double4_t){0, 0, 0, 0};
-  double f[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) f[i] = i;
-  const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
-  for (int it = 0; it < iters; ++it) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if (MF) c[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c[i], 0, 0, 0);
-#pragma unroll
-      for (int k = 0; k < NF; ++k) f[(i + k) & 7] = fma(f[(i + k) & 7], a, b);
-    }
-  }
-  double s = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) s += c[i][i & 3] + f[i];
-  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-}
-__global__ __launch_bounds__(256) void k_peak_fma_f64(double* out, int iters) {
-  double c[8];
-  const double a = 1.0 + threadIdx.x * 1e-9, b = 1e-9 * threadIdx.x;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) c[i] = i;
-  for (int it = 0; it < iters; ++it) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) c[i] = fma(c[i], a, b);
-  }
-  double s = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) s += c[i];
-  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
 // ------------------------------------------------------------------------------------
@@ -217,36 +146,6 @@ __global__ __launch_bounds__(256) void k_state_argmax(
     for (int i = threadIdx.x; i < K * K; i += 256) {
       const unsigned int c = ctab[i];
       if (c) atomicAdd(&conf[i], (unsigned long long)c);
-    }
-  }
-}
-
-// HBM access-pattern probe for the sweeps: every workgroup walks 16 windows in time, reading
-// two [16 x 64] fp64 row sets per step and writing two (the traffic of a forward + backward
-// pair), PERM 0: window-major rows (16 pieces of 512 B, Lm * 512 B apart), PERM 1: the 16
-// windows' rows of a step adjacent (one 8 KB piece).
-template <int PERM>
-__global__ __launch_bounds__(256) void k_probe_pattern(const double* __restrict__ src,
-                                                       double* __restrict__ dst, int Lm) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const size_t gbase = (size_t)blockIdx.x * 16 * Lm * 64;
-  double acc = 0.0;
-  for (int t = 0; t < Lm; ++t) {
-    double v[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int w = wave * 4 + r;
-      const size_t o = PERM ? gbase + ((size_t)t * 16 + w) * 64 + lane
-                            : gbase + ((size_t)w * Lm + t) * 64 + lane;
-      v[r] = src[o];
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int w = wave * 4 + r;
-      const size_t o = PERM ? gbase + ((size_t)t * 16 + w) * 64 + lane
-                            : gbase + ((size_t)w * Lm + t) * 64 + lane;
-      dst[o] = v[r] + acc;
-      acc += 1e-300;
     }
   }
 }

@@ -1784,6 +1784,49 @@ int svihmm_state_argmax(svihmm_ctx* h, const int32_t* true_sts, int32_t* out_z,
   return 0;
 }
 
+// backward sampling from the device-resident lalpha[T,K] (hmm_fast.pyx:97-122): blocked
+// composition of the per-row draw maps (K <= 64, T >= 1024), else the sequential single-wave
+// sampler.  *dz_out: device int64[T] (in h->scratch), valid until the next call.
+static int ffbs_draw(svihmm_ctx* h, const double* la, int64_t T, int K, const double* logA,
+                     const double* uniforms, int64_t** dz_out) {
+  const bool blocked = K <= 64 && T >= 1024 && h->variant[6] != 1;
+  const int KS = K <= 16 ? 16 : K <= 32 ? 32 : 64;
+  const int Ls = T >= 65536 ? 512 : 256;
+  const int Cs = (int)((T + Ls - 1) / Ls);
+  const size_t base = ((size_t)K * K + (size_t)T) * sizeof(double) + (size_t)T * sizeof(int64_t);
+  const size_t extra = blocked ? (size_t)T * KS + 2 * (size_t)Cs * KS + (size_t)Cs + 64 : 0;
+  CK(ensure(h->scratch, base + extra));
+  double* dlogA = (double*)h->scratch.p;
+  double* dun = dlogA + (size_t)K * K;
+  int64_t* dz = (int64_t*)(dun + T);
+  *dz_out = dz;
+  unsigned char* path = (unsigned char*)(dz + T);
+  unsigned char* mA = path + (size_t)T * KS;
+  unsigned char* mB = mA + (size_t)Cs * KS;
+  unsigned char* entry = mB + (size_t)Cs * KS;
+  HIPCK(hipMemcpyAsync(dlogA, logA, (size_t)K * K * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemcpyAsync(dun, uniforms, (size_t)T * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  {
+    ProfScope ps(h, KS_FFBS);
+    if (blocked) {
+#define FPATH(KM)                                                                                          \
+  hipLaunchKernelGGL(k_ffbs_paths<KM>, dim3(Cs), dim3(64), ((size_t)K * (KM + 1) + 2 * KM) * sizeof(double), \
+                     h->stream, la, (const double*)dlogA, (const double*)dun, T, K, Ls, path)
+      if (KS == 16) FPATH(16); else if (KS == 32) FPATH(32); else FPATH(64);
+#undef FPATH
+      hipLaunchKernelGGL(k_ffbs_compose, dim3(1), dim3(1024), 0, h->stream, (const unsigned char*)path, T, KS,
+                         Ls, Cs, mA, mB, entry);
+      hipLaunchKernelGGL(k_ffbs_gather, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, h->stream,
+                         (const unsigned char*)path, (const unsigned char*)entry, T, KS, Ls, dz);
+    } else {
+      hipLaunchKernelGGL(k_ffbs_sample, dim3(1), dim3(64), K > 64 ? (size_t)K * 8 : 0, h->stream,
+                         la, (const double*)dlogA, (const double*)dun, T, K, dz);
+    }
+    HIPCK(hipGetLastError());
+  }
+  return 0;
+}
+
 int svihmm_ffbs(svihmm_ctx* h, const double* logA, const double* uniforms, uint32_t flags,
                 int64_t* out_z, double* out_lalpha) {
   if (!h || !logA || !uniforms || !out_z) return fail("svihmm_ffbs: bad arguments");
@@ -1832,46 +1875,30 @@ int svihmm_ffbs(svihmm_ctx* h, const double* logA, const double* uniforms, uint3
     CK(launch_fb(h, 1, (int)T, 0, 1));
     la = (const double*)h->la.p;
   }
-  // backward sampling: blocked composition of the per-row draw maps (K <= 64, T >= 1024),
-  // else the sequential single-wave sampler
-  const bool blocked = K <= 64 && T >= 1024 && h->variant[6] != 1;
-  const int KS = K <= 16 ? 16 : K <= 32 ? 32 : 64;
-  const int Ls = T >= 65536 ? 512 : 256;
-  const int Cs = (int)((T + Ls - 1) / Ls);
-  const size_t base = ((size_t)K * K + (size_t)T) * sizeof(double) + (size_t)T * sizeof(int64_t);
-  const size_t extra = blocked ? (size_t)T * KS + 2 * (size_t)Cs * KS + (size_t)Cs + 64 : 0;
-  CK(ensure(h->scratch, base + extra));
-  double* dlogA = (double*)h->scratch.p;
-  double* dun = dlogA + (size_t)K * K;
-  int64_t* dz = (int64_t*)(dun + T);
-  unsigned char* path = (unsigned char*)(dz + T);
-  unsigned char* mA = path + (size_t)T * KS;
-  unsigned char* mB = mA + (size_t)Cs * KS;
-  unsigned char* entry = mB + (size_t)Cs * KS;
-  HIPCK(hipMemcpyAsync(dlogA, logA, (size_t)K * K * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIPCK(hipMemcpyAsync(dun, uniforms, (size_t)T * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  {
-    ProfScope ps(h, KS_FFBS);
-    if (blocked) {
-#define FPATH(KM)                                                                                          \
-  hipLaunchKernelGGL(k_ffbs_paths<KM>, dim3(Cs), dim3(64), ((size_t)K * (KM + 1) + 2 * KM) * sizeof(double), \
-                     h->stream, la, (const double*)dlogA, (const double*)dun, T, K, Ls, path)
-      if (KS == 16) FPATH(16); else if (KS == 32) FPATH(32); else FPATH(64);
-#undef FPATH
-      hipLaunchKernelGGL(k_ffbs_compose, dim3(1), dim3(1024), 0, h->stream, (const unsigned char*)path, T, KS,
-                         Ls, Cs, mA, mB, entry);
-      hipLaunchKernelGGL(k_ffbs_gather, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, h->stream,
-                         (const unsigned char*)path, (const unsigned char*)entry, T, KS, Ls, dz);
-    } else {
-      hipLaunchKernelGGL(k_ffbs_sample, dim3(1), dim3(64), K > 64 ? (size_t)K * 8 : 0, h->stream,
-                         la, (const double*)dlogA, (const double*)dun, T, K, dz);
-    }
-    HIPCK(hipGetLastError());
-  }
+  int64_t* dz = nullptr;
+  CK(ffbs_draw(h, la, T, K, logA, uniforms, &dz));
   CK(d2h(h, out_z, dz, (size_t)T * sizeof(int64_t)));
   if (out_lalpha) CK(d2h(h, out_lalpha, la, (size_t)T * K * sizeof(double)));
   HIPCK(hipStreamSynchronize(h->stream));
   h->lastB = 1; h->lastLm = (int)T;
+  return 0;
+}
+
+// hmm_fast.pyx:80-95: with lalpha_init supplied the reference skips the filter and only samples
+int svihmm_ffbs_sample(svihmm_ctx* h, int64_t T, int32_t K, const double* lalpha, const double* logA,
+                       const double* uniforms, int64_t* out_z) {
+  if (!h || !lalpha || !logA || !uniforms || !out_z || T <= 0 || K <= 0)
+    return fail("svihmm_ffbs_sample: bad arguments");
+  if (T > 2147483647LL) return fail("svihmm_ffbs_sample: T too large");
+  CK(set_device(h));
+  const size_t n = (size_t)T * K * sizeof(double);
+  CK(ensure(h->m_la, n));
+  h->m_nb = 0;
+  HIPCK(hipMemcpyAsync(h->m_la.p, lalpha, n, hipMemcpyHostToDevice, h->stream));
+  int64_t* dz = nullptr;
+  CK(ffbs_draw(h, (const double*)h->m_la.p, T, K, logA, uniforms, &dz));
+  CK(d2h(h, out_z, dz, (size_t)T * sizeof(int64_t)));
+  HIPCK(hipStreamSynchronize(h->stream));
   return 0;
 }
 
@@ -1950,6 +1977,15 @@ int svihmm_comm_init(svihmm_ctx* h, const char uid[128], int32_t rank, int32_t n
   std::memcpy(&id, uid, 128);
   NCCLCK(ncclCommInitRank(&h->comm, nranks, id, rank));
   h->rank = rank; h->nranks = nranks;
+  return 0;
+}
+
+int svihmm_comm_count(svihmm_ctx* h, int32_t* nranks_out) {
+  if (!h || !nranks_out) return fail("svihmm_comm_count: bad arguments");
+  if (!h->comm) { *nranks_out = 0; return 0; }
+  int n = 0;
+  NCCLCK(ncclCommCount(h->comm, &n));
+  *nranks_out = n;
   return 0;
 }
 
@@ -2045,108 +2081,6 @@ int svihmm_selftest_mfma(svihmm_ctx* h, const double* A16x4, const double* B4x16
   HIPCK(hipGetLastError());
   HIPCK(hipMemcpyAsync(C16x16, dC, 256 * 8, hipMemcpyDeviceToHost, h->stream));
   HIPCK(hipStreamSynchronize(h->stream));
-  return 0;
-}
-
-// which 0: v_mfma_f64_16x16x4_f64, 1: v_fma_f64.  Returns achieved TFLOP/s.
-int svihmm_peak_fp64(svihmm_ctx* h, int32_t which, double* tflops_out) {
-  if (!h || !tflops_out) return fail("bad arguments");
-  CK(set_device(h));
-  // which: 0 mfma (8 blocks/CU), 1 fma, 2 mfma 1 block/CU (1 wave/SIMD), 3 mfma 2 blocks/CU;
-  // +16: return s_memtime ticks per loop iteration of block 0 instead of TFLOP/s
-  const bool ticks = (which & 16) != 0;
-  if (which >= 400 && which <= 401) {   // sweep access-pattern probe: returns TB/s (read + write)
-    const int Lm = 257, groups = 488;
-    const size_t n = (size_t)groups * 16 * Lm * 64;
-    CK(ensure(h->scratch, 2 * n * sizeof(double)));
-    double* src = (double*)h->scratch.p;
-    double* dst = src + n;
-    HIPCK(hipMemsetAsync(src, 0, n * sizeof(double), h->stream));
-    hipEvent_t e0, e1;
-    HIPCK(hipEventCreate(&e0)); HIPCK(hipEventCreate(&e1));
-    for (int rep = 0; rep < 3; ++rep) {
-      HIPCK(hipEventRecord(e0, h->stream));
-      if (which == 400) hipLaunchKernelGGL(k_probe_pattern<0>, dim3(groups), dim3(256), 0, h->stream, (const double*)src, dst, Lm);
-      else hipLaunchKernelGGL(k_probe_pattern<1>, dim3(groups), dim3(256), 0, h->stream, (const double*)src, dst, Lm);
-      HIPCK(hipEventRecord(e1, h->stream));
-      HIPCK(hipEventSynchronize(e1));
-    }
-    float ms = 0.f;
-    HIPCK(hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    *tflops_out = 2.0 * n * sizeof(double) / (ms * 1e-3) / 1e12;
-    return 0;
-  }
-  if (which >= 200) {   // 200 + 10*nf + mf : mix probe, 2 blocks/CU; returns ns per loop iteration
-    const int nf = (which - 200) / 10, mf = (which - 200) % 10;
-    const int blocks = 512, threads = 256, iters = 4000;
-    CK(ensure(h->scratch, ((size_t)blocks * threads + 8) * sizeof(double)));
-    hipEvent_t e0, e1;
-    HIPCK(hipEventCreate(&e0)); HIPCK(hipEventCreate(&e1));
-    for (int rep = 0; rep < 2; ++rep) {
-      HIPCK(hipEventRecord(e0, h->stream));
-#define PM(N, M) hipLaunchKernelGGL((k_peak_mix<N, M>), dim3(blocks), dim3(threads), 0, h->stream, (double*)h->scratch.p, iters)
-      if (nf == 0) PM(0, true);
-      else if (nf == 8) { if (mf) PM(8, true); else PM(8, false); }
-      else { if (mf) PM(16, true); else PM(16, false); }
-#undef PM
-      HIPCK(hipEventRecord(e1, h->stream));
-      HIPCK(hipEventSynchronize(e1));
-    }
-    float ms = 0.f;
-    HIPCK(hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    *tflops_out = (double)ms * 1e6 / iters;
-    return 0;
-  }
-  if (which >= 100) {   // 100 + nacc: 1 block/CU (1 wave/SIMD), nacc independent accumulators
-    const int nacc = which - 100, blocks = 256, threads = 256, iters = 4000;
-    CK(ensure(h->scratch, ((size_t)blocks * threads + 8) * sizeof(double)));
-    hipEvent_t e0, e1;
-    HIPCK(hipEventCreate(&e0)); HIPCK(hipEventCreate(&e1));
-    for (int rep = 0; rep < 2; ++rep) {
-      HIPCK(hipEventRecord(e0, h->stream));
-#define PK(N) hipLaunchKernelGGL(k_peak_mfma_chain<N>, dim3(blocks), dim3(threads), 0, h->stream, (double*)h->scratch.p, iters)
-      if (nacc == 1) PK(1); else if (nacc == 2) PK(2); else if (nacc == 4) PK(4); else if (nacc == 8) PK(8);
-      else if (nacc == 12) PK(12); else PK(16);
-#undef PK
-      HIPCK(hipEventRecord(e1, h->stream));
-      HIPCK(hipEventSynchronize(e1));
-    }
-    float ms = 0.f;
-    HIPCK(hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    // nanoseconds per MFMA per SIMD
-    *tflops_out = (double)ms * 1e6 / ((double)iters * (nacc == 1 || nacc == 2 || nacc == 4 || nacc == 8 || nacc == 12 ? nacc : 16));
-    return 0;
-  }
-  which &= 15;
-  const int bpc = which == 2 ? 1 : which == 3 ? 2 : 8;
-  const int blocks = 256 * bpc, threads = 256, iters = 20000;
-  CK(ensure(h->scratch, ((size_t)blocks * threads + 8) * sizeof(double)));
-  hipEvent_t e0, e1;
-  HIPCK(hipEventCreate(&e0)); HIPCK(hipEventCreate(&e1));
-  for (int rep = 0; rep < 2; ++rep) {
-    HIPCK(hipEventRecord(e0, h->stream));
-    if (which != 1)
-      hipLaunchKernelGGL(k_peak_mfma_f64, dim3(blocks), dim3(threads), 0, h->stream, (double*)h->scratch.p, iters);
-    else
-      hipLaunchKernelGGL(k_peak_fma_f64, dim3(blocks), dim3(threads), 0, h->stream, (double*)h->scratch.p, iters);
-    HIPCK(hipEventRecord(e1, h->stream));
-    HIPCK(hipEventSynchronize(e1));
-  }
-  float ms = 0.f;
-  HIPCK(hipEventElapsedTime(&ms, e0, e1));
-  hipEventDestroy(e0); hipEventDestroy(e1);
-  double flops;
-  if (which != 1) flops = (double)blocks * (threads / 64) * (double)iters * 4.0 * 2048.0;
-  else flops = (double)blocks * threads * (double)iters * 8.0 * 2.0;
-  *tflops_out = flops / (ms * 1e-3) / 1e12;
-  if (ticks && which != 1) {
-    double tk = 0;
-    HIPCK(hipMemcpy(&tk, (double*)h->scratch.p + (size_t)blocks * threads, sizeof(double), hipMemcpyDeviceToHost));
-    *tflops_out = tk / iters;
-  }
   return 0;
 }
 

@@ -82,8 +82,20 @@ class HipEngine(object):
     def sync(self):
         L.check(self._lib.svihmm_sync(self._h), "svihmm_sync")
 
+    def on_next_mutation(self, callback):
+        """Register a one-shot callback that runs before the next call that uploads parameters
+        or overwrites the E-step intermediates (``lliks / lalpha / lbeta / var_x`` rows in HBM):
+        a host object that fetches those rows lazily resolves them while they are still valid."""
+        self._on_mutate = callback
+
+    def _pre_mutate(self):
+        cb, self._on_mutate = getattr(self, "_on_mutate", None), None
+        if cb is not None:
+            cb()
+
     # -- inputs ----------------------------------------------------------------------
     def set_obs(self, obs, mask=None):
+        self._pre_mutate()
         obs = np.asarray(obs, dtype=np.float64)
         if obs.ndim == 1:
             obs = obs[:, None]
@@ -101,6 +113,7 @@ class HipEngine(object):
         """Generate a synthetic sequence directly in HBM (reference ``gen_synthetic.generate_data``
         semantics; counter-based randomness, see ``include/svihmm.h``): it becomes the resident
         observation copy.  ``chols`` are lower Cholesky factors of the emission covariances."""
+        self._pre_mutate()
         tran = L.as_f64(tran)
         K = tran.shape[0]
         cdf = np.cumsum(tran, axis=1)
@@ -124,6 +137,7 @@ class HipEngine(object):
         """Upload a sequence that arrives in row blocks (``gen_synthetic.read_data_mmap``,
         reference ``gen_synthetic.py:188-191``): ``blocks`` yields ``[n_i, D]`` arrays in
         order; rows beyond the last block keep whatever the allocation held."""
+        self._pre_mutate()
         T, D = int(T), int(D)
         m = None
         if mask is not None:
@@ -144,6 +158,7 @@ class HipEngine(object):
         return row
 
     def set_globals(self, mod_init, ltran):
+        self._pre_mutate()
         ltran = L.as_f64(ltran)
         K = ltran.shape[0]
         mod_init = L.as_f64(mod_init, (K,))
@@ -158,6 +173,7 @@ class HipEngine(object):
         the device.  ``check=True`` waits for the factorisation so that a sigma that is
         not positive definite raises here; ``check=False`` returns immediately (the error
         then surfaces at the next synchronising call -- used in hot loops)."""
+        self._pre_mutate()
         mu = L.as_f64(mu)
         K, D = mu.shape
         sigma = L.as_f64(sigma, (K, D, D))
@@ -190,6 +206,7 @@ class HipEngine(object):
         return out[0], out[1], out[2]
 
     def set_lliks(self, lliks):
+        self._pre_mutate()
         lliks = L.as_f64(lliks)
         B, Lm, K = lliks.shape
         L.check(self._lib.svihmm_set_lliks(self._h, L.dptr(lliks), B, Lm), "svihmm_set_lliks")
@@ -200,6 +217,7 @@ class HipEngine(object):
         return np.ascontiguousarray(np.asarray(starts, dtype=np.int64).ravel())
 
     def loglik(self, starts, Lm, flags=0):
+        self._pre_mutate()
         st = self._starts(starts)
         out = np.empty((len(st), Lm, self.K))
         L.check(self._lib.svihmm_loglik(self._h, L.i64ptr(st), len(st), int(Lm), int(flags),
@@ -208,6 +226,7 @@ class HipEngine(object):
 
     def forward_backward(self, starts, Lm, flags=0, want=("lalpha", "lbeta", "var_x", "local_lb"),
                          B=None):
+        self._pre_mutate()
         st = None if starts is None else self._starts(starts)
         B = len(st) if st is not None else int(B)
         self._rows = B * int(Lm)
@@ -229,6 +248,7 @@ class HipEngine(object):
         """Whole-minibatch E-step -> PackedStats (or None with read=False: the
         statistics stay in HBM for allreduce()).  ``inner=(off, length)`` restricts
         the statistics to that segment of every window (buffered meta-observations)."""
+        self._pre_mutate()
         st = self._starts(starts)
         out = np.empty(self._packed_len()) if read else None
         off, ln = (0, int(Lm)) if inner is None else (int(inner[0]), int(inner[1]))
@@ -246,6 +266,7 @@ class HipEngine(object):
 
     def set_emission_cat(self, logp):
         """Categorical emissions: ``logp[k, v] = E_q log theta_k[v]`` (obs = symbol indices)."""
+        self._pre_mutate()
         logp = L.as_f64(logp)
         K, V = logp.shape
         L.check(self._lib.svihmm_set_emission_cat(self._h, K, V, L.dptr(logp)), "svihmm_set_emission_cat")
@@ -254,6 +275,7 @@ class HipEngine(object):
     def pred_logprob(self, starts, Lm, flags=L.MASK_AS_NAN):
         """Mean predictive log-probability of the masked rows of the windows and their number
         (reference pred_logprob / pred_logprob_full); ``(None, 0)`` when nothing is masked."""
+        self._pre_mutate()
         st = self._starts(starts)
         self._rows = len(st) * int(Lm)
         out = np.empty(2)
@@ -301,6 +323,7 @@ class HipEngine(object):
         return out
 
     def ffbs(self, logA, uniforms, flags=0, want_lalpha=True):
+        self._pre_mutate()
         logA = L.as_f64(logA, (self.K, self.K))
         u = L.as_f64(uniforms, (self.T,))
         z = np.empty(self.T, dtype=np.int64)
@@ -308,6 +331,19 @@ class HipEngine(object):
         L.check(self._lib.svihmm_ffbs(self._h, L.dptr(logA), L.dptr(u), int(flags),
                                       L.i64ptr(z), L.dptr(la)), "svihmm_ffbs")
         return z, la
+
+    def ffbs_sample(self, lalpha, logA, uniforms):
+        """Backward sampling only from the supplied forward messages (the ``lalpha_init``
+        branch of the reference's FFBS, hmm_fast.pyx:80-95)."""
+        self._pre_mutate()
+        lalpha = L.as_f64(lalpha)
+        T, K = lalpha.shape
+        logA = L.as_f64(logA, (K, K))
+        u = L.as_f64(uniforms, (T,))
+        z = np.empty(T, dtype=np.int64)
+        L.check(self._lib.svihmm_ffbs_sample(self._h, T, K, L.dptr(lalpha), L.dptr(logA), L.dptr(u),
+                                             L.i64ptr(z)), "svihmm_ffbs_sample")
+        return z
 
     # -- multi-GPU ------------------------------------------------------------------------
     def comm_unique_id(self):
@@ -319,6 +355,12 @@ class HipEngine(object):
         L.check(self._lib.svihmm_comm_init(self._h, uid, int(rank), int(nranks)),
                 "svihmm_comm_init")
         self._comm = True
+
+    def comm_count(self):
+        """Number of ranks RCCL itself reports for the communicator (0 without one)."""
+        n = C.c_int32()
+        L.check(self._lib.svihmm_comm_count(self._h, C.byref(n)), "svihmm_comm_count")
+        return n.value
 
     def allreduce_packed(self):
         L.check(self._lib.svihmm_allreduce_packed(self._h), "svihmm_allreduce_packed")
@@ -354,11 +396,6 @@ class HipEngine(object):
         L.check(self._lib.svihmm_selftest_mfma(self._h, L.dptr(A), L.dptr(B), L.dptr(out)),
                 "selftest_mfma")
         return out
-
-    def peak_fp64(self, which):
-        v = C.c_double()
-        L.check(self._lib.svihmm_peak_fp64(self._h, int(which), C.byref(v)), "peak_fp64")
-        return v.value
 
 
 def device_count():

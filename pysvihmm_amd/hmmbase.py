@@ -42,6 +42,19 @@ def is_niw_gaussian(e):
     return isinstance(e, Gaussian) or getattr(type(e), "svihmm_niw_fastpath", False)
 
 
+def dirichlet_elbo(prior, var):
+    """sum over rows of E_q[log Dir(.|prior_r)] + H[Dir(.|var_r)] for row-wise Dirichlet factors
+    (the ``*_energy + *_entropy`` terms of reference hmmbase.py:150-181 and
+    hmmsgd_metaobs.py:277-292, with their ``eps`` placement inside gammaln / digamma)."""
+    prior = np.asarray(prior, dtype=np.float64)
+    var = np.asarray(var, dtype=np.float64)
+    elog = digamma(var + eps) - digamma(var.sum(axis=1) + eps)[:, npa]      # E_q log theta
+    lognorm = lambda a: gammaln(a.sum(axis=1) + eps) - gammaln(a + eps).sum(axis=1)
+    energy = lognorm(prior) + ((prior - 1.) * elog).sum(axis=1)
+    entropy = -(lognorm(var) + ((var - 1.) * elog).sum(axis=1))
+    return float(energy.sum() + entropy.sum())
+
+
 class VariationalHMMBase(object, metaclass=abc.ABCMeta):
     """Abstract base class for finite variational HMMs."""
 
@@ -248,31 +261,9 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
     # -- ELBO ------------------------------------------------------------------------
     def lower_bound(self):
         """ Variational lower bound (reference hmmbase.py:145-199)."""
-        p_pi = self.prior_init
-        p_pisum = np.sum(p_pi)
-        q_pi = self.var_init
-        q_pidg = digamma(q_pi + eps)
-        q_pisum = np.sum(q_pi)
-        dg_q_pisum = digamma(q_pisum + eps)
-
-        pi_energy = (gammaln(p_pisum + eps) - np.sum(gammaln(p_pi + eps))
-                     + np.sum((p_pi - 1.) * (q_pidg - dg_q_pisum)))
-        pi_entropy = -(gammaln(q_pisum + eps) - np.sum(gammaln(q_pi + eps))
-                       + np.sum((q_pi - 1.) * (q_pidg - dg_q_pisum)))
-
-        p_A = self.prior_tran
-        p_Asum = np.sum(p_A, axis=1)
-        q_A = self.var_tran
-        q_Adg = digamma(q_A + eps)
-        q_Asum = np.sum(q_A, axis=1)
-        dg_q_Asum = digamma(q_Asum + eps)
-
-        A_energy = (gammaln(p_Asum + eps) - np.sum(gammaln(p_A + eps), axis=1)
-                    + np.sum((p_A - 1) * (q_Adg - dg_q_Asum[:, npa]), axis=1))
-        A_entropy = -(gammaln(q_Asum + eps) - np.sum(gammaln(q_A + eps), axis=1)
-                      + np.sum((q_A - 1) * (q_Adg - dg_q_Asum[:, npa]), axis=1))
-        A_energy = np.sum(A_energy)
-        A_entropy = np.sum(A_entropy)
+        # E_q[log p] - E_q[log q] of the Dirichlet factors (initial distribution, transition rows)
+        pi_term = dirichlet_elbo(self.prior_init[None, :], self.var_init[None, :])
+        A_term = dirichlet_elbo(self.prior_tran, self.var_tran)
 
         emit_vlb = self._emit_vlb()
 
@@ -283,7 +274,7 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
         else:
             lZ = np.sum(np.logaddexp.reduce(self.lalpha, axis=1))
 
-        return (pi_energy + pi_entropy + A_energy + A_entropy + emit_vlb + lZ)
+        return pi_term + A_term + emit_vlb + lZ
 
     # -- E-step ------------------------------------------------------------------------
     def local_update(self, obs=None, mask=None):
@@ -385,11 +376,14 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
         logA = np.log(A + DBL_EPSILON)
         if uniforms is None:
             uniforms = np.random.random_sample(self.T)
-        self._upload_obs()
         if lalpha_init is not None:
-            # backward sampling only, from the supplied messages
-            raise RuntimeError("lalpha_init is unusable in the reference on modern NumPy "
-                               "(hmm_fast.pyx:80); pass None")
+            # backward sampling only, from the supplied messages (hmm_fast.pyx:80-95: neither
+            # the likelihoods nor the filter run; lalpha_init itself is returned)
+            lalpha_init = np.asarray(lalpha_init, dtype=np.float64)
+            if lalpha_init.shape != (self.T, self.K):
+                raise RuntimeError("lalpha_init must have shape (T, K)")
+            return self.engine.ffbs_sample(lalpha_init, logA, uniforms), lalpha_init
+        self._upload_obs()
         self.engine.set_globals(mod_init, logA)
         flags = self._push_emission()
         z, lalpha = self.engine.ffbs(logA, uniforms, flags=flags)
@@ -413,18 +407,19 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
         return dist.hamming(true_sts, best_match[state_sq]), best_match
 
     def KL_L2_gaussian(self, emit_true, permutation):
-        KL = 0
-        distance_mus = 0
-        dim = len(self.var_emit[1].mu)
-        for k, k2 in enumerate(permutation):
-            k = permutation[k2]
-            diffmeans = emit_true[k].mu - self.var_emit[k2].mu
-            distance_mus += npl.norm(diffmeans)
-            sig_emit_inv = npl.inv(emit_true[k].sigma)
-            KL += .5 * (np.trace(np.dot(sig_emit_inv, self.var_emit[k2].sigma))
-                        + np.dot(diffmeans, np.dot(sig_emit_inv, diffmeans)) - dim
-                        - np.log(npl.det(self.var_emit[k2].sigma) / npl.det(emit_true[k].sigma)))
-        return KL, distance_mus
+        """Evaluation metric (reference hmmbase.py:364-390): for every learned state ``k2`` paired
+        with the true state ``k = permutation[k2]``, KL(N(learned) || N(true)) summed, and the
+        summed L2 distance of the means."""
+        kl_total = 0.
+        l2_total = 0.
+        for k2 in range(len(permutation)):
+            tru, fit = emit_true[permutation[k2]], self.var_emit[k2]
+            d = np.asarray(tru.mu) - np.asarray(fit.mu)
+            l2_total += npl.norm(d)
+            St, Sf = np.asarray(tru.sigma), np.asarray(fit.sigma)
+            kl_total += .5 * (np.trace(npl.solve(St, Sf)) + d.dot(npl.solve(St, d)) - d.shape[0]
+                              - (npl.slogdet(Sf)[1] - npl.slogdet(St)[1]))
+        return kl_total, l2_total
 
     def A_dist(self, A_true, perm):
         A = self.var_tran / np.sum(self.var_tran, axis=1)[:, np.newaxis]

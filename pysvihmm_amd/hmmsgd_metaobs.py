@@ -20,13 +20,14 @@ from __future__ import division
 
 import sys
 import time
+import weakref
 
 import numpy as np
 import numpy.random as npr
 from numpy import newaxis as npa
-from scipy.special import digamma, gammaln
+from scipy.special import digamma
 
-from .hmmbase import VariationalHMMBase, is_niw_gaussian
+from .hmmbase import VariationalHMMBase, is_niw_gaussian, dirichlet_elbo
 from .distributions import Gaussian, Categorical
 from . import util
 from . import _lib as L
@@ -202,17 +203,7 @@ class VBHMM(VariationalHMMBase):
 
     def global_lower_bound(self):
         """reference :273-296."""
-        p_A = self.prior_tran
-        p_Asum = np.sum(p_A, axis=1)
-        q_A = self.var_tran
-        q_Adg = digamma(q_A + eps)
-        q_Asum = np.sum(q_A, axis=1)
-        dg_q_Asum = digamma(q_Asum + eps)
-        A_energy = (gammaln(p_Asum + eps) - np.sum(gammaln(p_A + eps), axis=1)
-                    + np.sum((p_A - 1) * (q_Adg - dg_q_Asum[:, npa]), axis=1))
-        A_entropy = -(gammaln(q_Asum + eps) - np.sum(gammaln(q_A + eps), axis=1)
-                      + np.sum((q_A - 1) * (q_Adg - dg_q_Asum[:, npa]), axis=1))
-        return np.sum(A_energy) + np.sum(A_entropy) + self._emit_vlb()
+        return dirichlet_elbo(self.prior_tran, self.var_tran) + self._emit_vlb()
 
     # -- the SVI loop -----------------------------------------------------------------------
     def _stationary_init(self):
@@ -362,6 +353,11 @@ class VBHMM(VariationalHMMBase):
         round-robin over the ranks and the packed statistics are all-reduced."""
         K, D = self.K, self.D
         Lm = 2 * miniL + 1
+        # the previous iteration's lazily held window state is superseded, not fetched
+        self.__dict__.pop("_pending_rows", None)
+        eng = self.engine
+        if hasattr(eng, "on_next_mutation"):
+            eng.on_next_mutation(None)
         self._stationary_init()
         self._psi_expectations()
         self._push_globals()
@@ -397,6 +393,12 @@ class VBHMM(VariationalHMMBase):
             # state of the last window, fetched on first access (valid until the next upload)
             self._pending_rows = (b * Lm, Lm, {"lliks", "lalpha", "lbeta", "var_x"})
             self._lZ = None
+            # any later engine call that uploads parameters or reuses the intermediate buffers
+            # (pred_logprob_full, full_local_update, select_L, local_update, ...) first lets this
+            # object fetch those rows while they are still the last window's
+            if hasattr(eng, "on_next_mutation"):
+                ref = weakref.ref(self)
+                eng.on_next_mutation(lambda: ref() is not None and ref()._resolve_pending())
         return A_inter, emit_inter, lb
 
     # -- single meta-observation local update (reference :487-519) ----------------------------

@@ -3,13 +3,13 @@
 Only what sits on / next to the E-step path: NIW natural <-> moment conversions
 (reference ``util.py:12-60``), the weighted sufficient statistics
 (``util.py:73-83``, the CPU statement of what the device ``suffstats`` kernels
-reduce), masks (``util.py:163-206``), state matching (``util.py:236-277``, via
-SciPy's Hungarian solver instead of the vendored Munkres).  Plot helpers are out
-of scope.
+reduce), the hold-out masks ``gen_synthetic`` needs (``util.py:163-206``), state matching
+(``util.py:236-277``, via SciPy's Hungarian solver instead of the vendored Munkres).
+Plot helpers, ``KL_gaussian``, ``mvnrand`` and the Dirichlet one-liners are out of scope
+ and not provided.
 """
 
 import numpy as np
-import numpy.linalg as npl
 
 
 def _obj(*items):
@@ -74,66 +74,37 @@ def NIW_suffstats(G, data, weights):
     return _obj(xbar, neff, S, neff)
 
 
-def KL_gaussian(mu0, sig0, mu1, sig1):
-    D = len(mu0)
-    if D != len(mu1) or D != sig0.shape[0] or D != sig1.shape[0]:
-        raise RuntimeError("Means and covariances my be the same dimension.")
-    if sig0.shape[0] != sig0.shape[1] or sig1.shape[0] != sig1.shape[1]:
-        raise RuntimeError("Covariance matrices must be square.")
-    s1inv = npl.inv(sig1)
-    s0_ld = npl.slogdet(sig0)[1]
-    s1_ld = npl.slogdet(sig1)[1]
-    x = mu1 - mu0
-    tmp = np.trace(np.dot(s1inv, sig0)) + np.dot(x.T, np.dot(s1inv, x))
-    tmp += -D - s0_ld + s1_ld
-    return 0.5 * tmp
-
-
-def dirichlet_natural_pars(alpha):
-    return alpha - 1.
-
-
-def dirichlet_moment_pars(eta):
-    return eta + 1.
-
-
-def mvnrand(mean, cov, size=1):
-    mu = np.squeeze(mean)
-    D = mu.shape[0]
-    C = npl.cholesky(cov)
-    z = np.random.randn(size, D)
-    return np.squeeze(mu + np.dot(z, C.T))
-
-
 def make_mask(sts, miss=0., left=0):
-    """Mark a ``miss`` fraction of the observations right of ``left`` as
-    missing, evenly over states (``util.py:163-191``)."""
+    """Hold out a ``miss`` fraction of every state's observations at or after ``left``
+    (the held-out rows of ``gen_synthetic``'s smoothing setups; reference ``util.py:163-191``).
+    Per state label ``k = 0 .. n_labels-1`` in order: skipped when fewer than 10 of its rows lie
+    right of ``left``; the target count is ``ceil(miss * rows of k in the WHOLE sequence)``,
+    falling back to the fraction of the rows right of ``left`` when that is more than there
+    are; one ``np.random.choice(..., replace=False)`` draw per state (the global legacy
+    stream, so a seeded run reproduces the reference's masks)."""
     sts = np.asarray(sts)
-    sts_l = sts[left:]
-    K = np.unique(sts_l).shape[0]
-    mask = np.zeros(len(sts), dtype='bool')
-    if miss > 0.:
-        for k in range(K):
-            obs_k = np.where(sts_l == k)[0]
-            if obs_k.shape[0] < 10:
-                continue
-            nobs_k = np.ceil(miss * np.sum(sts == k))
-            if obs_k.shape[0] < nobs_k:
-                nobs_k = np.ceil(miss * obs_k.shape[0])
-            nobs_k = int(nobs_k)
-            inds = np.random.choice(obs_k, size=nobs_k, replace=False)
-            mask[left + inds] = True
-    return mask
+    out = np.zeros(sts.shape[0], dtype=bool)
+    if not miss > 0.:
+        return out
+    tail = sts[left:]
+    for k in range(np.unique(tail).shape[0]):
+        cand = np.flatnonzero(tail == k)
+        if cand.size < 10:
+            continue
+        want = np.ceil(miss * np.count_nonzero(sts == k))
+        if want > cand.size:
+            want = np.ceil(miss * cand.size)
+        out[left + np.random.choice(cand, size=int(want), replace=False)] = True
+    return out
 
 
 def make_mask_prediction(sts, miss=0.):
-    nobs = len(sts)
-    mask = np.zeros(nobs, dtype='bool')
-    if miss == 0.:
-        return mask
-    nmiss = int(np.ceil(miss * nobs))
-    mask[-nmiss:] = True
-    return mask
+    """Hold out the last ``ceil(miss * T)`` rows (prediction setup, reference ``util.py:194-206``)."""
+    T = len(sts)
+    out = np.zeros(T, dtype=bool)
+    if miss != 0.:
+        out[T - int(np.ceil(miss * T)):] = True
+    return out
 
 
 def munkres_match(sts_true, sts_pred, K):

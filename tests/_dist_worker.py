@@ -15,7 +15,7 @@ def main():
     dist.init_process_group("gloo")
     from oracle.engine import OracleEngine
     from pysvihmm_amd import hmmsgd_metaobs
-    from pysvihmm_amd.comm import TorchDistComm
+    from tests.dist_helpers import TorchDistComm
     from tests.test_host_logic import emit_from_fixture
     g = np.load(fixture)
     K = int(g["K"])

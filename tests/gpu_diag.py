@@ -10,7 +10,8 @@ import traceback
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
 from pysvihmm_amd.engine import HipEngine  # noqa: E402
 from pysvihmm_amd import _lib as L  # noqa: E402
 from oracle import ref_c  # noqa: E402
@@ -33,8 +34,10 @@ def main():
         traceback.print_exc()
     section("fp64 peaks")
     try:
-        print("v_mfma_f64_16x16x4: %.1f TFLOP/s" % eng.peak_fp64(0))
-        print("v_fma_f64:          %.1f TFLOP/s" % eng.peak_fp64(1))
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        from _probe import probe_fp64
+        print("v_mfma_f64_16x16x4: %.1f TFLOP/s" % probe_fp64(0))
+        print("v_fma_f64:          %.1f TFLOP/s" % probe_fp64(1))
     except Exception:
         traceback.print_exc()
 

@@ -223,3 +223,55 @@ def test_oracle_is_confined_to_tests_smoke_and_bench_baseline():
                     any(a.name.startswith("oracle") for a in getattr(n, "names", [])))
                    for n in ast.walk(fn))
         assert not uses or fn.name == "smoke", fn.name
+
+
+def _mask_fixture_model(engine, maxit, full_predprob):
+    g = np.load(os.path.join(GOLDEN, "metaobs_K4_D2_L10_mask.npz"))
+    K = int(g["K"])
+    return hmmsgd_metaobs.VBHMM(
+        g["obs"].copy(), np.ones(K), g["prior_tran"], emit_from_fixture(g, K),
+        tau=float(g["tau"]), kappa=float(g["kappa"]), metaobs_half=int(g["L"]), mb_sz=int(g["S"]),
+        mask=g["mask"], init_tran=g["init_tran"], maxit=maxit, seed=int(g["seed"]), engine=engine,
+        full_predprob=full_predprob)
+
+
+def test_last_window_state_survives_full_predprob():
+    """The last window's lliks / lalpha / lbeta / var_x are fetched lazily from the device
+    buffers; a whole-chain call in the same iteration (full_predprob on the last iteration)
+    reuses those buffers, so the rows must be fetched before it runs (round-1 advisor finding)."""
+    a = _mask_fixture_model(OracleEngine(), 1, False)
+    b = _mask_fixture_model(OracleEngine(), 1, True)
+    a.infer()
+    b.infer()
+    for name in ("lliks", "lalpha", "lbeta", "var_x"):
+        np.testing.assert_array_equal(getattr(a, name), getattr(b, name))
+    np.testing.assert_array_equal(a.elbo_vec, b.elbo_vec)
+    assert np.isfinite(b.pred_logprob_full_mean[0])
+    # a later engine call of any kind must not change what the object holds either
+    keep = a.var_x.copy()
+    a.full_local_update()
+    np.testing.assert_array_equal(a.var_x, keep)
+
+
+def test_ffbs_lalpha_init_branch_samples_only():
+    """hmm_fast.pyx:80-95: with lalpha_init the filter is skipped; the draws equal those of the
+    full call when lalpha_init is that call's own lalpha, and lalpha_init itself is returned."""
+    g = np.load(os.path.join(GOLDEN, "ffbs_K5_D3_T120.npz"))
+    K = int(g["K"])
+    emit = []
+    for k in range(K):
+        e = Gaussian(mu=g["mu"][k], sigma=np.eye(int(g["D"])), mu_0=g["mu"][k], sigma_0=g["sigma"][k],
+                     kappa_0=float(g["kappa"][k]), nu_0=float(g["nu"][k]))
+        e.mu_mf, e.sigma_mf = g["mu"][k].copy(), g["sigma"][k].copy()
+        e.kappa_mf, e.nu_mf = float(g["kappa"][k]), float(g["nu"][k])
+        emit.append(e)
+    hmm = hmmbatchcd.VBHMM(g["obs"].copy(), np.ones(K), np.ones((K, K)), np.array(emit),
+                           init_tran=g["var_tran"], engine=OracleEngine())
+    u = np.random.default_rng(5).random(hmm.T)
+    z, la = hmm.ffbs_fast(g["var_init"], uniforms=u)
+    z2, la2 = hmm.ffbs_fast(g["var_init"], lalpha_init=la, uniforms=u)
+    np.testing.assert_array_equal(z, z2)
+    assert la2 is la or np.array_equal(la2, la)
+    np.testing.assert_allclose(la, g["lalpha"], rtol=1e-9, atol=1e-8)   # the Cython module's lalpha
+    with pytest.raises(RuntimeError):
+        hmm.ffbs_fast(g["var_init"], lalpha_init=la[:-1], uniforms=u)
