@@ -199,3 +199,34 @@ int orc_estep_minibatch(const double* obs, const uint8_t* mask, int64_t T, int D
   free(ll); free(xw);
   return 0;
 }
+
+/* The same minibatch loop with the windows dealt in contiguous slices to `nthreads` OpenMP
+ * threads (each slice is the serial loop above on a private accumulator; the slices are added
+ * in slice order).  The reference itself is single-threaded: this exists only as bench.py's
+ * "all host cores" baseline (SURVEY.md 8d item ii). */
+int orc_estep_minibatch_mt(const double* obs, const uint8_t* mask, int64_t T, int D,
+                           const int64_t* starts, int B, int Lm, int K, const double* mod_init,
+                           const double* ltran, const double* mu, const double* sigma,
+                           const double* kappa, const double* nu, unsigned flags, int nthreads,
+                           double* packed) {
+  const size_t np_ = (size_t)K * K + (size_t)K * D + K + (size_t)K * D * D + 1;
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > B) nthreads = B > 0 ? B : 1;
+  double* parts = (double*)malloc(sizeof(double) * np_ * (size_t)nthreads);
+  int* rcs = (int*)calloc((size_t)nthreads, sizeof(int));
+  if (!parts || !rcs) { free(parts); free(rcs); return 2; }
+#pragma omp parallel for num_threads(nthreads) schedule(static, 1)
+  for (int th = 0; th < nthreads; ++th) {
+    const int b0 = (int)((int64_t)B * th / nthreads), b1 = (int)((int64_t)B * (th + 1) / nthreads);
+    rcs[th] = orc_estep_minibatch(obs, mask, T, D, starts + b0, b1 - b0, Lm, K, mod_init, ltran, mu,
+                                  sigma, kappa, nu, flags, parts + np_ * (size_t)th);
+  }
+  int rc = 0;
+  memset(packed, 0, sizeof(double) * np_);
+  for (int th = 0; th < nthreads; ++th) {
+    if (rcs[th]) rc = rcs[th];
+    for (size_t i = 0; i < np_; ++i) packed[i] += parts[np_ * (size_t)th + i];
+  }
+  free(parts); free(rcs);
+  return rc;
+}

@@ -32,6 +32,8 @@ def lib():
         l.orc_posterior.argtypes = [_dp, _dp, C.c_int64, C.c_int, _dp]
         l.orc_estep_minibatch.argtypes = [_dp, _up, C.c_int64, C.c_int, _ip, C.c_int, C.c_int,
                                           C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, C.c_uint, _dp]
+        l.orc_estep_minibatch_mt.argtypes = [_dp, _up, C.c_int64, C.c_int, _ip, C.c_int, C.c_int,
+                                             C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, C.c_uint, C.c_int, _dp]
         _lib = l
     return _lib
 
@@ -79,7 +81,9 @@ def posterior(la, lb):
     return q, s
 
 
-def estep_minibatch(obs, mask, starts, Lm, mod_init, ltran, mu, sigma, kappa, nu, flags=2):
+def estep_minibatch(obs, mask, starts, Lm, mod_init, ltran, mu, sigma, kappa, nu, flags=2, threads=1):
+    """``threads > 1``: the windows are dealt to that many OpenMP threads (bench.py's all-cores
+    baseline); the default is the reference's single-threaded loop."""
     obs, mod_init, ltran, mu, sigma, kappa, nu = map(_c, (obs, mod_init, ltran, mu, sigma,
                                                           kappa, nu))
     T, D = obs.shape
@@ -87,10 +91,15 @@ def estep_minibatch(obs, mask, starts, Lm, mod_init, ltran, mu, sigma, kappa, nu
     st = np.ascontiguousarray(starts, dtype=np.int64)
     m = None if mask is None else np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
     packed = np.empty(K * K + K * D + K + K * D * D + 1)
-    rc = lib().orc_estep_minibatch(_d(obs), None if m is None else m.ctypes.data_as(_up), T, D,
-                                   st.ctypes.data_as(_ip), len(st), int(Lm), K, _d(mod_init),
-                                   _d(ltran), _d(mu), _d(sigma), _d(kappa), _d(nu), int(flags),
-                                   _d(packed))
+    mp = None if m is None else m.ctypes.data_as(_up)
+    if threads > 1:
+        rc = lib().orc_estep_minibatch_mt(_d(obs), mp, T, D, st.ctypes.data_as(_ip), len(st), int(Lm), K,
+                                          _d(mod_init), _d(ltran), _d(mu), _d(sigma), _d(kappa), _d(nu),
+                                          int(flags), int(threads), _d(packed))
+    else:
+        rc = lib().orc_estep_minibatch(_d(obs), mp, T, D, st.ctypes.data_as(_ip), len(st), int(Lm), K,
+                                       _d(mod_init), _d(ltran), _d(mu), _d(sigma), _d(kappa), _d(nu),
+                                       int(flags), _d(packed))
     if rc:
         raise RuntimeError("orc_estep_minibatch rc=%d" % rc)
     return packed

@@ -4,8 +4,8 @@
 ``np.random.choice(K, p=tran[cur])`` transitions, ``emit[cur].rvs()[0]`` emissions,
 gen_synthetic.py:27-44) with the same global ``np.random`` stream consumption order,
 so a seeded run reproduces the reference's sequence given the same emission class.
-``generate_data_fast`` is a vectorised generator for the T=1e6..1e8 benchmark
-sequences.  The mmap writer fixes the reference's shape bug (it allocates obs with
+``generate_data_fast`` draws the same process run by run on the host (T up to ~1e7);
+``generate_data_device`` generates it in HBM (T = 1e8 and beyond).  The mmap writer fixes the reference's shape bug (it allocates obs with
 K instead of D columns and never writes the last row, gen_synthetic.py:165,173-180).
 """
 from __future__ import division
@@ -58,21 +58,35 @@ def generate_data_prediction(tran, emit, T, miss=0., nmasks=1):
 
 
 def generate_data_fast(tran, means, chols, T, rng=None):
-    """Vectorised Gaussian-HMM generator: state path by inverse-CDF on the rows of
-    ``tran`` (chunked), emissions ``means[z] + eps @ chol[z]'``."""
+    """Host generator for long Gaussian-HMM sequences (same process as ``generate_data``: start
+    in state 0, row-``tran`` transitions, ``means[z] + chol[z] n``), drawn run by run instead of
+    step by step: a visit to state ``k`` lasts Geometric(1 - tran[k,k]) steps and leaves to
+    ``j != k`` with probability ``tran[k,j] / (1 - tran[k,k])``.  Emissions are filled per
+    state, so the peak memory is the output itself.  ``chols``: [K,D,D] lower factors, or
+    anything with ``ndim != 3`` for unit covariances.  (For T >= 1e7 prefer
+    ``generate_data_device``: the sequence is then generated in HBM and never exists on the host.)"""
     rng = np.random.default_rng() if rng is None else rng
+    tran = np.asarray(tran, dtype=np.float64)
     K, D = means.shape
-    cdf = np.cumsum(tran, axis=1)
-    cdf[:, -1] = 1.0
-    u = rng.random(T)
+    stay = np.clip(np.diag(tran), 0.0, 1.0)
+    leave = tran.copy()
+    np.fill_diagonal(leave, 0.0)
+    tot = leave.sum(axis=1)
+    leave_cdf = np.cumsum(leave / np.where(tot > 0, tot, 1.0)[:, None], axis=1)
     sts = np.empty(T, dtype=np.int64)
-    cur = 0
-    sts[0] = 0
-    for t in range(1, T):
-        cur = int(np.searchsorted(cdf[cur], u[t]))
-        sts[t] = cur
-    z = rng.normal(size=(T, D))
-    obs = means[sts] + np.einsum('td,tkd->tk', z, chols[sts]) if chols.ndim == 3 else means[sts] + z
+    t, cur = 0, 0
+    while t < T:
+        run = T - t if (stay[cur] >= 1.0 or tot[cur] <= 0) else int(rng.geometric(1.0 - stay[cur]))
+        sts[t:t + run] = cur
+        t += run
+        if t < T:
+            cur = int(min(np.searchsorted(leave_cdf[cur], rng.random(), side='right'), K - 1))
+    obs = rng.normal(size=(T, D))
+    full = getattr(chols, "ndim", 0) == 3
+    for k in range(K):
+        rows = np.flatnonzero(sts == k)
+        if rows.size:
+            obs[rows] = (obs[rows].dot(chols[k].T) if full else obs[rows]) + means[k]
     return obs, sts
 
 

@@ -47,3 +47,22 @@ def unpack(buf, K, D):
 def relerr(a, b, floor=1e-12):
     a = np.asarray(a, dtype=float); b = np.asarray(b, dtype=float)
     return float(np.max(np.abs(a - b) / (floor + np.abs(b)))) if a.size else 0.0
+
+
+def ffbs_draws_exact(z, lalpha, logA, u, tol=1e-12):
+    """Row-by-row check of a backward-sampled path (hmm_fast.pyx:97-122): given the path's own
+    z[t+1], z[t] must be the inverse-CDF draw (rand_discrete, :29-36: first k with u <= cumsum)
+    of softmax(lalpha[t] + logA[:, z[t+1]]) at u[t].  Index output: EXACT on every row whose
+    uniform is further than ``tol`` from every CDF step (a row closer than that may
+    legitimately round either way).  Returns (rows that disagree outside tol, rows within tol)."""
+    z = np.asarray(z)
+    T, K = lalpha.shape
+    lp = np.array(lalpha, dtype=np.float64)
+    lp[:-1] += logA[:, z[1:]].T
+    p = np.exp(lp - lp.max(axis=1, keepdims=True))
+    p /= p.sum(axis=1, keepdims=True)
+    c = np.cumsum(p, axis=1)
+    want = np.minimum((c < u[:, None]).sum(axis=1), K - 1)
+    margin = np.min(np.abs(c[:, :-1] - u[:, None]), axis=1) if K > 1 else np.ones(T)
+    risky = margin <= tol
+    return int(np.sum((want != z) & ~risky)), int(risky.sum())

@@ -167,3 +167,48 @@ def test_hamming_dist_device_equals_host_route():
     hd, bm = cd.hamming_dist(cd.full_local_update(), sts)
     hd2, bm2 = cd.hamming_dist(None, sts)
     assert abs(hd - hd2) < 1e-12 and np.array_equal(bm, bm2)
+
+
+def test_last_window_state_survives_full_predprob_on_gpu():
+    """Round-1 advisor finding on the HIP engine: the lazily fetched last-window rows are read
+    before a whole-chain call of the same iteration reuses the device buffers."""
+    from tests.test_host_logic import _mask_fixture_model
+    a = _mask_fixture_model(None, 1, False)
+    b = _mask_fixture_model(None, 1, True)
+    a.infer()
+    b.infer()
+    g = np.load(os.path.join(GOLDEN, "metaobs_K4_D2_L10_mask.npz"))
+    S = int(g["S"])
+    for name in ("lliks", "lalpha", "lbeta", "var_x"):
+        np.testing.assert_allclose(getattr(a, name), getattr(b, name), rtol=1e-12, atol=1e-12)
+    # == the reference's state after its first iteration (last window of the first minibatch)
+    np.testing.assert_allclose(b.var_x, g["w_var_x"][S - 1], rtol=1e-6, atol=1e-11)
+    np.testing.assert_allclose(b.lalpha, g["w_lalpha"][S - 1], rtol=1e-9, atol=1e-8)
+    assert np.isfinite(b.pred_logprob_full_mean[0])
+
+
+def test_ffbs_lalpha_init_branch_on_gpu():
+    """hmm_fast.pyx:80-95 through svihmm_ffbs_sample: sampling only, from the caller's lalpha --
+    the Cython module's recorded lalpha gives exactly the sequential sampler's draws."""
+    from oracle import ref_numpy as R
+    from pysvihmm_amd.engine import HipEngine
+    g = np.load(os.path.join(GOLDEN, "ffbs_K5_D3_T120.npz"))
+    T = int(g["T"])
+    DE = np.finfo(np.float64).eps
+    logA = np.log(g["var_tran"] + DE)
+    e = HipEngine(0)
+    for seed in range(4):
+        u = np.random.default_rng(seed).random(T)
+        z = e.ffbs_sample(g["lalpha"], logA, u)
+        zref = R.ffbs_backward_sample(g["lalpha"], g["var_tran"], u)
+        np.testing.assert_array_equal(z, zref)
+    # long chain: the blocked composition of draw maps (T >= 1024) vs the sequential restatement
+    rng = np.random.default_rng(7)
+    K, T2 = 12, 5000
+    la = np.cumsum(rng.normal(size=(T2, K)), axis=0) * 0.3
+    A = rng.random((K, K)) + 0.05
+    u = rng.random(T2)
+    z = e.ffbs_sample(la, np.log(A + DE), u)
+    zref = R.ffbs_backward_sample(la, A, u)
+    np.testing.assert_array_equal(z, zref)
+    e.close()

@@ -238,9 +238,15 @@ def test_ffbs(eng):
     u = np.random.default_rng(9).random(T)
     z, la = eng.ffbs(logA, u)
     np.testing.assert_allclose(la, g["lalpha"], rtol=1e-9, atol=1e-8)
-    zref = R.ffbs_backward_sample(g["lalpha"], g["var_tran"], u)
-    assert (z == zref).mean() > 0.98
     assert z.min() >= 0 and z.max() < K
+    # index output, exact: the sequential sampler of hmm_fast.pyx:97-122 run on the lalpha the
+    # call returned gives the same path (checked row by row given z[t+1]; a row may differ only
+    # if its uniform lies within 1e-12 of a CDF step), and so does the recorded Cython lalpha
+    from tests.helpers import ffbs_draws_exact
+    bad, risky = ffbs_draws_exact(z, la, logA, u)
+    assert bad == 0, (bad, risky)
+    if risky == 0 and ffbs_draws_exact(z, g["lalpha"], logA, u) == (0, 0):
+        np.testing.assert_array_equal(z, R.ffbs_backward_sample(g["lalpha"], g["var_tran"], u))
 
 
 def test_full_size_properties(eng):

@@ -213,9 +213,13 @@ def test_oracle_is_confined_to_tests_smoke_and_bench_baseline():
 
     for path in glob.glob(os.path.join(root, "pysvihmm_amd", "*.py")) + glob.glob(os.path.join(root, "tools", "*.py")):
         assert not oracle_imports(path), path
-    src = open(os.path.join(root, "bench.py")).read().splitlines()
-    for ln in oracle_imports(os.path.join(root, "bench.py")):
-        assert any("no_cpu_baseline" in l for l in src[max(0, ln - 6):ln]), ln
+    # bench.py: only inside the function that times the CPU baselines
+    btree = ast.parse(open(os.path.join(root, "bench.py")).read())
+    inside = set()
+    for fn in [n for n in ast.walk(btree) if isinstance(n, ast.FunctionDef) and n.name == "cpu_baselines"]:
+        inside.update(n.lineno for n in ast.walk(fn) if isinstance(n, (ast.Import, ast.ImportFrom)))
+    hits = oracle_imports(os.path.join(root, "bench.py"))
+    assert hits and all(ln in inside for ln in hits), hits
     tree = ast.parse(open(os.path.join(root, "__graft_entry__.py")).read())
     for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
         uses = any(isinstance(n, (ast.Import, ast.ImportFrom)) and
