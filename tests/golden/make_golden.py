@@ -14,6 +14,18 @@ Mechanical edits applied to the temporary copies:
   4. hmm_fast.pyx:59,70  ``np.int_t``/``np.int_`` -> ``np.int64_t``/``np.int64``;
      hmm_fast.pyx:80 ``lalpha_init == None`` -> ``is None``; cythonize + gcc
   5. ``np.float_`` -> ``np.float64`` (NumPy 2)
+  6. Categorical branch of ``intermediate_pars`` / ``intermediate_pars_buffer``
+     (hmmsgd_metaobs.py:920-921, 996-997) -- the branch cannot execute as written on any NumPy
+     we know of: ``z[[[np.arange(n)], [data]]] = 1`` is the long-removed nested-list form of
+     ``z[np.arange(n), data] = 1`` (and ``data`` is an [n, 1] column there, because
+     ``local_update`` indexes ``obs[lo:hi, :]`` and so needs 2-D observations), and ``w *= z``
+     multiplies the [n] weights into the [n, C] one-hot IN PLACE (a broadcasting error).  The
+     staged copy uses the tuple index on the flattened integer symbols and ``w = w[:, None] * z``
+     -- what the surrounding comments ("mask w to only ...") and the downstream
+     ``_get_weighted_statistics(data, w)`` call require.  The Categorical fixture
+     records that the unpatched branch raises (``cat_intermediate_raises``) and the output of
+     the repaired branch; everything else in it (local_update on Categorical lliks,
+     ``global_update`` :1071-1084) is unmodified reference code.
 The absent third-party package ``pybasicbayes`` is satisfied by this repo's own
 emission classes (``pysvihmm_amd.distributions``); therefore the fixtures pin
 everything DOWNSTREAM of ``lliks`` (pure reference arithmetic) and record
@@ -63,6 +75,13 @@ def stage_reference(tmp):
         p = os.path.join(tmp, f)
         s = open(p).read().replace("np.float_)", "np.float64)")
         open(p, "w").write(s)
+
+    # keep an unrepaired copy of the metaobs module to show that its Categorical branch raises
+    shutil.copy(os.path.join(tmp, "hmmsgd_metaobs.py"), os.path.join(tmp, "hmmsgd_metaobs_asis.py"))
+    patch("hmmsgd_metaobs.py", lambda s: s.replace(
+        "z[[[np.arange(data.shape[0])], [data]]] = 1",
+        "z[np.arange(data.shape[0]), np.asarray(data).ravel().astype(int)] = 1").replace(
+        "w *= z", "w = w[:, None] * z"))
 
     # Cython module
     pyx = open(os.path.join(REF, "hmm_fast.pyx")).read()
@@ -133,13 +152,17 @@ def prior_arrays(var_emit):
                 nu0=np.array([float(g.nu_0) for g in var_emit]))
 
 
-def trace_metaobs(HM, name, K, D, T, L, S, maxit, miss, seed):
+def trace_metaobs(HM, name, K, D, T, L, S, maxit, miss, seed, ctor_kw=None, infer_kw=None, probes=()):
+    """``ctor_kw`` / ``infer_kw``: extra constructor / ``infer`` arguments (adaptive L, growBuffer);
+    ``probes``: (ind, halflength) pairs for direct ``get_local_messages`` calls after ``infer``."""
+    ctor_kw = dict(ctor_kw or {})
+    infer_kw = dict(infer_kw or {})
     rng = np.random.default_rng(seed)
     pb = make_problem(K, D, T, rng, miss)
     hmm = HM.VBHMM(pb["obs"].copy(), pb["prior_init"], pb["prior_tran"],
                    pb["prior_emit"], tau=1.0, kappa=0.7, metaobs_half=L, mb_sz=S,
                    mask=pb["mask"], init_tran=pb["init_tran"], maxit=maxit,
-                   seed=seed % (2 ** 31))
+                   seed=seed % (2 ** 31), **ctor_kw)
     rec = dict(obs=pb["obs"], mask=pb["mask"], prior_tran=pb["prior_tran"],
                init_tran=pb["init_tran"], L=L, S=S, T=T, K=K, D=D, maxit=maxit,
                tau=1.0, kappa=0.7, seed=seed % (2 ** 31))
@@ -156,6 +179,8 @@ def trace_metaobs(HM, name, K, D, T, L, S, maxit, miss, seed):
     def local_update(metaobs=None):
         pre = dict(var_init=hmm.var_init.copy(), var_tran=hmm.var_tran.copy(),
                    i1=metaobs.i1, i2=metaobs.i2)
+        if ctor_kw or infer_kw:
+            pre["iter"] = len(per_iter)
         pre.update(emit_arrays(hmm.var_emit))
         orig_local(metaobs=metaobs)
         pre.update(mod_init=hmm.mod_init.copy(), mod_tran=hmm.mod_tran.copy(),
@@ -184,16 +209,61 @@ def trace_metaobs(HM, name, K, D, T, L, S, maxit, miss, seed):
         d.update({"new_" + k: v for k, v in emit_arrays(hmm.var_emit).items()})
         per_iter.append(d)
 
+    orig_buf = hmm.intermediate_pars_buffer
+    orig_selL = hmm.select_L
+    orig_selB = hmm.select_buffer
+    chosen_L, chosen_buf = [], []
+
+    def intermediate_pars_buffer(metaobs, bufferL, L_):
+        A_i, e_i = orig_buf(metaobs, bufferL, L_)
+        w = per_window[-1]
+        w["A_i"] = A_i.copy()
+        w["xbar"] = np.array([e[0] for e in e_i])
+        w["neff"] = np.array([float(e[1]) for e in e_i])
+        w["Sk"] = np.array([e[2] for e in e_i])
+        return A_i, e_i
+
+    def select_L(*a, **k):
+        r = orig_selL(*a, **k)
+        chosen_L.append((len(per_iter), int(r)))
+        return r
+
+    def select_buffer(*a, **k):
+        r = orig_selB(*a, **k)
+        chosen_buf.append((len(per_iter), int(r)))
+        return r
+
     hmm.local_update = local_update
     hmm.intermediate_pars = intermediate_pars
     hmm.global_update = global_update
-    hmm.infer()
+    if ctor_kw or infer_kw:
+        hmm.intermediate_pars_buffer = intermediate_pars_buffer
+        hmm.select_L = select_L
+        hmm.select_buffer = select_buffer
+        rec["ctor_growBuffer"] = int(bool(ctor_kw.get("growBuffer", False)))
+        rec["ctor_bufferBudget"] = int(bool(ctor_kw.get("bufferBudget", False)))
+        for k_, v_ in infer_kw.items():
+            rec["infer_" + k_] = v_
+    hmm.infer(**infer_kw)
     rec["elbo_vec"] = hmm.elbo_vec.copy()
     nw = len(per_window)
+    ragged = len({w["lliks"].shape for w in per_window}) > 1
     for key in per_window[0]:
+        if ragged and key in ("lliks", "lalpha", "lbeta", "var_x"):
+            continue       # window length changes between iterations (adaptive L / buffer)
         rec["w_" + key] = np.array([w[key] for w in per_window])
     for key in per_iter[0]:
         rec["it_" + key] = np.array([d[key] for d in per_iter])
+    if ctor_kw or infer_kw:
+        rec["chosen_L"] = np.array(chosen_L, dtype=np.int64).reshape(-1, 2)      # (iteration, L)
+        rec["chosen_buffer"] = np.array(chosen_buf, dtype=np.int64).reshape(-1, 2)
+        # iteration index of every recorded window (the minibatch size may change: bufferBudget)
+        rec["w_iter"] = np.array([w["iter"] for w in per_window])
+        rec["w_len"] = np.array([w["lliks"].shape[0] for w in per_window])
+        for j, (ind, hl) in enumerate(probes):
+            rec["probe%d_ind" % j] = ind
+            rec["probe%d_half" % j] = hl
+            rec["probe%d_var_x" % j] = hmm.get_local_messages(ind, hl)
     rec["windows_per_iter"] = nw // maxit
     # full-sequence E-step with NaN masking (hmmsgd_metaobs.py:1147-1205)
     hmm.local_update = orig_local
@@ -260,6 +330,79 @@ def trace_ffbs(HB, HM, name, K, D, T, seed):
     print("wrote", name)
 
 
+def trace_categorical(HM, HM_asis, name, K, V, T, L, S, seed):
+    """Categorical emissions (hmmsgd_metaobs.py:907-926, 1071-1084).  ``infer`` itself raises for
+    them (``util.NIW_zero_nat_pars`` at :402-403), so the loop body is driven by hand exactly as
+    :405-439 does: stationary init, ``local_update``, ``intermediate_pars``, accumulation,
+    ``global_update``."""
+    from pysvihmm_amd.distributions import Categorical
+    rng = np.random.default_rng(seed)
+    tran = 0.85 * np.eye(K) + 0.15 / (K - 1) * (1 - np.eye(K))
+    emis = rng.dirichlet(0.3 * np.ones(V), size=K)
+    sts = np.empty(T, dtype=np.int64)
+    cur = 0
+    for t in range(T):
+        sts[t] = cur
+        cur = rng.choice(K, p=tran[cur])
+    obs = np.array([rng.choice(V, p=emis[z]) for z in sts], dtype=np.int64)[:, None]   # [T, 1] column
+    mask = rng.random(T) < 0.1
+    alphav_0 = 0.5 + rng.random(V)
+    prior_emit = np.array([Categorical(alphav_0=alphav_0, alpha_mf=alphav_0 + 5.0 * rng.random(V),
+                                       weights=np.ones(V) / V) for _ in range(K)])
+    init_tran = 1.0 + rng.random((K, K)) * T / K
+    mk = lambda mod: mod.VBHMM(obs.copy(), np.ones(K), np.ones((K, K)), prior_emit, tau=1.0, kappa=0.7,
+                               metaobs_half=L, mb_sz=S, mask=mask, init_tran=init_tran, maxit=2,
+                               seed=seed % (2 ** 31))
+    hmm = mk(HM)
+    rec = dict(obs=obs, mask=mask, K=K, V=V, T=T, L=L, S=S, tau=1.0, kappa=0.7, init_tran=init_tran,
+               alphav_0=alphav_0, init_alpha_mf=np.array([g.alpha_mf for g in hmm.var_emit]))
+    # (a) the unrepaired branch raises
+    asis = mk(HM_asis)
+    asis.local_update(metaobs=HM_asis.MetaObs(10, 10 + 2 * L))
+    try:
+        asis.intermediate_pars(HM_asis.MetaObs(10, 10 + 2 * L))
+        rec["cat_intermediate_raises"] = 0
+    except Exception as e:
+        rec["cat_intermediate_raises"] = 1
+        rec["cat_intermediate_error"] = type(e).__name__
+    # (b) two hand-driven iterations of the loop body
+    np.random.seed(seed % (2 ** 31))
+    wins, its = [], []
+    for it in range(2):
+        hmm.lrate = (it + hmm.tau) ** (-hmm.kappa)
+        minibatch = hmm.metaobs_fun(hmm.T, L, S)
+        A_inter = np.zeros_like(hmm.var_tran)
+        emit_inter = [np.zeros(V) for _ in range(K)]
+        lb = 0.
+        for data in minibatch:
+            A_mean = hmm.var_tran / np.sum(hmm.var_tran, axis=1)[:, None]
+            ew, ev = np.linalg.eig(A_mean.T)
+            hmm.var_init = np.abs(ev[:, np.argsort(ew)[::-1][0]])
+            hmm.local_update(metaobs=data)
+            A_i, e_i = hmm.intermediate_pars(data)
+            A_inter += A_i
+            for k in range(K):
+                emit_inter[k] += e_i[k]
+            lb += hmm.local_lower_bound()
+            wins.append(dict(i1=data.i1, i2=data.i2, lliks=hmm.lliks.copy(), lalpha=hmm.lalpha.copy(),
+                             lbeta=hmm.lbeta.copy(), var_x=hmm.var_x.copy(), A_i=A_i.copy(),
+                             e_i=np.array(e_i), local_lb=hmm.local_lower_bound(),
+                             var_init=hmm.var_init.copy()))
+        d = dict(A_inter=A_inter.copy(), emit_inter=np.array(emit_inter), lrate=hmm.lrate, lb=lb,
+                 var_tran_old=hmm.var_tran.copy(), alpha_old=np.array([g.alpha_mf for g in hmm.var_emit]))
+        hmm.global_update(A_inter, emit_inter)
+        d["var_tran_new"] = hmm.var_tran.copy()
+        d["alpha_new"] = np.array([g.alpha_mf for g in hmm.var_emit])
+        d["weights_new"] = np.array([g.weights for g in hmm.var_emit])
+        its.append(d)
+    for key in wins[0]:
+        rec["w_" + key] = np.array([w[key] for w in wins])
+    for key in its[0]:
+        rec["it_" + key] = np.array([d[key] for d in its])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)
+    print("wrote", name, "raises:", rec["cat_intermediate_raises"], rec.get("cat_intermediate_error"))
+
+
 def main():
     sys.path.insert(0, REPO)
     tmp = tempfile.mkdtemp(prefix="pysvihmm_ref_")
@@ -279,6 +422,19 @@ def main():
         trace_batch(CD, "batchcd_K4_D2_T300", 4, 2, 300, 3, 0.1, SEED + 4, False)
         trace_batch(SG, "batchsgd_K4_D3_T250", 4, 3, 250, 3, 0.1, SEED + 5, True)
         trace_ffbs(HB, HM, "ffbs_K5_D3_T120", 5, 3, 120, SEED + 6)
+        # adaptive window length (select_L, :521-569) and buffered meta-observations
+        # (select_buffer :579-661, intermediate_pars_buffer :932-1008, buffer_budget :571-577)
+        trace_metaobs(HM, "adaptive_K4_D2", 4, 2, 400, 3, 3, 4, 0.1, SEED + 7,
+                      infer_kw=dict(adaptive=True, perIter=2, epsilon=1e-7, minHalfL=2, Lincrement=1,
+                                    Lcutoff=30), probes=((57, 4), (200, 9)))
+        trace_metaobs(HM, "growbuf_K4_D2", 4, 2, 400, 5, 3, 4, 0.1, SEED + 8,
+                      ctor_kw=dict(growBuffer=True),
+                      infer_kw=dict(perIter=2, epsilon=1e-3, Lincrement=2, Lcutoff=40), probes=((120, 7),))
+        trace_metaobs(HM, "growbuf_budget_K3_D2", 3, 2, 500, 4, 5, 3, 0.0, SEED + 9,
+                      ctor_kw=dict(growBuffer=True, bufferBudget=True),
+                      infer_kw=dict(perIter=1, epsilon=1e-2, Lincrement=1, Lcutoff=25))
+        HMA = importlib.import_module("hmmsgd_metaobs_asis")
+        trace_categorical(HM, HMA, "categorical_K3_V5", 3, 5, 300, 6, 4, SEED + 10)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
