@@ -1,0 +1,156 @@
+"""Parity at BASELINE.json's full sizes.
+
+* configs[2] literal shape: K=64, D=32, T=1e6, L=128 (Lm=257) -- (a) the epoch sweep over all
+  3891 tiled windows (the bench workload) against the C oracle on EVERY window (the oracle's
+  windows are dealt to all host cores; on a small host: a sample of 96 windows spread over the
+  sequence) plus size-independent properties, per-window posteriors of 32 windows spread over
+  the sequence; (b) ``hmmsgd_metaobs.VBHMM(metaobs_half=128, mb_sz=64).infer(maxit=3)`` on the
+  HIP engine against the same class on the oracle engine.
+* configs[4]: K=256, D=64 full covariance, Lm=257, B=208 windows -- the large-batch wide path
+  (two-pass emission, k_sweeps_lin2, 64x64-block transition statistics) against the C oracle.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests.helpers import make_problem, unpack
+
+pytestmark = pytest.mark.gpu
+NCORE = os.cpu_count() or 1
+
+
+def _bench_problem(eng, T, K=64, D=32, seed=8675309):
+    """The bench's own workload: sequence generated in HBM, variational state of SURVEY 8d."""
+    import bench
+    rs = np.random.RandomState(seed)
+    tran = 0.9 * np.eye(K) + 0.1 / (K - 1) * (1.0 - np.eye(K))
+    means = rs.normal(0.0, 5.0, size=(K, D))
+    chols = np.broadcast_to(np.eye(D), (K, D, D)).copy()
+    eng.generate(tran, means, chols, T, seed=seed)
+    obs, sts = eng.read_generated()
+    pb = bench.variational_state(rs, means, obs[:20000], K, D, T)
+    pb["obs"], pb["sts"] = obs, sts
+    return pb
+
+
+def test_config3_epoch_sweep_t1e6_vs_oracle():
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    from oracle import ref_c
+    K, D, T, Lm = 64, 32, 1000000, 257
+    e = HipEngine(0)
+    pb = _bench_problem(e, T)
+    B = T // Lm
+    starts = np.arange(B, dtype=np.int64) * Lm
+    par = (pb["mod_init"], pb["ltran"], pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    e.set_globals(pb["mod_init"], pb["ltran"])
+    e.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    st = e.estep(starts, Lm, flags=L.TRANS_WRAP)
+    n = B * Lm
+    obs = pb["obs"][:n]
+    # size-independent properties
+    assert np.all(np.isfinite(st.buf))
+    assert abs(st.A_raw.sum() / n - 1.0) < 1e-11          # posteriors sum to one, Lm products per window
+    assert abs(st.neff.sum() / n - 1.0) < 1e-11
+    np.testing.assert_allclose(st.xbar.sum(0), obs.sum(0), rtol=1e-9, atol=1e-6)
+    np.testing.assert_allclose(st.S.sum(0), obs.T.dot(obs), rtol=1e-9)
+    assert np.all(np.linalg.eigvalsh(st.S) > -1e-6 * n)
+    # per-window posteriors of 32 windows spread over the sequence (oracle window by window)
+    for b in np.linspace(0, B - 1, 32).astype(int):
+        x = pb["obs"][starts[b]:starts[b] + Lm]
+        ll = ref_c.lliks_niw(x, pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+        la = ref_c.forward(ll, pb["mod_init"], pb["ltran"])
+        q, lz = ref_c.posterior(la, ref_c.backward(ll, pb["ltran"]))
+        got = e.read_rows("var_x", int(b) * Lm, Lm)
+        np.testing.assert_allclose(got, q, rtol=1e-6, atol=1e-12)
+    # the whole step against the oracle
+    if NCORE >= 32:
+        sel = starts
+        got = st.buf
+    else:                                                    # small host: 96 windows, own E-step
+        sel = starts[np.linspace(0, B - 1, 96).astype(int)]
+        got = e.estep(sel, Lm, flags=L.TRANS_WRAP).buf
+    ref = ref_c.estep_minibatch(pb["obs"], None, sel, Lm, *par, flags=2, threads=NCORE)
+    A, xbar, neff, S, lb = unpack(ref, K, D)
+    g = unpack(got, K, D)
+    sc = len(sel) * Lm
+    np.testing.assert_allclose(g[0], A, rtol=1e-6, atol=1e-10 * sc)
+    np.testing.assert_allclose(g[1], xbar, rtol=1e-6, atol=1e-9 * sc)
+    np.testing.assert_allclose(g[2], neff, rtol=1e-6, atol=1e-10 * sc)
+    np.testing.assert_allclose(g[3], S, rtol=1e-6, atol=1e-8 * sc)
+    np.testing.assert_allclose(g[4], lb, rtol=1e-11)
+    e.close()
+
+
+def test_config3_class_infer_l128_s64_vs_oracle_engine():
+    """configs[2] as the reference words it: hmmsgd_metaobs, metaobs half-length 128, minibatch 64,
+    T=1e6 -- three SVI iterations on the HIP engine == the same class on the oracle engine."""
+    from pysvihmm_amd import hmmsgd_metaobs
+    from pysvihmm_amd.distributions import Gaussian
+    from pysvihmm_amd.engine import HipEngine
+    from oracle.engine import OracleEngine
+    K, D, T = 64, 32, 1000000
+    e = HipEngine(0)
+    pb = _bench_problem(e, T)
+    obs = pb["obs"]
+    head = obs[:20000]
+
+    def model(engine):
+        np.random.seed(3)
+        prior = np.array([Gaussian(mu_0=head.mean(0), sigma_0=0.75 * np.cov(head.T), kappa_0=0.01, nu_0=D + 2)
+                          for _ in range(K)])
+        return hmmsgd_metaobs.VBHMM(obs, np.ones(K), np.ones((K, K)), prior, tau=1.0, kappa=0.7,
+                                    metaobs_half=128, mb_sz=64, maxit=3, seed=7, engine=engine)
+    a = model(e)
+    a.infer()
+    b = model(OracleEngine())
+    b.infer()
+    np.testing.assert_allclose(a.var_tran, b.var_tran, rtol=1e-6, atol=1e-9)
+    for k in range(K):
+        np.testing.assert_allclose(a.var_emit[k].mu_mf, b.var_emit[k].mu_mf, rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(a.var_emit[k].sigma_mf, b.var_emit[k].sigma_mf, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(a.var_emit[k].kappa_mf, b.var_emit[k].kappa_mf, rtol=1e-9)
+    np.testing.assert_allclose(a.elbo_vec, b.elbo_vec, rtol=1e-9)
+    np.testing.assert_allclose(a.var_x, b.var_x, rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(a.lalpha, b.lalpha, rtol=1e-9, atol=1e-7)
+    assert a.cur_mo.i1 == b.cur_mo.i1
+    e.close()
+
+
+@pytest.mark.skipif(NCORE < 16, reason="the K=256 oracle needs ~1 s per window: all-core host only")
+def test_config5_k256_d64_large_batch_vs_oracle():
+    """configs[4] shape at the batch size that selects the wide large-batch kernels."""
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    from oracle import ref_c
+    K, D, Lm, B = 256, 64, 257, 208
+    T = B * Lm + 500
+    pb = make_problem(K, D, T, seed=2560, miss=0.03, sep=4.0)
+    starts = (np.arange(B, dtype=np.int64) * Lm + 137) % (T - Lm)
+    e = HipEngine(0)
+    e.set_obs(pb["obs"], pb["mask"])
+    e.set_globals(pb["mod_init"], pb["ltran"])
+    e.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    par = (pb["mod_init"], pb["ltran"], pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    for flags in (L.TRANS_WRAP, L.TRANS_WRAP | L.MASK_AS_NAN):
+        e.profile(True); e.profile_reset()
+        st = e.estep(starts, Lm, flags=flags)
+        prof = e.profile_read(); e.profile(False)
+        assert "posterior" in prof and "forward_backward" in prof      # scaled sweeps + k_lin_posterior
+        ref = ref_c.estep_minibatch(pb["obs"], pb["mask"], starts, Lm, *par, flags=flags, threads=NCORE)
+        A, xbar, neff, S, lb = unpack(ref, K, D)
+        sc = B * Lm
+        np.testing.assert_allclose(st.A_raw, A, rtol=1e-6, atol=1e-10 * sc)
+        np.testing.assert_allclose(st.xbar, xbar, rtol=1e-6, atol=1e-9 * sc)
+        np.testing.assert_allclose(st.neff, neff, rtol=1e-6, atol=1e-10 * sc)
+        np.testing.assert_allclose(st.S, S, rtol=1e-6, atol=1e-8 * sc)
+        np.testing.assert_allclose(st.lb[0], lb, rtol=1e-10)
+    # posteriors of a few windows, row by row
+    for b in (0, 77, B - 1):
+        x = pb["obs"][starts[b]:starts[b] + Lm].copy()
+        x[pb["mask"][starts[b]:starts[b] + Lm]] = np.nan
+        ll = ref_c.lliks_niw(x, pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+        q, _ = ref_c.posterior(ref_c.forward(ll, pb["mod_init"], pb["ltran"]), ref_c.backward(ll, pb["ltran"]))
+        np.testing.assert_allclose(e.read_rows("var_x", b * Lm, Lm), q, rtol=1e-6, atol=1e-12)
+    e.close()
