@@ -57,6 +57,12 @@ typedef struct svihmm_ctx svihmm_ctx;
  * sweeps of large batches rebuild lbeta on demand and ignore the flag). */
 #define SVIHMM_KEEP_LBETA 8u
 
+/* svihmm_svi_iteration only: make the log-domain lliks / lalpha / lbeta of the batch's LAST window
+ * readable (svihmm_read_rows) after the call -- they are otherwise rebuilt on demand from the
+ * current parameters, which the iteration's global step replaces.  The reference leaves the
+ * state of the last meta-observation on the object (hmmsgd_metaobs.py:405-436). */
+#define SVIHMM_SVI_KEEP_WINDOW 16u
+
 /* ---- errors / lifecycle ------------------------------------------------------- */
 const char* svihmm_last_error(void);
 int svihmm_abi_version(void);
@@ -140,6 +146,42 @@ int svihmm_read_packed(svihmm_ctx* h, double* out_packed);
 int svihmm_estep_minibatch_ex(svihmm_ctx* h, const int64_t* starts, int32_t B,
                               int32_t Lm, int32_t inner_off, int32_t inner_len,
                               uint32_t flags, double* out_packed);
+
+/* ---- the SVI loop with the variational state resident in HBM ----------------------------------
+ * hmmsgd_metaobs.VBHMM.infer (:347-445) iterates  { stationary init :413-418, psi-expectations
+ * :502-504, E-step over the minibatch :405-436, global natural-gradient step :1010-1069
+ * (util.py:28-60), elbo_vec[it] = lb + global_lower_bound() :444-445, :273-296 }.  With these
+ * entry points var_tran and the K NIW factors stay on the device between iterations: per
+ * iteration the host sends the window starts and three scalars, and nothing has to come back
+ * until the caller wants the ELBO trace or the parameters.  Calls are asynchronous (they return
+ * when the work is enqueued); svihmm_svi_read_elbo / svihmm_svi_read_state synchronise.
+ *
+ * svihmm_svi_begin: uploads the state.  prior_tran / var_tran [K,K]; NIW prior (mu0 [K,D],
+ *   sigma0 [K,D,D], kappa0 [K], nu0 [K]) and current factors (mu, sigma, kappa, nu);
+ *   prior_logpart[k] = invwishart_log_partitionfunction(sigma0[k], nu0[k]) (constant of the
+ *   factors' ELBO term, computed once by the host); zsign = +1 / -1: the sign with which that
+ *   constant enters get_vlb (pybasicbayes / Bishop 10.74, see distributions.Gaussian.get_vlb).
+ *   The observations must be resident (svihmm_set_obs / svihmm_generate).
+ * svihmm_svi_iteration(it, ...): one iteration on windows starts[B] of length Lm (statistics over
+ *   the inner segment, as svihmm_estep_minibatch_ex; flags: SVIHMM_TRANS_WRAP | ...).
+ *   nwin_total = windows of the whole minibatch (= B on one GPU; with a communicator the ranks
+ *   hold shards and the packed statistics are all-reduced before the step): quirk Q2 adds
+ *   nwin_total * (prior_tran - 1).  rho = (it + tau)^-kappa; bfactA = (T-2L-1)/(2L*S),
+ *   bfactE = (T-2L-1)/((2L+1)*S) from the CONSTRUCTOR's L, S (quirk Q3).
+ * svihmm_svi_read_elbo: elbo_vec[0..n) and the device time of each iteration in ms (either may
+ *   be NULL).  svihmm_svi_read_state: current var_tran [K,K], var_init [K] (the stationary vector
+ *   of the last iteration, quirk Q5), NIW factors; any pointer may be NULL. */
+int svihmm_svi_begin(svihmm_ctx* h, int32_t K, int32_t D, const double* prior_tran,
+                     const double* var_tran, const double* mu0, const double* sigma0,
+                     const double* kappa0, const double* nu0, const double* prior_logpart,
+                     const double* mu, const double* sigma, const double* kappa, const double* nu,
+                     int32_t maxit, double zsign);
+int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32_t B,
+                         int32_t nwin_total, int32_t Lm, int32_t inner_off, int32_t inner_len,
+                         uint32_t flags, double rho, double bfactA, double bfactE);
+int svihmm_svi_read_elbo(svihmm_ctx* h, int32_t n, double* out_elbo, double* out_ms);
+int svihmm_svi_read_state(svihmm_ctx* h, double* var_tran, double* var_init, double* mu,
+                          double* sigma, double* kappa, double* nu);
 
 /* Categorical emissions (hmmsgd_metaobs.py:907-926, 1071-1084; pybasicbayes Categorical):
  * obs must be [T][1] holding the symbol index 0..V-1 as a double; logp[k][v] =

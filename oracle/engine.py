@@ -261,6 +261,53 @@ class OracleEngine(object):
             z[t] = R.rand_discrete(p, uniforms[t])
         return z
 
+    # -- the SVI loop protocol of HipEngine.svi_*: reference arithmetic, iteration by iteration
+    def svi_begin(self, prior_tran, var_tran, prior, factors, prior_logpart, maxit, zsign=1.0):
+        self._pre_mutate()
+        c = lambda a: np.array(a, dtype=np.float64)
+        self._svi = dict(prior_tran=c(prior_tran), var_tran=c(var_tran), prior=[c(a) for a in prior],
+                         mf=[c(a) for a in factors], elbo=np.full(int(maxit), np.nan),
+                         conv="pybasicbayes" if zsign > 0 else "bishop", var_init=None)
+        self.K = self._svi["var_tran"].shape[0]
+
+    def svi_iteration(self, it, starts, nwin_total, Lm, flags, rho, bfactA, bfactE, inner=None):
+        """hmmsgd_metaobs.py:351 .. 445 for one iteration (stationary init :413-418 by
+        np.linalg.eig as the reference does, psi :502-504, the minibatch loop, global_update
+        :1010-1069, global_lower_bound :273-296)."""
+        from pysvihmm_amd.distributions import Gaussian
+        sv = self._svi
+        sv["var_init"] = R.stationary_init(sv["var_tran"])
+        mod_init, ltran = R.psi_expectations(sv["var_init"], sv["var_tran"])
+        self.set_globals(mod_init, ltran)
+        self.set_emission_niw(*sv["mf"])
+        self.estep(starts, Lm, flags=flags, read=False, inner=inner)
+        self.allreduce_packed()
+        st = self._packed
+        K = self.K
+        A_inter = st.A_raw + nwin_total * (sv["prior_tran"] - 1.)
+        sv["var_tran"] = ((1. - rho) * (sv["var_tran"] - 1.) + rho * (bfactA * A_inter)) + 1.
+        mu, sg, ka, nu = sv["mf"]
+        mu0, sg0, ka0, nu0 = sv["prior"]
+        vlb = 0.
+        for k in range(K):
+            n_old = R.niw_nat(mu[k], sg[k], ka[k], nu[k])
+            n_0 = R.niw_nat(mu0[k], sg0[k], ka0[k], nu0[k])
+            e = [st.xbar[k], st.neff[k], st.S[k], st.neff[k]]
+            n_new = [(1. - rho) * n_old[i] + rho * (n_0[i] + bfactE * e[i]) for i in range(4)]
+            mu[k], sg[k], ka[k], nu[k] = R.niw_moment(*n_new)
+            g = Gaussian(mu=mu[k], sigma=np.eye(len(mu[k])), mu_0=mu0[k], sigma_0=sg0[k], kappa_0=ka0[k],
+                         nu_0=nu0[k])
+            g.mu_mf, g.sigma_mf, g.kappa_mf, g.nu_mf = mu[k], sg[k], ka[k], nu[k]
+            vlb += g.get_vlb(sv["conv"])
+        sv["elbo"][it] = st.lb[0] + R.dirichlet_lower_bound(sv["prior_tran"], sv["var_tran"]) + vlb
+
+    def svi_read_elbo(self, n):
+        return self._svi["elbo"][:n].copy(), np.zeros(n)
+
+    def svi_read_state(self):
+        sv = self._svi
+        return (sv["var_tran"].copy(), sv["var_init"].copy()) + tuple(a.copy() for a in sv["mf"])
+
     # -- multi-process (host all-reduce through an injected communicator)
     def allreduce_packed(self):
         if self._comm is not None:

@@ -23,7 +23,7 @@ leg may import this module.
 """
 
 import numpy as np
-from scipy.special import digamma
+from scipy.special import digamma, gammaln
 import scipy.linalg as sla
 
 eps = 1e-9  # reference hmmbase.py:30, hmmsgd_metaobs.py:26
@@ -220,6 +220,20 @@ def global_update_metaobs(var_tran, A_inter, mf, prior, emit_inter, lrate,
                  for i in range(4)]
         out.append(niw_moment(*n_new))
     return var_tran_new, out
+
+
+def dirichlet_lower_bound(prior, var):
+    """A_energy + A_entropy of reference hmmsgd_metaobs.py:277-292 (row-wise Dirichlet factors)."""
+    eps = 1e-9
+    p_sum = np.sum(prior, axis=1)
+    q_dg = digamma(var + eps)
+    q_sum = np.sum(var, axis=1)
+    dg_q_sum = digamma(q_sum + eps)
+    energy = (gammaln(p_sum + eps) - np.sum(gammaln(prior + eps), axis=1)
+              + np.sum((prior - 1) * (q_dg - dg_q_sum[:, None]), axis=1))
+    entropy = -(gammaln(q_sum + eps) - np.sum(gammaln(var + eps), axis=1)
+                + np.sum((var - 1) * (q_dg - dg_q_sum[:, None]), axis=1))
+    return np.sum(energy) + np.sum(entropy)
 
 
 # --- a12: FFBS (Cython variant) --------------------------------------------- #

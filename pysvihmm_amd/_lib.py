@@ -16,6 +16,7 @@ MASK_AS_NAN = 1
 TRANS_WRAP = 2
 USE_HOST_LLIKS = 4
 KEEP_LBETA = 8
+SVI_KEEP_WINDOW = 16
 
 _lib = None
 
@@ -47,6 +48,11 @@ SIGNATURES = {
     "svihmm_read_packed": (C.c_int, [C.c_void_p, _c_double_p]),
     "svihmm_estep_minibatch_ex": (C.c_int, [C.c_void_p, _c_int64_p, C.c_int32, C.c_int32,
                                             C.c_int32, C.c_int32, C.c_uint32, _c_double_p]),
+    "svihmm_svi_begin": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32] + [_c_double_p] * 11 + [C.c_int32, C.c_double]),
+    "svihmm_svi_iteration": (C.c_int, [C.c_void_p, C.c_int32, _c_int64_p, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_int32, C.c_int32, C.c_uint32, C.c_double, C.c_double, C.c_double]),
+    "svihmm_svi_read_elbo": (C.c_int, [C.c_void_p, C.c_int32, _c_double_p, _c_double_p]),
+    "svihmm_svi_read_state": (C.c_int, [C.c_void_p] + [_c_double_p] * 6),
     "svihmm_set_emission_cat": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _c_double_p]),
     "svihmm_packed_len": (C.c_int64, [C.c_void_p]),
     "svihmm_pred_logprob": (C.c_int, [C.c_void_p, _c_int64_p, C.c_int32, C.c_int32, C.c_uint32, _c_double_p]),

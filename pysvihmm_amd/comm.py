@@ -22,6 +22,14 @@ class RcclComm(object):
         uid = exchange_uid(engine.comm_unique_id() if self.rank == 0 else None)
         engine.comm_init(uid, self.rank, self.size)
 
+        self._engine = engine
+
+    def bind_engine(self, engine):
+        """The device-resident SVI loop all-reduces inside the engine (on the handle's stream):
+        the communicator must be the one this engine's handle was initialised with."""
+        if engine is not self._engine:
+            raise RuntimeError("RcclComm is bound to another engine handle")
+
     def allreduce_stats(self, engine, K, D):
         engine.allreduce_packed()
         return engine.read_packed()

@@ -1,0 +1,253 @@
+// kernels_svi.h -- the global side of one SVI iteration on the device (hmmsgd_metaobs.py:347-445):
+// stationary initial vector + psi-expectations before the E-step, the natural-gradient global
+// step and the global part of the ELBO after it.  With these the variational state (var_tran,
+// the K NIW factors) lives in HBM for the whole of infer(): per iteration only the window starts
+// and the learning rate go to the device and nothing has to come back.
+// Part of libsvihmm_hip.so; included by svihmm_hip.hip (single translation unit).
+#pragma once
+
+#define SVI_EPS 1e-9     // the reference's eps (hmmbase.py:30) inside digamma / gammaln
+
+// ------------------------------------------------------------------------------------
+//  G1: globals of an iteration, one workgroup of 1024 threads.
+//    (a) psi-expectations of the transition factor (hmmsgd_metaobs.py:502-504):
+//          ltran[i][j] = psi(var_tran[i][j] + eps) - psi(sum_j var_tran[i][j] + eps),
+//        plus exp(ltran) and its transpose for the scaled sweeps (what k_exp_transpose makes
+//        from host-supplied globals);
+//    (b) stationary initial vector (hmmsgd_metaobs.py:413-418): the reference takes |v| of the
+//        top eigenvector of the row-normalised var_tran^T from np.linalg.eig -- for a positive
+//        stochastic matrix the Perron vector, unit L2 norm.  Here: Grassmann-Taksar-Heyman
+//        elimination (state reduction without subtractions: every intermediate is a sum of
+//        products of positive numbers, component-wise relative accuracy ~K eps, no pivoting),
+//        K-1 dependent steps of a rank-one update on the shrinking leading block;
+//    (c) mod_init[k] = psi(var_init[k] + eps) - psi(sum var_init + eps)  (quirk Q5: the unit-L2
+//        vector goes into psi as if it were Dirichlet parameters).
+//  `work` = 2 K^2 doubles (LDS when they fit, else global scratch).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_svi_globals(
+    const double* __restrict__ var_tran, int K, double* __restrict__ work_g, int use_lds,
+    double* __restrict__ ltran, double* __restrict__ Aexp, double* __restrict__ AexpT,
+    double* __restrict__ var_init, double* __restrict__ mod_init) {
+  extern __shared__ double svi_lds[];
+  __shared__ double rs[1024];      // row sums, later the stationary vector (K <= 1024)
+  __shared__ double sc[4];
+  double* P = use_lds ? svi_lds : work_g;          // [K][K] working copy, then its reduced form
+  double* Q = P + (size_t)K * K;                   // [K][K] scaled columns (back-substitution)
+  const int tid = threadIdx.x, NT = 1024;
+  // row sums (one wave per row, round-robin)
+  {
+    const int lane = tid & 63, w = tid >> 6;
+    for (int i = w; i < K; i += 16) {
+      double s = 0.0;
+      for (int j = lane; j < K; j += 64) s += var_tran[(size_t)i * K + j];
+      s = wave_sum(s);
+      if (lane == 0) rs[i] = s;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < K * K; e += NT) {
+    const int i = e / K, j = e - i * K;
+    const double v = var_tran[e];
+    const double l = digamma_d(v + SVI_EPS) - digamma_d(rs[i] + SVI_EPS);
+    const double x = exp(l);
+    ltran[e] = l;
+    Aexp[e] = x;
+    AexpT[(size_t)j * K + i] = x;
+    P[e] = v / rs[i];                    // row-stochastic mean transition matrix
+  }
+  __syncthreads();
+  // GTH: eliminate states K-1 .. 1
+  for (int n = K - 1; n >= 1; --n) {
+    if (tid < 64) {
+      double s = 0.0;
+      for (int j = tid; j < n; j += 64) s += P[(size_t)n * K + j];
+      s = wave_sum(s);
+      if (tid == 0) sc[0] = 1.0 / s;
+    }
+    __syncthreads();
+    const double inv = sc[0];
+    for (int e = tid; e < n * n; e += NT) {
+      const int i = e / n, j = e - i * n;
+      const double c = P[(size_t)i * K + n] * inv;
+      P[(size_t)i * K + j] = fma(c, P[(size_t)n * K + j], P[(size_t)i * K + j]);
+      if (j == 0) Q[(size_t)i * K + n] = c;
+    }
+    __syncthreads();
+  }
+  // back-substitution: pi_0 = 1, pi_j = sum_{i<j} pi_i Q[i][j]   (one wave, lane-strided)
+  if (tid < 64) {
+    const int lane = tid;
+    if (lane == 0) rs[0] = 1.0;
+    for (int j = 1; j < K; ++j) {
+      double s = 0.0;
+      for (int i = lane; i < j; i += 64) s = fma(rs[i], Q[(size_t)i * K + j], s);
+      s = wave_sum(s);
+      if (lane == 0) rs[j] = s;
+      __builtin_amdgcn_wave_barrier();
+      __threadfence_block();
+    }
+    double n2 = 0.0, n1 = 0.0;
+    for (int i = lane; i < K; i += 64) n2 = fma(rs[i], rs[i], n2);
+    n2 = wave_sum(n2);
+    const double rn = 1.0 / sqrt(n2);
+    for (int i = lane; i < K; i += 64) { const double v = rs[i] * rn; rs[i] = v; n1 += v; }
+    n1 = wave_sum(n1);
+    if (lane == 0) sc[1] = n1;
+  }
+  __syncthreads();
+  const double dsum = digamma_d(sc[1] + SVI_EPS);
+  for (int k = tid; k < K; k += NT) {
+    const double v = rs[k];
+    var_init[k] = v;
+    mod_init[k] = digamma_d(v + SVI_EPS) - dsum;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+//  G2: natural-gradient global step (hmmsgd_metaobs.py:1010-1069, util.py:28-60) from the packed
+//  statistics [A_raw | xbar | neff | S | lb] of the minibatch (after the all-reduce, if any):
+//    transitions: var_tran <- (1-rho)(var_tran - 1) + rho * bA * (A_raw + nwin (prior_tran - 1)) + 1
+//                 (quirk Q2: prior_tran - 1 sits in every window's A_i)
+//    emissions  : eta = [kappa mu, kappa, sigma + kappa mu mu', nu + 2 + D];
+//                 eta <- (1-rho) eta + rho (eta_0 + bE * [xbar, neff, S, neff]);  back to moments.
+//  grid: K workgroups (one NIW factor each) + ceil(K^2 / 256) for the transition factor.
+//  niw = [mu K*D | sigma K*D*D | kappa K | nu K] (the E-step's parameter block, updated in place);
+//  prior = [mu0 K*D | sigma0 K*D*D | kappa0 K | nu0 K].
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_svi_global_step(
+    const double* __restrict__ packed, const double* __restrict__ prior_tran, double* __restrict__ var_tran,
+    double* __restrict__ niw, const double* __restrict__ prior, int K, int D, double rho, double bA,
+    double bE, double nwin) {
+  const size_t nmu = (size_t)K * D, nsg = (size_t)K * D * D;
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= K) {
+    const int e = ((int)blockIdx.x - K) * 256 + tid;
+    if (e < K * K) {
+      const double a_inter = packed[e] + nwin * (prior_tran[e] - 1.0);
+      const double nat_old = var_tran[e] - 1.0;
+      var_tran[e] = ((1.0 - rho) * nat_old + rho * (bA * a_inter)) + 1.0;
+    }
+    return;
+  }
+  const int k = blockIdx.x;
+  extern __shared__ double gs_lds[];       // mu_old [D] | mu_new [D] | mu_0 [D]
+  double* mo = gs_lds;
+  double* mn = mo + D;
+  double* m0 = mn + D;
+  double* mu = niw + (size_t)k * D;
+  double* sg = niw + nmu + (size_t)k * D * D;
+  double* kap = niw + nmu + nsg;
+  double* nu = kap + K;
+  const double* mu0 = prior + (size_t)k * D;
+  const double* sg0 = prior + nmu + (size_t)k * D * D;
+  const double ka0 = prior[nmu + nsg + k], nu0 = prior[nmu + nsg + K + k];
+  const double* xbar = packed + (size_t)K * K + (size_t)k * D;
+  const double neff = packed[(size_t)K * K + nmu + k];
+  const double* S = packed + (size_t)K * K + nmu + K + (size_t)k * D * D;
+  const double ka = kap[k], nuo = nu[k];
+  const double e2 = (1.0 - rho) * ka + rho * (ka0 + bE * neff);                        // kappa'
+  const double e4 = (1.0 - rho) * (nuo + 2 + D) + rho * ((nu0 + 2 + D) + bE * neff);
+  for (int a = tid; a < D; a += 256) {
+    const double m = mu[a], p = mu0[a];
+    mo[a] = m; m0[a] = p;
+    mn[a] = ((1.0 - rho) * (ka * m) + rho * (ka0 * p + bE * xbar[a])) / e2;            // mu' = e1 / e2
+  }
+  __syncthreads();
+  for (int e = tid; e < D * D; e += 256) {
+    const int a = e / D, b = e - a * D;
+    const double e3o = sg[e] + (mo[a] * mo[b]) * ka;
+    const double e3p = sg0[e] + (m0[a] * m0[b]) * ka0;
+    const double e3 = (1.0 - rho) * e3o + rho * (e3p + bE * S[e]);
+    sg[e] = e3 - (mn[a] * mn[b]) * e2;                                                 // sigma'
+  }
+  for (int a = tid; a < D; a += 256) mu[a] = mn[a];
+  if (tid == 0) { kap[k] = e2; nu[k] = e4 - 2 - D; }
+}
+
+// ------------------------------------------------------------------------------------
+//  G3: the NIW factors' term of global_lower_bound (hmmsgd_metaobs.py:294 sum_k get_vlb();
+//  formulas of distributions.niw_vlb_batch: Bishop 10.74 + 10.77) for the CURRENT factors, from
+//  what k_niw_to_theta_wave just produced: theta holds W = (nu/2) sigma_mf^-1 in feature form,
+//  logdet = log det sigma_mf.  One wave per state -> vlb[k].
+//  prior_logpart[k] = invwishart_log_partitionfunction(sigma_0[k], nu_0[k]) (host, constant);
+//  zsign: +1 pybasicbayes' sign of that term, -1 Bishop's (see distributions.Gaussian.get_vlb).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_svi_vlb(
+    const double* __restrict__ theta, const int* __restrict__ fab, int F, int D, int Kp,
+    const double* __restrict__ niw, const double* __restrict__ logdet, const double* __restrict__ prior,
+    const double* __restrict__ prior_logpart, double zsign, int K, double* __restrict__ vlb) {
+  const int k = blockIdx.x, lane = threadIdx.x;
+  const size_t nmu = (size_t)K * D, nsg = (size_t)K * D * D;
+  const double* m = niw + (size_t)k * D;
+  const double ka = niw[nmu + nsg + k], nu = niw[nmu + nsg + K + k];
+  const double* m0 = prior + (size_t)k * D;
+  const double* s0 = prior + nmu + (size_t)k * D * D;
+  const double ka0 = prior[nmu + nsg + k], nu0 = prior[nmu + nsg + K + k];
+  double tr = 0.0, qd = 0.0;
+  for (int f = lane; f < F; f += 64) {
+    const int ab = fab[f], a = ab & 0xffff, b = ab >> 16;
+    if (b >= D) continue;                    // linear and constant features
+    const double t = theta[(size_t)f * Kp + k];
+    tr = fma(t, s0[a * D + b], tr);
+    qd = fma(t, (m[a] - m0[a]) * (m[b] - m0[b]), qd);
+  }
+  double dg = 0.0, lg = 0.0;
+  for (int i = lane; i < D; i += 64) {
+    dg += digamma_d(0.5 * (nu - i));
+    lg += lgamma(0.5 * (nu - i));
+  }
+  tr = wave_sum(tr); qd = wave_sum(qd); dg = wave_sum(dg); lg = wave_sum(lg);
+  if (lane == 0) {
+    const double c = -2.0 / nu;
+    const double tr_s0 = c * tr, quad = c * qd, half_ld = 0.5 * logdet[k];
+    const double LN2 = 0.69314718055994530942, LNPI = 1.1447298858494001741, LN2PI = 1.8378770664093454836;
+    const double l_mf = dg + D * LN2 - 2.0 * half_ld;
+    const double logpart_mf = -(nu * half_ld - (nu * D / 2.0 * LN2 + D * (D - 1) / 4.0 * LNPI + lg));
+    const double iw_entropy = logpart_mf - (nu - D - 1) / 2.0 * l_mf + nu * D / 2.0;
+    const double q_entropy = -0.5 * (l_mf + D * ((log(ka) - LN2PI) - 1.0)) + iw_entropy;
+    const double p_avgengy = 0.5 * (D * (log(ka0) - LN2PI) + l_mf - D * ka0 / ka - ka0 * nu * quad)
+                             + zsign * prior_logpart[k] + (nu0 - D - 1) / 2.0 * l_mf - 0.5 * nu * tr_s0;
+    vlb[k] = p_avgengy + q_entropy;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+//  G4: elbo_vec[it] = lb + global_lower_bound()  (hmmsgd_metaobs.py:436-445, 273-296):
+//  lb = packed[last] (sum of the windows' local bounds), Dirichlet energy + entropy of the
+//  transition rows (hmmbase.dirichlet_elbo) for the UPDATED var_tran, sum_k vlb[k] in state order.
+//  One workgroup; fixed reduction order.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_svi_elbo(
+    const double* __restrict__ prior_tran, const double* __restrict__ var_tran, int K,
+    const double* __restrict__ vlb, const double* __restrict__ lb, double* __restrict__ elbo_out) {
+  __shared__ double rowv[1024], rowp[1024], red[1024];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int i = w; i < K; i += 16) {
+    double sv = 0.0, sp = 0.0;
+    for (int j = lane; j < K; j += 64) { sv += var_tran[(size_t)i * K + j]; sp += prior_tran[(size_t)i * K + j]; }
+    sv = wave_sum(sv); sp = wave_sum(sp);
+    if (lane == 0) { rowv[i] = sv; rowp[i] = sp; }
+  }
+  __syncthreads();
+  // per row i: energy = lgamma(sum p + eps) - sum lgamma(p + eps) + sum (p - 1) elog
+  //            entropy = -(lgamma(sum q + eps) - sum lgamma(q + eps) + sum (q - 1) elog)
+  double acc = 0.0;
+  for (int e = tid; e < K * K; e += 1024) {
+    const int i = e / K;
+    const double q = var_tran[e], p = prior_tran[e];
+    const double elog = digamma_d(q + SVI_EPS) - digamma_d(rowv[i] + SVI_EPS);
+    acc += (-lgamma(p + SVI_EPS) + (p - 1.0) * elog) - (-lgamma(q + SVI_EPS) + (q - 1.0) * elog);
+  }
+  for (int i = tid; i < K; i += 1024) acc += lgamma(rowp[i] + SVI_EPS) - lgamma(rowv[i] + SVI_EPS);
+  red[tid] = acc;
+  __syncthreads();
+  for (int o = 512; o >= 1; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    double v = 0.0;
+    for (int k = 0; k < K; ++k) v += vlb[k];
+    *elbo_out = lb[0] + red[0] + v;
+  }
+}

@@ -63,6 +63,7 @@ static int fail(const std::string& m) { g_err = m; return 1; }
 #include "kernels_recursion.h"
 #include "kernels_stats.h"
 #include "kernels_misc.h"
+#include "kernels_svi.h"
 
 // ------------------------------------------------------------------------------------
 //  host side
@@ -160,6 +161,14 @@ struct svihmm_ctx {
   std::vector<hipEvent_t> pool;
   double ms[SVIHMM_NKERN] = {0};
   int64_t cnt[SVIHMM_NKERN] = {0};
+  // device-resident SVI loop (svihmm_svi_*): var_tran | prior_tran | var_init | vlb[K] | logdet[K] |
+  // prior_logpart[K]; prior block [mu0 | sigma0 | kappa0 | nu0]; GTH scratch; elbo / event ring
+  Buf svi_state, svi_prior, svi_work;
+  int svi_K = 0, svi_D = 0, svi_maxit = 0;
+  double svi_zsign = 1.0;
+  double* svi_elbo = nullptr; int svi_elbo_cap = 0;      // pinned + mapped: elbo_vec
+  std::vector<hipEvent_t> svi_ev;                        // iteration boundaries (iter_time)
+  bool svi_active = false;
   // comm
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
@@ -239,9 +248,12 @@ int svihmm_destroy(svihmm_ctx* h) {
   Buf* bufs[] = {&h->obs, &h->mask, &h->mod_init, &h->ltran, &h->Aexp, &h->AexpT, &h->theta, &h->niw,
                  &h->fab, &h->starts, &h->ll, &h->la, &h->lb, &h->q, &h->lse_part,
                  &h->local_lb, &h->logz, &h->part, &h->packed, &h->scratch, &h->kexp, &h->hx, &h->gx,
-                 &h->zfac, &h->llE, &h->m_ll, &h->m_la, &h->m_lb, &h->chain, &h->chain2, &h->cat_table, &h->partc, &h->theta_orb, &h->prior, &h->vlb_aux, &h->gen_z};
+                 &h->zfac, &h->llE, &h->m_ll, &h->m_la, &h->m_lb, &h->chain, &h->chain2, &h->cat_table, &h->partc, &h->theta_orb, &h->prior, &h->vlb_aux, &h->gen_z,
+                 &h->svi_state, &h->svi_prior, &h->svi_work};
   for (Buf* b : bufs) release(*b);
   if (h->vlb_host) { hipHostFree(h->vlb_host); h->vlb_host = nullptr; }
+  if (h->svi_elbo) { hipHostFree(h->svi_elbo); h->svi_elbo = nullptr; }
+  for (auto e : h->svi_ev) hipEventDestroy(e);
   for (int i = 0; i < 2; ++i) {
     if (h->ev_em[i]) hipEventDestroy(h->ev_em[i]);
     if (h->ev_sw[i]) hipEventDestroy(h->ev_sw[i]);
@@ -413,19 +425,13 @@ static int upload_feature_table(svihmm_ctx* h, int D, int K) {
   return 0;
 }
 
-int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* mu,
-                            const double* sigma, const double* kappa, const double* nu) {
-  if (!h || K <= 0 || D <= 0 || !mu || !sigma || !kappa || !nu)
-    return fail("svihmm_set_emission_niw: bad arguments");
-  if ((size_t)(3 * D * (D + 1) + D) * 8 > 150 * 1024)
-    return fail("svihmm_set_emission_niw: D too large");
-  CK(set_device(h));
-  h->lin_stale = true;
+// NIW parameter block in h->niw ([mu | sigma | kappa | nu], on the device) -> theta (both layouts);
+// logdet_out (device, [K]) optionally receives log det sigma_mf.  Asynchronous: a factor that is
+// not positive definite is reported by the next synchronising call.
+static int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out) {
   CK(upload_feature_table(h, D, K));
   const int Fp = h->Fp, Kp = h->Kp;
   const size_t nmu = (size_t)K * D, nsg = (size_t)K * D * D;
-  const size_t nin = nmu + nsg + 2 * (size_t)K;
-  CK(ensure(h->niw, nin * sizeof(double) + 64));
   CK(ensure(h->theta, (size_t)Fp * Kp * sizeof(double)));
   double* dmu = (double*)h->niw.p;
   double* dsg = dmu + nmu;
@@ -439,17 +445,6 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
   }
   int* dstatus = nullptr;
   HIPCK(hipHostGetDevicePointer((void**)&dstatus, h->pin_status, 0));
-  // one pinned staging slot, one H2D copy, no stream synchronisation
-  void* pin = nullptr;
-  int slot = 0;
-  CK(pinned(h, (nin + 1) * sizeof(double), &pin, &slot));
-  double* hp = (double*)pin;
-  std::memcpy(hp, mu, nmu * sizeof(double));
-  std::memcpy(hp + nmu, sigma, nsg * sizeof(double));
-  std::memcpy(hp + nmu + nsg, kappa, K * sizeof(double));
-  std::memcpy(hp + nmu + nsg + K, nu, K * sizeof(double));
-  CK(pull_small(h, dmu, hp, nin * sizeof(double)));
-  CK(pin_release(h, slot));
   // theta's padded rows / columns are zeroed once per (buffer, shape); k_niw_to_theta
   // rewrites every live entry on each call
   if (h->theta_zero_p != h->theta.p || h->theta_zero_n != (size_t)Fp * Kp) {
@@ -472,7 +467,7 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
     ProfScope ps(h, KS_MISC);
 #define NIWW(DM) hipLaunchKernelGGL(k_niw_to_theta_wave<DM>, dim3(K), dim3(64), 0, h->stream, (const double*)dmu, \
                                     (const double*)dsg, (const double*)dka, (const double*)dnu, K, D, Kp,   \
-                                    (double*)h->theta.p, dstatus, orbp, (double*)nullptr)
+                                    (double*)h->theta.p, dstatus, orbp, logdet_out)
     if (D <= 8) NIWW(8);
     else if (D <= 16) NIWW(16);
     else if (D <= 32) NIWW(32);
@@ -483,7 +478,7 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
         hipFuncSetAttribute((const void*)k_niw_to_theta_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(k_niw_to_theta_generic, dim3(K), dim3(256), lds, h->stream, (const double*)dmu,
                          (const double*)dsg, (const double*)dka, (const double*)dnu, K, D, Kp,
-                         (double*)h->theta.p, dstatus, orbp, (double*)nullptr);
+                         (double*)h->theta.p, dstatus, orbp, logdet_out);
     }
 #undef NIWW
     HIPCK(hipGetLastError());
@@ -492,6 +487,33 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
   h->status_pending = true;
   h->eK = K; h->eD = D; h->have_emission = true; h->emis_cat = false;
   h->orb_valid = orbp != nullptr;
+  return 0;
+}
+
+int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* mu,
+                            const double* sigma, const double* kappa, const double* nu) {
+  if (!h || K <= 0 || D <= 0 || !mu || !sigma || !kappa || !nu)
+    return fail("svihmm_set_emission_niw: bad arguments");
+  if ((size_t)(3 * D * (D + 1) + D) * 8 > 150 * 1024)
+    return fail("svihmm_set_emission_niw: D too large");
+  CK(set_device(h));
+  h->lin_stale = true;
+  const size_t nmu = (size_t)K * D, nsg = (size_t)K * D * D;
+  const size_t nin = nmu + nsg + 2 * (size_t)K;
+  CK(ensure(h->niw, nin * sizeof(double) + 64));
+  double* dmu = (double*)h->niw.p;
+  // one pinned staging slot, pulled by a kernel, no stream synchronisation
+  void* pin = nullptr;
+  int slot = 0;
+  CK(pinned(h, (nin + 1) * sizeof(double), &pin, &slot));
+  double* hp = (double*)pin;
+  std::memcpy(hp, mu, nmu * sizeof(double));
+  std::memcpy(hp + nmu, sigma, nsg * sizeof(double));
+  std::memcpy(hp + nmu + nsg, kappa, K * sizeof(double));
+  std::memcpy(hp + nmu + nsg + K, nu, K * sizeof(double));
+  CK(pull_small(h, dmu, hp, nin * sizeof(double)));
+  CK(pin_release(h, slot));
+  CK(launch_niw_to_theta(h, K, D, nullptr));
   return 0;
 }
 
@@ -1667,6 +1689,26 @@ int svihmm_pred_logprob(svihmm_ctx* h, const int64_t* starts, int32_t B, int32_t
   return 0;
 }
 
+// emission -> sweeps -> statistics of a window batch into h->packed (B >= 1), asynchronous
+static int estep_core(svihmm_ctx* h, const int64_t* starts, int B, int Lm, int inner_off, int inner_len,
+                      uint32_t flags) {
+  if (inner_off < 0 || inner_len <= 0 || inner_off + inner_len > Lm)
+    return fail("svihmm_estep_minibatch_ex: inner segment out of range");
+  const int var = pick_fb(h, B, Lm, false);
+  if (use_pipeline(h, B, Lm, var, flags)) {
+    CK(estep_pipelined(h, starts, B, Lm, inner_off, inner_len, flags));
+  } else {
+    CK(prepare_ll(h, starts, B, Lm, flags, true, var == 3));
+    CK(run_fb(h, B, Lm, var, (flags & SVIHMM_KEEP_LBETA) != 0, true));
+    CK(launch_stats(h, B, Lm, inner_off, inner_len, flags));
+    CK(flush_lb(h, h->stream));   // no-op when k_finalize carried the ELBO total
+  }
+  h->have_packed = true;
+  h->mirror_valid = false;
+  h->lastB = B; h->lastLm = Lm;
+  return 0;
+}
+
 int svihmm_estep_minibatch(svihmm_ctx* h, const int64_t* starts, int32_t B, int32_t Lm,
                            uint32_t flags, double* out_packed) {
   return svihmm_estep_minibatch_ex(h, starts, B, Lm, 0, Lm, flags, out_packed);
@@ -1690,24 +1732,202 @@ int svihmm_estep_minibatch_ex(svihmm_ctx* h, const int64_t* starts, int32_t B, i
     }
     return 0;
   }
-  if (inner_off < 0 || inner_len <= 0 || inner_off + inner_len > Lm)
-    return fail("svihmm_estep_minibatch_ex: inner segment out of range");
-  const int var = pick_fb(h, B, Lm, false);
-  if (use_pipeline(h, B, Lm, var, flags)) {
-    CK(estep_pipelined(h, starts, B, Lm, inner_off, inner_len, flags));
-  } else {
-    CK(prepare_ll(h, starts, B, Lm, flags, true, var == 3));
-    CK(run_fb(h, B, Lm, var, (flags & SVIHMM_KEEP_LBETA) != 0, true));
-    CK(launch_stats(h, B, Lm, inner_off, inner_len, flags));
-    CK(flush_lb(h, h->stream));   // no-op when k_finalize carried the ELBO total
-  }
-  h->have_packed = true;
-  h->lastB = B; h->lastLm = Lm;
+  CK(estep_core(h, starts, B, Lm, inner_off, inner_len, flags));
   CK(launch_mirror(h));
   if (out_packed) {
     CK(read_packed_host(h, out_packed));
     CK(check_emission_status(h));
   }
+  return 0;
+}
+
+// ---- device-resident SVI loop (hmmsgd_metaobs.py:347-445) ------------------------------------
+// layout of h->svi_state: var_tran K*K | prior_tran K*K | var_init K | vlb K | logdet K | prior_logpart K
+static double* svi_ptr(svihmm_ctx* h, int which) {
+  const size_t K = h->svi_K, kk = K * K;
+  double* b = (double*)h->svi_state.p;
+  switch (which) {
+    case 0: return b;                    // var_tran
+    case 1: return b + kk;               // prior_tran
+    case 2: return b + 2 * kk;           // var_init
+    case 3: return b + 2 * kk + K;       // vlb
+    case 4: return b + 2 * kk + 2 * K;   // logdet
+    default: return b + 2 * kk + 3 * K;  // prior_logpart
+  }
+}
+static int svi_globals(svihmm_ctx* h) {
+  const int K = h->svi_K;
+  const size_t kk = (size_t)K * K * sizeof(double);
+  CK(ensure(h->mod_init, K * sizeof(double)));
+  CK(ensure(h->ltran, kk));
+  const int reach = K <= 64 ? (K + 15) / 16 * 16 : K <= 128 ? 128 : K <= 256 ? 256 : K;
+  const size_t slack = (size_t)(reach - K + 16) * K * sizeof(double);
+  CK(ensure(h->Aexp, kk + slack));
+  CK(ensure(h->AexpT, kk + slack));
+  if (h->slack_a != h->Aexp.p || h->slack_t != h->AexpT.p || h->slack_k != K) {
+    HIPCK(hipMemsetAsync((char*)h->Aexp.p + kk, 0, slack, h->stream));
+    HIPCK(hipMemsetAsync((char*)h->AexpT.p + kk, 0, slack, h->stream));
+    h->slack_a = h->Aexp.p; h->slack_t = h->AexpT.p; h->slack_k = K;
+  }
+  const size_t work = 2 * kk;
+  const int use_lds = work + 9 * 1024 <= 150 * 1024;
+  if (!use_lds) CK(ensure(h->svi_work, work));
+  if (use_lds && work > 48 * 1024)
+    hipFuncSetAttribute((const void*)k_svi_globals, hipFuncAttributeMaxDynamicSharedMemorySize, (int)work);
+  ProfScope ps(h, KS_MISC);
+  hipLaunchKernelGGL(k_svi_globals, dim3(1), dim3(1024), use_lds ? work : 0, h->stream,
+                     (const double*)svi_ptr(h, 0), K, (double*)h->svi_work.p, use_lds, (double*)h->ltran.p,
+                     (double*)h->Aexp.p, (double*)h->AexpT.p, svi_ptr(h, 2), (double*)h->mod_init.p);
+  HIPCK(hipGetLastError());
+  h->K = K; h->have_globals = true; h->lin_stale = true;
+  return 0;
+}
+// theta + log det for the factors now in h->niw, then their ELBO term into vlb[]
+static int svi_refresh_emission(svihmm_ctx* h) {
+  const int K = h->svi_K, D = h->svi_D;
+  CK(launch_niw_to_theta(h, K, D, svi_ptr(h, 4)));
+  h->lin_stale = true;
+  ProfScope ps(h, KS_MISC);
+  hipLaunchKernelGGL(k_svi_vlb, dim3(K), dim3(64), 0, h->stream, (const double*)h->theta.p,
+                     (const int*)h->fab.p, h->F, D, h->Kp, (const double*)h->niw.p,
+                     (const double*)svi_ptr(h, 4), (const double*)h->svi_prior.p,
+                     (const double*)svi_ptr(h, 5), h->svi_zsign, K, svi_ptr(h, 3));
+  HIPCK(hipGetLastError());
+  return 0;
+}
+
+int svihmm_svi_begin(svihmm_ctx* h, int32_t K, int32_t D, const double* prior_tran, const double* var_tran,
+                     const double* mu0, const double* sigma0, const double* kappa0, const double* nu0,
+                     const double* prior_logpart, const double* mu, const double* sigma,
+                     const double* kappa, const double* nu, int32_t maxit, double zsign) {
+  if (!h || K <= 0 || D <= 0 || !prior_tran || !var_tran || !mu0 || !sigma0 || !kappa0 || !nu0 ||
+      !prior_logpart || !mu || !sigma || !kappa || !nu || maxit <= 0)
+    return fail("svihmm_svi_begin: bad arguments");
+  if (K > 1024) return fail("svihmm_svi_begin: K > 1024 unsupported");
+  if (h->D != D) return fail("svihmm_svi_begin: D does not match the resident observations");
+  CK(set_device(h));
+  const size_t kk = (size_t)K * K, nmu = (size_t)K * D, nsg = (size_t)K * D * D;
+  const size_t nin = nmu + nsg + 2 * (size_t)K;
+  h->svi_K = K; h->svi_D = D; h->svi_maxit = maxit; h->svi_zsign = zsign;
+  CK(ensure(h->svi_state, (2 * kk + 4 * (size_t)K + 8) * sizeof(double)));
+  CK(ensure(h->svi_prior, (nin + 8) * sizeof(double)));
+  CK(ensure(h->niw, nin * sizeof(double) + 64));
+  // one staging slot: [var_tran | prior_tran | prior_logpart | prior block | niw block]
+  const size_t tot = 2 * kk + K + 2 * nin;
+  void* pin = nullptr;
+  int slot = 0;
+  CK(pinned(h, tot * sizeof(double), &pin, &slot));
+  double* hp = (double*)pin;
+  std::memcpy(hp, var_tran, kk * 8); std::memcpy(hp + kk, prior_tran, kk * 8);
+  std::memcpy(hp + 2 * kk, prior_logpart, K * 8);
+  double* pp = hp + 2 * kk + K;
+  std::memcpy(pp, mu0, nmu * 8); std::memcpy(pp + nmu, sigma0, nsg * 8);
+  std::memcpy(pp + nmu + nsg, kappa0, K * 8); std::memcpy(pp + nmu + nsg + K, nu0, K * 8);
+  double* np_ = pp + nin;
+  std::memcpy(np_, mu, nmu * 8); std::memcpy(np_ + nmu, sigma, nsg * 8);
+  std::memcpy(np_ + nmu + nsg, kappa, K * 8); std::memcpy(np_ + nmu + nsg + K, nu, K * 8);
+  CK(pull_small(h, svi_ptr(h, 0), hp, 2 * kk * 8));
+  CK(pull_small(h, svi_ptr(h, 5), hp + 2 * kk, K * 8));
+  CK(pull_small(h, h->svi_prior.p, pp, nin * 8));
+  CK(pull_small(h, h->niw.p, np_, nin * 8));
+  CK(pin_release(h, slot));
+  if (h->svi_elbo_cap < maxit) {
+    if (h->svi_elbo) hipHostFree(h->svi_elbo);
+    h->svi_elbo = nullptr; h->svi_elbo_cap = 0;
+    HIPCK(hipHostMalloc((void**)&h->svi_elbo, (size_t)maxit * sizeof(double) + 64, hipHostMallocMapped));
+    h->svi_elbo_cap = maxit;
+  }
+  for (int i = 0; i < maxit; ++i) h->svi_elbo[i] = NAN;
+  while ((int)h->svi_ev.size() < maxit + 1) {
+    hipEvent_t e;
+    HIPCK(hipEventCreate(&e));
+    h->svi_ev.push_back(e);
+  }
+  CK(svi_refresh_emission(h));       // theta of the initial factors (their vlb is not used)
+  h->svi_active = true;
+  return 0;
+}
+
+int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32_t B, int32_t nwin_total,
+                         int32_t Lm, int32_t inner_off, int32_t inner_len, uint32_t flags, double rho,
+                         double bfactA, double bfactE) {
+  if (!h || !h->svi_active) return fail("svihmm_svi_iteration: call svihmm_svi_begin first");
+  if (it < 0 || it >= h->svi_maxit) return fail("svihmm_svi_iteration: iteration index out of range");
+  if (B < 0 || (B > 0 && !starts) || nwin_total < B) return fail("svihmm_svi_iteration: bad window batch");
+  if (flags & SVIHMM_USE_HOST_LLIKS) return fail("svihmm_svi_iteration: NIW emission only");
+  CK(set_device(h));
+  const int K = h->svi_K, D = h->svi_D;
+  HIPCK(hipEventRecord(h->svi_ev[it], h->stream));
+  CK(svi_globals(h));
+  const bool keep = (flags & SVIHMM_SVI_KEEP_WINDOW) != 0;
+  flags &= ~(uint32_t)SVIHMM_SVI_KEEP_WINDOW;
+  if (B > 0) {
+    CK(estep_core(h, starts, B, Lm, inner_off, inner_len, flags));
+    // the last window's log-domain rows are rebuilt on demand from the CURRENT parameters:
+    // do it now, before the global step replaces them
+    if (keep && h->lin_mode) CK(materialise(h, B - 1, 1));
+  } else {   // empty shard of a multi-GPU minibatch: all-zero statistics
+    const size_t nb = (size_t)packed_len(h) * sizeof(double);
+    CK(ensure(h->packed, nb));
+    HIPCK(hipMemsetAsync(h->packed.p, 0, nb, h->stream));
+    h->have_packed = true; h->mirror_valid = false;
+  }
+  if (h->comm) {
+    ProfScope ps(h, KS_ALLREDUCE);
+    NCCLCK(ncclAllReduce(h->packed.p, h->packed.p, (size_t)packed_len(h), ncclDouble, ncclSum, h->comm, h->stream));
+  }
+  {
+    ProfScope ps(h, KS_MISC);
+    const unsigned nblk = (unsigned)K + (unsigned)((K * K + 255) / 256);
+    hipLaunchKernelGGL(k_svi_global_step, dim3(nblk), dim3(256), (size_t)3 * D * sizeof(double), h->stream,
+                       (const double*)h->packed.p, (const double*)svi_ptr(h, 1), svi_ptr(h, 0),
+                       (double*)h->niw.p, (const double*)h->svi_prior.p, K, D, rho, bfactA, bfactE,
+                       (double)nwin_total);
+    HIPCK(hipGetLastError());
+  }
+  CK(svi_refresh_emission(h));
+  {
+    ProfScope ps(h, KS_MISC);
+    double* delbo = nullptr;
+    HIPCK(hipHostGetDevicePointer((void**)&delbo, h->svi_elbo, 0));
+    const double* lb = (const double*)h->packed.p + (packed_len(h) - 1);
+    hipLaunchKernelGGL(k_svi_elbo, dim3(1), dim3(1024), 0, h->stream, (const double*)svi_ptr(h, 1),
+                       (const double*)svi_ptr(h, 0), K, (const double*)svi_ptr(h, 3), lb, delbo + it);
+    HIPCK(hipGetLastError());
+  }
+  HIPCK(hipEventRecord(h->svi_ev[it + 1], h->stream));
+  return 0;
+}
+
+int svihmm_svi_read_elbo(svihmm_ctx* h, int32_t n, double* out_elbo, double* out_ms) {
+  if (!h || !h->svi_active || n < 0 || n > h->svi_maxit) return fail("svihmm_svi_read_elbo: bad arguments");
+  CK(set_device(h));
+  HIPCK(hipStreamSynchronize(h->stream));
+  CK(check_emission_status(h));
+  for (int i = 0; i < n; ++i) {
+    if (out_elbo) out_elbo[i] = h->svi_elbo[i];
+    if (out_ms) {
+      float ms = 0.f;
+      out_ms[i] = hipEventElapsedTime(&ms, h->svi_ev[i], h->svi_ev[i + 1]) == hipSuccess ? (double)ms : NAN;
+    }
+  }
+  return 0;
+}
+
+int svihmm_svi_read_state(svihmm_ctx* h, double* var_tran, double* var_init, double* mu, double* sigma,
+                          double* kappa, double* nu) {
+  if (!h || !h->svi_active) return fail("svihmm_svi_read_state: no SVI state on the device");
+  CK(set_device(h));
+  const size_t K = h->svi_K, D = h->svi_D, nmu = K * D, nsg = K * D * D;
+  const double* nw = (const double*)h->niw.p;
+  if (var_tran) CK(d2h(h, var_tran, svi_ptr(h, 0), K * K * 8));
+  if (var_init) CK(d2h(h, var_init, svi_ptr(h, 2), K * 8));
+  if (mu) CK(d2h(h, mu, nw, nmu * 8));
+  if (sigma) CK(d2h(h, sigma, nw + nmu, nsg * 8));
+  if (kappa) CK(d2h(h, kappa, nw + nmu + nsg, K * 8));
+  if (nu) CK(d2h(h, nu, nw + nmu + nsg + K, K * 8));
+  HIPCK(hipStreamSynchronize(h->stream));
+  CK(check_emission_status(h));
   return 0;
 }
 

@@ -28,7 +28,7 @@ import scipy.linalg as sla
 from scipy.special import digamma, gammaln
 
 __all__ = ["Gaussian", "Categorical", "sample_niw", "sample_invwishart",
-           "niw_quadratic_form", "niw_vlb_batch"]
+           "niw_quadratic_form", "niw_vlb_batch", "niw_prior_logpart", "vlb_logz_sign"]
 
 
 # --------------------------------------------------------------------------- #
@@ -187,13 +187,17 @@ class Gaussian(object):
         return niw_quadratic_form(self.mu_mf, self.sigma_mf, self.kappa_mf,
                                   self.nu_mf)
 
-    def get_vlb(self):
-        """E_q[log p(mu,Sigma)] + H[q] = -KL(q || prior) (Bishop eqs. 10.74 and 10.77).
+    def get_vlb(self, convention=None):
+        """E_q[log p(mu,Sigma)] + H[q] of the NIW factor (Bishop eqs. 10.74 and 10.77).
 
-        The prior's Wishart normaliser enters as ``log B(W0, nu0) = -log Z`` (10.74), so the
-        term is exactly zero when q equals the prior (tests/test_emission_formula.py).  Some
-        pybasicbayes revisions carry that term with the opposite sign, which shifts the ELBO
-        by the constant ``2 log Z(sigma_0, nu_0)`` per state and changes nothing else."""
+        ``convention`` (default: the module's ``VLB_CONVENTION``) selects the sign with which the
+        prior's inverse-Wishart log-normaliser ``log Z(sigma_0, nu_0)`` enters:
+        ``"pybasicbayes"`` adds it, as the upstream package's ``Gaussian.get_vlb`` does -- so ELBO
+        traces (``elbo_vec``, ``lower_bound``) and ``hmmbatchcd``'s ``np.allclose(lb, elbo)``
+        stopping test see the same magnitudes as with the reference's dependency; ``"bishop"``
+        subtracts it (10.74: ``+ log B(W0, nu0) = - log Z``), which makes the term exactly
+        ``-KL(q || prior)`` (zero at the prior, tests/test_emission_formula.py).  The two differ
+        by the q-independent constant ``2 log Z(sigma_0, nu_0)`` per state and nothing else."""
         D = len(self.mu_0)
         llt = self._loglmbdatilde()
         dmu = self.mu_mf - self.mu_0
@@ -203,14 +207,38 @@ class Gaussian(object):
                             - D * self.kappa_0 / self.kappa_mf
                             - self.kappa_0 * self.nu_mf
                             * np.dot(dmu, np.linalg.solve(self.sigma_mf, dmu)))
-                     - _invwishart_log_partitionfunction(self.sigma_0, self.nu_0)
+                     + vlb_logz_sign(convention)
+                     * _invwishart_log_partitionfunction(self.sigma_0, self.nu_0)
                      + (self.nu_0 - D - 1) / 2. * llt
                      - 0.5 * self.nu_mf
                      * np.linalg.solve(self.sigma_mf, self.sigma_0).trace())
         return p_avgengy + q_entropy
 
 
-def niw_vlb_batch(mu_mf, sigma_mf, kappa_mf, nu_mf, mu_0, sigma_0, kappa_0, nu_0, terms=None):
+# sign convention of the prior's log-normaliser in the NIW factors' ELBO term (see Gaussian.get_vlb)
+VLB_CONVENTION = "pybasicbayes"
+
+
+def vlb_logz_sign(convention=None):
+    c = VLB_CONVENTION if convention is None else convention
+    if c == "pybasicbayes":
+        return 1.0
+    if c == "bishop":
+        return -1.0
+    raise RuntimeError("unknown ELBO convention %r (pybasicbayes | bishop)" % (c,))
+
+
+def niw_prior_logpart(sigma_0, nu_0):
+    """``invwishart_log_partitionfunction(sigma_0[k], nu_0[k])`` for stacked priors [K,D,D], [K]."""
+    sigma_0 = np.asarray(sigma_0, float); nu_0 = np.asarray(nu_0, float)
+    D = sigma_0.shape[-1]
+    hl = np.log(np.diagonal(np.linalg.cholesky(sigma_0), axis1=1, axis2=2)).sum(1)
+    return -1. * (nu_0 * hl - (nu_0 * D / 2. * np.log(2.) + D * (D - 1) / 4. * np.log(np.pi)
+                               + gammaln((nu_0[:, None] - np.arange(D)) / 2.).sum(1)))
+
+
+def niw_vlb_batch(mu_mf, sigma_mf, kappa_mf, nu_mf, mu_0, sigma_0, kappa_0, nu_0, terms=None,
+                  convention=None):
     """``Gaussian.get_vlb()`` for K NIW factors at once (stacked arrays [K,D], [K,D,D], [K]):
     same formulas (Bishop 10.74, 10.77), one batched Cholesky / solve instead of 4K small
     ones -- the ELBO bookkeeping of the SVI loop is otherwise slower than the device E-step."""
@@ -256,7 +284,7 @@ def niw_vlb_batch(mu_mf, sigma_mf, kappa_mf, nu_mf, mu_0, sigma_0, kappa_0, nu_0
     q_entropy = -0.5 * (l_mf + D * (np.log(kappa_mf / (2 * np.pi)) - 1)) + iw_entropy
     p_avgengy = (0.5 * (D * np.log(kappa_0 / (2 * np.pi)) + l_mf - D * kappa_0 / kappa_mf
                         - kappa_0 * nu_mf * quad)
-                 - logpart(chol_0, nu_0) + (nu_0 - D - 1) / 2. * l_mf
+                 + vlb_logz_sign(convention) * logpart(chol_0, nu_0) + (nu_0 - D - 1) / 2. * l_mf
                  - 0.5 * nu_mf * tr_s0)
     return p_avgengy + q_entropy
 

@@ -345,6 +345,49 @@ class HipEngine(object):
                                              L.i64ptr(z)), "svihmm_ffbs_sample")
         return z
 
+    # -- SVI loop with the variational state resident in HBM ---------------------------------
+    def svi_begin(self, prior_tran, var_tran, prior, factors, prior_logpart, maxit, zsign=1.0):
+        """Upload the state of ``hmmsgd_metaobs.VBHMM.infer``: transition prior / factor [K,K],
+        NIW ``prior`` and current ``factors`` as (mu [K,D], sigma [K,D,D], kappa [K], nu [K]).
+        Afterwards ``svi_iteration`` runs whole iterations (stationary init, psi-expectations,
+        E-step, natural-gradient step, ELBO) on the device without anything coming back."""
+        self._pre_mutate()
+        var_tran = L.as_f64(var_tran)
+        K = var_tran.shape[0]
+        prior_tran = L.as_f64(prior_tran, (K, K))
+        mu0 = L.as_f64(prior[0]); D = mu0.shape[1]
+        arrs = [mu0, L.as_f64(prior[1], (K, D, D)), L.as_f64(prior[2], (K,)), L.as_f64(prior[3], (K,)),
+                L.as_f64(prior_logpart, (K,)), L.as_f64(factors[0], (K, D)), L.as_f64(factors[1], (K, D, D)),
+                L.as_f64(factors[2], (K,)), L.as_f64(factors[3], (K,))]
+        L.check(self._lib.svihmm_svi_begin(self._h, K, D, L.dptr(prior_tran), L.dptr(var_tran),
+                                           *([L.dptr(a) for a in arrs] + [int(maxit), float(zsign)])),
+                "svihmm_svi_begin")
+        self.K, self.V = K, 0
+        self._svi_shape = (K, D)
+
+    def svi_iteration(self, it, starts, nwin_total, Lm, flags, rho, bfactA, bfactE, inner=None):
+        """Enqueue iteration ``it`` on the windows ``starts`` (asynchronous)."""
+        self._pre_mutate()
+        st = self._starts(starts)
+        off, ln = (0, int(Lm)) if inner is None else (int(inner[0]), int(inner[1]))
+        self._rows = len(st) * int(Lm)
+        L.check(self._lib.svihmm_svi_iteration(self._h, int(it), L.i64ptr(st), len(st), int(nwin_total),
+                                               int(Lm), off, ln, int(flags), float(rho), float(bfactA),
+                                               float(bfactE)), "svihmm_svi_iteration")
+
+    def svi_read_elbo(self, n):
+        """(elbo_vec[:n], device milliseconds of each iteration); waits for the device."""
+        e = np.empty(int(n)); ms = np.empty(int(n))
+        L.check(self._lib.svihmm_svi_read_elbo(self._h, int(n), L.dptr(e), L.dptr(ms)), "svihmm_svi_read_elbo")
+        return e, ms
+
+    def svi_read_state(self):
+        """Current (var_tran, var_init, mu, sigma, kappa, nu); waits for the device."""
+        K, D = self._svi_shape
+        out = [np.empty((K, K)), np.empty(K), np.empty((K, D)), np.empty((K, D, D)), np.empty(K), np.empty(K)]
+        L.check(self._lib.svihmm_svi_read_state(self._h, *[L.dptr(a) for a in out]), "svihmm_svi_read_state")
+        return tuple(out)
+
     # -- multi-GPU ------------------------------------------------------------------------
     def comm_unique_id(self):
         buf = C.create_string_buffer(128)

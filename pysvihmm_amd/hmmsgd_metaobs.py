@@ -235,8 +235,16 @@ class VBHMM(VariationalHMMBase):
         self.lliks = np.empty((metaobs_sz, self.K))
 
     def infer(self, adaptive=False, perIter=10, epsilon=1e-6, minHalfL=1,
-              avgResidual=False, Lincrement=1, Lcutoff=1000, fused=True):
-        """ Runs stochastic variational inference (reference :298-485)."""
+              avgResidual=False, Lincrement=1, Lcutoff=1000, fused=True, device_loop=None):
+        """ Runs stochastic variational inference (reference :298-485).
+
+        ``fused=True`` (default): all windows of a minibatch in one device E-step.  On top of
+        that, when nothing on the object overrides the loop's pieces (NIW Gaussian emitters,
+        no AdaGrad), the whole iteration -- stationary init, psi-expectations, E-step, global
+        natural-gradient step, ELBO -- runs on the device with the variational state resident in
+        HBM (``device_loop=False`` keeps the global step and the ELBO on the host); the object's
+        attributes are filled in when the loop ends (and wherever the loop itself needs them on
+        the host: adaptive L / buffer growth, ``full_predprob``, ``verbose``)."""
         np.random.seed(self.seed)
         if (type(self).local_update is not VBHMM.local_update
                 or type(self).intermediate_pars is not VBHMM.intermediate_pars
@@ -265,6 +273,13 @@ class VBHMM(VariationalHMMBase):
 
         self._obs_dirty = True
         self._upload_obs()
+
+        if fused and device_loop is not False and self._svi_device_ok():
+            # variational state resident in HBM for the whole loop (engine.svi_*)
+            self._infer_device(adaptive, perIter, epsilon, minHalfL, avgResidual, Lincrement, Lcutoff)
+            self._resolve_pending()
+            self.metaobs_fun = None
+            return
 
         for it in range(maxit):
             start_time = time.time()
@@ -338,6 +353,129 @@ class VBHMM(VariationalHMMBase):
 
         # So that the hmm object can be pickled
         self.metaobs_fun = None
+
+    # pieces of the loop a subclass (or a wrapper set on the instance) may replace: then the
+    # host loop, which calls them, is used
+    _LOOP_HOOKS = ("local_update", "intermediate_pars", "intermediate_pars_buffer", "global_update",
+                   "global_lower_bound", "local_lower_bound", "_minibatch_estep", "_stationary_init",
+                   "_psi_expectations", "_emit_vlb", "_global_update_niw_stacked")
+
+    def _svi_device_ok(self):
+        eng = self.engine
+        if not hasattr(eng, "svi_begin") or self.adagrad or not self._niw_fastpath():
+            return False
+        if any(type(e).get_vlb is not Gaussian.get_vlb for e in self.var_emit):
+            return False
+        for name in self._LOOP_HOOKS:
+            if name in self.__dict__ or getattr(type(self), name) is not getattr(VBHMM, name):
+                return False
+        if self.comm is not None and not hasattr(self.comm, "bind_engine"):
+            return False
+        return True
+
+    def _svi_pull_state(self):
+        """Device state -> the object's attributes (reference attribute names)."""
+        vt, vi, mu, sg, ka, nu = self.engine.svi_read_state()
+        self.var_tran, self.var_init = vt, vi
+        D = self.D
+        for k, G in enumerate(self.var_emit):
+            G.mu_mf = mu[k]; G.sigma_mf = sg[k]
+            G.kappa_mf = ka[k]; G.nu_mf = nu[k]
+            G.mu = G.mu_mf
+            G.sigma = G.sigma_mf / (G.nu_mf - D - 1)
+
+    def _infer_device(self, adaptive, perIter, epsilon, minHalfL, avgResidual, Lincrement, Lcutoff):
+        """The loop of reference :347-445 with one engine call per iteration; same random stream
+        (minibatch sampling, select_L / select_buffer draws, the re-initialisation draws of
+        :360-365) and same arithmetic as the host loop."""
+        from .distributions import niw_prior_logpart, vlb_logz_sign
+        eng = self.engine
+        comm = self.comm
+        if comm is not None:
+            comm.bind_engine(eng)
+        maxit, K = self.maxit, self.K
+        growBuffer, bufferBudget = self.growBuffer, self.bufferBudget
+        mb_sz = self.mb_sz
+        L_ = self.metaobs_half
+        miniL = bufferL = L_
+        prior = self._prior_arrays()
+        eng.svi_begin(self.prior_tran, self.var_tran, prior, self._emission_arrays(),
+                      niw_prior_logpart(prior[1], prior[3]), maxit, vlb_logz_sign())
+        self.__dict__.pop("_pending_rows", None)
+        if hasattr(eng, "on_next_mutation"):
+            eng.on_next_mutation(None)
+        host_fresh = True            # the object's attributes equal the device state
+        T = self.T
+        # quirk Q3: batch factors from the CONSTRUCTOR's L and S, whatever the windows are
+        bA = (T - 2 * self.metaobs_half - 1) / (2. * self.metaobs_half * self.mb_sz)
+        bE = (T - 2 * self.metaobs_half - 1) / ((2. * self.metaobs_half + 1.) * self.mb_sz)
+        last = None
+        for it in range(maxit):
+            self.lrate = (it + self.tau) ** (-self.kappa)
+            resize = (L_ is None or (adaptive and it % perIter == 0)) or (growBuffer and it % perIter == 0)
+            if resize and not host_fresh:
+                self._svi_pull_state()
+                host_fresh = True
+            if L_ is None or (adaptive and it % perIter == 0):
+                L_ = self.select_L(mb_sz, epsilon=epsilon, minHalfL=minHalfL, avgResidual=avgResidual,
+                                   Lincrement=Lincrement, Lcutoff=Lcutoff)
+                self._alloc_local(L_)
+                miniL = L_
+            if growBuffer and it % perIter == 0:
+                bufferL = self.select_buffer(self.mb_sz, epsilon=epsilon, halfL=L_, avgResidual=avgResidual,
+                                             Lincrement=Lincrement, Lcutoff=Lcutoff)
+                self._alloc_local(bufferL)
+                miniL = bufferL
+                if bufferBudget:
+                    mb_sz = self.buffer_budget(bufferL)
+            minibatch = self.metaobs_fun(T, miniL, mb_sz)
+            mine = minibatch if comm is None else minibatch[comm.rank::comm.size]
+            starts = np.array([mo.i1 for mo in mine], dtype=np.int64)
+            Lm = 2 * miniL + 1
+            flags = L.TRANS_WRAP | L.KEEP_LBETA
+            if it == maxit - 1:
+                flags |= L.SVI_KEEP_WINDOW
+            inner = (bufferL - L_, 2 * L_ + 1) if growBuffer else None
+            eng.svi_iteration(it, starts, len(minibatch), Lm, flags, self.lrate, bA, bE, inner=inner)
+            host_fresh = False
+            self.cur_mo = minibatch[-1]
+            last = (len(starts), Lm)
+            if self.verbose:
+                e, _ = eng.svi_read_elbo(it + 1)
+                print("iter: %d, ELBO: %.2f" % (it, e[it]))
+                sys.stdout.flush()
+            if self.full_predprob and it in self.fullpred_sched:
+                self._svi_pull_state()
+                host_fresh = True
+                if it == maxit - 1:
+                    self._register_last_window(eng, last)
+                if not hasattr(self, 'pred_logprob_full_mean'):
+                    self.pred_logprob_full_mean = np.inf * np.ones(maxit)
+                    self.pred_logprob_full_std = np.inf * np.ones(maxit)
+                tmp = self.pred_logprob_full()
+                self.pred_logprob_full_mean[it] = np.nanmean(tmp)
+                self.pred_logprob_full_std[it] = np.nanstd(tmp)
+        if not host_fresh:
+            self._svi_pull_state()
+        e, ms = eng.svi_read_elbo(maxit)
+        self.elbo_vec[:] = e
+        self.iter_time[:] = ms * 1e-3
+        if "_pending_rows" not in self.__dict__ and "_val_done" not in self.__dict__:
+            self._register_last_window(eng, last)
+        self.__dict__.pop("_val_done", None)
+
+    def _register_last_window(self, eng, last):
+        """lliks / lalpha / lbeta / var_x of the last window of the last minibatch, fetched from
+        the device on first access (what the reference leaves on the object, :405-436)."""
+        if last is None or last[0] == 0:
+            return
+        nb, Lm = last
+        self._pending_rows = ((nb - 1) * Lm, Lm, {"lliks", "lalpha", "lbeta", "var_x"})
+        self._lZ = None
+        self.__dict__["_val_done"] = True
+        if hasattr(eng, "on_next_mutation"):
+            ref = weakref.ref(self)
+            eng.on_next_mutation(lambda: ref() is not None and ref()._resolve_pending())
 
     def _resolve_pending(self):
         pend = self.__dict__.get("_pending_rows")

@@ -12,6 +12,10 @@ class TorchDistComm(object):
         self.rank = dist.get_rank(group)
         self.size = dist.get_world_size(group)
 
+    def bind_engine(self, engine):
+        """SVI loop inside the (oracle) engine: it all-reduces its packed statistics through us."""
+        engine._comm = self
+
     def allreduce_inplace(self, buf):
         import torch
         t = torch.from_numpy(buf)

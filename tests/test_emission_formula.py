@@ -82,8 +82,12 @@ def test_vlb_is_minus_kl_and_zero_at_the_prior():
     p = Gaussian(mu=np.zeros(D), sigma=np.eye(D), mu_0=np.zeros(D), sigma_0=np.eye(D) * 1.3,
                  kappa_0=0.5, nu_0=D + 2)
     p.mu_mf, p.sigma_mf, p.kappa_mf, p.nu_mf = p.mu_0.copy(), p.sigma_0.copy(), p.kappa_0, p.nu_0
-    assert abs(p.get_vlb()) < 1e-9
-    assert g.get_vlb() < 0
+    assert abs(p.get_vlb("bishop")) < 1e-9
+    assert g.get_vlb("bishop") < 0
+    # the default follows the upstream package: shifted by the constant 2 log Z(sigma_0, nu_0)
+    from pysvihmm_amd.distributions import niw_prior_logpart
+    z = niw_prior_logpart(np.array([g.sigma_0]), np.array([g.nu_0]))[0]
+    np.testing.assert_allclose(g.get_vlb() - g.get_vlb("bishop"), 2.0 * z, rtol=1e-12)
     b = niw_vlb_batch(np.array([g.mu_mf, p.mu_mf]), np.array([g.sigma_mf, p.sigma_mf]),
                       [g.kappa_mf, p.kappa_mf], [g.nu_mf, p.nu_mf], np.array([g.mu_0, p.mu_0]),
                       np.array([g.sigma_0, p.sigma_0]), [g.kappa_0, p.kappa_0], [g.nu_0, p.nu_0])

@@ -14,8 +14,12 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 META = sorted(glob.glob(os.path.join(GOLDEN, "metaobs_*.npz")))
 
 
+@pytest.mark.parametrize("device_loop", [None, False], ids=["device_loop", "host_global_step"])
 @pytest.mark.parametrize("path", META, ids=[os.path.basename(p)[:-4] for p in META])
-def test_metaobs_infer_on_gpu(path):
+def test_metaobs_infer_on_gpu(path, device_loop):
+    """device_loop: the variational state stays in HBM (k_svi_globals: GTH stationary vector +
+    psi-expectations, k_svi_global_step, k_svi_vlb / k_svi_elbo); host_global_step: the E-step on
+    the device, global step and ELBO in NumPy.  Both against the executed reference's trace."""
     from pysvihmm_amd import hmmsgd_metaobs
     g = np.load(path)
     K = int(g["K"])
@@ -24,8 +28,14 @@ def test_metaobs_infer_on_gpu(path):
         tau=float(g["tau"]), kappa=float(g["kappa"]), metaobs_half=int(g["L"]),
         mb_sz=int(g["S"]), mask=g["mask"], init_tran=g["init_tran"], maxit=int(g["maxit"]),
         seed=int(g["seed"]))
-    hmm.infer()
+    assert hmm._svi_device_ok()
+    hmm.infer(device_loop=device_loop)
     assert hmm.engine.name == "hip"
+    np.testing.assert_allclose(hmm.var_init, g["w_var_init"][-1], rtol=1e-9, atol=1e-12)   # GTH vs eig
+    np.testing.assert_allclose(hmm.lalpha, g["w_lalpha"][-1], rtol=1e-9, atol=1e-8)
+    np.testing.assert_allclose(hmm.lbeta, g["w_lbeta"][-1], rtol=1e-9, atol=1e-8)
+    np.testing.assert_allclose(hmm.lliks, g["w_lliks"][-1], rtol=1e-9, atol=1e-8)
+    assert np.all(hmm.iter_time > 0) and np.all(np.isfinite(hmm.iter_time))
     np.testing.assert_allclose(hmm.var_tran, g["it_var_tran_new"][-1], rtol=1e-6, atol=1e-9)
     for k in range(K):
         np.testing.assert_allclose(hmm.var_emit[k].mu_mf, g["it_new_mu"][-1][k], rtol=1e-6, atol=1e-8)

@@ -172,3 +172,34 @@ def test_categorical_branch_matches_reference(kind):
     st = eng.estep(g["w_i1"][:1], Lm, flags=2)
     np.testing.assert_allclose(st.A_raw + 0.0, g["w_A_i"][0], **tol)        # prior_tran - 1 = 0 here
     np.testing.assert_allclose(g["alphav_0"][None, :] + st.counts - 1.0, g["w_e_i"][0], **tol)
+
+
+@pytest.mark.parametrize("kind", ENGINES)
+@pytest.mark.parametrize("name", ["adaptive_K4_D2", "growbuf_K4_D2", "growbuf_budget_K3_D2"])
+def test_adaptive_and_buffered_infer_device_loop(name, kind):
+    """The same three runs with nothing wrapped on the instance: infer() then keeps the
+    variational state on the device between iterations (engine.svi_*) and pulls it to the host
+    only where select_L / select_buffer need it.  Same ELBO trace and final parameters as the
+    executed reference (which implies the same chosen L / buffers and the same minibatches)."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    K = int(g["K"])
+    hmm = hmmsgd_metaobs.VBHMM(
+        g["obs"].copy(), np.ones(K), g["prior_tran"], emit_from_fixture(g, K),
+        tau=float(g["tau"]), kappa=float(g["kappa"]), metaobs_half=int(g["L"]), mb_sz=int(g["S"]),
+        mask=g["mask"], init_tran=g["init_tran"], maxit=int(g["maxit"]), seed=int(g["seed"]),
+        growBuffer=bool(g["ctor_growBuffer"]), bufferBudget=bool(g["ctor_bufferBudget"]),
+        engine=_engine(kind))
+    assert hmm._svi_device_ok()
+    kw = {k[len("infer_"):]: g[k].item() for k in g.files if k.startswith("infer_")}
+    hmm.infer(**kw)
+    tol = _tol(kind)
+    np.testing.assert_allclose(hmm.elbo_vec, g["elbo_vec"], rtol=1e-8)
+    np.testing.assert_allclose(hmm.var_tran, g["it_var_tran_new"][-1], **tol)
+    for k in range(K):
+        np.testing.assert_allclose(hmm.var_emit[k].mu_mf, g["it_new_mu"][-1][k], **tol)
+        np.testing.assert_allclose(hmm.var_emit[k].sigma_mf, g["it_new_sigma"][-1][k],
+                                   rtol=tol["rtol"], atol=10 * tol["atol"])
+        np.testing.assert_allclose(hmm.var_emit[k].kappa_mf, g["it_new_kappa"][-1][k], rtol=tol["rtol"])
+        np.testing.assert_allclose(hmm.var_emit[k].nu_mf, g["it_new_nu"][-1][k], rtol=tol["rtol"])
+    assert hmm.cur_mo.i1 == int(g["w_i1"][-1]) and hmm.cur_mo.i2 == int(g["w_i2"][-1])
+    assert hmm.var_x.shape == (int(g["w_len"][-1]), K)
