@@ -1223,6 +1223,140 @@ __global__ __launch_bounds__(64) void k_wave_lin(
   }
 }
 
+// ------------------------------------------------------------------------------------
+//  K2f, minibatch-sized batches (K <= 64, up to a few hundred windows): the same scaled
+//  recursion with FOUR wavefronts per (window, direction).  A 64-window minibatch gives the
+//  one-wave kernel 128 wavefronts for 1024 SIMDs, each walking 64 broadcast reads + 64 FMAs per
+//  step (0.56 us); here wave w owns the source states i in [16w, 16w+16): it keeps its own copy
+//  of the entering vector in LDS (wave-private, so the broadcast needs no barrier), forms the
+//  partial sums over its 16 states for all 64 target states (16 FMAs), and after ONE workgroup
+//  barrier every wave adds up the four partials (double-buffered) and renormalises -- all four
+//  redundantly, so the next step's entering vector is already in each wave's registers.
+//  Same inputs / outputs and the same arithmetic per element as k_wave_lin except for the
+//  association of the 64-term sum ((4 x 16) instead of (4 chains x 16)).
+// ------------------------------------------------------------------------------------
+template <int KMAX>
+__global__ __launch_bounds__(256) void k_wave_lin4(
+    const double* __restrict__ Eh, const double* __restrict__ kexp,
+    const double* __restrict__ Aexp, const double* __restrict__ AexpT,
+    const double* __restrict__ mod_init, int Lm, int K, double* __restrict__ ah,
+    double* __restrict__ bh, double* __restrict__ hx, double* __restrict__ gx,
+    double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac) {
+  constexpr int NI = KMAX / 4;                  // source states per wave
+  __shared__ double p_s[4][2][64];              // wave-private copies of the entering vector
+  __shared__ double part[2][4][64];             // partial sums, double-buffered over steps
+  const int b = blockIdx.x, j = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const bool fwd = blockIdx.y == 0;
+  const bool valid = j < K;
+  const int jc = valid ? j : 0;
+  const double* __restrict__ Am = fwd ? Aexp : AexpT;
+  double a[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int src = w * NI + i;
+    a[i] = (valid && src < K) ? Am[(size_t)src * K + jc] : 0.0;
+  }
+  const size_t wrow = (size_t)b * Lm;
+  const double* __restrict__ Eb = Eh + wrow * K + jc;
+  double* __restrict__ ob = (fwd ? ah : bh) + wrow * K + jc;
+  double* __restrict__ xb = (fwd ? hx : gx) + wrow;
+  auto rowof = [&](int s) { return fwd ? s : Lm - 1 - s; };
+  double h = 0.0, mant = 1.0, hsum = 0.0;
+  int ex = 0;
+  double pcur;
+  {
+    const int t = rowof(0);
+    const double e0 = Eb[(size_t)t * K];
+    double o;
+    if (fwd) {
+      double mi_max = -INFINITY;
+      for (int k = 0; k < K; ++k) mi_max = fmax(mi_max, mod_init[k]);
+      h = (mi_max > -1e300 && mi_max < 1e300) ? ceil(mi_max * LOG2E_D) : 0.0;
+      o = valid ? exp(fma(-h, LN2_LO_D, fma(-h, LN2_HI_D, mod_init[jc]))) * e0 : 0.0;
+      pcur = o;
+    } else {
+      o = valid ? 1.0 : 0.0;
+      pcur = valid ? e0 : 0.0;
+    }
+    if (valid && w == 0) ob[(size_t)t * K] = o;
+  }
+  double hkeep = h;
+  constexpr int PD = 4;
+  auto eload = [&](int s) { return Eb[(size_t)rowof(s < Lm ? s : Lm - 1) * K]; };
+  double eq[PD];
+#pragma unroll
+  for (int u = 0; u < PD; ++u) eq[u] = eload(1 + u);
+  auto step = [&](int s, double et) {
+    const int cur = s & 1;
+    const int t = rowof(s);
+    double* __restrict__ mine = &p_s[w][cur][0];
+    mine[j] = pcur;                                  // wave-private: LDS keeps a wave's order
+    __builtin_amdgcn_wave_barrier();
+    const double tot = wave_sum_dpp(pcur);
+    const int e2 = __builtin_amdgcn_frexp_exp(tot);
+    if (fwd) {
+      const double mm = mant * tot;
+      ex += __builtin_amdgcn_frexp_exp(mm);
+      mant = __builtin_amdgcn_frexp_mant(mm);
+      hsum += h;
+    }
+    double s0 = 0.0, s1 = 0.0;
+    const double* __restrict__ src = mine + w * NI;
+#pragma unroll
+    for (int i = 0; i < NI; i += 2) {
+      s0 = fma(src[i], a[i], s0);
+      s1 = fma(src[i + 1], a[i + 1], s1);
+    }
+    part[cur][w][j] = s0 + s1;
+    __syncthreads();
+    const double acc = (part[cur][0][j] + part[cur][1][j]) + (part[cur][2][j] + part[cur][3][j]);
+    double o;
+    if (fwd) { o = valid ? ldexp(acc * et, -e2) : 0.0; pcur = o; }
+    else { o = valid ? ldexp(acc, -e2) : 0.0; pcur = et * o; }
+    h += (double)e2;
+    if (valid && w == (s & 3)) ob[(size_t)t * K] = o;      // the four waves take turns storing
+    hkeep = (j == (s & 63)) ? h : hkeep;
+    if ((s & 63) == 63 && w == 0) xb[rowof(s - 63 + j)] = hkeep;
+  };
+  int s = 1;
+  for (; s + PD <= Lm; s += PD) {
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+      const double et = eq[u];
+      eq[u] = eload(s + u + PD);
+      step(s + u, et);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < PD; ++u)
+    if (s + u < Lm) step(s + u, eq[u]);
+  if (w != 0) return;
+  {
+    const int sl = Lm - 1, s0 = sl & ~63;
+    if ((sl & 63) != 63 && s0 + j <= sl) xb[rowof(s0 + j)] = hkeep;
+  }
+  if (!fwd) return;
+  double ks = 0.0, kk = 0.0;
+  for (int t = j; t < Lm; t += 64) {
+    const double kv = kexp[wrow + t];
+    ks += kv;
+    kk += kv * (double)(Lm - t);
+  }
+  ks = wave_sum_dpp(ks);
+  kk = wave_sum_dpp(kk);
+  const double tot = wave_sum_dpp(pcur);
+  if (j == 0) {
+    const double mm = mant * tot;
+    const int exf = ex + __builtin_amdgcn_frexp_exp(mm);
+    const double mf = __builtin_amdgcn_frexp_mant(mm);
+    const double zm = __builtin_amdgcn_frexp_mant(tot);
+    const double zexp = (double)__builtin_amdgcn_frexp_exp(tot);
+    local_lb[b] = log(mf) + ((double)exf + hsum + h + kk) * LN2_D;
+    logz[b] = log(zm) + (h + ks + zexp) * LN2_D;
+    zfac[b] = make_double2(1.0 / zm, h + zexp);
+  }
+}
+
 // S2 of the chain scan: boundary vectors.  grid 2 (0: alpha at chunk starts, 1: beta at chunk
 // ends), one wavefront each, lane = state.  Chunk c spans rows [c*L, (c+1)*L] (the last one up
 // to T-1); bnd row b of the outputs belongs to chain row min(b*L, T-1).

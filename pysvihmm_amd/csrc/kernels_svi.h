@@ -217,12 +217,12 @@ __global__ __launch_bounds__(64) void k_svi_vlb(
 //  transition rows (hmmbase.dirichlet_elbo) for the UPDATED var_tran, sum_k vlb[k] in state order.
 //  One workgroup; fixed reduction order.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_svi_elbo(
+__global__ __launch_bounds__(256) void k_svi_elbo(
     const double* __restrict__ prior_tran, const double* __restrict__ var_tran, int K,
     const double* __restrict__ vlb, const double* __restrict__ lb, double* __restrict__ elbo_out) {
-  __shared__ double rowv[1024], rowp[1024], red[1024];
+  __shared__ double rowv[1024], rowp[1024], red[256];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  for (int i = w; i < K; i += 16) {
+  for (int i = w; i < K; i += 4) {
     double sv = 0.0, sp = 0.0;
     for (int j = lane; j < K; j += 64) { sv += var_tran[(size_t)i * K + j]; sp += prior_tran[(size_t)i * K + j]; }
     sv = wave_sum(sv); sp = wave_sum(sp);
@@ -232,16 +232,16 @@ __global__ __launch_bounds__(1024) void k_svi_elbo(
   // per row i: energy = lgamma(sum p + eps) - sum lgamma(p + eps) + sum (p - 1) elog
   //            entropy = -(lgamma(sum q + eps) - sum lgamma(q + eps) + sum (q - 1) elog)
   double acc = 0.0;
-  for (int e = tid; e < K * K; e += 1024) {
+  for (int e = tid; e < K * K; e += 256) {
     const int i = e / K;
     const double q = var_tran[e], p = prior_tran[e];
     const double elog = digamma_d(q + SVI_EPS) - digamma_d(rowv[i] + SVI_EPS);
     acc += (-lgamma(p + SVI_EPS) + (p - 1.0) * elog) - (-lgamma(q + SVI_EPS) + (q - 1.0) * elog);
   }
-  for (int i = tid; i < K; i += 1024) acc += lgamma(rowp[i] + SVI_EPS) - lgamma(rowv[i] + SVI_EPS);
+  for (int i = tid; i < K; i += 256) acc += lgamma(rowp[i] + SVI_EPS) - lgamma(rowv[i] + SVI_EPS);
   red[tid] = acc;
   __syncthreads();
-  for (int o = 512; o >= 1; o >>= 1) {
+  for (int o = 128; o >= 1; o >>= 1) {
     if (tid < o) red[tid] += red[tid + o];
     __syncthreads();
   }

@@ -907,6 +907,8 @@ static int ensure_fb_lin(svihmm_ctx* h, int B, int Lm) {
 // at once (190 VGPRs: two per SIMD); measured (tools/sweep_crossover.py, K = 64, Lm = 257)
 // 0.16 ms at 64 .. 0.19 ms at 1024 windows against 0.23 .. 0.25 ms, 0.33 against 0.26 ms at 1399
 #define LIN_WAVE_MAX 1025
+// up to this many windows: four waves per (window, direction); 2 x 256 x 4 = 2048 waves, two per SIMD
+#define LIN_WAVE4_MAX 256
 // both sweeps over windows [b0, b0+nb) of the current batch on `stream` (buffers ensured):
 // one launch, blockIdx.y = direction
 static int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_t stream) {
@@ -931,7 +933,16 @@ static int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_
 #define WL(KM, FK) hipLaunchKernelGGL((k_wave_lin<KM, FK>), gw, dim3(64), 0, stream, Eh, kx, (const double*)h->Aexp.p, \
                                       (const double*)h->AexpT.p, (const double*)h->mod_init.p, Lm, K, ah, bh, hx,  \
                                       gx, llb, lz, zf)
-    if (K <= 16) WL(16, false); else if (K <= 32) WL(32, false);
+    // up to a few hundred windows the chip is far from full with one wave per (window,
+    // direction): split each window's source states over four waves (variant[7] = 3: off)
+    if (K > 16 && nb <= LIN_WAVE4_MAX && h->variant[7] != 3) {
+#define WL4(KM) hipLaunchKernelGGL((k_wave_lin4<KM>), gw, dim3(256), 0, stream, Eh, kx, (const double*)h->Aexp.p, \
+                                   (const double*)h->AexpT.p, (const double*)h->mod_init.p, Lm, K, ah, bh, hx,  \
+                                   gx, llb, lz, zf)
+      if (K <= 32) WL4(32); else WL4(64);
+#undef WL4
+    }
+    else if (K <= 16) WL(16, false); else if (K <= 32) WL(32, false);
     else if (K == 64) WL(64, true); else WL(64, false);
 #undef WL
     HIPCK(hipGetLastError());
@@ -1891,7 +1902,7 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
     double* delbo = nullptr;
     HIPCK(hipHostGetDevicePointer((void**)&delbo, h->svi_elbo, 0));
     const double* lb = (const double*)h->packed.p + (packed_len(h) - 1);
-    hipLaunchKernelGGL(k_svi_elbo, dim3(1), dim3(1024), 0, h->stream, (const double*)svi_ptr(h, 1),
+    hipLaunchKernelGGL(k_svi_elbo, dim3(1), dim3(256), 0, h->stream, (const double*)svi_ptr(h, 1),
                        (const double*)svi_ptr(h, 0), K, (const double*)svi_ptr(h, 3), lb, delbo + it);
     HIPCK(hipGetLastError());
   }

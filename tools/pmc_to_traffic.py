@@ -10,7 +10,7 @@ import json
 import re
 import sys
 
-FAMILY = [("k_emission", "emission"), ("k_stats", "stats"), ("k_sweeps_lin", "forward_backward"),
+FAMILY = [("k_emission", "emission"), ("k_stats", "stats"), ("k_sweeps_lin<", "forward_backward"),
           ("k_fwd_mfma", "forward_backward"), ("k_bwd_mfma", "posterior"), ("k_finalize", "finalize")]
 
 
@@ -33,6 +33,9 @@ def main(path):
             best[fam] = {"kernel": name, "workgroups": grid, "fetch_bytes": fb, "write_bytes": wb,
                          "hbm_bytes_per_launch": fb + wb}
     out.update(sorted(best.items()))
+    # the epoch step = one launch of each family's bench-shape kernel (+ the small ones, < 1 %)
+    out["_step_total"] = {"hbm_bytes_per_step": sum(v["hbm_bytes_per_launch"] for v in best.values()),
+                          "families": sorted(best)}
     json.dump(out, sys.stdout, indent=1)
     print()
 

@@ -9,7 +9,10 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+# 2 blocks of 5 steps of the headline workload + the side figures (their kernels are told apart by
+# their launch grids: 3891-window epoch step, 64-window minibatch / SVI iteration, whole chain,
+# configs[4] K=256 D=64); PMC passes skip the side figures except the SVI iteration
+BENCH="python $ROOT/bench.py --steps 5 --warmup 2 --reps 2 --no-cpu-baseline"
 run() {  # name, rocprof args...
   local name=$1; shift
   rm -rf /tmp/prof_$name
@@ -20,5 +23,5 @@ run() {  # name, rocprof args...
 run kt --kernel-trace --stats > $OUT/${TAG}_kernel_stats.txt
 { run fetch --kernel-trace --pmc FETCH_SIZE; run write --kernel-trace --pmc WRITE_SIZE; } > $OUT/${TAG}_pmc_hbm.txt
 run sq --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS > $OUT/${TAG}_sq_counters.txt
-cd $ROOT && python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > $OUT/${TAG}_bench.json
+cd $ROOT && python bench.py 2>/dev/null | tail -1 > $OUT/${TAG}_bench.json
 tail -c 600 $OUT/${TAG}_bench.json
