@@ -9,7 +9,7 @@
 #define SVI_EPS 1e-9     // the reference's eps (hmmbase.py:30) inside digamma / gammaln
 
 // ------------------------------------------------------------------------------------
-//  G1: globals of an iteration, one workgroup of 1024 threads.
+//  G1: globals of an iteration, one workgroup of 512 threads.
 //    (a) psi-expectations of the transition factor (hmmsgd_metaobs.py:502-504):
 //          ltran[i][j] = psi(var_tran[i][j] + eps) - psi(sum_j var_tran[i][j] + eps),
 //        plus exp(ltran) and its transpose for the scaled sweeps (what k_exp_transpose makes
@@ -22,66 +22,83 @@
 //        K-1 dependent steps of a rank-one update on the shrinking leading block;
 //    (c) mod_init[k] = psi(var_init[k] + eps) - psi(sum var_init + eps)  (quirk Q5: the unit-L2
 //        vector goes into psi as if it were Dirichlet parameters).
-//  `work` = 2 K^2 doubles (LDS when they fit, else global scratch).
+//  `work` = 2 K (K|1) doubles (LDS when they fit, else global scratch).
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_svi_globals(
-    const double* __restrict__ var_tran, int K, double* __restrict__ work_g, int use_lds,
+template <bool LDSW>
+__global__ __launch_bounds__(512) void k_svi_globals(
+    const double* __restrict__ var_tran, int K, double* __restrict__ work_g,
     double* __restrict__ ltran, double* __restrict__ Aexp, double* __restrict__ AexpT,
     double* __restrict__ var_init, double* __restrict__ mod_init) {
   extern __shared__ double svi_lds[];
   __shared__ double rs[1024];      // row sums, later the stationary vector (K <= 1024)
+  __shared__ double psum[2][8];    // partial sums of the next pivot row (double-buffered)
   __shared__ double sc[4];
-  double* P = use_lds ? svi_lds : work_g;          // [K][K] working copy, then its reduced form
-  double* Q = P + (size_t)K * K;                   // [K][K] scaled columns (back-substitution)
-  const int tid = threadIdx.x, NT = 1024;
+  const int LD = K | 1;                            // odd row stride: a column walks all LDS banks
+  // LDSW is a template parameter so that the LDS instantiation keeps ds_* instructions (a
+  // run-time choice between the two spaces compiles to flat loads: 2x slower for this kernel)
+  auto Pm = [&]() -> double* { if constexpr (LDSW) return svi_lds; else return work_g; };
+  double* P = Pm();                                // [K][LD] working copy, then its reduced form
+  double* Q = P + (size_t)K * LD;                  // [K][LD] scaled columns (back-substitution)
+  const int tid = threadIdx.x, NT = 512;
+  const int lane = tid & 63, w = tid >> 6;
   // row sums (one wave per row, round-robin)
-  {
-    const int lane = tid & 63, w = tid >> 6;
-    for (int i = w; i < K; i += 16) {
-      double s = 0.0;
-      for (int j = lane; j < K; j += 64) s += var_tran[(size_t)i * K + j];
-      s = wave_sum(s);
-      if (lane == 0) rs[i] = s;
+  for (int i = w; i < K; i += 8) {
+    double s = 0.0;
+    for (int j = lane; j < K; j += 64) s += var_tran[(size_t)i * K + j];
+    s = wave_sum(s);
+    if (lane == 0) rs[i] = s;
+  }
+  __syncthreads();
+  for (int i = w; i < K; i += 8) {
+    const double rsum = rs[i], dgs = digamma_d(rsum + SVI_EPS);
+    for (int j = lane; j < K; j += 64) {
+      const size_t e = (size_t)i * K + j;
+      const double v = var_tran[e];
+      const double l = digamma_d(v + SVI_EPS) - dgs;
+      const double x = exp(l);
+      ltran[e] = l;
+      Aexp[e] = x;
+      AexpT[(size_t)j * K + i] = x;
+      P[(size_t)i * LD + j] = v / rsum;          // row-stochastic mean transition matrix
     }
   }
   __syncthreads();
-  for (int e = tid; e < K * K; e += NT) {
-    const int i = e / K, j = e - i * K;
-    const double v = var_tran[e];
-    const double l = digamma_d(v + SVI_EPS) - digamma_d(rs[i] + SVI_EPS);
-    const double x = exp(l);
-    ltran[e] = l;
-    Aexp[e] = x;
-    AexpT[(size_t)j * K + i] = x;
-    P[e] = v / rs[i];                    // row-stochastic mean transition matrix
+  // GTH: eliminate states K-1 .. 1.  Thread (r = tid / 8, c = tid % 8) owns columns c, c+8, ..
+  // of rows r, r+64, ..; one barrier per step (row n and column n are not written in step n).
+  // s_n = sum_{j<n} P[n][j] of the NEXT pivot row is gathered by that row's eight owners while
+  // they update it (psum), so a step costs one column element, n/8 fused updates and 8 reads.
+  const int r0 = tid >> 3, c0 = tid & 7;
+  if (r0 == ((K - 1) & 63)) {      // owners of row K-1 (rows r0, r0+64, ..: K-1 = r0 mod 64)
+    double s = 0.0;
+    for (int j = c0; j < K - 1; j += 8) s += P[(size_t)(K - 1) * LD + j];
+    psum[(K - 1) & 1][c0] = s;
   }
   __syncthreads();
-  // GTH: eliminate states K-1 .. 1
   for (int n = K - 1; n >= 1; --n) {
-    if (tid < 64) {
+    const double* __restrict__ rown = P + (size_t)n * LD;
+    const double* __restrict__ ps = psum[n & 1];
+    const double inv = 1.0 / (((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7])));
+    for (int i = r0; i < n; i += 64) {
+      double* __restrict__ rowi = P + (size_t)i * LD;
+      const double c = rowi[n] * inv;
       double s = 0.0;
-      for (int j = tid; j < n; j += 64) s += P[(size_t)n * K + j];
-      s = wave_sum(s);
-      if (tid == 0) sc[0] = 1.0 / s;
-    }
-    __syncthreads();
-    const double inv = sc[0];
-    for (int e = tid; e < n * n; e += NT) {
-      const int i = e / n, j = e - i * n;
-      const double c = P[(size_t)i * K + n] * inv;
-      P[(size_t)i * K + j] = fma(c, P[(size_t)n * K + j], P[(size_t)i * K + j]);
-      if (j == 0) Q[(size_t)i * K + n] = c;
+      for (int j = c0; j < n; j += 8) {
+        const double v = fma(c, rown[j], rowi[j]);
+        rowi[j] = v;
+        s += (j < n - 1) ? v : 0.0;
+      }
+      if (c0 == 0) Q[(size_t)i * LD + n] = c;
+      if (i == n - 1) psum[(n - 1) & 1][c0] = s;    // the next pivot row's partial sums
     }
     __syncthreads();
   }
   // back-substitution: pi_0 = 1, pi_j = sum_{i<j} pi_i Q[i][j]   (one wave, lane-strided)
   if (tid < 64) {
-    const int lane = tid;
     if (lane == 0) rs[0] = 1.0;
     for (int j = 1; j < K; ++j) {
       double s = 0.0;
-      for (int i = lane; i < j; i += 64) s = fma(rs[i], Q[(size_t)i * K + j], s);
-      s = wave_sum(s);
+      for (int i = lane; i < j; i += 64) s = fma(rs[i], Q[(size_t)i * LD + j], s);
+      s = wave_sum_dpp(s);
       if (lane == 0) rs[j] = s;
       __builtin_amdgcn_wave_barrier();
       __threadfence_block();
@@ -175,8 +192,30 @@ __global__ __launch_bounds__(256) void k_svi_global_step(
 __global__ __launch_bounds__(64) void k_svi_vlb(
     const double* __restrict__ theta, const int* __restrict__ fab, int F, int D, int Kp,
     const double* __restrict__ niw, const double* __restrict__ logdet, const double* __restrict__ prior,
-    const double* __restrict__ prior_logpart, double zsign, int K, double* __restrict__ vlb) {
-  const int k = blockIdx.x, lane = threadIdx.x;
+    const double* __restrict__ prior_logpart, double zsign, int K, double* __restrict__ vlb,
+    const double* __restrict__ prior_tran, const double* __restrict__ var_tran,
+    double* __restrict__ rowterm) {
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x >= K) {
+    // Dirichlet energy + entropy of transition row i for the UPDATED var_tran (hmmbase.
+    // dirichlet_elbo, reference hmmsgd_metaobs.py:277-292) minus the prior-only constants
+    // (lgamma of the prior row: added once by the host-supplied prior_const in k_svi_elbo)
+    const int i = (int)blockIdx.x - K;
+    double sv = 0.0;
+    for (int j = lane; j < K; j += 64) sv += var_tran[(size_t)i * K + j];
+    sv = wave_sum(sv);
+    const double dgs = digamma_d(sv + SVI_EPS);
+    double acc = 0.0;
+    for (int j = lane; j < K; j += 64) {
+      const double q = var_tran[(size_t)i * K + j], p = prior_tran[(size_t)i * K + j];
+      const double elog = digamma_d(q + SVI_EPS) - dgs;
+      acc += ((p - 1.0) - (q - 1.0)) * elog + lgamma(q + SVI_EPS);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) rowterm[i] = acc - lgamma(sv + SVI_EPS);
+    return;
+  }
+  const int k = blockIdx.x;
   const size_t nmu = (size_t)K * D, nsg = (size_t)K * D * D;
   const double* m = niw + (size_t)k * D;
   const double ka = niw[nmu + nsg + k], nu = niw[nmu + nsg + K + k];
@@ -213,41 +252,17 @@ __global__ __launch_bounds__(64) void k_svi_vlb(
 
 // ------------------------------------------------------------------------------------
 //  G4: elbo_vec[it] = lb + global_lower_bound()  (hmmsgd_metaobs.py:436-445, 273-296):
-//  lb = packed[last] (sum of the windows' local bounds), Dirichlet energy + entropy of the
-//  transition rows (hmmbase.dirichlet_elbo) for the UPDATED var_tran, sum_k vlb[k] in state order.
-//  One workgroup; fixed reduction order.
+//  lb = packed[last] (sum of the windows' local bounds) + the transition rows' Dirichlet terms
+//  (rowterm[i] from k_svi_vlb + prior_const = sum_i [lgamma(sum_j p_ij + eps) - sum_j lgamma(p_ij
+//  + eps)], a constant of the prior computed once by the host) + sum_k vlb[k]; fixed order.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_svi_elbo(
-    const double* __restrict__ prior_tran, const double* __restrict__ var_tran, int K,
-    const double* __restrict__ vlb, const double* __restrict__ lb, double* __restrict__ elbo_out) {
-  __shared__ double rowv[1024], rowp[1024], red[256];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  for (int i = w; i < K; i += 4) {
-    double sv = 0.0, sp = 0.0;
-    for (int j = lane; j < K; j += 64) { sv += var_tran[(size_t)i * K + j]; sp += prior_tran[(size_t)i * K + j]; }
-    sv = wave_sum(sv); sp = wave_sum(sp);
-    if (lane == 0) { rowv[i] = sv; rowp[i] = sp; }
-  }
-  __syncthreads();
-  // per row i: energy = lgamma(sum p + eps) - sum lgamma(p + eps) + sum (p - 1) elog
-  //            entropy = -(lgamma(sum q + eps) - sum lgamma(q + eps) + sum (q - 1) elog)
-  double acc = 0.0;
-  for (int e = tid; e < K * K; e += 256) {
-    const int i = e / K;
-    const double q = var_tran[e], p = prior_tran[e];
-    const double elog = digamma_d(q + SVI_EPS) - digamma_d(rowv[i] + SVI_EPS);
-    acc += (-lgamma(p + SVI_EPS) + (p - 1.0) * elog) - (-lgamma(q + SVI_EPS) + (q - 1.0) * elog);
-  }
-  for (int i = tid; i < K; i += 256) acc += lgamma(rowp[i] + SVI_EPS) - lgamma(rowv[i] + SVI_EPS);
-  red[tid] = acc;
-  __syncthreads();
-  for (int o = 128; o >= 1; o >>= 1) {
-    if (tid < o) red[tid] += red[tid + o];
-    __syncthreads();
-  }
-  if (tid == 0) {
-    double v = 0.0;
+__global__ __launch_bounds__(64) void k_svi_elbo(int K, const double* __restrict__ vlb,
+                                                 const double* __restrict__ rowterm, double prior_const,
+                                                 const double* __restrict__ lb, double* __restrict__ elbo_out) {
+  if (threadIdx.x == 0) {
+    double v = 0.0, d = 0.0;
     for (int k = 0; k < K; ++k) v += vlb[k];
-    *elbo_out = lb[0] + red[0] + v;
+    for (int i = 0; i < K; ++i) d += rowterm[i];
+    *elbo_out = lb[0] + (d + prior_const) + v;
   }
 }

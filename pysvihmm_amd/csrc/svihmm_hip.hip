@@ -165,7 +165,7 @@ struct svihmm_ctx {
   // prior_logpart[K]; prior block [mu0 | sigma0 | kappa0 | nu0]; GTH scratch; elbo / event ring
   Buf svi_state, svi_prior, svi_work;
   int svi_K = 0, svi_D = 0, svi_maxit = 0;
-  double svi_zsign = 1.0;
+  double svi_zsign = 1.0, svi_prior_const = 0.0;
   double* svi_elbo = nullptr; int svi_elbo_cap = 0;      // pinned + mapped: elbo_vec
   std::vector<hipEvent_t> svi_ev;                        // iteration boundaries (iter_time)
   bool svi_active = false;
@@ -1753,7 +1753,7 @@ int svihmm_estep_minibatch_ex(svihmm_ctx* h, const int64_t* starts, int32_t B, i
 }
 
 // ---- device-resident SVI loop (hmmsgd_metaobs.py:347-445) ------------------------------------
-// layout of h->svi_state: var_tran K*K | prior_tran K*K | var_init K | vlb K | logdet K | prior_logpart K
+// layout of h->svi_state: var_tran K*K | prior_tran K*K | var_init K | vlb K | logdet K | prior_logpart K | rowterm K
 static double* svi_ptr(svihmm_ctx* h, int which) {
   const size_t K = h->svi_K, kk = K * K;
   double* b = (double*)h->svi_state.p;
@@ -1763,7 +1763,8 @@ static double* svi_ptr(svihmm_ctx* h, int which) {
     case 2: return b + 2 * kk;           // var_init
     case 3: return b + 2 * kk + K;       // vlb
     case 4: return b + 2 * kk + 2 * K;   // logdet
-    default: return b + 2 * kk + 3 * K;  // prior_logpart
+    case 5: return b + 2 * kk + 3 * K;   // prior_logpart
+    default: return b + 2 * kk + 4 * K;  // rowterm (Dirichlet terms of the transition rows)
   }
 }
 static int svi_globals(svihmm_ctx* h) {
@@ -1780,15 +1781,21 @@ static int svi_globals(svihmm_ctx* h) {
     HIPCK(hipMemsetAsync((char*)h->AexpT.p + kk, 0, slack, h->stream));
     h->slack_a = h->Aexp.p; h->slack_t = h->AexpT.p; h->slack_k = K;
   }
-  const size_t work = 2 * kk;
+  const size_t work = 2 * (size_t)K * (K | 1) * sizeof(double);
   const int use_lds = work + 9 * 1024 <= 150 * 1024;
   if (!use_lds) CK(ensure(h->svi_work, work));
-  if (use_lds && work > 48 * 1024)
-    hipFuncSetAttribute((const void*)k_svi_globals, hipFuncAttributeMaxDynamicSharedMemorySize, (int)work);
   ProfScope ps(h, KS_MISC);
-  hipLaunchKernelGGL(k_svi_globals, dim3(1), dim3(1024), use_lds ? work : 0, h->stream,
-                     (const double*)svi_ptr(h, 0), K, (double*)h->svi_work.p, use_lds, (double*)h->ltran.p,
-                     (double*)h->Aexp.p, (double*)h->AexpT.p, svi_ptr(h, 2), (double*)h->mod_init.p);
+  if (use_lds) {
+    if (work > 48 * 1024)
+      hipFuncSetAttribute((const void*)k_svi_globals<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)work);
+    hipLaunchKernelGGL(k_svi_globals<true>, dim3(1), dim3(512), work, h->stream, (const double*)svi_ptr(h, 0), K,
+                       (double*)nullptr, (double*)h->ltran.p, (double*)h->Aexp.p, (double*)h->AexpT.p,
+                       svi_ptr(h, 2), (double*)h->mod_init.p);
+  } else {
+    hipLaunchKernelGGL(k_svi_globals<false>, dim3(1), dim3(512), 0, h->stream, (const double*)svi_ptr(h, 0), K,
+                       (double*)h->svi_work.p, (double*)h->ltran.p, (double*)h->Aexp.p, (double*)h->AexpT.p,
+                       svi_ptr(h, 2), (double*)h->mod_init.p);
+  }
   HIPCK(hipGetLastError());
   h->K = K; h->have_globals = true; h->lin_stale = true;
   return 0;
@@ -1799,10 +1806,11 @@ static int svi_refresh_emission(svihmm_ctx* h) {
   CK(launch_niw_to_theta(h, K, D, svi_ptr(h, 4)));
   h->lin_stale = true;
   ProfScope ps(h, KS_MISC);
-  hipLaunchKernelGGL(k_svi_vlb, dim3(K), dim3(64), 0, h->stream, (const double*)h->theta.p,
+  hipLaunchKernelGGL(k_svi_vlb, dim3(2 * K), dim3(64), 0, h->stream, (const double*)h->theta.p,
                      (const int*)h->fab.p, h->F, D, h->Kp, (const double*)h->niw.p,
                      (const double*)svi_ptr(h, 4), (const double*)h->svi_prior.p,
-                     (const double*)svi_ptr(h, 5), h->svi_zsign, K, svi_ptr(h, 3));
+                     (const double*)svi_ptr(h, 5), h->svi_zsign, K, svi_ptr(h, 3),
+                     (const double*)svi_ptr(h, 1), (const double*)svi_ptr(h, 0), svi_ptr(h, 6));
   HIPCK(hipGetLastError());
   return 0;
 }
@@ -1820,7 +1828,16 @@ int svihmm_svi_begin(svihmm_ctx* h, int32_t K, int32_t D, const double* prior_tr
   const size_t kk = (size_t)K * K, nmu = (size_t)K * D, nsg = (size_t)K * D * D;
   const size_t nin = nmu + nsg + 2 * (size_t)K;
   h->svi_K = K; h->svi_D = D; h->svi_maxit = maxit; h->svi_zsign = zsign;
-  CK(ensure(h->svi_state, (2 * kk + 4 * (size_t)K + 8) * sizeof(double)));
+  {   // sum_i [lgamma(sum_j p_ij + eps) - sum_j lgamma(p_ij + eps)]: the prior-only part of the rows' energy
+    double pc = 0.0;
+    for (int i = 0; i < K; ++i) {
+      double rsum = 0.0, lg = 0.0;
+      for (int j = 0; j < K; ++j) { const double p = prior_tran[(size_t)i * K + j]; rsum += p; lg += std::lgamma(p + 1e-9); }
+      pc += std::lgamma(rsum + 1e-9) - lg;
+    }
+    h->svi_prior_const = pc;
+  }
+  CK(ensure(h->svi_state, (2 * kk + 5 * (size_t)K + 8) * sizeof(double)));
   CK(ensure(h->svi_prior, (nin + 8) * sizeof(double)));
   CK(ensure(h->niw, nin * sizeof(double) + 64));
   // one staging slot: [var_tran | prior_tran | prior_logpart | prior block | niw block]
@@ -1902,8 +1919,8 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
     double* delbo = nullptr;
     HIPCK(hipHostGetDevicePointer((void**)&delbo, h->svi_elbo, 0));
     const double* lb = (const double*)h->packed.p + (packed_len(h) - 1);
-    hipLaunchKernelGGL(k_svi_elbo, dim3(1), dim3(256), 0, h->stream, (const double*)svi_ptr(h, 1),
-                       (const double*)svi_ptr(h, 0), K, (const double*)svi_ptr(h, 3), lb, delbo + it);
+    hipLaunchKernelGGL(k_svi_elbo, dim3(1), dim3(64), 0, h->stream, K, (const double*)svi_ptr(h, 3),
+                       (const double*)svi_ptr(h, 6), h->svi_prior_const, lb, delbo + it);
     HIPCK(hipGetLastError());
   }
   HIPCK(hipEventRecord(h->svi_ev[it + 1], h->stream));

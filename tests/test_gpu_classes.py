@@ -222,3 +222,46 @@ def test_ffbs_lalpha_init_branch_on_gpu():
     zref = R.ffbs_backward_sample(la, A, u)
     np.testing.assert_array_equal(z, zref)
     e.close()
+
+
+@pytest.mark.parametrize("K,D,B,Lm", [(3, 2, 5, 21), (64, 4, 9, 33), (100, 3, 6, 17), (20, 5, 210, 9)])
+def test_svi_iteration_engine_level(K, D, B, Lm):
+    """svihmm_svi_begin / svihmm_svi_iteration against the reference arithmetic, iteration by
+    iteration (oracle engine: np.linalg.eig stationary vector, psi, serial minibatch loop,
+    global_update, global_lower_bound): K = 100 takes the global-scratch instantiation of
+    k_svi_globals, B = 210 the MFMA sweeps."""
+    from oracle.engine import OracleEngine
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd.distributions import niw_prior_logpart
+    from pysvihmm_amd import _lib as L
+    from tests.helpers import make_problem
+    T = 4000
+    pb = make_problem(K, D, T, seed=K + D, miss=0.05)
+    rng = np.random.default_rng(K)
+    prior_tran = 0.5 + rng.random((K, K))
+    mu0 = np.tile(pb["obs"].mean(0), (K, 1)) + 0.1 * rng.normal(size=(K, D))
+    sg0 = np.tile(0.75 * np.cov(pb["obs"].T).reshape(D, D), (K, 1, 1))
+    ka0, nu0 = np.full(K, 0.01), np.full(K, D + 2.0)
+    prior = (mu0, sg0, ka0, nu0)
+    factors = (pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    bA, bE = (T - 2 * 8 - 1) / (2. * 8 * B), (T - 2 * 8 - 1) / ((2. * 8 + 1) * B)
+    res = []
+    for eng in (HipEngine(0), OracleEngine()):
+        eng.set_obs(pb["obs"], pb["mask"])
+        eng.svi_begin(prior_tran, pb["var_tran"], prior, factors, niw_prior_logpart(sg0, nu0), 3, 1.0)
+        r2 = np.random.default_rng(5)
+        for it in range(3):
+            starts = r2.integers(0, T - Lm, size=B)
+            flags = L.TRANS_WRAP | (L.SVI_KEEP_WINDOW if it == 2 else 0)
+            eng.svi_iteration(it, starts, B, Lm, flags, (it + 1.0) ** -0.7, bA, bE)
+        elbo, ms = eng.svi_read_elbo(3)
+        res.append((eng.svi_read_state(), elbo, eng.read_rows("lalpha", (B - 1) * Lm, Lm),
+                    eng.read_rows("var_x", (B - 1) * Lm, Lm)))
+        eng.close()
+    (sa, ea, la, qa), (sb, eb, lb, qb) = res
+    names = ("var_tran", "var_init", "mu", "sigma", "kappa", "nu")
+    for n, a, b in zip(names, sa, sb):
+        np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-9, err_msg=n)
+    np.testing.assert_allclose(ea, eb, rtol=1e-9)
+    np.testing.assert_allclose(la, lb, rtol=1e-9, atol=1e-7)
+    np.testing.assert_allclose(qa, qb, rtol=1e-6, atol=1e-11)
