@@ -9,7 +9,7 @@
 #define SVI_EPS 1e-9     // the reference's eps (hmmbase.py:30) inside digamma / gammaln
 
 // ------------------------------------------------------------------------------------
-//  G1: globals of an iteration, one workgroup of 512 threads.
+//  G1: globals of an iteration, K + 1 workgroups of 512 threads.
 //    (a) psi-expectations of the transition factor (hmmsgd_metaobs.py:502-504):
 //          ltran[i][j] = psi(var_tran[i][j] + eps) - psi(sum_j var_tran[i][j] + eps),
 //        plus exp(ltran) and its transpose for the scaled sweeps (what k_exp_transpose makes
@@ -24,8 +24,8 @@
 //        vector goes into psi as if it were Dirichlet parameters).
 //  `work` = 2 K (K|1) doubles (LDS when they fit, else global scratch).
 // ------------------------------------------------------------------------------------
-template <bool LDSW>
-__global__ __launch_bounds__(512) void k_svi_globals(
+template <bool LDSW, int NWV>
+__global__ __launch_bounds__(64 * NWV) void k_svi_globals(
     const double* __restrict__ var_tran, int K, double* __restrict__ work_g,
     double* __restrict__ ltran, double* __restrict__ Aexp, double* __restrict__ AexpT,
     double* __restrict__ var_init, double* __restrict__ mod_init) {
@@ -33,75 +33,177 @@ __global__ __launch_bounds__(512) void k_svi_globals(
   __shared__ double rs[1024];      // row sums, later the stationary vector (K <= 1024)
   __shared__ double psum[2][8];    // partial sums of the next pivot row (double-buffered)
   __shared__ double sc[4];
+  constexpr int NT = 64 * NWV, CPT = 64 / NWV;     // threads; register columns per thread (K <= 64 path)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6;
+  if ((int)blockIdx.x < K) {
+    // ---- (a) psi-expectations of transition row i = blockIdx.x: 4096 digamma / exp evaluations
+    // are ~40k cycles of fp64 work on one CU, so they are spread over K workgroups that run
+    // beside the elimination (the last workgroup)
+    const int i = blockIdx.x;
+    double s = 0.0;
+    for (int j = tid; j < K; j += NT) s += var_tran[(size_t)i * K + j];
+    s = wave_sum(s);
+    if (lane == 0) rs[w] = s;
+    __syncthreads();
+    double rsum = 0.0;
+    for (int u = 0; u < NWV; ++u) rsum += rs[u];
+    const double dgs = digamma_d(rsum + SVI_EPS);
+    for (int j = tid; j < K; j += NT) {
+      const size_t e = (size_t)i * K + j;
+      const double l = digamma_d(var_tran[e] + SVI_EPS) - dgs;
+      const double x = exp(l);
+      ltran[e] = l;
+      Aexp[e] = x;
+      AexpT[(size_t)j * K + i] = x;
+    }
+    return;
+  }
+  // ---- (b) stationary vector by GTH elimination, (c) mod_init: the last workgroup
   const int LD = K | 1;                            // odd row stride: a column walks all LDS banks
   // LDSW is a template parameter so that the LDS instantiation keeps ds_* instructions (a
   // run-time choice between the two spaces compiles to flat loads: 2x slower for this kernel)
   auto Pm = [&]() -> double* { if constexpr (LDSW) return svi_lds; else return work_g; };
   double* P = Pm();                                // [K][LD] working copy, then its reduced form
   double* Q = P + (size_t)K * LD;                  // [K][LD] scaled columns (back-substitution)
-  const int tid = threadIdx.x, NT = 512;
-  const int lane = tid & 63, w = tid >> 6;
-  // row sums (one wave per row, round-robin)
-  for (int i = w; i < K; i += 8) {
+  for (int i = w; i < K; i += NWV) {               // row sums (one wave per row, round-robin)
     double s = 0.0;
     for (int j = lane; j < K; j += 64) s += var_tran[(size_t)i * K + j];
     s = wave_sum(s);
     if (lane == 0) rs[i] = s;
   }
   __syncthreads();
-  for (int i = w; i < K; i += 8) {
-    const double rsum = rs[i], dgs = digamma_d(rsum + SVI_EPS);
-    for (int j = lane; j < K; j += 64) {
-      const size_t e = (size_t)i * K + j;
-      const double v = var_tran[e];
-      const double l = digamma_d(v + SVI_EPS) - dgs;
-      const double x = exp(l);
-      ltran[e] = l;
-      Aexp[e] = x;
-      AexpT[(size_t)j * K + i] = x;
-      P[(size_t)i * LD + j] = v / rsum;          // row-stochastic mean transition matrix
+  for (int e0 = 0; e0 < K * K; e0 += 8 * NT) {     // row-stochastic mean transition matrix
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * NT + tid;
+      v[u] = e < K * K ? var_tran[e] : 1.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * NT + tid;
+      if (e < K * K) {
+        const int i = e / K, j = e - i * K;
+        P[(size_t)i * LD + j] = v[u] / rs[i];
+      }
     }
   }
   __syncthreads();
-  // GTH: eliminate states K-1 .. 1.  Thread (r = tid / 8, c = tid % 8) owns columns c, c+8, ..
-  // of rows r, r+64, ..; one barrier per step (row n and column n are not written in step n).
-  // s_n = sum_{j<n} P[n][j] of the NEXT pivot row is gathered by that row's eight owners while
-  // they update it (psum), so a step costs one column element, n/8 fused updates and 8 reads.
-  const int r0 = tid >> 3, c0 = tid & 7;
-  if (r0 == ((K - 1) & 63)) {      // owners of row K-1 (rows r0, r0+64, ..: K-1 = r0 mod 64)
-    double s = 0.0;
-    for (int j = c0; j < K - 1; j += 8) s += P[(size_t)(K - 1) * LD + j];
-    psum[(K - 1) & 1][c0] = s;
-  }
-  __syncthreads();
-  for (int n = K - 1; n >= 1; --n) {
-    const double* __restrict__ rown = P + (size_t)n * LD;
-    const double* __restrict__ ps = psum[n & 1];
-    const double inv = 1.0 / (((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7])));
-    for (int i = r0; i < n; i += 64) {
-      double* __restrict__ rowi = P + (size_t)i * LD;
-      const double c = rowi[n] * inv;
-      double s = 0.0;
-      for (int j = c0; j < n; j += 8) {
-        const double v = fma(c, rown[j], rowi[j]);
-        rowi[j] = v;
-        s += (j < n - 1) ? v : 0.0;
+  if (K <= 64) {
+    // GTH with the matrix in registers (K <= 64): lane = column j, and a thread holds that
+    // column of the rows i = wave + NWV u.  Row conditions (i < n, "this is the next pivot row")
+    // are then wave-uniform: finished rows cost nothing, the pivot row's sum is one DPP
+    // reduction by its owner wave, which also leaves the reciprocal, and a step is: one LDS
+    // round trip (pivot row / column / reciprocal), <= CPT FMAs, one barrier.
+    __shared__ double prow[2][64], pcol[2][64], pinv[2];
+    double rv[CPT];
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+      const int i = w + NWV * u;
+      rv[u] = (i < K && lane < K) ? P[(size_t)i * LD + lane] : 0.0;
+    }
+    // n = K is a pseudo-step that only publishes row / column K-1
+    for (int n = K; n >= 1; --n) {
+      if (n < K) {
+        const int par = n & 1;
+        const double rn = lane < n ? prow[par][lane] : 0.0;
+        const double inv = pinv[par];
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+          const int i = w + NWV * u;
+          if (i < n) rv[u] = fma(pcol[par][i] * inv, rn, rv[u]);          // wave-uniform branch
+        }
+        if (w == (n % NWV) && lane < n) Q[(size_t)lane * LD + n] = pcol[par][lane] * inv;
       }
-      if (c0 == 0) Q[(size_t)i * LD + n] = c;
-      if (i == n - 1) psum[(n - 1) & 1][c0] = s;    // the next pivot row's partial sums
+      if (n > 1) {       // make row m / column m / 1 / (row m's sum) visible for step m
+        const int m = n - 1, par = m & 1;
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+          const int i = w + NWV * u;
+          if (i == m) {                                                   // wave-uniform
+            prow[par][lane] = rv[u];
+            const double s = wave_sum_dpp(lane < m ? rv[u] : 0.0);
+            if (lane == 0) pinv[par] = 1.0 / s;
+          }
+          if (i < m && lane == m) pcol[par][i] = rv[u];
+        }
+      }
+      __syncthreads();
+    }
+  } else {
+    // GTH: eliminate states K-1 .. 1.  Thread (row r = lane (+64, ..), column phase c = wave)
+    // owns columns c, c+8, .. of its rows: a wave's accesses to 64 different rows are 65 doubles
+    // apart (two lanes per LDS bank pair, the minimum for 8-byte words), the pivot row is a
+    // broadcast.  One barrier per step (row n and column n are not written in step n); the sum
+    // of the NEXT pivot row is gathered by its owners while they update it.
+    const int c0 = w;
+    {
+      double s = 0.0;
+      if (lane == ((K - 1) & 63))
+        for (int j = c0; j < K - 1; j += NWV) s += P[(size_t)(K - 1) * LD + j];
+      if (lane == ((K - 1) & 63)) psum[(K - 1) & 1][c0] = s;
     }
     __syncthreads();
+    for (int n = K - 1; n >= 1; --n) {
+      const double* __restrict__ rown = P + (size_t)n * LD;
+      const double* __restrict__ ps = psum[n & 1];
+      double tot = 0.0;
+      for (int u = 0; u < NWV; ++u) tot += ps[u];
+      const double inv = 1.0 / tot;
+      for (int i = lane; i < n; i += 64) {
+        double* __restrict__ rowi = P + (size_t)i * LD;
+        const double c = rowi[n] * inv;
+        double s = 0.0;
+        for (int jb = c0; jb < n; jb += 4 * NWV) {        // four of this thread's columns per trip, loads first
+          double rn[4], rv[4];
+  #pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int j = jb + NWV * u, jc = j < n ? j : n;      // clamped to column n: read, never written
+            rn[u] = rown[jc];
+            rv[u] = rowi[jc];
+          }
+  #pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int j = jb + NWV * u;
+            const double v = fma(c, rn[u], rv[u]);
+            if (j < n) rowi[j] = v;
+            s += (j < n - 1) ? v : 0.0;
+          }
+        }
+        if (c0 == 0) Q[(size_t)i * LD + n] = c;
+        if (i == n - 1) psum[(n - 1) & 1][c0] = s;    // the next pivot row's partial sums
+      }
+      __syncthreads();
+    }
   }
-  // back-substitution: pi_0 = 1, pi_j = sum_{i<j} pi_i Q[i][j]   (one wave, lane-strided)
+  // back-substitution: pi_0 = 1, pi_j = sum_{i<j} pi_i Q[i][j]
   if (tid < 64) {
-    if (lane == 0) rs[0] = 1.0;
-    for (int j = 1; j < K; ++j) {
-      double s = 0.0;
-      for (int i = lane; i < j; i += 64) s = fma(rs[i], Q[(size_t)i * LD + j], s);
-      s = wave_sum_dpp(s);
-      if (lane == 0) rs[j] = s;
+    if (K <= 64) {
+      // column-oriented: lane j accumulates pi_j; once pi_i is complete it is broadcast with a
+      // readlane and every later lane adds pi_i Q[i][j] (row i of Q: conflict-free, prefetchable)
+      double acc = lane == 0 ? 1.0 : 0.0;
+      double qn = (lane < K && 0 < lane) ? Q[lane] : 0.0;            // Q[0][lane]
+      for (int i = 0; i + 1 < K; ++i) {
+        const double qi = qn;
+        if (i + 2 < K) qn = (lane < K && i + 1 < lane) ? Q[(size_t)(i + 1) * LD + lane] : 0.0;
+        pin_all_lanes(acc);
+        const double pi_i = readlane_f64(acc, i);
+        acc = fma(pi_i, qi, acc);                                     // qi = 0 for lanes <= i
+      }
+      if (lane < K) rs[lane] = acc;
       __builtin_amdgcn_wave_barrier();
       __threadfence_block();
+    } else {
+      if (lane == 0) rs[0] = 1.0;
+      for (int j = 1; j < K; ++j) {
+        double s = 0.0;
+        for (int i = lane; i < j; i += 64) s = fma(rs[i], Q[(size_t)i * LD + j], s);
+        s = wave_sum_dpp(s);
+        if (lane == 0) rs[j] = s;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+      }
     }
     double n2 = 0.0, n1 = 0.0;
     for (int i = lane; i < K; i += 64) n2 = fma(rs[i], rs[i], n2);

@@ -1767,6 +1767,9 @@ static double* svi_ptr(svihmm_ctx* h, int which) {
     default: return b + 2 * kk + 4 * K;  // rowterm (Dirichlet terms of the transition rows)
   }
 }
+#ifndef SVI_GW
+#define SVI_GW 8      // wavefronts of the k_svi_globals workgroups
+#endif
 static int svi_globals(svihmm_ctx* h) {
   const int K = h->svi_K;
   const size_t kk = (size_t)K * K * sizeof(double);
@@ -1787,12 +1790,12 @@ static int svi_globals(svihmm_ctx* h) {
   ProfScope ps(h, KS_MISC);
   if (use_lds) {
     if (work > 48 * 1024)
-      hipFuncSetAttribute((const void*)k_svi_globals<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)work);
-    hipLaunchKernelGGL(k_svi_globals<true>, dim3(1), dim3(512), work, h->stream, (const double*)svi_ptr(h, 0), K,
+      hipFuncSetAttribute((const void*)k_svi_globals<true, SVI_GW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)work);
+    hipLaunchKernelGGL((k_svi_globals<true, SVI_GW>), dim3(K + 1), dim3(64 * SVI_GW), work, h->stream, (const double*)svi_ptr(h, 0), K,
                        (double*)nullptr, (double*)h->ltran.p, (double*)h->Aexp.p, (double*)h->AexpT.p,
                        svi_ptr(h, 2), (double*)h->mod_init.p);
   } else {
-    hipLaunchKernelGGL(k_svi_globals<false>, dim3(1), dim3(512), 0, h->stream, (const double*)svi_ptr(h, 0), K,
+    hipLaunchKernelGGL((k_svi_globals<false, SVI_GW>), dim3(K + 1), dim3(64 * SVI_GW), 0, h->stream, (const double*)svi_ptr(h, 0), K,
                        (double*)h->svi_work.p, (double*)h->ltran.p, (double*)h->Aexp.p, (double*)h->AexpT.p,
                        svi_ptr(h, 2), (double*)h->mod_init.p);
   }

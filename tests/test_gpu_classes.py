@@ -238,7 +238,7 @@ def test_svi_iteration_engine_level(K, D, B, Lm):
     T = 4000
     pb = make_problem(K, D, T, seed=K + D, miss=0.05)
     rng = np.random.default_rng(K)
-    prior_tran = 0.5 + rng.random((K, K))
+    prior_tran = 1.0 + rng.random((K, K))       # >= 1: var_tran stays positive (Dirichlet parameters)
     mu0 = np.tile(pb["obs"].mean(0), (K, 1)) + 0.1 * rng.normal(size=(K, D))
     sg0 = np.tile(0.75 * np.cov(pb["obs"].T).reshape(D, D), (K, 1, 1))
     ka0, nu0 = np.full(K, 0.01), np.full(K, D + 2.0)
