@@ -71,6 +71,24 @@ int svihmm_create(int device_id, svihmm_ctx** out);
 int svihmm_destroy(svihmm_ctx* h);
 int svihmm_sync(svihmm_ctx* h);
 
+/* ---- precision mode -----------------------------------------------------------------
+ * SVIHMM_F64 (default): the reference's own type throughout (hmmbase.py:102-103).
+ * SVIHMM_F32: north_star's second tolerance ("posteriors and natural gradients within 1e-3 fp32").
+ *   For the E-step fast path it covers -- NIW emissions, K <= 64, window batches (not the
+ *   whole-chain scan, not host-supplied lliks) -- the scaled emission likelihoods and the scaled
+ *   forward / backward messages are STORED as fp32 (half the HBM traffic of the sweeps) and the
+ *   expected-sufficient-statistics GEMM runs on v_mfma_f32_16x16x4_f32 (twice the matrix rate),
+ *   each row chunk accumulated in fp32 and the chunks reduced in fp64.  Two pieces stay fp64 on
+ *   purpose: the emission quadratic form (its expanded feature form cancels ~1e5 : 1, which
+ *   fp32 cannot carry) and the arithmetic of the recursion itself (exact binary exponents; the
+ *   launch is HBM-bound, not flop-bound).  Inputs and outputs of the ABI stay float64.
+ *   Calls outside that fast path run in fp64 regardless; svihmm_get_precision reports whether
+ *   the last E-step batch actually ran in the fp32 format. */
+#define SVIHMM_F64 0
+#define SVIHMM_F32 1
+int svihmm_set_precision(svihmm_ctx* h, int32_t mode);
+int svihmm_get_precision(svihmm_ctx* h, int32_t* mode_out, int32_t* last_batch_f32_out);
+
 /* ---- inputs ----------------------------------------------------------------- */
 /* obs[T,D], mask[T] (1 = missing, may be NULL): hmmbase.py:60-65,122-123.
  * Copied to HBM once; NaN entries are preserved. */

@@ -17,6 +17,7 @@ TRANS_WRAP = 2
 USE_HOST_LLIKS = 4
 KEEP_LBETA = 8
 SVI_KEEP_WINDOW = 16
+F64, F32 = 0, 1
 
 _lib = None
 
@@ -32,6 +33,8 @@ SIGNATURES = {
     "svihmm_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "svihmm_destroy": (C.c_int, [C.c_void_p]),
     "svihmm_sync": (C.c_int, [C.c_void_p]),
+    "svihmm_set_precision": (C.c_int, [C.c_void_p, C.c_int32]),
+    "svihmm_get_precision": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "svihmm_set_obs": (C.c_int, [C.c_void_p, _c_double_p, C.c_int64, C.c_int32, _c_uint8_p]),
     "svihmm_set_globals": (C.c_int, [C.c_void_p, C.c_int32, _c_double_p, _c_double_p]),
     "svihmm_set_emission_niw": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _c_double_p,

@@ -68,7 +68,8 @@ __global__ __launch_bounds__(EM_R) void k_emission_outer(
 template <int NT, int MT>
 __device__ __forceinline__ void emission_scaled_epilogue(
     const double (&outv)[MT][NT][4], const unsigned char* bad_s, int wave, int li, int lg,
-    int64_t g0, int64_t nrows, int K, int n0, double* __restrict__ ll, double* __restrict__ kexp) {
+    int64_t g0, int64_t nrows, int K, int n0, double* __restrict__ ll, double* __restrict__ kexp,
+    int st32 = 0) {
     // One exp per (row, state) is the algorithmic minimum of transcendental work on the
     // whole E-step; keep it lean: constants pinned in VGPRs, branch-free NaN/inf handling.
     ExpConsts ek;
@@ -97,10 +98,13 @@ __device__ __forceinline__ void emission_scaled_epilogue(
         mx = row16_max(mx);   // all lanes: the DPP reduction stays outside the store guards
         const double kx = (mx > -1e300 && mx < 1e300) ? ceil(mx * l2e) : 0.0;
         double* orow = ll + g * K + n0 + li;
+        float* orow32 = reinterpret_cast<float*>(ll) + g * K + n0 + li;   // fp32 mode: Eh stored as float
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           const double e = fast_exp_k(fma(kx, ek.c[13], fma(kx, ek.c[12], v[n])), ek);
-          if (g < nrows && n0 + n * 16 + li < K) orow[n * 16] = e;
+          if (g < nrows && n0 + n * 16 + li < K) {
+            if (st32) orow32[n * 16] = (float)e; else orow[n * 16] = e;      // uniform branch
+          }
         }
         if (li == 0 && g < nrows) kexp[g] = kx;
       }
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(256) void k_emission_mfma(
       for (int r = 0; r < 4; ++r) outv[m][n][r] = acc[m][n][r];
   __builtin_amdgcn_sched_barrier(0);
   if (SCALED) {
-    emission_scaled_epilogue<NT, MT>(outv, bad_s, wave, li, lg, g0, nrows, K, n0, ll, kexp);
+    emission_scaled_epilogue<NT, MT>(outv, bad_s, wave, li, lg, g0, nrows, K, n0, ll, kexp, (flags >> 16) & 1);
   } else {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -441,7 +445,7 @@ __global__ __launch_bounds__(256) void k_emission_orbit(
 #pragma unroll
       for (int r = 0; r < 4; ++r) outv[m][n][r] = acc[m][n][r];
   __builtin_amdgcn_sched_barrier(0);
-  emission_scaled_epilogue<NT, MT>(outv, bad_s, wave, li, lg, g0, nrows, K, 0, ll, kexp);
+  emission_scaled_epilogue<NT, MT>(outv, bad_s, wave, li, lg, g0, nrows, K, 0, ll, kexp, (flags >> 16) & 1);
 }
 
 // ------------------------------------------------------------------------------------

@@ -643,11 +643,11 @@ struct LinChain {
 // MODE 0: windows start from the initial distribution.  MODE 1: from chain.init_vec.
 // MODE 2: chunk matrices (unit initial vectors, all pseudo-windows read the chunk's rows,
 // nothing but the final matrix is stored; blockIdx.x = chunk * NW + row group).
-template <int NW, bool FULL, int MODE, bool BS = false>
+template <int NW, bool FULL, int MODE, bool BS = false, typename ST = double>
 __device__ __forceinline__ void fwd_lin_body(
-    LinShared<NW>& sh, const double* __restrict__ Eh, const double* __restrict__ kexp,
+    LinShared<NW>& sh, const ST* __restrict__ Eh, const double* __restrict__ kexp,
     const double* __restrict__ Aexp, const double* __restrict__ mod_init, int B, int Lm,
-    int wstride, int K, double* __restrict__ ah, double* __restrict__ hx,
+    int wstride, int K, ST* __restrict__ ah, double* __restrict__ hx,
     double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac,
     const LinChain& ch) {
   constexpr int KS = 4 * NW;
@@ -666,8 +666,8 @@ __device__ __forceinline__ void fwd_lin_body(
   }
   const double* __restrict__ Bcol = Aexp + jc;
   const size_t wrow = (size_t)L.b0 * wstride;
-  const double* __restrict__ Eb = Eh + wrow * K;
-  double* __restrict__ ab = ah + wrow * K;
+  const ST* __restrict__ Eb = Eh + wrow * K;
+  ST* __restrict__ ab = ah + wrow * K;
   double* __restrict__ hb = hx + wrow;
   const int i1 = Lm > 1 ? 1 : 0, i2 = Lm > 2 ? 2 : i1;
   double h[4], mant[4], hsum[4], ea[4], eb[4];
@@ -715,9 +715,9 @@ __device__ __forceinline__ void fwd_lin_body(
     double4_t acc, tot;
     if constexpr (BS) lin_matmul_stream<NW, FULL>(sh, CUR, li, lg, Bcol, K, acc, tot);
     else lin_matmul<NW>(sh, CUR, li, lg, Bv, acc, tot);
-    double* __restrict__ at = ab + (size_t)t * K;
+    ST* __restrict__ at = ab + (size_t)t * K;
     double* __restrict__ ht = hb + t;
-    const double* __restrict__ E2 = Eb + (size_t)t2 * K;
+    const ST* __restrict__ E2 = Eb + (size_t)t2 * K;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int e2 = __builtin_amdgcn_frexp_exp(tot[r]);
@@ -805,10 +805,10 @@ __device__ __forceinline__ void fwd_lin_body(
 // MODE 0: beta = 1 at the window's last row.  MODE 1 (chain chunks): the window has Lm rows
 // of which the top one is virtual -- it belongs to the next chunk and only supplies Eh and the
 // boundary vector chain.term_vec; nothing is stored for it.
-template <int NW, bool FULL, int MODE, bool BS = false>
+template <int NW, bool FULL, int MODE, bool BS = false, typename ST = double>
 __device__ __forceinline__ void bwd_lin_body(
-    LinShared<NW>& sh, const double* __restrict__ Eh, const double* __restrict__ AexpT, int B,
-    int Lm, int wstride, int K, double* __restrict__ bh, double* __restrict__ gx,
+    LinShared<NW>& sh, const ST* __restrict__ Eh, const double* __restrict__ AexpT, int B,
+    int Lm, int wstride, int K, ST* __restrict__ bh, double* __restrict__ gx,
     const LinChain& ch) {
   constexpr int KS = 4 * NW;
   LinLane<NW, FULL> L;
@@ -825,8 +825,8 @@ __device__ __forceinline__ void bwd_lin_body(
   }
   const double* __restrict__ Bcol = AexpT + jc;
   const size_t wrow = (size_t)L.b0 * wstride;
-  const double* __restrict__ Eb = Eh + wrow * K;
-  double* __restrict__ bb = bh + wrow * K;
+  const ST* __restrict__ Eb = Eh + wrow * K;
+  ST* __restrict__ bb = bh + wrow * K;
   double* __restrict__ gb = gx + wrow;
   const int top = Lm - 1;
   const int i1 = Lm > 1 ? top - 1 : top, i2 = Lm > 2 ? top - 2 : i1;
@@ -862,9 +862,9 @@ __device__ __forceinline__ void bwd_lin_body(
     double4_t acc, tot;
     if constexpr (BS) lin_matmul_stream<NW, FULL>(sh, CUR, li, lg, Bcol, K, acc, tot);
     else lin_matmul<NW>(sh, CUR, li, lg, Bv, acc, tot);
-    double* __restrict__ bt = bb + (size_t)t * K;
+    ST* __restrict__ bt = bb + (size_t)t * K;
     double* __restrict__ gt = gb + t;
-    const double* __restrict__ E2 = Eb + (size_t)t2 * K;
+    const ST* __restrict__ E2 = Eb + (size_t)t2 * K;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int e2 = __builtin_amdgcn_frexp_exp(tot[r]);
@@ -894,22 +894,24 @@ __device__ __forceinline__ void bwd_lin_body(
 // forward windows have Lm - 1 rows (the top row is the next chunk's), backward ones Lm with a
 // virtual top row.  MODE 3: the chain's last chunk (boundary initial vector, ordinary end).
 // MODE 2: grid (chunks * NW, 1), forward only (chunk matrices).
-template <int NW, bool FULL, int MODE, bool BS = false>
+// ST: storage type of Eh / ah / bh (float in the fp32 mode: the launch is HBM-bound, half the
+// bytes; the arithmetic of the recursion stays fp64 with its exact binary exponents).
+template <int NW, bool FULL, int MODE, bool BS = false, typename ST = double>
 __global__ __launch_bounds__(64 * NW) void k_sweeps_lin(
-    const double* __restrict__ Eh, const double* __restrict__ kexp,
+    const ST* __restrict__ Eh, const double* __restrict__ kexp,
     const double* __restrict__ Aexp, const double* __restrict__ AexpT,
     const double* __restrict__ mod_init, int B, int Lm, int wstride, int K,
-    double* __restrict__ ah, double* __restrict__ bh, double* __restrict__ hx,
+    ST* __restrict__ ah, ST* __restrict__ bh, double* __restrict__ hx,
     double* __restrict__ gx, double* __restrict__ local_lb, double* __restrict__ logz,
     double2* __restrict__ zfac, LinChain ch) {
   extern __shared__ double __attribute__((aligned(16))) lin_smem[];   // sizeof(LinShared<NW>)
   LinShared<NW>& sh = *reinterpret_cast<LinShared<NW>*>(lin_smem);
   if (blockIdx.y == 0)
-    fwd_lin_body<NW, FULL, (MODE == 3 ? 1 : MODE), BS>(sh, Eh, kexp, Aexp, mod_init, B,
+    fwd_lin_body<NW, FULL, (MODE == 3 ? 1 : MODE), BS, ST>(sh, Eh, kexp, Aexp, mod_init, B,
                                                    MODE == 1 ? Lm - 1 : Lm, wstride, K, ah, hx,
                                                    local_lb, logz, zfac, ch);
   else
-    bwd_lin_body<NW, FULL, (MODE == 1 ? 1 : 0), BS>(sh, Eh, AexpT, B, Lm, wstride, K, bh, gx, ch);
+    bwd_lin_body<NW, FULL, (MODE == 1 ? 1 : 0), BS, ST>(sh, Eh, AexpT, B, Lm, wstride, K, bh, gx, ch);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1103,12 +1105,12 @@ __global__ __launch_bounds__(64 * NW) void k_sweeps_lin2(
 // vmcnt instead of a full drain per step.  The exponent stream is written 64 steps at a time
 // (lane s & 63 keeps h_s; one coalesced store per 64 steps): 64 lanes storing one address
 // every step serialise in the memory pipeline.
-template <int KMAX, bool FULLK>
+template <int KMAX, bool FULLK, typename ST = double>
 __global__ __launch_bounds__(64) void k_wave_lin(
-    const double* __restrict__ Eh, const double* __restrict__ kexp,
+    const ST* __restrict__ Eh, const double* __restrict__ kexp,
     const double* __restrict__ Aexp, const double* __restrict__ AexpT,
-    const double* __restrict__ mod_init, int Lm, int K, double* __restrict__ ah,
-    double* __restrict__ bh, double* __restrict__ hx, double* __restrict__ gx,
+    const double* __restrict__ mod_init, int Lm, int K, ST* __restrict__ ah,
+    ST* __restrict__ bh, double* __restrict__ hx, double* __restrict__ gx,
     double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac) {
   __shared__ double p_s[2][64];
   const int b = blockIdx.x, j = threadIdx.x;
@@ -1122,8 +1124,8 @@ __global__ __launch_bounds__(64) void k_wave_lin(
 #pragma unroll
   for (int i = 0; i < KMAX; ++i) a[i] = (valid && i < K) ? Am[(size_t)i * K + jc] : 0.0;
   const size_t wrow = (size_t)b * Lm;
-  const double* __restrict__ Eb = Eh + wrow * K + jc;
-  double* __restrict__ ob = (fwd ? ah : bh) + wrow * K + jc;
+  const ST* __restrict__ Eb = Eh + wrow * K + jc;
+  ST* __restrict__ ob = (fwd ? ah : bh) + wrow * K + jc;
   double* __restrict__ xb = (fwd ? hx : gx) + wrow;
   auto rowof = [&](int s) { return fwd ? s : Lm - 1 - s; };
   double h = 0.0, mant = 1.0, hsum = 0.0;
@@ -1235,12 +1237,12 @@ __global__ __launch_bounds__(64) void k_wave_lin(
 //  Same inputs / outputs and the same arithmetic per element as k_wave_lin except for the
 //  association of the 64-term sum ((4 x 16) instead of (4 chains x 16)).
 // ------------------------------------------------------------------------------------
-template <int KMAX>
+template <int KMAX, typename ST = double>
 __global__ __launch_bounds__(256) void k_wave_lin4(
-    const double* __restrict__ Eh, const double* __restrict__ kexp,
+    const ST* __restrict__ Eh, const double* __restrict__ kexp,
     const double* __restrict__ Aexp, const double* __restrict__ AexpT,
-    const double* __restrict__ mod_init, int Lm, int K, double* __restrict__ ah,
-    double* __restrict__ bh, double* __restrict__ hx, double* __restrict__ gx,
+    const double* __restrict__ mod_init, int Lm, int K, ST* __restrict__ ah,
+    ST* __restrict__ bh, double* __restrict__ hx, double* __restrict__ gx,
     double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac) {
   constexpr int NI = KMAX / 4;                  // source states per wave
   __shared__ double p_s[4][2][64];              // wave-private copies of the entering vector
@@ -1257,8 +1259,8 @@ __global__ __launch_bounds__(256) void k_wave_lin4(
     a[i] = (valid && src < K) ? Am[(size_t)src * K + jc] : 0.0;
   }
   const size_t wrow = (size_t)b * Lm;
-  const double* __restrict__ Eb = Eh + wrow * K + jc;
-  double* __restrict__ ob = (fwd ? ah : bh) + wrow * K + jc;
+  const ST* __restrict__ Eb = Eh + wrow * K + jc;
+  ST* __restrict__ ob = (fwd ? ah : bh) + wrow * K + jc;
   double* __restrict__ xb = (fwd ? hx : gx) + wrow;
   auto rowof = [&](int s) { return fwd ? s : Lm - 1 - s; };
   double h = 0.0, mant = 1.0, hsum = 0.0;
@@ -1616,9 +1618,9 @@ __global__ __launch_bounds__(64) void k_chunk_ksum(const double* __restrict__ ke
 // posterior marginals from the scaled messages (API reads of var_x; the statistics GEMM
 // forms the same product in its staging threads and never needs this array).
 // One 16-lane row per (window, t) row.
-template <int KT>
+template <int KT, typename ST = double>
 __global__ __launch_bounds__(256) void k_lin_posterior(
-    const double* __restrict__ ah, const double* __restrict__ bh, const double* __restrict__ hx,
+    const ST* __restrict__ ah, const ST* __restrict__ bh, const double* __restrict__ hx,
     const double* __restrict__ gx, const double2* __restrict__ zfac, int64_t nrows, int Lm,
     int K, double* __restrict__ q) {
   const int li = threadIdx.x & 15;
@@ -1629,7 +1631,7 @@ __global__ __launch_bounds__(256) void k_lin_posterior(
 #pragma unroll
   for (int c = 0; c < KT; ++c) {
     const int k = li + 16 * c;
-    if (k < K) q[g * K + k] = (ah[g * K + k] * bh[g * K + k]) * s;
+    if (k < K) q[g * K + k] = ((double)ah[g * K + k] * (double)bh[g * K + k]) * s;
   }
 }
 

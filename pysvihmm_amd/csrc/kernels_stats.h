@@ -246,13 +246,30 @@ struct StRow4 {
 // TRONLY (K > 64): only the transition statistic sum_t q[t-1, pbase + i] q[t, kbase + j] of
 // one 64 x 64 block of (previous state, state) pairs: blockIdx.y = previous-state group,
 // blockIdx.z = state group, the m-tiles are the 64 q[prev] columns, no obs staging.
-template <int MT, int NTW, int NSPLIT, int XK, bool LIN, bool TRONLY = false>
+// CT: arithmetic type of the GEMM (LDS tiles, MFMA operands and accumulators): double =
+// v_mfma_f64_16x16x4_f64, float = v_mfma_f32_16x16x4_f32 (the fp32 mode: twice the matrix rate,
+// half the LDS traffic; a chunk's sums are accumulated in fp32 and leave as fp64 partials).
+// ST: storage type of the scaled messages q = ah and bh (LIN) as the sweeps wrote them.
+template <typename T> struct MF;
+template <> struct MF<double> {
+  typedef double4_t v4;
+  static __device__ __forceinline__ v4 mma(double a, double b, v4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int crow(int lg, int r) { return lg + 4 * r; }    // C row of register r
+};
+typedef float float4_mf __attribute__((ext_vector_type(4)));
+template <> struct MF<float> {
+  typedef float4_mf v4;
+  static __device__ __forceinline__ v4 mma(float a, float b, v4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int crow(int lg, int r) { return 4 * lg + r; }
+};
+template <int MT, int NTW, int NSPLIT, int XK, bool LIN, bool TRONLY = false, typename CT = double,
+          typename ST = double>
 __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
     const double* __restrict__ obs, const uint8_t* __restrict__ mask,
     const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K, int Fp, int F,
-    const int* __restrict__ fab, const double* __restrict__ q, int64_t rows_per_chunk,
+    const int* __restrict__ fab, const ST* __restrict__ q, int64_t rows_per_chunk,
     uint32_t flags, int Lq, int off, double* __restrict__ part, int KpTot, int mt_limit,
-    const double* __restrict__ bh, const double* __restrict__ hx, const double* __restrict__ gx,
+    const ST* __restrict__ bh, const double* __restrict__ hx, const double* __restrict__ gx,
     const double2* __restrict__ zfac) {
   static_assert(ST_RB == 32, "row permutation assumes 32-row stages");
   constexpr int NT = NTW * NSPLIT;
@@ -265,9 +282,10 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
   // columns of the A-operand tile: [0,D) x | D: 1 (0 on masked rows) | D+1 ZERO | D+2 ONE | QP0+i: q[prev][i]
   const int ZERO = D + 1, ONE = D + 2, QP0 = D + 3;
   const int C = QP0 + Kp;
-  double* rb0 = smem;                      // [C][67]
-  double* qs0 = rb0 + C * ST_CC;           // [2][32][QS]
-  StRow4* rinfo = reinterpret_cast<StRow4*>(qs0 + 2 * ST_RB * QS);  // [4][32]
+  CT* rb0 = reinterpret_cast<CT*>(smem);   // [C][67]
+  CT* qs0 = rb0 + C * ST_CC;               // [2][32][QS]
+  StRow4* rinfo = reinterpret_cast<StRow4*>(     // [4][32], 8-byte aligned behind the tiles
+      smem + (((size_t)(C * ST_CC + 2 * ST_RB * QS) * sizeof(CT) + 7) / 8));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int mg = wave & 3, ng = wave >> 2;
@@ -294,11 +312,11 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
     oa[m] = fa * ST_CC + lg * 8; ob[m] = fb * ST_CC + lg * 8;
   }
   const int obq = lg * QS + nt0 * 16 + li;   // B operand: qs[(4ks+lg)*QS + (nt0+n)*16 + li]
-  double4_t acc[MT][NTW];
+  typename MF<CT>::v4 acc[MT][NTW];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int n = 0; n < NTW; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int n = 0; n < NTW; ++n) acc[m][n] = (typename MF<CT>::v4){0, 0, 0, 0};
 
   const int64_t c0 = (int64_t)blockIdx.x * rows_per_chunk;
   const int64_t c1 = imin64(nrows, c0 + rows_per_chunk);
@@ -308,10 +326,10 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
   const int64_t bw0 = c0 / Lm;
   const unsigned t0 = (unsigned)(c0 - bw0 * Lm);
   const int64_t Q0 = bw0 * Lq + off;
-  const double* __restrict__ qthr = q + Q0 * K + kbase + sc;   // per-thread bases
-  const double* __restrict__ bthr = LIN ? bh + Q0 * K + kbase + sc : nullptr;
-  const double* __restrict__ pthr = q + Q0 * K + pbase + sc;
-  const double* __restrict__ bpthr = LIN ? bh + Q0 * K + pbase + sc : nullptr;
+  const ST* __restrict__ qthr = q + Q0 * K + kbase + sc;   // per-thread bases
+  const ST* __restrict__ bthr = LIN ? bh + Q0 * K + kbase + sc : nullptr;
+  const ST* __restrict__ pthr = q + Q0 * K + pbase + sc;
+  const ST* __restrict__ bpthr = LIN ? bh + Q0 * K + pbase + sc : nullptr;
 
   // ---- row bookkeeping, three stages ahead, in phases; threads 0..31
   unsigned ri_bwr = 0, ri_t = 0;
@@ -413,7 +431,7 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
       for (int k = 0; k < XK; ++k) {
         const int c = sc + TPR * k;
         const double v = c < D ? rx[k] : (c == D ? 1.0 : 0.0);
-        rb0[xwi[k] + U * ST_CS] = okx ? v : 0.0;
+        rb0[xwi[k] + U * ST_CS] = (CT)(okx ? v : 0.0);
       }
     }
     // Padded state columns (k >= K) are not masked: they read finite neighbours (the
@@ -422,20 +440,20 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
 #pragma unroll
     for (int k = 0; k < QK; ++k) {
       const double v = LIN ? (rq[k] * rq2[k]) * rsq : (okq ? rq[k] : 0.0);
-      qs0[U * ST_RB * QS + qwi + TPR * k] = v;
+      qs0[U * ST_RB * QS + qwi + TPR * k] = (CT)v;
     }
     if (need_qp) {
 #pragma unroll
       for (int k = 0; k < QK; ++k) {
         const double v = LIN ? (rp[k] * rp2[k]) * rsp : (okp ? rp[k] : 0.0);
-        rb0[pwi + U * ST_CS + TPR * k * ST_CC] = v;
+        rb0[pwi + U * ST_CS + TPR * k * ST_CC] = (CT)v;
       }
     }
   };
   // constant columns of both buffers
   if (sc == 0) {
-    rb0[ZERO * ST_CC + psr] = 0.0; rb0[ONE * ST_CC + psr] = 1.0;
-    rb0[ZERO * ST_CC + ST_CS + psr] = 0.0; rb0[ONE * ST_CC + ST_CS + psr] = 1.0;
+    rb0[ZERO * ST_CC + psr] = (CT)0; rb0[ONE * ST_CC + psr] = (CT)1;
+    rb0[ZERO * ST_CC + ST_CS + psr] = (CT)0; rb0[ONE * ST_CC + ST_CS + psr] = (CT)1;
   }
   const bool roleB = wave >= 4;   // the second wave of each SIMD
   row_info(0, 0);
@@ -456,15 +474,15 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
       if (st + 1 < nstage) commit(std::integral_constant<int, 1 - CUR>{});
       if (st + 2 < nstage) fetch((st + 2) & 3);
     }
-    const double* qs = qs0 + CUR * ST_RB * QS + obq;
-    double Bv[NTW], Ax[MT], Ay[MT];
+    const CT* qs = qs0 + CUR * ST_RB * QS + obq;
+    CT Bv[NTW], Ax[MT], Ay[MT];
 #pragma unroll
     for (int n = 0; n < NTW; ++n) Bv[n] = qs[n * 16];
 #pragma unroll
     for (int m = 0; m < MT; ++m) { Ax[m] = rb0[oa[m] + UO]; Ay[m] = rb0[ob[m] + UO]; }
 #pragma unroll
     for (int ks = 0; ks < ST_RB / 4; ++ks) {
-      double Bn[NTW], Axn[MT], Ayn[MT];
+      CT Bn[NTW], Axn[MT], Ayn[MT];
       if (ks + 1 < ST_RB / 4) {
 #pragma unroll
         for (int n = 0; n < NTW; ++n) Bn[n] = qs[(ks + 1) * 4 * QS + n * 16];
@@ -473,10 +491,9 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
       }
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const double A = Ax[m] * Ay[m];
+        const CT A = Ax[m] * Ay[m];
 #pragma unroll
-        for (int n = 0; n < NTW; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(A, Bv[n], acc[m][n], 0, 0, 0);
+        for (int n = 0; n < NTW; ++n) acc[m][n] = MF<CT>::mma(A, Bv[n], acc[m][n]);
       }
       if (ks + 1 < ST_RB / 4) {
 #pragma unroll
@@ -510,12 +527,12 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
   for (int m = 0; m < MT; ++m) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int fl = (mt0 + m) * 16 + lg + 4 * r;
+      const int fl = (mt0 + m) * 16 + MF<CT>::crow(lg, r);
       const int f = TRONLY ? Fp + pbase + fl : fl;
       if (TRONLY ? (fl < 64 && pbase + fl < KpTot) : (f < Ftot && (mt0 + m) < mt_limit)) {
 #pragma unroll
         for (int n = 0; n < NTW; ++n)
-          part[((size_t)blockIdx.x * Ftot + f) * KpTot + kbase + (nt0 + n) * 16 + li] = acc[m][n][r];
+          part[((size_t)blockIdx.x * Ftot + f) * KpTot + kbase + (nt0 + n) * 16 + li] = (double)acc[m][n][r];
       }
     }
   }

@@ -68,6 +68,7 @@ static int fail(const std::string& m) { g_err = m; return 1; }
 // ------------------------------------------------------------------------------------
 //  host side
 // ------------------------------------------------------------------------------------
+#define SVIHMM_INT_ST32 0x10000u   // internal kernel flag: scaled emission output stored as float
 struct Buf {
   void* p = nullptr;
   size_t cap = 0;
@@ -169,6 +170,10 @@ struct svihmm_ctx {
   double* svi_elbo = nullptr; int svi_elbo_cap = 0;      // pinned + mapped: elbo_vec
   std::vector<hipEvent_t> svi_ev;                        // iteration boundaries (iter_time)
   bool svi_active = false;
+  // precision mode (svihmm_set_precision): 0 fp64, 1 fp32 (see the header); cur_f32: the batch in
+  // flight / the intermediates currently held are in the fp32 format
+  int prec = 0;
+  bool cur_f32 = false;
   // comm
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
@@ -271,6 +276,17 @@ static int check_emission_status(svihmm_ctx* h);
 static int pinned(svihmm_ctx* h, size_t bytes, void** out, int* slot_out);
 static int pull_small(svihmm_ctx* h, void* dst, const void* pin, size_t bytes);
 static int pin_release(svihmm_ctx* h, int slot);
+int svihmm_set_precision(svihmm_ctx* h, int32_t mode) {
+  if (!h || (mode != SVIHMM_F64 && mode != SVIHMM_F32)) return fail("svihmm_set_precision: mode must be SVIHMM_F64 or SVIHMM_F32");
+  h->prec = mode;
+  return 0;
+}
+int svihmm_get_precision(svihmm_ctx* h, int32_t* mode_out, int32_t* last_batch_f32_out) {
+  if (!h) return fail("svihmm_get_precision: NULL handle");
+  if (mode_out) *mode_out = h->prec;
+  if (last_batch_f32_out) *last_batch_f32_out = h->cur_f32 ? 1 : 0;
+  return 0;
+}
 int svihmm_sync(svihmm_ctx* h) {
   CK(set_device(h));
   HIPCK(hipStreamSynchronize(h->stream));
@@ -692,6 +708,7 @@ static int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool sc
   }
   if (!stream) stream = h->stream;
   const uint8_t* mk = h->have_mask ? (const uint8_t*)h->mask.p : nullptr;
+  if (scaled && h->cur_f32) flags |= SVIHMM_INT_ST32;
   ProfScope ps(h, KS_EMISSION, stream);
   if (h->emis_cat) {   // table lookup (scaled output: the caller adds the k_scale_ll pass)
     if (scaled) return fail("internal: Categorical emission has no fused scaled output");
@@ -927,6 +944,39 @@ static int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_
   double* llb = (double*)h->local_lb.p + b0;
   double* lz = (double*)h->logz.p + b0;
   ProfScope ps(h, KS_FB, stream);
+  if (h->cur_f32) {
+    // fp32 mode (K <= 64, b0 == 0): the same kernels instantiated for float storage
+    const float* Ef = (const float*)h->ll.p;
+    float* af = (float*)h->la.p;
+    float* bf = (float*)h->lb.p;
+    if (nb < LIN_WAVE_MAX && h->variant[7] != 2) {
+      dim3 gw((unsigned)nb, 2);
+#define WLF(KM, FK) hipLaunchKernelGGL((k_wave_lin<KM, FK, float>), gw, dim3(64), 0, stream, Ef, kx, (const double*)h->Aexp.p, \
+                                       (const double*)h->AexpT.p, (const double*)h->mod_init.p, Lm, K, af, bf, hx,   \
+                                       gx, llb, lz, zf)
+#define WL4F(KM) hipLaunchKernelGGL((k_wave_lin4<KM, float>), gw, dim3(256), 0, stream, Ef, kx, (const double*)h->Aexp.p, \
+                                    (const double*)h->AexpT.p, (const double*)h->mod_init.p, Lm, K, af, bf, hx, gx, \
+                                    llb, lz, zf)
+      if (K > 16 && nb <= LIN_WAVE4_MAX && h->variant[7] != 3) { if (K <= 32) WL4F(32); else WL4F(64); }
+      else if (K <= 16) WLF(16, false); else if (K <= 32) WLF(32, false);
+      else if (K == 64) WLF(64, true); else WLF(64, false);
+#undef WLF
+#undef WL4F
+    } else {
+      const LinChain none = {};
+#define SWF(NWV, F) hipLaunchKernelGGL((k_sweeps_lin<NWV, F, 0, false, float>), grid, dim3(64 * NWV),              \
+                                       sizeof(LinShared<NWV>), stream, Ef, kx, (const double*)h->Aexp.p,         \
+                                       (const double*)h->AexpT.p, (const double*)h->mod_init.p, nb, Lm, Lm, K,   \
+                                       af, bf, hx, gx, llb, lz, zf, none)
+      if (NW == 1) { if (full) SWF(1, true); else SWF(1, false); }
+      else if (NW == 2) { if (full) SWF(2, true); else SWF(2, false); }
+      else if (NW == 3) { if (full) SWF(3, true); else SWF(3, false); }
+      else { if (full) SWF(4, true); else SWF(4, false); }
+#undef SWF
+    }
+    HIPCK(hipGetLastError());
+    return 0;
+  }
   if (K <= 64 && nb < LIN_WAVE_MAX && h->variant[7] != 2) {
     // small batches: one wavefront per (window, direction)
     dim3 gw((unsigned)nb, 2);
@@ -997,9 +1047,14 @@ static int ensure_q(svihmm_ctx* h, int B, int Lm, hipStream_t stream) {
 #define PQ(KT) hipLaunchKernelGGL(k_lin_posterior<KT>, grid, dim3(256), 0, stream, (const double*)h->la.p, \
                                   (const double*)h->lb.p, (const double*)h->hx.p, (const double*)h->gx.p,   \
                                   (const double2*)h->zfac.p, n, Lm, K, (double*)h->q.p)
-  if (K <= 16) PQ(1); else if (K <= 32) PQ(2); else if (K <= 48) PQ(3); else if (K <= 64) PQ(4);
+#define PQF(KT) hipLaunchKernelGGL((k_lin_posterior<KT, float>), grid, dim3(256), 0, stream, (const float*)h->la.p, \
+                                   (const float*)h->lb.p, (const double*)h->hx.p, (const double*)h->gx.p,          \
+                                   (const double2*)h->zfac.p, n, Lm, K, (double*)h->q.p)
+  if (h->cur_f32) { if (K <= 16) PQF(1); else if (K <= 32) PQF(2); else if (K <= 48) PQF(3); else PQF(4); }
+  else if (K <= 16) PQ(1); else if (K <= 32) PQ(2); else if (K <= 48) PQ(3); else if (K <= 64) PQ(4);
   else if (K <= 128) PQ(8); else if (K <= 192) PQ(12); else PQ(16);
 #undef PQ
+#undef PQF
   HIPCK(hipGetLastError());
   h->q_valid = true;
   return 0;
@@ -1239,7 +1294,26 @@ static int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, in
       const int mt_limit = big ? Fp / 16 : mtiles;
       const int xk = (D + 1 + TPR - 1) / TPR;
       if (lds > 150 * 1024 || xk > 9 || (big && Kp % 64 != 0)) var = 2;
-      else {
+      else if (lin && h->cur_f32 && !big) {
+        // fp32 mode: float LDS tiles, v_mfma_f32_16x16x4_f32, ah / bh read as float
+        const size_t ldsf = ((size_t)(D + 3 + KpW) * ST_CC + 2 * (size_t)ST_RB * (KpW + 1)) * 4 + 8 +
+                            4 * ST_RB * sizeof(StRow4);
+        dim3 grid((unsigned)nchunk, (mt_limit + 4 * 5 - 1) / (4 * 5), 1);
+#define ST3F(NTW, NS, XKV)                                                                        \
+  do {                                                                                           \
+    if (ldsf > 64 * 1024)                                                                        \
+      hipFuncSetAttribute((const void*)k_stats_mfma4<5, NTW, NS, XKV, true, false, float, float>, \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);                \
+    hipLaunchKernelGGL((k_stats_mfma4<5, NTW, NS, XKV, true, false, float, float>), grid,        \
+                       dim3(256 * NS), ldsf, stream, (const double*)h->obs.p, mk, starts_dev, n, \
+                       Lm, D, K, Fp, F, (const int*)h->fab.p, (const float*)h->la.p, rpc, flags, \
+                       Lq, off, partv, Kp, mt_limit, (const float*)h->lb.p, hxv, gxv, zfv);      \
+  } while (0)
+#define ST3FX(NTW, NS) do { if (xk <= 1) ST3F(NTW, NS, 1); else if (xk <= 3) ST3F(NTW, NS, 3); else if (xk <= 5) ST3F(NTW, NS, 5); else ST3F(NTW, NS, 9); } while (0)
+        if (NTt == 4) ST3FX(2, 2); else if (NTt == 3) ST3FX(3, 1); else if (NTt == 2) ST3FX(2, 1); else ST3FX(1, 1);
+#undef ST3FX
+#undef ST3F
+      } else {
         dim3 grid((unsigned)nchunk, (mt_limit + 4 * 5 - 1) / (4 * 5), big ? Kp / 64 : 1);
 #define ST3L(NTW, NS, XKV, LN)                                                                    \
   do {                                                                                           \
@@ -1431,6 +1505,7 @@ static int prepare_ll(svihmm_ctx* h, const int64_t* starts, int B, int Lm, uint3
   const bool host_ll = flags & SVIHMM_USE_HOST_LLIKS;
   CK(check_windows(h, starts, B, Lm, !host_ll || need_obs_for_stats));
   if (starts) CK(upload_starts(h, starts, B));
+  h->cur_f32 = false;
   if (host_ll) {
     if (!h->have_host_ll || h->hostB != B || h->hostLm != Lm)
       return fail("SVIHMM_USE_HOST_LLIKS: no uploaded lliks of shape [B,Lm,K]");
@@ -1439,6 +1514,10 @@ static int prepare_ll(svihmm_ctx* h, const int64_t* starts, int B, int Lm, uint3
     // K <= 64: the emission kernel owns whole rows and writes (Eh, kexp) itself; wider
     // models take the plain kernel plus one scaling pass
     const bool two_pass = lin && (h->Kp > 64 || h->emis_cat);
+    // fp32 mode: scaled messages stored as float + fp32 statistics GEMM, for what the mode
+    // covers (NIW emission, K <= 64, window batches on the scaled sweeps); everything else
+    // runs as fp64
+    h->cur_f32 = lin && h->prec == 1 && !two_pass && !use_chain(h, B, Lm);
     CK(launch_emission(h, B, Lm, flags, lin && !two_pass));
     if (two_pass) CK(launch_scale_ll(h, B, Lm));
     h->have_host_ll = false;
@@ -1602,6 +1681,7 @@ static int estep_pipelined(svihmm_ctx* h, const int64_t* starts, int B, int Lm, 
   CK(ensure_stats(h, plan[0].nchunk + plan[1].nchunk));
   h->have_host_ll = false;
   h->lin_mode = true; h->lin_stale = false; h->last_host_ll = false; h->eh_in_llE = false; h->last_flags = flags;
+  h->cur_f32 = false;
   h->q_valid = false; h->curB = B;
   h->m_nb = 0; h->have_lb = true;
   hipStream_t A = h->stream, Bs = h->stream2;

@@ -53,11 +53,15 @@ class HipEngine(object):
 
     name = "hip"
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, dtype="f64"):
         self._lib = L.load()
         h = C.c_void_p()
         L.check(self._lib.svihmm_create(int(device), C.byref(h)), "svihmm_create")
         self._h = h
+        if dtype not in ("f64", "f32", np.float64, np.float32):
+            raise RuntimeError("dtype must be 'f64' or 'f32'")
+        if dtype in ("f32", np.float32):
+            self.set_precision("f32")
         self.device = int(device)
         self.T = self.D = self.K = 0
         self.V = 0            # > 0: Categorical emission with V symbols is active
@@ -81,6 +85,18 @@ class HipEngine(object):
 
     def sync(self):
         L.check(self._lib.svihmm_sync(self._h), "svihmm_sync")
+
+    def set_precision(self, dtype):
+        """'f64' (default) or 'f32': fp32 storage of the scaled messages + fp32 statistics GEMM on
+        the E-step fast path (see include/svihmm.h); inputs and outputs stay float64."""
+        mode = {"f64": L.F64, "f32": L.F32}[dtype]
+        L.check(self._lib.svihmm_set_precision(self._h, mode), "svihmm_set_precision")
+
+    def precision(self):
+        """(mode, whether the last E-step batch ran in the fp32 format)."""
+        m, u = C.c_int32(), C.c_int32()
+        L.check(self._lib.svihmm_get_precision(self._h, C.byref(m), C.byref(u)), "svihmm_get_precision")
+        return ("f32" if m.value == L.F32 else "f64"), bool(u.value)
 
     def on_next_mutation(self, callback):
         """Register a one-shot callback that runs before the next call that uploads parameters

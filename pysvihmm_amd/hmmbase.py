@@ -82,7 +82,7 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
 
     def __init__(self, obs, prior_init, prior_tran, prior_emit, mask=None,
                  init_init=None, init_tran=None, verbose=False, sts=None,
-                 engine=None, device=0):
+                 engine=None, device=0, dtype="f64"):
         self.verbose = verbose
         self.sts = sts
 
@@ -118,6 +118,7 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
         self.elbo = -np.inf
         self._engine = engine
         self._device = device
+        self._dtype = dtype       # "f64" (the reference's type) or "f32" (engine precision mode)
         self._obs_dirty = True
         self._lZ = None
 
@@ -126,7 +127,7 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
     def engine(self):
         if self._engine is None:
             from .engine import HipEngine
-            self._engine = HipEngine(self._device)  # raises without library/GPU
+            self._engine = HipEngine(self._device, dtype=getattr(self, "_dtype", "f64"))  # raises without library/GPU
             self._obs_dirty = True
         return self._engine
 

@@ -28,11 +28,11 @@ class VBHMM(VariationalHMMBase):
 
     def __init__(self, obs, prior_init, prior_tran, prior_emit, tau=tau0,
                  kappa=kappa0, mask=None, init_init=None, init_tran=None,
-                 epsilon=1e-8, maxit=100, verbose=False, sts=None, engine=None, device=0):
+                 epsilon=1e-8, maxit=100, verbose=False, sts=None, engine=None, device=0, dtype="f64"):
         super(VBHMM, self).__init__(obs, prior_init, prior_tran, prior_emit,
                                     mask=mask, init_init=init_init,
                                     init_tran=init_tran, verbose=verbose,
-                                    sts=sts, engine=engine, device=device)
+                                    sts=sts, engine=engine, device=device, dtype=dtype)
         self.batch = self.obs
         self.elbo = -np.inf
         self.tau = tau

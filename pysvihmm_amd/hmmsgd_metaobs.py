@@ -113,14 +113,14 @@ class VBHMM(VariationalHMMBase):
                  full_predprob=False, init_init=None, init_tran=None,
                  maxit=100, verbose=False, adagrad=False, metaobs_fun='unif',
                  seed=None, sts=None, fullpred_freq=10, fullpred_sched=None,
-                 growBuffer=False, bufferBudget=False, engine=None, device=0, comm=None):
+                 growBuffer=False, bufferBudget=False, engine=None, device=0, comm=None, dtype="f64"):
         np.random.seed(seed)
         self.seed = seed
 
         super(VBHMM, self).__init__(obs, prior_init, prior_tran,
                                     prior_emit, mask=mask, init_init=init_init,
                                     init_tran=init_tran, verbose=verbose,
-                                    sts=sts, engine=engine, device=device)
+                                    sts=sts, engine=engine, device=device, dtype=dtype)
 
         self.elbo = -np.inf
         self.tau = tau
