@@ -100,6 +100,25 @@ def algorithmic_flops(rows):
     }
 
 
+def effective_cores():
+    """Host cores this process may actually use: the cgroup CPU quota when there is one (the GPU
+    boxes expose 256 hardware threads but grant the container 16), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return n
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -335,6 +354,38 @@ def side_figures(eng, L, pb, step, barrier, obs_host, args):
     res["minibatch_s64"] = {"windows": 64, "ms_per_step": dt64 * 1e3, "value": 64 * LM * K / dt64,
                             "unit": "updates/s", "note": "E-step + statistics of 64 windows (engine calls only)"}
 
+    # 1b. the same epoch step in the fp32 mode (scaled messages stored as float, statistics GEMM on
+    #     v_mfma_f32_16x16x4_f32; emission quadratic form and recursion arithmetic stay fp64):
+    #     a second figure beside the fp64 headline, never the headline
+    try:
+        ref64 = step().buf.copy()
+        eng.set_precision("f32")
+        for _ in range(3):
+            out32 = step()
+        used = eng.precision()[1]
+        eng.profile(True); eng.profile_reset()
+        blocks = []
+        for _ in range(5):
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                out32 = step()
+            barrier()
+            blocks.append((time.perf_counter() - t0) / args.steps)
+        p32 = eng.profile_read(); eng.profile(False)
+        dt32 = float(np.median(blocks))
+        rows = (T // LM) * LM
+        scale = np.maximum(np.abs(ref64), 1e-6 * rows)
+        res["f32_mode"] = {"ms_per_step": dt32 * 1e3, "value": rows * K / dt32, "unit": "updates/s",
+                           "dtype": "f32 storage of Eh/ah/bh + f32 MFMA statistics; f64 emission and recursion arithmetic",
+                           "ran_in_f32_format": bool(used),
+                           "max_rel_err_vs_f64_statistics": float(np.max(np.abs(out32.buf - ref64) / scale)),
+                           "kernels_ms": {k: v[0] / v[1] for k, v in p32.items()}}
+    except Exception as e:
+        res["f32_mode"] = {"error": repr(e)}
+    finally:
+        eng.set_precision("f64")
+
     # 2. one SVI iteration through the class surface (north_star: "local_update/global_update
     #    loop"): hmmsgd_metaobs.VBHMM.infer, E-step + global natural-gradient step + ELBO
     if obs_host is not None:
@@ -412,7 +463,8 @@ def cpu_baselines(eng, L, pb, step, obs_host):
     res = {}
     B = T // LM
     starts = np.arange(B, dtype=np.int64) * LM
-    ncore = os.cpu_count() or 1
+    ncore = effective_cores()
+    nhw = os.cpu_count() or 1
     par = (pb["mod_init"], pb["ltran"], pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
     # (i) plain-C port, 1 core
     nwin = 320   # ~12 s of single-core work
@@ -424,18 +476,19 @@ def cpu_baselines(eng, L, pb, step, obs_host):
     res["cpu_baseline"] = {
         "value": nwin * LM * K / cdt, "unit": "updates/s", "cores": 1, "kind": "port",
         "sample": "first %d of the %d windows of the same workload (%.1f s); plain-C restatement of the "
-                  "reference's single-threaded K^2 log-add-exp recursions, host has %d cores"
-                  % (nwin, B, cdt, ncore),
+                  "reference's single-threaded K^2 log-add-exp recursions; the container may use %d of "
+                  "the host's %d hardware threads" % (nwin, B, cdt, ncore, nhw),
         "gpu_vs_port_max_rel_err": err}
     # (ii) the same port with the windows dealt to all host cores (OpenMP)
     nthr = ncore
-    nwin_all = min(B, max(nthr * 12, 640))
+    nwin_all = min(B, max(nthr * 20, 320))
     t0 = time.perf_counter()
     ref_all = ref_c.estep_minibatch(obs_host, None, starts[:nwin_all], LM, *par, flags=2, threads=nthr)
     adt = time.perf_counter() - t0
     res["cpu_baseline_all_cores"] = {
         "value": nwin_all * LM * K / adt, "unit": "updates/s", "cores": nthr, "kind": "port",
-        "sample": "first %d windows (%.1f s), OpenMP over windows on %d threads" % (nwin_all, adt, nthr)}
+        "sample": "first %d windows (%.1f s), OpenMP over windows on %d threads = the container's CPU "
+                  "quota (host: %d hardware threads)" % (nwin_all, adt, nthr, nhw)}
     if nwin_all >= B:
         chk = step()
         res["cpu_baseline_all_cores"]["gpu_vs_port_max_rel_err_all_windows"] = float(

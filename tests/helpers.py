@@ -66,3 +66,16 @@ def ffbs_draws_exact(z, lalpha, logA, u, tol=1e-12):
     margin = np.min(np.abs(c[:, :-1] - u[:, None]), axis=1) if K > 1 else np.ones(T)
     risky = margin <= tol
     return int(np.sum((want != z) & ~risky)), int(risky.sum())
+
+
+def effective_cores():
+    """Cores the process may really use (cgroup quota or affinity), for the oracle's thread count."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return n

@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.helpers import make_problem, unpack
+from tests.helpers import make_problem, unpack, effective_cores
 from tests.test_host_logic import emit_from_fixture
 
 pytestmark = pytest.mark.gpu
@@ -43,7 +43,7 @@ def test_f32_estep_vs_fp64_oracle(K, D, B, Lm):
     st = e.estep(starts, Lm, flags=L.TRANS_WRAP)
     assert e.precision() == ("f32", True)
     ref = ref_c.estep_minibatch(pb["obs"], pb["mask"], starts, Lm, pb["mod_init"], pb["ltran"], pb["mu"],
-                                pb["sigma"], pb["kappa"], pb["nu"], flags=2, threads=os.cpu_count() or 1)
+                                pb["sigma"], pb["kappa"], pb["nu"], flags=2, threads=effective_cores())
     A, xbar, neff, S, lb = unpack(ref, K, D)
     sc = B * Lm
     worst = max(_close(st.A_raw, A, sc, "A"), _close(st.neff, neff, sc, "neff"),
