@@ -38,8 +38,14 @@ DBL_EPSILON = float(np.finfo(np.float64).eps)
 def is_niw_gaussian(e):
     """Device fast path is keyed on the concrete emission family, mirroring the
     reference's ``type(self.var_emit[0]) is Gaussian`` dispatch
-    (hmmsgd_metaobs.py:887,1050)."""
-    return isinstance(e, Gaussian) or getattr(type(e), "svihmm_niw_fastpath", False)
+    (hmmsgd_metaobs.py:887,1050): ``Gaussian`` itself, subclasses that keep its
+    ``expected_log_likelihood`` (an override must be honoured, so such objects take the generic
+    plugin route: host ``expected_log_likelihood`` -> uploaded ``lliks``), or any class that opts in
+    with ``svihmm_niw_fastpath = True``."""
+    t = type(e)
+    if getattr(t, "svihmm_niw_fastpath", False):
+        return True
+    return isinstance(e, Gaussian) and t.expected_log_likelihood is Gaussian.expected_log_likelihood
 
 
 def dirichlet_elbo(prior, var):
@@ -138,8 +144,8 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
                 getattr(self, name)
         d = dict(self.__dict__)
         d.pop('_pending_rows', None)
-        d.pop('_prior_on_device', None)
         d.pop('_prior_stack', None)
+        d.pop('_host_lliks', None)
         d['_engine'] = None       # device handles are not picklable
         d['_obs_dirty'] = True
         return d
@@ -157,9 +163,12 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
 
     def _upload_obs(self, force=False):
         """obs/mask -> HBM (once; again after set_data / in-place edits flagged by
-        ``_obs_dirty``)."""
-        if force or self._obs_dirty:
-            self.engine.set_obs(self.obs, self.mask)
+        ``_obs_dirty``, or when another model has used the same engine since: the resident copy
+        belongs to whoever uploaded last)."""
+        eng = self.engine
+        if force or self._obs_dirty or getattr(eng, "_obs_owner", None) != id(self):
+            eng.set_obs(self.obs, self.mask)
+            eng._obs_owner = id(self)
             self._obs_dirty = False
 
     def _psi_expectations(self):
@@ -214,10 +223,10 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
                 # log det / trace / quadratic form of sigma_mf from the device (it factorises
                 # sigma_mf for the E-step anyway): the host-side batched solve of K D x D systems
                 # costs more than the device E-step of a 64-window minibatch
-                key = (id(eng), mu0.shape)
-                if getattr(self, "_prior_on_device", None) != key:
+                key = (id(self), id(ve), mu0.shape)      # the engine's prior copy belongs to one model
+                if getattr(eng, "_prior_owner", None) != key:
                     eng.set_emission_prior(mu0, sg0)
-                    self._prior_on_device = key
+                    eng._prior_owner = key
                 terms = eng.niw_vlb_terms(mu, sg, ka, nu)
             return float(np.sum(niw_vlb_batch(
                 mu, sg, ka, nu, mu0, sg0, ka0, nu0, terms=terms)))
@@ -257,6 +266,7 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
             for k, odist in enumerate(self.var_emit):
                 ll[b, :, k] = np.nan_to_num(odist.expected_log_likelihood(x))
         self.engine.set_lliks(ll)
+        self._host_lliks = ll
         return L.USE_HOST_LLIKS
 
     # -- ELBO ------------------------------------------------------------------------
@@ -289,12 +299,38 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
         self._upload_obs()
         self._push_globals()
         flags = self._push_emission()
+        if (type(self).forward_msgs is not VariationalHMMBase.forward_msgs
+                or type(self).backward_msgs is not VariationalHMMBase.backward_msgs):
+            # a subclass replaced the message passes ("Override this for specialized behavior",
+            # reference hmmbase.py:279,304): follow the reference's sequence literally
+            self._local_update_literal([0], self.T, flags)
+            return
         r = self.engine.forward_backward([0], self.T, flags=flags)
         self.lalpha = r["lalpha"][0]
         self.lbeta = r["lbeta"][0]
         self.var_x = r["var_x"][0]
         self._lZ = float(r["local_lb"][0])
         self.lliks = self.engine.read_intermediate("lliks", 1, self.T)[0]
+
+    def _local_update_literal(self, starts, Lm, flags, metaobs=None):
+        """lliks from the engine (or the uploaded host lliks), then ``self.forward_msgs()`` /
+        ``self.backward_msgs()`` as overridable hooks, posterior on the host
+        (reference hmmbase.py:219-229)."""
+        if flags & L.USE_HOST_LLIKS:
+            self.lliks = self._host_lliks[0]
+        else:
+            self.lliks = self.engine.loglik(starts, Lm, flags=flags)[0]
+        if metaobs is None:
+            self.forward_msgs()
+            self.backward_msgs()
+        else:
+            self.forward_msgs(metaobs)
+            self.backward_msgs(metaobs)
+        v = self.lalpha + self.lbeta
+        v = v - np.max(v, axis=1)[:, npa]
+        v = np.exp(v)
+        self.var_x = v / np.sum(v, axis=1)[:, npa]
+        self._lZ = None
 
     def forward_msgs(self, obs=None, mask=None):
         """lalpha from ``self.lliks, self.mod_init, self.mod_tran``

@@ -246,8 +246,9 @@ class VBHMM(VariationalHMMBase):
         attributes are filled in when the loop ends (and wherever the loop itself needs them on
         the host: adaptive L / buffer growth, ``full_predprob``, ``verbose``)."""
         np.random.seed(self.seed)
-        if (type(self).local_update is not VBHMM.local_update
-                or type(self).intermediate_pars is not VBHMM.intermediate_pars
+        if (any(getattr(type(self), n) is not getattr(VBHMM, n) for n in
+                ("local_update", "intermediate_pars", "intermediate_pars_buffer", "forward_msgs",
+                 "backward_msgs", "local_lower_bound"))
                 or not (self._niw_fastpath() or self._cat_fastpath())):
             # subclass overrides, or an emission family the device statistics kernels
             # do not know (the reference dispatches on the type too, :887,907):
@@ -550,6 +551,10 @@ class VBHMM(VariationalHMMBase):
         self._upload_obs()
         self._push_globals()
         flags = self._push_emission(windows=[loff], Lm=Lm)
+        if (type(self).forward_msgs is not VBHMM.forward_msgs
+                or type(self).backward_msgs is not VBHMM.backward_msgs):
+            self._local_update_literal([loff], Lm, flags, metaobs if metaobs is not None else MetaObs(loff, uoff))
+            return
         r = self.engine.forward_backward([loff], Lm, flags=flags)
         self.lalpha = r["lalpha"][0]
         self.lbeta = r["lbeta"][0]

@@ -279,3 +279,59 @@ def test_ffbs_lalpha_init_branch_samples_only():
     np.testing.assert_allclose(la, g["lalpha"], rtol=1e-9, atol=1e-8)   # the Cython module's lalpha
     with pytest.raises(RuntimeError):
         hmm.ffbs_fast(g["var_init"], lalpha_init=la[:-1], uniforms=u)
+
+
+def test_overridden_hooks_are_honoured():
+    """Round-1 advisor findings: (i) a Gaussian subclass that overrides expected_log_likelihood
+    must not be sent down the NIW device kernel; (ii) subclasses overriding forward_msgs /
+    backward_msgs (the reference's documented extension points, hmmbase.py:279,304) are called by
+    local_update; (iii) two models sharing one engine do not see each other's resident data."""
+    from pysvihmm_amd.hmmbase import is_niw_gaussian
+    g = np.load(META[1])
+    K = int(g["K"])
+
+    class Tempered(Gaussian):
+        def expected_log_likelihood(self, x):
+            return 0.5 * Gaussian.expected_log_likelihood(self, x)
+
+    class OptIn(Tempered):
+        svihmm_niw_fastpath = True
+
+    base = emit_from_fixture(g, K)[0]
+    t = Tempered(mu=base.mu, sigma=base.sigma, mu_0=base.mu_0, sigma_0=base.sigma_0, kappa_0=base.kappa_0, nu_0=base.nu_0)
+    assert is_niw_gaussian(base) and not is_niw_gaussian(t)
+    assert is_niw_gaussian(OptIn(mu=base.mu, sigma=base.sigma, mu_0=base.mu_0, sigma_0=base.sigma_0,
+                                 kappa_0=base.kappa_0, nu_0=base.nu_0))
+
+    calls = []
+
+    class Hooked(hmmsgd_metaobs.VBHMM):
+        def forward_msgs(self, metaobs=None):
+            calls.append("f")
+            hmmsgd_metaobs.VBHMM.forward_msgs(self, metaobs)
+
+        def backward_msgs(self, metaobs=None):
+            calls.append("b")
+            hmmsgd_metaobs.VBHMM.backward_msgs(self, metaobs)
+
+    mk = lambda cls, eng: cls(g["obs"].copy(), np.ones(K), g["prior_tran"], emit_from_fixture(g, K),
+                              metaobs_half=int(g["L"]), mb_sz=int(g["S"]), mask=g["mask"],
+                              init_tran=g["init_tran"], maxit=2, seed=3, engine=eng)
+    a, b = mk(Hooked, OracleEngine()), mk(hmmsgd_metaobs.VBHMM, OracleEngine())
+    a.infer()
+    b.infer()
+    assert calls.count("f") == calls.count("b") == 2 * int(g["S"])        # the literal loop ran
+    np.testing.assert_allclose(a.var_tran, b.var_tran, rtol=1e-9)
+    np.testing.assert_allclose(a.elbo_vec, b.elbo_vec, rtol=1e-9)
+    mo = hmmsgd_metaobs.MetaObs(20, 20 + 2 * int(g["L"]))
+    a.local_update(metaobs=mo); b.local_update(metaobs=mo)
+    np.testing.assert_allclose(a.var_x, b.var_x, rtol=1e-9, atol=1e-12)
+    # (iii) a shared engine: model d uploads other data in between
+    eng = OracleEngine()
+    c = mk(hmmsgd_metaobs.VBHMM, eng)
+    d = hmmsgd_metaobs.VBHMM(g["obs"][::-1].copy(), np.ones(K), g["prior_tran"], emit_from_fixture(g, K),
+                             metaobs_half=int(g["L"]), mb_sz=int(g["S"]), init_tran=g["init_tran"], maxit=1,
+                             seed=3, engine=eng)
+    x1 = c.full_local_update()
+    d.full_local_update()
+    np.testing.assert_array_equal(c.full_local_update(), x1)
