@@ -481,7 +481,7 @@ def cpu_baselines(eng, L, pb, step, obs_host):
         "gpu_vs_port_max_rel_err": err}
     # (ii) the same port with the windows dealt to all host cores (OpenMP)
     nthr = ncore
-    nwin_all = min(B, max(nthr * 20, 320))
+    nwin_all = min(B, max(nthr * 250, 320))      # ~10 s at 37 ms per window and core
     t0 = time.perf_counter()
     ref_all = ref_c.estep_minibatch(obs_host, None, starts[:nwin_all], LM, *par, flags=2, threads=nthr)
     adt = time.perf_counter() - t0

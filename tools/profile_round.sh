@@ -21,7 +21,13 @@ run() {  # name, rocprof args...
   python $ROOT/tools/rocpd_summary.py $db
 }
 run kt --kernel-trace --stats > $OUT/${TAG}_kernel_stats.txt
+# HBM counters on the headline workload alone (no side figures), fp64 and fp32 mode separately
+BENCH_ALL=$BENCH
+BENCH="python $ROOT/bench.py --steps 5 --warmup 2 --reps 2 --no-cpu-baseline --no-side"
 { run fetch --kernel-trace --pmc FETCH_SIZE; run write --kernel-trace --pmc WRITE_SIZE; } > $OUT/${TAG}_pmc_hbm.txt
+BENCH="python $ROOT/tools/f32_profile_workload.py"
+{ run fetch32 --kernel-trace --pmc FETCH_SIZE; run write32 --kernel-trace --pmc WRITE_SIZE; } > $OUT/${TAG}_pmc_hbm_f32.txt
+BENCH=$BENCH_ALL
 run sq --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS > $OUT/${TAG}_sq_counters.txt
 cd $ROOT && python bench.py 2>/dev/null | tail -1 > $OUT/${TAG}_bench.json
 tail -c 600 $OUT/${TAG}_bench.json
