@@ -274,7 +274,10 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
   static_assert(ST_RB == 32, "row permutation assumes 32-row stages");
   constexpr int NT = NTW * NSPLIT;
   constexpr int Kp = 16 * NT;
-  constexpr int QS = Kp + 1;
+  // q tile row stride: the four k-rows (lg) of a B-operand read must fall on different banks --
+  // one double apart for 8-byte words (16 lanes per LDS pass), 16 floats apart for 4-byte words
+  // (32 lanes per pass: lg = 0, 1 -> banks li, 16 + li)
+  constexpr int QS = sizeof(CT) == 4 ? Kp + 16 : Kp + 1;
   constexpr int TPR = 8 * NSPLIT;          // staging threads per row (block / 32)
   constexpr int QK = Kp / TPR;             // q columns per staging thread (exact)
   static_assert(QK * TPR == Kp, "staging split");

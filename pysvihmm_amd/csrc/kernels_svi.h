@@ -236,11 +236,14 @@ __global__ __launch_bounds__(64 * NWV) void k_svi_globals(
 __global__ __launch_bounds__(256) void k_svi_global_step(
     const double* __restrict__ packed, const double* __restrict__ prior_tran, double* __restrict__ var_tran,
     double* __restrict__ niw, const double* __restrict__ prior, int K, int D, double rho, double bA,
-    double bE, double nwin) {
+    double bE, double nwin, double* __restrict__ lb_keep) {
   const size_t nmu = (size_t)K * D, nsg = (size_t)K * D * D;
   const int tid = threadIdx.x;
   if ((int)blockIdx.x >= K) {
     const int e = ((int)blockIdx.x - K) * 256 + tid;
+    // the minibatch's local bound, kept for the ELBO kernel (which runs on a side stream while
+    // the next E-step already rewrites `packed`)
+    if (e == 0) *lb_keep = packed[(size_t)K * K + nmu + K + nsg];
     if (e < K * K) {
       const double a_inter = packed[e] + nwin * (prior_tran[e] - 1.0);
       const double nat_old = var_tran[e] - 1.0;

@@ -152,7 +152,8 @@ struct svihmm_ctx {
   // variants: [0] emission (0 auto,1 outer,2 mfma) [1] stats (0 auto,1 outer,2 mfma,3 pipelined)
   // [2] sweeps (0 auto,1 wave,2 log-MFMA,3 scaled) [3] emission row tiles
   // [4] two-stream E-step pipeline (0 auto,1 off,2 on)
-  int variant[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // [8] row chunks of the statistics GEMM (0 = automatic)
+  int variant[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   // second stream + events of the pipelined E-step (created on first use)
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_em[2] = {nullptr, nullptr}, ev_sw[2] = {nullptr, nullptr};
@@ -170,6 +171,12 @@ struct svihmm_ctx {
   double* svi_elbo = nullptr; int svi_elbo_cap = 0;      // pinned + mapped: elbo_vec
   std::vector<hipEvent_t> svi_ev;                        // iteration boundaries (iter_time)
   bool svi_active = false;
+  hipEvent_t svi_ea = nullptr, svi_eb = nullptr, globals_ev = nullptr;   // side-stream globals kernel
+  hipEvent_t svi_ec = nullptr, svi_ed = nullptr;   // theta ready / side-stream ELBO kernels done
+  hipStream_t stream3 = nullptr;                   // the ELBO kernels' own stream
+  bool vlb_pending = false;
+  bool svi_globals_ready = false;   // Aexp / mod_init / var_init[slot] of the NEXT iteration are computed (or in flight)
+  int svi_globals_slot = 0, svi_vi_cur = 0;   // var_init slot the pending globals write / the last iteration used
   // precision mode (svihmm_set_precision): 0 fp64, 1 fp32 (see the header); cur_f32: the batch in
   // flight / the intermediates currently held are in the fp32 format
   int prec = 0;
@@ -258,6 +265,11 @@ int svihmm_destroy(svihmm_ctx* h) {
   for (Buf* b : bufs) release(*b);
   if (h->vlb_host) { hipHostFree(h->vlb_host); h->vlb_host = nullptr; }
   if (h->svi_elbo) { hipHostFree(h->svi_elbo); h->svi_elbo = nullptr; }
+  if (h->svi_ea) hipEventDestroy(h->svi_ea);
+  if (h->svi_eb) hipEventDestroy(h->svi_eb);
+  if (h->svi_ec) hipEventDestroy(h->svi_ec);
+  if (h->svi_ed) hipEventDestroy(h->svi_ed);
+  if (h->stream3) hipStreamDestroy(h->stream3);
   for (auto e : h->svi_ev) hipEventDestroy(e);
   for (int i = 0; i < 2; ++i) {
     if (h->ev_em[i]) hipEventDestroy(h->ev_em[i]);
@@ -273,6 +285,7 @@ int svihmm_destroy(svihmm_ctx* h) {
 }
 
 static int check_emission_status(svihmm_ctx* h);
+static int wait_globals(svihmm_ctx* h);
 static int pinned(svihmm_ctx* h, size_t bytes, void** out, int* slot_out);
 static int pull_small(svihmm_ctx* h, void* dst, const void* pin, size_t bytes);
 static int pin_release(svihmm_ctx* h, int slot);
@@ -351,6 +364,8 @@ int svihmm_set_globals(svihmm_ctx* h, int32_t K, const double* mod_init, const d
   if (!h || K <= 0 || !mod_init || !ltran) return fail("svihmm_set_globals: bad arguments");
   if (K > 1024) return fail("svihmm_set_globals: K > 1024 unsupported");
   CK(set_device(h));
+  CK(wait_globals(h));               // a globals kernel of the SVI loop may still be writing them
+  h->svi_globals_ready = false;
   h->lin_stale = true;
   const size_t kk = (size_t)K * K * sizeof(double);
   CK(ensure(h->mod_init, K * sizeof(double)));
@@ -1227,8 +1242,18 @@ static int pick_fb(const svihmm_ctx* h, int B, int Lm, bool want_logs) {
 }
 
 // messages + posterior for a window batch (mode from pick_fb, fixed before the emission ran)
+// the SVI loop's globals kernel runs on a side stream: everything that reads Aexp / mod_init /
+// var_init on the main stream waits for it here (no-op otherwise)
+static int wait_globals(svihmm_ctx* h) {
+  if (h->globals_ev) {
+    HIPCK(hipStreamWaitEvent(h->stream, h->globals_ev, 0));
+    h->globals_ev = nullptr;
+  }
+  return 0;
+}
 static int run_fb(svihmm_ctx* h, int B, int Lm, int var, bool want_lb, bool total) {
   h->m_nb = 0;
+  CK(wait_globals(h));
   if (var == 3) {
     h->have_lb = true;   // materialised lazily
     return launch_fb_lin(h, B, Lm, total);
@@ -1244,8 +1269,10 @@ static int run_fb(svihmm_ctx* h, int B, int Lm, int var, bool want_lb, bool tota
 // multiple of ST_RB (one resident workgroup per CU for the pipelined kernel: 128 chunks x 2
 // passes = 256)
 struct StatsPlan { int64_t rpc, nchunk; };
-static StatsPlan stats_plan(int64_t n) {
-  const int target_chunks = (n >= 128 * 1024) ? 128 : 256;
+static StatsPlan stats_plan(int64_t n, int forced = 0) {
+  // 128 chunks x 2 feature groups = one workgroup per CU at every batch size: more chunks only add
+  // partial-sum traffic (64 windows: statistics + finalize 74 -> 56 us, tools/chunk_sweep.py)
+  const int target_chunks = forced > 0 ? forced : 128;
   int64_t rpc = (n + target_chunks - 1) / target_chunks;
   rpc = (rpc + ST_RB - 1) / ST_RB * ST_RB;
   return {rpc, (n + rpc - 1) / rpc};
@@ -1296,7 +1323,7 @@ static int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, in
       if (lds > 150 * 1024 || xk > 9 || (big && Kp % 64 != 0)) var = 2;
       else if (lin && h->cur_f32 && !big) {
         // fp32 mode: float LDS tiles, v_mfma_f32_16x16x4_f32, ah / bh read as float
-        const size_t ldsf = ((size_t)(D + 3 + KpW) * ST_CC + 2 * (size_t)ST_RB * (KpW + 1)) * 4 + 8 +
+        const size_t ldsf = ((size_t)(D + 3 + KpW) * ST_CC + 2 * (size_t)ST_RB * (KpW + 16)) * 4 + 8 +
                             4 * ST_RB * sizeof(StRow4);
         dim3 grid((unsigned)nchunk, (mt_limit + 4 * 5 - 1) / (4 * 5), 1);
 #define ST3F(NTW, NS, XKV)                                                                        \
@@ -1450,7 +1477,7 @@ static int launch_stats_cat(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint3
 
 static int launch_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags) {
   if (h->emis_cat) return launch_stats_cat(h, B, Lq, off, Lm, flags);
-  const StatsPlan plan = stats_plan((int64_t)B * Lm);
+  const StatsPlan plan = stats_plan((int64_t)B * Lm, h->variant[8]);
   CK(ensure_stats(h, plan.nchunk));
   CK(launch_stats_range(h, 0, B, Lq, off, Lm, flags, plan, 0, h->stream));
   return launch_stats_finalize(h, plan.nchunk, h->stream);
@@ -1537,6 +1564,7 @@ static int prepare_ll(svihmm_ctx* h, const int64_t* starts, int B, int Lm, uint3
 // recomputed by the log-domain kernels into the m_* side buffers.
 static int materialise(svihmm_ctx* h, int b0, int nb) {
   if (h->m_nb > 0 && b0 >= h->m_b0 && b0 + nb <= h->m_b0 + h->m_nb) return 0;
+  CK(wait_globals(h));
   if (h->lin_stale)
     return fail("log-domain intermediates of the last E-step are rebuilt on demand and the "
                 "observations / globals / emission parameters have changed since: read them "
@@ -1833,7 +1861,8 @@ int svihmm_estep_minibatch_ex(svihmm_ctx* h, const int64_t* starts, int32_t B, i
 }
 
 // ---- device-resident SVI loop (hmmsgd_metaobs.py:347-445) ------------------------------------
-// layout of h->svi_state: var_tran K*K | prior_tran K*K | var_init K | vlb K | logdet K | prior_logpart K | rowterm K
+// layout of h->svi_state: var_tran K*K | prior_tran K*K | var_init K | vlb K | logdet K | prior_logpart K | rowterm K |
+// var_init' K (the stationary vector is double-buffered: the next iteration's is computed ahead)
 static double* svi_ptr(svihmm_ctx* h, int which) {
   const size_t K = h->svi_K, kk = K * K;
   double* b = (double*)h->svi_state.p;
@@ -1844,14 +1873,17 @@ static double* svi_ptr(svihmm_ctx* h, int which) {
     case 3: return b + 2 * kk + K;       // vlb
     case 4: return b + 2 * kk + 2 * K;   // logdet
     case 5: return b + 2 * kk + 3 * K;   // prior_logpart
-    default: return b + 2 * kk + 4 * K;  // rowterm (Dirichlet terms of the transition rows)
+    case 6: return b + 2 * kk + 4 * K;   // rowterm (Dirichlet terms of the transition rows)
+    case 7: return b + 2 * kk + 5 * K;   // second var_init slot
+    default: return b + 2 * kk + 6 * K;  // lb of the last two iterations (read by the side-stream ELBO kernel)
   }
 }
 #ifndef SVI_GW
 #define SVI_GW 8      // wavefronts of the k_svi_globals workgroups
 #endif
-static int svi_globals(svihmm_ctx* h) {
+static int svi_globals(svihmm_ctx* h, int slot) {
   const int K = h->svi_K;
+  double* vi_out = svi_ptr(h, slot ? 7 : 2);
   const size_t kk = (size_t)K * K * sizeof(double);
   CK(ensure(h->mod_init, K * sizeof(double)));
   CK(ensure(h->ltran, kk));
@@ -1859,42 +1891,80 @@ static int svi_globals(svihmm_ctx* h) {
   const size_t slack = (size_t)(reach - K + 16) * K * sizeof(double);
   CK(ensure(h->Aexp, kk + slack));
   CK(ensure(h->AexpT, kk + slack));
+  // The globals kernel depends on var_tran only, i.e. on the previous global step: it is launched
+  // on a side stream right after that step and runs beside the rest of the iteration (theta, ELBO
+  // kernels) and the next iteration's uploads and emission GEMM; the sweeps wait for it
+  // (wait_globals).  ~100 us off the critical path of a 64-window iteration.
+  if (!h->stream2) HIPCK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+  if (!h->svi_ea) {
+    HIPCK(hipEventCreateWithFlags(&h->svi_ea, hipEventDisableTiming));
+    HIPCK(hipEventCreateWithFlags(&h->svi_eb, hipEventDisableTiming));
+  }
+  hipStream_t s2 = h->stream2;
+  HIPCK(hipEventRecord(h->svi_ea, h->stream));
+  HIPCK(hipStreamWaitEvent(s2, h->svi_ea, 0));
   if (h->slack_a != h->Aexp.p || h->slack_t != h->AexpT.p || h->slack_k != K) {
-    HIPCK(hipMemsetAsync((char*)h->Aexp.p + kk, 0, slack, h->stream));
-    HIPCK(hipMemsetAsync((char*)h->AexpT.p + kk, 0, slack, h->stream));
+    HIPCK(hipMemsetAsync((char*)h->Aexp.p + kk, 0, slack, s2));
+    HIPCK(hipMemsetAsync((char*)h->AexpT.p + kk, 0, slack, s2));
     h->slack_a = h->Aexp.p; h->slack_t = h->AexpT.p; h->slack_k = K;
   }
   const size_t work = 2 * (size_t)K * (K | 1) * sizeof(double);
   const int use_lds = work + 9 * 1024 <= 150 * 1024;
   if (!use_lds) CK(ensure(h->svi_work, work));
-  ProfScope ps(h, KS_MISC);
-  if (use_lds) {
-    if (work > 48 * 1024)
-      hipFuncSetAttribute((const void*)k_svi_globals<true, SVI_GW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)work);
-    hipLaunchKernelGGL((k_svi_globals<true, SVI_GW>), dim3(K + 1), dim3(64 * SVI_GW), work, h->stream, (const double*)svi_ptr(h, 0), K,
-                       (double*)nullptr, (double*)h->ltran.p, (double*)h->Aexp.p, (double*)h->AexpT.p,
-                       svi_ptr(h, 2), (double*)h->mod_init.p);
-  } else {
-    hipLaunchKernelGGL((k_svi_globals<false, SVI_GW>), dim3(K + 1), dim3(64 * SVI_GW), 0, h->stream, (const double*)svi_ptr(h, 0), K,
-                       (double*)h->svi_work.p, (double*)h->ltran.p, (double*)h->Aexp.p, (double*)h->AexpT.p,
-                       svi_ptr(h, 2), (double*)h->mod_init.p);
+  {
+    ProfScope ps(h, KS_MISC, s2);
+    if (use_lds) {
+      if (work > 48 * 1024)
+        hipFuncSetAttribute((const void*)k_svi_globals<true, SVI_GW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)work);
+      hipLaunchKernelGGL((k_svi_globals<true, SVI_GW>), dim3(K + 1), dim3(64 * SVI_GW), work, s2, (const double*)svi_ptr(h, 0), K,
+                         (double*)nullptr, (double*)h->ltran.p, (double*)h->Aexp.p, (double*)h->AexpT.p,
+                         vi_out, (double*)h->mod_init.p);
+    } else {
+      hipLaunchKernelGGL((k_svi_globals<false, SVI_GW>), dim3(K + 1), dim3(64 * SVI_GW), 0, s2, (const double*)svi_ptr(h, 0), K,
+                         (double*)h->svi_work.p, (double*)h->ltran.p, (double*)h->Aexp.p, (double*)h->AexpT.p,
+                         vi_out, (double*)h->mod_init.p);
+    }
+    HIPCK(hipGetLastError());
   }
-  HIPCK(hipGetLastError());
+  HIPCK(hipEventRecord(h->svi_eb, s2));
+  h->globals_ev = h->svi_eb;
+  h->svi_globals_ready = true; h->svi_globals_slot = slot;
   h->K = K; h->have_globals = true; h->lin_stale = true;
   return 0;
 }
-// theta + log det for the factors now in h->niw, then their ELBO term into vlb[]
-static int svi_refresh_emission(svihmm_ctx* h) {
+// theta + log det for the factors now in h->niw (main stream: the next emission GEMM needs theta);
+// their ELBO term vlb[] and, with elbo_it >= 0, elbo_vec[elbo_it] on the side stream -- only the
+// ELBO trace needs them, so they stay off the critical path of the iteration chain.
+static int svi_refresh_emission(svihmm_ctx* h, int elbo_it, int lb_slot) {
   const int K = h->svi_K, D = h->svi_D;
+  if (!h->stream3) HIPCK(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
+  if (!h->svi_ec) {
+    HIPCK(hipEventCreateWithFlags(&h->svi_ec, hipEventDisableTiming));
+    HIPCK(hipEventCreateWithFlags(&h->svi_ed, hipEventDisableTiming));
+  }
   CK(launch_niw_to_theta(h, K, D, svi_ptr(h, 4)));
   h->lin_stale = true;
-  ProfScope ps(h, KS_MISC);
-  hipLaunchKernelGGL(k_svi_vlb, dim3(2 * K), dim3(64), 0, h->stream, (const double*)h->theta.p,
-                     (const int*)h->fab.p, h->F, D, h->Kp, (const double*)h->niw.p,
-                     (const double*)svi_ptr(h, 4), (const double*)h->svi_prior.p,
-                     (const double*)svi_ptr(h, 5), h->svi_zsign, K, svi_ptr(h, 3),
-                     (const double*)svi_ptr(h, 1), (const double*)svi_ptr(h, 0), svi_ptr(h, 6));
-  HIPCK(hipGetLastError());
+  hipStream_t s2 = h->stream3;
+  HIPCK(hipEventRecord(h->svi_ec, h->stream));
+  HIPCK(hipStreamWaitEvent(s2, h->svi_ec, 0));
+  {
+    ProfScope ps(h, KS_MISC, s2);
+    hipLaunchKernelGGL(k_svi_vlb, dim3(2 * K), dim3(64), 0, s2, (const double*)h->theta.p,
+                       (const int*)h->fab.p, h->F, D, h->Kp, (const double*)h->niw.p,
+                       (const double*)svi_ptr(h, 4), (const double*)h->svi_prior.p,
+                       (const double*)svi_ptr(h, 5), h->svi_zsign, K, svi_ptr(h, 3),
+                       (const double*)svi_ptr(h, 1), (const double*)svi_ptr(h, 0), svi_ptr(h, 6));
+    if (elbo_it >= 0) {
+      double* delbo = nullptr;
+      HIPCK(hipHostGetDevicePointer((void**)&delbo, h->svi_elbo, 0));
+      hipLaunchKernelGGL(k_svi_elbo, dim3(1), dim3(64), 0, s2, K, (const double*)svi_ptr(h, 3),
+                         (const double*)svi_ptr(h, 6), h->svi_prior_const, (const double*)svi_ptr(h, 8) + lb_slot,
+                         delbo + elbo_it);
+    }
+    HIPCK(hipGetLastError());
+  }
+  HIPCK(hipEventRecord(h->svi_ed, s2));
+  h->vlb_pending = true;
   return 0;
 }
 
@@ -1920,7 +1990,7 @@ int svihmm_svi_begin(svihmm_ctx* h, int32_t K, int32_t D, const double* prior_tr
     }
     h->svi_prior_const = pc;
   }
-  CK(ensure(h->svi_state, (2 * kk + 5 * (size_t)K + 8) * sizeof(double)));
+  CK(ensure(h->svi_state, (2 * kk + 6 * (size_t)K + 16) * sizeof(double)));
   CK(ensure(h->svi_prior, (nin + 8) * sizeof(double)));
   CK(ensure(h->niw, nin * sizeof(double) + 64));
   // one staging slot: [var_tran | prior_tran | prior_logpart | prior block | niw block]
@@ -1954,7 +2024,9 @@ int svihmm_svi_begin(svihmm_ctx* h, int32_t K, int32_t D, const double* prior_tr
     HIPCK(hipEventCreate(&e));
     h->svi_ev.push_back(e);
   }
-  CK(svi_refresh_emission(h));       // theta of the initial factors (their vlb is not used)
+  CK(svi_refresh_emission(h, -1, 0));   // theta of the initial factors (their vlb is not used)
+  h->svi_vi_cur = 1;
+  CK(svi_globals(h, 0));             // globals of iteration 0
   h->svi_active = true;
   return 0;
 }
@@ -1969,7 +2041,9 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
   CK(set_device(h));
   const int K = h->svi_K, D = h->svi_D;
   HIPCK(hipEventRecord(h->svi_ev[it], h->stream));
-  CK(svi_globals(h));
+  if (!h->svi_globals_ready) CK(svi_globals(h, h->svi_vi_cur ^ 1));   // (a host set_globals came in between)
+  h->svi_vi_cur = h->svi_globals_slot;
+  h->svi_globals_ready = false;       // consumed by this iteration's sweeps
   const bool keep = (flags & SVIHMM_SVI_KEEP_WINDOW) != 0;
   flags &= ~(uint32_t)SVIHMM_SVI_KEEP_WINDOW;
   if (B > 0) {
@@ -1987,25 +2061,21 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
     ProfScope ps(h, KS_ALLREDUCE);
     NCCLCK(ncclAllReduce(h->packed.p, h->packed.p, (size_t)packed_len(h), ncclDouble, ncclSum, h->comm, h->stream));
   }
+  CK(wait_globals(h));     // (an empty shard ran no sweeps)
+  // the previous iteration's ELBO kernels (their own stream) read var_tran / theta / logdet,
+  // which this global step and the NIW kernel after it rewrite (normally long finished)
+  if (h->vlb_pending) { HIPCK(hipStreamWaitEvent(h->stream, h->svi_ed, 0)); h->vlb_pending = false; }
   {
     ProfScope ps(h, KS_MISC);
     const unsigned nblk = (unsigned)K + (unsigned)((K * K + 255) / 256);
     hipLaunchKernelGGL(k_svi_global_step, dim3(nblk), dim3(256), (size_t)3 * D * sizeof(double), h->stream,
                        (const double*)h->packed.p, (const double*)svi_ptr(h, 1), svi_ptr(h, 0),
                        (double*)h->niw.p, (const double*)h->svi_prior.p, K, D, rho, bfactA, bfactE,
-                       (double)nwin_total);
+                       (double)nwin_total, svi_ptr(h, 8) + (it & 1));
     HIPCK(hipGetLastError());
   }
-  CK(svi_refresh_emission(h));
-  {
-    ProfScope ps(h, KS_MISC);
-    double* delbo = nullptr;
-    HIPCK(hipHostGetDevicePointer((void**)&delbo, h->svi_elbo, 0));
-    const double* lb = (const double*)h->packed.p + (packed_len(h) - 1);
-    hipLaunchKernelGGL(k_svi_elbo, dim3(1), dim3(64), 0, h->stream, K, (const double*)svi_ptr(h, 3),
-                       (const double*)svi_ptr(h, 6), h->svi_prior_const, lb, delbo + it);
-    HIPCK(hipGetLastError());
-  }
+  if (it + 1 < h->svi_maxit) CK(svi_globals(h, h->svi_vi_cur ^ 1));   // the next iteration's, ahead of time
+  CK(svi_refresh_emission(h, it, it & 1));
   HIPCK(hipEventRecord(h->svi_ev[it + 1], h->stream));
   return 0;
 }
@@ -2014,6 +2084,8 @@ int svihmm_svi_read_elbo(svihmm_ctx* h, int32_t n, double* out_elbo, double* out
   if (!h || !h->svi_active || n < 0 || n > h->svi_maxit) return fail("svihmm_svi_read_elbo: bad arguments");
   CK(set_device(h));
   HIPCK(hipStreamSynchronize(h->stream));
+  if (h->stream2) HIPCK(hipStreamSynchronize(h->stream2));
+  if (h->stream3) HIPCK(hipStreamSynchronize(h->stream3));
   CK(check_emission_status(h));
   for (int i = 0; i < n; ++i) {
     if (out_elbo) out_elbo[i] = h->svi_elbo[i];
@@ -2032,7 +2104,8 @@ int svihmm_svi_read_state(svihmm_ctx* h, double* var_tran, double* var_init, dou
   const size_t K = h->svi_K, D = h->svi_D, nmu = K * D, nsg = K * D * D;
   const double* nw = (const double*)h->niw.p;
   if (var_tran) CK(d2h(h, var_tran, svi_ptr(h, 0), K * K * 8));
-  if (var_init) CK(d2h(h, var_init, svi_ptr(h, 2), K * 8));
+  CK(wait_globals(h));
+  if (var_init) CK(d2h(h, var_init, svi_ptr(h, h->svi_vi_cur ? 7 : 2), K * 8));
   if (mu) CK(d2h(h, mu, nw, nmu * 8));
   if (sigma) CK(d2h(h, sigma, nw + nmu, nsg * 8));
   if (kappa) CK(d2h(h, kappa, nw + nmu + nsg, K * 8));
@@ -2168,6 +2241,7 @@ int svihmm_ffbs(svihmm_ctx* h, const double* logA, const double* uniforms, uint3
   int64_t st0 = 0;
   const int K = h->K;
   if (!h->have_globals) return fail("no globals: call svihmm_set_globals");
+  CK(wait_globals(h));
   // forward filter: long chains through the exact blocked scan (scaled sweeps), then lalpha
   // from (ah, h, K); short ones with the per-window log-domain kernel
   const double* la = nullptr;
@@ -2395,7 +2469,7 @@ int svihmm_profile_read(svihmm_ctx* h, double ms_out[SVIHMM_NKERN], int64_t coun
   return 0;
 }
 int svihmm_set_variant(svihmm_ctx* h, int32_t which, int32_t value) {
-  if (!h || which < 0 || which >= 8) return fail("svihmm_set_variant: bad arguments");
+  if (!h || which < 0 || which >= 16) return fail("svihmm_set_variant: bad arguments");
   h->variant[which] = value;
   return 0;
 }
