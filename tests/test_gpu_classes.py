@@ -270,3 +270,36 @@ def test_svi_iteration_engine_level(K, D, B, Lm):
     np.testing.assert_allclose(ea, eb, rtol=1e-9)
     np.testing.assert_allclose(la, lb, rtol=1e-9, atol=1e-7)
     np.testing.assert_allclose(qa, qb, rtol=1e-6, atol=1e-11)
+
+
+@pytest.mark.parametrize("K,D,Lm,S", [(1, 1, 3, 2), (2, 1, 1, 5), (3, 2, 5, 1), (7, 40, 9, 4)])
+def test_device_loop_edge_shapes(K, D, Lm, S):
+    """Degenerate shapes through the device-resident loop vs the oracle engine: a single state
+    (the stationary vector is [1]), windows of one row (L = 0 is rejected by the class, so the
+    engine is driven directly), one window per minibatch, D not a multiple of 8 (table-driven
+    emission kernel)."""
+    from oracle.engine import OracleEngine
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd.distributions import niw_prior_logpart
+    from pysvihmm_amd import _lib as L
+    from tests.helpers import make_problem
+    T = 300
+    pb = make_problem(K, D, T, seed=10 * K + D, miss=0.1)
+    prior_tran = np.ones((K, K))
+    mu0 = np.tile(pb["obs"].mean(0), (K, 1))
+    sg0 = np.tile((0.75 * np.cov(pb["obs"].T)).reshape(D, D) + 0.1 * np.eye(D), (K, 1, 1))
+    prior = (mu0, sg0, np.full(K, 0.01), np.full(K, D + 2.0))
+    factors = (pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    res = []
+    for eng in (HipEngine(0), OracleEngine()):
+        eng.set_obs(pb["obs"], pb["mask"])
+        eng.svi_begin(prior_tran, pb["var_tran"], prior, factors, niw_prior_logpart(sg0, prior[3]), 2, 1.0)
+        r2 = np.random.default_rng(1)
+        for it in range(2):
+            starts = r2.integers(0, T - Lm + 1, size=S)
+            eng.svi_iteration(it, starts, S, Lm, L.TRANS_WRAP, (it + 1.0) ** -0.7, 2.0, 1.5)
+        res.append((eng.svi_read_state(), eng.svi_read_elbo(2)[0]))
+        eng.close()
+    for a, b in zip(res[0][0], res[1][0]):
+        np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-9)
