@@ -254,6 +254,8 @@ int svihmm_destroy(svihmm_ctx* h) {
   if (!h) return 0;
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
+  if (h->stream2) hipStreamSynchronize(h->stream2);   // side streams of the SVI loop may still
+  if (h->stream3) hipStreamSynchronize(h->stream3);   // hold kernels that touch the buffers below
   if (h->comm) { ncclCommDestroy(h->comm); h->comm = nullptr; }
   for (auto& p : h->pending) { hipEventDestroy(p.e0); hipEventDestroy(p.e1); }
   for (auto e : h->pool) hipEventDestroy(e);
@@ -303,6 +305,8 @@ int svihmm_get_precision(svihmm_ctx* h, int32_t* mode_out, int32_t* last_batch_f
 int svihmm_sync(svihmm_ctx* h) {
   CK(set_device(h));
   HIPCK(hipStreamSynchronize(h->stream));
+  if (h->stream2) HIPCK(hipStreamSynchronize(h->stream2));
+  if (h->stream3) HIPCK(hipStreamSynchronize(h->stream3));
   return check_emission_status(h);
 }
 
