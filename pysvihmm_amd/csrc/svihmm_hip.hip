@@ -165,7 +165,7 @@ struct svihmm_ctx {
   int64_t cnt[SVIHMM_NKERN] = {0};
   // device-resident SVI loop (svihmm_svi_*): var_tran | prior_tran | var_init | vlb[K] | logdet[K] |
   // prior_logpart[K]; prior block [mu0 | sigma0 | kappa0 | nu0]; GTH scratch; elbo / event ring
-  Buf svi_state, svi_prior, svi_work;
+  Buf svi_state, svi_prior, svi_work, commtmp;
   int svi_K = 0, svi_D = 0, svi_maxit = 0;
   double svi_zsign = 1.0, svi_prior_const = 0.0;
   double* svi_elbo = nullptr; int svi_elbo_cap = 0;      // pinned + mapped: elbo_vec
@@ -263,7 +263,7 @@ int svihmm_destroy(svihmm_ctx* h) {
                  &h->fab, &h->starts, &h->ll, &h->la, &h->lb, &h->q, &h->lse_part,
                  &h->local_lb, &h->logz, &h->part, &h->packed, &h->scratch, &h->kexp, &h->hx, &h->gx,
                  &h->zfac, &h->llE, &h->m_ll, &h->m_la, &h->m_lb, &h->chain, &h->chain2, &h->cat_table, &h->partc, &h->theta_orb, &h->prior, &h->vlb_aux, &h->gen_z,
-                 &h->svi_state, &h->svi_prior, &h->svi_work};
+                 &h->svi_state, &h->svi_prior, &h->svi_work, &h->commtmp};
   for (Buf* b : bufs) release(*b);
   if (h->vlb_host) { hipHostFree(h->vlb_host); h->vlb_host = nullptr; }
   if (h->svi_elbo) { hipHostFree(h->svi_elbo); h->svi_elbo = nullptr; }
@@ -2421,18 +2421,14 @@ int svihmm_allreduce_host(svihmm_ctx* h, double* buf, int64_t n, int32_t op) {
   if (!h || !buf || n <= 0) return fail("svihmm_allreduce_host: bad arguments");
   if (!h->comm) return fail("svihmm_allreduce_host: communicator not initialised");
   CK(set_device(h));
-  Buf tmp;
-  CK(ensure(tmp, (size_t)n * sizeof(double)));
-  int rc = 0;
-  do {
-    if (hipMemcpyAsync(tmp.p, buf, n * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc = fail("allreduce_host: H2D failed"); break; }
-    ncclResult_t r = ncclAllReduce(tmp.p, tmp.p, (size_t)n, ncclDouble, op == 1 ? ncclMax : ncclSum, h->comm, h->stream);
-    if (r != ncclSuccess) { rc = fail(std::string("ncclAllReduce: ") + ncclGetErrorString(r)); break; }
-    if (hipMemcpyAsync(buf, tmp.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess) { rc = fail("allreduce_host: D2H failed"); break; }
-    if (hipStreamSynchronize(h->stream) != hipSuccess) { rc = fail("allreduce_host: sync failed"); break; }
-  } while (0);
-  release(tmp);
-  return rc;
+  // a persistent staging buffer: the barriers of a timed region must not pay hipMalloc / hipFree
+  CK(ensure(h->commtmp, (size_t)n * sizeof(double)));
+  void* tp = h->commtmp.p;
+  HIPCK(hipMemcpyAsync(tp, buf, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  NCCLCK(ncclAllReduce(tp, tp, (size_t)n, ncclDouble, op == 1 ? ncclMax : ncclSum, h->comm, h->stream));
+  HIPCK(hipMemcpyAsync(buf, tp, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  return 0;
 }
 
 // ---- measurement --------------------------------------------------------------------------

@@ -63,3 +63,55 @@ def test_sweep(case):
             np.testing.assert_allclose(q.sum(-1), 1.0, rtol=1e-11)
     finally:
         e.close()
+
+
+def _svi_cases():
+    rng = np.random.default_rng(20260929)
+    out = []
+    for i in range(16):
+        K = int(rng.choice([1, 2, 5, 16, 17, 40, 64, 65, 96, 130]))
+        D = int(rng.choice([1, 3, 8, 16, 24, 33]))
+        Lm = int(rng.choice([1, 4, 17, 65]))
+        S = int(rng.choice([1, 3, 20, 260]))
+        f32 = bool(rng.integers(0, 2)) and K <= 64
+        out.append((K, D, Lm, S, f32, i))
+    return out
+
+
+SVI_CASES = _svi_cases()
+
+
+@pytest.mark.parametrize("case", SVI_CASES, ids=["K%d_D%d_Lm%d_S%d_f32%d_%d" % c for c in SVI_CASES])
+def test_svi_loop_sweep(case):
+    """Randomised shapes through svihmm_svi_begin / svihmm_svi_iteration (three iterations, state
+    resident in HBM, side-stream globals) against the reference arithmetic of the oracle engine:
+    K on both sides of 64 and of the LDS / global-scratch switch of k_svi_globals, buffered
+    windows (inner segment), masks, fp64 and the fp32 mode (tolerance 1e-3 there)."""
+    from oracle.engine import OracleEngine
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd.distributions import niw_prior_logpart
+    from pysvihmm_amd import _lib as L
+    K, D, Lm, S, f32, i = case
+    T = max(6 * Lm, 500)
+    pb = make_problem(K, D, T, seed=2000 + i, miss=0.1 if i % 2 else 0.0, sep=3.0)
+    rng = np.random.default_rng(100 + i)
+    prior_tran = 1.0 + rng.random((K, K))
+    mu0 = np.tile(pb["obs"].mean(0), (K, 1))
+    sg0 = np.tile((0.75 * np.cov(pb["obs"].T)).reshape(D, D) + 0.05 * np.eye(D), (K, 1, 1))
+    prior = (mu0, sg0, np.full(K, 0.01), np.full(K, D + 2.0))
+    factors = (pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    inner = (Lm // 4, Lm - 2 * (Lm // 4)) if (i % 3 == 0 and Lm >= 4) else None
+    res = []
+    for eng in (HipEngine(0, dtype="f32" if f32 else "f64"), OracleEngine()):
+        eng.set_obs(pb["obs"], pb["mask"])
+        eng.svi_begin(prior_tran, pb["var_tran"], prior, factors, niw_prior_logpart(sg0, prior[3]), 3, 1.0)
+        r2 = np.random.default_rng(7)
+        for it in range(3):
+            starts = r2.integers(0, T - Lm + 1, size=S)
+            eng.svi_iteration(it, starts, S, Lm, L.TRANS_WRAP, (it + 2.0) ** -0.7, 1.7, 1.3, inner=inner)
+        res.append((eng.svi_read_state(), eng.svi_read_elbo(3)[0]))
+        eng.close()
+    rt, at = (1e-3, 1e-5) if f32 else (1e-6, 1e-8)
+    for name, a, b in zip(("var_tran", "var_init", "mu", "sigma", "kappa", "nu"), res[0][0], res[1][0]):
+        np.testing.assert_allclose(a, b, rtol=rt, atol=at * max(1.0, float(np.abs(b).max())), err_msg=name)
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-5 if f32 else 1e-9)
