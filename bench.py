@@ -207,8 +207,10 @@ def main():
     rows = B * LM
 
     def step(st=starts):
-        eng.set_globals(pb["mod_init"], pb["ltran"])
+        # (NIW factors first: their upload -> Cholesky -> theta chain is what the emission GEMM
+        #  waits for; the globals are only needed by the sweeps after it)
         eng.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"], check=False)
+        eng.set_globals(pb["mod_init"], pb["ltran"])
         eng.estep(st, LM, flags=L.TRANS_WRAP, read=False)
         if use_comm:
             eng.allreduce_packed()

@@ -499,7 +499,6 @@ class VBHMM(VariationalHMMBase):
             eng.on_next_mutation(None)
         self._stationary_init()
         self._psi_expectations()
-        self._push_globals()
         comm = self.comm
         mine = minibatch if comm is None else minibatch[comm.rank::comm.size]
         starts = np.array([mo.i1 for mo in mine], dtype=np.int64)
@@ -509,10 +508,13 @@ class VBHMM(VariationalHMMBase):
             bufferL, L_ = buffer
             inner = (bufferL - L_, 2 * L_ + 1)
         if len(starts):
+            # emission factors before the globals: the device's upload -> Cholesky -> theta chain
+            # is what the emission GEMM waits for, the globals are needed by the sweeps only
             # KEEP_LBETA: the reference leaves lbeta of the last window on the object
             flags = self._push_emission(windows=list(starts), Lm=Lm) | L.TRANS_WRAP | L.KEEP_LBETA
         else:
             flags = L.TRANS_WRAP
+        self._push_globals()
         # an empty shard still produces (zero) statistics so every rank joins the all-reduce
         st = self.engine.estep(starts, Lm, flags=flags, read=(comm is None), inner=inner)
         if comm is not None:
