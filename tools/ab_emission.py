@@ -5,11 +5,11 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import bench
+from _workload import bench_problem
 from pysvihmm_amd.engine import HipEngine
 from pysvihmm_amd import _lib as L
-pb = bench.synth(0)
 e = HipEngine(0)
-e.set_obs(pb["obs"], None)
+pb = bench_problem(e)
 B = bench.T // bench.LM
 st = np.arange(B, dtype=np.int64) * bench.LM
 e.set_globals(pb["mod_init"], pb["ltran"]); e.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])

@@ -9,9 +9,10 @@ import numpy as np
 import bench
 from pysvihmm_amd.engine import HipEngine
 from pysvihmm_amd import _lib as L
-pb = bench.synth(0)
+sys.path.insert(0, os.path.join(%r, "tools"))
+from _workload import bench_problem
 e = HipEngine(0)
-e.set_obs(pb["obs"], None)
+pb = bench_problem(e)
 B = bench.T // bench.LM
 st = np.arange(B, dtype=np.int64) * bench.LM
 e.set_globals(pb["mod_init"], pb["ltran"]); e.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
@@ -20,7 +21,7 @@ e.sync(); e.profile(True); e.profile_reset()
 for _ in range(10): e.estep(st, bench.LM, flags=L.TRANS_WRAP, read=False)
 p = e.profile_read()
 print({k: round(v[0] / max(v[1], 1), 4) for k, v in p.items() if v[1]})
-''' % ROOT
+''' % (ROOT, ROOT)
 for rnd in range(2):
     for lib in sys.argv[1:]:
         env = dict(os.environ)

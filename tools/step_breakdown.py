@@ -3,11 +3,11 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
+from _workload import bench_problem
 from pysvihmm_amd.engine import HipEngine
 from pysvihmm_amd import _lib as L
-pb = bench.synth(0)
 e = HipEngine(0)
-e.set_obs(pb["obs"], None)
+pb = bench_problem(e)
 LM = bench.LM
 B = bench.T // LM
 st = np.arange(B, dtype=np.int64) * LM

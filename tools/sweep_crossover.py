@@ -1,10 +1,13 @@
-import sys; sys.path.insert(0, '.')
+"""Sweep kernel crossover: wave-per-window against 16-window MFMA tiles, by minibatch size."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import bench
+from _workload import bench_problem
 from pysvihmm_amd.engine import HipEngine
 from pysvihmm_amd import _lib as L
-pb = bench.synth(0)
-e = HipEngine(0); e.set_obs(pb["obs"], None)
+e = HipEngine(0)
+pb = bench_problem(e)
 e.set_globals(pb["mod_init"], pb["ltran"]); e.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
 for B in (64, 128, 256, 384, 512, 768, 1024, 1399):
     st = (np.arange(B, dtype=np.int64) * 257)

@@ -3,14 +3,14 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
+from _workload import bench_problem
 from pysvihmm_amd.engine import HipEngine
 from pysvihmm_amd import _lib as L
-pb = bench.synth(0)
 e = HipEngine(0)
+pb = bench_problem(e)
 for kv in os.environ.get("SVIHMM_SET", "").split(","):
     if kv:
         k, v = kv.split(":"); e.set_variant(k, int(v))
-e.set_obs(pb["obs"], None)
 e.set_globals(pb["mod_init"], pb["ltran"])
 e.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
 LM = bench.LM
