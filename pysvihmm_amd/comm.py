@@ -52,6 +52,17 @@ def file_uid_exchange(rank, tag=None, timeout=300.0, directory=None):
     directory = directory or tempfile.gettempdir()
     path = os.path.join(directory, "svihmm_uid_%s.bin" % tag)
 
+    def launcher_start():
+        """Wall-clock start of the parent (launcher) process; None if /proc does not say."""
+        try:
+            with open("/proc/%d/stat" % os.getppid()) as f:
+                ticks = float(f.read().rsplit(")", 1)[1].split()[19])      # field 22: starttime
+            with open("/proc/stat") as f:
+                btime = [float(l.split()[1]) for l in f if l.startswith("btime")][0]
+            return btime + ticks / os.sysconf("SC_CLK_TCK")
+        except (OSError, ValueError, IndexError):
+            return None
+
     def exchange(uid):
         if rank == 0:
             tmp = path + ".tmp%d" % os.getpid()
@@ -60,11 +71,13 @@ def file_uid_exchange(rank, tag=None, timeout=300.0, directory=None):
             os.replace(tmp, path)          # atomic publish
             return uid
         t0 = time.time()
+        # a file left behind by a crashed earlier job with the same tag is older than this
+        # job's launcher (fallback: older than two minutes before this worker got here)
+        born = launcher_start()
+        fresh = (born - 1.0) if born is not None else (t0 - 120.0)
         while True:
             try:
-                # a file left behind by a crashed earlier job with the same tag is older than
-                # this job's workers (which all start within seconds of each other)
-                if os.path.getmtime(path) >= t0 - 120.0:
+                if os.path.getmtime(path) >= fresh:
                     with open(path, "rb") as f:
                         data = f.read()
                     if len(data) == 128:
