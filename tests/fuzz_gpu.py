@@ -1,0 +1,215 @@
+"""Long randomised campaign of the HIP E-step against the C oracle (run by hand on a GPU box:
+``python tests/fuzz_gpu.py --seed 1 --cases 300``).  Not collected by pytest -- the fixed-seed
+subset that runs every round is tests/test_gpu_random_sweep.py.  Every case draws a model shape
+(K up to 256, D up to 64, ragged against the 16-wide tiles), a window batch on either side of
+every kernel-selection threshold, masks / NaN rows, state separation from overlapping to
+1e4-nat gaps, near-absorbing transition rows, and checks
+
+  * the packed statistics of ``svihmm_estep_minibatch_ex`` (both transition conventions, random
+    inner segment) against ``orc_estep_minibatch``,
+  * ``lalpha / lbeta / var_x / local_lb`` of ``svihmm_forward_backward`` on sampled windows,
+  * the fp32 mode against the fp64 statistics (north_star's 1e-3),
+  * now and then one long chain (B = 1, Lm = T: the blocked scan) against the oracle's
+    sequential recursion.
+
+Prints one line per failing case (the case tuple reproduces it) and exits non-zero if any."""
+import argparse
+import os
+import sys
+import time
+import traceback
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests.helpers import make_problem, unpack, effective_cores  # noqa: E402
+
+NCORE = effective_cores()
+
+
+def draw_case(rng):
+    K = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 15, 16, 17, 24, 31, 32, 33, 47, 48, 49, 63, 64, 65, 80, 96,
+                        127, 128, 129, 192, 200, 256]))
+    D = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 13, 15, 16, 17, 24, 31, 32, 33, 40, 48, 63, 64]))
+    Lm = int(rng.choice([1, 2, 3, 4, 5, 8, 9, 16, 17, 31, 33, 64, 70, 129, 257, 300]))
+    B = int(rng.choice([1, 2, 3, 5, 15, 16, 17, 31, 33, 64, 65, 191, 192, 200, 255, 256, 257, 333, 600, 1023,
+                        1024, 1100]))
+    # keep the oracle's work per case bounded (~ a few seconds on one core)
+    cost = lambda: B * Lm * K * (2.0 * K + 3.0 * D * D)
+    while cost() > 6e9 and B > 1:
+        B = max(1, B // 2)
+    while cost() > 6e9 and Lm > 1:
+        Lm = max(1, Lm // 2)
+    sep = float(rng.choice([0.0, 0.5, 3.0, 20.0, 60.0]))
+    miss = float(rng.choice([0.0, 0.0, 0.1, 0.5]))
+    sparse = bool(rng.random() < 0.25)        # near-absorbing / sparse transition expectations
+    return K, D, Lm, B, sep, miss, sparse
+
+
+def problem(case, seed):
+    K, D, Lm, B, sep, miss, sparse = case
+    T = max(4 * Lm, 400)
+    pb = make_problem(K, D, T, seed=seed, miss=miss, sep=sep)
+    rng = np.random.default_rng(seed + 7)
+    if sparse:
+        from scipy.special import digamma
+        vt = 1e-3 + rng.random((K, K)) * (rng.random((K, K)) < 0.2) * T
+        vt[np.arange(K), np.arange(K)] += T
+        pb["ltran"] = digamma(vt + 1e-9) - digamma(vt.sum(1)[:, None] + 1e-9)
+    if rng.random() < 0.3:
+        pb["obs"][T // 3] = np.nan
+        pb["mask"][T // 3] = True
+    starts = rng.integers(0, T - Lm + 1, size=B)
+    return pb, starts, T
+
+
+def check_stats(got, ref, K, D, sc, xs, rtol, atol_scale, what):
+    names = ("A_raw", "xbar", "neff", "S", "lb")
+    g = unpack(got, K, D)
+    r = unpack(ref, K, D)
+    atol = (atol_scale * sc, atol_scale * sc * xs, atol_scale * sc, atol_scale * sc * xs * xs, 1e-6)
+    for n, a, b, at in zip(names, g, r, atol):
+        rt = 1e-9 if (n == "lb" and rtol < 1e-5) else rtol
+        np.testing.assert_allclose(a, b, rtol=rt, atol=at, err_msg="%s: %s" % (what, n))
+
+
+def run_case(e, L, ref_c, case, seed):
+    K, D, Lm, B, sep, miss, sparse = case
+    pb, starts, T = problem(case, seed)
+    obs, mask = pb["obs"], pb["mask"]
+    par = (pb["mod_init"], pb["ltran"], pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    e.set_precision("f64")
+    e.set_obs(obs, mask)
+    e.set_globals(pb["mod_init"], pb["ltran"])
+    e.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    sc = B * Lm
+    xs = max(1.0, float(np.nanmax(np.abs(obs))))
+    rng = np.random.default_rng(seed + 11)
+    f64 = {}
+    for flags in (L.TRANS_WRAP, L.MASK_AS_NAN):
+        st = e.estep(starts, Lm, flags=flags)
+        ref = ref_c.estep_minibatch(obs, mask, starts, Lm, *par, flags=flags, threads=NCORE)
+        check_stats(st.buf, ref, K, D, sc, xs, 1e-6, 1e-9, "estep flags=%d" % flags)
+        f64[flags] = st.buf.copy()
+    # messages of up to three windows
+    for b in rng.choice(B, size=min(B, 3), replace=False):
+        fb = e.forward_backward(starts[b:b + 1], Lm, flags=L.MASK_AS_NAN)
+        x = obs[starts[b]:starts[b] + Lm].copy()
+        x[mask[starts[b]:starts[b] + Lm]] = np.nan
+        ll = ref_c.lliks_niw(x, pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+        la = ref_c.forward(ll, pb["mod_init"], pb["ltran"])
+        lbm = ref_c.backward(ll, pb["ltran"])
+        q, _ = ref_c.posterior(la, lbm)
+        np.testing.assert_allclose(fb["lalpha"][0], la, rtol=1e-9, atol=1e-7, err_msg="lalpha")
+        np.testing.assert_allclose(fb["lbeta"][0], lbm, rtol=1e-9, atol=1e-7, err_msg="lbeta")
+        np.testing.assert_allclose(fb["var_x"][0], q, rtol=1e-6, atol=1e-12, err_msg="var_x")
+    # batch of windows through forward_backward: posteriors sum to one, equal the single-window ones
+    fbB = e.forward_backward(starts, Lm, flags=L.MASK_AS_NAN, want=("var_x", "local_lb"))
+    assert np.all(np.isfinite(fbB["var_x"])), "var_x not finite"
+    np.testing.assert_allclose(fbB["var_x"].sum(-1), 1.0, rtol=0, atol=1e-9, err_msg="var_x rows")
+    # fp32 mode (K <= 64 takes the float kernels; other shapes must still give fp64-grade results)
+    e.set_precision("f32")
+    st = e.estep(starts, Lm, flags=L.TRANS_WRAP)
+    e.set_precision("f64")
+    g = unpack(st.buf, K, D)
+    r = unpack(f64[L.TRANS_WRAP], K, D)
+    np.testing.assert_allclose(g[0], r[0], rtol=2e-3, atol=2e-4 * sc, err_msg="f32 A_raw")
+    np.testing.assert_allclose(g[2], r[2], rtol=2e-3, atol=2e-4 * sc, err_msg="f32 neff")
+    np.testing.assert_allclose(g[1], r[1], rtol=2e-3, atol=2e-4 * sc * xs, err_msg="f32 xbar")
+    np.testing.assert_allclose(g[4], r[4], rtol=1e-4, atol=1e-2, err_msg="f32 lb")
+    # inner segment (buffered meta-observations)
+    if Lm >= 3:
+        off = int(rng.integers(0, Lm // 2))
+        ln = int(rng.integers(1, Lm - off + 1))
+        st = e.estep(starts, Lm, flags=L.MASK_AS_NAN, inner=(off, ln))
+        acc = None
+        from oracle.engine import OracleEngine
+        oe = OracleEngine()
+        oe.set_obs(obs, mask)
+        oe.set_globals(pb["mod_init"], pb["ltran"])
+        oe.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+        acc = oe.estep(starts, Lm, flags=L.MASK_AS_NAN, inner=(off, ln))
+        check_stats(st.buf, acc.buf, K, D, sc, xs, 1e-6, 1e-9, "inner (%d,%d)" % (off, ln))
+
+
+def run_chain(e, L, ref_c, seed):
+    rng = np.random.default_rng(seed)
+    K = int(rng.choice([2, 5, 16, 33, 64, 100, 128]))
+    D = int(rng.choice([1, 3, 8, 17, 32]))
+    T = int(rng.choice([2048, 3000, 5000, 12345, 40000]))
+    if K > 64:
+        T = min(T, 12345)
+    pb = make_problem(K, D, T, seed=seed, miss=float(rng.choice([0.0, 0.1])), sep=float(rng.choice([0.5, 3.0, 20.0])))
+    par = (pb["mod_init"], pb["ltran"], pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    e.set_precision("f64")
+    e.set_obs(pb["obs"], pb["mask"])
+    e.set_globals(pb["mod_init"], pb["ltran"])
+    e.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    st = e.estep(np.zeros(1, dtype=np.int64), T, flags=L.MASK_AS_NAN)
+    ref = ref_c.estep_minibatch(pb["obs"], pb["mask"], np.zeros(1, dtype=np.int64), T, *par, flags=L.MASK_AS_NAN)
+    xs = max(1.0, float(np.nanmax(np.abs(pb["obs"]))))
+    check_stats(st.buf, ref, K, D, T, xs, 1e-6, 1e-9, "chain K=%d D=%d T=%d" % (K, D, T))
+    q = e.read_rows("var_x", 0, T)
+    x = pb["obs"].copy()
+    x[pb["mask"]] = np.nan
+    ll = ref_c.lliks_niw(x, pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    qr, _ = ref_c.posterior(ref_c.forward(ll, pb["mod_init"], pb["ltran"]), ref_c.backward(ll, pb["ltran"]))
+    np.testing.assert_allclose(q, qr, rtol=1e-6, atol=1e-12, err_msg="chain var_x")
+    return (K, D, T)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cases", type=int, default=100)
+    ap.add_argument("--chains", type=int, default=10)
+    ap.add_argument("--seconds", type=float, default=1e9, help="stop drawing new cases after this long")
+    args = ap.parse_args()
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    from oracle import ref_c
+    rng = np.random.default_rng(args.seed)
+    e = HipEngine(0)
+    t0 = time.time()
+    nfail = ndone = 0
+    for i in range(args.cases):
+        if time.time() - t0 > args.seconds:
+            break
+        case = draw_case(rng)
+        seed = args.seed * 100000 + i
+        try:
+            run_case(e, L, ref_c, case, seed)
+        except Exception as ex:       # report and go on: a campaign wants all the failures
+            nfail += 1
+            msg = str(ex).strip().splitlines()
+            print("FAIL case=%r seed=%d: %s | %s" % (case, seed, type(ex).__name__, " / ".join(msg[:6])[:600]))
+            if not isinstance(ex, AssertionError):
+                traceback.print_exc()
+                e.close()
+                e = HipEngine(0)
+        ndone += 1
+        if ndone % 20 == 0:
+            print("... %d cases, %d failures, %.0f s" % (ndone, nfail, time.time() - t0))
+            sys.stdout.flush()
+    for i in range(args.chains):
+        if time.time() - t0 > args.seconds:
+            break
+        seed = args.seed * 100000 + 50000 + i
+        try:
+            run_chain(e, L, ref_c, seed)
+        except Exception as ex:
+            nfail += 1
+            msg = str(ex).strip().splitlines()
+            print("FAIL chain seed=%d: %s | %s" % (seed, type(ex).__name__, " / ".join(msg[:6])[:600]))
+            if not isinstance(ex, AssertionError):
+                traceback.print_exc()
+                e.close()
+                e = HipEngine(0)
+        ndone += 1
+    print("fuzz: %d cases, %d failures, %.0f s (seed %d)" % (ndone, nfail, time.time() - t0, args.seed))
+    e.close()
+    return 1 if nfail else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
