@@ -69,7 +69,7 @@ template <int NT, int MT>
 __device__ __forceinline__ void emission_scaled_epilogue(
     const double (&outv)[MT][NT][4], const unsigned char* bad_s, int wave, int li, int lg,
     int64_t g0, int64_t nrows, int K, int n0, double* __restrict__ ll, double* __restrict__ kexp,
-    int st32 = 0) {
+    int st32, double* __restrict__ ll0, int Lm) {
     // One exp per (row, state) is the algorithmic minimum of transcendental work on the
     // whole E-step; keep it lean: constants pinned in VGPRs, branch-free NaN/inf handling.
     ExpConsts ek;
@@ -83,7 +83,7 @@ __device__ __forceinline__ void emission_scaled_epilogue(
       for (int r = 0; r < 4; ++r) {
         const int rl = wave * 16 * MT + m * 16 + lg + 4 * r;
         const int64_t g = g0 + rl;
-        const bool bd = bad_s[rl] != 0;
+        const bool bd = (bad_s[rl] & 1) != 0;
         double v[NT], mx = -INFINITY;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
@@ -107,6 +107,14 @@ __device__ __forceinline__ void emission_scaled_epilogue(
           }
         }
         if (li == 0 && g < nrows) kexp[g] = kx;
+        // first row of a window: its log-likelihoods unscaled, for the initial message
+        // (mod_init + ll_0 is combined in the log domain: k_lin_init)
+        if (ll0 && (bad_s[rl] & 2) && g < nrows) {
+          double* __restrict__ o0 = ll0 + (g / Lm) * K + n0 + li;
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            if (n0 + n * 16 + li < K) o0[n * 16] = v[n];
+        }
       }
     }
 }
@@ -116,7 +124,7 @@ __global__ __launch_bounds__(256) void k_emission_mfma(
     const double* __restrict__ obs, const uint8_t* __restrict__ mask,
     const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K, int Kp,
     int Fp, const double* __restrict__ theta, const int* __restrict__ fab,
-    uint32_t flags, double* __restrict__ ll, double* __restrict__ kexp) {
+    uint32_t flags, double* __restrict__ ll, double* __restrict__ kexp, double* __restrict__ ll0) {
   // workgroup = 4 waves x MT row tiles of 16 rows
   constexpr int ROWS = 64 * MT;
   extern __shared__ double smem[];
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(256) void k_emission_mfma(
       unsigned char bd = 0;
       if (valid && (flags & SVIHMM_MASK_AS_NAN) && mask) bd = mask[orow] != 0;
       rowoff[r] = valid ? orow * D : -1;
-      bad_s[r] = bd;
+      bad_s[r] = bd | ((valid && x == bwr * (unsigned)Lm) ? 2 : 0);   // bit 1: step 0 of its window
       xs[r * DS + D] = 1.0;
       xs[r * DS + D + 1] = 0.0;
     }
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(256) void k_emission_mfma(
       for (int j = 0; j < CH; ++j) {
         const int r = rb + j * rpp + rr;
         if (i < D && r < ROWS) {   // (256 >> sh rows per pass can exceed a 64-row tile)
-          if (v[j] != v[j]) { bad_s[r] = 1; v[j] = 0.0; }
+          if (v[j] != v[j]) { bad_s[r] |= 1; v[j] = 0.0; }
           xs[r * DS + i] = v[j];
         }
       }
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(256) void k_emission_mfma(
       for (int r = 0; r < 4; ++r) outv[m][n][r] = acc[m][n][r];
   __builtin_amdgcn_sched_barrier(0);
   if (SCALED) {
-    emission_scaled_epilogue<NT, MT>(outv, bad_s, wave, li, lg, g0, nrows, K, n0, ll, kexp, (flags >> 16) & 1);
+    emission_scaled_epilogue<NT, MT>(outv, bad_s, wave, li, lg, g0, nrows, K, n0, ll, kexp, (flags >> 16) & 1, ll0, Lm);
   } else {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(256) void k_emission_mfma(
       for (int r = 0; r < 4; ++r) {
         const int rl = wave * 16 * MT + m * 16 + lg + 4 * r;
         const int64_t g = g0 + rl;
-        const bool bd = bad_s[rl] != 0;
+        const bool bd = (bad_s[rl] & 1) != 0;
         if (g < nrows) {
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
@@ -310,7 +318,7 @@ __global__ __launch_bounds__(256) void k_emission_orbit(
     const double* __restrict__ obs, const uint8_t* __restrict__ mask,
     const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K,
     const double* __restrict__ orb, uint32_t flags, double* __restrict__ ll,
-    double* __restrict__ kexp) {
+    double* __restrict__ kexp, double* __restrict__ ll0) {
   constexpr int MT = 2, ROWS = 128, KP = 16 * NT;
   extern __shared__ double smem[];
   const int N = D + 1, c = D >> 2, nd = (D >> 1) + 1, nleft = (nd + 3) >> 2;
@@ -334,7 +342,7 @@ __global__ __launch_bounds__(256) void k_emission_orbit(
       unsigned char bd = 0;
       if (valid && (flags & SVIHMM_MASK_AS_NAN) && mask) bd = mask[orow] != 0;
       rowoff[r] = valid ? orow * D : -1;
-      bad_s[r] = bd;
+      bad_s[r] = bd | ((valid && x == bwr * (unsigned)Lm) ? 2 : 0);   // bit 1: step 0 of its window
       xs1[slot(r, -1)] = 1.0;
       xs1[slot(r, D)] = 1.0;
     }
@@ -358,7 +366,7 @@ __global__ __launch_bounds__(256) void k_emission_orbit(
       for (int j = 0; j < CH; ++j) {
         const int r = rb + j * rpp + rr;
         if (i < D && r < ROWS) {
-          if (v[j] != v[j]) { bad_s[r] = 1; v[j] = 0.0; }
+          if (v[j] != v[j]) { bad_s[r] |= 1; v[j] = 0.0; }
           xs1[slot(r, i)] = v[j];
           if (i + N <= LEN - 2) xs1[slot(r, i + N)] = v[j];
         }
@@ -445,7 +453,7 @@ __global__ __launch_bounds__(256) void k_emission_orbit(
 #pragma unroll
       for (int r = 0; r < 4; ++r) outv[m][n][r] = acc[m][n][r];
   __builtin_amdgcn_sched_barrier(0);
-  emission_scaled_epilogue<NT, MT>(outv, bad_s, wave, li, lg, g0, nrows, K, 0, ll, kexp, (flags >> 16) & 1);
+  emission_scaled_epilogue<NT, MT>(outv, bad_s, wave, li, lg, g0, nrows, K, 0, ll, kexp, (flags >> 16) & 1, ll0, Lm);
 }
 
 // ------------------------------------------------------------------------------------

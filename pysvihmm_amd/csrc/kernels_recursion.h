@@ -646,7 +646,8 @@ struct LinChain {
 template <int NW, bool FULL, int MODE, bool BS = false, typename ST = double>
 __device__ __forceinline__ void fwd_lin_body(
     LinShared<NW>& sh, const ST* __restrict__ Eh, const double* __restrict__ kexp,
-    const double* __restrict__ Aexp, const double* __restrict__ mod_init, int B, int Lm,
+    const double* __restrict__ Aexp, const double* __restrict__ a0v,
+    const double* __restrict__ a0e, int B, int Lm,
     int wstride, int K, ST* __restrict__ ah, double* __restrict__ hx,
     double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac,
     const LinChain& ch) {
@@ -675,13 +676,12 @@ __device__ __forceinline__ void fwd_lin_body(
   {
     double a0[4];
     if (MODE == 0) {
-      // common binary exponent of the initial distribution
-      double mi_max = -INFINITY;
-      for (int k = 0; k < K; ++k) mi_max = fmax(mi_max, mod_init[k]);
-      const double s0 = (mi_max > -1e300 && mi_max < 1e300) ? ceil(mi_max * LOG2E_D) : 0.0;
-      const double pij = vj ? exp(fma(-s0, LN2_LO_D, fma(-s0, LN2_HI_D, mod_init[jc]))) : 0.0;
+      // initial message and its exponent from k_lin_init (mod_init + ll_0, combined in the log domain)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { a0[r] = vj ? pij * Eb[L.oE[r]] : 0.0; h[r] = s0; }
+      for (int r = 0; r < 4; ++r) {
+        a0[r] = vj ? a0v[(size_t)L.gwc[r] * K + jc] : 0.0;
+        h[r] = a0e[L.gwc[r]];
+      }
     } else if (MODE == 1) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -900,14 +900,14 @@ template <int NW, bool FULL, int MODE, bool BS = false, typename ST = double>
 __global__ __launch_bounds__(64 * NW) void k_sweeps_lin(
     const ST* __restrict__ Eh, const double* __restrict__ kexp,
     const double* __restrict__ Aexp, const double* __restrict__ AexpT,
-    const double* __restrict__ mod_init, int B, int Lm, int wstride, int K,
+    const double* __restrict__ a0v, const double* __restrict__ a0e, int B, int Lm, int wstride, int K,
     ST* __restrict__ ah, ST* __restrict__ bh, double* __restrict__ hx,
     double* __restrict__ gx, double* __restrict__ local_lb, double* __restrict__ logz,
     double2* __restrict__ zfac, LinChain ch) {
   extern __shared__ double __attribute__((aligned(16))) lin_smem[];   // sizeof(LinShared<NW>)
   LinShared<NW>& sh = *reinterpret_cast<LinShared<NW>*>(lin_smem);
   if (blockIdx.y == 0)
-    fwd_lin_body<NW, FULL, (MODE == 3 ? 1 : MODE), BS, ST>(sh, Eh, kexp, Aexp, mod_init, B,
+    fwd_lin_body<NW, FULL, (MODE == 3 ? 1 : MODE), BS, ST>(sh, Eh, kexp, Aexp, a0v, a0e, B,
                                                    MODE == 1 ? Lm - 1 : Lm, wstride, K, ah, hx,
                                                    local_lb, logz, zfac, ch);
   else
@@ -926,7 +926,8 @@ template <int NW, bool FULL>
 __global__ __launch_bounds__(64 * NW) void k_sweeps_lin2(
     const double* __restrict__ Eh, const double* __restrict__ kexp,
     const double* __restrict__ Aexp, const double* __restrict__ AexpT,
-    const double* __restrict__ mod_init, int B, int Lm, int K, double* __restrict__ ah,
+    const double* __restrict__ a0v, const double* __restrict__ a0e, int B, int Lm, int K,
+    double* __restrict__ ah,
     double* __restrict__ bh, double* __restrict__ hx, double* __restrict__ gx,
     double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac) {
   constexpr int NT = 2 * NW, KS = 4 * NT;
@@ -965,27 +966,21 @@ __global__ __launch_bounds__(64 * NW) void k_sweeps_lin2(
   double h[4], mant[4], hsum[4];
   int ex[4];
   {
-    double s0 = 0.0, p0 = 1.0, p1 = 1.0;
-    if (fwd) {
-      double mi_max = -INFINITY;
-      for (int k = 0; k < K; ++k) mi_max = fmax(mi_max, mod_init[k]);
-      s0 = (mi_max > -1e300 && mi_max < 1e300) ? ceil(mi_max * LOG2E_D) : 0.0;
-      p0 = v0 ? exp(fma(-s0, LN2_LO_D, fma(-s0, LN2_HI_D, mod_init[jc0]))) : 0.0;
-      p1 = v1 ? exp(fma(-s0, LN2_LO_D, fma(-s0, LN2_HI_D, mod_init[jc1]))) : 0.0;
-    }
     const size_t ro = (size_t)rowof(0) * K;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const double e0 = (Eb + ro)[oE[r] + jc0], e1 = (Eb + ro)[oE[r] + jc1];
-      // forward: ah_0 = pi * Eh_0 (stored), P = ah_0;  backward: bh_top = 1 (stored), P = Eh_top
-      const double s0v = fwd ? p0 * e0 : 1.0, s1v = fwd ? p1 * e1 : 1.0;
+      // forward: ah_0 = the initial message of k_lin_init (stored), P = ah_0;
+      // backward: bh_top = 1 (stored), P = Eh_top
+      const double s0v = fwd ? a0v[(size_t)gwc[r] * K + jc0] : 1.0;
+      const double s1v = fwd ? a0v[(size_t)gwc[r] * K + jc1] : 1.0;
       if (v0) (ob + ro)[oE[r] + jc0] = s0v;
       if (v1) (ob + ro)[oE[r] + jc1] = s1v;
       sh.P[0][lg + 4 * r][j0] = v0 ? (fwd ? s0v : e0) : 0.0;
       sh.P[0][lg + 4 * r][j1] = v1 ? (fwd ? s1v : e1) : 0.0;
-      h[r] = s0; mant[r] = 1.0; ex[r] = 0; hsum[r] = 0.0;
+      h[r] = fwd ? a0e[gwc[r]] : 0.0; mant[r] = 1.0; ex[r] = 0; hsum[r] = 0.0;
     }
-    (xb + rowof(0))[oRw] = s0;
+    (xb + rowof(0))[oRw] = sel4(h, wave & 3);
   }
   __syncthreads();
   for (int s = 1; s < Lm; ++s) {
@@ -1109,7 +1104,8 @@ template <int KMAX, bool FULLK, typename ST = double>
 __global__ __launch_bounds__(64) void k_wave_lin(
     const ST* __restrict__ Eh, const double* __restrict__ kexp,
     const double* __restrict__ Aexp, const double* __restrict__ AexpT,
-    const double* __restrict__ mod_init, int Lm, int K, ST* __restrict__ ah,
+    const double* __restrict__ a0v, const double* __restrict__ a0e, int Lm, int K,
+    ST* __restrict__ ah,
     ST* __restrict__ bh, double* __restrict__ hx, double* __restrict__ gx,
     double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac) {
   __shared__ double p_s[2][64];
@@ -1135,11 +1131,9 @@ __global__ __launch_bounds__(64) void k_wave_lin(
     const int t = rowof(0);
     const double e0 = Eb[(size_t)t * K];
     double o;
-    if (fwd) {
-      double mi_max = -INFINITY;
-      for (int k = 0; k < K; ++k) mi_max = fmax(mi_max, mod_init[k]);
-      h = (mi_max > -1e300 && mi_max < 1e300) ? ceil(mi_max * LOG2E_D) : 0.0;
-      o = valid ? exp(fma(-h, LN2_LO_D, fma(-h, LN2_HI_D, mod_init[jc]))) * e0 : 0.0;
+    if (fwd) {      // the initial message of k_lin_init: mod_init + ll_0 combined in the log domain
+      h = a0e[b];
+      o = valid ? a0v[(size_t)b * K + jc] : 0.0;
       pcur = o;
     } else {
       o = valid ? 1.0 : 0.0;
@@ -1241,7 +1235,8 @@ template <int KMAX, typename ST = double>
 __global__ __launch_bounds__(256) void k_wave_lin4(
     const ST* __restrict__ Eh, const double* __restrict__ kexp,
     const double* __restrict__ Aexp, const double* __restrict__ AexpT,
-    const double* __restrict__ mod_init, int Lm, int K, ST* __restrict__ ah,
+    const double* __restrict__ a0v, const double* __restrict__ a0e, int Lm, int K,
+    ST* __restrict__ ah,
     ST* __restrict__ bh, double* __restrict__ hx, double* __restrict__ gx,
     double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac) {
   constexpr int NI = KMAX / 4;                  // source states per wave
@@ -1270,11 +1265,9 @@ __global__ __launch_bounds__(256) void k_wave_lin4(
     const int t = rowof(0);
     const double e0 = Eb[(size_t)t * K];
     double o;
-    if (fwd) {
-      double mi_max = -INFINITY;
-      for (int k = 0; k < K; ++k) mi_max = fmax(mi_max, mod_init[k]);
-      h = (mi_max > -1e300 && mi_max < 1e300) ? ceil(mi_max * LOG2E_D) : 0.0;
-      o = valid ? exp(fma(-h, LN2_LO_D, fma(-h, LN2_HI_D, mod_init[jc]))) * e0 : 0.0;
+    if (fwd) {      // the initial message of k_lin_init: mod_init + ll_0 combined in the log domain
+      h = a0e[b];
+      o = valid ? a0v[(size_t)b * K + jc] : 0.0;
       pcur = o;
     } else {
       o = valid ? 1.0 : 0.0;
@@ -1395,7 +1388,8 @@ template <int KMAX>
 __global__ __launch_bounds__(256) void k_chunk_scan(
     const double* __restrict__ Mm, const double* __restrict__ MmT, const double* __restrict__ Mh,
     int C, int Kp, int K, const double* __restrict__ Eh, const double* __restrict__ ksum,
-    const double* __restrict__ mod_init, double* __restrict__ abnd, double* __restrict__ aexp,
+    const double* __restrict__ a0v, const double* __restrict__ a0e, double* __restrict__ abnd,
+    double* __restrict__ aexp,
     double* __restrict__ bbnd, double* __restrict__ bexp, double* __restrict__ kbefore,
     double2* __restrict__ zfac, double* __restrict__ logz) {
   extern __shared__ double ring[];            // [4][KMAX][64]
@@ -1426,11 +1420,8 @@ __global__ __launch_bounds__(256) void k_chunk_scan(
   int e_lag = 0;
   if (wave == 0) {
     if (fwd) {
-      double mi_max = -INFINITY;
-      for (int k = 0; k < K; ++k) mi_max = fmax(mi_max, mod_init[k]);
-      const double s0 = (mi_max > -1e300 && mi_max < 1e300) ? ceil(mi_max * LOG2E_D) : 0.0;
-      a = vl ? exp(fma(-s0, LN2_LO_D, fma(-s0, LN2_HI_D, mod_init[lc]))) * Eh[lc] : 0.0;
-      Hx = s0;
+      a = vl ? a0v[lc] : 0.0;      // initial message of k_lin_init (chain = window 0)
+      Hx = a0e[0];
       if (vl) abnd[lane] = a;
       if (lane == 0) aexp[0] = Hx;
       mh = vl ? Mh[lane] : -INFINITY;
@@ -1522,7 +1513,8 @@ __device__ __forceinline__ double block256_max(double v, double* red) {
 __global__ __launch_bounds__(256) void k_chunk_scan_wide(
     const double* __restrict__ Mm, const double* __restrict__ MmT, const double* __restrict__ Mh,
     int C, int Kp, int K, const double* __restrict__ Eh, const double* __restrict__ ksum,
-    const double* __restrict__ mod_init, double* __restrict__ abnd, double* __restrict__ aexp,
+    const double* __restrict__ a0v, const double* __restrict__ a0e, double* __restrict__ abnd,
+    double* __restrict__ aexp,
     double* __restrict__ bbnd, double* __restrict__ bexp, double* __restrict__ kbefore,
     double2* __restrict__ zfac, double* __restrict__ logz) {
   __shared__ double ws[256];
@@ -1558,11 +1550,8 @@ __global__ __launch_bounds__(256) void k_chunk_scan_wide(
   double a, Hx = 0.0;
   int e_lag;
   if (fwd) {
-    double mi_max = -INFINITY;
-    for (int k = 0; k < K; ++k) mi_max = fmax(mi_max, mod_init[k]);
-    const double s0 = (mi_max > -1e300 && mi_max < 1e300) ? ceil(mi_max * LOG2E_D) : 0.0;
-    a = vl ? exp(fma(-s0, LN2_LO_D, fma(-s0, LN2_HI_D, mod_init[jc]))) * Eh[jc] : 0.0;
-    Hx = s0;
+    a = vl ? a0v[jc] : 0.0;      // initial message of k_lin_init (chain = window 0)
+    Hx = a0e[0];
     if (vl) abnd[j] = a;
     if (j == 0) aexp[0] = Hx;
   } else {
@@ -1618,6 +1607,32 @@ __global__ __launch_bounds__(64) void k_chunk_ksum(const double* __restrict__ ke
 // posterior marginals from the scaled messages (API reads of var_x; the statistics GEMM
 // forms the same product in its staging threads and never needs this array).
 // One 16-lane row per (window, t) row.
+// Initial message of every window of the scaled sweeps.  The reference forms
+// lalpha_0 = mod_init + lliks_0 in the log domain (hmmbase.py:292, hmmsgd_metaobs.py:800); a
+// product of two separately shifted exponentials loses the row when the state that carries the
+// first observation is rare in the initial distribution (psi(var_init) of a state with
+// stationary mass 1e-3 is -1000) -- so the sum is taken here, in the log domain, from the first
+// row's unscaled log-likelihoods (ll0: row b at b * stride), and scaled afterwards:
+//   a0[b][j] = exp(lalpha_0[j] - H_b ln 2),  H_b = ceil(max_j lalpha_0[j] / ln 2),
+//   a0exp[b] = H_b - k_0   (alpha_0 = a0 * 2^(a0exp + k_0), k_0 = the emission exponent of row 0).
+// One wavefront per window.
+__global__ __launch_bounds__(256) void k_lin_init(const double* __restrict__ mod_init,
+                                                  const double* __restrict__ ll0, size_t stride,
+                                                  const double* __restrict__ kexp, int B, int Lm, int K,
+                                                  double* __restrict__ a0, double* __restrict__ a0exp) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const double* __restrict__ l0 = ll0 + (size_t)b * stride;
+  double m = -INFINITY;
+  for (int j = lane; j < K; j += 64) m = fmax(m, mod_init[j] + l0[j]);
+  m = wave_max(m);
+  const double H = (m > -1e300 && m < 1e300) ? ceil(m * LOG2E_D) : 0.0;
+  for (int j = lane; j < K; j += 64)
+    a0[(size_t)b * K + j] = exp(fma(-H, LN2_LO_D, fma(-H, LN2_HI_D, mod_init[j] + l0[j])));
+  if (lane == 0) a0exp[b] = H - kexp[(size_t)b * Lm];
+}
+
 template <int KT, typename ST = double>
 __global__ __launch_bounds__(256) void k_lin_posterior(
     const ST* __restrict__ ah, const ST* __restrict__ bh, const double* __restrict__ hx,

@@ -136,6 +136,7 @@ struct svihmm_ctx {
   // scaled linear-domain sweeps: per-row binary exponents, (na, k) records, 1/Z factors,
   // Eh of host-supplied lliks; log-domain intermediates materialised on demand (m_*)
   Buf kexp, hx, gx, zfac, llE, m_ll, m_la, m_lb, chain, chain2;
+  Buf ll0, a0v, a0e;               // first-row log-likelihoods of the windows; initial messages + exponents (k_lin_init)
   bool lin_mode = false;           // ll/la/lb hold Eh / ah / bh of the last sweep (not logs)
   bool q_valid = false;            // lin_mode: var_x has been formed from ah, bh (k_lin_posterior)
   bool lin_stale = false;          // parameters changed since: logs can no longer be rebuilt
@@ -263,7 +264,7 @@ int svihmm_destroy(svihmm_ctx* h) {
                  &h->fab, &h->starts, &h->ll, &h->la, &h->lb, &h->q, &h->lse_part,
                  &h->local_lb, &h->logz, &h->part, &h->packed, &h->scratch, &h->kexp, &h->hx, &h->gx,
                  &h->zfac, &h->llE, &h->m_ll, &h->m_la, &h->m_lb, &h->chain, &h->chain2, &h->cat_table, &h->partc, &h->theta_orb, &h->prior, &h->vlb_aux, &h->gen_z,
-                 &h->svi_state, &h->svi_prior, &h->svi_work, &h->commtmp};
+                 &h->svi_state, &h->svi_prior, &h->svi_work, &h->commtmp, &h->ll0, &h->a0v, &h->a0e};
   for (Buf* b : bufs) release(*b);
   if (h->vlb_host) { hipHostFree(h->vlb_host); h->vlb_host = nullptr; }
   if (h->svi_elbo) { hipHostFree(h->svi_elbo); h->svi_elbo = nullptr; }
@@ -710,7 +711,7 @@ static int upload_starts(svihmm_ctx* h, const int64_t* starts, int B) {
 static int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled = false,
                            const int64_t* starts_dev = nullptr, double* out = nullptr,
                            double* kexp_out = nullptr, hipStream_t stream = nullptr,
-                           size_t min_lds = 0) {
+                           size_t min_lds = 0, double* ll0_out = nullptr) {
   if (!h->have_emission) return fail("no emission parameters: call svihmm_set_emission_niw");
   if (h->eD != h->D) return fail("emission D does not match obs D");
   if (!h->have_globals || h->eK != h->K) return fail("emission K does not match globals K");
@@ -724,6 +725,10 @@ static int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool sc
   if (scaled && !kexp_out) {
     CK(ensure(h->kexp, (size_t)n * sizeof(double)));
     kexp_out = (double*)h->kexp.p;
+  }
+  if (scaled && !ll0_out) {      // first-row log-likelihoods of every window (k_lin_init)
+    CK(ensure(h->ll0, (size_t)B * K * sizeof(double)));
+    ll0_out = (double*)h->ll0.p;
   }
   if (!stream) stream = h->stream;
   const uint8_t* mk = h->have_mask ? (const uint8_t*)h->mask.p : nullptr;
@@ -754,7 +759,7 @@ static int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool sc
     dim3 grid((unsigned)((n + 127) / 128));
 #define EMO(NTV, UV) hipLaunchKernelGGL((k_emission_orbit<NTV, UV>), grid, dim3(256), lds, stream,           \
                                         (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K,               \
-                                        (const double*)h->theta_orb.p, flags, out, kexp_out)
+                                        (const double*)h->theta_orb.p, flags, out, kexp_out, ll0_out)
     if (D % 16 == 0) { if (NT == 4) EMO(4, 4); else if (NT == 3) EMO(3, 4); else if (NT == 2) EMO(2, 4); else EMO(1, 4); }
     else             { if (NT == 4) EMO(4, 2); else if (NT == 3) EMO(3, 2); else if (NT == 2) EMO(2, 2); else EMO(1, 2); }
 #undef EMO
@@ -784,7 +789,7 @@ static int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool sc
     hipLaunchKernelGGL((k_emission_mfma<NTV, MTV, SC>), grid, dim3(256), lds, stream,         \
                        (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K,                  \
                        Kp, h->Fp, (const double*)h->theta.p, (const int*)h->fab.p, flags,     \
-                       out, kexp_out);                                                        \
+                       out, kexp_out, SC ? ll0_out : (double*)nullptr);                       \
   } while (0)
       if (scaled) {
         if (NT == 4) EMM_LAUNCH(4, 2, true); else if (NT == 3) EMM_LAUNCH(3, 2, true);
@@ -936,6 +941,22 @@ static int ensure_fb_lin(svihmm_ctx* h, int B, int Lm) {
   CK(ensure(h->local_lb, (size_t)B * sizeof(double)));
   CK(ensure(h->logz, (size_t)B * sizeof(double)));
   CK(ensure(h->packed, (size_t)packed_len(h) * sizeof(double)));
+  CK(ensure(h->a0v, (size_t)B * K * sizeof(double)));
+  CK(ensure(h->a0e, (size_t)B * sizeof(double)));
+  return 0;
+}
+// initial messages of windows [b0, b0+nb): mod_init + ll_0 in the log domain (k_lin_init); the
+// first rows' log-likelihoods come from the scaled emission's side output (ll0) or, where the
+// plain lliks are kept (host lliks, wide models, Categorical), straight from those
+static int launch_lin_init(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_t stream) {
+  const int K = h->K;
+  const double* src = h->eh_in_llE ? (const double*)h->ll.p + (size_t)b0 * Lm * K
+                                   : (const double*)h->ll0.p + (size_t)b0 * K;
+  const size_t stride = h->eh_in_llE ? (size_t)Lm * K : (size_t)K;
+  hipLaunchKernelGGL(k_lin_init, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, stream,
+                     (const double*)h->mod_init.p, src, stride, (const double*)h->kexp.p + (size_t)b0 * Lm,
+                     nb, Lm, K, (double*)h->a0v.p + (size_t)b0 * K, (double*)h->a0e.p + b0);
+  HIPCK(hipGetLastError());
   return 0;
 }
 // up to this many windows the wave-per-window scaled sweep beats the MFMA one (which is
@@ -962,7 +983,10 @@ static int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_
   double2* zf = (double2*)h->zfac.p + b0;
   double* llb = (double*)h->local_lb.p + b0;
   double* lz = (double*)h->logz.p + b0;
+  const double* a0v = (const double*)h->a0v.p + (size_t)b0 * K;
+  const double* a0e = (const double*)h->a0e.p + b0;
   ProfScope ps(h, KS_FB, stream);
+  CK(launch_lin_init(h, b0, nb, Lm, stream));
   if (h->cur_f32) {
     // fp32 mode (K <= 64, b0 == 0): the same kernels instantiated for float storage
     const float* Ef = (const float*)h->ll.p;
@@ -971,10 +995,10 @@ static int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_
     if (nb < LIN_WAVE_MAX && h->variant[7] != 2) {
       dim3 gw((unsigned)nb, 2);
 #define WLF(KM, FK) hipLaunchKernelGGL((k_wave_lin<KM, FK, float>), gw, dim3(64), 0, stream, Ef, kx, (const double*)h->Aexp.p, \
-                                       (const double*)h->AexpT.p, (const double*)h->mod_init.p, Lm, K, af, bf, hx,   \
+                                       (const double*)h->AexpT.p, a0v, a0e, Lm, K, af, bf, hx,   \
                                        gx, llb, lz, zf)
 #define WL4F(KM) hipLaunchKernelGGL((k_wave_lin4<KM, float>), gw, dim3(256), 0, stream, Ef, kx, (const double*)h->Aexp.p, \
-                                    (const double*)h->AexpT.p, (const double*)h->mod_init.p, Lm, K, af, bf, hx, gx, \
+                                    (const double*)h->AexpT.p, a0v, a0e, Lm, K, af, bf, hx, gx, \
                                     llb, lz, zf)
       if (K > 16 && nb <= LIN_WAVE4_MAX && h->variant[7] != 3) { if (K <= 32) WL4F(32); else WL4F(64); }
       else if (K <= 16) WLF(16, false); else if (K <= 32) WLF(32, false);
@@ -985,7 +1009,7 @@ static int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_
       const LinChain none = {};
 #define SWF(NWV, F) hipLaunchKernelGGL((k_sweeps_lin<NWV, F, 0, false, float>), grid, dim3(64 * NWV),              \
                                        sizeof(LinShared<NWV>), stream, Ef, kx, (const double*)h->Aexp.p,         \
-                                       (const double*)h->AexpT.p, (const double*)h->mod_init.p, nb, Lm, Lm, K,   \
+                                       (const double*)h->AexpT.p, a0v, a0e, nb, Lm, Lm, K,   \
                                        af, bf, hx, gx, llb, lz, zf, none)
       if (NW == 1) { if (full) SWF(1, true); else SWF(1, false); }
       else if (NW == 2) { if (full) SWF(2, true); else SWF(2, false); }
@@ -1000,13 +1024,13 @@ static int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_
     // small batches: one wavefront per (window, direction)
     dim3 gw((unsigned)nb, 2);
 #define WL(KM, FK) hipLaunchKernelGGL((k_wave_lin<KM, FK>), gw, dim3(64), 0, stream, Eh, kx, (const double*)h->Aexp.p, \
-                                      (const double*)h->AexpT.p, (const double*)h->mod_init.p, Lm, K, ah, bh, hx,  \
+                                      (const double*)h->AexpT.p, a0v, a0e, Lm, K, ah, bh, hx,  \
                                       gx, llb, lz, zf)
     // up to a few hundred windows the chip is far from full with one wave per (window,
     // direction): split each window's source states over four waves (variant[7] = 3: off)
     if (K > 16 && nb <= LIN_WAVE4_MAX && h->variant[7] != 3) {
 #define WL4(KM) hipLaunchKernelGGL((k_wave_lin4<KM>), gw, dim3(256), 0, stream, Eh, kx, (const double*)h->Aexp.p, \
-                                   (const double*)h->AexpT.p, (const double*)h->mod_init.p, Lm, K, ah, bh, hx,  \
+                                   (const double*)h->AexpT.p, a0v, a0e, Lm, K, ah, bh, hx,  \
                                    gx, llb, lz, zf)
       if (K <= 32) WL4(32); else WL4(64);
 #undef WL4
@@ -1026,7 +1050,7 @@ static int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
     hipLaunchKernelGGL((k_sweeps_lin<NWV, F, 0, BSV>), grid, dim3(64 * NWV), lds, stream, Eh, kx,          \
                        (const double*)h->Aexp.p, (const double*)h->AexpT.p,                                \
-                       (const double*)h->mod_init.p, nb, Lm, Lm, K, ah, bh, hx, gx, llb, lz, zf, none);    \
+                       a0v, a0e, nb, Lm, Lm, K, ah, bh, hx, gx, llb, lz, zf, none);    \
   } while (0)
 #define SWP(NWV, F) SWPX(NWV, F, false)
   if (NW == 1) { if (full) SWP(1, true); else SWP(1, false); }
@@ -1042,7 +1066,7 @@ static int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_
     hipFuncSetAttribute((const void*)k_sweeps_lin2<8, F>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
                         (int)lds);                                                                         \
     hipLaunchKernelGGL((k_sweeps_lin2<8, F>), grid, dim3(512), lds, stream, Eh, kx,                        \
-                       (const double*)h->Aexp.p, (const double*)h->AexpT.p, (const double*)h->mod_init.p,  \
+                       (const double*)h->Aexp.p, (const double*)h->AexpT.p, a0v, a0e,  \
                        nb, Lm, K, ah, bh, hx, gx, llb, lz, zf);                                            \
   } while (0)
     if (h->variant[7] == 1) { if (NW <= 12) { if (K == 192) SWPX(12, true, true); else SWPX(12, false, true); }
@@ -1128,18 +1152,20 @@ static int launch_fb_chain(svihmm_ctx* h, int Lm, bool total) {
   double* ah = (double*)h->la.p; double* bh = (double*)h->lb.p;
   double* hx = (double*)h->hx.p; double* gx = (double*)h->gx.p;
   const double* A = (const double*)h->Aexp.p; const double* At = (const double*)h->AexpT.p;
-  const double* mi = (const double*)h->mod_init.p;
+  const double* a0v = (const double*)h->a0v.p;
+  const double* a0e = (const double*)h->a0e.p;
   hipStream_t st = h->stream;
   ProfScope ps(h, KS_FB, st);
+  CK(launch_lin_init(h, 0, 1, Lm, st));
 #define SWPM(NWV, F, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH)                       \
   hipLaunchKernelGGL((k_sweeps_lin<NWV, F, MD>), GRID, dim3(64 * NWV), sizeof(LinShared<NWV>), st, EHP, KXP, A, At, \
-                     mi, BB, LL, WS, K, AH, BH, HX, GX, LB, LZ, ZF, CH)
+                     a0v, a0e, BB, LL, WS, K, AH, BH, HX, GX, LB, LZ, ZF, CH)
 #define SWPB(NWV, F, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH)                       \
   do {                                                                                                      \
     hipFuncSetAttribute((const void*)k_sweeps_lin<NWV, F, MD, true>,                                        \
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LinShared<NWV>));           \
     hipLaunchKernelGGL((k_sweeps_lin<NWV, F, MD, true>), GRID, dim3(64 * NWV), sizeof(LinShared<NWV>), st,  \
-                       EHP, KXP, A, At, mi, BB, LL, WS, K, AH, BH, HX, GX, LB, LZ, ZF, CH);                 \
+                       EHP, KXP, A, At, a0v, a0e, BB, LL, WS, K, AH, BH, HX, GX, LB, LZ, ZF, CH);                 \
   } while (0)
 #define SWPD(MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH)                                \
   do {                                                                                                      \
@@ -1175,13 +1201,13 @@ static int launch_fb_chain(svihmm_ctx* h, int Lm, bool total) {
     if (lds > 64 * 1024)                                                                                           \
       hipFuncSetAttribute((const void*)k_chunk_scan<KM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
     hipLaunchKernelGGL(k_chunk_scan<KM>, dim3(2), dim3(256), lds, st, (const double*)Mm, (const double*)MmT,       \
-                       (const double*)Mh, C, Kp, K, Eh, (const double*)ksum, mi, abnd, aexp, bbnd, bexp, kbef,     \
+                       (const double*)Mh, C, Kp, K, Eh, (const double*)ksum, a0v, a0e, abnd, aexp, bbnd, bexp, kbef,     \
                        (double2*)h->zfac.p, (double*)h->logz.p);                                                   \
   } while (0)
   if (K <= 16) SCAN(16); else if (K <= 32) SCAN(32); else if (K <= 64) SCAN(64);
   else
     hipLaunchKernelGGL(k_chunk_scan_wide, dim3(2), dim3(256), 0, st, (const double*)Mm, (const double*)MmT,
-                       (const double*)Mh, C, Kp, K, Eh, (const double*)ksum, mi, abnd, aexp, bbnd, bexp, kbef,
+                       (const double*)Mh, C, Kp, K, Eh, (const double*)ksum, a0v, a0e, abnd, aexp, bbnd, bexp, kbef,
                        (double2*)h->zfac.p, (double*)h->logz.p);
 #undef SCAN
   // S3: every chunk as a window with boundary conditions
@@ -1706,6 +1732,7 @@ static int estep_pipelined(svihmm_ctx* h, const int64_t* starts, int B, int Lm, 
   // all buffers first: ensure() may reallocate
   CK(ensure(h->ll, (size_t)n * K * sizeof(double)));
   CK(ensure(h->kexp, (size_t)n * sizeof(double)));
+  CK(ensure(h->ll0, (size_t)B * K * sizeof(double)));
   CK(ensure_fb_lin(h, B, Lm));
   int b0[2], nb[2];
   b0[0] = 0; nb[0] = ((B / 2 + 15) / 16) * 16; b0[1] = nb[0]; nb[1] = B - nb[0];
@@ -1724,7 +1751,8 @@ static int estep_pipelined(svihmm_ctx* h, const int64_t* starts, int B, int Lm, 
   for (int c = 0; c < 2; ++c) {
     const size_t ro = (size_t)b0[c] * Lm;
     CK(launch_emission(h, nb[c], Lm, flags, true, (const int64_t*)h->starts.p + b0[c],
-                       (double*)h->ll.p + ro * K, (double*)h->kexp.p + ro, A, em_lds));
+                       (double*)h->ll.p + ro * K, (double*)h->kexp.p + ro, A, em_lds,
+                       (double*)h->ll0.p + (size_t)b0[c] * K));
     HIPCK(hipEventRecord(h->ev_em[c], A));
     HIPCK(hipStreamWaitEvent(Bs, h->ev_em[c], 0));
     CK(launch_fb_lin_range(h, b0[c], nb[c], Lm, Bs));

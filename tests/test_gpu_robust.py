@@ -1,0 +1,115 @@
+"""Dynamic-range robustness of the scaled linear-domain paths (found by tests/fuzz_gpu.py).
+
+* A window that STARTS in a state the initial distribution makes rare: psi(var_init) of a state
+  with stationary mass 1e-4 is -1e4, the other states' emission terms are thousands of nats below
+  the row maximum when the states are well separated -- the reference adds the two in the log
+  domain (hmmbase.py:292, hmmsgd_metaobs.py:800); a product of two separately shifted
+  exponentials is 0 for every state and the window's posterior turns into NaN.
+* Transition expectations below the range of exp() (Dirichlet pseudo-counts of ~1e-3 and less:
+  psi(1e-3) = -1000): the scaled recursions cannot represent them; the engine must take the
+  exact log-domain recursion there.
+"""
+import numpy as np
+import pytest
+from scipy.special import digamma
+
+from tests.helpers import make_problem, unpack
+
+pytestmark = pytest.mark.gpu
+
+
+def _rare_init_problem(K, D, T, seed):
+    pb = make_problem(K, D, T, seed=seed, miss=0.05, sep=20.0)
+    rng = np.random.default_rng(seed + 1)
+    var_init = np.where(rng.random(K) < 0.5, 1e-4, 0.3) * (0.5 + rng.random(K))
+    var_init[0] = 0.4
+    var_init[K - 1] = 3e-5
+    pb["mod_init"] = digamma(var_init + 1e-9) - digamma(var_init.sum() + 1e-9)
+    return pb
+
+
+def _check(e, L, ref_c, pb, starts, Lm, rtol=1e-6):
+    K, D = pb["K"], pb["D"]
+    par = (pb["mod_init"], pb["ltran"], pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    e.set_obs(pb["obs"], pb["mask"])
+    e.set_globals(pb["mod_init"], pb["ltran"])
+    e.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    B = len(starts)
+    sc = B * Lm
+    xs = max(1.0, float(np.nanmax(np.abs(pb["obs"]))))
+    for flags in (L.TRANS_WRAP, L.MASK_AS_NAN):
+        st = e.estep(starts, Lm, flags=flags)
+        assert np.all(np.isfinite(st.buf)), "non-finite statistics"
+        ref = ref_c.estep_minibatch(pb["obs"], pb["mask"], starts, Lm, *par, flags=flags)
+        g, r = unpack(st.buf, K, D), unpack(ref, K, D)
+        np.testing.assert_allclose(g[0], r[0], rtol=rtol, atol=1e-9 * sc)
+        np.testing.assert_allclose(g[1], r[1], rtol=rtol, atol=1e-9 * sc * xs)
+        np.testing.assert_allclose(g[2], r[2], rtol=rtol, atol=1e-9 * sc)
+        np.testing.assert_allclose(g[3], r[3], rtol=rtol, atol=1e-9 * sc * xs * xs)
+        np.testing.assert_allclose(g[4], r[4], rtol=1e-9, atol=1e-6)
+    # posteriors of a few windows against the oracle's log-domain recursion
+    for b in np.unique(np.linspace(0, B - 1, 4).astype(int)):
+        x = pb["obs"][starts[b]:starts[b] + Lm].copy()
+        x[pb["mask"][starts[b]:starts[b] + Lm]] = np.nan
+        ll = ref_c.lliks_niw(x, pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+        q, _ = ref_c.posterior(ref_c.forward(ll, pb["mod_init"], pb["ltran"]), ref_c.backward(ll, pb["ltran"]))
+        np.testing.assert_allclose(e.read_rows("var_x", int(b) * Lm, Lm), q, rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("K,D,Lm,B", [(8, 4, 33, 20), (8, 4, 33, 300), (8, 4, 17, 1100), (64, 8, 9, 1100),
+                                      (33, 8, 65, 64), (100, 4, 9, 200), (200, 4, 9, 200)])
+def test_window_starts_in_a_rare_state(K, D, Lm, B):
+    """Every sweep kernel of the scaled path (k_wave_lin4, k_wave_lin, k_sweeps_lin, the streamed
+    wide-model variants): mod_init spans 1e4 nats and many windows start in a rare state."""
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    from oracle import ref_c
+    T = max(4 * Lm, 600)
+    pb = _rare_init_problem(K, D, T, seed=500 + K + B)
+    starts = np.random.default_rng(B).integers(0, T - Lm + 1, size=B)
+    e = HipEngine(0)
+    try:
+        _check(e, L, ref_c, pb, starts, Lm)
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("K,T", [(8, 3000), (64, 2500), (100, 2200)])
+def test_chain_starts_in_a_rare_state(K, T):
+    """The blocked scan's first boundary vector (k_chunk_scan / k_chunk_scan_wide)."""
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    from oracle import ref_c
+    pb = _rare_init_problem(K, 4, T, seed=900 + K)
+    # make sure the chain itself starts in a rare state
+    first = int(pb["sts"][0])
+    vi = np.exp(pb["mod_init"])
+    var_init = np.full(K, 0.3); var_init[first] = 2e-5
+    pb["mod_init"] = digamma(var_init + 1e-9) - digamma(var_init.sum() + 1e-9)
+    pb["mask"][0] = False
+    e = HipEngine(0)
+    try:
+        _check(e, L, ref_c, pb, np.zeros(1, dtype=np.int64), T)
+    finally:
+        e.close()
+
+
+def test_f32_mode_rare_initial_state():
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    K, D, Lm, B = 16, 8, 33, 400
+    T = 4000
+    pb = _rare_init_problem(K, D, T, seed=77)
+    starts = np.random.default_rng(5).integers(0, T - Lm + 1, size=B)
+    res = {}
+    for dt in ("f64", "f32"):
+        e = HipEngine(0, dtype=dt)
+        e.set_obs(pb["obs"], pb["mask"])
+        e.set_globals(pb["mod_init"], pb["ltran"])
+        e.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+        res[dt] = e.estep(starts, Lm, flags=L.TRANS_WRAP)
+        e.close()
+    assert np.all(np.isfinite(res["f32"].buf))
+    sc = B * Lm
+    np.testing.assert_allclose(res["f32"].A_raw, res["f64"].A_raw, rtol=2e-3, atol=2e-4 * sc)
+    np.testing.assert_allclose(res["f32"].neff, res["f64"].neff, rtol=2e-3, atol=2e-4 * sc)
