@@ -62,6 +62,7 @@ typedef struct svihmm_ctx svihmm_ctx;
  * current parameters, which the iteration's global step replaces.  The reference leaves the
  * state of the last meta-observation on the object (hmmsgd_metaobs.py:405-436). */
 #define SVIHMM_SVI_KEEP_WINDOW 16u
+#define SVIHMM_SVI_MIN_PSEUDOCOUNT 2.5e-3
 
 /* ---- errors / lifecycle ------------------------------------------------------- */
 const char* svihmm_last_error(void);
@@ -106,7 +107,15 @@ int svihmm_set_obs_rows(svihmm_ctx* h, int64_t row0, int64_t nrows, const double
 /* mod_init[K], ltran[K,K] in the log domain: the psi-expectations of
  * hmmbase.py:214-216 / hmmsgd_metaobs.py:502-504 (computed on the host with
  * SciPy's digamma, uploaded once per minibatch).  The FFBS variant passes
- * ltran = log(var_tran + DBL_EPSILON) instead (hmm_fast.pyx:91-93). */
+ * ltran = log(var_tran + DBL_EPSILON) instead (hmm_fast.pyx:91-93).
+ * Dynamic range: the fast recursions carry exp(ltran).  If any entry lies below
+ * SVIHMM_LTRAN_LINEAR_MIN (Dirichlet pseudo-counts of ~2e-3 and less: psi(1e-3) = -1000, not
+ * representable) every recursion with these globals runs the reference's own
+ * np.logaddexp.reduce form instead (hmmbase.py:295, 319; one exp per state PAIR and step --
+ * correct, an order of magnitude slower); the fp32 mode needs entries above
+ * SVIHMM_LTRAN_F32_MIN and computes in fp64 otherwise. */
+#define SVIHMM_LTRAN_LINEAR_MIN (-600.0)
+#define SVIHMM_LTRAN_F32_MIN (-60.0)
 int svihmm_set_globals(svihmm_ctx* h, int32_t K, const double* mod_init,
                        const double* ltran);
 
@@ -179,7 +188,11 @@ int svihmm_estep_minibatch_ex(svihmm_ctx* h, const int64_t* starts, int32_t B,
  *   prior_logpart[k] = invwishart_log_partitionfunction(sigma0[k], nu0[k]) (constant of the
  *   factors' ELBO term, computed once by the host); zsign = +1 / -1: the sign with which that
  *   constant enters get_vlb (pybasicbayes / Bishop 10.74, see distributions.Gaussian.get_vlb).
- *   The observations must be resident (svihmm_set_obs / svihmm_generate).
+ *   The observations must be resident (svihmm_set_obs / svihmm_generate).  Fails when an entry
+ *   of prior_tran or var_tran is below SVIHMM_SVI_MIN_PSEUDOCOUNT: var_tran never falls below the
+ *   smaller of the two during the loop, so above it psi(var_tran) stays inside the range of the
+ *   linear-domain recursions; sparser Dirichlet models take the per-call route
+ *   (svihmm_set_globals decides per upload).
  * svihmm_svi_iteration(it, ...): one iteration on windows starts[B] of length Lm (statistics over
  *   the inner segment, as svihmm_estep_minibatch_ex; flags: SVIHMM_TRANS_WRAP | ...).
  *   nwin_total = windows of the whole minibatch (= B on one GPU; with a communicator the ranks

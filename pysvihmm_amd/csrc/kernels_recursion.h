@@ -148,6 +148,73 @@ __global__ void k_fb_generic(const double* __restrict__ ll, const double* __rest
 }
 
 // ------------------------------------------------------------------------------------
+//  K2x: the reference's recursion literally -- np.logaddexp.reduce over (message + ltran)
+//       (hmmbase.py:295, 319): one exp per (source, target) pair and step.  Every other
+//       sweep kernel works with exp(ltran), which cannot represent transition expectations
+//       below the range of exp() (Dirichlet pseudo-counts of ~1e-3: psi(1e-3) = -1000); models
+//       like that are routed here (svihmm_set_globals decides).  Thread = state, block =
+//       roundup(K, 64); ltran in LDS (row stride K + 1: both directions conflict-free) when it
+//       fits.  grid (B, ndir).
+// ------------------------------------------------------------------------------------
+__global__ void k_fb_exact(const double* __restrict__ ll, const double* __restrict__ ltran,
+                           const double* __restrict__ mod_init, int Lm, int K, int dir0,
+                           int lt_in_lds, double* __restrict__ la_out, double* __restrict__ lb_out) {
+  extern __shared__ double sm[];
+  double* v_s = sm;              // [2][K]
+  double* lt_s = sm + 2 * K;     // [K][K + 1] if lt_in_lds
+  const int b = blockIdx.x, dir = dir0 + blockIdx.y, j = threadIdx.x;
+  const bool valid = j < K;
+  const int ls = lt_in_lds ? K + 1 : K;
+  const double* lt = ltran;
+  if (lt_in_lds) {
+    for (int e = threadIdx.x; e < K * K; e += blockDim.x) lt_s[(e / K) * (K + 1) + e % K] = ltran[e];
+    lt = lt_s;
+  }
+  const double* llb = ll + (size_t)b * Lm * K;
+  // element (source i, target j) of the transition expectations as seen from thread j:
+  // forward lt[i][j], backward (thread = source state) lt[j][i]
+  const size_t si = dir == 0 ? (size_t)ls : 1, sj = dir == 0 ? 1 : (size_t)ls;
+  const double* mycol = lt + (valid ? j : 0) * sj;
+  int cur = 0;
+  auto lse = [&](const double* v) {
+    double m = -INFINITY;
+    for (int i = 0; i < K; ++i) m = fmax(m, v[i] + mycol[i * si]);
+    if (!(m > -INFINITY)) return m;            // all terms -inf (or NaN): as np.logaddexp.reduce
+    if (!(m < INFINITY)) return m;
+    double s = 0.0;
+    for (int i = 0; i < K; ++i) s += exp(v[i] + mycol[i * si] - m);
+    return m + log(s);
+  };
+  if (dir == 0) {
+    double* out = la_out + (size_t)b * Lm * K;
+    double la = valid ? mod_init[j] + llb[j] : -INFINITY;
+    if (valid) out[j] = la;
+    for (int t = 1; t < Lm; ++t) {
+      if (valid) v_s[cur * K + j] = la;
+      __syncthreads();
+      if (valid) {
+        la = lse(v_s + cur * K) + llb[(size_t)t * K + j];
+        out[(size_t)t * K + j] = la;
+      }
+      cur ^= 1;
+    }
+  } else {
+    double* out = lb_out + (size_t)b * Lm * K;
+    double lb = 0.0;
+    if (valid) out[(size_t)(Lm - 1) * K + j] = 0.0;
+    for (int t = Lm - 2; t >= 0; --t) {
+      if (valid) v_s[cur * K + j] = lb + llb[(size_t)(t + 1) * K + j];
+      __syncthreads();
+      if (valid) {
+        lb = lse(v_s + cur * K);
+        out[(size_t)t * K + j] = lb;
+      }
+      cur ^= 1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 //  K2c/K2d: forward and backward(+posterior) sweeps as batched fp64 MFMA mat-mats.
 //  A workgroup owns 16 windows (the M dimension of v_mfma_f64_16x16x4_f64); wave s owns
 //  the 16-state tile n0=16*s (K <= 64 -> NW = Kp/16 waves).  Per time step

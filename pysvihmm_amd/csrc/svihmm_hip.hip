@@ -106,6 +106,9 @@ struct svihmm_ctx {
   int K = 0;
   Buf mod_init, ltran, Aexp, AexpT;
   bool have_globals = false;
+  // transition expectations below the range exp() represents with headroom: every recursion goes
+  // through the literal log-domain kernel (k_fb_exact); f32_ok: within the range of a float
+  bool exact_log = false, f32_ok = true;
   // emission
   int eK = 0, eD = 0, Kp = 0, F = 0, Fp = 0;
   Buf theta, theta_orb, fab, niw, cat_table, partc, prior, vlb_aux, gen_z;
@@ -365,6 +368,8 @@ int svihmm_set_obs_rows(svihmm_ctx* h, int64_t row0, int64_t nrows, const double
   return 0;
 }
 
+// SVIHMM_LTRAN_LINEAR_MIN: exp(-600) = 1e-261 is a normal double with 1e-47 of headroom for
+// products with a scaled message; below it: k_fb_exact
 int svihmm_set_globals(svihmm_ctx* h, int32_t K, const double* mod_init, const double* ltran) {
   if (!h || K <= 0 || !mod_init || !ltran) return fail("svihmm_set_globals: bad arguments");
   if (K > 1024) return fail("svihmm_set_globals: K > 1024 unsupported");
@@ -403,6 +408,17 @@ int svihmm_set_globals(svihmm_ctx* h, int32_t K, const double* mod_init, const d
   HIPCK(hipGetLastError());
   CK(pin_release(h, slot));   // guards the slot until the kernel has read it
   h->K = K; h->have_globals = true;
+  // dynamic range of the transition expectations (K^2 values, host side): exp(ltran) must stay a
+  // normal double with headroom for the scaled recursions, a normal float for the fp32 mode
+  double lmin = 0.0;
+  bool finite = true;
+  for (size_t i = 0; i < (size_t)K * K; ++i) {
+    const double v = ltran[i];
+    if (!(v > -1.7e308 && v < 1.7e308)) finite = false;
+    else if (v < lmin) lmin = v;
+  }
+  h->exact_log = !finite || lmin < SVIHMM_LTRAN_LINEAR_MIN;
+  h->f32_ok = finite && lmin > SVIHMM_LTRAN_F32_MIN;
   return 0;
 }
 
@@ -832,6 +848,17 @@ static int launch_fb(svihmm_ctx* h, int B, int Lm, int dir0, int ndir,
   dim3 grid(B, ndir);
   const double* A = (const double*)h->Aexp.p;
   const double* mi = (const double*)h->mod_init.p;
+  if (h->exact_log) {   // transition expectations outside exp()'s range: the literal recursion
+    const int threads = (K + 63) / 64 * 64;
+    const int in_lds = ((size_t)K * (K + 1) + 2 * K) * 8 <= 150 * 1024;
+    const size_t lds = (2 * (size_t)K + (in_lds ? (size_t)K * (K + 1) : 0)) * 8;
+    if (lds > 64 * 1024)
+      hipFuncSetAttribute((const void*)k_fb_exact, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_fb_exact, grid, dim3(threads), lds, h->stream, ll, (const double*)h->ltran.p, mi,
+                       Lm, K, dir0, in_lds, la, lb);
+    HIPCK(hipGetLastError());
+    return 0;
+  }
   if (K <= 16)
     hipLaunchKernelGGL(k_fb_wave<16>, grid, dim3(64), 0, h->stream, ll, A, mi, Lm, K, dir0, la, lb);
   else if (K <= 32)
@@ -1117,7 +1144,7 @@ static int launch_sum_lb(svihmm_ctx* h, int B, hipStream_t stream) {
 // that the sequential boundary scan (S2) stays short (S1's work does not depend on it)
 static int chain_len(int Lm) { return Lm >= 512 * 1024 ? 1024 : 256; }
 static bool use_chain(const svihmm_ctx* h, int B, int Lm) {
-  return B == 1 && h->K <= 256 && Lm >= 2048 && h->variant[6] != 1;
+  return B == 1 && h->K <= 256 && Lm >= 2048 && h->variant[6] != 1 && !h->exact_log;
 }
 static int launch_fb_chain(svihmm_ctx* h, int Lm, bool total) {
   const int K = h->K, T = Lm, L = chain_len(Lm);
@@ -1256,7 +1283,7 @@ static int flush_lb(svihmm_ctx* h, hipStream_t stream) {
 // linear-domain MFMA (the E-step fast path; logs are materialised on demand).
 static int pick_fb(const svihmm_ctx* h, int B, int Lm, bool want_logs) {
   int var = h->variant[2];
-  if (h->K > 256) return 1;
+  if (h->K > 256 || h->exact_log) return 1;
   if (h->K > 64) {   // no log-domain MFMA sweep beyond 64 states: scaled (streamed B) or per-window
     if (var == 2) var = 1;
     if (var == 0) var = ((B >= 192 || use_chain(h, B, Lm)) && !want_logs) ? 3 : 1;   // one long chain: blocked scan
@@ -1574,7 +1601,7 @@ static int prepare_ll(svihmm_ctx* h, const int64_t* starts, int B, int Lm, uint3
     // fp32 mode: scaled messages stored as float + fp32 statistics GEMM, for what the mode
     // covers (NIW emission, K <= 64, window batches on the scaled sweeps); everything else
     // runs as fp64
-    h->cur_f32 = lin && h->prec == 1 && !two_pass && !use_chain(h, B, Lm);
+    h->cur_f32 = lin && h->prec == 1 && h->f32_ok && !two_pass && !use_chain(h, B, Lm);
     CK(launch_emission(h, B, Lm, flags, lin && !two_pass));
     if (two_pass) CK(launch_scale_ll(h, B, Lm));
     h->have_host_ll = false;
@@ -2012,6 +2039,18 @@ int svihmm_svi_begin(svihmm_ctx* h, int32_t K, int32_t D, const double* prior_tr
   CK(set_device(h));
   const size_t kk = (size_t)K * K, nmu = (size_t)K * D, nsg = (size_t)K * D * D;
   const size_t nin = nmu + nsg + 2 * (size_t)K;
+  {
+    // every later var_tran is a convex combination of the current one and prior + statistics, so
+    // its entries never fall below this minimum: psi(v) - psi(row sum) stays inside the range of
+    // the linear-domain recursions for the whole loop (the row sums are < 1e12: psi < 28)
+    double vmin = INFINITY;
+    for (size_t i = 0; i < kk; ++i) vmin = std::fmin(vmin, std::fmin(prior_tran[i], var_tran[i]));
+    if (!(vmin >= SVIHMM_SVI_MIN_PSEUDOCOUNT))
+      return fail("svihmm_svi_begin: transition pseudo-counts below SVIHMM_SVI_MIN_PSEUDOCOUNT need the "
+                  "log-domain recursion: run the loop through svihmm_set_globals + svihmm_estep_minibatch");
+    h->exact_log = false;
+    h->f32_ok = vmin > 0.05;          // psi(0.05) - 28 > SVIHMM_LTRAN_F32_MIN
+  }
   h->svi_K = K; h->svi_D = D; h->svi_maxit = maxit; h->svi_zsign = zsign;
   {   // sum_i [lgamma(sum_j p_ij + eps) - sum_j lgamma(p_ij + eps)]: the prior-only part of the rows' energy
     double pc = 0.0;

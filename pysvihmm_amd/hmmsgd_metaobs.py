@@ -372,6 +372,10 @@ class VBHMM(VariationalHMMBase):
                 return False
         if self.comm is not None and not hasattr(self.comm, "bind_engine"):
             return False
+        # transition pseudo-counts this small need the log-domain recursion, which the engine
+        # selects per globals upload (include/svihmm.h: SVIHMM_SVI_MIN_PSEUDOCOUNT)
+        if min(np.min(self.prior_tran), np.min(self.var_tran)) < L.SVI_MIN_PSEUDOCOUNT:
+            return False
         return True
 
     def _svi_pull_state(self):

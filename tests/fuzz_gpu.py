@@ -43,16 +43,20 @@ def draw_case(rng):
     sep = float(rng.choice([0.0, 0.5, 3.0, 20.0, 60.0]))
     miss = float(rng.choice([0.0, 0.0, 0.1, 0.5]))
     sparse = bool(rng.random() < 0.25)        # near-absorbing / sparse transition expectations
-    return K, D, Lm, B, sep, miss, sparse
+    rare = bool(rng.random() < 0.3)           # initial distribution with states of mass 1e-4 and less
+    return K, D, Lm, B, sep, miss, sparse, rare
 
 
 def problem(case, seed):
-    K, D, Lm, B, sep, miss, sparse = case
+    K, D, Lm, B, sep, miss, sparse, rare = case
     T = max(4 * Lm, 400)
     pb = make_problem(K, D, T, seed=seed, miss=miss, sep=sep)
     rng = np.random.default_rng(seed + 7)
+    from scipy.special import digamma
+    if rare:
+        vi = np.where(rng.random(K) < 0.5, 10.0 ** -rng.uniform(3, 7, K), 0.3) * (0.5 + rng.random(K))
+        pb["mod_init"] = digamma(vi + 1e-9) - digamma(vi.sum() + 1e-9)
     if sparse:
-        from scipy.special import digamma
         vt = 1e-3 + rng.random((K, K)) * (rng.random((K, K)) < 0.2) * T
         vt[np.arange(K), np.arange(K)] += T
         pb["ltran"] = digamma(vt + 1e-9) - digamma(vt.sum(1)[:, None] + 1e-9)
@@ -74,7 +78,7 @@ def check_stats(got, ref, K, D, sc, xs, rtol, atol_scale, what):
 
 
 def run_case(e, L, ref_c, case, seed):
-    K, D, Lm, B, sep, miss, sparse = case
+    K, D, Lm, B, sep, miss, sparse, rare = case
     pb, starts, T = problem(case, seed)
     obs, mask = pb["obs"], pb["mask"]
     par = (pb["mod_init"], pb["ltran"], pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
@@ -111,6 +115,7 @@ def run_case(e, L, ref_c, case, seed):
     e.set_precision("f32")
     st = e.estep(starts, Lm, flags=L.TRANS_WRAP)
     e.set_precision("f64")
+    assert np.all(np.isfinite(st.buf)), "f32: non-finite statistics"
     g = unpack(st.buf, K, D)
     r = unpack(f64[L.TRANS_WRAP], K, D)
     np.testing.assert_allclose(g[0], r[0], rtol=2e-3, atol=2e-4 * sc, err_msg="f32 A_raw")

@@ -113,3 +113,118 @@ def test_f32_mode_rare_initial_state():
     sc = B * Lm
     np.testing.assert_allclose(res["f32"].A_raw, res["f64"].A_raw, rtol=2e-3, atol=2e-4 * sc)
     np.testing.assert_allclose(res["f32"].neff, res["f64"].neff, rtol=2e-3, atol=2e-4 * sc)
+
+
+def _sparse_ltran(K, T, seed):
+    """E[log A] of a sticky model with tiny Dirichlet pseudo-counts: psi(1e-3) = -1000."""
+    rng = np.random.default_rng(seed)
+    vt = 1e-3 + rng.random((K, K)) * (rng.random((K, K)) < 0.2) * T
+    vt[np.arange(K), np.arange(K)] += T
+    return digamma(vt + 1e-9) - digamma(vt.sum(1)[:, None] + 1e-9)
+
+
+@pytest.mark.parametrize("K,D,Lm,B,sep", [(3, 3, 2, 15, 60.0), (16, 15, 17, 31, 20.0), (48, 32, 33, 257, 20.0),
+                                          (127, 8, 65, 40, 60.0), (8, 8, 257, 3, 0.0), (31, 1, 64, 191, 60.0),
+                                          (65, 32, 9, 2, 20.0), (200, 4, 9, 200, 3.0)])
+def test_transition_expectations_below_exp_range(K, D, Lm, B, sep):
+    """Shapes the randomised campaign failed on before the log-domain route existed (NaN
+    statistics, finite-but-wrong statistics, -inf in lalpha / lbeta)."""
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    from oracle import ref_c
+    T = max(4 * Lm, 400)
+    pb = make_problem(K, D, T, seed=3000 + K + B, miss=0.1, sep=sep)
+    pb["ltran"] = _sparse_ltran(K, T, seed=K + B)
+    assert pb["ltran"].min() < L.LTRAN_LINEAR_MIN
+    starts = np.random.default_rng(B).integers(0, T - Lm + 1, size=B)
+    e = HipEngine(0)
+    try:
+        _check(e, L, ref_c, pb, starts, Lm)
+        for b in np.unique(np.linspace(0, B - 1, 3).astype(int)):
+            fb = e.forward_backward(starts[b:b + 1], Lm, flags=L.MASK_AS_NAN)
+            x = pb["obs"][starts[b]:starts[b] + Lm].copy()
+            x[pb["mask"][starts[b]:starts[b] + Lm]] = np.nan
+            ll = ref_c.lliks_niw(x, pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+            np.testing.assert_allclose(fb["lalpha"][0], ref_c.forward(ll, pb["mod_init"], pb["ltran"]), rtol=1e-9, atol=1e-7)
+            np.testing.assert_allclose(fb["lbeta"][0], ref_c.backward(ll, pb["ltran"]), rtol=1e-9, atol=1e-7)
+        # fp32 mode: outside a float's range the engine computes in fp64
+        ref64 = e.estep(starts, Lm, flags=L.TRANS_WRAP).buf.copy()
+        e.set_precision("f32")
+        got = e.estep(starts, Lm, flags=L.TRANS_WRAP).buf
+        np.testing.assert_allclose(got, ref64, rtol=1e-12, atol=0)
+    finally:
+        e.close()
+
+
+def test_chain_with_sparse_transitions():
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    from oracle import ref_c
+    K, D, T = 8, 4, 2500
+    pb = make_problem(K, D, T, seed=31, miss=0.05, sep=20.0)
+    pb["ltran"] = _sparse_ltran(K, T, seed=5)
+    e = HipEngine(0)
+    try:
+        _check(e, L, ref_c, pb, np.zeros(1, dtype=np.int64), T)
+    finally:
+        e.close()
+
+
+def test_f32_mode_moderately_sparse_transitions():
+    """Pseudo-counts of 0.01 (psi = -100): inside a double's range (fast path), outside a float's
+    -- the fp32 mode must not flush the messages."""
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    K, D, Lm, B, T = 16, 8, 33, 400, 4000
+    pb = make_problem(K, D, T, seed=41, sep=3.0)
+    rng = np.random.default_rng(3)
+    vt = 1e-2 + rng.random((K, K)) * (rng.random((K, K)) < 0.3) * T
+    vt[np.arange(K), np.arange(K)] += T
+    pb["ltran"] = digamma(vt + 1e-9) - digamma(vt.sum(1)[:, None] + 1e-9)
+    assert L.LTRAN_LINEAR_MIN < pb["ltran"].min() < L.LTRAN_F32_MIN
+    starts = rng.integers(0, T - Lm + 1, size=B)
+    res = {}
+    for dt in ("f64", "f32"):
+        e = HipEngine(0, dtype=dt)
+        e.set_obs(pb["obs"], pb["mask"])
+        e.set_globals(pb["mod_init"], pb["ltran"])
+        e.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+        res[dt] = e.estep(starts, Lm, flags=L.TRANS_WRAP).buf.copy()
+        e.close()
+    np.testing.assert_allclose(res["f32"], res["f64"], rtol=1e-12, atol=0)
+
+
+def test_svi_loop_with_tiny_dirichlet_prior():
+    """prior_tran = 1e-3: the device-resident loop refuses (svihmm_svi_begin), the class takes the
+    host loop by itself, and the run equals the oracle engine's."""
+    from pysvihmm_amd import hmmsgd_metaobs
+    from pysvihmm_amd.distributions import Gaussian
+    from pysvihmm_amd.engine import HipEngine
+    from oracle.engine import OracleEngine
+    K, D, T = 6, 3, 3000
+    pb = make_problem(K, D, T, seed=12, sep=20.0)
+    obs = pb["obs"]
+
+    def model(engine):
+        np.random.seed(4)
+        prior = np.array([Gaussian(mu_0=obs.mean(0), sigma_0=0.75 * np.cov(obs.T), kappa_0=0.01, nu_0=D + 2)
+                          for _ in range(K)])
+        return hmmsgd_metaobs.VBHMM(obs, np.ones(K), 1e-3 * np.ones((K, K)), prior, tau=1.0, kappa=0.7,
+                                    metaobs_half=8, mb_sz=6, maxit=6, seed=11, engine=engine)
+    e = HipEngine(0)
+    a = model(e)
+    assert not a._svi_device_ok()
+    a.infer()
+    b = model(OracleEngine())
+    b.infer()
+    assert np.all(np.isfinite(a.var_tran)) and np.all(np.isfinite(a.elbo_vec))
+    np.testing.assert_allclose(a.var_tran, b.var_tran, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(a.elbo_vec, b.elbo_vec, rtol=1e-8)
+    for k in range(K):
+        np.testing.assert_allclose(a.var_emit[k].mu_mf, b.var_emit[k].mu_mf, rtol=1e-6, atol=1e-8)
+    # the C ABI itself refuses the resident loop for such a model
+    prior = a._prior_arrays()
+    from pysvihmm_amd.distributions import niw_prior_logpart
+    with pytest.raises(RuntimeError, match="PSEUDOCOUNT"):
+        e.svi_begin(a.prior_tran, a.var_tran, prior, a._emission_arrays(), niw_prior_logpart(prior[1], prior[3]), 3)
+    e.close()
