@@ -163,11 +163,124 @@ def run_chain(e, L, ref_c, seed):
     return (K, D, T)
 
 
+def run_api_case(e, L, seed):
+    """The callers around the E-step, HipEngine vs OracleEngine on one random problem: FFBS
+    (lalpha + exact draws), held-out predictive log-probability, state decoding + count matrix,
+    host-supplied lliks, Categorical emissions, three iterations of the device-resident SVI loop."""
+    from oracle.engine import OracleEngine
+    from pysvihmm_amd.distributions import niw_prior_logpart
+    from tests.helpers import ffbs_draws_exact
+    from scipy.special import digamma
+    rng = np.random.default_rng(seed)
+    K = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 33, 64, 65, 100]))
+    D = int(rng.choice([1, 2, 3, 8, 9, 16]))
+    T = int(rng.choice([300, 1000, 2500, 5000]))
+    sep = float(rng.choice([0.5, 3.0, 20.0]))
+    pb = make_problem(K, D, T, seed=seed, miss=float(rng.choice([0.0, 0.1, 0.3])), sep=sep)
+    if rng.random() < 0.3:
+        vi = np.where(rng.random(K) < 0.5, 10.0 ** -rng.uniform(3, 6, K), 0.3) * (0.5 + rng.random(K))
+        pb["mod_init"] = digamma(vi + 1e-9) - digamma(vi.sum() + 1e-9)
+    what = "K=%d D=%d T=%d sep=%g" % (K, D, T, sep)
+    o = OracleEngine()
+    e.set_precision("f64")
+    for eng in (e, o):
+        eng.set_obs(pb["obs"], pb["mask"])
+        eng.set_globals(pb["mod_init"], pb["ltran"])
+        eng.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    # --- FFBS (the reference passes log(var_tran + eps) as transition weights, hmm_fast.pyx:91-93)
+    DE = np.finfo(np.float64).eps
+    vt = pb["var_tran"] / pb["var_tran"].sum(1)[:, None]
+    logA = np.log(vt + DE)
+    for eng in (e, o):
+        eng.set_globals(pb["mod_init"], logA)
+    u = rng.random(T)
+    z, la = e.ffbs(logA, u)
+    zo, lao = o.ffbs(logA, u)
+    np.testing.assert_allclose(la, lao, rtol=1e-9, atol=1e-7, err_msg=what + " ffbs lalpha")
+    bad, risky = ffbs_draws_exact(z, la, logA, u)
+    assert bad == 0, (what, "ffbs draws", bad, risky)
+    for eng in (e, o):
+        eng.set_globals(pb["mod_init"], pb["ltran"])
+    # --- windows
+    Lm = int(rng.choice([1, 3, 17, 65, 257]))
+    Lm = min(Lm, T // 2)
+    B = int(rng.choice([1, 4, 40, 260]))
+    while B * Lm * K * K > 3e7 and B > 1:
+        B //= 2
+    starts = rng.integers(0, T - Lm + 1, size=B)
+    # --- predictive log-probability of the held-out rows
+    v, n = e.pred_logprob(starts, Lm)
+    vo, no = o.pred_logprob(starts, Lm)
+    assert n == no, (what, "pred_logprob count", n, no)
+    if n:
+        np.testing.assert_allclose(v, vo, rtol=1e-8, err_msg=what + " pred_logprob")
+    # --- decoding + count matrix
+    true = rng.integers(-1, K + 1, size=B * Lm)
+    ro = o.forward_backward(starts, Lm, want=("var_x",))
+    e.forward_backward(starts, Lm, want=())
+    zz, dm = e.state_argmax(true)
+    q = ro["var_x"].reshape(-1, K)
+    top2 = np.sort(np.concatenate([q, np.full((len(q), 1), -1.0)], axis=1), axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 1e-9
+    assert np.array_equal(zz[clear], np.argmax(q, axis=1)[clear]), what + " argmax"
+    ok = (true >= 0) & (true < K)
+    ref = np.zeros((K, K), dtype=np.int64)
+    np.add.at(ref, (zz[ok], true[ok]), 1)
+    assert np.array_equal(dm, ref), what + " count matrix"
+    # --- host-supplied lliks == the NIW kernel's own
+    st1 = e.estep(starts, Lm, flags=L.TRANS_WRAP | L.MASK_AS_NAN)
+    ll = o.loglik(starts, Lm, flags=L.MASK_AS_NAN)
+    e.set_lliks(ll)
+    st2 = e.estep(starts, Lm, flags=L.TRANS_WRAP | L.MASK_AS_NAN | L.USE_HOST_LLIKS)
+    sc = B * Lm
+    xs = max(1.0, float(np.nanmax(np.abs(pb["obs"]))))
+    check_stats(st2.buf, st1.buf, K, D, sc, xs, 1e-6, 1e-9, what + " host lliks")
+    # --- device-resident SVI loop, three iterations
+    prior_tran = 0.5 + rng.random((K, K)) if rng.random() < 0.5 else np.ones((K, K))
+    var_tran0 = np.maximum(pb["var_tran"], 1.0)
+    mu0 = np.tile(pb["obs"].mean(0), (K, 1))
+    sg0 = np.tile(0.75 * np.atleast_2d(np.cov(pb["obs"].T)).reshape(D, D), (K, 1, 1))
+    ka0, nu0 = np.full(K, 0.01), np.full(K, D + 2.0)
+    prior = (mu0, sg0, ka0, nu0)
+    factors = (pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    Lh = max(Lm // 2, 1)
+    bA, bE = (T - 2 * Lh - 1) / (2. * Lh * B), (T - 2 * Lh - 1) / ((2. * Lh + 1) * B)
+    res = []
+    for eng in (e, o):
+        eng.svi_begin(prior_tran, var_tran0, prior, factors, niw_prior_logpart(sg0, nu0), 3, 1.0)
+        r2 = np.random.default_rng(seed + 1)
+        for it in range(3):
+            st = r2.integers(0, T - Lm + 1, size=B)
+            eng.svi_iteration(it, st, B, Lm, L.TRANS_WRAP, (it + 1.0) ** -0.7, bA, bE)
+        res.append((eng.svi_read_state(), eng.svi_read_elbo(3)[0]))
+    (sa, ea), (sb, eb) = res
+    for nme, a, b in zip(("var_tran", "var_init", "mu", "sigma", "kappa", "nu"), sa, sb):
+        np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-8, err_msg=what + " svi " + nme)
+    np.testing.assert_allclose(ea, eb, rtol=1e-8, err_msg=what + " svi elbo")
+    # --- Categorical emissions on the same state path
+    V = int(rng.choice([2, 5, 9, 30]))
+    theta = rng.dirichlet(np.ones(V) * 0.3, size=K)
+    cobs = np.array([rng.choice(V, p=theta[s_]) for s_ in pb["sts"][:T]], dtype=float)
+    alpha = rng.random((K, V)) * 5 + 0.2
+    table = digamma(alpha) - digamma(alpha.sum(1))[:, None]
+    for eng in (e, o):
+        eng.set_obs(cobs, pb["mask"])
+        eng.set_globals(pb["mod_init"], pb["ltran"])
+        eng.set_emission_cat(table)
+    for flags in (L.TRANS_WRAP, L.TRANS_WRAP | L.MASK_AS_NAN):
+        a, b = e.estep(starts, Lm, flags=flags), o.estep(starts, Lm, flags=flags)
+        np.testing.assert_allclose(a.A_raw, b.A_raw, rtol=1e-6, atol=1e-9 * sc, err_msg=what + " cat A_raw")
+        np.testing.assert_allclose(a.counts, b.counts, rtol=1e-6, atol=1e-9 * sc, err_msg=what + " cat counts")
+        np.testing.assert_allclose(a.lb[0], b.lb[0], rtol=1e-9, atol=1e-6, err_msg=what + " cat lb")
+    return what
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--chains", type=int, default=10)
+    ap.add_argument("--api", type=int, default=0, help="cases of the API-level campaign (callers around the E-step)")
     ap.add_argument("--seconds", type=float, default=1e9, help="stop drawing new cases after this long")
     args = ap.parse_args()
     from pysvihmm_amd.engine import HipEngine
@@ -211,6 +324,24 @@ def main():
                 e.close()
                 e = HipEngine(0)
         ndone += 1
+    for i in range(args.api):
+        if time.time() - t0 > args.seconds:
+            break
+        seed = args.seed * 100000 + 70000 + i
+        try:
+            run_api_case(e, L, seed)
+        except Exception as ex:
+            nfail += 1
+            msg = str(ex).strip().splitlines()
+            print("FAIL api seed=%d: %s | %s" % (seed, type(ex).__name__, " / ".join(msg[:6])[:600]))
+            if not isinstance(ex, AssertionError):
+                traceback.print_exc()
+            e.close()
+            e = HipEngine(0)
+        ndone += 1
+        if (i + 1) % 10 == 0:
+            print("... api %d, %d failures, %.0f s" % (i + 1, nfail, time.time() - t0))
+            sys.stdout.flush()
     print("fuzz: %d cases, %d failures, %.0f s (seed %d)" % (ndone, nfail, time.time() - t0, args.seed))
     e.close()
     return 1 if nfail else 0
