@@ -236,7 +236,9 @@ def run_api_case(e, L, seed):
     xs = max(1.0, float(np.nanmax(np.abs(pb["obs"]))))
     check_stats(st2.buf, st1.buf, K, D, sc, xs, 1e-6, 1e-9, what + " host lliks")
     # --- device-resident SVI loop, three iterations
-    prior_tran = 0.5 + rng.random((K, K)) if rng.random() < 0.5 else np.ones((K, K))
+    # >= 1: quirk Q2 adds nwin * (prior_tran - 1); below 1 var_tran goes negative and both
+    # implementations turn chaotic (psi of negative arguments)
+    prior_tran = 1.0 + rng.random((K, K)) if rng.random() < 0.5 else np.ones((K, K))
     var_tran0 = np.maximum(pb["var_tran"], 1.0)
     mu0 = np.tile(pb["obs"].mean(0), (K, 1))
     sg0 = np.tile(0.75 * np.atleast_2d(np.cov(pb["obs"].T)).reshape(D, D), (K, 1, 1))
