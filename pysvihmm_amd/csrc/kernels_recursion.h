@@ -1167,12 +1167,25 @@ __global__ __launch_bounds__(64 * NW) void k_sweeps_lin2(
 // vmcnt instead of a full drain per step.  The exponent stream is written 64 steps at a time
 // (lane s & 63 keeps h_s; one coalesced store per 64 steps): 64 lanes storing one address
 // every step serialise in the memory pipeline.
+// Initial message of a window, lane = state (K <= 64): lalpha_0 = mod_init + ll_0 combined in the
+// log domain (see k_lin_init), scaled by its own binary exponent H; returns a0[j], sets
+// h0 = H - k0 (k0: the emission exponent of the window's first row).
+__device__ __forceinline__ double lin_init_lane(const double* __restrict__ mod_init,
+                                                const double* __restrict__ l0, int jc, bool valid,
+                                                double k0, double& h0) {
+  const double v = valid ? mod_init[jc] + l0[jc] : -INFINITY;
+  const double m = wave_max(v);
+  const double H = (m > -1e300 && m < 1e300) ? ceil(m * LOG2E_D) : 0.0;
+  h0 = H - k0;
+  return valid ? exp(fma(-H, LN2_LO_D, fma(-H, LN2_HI_D, v))) : 0.0;
+}
+
 template <int KMAX, bool FULLK, typename ST = double>
 __global__ __launch_bounds__(64) void k_wave_lin(
     const ST* __restrict__ Eh, const double* __restrict__ kexp,
     const double* __restrict__ Aexp, const double* __restrict__ AexpT,
-    const double* __restrict__ a0v, const double* __restrict__ a0e, int Lm, int K,
-    ST* __restrict__ ah,
+    const double* __restrict__ mod_init, const double* __restrict__ ll0, size_t l0stride, int Lm,
+    int K, ST* __restrict__ ah,
     ST* __restrict__ bh, double* __restrict__ hx, double* __restrict__ gx,
     double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac) {
   __shared__ double p_s[2][64];
@@ -1198,9 +1211,8 @@ __global__ __launch_bounds__(64) void k_wave_lin(
     const int t = rowof(0);
     const double e0 = Eb[(size_t)t * K];
     double o;
-    if (fwd) {      // the initial message of k_lin_init: mod_init + ll_0 combined in the log domain
-      h = a0e[b];
-      o = valid ? a0v[(size_t)b * K + jc] : 0.0;
+    if (fwd) {      // mod_init + ll_0 combined in the log domain (every wave of the window alike)
+      o = lin_init_lane(mod_init, ll0 + (size_t)b * l0stride, jc, valid, kexp[wrow], h);
       pcur = o;
     } else {
       o = valid ? 1.0 : 0.0;
@@ -1302,8 +1314,8 @@ template <int KMAX, typename ST = double>
 __global__ __launch_bounds__(256) void k_wave_lin4(
     const ST* __restrict__ Eh, const double* __restrict__ kexp,
     const double* __restrict__ Aexp, const double* __restrict__ AexpT,
-    const double* __restrict__ a0v, const double* __restrict__ a0e, int Lm, int K,
-    ST* __restrict__ ah,
+    const double* __restrict__ mod_init, const double* __restrict__ ll0, size_t l0stride, int Lm,
+    int K, ST* __restrict__ ah,
     ST* __restrict__ bh, double* __restrict__ hx, double* __restrict__ gx,
     double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac) {
   constexpr int NI = KMAX / 4;                  // source states per wave
@@ -1332,9 +1344,8 @@ __global__ __launch_bounds__(256) void k_wave_lin4(
     const int t = rowof(0);
     const double e0 = Eb[(size_t)t * K];
     double o;
-    if (fwd) {      // the initial message of k_lin_init: mod_init + ll_0 combined in the log domain
-      h = a0e[b];
-      o = valid ? a0v[(size_t)b * K + jc] : 0.0;
+    if (fwd) {      // mod_init + ll_0 combined in the log domain (every wave of the window alike)
+      o = lin_init_lane(mod_init, ll0 + (size_t)b * l0stride, jc, valid, kexp[wrow], h);
       pcur = o;
     } else {
       o = valid ? 1.0 : 0.0;

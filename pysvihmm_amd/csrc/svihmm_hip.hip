@@ -1012,8 +1012,12 @@ static int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_
   double* lz = (double*)h->logz.p + b0;
   const double* a0v = (const double*)h->a0v.p + (size_t)b0 * K;
   const double* a0e = (const double*)h->a0e.p + b0;
+  // first-row log-likelihoods of the windows (see launch_lin_init): the wave-per-window kernels
+  // form the initial message themselves, the tile kernels take it from k_lin_init
+  const double* mi = (const double*)h->mod_init.p;
+  const double* l0 = h->eh_in_llE ? (const double*)h->ll.p + ro * K : (const double*)h->ll0.p + (size_t)b0 * K;
+  const size_t l0s = h->eh_in_llE ? (size_t)Lm * K : (size_t)K;
   ProfScope ps(h, KS_FB, stream);
-  CK(launch_lin_init(h, b0, nb, Lm, stream));
   if (h->cur_f32) {
     // fp32 mode (K <= 64, b0 == 0): the same kernels instantiated for float storage
     const float* Ef = (const float*)h->ll.p;
@@ -1022,10 +1026,10 @@ static int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_
     if (nb < LIN_WAVE_MAX && h->variant[7] != 2) {
       dim3 gw((unsigned)nb, 2);
 #define WLF(KM, FK) hipLaunchKernelGGL((k_wave_lin<KM, FK, float>), gw, dim3(64), 0, stream, Ef, kx, (const double*)h->Aexp.p, \
-                                       (const double*)h->AexpT.p, a0v, a0e, Lm, K, af, bf, hx,   \
+                                       (const double*)h->AexpT.p, mi, l0, l0s, Lm, K, af, bf, hx,   \
                                        gx, llb, lz, zf)
 #define WL4F(KM) hipLaunchKernelGGL((k_wave_lin4<KM, float>), gw, dim3(256), 0, stream, Ef, kx, (const double*)h->Aexp.p, \
-                                    (const double*)h->AexpT.p, a0v, a0e, Lm, K, af, bf, hx, gx, \
+                                    (const double*)h->AexpT.p, mi, l0, l0s, Lm, K, af, bf, hx, gx, \
                                     llb, lz, zf)
       if (K > 16 && nb <= LIN_WAVE4_MAX && h->variant[7] != 3) { if (K <= 32) WL4F(32); else WL4F(64); }
       else if (K <= 16) WLF(16, false); else if (K <= 32) WLF(32, false);
@@ -1033,6 +1037,7 @@ static int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_
 #undef WLF
 #undef WL4F
     } else {
+      CK(launch_lin_init(h, b0, nb, Lm, stream));
       const LinChain none = {};
 #define SWF(NWV, F) hipLaunchKernelGGL((k_sweeps_lin<NWV, F, 0, false, float>), grid, dim3(64 * NWV),              \
                                        sizeof(LinShared<NWV>), stream, Ef, kx, (const double*)h->Aexp.p,         \
@@ -1051,13 +1056,13 @@ static int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_
     // small batches: one wavefront per (window, direction)
     dim3 gw((unsigned)nb, 2);
 #define WL(KM, FK) hipLaunchKernelGGL((k_wave_lin<KM, FK>), gw, dim3(64), 0, stream, Eh, kx, (const double*)h->Aexp.p, \
-                                      (const double*)h->AexpT.p, a0v, a0e, Lm, K, ah, bh, hx,  \
+                                      (const double*)h->AexpT.p, mi, l0, l0s, Lm, K, ah, bh, hx,  \
                                       gx, llb, lz, zf)
     // up to a few hundred windows the chip is far from full with one wave per (window,
     // direction): split each window's source states over four waves (variant[7] = 3: off)
     if (K > 16 && nb <= LIN_WAVE4_MAX && h->variant[7] != 3) {
 #define WL4(KM) hipLaunchKernelGGL((k_wave_lin4<KM>), gw, dim3(256), 0, stream, Eh, kx, (const double*)h->Aexp.p, \
-                                   (const double*)h->AexpT.p, a0v, a0e, Lm, K, ah, bh, hx,  \
+                                   (const double*)h->AexpT.p, mi, l0, l0s, Lm, K, ah, bh, hx,  \
                                    gx, llb, lz, zf)
       if (K <= 32) WL4(32); else WL4(64);
 #undef WL4
@@ -1068,6 +1073,7 @@ static int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_
     HIPCK(hipGetLastError());
     return 0;
   }
+  CK(launch_lin_init(h, b0, nb, Lm, stream));
   const LinChain none = {};
 #define SWPX(NWV, F, BSV)                                                                                  \
   do {                                                                                                     \

@@ -415,6 +415,7 @@ class VBHMM(VariationalHMMBase):
         bA = (T - 2 * self.metaobs_half - 1) / (2. * self.metaobs_half * self.mb_sz)
         bE = (T - 2 * self.metaobs_half - 1) / ((2. * self.metaobs_half + 1.) * self.mb_sz)
         last = None
+        own_unif = getattr(self.metaobs_fun, "__func__", None) is VBHMM.metaobs_unif
         for it in range(maxit):
             self.lrate = (it + self.tau) ** (-self.kappa)
             resize = (L_ is None or (adaptive and it % perIter == 0)) or (growBuffer and it % perIter == 0)
@@ -433,17 +434,28 @@ class VBHMM(VariationalHMMBase):
                 miniL = bufferL
                 if bufferBudget:
                     mb_sz = self.buffer_budget(bufferL)
-            minibatch = self.metaobs_fun(T, miniL, mb_sz)
-            mine = minibatch if comm is None else minibatch[comm.rank::comm.size]
-            starts = np.array([mo.i1 for mo in mine], dtype=np.int64)
+            if own_unif:
+                # metaobs_unif (:210-227) without the list of MetaObs objects: the same single
+                # randint draw, window starts as an array (64 objects per iteration were most of
+                # the loop's host time)
+                c_vec = npr.randint(miniL, T - 1 - miniL + 1, mb_sz)
+                all_starts = np.asarray(c_vec, dtype=np.int64) - miniL
+                nwin = len(all_starts)
+                last_mo = MetaObs(c_vec[-1] - miniL, c_vec[-1] + miniL) if nwin else None
+            else:
+                minibatch = self.metaobs_fun(T, miniL, mb_sz)
+                all_starts = np.array([mo.i1 for mo in minibatch], dtype=np.int64)
+                nwin = len(minibatch)
+                last_mo = minibatch[-1] if nwin else None
+            starts = all_starts if comm is None else all_starts[comm.rank::comm.size]
             Lm = 2 * miniL + 1
             flags = L.TRANS_WRAP | L.KEEP_LBETA
             if it == maxit - 1:
                 flags |= L.SVI_KEEP_WINDOW
             inner = (bufferL - L_, 2 * L_ + 1) if growBuffer else None
-            eng.svi_iteration(it, starts, len(minibatch), Lm, flags, self.lrate, bA, bE, inner=inner)
+            eng.svi_iteration(it, starts, nwin, Lm, flags, self.lrate, bA, bE, inner=inner)
             host_fresh = False
-            self.cur_mo = minibatch[-1]
+            self.cur_mo = last_mo
             last = (len(starts), Lm)
             if self.verbose:
                 e, _ = eng.svi_read_elbo(it + 1)

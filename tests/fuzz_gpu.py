@@ -277,11 +277,66 @@ def run_api_case(e, L, seed):
     return what
 
 
+def run_class_case(e, seed):
+    """The reference's three classes end to end (small problems, a few iterations), HIP engine vs
+    oracle engine: hmmsgd_metaobs with random options (mask, full_predprob, growBuffer,
+    adaptive, noverlap sampler, host / device loop), hmmbatchcd, hmmbatchsgd."""
+    from oracle.engine import OracleEngine
+    from pysvihmm_amd import hmmsgd_metaobs, hmmbatchcd, hmmbatchsgd
+    from pysvihmm_amd.distributions import Gaussian
+    rng = np.random.default_rng(seed)
+    K = int(rng.choice([2, 3, 5, 8, 17]))
+    D = int(rng.choice([1, 2, 3, 8]))
+    T = int(rng.choice([300, 700, 1500]))
+    pb = make_problem(K, D, T, seed=seed, miss=0.0, sep=float(rng.choice([1.0, 3.0, 20.0])))
+    obs = pb["obs"]
+    mask = (rng.random(T) < 0.1) if rng.random() < 0.5 else None
+    kind = str(rng.choice(["metaobs", "metaobs", "metaobs", "batchcd", "batchsgd"]))
+    half = int(rng.choice([1, 3, 8, 20]))
+    opts = dict(metaobs_half=half, mb_sz=int(rng.choice([1, 2, 7, 20])), maxit=int(rng.choice([2, 5])),
+                metaobs_fun=str(rng.choice(["unif", "noverlap"])), full_predprob=bool(rng.random() < 0.3) and mask is not None,
+                growBuffer=bool(rng.random() < 0.25))
+    infer_kw = {}
+    if kind == "metaobs" and not opts["growBuffer"] and rng.random() < 0.25:
+        infer_kw = dict(adaptive=True, perIter=2, epsilon=1e-2, minHalfL=1, Lincrement=2, Lcutoff=10)
+    if kind == "metaobs" and rng.random() < 0.3:
+        infer_kw["device_loop"] = False
+    what = "%s K=%d D=%d T=%d %r %r" % (kind, K, D, T, opts if kind == "metaobs" else "", infer_kw)
+
+    def model(engine):
+        np.random.seed(seed % 100000)
+        sg0 = 0.75 * np.atleast_2d(np.cov(obs.T)).reshape(D, D)
+        prior = np.array([Gaussian(mu_0=obs.mean(0), sigma_0=sg0, kappa_0=0.01, nu_0=D + 2) for _ in range(K)])
+        m = None if mask is None else mask.copy()
+        if kind == "metaobs":
+            return hmmsgd_metaobs.VBHMM(obs.copy(), np.ones(K), np.ones((K, K)), prior, tau=1.0, kappa=0.7, mask=m,
+                                        seed=seed % 1000, engine=engine, **opts)
+        if kind == "batchcd":
+            return hmmbatchcd.VBHMM(obs.copy(), np.ones(K), np.ones((K, K)), prior, mask=m, maxit=3, engine=engine)
+        return hmmbatchsgd.VBHMM(obs.copy(), np.ones(K), np.ones((K, K)), prior, tau=1.0, kappa=0.7, mask=m, maxit=3,
+                                 engine=engine)
+    a, b = model(e), model(OracleEngine())
+    a.infer(**infer_kw)
+    b.infer(**infer_kw)
+    np.testing.assert_allclose(a.var_tran, b.var_tran, rtol=1e-6, atol=1e-9, err_msg=what + " var_tran")
+    np.testing.assert_allclose(a.var_init, b.var_init, rtol=1e-6, atol=1e-9, err_msg=what + " var_init")
+    for k in range(K):
+        np.testing.assert_allclose(a.var_emit[k].mu_mf, b.var_emit[k].mu_mf, rtol=1e-6, atol=1e-8, err_msg=what + " mu")
+        np.testing.assert_allclose(a.var_emit[k].sigma_mf, b.var_emit[k].sigma_mf, rtol=1e-6, atol=1e-7, err_msg=what + " sigma")
+    np.testing.assert_allclose(a.elbo_vec, b.elbo_vec, rtol=1e-8, err_msg=what + " elbo")
+    np.testing.assert_allclose(a.var_x, b.var_x, rtol=1e-6, atol=1e-11, err_msg=what + " var_x")
+    np.testing.assert_allclose(a.lalpha, b.lalpha, rtol=1e-9, atol=1e-7, err_msg=what + " lalpha")
+    if kind == "metaobs" and opts["full_predprob"]:
+        np.testing.assert_allclose(a.pred_logprob_full_mean, b.pred_logprob_full_mean, rtol=1e-8, err_msg=what + " predprob")
+    return what
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--chains", type=int, default=10)
+    ap.add_argument("--classes", type=int, default=0, help="cases of the class-level campaign")
     ap.add_argument("--api", type=int, default=0, help="cases of the API-level campaign (callers around the E-step)")
     ap.add_argument("--seconds", type=float, default=1e9, help="stop drawing new cases after this long")
     args = ap.parse_args()
@@ -343,6 +398,24 @@ def main():
         ndone += 1
         if (i + 1) % 10 == 0:
             print("... api %d, %d failures, %.0f s" % (i + 1, nfail, time.time() - t0))
+            sys.stdout.flush()
+    for i in range(args.classes):
+        if time.time() - t0 > args.seconds:
+            break
+        seed = args.seed * 100000 + 90000 + i
+        try:
+            run_class_case(e, seed)
+        except Exception as ex:
+            nfail += 1
+            msg = str(ex).strip().splitlines()
+            print("FAIL class seed=%d: %s | %s" % (seed, type(ex).__name__, " / ".join(msg[:6])[:600]))
+            if not isinstance(ex, AssertionError):
+                traceback.print_exc()
+            e.close()
+            e = HipEngine(0)
+        ndone += 1
+        if (i + 1) % 10 == 0:
+            print("... classes %d, %d failures, %.0f s" % (i + 1, nfail, time.time() - t0))
             sys.stdout.flush()
     print("fuzz: %d cases, %d failures, %.0f s (seed %d)" % (ndone, nfail, time.time() - t0, args.seed))
     e.close()
