@@ -21,6 +21,7 @@ run() {  # name, rocprof args...
   python $ROOT/tools/rocpd_summary.py $db
 }
 run kt --kernel-trace --stats > $OUT/${TAG}_kernel_stats.txt
+python $ROOT/tools/svi_trace.py $(find /tmp/prof_kt -name "*.db" | head -1) > $OUT/${TAG}_svi_iteration_trace.txt
 # HBM counters on the headline workload alone (no side figures), fp64 and fp32 mode separately
 BENCH_ALL=$BENCH
 BENCH="python $ROOT/bench.py --steps 5 --warmup 2 --reps 2 --no-cpu-baseline --no-side"
