@@ -331,11 +331,202 @@ def run_class_case(e, seed):
     return what
 
 
+def run_sequence(e, L, seed, nops=30):
+    """One random sequence of API calls on ONE handle (and the same sequence on an OracleEngine):
+    parameter / data uploads, precision switches, E-steps of changing shapes, message reads of the
+    lazily rebuilt intermediates, the callers around the E-step, short device-resident SVI runs --
+    what is compared after every call is that call's own result.  Aims at the state the handle
+    carries between calls (cached shapes, lazily materialised logs, side streams, pending sums)."""
+    from oracle.engine import OracleEngine
+    from pysvihmm_amd.distributions import niw_prior_logpart
+    from scipy.special import digamma
+    rng = np.random.default_rng(seed)
+    K = int(rng.choice([2, 3, 7, 16, 33, 64, 70]))
+    D = int(rng.choice([1, 3, 8, 16]))
+    T = int(rng.choice([400, 1200, 3000]))
+    o = OracleEngine()
+    hist = []
+    state = {"prec": "f64", "fresh": None, "pb": None}
+
+    def new_problem(keep_obs=False):
+        pb = make_problem(K, D, T, seed=int(rng.integers(1 << 30)), miss=float(rng.choice([0.0, 0.1])),
+                          sep=float(rng.choice([0.5, 3.0, 20.0])))
+        if rng.random() < 0.3:
+            vi = np.where(rng.random(K) < 0.5, 10.0 ** -rng.uniform(3, 6, K), 0.3) * (0.5 + rng.random(K))
+            pb["mod_init"] = digamma(vi + 1e-9) - digamma(vi.sum() + 1e-9)
+        if keep_obs and state["pb"] is not None:
+            for k in ("obs", "mask", "sts"):
+                pb[k] = state["pb"][k]
+        state["pb"] = pb
+        return pb
+
+    def upload(what):
+        pb = state["pb"]
+        for eng in (e, o):
+            if what in ("all", "obs"):
+                eng.set_obs(pb["obs"], pb["mask"] if pb["mask"].any() else None)
+            if what in ("all", "params"):
+                eng.set_globals(pb["mod_init"], pb["ltran"])
+                eng.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+        state["fresh"] = None
+
+    def windows():
+        Lm = int(rng.choice([1, 2, 9, 33, 65, 257]))
+        Lm = min(Lm, T // 2)
+        B = int(rng.choice([1, 3, 20, 64, 200, 300]))
+        while B * Lm * K * (K + 3 * D * D) > 4e8 and B > 1:
+            B //= 2
+        return rng.integers(0, T - Lm + 1, size=B), Lm
+
+    new_problem()
+    e.set_precision("f64")
+    upload("all")
+    for step in range(nops):
+        pb = state["pb"]
+        f32 = state["prec"] == "f32"
+        op = str(rng.choice(["estep", "estep", "fb", "read", "read", "params", "obs", "prec", "predlp", "argmax",
+                             "ffbs", "hostll", "svi", "loglik", "inner"]))
+        hist.append(op)
+        what = "seq seed=%d K=%d D=%d T=%d step %d %s (history %s)" % (seed, K, D, T, step, op, " ".join(hist[-8:]))
+        xs = max(1.0, float(np.nanmax(np.abs(pb["obs"]))))
+        if op == "params":
+            new_problem(keep_obs=True)
+            upload("params")
+        elif op == "obs":
+            keep = {k: state["pb"][k] for k in ("mod_init", "ltran", "mu", "sigma", "kappa", "nu")}
+            new_problem()
+            state["pb"].update(keep)
+            upload("obs")
+        elif op == "prec":
+            state["prec"] = "f32" if state["prec"] == "f64" else "f64"
+            e.set_precision(state["prec"])
+            state["fresh"] = None
+        elif op in ("estep", "inner"):
+            st, Lm = windows()
+            flags = int(rng.choice([L.TRANS_WRAP, L.MASK_AS_NAN, L.TRANS_WRAP | L.MASK_AS_NAN, 0]))
+            inner = None
+            if op == "inner" and Lm >= 3:
+                off = int(rng.integers(0, Lm // 2))
+                inner = (off, int(rng.integers(1, Lm - off + 1)))
+            a, b = e.estep(st, Lm, flags=flags, inner=inner), o.estep(st, Lm, flags=flags, inner=inner)
+            sc = len(st) * Lm
+            if f32:
+                assert np.all(np.isfinite(a.buf)), what
+                np.testing.assert_allclose(a.A_raw, b.A_raw, rtol=2e-3, atol=2e-4 * sc, err_msg=what)
+                np.testing.assert_allclose(a.neff, b.neff, rtol=2e-3, atol=2e-4 * sc, err_msg=what)
+            else:
+                check_stats(a.buf, b.buf, K, D, sc, xs, 1e-6, 1e-9, what)
+            state["fresh"] = (len(st), Lm)
+        elif op == "fb":
+            st, Lm = windows()
+            want = tuple(w for w in ("lalpha", "lbeta", "var_x", "local_lb") if rng.random() < 0.6)
+            flags = int(rng.choice([0, L.MASK_AS_NAN]))
+            a, b = e.forward_backward(st, Lm, flags=flags, want=want), o.forward_backward(st, Lm, flags=flags, want=want)
+            for w in want:
+                if f32 and w not in ("lalpha", "lbeta"):
+                    np.testing.assert_allclose(a[w], b[w], rtol=1e-3, atol=1e-4, err_msg=what + " " + w)
+                else:
+                    np.testing.assert_allclose(a[w], b[w], rtol=1e-6 if w == "var_x" else 1e-9,
+                                               atol=1e-11 if w == "var_x" else 1e-7, err_msg=what + " " + w)
+            state["fresh"] = (len(st), Lm)
+        elif op == "read":
+            if state["fresh"] is None:
+                continue
+            B, Lm = state["fresh"]
+            w = str(rng.choice(["lliks", "lalpha", "lbeta", "var_x"]))
+            r0 = int(rng.integers(0, B * Lm))
+            n = int(rng.integers(1, min(B * Lm - r0, 300) + 1))
+            a, b = e.read_rows(w, r0, n), o.read_rows(w, r0, n)
+            if f32 and w == "var_x":
+                np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-4, err_msg=what + " " + w)
+            else:
+                np.testing.assert_allclose(a, b, rtol=1e-6 if w == "var_x" else 1e-9,
+                                           atol=1e-11 if w == "var_x" else 1e-7, err_msg=what + " " + w)
+        elif op == "predlp":
+            st, Lm = windows()
+            a, b = e.pred_logprob(st, Lm), o.pred_logprob(st, Lm)
+            assert a[1] == b[1], what
+            if a[1]:
+                np.testing.assert_allclose(a[0], b[0], rtol=1e-3 if f32 else 1e-8, err_msg=what)
+            state["fresh"] = None
+        elif op == "argmax":
+            st, Lm = windows()
+            rb = o.forward_backward(st, Lm, want=("var_x",))
+            e.forward_backward(st, Lm, want=())
+            z, _ = e.state_argmax()
+            q = rb["var_x"].reshape(-1, K)
+            top2 = np.sort(np.concatenate([q, np.full((len(q), 1), -1.0)], axis=1), axis=1)[:, -2:]
+            clear = (top2[:, 1] - top2[:, 0]) > (1e-3 if f32 else 1e-9)
+            assert np.array_equal(z[clear], np.argmax(q, axis=1)[clear]), what
+            state["fresh"] = (len(st), Lm)
+        elif op == "ffbs":
+            if T > 1500:
+                continue
+            DE = np.finfo(np.float64).eps
+            vt = pb["var_tran"] / pb["var_tran"].sum(1)[:, None]
+            logA = np.log(vt + DE)
+            for eng in (e, o):
+                eng.set_globals(pb["mod_init"], logA)
+            u = rng.random(T)
+            (z, la), (zo, lao) = e.ffbs(logA, u), o.ffbs(logA, u)
+            np.testing.assert_allclose(la, lao, rtol=1e-9, atol=1e-7, err_msg=what)
+            from tests.helpers import ffbs_draws_exact
+            bad, risky = ffbs_draws_exact(z, la, logA, u)
+            assert bad == 0, (what, bad, risky)
+            for eng in (e, o):
+                eng.set_globals(pb["mod_init"], pb["ltran"])
+            state["fresh"] = None
+        elif op == "hostll":
+            st, Lm = windows()
+            ll = o.loglik(st, Lm, flags=L.MASK_AS_NAN)
+            for eng in (e, o):
+                eng.set_lliks(ll)
+            fl = L.TRANS_WRAP | L.MASK_AS_NAN | L.USE_HOST_LLIKS
+            a, b = e.estep(st, Lm, flags=fl), o.estep(st, Lm, flags=fl)
+            check_stats(a.buf, b.buf, K, D, len(st) * Lm, xs, 2e-3 if f32 else 1e-6, 2e-4 if f32 else 1e-9, what)
+            state["fresh"] = (len(st), Lm)
+        elif op == "loglik":
+            st, Lm = windows()
+            st = st[:5]
+            a, b = e.loglik(st, Lm, flags=L.MASK_AS_NAN), o.loglik(st, Lm, flags=L.MASK_AS_NAN)
+            np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-7, err_msg=what)
+            state["fresh"] = None
+        elif op == "svi":
+            st, Lm = windows()
+            B = len(st)
+            prior_tran = np.ones((K, K))
+            mu0 = np.tile(np.nanmean(pb["obs"], 0), (K, 1))
+            sg0 = np.tile(0.75 * np.atleast_2d(np.cov(pb["obs"][~np.isnan(pb["obs"]).any(1)].T)).reshape(D, D), (K, 1, 1))
+            prior = (mu0, sg0, np.full(K, 0.01), np.full(K, D + 2.0))
+            factors = (pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+            Lh = max(Lm // 2, 1)
+            bA, bE = (T - 2 * Lh - 1) / (2. * Lh * B), (T - 2 * Lh - 1) / ((2. * Lh + 1) * B)
+            res = []
+            sd = int(rng.integers(1 << 30))
+            for eng in (e, o):
+                eng.svi_begin(prior_tran, np.maximum(pb["var_tran"], 1.0), prior, factors,
+                              niw_prior_logpart(sg0, prior[3]), 2, 1.0)
+                r2 = np.random.default_rng(sd)
+                for it in range(2):
+                    eng.svi_iteration(it, r2.integers(0, T - Lm + 1, size=B), B, Lm, L.TRANS_WRAP, (it + 1.0) ** -0.7, bA, bE)
+                res.append((eng.svi_read_state(), eng.svi_read_elbo(2)[0]))
+            (sa, ea), (sb, eb) = res
+            tol = 5e-3 if f32 else 1e-6
+            for nme, a, b in zip(("var_tran", "var_init", "mu", "sigma", "kappa", "nu"), sa, sb):
+                np.testing.assert_allclose(a, b, rtol=tol, atol=tol * 1e-2 * (1 + np.abs(b).max()), err_msg=what + " " + nme)
+            np.testing.assert_allclose(ea, eb, rtol=1e-3 if f32 else 1e-8, err_msg=what + " elbo")
+            new_problem(keep_obs=True)      # both engines get fresh, identical parameters again
+            upload("params")
+    o.close()
+    return hist
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--chains", type=int, default=10)
+    ap.add_argument("--sequences", type=int, default=0, help="random call sequences on one handle")
     ap.add_argument("--classes", type=int, default=0, help="cases of the class-level campaign")
     ap.add_argument("--api", type=int, default=0, help="cases of the API-level campaign (callers around the E-step)")
     ap.add_argument("--seconds", type=float, default=1e9, help="stop drawing new cases after this long")
@@ -398,6 +589,24 @@ def main():
         ndone += 1
         if (i + 1) % 10 == 0:
             print("... api %d, %d failures, %.0f s" % (i + 1, nfail, time.time() - t0))
+            sys.stdout.flush()
+    for i in range(args.sequences):
+        if time.time() - t0 > args.seconds:
+            break
+        seed = args.seed * 100000 + 80000 + i
+        try:
+            run_sequence(e, L, seed)
+        except Exception as ex:
+            nfail += 1
+            msg = str(ex).strip().splitlines()
+            print("FAIL sequence seed=%d: %s | %s" % (seed, type(ex).__name__, " / ".join(msg[:8])[:900]))
+            if not isinstance(ex, AssertionError):
+                traceback.print_exc()
+            e.close()
+            e = HipEngine(0)
+        ndone += 1
+        if (i + 1) % 10 == 0:
+            print("... sequences %d, %d failures, %.0f s" % (i + 1, nfail, time.time() - t0))
             sys.stdout.flush()
     for i in range(args.classes):
         if time.time() - t0 > args.seconds:
