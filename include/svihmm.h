@@ -52,9 +52,10 @@ typedef struct svihmm_ctx svihmm_ctx;
 /* Use the lliks previously uploaded with svihmm_set_lliks (generic emission
  * plugin route) instead of evaluating the NIW emission kernel. */
 #define SVIHMM_USE_HOST_LLIKS 4u
-/* svihmm_estep_minibatch only: also materialise lbeta in HBM so that it can be read
- * back (the log-domain fused backward sweep otherwise keeps it in registers; the scaled
- * sweeps of large batches rebuild lbeta on demand and ignore the flag). */
+/* svihmm_estep_minibatch only: also write lbeta to HBM during the sweep (the log-domain fused
+ * backward sweep otherwise keeps it in registers).  A hint: without it a later read of lbeta
+ * costs one more backward sweep over the lliks still held (and fails once the parameters have
+ * changed); the scaled sweeps rebuild all logs on demand and ignore the flag. */
 #define SVIHMM_KEEP_LBETA 8u
 
 /* svihmm_svi_iteration only: make the log-domain lliks / lalpha / lbeta of the batch's LAST window
@@ -126,7 +127,11 @@ int svihmm_set_globals(svihmm_ctx* h, int32_t K, const double* mod_init,
  * The Cholesky factorisation runs on the device and the call does not wait for it: a
  * sigma that is not positive definite is reported by the next synchronising call
  * (svihmm_sync, svihmm_loglik, svihmm_forward_backward, svihmm_estep_minibatch with an
- * output buffer, svihmm_read_packed). */
+ * output buffer, svihmm_read_packed).  Reported the same way: a factor so far from the origin
+ * for its spread (mu' (nu/2 sigma^-1) mu > 1e8, e.g. raw data of size 1e5 with unit variance) that
+ * the emission GEMM -- which evaluates the quadratic form expanded around the origin -- would
+ * lose more than 1e-7 in the log-likelihoods; the cure is a shift of the observations and the NIW
+ * means by a common vector (the Python classes do that by themselves). */
 int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* mu,
                             const double* sigma, const double* kappa,
                             const double* nu);

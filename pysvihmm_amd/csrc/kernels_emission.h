@@ -2,6 +2,13 @@
 // Part of libsvihmm_hip.so; included by svihmm_hip.hip (single translation unit).
 #pragma once
 
+// The emission GEMM evaluates the NIW quadratic form expanded around the origin: its terms are of
+// size m'Wm = (nu/2) mu' sigma^-1 mu and cancel down to the (x - mu)'W(x - mu) the reference
+// computes centred.  Beyond this size the cancellation costs more than 1e-7 in the
+// log-likelihoods (measured: error ~ 5e-16 m'Wm) and the upload is refused (status word).
+#define NIW_CANCEL_LIMIT 1.0e8
+#define NIW_STATUS_RANGE (1 << 20)
+
 // ------------------------------------------------------------------------------------
 //  K1a: emission, VALU outer-product form (generic fallback).  lane = row.
 //       grid (ceil(n/128), Kp/16), block 128, LDS (D+1)*129*8 bytes.
@@ -559,6 +566,7 @@ __global__ __launch_bounds__(256) void k_niw_to_theta_generic(
     const double cst = 0.5 * llt - D / (2.0 * kappa[k]) - 0.5 * D * 1.8378770664093454835606594728112;
     theta_store(theta, orb, D, D, D, Kp, k, cst - mWm);
     if (logdet_out) logdet_out[k] = 2.0 * logdet;     // log det sigma_mf (ELBO terms)
+    if (mWm > NIW_CANCEL_LIMIT) atomicMax(status, NIW_STATUS_RANGE + 1 + k);
   }
 }
 
@@ -655,6 +663,7 @@ __global__ __launch_bounds__(64) void k_niw_to_theta_wave(
     const double cst = 0.5 * llt - D / (2.0 * kappa[k]) - 0.5 * D * 1.8378770664093454835606594728112;
     theta_store(theta, orb, D, D, D, Kp, k, cst - mWm);
     if (logdet_out) logdet_out[k] = 2.0 * logdet;
+    if (mWm > NIW_CANCEL_LIMIT) atomicMax(status, NIW_STATUS_RANGE + 1 + k);
   }
 }
 

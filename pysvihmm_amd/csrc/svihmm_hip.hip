@@ -452,6 +452,13 @@ static int check_emission_status(svihmm_ctx* h) {
   h->status_pending = false;
   const int st = h->pin_status ? *h->pin_status : 0;
   if (h->pin_status) *h->pin_status = 0;   // sticky until read: reset only here (stream idle)
+  if (st > NIW_STATUS_RANGE) {
+    h->have_emission = false;
+    return fail("svihmm_set_emission_niw: factor " + std::to_string(st - NIW_STATUS_RANGE - 1) +
+                " lies too far from the origin for its spread (mu' (nu/2 sigma^-1) mu > 1e8): the expanded "
+                "quadratic form would lose more than 1e-7 -- subtract a constant vector from the "
+                "observations and from the NIW means (the model is shift-equivariant)");
+  }
   if (st != 0) {
     h->have_emission = false;
     return fail("svihmm_set_emission_niw: sigma_mf[" + std::to_string(st - 1) + "] is not positive definite");
@@ -1686,6 +1693,16 @@ static int intermediate_ptr(svihmm_ctx* h, int what, int64_t row0, int64_t nrows
   Buf* src[] = {&h->ll, &h->la, &h->lb, &h->q};
   if (!h->lin_mode || what == 3 || (what == 0 && h->eh_in_llE)) {
     if (what == 3) CK(ensure_q(h, h->lastB, Lm, h->stream));
+    if (what == 2 && !h->have_lb) {
+      // the fused log-domain backward sweep kept lbeta in registers (no SVIHMM_KEEP_LBETA):
+      // one more backward sweep over the lliks still held, as long as they are current
+      if (h->lin_stale)
+        return fail("lbeta was not kept (SVIHMM_KEEP_LBETA) and the observations / globals / emission "
+                    "parameters have changed since: read it before the next parameter upload");
+      CK(wait_globals(h));
+      CK(launch_fb(h, h->lastB, Lm, 1, 1));
+      h->have_lb = true;
+    }
     if (!src[what]->p) return fail("intermediate buffer not available");
     *out = (const double*)src[what]->p + (size_t)row0 * K;
     return 0;
@@ -2206,8 +2223,6 @@ int svihmm_read_intermediate(svihmm_ctx* h, int32_t what, double* out) {
   if (h->lastB <= 0) return fail("svihmm_read_intermediate: nothing computed yet");
   CK(set_device(h));
   if (what < 0 || what > 3) return fail("svihmm_read_intermediate: bad selector");
-  if (what == 2 && !h->have_lb)
-    return fail("svihmm_read_intermediate: lbeta was not materialised (pass SVIHMM_KEEP_LBETA)");
   const int64_t rows = (int64_t)h->lastB * h->lastLm;
   const double* src = nullptr;
   CK(intermediate_ptr(h, what, 0, rows, &src));
@@ -2220,8 +2235,6 @@ int svihmm_read_rows(svihmm_ctx* h, int32_t what, int64_t row0, int64_t nrows, d
   if (!h || !out || row0 < 0 || nrows <= 0) return fail("svihmm_read_rows: bad arguments");
   if (h->lastB <= 0) return fail("svihmm_read_rows: nothing computed yet");
   if (what < 0 || what > 3) return fail("svihmm_read_rows: bad selector");
-  if (what == 2 && !h->have_lb)
-    return fail("svihmm_read_rows: lbeta was not materialised (pass SVIHMM_KEEP_LBETA)");
   if (row0 + nrows > (int64_t)h->lastB * h->lastLm) return fail("svihmm_read_rows: out of range");
   CK(set_device(h));
   const double* src = nullptr;

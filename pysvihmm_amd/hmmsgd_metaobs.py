@@ -381,6 +381,7 @@ class VBHMM(VariationalHMMBase):
     def _svi_pull_state(self):
         """Device state -> the object's attributes (reference attribute names)."""
         vt, vi, mu, sg, ka, nu = self.engine.svi_read_state()
+        mu = self._from_device_means(mu)
         self.var_tran, self.var_init = vt, vi
         D = self.D
         for k, G in enumerate(self.var_emit):
@@ -404,7 +405,10 @@ class VBHMM(VariationalHMMBase):
         L_ = self.metaobs_half
         miniL = bufferL = L_
         prior = self._prior_arrays()
-        eng.svi_begin(self.prior_tran, self.var_tran, prior, self._emission_arrays(),
+        fac = self._emission_arrays()
+        # (the resident observations are centred: means travel minus the centre, hmmbase._center_of)
+        eng.svi_begin(self.prior_tran, self.var_tran, (self._to_device_means(prior[0]),) + tuple(prior[1:]),
+                      (self._to_device_means(fac[0]),) + tuple(fac[1:]),
                       niw_prior_logpart(prior[1], prior[3]), maxit, vlb_logz_sign())
         self.__dict__.pop("_pending_rows", None)
         if hasattr(eng, "on_next_mutation"):
@@ -535,6 +539,7 @@ class VBHMM(VariationalHMMBase):
         st = self.engine.estep(starts, Lm, flags=flags, read=(comm is None), inner=inner)
         if comm is not None:
             st = comm.allreduce_stats(self.engine, K, D)
+        st = self._unshift_stats(st)
         # quirk Q2: prior_tran - 1 is part of every window's A_i
         A_inter = st.A_raw + nwin * (self.prior_tran - 1.)
         if hasattr(st, "counts"):

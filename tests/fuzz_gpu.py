@@ -296,6 +296,8 @@ def run_class_case(e, seed):
     opts = dict(metaobs_half=half, mb_sz=int(rng.choice([1, 2, 7, 20])), maxit=int(rng.choice([2, 5])),
                 metaobs_fun=str(rng.choice(["unif", "noverlap"])), full_predprob=bool(rng.random() < 0.3) and mask is not None,
                 growBuffer=bool(rng.random() < 0.25))
+    if opts["metaobs_fun"] == "noverlap" and 3 * (opts["mb_sz"] + 1) * (half + 1) > T - 2 * half:
+        opts["metaobs_fun"] = "unif"      # the reference's rejection loop (:246-252) never ends when the windows cannot fit
     infer_kw = {}
     if kind == "metaobs" and not opts["growBuffer"] and rng.random() < 0.25:
         infer_kw = dict(adaptive=True, perIter=2, epsilon=1e-2, minHalfL=1, Lincrement=2, Lcutoff=10)

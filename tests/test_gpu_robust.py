@@ -228,3 +228,71 @@ def test_svi_loop_with_tiny_dirichlet_prior():
     with pytest.raises(RuntimeError, match="PSEUDOCOUNT"):
         e.svi_begin(a.prior_tran, a.var_tran, prior, a._emission_arrays(), niw_prior_logpart(prior[1], prior[3]), 3)
     e.close()
+
+
+def test_engine_refuses_factors_far_from_the_origin():
+    """C-ABI level: data of size 1e7 with unit spread would lose ~0.2 in the log-likelihoods to
+    the cancellation of the expanded quadratic form -- the engine says so instead of computing;
+    1e3 (error 3e-9) passes."""
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    K, D, T = 5, 3, 500
+    pb = make_problem(K, D, T, seed=8, sep=3.0)
+    e = HipEngine(0)
+    try:
+        for off, ok in ((1e3, True), (1e7, False)):
+            e.set_obs(pb["obs"] + off, None)
+            e.set_globals(pb["mod_init"], pb["ltran"])
+            if ok:
+                e.set_emission_niw(pb["mu"] + off, pb["sigma"], pb["kappa"], pb["nu"])
+                assert np.all(np.isfinite(e.estep(np.array([0, 100]), 33).buf))
+            else:
+                with pytest.raises(RuntimeError, match="origin"):
+                    e.set_emission_niw(pb["mu"] + off, pb["sigma"], pb["kappa"], pb["nu"])
+                    e.estep(np.array([0, 100]), 33)
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("kind", ["metaobs_device_loop", "metaobs_host_loop", "batchcd"])
+def test_classes_on_data_far_from_the_origin(kind):
+    """The classes keep the resident observations centred (hmmbase._center_of): a sequence offset
+    by 1e5 (|x| / sigma ~ 1e5: the expanded form alone is off by 2e-5 in the log-likelihoods and
+    the engine would refuse the factors) gives what the same model gives on the un-shifted
+    sequence (the model is shift-equivariant).  Tolerances: with the variational state on the
+    device the whole loop runs in centred coordinates (1e-6); the host-side global steps are the
+    reference's own arithmetic on raw second moments, which cancel 1e10 : 10 at this offset
+    (1e-4, the same for the oracle engine)."""
+    from pysvihmm_amd import hmmsgd_metaobs, hmmbatchcd
+    from pysvihmm_amd.distributions import Gaussian
+    from pysvihmm_amd.engine import HipEngine
+    from oracle.engine import OracleEngine
+    K, D, T = 4, 3, 1500
+    OFF = 1e5
+    pb = make_problem(K, D, T, seed=21, sep=3.0)
+    mask = np.random.default_rng(2).random(T) < 0.05
+
+    def model(engine, off):
+        obs = pb["obs"] + off
+        np.random.seed(6)
+        prior = np.array([Gaussian(mu_0=pb["obs"].mean(0) + off, sigma_0=0.75 * np.cov(pb["obs"].T), kappa_0=0.01,
+                                   nu_0=D + 2) for _ in range(K)])
+        if kind == "batchcd":
+            return hmmbatchcd.VBHMM(obs, np.ones(K), np.ones((K, K)), prior, mask=mask.copy(), maxit=4, engine=engine)
+        return hmmsgd_metaobs.VBHMM(obs, np.ones(K), np.ones((K, K)), prior, tau=1.0, kappa=0.7,
+                                    metaobs_half=10, mb_sz=8, mask=mask.copy(), maxit=6, seed=3, engine=engine)
+    kw = {"device_loop": False} if kind == "metaobs_host_loop" else {}
+    e = HipEngine(0)
+    a, a0, b = model(e, OFF), model(e, 0.0), model(OracleEngine(), OFF)
+    for m in (a, a0, b):
+        m.infer(**kw)
+    tol = 1e-6 if kind == "metaobs_device_loop" else 1e-4
+    for ref, t in ((a0, tol), (b, 1e-4)):
+        np.testing.assert_allclose(a.var_tran, ref.var_tran, rtol=t, atol=1e-8)
+        np.testing.assert_allclose(a.var_x, ref.var_x, rtol=10 * t, atol=1e-7)
+        for k in range(K):
+            np.testing.assert_allclose(a.var_emit[k].mu_mf - OFF, ref.var_emit[k].mu_mf - (OFF if ref is b else 0.0),
+                                       rtol=t, atol=10 * t)
+            np.testing.assert_allclose(a.var_emit[k].sigma_mf, ref.var_emit[k].sigma_mf, rtol=10 * t, atol=10 * t)
+    np.testing.assert_allclose(a.elbo_vec, a0.elbo_vec, rtol=tol)
+    e.close()
