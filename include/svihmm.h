@@ -102,6 +102,11 @@ int svihmm_set_obs(svihmm_ctx* h, const double* obs, int64_t T, int32_t D,
  * with_mask), svihmm_set_obs_rows uploads rows [row0, row0+nrows) and returns when the block
  * is on the device.  Rows never written are undefined. */
 int svihmm_alloc_obs(svihmm_ctx* h, int64_t T, int32_t D, int32_t with_mask);
+/* obs[t, :] -= shift[D] on the resident copy, in place (NaN rows stay NaN).  The model is
+ * shift-equivariant; callers whose data lie far from the origin relative to their spread move
+ * them (and the NIW means they upload) by a common vector -- see svihmm_set_emission_niw on why.
+ * The Python classes centre the resident copy on the data mean this way (hmmbase._center_of). */
+int svihmm_shift_obs(svihmm_ctx* h, const double* shift);
 int svihmm_set_obs_rows(svihmm_ctx* h, int64_t row0, int64_t nrows, const double* obs,
                         const uint8_t* mask);
 

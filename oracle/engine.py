@@ -68,6 +68,10 @@ class OracleEngine(object):
         self.T, self.D = obs.shape
         self.mask = None if mask is None else np.asarray(mask).astype(bool).copy()
 
+    def shift_obs(self, shift):
+        self._pre_mutate()
+        self.obs = self.obs - np.asarray(shift, dtype=np.float64)[None, :]
+
     def set_obs_blocks(self, blocks, T, D, mask=None):
         obs = np.zeros((int(T), int(D)))
         row = 0

@@ -64,6 +64,7 @@ SIGNATURES = {
     "svihmm_pred_logprob": (C.c_int, [C.c_void_p, _c_int64_p, C.c_int32, C.c_int32, C.c_uint32, _c_double_p]),
     "svihmm_alloc_obs": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32]),
     "svihmm_set_obs_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _c_double_p, C.c_void_p]),
+    "svihmm_shift_obs": (C.c_int, [C.c_void_p, _c_double_p]),
     "svihmm_set_emission_prior": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _c_double_p, _c_double_p]),
     "svihmm_niw_vlb_terms": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _c_double_p, _c_double_p, _c_double_p,
                                        _c_double_p, _c_double_p]),

@@ -350,3 +350,10 @@ __global__ void k_finalize_cat(const double* __restrict__ part, int nchunk, int 
     packed[idx] = s;
   }
 }
+
+// obs[t][d] -= shift[d], in place (svihmm_shift_obs)
+__global__ __launch_bounds__(256) void k_shift_obs(double* __restrict__ obs, int64_t n, int D,
+                                                   const double* __restrict__ shift) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) obs[i] -= shift[i % D];
+}

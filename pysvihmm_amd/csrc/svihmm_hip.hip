@@ -333,6 +333,26 @@ int svihmm_set_obs(svihmm_ctx* h, const double* obs, int64_t T, int32_t D,
   return 0;
 }
 
+int svihmm_shift_obs(svihmm_ctx* h, const double* shift) {
+  if (!h || !shift) return fail("svihmm_shift_obs: bad arguments");
+  if (h->T <= 0 || !h->obs.p) return fail("svihmm_shift_obs: no resident observations");
+  CK(set_device(h));
+  h->lin_stale = true;
+  const int D = h->D;
+  void* pin = nullptr;
+  int slot = 0;
+  CK(pinned(h, (size_t)D * sizeof(double), &pin, &slot));
+  std::memcpy(pin, shift, (size_t)D * sizeof(double));
+  void* dpin = nullptr;
+  HIPCK(hipHostGetDevicePointer(&dpin, pin, 0));
+  const int64_t n = h->T * (int64_t)D;
+  hipLaunchKernelGGL(k_shift_obs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream,
+                     (double*)h->obs.p, n, D, (const double*)dpin);
+  HIPCK(hipGetLastError());
+  CK(pin_release(h, slot));
+  return 0;
+}
+
 // Chunked upload for sequences that arrive in pieces (gen_synthetic.py:188-191 read_data_mmap
 // yields [size, D] blocks of the on-disk float64 array): svihmm_alloc_obs sizes the resident
 // copy, svihmm_set_obs_rows fills rows [row0, row0 + nrows).  Each call returns once its

@@ -149,6 +149,14 @@ class HipEngine(object):
             "svihmm_read_generated")
         return obs, sts
 
+    def shift_obs(self, shift):
+        """obs[t, :] -= shift on the resident copy (the classes centre it on the data mean)."""
+        self._pre_mutate()
+        c = np.ascontiguousarray(shift, dtype=np.float64)
+        if c.shape != (self.D,):
+            raise RuntimeError("shift must have shape (D,)")
+        L.check(self._lib.svihmm_shift_obs(self._h, L.dptr(c)), "svihmm_shift_obs")
+
     def set_obs_blocks(self, blocks, T, D, mask=None):
         """Upload a sequence that arrives in row blocks (``gen_synthetic.read_data_mmap``,
         reference ``gen_synthetic.py:188-191``): ``blocks`` yields ``[n_i, D]`` arrays in

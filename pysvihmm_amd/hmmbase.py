@@ -167,8 +167,11 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
         belongs to whoever uploaded last)."""
         eng = self.engine
         if force or self._obs_dirty or getattr(eng, "_obs_owner", None) != id(self):
-            c = self._center = self._center_of(self.obs)
-            eng.set_obs(self.obs if c is None else self.obs - c, self.mask)
+            c = self._center_of(self.obs) if hasattr(eng, "shift_obs") else None
+            self._center = c
+            eng.set_obs(self.obs, self.mask)
+            if c is not None:
+                eng.shift_obs(c)
             eng._obs_owner = id(self)
             self._obs_dirty = False
 
