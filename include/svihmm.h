@@ -133,9 +133,9 @@ int svihmm_set_globals(svihmm_ctx* h, int32_t K, const double* mod_init,
  * sigma that is not positive definite is reported by the next synchronising call
  * (svihmm_sync, svihmm_loglik, svihmm_forward_backward, svihmm_estep_minibatch with an
  * output buffer, svihmm_read_packed).  Reported the same way: a factor so far from the origin
- * for its spread (mu' (nu/2 sigma^-1) mu > 1e8, e.g. raw data of size 1e5 with unit variance) that
+ * for its spread (mu' (nu/2 sigma^-1) mu > 1e9, e.g. raw data of size 1e4 with unit variance) that
  * the emission GEMM -- which evaluates the quadratic form expanded around the origin -- would
- * lose more than 1e-7 in the log-likelihoods; the cure is a shift of the observations and the NIW
+ * lose more than 5e-7 in the log-likelihoods; the cure is a shift of the observations and the NIW
  * means by a common vector (the Python classes do that by themselves). */
 int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* mu,
                             const double* sigma, const double* kappa,

@@ -4,9 +4,11 @@
 
 // The emission GEMM evaluates the NIW quadratic form expanded around the origin: its terms are of
 // size m'Wm = (nu/2) mu' sigma^-1 mu and cancel down to the (x - mu)'W(x - mu) the reference
-// computes centred.  Beyond this size the cancellation costs more than 1e-7 in the
-// log-likelihoods (measured: error ~ 5e-16 m'Wm) and the upload is refused (status word).
-#define NIW_CANCEL_LIMIT 1.0e8
+// computes centred.  Beyond this size the cancellation costs more than 5e-7 in the
+// log-likelihoods (measured: error ~ 5e-16 m'Wm) and the upload is refused (status word).  (A
+// common offset of the data reaches it at |mu| / sigma ~ 5e3; states separated by that many
+// standard deviations do too, where the loss is harmless -- such callers shift as well.)
+#define NIW_CANCEL_LIMIT 1.0e9
 #define NIW_STATUS_RANGE (1 << 20)
 
 // ------------------------------------------------------------------------------------

@@ -475,8 +475,8 @@ static int check_emission_status(svihmm_ctx* h) {
   if (st > NIW_STATUS_RANGE) {
     h->have_emission = false;
     return fail("svihmm_set_emission_niw: factor " + std::to_string(st - NIW_STATUS_RANGE - 1) +
-                " lies too far from the origin for its spread (mu' (nu/2 sigma^-1) mu > 1e8): the expanded "
-                "quadratic form would lose more than 1e-7 -- subtract a constant vector from the "
+                " lies too far from the origin for its spread (mu' (nu/2 sigma^-1) mu > 1e9): the expanded "
+                "quadratic form would lose more than 5e-7 -- subtract a constant vector from the "
                 "observations and from the NIW means (the model is shift-equivariant)");
   }
   if (st != 0) {

@@ -178,7 +178,7 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
     # The device evaluates the NIW quadratic form expanded around the origin (one GEMM over the
     # augmented features), the reference centred on each factor's mean: for data far from the
     # origin relative to their spread the expanded form cancels (error ~ 5e-16 mu'W mu; the engine
-    # refuses factors beyond 1e8).  The model is shift-equivariant, so the resident copy of the
+    # refuses factors beyond 1e9).  The model is shift-equivariant, so the resident copy of the
     # observations is kept centred on the data mean: means go to the device minus the centre,
     # first / second moments come back shifted and are put back here.  self.obs stays as given.
     def _center_of(self, obs):
