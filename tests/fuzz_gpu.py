@@ -257,7 +257,7 @@ def run_api_case(e, L, seed):
         res.append((eng.svi_read_state(), eng.svi_read_elbo(3)[0]))
     (sa, ea), (sb, eb) = res
     for nme, a, b in zip(("var_tran", "var_init", "mu", "sigma", "kappa", "nu"), sa, sb):
-        np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-8, err_msg=what + " svi " + nme)
+        np.testing.assert_allclose(a, b, rtol=1e-5 if nme == "sigma" else 1e-6, atol=1e-8, err_msg=what + " svi " + nme)
     np.testing.assert_allclose(ea, eb, rtol=1e-8, err_msg=what + " svi elbo")
     # --- Categorical emissions on the same state path
     V = int(rng.choice([2, 5, 9, 30]))
