@@ -115,3 +115,22 @@ def test_svi_loop_sweep(case):
     for name, a, b in zip(("var_tran", "var_init", "mu", "sigma", "kappa", "nu"), res[0][0], res[1][0]):
         np.testing.assert_allclose(a, b, rtol=rt, atol=at * max(1.0, float(np.abs(b).max())), err_msg=name)
     np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-5 if f32 else 1e-9)
+
+
+@pytest.mark.parametrize("case", [(300, 4, 33, 20, 3.0, 0.1, False, False), (512, 8, 17, 200, 20.0, 0.0, False, True),
+                                  (1024, 2, 9, 3, 3.0, 0.1, False, False), (300, 3, 257, 4, 3.0, 0.0, True, False)],
+                         ids=lambda c: "K%d_D%d_Lm%d_B%d" % c[:4])
+def test_models_beyond_256_states(case):
+    """K in (256, 1024]: generic per-window recursions (thread = state), emission / statistics
+    tiles in state groups; the full check list of the randomised campaign (statistics in both
+    transition conventions, messages, fp32-mode switch, inner segment), incl. a rare initial state
+    and transition expectations below exp()'s range."""
+    from tests.fuzz_gpu import run_case
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    from oracle import ref_c
+    e = HipEngine(0)
+    try:
+        run_case(e, L, ref_c, case, 4242)
+    finally:
+        e.close()
