@@ -136,7 +136,9 @@ int svihmm_set_globals(svihmm_ctx* h, int32_t K, const double* mod_init,
  * for its spread (mu' (nu/2 sigma^-1) mu > 1e9, e.g. raw data of size 1e4 with unit variance) that
  * the emission GEMM -- which evaluates the quadratic form expanded around the origin -- would
  * lose more than 5e-7 in the log-likelihoods; the cure is a shift of the observations and the NIW
- * means by a common vector (the Python classes do that by themselves). */
+ * means by a common vector (the Python classes do that by themselves).
+ * D <= SVIHMM_NIW_MAX_D; wider observations go the svihmm_set_lliks route (the classes do). */
+#define SVIHMM_NIW_MAX_D 79
 int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* mu,
                             const double* sigma, const double* kappa,
                             const double* nu);

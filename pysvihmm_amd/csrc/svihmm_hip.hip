@@ -573,8 +573,9 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
                             const double* sigma, const double* kappa, const double* nu) {
   if (!h || K <= 0 || D <= 0 || !mu || !sigma || !kappa || !nu)
     return fail("svihmm_set_emission_niw: bad arguments");
-  if ((size_t)(3 * D * (D + 1) + D) * 8 > 150 * 1024)
-    return fail("svihmm_set_emission_niw: D too large");
+  if (D > SVIHMM_NIW_MAX_D)   // (k_niw_to_theta_generic keeps three D x (D+1) matrices in LDS)
+    return fail("svihmm_set_emission_niw: D > SVIHMM_NIW_MAX_D: evaluate the expected log-likelihoods on the "
+                "host and pass them with svihmm_set_lliks / SVIHMM_USE_HOST_LLIKS");
   CK(set_device(h));
   h->lin_stale = true;
   const size_t nmu = (size_t)K * D, nsg = (size_t)K * D * D;

@@ -225,7 +225,10 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
                 np.array([float(g.nu_mf) for g in ve]))
 
     def _niw_fastpath(self):
-        return all(is_niw_gaussian(e) for e in self.var_emit)
+        # (observations wider than the NIW kernels take go the generic route: lliks from the
+        #  emitters' expected_log_likelihood on the host, recursions on the device)
+        d = self.obs.shape[1] if self.obs.ndim == 2 else 1
+        return d <= L.NIW_MAX_D and all(is_niw_gaussian(e) for e in self.var_emit)
 
     def _cat_fastpath(self):
         """Categorical emissions over one integer-valued observation column (the device keeps

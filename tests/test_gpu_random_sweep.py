@@ -134,3 +134,68 @@ def test_models_beyond_256_states(case):
         run_case(e, L, ref_c, case, 4242)
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("case", [(5, 65, 33, 20, 3.0, 0.1, False, False), (16, 72, 17, 300, 3.0, 0.0, False, True),
+                                  (64, 79, 65, 250, 3.0, 0.0, False, False)],
+                         ids=lambda c: "K%d_D%d_Lm%d_B%d" % c[:4])
+def test_observations_up_to_the_niw_kernels_width(case):
+    """D in (64, SVIHMM_NIW_MAX_D = 79]: generic NIW -> theta kernel, emission / statistics fallbacks."""
+    from tests.fuzz_gpu import run_case
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    from oracle import ref_c
+    e = HipEngine(0)
+    try:
+        run_case(e, L, ref_c, case, 777)
+    finally:
+        e.close()
+
+
+def test_observations_wider_than_the_niw_kernels():
+    """D > SVIHMM_NIW_MAX_D: the C ABI refuses the NIW upload and points at svihmm_set_lliks; with
+    host-evaluated lliks the recursions and the statistics run on the device for any D; the
+    classes take that route by themselves (hmmbase._niw_fastpath)."""
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L, hmmsgd_metaobs, hmmbatchcd
+    from pysvihmm_amd.distributions import Gaussian
+    from oracle.engine import OracleEngine
+    from tests.fuzz_gpu import check_stats
+    e = HipEngine(0)
+    try:
+        for (K, D, Lm, B) in [(5, 100, 33, 20), (16, 200, 9, 300)]:
+            T = 600
+            pb = make_problem(K, D, T, seed=D, miss=0.1)
+            st = np.random.default_rng(1).integers(0, T - Lm + 1, size=B)
+            o = OracleEngine()
+            for eng in (e, o):
+                eng.set_obs(pb["obs"], pb["mask"])
+                eng.set_globals(pb["mod_init"], pb["ltran"])
+            with pytest.raises(RuntimeError, match="SVIHMM_NIW_MAX_D"):
+                e.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+            o.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+            ll = o.loglik(st, Lm, flags=L.MASK_AS_NAN)
+            for eng in (e, o):
+                eng.set_lliks(ll)
+            fl = L.TRANS_WRAP | L.MASK_AS_NAN | L.USE_HOST_LLIKS
+            a, b = e.estep(st, Lm, flags=fl), o.estep(st, Lm, flags=fl)
+            check_stats(a.buf, b.buf, K, D, B * Lm, max(1.0, np.abs(pb["obs"]).max()), 1e-6, 1e-9, "host lliks D=%d" % D)
+        K, D, T = 3, 100, 400
+        pb = make_problem(K, D, T, seed=3)
+        obs = pb["obs"]
+
+        def model(engine, cd):
+            np.random.seed(6)
+            prior = np.array([Gaussian(mu_0=obs.mean(0), sigma_0=0.75 * np.cov(obs.T) + np.eye(D), kappa_0=0.01,
+                                       nu_0=D + 2) for _ in range(K)])
+            if cd:
+                return hmmbatchcd.VBHMM(obs.copy(), np.ones(K), np.ones((K, K)), prior, maxit=2, engine=engine)
+            return hmmsgd_metaobs.VBHMM(obs.copy(), np.ones(K), np.ones((K, K)), prior, tau=1.0, kappa=0.7,
+                                        metaobs_half=5, mb_sz=4, maxit=3, seed=3, engine=engine)
+        for cd in (False, True):
+            a, b = model(e, cd), model(OracleEngine(), cd)
+            a.infer(); b.infer()
+            np.testing.assert_allclose(a.var_tran, b.var_tran, rtol=1e-6, atol=1e-8)
+            np.testing.assert_allclose(a.elbo_vec, b.elbo_vec, rtol=1e-8)
+    finally:
+        e.close()
