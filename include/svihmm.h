@@ -118,7 +118,7 @@ int svihmm_set_obs_rows(svihmm_ctx* h, int64_t row0, int64_t nrows, const double
  * SVIHMM_LTRAN_LINEAR_MIN (Dirichlet pseudo-counts of ~2e-3 and less: psi(1e-3) = -1000, not
  * representable) every recursion with these globals runs the reference's own
  * np.logaddexp.reduce form instead (hmmbase.py:295, 319; one exp per state PAIR and step --
- * correct, 6-8x slower); the fp32 mode needs entries above
+ * correct, 5-7x slower); the fp32 mode needs entries above
  * SVIHMM_LTRAN_F32_MIN and computes in fp64 otherwise. */
 #define SVIHMM_LTRAN_LINEAR_MIN (-600.0)
 #define SVIHMM_LTRAN_F32_MIN (-60.0)

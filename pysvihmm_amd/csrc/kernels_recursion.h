@@ -181,8 +181,13 @@ __global__ void k_fb_exact(const double* __restrict__ ll, const double* __restri
     for (int i = 0; i < K; ++i) m = fmax(m, v[i] + mycol[i * si]);
     if (!(m > -INFINITY)) return m;            // all terms -inf (or NaN): as np.logaddexp.reduce
     if (!(m < INFINITY)) return m;
+    // terms more than 50 nats below the maximum cannot change the sum (K e^-50 < 2^-53): in the
+    // sparse models this kernel exists for that is most of them, and exp is the step's cost
     double s = 0.0;
-    for (int i = 0; i < K; ++i) s += exp(v[i] + mycol[i * si] - m);
+    for (int i = 0; i < K; ++i) {
+      const double d = v[i] + mycol[i * si] - m;
+      if (d > -50.0) s += exp(d);
+    }
     return m + log(s);
   };
   if (dir == 0) {
