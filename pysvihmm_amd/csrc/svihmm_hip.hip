@@ -1355,15 +1355,32 @@ static int run_fb(svihmm_ctx* h, int B, int Lm, int var, bool want_lb, bool tota
   return launch_posterior(h, B, Lm, total);
 }
 
-// row chunking of the statistics GEMM: ~256 row chunks (x feature/state tiles => >= 1024
-// workgroups at D=32) so that small minibatches still spread over the 256 CUs; chunk =
-// multiple of ST_RB (one resident workgroup per CU for the pipelined kernel: 128 chunks x 2
-// passes = 256)
+// m-tiles (16 features) per wave of the pipelined statistics GEMM: 5 is the instance tuned for
+// the bench shape (40 tiles = 2 workgroups of 4 x 5); narrow models have far fewer tiles (K = 16,
+// D = 8: 4; K = 64, D = 8: 7) and would run 5-tile waves mostly on padding, so they take 1 / 2 / 4.
+// The small instances exist for the staging widths narrow observations need (xk <= 3) only.
+static int stats_mt(const svihmm_ctx* h) {
+  const int Kp = h->Kp, Fp = h->Fp, D = h->D;
+  if (Kp > 64 || h->variant[10] == 1) return 5;
+  const int NSPLIT = (Kp / 16 == 4) ? 2 : 1;
+  const int xk = (D + 1 + 8 * NSPLIT - 1) / (8 * NSPLIT);
+  const int mt = (Fp + Kp) / 16;
+  if (xk > 3) return 5;
+  if (mt <= 16) return mt <= 4 ? 1 : mt <= 8 ? 2 : 4;
+  return (mt + 15) / 16 * 16 < (mt + 19) / 20 * 20 ? 4 : 5;    // whichever pads less (K = 64, D = 24: 25 tiles)
+}
+// row chunking of the statistics GEMM.  One pipelined workgroup is resident per CU, so the launch
+// should be a whole number of rounds of 256 workgroups: chunks x feature groups (grid.y) = 256 r.
+// 128 chunks x 2 feature groups at the bench shape; more chunks only add partial-sum traffic
+// (64 windows: statistics + finalize 74 -> 56 us, tools/chunk_sweep.py).  chunk = multiple of ST_RB.
 struct StatsPlan { int64_t rpc, nchunk; };
-static StatsPlan stats_plan(int64_t n, int forced = 0) {
-  // 128 chunks x 2 feature groups = one workgroup per CU at every batch size: more chunks only add
-  // partial-sum traffic (64 windows: statistics + finalize 74 -> 56 us, tools/chunk_sweep.py)
-  const int target_chunks = forced > 0 ? forced : 128;
+static StatsPlan stats_plan(const svihmm_ctx* h, int64_t n, int forced = 0) {
+  int target_chunks = forced > 0 ? forced : 128;
+  if (forced <= 0 && h->Kp <= 64 && h->Fp > 0 && !h->emis_cat) {
+    const int gy = ((h->Fp + h->Kp) / 16 + 4 * stats_mt(h) - 1) / (4 * stats_mt(h));
+    const int r = std::max(1, (128 * gy + 128) / 256);     // rounds: round(128 gy / 256)
+    target_chunks = std::max(1, 256 * r / gy);
+  }
   int64_t rpc = (n + target_chunks - 1) / target_chunks;
   rpc = (rpc + ST_RB - 1) / ST_RB * ST_RB;
   return {rpc, (n + rpc - 1) / rpc};
@@ -1416,36 +1433,46 @@ static int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, in
         // fp32 mode: float LDS tiles, v_mfma_f32_16x16x4_f32, ah / bh read as float
         const size_t ldsf = ((size_t)(D + 3 + KpW) * ST_CC + 2 * (size_t)ST_RB * (KpW + 16)) * 4 + 8 +
                             4 * ST_RB * sizeof(StRow4);
-        dim3 grid((unsigned)nchunk, (mt_limit + 4 * 5 - 1) / (4 * 5), 1);
-#define ST3F(NTW, NS, XKV)                                                                        \
+        const int MTs = stats_mt(h);
+        dim3 grid((unsigned)nchunk, (mt_limit + 4 * MTs - 1) / (4 * MTs), 1);
+#define ST3F(MTV, NTW, NS, XKV)                                                                   \
   do {                                                                                           \
     if (ldsf > 64 * 1024)                                                                        \
-      hipFuncSetAttribute((const void*)k_stats_mfma4<5, NTW, NS, XKV, true, false, float, float>, \
+      hipFuncSetAttribute((const void*)k_stats_mfma4<MTV, NTW, NS, XKV, true, false, float, float>, \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);                \
-    hipLaunchKernelGGL((k_stats_mfma4<5, NTW, NS, XKV, true, false, float, float>), grid,        \
+    hipLaunchKernelGGL((k_stats_mfma4<MTV, NTW, NS, XKV, true, false, float, float>), grid,      \
                        dim3(256 * NS), ldsf, stream, (const double*)h->obs.p, mk, starts_dev, n, \
                        Lm, D, K, Fp, F, (const int*)h->fab.p, (const float*)h->la.p, rpc, flags, \
                        Lq, off, partv, Kp, mt_limit, (const float*)h->lb.p, hxv, gxv, zfv);      \
   } while (0)
-#define ST3FX(NTW, NS) do { if (xk <= 1) ST3F(NTW, NS, 1); else if (xk <= 3) ST3F(NTW, NS, 3); else if (xk <= 5) ST3F(NTW, NS, 5); else ST3F(NTW, NS, 9); } while (0)
-        if (NTt == 4) ST3FX(2, 2); else if (NTt == 3) ST3FX(3, 1); else if (NTt == 2) ST3FX(2, 1); else ST3FX(1, 1);
+#define ST3FX(NTW, NS) do { if (xk <= 1) ST3F(5, NTW, NS, 1); else if (xk <= 3) ST3F(5, NTW, NS, 3); else if (xk <= 5) ST3F(5, NTW, NS, 5); else ST3F(5, NTW, NS, 9); } while (0)
+#define ST3FS(MTV, NTW, NS) do { if (xk <= 1) ST3F(MTV, NTW, NS, 1); else ST3F(MTV, NTW, NS, 3); } while (0)
+#define ST3FM(NTW, NS) do { if (MTs == 1) ST3FS(1, NTW, NS); else if (MTs == 2) ST3FS(2, NTW, NS); else if (MTs == 4) ST3FS(4, NTW, NS); else ST3FX(NTW, NS); } while (0)
+        if (NTt == 4) ST3FM(2, 2); else if (NTt == 3) ST3FM(3, 1); else if (NTt == 2) ST3FM(2, 1); else ST3FM(1, 1);
+#undef ST3FM
+#undef ST3FS
 #undef ST3FX
 #undef ST3F
       } else {
-        dim3 grid((unsigned)nchunk, (mt_limit + 4 * 5 - 1) / (4 * 5), big ? Kp / 64 : 1);
-#define ST3L(NTW, NS, XKV, LN)                                                                    \
+        const int MTs = stats_mt(h);
+        dim3 grid((unsigned)nchunk, (mt_limit + 4 * MTs - 1) / (4 * MTs), big ? Kp / 64 : 1);
+#define ST3L(MTV, NTW, NS, XKV, LN)                                                               \
   do {                                                                                           \
     if (lds > 64 * 1024)                                                                         \
-      hipFuncSetAttribute((const void*)k_stats_mfma4<5, NTW, NS, XKV, LN>,                       \
+      hipFuncSetAttribute((const void*)k_stats_mfma4<MTV, NTW, NS, XKV, LN>,                     \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
-    hipLaunchKernelGGL((k_stats_mfma4<5, NTW, NS, XKV, LN>), grid, dim3(256 * NS), lds, stream,  \
+    hipLaunchKernelGGL((k_stats_mfma4<MTV, NTW, NS, XKV, LN>), grid, dim3(256 * NS), lds, stream, \
                        (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, Fp,                  \
                        F, (const int*)h->fab.p, qv, rpc, flags, Lq, off,                          \
                        partv, Kp, mt_limit, bhv, hxv, gxv, zfv);                                  \
   } while (0)
-#define ST3(NTW, NS, XKV) do { if (lin) ST3L(NTW, NS, XKV, true); else ST3L(NTW, NS, XKV, false); } while (0)
-#define ST3X(NTW, NS) do { if (xk <= 1) ST3(NTW, NS, 1); else if (xk <= 3) ST3(NTW, NS, 3); else if (xk <= 5) ST3(NTW, NS, 5); else ST3(NTW, NS, 9); } while (0)
-        if (NTt == 4) ST3X(2, 2); else if (NTt == 3) ST3X(3, 1); else if (NTt == 2) ST3X(2, 1); else ST3X(1, 1);
+#define ST3(MTV, NTW, NS, XKV) do { if (lin) ST3L(MTV, NTW, NS, XKV, true); else ST3L(MTV, NTW, NS, XKV, false); } while (0)
+#define ST3X(NTW, NS) do { if (xk <= 1) ST3(5, NTW, NS, 1); else if (xk <= 3) ST3(5, NTW, NS, 3); else if (xk <= 5) ST3(5, NTW, NS, 5); else ST3(5, NTW, NS, 9); } while (0)
+#define ST3S(MTV, NTW, NS) do { if (xk <= 1) ST3(MTV, NTW, NS, 1); else ST3(MTV, NTW, NS, 3); } while (0)
+#define ST3M(NTW, NS) do { if (MTs == 1) ST3S(1, NTW, NS); else if (MTs == 2) ST3S(2, NTW, NS); else if (MTs == 4) ST3S(4, NTW, NS); else ST3X(NTW, NS); } while (0)
+        if (NTt == 4) ST3M(2, 2); else if (NTt == 3) ST3M(3, 1); else if (NTt == 2) ST3M(2, 1); else ST3M(1, 1);
+#undef ST3M
+#undef ST3S
 #undef ST3X
 #undef ST3
 #undef ST3L
@@ -1528,7 +1555,7 @@ static int launch_stats_cat(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint3
   const int64_t n = (int64_t)B * Lm;
   hipStream_t stream = h->stream;
   CK(ensure_q(h, h->curB, Lq, stream));
-  const StatsPlan plan = stats_plan(n);
+  const StatsPlan plan = stats_plan(h, n);
   const int64_t rpcc = (n + 1023) / 1024 > 64 ? (n + 1023) / 1024 : 64;
   const int nchunkc = (int)((n + rpcc - 1) / rpcc);
   CK(ensure(h->part, (size_t)plan.nchunk * KpT * KpT * sizeof(double)));
@@ -1568,7 +1595,7 @@ static int launch_stats_cat(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint3
 
 static int launch_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags) {
   if (h->emis_cat) return launch_stats_cat(h, B, Lq, off, Lm, flags);
-  const StatsPlan plan = stats_plan((int64_t)B * Lm, h->variant[8]);
+  const StatsPlan plan = stats_plan(h, (int64_t)B * Lm, h->variant[8]);
   CK(ensure_stats(h, plan.nchunk));
   CK(launch_stats_range(h, 0, B, Lq, off, Lm, flags, plan, 0, h->stream));
   return launch_stats_finalize(h, plan.nchunk, h->stream);
@@ -1807,7 +1834,7 @@ static int estep_pipelined(svihmm_ctx* h, const int64_t* starts, int B, int Lm, 
   CK(ensure_fb_lin(h, B, Lm));
   int b0[2], nb[2];
   b0[0] = 0; nb[0] = ((B / 2 + 15) / 16) * 16; b0[1] = nb[0]; nb[1] = B - nb[0];
-  StatsPlan plan[2] = {stats_plan((int64_t)nb[0] * inner_len), stats_plan((int64_t)nb[1] * inner_len)};
+  StatsPlan plan[2] = {stats_plan(h, (int64_t)nb[0] * inner_len), stats_plan(h, (int64_t)nb[1] * inner_len)};
   CK(ensure_stats(h, plan[0].nchunk + plan[1].nchunk));
   h->have_host_ll = false;
   h->lin_mode = true; h->lin_stale = false; h->last_host_ll = false; h->eh_in_llE = false; h->last_flags = flags;
