@@ -199,3 +199,20 @@ def test_observations_wider_than_the_niw_kernels():
             np.testing.assert_allclose(a.elbo_vec, b.elbo_vec, rtol=1e-8)
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("case", [(16, 4, 5000, 8, 3.0, 0.1, False, False), (8, 2, 100000, 2, 3.0, 0.0, False, False),
+                                  (64, 8, 20000, 3, 20.0, 0.0, False, True)],
+                         ids=lambda c: "K%d_D%d_Lm%d_B%d" % c[:4])
+def test_batches_of_long_windows(case):
+    """Several windows of thousands of rows each (adaptive / buffered meta-observations grow them;
+    one window alone takes the blocked scan, covered elsewhere): same check list."""
+    from tests.fuzz_gpu import run_case
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    from oracle import ref_c
+    e = HipEngine(0)
+    try:
+        run_case(e, L, ref_c, case, 999)
+    finally:
+        e.close()
