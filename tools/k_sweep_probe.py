@@ -11,6 +11,9 @@ from pysvihmm_amd.engine import HipEngine  # noqa: E402
 from pysvihmm_amd import _lib as L  # noqa: E402
 
 eng = HipEngine(0)
+for kv in os.environ.get("SVIHMM_SET", "").split(","):      # engine switches for A/B runs, e.g. 8:256
+    if kv:
+        eng.set_variant(int(kv.split(":")[0]), int(kv.split(":")[1]))
 T, D, LM = bench.T, bench.D, bench.LM
 B = T // LM
 st = np.arange(B, dtype=np.int64) * LM
