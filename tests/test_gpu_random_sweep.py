@@ -216,3 +216,18 @@ def test_batches_of_long_windows(case):
         run_case(e, L, ref_c, case, 999)
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("case", [(16, 8, 257, 1100, 3.0, 0.1, False, False), (8, 3, 300, 1100, 20.0, 0.0, False, True)],
+                         ids=lambda c: "K%d_D%d_Lm%d_B%d" % c[:4])
+def test_one_state_tile_large_batch(case):
+    """K <= 16 with more than 2^18 rows: the statistics plan that puts two workgroups on a CU."""
+    from tests.fuzz_gpu import run_case
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    from oracle import ref_c
+    e = HipEngine(0)
+    try:
+        run_case(e, L, ref_c, case, 1234)
+    finally:
+        e.close()
