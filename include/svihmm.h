@@ -35,7 +35,10 @@
 extern "C" {
 #endif
 
-#define SVIHMM_ABI_VERSION 1
+/* 2: svihmm_get_shift added, svihmm_shift_obs no longer changes what later calls mean (the shift is
+ *    the handle's business), svihmm_set_emission_diag added; 1 was rounds 1-2 (svi_*,
+ *    set_precision, shift_obs, ffbs_sample, comm_count were added under it). */
+#define SVIHMM_ABI_VERSION 2
 
 typedef struct svihmm_ctx svihmm_ctx;
 
@@ -93,7 +96,18 @@ int svihmm_get_precision(svihmm_ctx* h, int32_t* mode_out, int32_t* last_batch_f
 
 /* ---- inputs ----------------------------------------------------------------- */
 /* obs[T,D], mask[T] (1 = missing, may be NULL): hmmbase.py:60-65,122-123.
- * Copied to HBM once; NaN entries are preserved. */
+ * Copied to HBM once; NaN entries are preserved.
+ * Coordinates: the resident copy is kept CENTRED, obs_dev[t] = obs[t] - c, with c chosen by the
+ * library at upload (a point inside the data: column means of a row sample; svihmm_generate: the
+ * average of the state means; svihmm_alloc_obs: taken from the first block that arrives) because
+ * the emission GEMM evaluates the NIW quadratic form expanded around the resident copy's origin
+ * and loses ~5e-16 (mu-c)'W(mu-c) to cancellation.  The model is shift-equivariant and c never
+ * shows at this boundary: every mean that comes in (svihmm_set_emission_niw / _diag,
+ * svihmm_svi_begin, svihmm_set_emission_prior, svihmm_niw_vlb_terms) or goes out
+ * (svihmm_svi_read_state) and all statistics (svihmm_estep_minibatch*, svihmm_read_packed) are in
+ * the CALLER's coordinates, exactly as the reference evaluates everything in the coordinates of
+ * self.obs (hmmbase.py:219-229).  Only svihmm_allreduce_packed touches it internally: every rank
+ * has its own c, so the sum is formed in the common caller coordinates. */
 int svihmm_set_obs(svihmm_ctx* h, const double* obs, int64_t T, int32_t D,
                    const uint8_t* mask);
 
@@ -102,11 +116,12 @@ int svihmm_set_obs(svihmm_ctx* h, const double* obs, int64_t T, int32_t D,
  * with_mask), svihmm_set_obs_rows uploads rows [row0, row0+nrows) and returns when the block
  * is on the device.  Rows never written are undefined. */
 int svihmm_alloc_obs(svihmm_ctx* h, int64_t T, int32_t D, int32_t with_mask);
-/* obs[t, :] -= shift[D] on the resident copy, in place (NaN rows stay NaN).  The model is
- * shift-equivariant; callers whose data lie far from the origin relative to their spread move
- * them (and the NIW means they upload) by a common vector -- see svihmm_set_emission_niw on why.
- * The Python classes centre the resident copy on the data mean this way (hmmbase._center_of). */
+/* Moves the library's centre: c += shift[D] (resident copy, device-side NIW state and prior of a
+ * running SVI loop follow; NaN rows stay NaN).  Purely a conditioning hint -- no later call
+ * changes its meaning, results stay in the caller's coordinates.  Useful when the automatic
+ * centre is poor (strongly drifting data) or was switched off.  svihmm_get_shift reads c[D]. */
 int svihmm_shift_obs(svihmm_ctx* h, const double* shift);
+int svihmm_get_shift(svihmm_ctx* h, double* shift_out);
 int svihmm_set_obs_rows(svihmm_ctx* h, int64_t row0, int64_t nrows, const double* obs,
                         const uint8_t* mask);
 
@@ -132,11 +147,11 @@ int svihmm_set_globals(svihmm_ctx* h, int32_t K, const double* mod_init,
  * The Cholesky factorisation runs on the device and the call does not wait for it: a
  * sigma that is not positive definite is reported by the next synchronising call
  * (svihmm_sync, svihmm_loglik, svihmm_forward_backward, svihmm_estep_minibatch with an
- * output buffer, svihmm_read_packed).  Reported the same way: a factor so far from the origin
- * for its spread (mu' (nu/2 sigma^-1) mu > 1e9, e.g. raw data of size 1e4 with unit variance) that
- * the emission GEMM -- which evaluates the quadratic form expanded around the origin -- would
- * lose more than 5e-7 in the log-likelihoods; the cure is a shift of the observations and the NIW
- * means by a common vector (the Python classes do that by themselves).
+ * output buffer, svihmm_read_packed).  Reported the same way: a factor so far from the library's
+ * centre c of the resident observations for its spread ((mu-c)' (nu/2 sigma^-1) (mu-c) > 1e9,
+ * i.e. a state mean > 3e4 standard deviations away from the data) that the emission GEMM -- which
+ * evaluates the quadratic form expanded around c -- would lose more than 5e-7 in the
+ * log-likelihoods; svihmm_shift_obs moves the centre.
  * D <= SVIHMM_NIW_MAX_D; wider observations go the svihmm_set_lliks route (the classes do). */
 #define SVIHMM_NIW_MAX_D 79
 int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* mu,
@@ -201,10 +216,11 @@ int svihmm_estep_minibatch_ex(svihmm_ctx* h, const int64_t* starts, int32_t B,
  *   factors' ELBO term, computed once by the host); zsign = +1 / -1: the sign with which that
  *   constant enters get_vlb (pybasicbayes / Bishop 10.74, see distributions.Gaussian.get_vlb).
  *   The observations must be resident (svihmm_set_obs / svihmm_generate).  Fails when an entry
- *   of prior_tran or var_tran is below SVIHMM_SVI_MIN_PSEUDOCOUNT: var_tran never falls below the
- *   smaller of the two during the loop, so above it psi(var_tran) stays inside the range of the
- *   linear-domain recursions; sparser Dirichlet models take the per-call route
- *   (svihmm_set_globals decides per upload).
+ *   of prior_tran is below 1 or one of var_tran below SVIHMM_SVI_MIN_PSEUDOCOUNT: with
+ *   prior_tran >= 1 no entry of var_tran falls below min(var_tran, 1) during the loop (the step adds
+ *   rho bA nwin (prior_tran - 1) with bA nwin ~ T / 2L, quirk Q2 -- negative and large for sparser
+ *   priors), so psi(var_tran) stays inside the range of the linear-domain recursions; other
+ *   Dirichlet models take the per-call route (svihmm_set_globals decides per upload).
  * svihmm_svi_iteration(it, ...): one iteration on windows starts[B] of length Lm (statistics over
  *   the inner segment, as svihmm_estep_minibatch_ex; flags: SVIHMM_TRANS_WRAP | ...).
  *   nwin_total = windows of the whole minibatch (= B on one GPU; with a communicator the ranks
@@ -237,7 +253,8 @@ int64_t svihmm_packed_len(svihmm_ctx* h);
 
 /* ELBO bookkeeping of the SVI loop (hmmsgd_metaobs.py:273-296 global_lower_bound,
  * hmmbase.py:183-185: sum_k var_emit[k].get_vlb()): the data-dependent scalars of the NIW
- * factors' term for the given mean-field parameters (D <= 64) --
+ * factors' term for the given mean-field parameters (D <= 64: the width of the single-wave
+ * factorisation; wider factors take the host formulas, distributions.niw_vlb_batch) --
  * out[k] = log det sigma_mf[k], out[K+k] = tr(sigma_mf[k]^-1 sigma_0[k]),
  * out[2K+k] = (mu_mf[k]-mu_0[k])' sigma_mf[k]^-1 (mu_mf[k]-mu_0[k]); the host adds the
  * closed-form parts (digamma / gammaln of nu, kappa).  The prior (mu_0[K,D], sigma_0[K,D,D])
@@ -346,7 +363,8 @@ const char* svihmm_kernel_name(int32_t slot);
  * which 0 emission (1 VALU, 2 MFMA) | 1 statistics (1 VALU, 2 MFMA, 3 pipelined MFMA)
  * | 2 sweeps (1 wave-per-window, 2 log-domain MFMA, 3 scaled linear-domain MFMA)
  * | 3 emission row tiles per wave | 4 two-stream E-step pipeline (1 off, 2 on; default off)
- * | 6 blocked scan for one long window (B = 1, Lm >= 2048, K <= 64; 1 = off) */
+ * | 6 blocked scan for one long window (B = 1, Lm >= 2048, K <= 64; 1 = off)
+ * | 9 automatic centring of the resident observations at upload (1 = off: c = 0) */
 int svihmm_set_variant(svihmm_ctx* h, int32_t which, int32_t value);
 
 /* ---- diagnostics ------------------------------------------------------------------- */

@@ -11,6 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsvihmm_hip.so")
 
+ABI_VERSION = 2                   # include/svihmm.h SVIHMM_ABI_VERSION this binding was written against
 NKERN = 12
 MASK_AS_NAN = 1
 TRANS_WRAP = 2
@@ -66,6 +67,7 @@ SIGNATURES = {
     "svihmm_alloc_obs": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32]),
     "svihmm_set_obs_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _c_double_p, C.c_void_p]),
     "svihmm_shift_obs": (C.c_int, [C.c_void_p, _c_double_p]),
+    "svihmm_get_shift": (C.c_int, [C.c_void_p, _c_double_p]),
     "svihmm_set_emission_prior": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _c_double_p, _c_double_p]),
     "svihmm_niw_vlb_terms": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _c_double_p, _c_double_p, _c_double_p,
                                        _c_double_p, _c_double_p]),
@@ -110,6 +112,14 @@ def load():
         lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     except OSError as e:
         raise RuntimeError("cannot load %s: %s" % (LIB_PATH, e))
+    try:
+        lib.svihmm_abi_version.restype = C.c_int
+        got = lib.svihmm_abi_version()
+    except AttributeError:
+        got = None
+    if got != ABI_VERSION:
+        raise RuntimeError("%s has ABI version %s, this package needs %d: rebuild it "
+                           "(`make -C pysvihmm_amd/csrc`)" % (LIB_PATH, got, ABI_VERSION))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res

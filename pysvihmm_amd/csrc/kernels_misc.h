@@ -351,9 +351,46 @@ __global__ void k_finalize_cat(const double* __restrict__ part, int nchunk, int 
   }
 }
 
-// obs[t][d] -= shift[d], in place (svihmm_shift_obs)
+// obs[t][d] -= shift[d], in place, for n consecutive entries of whole rows (the handle keeps the
+// resident copy centred; svihmm_shift_obs).  ROUND: the result is an integer-valued symbol column
+// again (a Categorical table follows data that had been centred for a NIW family).
+template <bool ROUND>
 __global__ __launch_bounds__(256) void k_shift_obs(double* __restrict__ obs, int64_t n, int D,
                                                    const double* __restrict__ shift) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) obs[i] -= shift[i % D];
+  if (i < n) {
+    const double v = obs[i] - shift[i % D];
+    obs[i] = ROUND ? rint(v) : v;
+  }
+}
+// rows of [K][D] means -= shift (the NIW factors / prior resident on the device follow a change of
+// the handle's shift)
+__global__ __launch_bounds__(256) void k_shift_means(double* __restrict__ mu, int n, int D,
+                                                     const double* __restrict__ shift) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) mu[i] -= shift[i % D];
+}
+
+// Packed NIW statistics [A_raw | xbar | neff | S | lb] of observations x - c  ->  the same
+// statistics of x (sgn = +1), or back (sgn = -1; with cs = sgn * c in both cases):
+//   xbar_k += n_k cs,   S_k += cs xbar_k' + xbar_k cs' + n_k cs cs'      (xbar_k of the SOURCE).
+// Out of place; dst may be the host-visible mirror (then this is k_mirror with the handle's shift
+// undone: the C ABI hands out statistics in the caller's coordinates).
+__global__ __launch_bounds__(256) void k_packed_shift(const double* __restrict__ src, double* __restrict__ dst,
+                                                      int n, int K, int D, const double* __restrict__ c,
+                                                      double sgn) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int oX = K * K, oN = oX + K * D, oS = oN + K;
+  double v = src[i];
+  if (i >= oX && i < oN) {
+    const int k = (i - oX) / D, a = (i - oX) - k * D;
+    v += src[oN + k] * (sgn * c[a]);
+  } else if (i >= oS && i < oS + K * D * D) {
+    const int e = i - oS;
+    const int k = e / (D * D), r = e - k * D * D, a = r / D, b = r - a * D;
+    const double ca = sgn * c[a], cb = sgn * c[b];
+    v += ca * src[oX + k * D + b] + src[oX + k * D + a] * cb + src[oN + k] * ca * cb;
+  }
+  dst[i] = v;
 }

@@ -174,13 +174,24 @@ struct svihmm_ctx {
   double svi_zsign = 1.0, svi_prior_const = 0.0;
   double* svi_elbo = nullptr; int svi_elbo_cap = 0;      // pinned + mapped: elbo_vec
   std::vector<hipEvent_t> svi_ev;                        // iteration boundaries (iter_time)
-  bool svi_active = false;
+  bool svi_active = false, svi_f32_ok = true;
   hipEvent_t svi_ea = nullptr, svi_eb = nullptr, globals_ev = nullptr;   // side-stream globals kernel
   hipEvent_t svi_ec = nullptr, svi_ed = nullptr;   // theta ready / side-stream ELBO kernels done
   hipStream_t stream3 = nullptr;                   // the ELBO kernels' own stream
   bool vlb_pending = false;
   bool svi_globals_ready = false;   // Aexp / mod_init / var_init[slot] of the NEXT iteration are computed (or in flight)
   int svi_globals_slot = 0, svi_vi_cur = 0;   // var_init slot the pending globals write / the last iteration used
+  // The resident observations are kept centred: obs_dev[t] = obs_caller[t] - shift.  The shift is
+  // chosen at upload (a point inside the data) and moved by svihmm_shift_obs; it never shows at the
+  // ABI: means come in / go out in the caller's coordinates (set_emission_niw, svi_begin,
+  // svi_read_state), statistics are handed out in the caller's coordinates (launch_mirror), the
+  // device-side state (h->niw, svi_prior, packed) lives in centred coordinates.
+  std::vector<double> shift;     // [D]; empty = no observations yet
+  Buf shift_d;                   // the same vector on the device
+  bool shifted = false;          // some component is non-zero
+  bool center_pending = false;   // svihmm_alloc_obs: centre on the first block that arrives
+  int shift_epoch = 0, prior_epoch = -1;
+  std::vector<double> prior_mu0; // caller-coordinate prior means of svihmm_set_emission_prior
   // precision mode (svihmm_set_precision): 0 fp64, 1 fp32 (see the header); cur_f32: the batch in
   // flight / the intermediates currently held are in the fp32 format
   int prec = 0;
@@ -267,7 +278,8 @@ int svihmm_destroy(svihmm_ctx* h) {
                  &h->fab, &h->starts, &h->ll, &h->la, &h->lb, &h->q, &h->lse_part,
                  &h->local_lb, &h->logz, &h->part, &h->packed, &h->scratch, &h->kexp, &h->hx, &h->gx,
                  &h->zfac, &h->llE, &h->m_ll, &h->m_la, &h->m_lb, &h->chain, &h->chain2, &h->cat_table, &h->partc, &h->theta_orb, &h->prior, &h->vlb_aux, &h->gen_z,
-                 &h->svi_state, &h->svi_prior, &h->svi_work, &h->commtmp, &h->ll0, &h->a0v, &h->a0e};
+                 &h->svi_state, &h->svi_prior, &h->svi_work, &h->commtmp, &h->ll0, &h->a0v, &h->a0e,
+                 &h->shift_d};
   for (Buf* b : bufs) release(*b);
   if (h->vlb_host) { hipHostFree(h->vlb_host); h->vlb_host = nullptr; }
   if (h->svi_elbo) { hipHostFree(h->svi_elbo); h->svi_elbo = nullptr; }
@@ -295,6 +307,13 @@ static int wait_globals(svihmm_ctx* h);
 static int pinned(svihmm_ctx* h, size_t bytes, void** out, int* slot_out);
 static int pull_small(svihmm_ctx* h, void* dst, const void* pin, size_t bytes);
 static int pin_release(svihmm_ctx* h, int slot);
+static int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out);
+static double* svi_ptr(svihmm_ctx* h, int which);
+static int wait_side_streams(svihmm_ctx* h);
+static void sample_center(const svihmm_ctx* h, const double* obs, int64_t T, int D, std::vector<double>& c);
+static int reset_shift(svihmm_ctx* h, const std::vector<double>& c, int64_t row0, int64_t nrows);
+static int shift_rows(svihmm_ctx* h, const double* delta, int64_t row0, int64_t nrows, bool round_symbols);
+static int store_shift(svihmm_ctx* h, const std::vector<double>& c);
 int svihmm_set_precision(svihmm_ctx* h, int32_t mode) {
   if (!h || (mode != SVIHMM_F64 && mode != SVIHMM_F32)) return fail("svihmm_set_precision: mode must be SVIHMM_F64 or SVIHMM_F32");
   h->prec = mode;
@@ -328,9 +347,85 @@ int svihmm_set_obs(svihmm_ctx* h, const double* obs, int64_t T, int32_t D,
     CK(ensure(h->mask, (size_t)T));
     HIPCK(hipMemcpyAsync(h->mask.p, mask, (size_t)T, hipMemcpyHostToDevice, h->stream));
   }
-  HIPCK(hipStreamSynchronize(h->stream));
   h->T = T; h->D = D; h->gen_T = 0;
+  h->svi_active = false;               // a resident SVI state belonged to the previous sequence
+  h->center_pending = false;
+  std::vector<double> c;
+  sample_center(h, obs, T, D, c);
+  CK(reset_shift(h, c, 0, T));
+  HIPCK(hipStreamSynchronize(h->stream));
   return 0;
+}
+
+// ---- the handle's shift (see svihmm_ctx::shift) ---------------------------------------------
+// A point inside the data: per column the mean of the finite entries of a strided sample of rows.
+// Any vector works (the model is shift-equivariant); what matters is |x - c| being of the size of
+// the data's spread, so that the emission GEMM's expanded quadratic form does not cancel.
+static void sample_center(const svihmm_ctx* h, const double* obs, int64_t T, int D, std::vector<double>& c) {
+  c.assign((size_t)D, 0.0);
+  if (h->variant[9] == 1 || !obs || T <= 0) return;      // variant 9 = 1: no automatic centring
+  int64_t nsamp = ((int64_t)4 << 20) / D;
+  if (nsamp > 65536) nsamp = 65536;
+  if (nsamp < 16) nsamp = 16;
+  if (nsamp > T) nsamp = T;
+  const int64_t stride = T / nsamp;
+  std::vector<int64_t> cnt((size_t)D, 0);
+  for (int64_t i = 0; i < nsamp; ++i) {
+    const double* row = obs + (size_t)(i * stride) * D;
+    for (int d = 0; d < D; ++d) {
+      const double v = row[d];
+      if (v > -1.7e308 && v < 1.7e308) { c[d] += v; ++cnt[d]; }
+    }
+  }
+  for (int d = 0; d < D; ++d) {
+    c[d] = cnt[d] > 0 ? c[d] / (double)cnt[d] : 0.0;
+    if (!(c[d] > -1.7e308 && c[d] < 1.7e308)) c[d] = 0.0;
+  }
+}
+// rows [row0, row0 + nrows) of the resident copy -= delta[D] (host vector)
+static int shift_rows(svihmm_ctx* h, const double* delta, int64_t row0, int64_t nrows, bool round_symbols) {
+  const int D = h->D;
+  bool any = false;
+  for (int d = 0; d < D; ++d) any = any || delta[d] != 0.0;
+  if (!any || nrows <= 0) return 0;
+  void* pin = nullptr;
+  int slot = 0;
+  CK(pinned(h, (size_t)D * sizeof(double), &pin, &slot));
+  std::memcpy(pin, delta, (size_t)D * sizeof(double));
+  void* dpin = nullptr;
+  HIPCK(hipHostGetDevicePointer(&dpin, pin, 0));
+  const int64_t n = nrows * (int64_t)D;
+  double* base = (double*)h->obs.p + (size_t)row0 * D;
+  if (round_symbols)
+    hipLaunchKernelGGL(k_shift_obs<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, base, n, D,
+                       (const double*)dpin);
+  else
+    hipLaunchKernelGGL(k_shift_obs<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, base, n, D,
+                       (const double*)dpin);
+  HIPCK(hipGetLastError());
+  CK(pin_release(h, slot));
+  return 0;
+}
+// record c as the handle's shift (host + device copy)
+static int store_shift(svihmm_ctx* h, const std::vector<double>& c) {
+  const int D = h->D;
+  h->shift = c;
+  h->shifted = false;
+  for (int d = 0; d < D; ++d) h->shifted = h->shifted || c[d] != 0.0;
+  ++h->shift_epoch;
+  CK(ensure(h->shift_d, (size_t)D * sizeof(double)));
+  void* pin = nullptr;
+  int slot = 0;
+  CK(pinned(h, (size_t)D * sizeof(double), &pin, &slot));
+  std::memcpy(pin, c.data(), (size_t)D * sizeof(double));
+  CK(pull_small(h, h->shift_d.p, pin, (size_t)D * sizeof(double)));
+  CK(pin_release(h, slot));
+  return 0;
+}
+// freshly written rows [row0, row0 + nrows) hold caller coordinates: c becomes the shift, rows move
+static int reset_shift(svihmm_ctx* h, const std::vector<double>& c, int64_t row0, int64_t nrows) {
+  CK(store_shift(h, c));
+  return shift_rows(h, c.data(), row0, nrows, false);
 }
 
 int svihmm_shift_obs(svihmm_ctx* h, const double* shift) {
@@ -339,17 +434,43 @@ int svihmm_shift_obs(svihmm_ctx* h, const double* shift) {
   CK(set_device(h));
   h->lin_stale = true;
   const int D = h->D;
-  void* pin = nullptr;
-  int slot = 0;
-  CK(pinned(h, (size_t)D * sizeof(double), &pin, &slot));
-  std::memcpy(pin, shift, (size_t)D * sizeof(double));
-  void* dpin = nullptr;
-  HIPCK(hipHostGetDevicePointer(&dpin, pin, 0));
-  const int64_t n = h->T * (int64_t)D;
-  hipLaunchKernelGGL(k_shift_obs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream,
-                     (double*)h->obs.p, n, D, (const double*)dpin);
-  HIPCK(hipGetLastError());
-  CK(pin_release(h, slot));
+  for (int d = 0; d < D; ++d)
+    if (!(shift[d] > -1.7e308 && shift[d] < 1.7e308)) return fail("svihmm_shift_obs: shift must be finite");
+  CK(wait_side_streams(h));
+  CK(shift_rows(h, shift, 0, h->T, false));
+  std::vector<double> c = h->shift;
+  c.resize((size_t)D, 0.0);
+  for (int d = 0; d < D; ++d) c[d] += shift[d];
+  CK(store_shift(h, c));
+  // device-side parameters in centred coordinates follow: NIW means (+ theta), the SVI loop's prior
+  const bool niw_live = h->have_emission && !h->emis_cat && h->eD == D && h->niw.p;
+  if (niw_live || h->svi_active) {
+    void* pin = nullptr;
+    int slot = 0;
+    CK(pinned(h, (size_t)D * sizeof(double), &pin, &slot));
+    std::memcpy(pin, shift, (size_t)D * sizeof(double));
+    void* dpin = nullptr;
+    HIPCK(hipHostGetDevicePointer(&dpin, pin, 0));
+    if (niw_live) {
+      const int n = h->eK * D;
+      hipLaunchKernelGGL(k_shift_means, dim3((n + 255) / 256), dim3(256), 0, h->stream, (double*)h->niw.p, n, D,
+                         (const double*)dpin);
+    }
+    if (h->svi_active && h->svi_D == D) {
+      const int n = h->svi_K * D;
+      hipLaunchKernelGGL(k_shift_means, dim3((n + 255) / 256), dim3(256), 0, h->stream, (double*)h->svi_prior.p, n, D,
+                         (const double*)dpin);
+    }
+    HIPCK(hipGetLastError());
+    CK(pin_release(h, slot));
+    if (niw_live) CK(launch_niw_to_theta(h, h->eK, D, h->svi_active ? svi_ptr(h, 4) : nullptr));
+  }
+  return 0;
+}
+int svihmm_get_shift(svihmm_ctx* h, double* shift_out) {
+  if (!h || !shift_out) return fail("svihmm_get_shift: bad arguments");
+  if (h->T <= 0) return fail("svihmm_get_shift: no resident observations");
+  for (int d = 0; d < h->D; ++d) shift_out[d] = d < (int)h->shift.size() ? h->shift[d] : 0.0;
   return 0;
 }
 
@@ -368,7 +489,10 @@ int svihmm_alloc_obs(svihmm_ctx* h, int64_t T, int32_t D, int32_t with_mask) {
     CK(ensure(h->mask, (size_t)T));
     HIPCK(hipMemsetAsync(h->mask.p, 0, (size_t)T, h->stream));
   }
-  h->T = T; h->D = D;
+  h->T = T; h->D = D; h->gen_T = 0;
+  h->svi_active = false;
+  CK(store_shift(h, std::vector<double>((size_t)D, 0.0)));
+  h->center_pending = true;            // the first block that arrives fixes the shift
   return 0;
 }
 int svihmm_set_obs_rows(svihmm_ctx* h, int64_t row0, int64_t nrows, const double* obs,
@@ -384,6 +508,13 @@ int svihmm_set_obs_rows(svihmm_ctx* h, int64_t row0, int64_t nrows, const double
                        hipMemcpyHostToDevice, h->stream));
   if (mask)
     HIPCK(hipMemcpyAsync((uint8_t*)h->mask.p + row0, mask, (size_t)nrows, hipMemcpyHostToDevice, h->stream));
+  if (h->center_pending) {
+    h->center_pending = false;
+    std::vector<double> c;
+    sample_center(h, obs, nrows, h->D, c);
+    CK(store_shift(h, c));
+  }
+  CK(shift_rows(h, h->shift.data(), row0, nrows, false));
   HIPCK(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -475,9 +606,9 @@ static int check_emission_status(svihmm_ctx* h) {
   if (st > NIW_STATUS_RANGE) {
     h->have_emission = false;
     return fail("svihmm_set_emission_niw: factor " + std::to_string(st - NIW_STATUS_RANGE - 1) +
-                " lies too far from the origin for its spread (mu' (nu/2 sigma^-1) mu > 1e9): the expanded "
-                "quadratic form would lose more than 5e-7 -- subtract a constant vector from the "
-                "observations and from the NIW means (the model is shift-equivariant)");
+                " lies too far from the centre of the resident observations for its spread "
+                "((mu-c)' (nu/2 sigma^-1) (mu-c) > 1e9): the expanded quadratic form would lose more than "
+                "5e-7 in the log-likelihoods -- svihmm_shift_obs moves the centre (svihmm_get_shift reads it)");
   }
   if (st != 0) {
     h->have_emission = false;
@@ -569,6 +700,17 @@ static int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out) 
   return 0;
 }
 
+// means[K][D] in the caller's coordinates -> centred coordinates (and back), in place on the host
+static void to_centred(const svihmm_ctx* h, double* mu, int K, int D) {
+  if (!h->shifted || (int)h->shift.size() != D) return;
+  for (int k = 0; k < K; ++k)
+    for (int d = 0; d < D; ++d) mu[(size_t)k * D + d] -= h->shift[d];
+}
+static void from_centred(const svihmm_ctx* h, double* mu, int K, int D) {
+  if (!h->shifted || (int)h->shift.size() != D) return;
+  for (int k = 0; k < K; ++k)
+    for (int d = 0; d < D; ++d) mu[(size_t)k * D + d] += h->shift[d];
+}
 int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* mu,
                             const double* sigma, const double* kappa, const double* nu) {
   if (!h || K <= 0 || D <= 0 || !mu || !sigma || !kappa || !nu)
@@ -588,9 +730,11 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
   CK(pinned(h, (nin + 1) * sizeof(double), &pin, &slot));
   double* hp = (double*)pin;
   std::memcpy(hp, mu, nmu * sizeof(double));
+  to_centred(h, hp, K, D);             // the resident observations are x - shift: so are the means
   std::memcpy(hp + nmu, sigma, nsg * sizeof(double));
   std::memcpy(hp + nmu + nsg, kappa, K * sizeof(double));
   std::memcpy(hp + nmu + nsg + K, nu, K * sizeof(double));
+  if (h->vlb_pending) { HIPCK(hipStreamWaitEvent(h->stream, h->svi_ed, 0)); h->vlb_pending = false; }
   CK(pull_small(h, dmu, hp, nin * sizeof(double)));
   CK(pin_release(h, slot));
   CK(launch_niw_to_theta(h, K, D, nullptr));
@@ -607,10 +751,13 @@ int svihmm_set_emission_prior(svihmm_ctx* h, int32_t K, int32_t D, const double*
   int slot = 0;
   CK(pinned(h, (nmu + nsg) * sizeof(double), &pin, &slot));
   std::memcpy(pin, mu0, nmu * sizeof(double));
+  to_centred(h, (double*)pin, K, D);
   std::memcpy((double*)pin + nmu, sigma0, nsg * sizeof(double));
   CK(pull_small(h, h->prior.p, pin, (nmu + nsg) * sizeof(double)));
   CK(pin_release(h, slot));
   h->prior_K = K; h->prior_D = D;
+  h->prior_mu0.assign(mu0, mu0 + nmu);     // re-centred when the handle's shift has moved since
+  h->prior_epoch = h->shift_epoch;
   return 0;
 }
 int svihmm_niw_vlb_terms(svihmm_ctx* h, int32_t K, int32_t D, const double* mu, const double* sigma,
@@ -618,7 +765,7 @@ int svihmm_niw_vlb_terms(svihmm_ctx* h, int32_t K, int32_t D, const double* mu, 
   if (!h || K <= 0 || D <= 0 || !mu || !sigma || !kappa || !nu || !out3K)
     return fail("svihmm_niw_vlb_terms: bad arguments");
   if (h->prior_K != K || h->prior_D != D) return fail("svihmm_niw_vlb_terms: call svihmm_set_emission_prior first");
-  if (D > 64) return fail("svihmm_niw_vlb_terms: D > 64 not supported");
+  if (D > 64) return fail("svihmm_niw_vlb_terms: D > 64 not supported (the single-wave factorisation's width)");
   CK(set_device(h));
   CK(upload_feature_table(h, D, K));
   const int Fp = h->Fp, Kp = h->Kp;
@@ -647,11 +794,22 @@ int svihmm_niw_vlb_terms(svihmm_ctx* h, int32_t K, int32_t D, const double* mu, 
   CK(pinned(h, nin * sizeof(double), &pin, &slot));
   double* hp = (double*)pin;
   std::memcpy(hp, mu, nmu * sizeof(double));
+  to_centred(h, hp, K, D);     // (only differences mu - mu_0 enter; both travel centred)
   std::memcpy(hp + nmu, sigma, nsg * sizeof(double));
   std::memcpy(hp + nmu + nsg, kappa, K * sizeof(double));
   std::memcpy(hp + nmu + nsg + K, nu, K * sizeof(double));
   CK(pull_small(h, dmu, hp, nin * sizeof(double)));
   CK(pin_release(h, slot));
+  if (h->prior_epoch != h->shift_epoch) {
+    void* pin2 = nullptr;
+    int slot2 = 0;
+    CK(pinned(h, nmu * sizeof(double), &pin2, &slot2));
+    std::memcpy(pin2, h->prior_mu0.data(), nmu * sizeof(double));
+    to_centred(h, (double*)pin2, K, D);
+    CK(pull_small(h, h->prior.p, pin2, nmu * sizeof(double)));
+    CK(pin_release(h, slot2));
+    h->prior_epoch = h->shift_epoch;
+  }
   const double* p0 = (const double*)h->prior.p;
   {
     ProfScope ps(h, KS_MISC);
@@ -675,6 +833,15 @@ int svihmm_set_emission_cat(svihmm_ctx* h, int32_t K, int32_t V, const double* l
   if (!h || K <= 0 || V <= 0 || !logp) return fail("svihmm_set_emission_cat: bad arguments");
   CK(set_device(h));
   h->lin_stale = true;
+  h->center_pending = false;
+  if (h->shifted && h->T > 0) {
+    // the resident column holds symbol indices: a centred copy (the upload cannot know the family)
+    // goes back to exact integers and stays uncentred
+    std::vector<double> back(h->shift.size());
+    for (size_t d = 0; d < back.size(); ++d) back[d] = -h->shift[d];
+    CK(shift_rows(h, back.data(), 0, h->T, true));
+    CK(store_shift(h, std::vector<double>((size_t)h->D, 0.0)));
+  }
   const size_t n = (size_t)K * V;
   CK(ensure(h->cat_table, n * sizeof(double)));
   void* pin = nullptr;
@@ -1342,6 +1509,13 @@ static int wait_globals(svihmm_ctx* h) {
   }
   return 0;
 }
+// The SVI loop's side streams may still read what a host upload is about to rewrite: the ELBO
+// kernels (stream3) read niw / theta / logdet / var_tran, the globals kernel (stream2) var_tran.
+static int wait_side_streams(svihmm_ctx* h) {
+  CK(wait_globals(h));
+  if (h->vlb_pending) { HIPCK(hipStreamWaitEvent(h->stream, h->svi_ed, 0)); h->vlb_pending = false; }
+  return 0;
+}
 static int run_fb(svihmm_ctx* h, int B, int Lm, int var, bool want_lb, bool total) {
   h->m_nb = 0;
   CK(wait_globals(h));
@@ -1777,20 +1951,41 @@ static int launch_mirror(svihmm_ctx* h) {
   double* dev = nullptr;
   HIPCK(hipHostGetDevicePointer((void**)&dev, h->mirror, 0));
   ProfScope ps(h, KS_D2H);
-  hipLaunchKernelGGL(k_mirror, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream,
-                     (const double*)h->packed.p, dev, (int)n);
+  if (h->shifted && !h->emis_cat)      // statistics leave in the caller's coordinates
+    hipLaunchKernelGGL(k_packed_shift, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream,
+                       (const double*)h->packed.p, dev, (int)n, h->K, h->D, (const double*)h->shift_d.p, 1.0);
+  else
+    hipLaunchKernelGGL(k_mirror, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream,
+                       (const double*)h->packed.p, dev, (int)n);
   HIPCK(hipGetLastError());
   h->mirror_valid = true;
   return 0;
 }
 static int read_packed_host(svihmm_ctx* h, double* out) {
   const size_t nb = (size_t)packed_len(h) * sizeof(double);
-  if (h->mirror_valid) {
-    HIPCK(hipStreamSynchronize(h->stream));
-    std::memcpy(out, h->mirror, nb);
+  if (!h->mirror_valid) CK(launch_mirror(h));
+  HIPCK(hipStreamSynchronize(h->stream));
+  std::memcpy(out, h->mirror, nb);
+  return 0;
+}
+// Sum of the packed statistics over the ranks.  The buffer holds centred coordinates and every
+// rank has its own shift: the sum is formed in the callers' common coordinates and brought back.
+static int allreduce_packed_dev(svihmm_ctx* h) {
+  const size_t n = (size_t)packed_len(h);
+  if (h->shifted && !h->emis_cat && h->nranks > 1) {
+    CK(ensure(h->commtmp, n * sizeof(double)));
+    double* tmp = (double*)h->commtmp.p;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_packed_shift, dim3(nb), dim3(256), 0, h->stream, (const double*)h->packed.p, tmp, (int)n,
+                       h->K, h->D, (const double*)h->shift_d.p, 1.0);
+    NCCLCK(ncclAllReduce(tmp, tmp, n, ncclDouble, ncclSum, h->comm, h->stream));
+    hipLaunchKernelGGL(k_packed_shift, dim3(nb), dim3(256), 0, h->stream, (const double*)tmp, (double*)h->packed.p,
+                       (int)n, h->K, h->D, (const double*)h->shift_d.p, -1.0);
+    HIPCK(hipGetLastError());
     return 0;
   }
-  return d2h_sync_small(h, out, h->packed.p, nb);
+  NCCLCK(ncclAllReduce(h->packed.p, h->packed.p, n, ncclDouble, ncclSum, h->comm, h->stream));
+  return 0;
 }
 
 // ---- two-stream E-step pipeline -------------------------------------------------------------
@@ -2063,6 +2258,9 @@ static int svi_globals(svihmm_ctx* h, int slot) {
   h->globals_ev = h->svi_eb;
   h->svi_globals_ready = true; h->svi_globals_slot = slot;
   h->K = K; h->have_globals = true; h->lin_stale = true;
+  // (a host svihmm_set_globals between two iterations -- select_L, pred_logprob_full -- decides
+  //  these per upload; the loop's own globals are back in the range svi_begin verified)
+  h->exact_log = false; h->f32_ok = h->svi_f32_ok;
   return 0;
 }
 // theta + log det for the factors now in h->niw (main stream: the next emission GEMM needs theta);
@@ -2111,19 +2309,24 @@ int svihmm_svi_begin(svihmm_ctx* h, int32_t K, int32_t D, const double* prior_tr
   if (K > 1024) return fail("svihmm_svi_begin: K > 1024 unsupported");
   if (h->D != D) return fail("svihmm_svi_begin: D does not match the resident observations");
   CK(set_device(h));
+  CK(wait_side_streams(h));
   const size_t kk = (size_t)K * K, nmu = (size_t)K * D, nsg = (size_t)K * D * D;
   const size_t nin = nmu + nsg + 2 * (size_t)K;
   {
-    // every later var_tran is a convex combination of the current one and prior + statistics, so
-    // its entries never fall below this minimum: psi(v) - psi(row sum) stays inside the range of
-    // the linear-domain recursions for the whole loop (the row sums are < 1e12: psi < 28)
-    double vmin = INFINITY;
-    for (size_t i = 0; i < kk; ++i) vmin = std::fmin(vmin, std::fmin(prior_tran[i], var_tran[i]));
-    if (!(vmin >= SVIHMM_SVI_MIN_PSEUDOCOUNT))
-      return fail("svihmm_svi_begin: transition pseudo-counts below SVIHMM_SVI_MIN_PSEUDOCOUNT need the "
-                  "log-domain recursion: run the loop through svihmm_set_globals + svihmm_estep_minibatch");
+    // The global step is var_tran <- (1 - rho) var_tran + rho (1 + bA (A_raw + nwin (prior_tran - 1)))
+    // with bA nwin ~ T / 2L >> 1 (quirk Q2): only for prior_tran >= 1 is every later entry bounded
+    // below by min(var_tran, 1), so that psi(v) - psi(row sum) stays inside the range of the
+    // linear-domain recursions for the whole loop (the row sums are < 1e12: psi < 28).  Sparser
+    // priors can drive entries towards zero or below mid-loop; the host loop, which picks the
+    // recursion per upload, serves those.
+    double vmin = INFINITY, pmin = INFINITY;
+    for (size_t i = 0; i < kk; ++i) { vmin = std::fmin(vmin, var_tran[i]); pmin = std::fmin(pmin, prior_tran[i]); }
+    if (!(vmin >= SVIHMM_SVI_MIN_PSEUDOCOUNT) || !(pmin >= 1.0))
+      return fail("svihmm_svi_begin: prior_tran below 1 or var_tran below SVIHMM_SVI_MIN_PSEUDOCOUNT may need the "
+                  "log-domain recursion mid-loop: run the loop through svihmm_set_globals + svihmm_estep_minibatch");
+    h->svi_f32_ok = vmin > 0.05;      // psi(0.05) - 28 > SVIHMM_LTRAN_F32_MIN
     h->exact_log = false;
-    h->f32_ok = vmin > 0.05;          // psi(0.05) - 28 > SVIHMM_LTRAN_F32_MIN
+    h->f32_ok = h->svi_f32_ok;
   }
   h->svi_K = K; h->svi_D = D; h->svi_maxit = maxit; h->svi_zsign = zsign;
   {   // sum_i [lgamma(sum_j p_ij + eps) - sum_j lgamma(p_ij + eps)]: the prior-only part of the rows' energy
@@ -2148,9 +2351,11 @@ int svihmm_svi_begin(svihmm_ctx* h, int32_t K, int32_t D, const double* prior_tr
   std::memcpy(hp + 2 * kk, prior_logpart, K * 8);
   double* pp = hp + 2 * kk + K;
   std::memcpy(pp, mu0, nmu * 8); std::memcpy(pp + nmu, sigma0, nsg * 8);
+  to_centred(h, pp, K, D);             // the loop's state lives in the resident copy's coordinates
   std::memcpy(pp + nmu + nsg, kappa0, K * 8); std::memcpy(pp + nmu + nsg + K, nu0, K * 8);
   double* np_ = pp + nin;
   std::memcpy(np_, mu, nmu * 8); std::memcpy(np_ + nmu, sigma, nsg * 8);
+  to_centred(h, np_, K, D);
   std::memcpy(np_ + nmu + nsg, kappa, K * 8); std::memcpy(np_ + nmu + nsg + K, nu, K * 8);
   CK(pull_small(h, svi_ptr(h, 0), hp, 2 * kk * 8));
   CK(pull_small(h, svi_ptr(h, 5), hp + 2 * kk, K * 8));
@@ -2204,7 +2409,7 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
   }
   if (h->comm) {
     ProfScope ps(h, KS_ALLREDUCE);
-    NCCLCK(ncclAllReduce(h->packed.p, h->packed.p, (size_t)packed_len(h), ncclDouble, ncclSum, h->comm, h->stream));
+    CK(allreduce_packed_dev(h));
   }
   CK(wait_globals(h));     // (an empty shard ran no sweeps)
   // the previous iteration's ELBO kernels (their own stream) read var_tran / theta / logdet,
@@ -2256,6 +2461,9 @@ int svihmm_svi_read_state(svihmm_ctx* h, double* var_tran, double* var_init, dou
   if (kappa) CK(d2h(h, kappa, nw + nmu + nsg, K * 8));
   if (nu) CK(d2h(h, nu, nw + nmu + nsg + K, K * 8));
   HIPCK(hipStreamSynchronize(h->stream));
+  if (h->stream3) HIPCK(hipStreamSynchronize(h->stream3));   // ELBO kernels still reading niw / theta
+  h->vlb_pending = false;
+  if (mu) from_centred(h, mu, (int)K, (int)D);
   CK(check_emission_status(h));
   return 0;
 }
@@ -2491,8 +2699,19 @@ int svihmm_generate(svihmm_ctx* h, int64_t T, int32_t K, int32_t D, const double
                        (unsigned long long)seed, T, D, (double*)h->obs.p);
     HIPCK(hipGetLastError());
   }
-  HIPCK(hipStreamSynchronize(h->stream));
   h->T = T; h->D = D; h->gen_T = T;
+  h->svi_active = false;
+  h->center_pending = false;
+  {   // centre: the plain average of the state means (a point inside the data)
+    std::vector<double> c((size_t)D, 0.0);
+    if (h->variant[9] != 1) {
+      for (int k = 0; k < K; ++k)
+        for (int d = 0; d < D; ++d) c[d] += means[(size_t)k * D + d] / K;
+      for (int d = 0; d < D; ++d) if (!(c[d] > -1.7e308 && c[d] < 1.7e308)) c[d] = 0.0;
+    }
+    CK(reset_shift(h, c, 0, T));
+  }
+  HIPCK(hipStreamSynchronize(h->stream));
   return 0;
 }
 int svihmm_read_generated(svihmm_ctx* h, int32_t* sts_out, double* obs_out) {
@@ -2502,6 +2721,11 @@ int svihmm_read_generated(svihmm_ctx* h, int32_t* sts_out, double* obs_out) {
   if (sts_out) CK(d2h(h, sts_out, h->gen_z.p, (size_t)h->T * sizeof(int32_t)));
   if (obs_out) CK(d2h(h, obs_out, h->obs.p, (size_t)h->T * h->D * sizeof(double)));
   HIPCK(hipStreamSynchronize(h->stream));
+  if (obs_out && h->shifted) {          // the resident copy is centred: hand out caller coordinates
+    const size_t D = (size_t)h->D;
+    for (int64_t t = 0; t < h->T; ++t)
+      for (size_t d = 0; d < D; ++d) obs_out[(size_t)t * D + d] += h->shift[d];
+  }
   return 0;
 }
 
@@ -2548,8 +2772,7 @@ int svihmm_allreduce_packed(svihmm_ctx* h) {
   if (!h->comm) return fail("svihmm_allreduce_packed: communicator not initialised");
   CK(set_device(h));
   ProfScope ps(h, KS_ALLREDUCE);
-  const size_t n = (size_t)packed_len(h);
-  NCCLCK(ncclAllReduce(h->packed.p, h->packed.p, n, ncclDouble, ncclSum, h->comm, h->stream));
+  CK(allreduce_packed_dev(h));
   h->mirror_valid = false;
   return launch_mirror(h);   // the host-visible copy follows the reduced statistics
 }

@@ -124,6 +124,7 @@ class HipEngine(object):
                 raise RuntimeError("mask must have shape (T,)")
         L.check(self._lib.svihmm_set_obs(self._h, L.dptr(obs), T, D, L.u8ptr(m)), "svihmm_set_obs")
         self.T, self.D = T, D
+        self._obs_owner = None        # whoever uploaded claims the resident copy afterwards
 
     def generate(self, tran, means, chols, T, seed=0):
         """Generate a synthetic sequence directly in HBM (reference ``gen_synthetic.generate_data``
@@ -140,6 +141,7 @@ class HipEngine(object):
         L.check(self._lib.svihmm_generate(self._h, int(T), K, D, L.dptr(cdf), L.dptr(means), L.dptr(chols),
                                           int(seed) & 0xFFFFFFFFFFFFFFFF), "svihmm_generate")
         self.T, self.D = int(T), D
+        self._obs_owner = None
 
     def read_generated(self, want_obs=True, want_sts=True):
         sts = np.empty(self.T, dtype=np.int32) if want_sts else None
@@ -150,12 +152,19 @@ class HipEngine(object):
         return obs, sts
 
     def shift_obs(self, shift):
-        """obs[t, :] -= shift on the resident copy (the classes centre it on the data mean)."""
+        """Move the centre the handle keeps the resident observations at by ``shift`` (a
+        conditioning hint; results of every call stay in the caller's coordinates)."""
         self._pre_mutate()
         c = np.ascontiguousarray(shift, dtype=np.float64)
         if c.shape != (self.D,):
             raise RuntimeError("shift must have shape (D,)")
         L.check(self._lib.svihmm_shift_obs(self._h, L.dptr(c)), "svihmm_shift_obs")
+
+    def get_shift(self):
+        """The centre ``c`` of the resident copy (``obs_dev = obs - c``)."""
+        c = np.empty(self.D)
+        L.check(self._lib.svihmm_get_shift(self._h, L.dptr(c)), "svihmm_get_shift")
+        return c
 
     def set_obs_blocks(self, blocks, T, D, mask=None):
         """Upload a sequence that arrives in row blocks (``gen_synthetic.read_data_mmap``,
@@ -170,6 +179,7 @@ class HipEngine(object):
                 raise RuntimeError("mask must have shape (T,)")
         L.check(self._lib.svihmm_alloc_obs(self._h, T, D, int(m is not None)), "svihmm_alloc_obs")
         self.T, self.D = T, D
+        self._obs_owner = None
         row = 0
         for blk in blocks:
             blk = np.ascontiguousarray(np.asarray(blk, dtype=np.float64).reshape(-1, D))

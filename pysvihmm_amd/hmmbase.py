@@ -146,6 +146,7 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
         d.pop('_pending_rows', None)
         d.pop('_prior_stack', None)
         d.pop('_host_lliks', None)
+        d.pop('_obs_print', None)
         d['_engine'] = None       # device handles are not picklable
         d['_obs_dirty'] = True
         return d
@@ -164,52 +165,36 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
     def _upload_obs(self, force=False):
         """obs/mask -> HBM (once; again after set_data / in-place edits flagged by
         ``_obs_dirty``, or when another model has used the same engine since: the resident copy
-        belongs to whoever uploaded last)."""
+        belongs to whoever uploaded last -- the engines clear ``_obs_owner`` on every upload).
+        Coordinates are the engine's business: the resident copy is kept centred inside the
+        handle, means and statistics cross the C ABI in the coordinates of ``self.obs``
+        (include/svihmm.h, svihmm_set_obs)."""
         eng = self.engine
         if force or self._obs_dirty or getattr(eng, "_obs_owner", None) != id(self):
-            c = self._center_of(self.obs) if hasattr(eng, "shift_obs") else None
-            self._center = c
             eng.set_obs(self.obs, self.mask)
-            if c is not None:
-                eng.shift_obs(c)
             eng._obs_owner = id(self)
             self._obs_dirty = False
+            self._obs_print = self._obs_fingerprint()
 
-    # The device evaluates the NIW quadratic form expanded around the origin (one GEMM over the
-    # augmented features), the reference centred on each factor's mean: for data far from the
-    # origin relative to their spread the expanded form cancels (error ~ 5e-16 mu'W mu; the engine
-    # refuses factors beyond 1e9).  The model is shift-equivariant, so the resident copy of the
-    # observations is kept centred on the data mean: means go to the device minus the centre,
-    # first / second moments come back shifted and are put back here.  self.obs stays as given.
-    def _center_of(self, obs):
-        if obs.ndim != 2 or not self._niw_fastpath():
-            return None
-        head = obs[:50000]
-        ok = ~np.isnan(head).any(axis=1)
-        if not ok.any():
-            return None
-        c = head[ok].mean(axis=0)
-        return c if np.all(np.isfinite(c)) else None
+    def _obs_fingerprint(self):
+        """Identity + content probe of ``self.obs`` / ``self.mask``: buffer address, shape,
+        strides and the bytes of a strided sample (every 509th element, the first and last 4096)
+        and of the whole mask.  ``infer()`` of the SVI class uploads again only when this changed
+        (or ``_obs_dirty`` was set: ``set_data`` / ``set_mask``); an in-place edit that misses
+        every probed element must be flagged with ``set_data(self.obs, self.mask)``."""
+        import zlib
+        o = np.asarray(self.obs)
+        flat = o.reshape(-1) if o.flags.c_contiguous else None
+        if flat is None:
+            return None                   # (unusual layout: no probe, always upload)
+        sample = np.concatenate((flat[:4096], flat[::509], flat[-4096:]))
+        m = np.ascontiguousarray(self.mask)
+        return (o.__array_interface__["data"][0], o.shape, o.strides, hash(sample.tobytes()),
+                m.shape, zlib.crc32(m.view(np.uint8)))
 
-    def _to_device_means(self, mu):
-        c = self.__dict__.get("_center")
-        return mu if c is None else mu - c
-
-    def _from_device_means(self, mu):
-        c = self.__dict__.get("_center")
-        return mu if c is None else mu + c
-
-    def _unshift_stats(self, st):
-        """Packed statistics of the centred observations -> statistics of self.obs (in place):
-        xbar = xbar' + n c,  S = S' + c xbar'^T + xbar' c^T + n c c^T."""
-        c = self.__dict__.get("_center")
-        if c is None or not hasattr(st, "xbar"):
-            return st
-        n = st.neff
-        cx = np.einsum('a,kb->kab', c, st.xbar)
-        st.S[:] += cx + cx.transpose(0, 2, 1) + n[:, None, None] * np.outer(c, c)[None]
-        st.xbar[:] += n[:, None] * c[None, :]
-        return st
+    def _obs_unchanged(self):
+        fp = self.__dict__.get("_obs_print")
+        return fp is not None and fp == self._obs_fingerprint()
 
     def _psi_expectations(self):
         """reference hmmbase.py:214-216."""
@@ -290,7 +275,7 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
         upload ``lliks``.  Returns the flag word for the engine calls."""
         if self._niw_fastpath():
             mu, sg, ka, nu = self._emission_arrays()
-            self.engine.set_emission_niw(self._to_device_means(mu), sg, ka, nu)
+            self.engine.set_emission_niw(mu, sg, ka, nu)
             return L.MASK_AS_NAN if nan_mask else 0
         if self._cat_fastpath():
             # Categorical: E log theta table (pybasicbayes Categorical.expected_log_likelihood),
@@ -402,7 +387,7 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
         self._upload_obs()
         self._push_globals()
         flags = self._push_emission()
-        st = self._unshift_stats(self.engine.estep([0], self.T, flags=flags))  # no TRANS_WRAP: t=1..T-1
+        st = self.engine.estep([0], self.T, flags=flags)  # no TRANS_WRAP: t=1..T-1
         self._lZ = float(st.lb[0])
         self._q0 = self.engine.read_rows("var_x", 0, 1)[0]
         return st

@@ -272,7 +272,10 @@ class VBHMM(VariationalHMMBase):
         if (L_ is None or adaptive) and growBuffer:
             raise RuntimeError("Cannot specify both adaptive and buffer simultaneously!")
 
-        self._obs_dirty = True
+        # (the reference reads self.obs afresh in every call; the resident copy is uploaded again
+        #  unless the probe of hmmbase._obs_fingerprint finds it unchanged -- 256 MB at T = 1e6)
+        if not self._obs_unchanged():
+            self._obs_dirty = True
         self._upload_obs()
 
         if fused and device_loop is not False and self._svi_device_ok():
@@ -374,14 +377,15 @@ class VBHMM(VariationalHMMBase):
             return False
         # transition pseudo-counts this small need the log-domain recursion, which the engine
         # selects per globals upload (include/svihmm.h: SVIHMM_SVI_MIN_PSEUDOCOUNT)
-        if min(np.min(self.prior_tran), np.min(self.var_tran)) < L.SVI_MIN_PSEUDOCOUNT:
+        # (and the loop's range argument needs prior_tran >= 1: quirk Q2 scales prior_tran - 1 by
+        #  ~T / 2L, which drives var_tran towards zero or below for sparser priors)
+        if np.min(self.var_tran) < L.SVI_MIN_PSEUDOCOUNT or np.min(self.prior_tran) < 1.0:
             return False
         return True
 
     def _svi_pull_state(self):
         """Device state -> the object's attributes (reference attribute names)."""
         vt, vi, mu, sg, ka, nu = self.engine.svi_read_state()
-        mu = self._from_device_means(mu)
         self.var_tran, self.var_init = vt, vi
         D = self.D
         for k, G in enumerate(self.var_emit):
@@ -406,9 +410,7 @@ class VBHMM(VariationalHMMBase):
         miniL = bufferL = L_
         prior = self._prior_arrays()
         fac = self._emission_arrays()
-        # (the resident observations are centred: means travel minus the centre, hmmbase._center_of)
-        eng.svi_begin(self.prior_tran, self.var_tran, (self._to_device_means(prior[0]),) + tuple(prior[1:]),
-                      (self._to_device_means(fac[0]),) + tuple(fac[1:]),
+        eng.svi_begin(self.prior_tran, self.var_tran, prior, fac,
                       niw_prior_logpart(prior[1], prior[3]), maxit, vlb_logz_sign())
         self.__dict__.pop("_pending_rows", None)
         if hasattr(eng, "on_next_mutation"):
@@ -539,7 +541,6 @@ class VBHMM(VariationalHMMBase):
         st = self.engine.estep(starts, Lm, flags=flags, read=(comm is None), inner=inner)
         if comm is not None:
             st = comm.allreduce_stats(self.engine, K, D)
-        st = self._unshift_stats(st)
         # quirk Q2: prior_tran - 1 is part of every window's A_i
         A_inter = st.A_raw + nwin * (self.prior_tran - 1.)
         if hasattr(st, "counts"):

@@ -63,5 +63,7 @@ def test_generated_process_statistics_and_estep():
     a = e.estep(starts, 257).buf.copy()
     e.set_obs(obs, None)
     b = e.estep(starts, 257).buf
-    assert np.array_equal(a, b)
+    # (not bit-equal: the handle keeps either copy centred on a point of its own choosing --
+    #  average state mean for the generator, sample mean for an upload)
+    np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-8)
     e.close()

@@ -230,35 +230,12 @@ def test_svi_loop_with_tiny_dirichlet_prior():
     e.close()
 
 
-def test_engine_refuses_factors_far_from_the_origin():
-    """C-ABI level: data of size 1e7 with unit spread would lose ~0.2 in the log-likelihoods to
-    the cancellation of the expanded quadratic form -- the engine says so instead of computing;
-    1e3 (error 3e-9) passes."""
-    from pysvihmm_amd.engine import HipEngine
-    from pysvihmm_amd import _lib as L
-    K, D, T = 5, 3, 500
-    pb = make_problem(K, D, T, seed=8, sep=3.0)
-    e = HipEngine(0)
-    try:
-        for off, ok in ((1e3, True), (1e7, False)):
-            e.set_obs(pb["obs"] + off, None)
-            e.set_globals(pb["mod_init"], pb["ltran"])
-            if ok:
-                e.set_emission_niw(pb["mu"] + off, pb["sigma"], pb["kappa"], pb["nu"])
-                assert np.all(np.isfinite(e.estep(np.array([0, 100]), 33).buf))
-            else:
-                with pytest.raises(RuntimeError, match="origin"):
-                    e.set_emission_niw(pb["mu"] + off, pb["sigma"], pb["kappa"], pb["nu"])
-                    e.estep(np.array([0, 100]), 33)
-    finally:
-        e.close()
-
-
 @pytest.mark.parametrize("kind", ["metaobs_device_loop", "metaobs_host_loop", "batchcd"])
 def test_classes_on_data_far_from_the_origin(kind):
-    """The classes keep the resident observations centred (hmmbase._center_of): a sequence offset
-    by 1e5 (|x| / sigma ~ 1e5: the expanded form alone is off by 2e-5 in the log-likelihoods and
-    the engine would refuse the factors) gives what the same model gives on the un-shifted
+    """The handle keeps the resident observations centred (include/svihmm.h, svihmm_set_obs; the
+    C-ABI level tests are tests/test_gpu_coords.py): a sequence offset by 1e5 (|x| / sigma ~ 1e5:
+    the form expanded around the origin would be off by 2e-5 in the log-likelihoods) gives what
+    the same model gives on the un-shifted
     sequence (the model is shift-equivariant).  Tolerances: with the variational state on the
     device the whole loop runs in centred coordinates (1e-6); the host-side global steps are the
     reference's own arithmetic on raw second moments, which cancel 1e10 : 10 at this offset

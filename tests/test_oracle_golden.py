@@ -116,3 +116,56 @@ def test_ffbs_forward():
     np.testing.assert_allclose(la, g["lalpha"], rtol=1e-10, atol=1e-9)
     z = g["z"]
     assert z.shape == (int(g["T"]),) and z.min() >= 0 and z.max() < int(g["K"])
+
+
+# ---- the C port (oracle/ref_c.c) pinned DIRECTLY to the reference-executed fixtures --------------
+# Every full-size GPU parity test leans on ref_c; until round 3 it was pinned only through the
+# OracleEngine class traces.  CPU only (liboracle.so is built by oracle/Makefile).
+@pytest.mark.parametrize("path", META, ids=[os.path.basename(p)[:-4] for p in META])
+def test_c_port_window_trace(path):
+    from oracle import ref_c
+    g = np.load(path)
+    obs, mask, prior_tran = g["obs"], g["mask"], g["prior_tran"]
+    K, D = int(g["K"]), obs.shape[1]
+    for w in range(g["w_i1"].shape[0]):
+        i1, i2 = int(g["w_i1"][w]), int(g["w_i2"][w])
+        Lm = i2 - i1 + 1
+        mi, mt = g["w_mod_init"][w], g["w_mod_tran"][w]
+        par = (g["w_mu"][w], g["w_sigma"][w], g["w_kappa"][w], g["w_nu"][w])
+        # a3 (same formula as the emission class; the fixture's lliks come from that class
+        #     executed inside the reference's loop)
+        ll = ref_c.lliks_niw(obs[i1:i2 + 1], *par)
+        np.testing.assert_allclose(ll, g["w_lliks"][w], rtol=1e-10, atol=1e-9)
+        # a4..a6 from the RECORDED lliks: the reference's own arithmetic, bit for bit on the folds
+        la = ref_c.forward(g["w_lliks"][w], mi, mt)
+        lb = ref_c.backward(g["w_lliks"][w], mt)
+        np.testing.assert_allclose(la, g["w_lalpha"][w], rtol=1e-13, atol=1e-12)
+        np.testing.assert_allclose(lb, g["w_lbeta"][w], rtol=1e-13, atol=1e-12)
+        q, lbv = ref_c.posterior(la, lb)
+        np.testing.assert_allclose(q, g["w_var_x"][w], rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(lbv, g["w_local_lb"][w], rtol=1e-13)
+        # a7..a9: the fused minibatch entry point on this one window (quirks Q1, Q4, Q9)
+        buf = ref_c.estep_minibatch(obs, mask, np.array([i1]), Lm, mi, mt, *par, flags=2)
+        o = 0
+        A = buf[o:o + K * K].reshape(K, K); o += K * K
+        xbar = buf[o:o + K * D].reshape(K, D); o += K * D
+        neff = buf[o:o + K]; o += K
+        S = buf[o:o + K * D * D].reshape(K, D, D); o += K * D * D
+        np.testing.assert_allclose(A + prior_tran - 1.0, g["w_A_i"][w], rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(xbar, g["w_xbar"][w], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(neff, g["w_neff"][w], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(S, g["w_Sk"][w], rtol=1e-9, atol=1e-8)
+        np.testing.assert_allclose(buf[o], g["w_local_lb"][w], rtol=1e-10)
+
+
+@pytest.mark.parametrize("name", ["batchcd_K4_D2_T300", "batchsgd_K4_D3_T250"])
+def test_c_port_batch_trace(name):
+    from oracle import ref_c
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    for it in range(g["it_lliks"].shape[0]):
+        ll = g["it_lliks"][it]
+        la = ref_c.forward(ll, g["it_mod_init"][it], g["it_mod_tran"][it])
+        lb = ref_c.backward(ll, g["it_mod_tran"][it])
+        np.testing.assert_allclose(la, g["it_lalpha"][it], rtol=1e-13, atol=1e-12)
+        np.testing.assert_allclose(lb, g["it_lbeta"][it], rtol=1e-13, atol=1e-12)
+        np.testing.assert_allclose(ref_c.posterior(la, lb)[0], g["it_var_x"][it], rtol=1e-12, atol=1e-15)
