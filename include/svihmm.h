@@ -158,6 +158,24 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
                             const double* sigma, const double* kappa,
                             const double* nu);
 
+/* Diagonal-covariance Gaussian factors (pybasicbayes DiagonalGaussian; BASELINE configs[0]; the
+ * plugin objects the reference evaluates at hmmbase.py:219-220 and updates with
+ * meanfieldupdate at hmmbatchcd.py:189): per state and dimension a normal-inverse-gamma mean-field
+ * factor  sigma_d^2 ~ InvGamma(alphas, betas),  mu_d | sigma_d^2 ~ N(mu, sigma_d^2 / nus);  all four
+ * arrays [K,D].  E_q log N(x | mu, diag sigma^2) is linear in the 2 D + 1 features (x_d^2, x_d, 1):
+ * the emission and statistics GEMMs run on that feature table instead of the (D+1)(D+2)/2
+ * products a full covariance needs (D = 32: 80 instead of 576 feature rows).  Afterwards the
+ * packed statistics have the layout
+ *     [ A_raw K*K | xbar K*D | neff K | xsq K*D | lb ]      (svihmm_packed_len)
+ * with xsq[k,d] = sum over unmasked rows of q[t,k] x[t,d]^2 -- what the conjugate update needs
+ * (nus += n, mu = (nus0 mu0 + xbar)/nus, alphas += n/2, betas += (xsq + nus0 mu0^2 - nus mu^2)/2).
+ * Same asynchronous status word as svihmm_set_emission_niw (a non-positive nus / alphas / betas
+ * entry, or a factor > 3e4 standard deviations from the data).  The device-resident SVI loop
+ * (svihmm_svi_*) is NIW only; this family runs through svihmm_estep_minibatch*. */
+#define SVIHMM_DIAG_MAX_D 128
+int svihmm_set_emission_diag(svihmm_ctx* h, int32_t K, int32_t D, const double* mu,
+                             const double* nus, const double* alphas, const double* betas);
+
 /* Generic plugin route: lliks[B,Lm,K] evaluated by an arbitrary emission object on
  * the host (any object with expected_log_likelihood), already nan_to_num'ed. */
 int svihmm_set_lliks(svihmm_ctx* h, const double* lliks, int32_t B, int32_t Lm);

@@ -25,6 +25,17 @@ class _Packed(object):
         self.lb = buf[o:o + 1]
 
 
+class _PackedDiag(object):
+    def __init__(self, buf, K, D):
+        self.buf, self.K, self.D = buf, K, D
+        o = 0
+        self.A_raw = buf[o:o + K * K].reshape(K, K); o += K * K
+        self.xbar = buf[o:o + K * D].reshape(K, D); o += K * D
+        self.neff = buf[o:o + K]; o += K
+        self.xsq = buf[o:o + K * D].reshape(K, D); o += K * D
+        self.lb = buf[o:o + 1]
+
+
 class _PackedCat(object):
     def __init__(self, buf, K, V):
         self.buf, self.K, self.V = buf, K, V
@@ -97,12 +108,22 @@ class OracleEngine(object):
     def set_emission_niw(self, mu, sigma, kappa, nu, check=True):
         self._pre_mutate()
         self.V = 0
+        self.diag = False
         self.em = tuple(np.array(a, dtype=np.float64) for a in (mu, sigma, kappa, nu))
         for k in range(len(self.em[2])):
             np.linalg.cholesky(self.em[1][k])
 
+    def set_emission_diag(self, mu, nus, alphas, betas, check=True):
+        self._pre_mutate()
+        self.V = 0
+        self.diag = True
+        self.emd = tuple(np.array(a, dtype=np.float64) for a in (mu, nus, alphas, betas))
+        if not all(np.all(a > 0) for a in self.emd[1:]):
+            raise RuntimeError("set_emission_diag: nus / alphas / betas must be positive")
+
     def set_emission_cat(self, logp):
         self._pre_mutate()
+        self.diag = False
         self.cat = np.array(logp, dtype=np.float64)
         self.V = self.cat.shape[1]
 
@@ -122,6 +143,8 @@ class OracleEngine(object):
             ll = np.zeros((len(xv), self.K))
             ll[ok] = self.cat[:, xv[ok].astype(int)].T
             return ll
+        if getattr(self, "diag", False):
+            return R.lliks_diag(x, *self.emd)
         f = ref_c.lliks_niw if self.use_c else R.lliks_niw
         return f(x, *self.em)
 
@@ -166,6 +189,8 @@ class OracleEngine(object):
         K, D = self.K, self.D
         if getattr(self, "V", 0):
             return self._estep_cat(st, Lm, flags, read, inner)
+        if getattr(self, "diag", False):
+            return self._estep_diag(st, Lm, flags, read, inner)
         buf = np.zeros(K * K + K * D + K + K * D * D + 1)
         P = _Packed(buf, K, D)
         if B == 0:
@@ -238,6 +263,26 @@ class OracleEngine(object):
                     ok &= ~self.mask[s:s + ln]
                 for v in range(V):
                     P.counts[:, v] += q[b][ok & (x == v)].sum(0)
+            P.lb[0] = self._last["local_lb"].sum()
+        self._packed = P
+        return P if read else None
+
+    def _estep_diag(self, st, Lm, flags, read, inner):
+        K, D, B = self.K, self.D, len(st)
+        P = _PackedDiag(np.zeros(K * K + 2 * K * D + K + 1), K, D)
+        if B:
+            self.forward_backward(st, Lm, flags)
+            off, ln = (0, Lm) if inner is None else inner
+            q = self._last["var_x"][:, off:off + ln]
+            for b in range(B):
+                s = int(st[b]) + off
+                P.A_raw[:] += (R.transition_stat_wrap(q[b]) if flags & TRANS_WRAP
+                               else R.transition_stat_batch(q[b]))
+                inds = (np.ones(ln, bool) if self.mask is None else np.logical_not(self.mask[s:s + ln]))
+                x = self.obs[s:s + ln][inds]
+                for k in range(K):
+                    sx, n, sxx = R.diag_suffstats(x, q[b][inds, k])
+                    P.xbar[k] += sx; P.neff[k] += n; P.xsq[k] += sxx
             P.lb[0] = self._last["local_lb"].sum()
         self._packed = P
         return P if read else None

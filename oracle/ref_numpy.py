@@ -73,6 +73,28 @@ def lliks_niw(obs_rows, mu, sigma, kappa, nu):
     return out
 
 
+def lliks_diag(obs_rows, mu, nus, alphas, betas):
+    """lliks[:,k] = nan_to_num(E_q log N(x | mu_k, diag sigma_k^2)) for diagonal Gaussian factors
+    (per dimension a normal-inverse-gamma mean-field factor; pybasicbayes DiagonalGaussian, evaluated
+    where the reference evaluates any emitter: hmmbase.py:219-220).  Centred form:
+        sum_d [ -1/2 (alpha/beta) (x - m)^2 - 1/(2 nu) - 1/2 (log beta - psi(alpha)) ] - D/2 log 2 pi."""
+    from scipy.special import digamma
+    K, D = mu.shape
+    out = np.empty((obs_rows.shape[0], K))
+    for k in range(K):
+        d = obs_rows - mu[k]
+        v = ((-0.5 * (alphas[k] / betas[k]) * d ** 2).sum(1)
+             + (-0.5 / nus[k] - 0.5 * (np.log(betas[k]) - digamma(alphas[k]))).sum() - 0.5 * D * np.log(2. * np.pi))
+        out[:, k] = np.nan_to_num(v)
+    return out
+
+
+def diag_suffstats(obs_rows, w):
+    """(sum_t w x, sum_t w, sum_t w x^2): the diagonal family's expected sufficient statistics (the
+    diagonal of util.NIW_suffstats' second moment, util.py:73-83)."""
+    return w.dot(obs_rows), w.sum(), w.dot(obs_rows ** 2)
+
+
 # --- a4 / a5: messages ------------------------------------------------------ #
 def forward_msgs(ll, mod_init, ltran):
     """reference hmmbase.py:292-295 == hmmsgd_metaobs.py:800-803."""

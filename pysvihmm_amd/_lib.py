@@ -21,6 +21,7 @@ SVI_KEEP_WINDOW = 16
 SVI_MIN_PSEUDOCOUNT = 2.5e-3      # include/svihmm.h: smaller Dirichlet pseudo-counts take the per-call route
 LTRAN_LINEAR_MIN = -600.0
 NIW_MAX_D = 79                    # wider observations: host-evaluated lliks (generic plugin route)
+DIAG_MAX_D = 128                  # diagonal family on the device up to this width
 LTRAN_F32_MIN = -60.0
 F64, F32 = 0, 1
 
@@ -44,6 +45,8 @@ SIGNATURES = {
     "svihmm_set_globals": (C.c_int, [C.c_void_p, C.c_int32, _c_double_p, _c_double_p]),
     "svihmm_set_emission_niw": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _c_double_p,
                                           _c_double_p, _c_double_p, _c_double_p]),
+    "svihmm_set_emission_diag": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _c_double_p,
+                                           _c_double_p, _c_double_p, _c_double_p]),
     "svihmm_set_lliks": (C.c_int, [C.c_void_p, _c_double_p, C.c_int32, C.c_int32]),
     "svihmm_loglik": (C.c_int, [C.c_void_p, _c_int64_p, C.c_int32, C.c_int32, C.c_uint32,
                                 _c_double_p]),

@@ -481,6 +481,45 @@ __device__ __forceinline__ double digamma_d(double x) {
 __device__ __forceinline__ int feat_index_d(int a, int b, int D) {
   return a * (D + 1) - a * (a - 1) / 2 + (b - a);
 }
+// ------------------------------------------------------------------------------------
+//  K0d: diagonal-covariance Gaussian factors (pybasicbayes DiagonalGaussian: per dimension a
+//       normal-inverse-gamma mean-field factor  sigma_d^2 ~ InvGamma(alpha_d, beta_d),
+//       mu_d | sigma_d^2 ~ N(m_d, sigma_d^2 / nu_d))  ->  theta in the DIAGONAL feature order
+//       (upload_feature_table: f < D: x_f^2, D <= f < 2D: x_{f-D}, f = 2D: 1):
+//         E_q log N(x | mu, diag sigma^2) = sum_d [ -1/2 (alpha_d/beta_d) x_d^2 + m_d (alpha_d/beta_d) x_d
+//            - 1/2 (1/nu_d + m_d^2 alpha_d/beta_d) - 1/2 (log beta_d - psi(alpha_d)) ] - D/2 log 2 pi.
+//       2 D + 1 features instead of (D+1)(D+2)/2: the same table-driven GEMM kernels (emission,
+//       statistics) run it, at D = 32 on 80 instead of 576 feature rows.
+//       One wavefront per state; status as k_niw_to_theta (1 + k: a non-positive parameter;
+//       NIW_STATUS_RANGE + 1 + k: the factor lies too far from the data's centre).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_diag_to_theta(
+    const double* __restrict__ mu, const double* __restrict__ nus, const double* __restrict__ alphas,
+    const double* __restrict__ betas, int K, int D, int Kp, double* __restrict__ theta,
+    int* __restrict__ status) {
+  const int k = blockIdx.x, lane = threadIdx.x;
+  double cs = 0.0, mwm = 0.0;
+  bool bad = false;
+  for (int d = lane; d < D; d += 64) {
+    const size_t e = (size_t)k * D + d;
+    const double m = mu[e], nu = nus[e], a = alphas[e], b = betas[e];
+    if (!(nu > 0.0) || !(a > 0.0) || !(b > 0.0) || !(m == m)) bad = true;
+    const double prec = a / b;
+    theta[(size_t)d * Kp + k] = -0.5 * prec;
+    theta[(size_t)(D + d) * Kp + k] = m * prec;
+    cs += -0.5 * (1.0 / nu + m * m * prec) - 0.5 * (log(b) - digamma_d(a));
+    mwm += 0.5 * m * m * prec;
+  }
+  cs = wave_sum(cs);
+  mwm = wave_sum(mwm);
+  const bool anybad = __any(bad);
+  if (lane == 0) {
+    theta[(size_t)(2 * D) * Kp + k] = cs - 0.5 * D * 1.8378770664093453;   // log(2 pi)
+    if (anybad) atomicMax(status, 1 + k);
+    else if (mwm > NIW_CANCEL_LIMIT) atomicMax(status, NIW_STATUS_RANGE + 1 + k);
+  }
+}
+
 // generic D (workgroup per state, matrices in LDS): used for D > 64 only
 __global__ __launch_bounds__(256) void k_niw_to_theta_generic(
     const double* __restrict__ mu, const double* __restrict__ sigma,

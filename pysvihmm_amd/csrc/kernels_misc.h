@@ -376,9 +376,10 @@ __global__ __launch_bounds__(256) void k_shift_means(double* __restrict__ mu, in
 //   xbar_k += n_k cs,   S_k += cs xbar_k' + xbar_k cs' + n_k cs cs'      (xbar_k of the SOURCE).
 // Out of place; dst may be the host-visible mirror (then this is k_mirror with the handle's shift
 // undone: the C ABI hands out statistics in the caller's coordinates).
+// diag: layout [A_raw | xbar | neff | xsq K*D | lb]:  xsq_ka += 2 cs_a xbar_ka + n_k cs_a^2.
 __global__ __launch_bounds__(256) void k_packed_shift(const double* __restrict__ src, double* __restrict__ dst,
                                                       int n, int K, int D, const double* __restrict__ c,
-                                                      double sgn) {
+                                                      double sgn, int diag) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int oX = K * K, oN = oX + K * D, oS = oN + K;
@@ -386,7 +387,11 @@ __global__ __launch_bounds__(256) void k_packed_shift(const double* __restrict__
   if (i >= oX && i < oN) {
     const int k = (i - oX) / D, a = (i - oX) - k * D;
     v += src[oN + k] * (sgn * c[a]);
-  } else if (i >= oS && i < oS + K * D * D) {
+  } else if (diag && i >= oS && i < oS + K * D) {
+    const int k = (i - oS) / D, a = (i - oS) - k * D;
+    const double ca = sgn * c[a];
+    v += 2.0 * ca * src[oX + k * D + a] + src[oN + k] * ca * ca;
+  } else if (!diag && i >= oS && i < oS + K * D * D) {
     const int e = i - oS;
     const int k = e / (D * D), r = e - k * D * D, a = r / D, b = r - a * D;
     const double ca = sgn * c[a], cb = sgn * c[b];

@@ -547,9 +547,12 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
 // ------------------------------------------------------------------------------------
 // With `local_lb` the launch carries one extra workgroup that adds up the B per-window ELBO
 // terms into the last packed slot (fixed order; saves a kernel on the E-step's critical path).
+// diag: the diagonal family's layout [A_raw | xbar K*D | neff K | xsq K*D | lb] (features x_a^2 go
+// to xsq[k][a]); otherwise the NIW layout with the full K x D x D second moments.
 __global__ void k_finalize(const double* __restrict__ part, int nchunk, int D, int K,
                            int Kp, int Fp, int F, const int* __restrict__ fab,
-                           double* __restrict__ packed, const double* __restrict__ local_lb, int B) {
+                           double* __restrict__ packed, const double* __restrict__ local_lb, int B,
+                           int diag) {
   const int Ftot = Fp + Kp;
   if (local_lb && blockIdx.x == gridDim.x - 1) {
     __shared__ double red[256];
@@ -561,7 +564,7 @@ __global__ void k_finalize(const double* __restrict__ part, int nchunk, int D, i
       if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
       __syncthreads();
     }
-    if (threadIdx.x == 0) packed[(size_t)K * K + (size_t)K * D + K + (size_t)K * D * D] = red[0];
+    if (threadIdx.x == 0) packed[(size_t)K * K + (size_t)K * D + K + (size_t)K * D * (diag ? 1 : D)] = red[0];
     return;
   }
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -589,8 +592,11 @@ __global__ void k_finalize(const double* __restrict__ part, int nchunk, int D, i
     const int ab = fab[f];
     const int a = ab & 0xffff, b = ab >> 16;
     if (b < D) {  // a <= b < D
-      S[((size_t)k * D + a) * D + b] = s;
-      S[((size_t)k * D + b) * D + a] = s;
+      if (diag) S[(size_t)k * D + a] = s;
+      else {
+        S[((size_t)k * D + a) * D + b] = s;
+        S[((size_t)k * D + b) * D + a] = s;
+      }
     } else if (a < D) {
       xbar[(size_t)k * D + a] = s;
     } else {

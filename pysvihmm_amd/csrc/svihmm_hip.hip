@@ -122,6 +122,8 @@ struct svihmm_ctx {
   int lb_pending = 0;       // windows whose local_lb sum has not been written to packed yet
   bool orb_valid = false;   // theta_orb matches theta (k_theta_orbit ran since the last parameter upload)
   bool emis_cat = false; int V = 0;          // Categorical emission: table [V][K] = E log theta
+  bool emis_diag = false;                    // diagonal Gaussian family: 2 D + 1 features, h->niw = [mu | nus | alphas | betas]
+  bool tab_diag = false;                     // feature table currently on the device is the diagonal one
   void* theta_zero_p = nullptr; size_t theta_zero_n = 0;   // what the last theta memset covered
   int tabD = -1;
   // pinned host staging: a ring of slots, each guarded by an event recorded after the copy
@@ -206,6 +208,7 @@ struct svihmm_ctx {
 static size_t packed_len(const svihmm_ctx* h) {
   if (h->emis_cat) return (size_t)h->K * h->K + (size_t)h->K * h->V + 1;
   const size_t D = h->D > 0 ? h->D : 1;
+  if (h->emis_diag) return (size_t)h->K * h->K + 2 * (size_t)h->K * D + h->K + 1;
   return (size_t)h->K * h->K + (size_t)h->K * D + h->K + (size_t)h->K * D * D + 1;
 }
 
@@ -308,6 +311,7 @@ static int pinned(svihmm_ctx* h, size_t bytes, void** out, int* slot_out);
 static int pull_small(svihmm_ctx* h, void* dst, const void* pin, size_t bytes);
 static int pin_release(svihmm_ctx* h, int slot);
 static int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out);
+static int launch_diag_to_theta(svihmm_ctx* h, int K, int D);
 static double* svi_ptr(svihmm_ctx* h, int which);
 static int wait_side_streams(svihmm_ctx* h);
 static void sample_center(const svihmm_ctx* h, const double* obs, int64_t T, int D, std::vector<double>& c);
@@ -443,7 +447,7 @@ int svihmm_shift_obs(svihmm_ctx* h, const double* shift) {
   for (int d = 0; d < D; ++d) c[d] += shift[d];
   CK(store_shift(h, c));
   // device-side parameters in centred coordinates follow: NIW means (+ theta), the SVI loop's prior
-  const bool niw_live = h->have_emission && !h->emis_cat && h->eD == D && h->niw.p;
+  const bool niw_live = h->have_emission && !h->emis_cat && h->eD == D && h->niw.p;   // (NIW or diagonal: means lead the block)
   if (niw_live || h->svi_active) {
     void* pin = nullptr;
     int slot = 0;
@@ -463,7 +467,8 @@ int svihmm_shift_obs(svihmm_ctx* h, const double* shift) {
     }
     HIPCK(hipGetLastError());
     CK(pin_release(h, slot));
-    if (niw_live) CK(launch_niw_to_theta(h, h->eK, D, h->svi_active ? svi_ptr(h, 4) : nullptr));
+    if (niw_live && h->emis_diag) CK(launch_diag_to_theta(h, h->eK, D));
+    else if (niw_live) CK(launch_niw_to_theta(h, h->eK, D, h->svi_active ? svi_ptr(h, 4) : nullptr));
   }
   return 0;
 }
@@ -622,16 +627,24 @@ static inline int feat_index(int a, int b, int D) {  // 0 <= a <= b <= D
   return a * (D + 1) - a * (a - 1) / 2 + (b - a);
 }
 
-static int upload_feature_table(svihmm_ctx* h, int D, int K) {
-  const int F = (D + 1) * (D + 2) / 2, Fp = (F + 15) / 16 * 16, Kp = (K + 15) / 16 * 16;
-  if (h->tabD == D && h->Fp == Fp) { h->F = F; h->Kp = Kp; return 0; }
+// Features are products x~_a x~_b of the augmented row x~ = (x, 1); the table lists the (a, b) the
+// emission family needs.  Full covariance: all a <= b, F = (D+1)(D+2)/2.  Diagonal family:
+// x_a^2 (f = a), x_a (f = D + a), 1 (f = 2 D): F = 2 D + 1.  Emission and statistics GEMMs read
+// the table, so the family only changes the table and the theta builder.
+static int upload_feature_table(svihmm_ctx* h, int D, int K, bool diag = false) {
+  const int F = diag ? 2 * D + 1 : (D + 1) * (D + 2) / 2, Fp = (F + 15) / 16 * 16, Kp = (K + 15) / 16 * 16;
+  if (h->tabD == D && h->Fp == Fp && h->tab_diag == diag) { h->F = F; h->Kp = Kp; return 0; }
   std::vector<int> fab(Fp, (D + 1) | ((D + 1) << 16));  // padding -> zero slot
+  if (diag) {
+    for (int a = 0; a < D; ++a) { fab[a] = a | (a << 16); fab[D + a] = a | (D << 16); }
+    fab[2 * D] = D | (D << 16);
+  } else
   for (int a = 0; a <= D; ++a)
     for (int b = a; b <= D; ++b) fab[feat_index(a, b, D)] = a | (b << 16);
   CK(ensure(h->fab, fab.size() * sizeof(int)));
   HIPCK(hipMemcpyAsync(h->fab.p, fab.data(), fab.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIPCK(hipStreamSynchronize(h->stream));
-  h->tabD = D; h->F = F; h->Fp = Fp; h->Kp = Kp;
+  h->tabD = D; h->F = F; h->Fp = Fp; h->Kp = Kp; h->tab_diag = diag;
   return 0;
 }
 
@@ -695,8 +708,37 @@ static int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out) 
   }
   // status comes back asynchronously; it is examined at the next synchronising call
   h->status_pending = true;
-  h->eK = K; h->eD = D; h->have_emission = true; h->emis_cat = false;
+  h->eK = K; h->eD = D; h->have_emission = true; h->emis_cat = false; h->emis_diag = false;
   h->orb_valid = orbp != nullptr;
+  return 0;
+}
+
+// Diagonal family: parameter block [mu | nus | alphas | betas] (each [K][D], means centred) in
+// h->niw -> theta in the diagonal feature order.  Same asynchronous status word as the NIW builder.
+static int launch_diag_to_theta(svihmm_ctx* h, int K, int D) {
+  CK(upload_feature_table(h, D, K, true));
+  const int Fp = h->Fp, Kp = h->Kp;
+  const size_t n = (size_t)K * D;
+  CK(ensure(h->theta, (size_t)Fp * Kp * sizeof(double)));
+  if (!h->pin_status) {
+    HIPCK(hipHostMalloc((void**)&h->pin_status, 64, hipHostMallocMapped));
+    *h->pin_status = 0;
+  }
+  int* dstatus = nullptr;
+  HIPCK(hipHostGetDevicePointer((void**)&dstatus, h->pin_status, 0));
+  // padded rows / columns zeroed on every family or shape change (the NIW builder keys on the same pair)
+  HIPCK(hipMemsetAsync(h->theta.p, 0, (size_t)Fp * Kp * sizeof(double), h->stream));
+  h->theta_zero_p = nullptr; h->theta_zero_n = 0;
+  const double* p = (const double*)h->niw.p;
+  {
+    ProfScope ps(h, KS_MISC);
+    hipLaunchKernelGGL(k_diag_to_theta, dim3(K), dim3(64), 0, h->stream, p, p + n, p + 2 * n, p + 3 * n, K, D, Kp,
+                       (double*)h->theta.p, dstatus);
+    HIPCK(hipGetLastError());
+  }
+  h->status_pending = true;
+  h->eK = K; h->eD = D; h->have_emission = true; h->emis_cat = false; h->emis_diag = true;
+  h->orb_valid = false;
   return 0;
 }
 
@@ -739,6 +781,33 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
   CK(pin_release(h, slot));
   CK(launch_niw_to_theta(h, K, D, nullptr));
   return 0;
+}
+
+int svihmm_set_emission_diag(svihmm_ctx* h, int32_t K, int32_t D, const double* mu, const double* nus,
+                             const double* alphas, const double* betas) {
+  if (!h || K <= 0 || D <= 0 || !mu || !nus || !alphas || !betas)
+    return fail("svihmm_set_emission_diag: bad arguments");
+  if (D > SVIHMM_DIAG_MAX_D)
+    return fail("svihmm_set_emission_diag: D > SVIHMM_DIAG_MAX_D: evaluate the expected log-likelihoods on the "
+                "host and pass them with svihmm_set_lliks / SVIHMM_USE_HOST_LLIKS");
+  CK(set_device(h));
+  h->lin_stale = true;
+  const size_t n = (size_t)K * D;
+  CK(ensure(h->niw, 4 * n * sizeof(double) + 64));
+  void* pin = nullptr;
+  int slot = 0;
+  CK(pinned(h, 4 * n * sizeof(double), &pin, &slot));
+  double* hp = (double*)pin;
+  std::memcpy(hp, mu, n * sizeof(double));
+  to_centred(h, hp, K, D);
+  std::memcpy(hp + n, nus, n * sizeof(double));
+  std::memcpy(hp + 2 * n, alphas, n * sizeof(double));
+  std::memcpy(hp + 3 * n, betas, n * sizeof(double));
+  if (h->vlb_pending) { HIPCK(hipStreamWaitEvent(h->stream, h->svi_ed, 0)); h->vlb_pending = false; }
+  h->svi_active = false;               // (the resident NIW state of an SVI loop lived in h->niw)
+  CK(pull_small(h, h->niw.p, hp, 4 * n * sizeof(double)));
+  CK(pin_release(h, slot));
+  return launch_diag_to_theta(h, K, D);
 }
 
 // ---- ELBO terms of the NIW factors from the device-resident parameters --------------------
@@ -852,13 +921,13 @@ int svihmm_set_emission_cat(svihmm_ctx* h, int32_t K, int32_t V, const double* l
     for (int v = 0; v < V; ++v) hp[(size_t)v * K + k] = logp[(size_t)k * V + v];
   HIPCK(hipMemcpyAsync(h->cat_table.p, hp, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
   CK(pin_release(h, slot));
-  h->eK = K; h->eD = 1; h->V = V; h->Kp = (K + 15) / 16 * 16; h->have_emission = true; h->emis_cat = true;
+  h->eK = K; h->eD = 1; h->V = V; h->Kp = (K + 15) / 16 * 16; h->have_emission = true; h->emis_cat = true; h->emis_diag = false;
   return 0;
 }
 int64_t svihmm_packed_len(svihmm_ctx* h) { return h ? (int64_t)packed_len(h) : 0; }
 
 static int ensure_feature_table(svihmm_ctx* h) {
-  return upload_feature_table(h, h->D, h->K);
+  return upload_feature_table(h, h->D, h->K, h->emis_diag);
 }
 
 int svihmm_set_lliks(svihmm_ctx* h, const double* lliks, int32_t B, int32_t Lm) {
@@ -956,7 +1025,8 @@ static int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool sc
   int var = h->variant[0];
   if (var == 0 || scaled) var = 2;
   // scaled output, D % 8 == 0: the address-free orbit schedule (variant[5] = 1 keeps K1b)
-  if (scaled && K <= 64 && D >= 8 && D <= 40 && D % 8 == 0 && h->variant[5] != 1 && min_lds == 0) {
+  if (h->emis_diag) var = 2;    // table-driven GEMM only (the VALU fallback assumes the triangular order)
+  if (!h->emis_diag && scaled && K <= 64 && D >= 8 && D <= 40 && D % 8 == 0 && h->variant[5] != 1 && min_lds == 0) {
     const int NT = Kp / 16, LEN = D + D / 2 + 1;
     const int nks = (D / 4) * (D / 2 + 1) + (D / 2 + 1 + 3) / 4;
     if (!h->orb_valid) {
@@ -985,6 +1055,7 @@ static int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool sc
     if (lds > 150 * 1024 && MT == 4) { MT = 2; lds = (size_t)128 * DS * 8 + (size_t)h->Fp * 4 + 128 * 9; }
     if (lds < min_lds) lds = min_lds;   // occupancy cap: leave LDS for co-resident sweep workgroups
     if (lds > 150 * 1024 && scaled) return fail("emission: D too large for the scaled sweeps");
+    if (lds > 150 * 1024 && h->emis_diag) return fail("emission: D too large for the diagonal family's kernel");
     if (lds > 150 * 1024) var = 1;
     else {
       const int ntile = Kp / 16;
@@ -1713,7 +1784,7 @@ static int launch_stats_finalize(svihmm_ctx* h, int64_t nchunk, hipStream_t stre
   hipLaunchKernelGGL(k_finalize, dim3((unsigned)((tot + 255) / 256) + (lbB ? 1 : 0)), dim3(256), 0, stream,
                      (const double*)h->part.p, (int)nchunk, D, K, Kp, Fp, F,
                      (const int*)h->fab.p, (double*)h->packed.p,
-                     (const double*)(lbB ? h->local_lb.p : nullptr), lbB);
+                     (const double*)(lbB ? h->local_lb.p : nullptr), lbB, h->emis_diag ? 1 : 0);
   HIPCK(hipGetLastError());
   return 0;
 }
@@ -1953,7 +2024,7 @@ static int launch_mirror(svihmm_ctx* h) {
   ProfScope ps(h, KS_D2H);
   if (h->shifted && !h->emis_cat)      // statistics leave in the caller's coordinates
     hipLaunchKernelGGL(k_packed_shift, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream,
-                       (const double*)h->packed.p, dev, (int)n, h->K, h->D, (const double*)h->shift_d.p, 1.0);
+                       (const double*)h->packed.p, dev, (int)n, h->K, h->D, (const double*)h->shift_d.p, 1.0, h->emis_diag ? 1 : 0);
   else
     hipLaunchKernelGGL(k_mirror, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream,
                        (const double*)h->packed.p, dev, (int)n);
@@ -1977,10 +2048,10 @@ static int allreduce_packed_dev(svihmm_ctx* h) {
     double* tmp = (double*)h->commtmp.p;
     const unsigned nb = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_packed_shift, dim3(nb), dim3(256), 0, h->stream, (const double*)h->packed.p, tmp, (int)n,
-                       h->K, h->D, (const double*)h->shift_d.p, 1.0);
+                       h->K, h->D, (const double*)h->shift_d.p, 1.0, h->emis_diag ? 1 : 0);
     NCCLCK(ncclAllReduce(tmp, tmp, n, ncclDouble, ncclSum, h->comm, h->stream));
     hipLaunchKernelGGL(k_packed_shift, dim3(nb), dim3(256), 0, h->stream, (const double*)tmp, (double*)h->packed.p,
-                       (int)n, h->K, h->D, (const double*)h->shift_d.p, -1.0);
+                       (int)n, h->K, h->D, (const double*)h->shift_d.p, -1.0, h->emis_diag ? 1 : 0);
     HIPCK(hipGetLastError());
     return 0;
   }

@@ -16,6 +16,9 @@ exactly the members the reference touches:
   ``.rvs(size)``                    ``gen_synthetic.py:32,40``
   ``.mu_mf .sigma_mf .kappa_mf .nu_mf .mu_0 .sigma_0 .kappa_0 .nu_0 .mu .sigma``
         read and written by ``util.NIW_mf_moment_pars`` (``util.py:40-60``)
+  ``DiagonalGaussian(mu=, sigmas=, mu_0=, nus_0=, alphas_0=, betas_0=)``
+        the package's diagonal-covariance family (BASELINE configs[0]); same protocol, a
+        normal-inverse-gamma factor per dimension
 
 Parity status: *unpinned* -- no reference test or fixture pins this arithmetic
 and the upstream source is absent; the device emission kernel is checked against
@@ -27,7 +30,7 @@ import numpy as np
 import scipy.linalg as sla
 from scipy.special import digamma, gammaln
 
-__all__ = ["Gaussian", "Categorical", "sample_niw", "sample_invwishart",
+__all__ = ["Gaussian", "DiagonalGaussian", "Categorical", "sample_niw", "sample_invwishart",
            "niw_quadratic_form", "niw_vlb_batch", "niw_prior_logpart", "vlb_logz_sign"]
 
 
@@ -213,6 +216,135 @@ class Gaussian(object):
                      - 0.5 * self.nu_mf
                      * np.linalg.solve(self.sigma_mf, self.sigma_0).trace())
         return p_avgengy + q_entropy
+
+
+class DiagonalGaussian(object):
+    """Gaussian with diagonal covariance: per dimension a normal-inverse-gamma prior
+
+        sigma_d^2 ~ InvGamma(alphas_0[d], betas_0[d]),   mu_d | sigma_d^2 ~ N(mu_0[d], sigma_d^2 / nus_0[d])
+
+    and a mean-field factor of the same form ``(mf_mu, mf_nus, mf_alphas, mf_betas)`` (the
+    package's ``DiagonalGaussian``; scalars broadcast over the dimensions).  Implements the
+    protocol the reference's loops use (module docstring): ``expected_log_likelihood``,
+    ``meanfieldupdate``, ``get_vlb``, ``rvs``, ``mu`` / ``sigmas`` / ``sigma``.  On the device this
+    family runs on 2 D + 1 features per row instead of (D+1)(D+2)/2 (``svihmm_set_emission_diag``).
+    """
+
+    svihmm_diag_fastpath = True
+
+    def __init__(self, mu=None, sigmas=None, mu_0=None, nus_0=None, alphas_0=None, betas_0=None):
+        f = lambda a: None if a is None else np.array(a, dtype=np.float64)
+        self.mu_0 = f(mu_0)
+        D = None if self.mu_0 is None else self.mu_0.shape[0]
+        if D is None and mu is not None:
+            D = np.asarray(mu).shape[0]
+        b = lambda a: None if a is None else np.broadcast_to(np.asarray(a, dtype=np.float64), (D,)).copy()
+        self.nus_0, self.alphas_0, self.betas_0 = b(nus_0), b(alphas_0), b(betas_0)
+        self.mu = f(mu)
+        self.sigmas = b(sigmas)
+        have_prior = not any(a is None for a in (mu_0, nus_0, alphas_0, betas_0))
+        if have_prior:
+            self.mf_mu = self.mu_0.copy() if self.mu is None else self.mu.copy()
+            self.mf_nus, self.mf_alphas, self.mf_betas = self.nus_0.copy(), self.alphas_0.copy(), self.betas_0.copy()
+            if self.mu is None or self.sigmas is None:
+                given_mu, given_s = self.mu, self.sigmas
+                self.resample()      # initialise what was not given from the prior, as upstream does
+                if given_mu is not None:
+                    self.mu = given_mu
+                if given_s is not None:
+                    self.sigmas = given_s
+                self.mf_mu = self.mu.copy()
+
+    @property
+    def sigma(self):
+        return np.diag(self.sigmas)
+
+    def num_parameters(self):
+        return 2 * len(self.mu_0 if self.mu_0 is not None else self.mu)
+
+    # -- sampling ------------------------------------------------------------
+    def resample(self, data=()):
+        D = len(self.mu_0)
+        if len(data) == 0:
+            mu_n, nus_n, alphas_n, betas_n = self.mu_0, self.nus_0, self.alphas_0, self.betas_0
+        else:
+            data = np.reshape(np.asarray(data, dtype=np.float64), (-1, D))
+            mu_n, nus_n, alphas_n, betas_n = self._posterior_hypparams(
+                *self._get_weighted_statistics(data, np.ones(len(data))))
+        self.sigmas = 1. / np.random.gamma(alphas_n, scale=1. / betas_n)
+        self.mu = np.sqrt(self.sigmas / nus_n) * np.random.randn(D) + mu_n
+        return self
+
+    def rvs(self, size=None):
+        size = 1 if size is None else size
+        D = self.mu.shape[0]
+        shape = size + (D,) if isinstance(size, tuple) else (size, D)
+        return self.mu + np.sqrt(self.sigmas) * np.random.normal(size=shape)
+
+    # -- statistics / conjugate update --------------------------------------
+    def _get_weighted_statistics(self, data, weights, D=None):
+        """(n, sum_t w x, sum_t w x^2) per dimension: the expected sufficient statistics."""
+        D = len(self.mu_0) if D is None else D
+        data = np.reshape(data, (-1, D))
+        weights = np.asarray(weights, dtype=np.float64)
+        return weights.sum(), np.dot(weights, data), np.dot(weights, data ** 2)
+
+    def _posterior_hypparams(self, n, sx, sxx):
+        mu_0, nus_0, alphas_0, betas_0 = self.mu_0, self.nus_0, self.alphas_0, self.betas_0
+        nus_n = nus_0 + n
+        mu_n = (nus_0 * mu_0 + sx) / nus_n
+        alphas_n = alphas_0 + 0.5 * n
+        betas_n = betas_0 + 0.5 * (sxx + nus_0 * mu_0 ** 2 - nus_n * mu_n ** 2)
+        return mu_n, nus_n, alphas_n, betas_n
+
+    def _set_mf(self, mu_n, nus_n, alphas_n, betas_n):
+        self.mf_mu, self.mf_nus, self.mf_alphas, self.mf_betas = mu_n, nus_n, alphas_n, betas_n
+        self.mu = self.mf_mu
+        # point estimate: the factor's mean where it exists, its mode otherwise
+        self.sigmas = np.where(alphas_n > 1., betas_n / np.maximum(alphas_n - 1., 1e-300), betas_n / (alphas_n + 1.))
+
+    def meanfieldupdate(self, data, weights):
+        self._set_mf(*self._posterior_hypparams(*self._get_weighted_statistics(data, weights)))
+
+    # natural parameters (additive in the statistics): [nus mu, nus, 2 betas + nus mu^2, 2 alphas]
+    @staticmethod
+    def to_natural(mu, nus, alphas, betas):
+        return np.stack([nus * mu, nus, 2. * betas + nus * mu ** 2, 2. * alphas])
+
+    @staticmethod
+    def from_natural(eta):
+        nus = eta[1]
+        mu = eta[0] / nus
+        return mu, nus, 0.5 * eta[3], 0.5 * (eta[2] - nus * mu ** 2)
+
+    # -- mean-field expectations ---------------------------------------------
+    def mf_expectations(self):
+        """Coefficients (a, b, c) of E_q log N(x) = sum_d (a_d x_d^2 + b_d x_d) + c."""
+        mu, nus, al, be = self.mf_mu, self.mf_nus, self.mf_alphas, self.mf_betas
+        prec = al / be
+        c = (-0.5 * (1. / nus + mu ** 2 * prec) - 0.5 * (np.log(be) - digamma(al))).sum() \
+            - 0.5 * len(mu) * np.log(2. * np.pi)
+        return -0.5 * prec, mu * prec, c
+
+    def expected_log_likelihood(self, x):
+        """E_q[log N(x | mu, diag sigma^2)] under the factor (centred form); NaN rows stay NaN."""
+        mu, nus, al, be = self.mf_mu, self.mf_nus, self.mf_alphas, self.mf_betas
+        x = np.reshape(x, (-1, len(mu))) - mu
+        return ((-0.5 * (al / be) * x ** 2).sum(1)
+                + (-0.5 / nus - 0.5 * (np.log(be) - digamma(al))).sum() - 0.5 * len(mu) * np.log(2. * np.pi))
+
+    def get_vlb(self):
+        """E_q[log p(mu, sigma^2)] - E_q[log q(mu, sigma^2)] = -KL(q || prior), summed over the
+        dimensions (zero at the prior)."""
+        m, nu, al, be = self.mf_mu, self.mf_nus, self.mf_alphas, self.mf_betas
+        m0, nu0, al0, be0 = self.mu_0, self.nus_0, self.alphas_0, self.betas_0
+        elog = np.log(be) - digamma(al)            # E log sigma^2
+        prec = al / be                             # E 1 / sigma^2
+        p = (0.5 * np.log(nu0 / (2 * np.pi)) - (al0 + 1.5) * elog - 0.5 * nu0 * (1. / nu + (m - m0) ** 2 * prec)
+             + al0 * np.log(be0) - gammaln(al0) - be0 * prec)
+        q = (0.5 * np.log(nu / (2 * np.pi)) - (al + 1.5) * elog - 0.5
+             + al * np.log(be) - gammaln(al) - al)
+        return float((p - q).sum())
 
 
 # sign convention of the prior's log-normaliser in the NIW factors' ELBO term (see Gaussian.get_vlb)

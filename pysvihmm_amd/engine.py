@@ -31,6 +31,24 @@ class PackedStats(object):
         return K * K + K * D + K + K * D * D + 1
 
 
+class PackedDiagStats(object):
+    """View of the packed statistics of a diagonal-Gaussian E-step
+    ``[A_raw K*K | xbar K*D | neff K | xsq K*D | lb]`` (xsq[k, d] = sum_t q[t,k] x[t,d]^2)."""
+
+    def __init__(self, buf, K, D):
+        self.buf, self.K, self.D = buf, K, D
+        o = 0
+        self.A_raw = buf[o:o + K * K].reshape(K, K); o += K * K
+        self.xbar = buf[o:o + K * D].reshape(K, D); o += K * D
+        self.neff = buf[o:o + K]; o += K
+        self.xsq = buf[o:o + K * D].reshape(K, D); o += K * D
+        self.lb = buf[o:o + 1]
+
+    @staticmethod
+    def size(K, D):
+        return K * K + 2 * K * D + K + 1
+
+
 class PackedCatStats(object):
     """View of the packed statistics of a Categorical-emission E-step
     ``[A_raw K*K | counts K*V | lb]`` (counts[k, v] = sum of var_x[t, k] over unmasked rows
@@ -65,6 +83,7 @@ class HipEngine(object):
         self.device = int(device)
         self.T = self.D = self.K = 0
         self.V = 0            # > 0: Categorical emission with V symbols is active
+        self.diag = False     # diagonal-Gaussian emission is active (its own packed layout)
         self._comm = False
 
     # -- lifecycle ------------------------------------------------------------------
@@ -217,8 +236,24 @@ class HipEngine(object):
                                                   L.dptr(kappa), L.dptr(nu)),
                 "svihmm_set_emission_niw")
         self.V = 0
+        self.diag = False
         if check:
             L.check(self._lib.svihmm_sync(self._h), "svihmm_set_emission_niw")
+
+    def set_emission_diag(self, mu, nus, alphas, betas, check=True):
+        """Upload K diagonal-covariance Gaussian factors (normal-inverse-gamma mean field per
+        dimension, all arrays [K, D]); see ``svihmm_set_emission_diag``.  Statistics then come
+        back as ``PackedDiagStats``."""
+        self._pre_mutate()
+        mu = L.as_f64(mu)
+        K, D = mu.shape
+        nus, alphas, betas = (L.as_f64(a, (K, D)) for a in (nus, alphas, betas))
+        L.check(self._lib.svihmm_set_emission_diag(self._h, K, D, L.dptr(mu), L.dptr(nus), L.dptr(alphas),
+                                                   L.dptr(betas)), "svihmm_set_emission_diag")
+        self.V = 0
+        self.diag = True
+        if check:
+            L.check(self._lib.svihmm_sync(self._h), "svihmm_set_emission_diag")
 
     def set_emission_prior(self, mu0, sigma0):
         mu0 = L.as_f64(mu0)
@@ -293,10 +328,14 @@ class HipEngine(object):
         return self._wrap_packed(out) if read else None
 
     def _packed_len(self):
-        return PackedCatStats.size(self.K, self.V) if self.V else PackedStats.size(self.K, self.D)
+        if self.V:
+            return PackedCatStats.size(self.K, self.V)
+        return PackedDiagStats.size(self.K, self.D) if self.diag else PackedStats.size(self.K, self.D)
 
     def _wrap_packed(self, buf):
-        return PackedCatStats(buf, self.K, self.V) if self.V else PackedStats(buf, self.K, self.D)
+        if self.V:
+            return PackedCatStats(buf, self.K, self.V)
+        return PackedDiagStats(buf, self.K, self.D) if self.diag else PackedStats(buf, self.K, self.D)
 
     def set_emission_cat(self, logp):
         """Categorical emissions: ``logp[k, v] = E_q log theta_k[v]`` (obs = symbol indices)."""
@@ -305,6 +344,7 @@ class HipEngine(object):
         K, V = logp.shape
         L.check(self._lib.svihmm_set_emission_cat(self._h, K, V, L.dptr(logp)), "svihmm_set_emission_cat")
         self.V = V
+        self.diag = False
 
     def pred_logprob(self, starts, Lm, flags=L.MASK_AS_NAN):
         """Mean predictive log-probability of the masked rows of the windows and their number
@@ -397,6 +437,7 @@ class HipEngine(object):
                                            *([L.dptr(a) for a in arrs] + [int(maxit), float(zsign)])),
                 "svihmm_svi_begin")
         self.K, self.V = K, 0
+        self.diag = False
         self._svi_shape = (K, D)
 
     def svi_iteration(self, it, starts, nwin_total, Lm, flags, rho, bfactA, bfactE, inner=None):

@@ -48,6 +48,15 @@ def is_niw_gaussian(e):
     return isinstance(e, Gaussian) and t.expected_log_likelihood is Gaussian.expected_log_likelihood
 
 
+def is_diag_gaussian(e):
+    """Diagonal-covariance family (``distributions.DiagonalGaussian`` and subclasses that keep
+    its ``expected_log_likelihood``): the device runs it on 2 D + 1 features per row."""
+    from .distributions import DiagonalGaussian
+    t = type(e)
+    return (isinstance(e, DiagonalGaussian)
+            and t.expected_log_likelihood is DiagonalGaussian.expected_log_likelihood)
+
+
 def dirichlet_elbo(prior, var):
     """sum over rows of E_q[log Dir(.|prior_r)] + H[Dir(.|var_r)] for row-wise Dirichlet factors
     (the ``*_energy + *_entropy`` terms of reference hmmbase.py:150-181 and
@@ -215,6 +224,16 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
         d = self.obs.shape[1] if self.obs.ndim == 2 else 1
         return d <= L.NIW_MAX_D and all(is_niw_gaussian(e) for e in self.var_emit)
 
+    def _diag_fastpath(self):
+        d = self.obs.shape[1] if self.obs.ndim == 2 else 1
+        return (d <= L.DIAG_MAX_D and hasattr(self.engine, "set_emission_diag")
+                and all(is_diag_gaussian(e) for e in self.var_emit))
+
+    def _diag_arrays(self):
+        ve = self.var_emit
+        return tuple(np.array([getattr(g, n) for g in ve], dtype=np.float64)
+                     for n in ("mf_mu", "mf_nus", "mf_alphas", "mf_betas"))
+
     def _cat_fastpath(self):
         """Categorical emissions over one integer-valued observation column (the device keeps
         the E log theta table and counts symbols; reference hmmsgd_metaobs.py:907-926)."""
@@ -276,6 +295,10 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
         if self._niw_fastpath():
             mu, sg, ka, nu = self._emission_arrays()
             self.engine.set_emission_niw(mu, sg, ka, nu)
+            return L.MASK_AS_NAN if nan_mask else 0
+        if self._diag_fastpath():
+            # diagonal family: the K x D normal-inverse-gamma factors; lliks on 2 D + 1 features
+            self.engine.set_emission_diag(*self._diag_arrays())
             return L.MASK_AS_NAN if nan_mask else 0
         if self._cat_fastpath():
             # Categorical: E log theta table (pybasicbayes Categorical.expected_log_likelihood),

@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-from .hmmbase import VariationalHMMBase, is_niw_gaussian
+from .hmmbase import VariationalHMMBase, is_niw_gaussian, is_diag_gaussian
 
 eps = 1e-9
 
@@ -121,11 +121,17 @@ class VBHMM(VariationalHMMBase):
                 G._alpha_mf = G._posterior_hypparams(st.counts[k])
                 G.weights = G._alpha_mf / G._alpha_mf.sum()
             return
+        if hasattr(st, "xsq"):
+            # diagonal family: meanfieldupdate(obs[inds], q[inds, k]) from (n, sum q x, sum q x^2)
+            for k in range(self.K):
+                G = self.var_emit[k]
+                G._set_mf(*G._posterior_hypparams(st.neff[k], st.xbar[k], st.xsq[k]))
+            return
         for k in range(self.K):
             G = self.var_emit[k]
             if not is_niw_gaussian(G):
-                raise RuntimeError("fused batch update needs NIW Gaussian emissions; "
-                                   "call infer(fused=False)")
+                raise RuntimeError("fused batch update needs NIW / diagonal Gaussian or Categorical "
+                                   "emissions; call infer(fused=False)")
             n = st.neff[k]
             if n > 0:
                 xbar = st.xbar[k] / n

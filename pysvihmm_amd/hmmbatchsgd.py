@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-from .hmmbase import VariationalHMMBase, is_niw_gaussian
+from .hmmbase import VariationalHMMBase, is_niw_gaussian, is_diag_gaussian
 from . import util
 
 eps = 1e-9
@@ -109,6 +109,14 @@ class VBHMM(VariationalHMMBase):
     def _natgrad_emissions(self, lrate, stats_for_k):
         for k in range(self.K):
             G = self.var_emit[k]
+            if is_diag_gaussian(G):
+                # the same blend in the diagonal family's natural parameters (the reference's
+                # NIW arithmetic, util.py:28-60, has no counterpart for it)
+                new = stats_for_k(G, k)
+                eta = ((1. - lrate) * G.to_natural(G.mf_mu, G.mf_nus, G.mf_alphas, G.mf_betas)
+                       + lrate * G.to_natural(*new))
+                G._set_mf(*G.from_natural(eta))
+                continue
             mu_mf, sigma_mf, kappa_mf, nu_mf = stats_for_k(G, k)
             nats_t = util.NIW_mf_natural_pars(mu_mf, sigma_mf, kappa_mf, nu_mf)
             nats_old = util.NIW_mf_natural_pars(G.mu_mf, G.sigma_mf, G.kappa_mf, G.nu_mf)
@@ -123,6 +131,8 @@ class VBHMM(VariationalHMMBase):
         self.var_tran = ((1. - lrate) * nats_old + lrate * nats_t) + 1.
 
         def from_stats(G, k):
+            if hasattr(st, "xsq"):
+                return G._posterior_hypparams(st.neff[k], st.xbar[k], st.xsq[k])
             if not is_niw_gaussian(G):
                 raise RuntimeError("fused batch update needs NIW Gaussian emissions")
             n = st.neff[k]
@@ -146,4 +156,5 @@ class VBHMM(VariationalHMMBase):
         self.var_tran = ((1. - lrate) * nats_old + lrate * nats_t) + 1.
         inds = np.logical_not(self.mask)
         self._natgrad_emissions(
-            lrate, lambda G, k: util.NIW_meanfield(G, batch[inds, :], self.var_x[inds, k]))
+            lrate, lambda G, k: (G._posterior_hypparams(*G._get_weighted_statistics(batch[inds, :], self.var_x[inds, k]))
+                                 if is_diag_gaussian(G) else util.NIW_meanfield(G, batch[inds, :], self.var_x[inds, k])))

@@ -27,7 +27,7 @@ import numpy.random as npr
 from numpy import newaxis as npa
 from scipy.special import digamma
 
-from .hmmbase import VariationalHMMBase, is_niw_gaussian, dirichlet_elbo
+from .hmmbase import VariationalHMMBase, is_niw_gaussian, is_diag_gaussian, dirichlet_elbo
 from .distributions import Gaussian, Categorical
 from . import util
 from . import _lib as L
@@ -249,7 +249,7 @@ class VBHMM(VariationalHMMBase):
         if (any(getattr(type(self), n) is not getattr(VBHMM, n) for n in
                 ("local_update", "intermediate_pars", "intermediate_pars_buffer", "forward_msgs",
                  "backward_msgs", "local_lower_bound"))
-                or not (self._niw_fastpath() or self._cat_fastpath())):
+                or not (self._niw_fastpath() or self._cat_fastpath() or self._diag_fastpath())):
             # subclass overrides, or an emission family the device statistics kernels
             # do not know (the reference dispatches on the type too, :887,907):
             # follow the reference loop literally, E-step recursions still on the device
@@ -317,6 +317,8 @@ class VBHMM(VariationalHMMBase):
                     # the reference calls util.NIW_zero_nat_pars here for every family
                     # (:399), which raises for a Categorical; zeros of the right shape instead
                     emit_inter = [np.zeros(self.var_emit[0].num_parameters()) for k in range(K)]
+                elif is_diag_gaussian(self.var_emit[0]):
+                    emit_inter = [np.zeros((4, self.D)) for k in range(K)]
                 else:
                     emit_inter = [util.NIW_zero_nat_pars(self.var_emit[0]) for k in range(K)]
                 for data in minibatch:
@@ -546,6 +548,10 @@ class VBHMM(VariationalHMMBase):
         if hasattr(st, "counts"):
             # Categorical (reference :907-926): every window contributes alpha_0 + counts - 1
             emit_inter = [nwin * (G.alphav_0 - 1.) + st.counts[k] for k, G in enumerate(self.var_emit)]
+        elif hasattr(st, "xsq"):
+            # diagonal family: expected sufficient statistics [sum q x, n, sum q x^2, n] per state
+            emit_inter = [np.stack([st.xbar[k], np.full(D, st.neff[k]), st.xsq[k], np.full(D, st.neff[k])])
+                          for k in range(K)]
         else:
             emit_inter = _StackedStats(st.xbar.copy(), st.neff.copy(), st.S.copy())
         lb = float(st.lb[0])
@@ -756,6 +762,11 @@ class VBHMM(VariationalHMMBase):
                 G = self.var_emit[k]
                 weights = var_x[inds, k]
                 emit_inter.append(util.NIW_suffstats(G, obs[loff:(uoff + 1), :][inds, :], weights))
+        elif is_diag_gaussian(self.var_emit[0]):
+            x = obs[loff:(uoff + 1), :][inds, :]
+            for k in range(self.K):
+                n, sx, sxx = self.var_emit[k]._get_weighted_statistics(x, var_x[inds, k])
+                emit_inter.append(np.stack([sx, np.full(x.shape[1], n), sxx, np.full(x.shape[1], n)]))
         elif type(self.var_emit[0]) is Categorical:
             for k in range(self.K):
                 G = self.var_emit[k]
@@ -798,6 +809,16 @@ class VBHMM(VariationalHMMBase):
                 nats_new = (1. - lrate) * nats_old \
                     + lrate * (prior_hypparam + bfact * emit_inter[k])
                 util.NIW_mf_moment_pars(G, *nats_new)
+        elif is_diag_gaussian(self.var_emit[0]):
+            # the Gaussian branch's blend (reference :1050-1069) in the diagonal family's natural
+            # parameters [nus mu, nus, 2 betas + nus mu^2, 2 alphas] (an extension: the reference
+            # dispatches on Gaussian / Categorical only)
+            for k in range(self.K):
+                G = self.var_emit[k]
+                nats_old = G.to_natural(G.mf_mu, G.mf_nus, G.mf_alphas, G.mf_betas)
+                prior_hypparam = G.to_natural(G.mu_0, G.nus_0, G.alphas_0, G.betas_0)
+                nats_new = (1. - lrate) * nats_old + lrate * (prior_hypparam + bfact * emit_inter[k])
+                G._set_mf(*G.from_natural(nats_new))
         elif type(self.var_emit[0]) is Categorical:
             for k in range(self.K):
                 G = self.var_emit[k]
