@@ -156,6 +156,12 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reps", type=int, default=10, help="repetitions of the --steps block (median reported)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default, BASELINE configs[3]): one independent T=1M sequence per GPU; strong: ONE "
+                         "sequence, the epoch's 3891 windows dealt windows[rank::N] (north_star: 'minibatches shard "
+                         "across the GPUs'), one all-reduce per step.  At N>1 the weak run also reports the strong "
+                         "figure as a side record")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling side record of an N>1 weak run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side", action="store_true", help="skip the side figures (profiling runs)")
     args = ap.parse_args()
@@ -189,9 +195,12 @@ def main():
             raise SystemExit("RCCL communicator has %d ranks, expected %d" % (ranks_seen, world))
 
     # the sequence: generated in HBM (the path's own f3 row), resident before the timed region
-    rs, tran, means, chols = true_process(rank)
+    # (strong scaling: every rank holds the SAME sequence and works on its share of the windows)
+    strong = args.scaling == "strong"
+    seq = 0 if strong else rank
+    rs, tran, means, chols = true_process(seq)
     t0 = time.perf_counter()
-    eng.generate(tran, means, chols, T, seed=SEED + rank)
+    eng.generate(tran, means, chols, T, seed=SEED + seq)
     eng.sync()
     gen_ms = (time.perf_counter() - t0) * 1e3
     need_host_obs = rank == 0 and world == 1 and not (args.no_side and args.no_cpu_baseline)
@@ -203,7 +212,8 @@ def main():
         head = eng.read_generated(want_sts=False)[0][:20000]
     pb = variational_state(rs, means, head)
     B = T // LM
-    starts = np.arange(B, dtype=np.int64) * LM
+    all_starts = np.arange(B, dtype=np.int64) * LM
+    starts = all_starts[rank::world] if strong else all_starts
     rows = B * LM
 
     def step(st=starts):
@@ -245,7 +255,7 @@ def main():
         per_rank = [float(v) for v in eng.allreduce_host(slots, "sum")]
     assert np.all(np.isfinite(out.buf)), "non-finite statistics"
     # sanity: posteriors sum to one => wrap transition statistic sums to the row count
-    tot_rows = rows * world
+    tot_rows = rows if strong else rows * world
     assert abs(out.A_raw.sum() / tot_rows - 1.0) < 1e-9, out.A_raw.sum() / tot_rows
 
     dt = float(np.median(block))
@@ -255,6 +265,10 @@ def main():
     side = {}
     if world == 1 and not args.no_side:
         side = side_figures(eng, L, pb, step, barrier, obs_host, args)
+    if comm is not None and not strong and not args.no_strong:
+        # the other partitioning of DESIGN 6, measured in the same job: ONE sequence on every GPU
+        # (rank 0's), the epoch's windows and the S=64 minibatch dealt round-robin over the ranks
+        side["strong_scaling"] = strong_scaling(eng, L, comm, rank, world, args, barrier)
 
     if rank == 0:
         flops = algorithmic_flops(rows)
@@ -281,7 +295,7 @@ def main():
             "metric": "obs-state updates/sec (T*K/s) per SVI E-step, K=64 Gaussian HMM",
             "value": value, "unit": "updates/s", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (generated in HBM by svihmm_generate, %.1f ms)" % gen_ms,
             "reps": args.reps, "timing": "median of %d blocks of %d steps (max over ranks per block)"
                                          % (args.reps, args.steps),
@@ -291,7 +305,10 @@ def main():
                                    "resident, metaobs L=128 (Lm=257), one E-step over all "
                                    "3891 tiled windows (T*K=6.4e7 updates) per GPU per step",
                        "K": K, "D": D, "T": T, "Lm": LM, "windows_per_step": B,
-                       "sequences": world, "parallelism": "windows sharded; 1 sequence/GPU"},
+                       "sequences": 1 if strong else world,
+                       "parallelism": ("one sequence resident on every GPU, windows[rank::N] per rank, one "
+                                       "all-reduce of the packed statistics per step") if strong else
+                                      "windows sharded; 1 sequence/GPU"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
@@ -310,6 +327,10 @@ def main():
         }
         if per_rank is not None:
             res["per_rank_ms_per_step"] = per_rank
+        if "allreduce" in kern:
+            res["allreduce"] = {"ms_per_step": kern["allreduce"]["ms_per_launch"], "bytes": PackedStats.size(K, D) * 8,
+                                "note": "ncclAllReduce(sum, f64) of the packed statistics on the handle's stream "
+                                        "(HIP events around the call)"}
         res.update(side)
         print(json.dumps(res))
         sys.stdout.flush()
@@ -321,6 +342,51 @@ def main():
             except OSError:
                 pass
     eng.close()
+
+
+def strong_scaling(eng, L, comm, rank, world, args, barrier):
+    """One sequence, windows dealt over the ranks (DESIGN 6 mode (i)).  Every rank regenerates
+    rank 0's sequence in its own HBM (counter-based generator: bit-identical copies)."""
+    rs, tran, means, chols = true_process(0)
+    eng.generate(tran, means, chols, T, seed=SEED)
+    head = eng.read_generated(want_sts=False)[0][:20000]
+    pb = variational_state(rs, means, head)
+    B = T // LM
+    all_starts = np.arange(B, dtype=np.int64) * LM
+    st64 = (np.arange(64, dtype=np.int64) * (T // 64)) % (T - LM)
+    out = {}
+    for name, st_all, reps in (("epoch", all_starts, 5), ("minibatch_s64", st64, 5)):
+        mine = st_all[rank::world]
+
+        def step():
+            eng.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"], check=False)
+            eng.set_globals(pb["mod_init"], pb["ltran"])
+            eng.estep(mine, LM, flags=L.TRANS_WRAP, read=False)     # (an empty shard yields zero statistics)
+            eng.allreduce_packed()
+            return eng.read_packed()
+        for _ in range(3):
+            res = step()
+        eng.profile(True); eng.profile_reset()
+        blocks = np.zeros(reps)
+        for r in range(reps):
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                res = step()
+            barrier()
+            blocks[r] = time.perf_counter() - t0
+        prof = eng.profile_read(); eng.profile(False)
+        blocks = eng.allreduce_host(blocks, "max")
+        dt = float(np.median(blocks)) / args.steps
+        nrows = len(st_all) * LM
+        assert abs(res.A_raw.sum() / nrows - 1.0) < 1e-9          # every rank holds the statistics of ALL windows
+        ar = prof.get("allreduce", (0.0, 0))
+        out[name] = {"windows": int(len(st_all)), "windows_per_rank": int(len(mine)), "ms_per_step": dt * 1e3,
+                     "value": nrows * K / dt, "unit": "updates/s", "scaling": "strong",
+                     "allreduce_ms_per_step": ar[0] / max(ar[1], 1)}
+    out["note"] = ("one T=1e6 sequence resident on all %d GPUs, windows[rank::%d] per rank, one all-reduce per step; "
+                   "value = rows of the WHOLE batch x K / time (max over ranks)" % (world, world))
+    return out
 
 
 def median_time(fn, sync, n, warm=2):

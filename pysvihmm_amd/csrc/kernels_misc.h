@@ -395,7 +395,15 @@ __global__ __launch_bounds__(256) void k_packed_shift(const double* __restrict__
     const int e = i - oS;
     const int k = e / (D * D), r = e - k * D * D, a = r / D, b = r - a * D;
     const double ca = sgn * c[a], cb = sgn * c[b];
-    v += ca * src[oX + k * D + b] + src[oX + k * D + a] * cb + src[oN + k] * ca * cb;
+    // order-symmetric in (a, b) with every product rounded (no FMA contraction: fused, the two
+    // cross terms round differently for (a, b) and (b, a)): S stays bit-symmetric
+    {
+#pragma clang fp contract(off)
+      const double p1 = ca * src[oX + k * D + b], p2 = cb * src[oX + k * D + a];
+      const double cross = fmin(p1, p2) + fmax(p1, p2);
+      const double quad = src[oN + k] * (ca * cb);
+      v = v + (cross + quad);
+    }
   }
   dst[i] = v;
 }

@@ -318,6 +318,7 @@ static void sample_center(const svihmm_ctx* h, const double* obs, int64_t T, int
 static int reset_shift(svihmm_ctx* h, const std::vector<double>& c, int64_t row0, int64_t nrows);
 static int shift_rows(svihmm_ctx* h, const double* delta, int64_t row0, int64_t nrows, bool round_symbols);
 static int store_shift(svihmm_ctx* h, const std::vector<double>& c);
+static int params_follow_centre(svihmm_ctx* h, const double* delta);
 int svihmm_set_precision(svihmm_ctx* h, int32_t mode) {
   if (!h || (mode != SVIHMM_F64 && mode != SVIHMM_F32)) return fail("svihmm_set_precision: mode must be SVIHMM_F64 or SVIHMM_F32");
   h->prec = mode;
@@ -426,10 +427,48 @@ static int store_shift(svihmm_ctx* h, const std::vector<double>& c) {
   CK(pin_release(h, slot));
   return 0;
 }
-// freshly written rows [row0, row0 + nrows) hold caller coordinates: c becomes the shift, rows move
+// The centre moved by delta[D]: device-side parameters kept in centred coordinates follow -- the
+// means of the NIW / diagonal factors in h->niw (theta is rebuilt), the prior means of a running
+// SVI loop.  What the caller uploaded keeps its meaning.
+static int params_follow_centre(svihmm_ctx* h, const double* delta) {
+  const int D = h->D;
+  bool any = false;
+  for (int d = 0; d < D; ++d) any = any || delta[d] != 0.0;
+  const bool live = h->have_emission && !h->emis_cat && h->eD == D && h->niw.p;   // (NIW or diagonal: means lead the block)
+  const bool svi = h->svi_active && h->svi_D == D;
+  if (!any || (!live && !svi)) return 0;
+  CK(wait_side_streams(h));
+  void* pin = nullptr;
+  int slot = 0;
+  CK(pinned(h, (size_t)D * sizeof(double), &pin, &slot));
+  std::memcpy(pin, delta, (size_t)D * sizeof(double));
+  void* dpin = nullptr;
+  HIPCK(hipHostGetDevicePointer(&dpin, pin, 0));
+  if (live) {
+    const int n = h->eK * D;
+    hipLaunchKernelGGL(k_shift_means, dim3((n + 255) / 256), dim3(256), 0, h->stream, (double*)h->niw.p, n, D,
+                       (const double*)dpin);
+  }
+  if (svi) {
+    const int n = h->svi_K * D;
+    hipLaunchKernelGGL(k_shift_means, dim3((n + 255) / 256), dim3(256), 0, h->stream, (double*)h->svi_prior.p, n, D,
+                       (const double*)dpin);
+  }
+  HIPCK(hipGetLastError());
+  CK(pin_release(h, slot));
+  if (live && h->emis_diag) CK(launch_diag_to_theta(h, h->eK, D));
+  else if (live) CK(launch_niw_to_theta(h, h->eK, D, svi ? svi_ptr(h, 4) : nullptr));
+  return 0;
+}
+// freshly written rows [row0, row0 + nrows) hold caller coordinates: c becomes the shift, rows move,
+// parameters already on the device follow the change of centre
 static int reset_shift(svihmm_ctx* h, const std::vector<double>& c, int64_t row0, int64_t nrows) {
+  std::vector<double> delta(c);
+  if ((int)h->shift.size() == h->D)
+    for (int d = 0; d < h->D; ++d) delta[d] -= h->shift[d];
   CK(store_shift(h, c));
-  return shift_rows(h, c.data(), row0, nrows, false);
+  CK(shift_rows(h, c.data(), row0, nrows, false));
+  return params_follow_centre(h, delta.data());
 }
 
 int svihmm_shift_obs(svihmm_ctx* h, const double* shift) {
@@ -446,31 +485,7 @@ int svihmm_shift_obs(svihmm_ctx* h, const double* shift) {
   c.resize((size_t)D, 0.0);
   for (int d = 0; d < D; ++d) c[d] += shift[d];
   CK(store_shift(h, c));
-  // device-side parameters in centred coordinates follow: NIW means (+ theta), the SVI loop's prior
-  const bool niw_live = h->have_emission && !h->emis_cat && h->eD == D && h->niw.p;   // (NIW or diagonal: means lead the block)
-  if (niw_live || h->svi_active) {
-    void* pin = nullptr;
-    int slot = 0;
-    CK(pinned(h, (size_t)D * sizeof(double), &pin, &slot));
-    std::memcpy(pin, shift, (size_t)D * sizeof(double));
-    void* dpin = nullptr;
-    HIPCK(hipHostGetDevicePointer(&dpin, pin, 0));
-    if (niw_live) {
-      const int n = h->eK * D;
-      hipLaunchKernelGGL(k_shift_means, dim3((n + 255) / 256), dim3(256), 0, h->stream, (double*)h->niw.p, n, D,
-                         (const double*)dpin);
-    }
-    if (h->svi_active && h->svi_D == D) {
-      const int n = h->svi_K * D;
-      hipLaunchKernelGGL(k_shift_means, dim3((n + 255) / 256), dim3(256), 0, h->stream, (double*)h->svi_prior.p, n, D,
-                         (const double*)dpin);
-    }
-    HIPCK(hipGetLastError());
-    CK(pin_release(h, slot));
-    if (niw_live && h->emis_diag) CK(launch_diag_to_theta(h, h->eK, D));
-    else if (niw_live) CK(launch_niw_to_theta(h, h->eK, D, h->svi_active ? svi_ptr(h, 4) : nullptr));
-  }
-  return 0;
+  return params_follow_centre(h, shift);
 }
 int svihmm_get_shift(svihmm_ctx* h, double* shift_out) {
   if (!h || !shift_out) return fail("svihmm_get_shift: bad arguments");
@@ -496,7 +511,7 @@ int svihmm_alloc_obs(svihmm_ctx* h, int64_t T, int32_t D, int32_t with_mask) {
   }
   h->T = T; h->D = D; h->gen_T = 0;
   h->svi_active = false;
-  CK(store_shift(h, std::vector<double>((size_t)D, 0.0)));
+  CK(reset_shift(h, std::vector<double>((size_t)D, 0.0), 0, 0));
   h->center_pending = true;            // the first block that arrives fixes the shift
   return 0;
 }
@@ -517,7 +532,7 @@ int svihmm_set_obs_rows(svihmm_ctx* h, int64_t row0, int64_t nrows, const double
     h->center_pending = false;
     std::vector<double> c;
     sample_center(h, obs, nrows, h->D, c);
-    CK(store_shift(h, c));
+    CK(reset_shift(h, c, 0, 0));         // (rows written before this call would be undefined anyway)
   }
   CK(shift_rows(h, h->shift.data(), row0, nrows, false));
   HIPCK(hipStreamSynchronize(h->stream));

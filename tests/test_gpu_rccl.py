@@ -77,6 +77,21 @@ def test_bench_forced_comm_dry_run():
     assert j["n_gpus"] == 1 and j["ranks"] == 1 and j["ranks_source"] == "ncclCommCount"
     assert j["steps"] == 3 and len(j["ms_per_step_reps"]) == 3 and j["value"] > 1e9
     assert "allreduce" in j["kernels"] and len(j["per_rank_ms_per_step"]) == 1
+    assert j["scaling"] == "weak" and j["allreduce"]["ms_per_step"] > 0
+    # the weak run carries the strong-scaling record of the same job (one sequence, windows dealt)
+    ss = j["strong_scaling"]
+    for name, nwin in (("epoch", 3891), ("minibatch_s64", 64)):
+        assert ss[name]["scaling"] == "strong" and ss[name]["windows"] == nwin == ss[name]["windows_per_rank"]
+        assert ss[name]["value"] > 1e9 and ss[name]["allreduce_ms_per_step"] > 0
+
+
+def test_bench_strong_scaling_dry_run():
+    """`--scaling strong` through the forced communicator at world size 1: the headline is then
+    the one-sequence epoch with the windows dealt over the ranks."""
+    j = _bench({"SVIHMM_FORCE_COMM": "1"}, "--scaling", "strong", "--steps", "3", "--warmup", "1", "--reps", "3",
+               "--no-side", "--no-cpu-baseline")
+    assert j["scaling"] == "strong" and j["config"]["sequences"] == 1 and j["ranks"] == 1
+    assert j["value"] > 1e9 and "strong_scaling" not in j
 
 
 def test_bench_self_launch_two_gpus():
