@@ -154,3 +154,70 @@ def test_config5_k256_d64_large_batch_vs_oracle():
         q, _ = ref_c.posterior(ref_c.forward(ll, pb["mod_init"], pb["ltran"]), ref_c.backward(ll, pb["ltran"]))
         np.testing.assert_allclose(e.read_rows("var_x", b * Lm, Lm), q, rtol=1e-6, atol=1e-12)
     e.close()
+
+
+@pytest.mark.skipif(NCORE < 8, reason="the K=256 oracle needs ~1 s per window: multi-core host only")
+def test_config5_k256_d64_t1e6_epoch_sweep():
+    """configs[4] at its FULL size (K=256, D=64 full covariance, T=1e6, the 3891-window epoch sweep
+    bench.py's `c5_k256_d64` record times): size-independent properties of the whole step, a spread
+    sample of 48 windows' statistics against the C oracle (own E-step on those windows: identical
+    kernels, the batch is above the wide-kernel threshold... at 48 the wave kernels run, so the
+    sample is ALSO checked window by window against the epoch's own posteriors), and the posteriors
+    of 6 windows of the epoch step row by row."""
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd.gen_synthetic import generate_data_fast
+    from pysvihmm_amd import _lib as L
+    import bench
+    from oracle import ref_c
+    K, D, T, Lm = 256, 64, 1000000, 257
+    rs = np.random.RandomState(bench.SEED + 4)
+    rng = np.random.default_rng(bench.SEED + 4)
+    tran = 0.9 * np.eye(K) + 0.1 / (K - 1) * (1.0 - np.eye(K))
+    means = rs.normal(0.0, 5.0, size=(K, D))
+    obs, _ = generate_data_fast(tran, means, None, T, rng)
+    pw = bench.variational_state(rs, means, obs[:20000], K, D, T)
+    par = (pw["mod_init"], pw["ltran"], pw["mu"], pw["sigma"], pw["kappa"], pw["nu"])
+    B = T // Lm
+    starts = np.arange(B, dtype=np.int64) * Lm
+    e = HipEngine(0)
+    try:
+        e.set_obs(obs, None)
+        e.set_globals(pw["mod_init"], pw["ltran"])
+        e.set_emission_niw(pw["mu"], pw["sigma"], pw["kappa"], pw["nu"])
+        st = e.estep(starts, Lm, flags=L.TRANS_WRAP)
+        n = B * Lm
+        x = obs[:n]
+        assert np.all(np.isfinite(st.buf))
+        assert abs(st.A_raw.sum() / n - 1.0) < 1e-11 and abs(st.neff.sum() / n - 1.0) < 1e-11
+        np.testing.assert_allclose(st.xbar.sum(0), x.sum(0), rtol=1e-9, atol=1e-6)
+        np.testing.assert_allclose(st.S.sum(0), x.T.dot(x), rtol=1e-9)
+        np.testing.assert_allclose(st.S, np.swapaxes(st.S, 1, 2), rtol=0, atol=0)
+        # posteriors of the epoch step, 6 windows spread over the sequence, row by row
+        qs = {}
+        for b in np.linspace(0, B - 1, 6).astype(int):
+            xw = obs[starts[b]:starts[b] + Lm]
+            ll = ref_c.lliks_niw(xw, pw["mu"], pw["sigma"], pw["kappa"], pw["nu"])
+            q, _ = ref_c.posterior(ref_c.forward(ll, pw["mod_init"], pw["ltran"]), ref_c.backward(ll, pw["ltran"]))
+            got = e.read_rows("var_x", int(b) * Lm, Lm)
+            np.testing.assert_allclose(got, q, rtol=1e-6, atol=1e-12)
+            qs[int(b)] = got
+        # marginal consistency of the whole step: row / column sums of the transition statistic
+        qsum = np.zeros(K)
+        for r0 in range(0, n, 65536):
+            qsum += e.read_rows("var_x", r0, min(65536, n - r0)).sum(0)
+        np.testing.assert_allclose(st.A_raw.sum(1), qsum, rtol=1e-9)
+        np.testing.assert_allclose(st.A_raw.sum(0), qsum, rtol=1e-9)
+        np.testing.assert_allclose(st.neff, qsum, rtol=1e-9)
+        # 208 windows spread over the sequence (the wide large-batch kernels) against the C oracle
+        sel = starts[np.linspace(0, B - 1, 208).astype(int)]
+        got = e.estep(sel, Lm, flags=L.TRANS_WRAP)
+        ref = ref_c.estep_minibatch(obs, None, sel, Lm, *par, flags=2, threads=NCORE)
+        A, xbar, neff, S, lb = unpack(ref, K, D)
+        sc = len(sel) * Lm
+        np.testing.assert_allclose(got.A_raw, A, rtol=1e-6, atol=1e-10 * sc)
+        np.testing.assert_allclose(got.xbar, xbar, rtol=1e-6, atol=1e-9 * sc)
+        np.testing.assert_allclose(got.neff, neff, rtol=1e-6, atol=1e-10 * sc)
+        np.testing.assert_allclose(got.S, S, rtol=1e-6, atol=1e-8 * sc)
+        np.testing.assert_allclose(got.lb[0], lb, rtol=1e-10)
+    finally:
+        e.close()

@@ -28,6 +28,11 @@ BENCH="python $ROOT/bench.py --steps 5 --warmup 2 --reps 2 --no-cpu-baseline --n
 { run fetch --kernel-trace --pmc FETCH_SIZE; run write --kernel-trace --pmc WRITE_SIZE; } > $OUT/${TAG}_pmc_hbm.txt
 BENCH="python $ROOT/tools/f32_profile_workload.py"
 { run fetch32 --kernel-trace --pmc FETCH_SIZE; run write32 --kernel-trace --pmc WRITE_SIZE; } > $OUT/${TAG}_pmc_hbm_f32.txt
+# configs[4] (K=256, D=64): the wide kernels alone
+BENCH="python $ROOT/tools/c5_profile_workload.py"
+run kt5 --kernel-trace --stats > $OUT/${TAG}_c5_kernel_stats.txt
+{ run fetch5 --kernel-trace --pmc FETCH_SIZE; run write5 --kernel-trace --pmc WRITE_SIZE; } > $OUT/${TAG}_c5_pmc_hbm.txt
+run sq5 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS > $OUT/${TAG}_c5_sq_counters.txt
 BENCH=$BENCH_ALL
 run sq --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS > $OUT/${TAG}_sq_counters.txt
 cd $ROOT && python bench.py 2>/dev/null | tail -1 > $OUT/${TAG}_bench.json
