@@ -356,8 +356,15 @@ def run_sequence(e, L, seed, nops=30):
         if rng.random() < 0.3:
             vi = np.where(rng.random(K) < 0.5, 10.0 ** -rng.uniform(3, 6, K), 0.3) * (0.5 + rng.random(K))
             pb["mod_init"] = digamma(vi + 1e-9) - digamma(vi.sum() + 1e-9)
+        # data anywhere on the axis: the handle keeps its resident copy centred, the C ABI is
+        # coordinate-invariant (means / statistics in the caller's coordinates)
+        offs = float(rng.choice([0.0, 0.0, 40.0, -3e3, 1e5]))
+        pb["obs"] = pb["obs"] + offs
+        pb["mu"] = pb["mu"] + offs
+        pb["offset"] = offs
         if keep_obs and state["pb"] is not None:
-            for k in ("obs", "mask", "sts"):
+            pb["mu"] = pb["mu"] - offs + state["pb"]["offset"]
+            for k in ("obs", "mask", "sts", "offset"):
                 pb[k] = state["pb"][k]
         state["pb"] = pb
         return pb
@@ -387,18 +394,73 @@ def run_sequence(e, L, seed, nops=30):
         pb = state["pb"]
         f32 = state["prec"] == "f32"
         op = str(rng.choice(["estep", "estep", "fb", "read", "read", "params", "obs", "prec", "predlp", "argmax",
-                             "ffbs", "hostll", "svi", "loglik", "inner"]))
+                             "ffbs", "hostll", "svi", "loglik", "inner", "shift", "class", "reobs", "diag"]))
         hist.append(op)
         what = "seq seed=%d K=%d D=%d T=%d step %d %s (history %s)" % (seed, K, D, T, step, op, " ".join(hist[-8:]))
         xs = max(1.0, float(np.nanmax(np.abs(pb["obs"]))))
         if op == "params":
             new_problem(keep_obs=True)
             upload("params")
+        elif op == "shift":
+            # the centre moves, nothing else: whatever follows must still agree with the oracle
+            e.shift_obs(rng.normal(size=D) * float(rng.choice([0.1, 5.0, 300.0])))
+            state["fresh"] = None
+        elif op == "reobs":
+            # the SAME data uploaded again under the parameters already on the device (the new
+            # centre is chosen afresh; device-side means and theta follow it)
+            for eng in (e, o):
+                eng.set_obs(pb["obs"], pb["mask"] if pb["mask"].any() else None)
+            state["fresh"] = None
+        elif op == "class":
+            # a class borrows the handle for its own model and data (the state
+            # that broke the bench's cross-check); afterwards the sequence's data come back and the
+            # raw calls go on with the caller's parameters
+            from pysvihmm_amd import hmmsgd_metaobs
+            from pysvihmm_amd.distributions import Gaussian
+            Kc, Dc, Tc = 3, D, 500
+            cp = make_problem(Kc, Dc, Tc, seed=int(rng.integers(1 << 30)), sep=3.0)
+            cobs = cp["obs"] + float(rng.choice([0.0, 77.0, -2e4]))
+            out = []
+            for eng in (e, o):
+                np.random.seed(11)
+                prior = np.array([Gaussian(mu_0=cobs.mean(0), sigma_0=0.75 * np.atleast_2d(np.cov(cobs.T)),
+                                           kappa_0=0.01, nu_0=Dc + 2) for _ in range(Kc)])
+                m = hmmsgd_metaobs.VBHMM(cobs, np.ones(Kc), np.ones((Kc, Kc)), prior, tau=1.0, kappa=0.7, metaobs_half=6,
+                                         mb_sz=5, maxit=3, seed=2, engine=eng)
+                m.infer()
+                out.append(m)
+            if not f32:
+                np.testing.assert_allclose(out[0].var_tran, out[1].var_tran, rtol=1e-6, atol=1e-9, err_msg=what)
+                np.testing.assert_allclose(out[0].elbo_vec, out[1].elbo_vec, rtol=1e-6, err_msg=what)
+            upload("all")
+        elif op == "diag":
+            st, Lm = windows()
+            dp = (pb["mu"], 0.5 + 4 * rng.random((K, D)), 2.0 + 5 * rng.random((K, D)), 1.0 + 6 * rng.random((K, D)))
+            for eng in (e, o):
+                eng.set_emission_diag(*dp)
+            a, b = e.estep(st, Lm, flags=L.TRANS_WRAP), o.estep(st, Lm, flags=L.TRANS_WRAP)
+            sc = len(st) * Lm
+            tol, at = (2e-3, 2e-4) if f32 else (1e-6, 1e-9)
+            np.testing.assert_allclose(a.A_raw, b.A_raw, rtol=tol, atol=at * sc, err_msg=what)
+            np.testing.assert_allclose(a.neff, b.neff, rtol=tol, atol=at * sc, err_msg=what)
+            if not f32:
+                np.testing.assert_allclose(a.xbar, b.xbar, rtol=tol, atol=at * sc * xs, err_msg=what)
+                np.testing.assert_allclose(a.xsq, b.xsq, rtol=tol, atol=at * sc * xs * xs, err_msg=what)
+                np.testing.assert_allclose(a.lb, b.lb, rtol=1e-9, atol=1e-6, err_msg=what)
+            upload("params")          # back to the NIW family
+            state["fresh"] = None
         elif op == "obs":
-            keep = {k: state["pb"][k] for k in ("mod_init", "ltran", "mu", "sigma", "kappa", "nu")}
+            # new data under the parameters already on the device (their means move with the data's
+            # offset on the host side of the comparison; on the device they must follow the new centre)
+            old = state["pb"]
+            keep = {k: old[k] for k in ("mod_init", "ltran", "sigma", "kappa", "nu")}
+            mu_rel = old["mu"] - old["offset"]
             new_problem()
             state["pb"].update(keep)
+            state["pb"]["mu"] = mu_rel + state["pb"]["offset"]
             upload("obs")
+            for eng in (e, o):     # (the means moved with the data: an upload in the caller's coordinates)
+                eng.set_emission_niw(state["pb"]["mu"], keep["sigma"], keep["kappa"], keep["nu"])
         elif op == "prec":
             state["prec"] = "f32" if state["prec"] == "f64" else "f64"
             if os.environ.get("FUZZ_F64"):          # replay aid: the same sequence without the fp32 mode
