@@ -135,6 +135,7 @@ struct svihmm_ctx {
   double* mirror = nullptr; size_t mirror_cap = 0;   // pinned + mapped copy of `packed`
   bool mirror_valid = false;
   bool status_pending = false;
+  bool status_auto = false;      // the pending status word stems from an automatic theta rebuild (params_follow_centre)
   bool have_emission = false;
   // work
   Buf starts, ll, la, lb, q, lse_part, local_lb, logz, part, packed, scratch;
@@ -319,6 +320,7 @@ static int reset_shift(svihmm_ctx* h, const std::vector<double>& c, int64_t row0
 static int shift_rows(svihmm_ctx* h, const double* delta, int64_t row0, int64_t nrows, bool round_symbols);
 static int store_shift(svihmm_ctx* h, const std::vector<double>& c);
 static int params_follow_centre(svihmm_ctx* h, const double* delta);
+static int drop_auto_status(svihmm_ctx* h);
 int svihmm_set_precision(svihmm_ctx* h, int32_t mode) {
   if (!h || (mode != SVIHMM_F64 && mode != SVIHMM_F32)) return fail("svihmm_set_precision: mode must be SVIHMM_F64 or SVIHMM_F32");
   h->prec = mode;
@@ -458,6 +460,18 @@ static int params_follow_centre(svihmm_ctx* h, const double* delta) {
   CK(pin_release(h, slot));
   if (live && h->emis_diag) CK(launch_diag_to_theta(h, h->eK, D));
   else if (live) CK(launch_niw_to_theta(h, h->eK, D, svi ? svi_ptr(h, 4) : nullptr));
+  if (live) h->status_auto = true;
+  return 0;
+}
+// An explicit parameter upload supersedes whatever an automatic rebuild of theta reported (new
+// observations uploaded under the previous model's factors may lie anywhere relative to them).
+static int drop_auto_status(svihmm_ctx* h) {
+  if (h->status_pending && h->status_auto) {
+    HIPCK(hipStreamSynchronize(h->stream));
+    if (h->pin_status) *h->pin_status = 0;
+    h->status_pending = false;
+  }
+  h->status_auto = false;
   return 0;
 }
 // freshly written rows [row0, row0 + nrows) hold caller coordinates: c becomes the shift, rows move,
@@ -792,6 +806,7 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
   std::memcpy(hp + nmu + nsg, kappa, K * sizeof(double));
   std::memcpy(hp + nmu + nsg + K, nu, K * sizeof(double));
   if (h->vlb_pending) { HIPCK(hipStreamWaitEvent(h->stream, h->svi_ed, 0)); h->vlb_pending = false; }
+  CK(drop_auto_status(h));
   CK(pull_small(h, dmu, hp, nin * sizeof(double)));
   CK(pin_release(h, slot));
   CK(launch_niw_to_theta(h, K, D, nullptr));
@@ -820,6 +835,7 @@ int svihmm_set_emission_diag(svihmm_ctx* h, int32_t K, int32_t D, const double* 
   std::memcpy(hp + 3 * n, betas, n * sizeof(double));
   if (h->vlb_pending) { HIPCK(hipStreamWaitEvent(h->stream, h->svi_ed, 0)); h->vlb_pending = false; }
   h->svi_active = false;               // (the resident NIW state of an SVI loop lived in h->niw)
+  CK(drop_auto_status(h));
   CK(pull_small(h, h->niw.p, hp, 4 * n * sizeof(double)));
   CK(pin_release(h, slot));
   return launch_diag_to_theta(h, K, D);
@@ -918,6 +934,7 @@ int svihmm_set_emission_cat(svihmm_ctx* h, int32_t K, int32_t V, const double* l
   CK(set_device(h));
   h->lin_stale = true;
   h->center_pending = false;
+  CK(drop_auto_status(h));
   if (h->shifted && h->T > 0) {
     // the resident column holds symbol indices: a centred copy (the upload cannot know the family)
     // goes back to exact integers and stays uncentred
@@ -2396,6 +2413,7 @@ int svihmm_svi_begin(svihmm_ctx* h, int32_t K, int32_t D, const double* prior_tr
   if (h->D != D) return fail("svihmm_svi_begin: D does not match the resident observations");
   CK(set_device(h));
   CK(wait_side_streams(h));
+  CK(drop_auto_status(h));
   const size_t kk = (size_t)K * K, nmu = (size_t)K * D, nsg = (size_t)K * D * D;
   const size_t nin = nmu + nsg + 2 * (size_t)K;
   {
