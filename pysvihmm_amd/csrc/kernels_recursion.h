@@ -1307,14 +1307,30 @@ __global__ __launch_bounds__(64) void k_wave_lin(
 //  K2f, minibatch-sized batches (K <= 64, up to a few hundred windows): the same scaled
 //  recursion with FOUR wavefronts per (window, direction).  A 64-window minibatch gives the
 //  one-wave kernel 128 wavefronts for 1024 SIMDs, each walking 64 broadcast reads + 64 FMAs per
-//  step (0.56 us); here wave w owns the source states i in [16w, 16w+16): it keeps its own copy
-//  of the entering vector in LDS (wave-private, so the broadcast needs no barrier), forms the
-//  partial sums over its 16 states for all 64 target states (16 FMAs), and after ONE workgroup
-//  barrier every wave adds up the four partials (double-buffered) and renormalises -- all four
-//  redundantly, so the next step's entering vector is already in each wave's registers.
-//  Same inputs / outputs and the same arithmetic per element as k_wave_lin except for the
-//  association of the 64-term sum ((4 x 16) instead of (4 chains x 16)).
+//  step (0.56 us).  Here every wave keeps the whole entering vector in registers (lane l = state
+//  l) and wave w owns the TARGET states [16w, 16w+16): lane (r, c) = 16 r + c forms the partial
+//  sum of target 16 w + c over the source block [16r, 16r+16) -- the sources reach it as DPP
+//  row broadcasts of the wave's own registers (row_newbcast:N hands lane 16r+N's value to the
+//  16 lanes of row r), so a step has no LDS round trip for the mat-vec operand.  The partials go
+//  through LDS once (part[r][target], conflict-free both ways), ONE workgroup barrier, and
+//  every wave adds up the four partials of all 64 targets redundantly and renormalises, so the
+//  next step's entering vector is already in each wave's registers.  (Round 2 split the SOURCES
+//  over the waves and broadcast them through a wave-private LDS copy: two LDS round trips per
+//  step, 0.43 us; this form: one.)  Same inputs / outputs as k_wave_lin, and the same
+//  arithmetic per element up to the association of the 64-term sum (4 blocks x (8 + 8)).
 // ------------------------------------------------------------------------------------
+// acc += (lane 16 r + N of p, broadcast over row r) * a: one DP-ALU DPP instruction (the builtin
+// route costs two v_mov_b32_dpp + the FMA).  FIRST: two wait states in front, the hazard between a
+// VALU write of p and its DPP read is the compiler's to keep and it cannot see into the asm.
+template <int N, bool FIRST = false>
+__device__ __forceinline__ void fmac_row_bcast(double& acc, double p, double a) {
+  if (FIRST)
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc) : "v"(p), "v"(a), "n"(N));
+  else
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc) : "v"(p), "v"(a), "n"(N));
+}
 template <int KMAX, typename ST = double>
 __global__ __launch_bounds__(256) void k_wave_lin4(
     const ST* __restrict__ Eh, const double* __restrict__ kexp,
@@ -1323,19 +1339,20 @@ __global__ __launch_bounds__(256) void k_wave_lin4(
     int K, ST* __restrict__ ah,
     ST* __restrict__ bh, double* __restrict__ hx, double* __restrict__ gx,
     double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac) {
-  constexpr int NI = KMAX / 4;                  // source states per wave
-  __shared__ double p_s[4][2][64];              // wave-private copies of the entering vector
-  __shared__ double part[2][4][64];             // partial sums, double-buffered over steps
+  static_assert(KMAX == 64, "lane = state, four source blocks of 16");
+  __shared__ double part[2][4][64];             // [step parity][source block][target], double-buffered
   const int b = blockIdx.x, j = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = j >> 4, c = j & 15;             // source block, target within the wave's 16
+  const int tgt = 16 * w + c;
   const bool fwd = blockIdx.y == 0;
   const bool valid = j < K;
   const int jc = valid ? j : 0;
   const double* __restrict__ Am = fwd ? Aexp : AexpT;
-  double a[NI];
+  double a[16];                                 // a[N] = A[16 r + N][tgt] (fwd) / A[tgt][16 r + N] (bwd)
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int src = w * NI + i;
-    a[i] = (valid && src < K) ? Am[(size_t)src * K + jc] : 0.0;
+  for (int i = 0; i < 16; ++i) {
+    const int src = 16 * r + i;
+    a[i] = (tgt < K && src < K) ? Am[(size_t)src * K + tgt] : 0.0;
   }
   const size_t wrow = (size_t)b * Lm;
   const ST* __restrict__ Eb = Eh + wrow * K + jc;
@@ -1367,9 +1384,7 @@ __global__ __launch_bounds__(256) void k_wave_lin4(
   auto step = [&](int s, double et) {
     const int cur = s & 1;
     const int t = rowof(s);
-    double* __restrict__ mine = &p_s[w][cur][0];
-    mine[j] = pcur;                                  // wave-private: LDS keeps a wave's order
-    __builtin_amdgcn_wave_barrier();
+    // exponent and bookkeeping from the entering vector (off the mat-vec's dependency chain)
     const double tot = wave_sum_dpp(pcur);
     const int e2 = __builtin_amdgcn_frexp_exp(tot);
     if (fwd) {
@@ -1379,13 +1394,12 @@ __global__ __launch_bounds__(256) void k_wave_lin4(
       hsum += h;
     }
     double s0 = 0.0, s1 = 0.0;
-    const double* __restrict__ src = mine + w * NI;
-#pragma unroll
-    for (int i = 0; i < NI; i += 2) {
-      s0 = fma(src[i], a[i], s0);
-      s1 = fma(src[i + 1], a[i + 1], s1);
-    }
-    part[cur][w][j] = s0 + s1;
+    fmac_row_bcast<0, true>(s0, pcur, a[0]);
+    fmac_row_bcast<1>(s1, pcur, a[1]);
+#define WL4_PAIR(N) fmac_row_bcast<N>(s0, pcur, a[N]); fmac_row_bcast<N + 1>(s1, pcur, a[N + 1]);
+    WL4_PAIR(2) WL4_PAIR(4) WL4_PAIR(6) WL4_PAIR(8) WL4_PAIR(10) WL4_PAIR(12) WL4_PAIR(14)
+#undef WL4_PAIR
+    part[cur][r][tgt] = s0 + s1;
     __syncthreads();
     const double acc = (part[cur][0][j] + part[cur][1][j]) + (part[cur][2][j] + part[cur][3][j]);
     double o;

@@ -1329,7 +1329,7 @@ static int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_
 #define WL4F(KM) hipLaunchKernelGGL((k_wave_lin4<KM, float>), gw, dim3(256), 0, stream, Ef, kx, (const double*)h->Aexp.p, \
                                     (const double*)h->AexpT.p, mi, l0, l0s, Lm, K, af, bf, hx, gx, \
                                     llb, lz, zf)
-      if (K > 16 && nb <= LIN_WAVE4_MAX && h->variant[7] != 3) { if (K <= 32) WL4F(32); else WL4F(64); }
+      if (K > 16 && nb <= LIN_WAVE4_MAX && h->variant[7] != 3) { WL4F(64); }
       else if (K <= 16) WLF(16, false); else if (K <= 32) WLF(32, false);
       else if (K == 64) WLF(64, true); else WLF(64, false);
 #undef WLF
@@ -1362,7 +1362,7 @@ static int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_
 #define WL4(KM) hipLaunchKernelGGL((k_wave_lin4<KM>), gw, dim3(256), 0, stream, Eh, kx, (const double*)h->Aexp.p, \
                                    (const double*)h->AexpT.p, mi, l0, l0s, Lm, K, ah, bh, hx,  \
                                    gx, llb, lz, zf)
-      if (K <= 32) WL4(32); else WL4(64);
+      WL4(64);
 #undef WL4
     }
     else if (K <= 16) WL(16, false); else if (K <= 32) WL(32, false);
