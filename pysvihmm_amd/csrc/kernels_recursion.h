@@ -1319,37 +1319,17 @@ __global__ __launch_bounds__(64) void k_wave_lin(
 //  step, 0.43 us; this form: one.)  Same inputs / outputs as k_wave_lin, and the same
 //  arithmetic per element up to the association of the 64-term sum (4 blocks x (8 + 8)).
 // ------------------------------------------------------------------------------------
-// One step's mat-vec share of a lane (r, c): s0 + s1 = sum_N p[16 r + N] a[N] and rs = sum_N p[16 r + N]
-// (the row's share of the entering vector's total), as 32 DP-ALU DPP instructions with row_newbcast:N
-// (lane 16 r + N of p to the 16 lanes of row r) -- no LDS, no readlane, four independent chains.
-// One asm statement: the two wait states between a VALU write of p and its first DPP read are
-// inside (the compiler cannot see the hazard), and the scheduler may move other work around it.
-__device__ __forceinline__ void row_matvec16(double p, const double (&a)[16], double& s0, double& s1, double& rs0,
-                                             double& rs1) {
-  s0 = 0.0; s1 = 0.0; rs0 = 0.0; rs1 = 0.0;
-  const double one = 1.0;     // (only v_fmac_f64 has a DPP form among the DP-ALU instructions: the sum is a product with 1)
-#define RB(N) " row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n\t"
-  asm("s_nop 1\n\t"
-      "v_fmac_f64_dpp %0, %4, %5" RB(0) "v_fmac_f64_dpp %1, %4, %6" RB(1)
-      "v_fmac_f64_dpp %2, %4, %21" RB(0) "v_fmac_f64_dpp %3, %4, %21" RB(1)
-      "v_fmac_f64_dpp %0, %4, %7" RB(2) "v_fmac_f64_dpp %1, %4, %8" RB(3)
-      "v_fmac_f64_dpp %2, %4, %21" RB(2) "v_fmac_f64_dpp %3, %4, %21" RB(3)
-      "v_fmac_f64_dpp %0, %4, %9" RB(4) "v_fmac_f64_dpp %1, %4, %10" RB(5)
-      "v_fmac_f64_dpp %2, %4, %21" RB(4) "v_fmac_f64_dpp %3, %4, %21" RB(5)
-      "v_fmac_f64_dpp %0, %4, %11" RB(6) "v_fmac_f64_dpp %1, %4, %12" RB(7)
-      "v_fmac_f64_dpp %2, %4, %21" RB(6) "v_fmac_f64_dpp %3, %4, %21" RB(7)
-      "v_fmac_f64_dpp %0, %4, %13" RB(8) "v_fmac_f64_dpp %1, %4, %14" RB(9)
-      "v_fmac_f64_dpp %2, %4, %21" RB(8) "v_fmac_f64_dpp %3, %4, %21" RB(9)
-      "v_fmac_f64_dpp %0, %4, %15" RB(10) "v_fmac_f64_dpp %1, %4, %16" RB(11)
-      "v_fmac_f64_dpp %2, %4, %21" RB(10) "v_fmac_f64_dpp %3, %4, %21" RB(11)
-      "v_fmac_f64_dpp %0, %4, %17" RB(12) "v_fmac_f64_dpp %1, %4, %18" RB(13)
-      "v_fmac_f64_dpp %2, %4, %21" RB(12) "v_fmac_f64_dpp %3, %4, %21" RB(13)
-      "v_fmac_f64_dpp %0, %4, %19" RB(14) "v_fmac_f64_dpp %1, %4, %20" RB(15)
-      "v_fmac_f64_dpp %2, %4, %21" RB(14) "v_fmac_f64_dpp %3, %4, %21" RB(15)
-      : "+v"(s0), "+v"(s1), "+v"(rs0), "+v"(rs1)
-      : "v"(p), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]),
-        "v"(a[9]), "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]), "v"(a[14]), "v"(a[15]), "v"(one));
-#undef RB
+// acc += (lane 16 r + N of p, broadcast over row r) * a: one DP-ALU DPP instruction (the builtin
+// route costs two v_mov_b32_dpp + the FMA).  FIRST: two wait states in front, the hazard between a
+// VALU write of p and its DPP read is the compiler's to keep and it cannot see into the asm.
+template <int N, bool FIRST = false>
+__device__ __forceinline__ void fmac_row_bcast(double& acc, double p, double a) {
+  if (FIRST)
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc) : "v"(p), "v"(a), "n"(N));
+  else
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc) : "v"(p), "v"(a), "n"(N));
 }
 template <int KMAX, typename ST = double>
 __global__ __launch_bounds__(256) void k_wave_lin4(
@@ -1361,7 +1341,6 @@ __global__ __launch_bounds__(256) void k_wave_lin4(
     double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac) {
   static_assert(KMAX == 64, "lane = state, four source blocks of 16");
   __shared__ double part[2][4][64];             // [step parity][source block][target], double-buffered
-  __shared__ double rsum[2][4];                 // [step parity][source block]: the block's share of sum_j p[j]
   const int b = blockIdx.x, j = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r = j >> 4, c = j & 15;             // source block, target within the wave's 16
   const int tgt = 16 * w + c;
@@ -1397,7 +1376,7 @@ __global__ __launch_bounds__(256) void k_wave_lin4(
     if (valid && w == 0) ob[(size_t)t * K] = o;
   }
   double hkeep = h;
-  constexpr int PD = 12;    // Eh rows in flight (one register each): ~5 us of HBM latency cover at 0.4 us a step
+  constexpr int PD = 12;    // Eh rows in flight (one register each): measured 102.8 -> 96.4 us against PD = 4
   auto eload = [&](int s) { return Eb[(size_t)rowof(s < Lm ? s : Lm - 1) * K]; };
   double eq[PD];
 #pragma unroll
@@ -1405,15 +1384,8 @@ __global__ __launch_bounds__(256) void k_wave_lin4(
   auto step = [&](int s, double et) {
     const int cur = s & 1;
     const int t = rowof(s);
-    double s0, s1, rs0, rs1;
-    row_matvec16(pcur, a, s0, s1, rs0, rs1);
-    part[cur][r][tgt] = s0 + s1;
-    if (w == 0 && c == 0) rsum[cur][r] = rs0 + rs1;
-    __syncthreads();
-    const double acc = (part[cur][0][j] + part[cur][1][j]) + (part[cur][2][j] + part[cur][3][j]);
-    // total of the entering vector -> renormalisation exponent and the bound's running product
-    // (its four row shares ride through the same barrier as the partial sums)
-    const double tot = (rsum[cur][0] + rsum[cur][1]) + (rsum[cur][2] + rsum[cur][3]);
+    // exponent and bookkeeping from the entering vector (off the mat-vec's dependency chain)
+    const double tot = wave_sum_dpp(pcur);
     const int e2 = __builtin_amdgcn_frexp_exp(tot);
     if (fwd) {
       const double mm = mant * tot;
@@ -1421,6 +1393,15 @@ __global__ __launch_bounds__(256) void k_wave_lin4(
       mant = __builtin_amdgcn_frexp_mant(mm);
       hsum += h;
     }
+    double s0 = 0.0, s1 = 0.0;
+    fmac_row_bcast<0, true>(s0, pcur, a[0]);
+    fmac_row_bcast<1>(s1, pcur, a[1]);
+#define WL4_PAIR(N) fmac_row_bcast<N>(s0, pcur, a[N]); fmac_row_bcast<N + 1>(s1, pcur, a[N + 1]);
+    WL4_PAIR(2) WL4_PAIR(4) WL4_PAIR(6) WL4_PAIR(8) WL4_PAIR(10) WL4_PAIR(12) WL4_PAIR(14)
+#undef WL4_PAIR
+    part[cur][r][tgt] = s0 + s1;
+    __syncthreads();
+    const double acc = (part[cur][0][j] + part[cur][1][j]) + (part[cur][2][j] + part[cur][3][j]);
     double o;
     if (fwd) { o = valid ? ldexp(acc * et, -e2) : 0.0; pcur = o; }
     else { o = valid ? ldexp(acc, -e2) : 0.0; pcur = et * o; }
