@@ -245,7 +245,8 @@ int svihmm_estep_minibatch_ex(svihmm_ctx* h, const int64_t* starts, int32_t B,
  *   hold shards and the packed statistics are all-reduced before the step): quirk Q2 adds
  *   nwin_total * (prior_tran - 1).  rho = (it + tau)^-kappa; bfactA = (T-2L-1)/(2L*S),
  *   bfactE = (T-2L-1)/((2L+1)*S) from the CONSTRUCTOR's L, S (quirk Q3).
- * svihmm_svi_read_elbo: elbo_vec[0..n) and the device time of each iteration in ms (either may
+ * svihmm_svi_read_elbo: elbo_vec[0..n) and the device time of each iteration in ms (from the
+ *   iteration's first to its last launch on the handle's stream; either may
  *   be NULL).  svihmm_svi_read_state: current var_tran [K,K], var_init [K] (the stationary vector
  *   of the last iteration, quirk Q5), NIW factors; any pointer may be NULL. */
 int svihmm_svi_begin(svihmm_ctx* h, int32_t K, int32_t D, const double* prior_tran,
@@ -257,6 +258,11 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
                          int32_t nwin_total, int32_t Lm, int32_t inner_off, int32_t inner_len,
                          uint32_t flags, double rho, double bfactA, double bfactE);
 int svihmm_svi_read_elbo(svihmm_ctx* h, int32_t n, double* out_elbo, double* out_ms);
+/* mod_init[K] / ltran[K,K] as the recursions currently hold them (either may be NULL): the last
+ * svihmm_set_globals upload, or -- after svihmm_svi_iteration -- the psi-expectations that
+ * iteration computed on the device (hmmsgd_metaobs.py:502-504; the reference leaves them on the
+ * object as mod_init / mod_tran). */
+int svihmm_read_globals(svihmm_ctx* h, double* mod_init_out, double* ltran_out);
 int svihmm_svi_read_state(svihmm_ctx* h, double* var_tran, double* var_init, double* mu,
                           double* sigma, double* kappa, double* nu);
 

@@ -356,6 +356,9 @@ class OracleEngine(object):
             vlb += g.get_vlb(sv["conv"])
         sv["elbo"][it] = st.lb[0] + R.dirichlet_lower_bound(sv["prior_tran"], sv["var_tran"]) + vlb
 
+    def read_globals(self):
+        return self.mod_init.copy(), self.ltran.copy()
+
     def svi_read_elbo(self, n):
         return self._svi["elbo"][:n].copy(), np.zeros(n)
 

@@ -20,7 +20,15 @@ class RcclComm(object):
         ncclUniqueId from rank 0 (``file_uid_exchange``, a TCP store, ...)."""
         self.rank, self.size = int(rank), int(size)
         uid = exchange_uid(engine.comm_unique_id() if self.rank == 0 else None)
-        engine.comm_init(uid, self.rank, self.size)
+        engine.comm_init(uid, self.rank, self.size)      # collective: returns once every rank has joined
+        if self.rank == 0 and getattr(exchange_uid, "path", None):
+            # consumed: a later job with the same tag (one long-lived parent launching several jobs on
+            # one MASTER_PORT) must never find this job's id
+            import os
+            try:
+                os.remove(exchange_uid.path)
+            except OSError:
+                pass
 
         self._engine = engine
 
@@ -73,6 +81,9 @@ def file_uid_exchange(rank, tag=None, timeout=300.0, directory=None):
         t0 = time.time()
         # a file left behind by a crashed earlier job with the same tag is older than this
         # job's launcher (fallback: older than two minutes before this worker got here)
+        # (no bound relative to THIS worker's arrival: workers may start minutes apart.  A job that
+        #  completes its rendezvous removes the file -- RcclComm -- so what a long-lived launcher's
+        #  earlier jobs can leave behind is limited to jobs that crashed inside the rendezvous)
         born = launcher_start()
         fresh = (born - 1.0) if born is not None else (t0 - 120.0)
         while True:

@@ -2473,7 +2473,7 @@ int svihmm_svi_begin(svihmm_ctx* h, int32_t K, int32_t D, const double* prior_tr
     h->svi_elbo_cap = maxit;
   }
   for (int i = 0; i < maxit; ++i) h->svi_elbo[i] = NAN;
-  while ((int)h->svi_ev.size() < maxit + 1) {
+  while ((int)h->svi_ev.size() < 2 * maxit) {      // [2 it]: first launch of iteration it, [2 it + 1]: its last
     hipEvent_t e;
     HIPCK(hipEventCreate(&e));
     h->svi_ev.push_back(e);
@@ -2494,7 +2494,7 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
   if (flags & SVIHMM_USE_HOST_LLIKS) return fail("svihmm_svi_iteration: NIW emission only");
   CK(set_device(h));
   const int K = h->svi_K, D = h->svi_D;
-  HIPCK(hipEventRecord(h->svi_ev[it], h->stream));
+  HIPCK(hipEventRecord(h->svi_ev[2 * it], h->stream));
   if (!h->svi_globals_ready) CK(svi_globals(h, h->svi_vi_cur ^ 1));   // (a host set_globals came in between)
   h->svi_vi_cur = h->svi_globals_slot;
   h->svi_globals_ready = false;       // consumed by this iteration's sweeps
@@ -2530,7 +2530,7 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
   }
   if (it + 1 < h->svi_maxit) CK(svi_globals(h, h->svi_vi_cur ^ 1));   // the next iteration's, ahead of time
   CK(svi_refresh_emission(h, it, it & 1));
-  HIPCK(hipEventRecord(h->svi_ev[it + 1], h->stream));
+  HIPCK(hipEventRecord(h->svi_ev[2 * it + 1], h->stream));
   return 0;
 }
 
@@ -2545,7 +2545,7 @@ int svihmm_svi_read_elbo(svihmm_ctx* h, int32_t n, double* out_elbo, double* out
     if (out_elbo) out_elbo[i] = h->svi_elbo[i];
     if (out_ms) {
       float ms = 0.f;
-      out_ms[i] = hipEventElapsedTime(&ms, h->svi_ev[i], h->svi_ev[i + 1]) == hipSuccess ? (double)ms : NAN;
+      out_ms[i] = hipEventElapsedTime(&ms, h->svi_ev[2 * i], h->svi_ev[2 * i + 1]) == hipSuccess ? (double)ms : NAN;
     }
   }
   return 0;
@@ -2569,6 +2569,21 @@ int svihmm_svi_read_state(svihmm_ctx* h, double* var_tran, double* var_init, dou
   h->vlb_pending = false;
   if (mu) from_centred(h, mu, (int)K, (int)D);
   CK(check_emission_status(h));
+  return 0;
+}
+
+// The globals the recursions currently hold (log domain): what svihmm_set_globals uploaded last, or
+// what the device-resident loop's last iteration computed from var_tran (the reference leaves that
+// iteration's psi-expectations on the object: hmmsgd_metaobs.py:502-504).
+int svihmm_read_globals(svihmm_ctx* h, double* mod_init_out, double* ltran_out) {
+  if (!h || (!mod_init_out && !ltran_out)) return fail("svihmm_read_globals: bad arguments");
+  if (!h->have_globals) return fail("svihmm_read_globals: no globals on the device");
+  CK(set_device(h));
+  CK(wait_globals(h));
+  const size_t K = h->K;
+  if (mod_init_out) CK(d2h(h, mod_init_out, h->mod_init.p, K * 8));
+  if (ltran_out) CK(d2h(h, ltran_out, h->ltran.p, K * K * 8));
+  HIPCK(hipStreamSynchronize(h->stream));
   return 0;
 }
 

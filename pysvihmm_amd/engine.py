@@ -463,6 +463,12 @@ class HipEngine(object):
         L.check(self._lib.svihmm_svi_read_state(self._h, *[L.dptr(a) for a in out]), "svihmm_svi_read_state")
         return tuple(out)
 
+    def read_globals(self):
+        """(mod_init [K], ltran [K,K]) as the recursions currently hold them."""
+        mi, lt = np.empty(self.K), np.empty((self.K, self.K))
+        L.check(self._lib.svihmm_read_globals(self._h, L.dptr(mi), L.dptr(lt)), "svihmm_read_globals")
+        return mi, lt
+
     # -- multi-GPU ------------------------------------------------------------------------
     def comm_unique_id(self):
         buf = C.create_string_buffer(128)

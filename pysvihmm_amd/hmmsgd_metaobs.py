@@ -485,6 +485,9 @@ class VBHMM(VariationalHMMBase):
         e, ms = eng.svi_read_elbo(maxit)
         self.elbo_vec[:] = e
         self.iter_time[:] = ms * 1e-3
+        # the reference leaves the last computation's psi-expectations on the object (:502-504)
+        if hasattr(eng, "read_globals"):
+            self.mod_init, self.mod_tran = eng.read_globals()
         if "_pending_rows" not in self.__dict__ and "_val_done" not in self.__dict__:
             self._register_last_window(eng, last)
         self.__dict__.pop("_val_done", None)

@@ -303,3 +303,38 @@ def test_device_loop_edge_shapes(K, D, Lm, S):
     for a, b in zip(res[0][0], res[1][0]):
         np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-9)
+
+
+def test_device_loop_leaves_psi_expectations_and_iteration_times():
+    """mod_init / mod_tran after the device-resident loop == the host loop's (the last iteration's
+    psi-expectations, reference hmmsgd_metaobs.py:502-504); iter_time covers the iteration itself
+    (first to last launch), not the host's pause before the next one."""
+    import time
+    from pysvihmm_amd import hmmsgd_metaobs
+    from pysvihmm_amd.distributions import Gaussian
+    from pysvihmm_amd.engine import HipEngine
+    from tests.helpers import make_problem
+    K, D, T = 4, 2, 3000
+    pb = make_problem(K, D, T, seed=5)
+    e = HipEngine(0)
+    runs = []
+    try:
+        for dl in (None, False):
+            np.random.seed(1)
+            prior = np.array([Gaussian(mu_0=pb["obs"].mean(0), sigma_0=0.75 * np.cov(pb["obs"].T), kappa_0=0.01,
+                                       nu_0=D + 2) for _ in range(K)])
+            m = hmmsgd_metaobs.VBHMM(pb["obs"], np.ones(K), np.ones((K, K)), prior, tau=1.0, kappa=0.7, metaobs_half=6,
+                                     mb_sz=5, maxit=6, seed=3, engine=e)
+            if dl is None:       # a slow host between the iterations must not show in iter_time
+                orig = e.svi_iteration
+                e.svi_iteration = lambda *a, **k: (time.sleep(0.02), orig(*a, **k))[1]
+            m.infer(device_loop=dl)
+            if dl is None:
+                del e.svi_iteration
+            runs.append(m)
+    finally:
+        e.close()
+    a, b = runs
+    np.testing.assert_allclose(a.mod_tran, b.mod_tran, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(a.mod_init, b.mod_init, rtol=1e-6, atol=1e-8)
+    assert np.all(a.iter_time > 0) and np.all(a.iter_time < 0.01), a.iter_time

@@ -335,3 +335,28 @@ def test_overridden_hooks_are_honoured():
     x1 = c.full_local_update()
     d.full_local_update()
     np.testing.assert_array_equal(c.full_local_update(), x1)
+
+
+def test_device_loop_leaves_the_last_iterations_psi_expectations():
+    """After infer() the reference's object holds mod_init / mod_tran of the LAST iteration
+    (hmmsgd_metaobs.py:502-504, computed before that iteration's global step); the loop with the
+    state resident in the engine must leave the same (round-2 advisor finding)."""
+    from pysvihmm_amd import hmmsgd_metaobs
+    from pysvihmm_amd.distributions import Gaussian
+    from oracle.engine import OracleEngine
+    from tests.helpers import make_problem
+    K, D, T = 4, 2, 600
+    pb = make_problem(K, D, T, seed=5)
+    runs = []
+    for dl in (None, False):
+        np.random.seed(1)
+        prior = np.array([Gaussian(mu_0=pb["obs"].mean(0), sigma_0=0.75 * np.cov(pb["obs"].T), kappa_0=0.01, nu_0=D + 2)
+                          for _ in range(K)])
+        m = hmmsgd_metaobs.VBHMM(pb["obs"], np.ones(K), np.ones((K, K)), prior, tau=1.0, kappa=0.7, metaobs_half=6,
+                                 mb_sz=5, maxit=4, seed=3, engine=OracleEngine())
+        m.infer(device_loop=dl)
+        runs.append(m)
+    a, b = runs
+    np.testing.assert_allclose(a.var_tran, b.var_tran, rtol=1e-9)
+    np.testing.assert_allclose(a.mod_tran, b.mod_tran, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(a.mod_init, b.mod_init, rtol=1e-7, atol=1e-9)
