@@ -388,7 +388,9 @@ const char* svihmm_kernel_name(int32_t slot);
  * | 2 sweeps (1 wave-per-window, 2 log-domain MFMA, 3 scaled linear-domain MFMA)
  * | 3 emission row tiles per wave | 4 two-stream E-step pipeline (1 off, 2 on; default off)
  * | 6 blocked scan for one long window (B = 1, Lm >= 2048, K <= 64; 1 = off)
- * | 9 automatic centring of the resident observations at upload (1 = off: c = 0) */
+ * | 9 automatic centring of the resident observations at upload (1 = off: c = 0)
+ * | 11 svihmm_allreduce_packed forms the sum in caller coordinates also at one rank (1 = on: the
+ *      multi-rank path's coordinate round trip, exercised on a single GPU) */
 int svihmm_set_variant(svihmm_ctx* h, int32_t which, int32_t value);
 
 /* ---- diagnostics ------------------------------------------------------------------- */

@@ -2075,7 +2075,7 @@ static int read_packed_host(svihmm_ctx* h, double* out) {
 // rank has its own shift: the sum is formed in the callers' common coordinates and brought back.
 static int allreduce_packed_dev(svihmm_ctx* h) {
   const size_t n = (size_t)packed_len(h);
-  if (h->shifted && !h->emis_cat && h->nranks > 1) {
+  if (h->shifted && !h->emis_cat && (h->nranks > 1 || h->variant[11] == 1)) {   // (variant 11: rehearsal at one rank)
     CK(ensure(h->commtmp, n * sizeof(double)));
     double* tmp = (double*)h->commtmp.p;
     const unsigned nb = (unsigned)((n + 255) / 256);

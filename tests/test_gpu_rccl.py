@@ -111,3 +111,60 @@ def test_bench_refuses_more_gpus_than_visible():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n + 1)], cwd=REPO,
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "{" not in r.stdout
+
+
+def test_allreduce_in_caller_coordinates_rehearsal(tmp_path):
+    """Every rank's handle has its own centre, so the multi-rank all-reduce forms the sum in the
+    ranks' common caller coordinates (k_packed_shift +1 -> ncclAllReduce -> -1).  That round trip
+    only runs at nranks > 1; variant 11 switches it on at one rank: statistics after the
+    all-reduce == statistics before it (NIW and diagonal family, data far from the origin), and
+    the device-resident SVI loop (which all-reduces inside svihmm_svi_iteration) is unchanged."""
+    from pysvihmm_amd.comm import RcclComm, file_uid_exchange
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import hmmsgd_metaobs
+    from pysvihmm_amd.distributions import Gaussian
+    from pysvihmm_amd import _lib as L
+    from tests.helpers import make_problem
+    K, D, T = 5, 3, 1500
+    pb = make_problem(K, D, T, seed=4, sep=3.0)
+    off = np.array([2e3, -40.0, 0.5])
+    obs, mu = pb["obs"] + off, pb["mu"] + off
+    starts = np.arange(40, dtype=np.int64) * 33
+    e = HipEngine(0)
+    try:
+        comm = RcclComm(e, 0, 1, file_uid_exchange(0, tag="rehearsal_%d" % os.getpid(), directory=str(tmp_path)))
+        e.set_obs(obs, None)
+        assert np.all(np.abs(e.get_shift() - off) < 10.0)
+        e.set_globals(pb["mod_init"], pb["ltran"])
+        rng = np.random.default_rng(0)
+        diag = (mu, 0.5 + rng.random((K, D)), 2.0 + rng.random((K, D)), 1.0 + rng.random((K, D)))
+        for upload in (lambda: e.set_emission_niw(mu, pb["sigma"], pb["kappa"], pb["nu"]),
+                       lambda: e.set_emission_diag(*diag)):
+            upload()
+            ref = e.estep(starts, 33, flags=L.TRANS_WRAP).buf.copy()
+            for v in (0, 1):
+                e.set_variant(11, v)
+                e.estep(starts, 33, flags=L.TRANS_WRAP, read=False)
+                e.allreduce_packed()
+                got = e.read_packed().buf
+                np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-9 * np.abs(ref).max())
+            e.set_variant(11, 0)
+        # the loop with the all-reduce inside the iteration
+        res = []
+        for v in (0, 1):
+            e.set_variant(11, v)
+            np.random.seed(2)
+            prior = np.array([Gaussian(mu_0=obs.mean(0), sigma_0=0.75 * np.cov(obs.T), kappa_0=0.01, nu_0=D + 2)
+                              for _ in range(K)])
+            m = hmmsgd_metaobs.VBHMM(obs, np.ones(K), np.ones((K, K)), prior, tau=1.0, kappa=0.7, metaobs_half=8,
+                                     mb_sz=6, maxit=5, seed=4, engine=e, comm=comm)
+            m.infer()
+            res.append(m)
+        np.testing.assert_allclose(res[1].var_tran, res[0].var_tran, rtol=1e-9)
+        np.testing.assert_allclose(res[1].elbo_vec, res[0].elbo_vec, rtol=1e-9)
+        for k in range(K):
+            np.testing.assert_allclose(res[1].var_emit[k].mu_mf, res[0].var_emit[k].mu_mf, rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(res[1].var_emit[k].sigma_mf, res[0].var_emit[k].sigma_mf, rtol=1e-8, atol=1e-9)
+    finally:
+        e.set_variant(11, 0)
+        e.close()
