@@ -2057,6 +2057,79 @@ __global__ __launch_bounds__(256) void k_lbeta_fix(
   }
 }
 
+// The same two repairs for wide models (64 < K <= 1024): one wave per row, lane = states lane + 64 q;
+// the transition expectations are read from L2 (column / row accesses coalesce over the lanes) --
+// only rows that hold an underflowed entry pay for it.
+__global__ __launch_bounds__(256) void k_lalpha_fix_wide(
+    const double* __restrict__ src, const double* __restrict__ ah, const double* __restrict__ ll,
+    const double* __restrict__ ltran, const double* __restrict__ mod_init, int64_t T, int K,
+    double* __restrict__ dst) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  for (int64_t t = r0 + wave; t < r0 + 64 && t < T; t += 4) {
+    bool any = false;
+    for (int j = lane; j < K; j += 64) any = any || ah[t * K + j] < 1e-200;
+    const bool fix_row = __ballot(any) != 0ull;
+    const double* __restrict__ pr = src + (t > 0 ? t - 1 : 0) * K;
+    for (int j0 = 0; j0 < K; j0 += 64) {
+      const int j = j0 + lane;
+      const bool vj = j < K;
+      const int jc = vj ? j : 0;
+      double v = vj ? src[t * K + j] : 0.0;
+      const bool need = fix_row && vj && ah[t * K + j] < 1e-200;
+      if (__ballot(need) != 0ull) {
+        double fixed;
+        if (t == 0) fixed = mod_init[jc] + ll[jc];
+        else {
+          double m = -INFINITY;
+          for (int i = 0; i < K; ++i) m = fmax(m, pr[i] + ltran[(size_t)i * K + jc]);
+          double sm = 0.0;
+          for (int i = 0; i < K; ++i) sm += exp(pr[i] + ltran[(size_t)i * K + jc] - m);
+          fixed = (m > -INFINITY ? m + log(sm) : -INFINITY) + ll[t * K + jc];
+        }
+        if (need) v = fixed;
+      }
+      if (vj) dst[t * K + j] = v;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_lbeta_fix_wide(
+    const double* __restrict__ src, const double* __restrict__ bh, const double* __restrict__ ll,
+    const double* __restrict__ ltran, int64_t T, int K, double* __restrict__ dst) {
+  extern __shared__ double fw_s[];              // [4 waves][K]: lbeta_{t+1} + ll_{t+1} of the wave's row
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* __restrict__ nx = fw_s + (size_t)wave * K;
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  for (int64_t t = r0 + wave; t < r0 + 64 && t < T; t += 4) {
+    bool any = false;
+    for (int i = lane; i < K; i += 64) any = any || bh[t * K + i] < 1e-200;
+    const bool fix_row = __ballot(any) != 0ull;
+    if (fix_row && t < T - 1)
+      for (int j = lane; j < K; j += 64) nx[j] = src[(t + 1) * K + j] + ll[(t + 1) * K + j];
+    __builtin_amdgcn_wave_barrier();
+    for (int i0 = 0; i0 < K; i0 += 64) {
+      const int i = i0 + lane;
+      const bool vi = i < K;
+      const int ic = vi ? i : 0;
+      double v = vi ? src[t * K + i] : 0.0;
+      const bool need = fix_row && vi && bh[t * K + i] < 1e-200;
+      if (need) {                                   // (rows of ltran: a lane walks its own row)
+        if (t == T - 1) v = 0.0;
+        else {
+          const double* __restrict__ lr = ltran + (size_t)ic * K;
+          double m = -INFINITY;
+          for (int j = 0; j < K; ++j) m = fmax(m, nx[j] + lr[j]);
+          double sm = 0.0;
+          for (int j = 0; j < K; ++j) sm += exp(nx[j] + lr[j] - m);
+          v = m > -INFINITY ? m + log(sm) : -INFINITY;
+        }
+      }
+      if (vi) dst[t * K + i] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 template <int KMAX>
 __global__ __launch_bounds__(64) void k_ffbs_paths(
     const double* __restrict__ la, const double* __restrict__ logA, const double* __restrict__ unif,

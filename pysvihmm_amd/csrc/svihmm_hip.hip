@@ -1590,7 +1590,9 @@ static int pick_fb(const svihmm_ctx* h, int B, int Lm, bool want_logs) {
   if (h->K > 256 || h->exact_log) return 1;
   if (h->K > 64) {   // no log-domain MFMA sweep beyond 64 states: scaled (streamed B) or per-window
     if (var == 2) var = 1;
-    if (var == 0) var = ((B >= 192 || use_chain(h, B, Lm)) && !want_logs) ? 3 : 1;   // one long chain: blocked scan
+    // one long chain: blocked scan (its messages convert to logs row by row, see materialise);
+    // large batches: scaled sweeps unless the logs themselves are wanted
+    if (var == 0) var = (use_chain(h, B, Lm) || (B >= 192 && !want_logs)) ? 3 : 1;
     if (var == 3 && !use_chain(h, B, Lm) && (size_t)16 * Lm * h->K * sizeof(double) >= ((size_t)1 << 32)) var = 1;
     return var;
   }
@@ -1980,7 +1982,7 @@ static int materialise(svihmm_ctx* h, int b0, int nb) {
                        (double*)h->m_ll.p));
     ll = (const double*)h->m_ll.p;
   }
-  if (h->lastB == 1 && K <= 64 && h->chain_T == Lm && h->chain_kbef && use_chain(h, 1, Lm)) {
+  if (h->lastB == 1 && K <= 256 && h->chain_T == Lm && h->chain_kbef && use_chain(h, 1, Lm)) {
     // the blocked scan's messages -> logs (k_chain_lalpha both ways), entries lost to underflow
     // recomputed in the log domain row by row (k_lalpha_fix / k_lbeta_fix): no sequential pass
     const size_t ne = (size_t)Lm * K;
@@ -2006,7 +2008,15 @@ static int materialise(svihmm_ctx* h, int b0, int nb) {
     hipLaunchKernelGGL(k_lbeta_fix<KM>, dim3(nblk), dim3(256), 0, h->stream, (const double*)tb,                   \
                        (const double*)h->lb.p, ll, (const double*)h->ltran.p, T, K, (double*)h->m_lb.p);          \
   } while (0)
-    if (K <= 16) LFIX(16); else if (K <= 32) LFIX(32); else LFIX(64);
+    if (K <= 16) LFIX(16); else if (K <= 32) LFIX(32); else if (K <= 64) LFIX(64);
+    else {
+      hipLaunchKernelGGL(k_lalpha_fix_wide, dim3(nblk), dim3(256), 0, h->stream, (const double*)ta,
+                         (const double*)h->la.p, ll, (const double*)h->ltran.p, (const double*)h->mod_init.p, T, K,
+                         (double*)h->m_la.p);
+      hipLaunchKernelGGL(k_lbeta_fix_wide, dim3(nblk), dim3(256), (size_t)4 * K * sizeof(double), h->stream,
+                         (const double*)tb, (const double*)h->lb.p, ll, (const double*)h->ltran.p, T, K,
+                         (double*)h->m_lb.p);
+    }
 #undef LFIX
     HIPCK(hipGetLastError());
   } else {

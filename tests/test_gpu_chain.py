@@ -123,7 +123,10 @@ def test_ffbs_long_chain_blocked(K, T, D, sep):
     e.close()
 
 
-@pytest.mark.parametrize("K,T,D,sep", [(7, 4100, 3, 2.0), (16, 6000, 8, 14.0), (64, 5000, 16, 9.0)])
+# ... and wide models (64 < K <= 256: k_lalpha_fix_wide / k_lbeta_fix_wide, round 3)
+@pytest.mark.parametrize("K,T,D,sep", [(7, 4100, 3, 2.0), (16, 6000, 8, 14.0), (64, 5000, 16, 9.0),
+                                       (80, 2600, 3, 2.0), (100, 3000, 4, 12.0), (200, 2400, 3, 20.0),
+                                       (256, 2500, 2, 15.0)])
 def test_chain_logs_from_scaled_messages(K, T, D, sep):
     """lalpha / lbeta of one long chain (hmmbase.local_update's attributes) come from the blocked
     scan's scaled messages plus a row-parallel log-domain fix-up of underflowed entries -- no
