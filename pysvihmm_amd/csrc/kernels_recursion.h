@@ -2197,6 +2197,80 @@ __global__ __launch_bounds__(64) void k_ffbs_paths(
   }
 }
 
+// P1 for wide models (64 < K <= 256; states still fit the one-byte path entries): one workgroup of
+// 256 threads per chunk, thread = entry state.  Until the paths have coupled every thread draws for
+// its own current state (three passes over the K source states: maximum, total, inverse CDF -- the
+// transition column comes from L2); afterwards one cooperative draw per row, thread = state, with
+// workgroup-wide maximum / total / inclusive scan through LDS.  Same arithmetic per draw as
+// k_ffbs_paths (u * sum_k p_k <= cumsum_k p_k, terms in state order).
+__global__ __launch_bounds__(256) void k_ffbs_paths_wide(
+    const double* __restrict__ la, const double* __restrict__ logA, const double* __restrict__ unif,
+    int64_t T, int K, int Ls, unsigned char* __restrict__ path) {
+  __shared__ double rw[256];          // the lalpha row of the step
+  __shared__ double red[8];           // per-wave partials of the cooperative draw
+  __shared__ int flag[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t lo = (int64_t)blockIdx.x * Ls;
+  const int64_t hi = lo + Ls < T ? lo + Ls : T;
+  const bool vs = tid < K;
+  int cur = vs ? tid : 0;
+  bool coupled = false;
+  for (int64_t t = hi - 1; t >= lo; --t) {
+    const bool first = t == T - 1;
+    const double r = unif[t];
+    __syncthreads();                                  // (previous row's readers are done)
+    rw[tid] = vs ? la[t * K + tid] : -INFINITY;
+    if (tid == 0) { flag[0] = 0; }
+    __syncthreads();
+    if (!coupled) {
+      const double* __restrict__ col = logA + cur;    // logA[k][cur] = col[k * K]
+      double m = -INFINITY;
+      for (int k = 0; k < K; ++k) m = fmax(m, rw[k] + (first ? 0.0 : col[(size_t)k * K]));
+      double tot = 0.0;
+      for (int k = 0; k < K; ++k) tot += exp(rw[k] + (first ? 0.0 : col[(size_t)k * K]) - m);
+      const double thr = r * tot;
+      double c = 0.0;
+      int zz = K - 1;
+      for (int k = 0; k < K; ++k) {
+        c += exp(rw[k] + (first ? 0.0 : col[(size_t)k * K]) - m);
+        if (thr <= c) { zz = k; break; }
+      }
+      cur = zz;
+      if (tid == 0) flag[1] = cur;
+      __syncthreads();
+      if (vs && cur != flag[1]) flag[0] = 1;          // benign race: any writer writes 1
+      __syncthreads();
+      coupled = flag[0] == 0;
+    } else {
+      // cooperative draw, thread = state k (all threads hold the same `cur`)
+      const double lp = vs ? rw[tid] + (first ? 0.0 : logA[(size_t)tid * K + cur]) : -INFINITY;
+      double wm = wave_max(lp);
+      if (lane == 0) red[wave] = wm;
+      __syncthreads();
+      const double m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+      const double pk = vs ? exp(lp - m) : 0.0;
+      double c = pk;                                  // inclusive scan inside the wave, state order
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const double v = __shfl_up(c, o, 64);
+        if (lane >= o) c += v;
+      }
+      if (lane == 63) red[4 + wave] = c;
+      __syncthreads();
+      double before = 0.0;
+      for (int w2 = 0; w2 < wave; ++w2) before += red[4 + w2];
+      const double tot = ((red[4] + red[5]) + red[6]) + red[7];
+      c += before;
+      const unsigned long long bal = __ballot(vs && r * tot <= c);
+      if (lane == 0) red[wave] = bal ? (double)(wave * 64 + __ffsll((long long)bal) - 1) : 1e9;
+      __syncthreads();
+      const double f = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+      cur = f < 1e8 ? (int)f : K - 1;
+    }
+    path[t * 256 + tid] = (unsigned char)cur;
+  }
+}
+
 // P2: maps[c][s] = state at the first row of chunk c given entry state s (= path row lo_c);
 // suffix composition H_c = G_c o G_{c+1} o ... ; entry[c] = H_{c+1}(0) (last chunk: 0, unused).
 __global__ __launch_bounds__(1024) void k_ffbs_compose(const unsigned char* __restrict__ path, int64_t T,

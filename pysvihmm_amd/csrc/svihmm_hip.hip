@@ -2671,8 +2671,8 @@ int svihmm_state_argmax(svihmm_ctx* h, const int32_t* true_sts, int32_t* out_z,
 // sampler.  *dz_out: device int64[T] (in h->scratch), valid until the next call.
 static int ffbs_draw(svihmm_ctx* h, const double* la, int64_t T, int K, const double* logA,
                      const double* uniforms, int64_t** dz_out) {
-  const bool blocked = K <= 64 && T >= 1024 && h->variant[6] != 1;
-  const int KS = K <= 16 ? 16 : K <= 32 ? 32 : 64;
+  const bool blocked = K <= 256 && T >= 1024 && h->variant[6] != 1;
+  const int KS = K <= 16 ? 16 : K <= 32 ? 32 : K <= 64 ? 64 : 256;      // path entries per row
   const int Ls = T >= 65536 ? 512 : 256;
   const int Cs = (int)((T + Ls - 1) / Ls);
   const size_t base = ((size_t)K * K + (size_t)T) * sizeof(double) + (size_t)T * sizeof(int64_t);
@@ -2694,7 +2694,10 @@ static int ffbs_draw(svihmm_ctx* h, const double* la, int64_t T, int K, const do
 #define FPATH(KM)                                                                                          \
   hipLaunchKernelGGL(k_ffbs_paths<KM>, dim3(Cs), dim3(64), ((size_t)K * (KM + 1) + 2 * KM) * sizeof(double), \
                      h->stream, la, (const double*)dlogA, (const double*)dun, T, K, Ls, path)
-      if (KS == 16) FPATH(16); else if (KS == 32) FPATH(32); else FPATH(64);
+      if (KS == 16) FPATH(16); else if (KS == 32) FPATH(32); else if (KS == 64) FPATH(64);
+      else
+        hipLaunchKernelGGL(k_ffbs_paths_wide, dim3(Cs), dim3(256), 0, h->stream, la, (const double*)dlogA,
+                           (const double*)dun, T, K, Ls, path);
 #undef FPATH
       hipLaunchKernelGGL(k_ffbs_compose, dim3(1), dim3(1024), 0, h->stream, (const unsigned char*)path, T, KS,
                          Ls, Cs, mA, mB, entry);
@@ -2723,7 +2726,7 @@ int svihmm_ffbs(svihmm_ctx* h, const double* logA, const double* uniforms, uint3
   // forward filter: long chains through the exact blocked scan (scaled sweeps), then lalpha
   // from (ah, h, K); short ones with the per-window log-domain kernel
   const double* la = nullptr;
-  if (K <= 64 && use_chain(h, 1, (int)T)) {
+  if (K <= 256 && use_chain(h, 1, (int)T)) {
     CK(prepare_ll(h, &st0, 1, (int)T, flags, false, true));
     CK(launch_fb_chain(h, (int)T, false));
     CK(ensure(h->m_la, (size_t)T * K * sizeof(double)));
@@ -2748,7 +2751,10 @@ int svihmm_ffbs(svihmm_ctx* h, const double* logA, const double* uniforms, uint3
 #define LFIX(KM) hipLaunchKernelGGL(k_lalpha_fix<KM>, dim3(nblk), dim3(256), 0, h->stream, la, (const double*)h->la.p, \
                                     llp, (const double*)h->ltran.p,                                              \
                                     (const double*)h->mod_init.p, T, K, (double*)h->m_lb.p)
-      if (K <= 16) LFIX(16); else if (K <= 32) LFIX(32); else LFIX(64);
+      if (K <= 16) LFIX(16); else if (K <= 32) LFIX(32); else if (K <= 64) LFIX(64);
+      else
+        hipLaunchKernelGGL(k_lalpha_fix_wide, dim3(nblk), dim3(256), 0, h->stream, la, (const double*)h->la.p, llp,
+                           (const double*)h->ltran.p, (const double*)h->mod_init.p, T, K, (double*)h->m_lb.p);
 #undef LFIX
       HIPCK(hipGetLastError());
       la = (const double*)h->m_lb.p;
