@@ -51,6 +51,9 @@ sys.path.insert(0, REPO)
 if os.environ.get("NCCL_DEBUG", "").upper() in ("VERSION", "INFO"):
     del os.environ["NCCL_DEBUG"]
 os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")   # whatever RCCL still says: not on stdout
+# one node by contract (--gpus N of ONE node, rendezvous on 127.0.0.1): RCCL's bootstrap sockets on
+# the loopback interface -- the GPU boxes have no network, and an unrelated interface must not be picked
+os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
 
 K, D, T, LHALF = 64, 32, 1000000, 128
 LM = 2 * LHALF + 1

@@ -73,6 +73,39 @@ def test_diag_estep_vs_oracle(K, D, T, B, Lm, off):
         e.close()
 
 
+def test_diag_parameters_follow_the_centre():
+    """The diagonal factors on the device live in centred coordinates like the NIW ones: an explicit
+    shift of the centre and a re-upload of the observations under live factors change nothing."""
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    from oracle.engine import OracleEngine
+    K, D, T, Lm = 6, 4, 1500, 33
+    pb = make_problem(K, D, T, seed=9, miss=0.05)
+    obs = pb["obs"] + np.array([300.0, -2e4, 0.0, 5.0])
+    mu, nus, al, be = _diag_params(pb, 2)
+    mu = mu + np.array([300.0, -2e4, 0.0, 5.0])
+    starts = np.arange(40, dtype=np.int64) * 33
+    e, o = HipEngine(0), OracleEngine()
+    try:
+        for eng in (e, o):
+            eng.set_obs(obs, pb["mask"])
+            eng.set_globals(pb["mod_init"], pb["ltran"])
+            eng.set_emission_diag(mu, nus, al, be)
+        ref = o.estep(starts, Lm, flags=L.TRANS_WRAP)
+        _close(e.estep(starts, Lm, flags=L.TRANS_WRAP), ref, K, D, 40 * Lm, 2e4)
+        e.shift_obs(np.array([1.0, -7.0, 0.25, 100.0]))
+        _close(e.estep(starts, Lm, flags=L.TRANS_WRAP), ref, K, D, 40 * Lm, 2e4)
+        e.set_obs(obs, pb["mask"])                      # new centre chosen, factors stay
+        _close(e.estep(starts, Lm, flags=L.TRANS_WRAP), ref, K, D, 40 * Lm, 2e4)
+        e.set_variant(9, 1)                             # ... also when the new centre is the origin
+        e.set_obs(obs[:, :], pb["mask"])
+        e.set_variant(9, 0)
+        e.shift_obs(obs[~pb["mask"]].mean(0))
+        _close(e.estep(starts, Lm, flags=L.TRANS_WRAP), ref, K, D, 40 * Lm, 2e4)
+    finally:
+        e.close()
+
+
 def test_diag_refuses_bad_parameters():
     from pysvihmm_amd.engine import HipEngine
     pb = make_problem(4, 3, 300, seed=1)
