@@ -440,6 +440,7 @@ static int params_follow_centre(svihmm_ctx* h, const double* delta) {
   const bool svi = h->svi_active && h->svi_D == D;
   if (!any || (!live && !svi)) return 0;
   CK(wait_side_streams(h));
+  if (live) CK(drop_auto_status(h));      // this rebuild supersedes what an earlier automatic one reported
   void* pin = nullptr;
   int slot = 0;
   CK(pinned(h, (size_t)D * sizeof(double), &pin, &slot));
