@@ -153,7 +153,7 @@ int svihmm_set_globals(svihmm_ctx* h, int32_t K, const double* mod_init,
  * evaluates the quadratic form expanded around c -- would lose more than 5e-7 in the
  * log-likelihoods; svihmm_shift_obs moves the centre.
  * D <= SVIHMM_NIW_MAX_D; wider observations go the svihmm_set_lliks route (the classes do). */
-#define SVIHMM_NIW_MAX_D 79
+#define SVIHMM_NIW_MAX_D 96
 int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* mu,
                             const double* sigma, const double* kappa,
                             const double* nu);

@@ -20,7 +20,7 @@ KEEP_LBETA = 8
 SVI_KEEP_WINDOW = 16
 SVI_MIN_PSEUDOCOUNT = 2.5e-3      # include/svihmm.h: smaller Dirichlet pseudo-counts take the per-call route
 LTRAN_LINEAR_MIN = -600.0
-NIW_MAX_D = 79                    # wider observations: host-evaluated lliks (generic plugin route)
+NIW_MAX_D = 96                    # wider observations: host-evaluated lliks (generic plugin route)
 DIAG_MAX_D = 128                  # diagonal family on the device up to this width
 LTRAN_F32_MIN = -60.0
 F64, F32 = 0, 1

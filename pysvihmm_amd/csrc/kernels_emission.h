@@ -528,10 +528,11 @@ __global__ __launch_bounds__(256) void k_niw_to_theta_generic(
     double* __restrict__ logdet_out) {
   extern __shared__ double sm[];
   const int S = D + 1;
-  double* Lm_ = sm;            // [D][S] Cholesky factor (lower)
+  double* Lm_ = sm;            // [D][S] Cholesky factor (lower); once its inverse stands: W
   double* Li = Lm_ + D * S;    // [D][S] its inverse (lower)
-  double* W = Li + D * S;      // [D][S]
-  double* wm = W + D * S;      // [D]
+  double* W = Lm_;             // [D][S] (nu/2) sigma^-1 takes the factor's place (its diagonal is kept in ld)
+  double* wm = Li + D * S;     // [D]
+  double* ld = wm + D;         // [D] diagonal of the Cholesky factor
   __shared__ int bad;
   const int k = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const double* Sg = sigma + (size_t)k * D * D;
@@ -574,6 +575,8 @@ __global__ __launch_bounds__(256) void k_niw_to_theta_generic(
     }
   }
   __syncthreads();
+  for (int i = tid; i < D; i += nt) ld[i] = Lm_[i * S + i];
+  __syncthreads();
   const double hn = 0.5 * nu[k];
   for (int e = tid; e < D * D; e += nt) {
     const int i = e / D, j = e - i * D;
@@ -599,7 +602,7 @@ __global__ __launch_bounds__(256) void k_niw_to_theta_generic(
   if (tid == 0) {
     double logdet = 0.0, llt = D * log(2.0), mWm = 0.0;
     for (int i = 0; i < D; ++i) {
-      logdet += log(Lm_[i * S + i]);
+      logdet += log(ld[i]);
       llt += digamma_d(0.5 * (nu[k] - i));
       mWm += m[i] * wm[i];
     }

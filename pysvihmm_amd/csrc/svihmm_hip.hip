@@ -726,7 +726,7 @@ static int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out) 
     else if (D <= 32) NIWW(32);
     else if (D <= 64) NIWW(64);
     else {
-      const size_t lds = (size_t)(3 * D * (D + 1) + D) * sizeof(double);
+      const size_t lds = (size_t)(2 * D * (D + 1) + 2 * D) * sizeof(double);
       if (lds > 64 * 1024)
         hipFuncSetAttribute((const void*)k_niw_to_theta_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(k_niw_to_theta_generic, dim3(K), dim3(256), lds, h->stream, (const double*)dmu,
@@ -787,7 +787,7 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
                             const double* sigma, const double* kappa, const double* nu) {
   if (!h || K <= 0 || D <= 0 || !mu || !sigma || !kappa || !nu)
     return fail("svihmm_set_emission_niw: bad arguments");
-  if (D > SVIHMM_NIW_MAX_D)   // (k_niw_to_theta_generic keeps three D x (D+1) matrices in LDS)
+  if (D > SVIHMM_NIW_MAX_D)   // (k_niw_to_theta_generic keeps two D x (D+1) matrices in LDS)
     return fail("svihmm_set_emission_niw: D > SVIHMM_NIW_MAX_D: evaluate the expected log-likelihoods on the "
                 "host and pass them with svihmm_set_lliks / SVIHMM_USE_HOST_LLIKS");
   CK(set_device(h));

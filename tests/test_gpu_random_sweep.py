@@ -137,10 +137,12 @@ def test_models_beyond_256_states(case):
 
 
 @pytest.mark.parametrize("case", [(5, 65, 33, 20, 3.0, 0.1, False, False), (16, 72, 17, 300, 3.0, 0.0, False, True),
-                                  (64, 79, 65, 250, 3.0, 0.0, False, False)],
+                                  (64, 79, 65, 250, 3.0, 0.0, False, False), (8, 80, 33, 40, 3.0, 0.1, False, False),
+                                  (32, 96, 17, 260, 3.0, 0.0, False, False)],
                          ids=lambda c: "K%d_D%d_Lm%d_B%d" % c[:4])
 def test_observations_up_to_the_niw_kernels_width(case):
-    """D in (64, SVIHMM_NIW_MAX_D = 79]: generic NIW -> theta kernel, emission / statistics fallbacks."""
+    """D in (64, SVIHMM_NIW_MAX_D = 96]: generic NIW -> theta kernel (two D x (D+1) matrices in LDS since
+    round 3; 79 before), emission / statistics fallbacks."""
     from tests.fuzz_gpu import run_case
     from pysvihmm_amd.engine import HipEngine
     from pysvihmm_amd import _lib as L
