@@ -389,6 +389,7 @@ const char* svihmm_kernel_name(int32_t slot);
  * | 3 emission row tiles per wave | 4 two-stream E-step pipeline (1 off, 2 on; default off)
  * | 6 blocked scan for one long window (B = 1, Lm >= 2048, K <= 64; 1 = off)
  * | 9 automatic centring of the resident observations at upload (1 = off: c = 0)
+ * | 12 barrier-free statistics GEMM with three LDS buffers (1 = off: the double-buffered kernel)
  * | 11 svihmm_allreduce_packed forms the sum in caller coordinates also at one rank (1 = on: the
  *      multi-rank path's coordinate round trip, exercised on a single GPU) */
 int svihmm_set_variant(svihmm_ctx* h, int32_t which, int32_t value);

@@ -1739,6 +1739,23 @@ static int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, in
       } else {
         const int MTs = stats_mt(h);
         dim3 grid((unsigned)nchunk, (mt_limit + 4 * MTs - 1) / (4 * MTs), big ? Kp / 64 : 1);
+        // four state tiles, five feature tiles per wave, scaled sweeps (the K = 64 epoch shapes): the
+        // barrier-free stage loop with three LDS buffers, where they fit (D <= 55)
+        const size_t lds3 = ((size_t)(D + 3 + KpW) * (3 * ST_CS + 2) + 3 * (size_t)ST_RB * (KpW + 1)) * 8 +
+                            4 * ST_RB * sizeof(StRow4) + 16;
+        const bool tb = lin && !big && NTt == 4 && MTs == 5 && lds3 <= 160 * 1024 && h->variant[12] != 1;
+        if (tb) {
+#define ST3T(XKV)                                                                                              \
+  do {                                                                                                         \
+    hipFuncSetAttribute((const void*)k_stats_mfma4<5, 2, 2, XKV, true, false, double, double, 3>,              \
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);                                \
+    hipLaunchKernelGGL((k_stats_mfma4<5, 2, 2, XKV, true, false, double, double, 3>), grid, dim3(512), lds3,   \
+                       stream, (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, Fp, F,                    \
+                       (const int*)h->fab.p, qv, rpc, flags, Lq, off, partv, Kp, mt_limit, bhv, hxv, gxv, zfv); \
+  } while (0)
+          if (xk <= 1) ST3T(1); else if (xk <= 3) ST3T(3); else if (xk <= 5) ST3T(5); else ST3T(9);
+#undef ST3T
+        } else {
 #define ST3L(MTV, NTW, NS, XKV, LN)                                                               \
   do {                                                                                           \
     if (lds > 64 * 1024)                                                                         \
@@ -1759,6 +1776,7 @@ static int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, in
 #undef ST3X
 #undef ST3
 #undef ST3L
+        }
         if (big) {   // transition tiles: one 64 x 64 (previous state, state) block per workgroup
           dim3 g2((unsigned)nchunk, Kp / 64, Kp / 64);
 #define STT(XKV)                                                                                  \
