@@ -1331,63 +1331,66 @@ __device__ __forceinline__ void fmac_row_bcast(double& acc, double p, double a) 
     asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
                  : "+v"(acc) : "v"(p), "v"(a), "n"(N));
 }
-template <int KMAX, typename ST = double>
-__global__ __launch_bounds__(256) void k_wave_lin4(
+// The body is instantiated per direction and for K = 64 exactly (FULLK): at one wave per SIMD a
+// step is instruction-issue bound, so the direction selects, validity selects and 64-bit row
+// address products of a generic body are what it would spend its time on (running pointers here).
+template <bool FWD, bool FULLK, typename ST>
+__device__ __forceinline__ void wave_lin4_body(
     const ST* __restrict__ Eh, const double* __restrict__ kexp,
-    const double* __restrict__ Aexp, const double* __restrict__ AexpT,
-    const double* __restrict__ mod_init, const double* __restrict__ ll0, size_t l0stride, int Lm,
-    int K, ST* __restrict__ ah,
-    ST* __restrict__ bh, double* __restrict__ hx, double* __restrict__ gx,
-    double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac) {
-  static_assert(KMAX == 64, "lane = state, four source blocks of 16");
-  __shared__ double part[2][4][64];             // [step parity][source block][target], double-buffered
+    const double* __restrict__ Am, const double* __restrict__ mod_init,
+    const double* __restrict__ ll0, size_t l0stride, int Lm, int K, ST* __restrict__ out,
+    double* __restrict__ xout, double* __restrict__ local_lb, double* __restrict__ logz,
+    double2* __restrict__ zfac, double (&part)[2][4][64]) {
   const int b = blockIdx.x, j = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r = j >> 4, c = j & 15;             // source block, target within the wave's 16
   const int tgt = 16 * w + c;
-  const bool fwd = blockIdx.y == 0;
-  const bool valid = j < K;
+  const bool valid = FULLK || j < K;
   const int jc = valid ? j : 0;
-  const double* __restrict__ Am = fwd ? Aexp : AexpT;
   double a[16];                                 // a[N] = A[16 r + N][tgt] (fwd) / A[tgt][16 r + N] (bwd)
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int src = 16 * r + i;
-    a[i] = (tgt < K && src < K) ? Am[(size_t)src * K + tgt] : 0.0;
+    a[i] = (FULLK || (tgt < K && src < K)) ? Am[(size_t)src * K + tgt] : 0.0;
   }
   const size_t wrow = (size_t)b * Lm;
-  const ST* __restrict__ Eb = Eh + wrow * K + jc;
-  ST* __restrict__ ob = (fwd ? ah : bh) + wrow * K + jc;
-  double* __restrict__ xb = (fwd ? hx : gx) + wrow;
-  auto rowof = [&](int s) { return fwd ? s : Lm - 1 - s; };
+  const ptrdiff_t dstep = FWD ? (ptrdiff_t)K : -(ptrdiff_t)K;          // one sweep step in elements
+  const size_t row0 = FWD ? 0 : (size_t)(Lm - 1);
+  const ST* __restrict__ ep = Eh + (wrow + row0) * K + jc;            // Eh row of sweep step 0
+  ST* __restrict__ op = out + (wrow + row0) * K + jc;
+  double* __restrict__ xb = xout + wrow;
+  auto rowof = [&](int s) { return FWD ? s : Lm - 1 - s; };
   double h = 0.0, mant = 1.0, hsum = 0.0;
   int ex = 0;
   double pcur;
   {
-    const int t = rowof(0);
-    const double e0 = Eb[(size_t)t * K];
     double o;
-    if (fwd) {      // mod_init + ll_0 combined in the log domain (every wave of the window alike)
+    if (FWD) {      // mod_init + ll_0 combined in the log domain (every wave of the window alike)
       o = lin_init_lane(mod_init, ll0 + (size_t)b * l0stride, jc, valid, kexp[wrow], h);
       pcur = o;
     } else {
+      const double e0 = *ep;
       o = valid ? 1.0 : 0.0;
       pcur = valid ? e0 : 0.0;
     }
-    if (valid && w == 0) ob[(size_t)t * K] = o;
+    if (valid && w == 0) *op = o;
   }
   double hkeep = h;
   constexpr int PD = 12;    // Eh rows in flight (one register each): measured 102.8 -> 96.4 us against PD = 4
-  auto eload = [&](int s) { return Eb[(size_t)rowof(s < Lm ? s : Lm - 1) * K]; };
+  // loads run PD steps ahead of the step: a running pointer in the main loop (where step s + PD is
+  // still inside the window), clamped row arithmetic in the <= 2 PD - 1 steps at the window's end
+  const ST* __restrict__ lp = ep + dstep;
+  auto eclamped = [&](int s) { return ep[(ptrdiff_t)(s < Lm ? s : Lm - 1) * dstep]; };
   double eq[PD];
 #pragma unroll
-  for (int u = 0; u < PD; ++u) eq[u] = eload(1 + u);
+  for (int u = 0; u < PD; ++u) eq[u] = eclamped(1 + u);
+  lp += (ptrdiff_t)PD * dstep;                  // -> row of step 1 + PD
   auto step = [&](int s, double et) {
     const int cur = s & 1;
-    const int t = rowof(s);
+    op += dstep;
     // exponent and bookkeeping from the entering vector (off the mat-vec's dependency chain)
     const double tot = wave_sum_dpp(pcur);
     const int e2 = __builtin_amdgcn_frexp_exp(tot);
-    if (fwd) {
+    if (FWD) {
       const double mm = mant * tot;
       ex += __builtin_amdgcn_frexp_exp(mm);
       mant = __builtin_amdgcn_frexp_mant(mm);
@@ -1403,19 +1406,28 @@ __global__ __launch_bounds__(256) void k_wave_lin4(
     __syncthreads();
     const double acc = (part[cur][0][j] + part[cur][1][j]) + (part[cur][2][j] + part[cur][3][j]);
     double o;
-    if (fwd) { o = valid ? ldexp(acc * et, -e2) : 0.0; pcur = o; }
-    else { o = valid ? ldexp(acc, -e2) : 0.0; pcur = et * o; }
+    if (FWD) { o = ldexp(acc * et, -e2); if (!FULLK) o = valid ? o : 0.0; pcur = o; }
+    else { o = ldexp(acc, -e2); if (!FULLK) o = valid ? o : 0.0; pcur = et * o; }
     h += (double)e2;
-    if (valid && w == (s & 3)) ob[(size_t)t * K] = o;      // the four waves take turns storing
+    if (valid && w == (s & 3)) *op = o;                    // the four waves take turns storing
     hkeep = (j == (s & 63)) ? h : hkeep;
     if ((s & 63) == 63 && w == 0) xb[rowof(s - 63 + j)] = hkeep;
   };
   int s = 1;
+  for (; s + 2 * PD <= Lm; s += PD) {           // every load of this trip: row s + u + PD <= Lm - 1
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+      const double et = eq[u];
+      eq[u] = *lp;
+      lp += dstep;
+      step(s + u, et);
+    }
+  }
   for (; s + PD <= Lm; s += PD) {
 #pragma unroll
     for (int u = 0; u < PD; ++u) {
       const double et = eq[u];
-      eq[u] = eload(s + u + PD);
+      eq[u] = eclamped(s + u + PD);
       step(s + u, et);
     }
   }
@@ -1427,7 +1439,7 @@ __global__ __launch_bounds__(256) void k_wave_lin4(
     const int sl = Lm - 1, s0 = sl & ~63;
     if ((sl & 63) != 63 && s0 + j <= sl) xb[rowof(s0 + j)] = hkeep;
   }
-  if (!fwd) return;
+  if (!FWD) return;
   double ks = 0.0, kk = 0.0;
   for (int t = j; t < Lm; t += 64) {
     const double kv = kexp[wrow + t];
@@ -1446,6 +1458,24 @@ __global__ __launch_bounds__(256) void k_wave_lin4(
     local_lb[b] = log(mf) + ((double)exf + hsum + h + kk) * LN2_D;
     logz[b] = log(zm) + (h + ks + zexp) * LN2_D;
     zfac[b] = make_double2(1.0 / zm, h + zexp);
+  }
+}
+template <int KMAX, typename ST = double>
+__global__ __launch_bounds__(256) void k_wave_lin4(
+    const ST* __restrict__ Eh, const double* __restrict__ kexp,
+    const double* __restrict__ Aexp, const double* __restrict__ AexpT,
+    const double* __restrict__ mod_init, const double* __restrict__ ll0, size_t l0stride, int Lm,
+    int K, ST* __restrict__ ah,
+    ST* __restrict__ bh, double* __restrict__ hx, double* __restrict__ gx,
+    double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac) {
+  static_assert(KMAX == 64, "lane = state, four source blocks of 16");
+  __shared__ double part[2][4][64];             // [step parity][source block][target], double-buffered
+  if (blockIdx.y == 0) {
+    if (K == 64) wave_lin4_body<true, true, ST>(Eh, kexp, Aexp, mod_init, ll0, l0stride, Lm, K, ah, hx, local_lb, logz, zfac, part);
+    else wave_lin4_body<true, false, ST>(Eh, kexp, Aexp, mod_init, ll0, l0stride, Lm, K, ah, hx, local_lb, logz, zfac, part);
+  } else {
+    if (K == 64) wave_lin4_body<false, true, ST>(Eh, kexp, AexpT, mod_init, ll0, l0stride, Lm, K, bh, gx, local_lb, logz, zfac, part);
+    else wave_lin4_body<false, false, ST>(Eh, kexp, AexpT, mod_init, ll0, l0stride, Lm, K, bh, gx, local_lb, logz, zfac, part);
   }
 }
 
