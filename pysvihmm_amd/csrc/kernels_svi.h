@@ -24,6 +24,57 @@
 //        vector goes into psi as if it were Dirichlet parameters).
 //  `work` = 2 K (K|1) doubles (LDS when they fit, else global scratch).
 // ------------------------------------------------------------------------------------
+// GTH elimination for K <= 64 by ONE wavefront, matrix in registers: lane i holds row i (64
+// doubles), the loops over states are unrolled completely so that every register index is a
+// compile-time constant.  Step N (N = K-1 .. 1): s = sum_{j<N} P[N][j] (each lane sums its own row,
+// lane N's sum is the one read), column N is scaled by 1/s and stays in place as Q[i][N], and
+// P[i][j] += Q[i][N] P[N][j] with the pivot row's entries read by v_readlane -- no LDS, no barrier:
+// ~4 N + 40 instructions per step instead of an LDS round trip + workgroup barrier (round 2:
+// ~1.4 us per step, 90 us in all).  Then pi_0 = 1, pi_j = sum_{i<j} pi_i Q[i][j] as one wave
+// reduction per state.  Sums of positive products only, as before.
+template <int N>
+struct GthStep {
+  static __device__ __forceinline__ void run(double (&r)[64], int K) {
+    if (N < K) {                                   // (uniform: states beyond K do not exist)
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        if ((j & 3) == 0) s0 += r[j]; else if ((j & 3) == 1) s1 += r[j]; else if ((j & 3) == 2) s2 += r[j]; else s3 += r[j];
+      }
+      double s = (s0 + s1) + (s2 + s3);
+      pin_all_lanes(s);
+      const double inv = 1.0 / readlane_f64(s, N);
+      const double c = r[N] * inv;
+      r[N] = c;
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        double pj = r[j];
+        pin_all_lanes(pj);
+        r[j] = fma(c, readlane_f64(pj, N), r[j]);
+      }
+    }
+    GthStep<N - 1>::run(r, K);
+  }
+};
+template <>
+struct GthStep<0> {
+  static __device__ __forceinline__ void run(double (&)[64], int) {}
+};
+template <int J>
+struct GthBack {
+  static __device__ __forceinline__ void run(const double (&r)[64], int K, int lane, double& p) {
+    GthBack<J - 1>::run(r, K, lane, p);
+    if (J < K) {
+      const double t = wave_sum_dpp(lane < J ? p * r[J] : 0.0);
+      p = lane == J ? t : p;
+    }
+  }
+};
+template <>
+struct GthBack<0> {
+  static __device__ __forceinline__ void run(const double (&)[64], int, int, double&) {}
+};
+
 template <bool LDSW, int NWV>
 __global__ __launch_bounds__(64 * NWV) void k_svi_globals(
     const double* __restrict__ var_tran, int K, double* __restrict__ work_g,
@@ -91,45 +142,17 @@ __global__ __launch_bounds__(64 * NWV) void k_svi_globals(
   }
   __syncthreads();
   if (K <= 64) {
-    // GTH with the matrix in registers (K <= 64): lane = column j, and a thread holds that
-    // column of the rows i = wave + NWV u.  Row conditions (i < n, "this is the next pivot row")
-    // are then wave-uniform: finished rows cost nothing, the pivot row's sum is one DPP
-    // reduction by its owner wave, which also leaves the reciprocal, and a step is: one LDS
-    // round trip (pivot row / column / reciprocal), <= CPT FMAs, one barrier.
-    __shared__ double prow[2][64], pcol[2][64], pinv[2];
-    double rv[CPT];
+    // one wavefront, matrix in registers (GthStep / GthBack above); the other waves are done
+    if (w == 0) {
+      double r[64];
 #pragma unroll
-    for (int u = 0; u < CPT; ++u) {
-      const int i = w + NWV * u;
-      rv[u] = (i < K && lane < K) ? P[(size_t)i * LD + lane] : 0.0;
-    }
-    // n = K is a pseudo-step that only publishes row / column K-1
-    for (int n = K; n >= 1; --n) {
-      if (n < K) {
-        const int par = n & 1;
-        const double rn = lane < n ? prow[par][lane] : 0.0;
-        const double inv = pinv[par];
-#pragma unroll
-        for (int u = 0; u < CPT; ++u) {
-          const int i = w + NWV * u;
-          if (i < n) rv[u] = fma(pcol[par][i] * inv, rn, rv[u]);          // wave-uniform branch
-        }
-        if (w == (n % NWV) && lane < n) Q[(size_t)lane * LD + n] = pcol[par][lane] * inv;
-      }
-      if (n > 1) {       // make row m / column m / 1 / (row m's sum) visible for step m
-        const int m = n - 1, par = m & 1;
-#pragma unroll
-        for (int u = 0; u < CPT; ++u) {
-          const int i = w + NWV * u;
-          if (i == m) {                                                   // wave-uniform
-            prow[par][lane] = rv[u];
-            const double s = wave_sum_dpp(lane < m ? rv[u] : 0.0);
-            if (lane == 0) pinv[par] = 1.0 / s;
-          }
-          if (i < m && lane == m) pcol[par][i] = rv[u];
-        }
-      }
-      __syncthreads();
+      for (int j = 0; j < 64; ++j) r[j] = (lane < K && j < K) ? P[(size_t)lane * LD + j] : 0.0;
+      GthStep<63>::run(r, K);
+      double pst = lane == 0 ? 1.0 : 0.0;
+      GthBack<63>::run(r, K, lane, pst);
+      if (lane < K) rs[lane] = pst;
+      __builtin_amdgcn_wave_barrier();
+      __threadfence_block();
     }
   } else {
     // GTH: eliminate states K-1 .. 1.  Thread (row r = lane (+64, ..), column phase c = wave)
@@ -180,20 +203,7 @@ __global__ __launch_bounds__(64 * NWV) void k_svi_globals(
   // back-substitution: pi_0 = 1, pi_j = sum_{i<j} pi_i Q[i][j]
   if (tid < 64) {
     if (K <= 64) {
-      // column-oriented: lane j accumulates pi_j; once pi_i is complete it is broadcast with a
-      // readlane and every later lane adds pi_i Q[i][j] (row i of Q: conflict-free, prefetchable)
-      double acc = lane == 0 ? 1.0 : 0.0;
-      double qn = (lane < K && 0 < lane) ? Q[lane] : 0.0;            // Q[0][lane]
-      for (int i = 0; i + 1 < K; ++i) {
-        const double qi = qn;
-        if (i + 2 < K) qn = (lane < K && i + 1 < lane) ? Q[(size_t)(i + 1) * LD + lane] : 0.0;
-        pin_all_lanes(acc);
-        const double pi_i = readlane_f64(acc, i);
-        acc = fma(pi_i, qi, acc);                                     // qi = 0 for lanes <= i
-      }
-      if (lane < K) rs[lane] = acc;
-      __builtin_amdgcn_wave_barrier();
-      __threadfence_block();
+      // (rs already holds the un-normalised stationary vector: the register path above)
     } else {
       if (lane == 0) rs[0] = 1.0;
       for (int j = 1; j < K; ++j) {
