@@ -614,7 +614,10 @@ def run_sequence(e, L, seed, nops=30):
                     # a tiny, batch-factor-amplified minibatch cancels 1e3 : 1 (the tolerance of the
                     # mode is stated on the natural gradients, which are the raw moments)
                     continue
-                np.testing.assert_allclose(a, b, rtol=tol, atol=tol * 1e-2 * (1 + np.abs(b).max()), err_msg=what + " " + nme)
+                # (fp32 mode: single entries of a batch-factor-amplified update can be off by a few times
+                #  the mode's tolerance relative to the array's scale)
+                np.testing.assert_allclose(a, b, rtol=tol, atol=tol * (4e-2 if f32 else 1e-2) * (1 + np.abs(b).max()),
+                                           err_msg=what + " " + nme)
             if not f32:     # (the ELBO's NIW terms inherit the scale matrices' cancellation)
                 np.testing.assert_allclose(ea, eb, rtol=max(1e-8, 1e-11 * pb["offset"] ** 2), err_msg=what + " elbo")
             else:
