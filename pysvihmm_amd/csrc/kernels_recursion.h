@@ -994,7 +994,13 @@ __global__ __launch_bounds__(64 * NW) void k_sweeps_lin(
 //  every A operand between their two MFMAs, and the compiler can keep a whole group of B
 //  values in flight.  Ordinary windows only (no chain modes); both directions in one launch.
 // ------------------------------------------------------------------------------------
-template <int NW, bool FULL>
+// WT = window tiles (16 windows each) per wave.  WT = 2 (round 3, more than one 16-window
+// workgroup per CU): the 32 windows share every streamed B value, the loads per MFMA halve.  It
+// only pays with the exponent books kept per wave (below): with all four C registers' books in
+// every wave the kernel spilled 130 registers and ran 6.7 ms on configs[4] against 6.35 ms of
+// WT = 1; with one register's books per wave 5.3 ms (WT = 1: 6.1 ms).  (Two wave groups of 124
+// registers sharing the B stream through L1 in one 1024-thread workgroup: 12.5 ms.)
+template <int NW, bool FULL, int WT = 1>
 __global__ __launch_bounds__(64 * NW) void k_sweeps_lin2(
     const double* __restrict__ Eh, const double* __restrict__ kexp,
     const double* __restrict__ Aexp, const double* __restrict__ AexpT,
@@ -1002,16 +1008,20 @@ __global__ __launch_bounds__(64 * NW) void k_sweeps_lin2(
     double* __restrict__ ah,
     double* __restrict__ bh, double* __restrict__ hx, double* __restrict__ gx,
     double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac) {
-  constexpr int NT = 2 * NW, KS = 4 * NT;
+  constexpr int NT = 2 * NW, KS = 4 * NT, PS = 16 * NT + 2, WR = 16 * WT;
+  static_assert(NW % 4 == 0, "a wave tracks the exponents of window rows lg + 4 (wave & 3)");
   extern __shared__ double __attribute__((aligned(16))) lin_smem[];
-  LinShared<NT>& sh = *reinterpret_cast<LinShared<NT>*>(lin_smem);
+  typedef double PRow[PS];
+  PRow* P0 = reinterpret_cast<PRow*>(lin_smem);             // P[2][WR][PS]
+  auto Pb = [&](int buf) { return P0 + buf * WR; };
   const bool fwd = blockIdx.y == 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
+  const int rw = wave & 3;         // the C register whose window rows this wave keeps the books of
   const int j0 = wave * 32 + li, j1 = j0 + 16;
   const bool v0 = FULL || j0 < K, v1 = FULL || j1 < K;
   const int jc0 = v0 ? j0 : 0, jc1 = v1 ? j1 : 0;
-  const int b0 = blockIdx.x * 16;
+  const int b0 = blockIdx.x * WR;
   const size_t wrow = (size_t)b0 * Lm;
   const double* __restrict__ Eb = Eh + wrow * K;
   double* __restrict__ ob = (fwd ? ah : bh) + wrow * K;      // stored vector: ah (fwd) / bh (bwd)
@@ -1020,110 +1030,128 @@ __global__ __launch_bounds__(64 * NW) void k_sweeps_lin2(
   // tile; rows beyond K are read from the zeroed slack the host keeps behind the matrices
   const double* __restrict__ Bm = fwd ? Aexp : AexpT;
   const int lo0 = 2 * lg * K + jc0, lo1 = 2 * lg * K + jc1;
-  unsigned oR[4], oE[4], oRw;
-  int gwc[4];
+  auto gwin = [&](int wt, int r) { const int gw = b0 + 16 * wt + lg + 4 * r; return gw < B ? gw : B - 1; };
+  unsigned oE[WT][4], oRw[WT];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int gw = b0 + lg + 4 * r;
-    gwc[r] = gw < B ? gw : B - 1;
-    oR[r] = (unsigned)(gwc[r] - b0) * (unsigned)Lm;
-    oE[r] = oR[r] * (unsigned)K;
-  }
-  {
-    const int gww = b0 + lg + 4 * (wave & 3);
-    oRw = (unsigned)((gww < B ? gww : B - 1) - b0) * (unsigned)Lm;
+  for (int wt = 0; wt < WT; ++wt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) oE[wt][r] = (unsigned)(gwin(wt, r) - b0) * (unsigned)Lm * (unsigned)K;
+    oRw[wt] = (unsigned)(gwin(wt, rw) - b0) * (unsigned)Lm;
   }
   // row touched by sweep step s (s = 0: the initial row)
   auto rowof = [&](int s) { return fwd ? s : Lm - 1 - s; };
-  double h[4], mant[4], hsum[4];
-  int ex[4];
+  // exponent books of window rows lg + 4 rw (every wave keeps one of the four C registers' rows;
+  // the sums are exact in double): h = exponent of the stored vector, hsum = sum_s (h_s + the
+  // exponent split off the running mantissa), mant = that mantissa
+  double h[WT], mant[WT], hsum[WT];
   {
     const size_t ro = (size_t)rowof(0) * K;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const double e0 = (Eb + ro)[oE[r] + jc0], e1 = (Eb + ro)[oE[r] + jc1];
-      // forward: ah_0 = the initial message of k_lin_init (stored), P = ah_0;
-      // backward: bh_top = 1 (stored), P = Eh_top
-      const double s0v = fwd ? a0v[(size_t)gwc[r] * K + jc0] : 1.0;
-      const double s1v = fwd ? a0v[(size_t)gwc[r] * K + jc1] : 1.0;
-      if (v0) (ob + ro)[oE[r] + jc0] = s0v;
-      if (v1) (ob + ro)[oE[r] + jc1] = s1v;
-      sh.P[0][lg + 4 * r][j0] = v0 ? (fwd ? s0v : e0) : 0.0;
-      sh.P[0][lg + 4 * r][j1] = v1 ? (fwd ? s1v : e1) : 0.0;
-      h[r] = fwd ? a0e[gwc[r]] : 0.0; mant[r] = 1.0; ex[r] = 0; hsum[r] = 0.0;
+    for (int wt = 0; wt < WT; ++wt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double e0 = (Eb + ro)[oE[wt][r] + jc0], e1 = (Eb + ro)[oE[wt][r] + jc1];
+        // forward: ah_0 = the initial message of k_lin_init (stored), P = ah_0;
+        // backward: bh_top = 1 (stored), P = Eh_top
+        const int gw = gwin(wt, r);
+        const double s0v = fwd ? a0v[(size_t)gw * K + jc0] : 1.0;
+        const double s1v = fwd ? a0v[(size_t)gw * K + jc1] : 1.0;
+        if (v0) (ob + ro)[oE[wt][r] + jc0] = s0v;
+        if (v1) (ob + ro)[oE[wt][r] + jc1] = s1v;
+        Pb(0)[16 * wt + lg + 4 * r][j0] = v0 ? (fwd ? s0v : e0) : 0.0;
+        Pb(0)[16 * wt + lg + 4 * r][j1] = v1 ? (fwd ? s1v : e1) : 0.0;
+      }
+      h[wt] = fwd ? a0e[gwin(wt, rw)] : 0.0; mant[wt] = 1.0; hsum[wt] = 0.0;
+      (xb + rowof(0))[oRw[wt]] = h[wt];
     }
-    (xb + rowof(0))[oRw] = sel4(h, wave & 3);
   }
   __syncthreads();
   for (int s = 1; s < Lm; ++s) {
     const int cur = (s - 1) & 1, nxt = s & 1;
     const int t = rowof(s);
     const size_t ro = (size_t)t * K;
-    double e0[4], e1[4];
+    double e0[WT][4], e1[WT][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { e0[r] = (Eb + ro)[oE[r] + jc0]; e1[r] = (Eb + ro)[oE[r] + jc1]; }
-    // out[w][j] = sum_i P[w][i] M[i][j] for this wave's two tiles; tot[w] = sum_i P[w][i]
-    double4_t p0 = {0, 0, 0, 0}, p1 = p0, q0 = p0, q1 = p0;
-    const double* pr = &sh.P[cur][li][2 * lg];
+    for (int wt = 0; wt < WT; ++wt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { e0[wt][r] = (Eb + ro)[oE[wt][r] + jc0]; e1[wt][r] = (Eb + ro)[oE[wt][r] + jc1]; }
+    // out[w][j] = sum_i P[w][i] M[i][j] for this wave's two state tiles and WT window tiles;
+    // tot[w] = sum_i P[w][i]
+    double4_t p0[WT], p1[WT], q0[WT], q1[WT];
+    const double* pr[WT];
+    double sa[WT], sb[WT];
+#pragma unroll
+    for (int wt = 0; wt < WT; ++wt) {
+      p0[wt] = (double4_t){0, 0, 0, 0}; p1[wt] = p0[wt]; q0[wt] = p0[wt]; q1[wt] = p0[wt];
+      pr[wt] = &Pb(cur)[16 * wt + li][2 * lg];
+      sa[wt] = 0.0; sb[wt] = 0.0;
+    }
     // A rolled loop with running pointers: fully unrolled, the compiler materialises all 256
     // lane addresses of the streamed tile as loop invariants of the time loop and spills them.
     const double* __restrict__ pb0 = Bm + lo0;
     const double* __restrict__ pb1 = Bm + lo1;
     const size_t K1 = (size_t)K, K8 = (size_t)8 * K, K9 = (size_t)9 * K, K16 = (size_t)16 * K;
-    double sa = 0.0, sb = 0.0;
 #pragma unroll 4
     for (int c = 0; c < KS / 4; ++c) {        // 4 k-steps (16 transition rows) per trip
       const double b00 = pb0[0], b01 = pb0[K1], b02 = pb0[K8], b03 = pb0[K9];
       const double b10 = pb1[0], b11 = pb1[K1], b12 = pb1[K8], b13 = pb1[K9];
       pb0 += K16; pb1 += K16;
-      const double2 x = *reinterpret_cast<const double2*>(pr);
-      const double2 y = *reinterpret_cast<const double2*>(pr + 8);
-      pr += 16;
-      p0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, b00, p0, 0, 0, 0);
-      q0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, b10, q0, 0, 0, 0);
-      p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, b01, p1, 0, 0, 0);
-      q1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, b11, q1, 0, 0, 0);
-      p0 = __builtin_amdgcn_mfma_f64_16x16x4f64(y.x, b02, p0, 0, 0, 0);
-      q0 = __builtin_amdgcn_mfma_f64_16x16x4f64(y.x, b12, q0, 0, 0, 0);
-      p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y.y, b03, p1, 0, 0, 0);
-      q1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y.y, b13, q1, 0, 0, 0);
-      sa += x.x + y.x;
-      sb += x.y + y.y;
+#pragma unroll
+      for (int wt = 0; wt < WT; ++wt) {
+        const double2 x = *reinterpret_cast<const double2*>(pr[wt]);
+        const double2 y = *reinterpret_cast<const double2*>(pr[wt] + 8);
+        pr[wt] += 16;
+        p0[wt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, b00, p0[wt], 0, 0, 0);
+        q0[wt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, b10, q0[wt], 0, 0, 0);
+        p1[wt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, b01, p1[wt], 0, 0, 0);
+        q1[wt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, b11, q1[wt], 0, 0, 0);
+        p0[wt] = __builtin_amdgcn_mfma_f64_16x16x4f64(y.x, b02, p0[wt], 0, 0, 0);
+        q0[wt] = __builtin_amdgcn_mfma_f64_16x16x4f64(y.x, b12, q0[wt], 0, 0, 0);
+        p1[wt] = __builtin_amdgcn_mfma_f64_16x16x4f64(y.y, b03, p1[wt], 0, 0, 0);
+        q1[wt] = __builtin_amdgcn_mfma_f64_16x16x4f64(y.y, b13, q1[wt], 0, 0, 0);
+        sa[wt] += x.x + y.x;
+        sb[wt] += x.y + y.y;
+      }
     }
     const double4_t z = {0, 0, 0, 0};
-    const double4_t tot = __builtin_amdgcn_mfma_f64_16x16x4f64(sa + sb, 1.0, z, 0, 0, 0);
-    const double4_t acc0 = p0 + p1, acc1 = q0 + q1;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int e2 = __builtin_amdgcn_frexp_exp(tot[r]);
-      double o0, o1, n0, n1;      // stored value, next P value
-      if (fwd) {
-        o0 = v0 ? ldexp(acc0[r] * e0[r], -e2) : 0.0; o1 = v1 ? ldexp(acc1[r] * e1[r], -e2) : 0.0;
-        n0 = o0; n1 = o1;
-        const double mm = mant[r] * tot[r];
-        ex[r] += __builtin_amdgcn_frexp_exp(mm);
-        mant[r] = __builtin_amdgcn_frexp_mant(mm);
-        hsum[r] += h[r];
-      } else {
-        o0 = v0 ? ldexp(acc0[r], -e2) : 0.0; o1 = v1 ? ldexp(acc1[r], -e2) : 0.0;
-        n0 = e0[r] * o0; n1 = e1[r] * o1;
+    for (int wt = 0; wt < WT; ++wt) {
+      const double4_t tot = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[wt] + sb[wt], 1.0, z, 0, 0, 0);
+      const double4_t acc0 = p0[wt] + p1[wt], acc1 = q0[wt] + q1[wt];
+      const double totw = rw == 0 ? tot[0] : (rw == 1 ? tot[1] : (rw == 2 ? tot[2] : tot[3]));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int e2 = __builtin_amdgcn_frexp_exp(tot[r]);
+        double o0, o1, n0, n1;      // stored value, next P value
+        if (fwd) {
+          o0 = v0 ? ldexp(acc0[r] * e0[wt][r], -e2) : 0.0; o1 = v1 ? ldexp(acc1[r] * e1[wt][r], -e2) : 0.0;
+          n0 = o0; n1 = o1;
+        } else {
+          o0 = v0 ? ldexp(acc0[r], -e2) : 0.0; o1 = v1 ? ldexp(acc1[r], -e2) : 0.0;
+          n0 = e0[wt][r] * o0; n1 = e1[wt][r] * o1;
+        }
+        Pb(nxt)[16 * wt + lg + 4 * r][j0] = n0;
+        Pb(nxt)[16 * wt + lg + 4 * r][j1] = n1;
+        if (v0) (ob + ro)[oE[wt][r] + jc0] = o0;
+        if (v1) (ob + ro)[oE[wt][r] + jc1] = o1;
       }
-      sh.P[nxt][lg + 4 * r][j0] = n0;
-      sh.P[nxt][lg + 4 * r][j1] = n1;
-      if (v0) (ob + ro)[oE[r] + jc0] = o0;
-      if (v1) (ob + ro)[oE[r] + jc1] = o1;
-      h[r] += (double)e2;
+      if (fwd) {
+        const double mm = mant[wt] * totw;
+        hsum[wt] += h[wt] + (double)__builtin_amdgcn_frexp_exp(mm);
+        mant[wt] = __builtin_amdgcn_frexp_mant(mm);
+      }
+      h[wt] += (double)__builtin_amdgcn_frexp_exp(totw);
+      (xb + t)[oRw[wt]] = h[wt];
     }
-    (xb + t)[oRw] = sel4(h, wave & 3);
     __syncthreads();
   }
   if (!fwd) return;
   // ---- forward epilogue: K sums, Z, local_lb (as in fwd_lin_body)
   {
     const int last = (Lm - 1) & 1;
-    double* scr = &sh.P[1 - last][0][0];
+    double* scr = &Pb(1 - last)[0][0];          // free buffer: [0, WR) K_top, [WR, 2 WR) sum_t K_t
     const double* __restrict__ kbw = kexp + wrow;
-    for (int w = threadIdx.x >> 4; w < 16; w += 4 * NW) {
+    for (int w = threadIdx.x >> 4; w < WR; w += 4 * NW) {
       const int gw = b0 + w;
       const unsigned o = (unsigned)((gw < B ? gw : B - 1) - b0) * (unsigned)Lm;
       double a = 0.0, c = 0.0;
@@ -1134,23 +1162,33 @@ __global__ __launch_bounds__(64 * NW) void k_sweeps_lin2(
       }
       a = row16_sum(a);
       c = row16_sum(c);
-      if (li == 0) { scr[w] = a; scr[16 + w] = c; }
+      if (li == 0) { scr[w] = a; scr[WR + w] = c; }
     }
     __syncthreads();
-    const double4_t tot = lin_rowsum<NT>(sh, last, li, lg);
-    if (wave == 0 && li == 0) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int w = lg + 4 * r;
-        const double Ktop = scr[w], KK = scr[16 + w];
-        const double mm = mant[r] * tot[r];
-        const int exf = ex[r] + __builtin_amdgcn_frexp_exp(mm);
+    for (int wt = 0; wt < WT; ++wt) {
+      double sr = 0.0;
+      const double* prow = &Pb(last)[16 * wt + li][2 * lg];
+#pragma unroll
+      for (int c = 0; c < 2 * NT; ++c) {
+        const double2 x = *reinterpret_cast<const double2*>(prow + 8 * c);
+        sr += x.x + x.y;
+      }
+      const double4_t z = {0, 0, 0, 0};
+      const double4_t tot = __builtin_amdgcn_mfma_f64_16x16x4f64(sr, 1.0, z, 0, 0, 0);
+      if (wave < 4 && li == 0) {          // wave rw: window rows lg + 4 rw
+        const double totw = rw == 0 ? tot[0] : (rw == 1 ? tot[1] : (rw == 2 ? tot[2] : tot[3]));
+        const int w = 16 * wt + lg + 4 * rw;
+        const int gw = gwin(wt, rw);
+        const double Ktop = scr[w], KK = scr[WR + w];
+        const double mm = mant[wt] * totw;
+        const double exf = (double)__builtin_amdgcn_frexp_exp(mm);
         const double mf = __builtin_amdgcn_frexp_mant(mm);
-        const double zm = __builtin_amdgcn_frexp_mant(tot[r]);
-        const double zexp = (double)__builtin_amdgcn_frexp_exp(tot[r]);
-        local_lb[gwc[r]] = log(mf) + ((double)exf + hsum[r] + h[r] + KK) * LN2_D;
-        logz[gwc[r]] = log(zm) + (h[r] + Ktop + zexp) * LN2_D;
-        zfac[gwc[r]] = make_double2(1.0 / zm, h[r] + zexp);
+        const double zm = __builtin_amdgcn_frexp_mant(totw);
+        const double zexp = (double)__builtin_amdgcn_frexp_exp(totw);
+        local_lb[gw] = log(mf) + (exf + hsum[wt] + h[wt] + KK) * LN2_D;
+        logz[gw] = log(zm) + (h[wt] + Ktop + zexp) * LN2_D;
+        zfac[gw] = make_double2(1.0 / zm, h[wt] + zexp);
       }
     }
   }

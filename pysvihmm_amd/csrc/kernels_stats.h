@@ -244,8 +244,9 @@ struct StRow4 {
 #define ST_CC (2 * ST_CS + 1)  // column stride (both buffers + 1 pad): 67
 
 // TRONLY (K > 64): only the transition statistic sum_t q[t-1, pbase + i] q[t, kbase + j] of
-// one 64 x 64 block of (previous state, state) pairs: blockIdx.y = previous-state group,
-// blockIdx.z = state group, the m-tiles are the 64 q[prev] columns, no obs staging.
+// one (64 MT) x 64 block of (previous state, state) pairs: blockIdx.y = previous-state group,
+// blockIdx.z = state group, the m-tiles are the 64 MT q[prev] columns (MT per wave), no obs
+// columns in the tile (ZERO, ONE, then q[prev]) and no second A factor.
 // CT: arithmetic type of the GEMM (LDS tiles, MFMA operands and accumulators): double =
 // v_mfma_f64_16x16x4_f64, float = v_mfma_f32_16x16x4_f32 (the fp32 mode: twice the matrix rate,
 // half the LDS traffic; a chunk's sums are accumulated in fp32 and leave as fp64 partials).
@@ -298,8 +299,9 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
   static_assert(QK * TPR == Kp, "staging split");
   extern __shared__ double smem[];
   // columns of the A-operand tile: [0,D) x | D: 1 (0 on masked rows) | D+1 ZERO | D+2 ONE | QP0+i: q[prev][i]
-  const int ZERO = D + 1, ONE = D + 2, QP0 = D + 3;
-  const int C = QP0 + Kp;
+  constexpr int PG = TRONLY ? MT : 1;      // previous-state groups of Kp columns staged
+  const int ZERO = TRONLY ? 0 : D + 1, ONE = ZERO + 1, QP0 = ZERO + 2;
+  const int C = QP0 + Kp * PG;
   CT* rb0 = reinterpret_cast<CT*>(smem);   // [C][CC]
   CT* qs0 = rb0 + C * CC;                  // [NB][32][QS]
   StRow4* rinfo = reinterpret_cast<StRow4*>(     // [4][32], 8-byte aligned behind the tiles
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
   const int mg = wave & 3, ng = wave >> 2;
   const int Ftot = Fp + KpTot;
   const int kbase = blockIdx.z * Kp;
-  const int pbase = TRONLY ? blockIdx.y * 64 : 0;     // first previous state of this block
+  const int pbase = TRONLY ? blockIdx.y * Kp * PG : 0;     // first previous state of this block
   const int mt0 = TRONLY ? mg * MT : (blockIdx.y * 4 + mg) * MT;
   const int nt0 = ng * NTW;
   const int wg_m0 = blockIdx.y * 4 * MT * 16, wg_m1 = wg_m0 + 4 * MT * 16;
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
   for (int m = 0; m < MT; ++m) {
     const int f = (mt0 + m) * 16 + li;
     int fa = ZERO, fb = ZERO;
-    if (TRONLY) { if (f < 64 && pbase + f < K) { fa = QP0 + f; fb = ONE; } }
+    if (TRONLY) { if (f < Kp * PG && pbase + f < K) { fa = QP0 + f; fb = ONE; } }
     else if (f < F) { const int ab = fab[f]; fa = ab & 0xffff; fb = ab >> 16; }
     else if (f >= Fp && f - Fp < K && mt_limit * 16 > Fp) { fa = QP0 + (f - Fp); fb = ONE; }
     oa[m] = fa * CC + lg * 8; ob[m] = fb * CC + lg * 8;
@@ -412,8 +414,9 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
   }
   const int qwi = sr * QS + sc;                 // q tile element of this thread (column 0)
   const int pwi = (QP0 + sc) * CC + psr;     // q[prev] column of this thread (buffer 0)
-  double rx[XK], rq[QK], rp[QK];
-  double rq2[LIN ? QK : 1], rp2[LIN ? QK : 1], rsq = 0.0, rsp = 0.0;
+  constexpr int PK = QK * PG;               // q[prev] columns per staging thread
+  double rx[XK], rq[QK], rp[PK];
+  double rq2[LIN ? QK : 1], rp2[LIN ? PK : 1], rsq = 0.0, rsp = 0.0;
   bool okx = false, okq = false, okp = false;
   auto fetch = [&](int buf) {
     const StRow4 ri = rinfo[buf * ST_RB + sr];
@@ -436,10 +439,10 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
     if (need_qp) {
       const int o = okp ? ri.poff : 0;
 #pragma unroll
-      for (int k = 0; k < QK; ++k) rp[k] = pthr[o + TPR * k];
+      for (int k = 0; k < PK; ++k) rp[k] = pthr[o + TPR * k];
       if (LIN) {
 #pragma unroll
-        for (int k = 0; k < QK; ++k) rp2[k] = bpthr[o + TPR * k];
+        for (int k = 0; k < PK; ++k) rp2[k] = bpthr[o + TPR * k];
       }
     }
   };
@@ -463,7 +466,7 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
     }
     if (need_qp) {
 #pragma unroll
-      for (int k = 0; k < QK; ++k) {
+      for (int k = 0; k < PK; ++k) {
         const double v = LIN ? (rp[k] * rp2[k]) * rsp : (okp ? rp[k] : 0.0);
         rb0[pwi + U * ST_CS + TPR * k * CC] = (CT)v;
       }
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
       }
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const CT A = Ax[m] * Ay[m];
+        const CT A = TRONLY ? Ax[m] : Ax[m] * Ay[m];
 #pragma unroll
         for (int n = 0; n < NTW; ++n) acc[m][n] = MF<CT>::mma(A, Bv[n], acc[m][n]);
       }
@@ -580,7 +583,7 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
     for (int r = 0; r < 4; ++r) {
       const int fl = (mt0 + m) * 16 + MF<CT>::crow(lg, r);
       const int f = TRONLY ? Fp + pbase + fl : fl;
-      if (TRONLY ? (fl < 64 && pbase + fl < KpTot) : (f < Ftot && (mt0 + m) < mt_limit)) {
+      if (TRONLY ? (fl < Kp * PG && pbase + fl < KpTot) : (f < Ftot && (mt0 + m) < mt_limit)) {
 #pragma unroll
         for (int n = 0; n < NTW; ++n)
           part[((size_t)blockIdx.x * Ftot + f) * KpTot + kbase + (nt0 + n) * 16 + li] = (double)acc[m][n][r];

@@ -1392,18 +1392,23 @@ static int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_
   else if (NW <= 8) { if (K == 128) SWPX(8, true, true); else SWPX(8, false, true); }      // K > 64: B streamed
   else {
     // 128 < K <= 256: eight waves of two state tiles (256 VGPRs each) instead of 16 x 1
-#define SWP2(F)                                                                                            \
+#define SWP2(F, WT)                                                                                        \
   do {                                                                                                     \
-    const size_t lds = sizeof(LinShared<16>);                                                              \
-    hipFuncSetAttribute((const void*)k_sweeps_lin2<8, F>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+    const size_t lds = (size_t)(WT) * sizeof(LinShared<16>);                                               \
+    dim3 g2((unsigned)((nb + 16 * (WT) - 1) / (16 * (WT))), 2);                                            \
+    hipFuncSetAttribute((const void*)k_sweeps_lin2<8, F, WT>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                         (int)lds);                                                                         \
-    hipLaunchKernelGGL((k_sweeps_lin2<8, F>), grid, dim3(512), lds, stream, Eh, kx,                        \
+    hipLaunchKernelGGL((k_sweeps_lin2<8, F, WT>), g2, dim3(512), lds, stream, Eh, kx,                      \
                        (const double*)h->Aexp.p, (const double*)h->AexpT.p, a0v, a0e,  \
                        nb, Lm, K, ah, bh, hx, gx, llb, lz, zf);                                            \
   } while (0)
+    // more 16-window workgroups than CUs: 32 windows per workgroup share the streamed transition
+    // tile (variant[13] = 1: off)
+    const bool w32 = 2 * ((nb + 15) / 16) > 256 && h->variant[13] != 1;     // 256 CUs
     if (h->variant[7] == 1) { if (NW <= 12) { if (K == 192) SWPX(12, true, true); else SWPX(12, false, true); }
                               else { if (K == 256) SWPX(16, true, true); else SWPX(16, false, true); } }
-    else if (K == 256) SWP2(true); else SWP2(false);
+    else if (w32) { if (K == 256) SWP2(true, 2); else SWP2(false, 2); }
+    else if (K == 256) SWP2(true, 1); else SWP2(false, 1);
 #undef SWP2
   }
 #undef SWP
@@ -1687,7 +1692,7 @@ static int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, in
     if (lds > 150 * 1024 || (D + 1 + TPR - 1) / TPR > 9 || (Kp > 64 && Kp % 64 != 0)) var = 2;
   }
   // scaled sweeps: the pipelined kernel forms q = ah * bh * scale itself; the others read var_x
-  const bool lin = h->lin_mode && !h->q_valid && var == 3 && Kp <= 64;
+  const bool lin = h->lin_mode && !h->q_valid && var == 3 && (Kp <= 64 || h->variant[15] == 1);
   if (h->lin_mode && !lin) CK(ensure_q(h, h->curB, Lq, stream));
   const size_t qo = (size_t)b0 * Lq * K;
   const double* qv = (const double*)(lin ? h->la.p : h->q.p) + qo;
@@ -1781,31 +1786,40 @@ static int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, in
 #undef ST3
 #undef ST3L
         }
-        if (big) {   // transition tiles: one 64 x 64 (previous state, state) block per workgroup
-          dim3 g2((unsigned)nchunk, Kp / 64, Kp / 64);
-#define STT(XKV)                                                                                  \
+        if (big) {
+          // transition tiles: one (64 MTt) x 64 (previous state, state) block per workgroup; two
+          // m-tiles per wave where the state count allows (round 3: 4 MFMAs on 4 LDS reads per
+          // k-step instead of 2 on 4; variant[14] = 1: one)
+          const int MTt = (Kp % 128 == 0 && h->variant[14] != 1) ? 2 : 1;
+          dim3 g2((unsigned)nchunk, Kp / (64 * MTt), Kp / 64);
+          const size_t ldt = ((size_t)(2 + 64 * MTt) * ST_CC + 2 * (size_t)ST_RB * 65) * 8 + 4 * ST_RB * sizeof(StRow4);
+          const size_t ldt3 = ((size_t)(2 + 64 * MTt) * (3 * ST_CS + 2) + 3 * (size_t)ST_RB * 65) * 8 +
+                              4 * ST_RB * sizeof(StRow4) + 16;
+#define STT(MTV, LN)                                                                              \
   do {                                                                                           \
-    if (lds > 64 * 1024)                                                                         \
-      hipFuncSetAttribute((const void*)k_stats_mfma4<1, 2, 2, XKV, false, true>,                 \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
-    hipLaunchKernelGGL((k_stats_mfma4<1, 2, 2, XKV, false, true>), g2, dim3(512), lds, stream,   \
+    hipFuncSetAttribute((const void*)k_stats_mfma4<MTV, 2, 2, 1, LN, true>,                      \
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldt);                   \
+    hipLaunchKernelGGL((k_stats_mfma4<MTV, 2, 2, 1, LN, true>), g2, dim3(512), ldt, stream,      \
                        (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, Fp,                  \
                        F, (const int*)h->fab.p, qv, rpc, flags, Lq, off,                          \
                        partv, Kp, mt_limit, bhv, hxv, gxv, zfv);                                  \
   } while (0)
-#define STT3(XKV)                                                                                 \
+#define STT3(MTV, LN)                                                                             \
   do {                                                                                           \
-    hipFuncSetAttribute((const void*)k_stats_mfma4<1, 2, 2, XKV, false, true, double, double, 3>, \
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);                  \
-    hipLaunchKernelGGL((k_stats_mfma4<1, 2, 2, XKV, false, true, double, double, 3>), g2, dim3(512), lds3, stream, \
+    hipFuncSetAttribute((const void*)k_stats_mfma4<MTV, 2, 2, 1, LN, true, double, double, 3>,   \
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldt3);                  \
+    hipLaunchKernelGGL((k_stats_mfma4<MTV, 2, 2, 1, LN, true, double, double, 3>), g2, dim3(512), ldt3, stream, \
                        (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, Fp,                  \
                        F, (const int*)h->fab.p, qv, rpc, flags, Lq, off,                          \
                        partv, Kp, mt_limit, bhv, hxv, gxv, zfv);                                  \
   } while (0)
-          if (lds3 <= 160 * 1024 && h->variant[12] != 1) {
-            if (xk <= 1) STT3(1); else if (xk <= 3) STT3(3); else if (xk <= 5) STT3(5); else STT3(9);
+          // (no obs columns in these tiles: XK = 1 always, the three-buffer loop always fits)
+          if (h->variant[12] != 1) {
+            if (lin) { if (MTt == 2) STT3(2, true); else STT3(1, true); }
+            else { if (MTt == 2) STT3(2, false); else STT3(1, false); }
           } else {
-            if (xk <= 1) STT(1); else if (xk <= 3) STT(3); else if (xk <= 5) STT(5); else STT(9);
+            if (lin) { if (MTt == 2) STT(2, true); else STT(1, true); }
+            else { if (MTt == 2) STT(2, false); else STT(1, false); }
           }
 #undef STT3
 #undef STT

@@ -213,3 +213,38 @@ def test_extreme_shapes(eng, K, Lm, B):
     st3 = eng.estep(starts[sub], Lm, flags=L.TRANS_WRAP)
     eng.set_variant("fb", 0)
     np.testing.assert_allclose(st3.buf, st2.buf, rtol=1e-8, atol=1e-9 * len(sub) * Lm)
+
+
+@pytest.mark.parametrize("K,B", [(200, 2061), (256, 2100), (130, 2049)])
+def test_wide_sweeps_32_windows_per_workgroup(eng, K, B):
+    """More than 2048 windows on a wide model (K > 128): `k_sweeps_lin2` runs 32 windows per
+    workgroup (two window tiles per wave sharing the streamed transition tile) and the
+    transition statistic 128 x 64 blocks.  Ragged K and B (B % 32 != 0: clamped tail windows);
+    bit-identical to the 16-window / 64 x 64 variants (variant 13 / 14) and equal to the C oracle."""
+    from pysvihmm_amd import _lib as L
+    from oracle import ref_c
+    D, T, Lm = 2, 9000, 5
+    pb = make_problem(K, D, T, seed=900 + K, miss=0.03)
+    rng = np.random.default_rng(K + B)
+    starts = rng.integers(0, T - Lm + 1, size=B)
+    _push(eng, pb)
+    flags = L.TRANS_WRAP
+    st = eng.estep(starts, Lm, flags=flags)
+    post = eng.forward_backward(starts, Lm, want=("var_x", "local_lb"))
+    try:
+        eng.set_variant(13, 1); eng.set_variant(14, 1)
+        st16 = eng.estep(starts, Lm, flags=flags)
+        post16 = eng.forward_backward(starts, Lm, want=("var_x", "local_lb"))
+    finally:
+        eng.set_variant(13, 0); eng.set_variant(14, 0)
+    assert np.array_equal(st.buf, st16.buf)
+    assert np.array_equal(post["var_x"], post16["var_x"]) and np.array_equal(post["local_lb"], post16["local_lb"])
+    ref = ref_c.estep_minibatch(pb["obs"], pb["mask"], starts, Lm, pb["mod_init"], pb["ltran"],
+                                pb["mu"], pb["sigma"], pb["kappa"], pb["nu"], flags=flags)
+    A, xbar, neff, S, lb = unpack(ref, K, D)
+    sc = B * Lm
+    np.testing.assert_allclose(st.A_raw, A, rtol=RTOL, atol=1e-9 * sc)
+    np.testing.assert_allclose(st.neff, neff, rtol=RTOL, atol=1e-9 * sc)
+    np.testing.assert_allclose(st.xbar, xbar, rtol=RTOL, atol=1e-8 * sc)
+    np.testing.assert_allclose(st.S, S, rtol=RTOL, atol=1e-7 * sc)
+    np.testing.assert_allclose(st.lb[0], lb, rtol=1e-10)
