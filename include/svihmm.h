@@ -391,7 +391,11 @@ const char* svihmm_kernel_name(int32_t slot);
  * | 9 automatic centring of the resident observations at upload (1 = off: c = 0)
  * | 12 barrier-free statistics GEMM with three LDS buffers (1 = off: the double-buffered kernel)
  * | 11 svihmm_allreduce_packed forms the sum in caller coordinates also at one rank (1 = on: the
- *      multi-rank path's coordinate round trip, exercised on a single GPU) */
+ *      multi-rank path's coordinate round trip, exercised on a single GPU)
+ * | 7 scaled sweeps' kernel family (K > 128: 1 one state tile per wave, 2 two tiles per wave for every K)
+ * | 13 wide models' sweeps with 32 windows per workgroup (1 = off: 16)
+ * | 14 wide models' transition statistic in 128 x 64 blocks (1 = off: 64 x 64)
+ * | 15 wide models' statistics GEMM forms q = ah bh scale itself (1 = off: separate posterior pass) */
 int svihmm_set_variant(svihmm_ctx* h, int32_t which, int32_t value);
 
 /* ---- diagnostics ------------------------------------------------------------------- */

@@ -76,10 +76,10 @@ struct Buf {
 static int ensure(Buf& b, size_t bytes) {
   if (bytes <= b.cap && b.p) return 0;
   if (b.p) { hipFree(b.p); b.p = nullptr; b.cap = 0; }
-  // 256 bytes past `cap` always belong to the allocation: kernels that stage padded state
-  // columns read up to 15 doubles beyond the last row
+  // 512 bytes past `cap` always belong to the allocation: kernels that stage padded state
+  // columns read up to 63 doubles beyond the last row (K > 64: state groups of 64)
   size_t want = bytes + bytes / 8 + 256;
-  HIPCK(hipMalloc(&b.p, want + 256));
+  HIPCK(hipMalloc(&b.p, want + 512));
   b.cap = want;
   return 0;
 }
@@ -662,7 +662,9 @@ static inline int feat_index(int a, int b, int D) {  // 0 <= a <= b <= D
 // x_a^2 (f = a), x_a (f = D + a), 1 (f = 2 D): F = 2 D + 1.  Emission and statistics GEMMs read
 // the table, so the family only changes the table and the theta builder.
 static int upload_feature_table(svihmm_ctx* h, int D, int K, bool diag = false) {
-  const int F = diag ? 2 * D + 1 : (D + 1) * (D + 2) / 2, Fp = (F + 15) / 16 * 16, Kp = (K + 15) / 16 * 16;
+  const int F = diag ? 2 * D + 1 : (D + 1) * (D + 2) / 2, Fp = (F + 15) / 16 * 16;
+  // padded state count: tiles of 16; wide models in groups of 64 (the statistics GEMM's state groups)
+  const int Kp = K > 64 ? (K + 63) / 64 * 64 : (K + 15) / 16 * 16;
   if (h->tabD == D && h->Fp == Fp && h->tab_diag == diag) { h->F = F; h->Kp = Kp; return 0; }
   std::vector<int> fab(Fp, (D + 1) | ((D + 1) << 16));  // padding -> zero slot
   if (diag) {
@@ -954,7 +956,7 @@ int svihmm_set_emission_cat(svihmm_ctx* h, int32_t K, int32_t V, const double* l
     for (int v = 0; v < V; ++v) hp[(size_t)v * K + k] = logp[(size_t)k * V + v];
   HIPCK(hipMemcpyAsync(h->cat_table.p, hp, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
   CK(pin_release(h, slot));
-  h->eK = K; h->eD = 1; h->V = V; h->Kp = (K + 15) / 16 * 16; h->have_emission = true; h->emis_cat = true; h->emis_diag = false;
+  h->eK = K; h->eD = 1; h->V = V; h->Kp = K > 64 ? (K + 63) / 64 * 64 : (K + 15) / 16 * 16; h->have_emission = true; h->emis_cat = true; h->emis_diag = false;
   return 0;
 }
 int64_t svihmm_packed_len(svihmm_ctx* h) { return h ? (int64_t)packed_len(h) : 0; }
@@ -1405,8 +1407,11 @@ static int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_
     // more 16-window workgroups than CUs: 32 windows per workgroup share the streamed transition
     // tile (variant[13] = 1: off)
     const bool w32 = 2 * ((nb + 15) / 16) > 256 && h->variant[13] != 1;     // 256 CUs
-    if (h->variant[7] == 1) { if (NW <= 12) { if (K == 192) SWPX(12, true, true); else SWPX(12, false, true); }
-                              else { if (K == 256) SWPX(16, true, true); else SWPX(16, false, true); } }
+    // 128 < K <= 192: twelve waves of one state tile (three per SIMD; the eight two-tile waves would
+    // run four empty tiles: 4.85 against 6.1 ms at K = 192, D = 32, T = 1e6).  variant[7] = 1: one
+    // tile per wave for every K, 2: two tiles per wave for every K
+    if (NW <= 12 && h->variant[7] != 2) { if (K == 192) SWPX(12, true, true); else SWPX(12, false, true); }
+    else if (h->variant[7] == 1) { if (K == 256) SWPX(16, true, true); else SWPX(16, false, true); }
     else if (w32) { if (K == 256) SWP2(true, 2); else SWP2(false, 2); }
     else if (K == 256) SWP2(true, 1); else SWP2(false, 1);
 #undef SWP2
@@ -1692,7 +1697,9 @@ static int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, in
     if (lds > 150 * 1024 || (D + 1 + TPR - 1) / TPR > 9 || (Kp > 64 && Kp % 64 != 0)) var = 2;
   }
   // scaled sweeps: the pipelined kernel forms q = ah * bh * scale itself; the others read var_x
-  const bool lin = h->lin_mode && !h->q_valid && var == 3 && (Kp <= 64 || h->variant[15] == 1);
+  // (wide models too, round 3: the separate posterior pass costs more than the second operand's loads;
+  //  variant[15] = 1: K > 64 through q as before)
+  const bool lin = h->lin_mode && !h->q_valid && var == 3 && (Kp <= 64 || h->variant[15] != 1);
   if (h->lin_mode && !lin) CK(ensure_q(h, h->curB, Lq, stream));
   const size_t qo = (size_t)b0 * Lq * K;
   const double* qv = (const double*)(lin ? h->la.p : h->q.p) + qo;
