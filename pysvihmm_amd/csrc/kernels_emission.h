@@ -322,24 +322,30 @@ __global__ void k_theta_orbit(const double* __restrict__ theta, int D, int Kp, i
   if (k < Kp) orb[(size_t)fo * Kp + (k & 15) * NT + (k >> 4)] = valid ? theta[(size_t)f * Kp + k] : 0.0;
 }
 
-template <int NT, int U>
+// MT = row tiles per wave: 2 (128 rows per workgroup) for batches that fill the chip, 1 (64 rows,
+// round 3) for minibatches with fewer than one 128-row workgroup per CU -- the SVI iteration of 64
+// windows is 129 workgroups of 128 rows on 256 CUs.
+template <int NT, int U, int MT = 2>
 __global__ __launch_bounds__(256) void k_emission_orbit(
     const double* __restrict__ obs, const uint8_t* __restrict__ mask,
     const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K,
     const double* __restrict__ orb, uint32_t flags, double* __restrict__ ll,
     double* __restrict__ kexp, double* __restrict__ ll0) {
-  constexpr int MT = 2, ROWS = 128, KP = 16 * NT;
+  constexpr int ROWS = 64 * MT, KP = 16 * NT;
+  typedef typename std::conditional<MT == 2, double2, double>::type XV;   // one column of the wave's row tiles
   extern __shared__ double smem[];
   const int N = D + 1, c = D >> 2, nd = (D >> 1) + 1, nleft = (nd + 3) >> 2;
   const int LEN = D + (D >> 1) + 1;                 // slots -1 .. 3D/2 - 1 (odd count)
-  double2* xs2 = (double2*)smem;                    // [64 row pairs][LEN] (row r, row r + 16)
+  XV* xs2 = (XV*)smem;                              // [64][LEN]: MT = 2 (row r, row r + 16) pairs
   long long* rowoff = (long long*)(xs2 + 64 * LEN);
   unsigned char* bad_s = (unsigned char*)(rowoff + ROWS);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t g0 = (int64_t)blockIdx.x * ROWS;
   double* xs1 = (double*)xs2;
   // row r of the tile -> wave r >> 5, row tile (r >> 4) & 1, lane row r & 15
-  auto slot = [&](int r, int idx) { return ((((r >> 5) * 16 + (r & 15)) * LEN + idx + 1) << 1) + ((r >> 4) & 1); };
+  auto slot = [&](int r, int idx) {
+    return MT == 2 ? ((((r >> 5) * 16 + (r & 15)) * LEN + idx + 1) << 1) + ((r >> 4) & 1) : r * LEN + idx + 1;
+  };
   {
     const int64_t bw0 = g0 / Lm;
     const unsigned t0 = (unsigned)(g0 - bw0 * Lm);
@@ -391,15 +397,21 @@ __global__ __launch_bounds__(256) void k_emission_orbit(
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
-  const double2* rowp = xs2 + (wave * 16 + li) * LEN + 1;      // slot 0 of this lane's row pair
-  const double2* pa0 = rowp + c * lg;
+  const XV* rowp = xs2 + (wave * 16 + li) * LEN + 1;           // slot 0 of this lane's row (pair)
+  const XV* pa0 = rowp + c * lg;
   const unsigned loff = (unsigned)(lg * KP + li * NT);         // lane part of the theta address
-  auto kstep = [&](const double2 xa, const double2 xb, const double (&Bv)[NT]) {
-    const double A0 = xa.x * xb.x, A1 = xa.y * xb.y;
+  auto kstep = [&](const XV xa, const XV xb, const double (&Bv)[NT]) {
+    if constexpr (MT == 2) {
+      const double A0 = xa.x * xb.x, A1 = xa.y * xb.y;
 #pragma unroll
-    for (int n = 0; n < NT; ++n) acc[0][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, Bv[n], acc[0][n], 0, 0, 0);
+      for (int n = 0; n < NT; ++n) acc[0][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, Bv[n], acc[0][n], 0, 0, 0);
 #pragma unroll
-    for (int n = 0; n < NT; ++n) acc[1][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, Bv[n], acc[1][n], 0, 0, 0);
+      for (int n = 0; n < NT; ++n) acc[1][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, Bv[n], acc[1][n], 0, 0, 0);
+    } else {
+      const double A0 = xa * xb;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[0][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, Bv[n], acc[0][n], 0, 0, 0);
+    }
   };
   auto loadB = [&](const double* trow, double (&Bv)[NT]) {
     if constexpr (NT % 2 == 0) {
@@ -418,9 +430,9 @@ __global__ __launch_bounds__(256) void k_emission_orbit(
   const int nblk = nd * (c / U);
   int bd = 0, ba = 0;                                // (delta, a0) of the next block to compute
   auto block = [&](const double (&Bv)[U][NT]) {
-    const double2* pa = pa0 + ba;
-    const double2* pb = pa + bd;
-    double2 xa[U], xb[U];
+    const XV* pa = pa0 + ba;
+    const XV* pb = pa + bd;
+    XV xa[U], xb[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) { xa[u] = pa[u]; xb[u] = pb[u]; }
 #pragma unroll
@@ -445,8 +457,8 @@ __global__ __launch_bounds__(256) void k_emission_orbit(
   }
   const double* tbs = orb + (size_t)nblk * (U * 4 * KP);
   {
-    const double2 xl = rowp[N - 1];
-    const double2* p2 = rowp + lg - 1;
+    const XV xl = rowp[N - 1];
+    const XV* p2 = rowp + lg - 1;
     for (int j = 0; j < nleft; ++j) {
       double Bv[NT];
       loadB(tbs, Bv);

@@ -131,6 +131,11 @@ struct svihmm_ctx {
   struct PinSlot { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool busy = false; };
   PinSlot pins[6];
   int pin_next = 0;
+  // window starts of the SVI loop's iterations: their own ring, released by the iterations' end
+  // events (an event record between two kernels of the chain costs ~7 us of dispatch)
+  struct StartSlot { void* p = nullptr; size_t cap = 0; int used_it = -1; };
+  StartSlot svi_starts[8];
+  int svi_upload_it = -1;
   int* pin_status = nullptr;                 // pinned: NIW factorisation status (lazy check)
   double* mirror = nullptr; size_t mirror_cap = 0;   // pinned + mapped copy of `packed`
   bool mirror_valid = false;
@@ -177,6 +182,8 @@ struct svihmm_ctx {
   double svi_zsign = 1.0, svi_prior_const = 0.0;
   double* svi_elbo = nullptr; int svi_elbo_cap = 0;      // pinned + mapped: elbo_vec
   std::vector<hipEvent_t> svi_ev;                        // iteration boundaries (iter_time)
+  std::vector<int> svi_ev_begin;                         // event that marks the start of iteration it
+  int svi_last_it = -1;
   bool svi_active = false, svi_f32_ok = true;
   hipEvent_t svi_ea = nullptr, svi_eb = nullptr, globals_ev = nullptr;   // side-stream globals kernel
   hipEvent_t svi_ec = nullptr, svi_ed = nullptr;   // theta ready / side-stream ELBO kernels done
@@ -299,6 +306,7 @@ int svihmm_destroy(svihmm_ctx* h) {
   }
   if (h->stream2) hipStreamDestroy(h->stream2);
   for (auto& ps : h->pins) { if (ps.p) hipHostFree(ps.p); if (ps.ev) hipEventDestroy(ps.ev); }
+  for (auto& ss : h->svi_starts) if (ss.p) hipHostFree(ss.p);
   if (h->pin_status) hipHostFree(h->pin_status);
   if (h->mirror) hipHostFree(h->mirror);
   hipStreamDestroy(h->stream);
@@ -1008,7 +1016,20 @@ static int pull_small(svihmm_ctx* h, void* dst, const void* pin, size_t bytes) {
 static int upload_starts(svihmm_ctx* h, const int64_t* starts, int B) {
   CK(ensure(h->starts, (size_t)B * sizeof(int64_t)));
   const size_t nb = (size_t)B * sizeof(int64_t);
-  if (nb <= (size_t)4 << 20) {   // through a pinned slot: no host-side wait for the stream
+  if (h->svi_upload_it >= 0 && nb <= (size_t)1 << 20) {
+    svihmm_ctx::StartSlot& ss = h->svi_starts[h->svi_upload_it % 8];
+    if (ss.used_it >= 0 && 2 * ss.used_it + 1 < (int)h->svi_ev.size())
+      HIPCK(hipEventSynchronize(h->svi_ev[2 * ss.used_it + 1]));   // (eight iterations back: long complete)
+    if (nb > ss.cap) {
+      if (ss.p) hipHostFree(ss.p);
+      ss.p = nullptr; ss.cap = 0;
+      HIPCK(hipHostMalloc(&ss.p, nb + 4096, hipHostMallocMapped));
+      ss.cap = nb + 4096;
+    }
+    std::memcpy(ss.p, starts, nb);
+    CK(pull_small(h, h->starts.p, ss.p, nb));
+    ss.used_it = h->svi_upload_it;
+  } else if (nb <= (size_t)4 << 20) {   // through a pinned slot: no host-side wait for the stream
     void* pin = nullptr;
     int slot = 0;
     CK(pinned(h, nb, &pin, &slot));
@@ -1071,13 +1092,18 @@ static int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool sc
       HIPCK(hipGetLastError());
       h->orb_valid = true;
     }
-    const size_t lds = (size_t)128 * LEN * 8 + 128 * 9;
-    dim3 grid((unsigned)((n + 127) / 128));
-#define EMO(NTV, UV) hipLaunchKernelGGL((k_emission_orbit<NTV, UV>), grid, dim3(256), lds, stream,           \
+    // fewer than one 128-row workgroup per CU: 64-row workgroups (variant[5] = 2: always 128)
+    const int MTo = ((n + 127) / 128 < 256 && h->variant[5] != 2) ? 1 : 2;
+    const int rows = 64 * MTo;
+    const size_t lds = (size_t)rows * LEN * 8 + rows * 9;
+    dim3 grid((unsigned)((n + rows - 1) / rows));
+#define EMO(NTV, UV, MTV) hipLaunchKernelGGL((k_emission_orbit<NTV, UV, MTV>), grid, dim3(256), lds, stream,  \
                                         (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K,               \
                                         (const double*)h->theta_orb.p, flags, out, kexp_out, ll0_out)
-    if (D % 16 == 0) { if (NT == 4) EMO(4, 4); else if (NT == 3) EMO(3, 4); else if (NT == 2) EMO(2, 4); else EMO(1, 4); }
-    else             { if (NT == 4) EMO(4, 2); else if (NT == 3) EMO(3, 2); else if (NT == 2) EMO(2, 2); else EMO(1, 2); }
+#define EMOM(NTV, UV) do { if (MTo == 1) EMO(NTV, UV, 1); else EMO(NTV, UV, 2); } while (0)
+    if (D % 16 == 0) { if (NT == 4) EMOM(4, 4); else if (NT == 3) EMOM(3, 4); else if (NT == 2) EMOM(2, 4); else EMOM(1, 4); }
+    else             { if (NT == 4) EMOM(4, 2); else if (NT == 3) EMOM(3, 2); else if (NT == 2) EMOM(2, 2); else EMOM(1, 2); }
+#undef EMOM
 #undef EMO
     HIPCK(hipGetLastError());
     return 0;
@@ -1634,7 +1660,11 @@ static int wait_side_streams(svihmm_ctx* h) {
 }
 static int run_fb(svihmm_ctx* h, int B, int Lm, int var, bool want_lb, bool total) {
   h->m_nb = 0;
-  CK(wait_globals(h));
+  // the sweeps need the globals kernel of the SVI loop's side stream; the loop's other cross-stream
+  // wait (the previous iteration's ELBO kernels, before the global step rewrites what they read) is
+  // taken at the same place: every stream-order event between two kernels of the iteration's chain
+  // costs a few microseconds of dispatch, two in a row less than two apart
+  CK(wait_side_streams(h));
   if (var == 3) {
     h->have_lb = true;   // materialised lazily
     return launch_fb_lin(h, B, Lm, total);
@@ -2437,7 +2467,7 @@ static int svi_globals(svihmm_ctx* h, int slot) {
 // theta + log det for the factors now in h->niw (main stream: the next emission GEMM needs theta);
 // their ELBO term vlb[] and, with elbo_it >= 0, elbo_vec[elbo_it] on the side stream -- only the
 // ELBO trace needs them, so they stay off the critical path of the iteration chain.
-static int svi_refresh_emission(svihmm_ctx* h, int elbo_it, int lb_slot) {
+static int svi_refresh_emission(svihmm_ctx* h, int elbo_it, int lb_slot, hipEvent_t after_theta = nullptr) {
   const int K = h->svi_K, D = h->svi_D;
   if (!h->stream3) HIPCK(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
   if (!h->svi_ec) {
@@ -2447,8 +2477,10 @@ static int svi_refresh_emission(svihmm_ctx* h, int elbo_it, int lb_slot) {
   CK(launch_niw_to_theta(h, K, D, svi_ptr(h, 4)));
   h->lin_stale = true;
   hipStream_t s2 = h->stream3;
-  HIPCK(hipEventRecord(h->svi_ec, h->stream));
-  HIPCK(hipStreamWaitEvent(s2, h->svi_ec, 0));
+  // (the iteration's end-of-iteration timing event doubles as the fork point of the ELBO kernels)
+  hipEvent_t fork = after_theta ? after_theta : h->svi_ec;
+  HIPCK(hipEventRecord(fork, h->stream));
+  HIPCK(hipStreamWaitEvent(s2, fork, 0));
   {
     ProfScope ps(h, KS_MISC, s2);
     hipLaunchKernelGGL(k_svi_vlb, dim3(2 * K), dim3(64), 0, s2, (const double*)h->theta.p,
@@ -2546,6 +2578,10 @@ int svihmm_svi_begin(svihmm_ctx* h, int32_t K, int32_t D, const double* prior_tr
     HIPCK(hipEventCreate(&e));
     h->svi_ev.push_back(e);
   }
+  h->svi_ev_begin.assign(maxit, 0);
+  h->svi_last_it = -1;
+  HIPCK(hipStreamSynchronize(h->stream));          // (the rings below are keyed to this loop's events)
+  for (auto& ss : h->svi_starts) ss.used_it = -1;
   CK(svi_refresh_emission(h, -1, 0));   // theta of the initial factors (their vlb is not used)
   h->svi_vi_cur = 1;
   CK(svi_globals(h, 0));             // globals of iteration 0
@@ -2562,14 +2598,26 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
   if (flags & SVIHMM_USE_HOST_LLIKS) return fail("svihmm_svi_iteration: NIW emission only");
   CK(set_device(h));
   const int K = h->svi_K, D = h->svi_D;
-  HIPCK(hipEventRecord(h->svi_ev[2 * it], h->stream));
+  // start of the iteration: when the previous iteration is still running, the stream would execute
+  // this marker right behind that iteration's end marker -- the end marker serves as both
+  if ((int)h->svi_ev_begin.size() < h->svi_maxit) h->svi_ev_begin.resize(h->svi_maxit, 0);
+  h->svi_ev_begin[it] = 2 * it;
+  if (it > 0 && h->svi_last_it == it - 1 && hipEventQuery(h->svi_ev[2 * it - 1]) == hipErrorNotReady)
+    h->svi_ev_begin[it] = 2 * it - 1;
+  else
+    HIPCK(hipEventRecord(h->svi_ev[2 * it], h->stream));
+  (void)hipGetLastError();            // (hipErrorNotReady is not an error here)
+  h->svi_last_it = it;
   if (!h->svi_globals_ready) CK(svi_globals(h, h->svi_vi_cur ^ 1));   // (a host set_globals came in between)
   h->svi_vi_cur = h->svi_globals_slot;
   h->svi_globals_ready = false;       // consumed by this iteration's sweeps
   const bool keep = (flags & SVIHMM_SVI_KEEP_WINDOW) != 0;
   flags &= ~(uint32_t)SVIHMM_SVI_KEEP_WINDOW;
   if (B > 0) {
-    CK(estep_core(h, starts, B, Lm, inner_off, inner_len, flags));
+    h->svi_upload_it = it;
+    const int rc = estep_core(h, starts, B, Lm, inner_off, inner_len, flags);
+    h->svi_upload_it = -1;
+    if (rc) return rc;
     // the last window's log-domain rows are rebuilt on demand from the CURRENT parameters:
     // do it now, before the global step replaces them
     if (keep && h->lin_mode) CK(materialise(h, B - 1, 1));
@@ -2596,9 +2644,12 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
                        (double)nwin_total, svi_ptr(h, 8) + (it & 1));
     HIPCK(hipGetLastError());
   }
-  if (it + 1 < h->svi_maxit) CK(svi_globals(h, h->svi_vi_cur ^ 1));   // the next iteration's, ahead of time
-  CK(svi_refresh_emission(h, it, it & 1));
-  HIPCK(hipEventRecord(h->svi_ev[2 * it + 1], h->stream));
+  // the next iteration's globals, ahead of time, forked right behind the global step (its own event:
+  // forked behind theta together with the ELBO kernels it competes with the next emission GEMM,
+  // ends after that GEMM, and a stream wait that really has to block wakes up ~20 us late -- measured
+  // 0.272 against 0.25 ms per iteration)
+  if (it + 1 < h->svi_maxit) CK(svi_globals(h, h->svi_vi_cur ^ 1));
+  CK(svi_refresh_emission(h, it, it & 1, h->svi_ev[2 * it + 1]));
   return 0;
 }
 
@@ -2613,7 +2664,7 @@ int svihmm_svi_read_elbo(svihmm_ctx* h, int32_t n, double* out_elbo, double* out
     if (out_elbo) out_elbo[i] = h->svi_elbo[i];
     if (out_ms) {
       float ms = 0.f;
-      out_ms[i] = hipEventElapsedTime(&ms, h->svi_ev[2 * i], h->svi_ev[2 * i + 1]) == hipSuccess ? (double)ms : NAN;
+      out_ms[i] = hipEventElapsedTime(&ms, h->svi_ev[(int)h->svi_ev_begin.size() > i ? h->svi_ev_begin[i] : 2 * i], h->svi_ev[2 * i + 1]) == hipSuccess ? (double)ms : NAN;
     }
   }
   return 0;

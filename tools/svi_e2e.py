@@ -19,6 +19,6 @@ for mb, L_ in ((64, 128), (3891, 128)):
     hmm = hmmsgd_metaobs.VBHMM(obs, np.ones(K), np.ones((K, K)), prior, tau=1.0, kappa=0.7, metaobs_half=L_,
                                mb_sz=mb, maxit=int(os.environ.get("MAXIT", 12)), seed=1, metaobs_fun='unif')
     pr = cProfile.Profile(); t0 = time.time(); pr.enable(); hmm.infer(); pr.disable(); dt = time.time() - t0
-    print("mb_sz=%d: %.1f ms/iteration wall (iter_time mean %.2f ms = E-step + global step), elbo[-1]=%.4g" % (
+    print("mb_sz=%d: %.1f ms/iteration wall (iter_time mean %.4f ms = E-step + global step), elbo[-1]=%.4g" % (
         mb, dt / int(os.environ.get("MAXIT", 12)) * 1e3, hmm.iter_time[2:].mean() * 1e3, hmm.elbo_vec[-1]))
     pstats.Stats(pr).sort_stats("cumulative").print_stats(int(os.environ.get("NSTAT", 14)))
