@@ -281,7 +281,9 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
     const int* __restrict__ fab, const ST* __restrict__ q, int64_t rows_per_chunk,
     uint32_t flags, int Lq, int off, double* __restrict__ part, int KpTot, int mt_limit,
     const ST* __restrict__ bh, const double* __restrict__ hx, const double* __restrict__ gx,
-    const double2* __restrict__ zfac) {
+    const double2* __restrict__ zfac, double* __restrict__ qout) {
+  // qout (LIN, wide models): the first feature group's workgroups also write the posteriors
+  // q = ah bh scale they form while staging, for the transition-block launch that follows
   static_assert(ST_RB == 32, "row permutation assumes 32-row stages");
   static_assert(NB == 2 || NB == 3, "double or triple buffering");
   // column stride of the A-operand tile: NB buffers of 33 row slots + padding such that 16
@@ -349,6 +351,7 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
   const int64_t Q0 = bw0 * Lq + off;
   const ST* __restrict__ qthr = q + Q0 * K + kbase + sc;   // per-thread bases
   const ST* __restrict__ bthr = LIN ? bh + Q0 * K + kbase + sc : nullptr;
+  double* __restrict__ qothr = (LIN && qout && blockIdx.y == 0) ? qout + Q0 * K + kbase + sc : nullptr;
   const ST* __restrict__ pthr = q + Q0 * K + pbase + sc;
   const ST* __restrict__ bpthr = LIN ? bh + Q0 * K + pbase + sc : nullptr;
 
@@ -418,6 +421,7 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
   double rx[XK], rq[QK], rp[PK];
   double rq2[LIN ? QK : 1], rp2[LIN ? PK : 1], rsq = 0.0, rsp = 0.0;
   bool okx = false, okq = false, okp = false;
+  int qo_row = 0;                            // q offset of the row fetched last (qout)
   auto fetch = [&](int buf) {
     const StRow4 ri = rinfo[buf * ST_RB + sr];
     okx = ri.ooff >= 0; okq = ri.qoff >= 0; okp = ri.pok != 0;
@@ -429,6 +433,7 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
     }
     {
       const int o = okq ? ri.qoff : 0;
+      qo_row = o;
 #pragma unroll
       for (int k = 0; k < QK; ++k) rq[k] = qthr[o + TPR * k];
       if (LIN) {
@@ -463,6 +468,7 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
     for (int k = 0; k < QK; ++k) {
       const double v = LIN ? (rq[k] * rq2[k]) * rsq : (okq ? rq[k] : 0.0);
       qs0[U * ST_RB * QS + qwi + TPR * k] = (CT)v;
+      if (LIN && qothr && okq && kbase + sc + TPR * k < K) qothr[qo_row + TPR * k] = v;
     }
     if (need_qp) {
 #pragma unroll

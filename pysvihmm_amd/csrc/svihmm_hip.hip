@@ -1732,7 +1732,7 @@ static int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, in
   const bool lin = h->lin_mode && !h->q_valid && var == 3 && (Kp <= 64 || h->variant[15] != 1);
   if (h->lin_mode && !lin) CK(ensure_q(h, h->curB, Lq, stream));
   const size_t qo = (size_t)b0 * Lq * K;
-  const double* qv = (const double*)(lin ? h->la.p : h->q.p) + qo;
+  const double* qv = (const double*)(lin ? h->la.p : h->q.p) + qo;   // (reassigned: see the transition blocks)
   const double* bhv = lin ? (const double*)h->lb.p + qo : nullptr;
   const double* hxv = lin ? (const double*)h->hx.p + (size_t)b0 * Lq : nullptr;
   const double* gxv = lin ? (const double*)h->gx.p + (size_t)b0 * Lq : nullptr;
@@ -1745,6 +1745,14 @@ static int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, in
       // K > 64: state groups of 64 in grid.z for the emission-statistics tiles; the K x K
       // transition tiles (which need q[t-1] of ALL states as operand rows) go to k_stats_mfma.
       const bool big = Kp > 64;
+      // wide models, scaled sweeps: the feature launch leaves q = ah bh scale behind for the
+      // transition-block launch (whose little matrix work per staged row cannot carry two more
+      // operand streams: 3.3 against 2.4 ms on configs[4])
+      double* qoutv = nullptr;
+      if (big && lin) {
+        CK(ensure(h->q, (size_t)h->curB * Lq * K * sizeof(double)));
+        qoutv = (double*)h->q.p + qo;
+      }
       const int NTt = big ? 4 : Kp / 16;                // n-tiles per workgroup
       const int KpW = 16 * NTt;
       const int NSPLIT = (NTt == 4) ? 2 : 1;
@@ -1768,7 +1776,7 @@ static int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, in
     hipLaunchKernelGGL((k_stats_mfma4<MTV, NTW, NS, XKV, true, false, float, float>), grid,      \
                        dim3(256 * NS), ldsf, stream, (const double*)h->obs.p, mk, starts_dev, n, \
                        Lm, D, K, Fp, F, (const int*)h->fab.p, (const float*)h->la.p, rpc, flags, \
-                       Lq, off, partv, Kp, mt_limit, (const float*)h->lb.p, hxv, gxv, zfv);      \
+                       Lq, off, partv, Kp, mt_limit, (const float*)h->lb.p, hxv, gxv, zfv, (double*)nullptr); \
   } while (0)
 #define ST3FX(NTW, NS) do { if (xk <= 1) ST3F(5, NTW, NS, 1); else if (xk <= 3) ST3F(5, NTW, NS, 3); else if (xk <= 5) ST3F(5, NTW, NS, 5); else ST3F(5, NTW, NS, 9); } while (0)
 #define ST3FS(MTV, NTW, NS) do { if (xk <= 1) ST3F(MTV, NTW, NS, 1); else ST3F(MTV, NTW, NS, 3); } while (0)
@@ -1795,7 +1803,7 @@ static int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, in
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);                                \
     hipLaunchKernelGGL((k_stats_mfma4<5, 2, 2, XKV, LN, false, double, double, 3>), grid, dim3(512), lds3,     \
                        stream, (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, Fp, F,                    \
-                       (const int*)h->fab.p, qv, rpc, flags, Lq, off, partv, Kp, mt_limit, bhv, hxv, gxv, zfv); \
+                       (const int*)h->fab.p, qv, rpc, flags, Lq, off, partv, Kp, mt_limit, bhv, hxv, gxv, zfv, qoutv); \
   } while (0)
 #define ST3T(XKV) do { if (lin) ST3TL(XKV, true); else ST3TL(XKV, false); } while (0)
           if (xk <= 1) ST3T(1); else if (xk <= 3) ST3T(3); else if (xk <= 5) ST3T(5); else ST3T(9);
@@ -1810,7 +1818,7 @@ static int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, in
     hipLaunchKernelGGL((k_stats_mfma4<MTV, NTW, NS, XKV, LN>), grid, dim3(256 * NS), lds, stream, \
                        (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, Fp,                  \
                        F, (const int*)h->fab.p, qv, rpc, flags, Lq, off,                          \
-                       partv, Kp, mt_limit, bhv, hxv, gxv, zfv);                                  \
+                       partv, Kp, mt_limit, bhv, hxv, gxv, zfv, qoutv);                           \
   } while (0)
 #define ST3(MTV, NTW, NS, XKV) do { if (lin) ST3L(MTV, NTW, NS, XKV, true); else ST3L(MTV, NTW, NS, XKV, false); } while (0)
 #define ST3X(NTW, NS) do { if (xk <= 1) ST3(5, NTW, NS, 1); else if (xk <= 3) ST3(5, NTW, NS, 3); else if (xk <= 5) ST3(5, NTW, NS, 5); else ST3(5, NTW, NS, 9); } while (0)
@@ -1839,7 +1847,7 @@ static int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, in
     hipLaunchKernelGGL((k_stats_mfma4<MTV, 2, 2, 1, LN, true>), g2, dim3(512), ldt, stream,      \
                        (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, Fp,                  \
                        F, (const int*)h->fab.p, qv, rpc, flags, Lq, off,                          \
-                       partv, Kp, mt_limit, bhv, hxv, gxv, zfv);                                  \
+                       partv, Kp, mt_limit, bhv, hxv, gxv, zfv, qoutv);                           \
   } while (0)
 #define STT3(MTV, LN)                                                                             \
   do {                                                                                           \
@@ -1848,16 +1856,13 @@ static int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, in
     hipLaunchKernelGGL((k_stats_mfma4<MTV, 2, 2, 1, LN, true, double, double, 3>), g2, dim3(512), ldt3, stream, \
                        (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, Fp,                  \
                        F, (const int*)h->fab.p, qv, rpc, flags, Lq, off,                          \
-                       partv, Kp, mt_limit, bhv, hxv, gxv, zfv);                                  \
+                       partv, Kp, mt_limit, bhv, hxv, gxv, zfv, qoutv);                           \
   } while (0)
           // (no obs columns in these tiles: XK = 1 always, the three-buffer loop always fits)
-          if (h->variant[12] != 1) {
-            if (lin) { if (MTt == 2) STT3(2, true); else STT3(1, true); }
-            else { if (MTt == 2) STT3(2, false); else STT3(1, false); }
-          } else {
-            if (lin) { if (MTt == 2) STT(2, true); else STT(1, true); }
-            else { if (MTt == 2) STT(2, false); else STT(1, false); }
-          }
+          if (lin) qv = qoutv;      // written by the feature launch above
+          if (h->variant[12] != 1) { if (MTt == 2) STT3(2, false); else STT3(1, false); }
+          else { if (MTt == 2) STT(2, false); else STT(1, false); }
+          if (lin && off == 0 && Lm == Lq && b0 == 0 && nb == h->curB) h->q_valid = true;
 #undef STT3
 #undef STT
         }
@@ -1942,7 +1947,7 @@ static int launch_stats_cat(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint3
                        (const double*)h->obs.p, mk, (const int64_t*)h->starts.p, n, Lm, D, K, 0, 0,
                        (const int*)nullptr, (const double*)h->q.p, plan.rpc, flags, Lq, off,
                        (double*)h->part.p, KpT, 0, (const double*)nullptr, (const double*)nullptr,
-                       (const double*)nullptr, (const double2*)nullptr);
+                       (const double*)nullptr, (const double2*)nullptr, (double*)nullptr);
     const size_t ldsc = (size_t)V * Kp * sizeof(double);
     if (ldsc > 150 * 1024) return fail("Categorical statistics: V * K too large for the LDS table");
     if (ldsc > 64 * 1024)

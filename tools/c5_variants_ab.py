@@ -10,7 +10,7 @@ e = HipEngine(0); e.set_obs(pb['obs'], None); e.set_globals(pb['mod_init'], pb['
 e.set_emission_niw(pb['mu'], pb['sigma'], pb['kappa'], pb['nu'])
 B = T // Lm; starts = np.arange(B, dtype=np.int64) * Lm
 ref = None
-for name, var in [("base", {}), ("lin stats", {15: 1}), ("emission mt4", {3: 4}), ("both", {3: 4, 15: 1}), ("old r3c", {13: 1, 14: 1})]:
+for name, var in [("base", {}), ("posterior pass (15:1)", {15: 1}), ("round start (13,14,15:1)", {13: 1, 14: 1, 15: 1})]:
     for i in (3, 12, 13, 14, 15): e.set_variant(i, var.get(i, 0))
     e.estep(starts, Lm, read=False); out = e.read_packed().buf.copy()
     if ref is None: ref = out
