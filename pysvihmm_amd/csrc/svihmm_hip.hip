@@ -1121,6 +1121,9 @@ static int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool sc
     else {
       const int ntile = Kp / 16;
       int NT = (ntile % 4 == 0) ? 4 : (ntile % 2 == 0) ? 2 : 1;
+      // wide models: eight state tiles per wave -- every generated A operand feeds 8 instead of 4
+      // MFMAs (variant[3] = 1: four)
+      if (!scaled && MT == 2 && ntile % 8 == 0 && h->variant[3] != 1) NT = 8;
       if (scaled) { NT = ntile; MT = 2; }   // the workgroup must own whole rows (K <= 64)
       const int rows = 64 * MT;
       dim3 grid((unsigned)((n + rows - 1) / rows), ntile / NT);
@@ -1140,7 +1143,8 @@ static int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool sc
       } else if (MT == 4) {
         if (NT == 4) EMM_LAUNCH(4, 4, false); else if (NT == 2) EMM_LAUNCH(2, 4, false); else EMM_LAUNCH(1, 4, false);
       } else {
-        if (NT == 4) EMM_LAUNCH(4, 2, false); else if (NT == 2) EMM_LAUNCH(2, 2, false); else EMM_LAUNCH(1, 2, false);
+        if (NT == 8) EMM_LAUNCH(8, 2, false); else if (NT == 4) EMM_LAUNCH(4, 2, false);
+        else if (NT == 2) EMM_LAUNCH(2, 2, false); else EMM_LAUNCH(1, 2, false);
       }
 #undef EMM_LAUNCH
     }
