@@ -1070,11 +1070,6 @@ __global__ __launch_bounds__(64 * NW) void k_sweeps_lin2(
     const int cur = (s - 1) & 1, nxt = s & 1;
     const int t = rowof(s);
     const size_t ro = (size_t)t * K;
-    double e0[WT][4], e1[WT][4];
-#pragma unroll
-    for (int wt = 0; wt < WT; ++wt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { e0[wt][r] = (Eb + ro)[oE[wt][r] + jc0]; e1[wt][r] = (Eb + ro)[oE[wt][r] + jc1]; }
     // out[w][j] = sum_i P[w][i] M[i][j] for this wave's two state tiles and WT window tiles;
     // tot[w] = sum_i P[w][i]
     double4_t p0[WT], p1[WT], q0[WT], q1[WT];
@@ -1113,6 +1108,16 @@ __global__ __launch_bounds__(64 * NW) void k_sweeps_lin2(
         sb[wt] += x.y + y.y;
       }
     }
+    // the step's Eh values are requested BEHIND the B stream: vmcnt retires in order, so loads issued
+    // in front of the GEMM loop make its first operand wait for their HBM latency, and they would
+    // hold 16 WT registers through the loop
+    __builtin_amdgcn_sched_barrier(0);
+    double e0[WT][4], e1[WT][4];
+#pragma unroll
+    for (int wt = 0; wt < WT; ++wt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { e0[wt][r] = (Eb + ro)[oE[wt][r] + jc0]; e1[wt][r] = (Eb + ro)[oE[wt][r] + jc1]; }
+    __builtin_amdgcn_sched_barrier(0);
     const double4_t z = {0, 0, 0, 0};
 #pragma unroll
     for (int wt = 0; wt < WT; ++wt) {
