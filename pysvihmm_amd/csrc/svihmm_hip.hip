@@ -121,6 +121,9 @@ struct svihmm_ctx {
   const double* chain_kbef = nullptr; int chain_C = 0, chain_L = 0, chain_T = 0;   // of the last launch_fb_chain
   int lb_pending = 0;       // windows whose local_lb sum has not been written to packed yet
   bool orb_valid = false;   // theta_orb matches theta (k_theta_orbit ran since the last parameter upload)
+  Buf uwb;                  // fp32 mode: centred factors U_k as bf16 triples + bias (k_emission_bf16x3)
+  void* uw_zero_p = nullptr;
+  bool uw_valid = false;    // uwb matches the NIW factors in h->niw
   bool emis_cat = false; int V = 0;          // Categorical emission: table [V][K] = E log theta
   bool emis_diag = false;                    // diagonal Gaussian family: 2 D + 1 features, h->niw = [mu | nus | alphas | betas]
   bool tab_diag = false;                     // feature table currently on the device is the diagonal one
@@ -691,6 +694,23 @@ static int upload_feature_table(svihmm_ctx* h, int D, int K, bool diag = false) 
 // NIW parameter block in h->niw ([mu | sigma | kappa | nu], on the device) -> theta (both layouts);
 // logdet_out (device, [K]) optionally receives log det sigma_mf.  Asynchronous: a factor that is
 // not positive definite is reported by the next synchronising call.
+// fp32-mode emission (k_emission_bf16x3): shapes it takes and its parameter buffers -- 64 states of
+// EMB_BLOCKS x 64 x 16 B operand blocks, then 64 x EMB_BIAS_STRIDE floats (zeroed once: the kernel
+// streams whole stages, states beyond K included)
+static bool emb_shape_ok(int K, int D) { return K <= 64 && D <= 32; }
+static int emb_buffers(svihmm_ctx* h, uint4** uwp, float** ubp) {
+  const size_t nblk = (size_t)64 * EMB_BLOCKS * 64 * sizeof(uint4), nb = nblk + (size_t)64 * EMB_BIAS_STRIDE * sizeof(float);
+  CK(ensure(h->uwb, nb));
+  if (h->uw_zero_p != h->uwb.p) {
+    HIPCK(hipMemsetAsync(h->uwb.p, 0, nb, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));     // once per handle; the emission launch may sit on another stream
+    h->uw_zero_p = h->uwb.p;
+    h->uw_valid = false;
+  }
+  *uwp = (uint4*)h->uwb.p;
+  *ubp = (float*)((char*)h->uwb.p + nblk);
+  return 0;
+}
 static int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out) {
   CK(upload_feature_table(h, D, K));
   const int Fp = h->Fp, Kp = h->Kp;
@@ -726,11 +746,15 @@ static int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out) 
     }
     orbp = (double*)h->theta_orb.p;
   }
+  // fp32 mode: the centred factors of k_emission_bf16x3 come out of the same launch
+  uint4* uwp = nullptr;
+  float* ubp = nullptr;
+  if (h->prec == 1 && emb_shape_ok(K, D)) CK(emb_buffers(h, &uwp, &ubp));
   {
     ProfScope ps(h, KS_MISC);
 #define NIWW(DM) hipLaunchKernelGGL(k_niw_to_theta_wave<DM>, dim3(K), dim3(64), 0, h->stream, (const double*)dmu, \
                                     (const double*)dsg, (const double*)dka, (const double*)dnu, K, D, Kp,   \
-                                    (double*)h->theta.p, dstatus, orbp, logdet_out)
+                                    (double*)h->theta.p, dstatus, orbp, logdet_out, uwp, ubp)
     if (D <= 8) NIWW(8);
     else if (D <= 16) NIWW(16);
     else if (D <= 32) NIWW(32);
@@ -750,6 +774,7 @@ static int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out) 
   h->status_pending = true;
   h->eK = K; h->eD = D; h->have_emission = true; h->emis_cat = false; h->emis_diag = false;
   h->orb_valid = orbp != nullptr;
+  h->uw_valid = uwp != nullptr;
   return 0;
 }
 
@@ -777,7 +802,7 @@ static int launch_diag_to_theta(svihmm_ctx* h, int K, int D) {
     HIPCK(hipGetLastError());
   }
   h->status_pending = true;
-  h->eK = K; h->eD = D; h->have_emission = true; h->emis_cat = false; h->emis_diag = true;
+  h->eK = K; h->eD = D; h->have_emission = true; h->emis_cat = false; h->emis_diag = true; h->uw_valid = false;
   h->orb_valid = false;
   return 0;
 }
@@ -964,7 +989,7 @@ int svihmm_set_emission_cat(svihmm_ctx* h, int32_t K, int32_t V, const double* l
     for (int v = 0; v < V; ++v) hp[(size_t)v * K + k] = logp[(size_t)k * V + v];
   HIPCK(hipMemcpyAsync(h->cat_table.p, hp, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
   CK(pin_release(h, slot));
-  h->eK = K; h->eD = 1; h->V = V; h->Kp = K > 64 ? (K + 63) / 64 * 64 : (K + 15) / 16 * 16; h->have_emission = true; h->emis_cat = true; h->emis_diag = false;
+  h->eK = K; h->eD = 1; h->V = V; h->Kp = K > 64 ? (K + 63) / 64 * 64 : (K + 15) / 16 * 16; h->have_emission = true; h->emis_cat = true; h->emis_diag = false; h->uw_valid = false;
   return 0;
 }
 int64_t svihmm_packed_len(svihmm_ctx* h) { return h ? (int64_t)packed_len(h) : 0; }
@@ -1075,6 +1100,38 @@ static int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool sc
     hipLaunchKernelGGL(k_emission_cat, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream,
                        (const double*)h->obs.p, mk, starts_dev, n, Lm, K, h->V,
                        (const double*)h->cat_table.p, flags, out);
+    HIPCK(hipGetLastError());
+    return 0;
+  }
+  // fp32 mode, large batches of a NIW model with K <= 64, D <= 32: the centred bf16 x 3 kernel
+  // (variant[5] = 3: the fp64 feature GEMM also in this mode)
+  if (!h->emis_diag && scaled && (flags & SVIHMM_INT_ST32) && emb_shape_ok(K, D) && h->niw.p &&
+      h->variant[5] != 3 && min_lds == 0 && (n + 127) / 128 >= 256) {
+    uint4* uwp = nullptr;
+    float* ubp = nullptr;
+    CK(emb_buffers(h, &uwp, &ubp));
+    if (!h->uw_valid) {   // the mode was switched on after the parameter upload: factors from the resident NIW block
+      const double* dmu = (const double*)h->niw.p;
+      const double* dsg = dmu + (size_t)K * D;
+      const double* dka = dsg + (size_t)K * D * D;
+      const double* dnu = dka + K;
+#define NIWU(DM) hipLaunchKernelGGL(k_niw_to_theta_wave<DM>, dim3(K), dim3(64), 0, stream, dmu, dsg, dka, dnu, K, D, Kp, \
+                                    (double*)nullptr, (int*)nullptr, (double*)nullptr, (double*)nullptr, uwp, ubp)
+      if (D <= 8) NIWU(8); else if (D <= 16) NIWU(16); else NIWU(32);
+#undef NIWU
+      HIPCK(hipGetLastError());
+      h->uw_valid = true;
+    }
+    const size_t lds = (size_t)2 * 2 * EMB_NS * EMB_BLOCKS * 64 * 16 + (size_t)64 * EMB_BIAS_STRIDE * 4 +
+                       (size_t)8 * 64 * EMB_TS * 4 + (size_t)2 * 256 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIPCK(hipFuncSetAttribute((const void*)k_emission_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(k_emission_bf16x3, dim3((unsigned)((n + 255) / 256)), dim3(512), lds, stream,
+                       (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, (const uint4*)uwp, (const float*)ubp,
+                       flags, (float*)out, kexp_out, ll0_out);
     HIPCK(hipGetLastError());
     return 0;
   }

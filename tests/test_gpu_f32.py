@@ -114,3 +114,62 @@ def test_f32_class_infer_vs_reference_trace(name):
         np.testing.assert_allclose(hmm.var_emit[k].sigma_mf, g["it_new_sigma"][-1][k], rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(hmm.elbo_vec, g["elbo_vec"], rtol=1e-5)
     assert np.abs(hmm.var_x - g["w_var_x"][-1]).max() < 1e-3
+
+
+@pytest.mark.parametrize("K,D,B,Lm,off,sep", [(64, 32, 160, 257, 0.0, 4.0), (33, 16, 600, 65, 0.0, 4.0),
+                                              (5, 3, 1200, 40, 0.0, 1.0), (64, 32, 130, 257, 1e4, 4.0),
+                                              (17, 32, 2100, 16, -30.0, 0.5), (64, 7, 1040, 33, 0.0, 1.0),
+                                              (64, 32, 140, 257, 0.0, 0.25), (48, 24, 300, 129, 7.0, 0.4)])
+def test_f32_bf16x3_emission_large_batch(K, D, B, Lm, off, sep):
+    """Batches of >= 256 x 128 rows (NIW, K <= 64, D <= 32) in the fp32 mode take k_emission_bf16x3:
+    the centred quadratic form on the bf16 matrix pipe, x and U as three bf16 terms each.  Tolerance,
+    written here: statistics as the mode's other kernels (1e-3, asserted below 1e-4), posteriors
+    within 1e-4 absolute, local bound within 1e-5 relative (the log-likelihoods are fp32 values of
+    size |ll|), and the same batch through the fp64 feature GEMM of the mode (variant 5 = 3) agrees
+    to the same bounds.  Ragged K (state groups and pairs with padding), ragged D, masked rows, data
+    far from the origin (the handle's centre keeps the operands small), overlapping states (sep < 1:
+    soft posteriors, where an error in the log-likelihoods shows)."""
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    from oracle import ref_c
+    T = max(6000, B * 3 + Lm)
+    pb = make_problem(K, D, T, seed=K * 5 + D + 1, miss=0.03, sep=sep)
+    obs = pb["obs"] + off
+    mu = pb["mu"] + off
+    starts = np.random.default_rng(B + 1).integers(0, T - Lm + 1, size=B)
+    assert B * Lm >= 256 * 128
+    e = HipEngine(0, dtype="f32")
+    e.set_obs(obs, pb["mask"])
+    e.set_globals(pb["mod_init"], pb["ltran"])
+    e.set_emission_niw(mu, pb["sigma"], pb["kappa"], pb["nu"])
+    st = e.estep(starts, Lm, flags=L.TRANS_WRAP)
+    assert e.precision() == ("f32", True)
+    buf = st.buf.copy()
+    ref = ref_c.estep_minibatch(obs, pb["mask"], starts, Lm, pb["mod_init"], pb["ltran"], mu,
+                                pb["sigma"], pb["kappa"], pb["nu"], flags=2, threads=effective_cores())
+    A, xbar, neff, S, lb = unpack(ref, K, D)
+    sc = B * Lm
+    xs = max(np.abs(obs).max(), 1.0)
+    worst = max(_close(st.A_raw, A, sc, "A"), _close(st.neff, neff, sc, "neff"),
+                _close(st.xbar, xbar, sc * xs, "xbar"), _close(st.S, S, sc * xs ** 2, "S"))
+    assert worst < 1e-4, worst
+    np.testing.assert_allclose(st.lb[0], lb, rtol=1e-5)
+    for b in (0, B // 2, B - 1):
+        x = obs[starts[b]:starts[b] + Lm]
+        ll = ref_c.lliks_niw(x, mu, pb["sigma"], pb["kappa"], pb["nu"])
+        q, _ = ref_c.posterior(ref_c.forward(ll, pb["mod_init"], pb["ltran"]), ref_c.backward(ll, pb["ltran"]))
+        assert np.abs(e.read_rows("var_x", b * Lm, Lm) - q).max() < 1e-4
+    # the same batch with the fp64 feature GEMM in front of the fp32 sweeps / statistics
+    e.set_variant(5, 3)
+    st2 = e.estep(starts, Lm, flags=L.TRANS_WRAP)
+    assert e.precision() == ("f32", True)
+    np.testing.assert_allclose(st2.lb[0], lb, rtol=1e-5)
+    d = np.abs(st2.buf - buf)
+    assert np.all(d <= 1e-3 * np.abs(buf) + 1e-6 * sc * xs ** 2)
+    # the mode switched on AFTER the parameter upload: factors built from the resident NIW block
+    e3 = HipEngine(0)
+    e3.set_obs(obs, pb["mask"]); e3.set_globals(pb["mod_init"], pb["ltran"])
+    e3.set_emission_niw(mu, pb["sigma"], pb["kappa"], pb["nu"])
+    e3.set_precision("f32")
+    np.testing.assert_array_equal(e3.estep(starts, Lm, flags=L.TRANS_WRAP).buf, buf)
+    e.close(); e3.close()
