@@ -15,9 +15,7 @@
 // A value is carried as three bf16 terms hi + mid + lo (round-to-nearest each, residuals formed
 // in double): 24+ significant bits, i.e. the value to fp32 accuracy, on the bf16 matrix pipe.
 constexpr int EMB_BLOCKS = 6;         // per state: 3 terms x 2 k-blocks of 64 lanes x 16 B (A operands)
-constexpr int EMB_BIAS_STRIDE = 36;   // per state: 32 bias floats, the constant, padding
-constexpr int EMB_NS = 2;             // states per LDS stage and state group
-constexpr int EMB_TS = 36;            // row stride (floats) of a wave's 64 x 32 log-likelihood tile in LDS
+constexpr int EMB_REC = 6400;         // bytes per state record: the six blocks, 32 bias floats, the constant, padding
 __device__ __forceinline__ uint32_t bf16_rne(float f) {
   uint32_t u = __float_as_uint(f);
   u += 0x7fffu + ((u >> 16) & 1u);
@@ -506,18 +504,17 @@ __global__ __launch_bounds__(256) void k_emission_orbit(
 //  travel as three bf16 terms each (hi + mid + lo = the value to fp32 accuracy) and the six
 //  products hi hi, hi mid, mid hi, hi lo, lo hi, mid mid accumulate in fp32 -- what is left out
 //  is below 2^-24 of a product.  bf16 MFMA runs at 16x the fp32-input MFMA rate on gfx950, so the
-//  six-term product is 2.7x faster than an fp32 MFMA GEMM of the same shape and ~5x faster than
-//  the fp64 feature GEMM.
+//  six-term product is 2.7x faster than an fp32 MFMA GEMM of the same shape.
 //  v_mfma_f32_32x32x16_bf16: M = the 32 components of one state (A = U_k blocks from LDS),
 //  N = 32 rows of the batch (B = x, held in registers for the whole state loop), k = the
 //  observation's dimensions (two instructions per product term); C = the bias.  A lane's 16
 //  results are components of ONE row: the square sum is in-lane plus one exchange between the
 //  wave's halves, which at the same time deals the states of a pair to the two halves.
-//  Workgroup = 8 waves on 256 rows: wave (grp, wq) takes rows 64 wq .. + 63 (two row tiles) and
-//  the states of group grp (the first / second half), so that a wave's 64 x 32 ll tile fits LDS
-//  beside the others'.  U streams through LDS in stages of EMB_NS states per group (double-
-//  buffered, one barrier per stage); the ll tiles are transposed through LDS so that the scaled
-//  epilogue (row maximum over both groups, exp2, float store) writes whole rows.
+//  Workgroup = 4 waves x 64 rows, two workgroups per CU (so that one's prologue / epilogue runs
+//  under the other's MFMAs).  The state records (six operand blocks + bias + constant, EMB_REC
+//  bytes) stream global -> LDS directly (global_load_lds_dwordx4, two buffers, one barrier per
+//  state); the wave's 64 x 64 ll tile is transposed through LDS (XOR-swizzled columns) so that the
+//  scaled epilogue (row maximum, exp2, float store) writes whole rows.
 // ------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 embf8_t;
 typedef __attribute__((ext_vector_type(16))) float emf16_t;
@@ -527,45 +524,49 @@ __device__ __forceinline__ float row16_max_f32(float v) {
   v = fmaxf(v, __shfl_xor(v, 4, 64)); v = fmaxf(v, __shfl_xor(v, 8, 64));
   return v;
 }
+// fp32 value -> three bf16 terms, residuals exact in fp32
+__device__ __forceinline__ void bf16_split3f(float f, uint32_t (&t)[3]) {
+  t[0] = bf16_rne(f);
+  float r = f - bf16_up(t[0]);
+  t[1] = bf16_rne(r);
+  r -= bf16_up(t[1]);
+  t[2] = bf16_rne(r);
+}
+__device__ __forceinline__ void emb_glds16(const char* src, char* dst_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
+}
 
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_emission_bf16x3(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_emission_bf16x3(
     const double* __restrict__ obs, const uint8_t* __restrict__ mask,
     const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K,
-    const uint4* __restrict__ uw, const float* __restrict__ ub, uint32_t flags,
+    const char* __restrict__ uw, uint32_t flags,
     float* __restrict__ Eh, double* __restrict__ kexp, double* __restrict__ ll0) {
-  constexpr int NTH = 512, ROWS = 256;
-  constexpr int GR4 = EMB_NS * EMB_BLOCKS * 64;          // uint4 per stage and state group (768)
-  constexpr int CH4 = 2 * GR4, PER = CH4 / NTH;          // both groups: 1536 = 3 per thread
+  constexpr int ROWS = 256;
   extern __shared__ uint4 smem4[];
-  uint4* stage = smem4;                                              // [2][2][GR4]
-  float* bias_s = reinterpret_cast<float*>(stage + 2 * CH4);         // [64][EMB_BIAS_STRIDE]
-  float* tile_s = bias_s + 64 * EMB_BIAS_STRIDE;                     // [8 waves][64 rows][EMB_TS]
-  int* bad_s = reinterpret_cast<int*>(tile_s + 8 * 64 * EMB_TS);     // [2 groups][ROWS]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int grp = wave >> 2, wq = wave & 3;              // state group, row block of 64
+  char* stage = reinterpret_cast<char*>(smem4);                      // [2][EMB_REC]
+  float* tile_s = reinterpret_cast<float*>(stage + 2 * EMB_REC);     // [4 waves][64 rows][64 states]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int t = lane & 31, hh = lane >> 5;
   const int64_t g0 = (int64_t)blockIdx.x * ROWS;
-  const int SG = ((K + 2 * EMB_NS - 1) / (2 * EMB_NS)) * EMB_NS;     // states per group (multiple of EMB_NS)
-  const int nst = SG / EMB_NS;
+  const int npair = (K + 1) >> 1;
 
-  // stage 0 of U on its way while the rows are prepared
-  const uint4* usrc[PER];
-  uint4 sreg[PER];
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int o = tid + i * NTH, og = o / GR4;
-    usrc[i] = uw + (size_t)og * SG * (EMB_BLOCKS * 64) + (o - og * GR4);
-    sreg[i] = usrc[i][0];
-  }
-  for (int i = tid; i < 64 * EMB_BIAS_STRIDE; i += NTH)
-    bias_s[i] = (i < K * EMB_BIAS_STRIDE) ? ub[i] : 0.0f;
+  auto stage_load = [&](int k, int buf) {                            // record of state k -> buffer buf
+    const char* src = uw + (size_t)k * EMB_REC + lane * 16;
+    char* dst = stage + buf * EMB_REC;
+    emb_glds16(src + wave * 1024, dst + wave * 1024);
+    if (wave < 2) emb_glds16(src + (4 + wave) * 1024, dst + (4 + wave) * 1024);
+    if (wave == 2 && lane < 16) emb_glds16(src + 6144, dst + 6144);
+  };
+  stage_load(0, 0);
 
   // ---- the lane's two rows: dimensions 16 c + 8 hh + e as three bf16 terms (B operands)
-  int* badg = bad_s + grp * ROWS;
   embf8_t xb[2][3][2];
+  int bflag[2];
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
-    const int r = wq * 64 + m * 32 + t;
+    const int r = wave * 64 + m * 32 + t;
     const int64_t g = g0 + r;
     const bool valid = g < nrows;
     const int64_t gg = valid ? g : 0;
@@ -574,29 +575,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int64_t orow = starts[wi] + tt;
     int bd = 0;
     if (valid && (flags & SVIHMM_MASK_AS_NAN) && mask) bd = mask[orow] != 0;
-    if (hh == 0) badg[r] = bd | ((valid && tt == 0) ? 2 : 0);        // bit 1: step 0 of its window
     const double* xp = obs + orow * D;
     bool isnan_ = false;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       double v[8];
+      const int i0 = 16 * c + 8 * hh;
+      if ((D & 7) == 0) {                                            // whole groups of eight: 16-byte loads
+        const bool ok = valid && i0 < D;
+        const double2* x2 = reinterpret_cast<const double2*>(xp + (ok ? i0 : 0));
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int idx = 16 * c + 8 * hh + e;
-        const bool ok = valid && idx < D;
-        const double x = xp[ok ? idx : 0];
-        v[e] = ok ? x : 0.0;
+        for (int e = 0; e < 4; ++e) {
+          const double2 q2 = x2[e];
+          v[2 * e] = ok ? q2.x : 0.0; v[2 * e + 1] = ok ? q2.y : 0.0;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const bool ok = valid && i0 + e < D;
+          const double x = xp[ok ? i0 + e : 0];
+          v[e] = ok ? x : 0.0;
+        }
       }
       uint32_t w3[3][4];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         if (v[e] != v[e]) { isnan_ = true; v[e] = 0.0; }
         uint32_t t3[3];
-#if defined(EMB_KO) && (EMB_KO & 1)
-        t3[0] = __float_as_uint((float)v[e]) >> 16; t3[1] = t3[0] ^ 0x100; t3[2] = t3[0] ^ 0x200;
-#else
-        bf16_split3(v[e], t3);
-#endif
+        bf16_split3f((float)v[e], t3);
 #pragma unroll
         for (int s3 = 0; s3 < 3; ++s3) {
           if (e & 1) w3[s3][e >> 1] |= t3[s3] << 16; else w3[s3][e >> 1] = t3[s3];
@@ -606,111 +612,94 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int s3 = 0; s3 < 3; ++s3)
         xb[m][s3][c] = emb_cast(make_uint4(w3[s3][0], w3[s3][1], w3[s3][2], w3[s3][3]));
     }
-    if (isnan_) atomicOr(&badg[r], 1);                               // (after the wave's own store above)
+    int bf = bd | (isnan_ ? 1 : 0);
+    bf |= __shfl_xor(bf, 32, 64);                                    // the row's other half of the dimensions
+    bflag[m] = bf | ((valid && tt == 0) ? 2 : 0);                    // bit 1: step 0 of its window
   }
-#pragma unroll
-  for (int i = 0; i < PER; ++i) stage[tid + i * NTH] = sreg[i];
-  __syncthreads();
+  __syncthreads();                                                   // (carries the wait for record 0)
 
-  float* tw = tile_s + wave * 64 * EMB_TS;
-  for (int st = 0; st < nst; ++st) {
-#if !(defined(EMB_KO) && (EMB_KO & 2))
-    if (st + 1 < nst) {
+  float* tw = tile_s + wave * 64 * 64;
+  for (int sp = 0; sp < npair; ++sp) {
+    float pp[2][2];
 #pragma unroll
-      for (int i = 0; i < PER; ++i) sreg[i] = usrc[i][(size_t)(st + 1) * GR4];
-    }
-#endif
-    const uint4* sb = stage + (st & 1) * CH4 + grp * GR4;
+    for (int u = 0; u < 2; ++u) {
+      const int ks = 2 * sp + u;
+      const char* sb = stage + u * EMB_REC;
+      emf16_t bv;
 #pragma unroll
-    for (int sp = 0; sp < EMB_NS / 2; ++sp) {
-      float pp[2][2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int ks = grp * SG + st * EMB_NS + 2 * sp + u;
-        emf16_t bv;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 b4 = *reinterpret_cast<const float4*>(bias_s + ks * EMB_BIAS_STRIDE + 8 * q + 4 * hh);
-          bv[4 * q] = b4.x; bv[4 * q + 1] = b4.y; bv[4 * q + 2] = b4.z; bv[4 * q + 3] = b4.w;
-        }
-        embf8_t a[3][2];
-#pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3)
-#pragma unroll
-          for (int c = 0; c < 2; ++c) a[s3][c] = emb_cast(sb[((2 * sp + u) * EMB_BLOCKS + s3 * 2 + c) * 64 + lane]);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          emf16_t acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], xb[m][0][0], bv, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], xb[m][0][1], acc, 0, 0, 0);
-#pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][c], xb[m][1][c], acc, 0, 0, 0);   // hi mid
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][c], xb[m][0][c], acc, 0, 0, 0);   // mid hi
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][c], xb[m][2][c], acc, 0, 0, 0);   // hi lo
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][c], xb[m][0][c], acc, 0, 0, 0);   // lo hi
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][c], xb[m][1][c], acc, 0, 0, 0);   // mid mid
-          }
-#if defined(EMB_KO) && (EMB_KO & 8)
-          pp[u][m] = acc[0] + acc[5];
-#else
-          float p0 = 0.0f, p1 = 0.0f;
-#pragma unroll
-          for (int r = 0; r < 16; r += 2) { p0 = fmaf(acc[r], acc[r], p0); p1 = fmaf(acc[r + 1], acc[r + 1], p1); }
-          pp[u][m] = p0 + p1;
-#endif
-        }
+      for (int q = 0; q < 4; ++q) {
+        const float4 b4 = *reinterpret_cast<const float4*>(sb + 6144 + (8 * q + 4 * hh) * 4);
+        bv[4 * q] = b4.x; bv[4 * q + 1] = b4.y; bv[4 * q + 2] = b4.z; bv[4 * q + 3] = b4.w;
       }
-      // the halves exchange: lanes 0..31 finish the pair's first state, lanes 32..63 its second
-      const int kl = st * EMB_NS + 2 * sp + hh;                      // state within the group
-      const float cst = bias_s[(grp * SG + kl) * EMB_BIAS_STRIDE + 32];
+      embf8_t a[3][2];
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) a[s3][c] = emb_cast(*reinterpret_cast<const uint4*>(sb + ((s3 * 2 + c) * 64 + lane) * 16));
+      const float cst = *reinterpret_cast<const float*>(sb + 6144 + 128);
+      // the next record's copy is issued BEHIND this state's LDS reads: the compiler waits for an
+      // outstanding global -> LDS copy in front of the next LDS read, and that is then the barrier
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 1 < 2 * npair) stage_load(ks + 1, (u + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      emf16_t acc[2];
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-        const float send = hh ? pp[0][m] : pp[1][m];
-        const float keep = hh ? pp[1][m] : pp[0][m];
-        const float recv = __shfl_xor(send, 32, 64);
-        tw[(m * 32 + t) * EMB_TS + kl] = cst - (keep + recv);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], xb[m][0][0], bv, 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], xb[m][0][1], acc[m], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][c], xb[m][1][c], acc[m], 0, 0, 0);   // hi mid
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][c], xb[m][0][c], acc[m], 0, 0, 0);   // mid hi
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][c], xb[m][2][c], acc[m], 0, 0, 0);   // hi lo
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][c], xb[m][0][c], acc[m], 0, 0, 0);   // lo hi
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][c], xb[m][1][c], acc[m], 0, 0, 0);   // mid mid
+        }
+      }
+      // the barrier stays BEHIND the MFMAs (it carries the wait for the copy issued above); the
+      // square sums may drift into the next state's MFMA stream
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();                                               // record ks + 1 landed, record ks free
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) { p0 = fmaf(acc[m][r], acc[m][r], p0); p1 = fmaf(acc[m][r + 1], acc[m][r + 1], p1); }
+        pp[u][m] = cst - (p0 + p1);                                  // the lane half's share of cst - |y|^2
       }
     }
-#if !(defined(EMB_KO) && (EMB_KO & 2))
-    if (st + 1 < nst) {
+    // the halves exchange: lanes 0..31 finish the pair's first state, lanes 32..63 its second
+    const int kl = 2 * sp + hh;
 #pragma unroll
-      for (int i = 0; i < PER; ++i) stage[((st + 1) & 1) * CH4 + tid + i * NTH] = sreg[i];
+    for (int m = 0; m < 2; ++m) {
+      const float send = hh ? pp[0][m] : pp[1][m];
+      const float keep = hh ? pp[1][m] : pp[0][m];
+      const float recv = __shfl_xor(send, 32, 64);
+      const int r = m * 32 + t;
+      tw[r * 64 + (kl ^ ((r & 15) << 2))] = keep + recv;
     }
-#endif
-#if !(defined(EMB_KO) && (EMB_KO & 4))
-    __syncthreads();
-#endif
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
 
-  // ---- scaled epilogue: Eh = exp(ll) 2^-k, k = ceil(max_j ll / ln 2).  16 lanes per row, the
-  //      lane takes two adjacent states of either group; wave (grp, wq) finishes rows 32 grp .. + 31
-  //      of its row block from both groups' tiles
+  // ---- scaled epilogue: Eh = exp(ll) 2^-k, k = ceil(max_j ll / ln 2); 16 lanes per row of the
+  //      wave's own tile, four adjacent states each
   const int sg = lane & 15, rq = lane >> 4;
-  const float* t0 = tile_s + wq * 64 * EMB_TS;
-  const float* t1 = tile_s + (4 + wq) * 64 * EMB_TS;
   const double L2E = 1.4426950408889634074;
   const float l2e = 1.44269504f, fbig = 3.0e38f;
-  const bool lv = 2 * sg < SG;
-#if defined(EMB_KO) && (EMB_KO & 16)
-  if (g0 >= 0) return;
-#endif
-  for (int it = 0; it < 8; ++it) {
-    const int rl = grp * 32 + it * 4 + rq, r = wq * 64 + rl;
-    const int64_t g = g0 + r;
-    float2 va = make_float2(0.0f, 0.0f), vb = va;
-    if (lv) {
-      va = *reinterpret_cast<const float2*>(t0 + rl * EMB_TS + 2 * sg);
-      vb = *reinterpret_cast<const float2*>(t1 + rl * EMB_TS + 2 * sg);
-    }
-    const int bf = badg[r];
-    float v[4] = {va.x, va.y, vb.x, vb.y};
-    int kst[4] = {2 * sg, 2 * sg + 1, SG + 2 * sg, SG + 2 * sg + 1};
+  for (int it = 0; it < 16; ++it) {
+    const int rl = it * 4 + rq;
+    const int64_t g = g0 + wave * 64 + rl;
+    const float4 v4 = *reinterpret_cast<const float4*>(tw + rl * 64 + ((4 * sg) ^ ((rl & 15) << 2)));
+    const int bf = __shfl(bflag[it >> 3], rl & 31, 64);
+    float v[4] = {v4.x, v4.y, v4.z, v4.w};
     float mx = -INFINITY;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float x = v[i];
       x = (x != x || (bf & 1)) ? 0.0f : fminf(fmaxf(x, -fbig), fbig);
-      v[i] = (lv && kst[i] < K) ? x : -INFINITY;
+      v[i] = (4 * sg + i < K) ? x : -INFINITY;
       mx = fmaxf(mx, v[i]);
     }
     mx = row16_max_f32(mx);
@@ -720,19 +709,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(fmaf(v[i] - mx, l2e, fr));
     if (g < nrows) {
-      float* orow = Eh + g * K;
-      if (K == 64) {
-        *reinterpret_cast<float2*>(orow + kst[0]) = make_float2(e[0], e[1]);
-        *reinterpret_cast<float2*>(orow + kst[2]) = make_float2(e[2], e[3]);
-      } else {
+      float* orow = Eh + g * K + 4 * sg;
+      if (K == 64) *reinterpret_cast<float4*>(orow) = make_float4(e[0], e[1], e[2], e[3]);
+      else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) if (lv && kst[i] < K) orow[kst[i]] = e[i];
+        for (int i = 0; i < 4; ++i) if (4 * sg + i < K) orow[i] = e[i];
       }
       if (sg == 0) kexp[g] = (double)kx;
       if (ll0 && (bf & 2)) {
-        double* o0 = ll0 + (g / Lm) * K;
+        double* o0 = ll0 + (g / Lm) * K + 4 * sg;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) if (lv && kst[i] < K) o0[kst[i]] = (double)v[i];
+        for (int i = 0; i < 4; ++i) if (4 * sg + i < K) o0[i] = (double)v[i];
       }
     }
   }
@@ -898,7 +885,7 @@ __global__ __launch_bounds__(64) void k_niw_to_theta_wave(
     const double* __restrict__ mu, const double* __restrict__ sigma,
     const double* __restrict__ kappa, const double* __restrict__ nu, int K, int D, int Kp,
     double* __restrict__ theta, int* __restrict__ status, double* __restrict__ orb,
-    double* __restrict__ logdet_out, uint4* __restrict__ uw = nullptr, float* __restrict__ ub = nullptr) {
+    double* __restrict__ logdet_out, uint4* __restrict__ uw = nullptr) {
   __shared__ double col[64];
   __shared__ double Ls[DMAX][DMAX + 1];    // L (row-major), later X = L^-1 stored as Ls[c][r]
   __shared__ double ms[DMAX];
@@ -965,7 +952,8 @@ __global__ __launch_bounds__(64) void k_niw_to_theta_wave(
     if (uw) {
       const double shn = sqrt(hn);
       const int j = a & 31, hh = a >> 5;
-      uint4* blk = uw + (size_t)k * (EMB_BLOCKS * 64);
+      uint4* blk = uw + (size_t)k * (EMB_REC / 16);
+      float* ub = reinterpret_cast<float*>(blk + EMB_BLOCKS * 64);
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc) {
         uint32_t w3[3][4];
@@ -990,7 +978,7 @@ __global__ __launch_bounds__(64) void k_niw_to_theta_wave(
 #pragma unroll
           for (int cl = 0; cl < DMAX; ++cl) b = fma(Ls[cl][a < DMAX ? a : 0], ms[cl], b);           // sum_c X[a][c] m_c
         }
-        ub[(size_t)k * EMB_BIAS_STRIDE + a] = (float)(-shn * b);
+        ub[a] = (float)(-shn * b);
       }
     }
   }
@@ -1017,8 +1005,8 @@ __global__ __launch_bounds__(64) void k_niw_to_theta_wave(
     if (theta) theta_store(theta, orb, D, D, D, Kp, k, cst - mWm);
     if (logdet_out) logdet_out[k] = 2.0 * logdet;
     if (status && mWm > NIW_CANCEL_LIMIT) atomicMax(status, NIW_STATUS_RANGE + 1 + k);
-    if constexpr (DMAX <= 32) {
-      if (ub) ub[(size_t)k * EMB_BIAS_STRIDE + 32] = (float)cst;     // ll = cst - |U x + b|^2
+    if constexpr (DMAX <= 32) {   // ll = cst - |U x + b|^2; each half of the wave adds its share of the squares to cst / 2
+      if (uw) reinterpret_cast<float*>(uw + (size_t)k * (EMB_REC / 16) + EMB_BLOCKS * 64)[32] = (float)(0.5 * cst);
     }
   }
 }

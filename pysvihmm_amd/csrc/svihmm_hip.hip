@@ -694,12 +694,11 @@ static int upload_feature_table(svihmm_ctx* h, int D, int K, bool diag = false) 
 // NIW parameter block in h->niw ([mu | sigma | kappa | nu], on the device) -> theta (both layouts);
 // logdet_out (device, [K]) optionally receives log det sigma_mf.  Asynchronous: a factor that is
 // not positive definite is reported by the next synchronising call.
-// fp32-mode emission (k_emission_bf16x3): shapes it takes and its parameter buffers -- 64 states of
-// EMB_BLOCKS x 64 x 16 B operand blocks, then 64 x EMB_BIAS_STRIDE floats (zeroed once: the kernel
-// streams whole stages, states beyond K included)
+// fp32-mode emission (k_emission_bf16x3): shapes it takes and its parameter buffer -- 64 state records
+// of EMB_REC bytes (zeroed once: the kernel streams records in pairs, one beyond an odd K included)
 static bool emb_shape_ok(int K, int D) { return K <= 64 && D <= 32; }
-static int emb_buffers(svihmm_ctx* h, uint4** uwp, float** ubp) {
-  const size_t nblk = (size_t)64 * EMB_BLOCKS * 64 * sizeof(uint4), nb = nblk + (size_t)64 * EMB_BIAS_STRIDE * sizeof(float);
+static int emb_buffers(svihmm_ctx* h, uint4** uwp) {
+  const size_t nb = (size_t)64 * EMB_REC;
   CK(ensure(h->uwb, nb));
   if (h->uw_zero_p != h->uwb.p) {
     HIPCK(hipMemsetAsync(h->uwb.p, 0, nb, h->stream));
@@ -708,7 +707,6 @@ static int emb_buffers(svihmm_ctx* h, uint4** uwp, float** ubp) {
     h->uw_valid = false;
   }
   *uwp = (uint4*)h->uwb.p;
-  *ubp = (float*)((char*)h->uwb.p + nblk);
   return 0;
 }
 static int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out) {
@@ -748,13 +746,12 @@ static int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out) 
   }
   // fp32 mode: the centred factors of k_emission_bf16x3 come out of the same launch
   uint4* uwp = nullptr;
-  float* ubp = nullptr;
-  if (h->prec == 1 && emb_shape_ok(K, D)) CK(emb_buffers(h, &uwp, &ubp));
+  if (h->prec == 1 && emb_shape_ok(K, D)) CK(emb_buffers(h, &uwp));
   {
     ProfScope ps(h, KS_MISC);
 #define NIWW(DM) hipLaunchKernelGGL(k_niw_to_theta_wave<DM>, dim3(K), dim3(64), 0, h->stream, (const double*)dmu, \
                                     (const double*)dsg, (const double*)dka, (const double*)dnu, K, D, Kp,   \
-                                    (double*)h->theta.p, dstatus, orbp, logdet_out, uwp, ubp)
+                                    (double*)h->theta.p, dstatus, orbp, logdet_out, uwp)
     if (D <= 8) NIWW(8);
     else if (D <= 16) NIWW(16);
     else if (D <= 32) NIWW(32);
@@ -1108,29 +1105,27 @@ static int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool sc
   if (!h->emis_diag && scaled && (flags & SVIHMM_INT_ST32) && emb_shape_ok(K, D) && h->niw.p &&
       h->variant[5] != 3 && min_lds == 0 && (n + 127) / 128 >= 256) {
     uint4* uwp = nullptr;
-    float* ubp = nullptr;
-    CK(emb_buffers(h, &uwp, &ubp));
+    CK(emb_buffers(h, &uwp));
     if (!h->uw_valid) {   // the mode was switched on after the parameter upload: factors from the resident NIW block
       const double* dmu = (const double*)h->niw.p;
       const double* dsg = dmu + (size_t)K * D;
       const double* dka = dsg + (size_t)K * D * D;
       const double* dnu = dka + K;
 #define NIWU(DM) hipLaunchKernelGGL(k_niw_to_theta_wave<DM>, dim3(K), dim3(64), 0, stream, dmu, dsg, dka, dnu, K, D, Kp, \
-                                    (double*)nullptr, (int*)nullptr, (double*)nullptr, (double*)nullptr, uwp, ubp)
+                                    (double*)nullptr, (int*)nullptr, (double*)nullptr, (double*)nullptr, uwp)
       if (D <= 8) NIWU(8); else if (D <= 16) NIWU(16); else NIWU(32);
 #undef NIWU
       HIPCK(hipGetLastError());
       h->uw_valid = true;
     }
-    const size_t lds = (size_t)2 * 2 * EMB_NS * EMB_BLOCKS * 64 * 16 + (size_t)64 * EMB_BIAS_STRIDE * 4 +
-                       (size_t)8 * 64 * EMB_TS * 4 + (size_t)2 * 256 * 4;
+    const size_t lds = (size_t)2 * EMB_REC + (size_t)4 * 64 * 64 * 4;     // two workgroups per CU
     static bool attr_set = false;
     if (!attr_set) {
       HIPCK(hipFuncSetAttribute((const void*)k_emission_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr_set = true;
     }
-    hipLaunchKernelGGL(k_emission_bf16x3, dim3((unsigned)((n + 255) / 256)), dim3(512), lds, stream,
-                       (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, (const uint4*)uwp, (const float*)ubp,
+    hipLaunchKernelGGL(k_emission_bf16x3, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, stream,
+                       (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, (const char*)uwp,
                        flags, (float*)out, kexp_out, ll0_out);
     HIPCK(hipGetLastError());
     return 0;

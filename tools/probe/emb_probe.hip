@@ -20,7 +20,7 @@ int main(int argc, char** argv) {
   for (auto& v : obs) v = (rand() / (double)RAND_MAX - 0.5) * 8.0;
   std::vector<int64_t> starts(B);
   for (int64_t b = 0; b < B; ++b) starts[b] = b * Lm;
-  const size_t nblk = (size_t)64 * EMB_BLOCKS * 64 * 16, nb = nblk + 64 * EMB_BIAS_STRIDE * 4;
+  const size_t nb = (size_t)64 * EMB_REC;
   std::vector<uint16_t> uwh(nb / 2);
   for (auto& v : uwh) v = (uint16_t)(0x3c00 + (rand() & 0x3ff));   // bf16 ~ 0.008 .. 0.03
   double *dobs, *dkexp, *dll0; int64_t* dst; char* duw; float* dEh;
@@ -29,13 +29,12 @@ int main(int argc, char** argv) {
   CKH(hipMemcpy(dobs, obs.data(), obs.size() * 8, hipMemcpyHostToDevice));
   CKH(hipMemcpy(dst, starts.data(), B * 8, hipMemcpyHostToDevice));
   CKH(hipMemcpy(duw, uwh.data(), nb, hipMemcpyHostToDevice));
-  const size_t lds = (size_t)2 * 2 * EMB_NS * EMB_BLOCKS * 64 * 16 + (size_t)64 * EMB_BIAS_STRIDE * 4 +
-                     (size_t)8 * 64 * EMB_TS * 4 + (size_t)2 * 256 * 4;
+  const size_t lds = (size_t)2 * EMB_REC + (size_t)4 * 64 * 64 * 4;
   CKH(hipFuncSetAttribute((const void*)k_emission_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   auto launch = [&]() {
-    hipLaunchKernelGGL(k_emission_bf16x3, dim3((unsigned)((n + 255) / 256)), dim3(512), lds, 0, dobs, (const uint8_t*)nullptr,
-                       dst, n, Lm, D, K, (const uint4*)duw, (const float*)(duw + nblk), 0x10000u, dEh, dkexp, dll0);
+    hipLaunchKernelGGL(k_emission_bf16x3, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, 0, dobs, (const uint8_t*)nullptr,
+                       dst, n, Lm, D, K, (const char*)duw, 0x10000u, dEh, dkexp, dll0);
   };
   for (int i = 0; i < 3; ++i) launch();
   CKH(hipDeviceSynchronize());
