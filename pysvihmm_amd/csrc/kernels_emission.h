@@ -16,6 +16,8 @@
 // in double): 24+ significant bits, i.e. the value to fp32 accuracy, on the bf16 matrix pipe.
 constexpr int EMB_BLOCKS = 6;         // per state: 3 terms x 2 k-blocks of 64 lanes x 16 B (A operands)
 constexpr int EMB_REC = 6400;         // bytes per state record: the six blocks, 32 bias floats, the constant, padding
+constexpr int EMB_BUF = 7168;         // LDS bytes per record buffer (the last 1 KB copy runs 768 B past the record)
+constexpr int EMB_NREC = 68;          // records in the parameter buffer: 64 states + what the copies run ahead
 __device__ __forceinline__ uint32_t bf16_rne(float f) {
   uint32_t u = __float_as_uint(f);
   u += 0x7fffu + ((u >> 16) & 1u);
@@ -537,6 +539,18 @@ __device__ __forceinline__ void emb_glds16(const char* src, char* dst_wave_base)
                                    (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
 }
 
+// End of a state's step: the wave's own global -> LDS copies have landed, then the workgroup meets.
+// (Not __syncthreads(): its fences make the compiler drain the LDS reads just issued for the NEXT
+// state in front of this state's MFMAs.)
+__device__ __forceinline__ void emb_step_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if !(defined(EMB_KO) && (EMB_KO & 4))
+  __builtin_amdgcn_s_barrier();
+#endif
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_emission_bf16x3(
     const double* __restrict__ obs, const uint8_t* __restrict__ mask,
     const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K,
@@ -544,22 +558,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float* __restrict__ Eh, double* __restrict__ kexp, double* __restrict__ ll0) {
   constexpr int ROWS = 256;
   extern __shared__ uint4 smem4[];
-  char* stage = reinterpret_cast<char*>(smem4);                      // [2][EMB_REC]
-  float* tile_s = reinterpret_cast<float*>(stage + 2 * EMB_REC);     // [4 waves][64 rows][64 states]
+  char* stage = reinterpret_cast<char*>(smem4);                      // [2][EMB_BUF]
+  float* tile_s = reinterpret_cast<float*>(stage + 2 * EMB_BUF);     // [4 waves][64 rows][64 states]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int t = lane & 31, hh = lane >> 5;
   const int64_t g0 = (int64_t)blockIdx.x * ROWS;
   const int npair = (K + 1) >> 1;
 
-  auto stage_load = [&](int k, int buf) {                            // record of state k -> buffer buf
+  // record of state k -> buffer buf, branch-free: every wave issues two 1 KB copies (chunks wave and
+  // min(4 + wave, 6); chunk 6 = the bias block, copied with 768 B of the next record behind it into
+  // the buffer's slack, by waves 2 and 3 alike).  The parameter buffer holds EMB_NREC records.
+  const int ch2 = (4 + wave < 6 ? 4 + wave : 6) * 1024;
+  auto stage_load = [&](int k, int buf) {
     const char* src = uw + (size_t)k * EMB_REC + lane * 16;
-    char* dst = stage + buf * EMB_REC;
+    char* dst = stage + buf * EMB_BUF;
+#if !(defined(EMB_KO) && (EMB_KO & 2))
     emb_glds16(src + wave * 1024, dst + wave * 1024);
-    if (wave < 2) emb_glds16(src + (4 + wave) * 1024, dst + (4 + wave) * 1024);
-    if (wave == 2 && lane < 16) emb_glds16(src + 6144, dst + 6144);
+    emb_glds16(src + ch2, dst + ch2);
+#endif
   };
   stage_load(0, 0);
+  stage_load(1, 1);
 
   // ---- the lane's two rows: dimensions 16 c + 8 hh + e as three bf16 terms (B operands)
   embf8_t xb[2][3][2];
@@ -616,58 +636,87 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     bf |= __shfl_xor(bf, 32, 64);                                    // the row's other half of the dimensions
     bflag[m] = bf | ((valid && tt == 0) ? 2 : 0);                    // bit 1: step 0 of its window
   }
-  __syncthreads();                                                   // (carries the wait for record 0)
+  __syncthreads();                                                   // (carries the wait for records 0 and 1)
 
+  // One step per state: the operands of state ks + 1 are read from LDS into the OTHER register set
+  // while the MFMAs of state ks run (the LDS latency hides under the wave's own MFMAs), the copy
+  // of record ks + 2 is issued behind those reads into the buffer record ks came from (the
+  // compiler waits for an outstanding global -> LDS copy in front of the next LDS read -- that is
+  // then the step's barrier, which stays behind the MFMAs).
+  struct Ops { embf8_t a[3][2]; emf16_t bv; float cst; };
+  auto read_ops = [&](Ops& o, int buf) {
+    const char* sb = stage + buf * EMB_BUF;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 b4 = *reinterpret_cast<const float4*>(sb + 6144 + (8 * q + 4 * hh) * 4);
+      o.bv[4 * q] = b4.x; o.bv[4 * q + 1] = b4.y; o.bv[4 * q + 2] = b4.z; o.bv[4 * q + 3] = b4.w;
+    }
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) o.a[s3][c] = emb_cast(*reinterpret_cast<const uint4*>(sb + ((s3 * 2 + c) * 64 + lane) * 16));
+    o.cst = *reinterpret_cast<const float*>(sb + 6144 + 128);
+  };
+  auto mfmas = [&](const Ops& o, emf16_t (&acc)[2]) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a[0][0], xb[m][0][0], o.bv, 0, 0, 0);
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a[0][1], xb[m][0][1], acc[m], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a[0][c], xb[m][1][c], acc[m], 0, 0, 0);   // hi mid
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a[1][c], xb[m][0][c], acc[m], 0, 0, 0);   // mid hi
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a[0][c], xb[m][2][c], acc[m], 0, 0, 0);   // hi lo
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a[2][c], xb[m][0][c], acc[m], 0, 0, 0);   // lo hi
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a[1][c], xb[m][1][c], acc[m], 0, 0, 0);   // mid mid
+      }
+    }
+  };
+  auto squares = [&](const emf16_t (&acc)[2], float cst, float (&p)[2]) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) { p0 = fmaf(acc[m][r], acc[m][r], p0); p1 = fmaf(acc[m][r + 1], acc[m][r + 1], p1); }
+      p[m] = cst - (p0 + p1);                                        // the lane half's share of cst - |y|^2
+    }
+  };
+  // (the compiler's wait-count bookkeeping loses the age of LDS reads across the loop's back edge and
+  // would drain the reads just issued in front of the MFMAs; an empty use of the prefetched operands
+  // at the END of the step, where they have long landed, settles them for it)
+  auto settle = [&](const Ops& o) {
+    asm volatile("" :: "v"(o.a[0][0]), "v"(o.a[0][1]), "v"(o.a[1][0]), "v"(o.a[1][1]), "v"(o.a[2][0]), "v"(o.a[2][1]),
+                 "v"(o.bv), "v"(o.cst));
+  };
   float* tw = tile_s + wave * 64 * 64;
+  const int nst = 2 * npair;
+  Ops oa, ob;
+  read_ops(oa, 0);
+  settle(oa);
   for (int sp = 0; sp < npair; ++sp) {
     float pp[2][2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int ks = 2 * sp + u;
-      const char* sb = stage + u * EMB_REC;
-      emf16_t bv;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 b4 = *reinterpret_cast<const float4*>(sb + 6144 + (8 * q + 4 * hh) * 4);
-        bv[4 * q] = b4.x; bv[4 * q + 1] = b4.y; bv[4 * q + 2] = b4.z; bv[4 * q + 3] = b4.w;
-      }
-      embf8_t a[3][2];
-#pragma unroll
-      for (int s3 = 0; s3 < 3; ++s3)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) a[s3][c] = emb_cast(*reinterpret_cast<const uint4*>(sb + ((s3 * 2 + c) * 64 + lane) * 16));
-      const float cst = *reinterpret_cast<const float*>(sb + 6144 + 128);
-      // the next record's copy is issued BEHIND this state's LDS reads: the compiler waits for an
-      // outstanding global -> LDS copy in front of the next LDS read, and that is then the barrier
+    emf16_t acc[2];
+    {   // state 2 sp: operands in oa, record 2 sp + 1 (buffer 1) -> ob, record 2 sp + 2 -> buffer 0
+      read_ops(ob, 1);
       __builtin_amdgcn_sched_barrier(0);
-      if (ks + 1 < 2 * npair) stage_load(ks + 1, (u + 1) & 1);
+      stage_load(2 * sp + 2, 0);                                     // (behind the last state: spare records)
       __builtin_amdgcn_sched_barrier(0);
-      emf16_t acc[2];
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], xb[m][0][0], bv, 0, 0, 0);
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][1], xb[m][0][1], acc[m], 0, 0, 0);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][c], xb[m][1][c], acc[m], 0, 0, 0);   // hi mid
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][c], xb[m][0][c], acc[m], 0, 0, 0);   // mid hi
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][c], xb[m][2][c], acc[m], 0, 0, 0);   // hi lo
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][c], xb[m][0][c], acc[m], 0, 0, 0);   // lo hi
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][c], xb[m][1][c], acc[m], 0, 0, 0);   // mid mid
-        }
-      }
-      // the barrier stays BEHIND the MFMAs (it carries the wait for the copy issued above); the
-      // square sums may drift into the next state's MFMA stream
+      mfmas(oa, acc);
       __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();                                               // record ks + 1 landed, record ks free
+      settle(ob);
+      emb_step_barrier();
+      squares(acc, oa.cst, pp[0]);
+    }
+    {   // state 2 sp + 1: operands in ob, record 2 sp + 2 (buffer 0) -> oa, record 2 sp + 3 -> buffer 1
+      read_ops(oa, 0);                                               // (behind the last state: unused)
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        float p0 = 0.0f, p1 = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) { p0 = fmaf(acc[m][r], acc[m][r], p0); p1 = fmaf(acc[m][r + 1], acc[m][r + 1], p1); }
-        pp[u][m] = cst - (p0 + p1);                                  // the lane half's share of cst - |y|^2
-      }
+      stage_load(2 * sp + 3, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(ob, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      settle(oa);
+      emb_step_barrier();
+      squares(acc, ob.cst, pp[1]);
     }
     // the halves exchange: lanes 0..31 finish the pair's first state, lanes 32..63 its second
     const int kl = 2 * sp + hh;

@@ -694,11 +694,11 @@ static int upload_feature_table(svihmm_ctx* h, int D, int K, bool diag = false) 
 // NIW parameter block in h->niw ([mu | sigma | kappa | nu], on the device) -> theta (both layouts);
 // logdet_out (device, [K]) optionally receives log det sigma_mf.  Asynchronous: a factor that is
 // not positive definite is reported by the next synchronising call.
-// fp32-mode emission (k_emission_bf16x3): shapes it takes and its parameter buffer -- 64 state records
-// of EMB_REC bytes (zeroed once: the kernel streams records in pairs, one beyond an odd K included)
+// fp32-mode emission (k_emission_bf16x3): shapes it takes and its parameter buffer -- EMB_NREC state
+// records of EMB_REC bytes (zeroed once: the kernel's copies run up to two records + 1 KB ahead)
 static bool emb_shape_ok(int K, int D) { return K <= 64 && D <= 32; }
 static int emb_buffers(svihmm_ctx* h, uint4** uwp) {
-  const size_t nb = (size_t)64 * EMB_REC;
+  const size_t nb = (size_t)EMB_NREC * EMB_REC;
   CK(ensure(h->uwb, nb));
   if (h->uw_zero_p != h->uwb.p) {
     HIPCK(hipMemsetAsync(h->uwb.p, 0, nb, h->stream));
@@ -1118,7 +1118,7 @@ static int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool sc
       HIPCK(hipGetLastError());
       h->uw_valid = true;
     }
-    const size_t lds = (size_t)2 * EMB_REC + (size_t)4 * 64 * 64 * 4;     // two workgroups per CU
+    const size_t lds = (size_t)2 * EMB_BUF + (size_t)4 * 64 * 64 * 4;     // two workgroups per CU
     static bool attr_set = false;
     if (!attr_set) {
       HIPCK(hipFuncSetAttribute((const void*)k_emission_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -20,7 +20,7 @@ int main(int argc, char** argv) {
   for (auto& v : obs) v = (rand() / (double)RAND_MAX - 0.5) * 8.0;
   std::vector<int64_t> starts(B);
   for (int64_t b = 0; b < B; ++b) starts[b] = b * Lm;
-  const size_t nb = (size_t)64 * EMB_REC;
+  const size_t nb = (size_t)EMB_NREC * EMB_REC;
   std::vector<uint16_t> uwh(nb / 2);
   for (auto& v : uwh) v = (uint16_t)(0x3c00 + (rand() & 0x3ff));   // bf16 ~ 0.008 .. 0.03
   double *dobs, *dkexp, *dll0; int64_t* dst; char* duw; float* dEh;
@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
   CKH(hipMemcpy(dobs, obs.data(), obs.size() * 8, hipMemcpyHostToDevice));
   CKH(hipMemcpy(dst, starts.data(), B * 8, hipMemcpyHostToDevice));
   CKH(hipMemcpy(duw, uwh.data(), nb, hipMemcpyHostToDevice));
-  const size_t lds = (size_t)2 * EMB_REC + (size_t)4 * 64 * 64 * 4;
+  const size_t lds = (size_t)2 * EMB_BUF + (size_t)4 * 64 * 64 * 4;
   CKH(hipFuncSetAttribute((const void*)k_emission_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   auto launch = [&]() {
