@@ -426,7 +426,8 @@ def side_figures(eng, L, pb, step, barrier, obs_host, args):
                             "unit": "updates/s", "note": "E-step + statistics of 64 windows (engine calls only)"}
 
     # 1b. the same epoch step in the fp32 mode (scaled messages stored as float, statistics GEMM on
-    #     v_mfma_f32_16x16x4_f32; emission quadratic form and recursion arithmetic stay fp64):
+    #     v_mfma_f32_16x16x4_f32, emission as the centred quadratic form on the bf16 matrix pipe with
+    #     three-term operands = fp32 accuracy; the sweeps' arithmetic stays fp64):
     #     a second figure beside the fp64 headline, never the headline
     try:
         ref64 = step().buf.copy()
@@ -448,7 +449,7 @@ def side_figures(eng, L, pb, step, barrier, obs_host, args):
         rows = (T // LM) * LM
         scale = np.maximum(np.abs(ref64), 1e-6 * rows)
         res["f32_mode"] = {"ms_per_step": dt32 * 1e3, "value": rows * K / dt32, "unit": "updates/s",
-                           "dtype": "f32 storage of Eh/ah/bh + f32 MFMA statistics; f64 emission and recursion arithmetic",
+                           "dtype": "f32 storage of Eh/ah/bh + f32 MFMA statistics + centred emission on bf16 MFMA (x and U as three bf16 terms, fp32 accumulators); f64 recursion arithmetic",
                            "ran_in_f32_format": bool(used),
                            "max_rel_err_vs_f64_statistics": float(np.max(np.abs(out32.buf - ref64) / scale)),
                            "kernels_ms": {k: v[0] / v[1] for k, v in p32.items()}}

@@ -83,10 +83,14 @@ int svihmm_sync(svihmm_ctx* h);
  *   whole-chain scan, not host-supplied lliks) -- the scaled emission likelihoods and the scaled
  *   forward / backward messages are STORED as fp32 (half the HBM traffic of the sweeps) and the
  *   expected-sufficient-statistics GEMM runs on v_mfma_f32_16x16x4_f32 (twice the matrix rate),
- *   each row chunk accumulated in fp32 and the chunks reduced in fp64.  Two pieces stay fp64 on
- *   purpose: the emission quadratic form (its expanded feature form cancels ~1e5 : 1, which
- *   fp32 cannot carry) and the arithmetic of the recursion itself (exact binary exponents; the
- *   launch is HBM-bound, not flop-bound).  Inputs and outputs of the ABI stay float64.
+ *   each row chunk accumulated in fp32 and the chunks reduced in fp64.  The emission quadratic
+ *   form of large batches (>= 32768 rows, D <= 32) is evaluated CENTRED, c_k - |U_k x + b_k|^2 with
+ *   U_k = sqrt(nu_k/2) L_k^-1, on the bf16 matrix pipe: x and U_k as three bf16 terms each (= the
+ *   values to fp32 accuracy), six products into fp32 accumulators (round 3; the expanded feature
+ *   form of the fp64 kernels cancels ~1e5 : 1, which fp32 cannot carry -- smaller batches and
+ *   D > 32 keep that fp64 GEMM).  The arithmetic of the recursion itself stays fp64 (exact
+ *   binary exponents; the launch is HBM-bound, not flop-bound).  Inputs and outputs of the ABI
+ *   stay float64.
  *   Calls outside that fast path run in fp64 regardless; svihmm_get_precision reports whether
  *   the last E-step batch actually ran in the fp32 format. */
 #define SVIHMM_F64 0

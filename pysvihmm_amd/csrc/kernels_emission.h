@@ -14,10 +14,13 @@
 // ---- fp32 mode: operand format of k_emission_bf16x3 (K1d) -----------------------------
 // A value is carried as three bf16 terms hi + mid + lo (round-to-nearest each, residuals formed
 // in double): 24+ significant bits, i.e. the value to fp32 accuracy, on the bf16 matrix pipe.
-constexpr int EMB_BLOCKS = 6;         // per state: 3 terms x 2 k-blocks of 64 lanes x 16 B (A operands)
-constexpr int EMB_REC = 6400;         // bytes per state record: the six blocks, 32 bias floats, the constant, padding
-constexpr int EMB_BUF = 7168;         // LDS bytes per record buffer (the last 1 KB copy runs 768 B past the record)
-constexpr int EMB_NREC = 68;          // records in the parameter buffer: 64 states + what the copies run ahead
+// States travel in PAIRS (k, k') = (2 p, 2 p + 1).  U is lower triangular: the components 0..15 of a
+// state do not see the dimensions 16..31, so the k-block of those dimensions serves the upper
+// components of BOTH states of a pair in one MFMA (rows 0..15: components 16..31 of k, rows 16..31:
+// of k') -- three instead of four instructions per pair and product term.
+constexpr int EMB_BLOCKS = 9;         // per pair: 3 terms x {k dims 0..15, k' dims 0..15, both dims 16..31} of 64 lanes x 16 B
+constexpr int EMB_REC = 10240;        // bytes per pair record: the nine blocks, 2 x 32 bias floats, the two constants, padding
+constexpr int EMB_NREC = 34;          // records in the parameter buffer: 32 pairs + what the copies run ahead
 __device__ __forceinline__ uint32_t bf16_rne(float f) {
   uint32_t u = __float_as_uint(f);
   u += 0x7fffu + ((u >> 16) & 1u);
@@ -507,16 +510,25 @@ __global__ __launch_bounds__(256) void k_emission_orbit(
 //  products hi hi, hi mid, mid hi, hi lo, lo hi, mid mid accumulate in fp32 -- what is left out
 //  is below 2^-24 of a product.  bf16 MFMA runs at 16x the fp32-input MFMA rate on gfx950, so the
 //  six-term product is 2.7x faster than an fp32 MFMA GEMM of the same shape.
-//  v_mfma_f32_32x32x16_bf16: M = the 32 components of one state (A = U_k blocks from LDS),
-//  N = 32 rows of the batch (B = x, held in registers for the whole state loop), k = the
-//  observation's dimensions (two instructions per product term); C = the bias.  A lane's 16
-//  results are components of ONE row: the square sum is in-lane plus one exchange between the
-//  wave's halves, which at the same time deals the states of a pair to the two halves.
+//  v_mfma_f32_32x32x16_bf16: M = 32 components (A = U blocks from LDS), N = 32 rows of the batch
+//  (B = x, held in registers for the whole state loop), k = 16 of the observation's dimensions;
+//  C = the bias.  U is lower triangular, so the states go in pairs: per product term one MFMA per
+//  state for the dimensions 0..15 (all 32 components) and ONE for the dimensions 16..31 of both
+//  (rows 0..15: components 16..31 of the first state, rows 16..31: of the second) -- 18 MFMAs per
+//  pair and row tile instead of 24.  A lane's results are components of ONE row: the square sum is
+//  in-lane plus one exchange between the wave's halves, which at the same time deals the two
+//  states of the pair to the two halves.
 //  Workgroup = 4 waves x 64 rows, two workgroups per CU (so that one's prologue / epilogue runs
-//  under the other's MFMAs).  The state records (six operand blocks + bias + constant, EMB_REC
-//  bytes) stream global -> LDS directly (global_load_lds_dwordx4, two buffers, one barrier per
-//  state); the wave's 64 x 64 ll tile is transposed through LDS (XOR-swizzled columns) so that the
-//  scaled epilogue (row maximum, exp2, float store) writes whole rows.
+//  under the other's MFMAs).  The pair records (nine operand blocks + biases + constants, EMB_REC
+//  bytes) stream global -> LDS directly (global_load_lds_dwordx4) through ONE buffer: operands
+//  LDS -> registers, barrier, the next record's copy under this pair's 36 MFMAs, barrier.  The
+//  wave's 64 x 64 ll tile is transposed through LDS (XOR-swizzled columns) so that the scaled
+//  epilogue (row maximum, exp2, float store) writes whole rows.
+//  Measured (bench shape, 1e6 rows, K = 64, D = 32): 0.52 ms against 1.17 ms of the fp64 feature
+//  GEMM; on full-range random operands (tools/probe/emb_probe.hip) the bf16 pipe is power-bound:
+//  ~1000-1080 TF/s at 1.74 GHz with the MFMA pipe 64 % busy, whatever the schedule (staging,
+//  barriers, operand prefetch knocked out: +-3 %), which is why the levers that paid were the ones
+//  that remove MFMAs (the pairing) or idle phases (two independent workgroups per CU).
 // ------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 embf8_t;
 typedef __attribute__((ext_vector_type(16))) float emf16_t;
@@ -539,9 +551,10 @@ __device__ __forceinline__ void emb_glds16(const char* src, char* dst_wave_base)
                                    (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
 }
 
-// End of a state's step: the wave's own global -> LDS copies have landed, then the workgroup meets.
-// (Not __syncthreads(): its fences make the compiler drain the LDS reads just issued for the NEXT
-// state in front of this state's MFMAs.)
+// End of a pair's step: the wave's own global -> LDS copies have landed, then the workgroup meets
+// (raw barrier with the explicit wait; the step's other barrier, behind the operand reads, waits
+// for lgkmcnt the same way).  The sched_barriers keep the MFMAs in front of it: without them the
+// compiler hoists the barrier -- and with it the wait for the copy just issued -- above the MFMAs.
 __device__ __forceinline__ void emb_step_barrier() {
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -558,28 +571,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float* __restrict__ Eh, double* __restrict__ kexp, double* __restrict__ ll0) {
   constexpr int ROWS = 256;
   extern __shared__ uint4 smem4[];
-  char* stage = reinterpret_cast<char*>(smem4);                      // [2][EMB_BUF]
-  float* tile_s = reinterpret_cast<float*>(stage + 2 * EMB_BUF);     // [4 waves][64 rows][64 states]
+  char* stage = reinterpret_cast<char*>(smem4);                      // [EMB_REC]: one pair record
+  float* tile_s = reinterpret_cast<float*>(stage + EMB_REC);         // [4 waves][64 rows][64 states]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int t = lane & 31, hh = lane >> 5;
   const int64_t g0 = (int64_t)blockIdx.x * ROWS;
   const int npair = (K + 1) >> 1;
 
-  // record of state k -> buffer buf, branch-free: every wave issues two 1 KB copies (chunks wave and
-  // min(4 + wave, 6); chunk 6 = the bias block, copied with 768 B of the next record behind it into
-  // the buffer's slack, by waves 2 and 3 alike).  The parameter buffer holds EMB_NREC records.
-  const int ch2 = (4 + wave < 6 ? 4 + wave : 6) * 1024;
-  auto stage_load = [&](int k, int buf) {
-    const char* src = uw + (size_t)k * EMB_REC + lane * 16;
-    char* dst = stage + buf * EMB_BUF;
+  // pair record p -> the LDS buffer, branch-free: every wave issues three 1 KB copies (chunks wave,
+  // 4 + wave and min(8 + wave, 9); the last chunk is copied by waves 1..3 alike)
+  const int ch3 = (8 + wave < 9 ? 8 + wave : 9) * 1024;
+  auto stage_load = [&](int pr) {
 #if !(defined(EMB_KO) && (EMB_KO & 2))
-    emb_glds16(src + wave * 1024, dst + wave * 1024);
-    emb_glds16(src + ch2, dst + ch2);
+    const char* src = uw + (size_t)pr * EMB_REC + lane * 16;
+    emb_glds16(src + wave * 1024, stage + wave * 1024);
+    emb_glds16(src + (4 + wave) * 1024, stage + (4 + wave) * 1024);
+    emb_glds16(src + ch3, stage + ch3);
 #endif
   };
-  stage_load(0, 0);
-  stage_load(1, 1);
+  stage_load(0);
 
   // ---- the lane's two rows: dimensions 16 c + 8 hh + e as three bf16 terms (B operands)
   embf8_t xb[2][3][2];
@@ -636,87 +647,68 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     bf |= __shfl_xor(bf, 32, 64);                                    // the row's other half of the dimensions
     bflag[m] = bf | ((valid && tt == 0) ? 2 : 0);                    // bit 1: step 0 of its window
   }
-  __syncthreads();                                                   // (carries the wait for records 0 and 1)
+  __syncthreads();                                                   // (carries the wait for record 0)
 
-  // One step per state: the operands of state ks + 1 are read from LDS into the OTHER register set
-  // while the MFMAs of state ks run (the LDS latency hides under the wave's own MFMAs), the copy
-  // of record ks + 2 is issued behind those reads into the buffer record ks came from (the
-  // compiler waits for an outstanding global -> LDS copy in front of the next LDS read -- that is
-  // then the step's barrier, which stays behind the MFMAs).
-  struct Ops { embf8_t a[3][2]; emf16_t bv; float cst; };
-  auto read_ops = [&](Ops& o, int buf) {
-    const char* sb = stage + buf * EMB_BUF;
+  // One step per pair: operands LDS -> registers, barrier (the buffer is free), the next record's copy
+  // on its way under this pair's 36 MFMAs, barrier (it has landed).
+  float* tw = tile_s + wave * 64 * 64;
+  const emf16_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int sp = 0; sp < npair; ++sp) {
+    embf8_t a[3][3];
+    emf16_t bv[2];
+    float cst[2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 b4 = *reinterpret_cast<const float4*>(sb + 6144 + (8 * q + 4 * hh) * 4);
-      o.bv[4 * q] = b4.x; o.bv[4 * q + 1] = b4.y; o.bv[4 * q + 2] = b4.z; o.bv[4 * q + 3] = b4.w;
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 b4 = *reinterpret_cast<const float4*>(stage + 9216 + (32 * u + 8 * q + 4 * hh) * 4);
+        bv[u][4 * q] = b4.x; bv[u][4 * q + 1] = b4.y; bv[u][4 * q + 2] = b4.z; bv[u][4 * q + 3] = b4.w;
+      }
+      cst[u] = *reinterpret_cast<const float*>(stage + 9216 + (64 + u) * 4);
     }
 #pragma unroll
     for (int s3 = 0; s3 < 3; ++s3)
 #pragma unroll
-      for (int c = 0; c < 2; ++c) o.a[s3][c] = emb_cast(*reinterpret_cast<const uint4*>(sb + ((s3 * 2 + c) * 64 + lane) * 16));
-    o.cst = *reinterpret_cast<const float*>(sb + 6144 + 128);
-  };
-  auto mfmas = [&](const Ops& o, emf16_t (&acc)[2]) {
+      for (int b3 = 0; b3 < 3; ++b3) a[s3][b3] = emb_cast(*reinterpret_cast<const uint4*>(stage + ((s3 * 3 + b3) * 64 + lane) * 16));
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    stage_load(sp + 1);                                              // (behind the last pair: a spare record)
+    __builtin_amdgcn_sched_barrier(0);
+    emf16_t acc[2][3];                                               // [row tile][k, k', upper components of both]
+    // the six products: (U term, x term)
+    constexpr int TA[6] = {0, 0, 1, 0, 2, 1}, TB[6] = {0, 1, 0, 2, 0, 1};
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a[0][0], xb[m][0][0], o.bv, 0, 0, 0);
-      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a[0][1], xb[m][0][1], acc[m], 0, 0, 0);
+      acc[m][0] = bv[0]; acc[m][1] = bv[1]; acc[m][2] = zero16;
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a[0][c], xb[m][1][c], acc[m], 0, 0, 0);   // hi mid
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a[1][c], xb[m][0][c], acc[m], 0, 0, 0);   // mid hi
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a[0][c], xb[m][2][c], acc[m], 0, 0, 0);   // hi lo
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a[2][c], xb[m][0][c], acc[m], 0, 0, 0);   // lo hi
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.a[1][c], xb[m][1][c], acc[m], 0, 0, 0);   // mid mid
+      for (int pi = 0; pi < 6; ++pi) {
+        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[pi]][0], xb[m][TB[pi]][0], acc[m][0], 0, 0, 0);
+        acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[pi]][1], xb[m][TB[pi]][0], acc[m][1], 0, 0, 0);
+        acc[m][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[pi]][2], xb[m][TB[pi]][1], acc[m][2], 0, 0, 0);
       }
     }
-  };
-  auto squares = [&](const emf16_t (&acc)[2], float cst, float (&p)[2]) {
+    __builtin_amdgcn_sched_barrier(0);
+    // |y|^2 of the lane half's components: registers 0..7 are components 0..15 (dims 0..15 only),
+    // registers 8..15 components 16..31 = the state's own block + its half of the shared block
+    float pp[2][2];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      float p0 = 0.0f, p1 = 0.0f;
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) { p0 = fmaf(acc[m][r], acc[m][r], p0); p1 = fmaf(acc[m][r + 1], acc[m][r + 1], p1); }
-      p[m] = cst - (p0 + p1);                                        // the lane half's share of cst - |y|^2
-    }
-  };
-  // (the compiler's wait-count bookkeeping loses the age of LDS reads across the loop's back edge and
-  // would drain the reads just issued in front of the MFMAs; an empty use of the prefetched operands
-  // at the END of the step, where they have long landed, settles them for it)
-  auto settle = [&](const Ops& o) {
-    asm volatile("" :: "v"(o.a[0][0]), "v"(o.a[0][1]), "v"(o.a[1][0]), "v"(o.a[1][1]), "v"(o.a[2][0]), "v"(o.a[2][1]),
-                 "v"(o.bv), "v"(o.cst));
-  };
-  float* tw = tile_s + wave * 64 * 64;
-  const int nst = 2 * npair;
-  Ops oa, ob;
-  read_ops(oa, 0);
-  settle(oa);
-  for (int sp = 0; sp < npair; ++sp) {
-    float pp[2][2];
-    emf16_t acc[2];
-    {   // state 2 sp: operands in oa, record 2 sp + 1 (buffer 1) -> ob, record 2 sp + 2 -> buffer 0
-      read_ops(ob, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      stage_load(2 * sp + 2, 0);                                     // (behind the last state: spare records)
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(oa, acc);
-      __builtin_amdgcn_sched_barrier(0);
-      settle(ob);
-      emb_step_barrier();
-      squares(acc, oa.cst, pp[0]);
-    }
-    {   // state 2 sp + 1: operands in ob, record 2 sp + 2 (buffer 0) -> oa, record 2 sp + 3 -> buffer 1
-      read_ops(oa, 0);                                               // (behind the last state: unused)
-      __builtin_amdgcn_sched_barrier(0);
-      stage_load(2 * sp + 3, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(ob, acc);
-      __builtin_amdgcn_sched_barrier(0);
-      settle(oa);
-      emb_step_barrier();
-      squares(acc, ob.cst, pp[1]);
+      for (int u = 0; u < 2; ++u) {
+        float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) {
+          p0 = fmaf(acc[m][u][r], acc[m][u][r], p0); p1 = fmaf(acc[m][u][r + 1], acc[m][u][r + 1], p1);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) {
+          const float y0 = acc[m][u][8 + r] + acc[m][2][8 * u + r], y1 = acc[m][u][9 + r] + acc[m][2][8 * u + r + 1];
+          p0 = fmaf(y0, y0, p0); p1 = fmaf(y1, y1, p1);
+        }
+        pp[u][m] = cst[u] - (p0 + p1);                               // the lane half's share of cst - |y|^2
+      }
     }
     // the halves exchange: lanes 0..31 finish the pair's first state, lanes 32..63 its second
     const int kl = 2 * sp + hh;
@@ -728,6 +720,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int r = m * 32 + t;
       tw[r * 64 + (kl ^ ((r & 15) << 2))] = keep + recv;
     }
+    emb_step_barrier();
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -1000,8 +993,8 @@ __global__ __launch_bounds__(64) void k_niw_to_theta_wave(
     // entries e = 0..7: U[j][16 c + 8 h + e]), bias b = -U m in fp32
     if (uw) {
       const double shn = sqrt(hn);
-      const int j = a & 31, hh = a >> 5;
-      uint4* blk = uw + (size_t)k * (EMB_REC / 16);
+      const int j = a & 31, hh = a >> 5, u = k & 1;
+      uint4* blk = uw + (size_t)(k >> 1) * (EMB_REC / 16);
       float* ub = reinterpret_cast<float*>(blk + EMB_BLOCKS * 64);
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc) {
@@ -1018,8 +1011,11 @@ __global__ __launch_bounds__(64) void k_niw_to_theta_wave(
           }
         }
 #pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3)
-          blk[(s3 * 2 + cc) * 64 + a] = make_uint4(w3[s3][0], w3[s3][1], w3[s3][2], w3[s3][3]);
+        for (int s3 = 0; s3 < 3; ++s3) {
+          const uint4 q = make_uint4(w3[s3][0], w3[s3][1], w3[s3][2], w3[s3][3]);
+          if (cc == 0) blk[(s3 * 3 + u) * 64 + a] = q;                                   // dims 0..15, all components
+          else if (j >= 16) blk[(s3 * 3 + 2) * 64 + 32 * hh + 16 * u + (j - 16)] = q;    // dims 16..31, components 16..31
+        }
       }
       if (a < 32) {
         double b = 0.0;
@@ -1027,7 +1023,7 @@ __global__ __launch_bounds__(64) void k_niw_to_theta_wave(
 #pragma unroll
           for (int cl = 0; cl < DMAX; ++cl) b = fma(Ls[cl][a < DMAX ? a : 0], ms[cl], b);           // sum_c X[a][c] m_c
         }
-        ub[a] = (float)(-shn * b);
+        ub[32 * u + a] = (float)(-shn * b);
       }
     }
   }
@@ -1055,7 +1051,7 @@ __global__ __launch_bounds__(64) void k_niw_to_theta_wave(
     if (logdet_out) logdet_out[k] = 2.0 * logdet;
     if (status && mWm > NIW_CANCEL_LIMIT) atomicMax(status, NIW_STATUS_RANGE + 1 + k);
     if constexpr (DMAX <= 32) {   // ll = cst - |U x + b|^2; each half of the wave adds its share of the squares to cst / 2
-      if (uw) reinterpret_cast<float*>(uw + (size_t)k * (EMB_REC / 16) + EMB_BLOCKS * 64)[32] = (float)(0.5 * cst);
+      if (uw) reinterpret_cast<float*>(uw + (size_t)(k >> 1) * (EMB_REC / 16) + EMB_BLOCKS * 64)[64 + (k & 1)] = (float)(0.5 * cst);
     }
   }
 }

@@ -1118,7 +1118,7 @@ static int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool sc
       HIPCK(hipGetLastError());
       h->uw_valid = true;
     }
-    const size_t lds = (size_t)2 * EMB_BUF + (size_t)4 * 64 * 64 * 4;     // two workgroups per CU
+    const size_t lds = (size_t)EMB_REC + (size_t)4 * 64 * 64 * 4;         // two workgroups per CU
     static bool attr_set = false;
     if (!attr_set) {
       HIPCK(hipFuncSetAttribute((const void*)k_emission_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
   CKH(hipMemcpy(dobs, obs.data(), obs.size() * 8, hipMemcpyHostToDevice));
   CKH(hipMemcpy(dst, starts.data(), B * 8, hipMemcpyHostToDevice));
   CKH(hipMemcpy(duw, uwh.data(), nb, hipMemcpyHostToDevice));
-  const size_t lds = (size_t)2 * EMB_BUF + (size_t)4 * 64 * 64 * 4;
+  const size_t lds = (size_t)EMB_REC + (size_t)4 * 64 * 64 * 4;
   CKH(hipFuncSetAttribute((const void*)k_emission_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   auto launch = [&]() {
@@ -43,7 +43,7 @@ int main(int argc, char** argv) {
   hipEventRecord(e1);
   CKH(hipDeviceSynchronize());
   float ms; hipEventElapsedTime(&ms, e0, e1);
-  const double fl = (double)n * K * 6 * 2 * 32 * 32;
+  const double fl = (double)n * K * 6 * 2 * 32 * 24;
   printf("K=%d D=%d: %.4f ms per launch, %.1f TF/s bf16 (six-term products)\n", K, D, ms / 20, fl / (ms / 20 * 1e-3) / 1e12);
   return 0;
 }
