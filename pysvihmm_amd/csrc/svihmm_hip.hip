@@ -744,9 +744,11 @@ static int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out) 
     }
     orbp = (double*)h->theta_orb.p;
   }
-  // fp32 mode: the centred factors of k_emission_bf16x3 come out of the same launch
+  // fp32 mode: the centred factors of k_emission_bf16x3 come out of the same launch (not inside the
+  // device-resident SVI loop: its minibatches stay below that kernel's batch size, and a large batch
+  // that follows builds them on demand)
   uint4* uwp = nullptr;
-  if (h->prec == 1 && emb_shape_ok(K, D)) CK(emb_buffers(h, &uwp));
+  if (h->prec == 1 && emb_shape_ok(K, D) && !h->svi_active) CK(emb_buffers(h, &uwp));
   {
     ProfScope ps(h, KS_MISC);
 #define NIWW(DM) hipLaunchKernelGGL(k_niw_to_theta_wave<DM>, dim3(K), dim3(64), 0, h->stream, (const double*)dmu, \
