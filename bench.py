@@ -453,6 +453,19 @@ def side_figures(eng, L, pb, step, barrier, obs_host, args):
                            "ran_in_f32_format": bool(used),
                            "max_rel_err_vs_f64_statistics": float(np.max(np.abs(out32.buf - ref64) / scale)),
                            "kernels_ms": {k: v[0] / v[1] for k, v in p32.items()}}
+        # the mode's emission kernel (k_emission_bf16x3): 18 v_mfma_f32_32x32x16_bf16 per pair of states and
+        # 32-row tile = 9216 K flop per row on the bf16 pipe; the centred triangular form it evaluates is
+        # K D (D + 1) flop per row of fp32 arithmetic
+        em = p32.get("emission")
+        if em and em[1] > 0 and K <= 64 and D <= 32:
+            ems = em[0] / em[1] * 1e-3
+            res["f32_mode"]["roofline_emission"] = {
+                "bound": "mfma", "kernel": "k_emission_bf16x3", "achieved": rows * K * 9216.0 / ems / 1e12,
+                "peak": 2500.0, "unit": "TFLOP/s", "frac": rows * K * 9216.0 / ems / 1e12 / 2500.0,
+                "fp32_equivalent_tflops": rows * K * D * (D + 1.0) / ems / 1e12,
+                "note": "bf16 dense MFMA peak (MI355X_MICROARCH.md); x and U as three bf16 terms, six products in fp32 "
+                        "accumulators; fp32_equivalent = the centred triangular quadratic form's K D (D+1) flop per row "
+                        "(fp32-input MFMA peak: 157 TF/s)"}
     except Exception as e:
         res["f32_mode"] = {"error": repr(e)}
     finally:

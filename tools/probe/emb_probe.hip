@@ -1,6 +1,8 @@
-// Standalone timing probe of k_emission_bf16x3 (fp32-mode emission): the bench shape (K = 64, D = 32,
-// 3891 windows of 257 rows) on random data, HIP events around 20 launches.  Build + run:
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form=1 -o emb_probe emb_probe.hip && ./emb_probe
+// Stand-alone timing probe of k_emission_bf16x3 (fp32-mode emission): the bench shape (K = 64, D = 32,
+// 3891 windows of 257 rows) on full-range random operands, HIP events around 20 launches.
+//   make -C tools/probe emb_probe [EMB_KO=2|4|6] && tools/probe/emb_probe [K D]
+// (EMB_KO knocks parts of the kernel out for timing: 2 = no record copies, 4 = no step barrier;
+// tools/probe/prof_emb.sh runs it under rocprofv3 with the SQ counters.)
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>
