@@ -124,6 +124,7 @@ struct svihmm_ctx {
   Buf uwb;                  // fp32 mode: centred factors U_k as bf16 triples + bias (k_emission_bf16x3)
   void* uw_zero_p = nullptr;
   bool uw_valid = false;    // uwb matches the NIW factors in h->niw
+  bool emb_attr_set = false;
   bool emis_cat = false; int V = 0;          // Categorical emission: table [V][K] = E log theta
   bool emis_diag = false;                    // diagonal Gaussian family: 2 D + 1 features, h->niw = [mu | nus | alphas | betas]
   bool tab_diag = false;                     // feature table currently on the device is the diagonal one
@@ -1121,10 +1122,9 @@ static int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool sc
       h->uw_valid = true;
     }
     const size_t lds = (size_t)EMB_REC + (size_t)4 * 64 * 64 * 4;         // two workgroups per CU
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!h->emb_attr_set) {   // (per handle = per device)
       HIPCK(hipFuncSetAttribute((const void*)k_emission_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = true;
+      h->emb_attr_set = true;
     }
     hipLaunchKernelGGL(k_emission_bf16x3, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, stream,
                        (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, (const char*)uwp,
