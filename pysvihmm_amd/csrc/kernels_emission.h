@@ -747,8 +747,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       mx = fmaxf(mx, v[i]);
     }
     mx = row16_max_f32(mx);
-    const float kx = (fabsf(mx) < 1e30f) ? ceilf(mx * l2e) : 0.0f;
-    const float fr = (float)fma((double)mx, L2E, -(double)kx);       // mx log2 e - k, formed in double
+    // k and the row constant mx log2 e - k in (-1, 0] are formed in double: a row far from every state
+    // has |mx| ~ 1e14 and more, where a float product would miss the integer by millions
+    const double kx = (fabsf(mx) < 1e30f) ? ceil((double)mx * L2E) : 0.0;
+    const float fr = (float)fma((double)mx, L2E, -kx);
     float e[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(fmaf(v[i] - mx, l2e, fr));
@@ -759,7 +761,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int i = 0; i < 4; ++i) if (4 * sg + i < K) orow[i] = e[i];
       }
-      if (sg == 0) kexp[g] = (double)kx;
+      if (sg == 0) kexp[g] = kx;
       if (ll0 && (bf & 2)) {
         double* o0 = ll0 + (g / Lm) * K + 4 * sg;
 #pragma unroll

@@ -175,3 +175,47 @@ def test_f32_bf16x3_emission_large_batch(K, D, B, Lm, off, sep):
     e3.set_precision("f32")
     np.testing.assert_array_equal(e3.estep(starts, Lm, flags=L.TRANS_WRAP).buf, buf)
     e.close(); e3.close()
+
+
+@pytest.mark.parametrize("flags_name", ["TRANS_WRAP", "MASK_AS_NAN"])
+def test_f32_bf16x3_emission_nan_rows_and_outliers(flags_name):
+    """Rows with NaN entries (log-likelihood 0 for every state, hmmbase.py:220), the missing-data flag and
+    a row 1e6 standard deviations away from every state, in a batch large enough for k_emission_bf16x3:
+    the fp32 mode's statistics stay within its tolerance of the fp64 oracle and nothing non-finite
+    leaves the kernel."""
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    from oracle import ref_c
+    K, D, B, Lm = 40, 20, 520, 64
+    T = 6000
+    pb = make_problem(K, D, T, seed=11, miss=0.05, sep=2.0)
+    obs = pb["obs"].copy()
+    rng = np.random.default_rng(5)
+    obs[rng.integers(0, T, size=40)] = np.nan                  # whole rows
+    obs[rng.integers(0, T, size=40), rng.integers(0, D, size=40)] = np.nan
+    obs[1234] = 1e6                                            # far from every state
+    starts = rng.integers(0, T - Lm + 1, size=B)
+    flags = getattr(L, flags_name)
+    e = HipEngine(0, dtype="f32")
+    e.set_obs(obs, pb["mask"]); e.set_globals(pb["mod_init"], pb["ltran"])
+    e.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+    st = e.estep(starts, Lm, flags=flags)
+    assert e.precision() == ("f32", True)
+    ref = ref_c.estep_minibatch(obs, pb["mask"], starts, Lm, pb["mod_init"], pb["ltran"], pb["mu"],
+                                pb["sigma"], pb["kappa"], pb["nu"], flags=int(flags), threads=effective_cores())
+    A, xbar, neff, S, lb = unpack(ref, K, D)
+    sc = B * Lm
+    # (the moments of a state that a NaN row contributes to are NaN in the reference as well: posteriors,
+    #  transition counts and the bound are what a NaN row must leave intact)
+    assert np.all(np.isfinite(st.A_raw)) and np.all(np.isfinite(st.neff)) and np.isfinite(st.lb[0])
+    _close(st.A_raw, A, sc, "A"); _close(st.neff, neff, sc, "neff")
+    np.testing.assert_array_equal(np.isnan(st.xbar), np.isnan(xbar))
+    ok = ~np.isnan(xbar)
+    if ok.any():
+        _close(st.xbar[ok], xbar[ok], sc * 1e6, "xbar")
+    np.testing.assert_allclose(st.lb[0], lb, rtol=1e-5)
+    # the same through the fp64 feature GEMM of the mode
+    e.set_variant(5, 3)
+    st2 = e.estep(starts, Lm, flags=flags)
+    np.testing.assert_allclose(st2.neff, st.neff, rtol=1e-3, atol=1e-6 * sc)
+    e.close()
