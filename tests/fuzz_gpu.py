@@ -285,6 +285,7 @@ def run_class_case(e, seed):
     from pysvihmm_amd import hmmsgd_metaobs, hmmbatchcd, hmmbatchsgd
     from pysvihmm_amd.distributions import Gaussian
     rng = np.random.default_rng(seed)
+    e.set_precision("f64")     # (a call sequence before may have left the shared handle in the fp32 mode)
     K = int(rng.choice([2, 3, 5, 8, 17]))
     D = int(rng.choice([1, 2, 3, 8]))
     T = int(rng.choice([300, 700, 1500]))
