@@ -1,5 +1,5 @@
 // device_helpers.h -- wave / row reductions, fp64 exp/log, DPP helpers shared by the kernels.
-// Part of libsvihmm_hip.so; included by svihmm_hip.hip (single translation unit).
+// Part of libsvihmm_hip.so; included by every translation unit (host.h lists them).
 #pragma once
 
 // ------------------------------------------------------------------------------------
@@ -157,4 +157,18 @@ __device__ __forceinline__ double wave64_max_fast(double v) {
   v = fmax_raw(v, __shfl_xor(v, 16, 64));
   v = fmax_raw(v, __shfl_xor(v, 32, 64));
   return v;
+}
+
+// digamma (recurrence to x >= 10 + asymptotic series) and the triangular feature index, shared by the
+// theta builders (kernels_emission.h) and the SVI loop's kernels (kernels_svi.h)
+__device__ __forceinline__ double digamma_d(double x) {
+  double r = 0.0;
+  while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
+  const double f = 1.0 / (x * x);
+  const double t = f * (-1.0 / 12 + f * (1.0 / 120 + f * (-1.0 / 252 + f * (1.0 / 240 +
+                   f * (-1.0 / 132 + f * (691.0 / 32760 + f * (-1.0 / 12)))))));
+  return r + log(x) - 0.5 / x + t;
+}
+__device__ __forceinline__ int feat_index_d(int a, int b, int D) {
+  return a * (D + 1) - a * (a - 1) / 2 + (b - a);
 }

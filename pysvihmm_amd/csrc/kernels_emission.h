@@ -1,5 +1,5 @@
 // kernels_emission.h -- K0 NIW -> theta, K1 emission expected log-likelihood (VALU fallback + fp64 MFMA GEMM).
-// Part of libsvihmm_hip.so; included by svihmm_hip.hip (single translation unit).
+// Part of libsvihmm_hip.so; compiled in tu_emission.hip.
 #pragma once
 
 // The emission GEMM evaluates the NIW quadratic form expanded around the origin: its terms are of
@@ -9,7 +9,6 @@
 // common offset of the data reaches it at |mu| / sigma ~ 5e3; states separated by that many
 // standard deviations do too, where the loss is harmless -- such callers shift as well.)
 #define NIW_CANCEL_LIMIT 1.0e9
-#define NIW_STATUS_RANGE (1 << 20)
 
 // ---- fp32 mode: operand format of k_emission_bf16x3 (K1d) -----------------------------
 // A value is carried as three bf16 terms hi + mid + lo (round-to-nearest each, residuals formed
@@ -776,17 +775,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 //      W = (nu/2) sigma^-1 = (nu/2) L^-T L^-1, E log|Lambda| (digamma), linear and constant
 //      terms of the quadratic form.  status[0] = 1 + k if sigma_k is not positive definite.
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ double digamma_d(double x) {
-  double r = 0.0;
-  while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
-  const double f = 1.0 / (x * x);
-  const double t = f * (-1.0 / 12 + f * (1.0 / 120 + f * (-1.0 / 252 + f * (1.0 / 240 +
-                   f * (-1.0 / 132 + f * (691.0 / 32760 + f * (-1.0 / 12)))))));
-  return r + log(x) - 0.5 / x + t;
-}
-__device__ __forceinline__ int feat_index_d(int a, int b, int D) {
-  return a * (D + 1) - a * (a - 1) / 2 + (b - a);
-}
 // ------------------------------------------------------------------------------------
 //  K0d: diagonal-covariance Gaussian factors (pybasicbayes DiagonalGaussian: per dimension a
 //       normal-inverse-gamma mean-field factor  sigma_d^2 ~ InvGamma(alpha_d, beta_d),
@@ -1092,3 +1080,31 @@ __global__ __launch_bounds__(64) void k_niw_vlb_terms(
     out[2 * K + k] = c * qd;
   }
 }
+
+// ------------------------------------------------------------------------------------
+//  K8: Categorical emissions (reference Categorical branches hmmsgd_metaobs.py:907-926,
+//      1071-1084).  obs is [T][1] with the symbol index stored as a double.
+//      K8a  ll[row][k] = table[x_row][k]  (table = E log theta, transposed to [V][K]);
+//           masked (MASK_AS_NAN) or NaN rows -> 0 for every state, like the Gaussian path.
+//      K8b  counts[v][k] = sum over unmasked rows with x = v of q[row][k]: one wavefront per
+//           row chunk walks its rows in order (lane = state, LDS table [V][Kp]), so the sums
+//           are deterministic; per-chunk partials, reduced by k_finalize_cat.
+//      Gather / HBM-bound work: no MFMA here (the transition statistic still runs on the
+//      pipelined GEMM in its transition-only mode).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_emission_cat(
+    const double* __restrict__ obs, const uint8_t* __restrict__ mask,
+    const int64_t* __restrict__ starts, int64_t nrows, int Lm, int K, int V,
+    const double* __restrict__ table, uint32_t flags, double* __restrict__ ll) {
+  const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (g >= nrows) return;
+  const int64_t b = g / Lm;
+  const int64_t orow = starts[b] + (g - b * Lm);
+  const double x = obs[orow];
+  bool bad = (x != x) || ((flags & SVIHMM_MASK_AS_NAN) && mask && mask[orow]);
+  const int v = bad ? 0 : (int)x;
+  bad |= v < 0 || v >= V;
+  for (int k = lane; k < K; k += 64) ll[g * K + k] = bad ? 0.0 : table[(size_t)v * K + k];
+}
+

@@ -1,5 +1,5 @@
 // kernels_misc.h -- exp/transpose of ltran, MFMA layout self-test, small utility kernels.
-// Part of libsvihmm_hip.so; included by svihmm_hip.hip (single translation unit).
+// Part of libsvihmm_hip.so; compiled in svihmm_hip.hip.
 #pragma once
 
 // small utility kernels
@@ -275,80 +275,6 @@ __global__ __launch_bounds__(256) void k_gen_obs(const int32_t* __restrict__ z, 
 __global__ void k_mirror(const double* __restrict__ src, double* __restrict__ dst, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[i];
-}
-
-// ------------------------------------------------------------------------------------
-//  K8: Categorical emissions (reference Categorical branches hmmsgd_metaobs.py:907-926,
-//      1071-1084).  obs is [T][1] with the symbol index stored as a double.
-//      K8a  ll[row][k] = table[x_row][k]  (table = E log theta, transposed to [V][K]);
-//           masked (MASK_AS_NAN) or NaN rows -> 0 for every state, like the Gaussian path.
-//      K8b  counts[v][k] = sum over unmasked rows with x = v of q[row][k]: one wavefront per
-//           row chunk walks its rows in order (lane = state, LDS table [V][Kp]), so the sums
-//           are deterministic; per-chunk partials, reduced by k_finalize_cat.
-//      Gather / HBM-bound work: no MFMA here (the transition statistic still runs on the
-//      pipelined GEMM in its transition-only mode).
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_emission_cat(
-    const double* __restrict__ obs, const uint8_t* __restrict__ mask,
-    const int64_t* __restrict__ starts, int64_t nrows, int Lm, int K, int V,
-    const double* __restrict__ table, uint32_t flags, double* __restrict__ ll) {
-  const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (g >= nrows) return;
-  const int64_t b = g / Lm;
-  const int64_t orow = starts[b] + (g - b * Lm);
-  const double x = obs[orow];
-  bool bad = (x != x) || ((flags & SVIHMM_MASK_AS_NAN) && mask && mask[orow]);
-  const int v = bad ? 0 : (int)x;
-  bad |= v < 0 || v >= V;
-  for (int k = lane; k < K; k += 64) ll[g * K + k] = bad ? 0.0 : table[(size_t)v * K + k];
-}
-
-__global__ __launch_bounds__(64) void k_stats_cat(
-    const double* __restrict__ obs, const uint8_t* __restrict__ mask,
-    const int64_t* __restrict__ starts, int64_t nrows, int Lm, int K, int Kp, int V,
-    const double* __restrict__ q, int64_t rows_per_chunk, int Lq, int off,
-    double* __restrict__ partc) {
-  extern __shared__ double tab[];             // [V][Kp]
-  const int lane = threadIdx.x;
-  for (int e = lane; e < V * Kp; e += 64) tab[e] = 0.0;
-  __syncthreads();
-  const int64_t c0 = (int64_t)blockIdx.x * rows_per_chunk;
-  const int64_t c1 = imin64(nrows, c0 + rows_per_chunk);
-  for (int64_t g = c0; g < c1; ++g) {
-    const int64_t bw = g / Lm;
-    const int64_t t = g - bw * Lm;
-    const int64_t orow = starts[bw] + off + t;
-    const double x = obs[orow];
-    if ((mask && mask[orow]) || x != x) continue;      // uniform
-    const int v = (int)x;
-    if (v < 0 || v >= V) continue;
-    const int64_t qrow = bw * Lq + off + t;
-    for (int k = lane; k < K; k += 64) tab[v * Kp + k] += q[qrow * K + k];
-  }
-  __syncthreads();
-  double* out = partc + (size_t)blockIdx.x * V * Kp;
-  for (int e = lane; e < V * Kp; e += 64) out[e] = tab[e];
-}
-
-// packed (Categorical layout) = [A_raw K*K | counts K*V | lb]
-__global__ void k_finalize_cat(const double* __restrict__ part, int nchunk, int KpT,
-                               const double* __restrict__ partc, int nchunkc, int K, int Kp, int V,
-                               double* __restrict__ packed) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t nA = (int64_t)K * K, nC = (int64_t)K * V;
-  if (idx < nA) {
-    const int i = idx / K, k = idx - (int64_t)i * K;
-    double s = 0.0;
-    for (int c = 0; c < nchunk; ++c) s += part[((size_t)c * KpT + i) * KpT + k];   // Ftot = KpT (Fp = 0)
-    packed[idx] = s;
-  } else if (idx < nA + nC) {
-    const int64_t e = idx - nA;
-    const int k = e / V, v = e - (int64_t)k * V;
-    double s = 0.0;
-    for (int c = 0; c < nchunkc; ++c) s += partc[((size_t)c * V + v) * Kp + k];
-    packed[idx] = s;
-  }
 }
 
 // obs[t][d] -= shift[d], in place, for n consecutive entries of whole rows (the handle keeps the

@@ -1,5 +1,5 @@
 // kernels_recursion.h -- K2 forward/backward sweeps (wave-per-window, generic, batched fp64 MFMA), K3 posterior, K6 FFBS sampling.
-// Part of libsvihmm_hip.so; included by svihmm_hip.hip (single translation unit).
+// Part of libsvihmm_hip.so; compiled in tu_recursion.hip.
 #pragma once
 
 // ------------------------------------------------------------------------------------
@@ -2379,3 +2379,22 @@ __global__ __launch_bounds__(256) void k_ffbs_gather(const unsigned char* __rest
   z[t] = path[t * KS + entry[t / Ls]];
 }
 
+__global__ void k_reduce_lb(const double* __restrict__ lse_part, int B, int nseg,
+                            double* __restrict__ local_lb, double* __restrict__ lb_total) {
+  // single block; deterministic order
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    double s = 0.0;
+    for (int i = 0; i < nseg; ++i) s += lse_part[(size_t)b * nseg + i];
+    local_lb[b] = s;
+    acc += s;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && lb_total) *lb_total = red[0];
+}

@@ -1,5 +1,5 @@
 // kernels_stats.h -- K4 expected sufficient statistics (VALU fallback + fp64 MFMA GEMMs), K5 deterministic finalize.
-// Part of libsvihmm_hip.so; included by svihmm_hip.hip (single translation unit).
+// Part of libsvihmm_hip.so; compiled in tu_stats.hip.
 #pragma once
 
 // ------------------------------------------------------------------------------------
@@ -664,22 +664,53 @@ __global__ void k_finalize(const double* __restrict__ part, int nchunk, int D, i
   }
 }
 
-__global__ void k_reduce_lb(const double* __restrict__ lse_part, int B, int nseg,
-                            double* __restrict__ local_lb, double* __restrict__ lb_total) {
-  // single block; deterministic order
-  __shared__ double red[256];
-  double acc = 0.0;
-  for (int b = threadIdx.x; b < B; b += blockDim.x) {
-    double s = 0.0;
-    for (int i = 0; i < nseg; ++i) s += lse_part[(size_t)b * nseg + i];
-    local_lb[b] = s;
-    acc += s;
-  }
-  red[threadIdx.x] = acc;
+// ------------------------------------------------------------------------------------
+//  K8b/K8c: Categorical symbol counts and their finalize (see kernels_emission.h, K8)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_stats_cat(
+    const double* __restrict__ obs, const uint8_t* __restrict__ mask,
+    const int64_t* __restrict__ starts, int64_t nrows, int Lm, int K, int Kp, int V,
+    const double* __restrict__ q, int64_t rows_per_chunk, int Lq, int off,
+    double* __restrict__ partc) {
+  extern __shared__ double tab[];             // [V][Kp]
+  const int lane = threadIdx.x;
+  for (int e = lane; e < V * Kp; e += 64) tab[e] = 0.0;
   __syncthreads();
-  for (int o = 128; o >= 1; o >>= 1) {
-    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
+  const int64_t c0 = (int64_t)blockIdx.x * rows_per_chunk;
+  const int64_t c1 = imin64(nrows, c0 + rows_per_chunk);
+  for (int64_t g = c0; g < c1; ++g) {
+    const int64_t bw = g / Lm;
+    const int64_t t = g - bw * Lm;
+    const int64_t orow = starts[bw] + off + t;
+    const double x = obs[orow];
+    if ((mask && mask[orow]) || x != x) continue;      // uniform
+    const int v = (int)x;
+    if (v < 0 || v >= V) continue;
+    const int64_t qrow = bw * Lq + off + t;
+    for (int k = lane; k < K; k += 64) tab[v * Kp + k] += q[qrow * K + k];
   }
-  if (threadIdx.x == 0 && lb_total) *lb_total = red[0];
+  __syncthreads();
+  double* out = partc + (size_t)blockIdx.x * V * Kp;
+  for (int e = lane; e < V * Kp; e += 64) out[e] = tab[e];
 }
+
+// packed (Categorical layout) = [A_raw K*K | counts K*V | lb]
+__global__ void k_finalize_cat(const double* __restrict__ part, int nchunk, int KpT,
+                               const double* __restrict__ partc, int nchunkc, int K, int Kp, int V,
+                               double* __restrict__ packed) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nA = (int64_t)K * K, nC = (int64_t)K * V;
+  if (idx < nA) {
+    const int i = idx / K, k = idx - (int64_t)i * K;
+    double s = 0.0;
+    for (int c = 0; c < nchunk; ++c) s += part[((size_t)c * KpT + i) * KpT + k];   // Ftot = KpT (Fp = 0)
+    packed[idx] = s;
+  } else if (idx < nA + nC) {
+    const int64_t e = idx - nA;
+    const int k = e / V, v = e - (int64_t)k * V;
+    double s = 0.0;
+    for (int c = 0; c < nchunkc; ++c) s += partc[((size_t)c * V + v) * Kp + k];
+    packed[idx] = s;
+  }
+}
+

@@ -3,7 +3,7 @@
 // step and the global part of the ELBO after it.  With these the variational state (var_tran,
 // the K NIW factors) lives in HBM for the whole of infer(): per iteration only the window starts
 // and the learning rate go to the device and nothing has to come back.
-// Part of libsvihmm_hip.so; included by svihmm_hip.hip (single translation unit).
+// Part of libsvihmm_hip.so; compiled in svihmm_hip.hip.
 #pragma once
 
 #define SVI_EPS 1e-9     // the reference's eps (hmmbase.py:30) inside digamma / gammaln

@@ -9,3 +9,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int64_t imin64(int64_t a, int64_t b) { return a < b ? a : b; }
 
+
+// status word of the NIW / diagonal theta builders: 1 + k = factor k not positive definite,
+// NIW_STATUS_RANGE + 1 + k = factor k too far from the data centre (kernels_emission.h)
+#define NIW_STATUS_RANGE (1 << 20)

@@ -19,236 +19,15 @@
 //   la[t,j] = m + log( sum_i exp(la[t-1,i]-m) * exp(ltran[i,j]) ) + ll[t,j]
 // is algebraically the reference's LSE_i(la[t-1,i] + ltran[i,j]) + ll[t,j]
 // (hmmbase.py:295) with K exps + K logs per step instead of K^2.
-#include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
-
-#include <cmath>
-#include <cstdint>
-#include <cstdio>
-#include <cstring>
-#include <cstdlib>
-#include <string>
-#include <type_traits>
-#include <vector>
-
-#include "../../include/svihmm.h"
-#include "svihmm_common.h"
-
-// ------------------------------------------------------------------------------------
-//  error handling
-// ------------------------------------------------------------------------------------
-static thread_local std::string g_err;
-static int fail(const std::string& m) { g_err = m; return 1; }
-#define HIPCK(x)                                                                   \
-  do {                                                                             \
-    hipError_t e_ = (x);                                                           \
-    if (e_ != hipSuccess)                                                          \
-      return fail(std::string(#x) + ": " + hipGetErrorString(e_) + " (" __FILE__ \
-                  ":" + std::to_string(__LINE__) + ")");                           \
-  } while (0)
-#define NCCLCK(x)                                                                  \
-  do {                                                                             \
-    ncclResult_t r_ = (x);                                                         \
-    if (r_ != ncclSuccess)                                                         \
-      return fail(std::string(#x) + ": " + ncclGetErrorString(r_));                \
-  } while (0)
-#define CK(x)              \
-  do {                     \
-    if (int r__ = (x)) return r__; \
-  } while (0)
-
-
+#include "host.h"
 #include "device_helpers.h"
-#include "kernels_emission.h"
-#include "kernels_recursion.h"
-#include "kernels_stats.h"
 #include "kernels_misc.h"
 #include "kernels_svi.h"
 
-// ------------------------------------------------------------------------------------
-//  host side
-// ------------------------------------------------------------------------------------
-#define SVIHMM_INT_ST32 0x10000u   // internal kernel flag: scaled emission output stored as float
-struct Buf {
-  void* p = nullptr;
-  size_t cap = 0;
-};
-static int ensure(Buf& b, size_t bytes) {
-  if (bytes <= b.cap && b.p) return 0;
-  if (b.p) { hipFree(b.p); b.p = nullptr; b.cap = 0; }
-  // 512 bytes past `cap` always belong to the allocation: kernels that stage padded state
-  // columns read up to 63 doubles beyond the last row (K > 64: state groups of 64)
-  size_t want = bytes + bytes / 8 + 256;
-  HIPCK(hipMalloc(&b.p, want + 512));
-  b.cap = want;
-  return 0;
-}
-static void release(Buf& b) {
-  if (b.p) hipFree(b.p);
-  b.p = nullptr; b.cap = 0;
-}
-
-enum { KS_EMISSION = 0, KS_FB, KS_POSTERIOR, KS_STATS, KS_FINALIZE, KS_FFBS, KS_MISC,
-       KS_ALLREDUCE, KS_H2D, KS_D2H, KS_RES0, KS_RES1 };
+thread_local std::string g_err;
 static const char* kKernNames[SVIHMM_NKERN] = {
     "emission", "forward_backward", "posterior", "stats", "finalize", "ffbs_sample",
     "misc", "allreduce", "h2d", "d2h", "reserved0", "reserved1"};
-
-struct Pending { int slot; hipEvent_t e0, e1; };
-
-struct svihmm_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  // data
-  int64_t T = 0; int D = 0; bool have_mask = false;
-  Buf obs, mask;
-  // globals
-  int K = 0;
-  Buf mod_init, ltran, Aexp, AexpT;
-  bool have_globals = false;
-  // transition expectations below the range exp() represents with headroom: every recursion goes
-  // through the literal log-domain kernel (k_fb_exact); f32_ok: within the range of a float
-  bool exact_log = false, f32_ok = true;
-  // emission
-  int eK = 0, eD = 0, Kp = 0, F = 0, Fp = 0;
-  Buf theta, theta_orb, fab, niw, cat_table, partc, prior, vlb_aux, gen_z;
-  int64_t gen_T = 0;
-  double* vlb_host = nullptr;   // pinned + mapped: [3][K] ELBO terms
-  int prior_K = 0, prior_D = 0, vlb_host_K = 0;
-  void *slack_a = nullptr, *slack_t = nullptr;   // Aexp / AexpT whose slack rows are zeroed
-  int slack_k = 0;
-  void* orb_zero_p = nullptr; size_t orb_zero_n = 0;
-  const double* chain_kbef = nullptr; int chain_C = 0, chain_L = 0, chain_T = 0;   // of the last launch_fb_chain
-  int lb_pending = 0;       // windows whose local_lb sum has not been written to packed yet
-  bool orb_valid = false;   // theta_orb matches theta (k_theta_orbit ran since the last parameter upload)
-  Buf uwb;                  // fp32 mode: centred factors U_k as bf16 triples + bias (k_emission_bf16x3)
-  void* uw_zero_p = nullptr;
-  bool uw_valid = false;    // uwb matches the NIW factors in h->niw
-  bool emb_attr_set = false;
-  bool emis_cat = false; int V = 0;          // Categorical emission: table [V][K] = E log theta
-  bool emis_diag = false;                    // diagonal Gaussian family: 2 D + 1 features, h->niw = [mu | nus | alphas | betas]
-  bool tab_diag = false;                     // feature table currently on the device is the diagonal one
-  void* theta_zero_p = nullptr; size_t theta_zero_n = 0;   // what the last theta memset covered
-  int tabD = -1;
-  // pinned host staging: a ring of slots, each guarded by an event recorded after the copy
-  // that uses it, so that parameter uploads and small readbacks never synchronise the stream
-  struct PinSlot { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool busy = false; };
-  PinSlot pins[6];
-  int pin_next = 0;
-  // window starts of the SVI loop's iterations: their own ring, released by the iterations' end
-  // events (an event record between two kernels of the chain costs ~7 us of dispatch)
-  struct StartSlot { void* p = nullptr; size_t cap = 0; int used_it = -1; };
-  StartSlot svi_starts[8];
-  int svi_upload_it = -1;
-  int* pin_status = nullptr;                 // pinned: NIW factorisation status (lazy check)
-  double* mirror = nullptr; size_t mirror_cap = 0;   // pinned + mapped copy of `packed`
-  bool mirror_valid = false;
-  bool status_pending = false;
-  bool status_auto = false;      // the pending status word stems from an automatic theta rebuild (params_follow_centre)
-  bool have_emission = false;
-  // work
-  Buf starts, ll, la, lb, q, lse_part, local_lb, logz, part, packed, scratch;
-  // scaled linear-domain sweeps: per-row binary exponents, (na, k) records, 1/Z factors,
-  // Eh of host-supplied lliks; log-domain intermediates materialised on demand (m_*)
-  Buf kexp, hx, gx, zfac, llE, m_ll, m_la, m_lb, chain, chain2;
-  Buf ll0, a0v, a0e;               // first-row log-likelihoods of the windows; initial messages + exponents (k_lin_init)
-  bool lin_mode = false;           // ll/la/lb hold Eh / ah / bh of the last sweep (not logs)
-  bool q_valid = false;            // lin_mode: var_x has been formed from ah, bh (k_lin_posterior)
-  bool lin_stale = false;          // parameters changed since: logs can no longer be rebuilt
-  bool last_host_ll = false;       // the last sweep ran on host-supplied lliks
-  bool eh_in_llE = false;          // scaled emission lives in llE (h->ll holds the plain lliks)
-  uint32_t last_flags = 0;
-  int m_b0 = 0, m_nb = 0;          // window range currently materialised in m_*
-  int lastB = 0, lastLm = 0;       // shape of the intermediates currently held
-  int curB = 0;                    // windows of the batch being processed
-  int hostB = 0, hostLm = 0;       // shape of host-uploaded lliks
-  bool have_host_ll = false;
-  bool have_packed = false;
-  bool have_lb = false;           // lbeta materialised by the last call
-  // variants: [0] emission (0 auto,1 outer,2 mfma) [1] stats (0 auto,1 outer,2 mfma,3 pipelined)
-  // [2] sweeps (0 auto,1 wave,2 log-MFMA,3 scaled) [3] emission row tiles
-  // [4] two-stream E-step pipeline (0 auto,1 off,2 on)
-  // [8] row chunks of the statistics GEMM (0 = automatic)
-  int variant[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  // second stream + events of the pipelined E-step (created on first use)
-  hipStream_t stream2 = nullptr;
-  hipEvent_t ev_em[2] = {nullptr, nullptr}, ev_sw[2] = {nullptr, nullptr};
-  // profiling
-  bool prof = false;
-  std::vector<Pending> pending;
-  std::vector<hipEvent_t> pool;
-  double ms[SVIHMM_NKERN] = {0};
-  int64_t cnt[SVIHMM_NKERN] = {0};
-  // device-resident SVI loop (svihmm_svi_*): var_tran | prior_tran | var_init | vlb[K] | logdet[K] |
-  // prior_logpart[K]; prior block [mu0 | sigma0 | kappa0 | nu0]; GTH scratch; elbo / event ring
-  Buf svi_state, svi_prior, svi_work, commtmp;
-  int svi_K = 0, svi_D = 0, svi_maxit = 0;
-  double svi_zsign = 1.0, svi_prior_const = 0.0;
-  double* svi_elbo = nullptr; int svi_elbo_cap = 0;      // pinned + mapped: elbo_vec
-  std::vector<hipEvent_t> svi_ev;                        // iteration boundaries (iter_time)
-  std::vector<int> svi_ev_begin;                         // event that marks the start of iteration it
-  int svi_last_it = -1;
-  bool svi_active = false, svi_f32_ok = true;
-  hipEvent_t svi_ea = nullptr, svi_eb = nullptr, globals_ev = nullptr;   // side-stream globals kernel
-  hipEvent_t svi_ec = nullptr, svi_ed = nullptr;   // theta ready / side-stream ELBO kernels done
-  hipStream_t stream3 = nullptr;                   // the ELBO kernels' own stream
-  bool vlb_pending = false;
-  bool svi_globals_ready = false;   // Aexp / mod_init / var_init[slot] of the NEXT iteration are computed (or in flight)
-  int svi_globals_slot = 0, svi_vi_cur = 0;   // var_init slot the pending globals write / the last iteration used
-  // The resident observations are kept centred: obs_dev[t] = obs_caller[t] - shift.  The shift is
-  // chosen at upload (a point inside the data) and moved by svihmm_shift_obs; it never shows at the
-  // ABI: means come in / go out in the caller's coordinates (set_emission_niw, svi_begin,
-  // svi_read_state), statistics are handed out in the caller's coordinates (launch_mirror), the
-  // device-side state (h->niw, svi_prior, packed) lives in centred coordinates.
-  std::vector<double> shift;     // [D]; empty = no observations yet
-  Buf shift_d;                   // the same vector on the device
-  bool shifted = false;          // some component is non-zero
-  bool center_pending = false;   // svihmm_alloc_obs: centre on the first block that arrives
-  int shift_epoch = 0, prior_epoch = -1;
-  std::vector<double> prior_mu0; // caller-coordinate prior means of svihmm_set_emission_prior
-  // precision mode (svihmm_set_precision): 0 fp64, 1 fp32 (see the header); cur_f32: the batch in
-  // flight / the intermediates currently held are in the fp32 format
-  int prec = 0;
-  bool cur_f32 = false;
-  // comm
-  ncclComm_t comm = nullptr;
-  int rank = 0, nranks = 1;
-};
-
-// length of the packed statistics in the layout of the current emission family:
-// NIW  [A_raw K*K | xbar K*D | neff K | S K*D*D | lb],  Categorical  [A_raw K*K | counts K*V | lb]
-static size_t packed_len(const svihmm_ctx* h) {
-  if (h->emis_cat) return (size_t)h->K * h->K + (size_t)h->K * h->V + 1;
-  const size_t D = h->D > 0 ? h->D : 1;
-  if (h->emis_diag) return (size_t)h->K * h->K + 2 * (size_t)h->K * D + h->K + 1;
-  return (size_t)h->K * h->K + (size_t)h->K * D + h->K + (size_t)h->K * D * D + 1;
-}
-
-struct ProfScope {
-  svihmm_ctx* h; int slot; hipEvent_t e0 = nullptr, e1 = nullptr; bool on; hipStream_t st;
-  ProfScope(svihmm_ctx* h_, int slot_, hipStream_t st_ = nullptr)
-      : h(h_), slot(slot_), on(h_->prof), st(st_ ? st_ : h_->stream) {
-    if (!on) return;
-    auto get = [&]() {
-      hipEvent_t e;
-      if (!h->pool.empty()) { e = h->pool.back(); h->pool.pop_back(); }
-      else hipEventCreate(&e);
-      return e;
-    };
-    e0 = get(); e1 = get();
-    hipEventRecord(e0, st);
-  }
-  ~ProfScope() {
-    if (!on) return;
-    hipEventRecord(e1, st);
-    h->pending.push_back({slot, e0, e1});
-  }
-};
-
-static int set_device(svihmm_ctx* h) {
-  HIPCK(hipSetDevice(h->device));
-  return 0;
-}
 
 extern "C" {
 
@@ -319,12 +98,9 @@ int svihmm_destroy(svihmm_ctx* h) {
 }
 
 static int check_emission_status(svihmm_ctx* h);
-static int wait_globals(svihmm_ctx* h);
 static int pinned(svihmm_ctx* h, size_t bytes, void** out, int* slot_out);
 static int pull_small(svihmm_ctx* h, void* dst, const void* pin, size_t bytes);
 static int pin_release(svihmm_ctx* h, int slot);
-static int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out);
-static int launch_diag_to_theta(svihmm_ctx* h, int K, int D);
 static double* svi_ptr(svihmm_ctx* h, int which);
 static int wait_side_streams(svihmm_ctx* h);
 static void sample_center(const svihmm_ctx* h, const double* obs, int64_t T, int D, std::vector<double>& c);
@@ -383,6 +159,10 @@ int svihmm_set_obs(svihmm_ctx* h, const double* obs, int64_t T, int32_t D,
 static void sample_center(const svihmm_ctx* h, const double* obs, int64_t T, int D, std::vector<double>& c) {
   c.assign((size_t)D, 0.0);
   if (h->variant[9] == 1 || !obs || T <= 0) return;      // variant 9 = 1: no automatic centring
+  // a Categorical table is the active emission: the column holds symbol indices, which the lookup
+  // kernels truncate to int -- it stays exactly as uploaded (round-3 advisor finding: set_emission_cat
+  // followed by set_obs centred the symbols)
+  if (h->have_emission && h->emis_cat) return;
   int64_t nsamp = ((int64_t)4 << 20) / D;
   if (nsamp > 65536) nsamp = 65536;
   if (nsamp < 16) nsamp = 16;
@@ -673,7 +453,7 @@ static inline int feat_index(int a, int b, int D) {  // 0 <= a <= b <= D
 // emission family needs.  Full covariance: all a <= b, F = (D+1)(D+2)/2.  Diagonal family:
 // x_a^2 (f = a), x_a (f = D + a), 1 (f = 2 D): F = 2 D + 1.  Emission and statistics GEMMs read
 // the table, so the family only changes the table and the theta builder.
-static int upload_feature_table(svihmm_ctx* h, int D, int K, bool diag = false) {
+int upload_feature_table(svihmm_ctx* h, int D, int K, bool diag) {
   const int F = diag ? 2 * D + 1 : (D + 1) * (D + 2) / 2, Fp = (F + 15) / 16 * 16;
   // padded state count: tiles of 16; wide models in groups of 64 (the statistics GEMM's state groups)
   const int Kp = K > 64 ? (K + 63) / 64 * 64 : (K + 15) / 16 * 16;
@@ -692,120 +472,6 @@ static int upload_feature_table(svihmm_ctx* h, int D, int K, bool diag = false) 
   return 0;
 }
 
-// NIW parameter block in h->niw ([mu | sigma | kappa | nu], on the device) -> theta (both layouts);
-// logdet_out (device, [K]) optionally receives log det sigma_mf.  Asynchronous: a factor that is
-// not positive definite is reported by the next synchronising call.
-// fp32-mode emission (k_emission_bf16x3): shapes it takes and its parameter buffer -- EMB_NREC state
-// records of EMB_REC bytes (zeroed once: the kernel's copies run up to two records + 1 KB ahead)
-static bool emb_shape_ok(int K, int D) { return K <= 64 && D <= 32; }
-static int emb_buffers(svihmm_ctx* h, uint4** uwp) {
-  const size_t nb = (size_t)EMB_NREC * EMB_REC;
-  CK(ensure(h->uwb, nb));
-  if (h->uw_zero_p != h->uwb.p) {
-    HIPCK(hipMemsetAsync(h->uwb.p, 0, nb, h->stream));
-    HIPCK(hipStreamSynchronize(h->stream));     // once per handle; the emission launch may sit on another stream
-    h->uw_zero_p = h->uwb.p;
-    h->uw_valid = false;
-  }
-  *uwp = (uint4*)h->uwb.p;
-  return 0;
-}
-static int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out) {
-  CK(upload_feature_table(h, D, K));
-  const int Fp = h->Fp, Kp = h->Kp;
-  const size_t nmu = (size_t)K * D, nsg = (size_t)K * D * D;
-  CK(ensure(h->theta, (size_t)Fp * Kp * sizeof(double)));
-  double* dmu = (double*)h->niw.p;
-  double* dsg = dmu + nmu;
-  double* dka = dsg + nsg;
-  double* dnu = dka + K;
-  // status word: pinned + mapped host memory, written (atomicMax) by the kernel only when a
-  // factor is not positive definite -- no device-to-host copy on the critical path
-  if (!h->pin_status) {
-    HIPCK(hipHostMalloc((void**)&h->pin_status, 64, hipHostMallocMapped));
-    *h->pin_status = 0;
-  }
-  int* dstatus = nullptr;
-  HIPCK(hipHostGetDevicePointer((void**)&dstatus, h->pin_status, 0));
-  // theta's padded rows / columns are zeroed once per (buffer, shape); k_niw_to_theta
-  // rewrites every live entry on each call
-  if (h->theta_zero_p != h->theta.p || h->theta_zero_n != (size_t)Fp * Kp) {
-    HIPCK(hipMemsetAsync(h->theta.p, 0, (size_t)Fp * Kp * sizeof(double), h->stream));
-    h->theta_zero_p = h->theta.p; h->theta_zero_n = (size_t)Fp * Kp;
-  }
-  // shapes the orbit-schedule emission kernel takes: theta is written in its layout as well
-  double* orbp = nullptr;
-  if (K <= 64 && D >= 8 && D <= 40 && D % 8 == 0) {
-    const size_t nks = (size_t)(D / 4) * (D / 2 + 1) + (D / 2 + 1 + 3) / 4;
-    const size_t nb = nks * 4 * Kp * sizeof(double);
-    CK(ensure(h->theta_orb, nb));
-    if (h->orb_zero_p != h->theta_orb.p || h->orb_zero_n != nb) {   // padding rows / columns: once
-      HIPCK(hipMemsetAsync(h->theta_orb.p, 0, nb, h->stream));
-      h->orb_zero_p = h->theta_orb.p; h->orb_zero_n = nb;
-    }
-    orbp = (double*)h->theta_orb.p;
-  }
-  // fp32 mode: the centred factors of k_emission_bf16x3 come out of the same launch (not inside the
-  // device-resident SVI loop: its minibatches stay below that kernel's batch size, and a large batch
-  // that follows builds them on demand)
-  uint4* uwp = nullptr;
-  if (h->prec == 1 && emb_shape_ok(K, D) && !h->svi_active) CK(emb_buffers(h, &uwp));
-  {
-    ProfScope ps(h, KS_MISC);
-#define NIWW(DM) hipLaunchKernelGGL(k_niw_to_theta_wave<DM>, dim3(K), dim3(64), 0, h->stream, (const double*)dmu, \
-                                    (const double*)dsg, (const double*)dka, (const double*)dnu, K, D, Kp,   \
-                                    (double*)h->theta.p, dstatus, orbp, logdet_out, uwp)
-    if (D <= 8) NIWW(8);
-    else if (D <= 16) NIWW(16);
-    else if (D <= 32) NIWW(32);
-    else if (D <= 64) NIWW(64);
-    else {
-      const size_t lds = (size_t)(2 * D * (D + 1) + 2 * D) * sizeof(double);
-      if (lds > 64 * 1024)
-        hipFuncSetAttribute((const void*)k_niw_to_theta_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(k_niw_to_theta_generic, dim3(K), dim3(256), lds, h->stream, (const double*)dmu,
-                         (const double*)dsg, (const double*)dka, (const double*)dnu, K, D, Kp,
-                         (double*)h->theta.p, dstatus, orbp, logdet_out);
-    }
-#undef NIWW
-    HIPCK(hipGetLastError());
-  }
-  // status comes back asynchronously; it is examined at the next synchronising call
-  h->status_pending = true;
-  h->eK = K; h->eD = D; h->have_emission = true; h->emis_cat = false; h->emis_diag = false;
-  h->orb_valid = orbp != nullptr;
-  h->uw_valid = uwp != nullptr;
-  return 0;
-}
-
-// Diagonal family: parameter block [mu | nus | alphas | betas] (each [K][D], means centred) in
-// h->niw -> theta in the diagonal feature order.  Same asynchronous status word as the NIW builder.
-static int launch_diag_to_theta(svihmm_ctx* h, int K, int D) {
-  CK(upload_feature_table(h, D, K, true));
-  const int Fp = h->Fp, Kp = h->Kp;
-  const size_t n = (size_t)K * D;
-  CK(ensure(h->theta, (size_t)Fp * Kp * sizeof(double)));
-  if (!h->pin_status) {
-    HIPCK(hipHostMalloc((void**)&h->pin_status, 64, hipHostMallocMapped));
-    *h->pin_status = 0;
-  }
-  int* dstatus = nullptr;
-  HIPCK(hipHostGetDevicePointer((void**)&dstatus, h->pin_status, 0));
-  // padded rows / columns zeroed on every family or shape change (the NIW builder keys on the same pair)
-  HIPCK(hipMemsetAsync(h->theta.p, 0, (size_t)Fp * Kp * sizeof(double), h->stream));
-  h->theta_zero_p = nullptr; h->theta_zero_n = 0;
-  const double* p = (const double*)h->niw.p;
-  {
-    ProfScope ps(h, KS_MISC);
-    hipLaunchKernelGGL(k_diag_to_theta, dim3(K), dim3(64), 0, h->stream, p, p + n, p + 2 * n, p + 3 * n, K, D, Kp,
-                       (double*)h->theta.p, dstatus);
-    HIPCK(hipGetLastError());
-  }
-  h->status_pending = true;
-  h->eK = K; h->eD = D; h->have_emission = true; h->emis_cat = false; h->emis_diag = true; h->uw_valid = false;
-  h->orb_valid = false;
-  return 0;
-}
 
 // means[K][D] in the caller's coordinates -> centred coordinates (and back), in place on the host
 static void to_centred(const svihmm_ctx* h, double* mu, int K, int D) {
@@ -947,23 +613,22 @@ int svihmm_niw_vlb_terms(svihmm_ctx* h, int32_t K, int32_t D, const double* mu, 
     h->prior_epoch = h->shift_epoch;
   }
   const double* p0 = (const double*)h->prior.p;
-  {
-    ProfScope ps(h, KS_MISC);
-#define NIWV(DM) hipLaunchKernelGGL(k_niw_to_theta_wave<DM>, dim3(K), dim3(64), 0, h->stream, (const double*)dmu, \
-                                    (const double*)dsg, (const double*)dka, (const double*)dnu, K, D, Kp, th2,    \
-                                    dstat, (double*)nullptr, ld)
-    if (D <= 8) NIWV(8); else if (D <= 16) NIWV(16); else if (D <= 32) NIWV(32); else NIWV(64);
-#undef NIWV
-    hipLaunchKernelGGL(k_niw_vlb_terms, dim3(K), dim3(64), 0, h->stream, (const double*)th2,
-                       (const int*)h->fab.p, h->F, D, Kp, (const double*)dmu, (const double*)dnu,
-                       (const double*)ld, p0, p0 + nmu, K, dout);
-    HIPCK(hipGetLastError());
-  }
+  CK(launch_niw_vlb(h, K, D, dmu, dsg, dka, dnu, th2, dstat, ld, p0, dout));
   HIPCK(hipStreamSynchronize(h->stream));
   std::memcpy(out3K, h->vlb_host, (size_t)3 * K * sizeof(double));
   return 0;
 }
 
+// The resident column holds symbol indices: a centred copy (an upload cannot know the family that
+// will read it; svihmm_shift_obs may have moved it) goes back to exact integers and stays uncentred.
+// Called when the table is set and again in front of every lookup / count launch.
+int cat_uncentre(svihmm_ctx* h) {
+  if (!h->shifted || h->T <= 0) return 0;
+  std::vector<double> back(h->shift.size());
+  for (size_t d = 0; d < back.size(); ++d) back[d] = -h->shift[d];
+  CK(shift_rows(h, back.data(), 0, h->T, true));
+  return store_shift(h, std::vector<double>((size_t)h->D, 0.0));
+}
 // feature table is also needed by the statistics kernels when only host lliks are used
 int svihmm_set_emission_cat(svihmm_ctx* h, int32_t K, int32_t V, const double* logp) {
   if (!h || K <= 0 || V <= 0 || !logp) return fail("svihmm_set_emission_cat: bad arguments");
@@ -971,14 +636,7 @@ int svihmm_set_emission_cat(svihmm_ctx* h, int32_t K, int32_t V, const double* l
   h->lin_stale = true;
   h->center_pending = false;
   CK(drop_auto_status(h));
-  if (h->shifted && h->T > 0) {
-    // the resident column holds symbol indices: a centred copy (the upload cannot know the family)
-    // goes back to exact integers and stays uncentred
-    std::vector<double> back(h->shift.size());
-    for (size_t d = 0; d < back.size(); ++d) back[d] = -h->shift[d];
-    CK(shift_rows(h, back.data(), 0, h->T, true));
-    CK(store_shift(h, std::vector<double>((size_t)h->D, 0.0)));
-  }
+  CK(cat_uncentre(h));
   const size_t n = (size_t)K * V;
   CK(ensure(h->cat_table, n * sizeof(double)));
   void* pin = nullptr;
@@ -994,7 +652,7 @@ int svihmm_set_emission_cat(svihmm_ctx* h, int32_t K, int32_t V, const double* l
 }
 int64_t svihmm_packed_len(svihmm_ctx* h) { return h ? (int64_t)packed_len(h) : 0; }
 
-static int ensure_feature_table(svihmm_ctx* h) {
+int ensure_feature_table(svihmm_ctx* h) {
   return upload_feature_table(h, h->D, h->K, h->emis_diag);
 }
 
@@ -1004,6 +662,8 @@ int svihmm_set_lliks(svihmm_ctx* h, const double* lliks, int32_t B, int32_t Lm) 
   CK(set_device(h));
   h->lin_stale = true;
   const size_t n = (size_t)B * Lm * h->K * sizeof(double);
+  // (host-evaluated emitters do not use the factors an automatic theta rebuild may have complained about)
+  CK(drop_auto_status(h));
   CK(ensure(h->ll, n));
   HIPCK(hipMemcpyAsync(h->ll.p, lliks, n, hipMemcpyHostToDevice, h->stream));
   HIPCK(hipStreamSynchronize(h->stream));
@@ -1067,615 +727,7 @@ static int upload_starts(svihmm_ctx* h, const int64_t* starts, int B) {
   return 0;
 }
 
-// scaled: write (Eh, kexp) for the linear-domain sweeps instead of ll (K <= 64 only).
-// starts_dev / out: window starts and destination (default: the handle's buffers).
-static int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled = false,
-                           const int64_t* starts_dev = nullptr, double* out = nullptr,
-                           double* kexp_out = nullptr, hipStream_t stream = nullptr,
-                           size_t min_lds = 0, double* ll0_out = nullptr) {
-  if (!h->have_emission) return fail("no emission parameters: call svihmm_set_emission_niw");
-  if (h->eD != h->D) return fail("emission D does not match obs D");
-  if (!h->have_globals || h->eK != h->K) return fail("emission K does not match globals K");
-  const int64_t n = (int64_t)B * Lm;
-  const int D = h->D, K = h->K, Kp = h->Kp;
-  if (!out) {
-    CK(ensure(h->ll, (size_t)n * K * sizeof(double)));
-    out = (double*)h->ll.p;
-  }
-  if (!starts_dev) starts_dev = (const int64_t*)h->starts.p;
-  if (scaled && !kexp_out) {
-    CK(ensure(h->kexp, (size_t)n * sizeof(double)));
-    kexp_out = (double*)h->kexp.p;
-  }
-  if (scaled && !ll0_out) {      // first-row log-likelihoods of every window (k_lin_init)
-    CK(ensure(h->ll0, (size_t)B * K * sizeof(double)));
-    ll0_out = (double*)h->ll0.p;
-  }
-  if (!stream) stream = h->stream;
-  const uint8_t* mk = h->have_mask ? (const uint8_t*)h->mask.p : nullptr;
-  if (scaled && h->cur_f32) flags |= SVIHMM_INT_ST32;
-  ProfScope ps(h, KS_EMISSION, stream);
-  if (h->emis_cat) {   // table lookup (scaled output: the caller adds the k_scale_ll pass)
-    if (scaled) return fail("internal: Categorical emission has no fused scaled output");
-    hipLaunchKernelGGL(k_emission_cat, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream,
-                       (const double*)h->obs.p, mk, starts_dev, n, Lm, K, h->V,
-                       (const double*)h->cat_table.p, flags, out);
-    HIPCK(hipGetLastError());
-    return 0;
-  }
-  // fp32 mode, large batches of a NIW model with K <= 64, D <= 32: the centred bf16 x 3 kernel
-  // (variant[5] = 3: the fp64 feature GEMM also in this mode)
-  if (!h->emis_diag && scaled && (flags & SVIHMM_INT_ST32) && emb_shape_ok(K, D) && h->niw.p &&
-      h->variant[5] != 3 && min_lds == 0 && (n + 127) / 128 >= 256) {
-    uint4* uwp = nullptr;
-    CK(emb_buffers(h, &uwp));
-    if (!h->uw_valid) {   // the mode was switched on after the parameter upload: factors from the resident NIW block
-      const double* dmu = (const double*)h->niw.p;
-      const double* dsg = dmu + (size_t)K * D;
-      const double* dka = dsg + (size_t)K * D * D;
-      const double* dnu = dka + K;
-#define NIWU(DM) hipLaunchKernelGGL(k_niw_to_theta_wave<DM>, dim3(K), dim3(64), 0, stream, dmu, dsg, dka, dnu, K, D, Kp, \
-                                    (double*)nullptr, (int*)nullptr, (double*)nullptr, (double*)nullptr, uwp)
-      if (D <= 8) NIWU(8); else if (D <= 16) NIWU(16); else NIWU(32);
-#undef NIWU
-      HIPCK(hipGetLastError());
-      h->uw_valid = true;
-    }
-    const size_t lds = (size_t)EMB_REC + (size_t)4 * 64 * 64 * 4;         // two workgroups per CU
-    if (!h->emb_attr_set) {   // (per handle = per device)
-      HIPCK(hipFuncSetAttribute((const void*)k_emission_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      h->emb_attr_set = true;
-    }
-    hipLaunchKernelGGL(k_emission_bf16x3, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, stream,
-                       (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, (const char*)uwp,
-                       flags, (float*)out, kexp_out, ll0_out);
-    HIPCK(hipGetLastError());
-    return 0;
-  }
-  int var = h->variant[0];
-  if (var == 0 || scaled) var = 2;
-  // scaled output, D % 8 == 0: the address-free orbit schedule (variant[5] = 1 keeps K1b)
-  if (h->emis_diag) var = 2;    // table-driven GEMM only (the VALU fallback assumes the triangular order)
-  if (!h->emis_diag && scaled && K <= 64 && D >= 8 && D <= 40 && D % 8 == 0 && h->variant[5] != 1 && min_lds == 0) {
-    const int NT = Kp / 16, LEN = D + D / 2 + 1;
-    const int nks = (D / 4) * (D / 2 + 1) + (D / 2 + 1 + 3) / 4;
-    if (!h->orb_valid) {
-      CK(ensure(h->theta_orb, (size_t)nks * 4 * Kp * sizeof(double)));
-      hipLaunchKernelGGL(k_theta_orbit, dim3(nks * 4), dim3(64), 0, stream, (const double*)h->theta.p,
-                         D, Kp, NT, (double*)h->theta_orb.p);
-      HIPCK(hipGetLastError());
-      h->orb_valid = true;
-    }
-    // fewer than one 128-row workgroup per CU: 64-row workgroups (variant[5] = 2: always 128)
-    const int MTo = ((n + 127) / 128 < 256 && h->variant[5] != 2) ? 1 : 2;
-    const int rows = 64 * MTo;
-    const size_t lds = (size_t)rows * LEN * 8 + rows * 9;
-    dim3 grid((unsigned)((n + rows - 1) / rows));
-#define EMO(NTV, UV, MTV) hipLaunchKernelGGL((k_emission_orbit<NTV, UV, MTV>), grid, dim3(256), lds, stream,  \
-                                        (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K,               \
-                                        (const double*)h->theta_orb.p, flags, out, kexp_out, ll0_out)
-#define EMOM(NTV, UV) do { if (MTo == 1) EMO(NTV, UV, 1); else EMO(NTV, UV, 2); } while (0)
-    if (D % 16 == 0) { if (NT == 4) EMOM(4, 4); else if (NT == 3) EMOM(3, 4); else if (NT == 2) EMOM(2, 4); else EMOM(1, 4); }
-    else             { if (NT == 4) EMOM(4, 2); else if (NT == 3) EMOM(3, 2); else if (NT == 2) EMOM(2, 2); else EMOM(1, 2); }
-#undef EMOM
-#undef EMO
-    HIPCK(hipGetLastError());
-    return 0;
-  }
-  if (var == 2) {
-    const int DS = (D + 2) | 1;
-    int MT = h->variant[3] > 0 ? h->variant[3] : 2;
-    if (MT != 2 && MT != 4) MT = 2;
-    size_t lds = (size_t)(64 * MT) * DS * 8 + (size_t)h->Fp * 4 + (size_t)(64 * MT) * 9;
-    if (lds > 150 * 1024 && MT == 4) { MT = 2; lds = (size_t)128 * DS * 8 + (size_t)h->Fp * 4 + 128 * 9; }
-    if (lds < min_lds) lds = min_lds;   // occupancy cap: leave LDS for co-resident sweep workgroups
-    if (lds > 150 * 1024 && scaled) return fail("emission: D too large for the scaled sweeps");
-    if (lds > 150 * 1024 && h->emis_diag) return fail("emission: D too large for the diagonal family's kernel");
-    if (lds > 150 * 1024) var = 1;
-    else {
-      const int ntile = Kp / 16;
-      int NT = (ntile % 4 == 0) ? 4 : (ntile % 2 == 0) ? 2 : 1;
-      // wide models: eight state tiles per wave -- every generated A operand feeds 8 instead of 4
-      // MFMAs (variant[3] = 1: four)
-      if (!scaled && MT == 2 && ntile % 8 == 0 && h->variant[3] != 1) NT = 8;
-      if (scaled) { NT = ntile; MT = 2; }   // the workgroup must own whole rows (K <= 64)
-      const int rows = 64 * MT;
-      dim3 grid((unsigned)((n + rows - 1) / rows), ntile / NT);
-#define EMM_LAUNCH(NTV, MTV, SC)                                                             \
-  do {                                                                                        \
-    if (lds > 64 * 1024)                                                                      \
-      hipFuncSetAttribute((const void*)k_emission_mfma<NTV, MTV, SC>,                         \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
-    hipLaunchKernelGGL((k_emission_mfma<NTV, MTV, SC>), grid, dim3(256), lds, stream,         \
-                       (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K,                  \
-                       Kp, h->Fp, (const double*)h->theta.p, (const int*)h->fab.p, flags,     \
-                       out, kexp_out, SC ? ll0_out : (double*)nullptr);                       \
-  } while (0)
-      if (scaled) {
-        if (NT == 4) EMM_LAUNCH(4, 2, true); else if (NT == 3) EMM_LAUNCH(3, 2, true);
-        else if (NT == 2) EMM_LAUNCH(2, 2, true); else EMM_LAUNCH(1, 2, true);
-      } else if (MT == 4) {
-        if (NT == 4) EMM_LAUNCH(4, 4, false); else if (NT == 2) EMM_LAUNCH(2, 4, false); else EMM_LAUNCH(1, 4, false);
-      } else {
-        if (NT == 8) EMM_LAUNCH(8, 2, false); else if (NT == 4) EMM_LAUNCH(4, 2, false);
-        else if (NT == 2) EMM_LAUNCH(2, 2, false); else EMM_LAUNCH(1, 2, false);
-      }
-#undef EMM_LAUNCH
-    }
-  }
-  if (var == 1) {
-    const size_t lds = (size_t)(D + 1) * (EM_R + 1) * 8;
-    if (lds > 160 * 1024) return fail("emission: D too large for the LDS-staged kernels");
-    if (lds > 64 * 1024)
-      hipFuncSetAttribute((const void*)k_emission_outer, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    dim3 grid((unsigned)((n + EM_R - 1) / EM_R), Kp / 16);
-    hipLaunchKernelGGL(k_emission_outer, grid, dim3(EM_R), lds, stream,
-                       (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K,
-                       Kp, (const double*)h->theta.p, flags, out);
-  }
-  HIPCK(hipGetLastError());
-  return 0;
-}
 
-static int launch_fb(svihmm_ctx* h, int B, int Lm, int dir0, int ndir,
-                     const double* ll = nullptr, double* la = nullptr, double* lb = nullptr) {
-  if (!h->have_globals) return fail("no globals: call svihmm_set_globals");
-  const int K = h->K;
-  const size_t n = (size_t)B * Lm * K * sizeof(double);
-  if (!ll) {
-    if (dir0 == 0) CK(ensure(h->la, n));
-    if (dir0 + ndir > 1) CK(ensure(h->lb, n));
-    ll = (const double*)h->ll.p;
-    la = (double*)h->la.p;
-    lb = (double*)h->lb.p;
-  }
-  ProfScope ps(h, KS_FB);
-  dim3 grid(B, ndir);
-  const double* A = (const double*)h->Aexp.p;
-  const double* mi = (const double*)h->mod_init.p;
-  if (h->exact_log) {   // transition expectations outside exp()'s range: the literal recursion
-    const int threads = (K + 63) / 64 * 64;
-    const int in_lds = ((size_t)K * (K + 1) + 2 * K) * 8 <= 150 * 1024;
-    const size_t lds = (2 * (size_t)K + (in_lds ? (size_t)K * (K + 1) : 0)) * 8;
-    if (lds > 64 * 1024)
-      hipFuncSetAttribute((const void*)k_fb_exact, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_fb_exact, grid, dim3(threads), lds, h->stream, ll, (const double*)h->ltran.p, mi,
-                       Lm, K, dir0, in_lds, la, lb);
-    HIPCK(hipGetLastError());
-    return 0;
-  }
-  if (K <= 16)
-    hipLaunchKernelGGL(k_fb_wave<16>, grid, dim3(64), 0, h->stream, ll, A, mi, Lm, K, dir0, la, lb);
-  else if (K <= 32)
-    hipLaunchKernelGGL(k_fb_wave<32>, grid, dim3(64), 0, h->stream, ll, A, mi, Lm, K, dir0, la, lb);
-  else if (K <= 64)
-    hipLaunchKernelGGL(k_fb_wave<64>, grid, dim3(64), 0, h->stream, ll, A, mi, Lm, K, dir0, la, lb);
-  else {
-    const int threads = (K + 63) / 64 * 64;
-    const int in_lds = ((size_t)K * K * 8 + 2 * K * 8 + 128) <= 150 * 1024;
-    const size_t lds = (2 * (size_t)K + 16) * 8 + (in_lds ? (size_t)K * K * 8 : 0);
-    if (lds > 64 * 1024)
-      hipFuncSetAttribute((const void*)k_fb_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_fb_generic, grid, dim3(threads), lds, h->stream, ll, A,
-                       (const double*)h->AexpT.p, mi, Lm, K, dir0, in_lds, la, lb);
-  }
-  HIPCK(hipGetLastError());
-  return 0;
-}
-
-static int launch_posterior(svihmm_ctx* h, int B, int Lm, bool total) {
-  const int K = h->K;
-  // rows per workgroup: 256 for big batches, down to 16 so that small ones give >= ~2048 workgroups
-  int rps = 256;
-  while (rps > 16 && (int64_t)B * ((Lm + rps - 1) / rps) < 2048) rps >>= 1;
-  const int nseg = (Lm + rps - 1) / rps;
-  CK(ensure(h->q, (size_t)B * Lm * K * sizeof(double)));
-  CK(ensure(h->lse_part, (size_t)B * nseg * sizeof(double)));
-  CK(ensure(h->local_lb, (size_t)B * sizeof(double)));
-  CK(ensure(h->packed, (size_t)packed_len(h) * sizeof(double)));
-  ProfScope ps(h, KS_POSTERIOR);
-  dim3 grid((unsigned)((size_t)B * nseg));
-#define POST_LAUNCH(KPL)                                                                  \
-  hipLaunchKernelGGL(k_posterior<KPL>, grid, dim3(256), 0, h->stream, (const double*)h->la.p, \
-                     (const double*)h->lb.p, Lm, K, nseg, rps, (double*)h->q.p, (double*)h->lse_part.p)
-  if (K <= 64) POST_LAUNCH(1);
-  else if (K <= 256) POST_LAUNCH(4);
-  else POST_LAUNCH(16);
-#undef POST_LAUNCH
-  double* lbtot = nullptr;
-  if (total) lbtot = (double*)h->packed.p + (packed_len(h) - 1);
-  hipLaunchKernelGGL(k_reduce_lb, dim3(1), dim3(256), 0, h->stream, (const double*)h->lse_part.p,
-                     B, nseg, (double*)h->local_lb.p, lbtot);
-  HIPCK(hipGetLastError());
-  return 0;
-}
-
-// forward sweep, then backward sweep with the posterior fused (K <= 64).  want_lb: also
-// materialise lbeta (API readback); total: write sum_b local_lb into packed[last].
-static int launch_fb_fused(svihmm_ctx* h, int B, int Lm, bool want_lb, bool total) {
-  if (!h->have_globals) return fail("no globals: call svihmm_set_globals");
-  const int K = h->K;
-  const size_t n = (size_t)B * Lm * K * sizeof(double);
-  CK(ensure(h->la, n));
-  CK(ensure(h->q, n));
-  if (want_lb) CK(ensure(h->lb, n));
-  CK(ensure(h->local_lb, (size_t)B * sizeof(double)));
-  CK(ensure(h->logz, (size_t)B * sizeof(double)));
-  CK(ensure(h->packed, (size_t)packed_len(h) * sizeof(double)));
-  const int NW = (K + 15) / 16;
-  dim3 grid((B + 15) / 16);
-  const double* ll = (const double*)h->ll.p;
-  double* la = (double*)h->la.p;
-  double* lb = want_lb ? (double*)h->lb.p : nullptr;
-  double* q = (double*)h->q.p;
-  double* llb = (double*)h->local_lb.p;
-  double* lz = (double*)h->logz.p;
-  {
-    ProfScope ps(h, KS_FB);
-#define FWD(NWV, F) hipLaunchKernelGGL((k_fwd_mfma<NWV, F>), grid, dim3(64 * NWV), 0, h->stream, ll, \
-                                       (const double*)h->Aexp.p, (const double*)h->mod_init.p, B, Lm, K, la, llb, lz)
-    const bool full = (K == 16 * NW);
-    if (NW == 1) { if (full) FWD(1, true); else FWD(1, false); }
-    else if (NW == 2) { if (full) FWD(2, true); else FWD(2, false); }
-    else if (NW == 3) { if (full) FWD(3, true); else FWD(3, false); }
-    else { if (full) FWD(4, true); else FWD(4, false); }
-#undef FWD
-    HIPCK(hipGetLastError());
-  }
-  {
-    ProfScope ps(h, KS_POSTERIOR);
-    const bool full = (K == 16 * NW);
-#define BWD(NWV, F, W) hipLaunchKernelGGL((k_bwd_mfma<NWV, F, W>), grid, dim3(64 * NWV), 0, h->stream, ll, \
-                                          (const double*)h->AexpT.p, (const double*)la, (const double*)lz, B, Lm, K, lb, q)
-#define BWD2(NWV) do { if (full) { if (want_lb) BWD(NWV, true, true); else BWD(NWV, true, false); } \
-                       else { if (want_lb) BWD(NWV, false, true); else BWD(NWV, false, false); } } while (0)
-    if (NW == 1) BWD2(1); else if (NW == 2) BWD2(2); else if (NW == 3) BWD2(3); else BWD2(4);
-#undef BWD2
-#undef BWD
-    if (total) {
-      double* lbtot = (double*)h->packed.p + (packed_len(h) - 1);
-      hipLaunchKernelGGL(k_sum_lb, dim3(1), dim3(256), 0, h->stream, (const double*)llb, B, lbtot);
-    }
-    HIPCK(hipGetLastError());
-  }
-  return 0;
-}
-
-// scaled linear-domain sweeps (K <= 64): Eh / kexp -> ah, (na, k), Z -> var_x
-static int ensure_fb_lin(svihmm_ctx* h, int B, int Lm) {
-  const int K = h->K;
-  const size_t n = (size_t)B * Lm * K * sizeof(double);
-  CK(ensure(h->la, n));
-  CK(ensure(h->lb, n));
-  CK(ensure(h->hx, (size_t)B * Lm * sizeof(double)));
-  CK(ensure(h->gx, (size_t)B * Lm * sizeof(double)));
-  CK(ensure(h->zfac, (size_t)B * sizeof(double2)));
-  CK(ensure(h->local_lb, (size_t)B * sizeof(double)));
-  CK(ensure(h->logz, (size_t)B * sizeof(double)));
-  CK(ensure(h->packed, (size_t)packed_len(h) * sizeof(double)));
-  CK(ensure(h->a0v, (size_t)B * K * sizeof(double)));
-  CK(ensure(h->a0e, (size_t)B * sizeof(double)));
-  return 0;
-}
-// initial messages of windows [b0, b0+nb): mod_init + ll_0 in the log domain (k_lin_init); the
-// first rows' log-likelihoods come from the scaled emission's side output (ll0) or, where the
-// plain lliks are kept (host lliks, wide models, Categorical), straight from those
-static int launch_lin_init(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_t stream) {
-  const int K = h->K;
-  const double* src = h->eh_in_llE ? (const double*)h->ll.p + (size_t)b0 * Lm * K
-                                   : (const double*)h->ll0.p + (size_t)b0 * K;
-  const size_t stride = h->eh_in_llE ? (size_t)Lm * K : (size_t)K;
-  hipLaunchKernelGGL(k_lin_init, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, stream,
-                     (const double*)h->mod_init.p, src, stride, (const double*)h->kexp.p + (size_t)b0 * Lm,
-                     nb, Lm, K, (double*)h->a0v.p + (size_t)b0 * K, (double*)h->a0e.p + b0);
-  HIPCK(hipGetLastError());
-  return 0;
-}
-// up to this many windows the wave-per-window scaled sweep beats the MFMA one (which is
-// latency-bound at ~0.9 us per step however few windows it gets): 2 x 1024 waves are resident
-// at once (190 VGPRs: two per SIMD); measured (tools/sweep_crossover.py, K = 64, Lm = 257)
-// 0.16 ms at 64 .. 0.19 ms at 1024 windows against 0.23 .. 0.25 ms, 0.33 against 0.26 ms at 1399
-#define LIN_WAVE_MAX 1025
-// up to this many windows: four waves per (window, direction); 2 x 256 x 4 = 2048 waves, two per SIMD
-#define LIN_WAVE4_MAX 256
-// both sweeps over windows [b0, b0+nb) of the current batch on `stream` (buffers ensured):
-// one launch, blockIdx.y = direction
-static int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_t stream) {
-  const int K = h->K;
-  const int NW = (K + 15) / 16;
-  const bool full = (K == 16 * NW);
-  dim3 grid((nb + 15) / 16, 2);
-  const size_t ro = (size_t)b0 * Lm;
-  const double* Eh = (const double*)(h->eh_in_llE ? h->llE.p : h->ll.p) + ro * K;
-  const double* kx = (const double*)h->kexp.p + ro;
-  double* ah = (double*)h->la.p + ro * K;
-  double* bh = (double*)h->lb.p + ro * K;
-  double* hx = (double*)h->hx.p + ro;
-  double* gx = (double*)h->gx.p + ro;
-  double2* zf = (double2*)h->zfac.p + b0;
-  double* llb = (double*)h->local_lb.p + b0;
-  double* lz = (double*)h->logz.p + b0;
-  const double* a0v = (const double*)h->a0v.p + (size_t)b0 * K;
-  const double* a0e = (const double*)h->a0e.p + b0;
-  // first-row log-likelihoods of the windows (see launch_lin_init): the wave-per-window kernels
-  // form the initial message themselves, the tile kernels take it from k_lin_init
-  const double* mi = (const double*)h->mod_init.p;
-  const double* l0 = h->eh_in_llE ? (const double*)h->ll.p + ro * K : (const double*)h->ll0.p + (size_t)b0 * K;
-  const size_t l0s = h->eh_in_llE ? (size_t)Lm * K : (size_t)K;
-  ProfScope ps(h, KS_FB, stream);
-  if (h->cur_f32) {
-    // fp32 mode (K <= 64, b0 == 0): the same kernels instantiated for float storage
-    const float* Ef = (const float*)h->ll.p;
-    float* af = (float*)h->la.p;
-    float* bf = (float*)h->lb.p;
-    if (nb < LIN_WAVE_MAX && h->variant[7] != 2) {
-      dim3 gw((unsigned)nb, 2);
-#define WLF(KM, FK) hipLaunchKernelGGL((k_wave_lin<KM, FK, float>), gw, dim3(64), 0, stream, Ef, kx, (const double*)h->Aexp.p, \
-                                       (const double*)h->AexpT.p, mi, l0, l0s, Lm, K, af, bf, hx,   \
-                                       gx, llb, lz, zf)
-#define WL4F(KM) hipLaunchKernelGGL((k_wave_lin4<KM, float>), gw, dim3(256), 0, stream, Ef, kx, (const double*)h->Aexp.p, \
-                                    (const double*)h->AexpT.p, mi, l0, l0s, Lm, K, af, bf, hx, gx, \
-                                    llb, lz, zf)
-      if (K > 16 && nb <= LIN_WAVE4_MAX && h->variant[7] != 3) { WL4F(64); }
-      else if (K <= 16) WLF(16, false); else if (K <= 32) WLF(32, false);
-      else if (K == 64) WLF(64, true); else WLF(64, false);
-#undef WLF
-#undef WL4F
-    } else {
-      CK(launch_lin_init(h, b0, nb, Lm, stream));
-      const LinChain none = {};
-#define SWF(NWV, F) hipLaunchKernelGGL((k_sweeps_lin<NWV, F, 0, false, float>), grid, dim3(64 * NWV),              \
-                                       sizeof(LinShared<NWV>), stream, Ef, kx, (const double*)h->Aexp.p,         \
-                                       (const double*)h->AexpT.p, a0v, a0e, nb, Lm, Lm, K,   \
-                                       af, bf, hx, gx, llb, lz, zf, none)
-      if (NW == 1) { if (full) SWF(1, true); else SWF(1, false); }
-      else if (NW == 2) { if (full) SWF(2, true); else SWF(2, false); }
-      else if (NW == 3) { if (full) SWF(3, true); else SWF(3, false); }
-      else { if (full) SWF(4, true); else SWF(4, false); }
-#undef SWF
-    }
-    HIPCK(hipGetLastError());
-    return 0;
-  }
-  if (K <= 64 && nb < LIN_WAVE_MAX && h->variant[7] != 2) {
-    // small batches: one wavefront per (window, direction)
-    dim3 gw((unsigned)nb, 2);
-#define WL(KM, FK) hipLaunchKernelGGL((k_wave_lin<KM, FK>), gw, dim3(64), 0, stream, Eh, kx, (const double*)h->Aexp.p, \
-                                      (const double*)h->AexpT.p, mi, l0, l0s, Lm, K, ah, bh, hx,  \
-                                      gx, llb, lz, zf)
-    // up to a few hundred windows the chip is far from full with one wave per (window,
-    // direction): split each window's source states over four waves (variant[7] = 3: off)
-    if (K > 16 && nb <= LIN_WAVE4_MAX && h->variant[7] != 3) {
-#define WL4(KM) hipLaunchKernelGGL((k_wave_lin4<KM>), gw, dim3(256), 0, stream, Eh, kx, (const double*)h->Aexp.p, \
-                                   (const double*)h->AexpT.p, mi, l0, l0s, Lm, K, ah, bh, hx,  \
-                                   gx, llb, lz, zf)
-      WL4(64);
-#undef WL4
-    }
-    else if (K <= 16) WL(16, false); else if (K <= 32) WL(32, false);
-    else if (K == 64) WL(64, true); else WL(64, false);
-#undef WL
-    HIPCK(hipGetLastError());
-    return 0;
-  }
-  CK(launch_lin_init(h, b0, nb, Lm, stream));
-  const LinChain none = {};
-#define SWPX(NWV, F, BSV)                                                                                  \
-  do {                                                                                                     \
-    const size_t lds = sizeof(LinShared<NWV>);                                                             \
-    if (lds > 64 * 1024)                                                                                   \
-      hipFuncSetAttribute((const void*)k_sweeps_lin<NWV, F, 0, BSV>,                                       \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
-    hipLaunchKernelGGL((k_sweeps_lin<NWV, F, 0, BSV>), grid, dim3(64 * NWV), lds, stream, Eh, kx,          \
-                       (const double*)h->Aexp.p, (const double*)h->AexpT.p,                                \
-                       a0v, a0e, nb, Lm, Lm, K, ah, bh, hx, gx, llb, lz, zf, none);    \
-  } while (0)
-#define SWP(NWV, F) SWPX(NWV, F, false)
-  if (NW == 1) { if (full) SWP(1, true); else SWP(1, false); }
-  else if (NW == 2) { if (full) SWP(2, true); else SWP(2, false); }
-  else if (NW == 3) { if (full) SWP(3, true); else SWP(3, false); }
-  else if (NW == 4) { if (full) SWP(4, true); else SWP(4, false); }
-  else if (NW <= 8) { if (K == 128) SWPX(8, true, true); else SWPX(8, false, true); }      // K > 64: B streamed
-  else {
-    // 128 < K <= 256: eight waves of two state tiles (256 VGPRs each) instead of 16 x 1
-#define SWP2(F, WT)                                                                                        \
-  do {                                                                                                     \
-    const size_t lds = (size_t)(WT) * sizeof(LinShared<16>);                                               \
-    dim3 g2((unsigned)((nb + 16 * (WT) - 1) / (16 * (WT))), 2);                                            \
-    hipFuncSetAttribute((const void*)k_sweeps_lin2<8, F, WT>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                        (int)lds);                                                                         \
-    hipLaunchKernelGGL((k_sweeps_lin2<8, F, WT>), g2, dim3(512), lds, stream, Eh, kx,                      \
-                       (const double*)h->Aexp.p, (const double*)h->AexpT.p, a0v, a0e,  \
-                       nb, Lm, K, ah, bh, hx, gx, llb, lz, zf);                                            \
-  } while (0)
-    // more 16-window workgroups than CUs: 32 windows per workgroup share the streamed transition
-    // tile (variant[13] = 1: off)
-    const bool w32 = 2 * ((nb + 15) / 16) > 256 && h->variant[13] != 1;     // 256 CUs
-    // 128 < K <= 192: twelve waves of one state tile (three per SIMD; the eight two-tile waves would
-    // run four empty tiles: 4.85 against 6.1 ms at K = 192, D = 32, T = 1e6).  variant[7] = 1: one
-    // tile per wave for every K, 2: two tiles per wave for every K
-    if (NW <= 12 && h->variant[7] != 2) { if (K == 192) SWPX(12, true, true); else SWPX(12, false, true); }
-    else if (h->variant[7] == 1) { if (K == 256) SWPX(16, true, true); else SWPX(16, false, true); }
-    else if (w32) { if (K == 256) SWP2(true, 2); else SWP2(false, 2); }
-    else if (K == 256) SWP2(true, 1); else SWP2(false, 1);
-#undef SWP2
-  }
-#undef SWP
-#undef SWPX
-  HIPCK(hipGetLastError());
-  return 0;
-}
-// var_x of the last scaled sweep (B windows of length Lm), formed on first use
-static int ensure_q(svihmm_ctx* h, int B, int Lm, hipStream_t stream) {
-  if (!h->lin_mode || h->q_valid) return 0;
-  const int K = h->K;
-  const int64_t n = (int64_t)B * Lm;
-  CK(ensure(h->q, (size_t)n * K * sizeof(double)));
-  ProfScope ps(h, KS_POSTERIOR, stream);
-  dim3 grid((unsigned)((n + 15) / 16));
-#define PQ(KT) hipLaunchKernelGGL(k_lin_posterior<KT>, grid, dim3(256), 0, stream, (const double*)h->la.p, \
-                                  (const double*)h->lb.p, (const double*)h->hx.p, (const double*)h->gx.p,   \
-                                  (const double2*)h->zfac.p, n, Lm, K, (double*)h->q.p)
-#define PQF(KT) hipLaunchKernelGGL((k_lin_posterior<KT, float>), grid, dim3(256), 0, stream, (const float*)h->la.p, \
-                                   (const float*)h->lb.p, (const double*)h->hx.p, (const double*)h->gx.p,          \
-                                   (const double2*)h->zfac.p, n, Lm, K, (double*)h->q.p)
-  if (h->cur_f32) { if (K <= 16) PQF(1); else if (K <= 32) PQF(2); else if (K <= 48) PQF(3); else PQF(4); }
-  else if (K <= 16) PQ(1); else if (K <= 32) PQ(2); else if (K <= 48) PQ(3); else if (K <= 64) PQ(4);
-  else if (K <= 128) PQ(8); else if (K <= 192) PQ(12); else PQ(16);
-#undef PQ
-#undef PQF
-  HIPCK(hipGetLastError());
-  h->q_valid = true;
-  return 0;
-}
-// ELBO total still owed to packed[last] (set by the scaled sweeps, paid by k_finalize or here)
-static int flush_lb(svihmm_ctx* h, hipStream_t stream);
-static int launch_sum_lb(svihmm_ctx* h, int B, hipStream_t stream) {
-  double* lbtot = (double*)h->packed.p + (packed_len(h) - 1);
-  hipLaunchKernelGGL(k_sum_lb, dim3(1), dim3(256), 0, stream, (const double*)h->local_lb.p, B, lbtot);
-  HIPCK(hipGetLastError());
-  return 0;
-}
-// One long window (B = 1, the full-chain E-step) as an exact blocked scan over chunks of
-// CHAIN_L steps: chunk matrices (S1), boundary vectors (S2), all chunks as concurrent windows
-// with boundary conditions (S3).  See the comment above LinChain in kernels_recursion.h.
-// chunk length: 256 steps give the most concurrent windows in S3; very long chains use 1024 so
-// that the sequential boundary scan (S2) stays short (S1's work does not depend on it)
-static int chain_len(int Lm) { return Lm >= 512 * 1024 ? 1024 : 256; }
-static bool use_chain(const svihmm_ctx* h, int B, int Lm) {
-  return B == 1 && h->K <= 256 && Lm >= 2048 && h->variant[6] != 1 && !h->exact_log;
-}
-static int launch_fb_chain(svihmm_ctx* h, int Lm, bool total) {
-  const int K = h->K, T = Lm, L = chain_len(Lm);
-  // state tiles the sweep kernels are instantiated for: exact up to 64 states, 8 / 16 tiles with
-  // the transition tile streamed beyond (the chunk matrices are laid out for that width)
-  const int NWt = (K + 15) / 16;
-  const int NW = NWt <= 4 ? NWt : NWt <= 8 ? 8 : 16, Kp = 16 * NW;
-  const bool full = (K == Kp);
-  const int Cfull = (T - 2) / L;            // interior chunks; the tail chunk has 1..L steps
-  const int C = Cfull + 1;
-  const int ltail = T - 1 - Cfull * L;      // steps of the tail chunk (rows Cfull*L .. T-1)
-  CK(ensure_fb_lin(h, 1, Lm));
-  // chunk matrices + transposes + row exponents | boundary vectors and exponents | per-chunk scalars
-  const size_t nM = (size_t)C * Kp * K;
-  CK(ensure(h->chain, (2 * nM + (size_t)C * Kp + 2 * (size_t)(C + 1) * K + 7 * (size_t)(C + 1) + 8) * sizeof(double)));
-  double* Mm = (double*)h->chain.p;
-  double* MmT = Mm + nM;
-  double* Mh = MmT + nM;
-  double* abnd = Mh + (size_t)C * Kp;
-  double* bbnd = abnd + (size_t)(C + 1) * K;
-  double* aexp = bbnd + (size_t)(C + 1) * K;
-  double* bexp = aexp + (C + 1);
-  double* kbef = bexp + (C + 1);
-  double* lbw = kbef + (C + 1);             // per-chunk local_lb
-  double* lzw = lbw + (C + 1);              // scratch logz of the S3 windows
-  double* ksum = lzw + (C + 1);             // per-chunk sums of the emission row exponents
-  h->chain_kbef = kbef; h->chain_C = C; h->chain_L = L; h->chain_T = T;
-  CK(ensure(h->chain2, (size_t)(C + 1) * sizeof(double2)));
-  double2* zfw = (double2*)h->chain2.p;     // scratch zfac of the S3 windows (the global one comes from S2)
-  const double* Eh = (const double*)(h->eh_in_llE ? h->llE.p : h->ll.p);
-  const double* kx = (const double*)h->kexp.p;
-  double* ah = (double*)h->la.p; double* bh = (double*)h->lb.p;
-  double* hx = (double*)h->hx.p; double* gx = (double*)h->gx.p;
-  const double* A = (const double*)h->Aexp.p; const double* At = (const double*)h->AexpT.p;
-  const double* a0v = (const double*)h->a0v.p;
-  const double* a0e = (const double*)h->a0e.p;
-  hipStream_t st = h->stream;
-  ProfScope ps(h, KS_FB, st);
-  CK(launch_lin_init(h, 0, 1, Lm, st));
-#define SWPM(NWV, F, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH)                       \
-  hipLaunchKernelGGL((k_sweeps_lin<NWV, F, MD>), GRID, dim3(64 * NWV), sizeof(LinShared<NWV>), st, EHP, KXP, A, At, \
-                     a0v, a0e, BB, LL, WS, K, AH, BH, HX, GX, LB, LZ, ZF, CH)
-#define SWPB(NWV, F, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH)                       \
-  do {                                                                                                      \
-    hipFuncSetAttribute((const void*)k_sweeps_lin<NWV, F, MD, true>,                                        \
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LinShared<NWV>));           \
-    hipLaunchKernelGGL((k_sweeps_lin<NWV, F, MD, true>), GRID, dim3(64 * NWV), sizeof(LinShared<NWV>), st,  \
-                       EHP, KXP, A, At, a0v, a0e, BB, LL, WS, K, AH, BH, HX, GX, LB, LZ, ZF, CH);                 \
-  } while (0)
-#define SWPD(MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH)                                \
-  do {                                                                                                      \
-    if (NW == 8) { if (full) SWPB(8, true, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH); \
-                   else SWPB(8, false, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH); }   \
-    else if (NW == 16) { if (full) SWPB(16, true, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH); \
-                         else SWPB(16, false, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH); } \
-    else if (NW == 1) { if (full) SWPM(1, true, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH); \
-                   else SWPM(1, false, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH); }   \
-    else if (NW == 2) { if (full) SWPM(2, true, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH); \
-                        else SWPM(2, false, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH); } \
-    else if (NW == 3) { if (full) SWPM(3, true, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH); \
-                        else SWPM(3, false, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH); } \
-    else { if (full) SWPM(4, true, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH);         \
-           else SWPM(4, false, MD, GRID, BB, LL, WS, EHP, KXP, AH, BH, HX, GX, LB, LZ, ZF, CH); }           \
-  } while (0)
-  LinChain ch = {};
-  ch.Mout = Mm; ch.MoutT = MmT; ch.Mh = Mh;
-  // S1: chunk matrices.  Interior chunks: L steps (rows c*L .. c*L+L); tail: ltail steps.
-  if (Cfull > 0)
-    SWPD(2, dim3((unsigned)(Cfull * NW), 1), Cfull, L + 1, L, Eh, kx, ah, bh, hx, gx, lbw, lzw, zfw, ch);
-  {
-    LinChain ct = ch;
-    ct.Mout = Mm + (size_t)Cfull * Kp * K; ct.MoutT = MmT + (size_t)Cfull * Kp * K; ct.Mh = Mh + (size_t)Cfull * Kp;
-    const size_t ro = (size_t)Cfull * L;
-    SWPD(2, dim3((unsigned)NW, 1), 1, ltail + 1, L, Eh + ro * K, kx + ro, ah, bh, hx, gx, lbw, lzw, zfw, ct);
-  }
-  // S2: boundary vectors, Z
-  hipLaunchKernelGGL(k_chunk_ksum, dim3(C), dim3(64), 0, st, kx, C, L, (int64_t)T, ksum);
-#define SCAN(KM)                                                                                                   \
-  do {                                                                                                             \
-    const size_t lds = (size_t)4 * KM * 64 * sizeof(double);                                                       \
-    if (lds > 64 * 1024)                                                                                           \
-      hipFuncSetAttribute((const void*)k_chunk_scan<KM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
-    hipLaunchKernelGGL(k_chunk_scan<KM>, dim3(2), dim3(256), lds, st, (const double*)Mm, (const double*)MmT,       \
-                       (const double*)Mh, C, Kp, K, Eh, (const double*)ksum, a0v, a0e, abnd, aexp, bbnd, bexp, kbef,     \
-                       (double2*)h->zfac.p, (double*)h->logz.p);                                                   \
-  } while (0)
-  if (K <= 16) SCAN(16); else if (K <= 32) SCAN(32); else if (K <= 64) SCAN(64);
-  else
-    hipLaunchKernelGGL(k_chunk_scan_wide, dim3(2), dim3(256), 0, st, (const double*)Mm, (const double*)MmT,
-                       (const double*)Mh, C, Kp, K, Eh, (const double*)ksum, a0v, a0e, abnd, aexp, bbnd, bexp, kbef,
-                       (double2*)h->zfac.p, (double*)h->logz.p);
-#undef SCAN
-  // S3: every chunk as a window with boundary conditions
-  ch.init_vec = abnd; ch.init_exp = aexp; ch.kbefore = kbef;
-  ch.term_vec = bbnd + K; ch.term_exp = bexp + 1;       // window c ends at boundary c + 1
-  if (Cfull > 0)
-    SWPD(1, dim3((unsigned)((Cfull + 15) / 16), 2), Cfull, L + 1, L, Eh, kx, ah, bh, hx, gx, lbw, lzw, zfw, ch);
-  {
-    LinChain ct = ch;
-    ct.init_vec = abnd + (size_t)Cfull * K; ct.init_exp = aexp + Cfull; ct.kbefore = kbef + Cfull;
-    const size_t ro = (size_t)Cfull * L;
-    SWPD(3, dim3(1, 2), 1, ltail + 1, L, Eh + ro * K, kx + ro, ah + ro * K, bh + ro * K, hx + ro, gx + ro,
-         lbw + Cfull, lzw + Cfull, zfw + Cfull, ct);
-  }
-#undef SWPD
-#undef SWPB
-#undef SWPM
-  HIPCK(hipGetLastError());
-  // local_lb[0] = sum of the chunks' parts (fixed order)
-  hipLaunchKernelGGL(k_sum_lb, dim3(1), dim3(256), 0, st, (const double*)lbw, C, (double*)h->local_lb.p);
-  if (total) {
-    double* lbtot = (double*)h->packed.p + (packed_len(h) - 1);
-    hipLaunchKernelGGL(k_sum_lb, dim3(1), dim3(256), 0, st, (const double*)lbw, C, lbtot);
-  }
-  HIPCK(hipGetLastError());
-  return 0;
-}
-
-static int launch_fb_lin(svihmm_ctx* h, int B, int Lm, bool total) {
-  if (!h->have_globals) return fail("no globals: call svihmm_set_globals");
-  if (use_chain(h, B, Lm)) return launch_fb_chain(h, Lm, total);
-  CK(ensure_fb_lin(h, B, Lm));
-  CK(launch_fb_lin_range(h, 0, B, Lm, h->stream));
-  if (total) h->lb_pending = B;   // summed by k_finalize's extra workgroup (or flush_lb)
-  return 0;
-}
-static int flush_lb(svihmm_ctx* h, hipStream_t stream) {
-  if (!h->lb_pending) return 0;
-  const int B = h->lb_pending;
-  h->lb_pending = 0;
-  return launch_sum_lb(h, B, stream);
-}
 
 // Which sweep implementation a batch uses: 1 wave-per-window (log domain; small batches,
 // K > 64), 2 log-domain MFMA (callers that want lalpha / lbeta back), 3 scaled
@@ -1702,7 +754,7 @@ static int pick_fb(const svihmm_ctx* h, int B, int Lm, bool want_logs) {
 // messages + posterior for a window batch (mode from pick_fb, fixed before the emission ran)
 // the SVI loop's globals kernel runs on a side stream: everything that reads Aexp / mod_init /
 // var_init on the main stream waits for it here (no-op otherwise)
-static int wait_globals(svihmm_ctx* h) {
+int wait_globals(svihmm_ctx* h) {
   if (h->globals_ev) {
     HIPCK(hipStreamWaitEvent(h->stream, h->globals_ev, 0));
     h->globals_ev = nullptr;
@@ -1733,308 +785,8 @@ static int run_fb(svihmm_ctx* h, int B, int Lm, int var, bool want_lb, bool tota
   return launch_posterior(h, B, Lm, total);
 }
 
-// m-tiles (16 features) per wave of the pipelined statistics GEMM: 5 is the instance tuned for
-// the bench shape (40 tiles = 2 workgroups of 4 x 5); narrow models have far fewer tiles (K = 16,
-// D = 8: 4; K = 64, D = 8: 7) and would run 5-tile waves mostly on padding, so they take 1 / 2 / 4.
-// The small instances exist for the staging widths narrow observations need (xk <= 3) only.
-static int stats_mt(const svihmm_ctx* h) {
-  const int Kp = h->Kp, Fp = h->Fp, D = h->D;
-  if (Kp > 64 || h->variant[10] == 1) return 5;
-  const int NSPLIT = (Kp / 16 == 4) ? 2 : 1;
-  const int xk = (D + 1 + 8 * NSPLIT - 1) / (8 * NSPLIT);
-  const int mt = (Fp + Kp) / 16;
-  if (xk > 3) return 5;
-  if (mt <= 16) return mt <= 4 ? 1 : mt <= 8 ? 2 : 4;
-  return (mt + 15) / 16 * 16 < (mt + 19) / 20 * 20 ? 4 : 5;    // whichever pads less (K = 64, D = 24: 25 tiles)
-}
-// row chunking of the statistics GEMM.  One pipelined workgroup is resident per CU, so the launch
-// should be a whole number of rounds of 256 workgroups: chunks x feature groups (grid.y) = 256 r.
-// 128 chunks x 2 feature groups at the bench shape; more chunks only add partial-sum traffic
-// (64 windows: statistics + finalize 74 -> 56 us, tools/chunk_sweep.py).  chunk = multiple of ST_RB.
-struct StatsPlan { int64_t rpc, nchunk; };
-static StatsPlan stats_plan(const svihmm_ctx* h, int64_t n, int forced = 0) {
-  int target_chunks = forced > 0 ? forced : 128;
-  if (forced <= 0 && h->Kp <= 64 && h->Fp > 0 && !h->emis_cat) {
-    const int gy = ((h->Fp + h->Kp) / 16 + 4 * stats_mt(h) - 1) / (4 * stats_mt(h));
-    const int r = std::max(1, (128 * gy + 128) / 256);     // rounds: round(128 gy / 256)
-    // one state tile (K <= 16): the 4-wave workgroups are small enough for two per CU, and the
-    // launch is latency- rather than MFMA-bound (K = 16, D = 32: 0.61 -> 0.46 ms); wider models: one
-    const int per_cu = (h->Kp == 16 && n >= (int64_t)1 << 18) ? 2 : 1;   // (small batches: more chunks only add partial sums)
-    target_chunks = std::max(1, 256 * r * per_cu / gy);
-  }
-  int64_t rpc = (n + target_chunks - 1) / target_chunks;
-  rpc = (rpc + ST_RB - 1) / ST_RB * ST_RB;
-  return {rpc, (n + rpc - 1) / rpc};
-}
-// partial statistics of windows [b0, b0+nb) (inner segment [off, off+Lm) of each window of
-// length Lq) into partial slots [chunk_base, chunk_base + plan.nchunk) on `stream`
-static int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, int Lm, uint32_t flags,
-                              StatsPlan plan, int64_t chunk_base, hipStream_t stream) {
-  const int D = h->D, K = h->K, Kp = h->Kp, Fp = h->Fp, F = h->F;
-  const int Ftot = Fp + Kp;
-  const int64_t n = (int64_t)nb * Lm;
-  const int64_t rpc = plan.rpc, nchunk = plan.nchunk;
-  const uint8_t* mk = h->have_mask ? (const uint8_t*)h->mask.p : nullptr;
-  const int64_t* starts_dev = (const int64_t*)h->starts.p + b0;
-  int var = h->variant[1];
-  if (var == 0) var = 3;
-  if (var == 3) {   // feasibility of the pipelined kernel (same test as below)
-    const int KpW = Kp > 64 ? 64 : Kp;
-    const int TPR = 8 * ((KpW / 16 == 4) ? 2 : 1);
-    const size_t lds = ((size_t)(D + 3 + KpW) * ST_CC + 2 * (size_t)ST_RB * (KpW + 1)) * 8 + 4 * ST_RB * sizeof(StRow4);
-    if (lds > 150 * 1024 || (D + 1 + TPR - 1) / TPR > 9 || (Kp > 64 && Kp % 64 != 0)) var = 2;
-  }
-  // scaled sweeps: the pipelined kernel forms q = ah * bh * scale itself; the others read var_x
-  // (wide models too, round 3: the separate posterior pass costs more than the second operand's loads;
-  //  variant[15] = 1: K > 64 through q as before)
-  const bool lin = h->lin_mode && !h->q_valid && var == 3 && (Kp <= 64 || h->variant[15] != 1);
-  if (h->lin_mode && !lin) CK(ensure_q(h, h->curB, Lq, stream));
-  const size_t qo = (size_t)b0 * Lq * K;
-  const double* qv = (const double*)(lin ? h->la.p : h->q.p) + qo;   // (reassigned: see the transition blocks)
-  const double* bhv = lin ? (const double*)h->lb.p + qo : nullptr;
-  const double* hxv = lin ? (const double*)h->hx.p + (size_t)b0 * Lq : nullptr;
-  const double* gxv = lin ? (const double*)h->gx.p + (size_t)b0 * Lq : nullptr;
-  const double2* zfv = lin ? (const double2*)h->zfac.p + b0 : nullptr;
-  double* partv = (double*)h->part.p + (size_t)chunk_base * Ftot * Kp;
-  {
-    ProfScope ps(h, KS_STATS, stream);
-    if (var == 3) {
-      // pipelined VGPR-form GEMM.  K <= 64: all tiles (statistics + transition) in one launch.
-      // K > 64: state groups of 64 in grid.z for the emission-statistics tiles; the K x K
-      // transition tiles (which need q[t-1] of ALL states as operand rows) go to k_stats_mfma.
-      const bool big = Kp > 64;
-      // wide models, scaled sweeps: the feature launch leaves q = ah bh scale behind for the
-      // transition-block launch (whose little matrix work per staged row cannot carry two more
-      // operand streams: 3.3 against 2.4 ms on configs[4])
-      double* qoutv = nullptr;
-      if (big && lin) {
-        CK(ensure(h->q, (size_t)h->curB * Lq * K * sizeof(double)));
-        qoutv = (double*)h->q.p + qo;
-      }
-      const int NTt = big ? 4 : Kp / 16;                // n-tiles per workgroup
-      const int KpW = 16 * NTt;
-      const int NSPLIT = (NTt == 4) ? 2 : 1;
-      const int TPR = 8 * NSPLIT;
-      const size_t lds = ((size_t)(D + 3 + KpW) * ST_CC + 2 * (size_t)ST_RB * (KpW + 1)) * 8 + 4 * ST_RB * sizeof(StRow4);
-      const int mtiles = Ftot / 16;
-      const int mt_limit = big ? Fp / 16 : mtiles;
-      const int xk = (D + 1 + TPR - 1) / TPR;
-      if (lds > 150 * 1024 || xk > 9 || (big && Kp % 64 != 0)) var = 2;
-      else if (lin && h->cur_f32 && !big) {
-        // fp32 mode: float LDS tiles, v_mfma_f32_16x16x4_f32, ah / bh read as float
-        const size_t ldsf = ((size_t)(D + 3 + KpW) * ST_CC + 2 * (size_t)ST_RB * (KpW + 16)) * 4 + 8 +
-                            4 * ST_RB * sizeof(StRow4);
-        const int MTs = stats_mt(h);
-        dim3 grid((unsigned)nchunk, (mt_limit + 4 * MTs - 1) / (4 * MTs), 1);
-#define ST3F(MTV, NTW, NS, XKV)                                                                   \
-  do {                                                                                           \
-    if (ldsf > 64 * 1024)                                                                        \
-      hipFuncSetAttribute((const void*)k_stats_mfma4<MTV, NTW, NS, XKV, true, false, float, float>, \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);                \
-    hipLaunchKernelGGL((k_stats_mfma4<MTV, NTW, NS, XKV, true, false, float, float>), grid,      \
-                       dim3(256 * NS), ldsf, stream, (const double*)h->obs.p, mk, starts_dev, n, \
-                       Lm, D, K, Fp, F, (const int*)h->fab.p, (const float*)h->la.p, rpc, flags, \
-                       Lq, off, partv, Kp, mt_limit, (const float*)h->lb.p, hxv, gxv, zfv, (double*)nullptr); \
-  } while (0)
-#define ST3FX(NTW, NS) do { if (xk <= 1) ST3F(5, NTW, NS, 1); else if (xk <= 3) ST3F(5, NTW, NS, 3); else if (xk <= 5) ST3F(5, NTW, NS, 5); else ST3F(5, NTW, NS, 9); } while (0)
-#define ST3FS(MTV, NTW, NS) do { if (xk <= 1) ST3F(MTV, NTW, NS, 1); else ST3F(MTV, NTW, NS, 3); } while (0)
-#define ST3FM(NTW, NS) do { if (MTs == 1) ST3FS(1, NTW, NS); else if (MTs == 2) ST3FS(2, NTW, NS); else if (MTs == 4) ST3FS(4, NTW, NS); else ST3FX(NTW, NS); } while (0)
-        // (the barrier-free three-buffer variant measured slower here: 0.85 against 0.83 ms -- the fp32
-        //  stage is half as long, the counter wait bites; this mode keeps the stage barrier)
-        if (NTt == 4) ST3FM(2, 2); else if (NTt == 3) ST3FM(3, 1); else if (NTt == 2) ST3FM(2, 1); else ST3FM(1, 1);
-#undef ST3FM
-#undef ST3FS
-#undef ST3FX
-#undef ST3F
-      } else {
-        const int MTs = stats_mt(h);
-        dim3 grid((unsigned)nchunk, (mt_limit + 4 * MTs - 1) / (4 * MTs), big ? Kp / 64 : 1);
-        // four state tiles, five feature tiles per wave, scaled sweeps (the K = 64 epoch shapes): the
-        // barrier-free stage loop with three LDS buffers, where they fit (D <= 55)
-        const size_t lds3 = ((size_t)(D + 3 + KpW) * (3 * ST_CS + 2) + 3 * (size_t)ST_RB * (KpW + 1)) * 8 +
-                            4 * ST_RB * sizeof(StRow4) + 16;
-        const bool tb = NTt == 4 && MTs == 5 && lds3 <= 160 * 1024 && h->variant[12] != 1;
-        if (tb) {
-#define ST3TL(XKV, LN)                                                                                         \
-  do {                                                                                                         \
-    hipFuncSetAttribute((const void*)k_stats_mfma4<5, 2, 2, XKV, LN, false, double, double, 3>,                \
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);                                \
-    hipLaunchKernelGGL((k_stats_mfma4<5, 2, 2, XKV, LN, false, double, double, 3>), grid, dim3(512), lds3,     \
-                       stream, (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, Fp, F,                    \
-                       (const int*)h->fab.p, qv, rpc, flags, Lq, off, partv, Kp, mt_limit, bhv, hxv, gxv, zfv, qoutv); \
-  } while (0)
-#define ST3T(XKV) do { if (lin) ST3TL(XKV, true); else ST3TL(XKV, false); } while (0)
-          if (xk <= 1) ST3T(1); else if (xk <= 3) ST3T(3); else if (xk <= 5) ST3T(5); else ST3T(9);
-#undef ST3T
-#undef ST3TL
-        } else {
-#define ST3L(MTV, NTW, NS, XKV, LN)                                                               \
-  do {                                                                                           \
-    if (lds > 64 * 1024)                                                                         \
-      hipFuncSetAttribute((const void*)k_stats_mfma4<MTV, NTW, NS, XKV, LN>,                     \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
-    hipLaunchKernelGGL((k_stats_mfma4<MTV, NTW, NS, XKV, LN>), grid, dim3(256 * NS), lds, stream, \
-                       (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, Fp,                  \
-                       F, (const int*)h->fab.p, qv, rpc, flags, Lq, off,                          \
-                       partv, Kp, mt_limit, bhv, hxv, gxv, zfv, qoutv);                           \
-  } while (0)
-#define ST3(MTV, NTW, NS, XKV) do { if (lin) ST3L(MTV, NTW, NS, XKV, true); else ST3L(MTV, NTW, NS, XKV, false); } while (0)
-#define ST3X(NTW, NS) do { if (xk <= 1) ST3(5, NTW, NS, 1); else if (xk <= 3) ST3(5, NTW, NS, 3); else if (xk <= 5) ST3(5, NTW, NS, 5); else ST3(5, NTW, NS, 9); } while (0)
-#define ST3S(MTV, NTW, NS) do { if (xk <= 1) ST3(MTV, NTW, NS, 1); else ST3(MTV, NTW, NS, 3); } while (0)
-#define ST3M(NTW, NS) do { if (MTs == 1) ST3S(1, NTW, NS); else if (MTs == 2) ST3S(2, NTW, NS); else if (MTs == 4) ST3S(4, NTW, NS); else ST3X(NTW, NS); } while (0)
-        if (NTt == 4) ST3M(2, 2); else if (NTt == 3) ST3M(3, 1); else if (NTt == 2) ST3M(2, 1); else ST3M(1, 1);
-#undef ST3M
-#undef ST3S
-#undef ST3X
-#undef ST3
-#undef ST3L
-        }
-        if (big) {
-          // transition tiles: one (64 MTt) x 64 (previous state, state) block per workgroup; two
-          // m-tiles per wave where the state count allows (round 3: 4 MFMAs on 4 LDS reads per
-          // k-step instead of 2 on 4; variant[14] = 1: one)
-          const int MTt = (Kp % 128 == 0 && h->variant[14] != 1) ? 2 : 1;
-          dim3 g2((unsigned)nchunk, Kp / (64 * MTt), Kp / 64);
-          const size_t ldt = ((size_t)(2 + 64 * MTt) * ST_CC + 2 * (size_t)ST_RB * 65) * 8 + 4 * ST_RB * sizeof(StRow4);
-          const size_t ldt3 = ((size_t)(2 + 64 * MTt) * (3 * ST_CS + 2) + 3 * (size_t)ST_RB * 65) * 8 +
-                              4 * ST_RB * sizeof(StRow4) + 16;
-#define STT(MTV, LN)                                                                              \
-  do {                                                                                           \
-    hipFuncSetAttribute((const void*)k_stats_mfma4<MTV, 2, 2, 1, LN, true>,                      \
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldt);                   \
-    hipLaunchKernelGGL((k_stats_mfma4<MTV, 2, 2, 1, LN, true>), g2, dim3(512), ldt, stream,      \
-                       (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, Fp,                  \
-                       F, (const int*)h->fab.p, qv, rpc, flags, Lq, off,                          \
-                       partv, Kp, mt_limit, bhv, hxv, gxv, zfv, qoutv);                           \
-  } while (0)
-#define STT3(MTV, LN)                                                                             \
-  do {                                                                                           \
-    hipFuncSetAttribute((const void*)k_stats_mfma4<MTV, 2, 2, 1, LN, true, double, double, 3>,   \
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldt3);                  \
-    hipLaunchKernelGGL((k_stats_mfma4<MTV, 2, 2, 1, LN, true, double, double, 3>), g2, dim3(512), ldt3, stream, \
-                       (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, Fp,                  \
-                       F, (const int*)h->fab.p, qv, rpc, flags, Lq, off,                          \
-                       partv, Kp, mt_limit, bhv, hxv, gxv, zfv, qoutv);                           \
-  } while (0)
-          // (no obs columns in these tiles: XK = 1 always, the three-buffer loop always fits)
-          if (lin) qv = qoutv;      // written by the feature launch above
-          if (h->variant[12] != 1) { if (MTt == 2) STT3(2, false); else STT3(1, false); }
-          else { if (MTt == 2) STT(2, false); else STT(1, false); }
-          if (lin && off == 0 && Lm == Lq && b0 == 0 && nb == h->curB) h->q_valid = true;
-#undef STT3
-#undef STT
-        }
-      }
-    }
-    if (var == 2) {
-      const int ntile = Kp / 16;
-      const int NT = (ntile % 4 == 0) ? 4 : (ntile % 2 == 0) ? 2 : 1;
-      const int MT = 3;
-      const int DS = (D + 2) | 1;
-      const size_t lds = ((size_t)ST_RB * DS + (size_t)ST_RB * (16 * NT + 1) + (size_t)ST_RB * (Kp + 1)) * 8;
-      if (lds > 150 * 1024) var = 1;
-      else {
-        const int mtiles = Ftot / 16;
-        dim3 grid((unsigned)nchunk, (mtiles + 4 * MT - 1) / (4 * MT), ntile / NT);
-#define ST_LAUNCH(NTV)                                                                        \
-  do {                                                                                        \
-    if (lds > 64 * 1024)                                                                      \
-      hipFuncSetAttribute((const void*)k_stats_mfma<3, NTV>,                                  \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
-    hipLaunchKernelGGL((k_stats_mfma<3, NTV>), grid, dim3(256), lds, stream,                  \
-                       (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K,                  \
-                       Kp, Fp, F, (const int*)h->fab.p, qv, rpc, flags,                       \
-                       Lq, off, partv, 0);                                                    \
-  } while (0)
-        if (NT == 4) ST_LAUNCH(4); else if (NT == 2) ST_LAUNCH(2); else ST_LAUNCH(1);
-#undef ST_LAUNCH
-      }
-    }
-    if (var == 1) {
-      dim3 grid((unsigned)nchunk, Ftot / 16, (Kp + 63) / 64);
-      hipLaunchKernelGGL(k_stats_outer, grid, dim3(64), 0, stream, (const double*)h->obs.p, mk,
-                         starts_dev, n, Lm, D, K, Kp, Fp, F,
-                         (const int*)h->fab.p, qv, rpc, flags, Lq, off, partv);
-    }
-    HIPCK(hipGetLastError());
-  }
-  return 0;
-}
-static int launch_stats_finalize(svihmm_ctx* h, int64_t nchunk, hipStream_t stream) {
-  const int D = h->D, K = h->K, Kp = h->Kp, Fp = h->Fp, F = h->F;
-  ProfScope ps(h, KS_FINALIZE, stream);
-  const int64_t tot = (int64_t)(Fp + Kp) * Kp;
-  const int lbB = h->lb_pending;     // deferred ELBO total of the scaled sweeps rides along
-  h->lb_pending = 0;
-  hipLaunchKernelGGL(k_finalize, dim3((unsigned)((tot + 255) / 256) + (lbB ? 1 : 0)), dim3(256), 0, stream,
-                     (const double*)h->part.p, (int)nchunk, D, K, Kp, Fp, F,
-                     (const int*)h->fab.p, (double*)h->packed.p,
-                     (const double*)(lbB ? h->local_lb.p : nullptr), lbB, h->emis_diag ? 1 : 0);
-  HIPCK(hipGetLastError());
-  return 0;
-}
-static int ensure_stats(svihmm_ctx* h, int64_t nchunk_total) {
-  CK(ensure_feature_table(h));
-  CK(ensure(h->part, (size_t)nchunk_total * (h->Fp + h->Kp) * h->Kp * sizeof(double)));
-  CK(ensure(h->packed, (size_t)packed_len(h) * sizeof(double)));
-  return 0;
-}
-// Categorical statistics: transition block on the pipelined GEMM (transition-only mode),
-// symbol counts by k_stats_cat, both reduced by k_finalize_cat into [A_raw | counts | lb]
-static int launch_stats_cat(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags) {
-  const int K = h->K, Kp = h->Kp, V = h->V, D = h->D;
-  if (K > 256) return fail("Categorical statistics: K > 256 unsupported");
-  const int KpT = (K + 63) / 64 * 64;
-  const int64_t n = (int64_t)B * Lm;
-  hipStream_t stream = h->stream;
-  CK(ensure_q(h, h->curB, Lq, stream));
-  const StatsPlan plan = stats_plan(h, n);
-  const int64_t rpcc = (n + 1023) / 1024 > 64 ? (n + 1023) / 1024 : 64;
-  const int nchunkc = (int)((n + rpcc - 1) / rpcc);
-  CK(ensure(h->part, (size_t)plan.nchunk * KpT * KpT * sizeof(double)));
-  CK(ensure(h->partc, (size_t)nchunkc * V * Kp * sizeof(double)));
-  CK(ensure(h->packed, packed_len(h) * sizeof(double)));
-  const uint8_t* mk = h->have_mask ? (const uint8_t*)h->mask.p : nullptr;
-  {
-    ProfScope ps(h, KS_STATS, stream);
-    const size_t lds = ((size_t)(D + 3 + 64) * ST_CC + 2 * (size_t)ST_RB * 65) * 8 + 4 * ST_RB * sizeof(StRow4);
-    hipFuncSetAttribute((const void*)k_stats_mfma4<1, 2, 2, 1, false, true>,
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    dim3 g2((unsigned)plan.nchunk, KpT / 64, KpT / 64);
-    hipLaunchKernelGGL((k_stats_mfma4<1, 2, 2, 1, false, true>), g2, dim3(512), lds, stream,
-                       (const double*)h->obs.p, mk, (const int64_t*)h->starts.p, n, Lm, D, K, 0, 0,
-                       (const int*)nullptr, (const double*)h->q.p, plan.rpc, flags, Lq, off,
-                       (double*)h->part.p, KpT, 0, (const double*)nullptr, (const double*)nullptr,
-                       (const double*)nullptr, (const double2*)nullptr, (double*)nullptr);
-    const size_t ldsc = (size_t)V * Kp * sizeof(double);
-    if (ldsc > 150 * 1024) return fail("Categorical statistics: V * K too large for the LDS table");
-    if (ldsc > 64 * 1024)
-      hipFuncSetAttribute((const void*)k_stats_cat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc);
-    hipLaunchKernelGGL(k_stats_cat, dim3((unsigned)nchunkc), dim3(64), ldsc, stream, (const double*)h->obs.p, mk,
-                       (const int64_t*)h->starts.p, n, Lm, K, Kp, V, (const double*)h->q.p, rpcc, Lq, off,
-                       (double*)h->partc.p);
-    HIPCK(hipGetLastError());
-  }
-  {
-    ProfScope ps(h, KS_FINALIZE, stream);
-    const int64_t tot = (int64_t)K * K + (int64_t)K * V;
-    hipLaunchKernelGGL(k_finalize_cat, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream,
-                       (const double*)h->part.p, (int)plan.nchunk, KpT, (const double*)h->partc.p, nchunkc,
-                       K, Kp, V, (double*)h->packed.p);
-    HIPCK(hipGetLastError());
-  }
-  return flush_lb(h, stream);
-}
 
-static int launch_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags) {
-  if (h->emis_cat) return launch_stats_cat(h, B, Lq, off, Lm, flags);
-  const StatsPlan plan = stats_plan(h, (int64_t)B * Lm, h->variant[8]);
-  CK(ensure_stats(h, plan.nchunk));
-  CK(launch_stats_range(h, 0, B, Lq, off, Lm, flags, plan, 0, h->stream));
-  return launch_stats_finalize(h, plan.nchunk, h->stream);
-}
-
-static int d2h(svihmm_ctx* h, void* dst, const void* src, size_t bytes) {
+int d2h(svihmm_ctx* h, void* dst, const void* src, size_t bytes) {
   ProfScope ps(h, KS_D2H);
   HIPCK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
   return 0;
@@ -2060,25 +812,10 @@ int64_t svihmm_packed_size(int32_t K, int32_t D) {
   return (int64_t)K * K + (int64_t)K * D + K + (int64_t)K * D * D + 1;
 }
 
-static int launch_scale_ll(svihmm_ctx* h, int B, int Lm) {
-  const int64_t n = (int64_t)B * Lm;
-  const int K = h->K;
-  CK(ensure(h->llE, (size_t)n * K * sizeof(double)));
-  CK(ensure(h->kexp, (size_t)n * sizeof(double)));
-  ProfScope ps(h, KS_EMISSION);
-  dim3 grid((unsigned)((n + 15) / 16));
-#define SC(KT) hipLaunchKernelGGL(k_scale_ll<KT>, grid, dim3(256), 0, h->stream, (const double*)h->ll.p, \
-                                  n, K, (double*)h->llE.p, (double*)h->kexp.p)
-  if (K <= 16) SC(1); else if (K <= 32) SC(2); else if (K <= 48) SC(3); else if (K <= 64) SC(4);
-  else if (K <= 128) SC(8); else if (K <= 192) SC(12); else SC(16);
-#undef SC
-  HIPCK(hipGetLastError());
-  return 0;
-}
 
 // lin: the batch goes through the scaled linear-domain sweeps (pick_fb == 3)
-static int prepare_ll(svihmm_ctx* h, const int64_t* starts, int B, int Lm, uint32_t flags,
-                      bool need_obs_for_stats, bool lin = false) {
+int prepare_ll(svihmm_ctx* h, const int64_t* starts, int B, int Lm, uint32_t flags,
+                      bool need_obs_for_stats, bool lin) {
   if (!h->have_globals) return fail("no globals: call svihmm_set_globals");
   const bool host_ll = flags & SVIHMM_USE_HOST_LLIKS;
   CK(check_windows(h, starts, B, Lm, !host_ll || need_obs_for_stats));
@@ -2111,71 +848,6 @@ static int prepare_ll(svihmm_ctx* h, const int64_t* starts, int B, int Lm, uint3
   return 0;
 }
 
-// Log-domain lliks / lalpha / lbeta of windows [b0, b0+nb) of the last (scaled) sweep,
-// recomputed by the log-domain kernels into the m_* side buffers.
-static int materialise(svihmm_ctx* h, int b0, int nb) {
-  if (h->m_nb > 0 && b0 >= h->m_b0 && b0 + nb <= h->m_b0 + h->m_nb) return 0;
-  CK(wait_globals(h));
-  if (h->lin_stale)
-    return fail("log-domain intermediates of the last E-step are rebuilt on demand and the "
-                "observations / globals / emission parameters have changed since: read them "
-                "before the next parameter upload");
-  const int Lm = h->lastLm, K = h->K;
-  const size_t n = (size_t)nb * Lm * K * sizeof(double);
-  CK(ensure(h->m_la, n));
-  CK(ensure(h->m_lb, n));
-  const double* ll;
-  if (h->eh_in_llE) {   // the plain lliks are still in h->ll
-    ll = (const double*)h->ll.p + (size_t)b0 * Lm * K;
-  } else {
-    CK(ensure(h->m_ll, n));
-    CK(launch_emission(h, nb, Lm, h->last_flags, false, (const int64_t*)h->starts.p + b0,
-                       (double*)h->m_ll.p));
-    ll = (const double*)h->m_ll.p;
-  }
-  if (h->lastB == 1 && K <= 256 && h->chain_T == Lm && h->chain_kbef && use_chain(h, 1, Lm)) {
-    // the blocked scan's messages -> logs (k_chain_lalpha both ways), entries lost to underflow
-    // recomputed in the log domain row by row (k_lalpha_fix / k_lbeta_fix): no sequential pass
-    const size_t ne = (size_t)Lm * K;
-    CK(ensure(h->scratch, (2 * ne + 8) * sizeof(double)));
-    double* ta = (double*)h->scratch.p;
-    double* tb = ta + ne;
-    double* ktop = tb + ne;
-    const int64_t T = Lm;
-    ProfScope ps(h, KS_FB);
-    hipLaunchKernelGGL(k_ksum_all, dim3(1), dim3(256), 0, h->stream, (const double*)h->kexp.p, T, ktop);
-    hipLaunchKernelGGL(k_chain_lalpha, dim3(h->chain_C), dim3(256), 0, h->stream, (const double*)h->la.p,
-                       (const double*)h->hx.p, (const double*)h->kexp.p, h->chain_kbef, h->chain_L,
-                       h->chain_C, T, K, ta, (const double*)nullptr);
-    hipLaunchKernelGGL(k_chain_lalpha, dim3(h->chain_C), dim3(256), 0, h->stream, (const double*)h->lb.p,
-                       (const double*)h->gx.p, (const double*)h->kexp.p, h->chain_kbef, h->chain_L,
-                       h->chain_C, T, K, tb, (const double*)ktop);
-    const unsigned nblk = (unsigned)((T + 63) / 64);
-#define LFIX(KM)                                                                                                  \
-  do {                                                                                                            \
-    hipLaunchKernelGGL(k_lalpha_fix<KM>, dim3(nblk), dim3(256), 0, h->stream, (const double*)ta,                  \
-                       (const double*)h->la.p, ll, (const double*)h->ltran.p, (const double*)h->mod_init.p, T, K, \
-                       (double*)h->m_la.p);                                                                       \
-    hipLaunchKernelGGL(k_lbeta_fix<KM>, dim3(nblk), dim3(256), 0, h->stream, (const double*)tb,                   \
-                       (const double*)h->lb.p, ll, (const double*)h->ltran.p, T, K, (double*)h->m_lb.p);          \
-  } while (0)
-    if (K <= 16) LFIX(16); else if (K <= 32) LFIX(32); else if (K <= 64) LFIX(64);
-    else {
-      hipLaunchKernelGGL(k_lalpha_fix_wide, dim3(nblk), dim3(256), 0, h->stream, (const double*)ta,
-                         (const double*)h->la.p, ll, (const double*)h->ltran.p, (const double*)h->mod_init.p, T, K,
-                         (double*)h->m_la.p);
-      hipLaunchKernelGGL(k_lbeta_fix_wide, dim3(nblk), dim3(256), (size_t)4 * K * sizeof(double), h->stream,
-                         (const double*)tb, (const double*)h->lb.p, ll, (const double*)h->ltran.p, T, K,
-                         (double*)h->m_lb.p);
-    }
-#undef LFIX
-    HIPCK(hipGetLastError());
-  } else {
-    CK(launch_fb(h, nb, Lm, 0, 2, ll, (double*)h->m_la.p, (double*)h->m_lb.p));
-  }
-  h->m_b0 = b0; h->m_nb = nb;
-  return 0;
-}
 // device pointer of row `row0` of intermediate `what` (0 lliks, 1 lalpha, 2 lbeta, 3 var_x)
 static int intermediate_ptr(svihmm_ctx* h, int what, int64_t row0, int64_t nrows, const double** out) {
   const int K = h->K, Lm = h->lastLm;
@@ -2838,130 +1510,6 @@ int svihmm_state_argmax(svihmm_ctx* h, const int32_t* true_sts, int32_t* out_z,
   return 0;
 }
 
-// backward sampling from the device-resident lalpha[T,K] (hmm_fast.pyx:97-122): blocked
-// composition of the per-row draw maps (K <= 64, T >= 1024), else the sequential single-wave
-// sampler.  *dz_out: device int64[T] (in h->scratch), valid until the next call.
-static int ffbs_draw(svihmm_ctx* h, const double* la, int64_t T, int K, const double* logA,
-                     const double* uniforms, int64_t** dz_out) {
-  const bool blocked = K <= 256 && T >= 1024 && h->variant[6] != 1;
-  const int KS = K <= 16 ? 16 : K <= 32 ? 32 : K <= 64 ? 64 : 256;      // path entries per row
-  const int Ls = T >= 65536 ? 512 : 256;
-  const int Cs = (int)((T + Ls - 1) / Ls);
-  const size_t base = ((size_t)K * K + (size_t)T) * sizeof(double) + (size_t)T * sizeof(int64_t);
-  const size_t extra = blocked ? (size_t)T * KS + 2 * (size_t)Cs * KS + (size_t)Cs + 64 : 0;
-  CK(ensure(h->scratch, base + extra));
-  double* dlogA = (double*)h->scratch.p;
-  double* dun = dlogA + (size_t)K * K;
-  int64_t* dz = (int64_t*)(dun + T);
-  *dz_out = dz;
-  unsigned char* path = (unsigned char*)(dz + T);
-  unsigned char* mA = path + (size_t)T * KS;
-  unsigned char* mB = mA + (size_t)Cs * KS;
-  unsigned char* entry = mB + (size_t)Cs * KS;
-  HIPCK(hipMemcpyAsync(dlogA, logA, (size_t)K * K * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIPCK(hipMemcpyAsync(dun, uniforms, (size_t)T * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  {
-    ProfScope ps(h, KS_FFBS);
-    if (blocked) {
-#define FPATH(KM)                                                                                          \
-  hipLaunchKernelGGL(k_ffbs_paths<KM>, dim3(Cs), dim3(64), ((size_t)K * (KM + 1) + 2 * KM) * sizeof(double), \
-                     h->stream, la, (const double*)dlogA, (const double*)dun, T, K, Ls, path)
-      if (KS == 16) FPATH(16); else if (KS == 32) FPATH(32); else if (KS == 64) FPATH(64);
-      else
-        hipLaunchKernelGGL(k_ffbs_paths_wide, dim3(Cs), dim3(256), 0, h->stream, la, (const double*)dlogA,
-                           (const double*)dun, T, K, Ls, path);
-#undef FPATH
-      hipLaunchKernelGGL(k_ffbs_compose, dim3(1), dim3(1024), 0, h->stream, (const unsigned char*)path, T, KS,
-                         Ls, Cs, mA, mB, entry);
-      hipLaunchKernelGGL(k_ffbs_gather, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, h->stream,
-                         (const unsigned char*)path, (const unsigned char*)entry, T, KS, Ls, dz);
-    } else {
-      hipLaunchKernelGGL(k_ffbs_sample, dim3(1), dim3(64), K > 64 ? (size_t)K * 8 : 0, h->stream,
-                         la, (const double*)dlogA, (const double*)dun, T, K, dz);
-    }
-    HIPCK(hipGetLastError());
-  }
-  return 0;
-}
-
-int svihmm_ffbs(svihmm_ctx* h, const double* logA, const double* uniforms, uint32_t flags,
-                int64_t* out_z, double* out_lalpha) {
-  if (!h || !logA || !uniforms || !out_z) return fail("svihmm_ffbs: bad arguments");
-  CK(set_device(h));
-  const int64_t T = h->T;
-  if (T <= 0) return fail("svihmm_ffbs: no observations");
-  if (T > 2147483647LL) return fail("svihmm_ffbs: T too large");
-  int64_t st0 = 0;
-  const int K = h->K;
-  if (!h->have_globals) return fail("no globals: call svihmm_set_globals");
-  CK(wait_globals(h));
-  // forward filter: long chains through the exact blocked scan (scaled sweeps), then lalpha
-  // from (ah, h, K); short ones with the per-window log-domain kernel
-  const double* la = nullptr;
-  if (K <= 256 && use_chain(h, 1, (int)T)) {
-    CK(prepare_ll(h, &st0, 1, (int)T, flags, false, true));
-    CK(launch_fb_chain(h, (int)T, false));
-    CK(ensure(h->m_la, (size_t)T * K * sizeof(double)));
-    h->m_nb = 0;
-    ProfScope ps(h, KS_FB);
-    hipLaunchKernelGGL(k_chain_lalpha, dim3(h->chain_C), dim3(256), 0, h->stream, (const double*)h->la.p,
-                       (const double*)h->hx.p, (const double*)h->kexp.p, h->chain_kbef, h->chain_L,
-                       h->chain_C, T, K, (double*)h->m_la.p);
-    HIPCK(hipGetLastError());
-    la = (const double*)h->m_la.p;
-    if (out_lalpha) {
-      // the caller wants lalpha itself: entries the scaled messages lost to underflow are
-      // recomputed in the log domain (plain lliks into m_ll, corrected copy into m_lb)
-      CK(ensure(h->m_lb, (size_t)T * K * sizeof(double)));
-      const double* llp = (const double*)h->ll.p;     // host-supplied / two-pass lliks are still there
-      if (!h->eh_in_llE) {
-        CK(ensure(h->m_ll, (size_t)T * K * sizeof(double)));
-        CK(launch_emission(h, 1, (int)T, flags, false, nullptr, (double*)h->m_ll.p));
-        llp = (const double*)h->m_ll.p;
-      }
-      const unsigned nblk = (unsigned)((T + 63) / 64);
-#define LFIX(KM) hipLaunchKernelGGL(k_lalpha_fix<KM>, dim3(nblk), dim3(256), 0, h->stream, la, (const double*)h->la.p, \
-                                    llp, (const double*)h->ltran.p,                                              \
-                                    (const double*)h->mod_init.p, T, K, (double*)h->m_lb.p)
-      if (K <= 16) LFIX(16); else if (K <= 32) LFIX(32); else if (K <= 64) LFIX(64);
-      else
-        hipLaunchKernelGGL(k_lalpha_fix_wide, dim3(nblk), dim3(256), 0, h->stream, la, (const double*)h->la.p, llp,
-                           (const double*)h->ltran.p, (const double*)h->mod_init.p, T, K, (double*)h->m_lb.p);
-#undef LFIX
-      HIPCK(hipGetLastError());
-      la = (const double*)h->m_lb.p;
-    }
-  } else {
-    CK(prepare_ll(h, &st0, 1, (int)T, flags, false));
-    CK(launch_fb(h, 1, (int)T, 0, 1));
-    la = (const double*)h->la.p;
-  }
-  int64_t* dz = nullptr;
-  CK(ffbs_draw(h, la, T, K, logA, uniforms, &dz));
-  CK(d2h(h, out_z, dz, (size_t)T * sizeof(int64_t)));
-  if (out_lalpha) CK(d2h(h, out_lalpha, la, (size_t)T * K * sizeof(double)));
-  HIPCK(hipStreamSynchronize(h->stream));
-  h->lastB = 1; h->lastLm = (int)T;
-  return 0;
-}
-
-// hmm_fast.pyx:80-95: with lalpha_init supplied the reference skips the filter and only samples
-int svihmm_ffbs_sample(svihmm_ctx* h, int64_t T, int32_t K, const double* lalpha, const double* logA,
-                       const double* uniforms, int64_t* out_z) {
-  if (!h || !lalpha || !logA || !uniforms || !out_z || T <= 0 || K <= 0)
-    return fail("svihmm_ffbs_sample: bad arguments");
-  if (T > 2147483647LL) return fail("svihmm_ffbs_sample: T too large");
-  CK(set_device(h));
-  const size_t n = (size_t)T * K * sizeof(double);
-  CK(ensure(h->m_la, n));
-  h->m_nb = 0;
-  HIPCK(hipMemcpyAsync(h->m_la.p, lalpha, n, hipMemcpyHostToDevice, h->stream));
-  int64_t* dz = nullptr;
-  CK(ffbs_draw(h, (const double*)h->m_la.p, T, K, logA, uniforms, &dz));
-  CK(d2h(h, out_z, dz, (size_t)T * sizeof(int64_t)));
-  HIPCK(hipStreamSynchronize(h->stream));
-  return 0;
-}
 
 // ---- synthetic sequences generated in HBM (gen_synthetic.py:27-44) --------------------------
 int svihmm_generate(svihmm_ctx* h, int64_t T, int32_t K, int32_t D, const double* cdf,
@@ -3011,7 +1559,7 @@ int svihmm_generate(svihmm_ctx* h, int64_t T, int32_t K, int32_t D, const double
   h->center_pending = false;
   {   // centre: the plain average of the state means (a point inside the data)
     std::vector<double> c((size_t)D, 0.0);
-    if (h->variant[9] != 1) {
+    if (h->variant[9] != 1 && !(h->have_emission && h->emis_cat)) {
       for (int k = 0; k < K; ++k)
         for (int d = 0; d < D; ++d) c[d] += means[(size_t)k * D + d] / K;
       for (int d = 0; d < D; ++d) if (!(c[d] > -1.7e308 && c[d] < 1.7e308)) c[d] = 0.0;
@@ -3157,3 +1705,4 @@ int svihmm_selftest_mfma(svihmm_ctx* h, const double* A16x4, const double* B4x16
 }
 
 }  // extern "C"
+

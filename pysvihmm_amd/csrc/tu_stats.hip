@@ -1,0 +1,310 @@
+// tu_stats.hip -- statistics GEMMs, finalize: kernels and launchers
+// One of the translation units of libsvihmm_hip.so (see host.h).
+#include "host.h"
+#include "device_helpers.h"
+#include "kernels_stats.h"
+
+extern "C" {
+
+// m-tiles (16 features) per wave of the pipelined statistics GEMM: 5 is the instance tuned for
+// the bench shape (40 tiles = 2 workgroups of 4 x 5); narrow models have far fewer tiles (K = 16,
+// D = 8: 4; K = 64, D = 8: 7) and would run 5-tile waves mostly on padding, so they take 1 / 2 / 4.
+// The small instances exist for the staging widths narrow observations need (xk <= 3) only.
+static int stats_mt(const svihmm_ctx* h) {
+  const int Kp = h->Kp, Fp = h->Fp, D = h->D;
+  if (Kp > 64 || h->variant[10] == 1) return 5;
+  const int NSPLIT = (Kp / 16 == 4) ? 2 : 1;
+  const int xk = (D + 1 + 8 * NSPLIT - 1) / (8 * NSPLIT);
+  const int mt = (Fp + Kp) / 16;
+  if (xk > 3) return 5;
+  if (mt <= 16) return mt <= 4 ? 1 : mt <= 8 ? 2 : 4;
+  return (mt + 15) / 16 * 16 < (mt + 19) / 20 * 20 ? 4 : 5;    // whichever pads less (K = 64, D = 24: 25 tiles)
+}
+// row chunking of the statistics GEMM.  One pipelined workgroup is resident per CU, so the launch
+// should be a whole number of rounds of 256 workgroups: chunks x feature groups (grid.y) = 256 r.
+// 128 chunks x 2 feature groups at the bench shape; more chunks only add partial-sum traffic
+// (64 windows: statistics + finalize 74 -> 56 us, tools/chunk_sweep.py).  chunk = multiple of ST_RB.
+StatsPlan stats_plan(const svihmm_ctx* h, int64_t n, int forced) {
+  int target_chunks = forced > 0 ? forced : 128;
+  if (forced <= 0 && h->Kp <= 64 && h->Fp > 0 && !h->emis_cat) {
+    const int gy = ((h->Fp + h->Kp) / 16 + 4 * stats_mt(h) - 1) / (4 * stats_mt(h));
+    const int r = std::max(1, (128 * gy + 128) / 256);     // rounds: round(128 gy / 256)
+    // one state tile (K <= 16): the 4-wave workgroups are small enough for two per CU, and the
+    // launch is latency- rather than MFMA-bound (K = 16, D = 32: 0.61 -> 0.46 ms); wider models: one
+    const int per_cu = (h->Kp == 16 && n >= (int64_t)1 << 18) ? 2 : 1;   // (small batches: more chunks only add partial sums)
+    target_chunks = std::max(1, 256 * r * per_cu / gy);
+  }
+  int64_t rpc = (n + target_chunks - 1) / target_chunks;
+  rpc = (rpc + ST_RB - 1) / ST_RB * ST_RB;
+  return {rpc, (n + rpc - 1) / rpc};
+}
+// partial statistics of windows [b0, b0+nb) (inner segment [off, off+Lm) of each window of
+// length Lq) into partial slots [chunk_base, chunk_base + plan.nchunk) on `stream`
+int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, int Lm, uint32_t flags,
+                              StatsPlan plan, int64_t chunk_base, hipStream_t stream) {
+  const int D = h->D, K = h->K, Kp = h->Kp, Fp = h->Fp, F = h->F;
+  const int Ftot = Fp + Kp;
+  const int64_t n = (int64_t)nb * Lm;
+  const int64_t rpc = plan.rpc, nchunk = plan.nchunk;
+  const uint8_t* mk = h->have_mask ? (const uint8_t*)h->mask.p : nullptr;
+  const int64_t* starts_dev = (const int64_t*)h->starts.p + b0;
+  int var = h->variant[1];
+  if (var == 0) var = 3;
+  if (var == 3) {   // feasibility of the pipelined kernel (same test as below)
+    const int KpW = Kp > 64 ? 64 : Kp;
+    const int TPR = 8 * ((KpW / 16 == 4) ? 2 : 1);
+    const size_t lds = ((size_t)(D + 3 + KpW) * ST_CC + 2 * (size_t)ST_RB * (KpW + 1)) * 8 + 4 * ST_RB * sizeof(StRow4);
+    if (lds > 150 * 1024 || (D + 1 + TPR - 1) / TPR > 9 || (Kp > 64 && Kp % 64 != 0)) var = 2;
+  }
+  // scaled sweeps: the pipelined kernel forms q = ah * bh * scale itself; the others read var_x
+  // (wide models too, round 3: the separate posterior pass costs more than the second operand's loads;
+  //  variant[15] = 1: K > 64 through q as before)
+  const bool lin = h->lin_mode && !h->q_valid && var == 3 && (Kp <= 64 || h->variant[15] != 1);
+  if (h->lin_mode && !lin) CK(ensure_q(h, h->curB, Lq, stream));
+  const size_t qo = (size_t)b0 * Lq * K;
+  const double* qv = (const double*)(lin ? h->la.p : h->q.p) + qo;   // (reassigned: see the transition blocks)
+  const double* bhv = lin ? (const double*)h->lb.p + qo : nullptr;
+  const double* hxv = lin ? (const double*)h->hx.p + (size_t)b0 * Lq : nullptr;
+  const double* gxv = lin ? (const double*)h->gx.p + (size_t)b0 * Lq : nullptr;
+  const double2* zfv = lin ? (const double2*)h->zfac.p + b0 : nullptr;
+  double* partv = (double*)h->part.p + (size_t)chunk_base * Ftot * Kp;
+  {
+    ProfScope ps(h, KS_STATS, stream);
+    if (var == 3) {
+      // pipelined VGPR-form GEMM.  K <= 64: all tiles (statistics + transition) in one launch.
+      // K > 64: state groups of 64 in grid.z for the emission-statistics tiles; the K x K
+      // transition tiles (which need q[t-1] of ALL states as operand rows) go to k_stats_mfma.
+      const bool big = Kp > 64;
+      // wide models, scaled sweeps: the feature launch leaves q = ah bh scale behind for the
+      // transition-block launch (whose little matrix work per staged row cannot carry two more
+      // operand streams: 3.3 against 2.4 ms on configs[4])
+      double* qoutv = nullptr;
+      if (big && lin) {
+        CK(ensure(h->q, (size_t)h->curB * Lq * K * sizeof(double)));
+        qoutv = (double*)h->q.p + qo;
+      }
+      const int NTt = big ? 4 : Kp / 16;                // n-tiles per workgroup
+      const int KpW = 16 * NTt;
+      const int NSPLIT = (NTt == 4) ? 2 : 1;
+      const int TPR = 8 * NSPLIT;
+      const size_t lds = ((size_t)(D + 3 + KpW) * ST_CC + 2 * (size_t)ST_RB * (KpW + 1)) * 8 + 4 * ST_RB * sizeof(StRow4);
+      const int mtiles = Ftot / 16;
+      const int mt_limit = big ? Fp / 16 : mtiles;
+      const int xk = (D + 1 + TPR - 1) / TPR;
+      if (lds > 150 * 1024 || xk > 9 || (big && Kp % 64 != 0)) var = 2;
+      else if (lin && h->cur_f32 && !big) {
+        // fp32 mode: float LDS tiles, v_mfma_f32_16x16x4_f32, ah / bh read as float
+        const size_t ldsf = ((size_t)(D + 3 + KpW) * ST_CC + 2 * (size_t)ST_RB * (KpW + 16)) * 4 + 8 +
+                            4 * ST_RB * sizeof(StRow4);
+        const int MTs = stats_mt(h);
+        dim3 grid((unsigned)nchunk, (mt_limit + 4 * MTs - 1) / (4 * MTs), 1);
+#define ST3F(MTV, NTW, NS, XKV)                                                                   \
+  do {                                                                                           \
+    if (ldsf > 64 * 1024)                                                                        \
+      hipFuncSetAttribute((const void*)k_stats_mfma4<MTV, NTW, NS, XKV, true, false, float, float>, \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);                \
+    hipLaunchKernelGGL((k_stats_mfma4<MTV, NTW, NS, XKV, true, false, float, float>), grid,      \
+                       dim3(256 * NS), ldsf, stream, (const double*)h->obs.p, mk, starts_dev, n, \
+                       Lm, D, K, Fp, F, (const int*)h->fab.p, (const float*)h->la.p, rpc, flags, \
+                       Lq, off, partv, Kp, mt_limit, (const float*)h->lb.p, hxv, gxv, zfv, (double*)nullptr); \
+  } while (0)
+#define ST3FX(NTW, NS) do { if (xk <= 1) ST3F(5, NTW, NS, 1); else if (xk <= 3) ST3F(5, NTW, NS, 3); else if (xk <= 5) ST3F(5, NTW, NS, 5); else ST3F(5, NTW, NS, 9); } while (0)
+#define ST3FS(MTV, NTW, NS) do { if (xk <= 1) ST3F(MTV, NTW, NS, 1); else ST3F(MTV, NTW, NS, 3); } while (0)
+#define ST3FM(NTW, NS) do { if (MTs == 1) ST3FS(1, NTW, NS); else if (MTs == 2) ST3FS(2, NTW, NS); else if (MTs == 4) ST3FS(4, NTW, NS); else ST3FX(NTW, NS); } while (0)
+        // (the barrier-free three-buffer variant measured slower here: 0.85 against 0.83 ms -- the fp32
+        //  stage is half as long, the counter wait bites; this mode keeps the stage barrier)
+        if (NTt == 4) ST3FM(2, 2); else if (NTt == 3) ST3FM(3, 1); else if (NTt == 2) ST3FM(2, 1); else ST3FM(1, 1);
+#undef ST3FM
+#undef ST3FS
+#undef ST3FX
+#undef ST3F
+      } else {
+        const int MTs = stats_mt(h);
+        dim3 grid((unsigned)nchunk, (mt_limit + 4 * MTs - 1) / (4 * MTs), big ? Kp / 64 : 1);
+        // four state tiles, five feature tiles per wave, scaled sweeps (the K = 64 epoch shapes): the
+        // barrier-free stage loop with three LDS buffers, where they fit (D <= 55)
+        const size_t lds3 = ((size_t)(D + 3 + KpW) * (3 * ST_CS + 2) + 3 * (size_t)ST_RB * (KpW + 1)) * 8 +
+                            4 * ST_RB * sizeof(StRow4) + 16;
+        const bool tb = NTt == 4 && MTs == 5 && lds3 <= 160 * 1024 && h->variant[12] != 1;
+        if (tb) {
+#define ST3TL(XKV, LN)                                                                                         \
+  do {                                                                                                         \
+    hipFuncSetAttribute((const void*)k_stats_mfma4<5, 2, 2, XKV, LN, false, double, double, 3>,                \
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);                                \
+    hipLaunchKernelGGL((k_stats_mfma4<5, 2, 2, XKV, LN, false, double, double, 3>), grid, dim3(512), lds3,     \
+                       stream, (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, Fp, F,                    \
+                       (const int*)h->fab.p, qv, rpc, flags, Lq, off, partv, Kp, mt_limit, bhv, hxv, gxv, zfv, qoutv); \
+  } while (0)
+#define ST3T(XKV) do { if (lin) ST3TL(XKV, true); else ST3TL(XKV, false); } while (0)
+          if (xk <= 1) ST3T(1); else if (xk <= 3) ST3T(3); else if (xk <= 5) ST3T(5); else ST3T(9);
+#undef ST3T
+#undef ST3TL
+        } else {
+#define ST3L(MTV, NTW, NS, XKV, LN)                                                               \
+  do {                                                                                           \
+    if (lds > 64 * 1024)                                                                         \
+      hipFuncSetAttribute((const void*)k_stats_mfma4<MTV, NTW, NS, XKV, LN>,                     \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
+    hipLaunchKernelGGL((k_stats_mfma4<MTV, NTW, NS, XKV, LN>), grid, dim3(256 * NS), lds, stream, \
+                       (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, Fp,                  \
+                       F, (const int*)h->fab.p, qv, rpc, flags, Lq, off,                          \
+                       partv, Kp, mt_limit, bhv, hxv, gxv, zfv, qoutv);                           \
+  } while (0)
+#define ST3(MTV, NTW, NS, XKV) do { if (lin) ST3L(MTV, NTW, NS, XKV, true); else ST3L(MTV, NTW, NS, XKV, false); } while (0)
+#define ST3X(NTW, NS) do { if (xk <= 1) ST3(5, NTW, NS, 1); else if (xk <= 3) ST3(5, NTW, NS, 3); else if (xk <= 5) ST3(5, NTW, NS, 5); else ST3(5, NTW, NS, 9); } while (0)
+#define ST3S(MTV, NTW, NS) do { if (xk <= 1) ST3(MTV, NTW, NS, 1); else ST3(MTV, NTW, NS, 3); } while (0)
+#define ST3M(NTW, NS) do { if (MTs == 1) ST3S(1, NTW, NS); else if (MTs == 2) ST3S(2, NTW, NS); else if (MTs == 4) ST3S(4, NTW, NS); else ST3X(NTW, NS); } while (0)
+        if (NTt == 4) ST3M(2, 2); else if (NTt == 3) ST3M(3, 1); else if (NTt == 2) ST3M(2, 1); else ST3M(1, 1);
+#undef ST3M
+#undef ST3S
+#undef ST3X
+#undef ST3
+#undef ST3L
+        }
+        if (big) {
+          // transition tiles: one (64 MTt) x 64 (previous state, state) block per workgroup; two
+          // m-tiles per wave where the state count allows (round 3: 4 MFMAs on 4 LDS reads per
+          // k-step instead of 2 on 4; variant[14] = 1: one)
+          const int MTt = (Kp % 128 == 0 && h->variant[14] != 1) ? 2 : 1;
+          dim3 g2((unsigned)nchunk, Kp / (64 * MTt), Kp / 64);
+          const size_t ldt = ((size_t)(2 + 64 * MTt) * ST_CC + 2 * (size_t)ST_RB * 65) * 8 + 4 * ST_RB * sizeof(StRow4);
+          const size_t ldt3 = ((size_t)(2 + 64 * MTt) * (3 * ST_CS + 2) + 3 * (size_t)ST_RB * 65) * 8 +
+                              4 * ST_RB * sizeof(StRow4) + 16;
+#define STT(MTV, LN)                                                                              \
+  do {                                                                                           \
+    hipFuncSetAttribute((const void*)k_stats_mfma4<MTV, 2, 2, 1, LN, true>,                      \
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldt);                   \
+    hipLaunchKernelGGL((k_stats_mfma4<MTV, 2, 2, 1, LN, true>), g2, dim3(512), ldt, stream,      \
+                       (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, Fp,                  \
+                       F, (const int*)h->fab.p, qv, rpc, flags, Lq, off,                          \
+                       partv, Kp, mt_limit, bhv, hxv, gxv, zfv, qoutv);                           \
+  } while (0)
+#define STT3(MTV, LN)                                                                             \
+  do {                                                                                           \
+    hipFuncSetAttribute((const void*)k_stats_mfma4<MTV, 2, 2, 1, LN, true, double, double, 3>,   \
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldt3);                  \
+    hipLaunchKernelGGL((k_stats_mfma4<MTV, 2, 2, 1, LN, true, double, double, 3>), g2, dim3(512), ldt3, stream, \
+                       (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, Fp,                  \
+                       F, (const int*)h->fab.p, qv, rpc, flags, Lq, off,                          \
+                       partv, Kp, mt_limit, bhv, hxv, gxv, zfv, qoutv);                           \
+  } while (0)
+          // (no obs columns in these tiles: XK = 1 always, the three-buffer loop always fits)
+          if (lin) qv = qoutv;      // written by the feature launch above
+          if (h->variant[12] != 1) { if (MTt == 2) STT3(2, false); else STT3(1, false); }
+          else { if (MTt == 2) STT(2, false); else STT(1, false); }
+          if (lin && off == 0 && Lm == Lq && b0 == 0 && nb == h->curB) h->q_valid = true;
+#undef STT3
+#undef STT
+        }
+      }
+    }
+    if (var == 2) {
+      const int ntile = Kp / 16;
+      const int NT = (ntile % 4 == 0) ? 4 : (ntile % 2 == 0) ? 2 : 1;
+      const int MT = 3;
+      const int DS = (D + 2) | 1;
+      const size_t lds = ((size_t)ST_RB * DS + (size_t)ST_RB * (16 * NT + 1) + (size_t)ST_RB * (Kp + 1)) * 8;
+      if (lds > 150 * 1024) var = 1;
+      else {
+        const int mtiles = Ftot / 16;
+        dim3 grid((unsigned)nchunk, (mtiles + 4 * MT - 1) / (4 * MT), ntile / NT);
+#define ST_LAUNCH(NTV)                                                                        \
+  do {                                                                                        \
+    if (lds > 64 * 1024)                                                                      \
+      hipFuncSetAttribute((const void*)k_stats_mfma<3, NTV>,                                  \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+    hipLaunchKernelGGL((k_stats_mfma<3, NTV>), grid, dim3(256), lds, stream,                  \
+                       (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K,                  \
+                       Kp, Fp, F, (const int*)h->fab.p, qv, rpc, flags,                       \
+                       Lq, off, partv, 0);                                                    \
+  } while (0)
+        if (NT == 4) ST_LAUNCH(4); else if (NT == 2) ST_LAUNCH(2); else ST_LAUNCH(1);
+#undef ST_LAUNCH
+      }
+    }
+    if (var == 1) {
+      dim3 grid((unsigned)nchunk, Ftot / 16, (Kp + 63) / 64);
+      hipLaunchKernelGGL(k_stats_outer, grid, dim3(64), 0, stream, (const double*)h->obs.p, mk,
+                         starts_dev, n, Lm, D, K, Kp, Fp, F,
+                         (const int*)h->fab.p, qv, rpc, flags, Lq, off, partv);
+    }
+    HIPCK(hipGetLastError());
+  }
+  return 0;
+}
+int launch_stats_finalize(svihmm_ctx* h, int64_t nchunk, hipStream_t stream) {
+  const int D = h->D, K = h->K, Kp = h->Kp, Fp = h->Fp, F = h->F;
+  ProfScope ps(h, KS_FINALIZE, stream);
+  const int64_t tot = (int64_t)(Fp + Kp) * Kp;
+  const int lbB = h->lb_pending;     // deferred ELBO total of the scaled sweeps rides along
+  h->lb_pending = 0;
+  hipLaunchKernelGGL(k_finalize, dim3((unsigned)((tot + 255) / 256) + (lbB ? 1 : 0)), dim3(256), 0, stream,
+                     (const double*)h->part.p, (int)nchunk, D, K, Kp, Fp, F,
+                     (const int*)h->fab.p, (double*)h->packed.p,
+                     (const double*)(lbB ? h->local_lb.p : nullptr), lbB, h->emis_diag ? 1 : 0);
+  HIPCK(hipGetLastError());
+  return 0;
+}
+int ensure_stats(svihmm_ctx* h, int64_t nchunk_total) {
+  CK(ensure_feature_table(h));
+  CK(ensure(h->part, (size_t)nchunk_total * (h->Fp + h->Kp) * h->Kp * sizeof(double)));
+  CK(ensure(h->packed, (size_t)packed_len(h) * sizeof(double)));
+  return 0;
+}
+// Categorical statistics: transition block on the pipelined GEMM (transition-only mode),
+// symbol counts by k_stats_cat, both reduced by k_finalize_cat into [A_raw | counts | lb]
+static int launch_stats_cat(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags) {
+  const int K = h->K, Kp = h->Kp, V = h->V, D = h->D;
+  if (K > 256) return fail("Categorical statistics: K > 256 unsupported");
+  CK(cat_uncentre(h));
+  const int KpT = (K + 63) / 64 * 64;
+  const int64_t n = (int64_t)B * Lm;
+  hipStream_t stream = h->stream;
+  CK(ensure_q(h, h->curB, Lq, stream));
+  const StatsPlan plan = stats_plan(h, n);
+  const int64_t rpcc = (n + 1023) / 1024 > 64 ? (n + 1023) / 1024 : 64;
+  const int nchunkc = (int)((n + rpcc - 1) / rpcc);
+  CK(ensure(h->part, (size_t)plan.nchunk * KpT * KpT * sizeof(double)));
+  CK(ensure(h->partc, (size_t)nchunkc * V * Kp * sizeof(double)));
+  CK(ensure(h->packed, packed_len(h) * sizeof(double)));
+  const uint8_t* mk = h->have_mask ? (const uint8_t*)h->mask.p : nullptr;
+  {
+    ProfScope ps(h, KS_STATS, stream);
+    const size_t lds = ((size_t)(D + 3 + 64) * ST_CC + 2 * (size_t)ST_RB * 65) * 8 + 4 * ST_RB * sizeof(StRow4);
+    hipFuncSetAttribute((const void*)k_stats_mfma4<1, 2, 2, 1, false, true>,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 g2((unsigned)plan.nchunk, KpT / 64, KpT / 64);
+    hipLaunchKernelGGL((k_stats_mfma4<1, 2, 2, 1, false, true>), g2, dim3(512), lds, stream,
+                       (const double*)h->obs.p, mk, (const int64_t*)h->starts.p, n, Lm, D, K, 0, 0,
+                       (const int*)nullptr, (const double*)h->q.p, plan.rpc, flags, Lq, off,
+                       (double*)h->part.p, KpT, 0, (const double*)nullptr, (const double*)nullptr,
+                       (const double*)nullptr, (const double2*)nullptr, (double*)nullptr);
+    const size_t ldsc = (size_t)V * Kp * sizeof(double);
+    if (ldsc > 150 * 1024) return fail("Categorical statistics: V * K too large for the LDS table");
+    if (ldsc > 64 * 1024)
+      hipFuncSetAttribute((const void*)k_stats_cat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc);
+    hipLaunchKernelGGL(k_stats_cat, dim3((unsigned)nchunkc), dim3(64), ldsc, stream, (const double*)h->obs.p, mk,
+                       (const int64_t*)h->starts.p, n, Lm, K, Kp, V, (const double*)h->q.p, rpcc, Lq, off,
+                       (double*)h->partc.p);
+    HIPCK(hipGetLastError());
+  }
+  {
+    ProfScope ps(h, KS_FINALIZE, stream);
+    const int64_t tot = (int64_t)K * K + (int64_t)K * V;
+    hipLaunchKernelGGL(k_finalize_cat, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream,
+                       (const double*)h->part.p, (int)plan.nchunk, KpT, (const double*)h->partc.p, nchunkc,
+                       K, Kp, V, (double*)h->packed.p);
+    HIPCK(hipGetLastError());
+  }
+  return flush_lb(h, stream);
+}
+
+int launch_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags) {
+  if (h->emis_cat) return launch_stats_cat(h, B, Lq, off, Lm, flags);
+  const StatsPlan plan = stats_plan(h, (int64_t)B * Lm, h->variant[8]);
+  CK(ensure_stats(h, plan.nchunk));
+  CK(launch_stats_range(h, 0, B, Lq, off, Lm, flags, plan, 0, h->stream));
+  return launch_stats_finalize(h, plan.nchunk, h->stream);
+}
+
+}  // extern "C"

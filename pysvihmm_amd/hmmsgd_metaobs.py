@@ -272,8 +272,9 @@ class VBHMM(VariationalHMMBase):
         if (L_ is None or adaptive) and growBuffer:
             raise RuntimeError("Cannot specify both adaptive and buffer simultaneously!")
 
-        # (the reference reads self.obs afresh in every call; the resident copy is uploaded again
-        #  unless the probe of hmmbase._obs_fingerprint finds it unchanged -- 256 MB at T = 1e6)
+        # (the reference reads self.obs afresh in every call: so does this one.  Opt-in
+        #  `self.assume_obs_unchanged = True` skips the upload while hmmbase._obs_fingerprint's
+        #  sampled probe finds the buffer unchanged -- 256 MB at T = 1e6)
         if not self._obs_unchanged():
             self._obs_dirty = True
         self._upload_obs()
@@ -423,6 +424,7 @@ class VBHMM(VariationalHMMBase):
         bA = (T - 2 * self.metaobs_half - 1) / (2. * self.metaobs_half * self.mb_sz)
         bE = (T - 2 * self.metaobs_half - 1) / ((2. * self.metaobs_half + 1.) * self.mb_sz)
         last = None
+        loop_globals_live = False
         own_unif = getattr(self.metaobs_fun, "__func__", None) is VBHMM.metaobs_unif
         for it in range(maxit):
             self.lrate = (it + self.tau) ** (-self.kappa)
@@ -463,6 +465,7 @@ class VBHMM(VariationalHMMBase):
             inner = (bufferL - L_, 2 * L_ + 1) if growBuffer else None
             eng.svi_iteration(it, starts, nwin, Lm, flags, self.lrate, bA, bE, inner=inner)
             host_fresh = False
+            loop_globals_live = True      # the handle's ltran / mod_init are this iteration's
             self.cur_mo = last_mo
             last = (len(starts), Lm)
             if self.verbose:
@@ -477,7 +480,13 @@ class VBHMM(VariationalHMMBase):
                 if not hasattr(self, 'pred_logprob_full_mean'):
                     self.pred_logprob_full_mean = np.inf * np.ones(maxit)
                     self.pred_logprob_full_std = np.inf * np.ones(maxit)
+                # the hook uploads psi-expectations of the UPDATED state to the handle; the
+                # reference's full_local_update keeps them in locals (:1157-1159), its object still
+                # holds the last local_update's (:502-504): take those off the handle first
+                if loop_globals_live and hasattr(eng, "read_globals"):
+                    self.mod_init, self.mod_tran = eng.read_globals()
                 tmp = self.pred_logprob_full()
+                loop_globals_live = False
                 self.pred_logprob_full_mean[it] = np.nanmean(tmp)
                 self.pred_logprob_full_std[it] = np.nanstd(tmp)
         if not host_fresh:
@@ -485,8 +494,11 @@ class VBHMM(VariationalHMMBase):
         e, ms = eng.svi_read_elbo(maxit)
         self.elbo_vec[:] = e
         self.iter_time[:] = ms * 1e-3
-        # the reference leaves the last computation's psi-expectations on the object (:502-504)
-        if hasattr(eng, "read_globals"):
+        # the reference leaves the last local_update's psi-expectations on the object (:502-504).
+        # (A validation hook after the last iteration has overwritten the handle's copy: they were
+        #  read before it ran.  The loop always runs to maxit, so no globals kernel of a further
+        #  iteration has been pre-launched into the handle's buffers at this point.)
+        if loop_globals_live and hasattr(eng, "read_globals"):
             self.mod_init, self.mod_tran = eng.read_globals()
         if "_pending_rows" not in self.__dict__ and "_val_done" not in self.__dict__:
             self._register_last_window(eng, last)

@@ -268,3 +268,49 @@ def test_categorical_table_after_niw_factors_on_a_symbol_column():
         np.testing.assert_allclose(a.buf, b.buf, rtol=1e-9, atol=1e-9)
     finally:
         e.close()
+
+
+def test_categorical_table_set_before_the_observations():
+    """ABI order  set_emission_cat -> set_obs(new symbol column) -> estep  (valid since ABI v1; the
+    classes never use it: _push_emission follows _upload_obs).  Round-3 advisor finding: every upload
+    centred the resident copy, the lookup / count kernels then truncated x - c with (int)x and the
+    lliks / counts were silently wrong.  Under an active table the column stays exactly as uploaded;
+    an explicit svihmm_shift_obs afterwards is undone (with rounding) in front of the next launch.
+    Block upload and the loglik entry point included."""
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    from oracle.engine import OracleEngine
+    K, V, T = 3, 7, 900
+    rng = np.random.default_rng(13)
+    mod_init = np.log(np.full(K, 1.0 / K))
+    ltran = np.log(0.8 * np.eye(K) + 0.2 / K)
+    logp = np.log(rng.dirichlet(np.ones(V), size=K))
+    starts = np.arange(20, dtype=np.int64) * 40
+    e, o = HipEngine(0), OracleEngine()
+    try:
+        for eng in (e, o):
+            eng.set_obs(rng.integers(0, V, size=(T, 1)).astype(np.float64), None)   # some earlier column
+            eng.set_globals(mod_init, ltran)
+            eng.set_emission_cat(logp)
+        sym = rng.integers(2, V, size=T).astype(np.float64)[:, None]                # mean well away from 0
+        for eng in (e, o):
+            eng.set_obs(sym, None)                                                  # table first, data second
+        assert e.get_shift()[0] == 0.0
+        a = e.estep(starts, 40, flags=L.TRANS_WRAP)
+        b = o.estep(starts, 40, flags=L.TRANS_WRAP)
+        np.testing.assert_allclose(a.buf, b.buf, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(e.loglik(starts[:3], 40), o.loglik(starts[:3], 40), rtol=0, atol=1e-12)
+        # an explicit shift under the table: put back before the next lookup
+        e.shift_obs(np.array([2.5]))
+        a2 = e.estep(starts, 40, flags=L.TRANS_WRAP)
+        assert e.get_shift()[0] == 0.0
+        np.testing.assert_array_equal(a2.buf, a.buf)
+        # block upload under the table
+        sym2 = rng.integers(1, V, size=T).astype(np.float64)[:, None]
+        e.set_obs_blocks([sym2[:500], sym2[500:]], T, 1)
+        o.set_obs(sym2, None)
+        assert e.get_shift()[0] == 0.0
+        np.testing.assert_allclose(e.estep(starts, 40, flags=L.TRANS_WRAP).buf,
+                                   o.estep(starts, 40, flags=L.TRANS_WRAP).buf, rtol=1e-9, atol=1e-9)
+    finally:
+        e.close()
