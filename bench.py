@@ -130,6 +130,18 @@ def free_port():
     return p
 
 
+def rank_envs(n, port, base=None):
+    """Launch environment of each of the n ranks of one node (one process per GPU; rendezvous on
+    127.0.0.1; dmabuf IPC for RCCL)."""
+    envs = []
+    for r in range(n):
+        env = dict(os.environ if base is None else base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SVIHMM_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        envs.append(env)
+    return envs
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU)
     ourselves; rank 0's stdout (the JSON line) passes through.  Exit code = worst child."""
@@ -138,12 +150,8 @@ def launch_ranks(args):
     if ndev < args.gpus:
         sys.stderr.write("bench.py: --gpus %d but only %d HIP device(s) visible\n" % (args.gpus, ndev))
         return 2
-    port = str(free_port())
     procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, SVIHMM_BENCH_CHILD="1")
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for r, env in enumerate(rank_envs(args.gpus, free_port())):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
@@ -153,12 +161,188 @@ def launch_ranks(args):
     return rc
 
 
+def packed_size(Kq, Dq):
+    return Kq * Kq + Kq * Dq + Kq + Kq * Dq * Dq + 1
+
+
+def headline_record(args, strong, world, ranks_seen, have_comm, block, per_rank, prof, rows, gen_ms, side):
+    """The ONE JSON line from the measured blocks (seconds per block of args.steps steps, already
+    MAX-reduced over ranks) and the HIP-event profile of the timed region."""
+    dt = float(np.median(block))
+    ms_per_step = dt / args.steps * 1e3
+    tot_rows = rows if strong else rows * world
+    value = tot_rows * K * args.steps / dt
+    flops = algorithmic_flops(rows)
+    nlaunch = args.reps * args.steps
+    kern = {}
+    for name, (ms, cnt) in prof.items():
+        kern[name] = {"ms_per_launch": ms / cnt, "launches": cnt}
+        if name in flops:
+            kern[name]["tflops"] = flops[name] / (ms / cnt * 1e-3) / 1e12
+    dom = max((k for k in kern if k in flops), key=lambda k: kern[k]["ms_per_launch"])
+    achieved_ev = kern[dom]["tflops"]
+    # counters and the profiler's clock come from the committed profile set (tools/profile_round.sh):
+    # HBM bytes per launch / per step (FETCH_SIZE, WRITE_SIZE passes) and rocprofv3's average duration
+    traffic = step_traffic = prof_us = None
+    prof_src = pmc_src = None
+    try:
+        pj = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+        traffic = pj.get(dom, {}).get("hbm_bytes_per_launch")
+        step_traffic = pj.get("_step_total", {}).get("hbm_bytes_per_step")
+        pmc_src = pj.get("_note", "").split("source ")[-1] or None
+    except Exception:
+        pass
+    try:
+        kj = json.load(open(os.path.join(REPO, "profiles", "kernel_stats.json")))
+        prof_us = kj.get(dom, {}).get("avg_us")
+        prof_src = kj.get("_note", "").split("source ")[-1] or None
+    except Exception:
+        pass
+    achieved_prof = flops[dom] / (prof_us * 1e-6) / 1e12 if prof_us else None
+    # algorithmic HBM bytes of the whole step: obs read once + packed stats out
+    alg_bytes = rows * D * 8.0 + packed_size(K, D) * 8.0
+    step_flops = sum(flops.values())
+    # roofline.frac is the figure a reader recomputes from profiles/ (rocprofv3's average of the
+    # dominant kernel); the live HIP-event figure of THIS run is frac_events.  Without a committed
+    # profile set the live figure is all there is.
+    achieved = achieved_prof if achieved_prof else achieved_ev
+    res = {
+        "metric": "obs-state updates/sec (T*K/s) per SVI E-step, K=64 Gaussian HMM",
+        "value": value, "unit": "updates/s", "n_gpus": args.gpus, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic (generated in HBM by svihmm_generate, %.1f ms)" % gen_ms,
+        "reps": args.reps, "timing": "median of %d blocks of %d steps (max over ranks per block)"
+                                     % (args.reps, args.steps),
+        "timed_region_s": float(np.sum(block)),
+        "ms_per_step_reps": [float(b / args.steps * 1e3) for b in block],
+        "ranks": ranks_seen, "ranks_source": "ncclCommCount" if have_comm else "no communicator",
+        "config": {"workload": "configs[2]: K=64 D=32 full-cov NIW-Gaussian HMM, T=1e6 "
+                               "resident, metaobs L=128 (Lm=257), one E-step over all "
+                               "3891 tiled windows (T*K=6.4e7 updates) per GPU per step",
+                   "K": K, "D": D, "T": T, "Lm": LM, "windows_per_step": rows // LM,
+                   "sequences": 1 if strong else world,
+                   "parallelism": ("one sequence resident on every GPU, windows[rank::N] per rank, one "
+                                   "all-reduce of the packed statistics per step") if strong else
+                                  "windows sharded; 1 sequence/GPU"},
+        "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved,
+                     "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / FP64_PEAK_TFLOPS,
+                     "frac_source": ("rocprofv3 --kernel-trace --stats average of the kernel, %s (%.1f us)"
+                                     % (prof_src, prof_us)) if achieved_prof else
+                                    "HIP events of this run (no profiles/kernel_stats.json)",
+                     "achieved_events": achieved_ev, "frac_events": achieved_ev / FP64_PEAK_TFLOPS,
+                     "whole_step_frac": step_flops / (ms_per_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                     "traffic": traffic,
+                     "traffic_ratio": (step_traffic / alg_bytes) if step_traffic else None,
+                     "clock": "frac: the profiler's clock (reproducible from profiles/); frac_events: HIP events "
+                              "around every launch of the kernel in the timed region (%d launches; a few %% "
+                              "shorter than under the profiler); whole_step_frac: algorithmic flop of emission + "
+                              "sweeps + statistics / ms_per_step / peak" % nlaunch,
+                     "note": "fp64: v_mfma_f64_16x16x4_f64; peak = MI355X datasheet fp64 "
+                             "(matrix = vector = 78.6 TF); traffic_ratio = counter bytes per step / "
+                             "algorithmic bytes (%s)" % pmc_src},
+        "roofline_hbm": {"bound": "hbm", "achieved": alg_bytes / (ms_per_step * 1e-3) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic_per_step": step_traffic,
+                         "note": "algorithmic bytes (obs read once + stats) / step time; the "
+                                 "path is compute-bound (SURVEY.md 8d)"},
+        "kernels": kern,
+    }
+    if per_rank is not None:
+        res["per_rank_ms_per_step"] = per_rank
+    if "allreduce" in kern:
+        res["allreduce"] = {"ms_per_step": kern["allreduce"]["ms_per_launch"], "bytes": packed_size(K, D) * 8,
+                            "note": "ncclAllReduce(sum, f64) of the packed statistics on the handle's stream "
+                                    "(HIP events around the call)"}
+    res.update(side)
+    return res
+
+
+REQUIRED = {"metric": str, "value": float, "unit": str, "n_gpus": int, "steps": int, "warmup": int,
+            "ms_per_step": float, "higher_is_better": bool, "scaling": str, "dtype": str, "data": str,
+            "config": dict, "roofline": dict, "ranks": int}
+
+
+def validate_record(res, n_gpus):
+    """Schema of the line the driver parses (contract of the task + the multi-GPU extras)."""
+    for k, t in REQUIRED.items():
+        assert k in res, "missing key %s" % k
+        assert isinstance(res[k], t), "%s: %r is not %s" % (k, res[k], t.__name__)
+    assert "vs_baseline" in res and res["vs_baseline"] is None
+    assert res["n_gpus"] == n_gpus and res["ranks"] == n_gpus
+    assert "workload" in res["config"] and "model" not in res["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in res["roofline"], "roofline.%s" % k
+    if n_gpus > 1:
+        assert len(res["per_rank_ms_per_step"]) == n_gpus
+        assert "ms_per_step" in res["allreduce"]
+        ss = res["strong_scaling"]
+        for leg in ("epoch", "minibatch_s64"):
+            for k in ("windows", "windows_per_rank", "ms_per_step", "value", "allreduce_ms_per_step"):
+                assert k in ss[leg], "strong_scaling.%s.%s" % (leg, k)
+    json.loads(json.dumps(res))
+    return True
+
+
+def dry_run(args):
+    """`bench.py --gpus N --dry-run`: everything of an N-rank run that needs no device -- the N launch
+    environments (one process per GPU, loopback rendezvous, rank / local-rank / world-size, dmabuf
+    IPC), the window partitions of both scaling modes, and the record assembly on synthetic timings,
+    validated against the schema.  Prints the (synthetic, marked) line; exit code 0 = consistent."""
+    n = args.gpus
+    envs = rank_envs(n, free_port(), base={})
+    assert len(envs) == n
+    ports = {e["MASTER_PORT"] for e in envs}
+    assert len(ports) == 1 and all(e["MASTER_ADDR"] == "127.0.0.1" for e in envs)
+    assert [int(e["RANK"]) for e in envs] == list(range(n)) == [int(e["LOCAL_RANK"]) for e in envs]
+    assert all(int(e["WORLD_SIZE"]) == n and e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for e in envs)
+    B = T // LM
+    all_starts = np.arange(B, dtype=np.int64) * LM
+    st64 = (np.arange(64, dtype=np.int64) * (T // 64)) % (T - LM)
+    for st in (all_starts, st64):       # strong scaling: the ranks' shares tile the batch exactly once
+        parts = [st[r::n] for r in range(n)]
+        assert sum(len(p) for p in parts) == len(st)
+        assert np.array_equal(np.sort(np.concatenate(parts)), np.sort(st))
+    rows = B * LM
+    strong = args.scaling == "strong"
+    # synthetic timings shaped like a real run (NOT measurements)
+    rng = np.random.default_rng(0)
+    block = args.steps * 3.2e-3 * (1.0 + 0.01 * rng.random(args.reps))
+    prof = {"emission": (1.16 * args.reps * args.steps, args.reps * args.steps),
+            "forward_backward": (0.45 * args.reps * args.steps, args.reps * args.steps),
+            "stats": (1.35 * args.reps * args.steps, args.reps * args.steps)}
+    side = {}
+    per_rank = None
+    if n > 1:
+        prof["allreduce"] = (0.05 * args.reps * args.steps, args.reps * args.steps)
+        per_rank = [3.2] * n
+        leg = lambda w: {"windows": int(w), "windows_per_rank": int((w + n - 1) // n), "ms_per_step": 1.0,
+                         "value": 1.0, "unit": "updates/s", "scaling": "strong", "allreduce_ms_per_step": 0.05}
+        if not strong and not args.no_strong:
+            side["strong_scaling"] = {"epoch": leg(B), "minibatch_s64": leg(64), "note": "synthetic"}
+    res = headline_record(args, strong, n, n, n > 1, block, per_rank, prof, rows, 0.0, side)
+    res["data"] = "DRY RUN: synthetic timings, no device touched -- not a measurement"
+    if n > 1 and strong:
+        res["strong_scaling"] = {"epoch": leg(B), "minibatch_s64": leg(64)}     # (schema check only)
+    validate_record(res, n)
+    print(json.dumps(res))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--reps", type=int, default=10, help="repetitions of the --steps block (median reported)")
+    ap.add_argument("--reps", type=int, default=0,
+                    help="repetitions of the --steps block (median reported); default: as many as make the "
+                         "headline region span >= 5 s of GPU time (80 blocks of 20 steps at ~3.1 ms), so that "
+                         "a coarse utilisation sampler sees it")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no devices: build every rank's launch environment for --gpus N, run the record "
+                         "assembly on synthetic timings and validate the schema of the line (tests)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default, BASELINE configs[3]): one independent T=1M sequence per GPU; strong: ONE "
                          "sequence, the epoch's 3891 windows dealt windows[rank::N] (north_star: 'minibatches shard "
@@ -169,6 +353,10 @@ def main():
     ap.add_argument("--no-side", action="store_true", help="skip the side figures (profiling runs)")
     args = ap.parse_args()
 
+    if args.reps <= 0:
+        args.reps = max(10, int(np.ceil(5.0 / (max(args.steps, 1) * 3.2e-3))))
+    if args.dry_run:
+        raise SystemExit(dry_run(args))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
@@ -261,10 +449,6 @@ def main():
     tot_rows = rows if strong else rows * world
     assert abs(out.A_raw.sum() / tot_rows - 1.0) < 1e-9, out.A_raw.sum() / tot_rows
 
-    dt = float(np.median(block))
-    ms_per_step = dt / args.steps * 1e3
-    value = tot_rows * K * args.steps / dt
-
     side = {}
     if world == 1 and not args.no_side:
         side = side_figures(eng, L, pb, step, barrier, obs_host, args)
@@ -274,67 +458,8 @@ def main():
         side["strong_scaling"] = strong_scaling(eng, L, comm, rank, world, args, barrier)
 
     if rank == 0:
-        flops = algorithmic_flops(rows)
-        nlaunch = args.reps * args.steps
-        kern = {}
-        for name, (ms, cnt) in prof.items():
-            kern[name] = {"ms_per_launch": ms / cnt, "launches": cnt}
-            if name in flops:
-                kern[name]["tflops"] = flops[name] / (ms / cnt * 1e-3) / 1e12
-        dom = max((k for k in kern if k in flops), key=lambda k: kern[k]["ms_per_launch"])
-        achieved = kern[dom]["tflops"]
-        traffic = step_traffic = None
-        pmc_path = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_path):
-            try:
-                pj = json.load(open(pmc_path))
-                traffic = pj.get(dom, {}).get("hbm_bytes_per_launch")
-                step_traffic = pj.get("_step_total", {}).get("hbm_bytes_per_step")
-            except Exception:
-                traffic = None
-        # algorithmic HBM bytes of the whole step: obs read once + packed stats out
-        alg_bytes = rows * D * 8.0 + PackedStats.size(K, D) * 8.0
-        res = {
-            "metric": "obs-state updates/sec (T*K/s) per SVI E-step, K=64 Gaussian HMM",
-            "value": value, "unit": "updates/s", "n_gpus": args.gpus, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic (generated in HBM by svihmm_generate, %.1f ms)" % gen_ms,
-            "reps": args.reps, "timing": "median of %d blocks of %d steps (max over ranks per block)"
-                                         % (args.reps, args.steps),
-            "ms_per_step_reps": [float(b / args.steps * 1e3) for b in block],
-            "ranks": ranks_seen, "ranks_source": "ncclCommCount" if comm is not None else "no communicator",
-            "config": {"workload": "configs[2]: K=64 D=32 full-cov NIW-Gaussian HMM, T=1e6 "
-                                   "resident, metaobs L=128 (Lm=257), one E-step over all "
-                                   "3891 tiled windows (T*K=6.4e7 updates) per GPU per step",
-                       "K": K, "D": D, "T": T, "Lm": LM, "windows_per_step": B,
-                       "sequences": 1 if strong else world,
-                       "parallelism": ("one sequence resident on every GPU, windows[rank::N] per rank, one "
-                                       "all-reduce of the packed statistics per step") if strong else
-                                      "windows sharded; 1 sequence/GPU"},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved,
-                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
-                         "clock": "HIP events around every launch of the kernel in the timed region "
-                                  "(%d launches); rocprofv3's average for the same kernel is in "
-                                  "profiles/ (a few %% longer under the profiler)" % nlaunch,
-                         "note": "fp64: v_mfma_f64_16x16x4_f64; peak = MI355X datasheet fp64 "
-                                 "(matrix = vector = 78.6 TF)"},
-            "roofline_hbm": {"bound": "hbm", "achieved": alg_bytes / (ms_per_step * 1e-3) / 1e9,
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "traffic_per_step": step_traffic,
-                             "note": "algorithmic bytes (obs read once + stats) / step time; the "
-                                     "path is compute-bound (SURVEY.md 8d)"},
-            "kernels": kern,
-        }
-        if per_rank is not None:
-            res["per_rank_ms_per_step"] = per_rank
-        if "allreduce" in kern:
-            res["allreduce"] = {"ms_per_step": kern["allreduce"]["ms_per_launch"], "bytes": PackedStats.size(K, D) * 8,
-                                "note": "ncclAllReduce(sum, f64) of the packed statistics on the handle's stream "
-                                        "(HIP events around the call)"}
-        res.update(side)
+        res = headline_record(args, strong, world, ranks_seen, comm is not None, block, per_rank, prof, rows,
+                              gen_ms, side)
         print(json.dumps(res))
         sys.stdout.flush()
     if comm is not None:
@@ -513,6 +638,12 @@ def side_figures(eng, L, pb, step, barrier, obs_host, args):
         res.setdefault("svi_iteration_s64", {})["raw_step_after_class_max_rel_diff"] = drift
         assert drift < 1e-9, "raw E-step on the shared handle changed after the class ran: %g" % drift
 
+    # 4b. configs[1]: K=16, D=8, T=1e5 -- epoch step, full-chain E-step, ffbs_fast beside the C port's
+    #     Cython-variant forward filter on one core (replaces the resident sequence)
+    try:
+        res["c2_k16_d8"] = config1_record(eng, L, with_cpu=not args.no_cpu_baseline)
+    except Exception as e:
+        res["c2_k16_d8"] = {"error": repr(e)}
     # 5. configs[4]: K=256, D=64 full covariance, T=1e6, epoch sweep of 3891 windows
     try:
         res["c5_k256_d64"] = wide_model(eng, L)
@@ -607,6 +738,85 @@ def cpu_baselines(eng, L, pb, step, obs_host):
         "value": nwin_np * LM * K / ndt, "unit": "updates/s", "cores": 1, "kind": "port",
         "sample": "first %d windows (%.1f s); NumPy restatement of the reference's local_update + "
                   "intermediate_pars expressions (np.logaddexp.reduce folds, np.outer loop)" % (nwin_np, ndt)}
+    return res
+
+
+def config1_record(eng, L, with_cpu=True):
+    """BASELINE configs[1]: K=16, D=8 full-covariance NIW-Gaussian HMM, T=1e5, "single-GPU E-step vs
+    Cython hmm_fast": the windowed epoch step, the full-chain E-step (`full_local_update`) and
+    `ffbs_fast` (forward filter + backward sampling, `z` and `lalpha` back on the host), with the C port's
+    forward filter IN THE CYTHON VARIANT -- mod_init with DBL_EPSILON, transitions log(var_tran +
+    DBL_EPSILON) un-normalised, /root/reference/hmm_fast.pyx:74-93 -- timed on one host core beside it
+    and used as the check of the returned lalpha (asserted)."""
+    from scipy.special import digamma
+    K1, D1, T1 = 16, 8, 100000
+    DE = np.finfo(np.float64).eps
+    rs = np.random.RandomState(SEED + 1)
+    tran = 0.9 * np.eye(K1) + 0.1 / (K1 - 1) * (1.0 - np.eye(K1))
+    means = rs.normal(0.0, 5.0, size=(K1, D1))
+    chols = np.broadcast_to(np.eye(D1), (K1, D1, D1)).copy()
+    eng.generate(tran, means, chols, T1, seed=SEED + 1)
+    obs = eng.read_generated(want_sts=False)[0]
+    p1 = variational_state(rs, means, obs[:20000], K1, D1, T1)
+    B1 = T1 // LM
+    st = np.arange(B1, dtype=np.int64) * LM
+    eng.set_emission_niw(p1["mu"], p1["sigma"], p1["kappa"], p1["nu"])
+
+    def epoch():
+        eng.set_emission_niw(p1["mu"], p1["sigma"], p1["kappa"], p1["nu"], check=False)
+        eng.set_globals(p1["mod_init"], p1["ltran"])
+        eng.estep(st, LM, flags=L.TRANS_WRAP, read=False)
+        return eng.read_packed()
+
+    def full_chain():
+        eng.set_globals(p1["mod_init"], p1["ltran"])
+        eng.estep([0], T1, flags=0, read=False)
+        return eng.read_packed()
+    out = epoch()
+    assert np.all(np.isfinite(out.buf)) and abs(out.A_raw.sum() / (B1 * LM) - 1.0) < 1e-9
+    t_ep = median_time(epoch, eng.sync, 20, warm=3)
+    fc = full_chain()
+    assert np.all(np.isfinite(fc.buf)) and abs(fc.neff.sum() / T1 - 1.0) < 1e-9
+    t_fc = median_time(full_chain, eng.sync, 10, warm=2)
+    # ffbs_fast as hmmbase.ffbs_fast issues it (Cython variant of the globals)
+    var_tran = 1.0 + rs.random_sample((K1, K1)) * T1 / K1
+    var_init = rs.random_sample(K1) + 0.1
+    mi_cy = digamma(var_init + DE) - digamma(var_init.sum() + DE)
+    logA = np.log(var_tran + DE)
+    u = np.random.default_rng(2).random(T1)
+    holder = {}
+
+    def ffbs():
+        eng.set_globals(mi_cy, logA)
+        holder["z"], holder["la"] = eng.ffbs(logA, u, want_lalpha=True)
+    t_ff = median_time(ffbs, eng.sync, 10, warm=2)
+    res = {"K": K1, "D": D1, "T": T1, "Lm": LM,
+           "epoch_step": {"windows": B1, "ms": t_ep * 1e3, "value": B1 * LM * K1 / t_ep, "unit": "updates/s",
+                          "note": "parameter upload + E-step over all 389 tiled windows + statistics read-back"},
+           "full_chain_estep": {"ms": t_fc * 1e3, "value": T1 * K1 / t_fc, "unit": "updates/s",
+                                "note": "full_local_update: one window = the whole sequence (exact blocked scan), "
+                                        "E-step + statistics"},
+           "ffbs_fast": {"ms": t_ff * 1e3, "value": T1 * K1 / t_ff, "unit": "updates/s",
+                         "note": "hmm_fast.FFBS semantics: forward filter + backward sampling, z[T] and lalpha[T,K] "
+                                 "(12.8 MB) back on the host"}}
+    if with_cpu:
+        from oracle import ref_c
+        t0 = time.perf_counter()
+        ll = ref_c.lliks_niw(obs, p1["mu"], p1["sigma"], p1["kappa"], p1["nu"])
+        t1 = time.perf_counter()
+        la = ref_c.forward(ll, mi_cy, logA)
+        t2 = time.perf_counter()
+        err = float(np.max(np.abs(holder["la"] - la) / (1.0 + np.abs(la))))
+        assert err < 1e-9, "ffbs lalpha vs the C port's Cython-variant forward filter: %g" % err
+        z = holder["z"]
+        assert z.shape == (T1,) and z.min() >= 0 and z.max() < K1
+        res["cpu_baseline_ffbs"] = {
+            "value": T1 * K1 / (t2 - t0), "unit": "updates/s", "cores": 1, "kind": "port",
+            "ms": (t2 - t0) * 1e3, "ms_lliks": (t1 - t0) * 1e3, "ms_forward_filter": (t2 - t1) * 1e3,
+            "sample": "the whole T=1e5 sequence: expected log-likelihoods + the forward filter of "
+                      "hmm_fast.pyx:80-93 (K^2 log-add-exp per step, log(var_tran + DBL_EPSILON)) in plain C on "
+                      "one core; the O(T K) backward sampling pass is not included",
+            "gpu_lalpha_vs_port_max_rel_err": err}
     return res
 
 

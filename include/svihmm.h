@@ -35,10 +35,11 @@
 extern "C" {
 #endif
 
-/* 2: svihmm_get_shift added, svihmm_shift_obs no longer changes what later calls mean (the shift is
+/* 3: svihmm_export_packed / svihmm_import_packed added (round 4; nothing else changed meaning).
+ * 2: svihmm_get_shift added, svihmm_shift_obs no longer changes what later calls mean (the shift is
  *    the handle's business), svihmm_set_emission_diag added; 1 was rounds 1-2 (svi_*,
  *    set_precision, shift_obs, ffbs_sample, comm_count were added under it). */
-#define SVIHMM_ABI_VERSION 2
+#define SVIHMM_ABI_VERSION 3
 
 typedef struct svihmm_ctx svihmm_ctx;
 
@@ -373,6 +374,13 @@ int svihmm_comm_count(svihmm_ctx* h, int32_t* nranks_out);
  * "A_inter += A_i ; emit_inter[k] += e_i[k]" accumulation of
  * hmmsgd_metaobs.py:430-436 extended across ranks. */
 int svihmm_allreduce_packed(svihmm_ctx* h);
+/* The same exchange with the sum formed by the HOST (a communicator other than RCCL -- MPI, gloo --
+ * or two handles on one device): svihmm_export_packed hands out exactly what the all-reduce puts on
+ * the wire -- this rank's statistics in the callers' common coordinates (every rank's resident copy
+ * has its own centre) -- and svihmm_import_packed takes the reduced vector back into the handle, from
+ * where svihmm_read_packed continues as after svihmm_allreduce_packed (hmmsgd_metaobs.py:430-436). */
+int svihmm_export_packed(svihmm_ctx* h, double* out_packed);
+int svihmm_import_packed(svihmm_ctx* h, const double* packed_in);
 /* Generic all-reduce of a small host vector (op 0: sum, 1: max) through HBM;
  * used for barriers and max-over-ranks timing. */
 int svihmm_allreduce_host(svihmm_ctx* h, double* buf, int64_t n, int32_t op);

@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsvihmm_hip.so")
 
-ABI_VERSION = 2                   # include/svihmm.h SVIHMM_ABI_VERSION this binding was written against
+ABI_VERSION = 3                   # include/svihmm.h SVIHMM_ABI_VERSION this binding was written against
 NKERN = 12
 MASK_AS_NAN = 1
 TRANS_WRAP = 2
@@ -90,6 +90,8 @@ SIGNATURES = {
     "svihmm_comm_init": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32]),
     "svihmm_comm_destroy": (C.c_int, [C.c_void_p]),
     "svihmm_allreduce_packed": (C.c_int, [C.c_void_p]),
+    "svihmm_export_packed": (C.c_int, [C.c_void_p, _c_double_p]),
+    "svihmm_import_packed": (C.c_int, [C.c_void_p, _c_double_p]),
     "svihmm_allreduce_host": (C.c_int, [C.c_void_p, _c_double_p, C.c_int64, C.c_int32]),
     "svihmm_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "svihmm_profile_reset": (C.c_int, [C.c_void_p]),

@@ -906,22 +906,39 @@ static int read_packed_host(svihmm_ctx* h, double* out) {
 }
 // Sum of the packed statistics over the ranks.  The buffer holds centred coordinates and every
 // rank has its own shift: the sum is formed in the callers' common coordinates and brought back.
-static int allreduce_packed_dev(svihmm_ctx* h) {
+// packed_to_common: the statistics in the coordinates every rank shares (the callers'), as a device
+// buffer (commtmp; `packed` itself where no shift applies); packed_from_common: the reduced buffer
+// back into this handle's centred coordinates.  The RCCL all-reduce and the host-mediated exchange
+// (svihmm_export_packed / svihmm_import_packed) run between the same two halves.
+static bool common_needs_shift(const svihmm_ctx* h, bool always) {
+  return h->shifted && !h->emis_cat && (always || h->nranks > 1 || h->variant[11] == 1);   // (variant 11: rehearsal at one rank)
+}
+static int packed_to_common(svihmm_ctx* h, bool always, double** buf_out) {
   const size_t n = (size_t)packed_len(h);
-  if (h->shifted && !h->emis_cat && (h->nranks > 1 || h->variant[11] == 1)) {   // (variant 11: rehearsal at one rank)
-    CK(ensure(h->commtmp, n * sizeof(double)));
-    double* tmp = (double*)h->commtmp.p;
-    const unsigned nb = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(k_packed_shift, dim3(nb), dim3(256), 0, h->stream, (const double*)h->packed.p, tmp, (int)n,
-                       h->K, h->D, (const double*)h->shift_d.p, 1.0, h->emis_diag ? 1 : 0);
-    NCCLCK(ncclAllReduce(tmp, tmp, n, ncclDouble, ncclSum, h->comm, h->stream));
-    hipLaunchKernelGGL(k_packed_shift, dim3(nb), dim3(256), 0, h->stream, (const double*)tmp, (double*)h->packed.p,
-                       (int)n, h->K, h->D, (const double*)h->shift_d.p, -1.0, h->emis_diag ? 1 : 0);
-    HIPCK(hipGetLastError());
-    return 0;
-  }
-  NCCLCK(ncclAllReduce(h->packed.p, h->packed.p, n, ncclDouble, ncclSum, h->comm, h->stream));
+  if (!common_needs_shift(h, always)) { *buf_out = (double*)h->packed.p; return 0; }
+  CK(ensure(h->commtmp, n * sizeof(double)));
+  double* tmp = (double*)h->commtmp.p;
+  hipLaunchKernelGGL(k_packed_shift, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream,
+                     (const double*)h->packed.p, tmp, (int)n, h->K, h->D, (const double*)h->shift_d.p, 1.0,
+                     h->emis_diag ? 1 : 0);
+  HIPCK(hipGetLastError());
+  *buf_out = tmp;
   return 0;
+}
+static int packed_from_common(svihmm_ctx* h, const double* buf) {
+  if (buf == (const double*)h->packed.p) return 0;
+  const size_t n = (size_t)packed_len(h);
+  hipLaunchKernelGGL(k_packed_shift, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, buf,
+                     (double*)h->packed.p, (int)n, h->K, h->D, (const double*)h->shift_d.p, -1.0,
+                     h->emis_diag ? 1 : 0);
+  HIPCK(hipGetLastError());
+  return 0;
+}
+static int allreduce_packed_dev(svihmm_ctx* h) {
+  double* buf = nullptr;
+  CK(packed_to_common(h, false, &buf));
+  NCCLCK(ncclAllReduce(buf, buf, (size_t)packed_len(h), ncclDouble, ncclSum, h->comm, h->stream));
+  return packed_from_common(h, buf);
 }
 
 // ---- two-stream E-step pipeline -------------------------------------------------------------
@@ -1630,6 +1647,39 @@ int svihmm_allreduce_packed(svihmm_ctx* h) {
   CK(allreduce_packed_dev(h));
   h->mirror_valid = false;
   return launch_mirror(h);   // the host-visible copy follows the reduced statistics
+}
+
+// Host-mediated exchange of the same statistics (a communicator other than RCCL -- MPI, gloo -- or
+// two handles on one device): export hands out what the all-reduce would put on the wire (caller
+// coordinates), import takes the reduced vector back into the handle's centred `packed`, from where
+// svihmm_read_packed / the device-side global step continue as after svihmm_allreduce_packed.
+int svihmm_export_packed(svihmm_ctx* h, double* out_packed) {
+  if (!h || !out_packed) return fail("svihmm_export_packed: bad arguments");
+  if (!h->have_packed) return fail("svihmm_export_packed: no statistics computed yet");
+  CK(set_device(h));
+  double* buf = nullptr;
+  CK(packed_to_common(h, true, &buf));
+  return d2h_sync_small(h, out_packed, buf, (size_t)packed_len(h) * sizeof(double));
+}
+int svihmm_import_packed(svihmm_ctx* h, const double* packed_in) {
+  if (!h || !packed_in) return fail("svihmm_import_packed: bad arguments");
+  if (!h->have_globals || h->D <= 0) return fail("svihmm_import_packed: set obs / globals / emission first");
+  CK(set_device(h));
+  const size_t nb = (size_t)packed_len(h) * sizeof(double);
+  CK(ensure(h->packed, nb));
+  const bool sh = common_needs_shift(h, true);
+  if (sh) CK(ensure(h->commtmp, nb));
+  double* dst = sh ? (double*)h->commtmp.p : (double*)h->packed.p;
+  void* pin = nullptr;
+  int slot = 0;
+  CK(pinned(h, nb, &pin, &slot));
+  std::memcpy(pin, packed_in, nb);
+  CK(pull_small(h, dst, pin, nb));
+  CK(pin_release(h, slot));
+  CK(packed_from_common(h, dst));
+  h->have_packed = true;
+  h->mirror_valid = false;
+  return 0;
 }
 
 int svihmm_allreduce_host(svihmm_ctx* h, double* buf, int64_t n, int32_t op) {

@@ -164,6 +164,9 @@ static int launch_lin_init(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_t st
 // one launch, blockIdx.y = direction
 int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_t stream) {
   const int K = h->K;
+  // measurement only (tools/r4_overlap_probe.py): variant[7] = 9 skips the sweep launch -- the
+  // statistics then read the previous step's messages; bounds what hiding the sweeps could give
+  if (h->variant[7] == 9) return 0;
   const int NW = (K + 15) / 16;
   const bool full = (K == 16 * NW);
   dim3 grid((nb + 15) / 16, 2);

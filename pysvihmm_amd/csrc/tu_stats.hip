@@ -59,7 +59,8 @@ int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, int Lm, u
   // scaled sweeps: the pipelined kernel forms q = ah * bh * scale itself; the others read var_x
   // (wide models too, round 3: the separate posterior pass costs more than the second operand's loads;
   //  variant[15] = 1: K > 64 through q as before)
-  const bool lin = h->lin_mode && !h->q_valid && var == 3 && (Kp <= 64 || h->variant[15] != 1);
+  // (variant[15] = 2, measurement only: posteriors by their own pass + the GEMM on plain q for every K)
+  const bool lin = h->lin_mode && !h->q_valid && var == 3 && (Kp <= 64 || h->variant[15] != 1) && h->variant[15] != 2;
   if (h->lin_mode && !lin) CK(ensure_q(h, h->curB, Lq, stream));
   const size_t qo = (size_t)b0 * Lq * K;
   const double* qv = (const double*)(lin ? h->la.p : h->q.p) + qo;   // (reassigned: see the transition blocks)

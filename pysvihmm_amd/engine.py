@@ -489,6 +489,17 @@ class HipEngine(object):
     def allreduce_packed(self):
         L.check(self._lib.svihmm_allreduce_packed(self._h), "svihmm_allreduce_packed")
 
+    def export_packed(self):
+        """This handle's statistics as the all-reduce would put them on the wire (caller coordinates)."""
+        out = np.empty(self._packed_len())
+        L.check(self._lib.svihmm_export_packed(self._h, L.dptr(out)), "svihmm_export_packed")
+        return out
+
+    def import_packed(self, buf):
+        """The reduced vector of a host-side exchange back into the handle (see export_packed)."""
+        buf = L.as_f64(buf, (self._packed_len(),))
+        L.check(self._lib.svihmm_import_packed(self._h, L.dptr(buf)), "svihmm_import_packed")
+
     def allreduce_host(self, arr, op="sum"):
         a = np.ascontiguousarray(np.asarray(arr, dtype=np.float64).ravel())
         L.check(self._lib.svihmm_allreduce_host(self._h, L.dptr(a), a.size,

@@ -643,7 +643,7 @@ def run_sequence(e, L, seed, nops=30):
     return hist
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cases", type=int, default=100)
@@ -655,7 +655,7 @@ def main():
     ap.add_argument("--classes", type=int, default=0, help="cases of the class-level campaign")
     ap.add_argument("--api", type=int, default=0, help="cases of the API-level campaign (callers around the E-step)")
     ap.add_argument("--seconds", type=float, default=1e9, help="stop drawing new cases after this long")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     from pysvihmm_amd.engine import HipEngine
     from pysvihmm_amd import _lib as L
     from oracle import ref_c

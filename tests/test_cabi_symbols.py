@@ -29,6 +29,6 @@ def test_ctypes_prototypes_match_header():
 
 def test_load_and_version_without_gpu():
     lib = _lib.load()
-    assert lib.svihmm_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.svihmm_abi_version() == _lib.ABI_VERSION == 3
     assert lib.svihmm_packed_size(64, 32) == 64 * 64 + 64 * 32 + 64 + 64 * 32 * 32 + 1
     assert lib.svihmm_kernel_name(0) == b"emission"

@@ -43,3 +43,24 @@ def test_api_and_class_cases(eng):
         fuzz_gpu.run_api_case(eng, L, 3170000 + i)
     for i in range(4):
         fuzz_gpu.run_class_case(eng, 3190000 + i)
+
+
+# ---- the campaign itself, time-boxed: every leg of tests/fuzz_gpu.py through its
+# own driver (main: case drawing, failure accounting, engine re-creation after a hard error), fixed
+# seed, 12 s per leg = 60 s in all.  A failure prints the leg's seed for `fuzz_gpu.py --replay`.
+LEGS = {"statistics": ["--cases", "100000", "--chains", "0"],
+        "chains": ["--cases", "0", "--chains", "1000"],
+        "api": ["--cases", "0", "--chains", "0", "--api", "100000"],
+        "sequences": ["--cases", "0", "--chains", "0", "--sequences", "100000"],
+        "classes": ["--cases", "0", "--chains", "0", "--classes", "100000"]}
+
+
+@pytest.mark.parametrize("leg", sorted(LEGS))
+def test_campaign_leg_time_boxed(leg, capsys):
+    from tests import fuzz_gpu
+    rc = fuzz_gpu.main(["--seed", "404", "--seconds", "12"] + LEGS[leg])
+    out = capsys.readouterr().out
+    assert rc == 0, out[-3000:]
+    import re
+    m = re.search(r"fuzz: (\d+) cases, (\d+) failures", out)
+    assert m and int(m.group(1)) >= 3 and int(m.group(2)) == 0, out[-1000:]

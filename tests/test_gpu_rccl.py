@@ -168,3 +168,68 @@ def test_allreduce_in_caller_coordinates_rehearsal(tmp_path):
     finally:
         e.set_variant(11, 0)
         e.close()
+
+
+@pytest.mark.parametrize("family", ["niw", "diag"])
+def test_two_handles_with_different_centres_host_sum_stands_in_for_the_allreduce(family):
+    """The arithmetic of svihmm_allreduce_packed on ranks whose resident copies have DIFFERENT
+    centres (each rank its own sequence: bench.py's weak mode, BASELINE configs[3]) has never run at
+    world size 2 on hardware.  Its two halves -- statistics into the callers' common coordinates
+    (+c_r), the reduced vector back into the handle's centred `packed` (-c_r) -- are what
+    svihmm_export_packed / svihmm_import_packed run; here two handles on ONE device hold two sequences
+    whose centres lie 150 apart, a host-side sum stands in for ncclAllReduce, and the result is
+    checked against the C oracle on the union of the windows and for equality across the handles."""
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    from oracle import ref_c
+    from tests.helpers import make_problem, unpack
+    K, D, T, Lm = 6, 5, 4000, 41
+    offs = [np.full(D, 100.0), np.linspace(-60.0, -40.0, D)]
+    half = [make_problem(K // 2, D, T, seed=31 + r, miss=0.03) for r in range(2)]
+    pm = make_problem(K, D, 100, seed=33)                      # globals / factor shapes of the 6-state model
+    xs = [half[r]["obs"] + offs[r] for r in range(2)]          # rank r's sequence lives around offs[r]
+    mu = np.concatenate([half[r]["mu"] + offs[r] for r in range(2)])   # one model: three states at each place
+    starts = [np.arange(30, dtype=np.int64) * 97 + 11 * r for r in range(2)]
+    nus = 0.5 + pm["kappa"][:, None] * np.ones((K, D))
+    al = 3.0 + 0.1 * np.arange(K)[:, None] + np.zeros((K, D))
+    be = 2.0 + 0.05 * np.arange(D)[None, :] + np.zeros((K, D))
+    engs = [HipEngine(0), HipEngine(0)]
+    try:
+        own, refs = [], []
+        for r, e in enumerate(engs):
+            e.set_obs(xs[r], half[r]["mask"])
+            e.set_globals(pm["mod_init"], pm["ltran"])
+            if family == "niw":
+                e.set_emission_niw(mu, pm["sigma"], pm["kappa"], pm["nu"])
+                refs.append(ref_c.estep_minibatch(xs[r], half[r]["mask"], starts[r], Lm, pm["mod_init"],
+                                                  pm["ltran"], mu, pm["sigma"], pm["kappa"], pm["nu"], flags=2))
+            else:
+                e.set_emission_diag(mu, nus, al, be)
+            e.estep(starts[r], Lm, flags=L.TRANS_WRAP, read=False)
+            own.append(e.export_packed())
+            np.testing.assert_array_equal(own[r], e.read_packed().buf)   # = what read_packed hands out
+        c0, c1 = engs[0].get_shift(), engs[1].get_shift()
+        assert np.abs(c0 - c1).min() > 100.0                             # the handles' centres differ
+        total = own[0] + own[1]                                          # stands in for ncclAllReduce(sum)
+        back = []
+        for e in engs:
+            e.import_packed(total)
+            back.append(e.read_packed().buf)
+        # each handle's -c_r / +c_r round trip returns the sum (second moments are ~ n |x|^2)
+        n = sum(len(s) for s in starts) * Lm
+        scale = np.maximum(np.abs(total), 1e-12 * n * 150.0 ** 2)
+        for b in back:
+            assert np.max(np.abs(b - total) / scale) < 1e-11, np.max(np.abs(b - total) / scale)
+        if family == "niw":
+            A, xbar, neff, S, lb = unpack(refs[0] + refs[1], K, D)
+            g = engs[1].read_packed()
+            np.testing.assert_allclose(g.A_raw, A, rtol=1e-6, atol=1e-9 * n)
+            np.testing.assert_allclose(g.neff, neff, rtol=1e-6, atol=1e-9 * n)
+            np.testing.assert_allclose(g.xbar, xbar, rtol=1e-6, atol=1e-7 * n)
+            np.testing.assert_allclose(g.S, S, rtol=1e-6, atol=1e-5 * n)
+            np.testing.assert_allclose(g.lb[0], lb, rtol=1e-9)
+            # every state of the model took mass on exactly one of the two ranks
+            assert (neff > 50).all()
+    finally:
+        for e in engs:
+            e.close()
