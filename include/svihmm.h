@@ -390,6 +390,11 @@ int svihmm_allreduce_host(svihmm_ctx* h, double* buf, int64_t n, int32_t op);
  * the handle's stream; svihmm_profile_read returns accumulated milliseconds and
  * launch counts per kernel slot since the last reset. */
 #define SVIHMM_NKERN 12
+/* on = 0: off; 1: every slot; SVIHMM_PROF_SLOTS | (1 << slot) | ...: those slots only (an event
+ * pair between two dependent kernels costs a few microseconds of dispatch -- measured 0.055 ms on
+ * the 3.15 ms bench step with all slots -- so a timed region that wants one kernel's duration
+ * brackets only that kernel). */
+#define SVIHMM_PROF_SLOTS 0x40000000
 int svihmm_profile_enable(svihmm_ctx* h, int32_t on);
 int svihmm_profile_reset(svihmm_ctx* h);
 int svihmm_profile_read(svihmm_ctx* h, double ms_out[SVIHMM_NKERN],

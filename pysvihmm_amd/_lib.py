@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libsvihmm_hip.so")
 
 ABI_VERSION = 3                   # include/svihmm.h SVIHMM_ABI_VERSION this binding was written against
 NKERN = 12
+PROF_SLOTS = 0x40000000          # svihmm_profile_enable: only the slots whose bits follow
 MASK_AS_NAN = 1
 TRANS_WRAP = 2
 USE_HOST_LLIKS = 4

@@ -151,8 +151,9 @@ struct svihmm_ctx {
   // second stream + events of the pipelined E-step (created on first use)
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_em[2] = {nullptr, nullptr}, ev_sw[2] = {nullptr, nullptr};
-  // profiling
+  // profiling (prof_mask: bit s = record events around launches of slot s)
   bool prof = false;
+  uint32_t prof_mask = 0xffffffffu;
   std::vector<Pending> pending;
   std::vector<hipEvent_t> pool;
   double ms[SVIHMM_NKERN] = {0};
@@ -205,7 +206,7 @@ inline size_t packed_len(const svihmm_ctx* h) {
 struct ProfScope {
   svihmm_ctx* h; int slot; hipEvent_t e0 = nullptr, e1 = nullptr; bool on; hipStream_t st;
   ProfScope(svihmm_ctx* h_, int slot_, hipStream_t st_ = nullptr)
-      : h(h_), slot(slot_), on(h_->prof), st(st_ ? st_ : h_->stream) {
+      : h(h_), slot(slot_), on(h_->prof && ((h_->prof_mask >> slot_) & 1u)), st(st_ ? st_ : h_->stream) {
     if (!on) return;
     auto get = [&]() {
       hipEvent_t e;

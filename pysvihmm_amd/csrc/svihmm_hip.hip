@@ -1716,6 +1716,10 @@ int svihmm_profile_enable(svihmm_ctx* h, int32_t on) {
   CK(set_device(h));
   if (!on) drain(h);
   h->prof = on != 0;
+  // on = 1: every slot; on = SVIHMM_PROF_SLOTS | (1 << slot) | ...: only those slots (an event pair
+  // between two dependent kernels costs a few microseconds of dispatch: a timed region that wants
+  // one kernel's duration should not pay for eleven)
+  h->prof_mask = (on & SVIHMM_PROF_SLOTS) ? ((uint32_t)on & 0xfffu) : 0xffffffffu;
   return 0;
 }
 int svihmm_profile_reset(svihmm_ctx* h) {

@@ -508,8 +508,16 @@ class HipEngine(object):
         return a.reshape(np.shape(arr))
 
     # -- measurement ------------------------------------------------------------------------
-    def profile(self, on=True):
-        L.check(self._lib.svihmm_profile_enable(self._h, 1 if on else 0), "profile_enable")
+    def profile(self, on=True, only=None):
+        """HIP events around the handle's launches; ``only``: names of the kernel slots to bracket
+        (``svihmm_kernel_name``), the others run without events."""
+        v = 1 if on else 0
+        if on and only is not None:
+            names = [self._lib.svihmm_kernel_name(i).decode() for i in range(L.NKERN)]
+            v = L.PROF_SLOTS
+            for n in only:
+                v |= 1 << names.index(n)
+        L.check(self._lib.svihmm_profile_enable(self._h, v), "profile_enable")
 
     def profile_reset(self):
         L.check(self._lib.svihmm_profile_reset(self._h), "profile_reset")
