@@ -35,7 +35,8 @@
 extern "C" {
 #endif
 
-/* 3: svihmm_export_packed / svihmm_import_packed added (round 4; nothing else changed meaning).
+/* 3: svihmm_export_packed / svihmm_import_packed, svihmm_svi_set_adagrad / _read_adagrad added, slot mask
+ *    of svihmm_profile_enable (round 4; nothing else changed meaning).
  * 2: svihmm_get_shift added, svihmm_shift_obs no longer changes what later calls mean (the shift is
  *    the handle's business), svihmm_set_emission_diag added; 1 was rounds 1-2 (svi_*,
  *    set_precision, shift_obs, ffbs_sample, comm_count were added under it). */
@@ -262,6 +263,12 @@ int svihmm_svi_begin(svihmm_ctx* h, int32_t K, int32_t D, const double* prior_tr
 int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32_t B,
                          int32_t nwin_total, int32_t Lm, int32_t inner_off, int32_t inner_len,
                          uint32_t flags, double rho, double bfactA, double bfactE);
+/* AdaGrad-scaled transition step (hmmsgd_metaobs.py:179-183 ada_G = ones, :1036-1040
+ * ada_G += nats_old^2; adaMatrix = ada_G^.25; nats_new = (1 - 1/adaMatrix) nats_old + A_up/adaMatrix):
+ * after svihmm_svi_begin, svihmm_svi_set_adagrad uploads the K x K accumulator (NULL: the plain rho
+ * step again); it stays on the device with var_tran, svihmm_svi_read_adagrad hands it back. */
+int svihmm_svi_set_adagrad(svihmm_ctx* h, const double* ada_G);
+int svihmm_svi_read_adagrad(svihmm_ctx* h, double* ada_G_out);
 int svihmm_svi_read_elbo(svihmm_ctx* h, int32_t n, double* out_elbo, double* out_ms);
 /* mod_init[K] / ltran[K,K] as the recursions currently hold them (either may be NULL): the last
  * svihmm_set_globals upload, or -- after svihmm_svi_iteration -- the psi-expectations that

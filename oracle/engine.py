@@ -340,7 +340,13 @@ class OracleEngine(object):
         st = self._packed
         K = self.K
         A_inter = st.A_raw + nwin_total * (sv["prior_tran"] - 1.)
-        sv["var_tran"] = ((1. - rho) * (sv["var_tran"] - 1.) + rho * (bfactA * A_inter)) + 1.
+        if sv.get("ada_G") is not None:            # hmmsgd_metaobs.py:1036-1040
+            nats_old = sv["var_tran"] - 1.
+            sv["ada_G"] = sv["ada_G"] + nats_old ** 2
+            ada = sv["ada_G"] ** .25
+            sv["var_tran"] = ((1. - 1.0 / ada) * nats_old + (bfactA * A_inter) / ada) + 1.
+        else:
+            sv["var_tran"] = ((1. - rho) * (sv["var_tran"] - 1.) + rho * (bfactA * A_inter)) + 1.
         mu, sg, ka, nu = sv["mf"]
         mu0, sg0, ka0, nu0 = sv["prior"]
         vlb = 0.
@@ -355,6 +361,12 @@ class OracleEngine(object):
             g.mu_mf, g.sigma_mf, g.kappa_mf, g.nu_mf = mu[k], sg[k], ka[k], nu[k]
             vlb += g.get_vlb(sv["conv"])
         sv["elbo"][it] = st.lb[0] + R.dirichlet_lower_bound(sv["prior_tran"], sv["var_tran"]) + vlb
+
+    def svi_set_adagrad(self, ada_G):
+        self._svi["ada_G"] = None if ada_G is None else np.array(ada_G, dtype=np.float64)
+
+    def svi_read_adagrad(self):
+        return self._svi["ada_G"].copy()
 
     def read_globals(self):
         return self.mod_init.copy(), self.ltran.copy()

@@ -167,7 +167,7 @@ struct svihmm_ctx {
   std::vector<hipEvent_t> svi_ev;                        // iteration boundaries (iter_time)
   std::vector<int> svi_ev_begin;                         // event that marks the start of iteration it
   int svi_last_it = -1;
-  bool svi_active = false, svi_f32_ok = true;
+  bool svi_active = false, svi_f32_ok = true, svi_adagrad = false;
   hipEvent_t svi_ea = nullptr, svi_eb = nullptr, globals_ev = nullptr;   // side-stream globals kernel
   hipEvent_t svi_ec = nullptr, svi_ed = nullptr;   // theta ready / side-stream ELBO kernels done
   hipStream_t stream3 = nullptr;                   // the ELBO kernels' own stream

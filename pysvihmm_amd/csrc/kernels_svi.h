@@ -236,7 +236,8 @@ __global__ __launch_bounds__(64 * NWV) void k_svi_globals(
 //  G2: natural-gradient global step (hmmsgd_metaobs.py:1010-1069, util.py:28-60) from the packed
 //  statistics [A_raw | xbar | neff | S | lb] of the minibatch (after the all-reduce, if any):
 //    transitions: var_tran <- (1-rho)(var_tran - 1) + rho * bA * (A_raw + nwin (prior_tran - 1)) + 1
-//                 (quirk Q2: prior_tran - 1 sits in every window's A_i)
+//                 (quirk Q2: prior_tran - 1 sits in every window's A_i); with ada_G (AdaGrad, :1036-1040)
+//                 G += (var_tran - 1)^2, step 1 / G^(1/4) per entry instead of rho
 //    emissions  : eta = [kappa mu, kappa, sigma + kappa mu mu', nu + 2 + D];
 //                 eta <- (1-rho) eta + rho (eta_0 + bE * [xbar, neff, S, neff]);  back to moments.
 //  grid: K workgroups (one NIW factor each) + ceil(K^2 / 256) for the transition factor.
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(64 * NWV) void k_svi_globals(
 __global__ __launch_bounds__(256) void k_svi_global_step(
     const double* __restrict__ packed, const double* __restrict__ prior_tran, double* __restrict__ var_tran,
     double* __restrict__ niw, const double* __restrict__ prior, int K, int D, double rho, double bA,
-    double bE, double nwin, double* __restrict__ lb_keep) {
+    double bE, double nwin, double* __restrict__ lb_keep, double* __restrict__ ada_G) {
   const size_t nmu = (size_t)K * D, nsg = (size_t)K * D * D;
   const int tid = threadIdx.x;
   if ((int)blockIdx.x >= K) {
@@ -257,6 +258,14 @@ __global__ __launch_bounds__(256) void k_svi_global_step(
     if (e < K * K) {
       const double a_inter = packed[e] + nwin * (prior_tran[e] - 1.0);
       const double nat_old = var_tran[e] - 1.0;
+      if (ada_G) {
+        // AdaGrad-scaled step of the transition factor (hmmsgd_metaobs.py:1036-1040): the
+        // accumulated squared natural parameters set a per-entry step 1 / G^(1/4); rho is not used
+        const double g = ada_G[e] + nat_old * nat_old;
+        ada_G[e] = g;
+        const double am = sqrt(sqrt(g));
+        var_tran[e] = ((1.0 - 1.0 / am) * nat_old + (bA * a_inter) / am) + 1.0;
+      } else
       var_tran[e] = ((1.0 - rho) * nat_old + rho * (bA * a_inter)) + 1.0;
     }
     return;

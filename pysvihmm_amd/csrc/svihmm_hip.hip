@@ -1156,7 +1156,8 @@ static double* svi_ptr(svihmm_ctx* h, int which) {
     case 5: return b + 2 * kk + 3 * K;   // prior_logpart
     case 6: return b + 2 * kk + 4 * K;   // rowterm (Dirichlet terms of the transition rows)
     case 7: return b + 2 * kk + 5 * K;   // second var_init slot
-    default: return b + 2 * kk + 6 * K;  // lb of the last two iterations (read by the side-stream ELBO kernel)
+    case 8: return b + 2 * kk + 6 * K;   // lb of the last two iterations (read by the side-stream ELBO kernel)
+    default: return b + 2 * kk + 6 * K + 16;   // ada_G K*K (AdaGrad: accumulated squared natural parameters)
   }
 }
 #ifndef SVI_GW
@@ -1294,7 +1295,8 @@ int svihmm_svi_begin(svihmm_ctx* h, int32_t K, int32_t D, const double* prior_tr
     }
     h->svi_prior_const = pc;
   }
-  CK(ensure(h->svi_state, (2 * kk + 6 * (size_t)K + 16) * sizeof(double)));
+  CK(ensure(h->svi_state, (3 * kk + 6 * (size_t)K + 16) * sizeof(double)));
+  h->svi_adagrad = false;
   CK(ensure(h->svi_prior, (nin + 8) * sizeof(double)));
   CK(ensure(h->niw, nin * sizeof(double) + 64));
   // one staging slot: [var_tran | prior_tran | prior_logpart | prior block | niw block]
@@ -1393,7 +1395,7 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
     hipLaunchKernelGGL(k_svi_global_step, dim3(nblk), dim3(256), (size_t)3 * D * sizeof(double), h->stream,
                        (const double*)h->packed.p, (const double*)svi_ptr(h, 1), svi_ptr(h, 0),
                        (double*)h->niw.p, (const double*)h->svi_prior.p, K, D, rho, bfactA, bfactE,
-                       (double)nwin_total, svi_ptr(h, 8) + (it & 1));
+                       (double)nwin_total, svi_ptr(h, 8) + (it & 1), h->svi_adagrad ? svi_ptr(h, 9) : (double*)nullptr);
     HIPCK(hipGetLastError());
   }
   // the next iteration's globals, ahead of time, forked right behind the global step (its own event:
@@ -1403,6 +1405,30 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
   if (it + 1 < h->svi_maxit) CK(svi_globals(h, h->svi_vi_cur ^ 1));
   CK(svi_refresh_emission(h, it, it & 1, h->svi_ev[2 * it + 1]));
   return 0;
+}
+
+// AdaGrad (hmmsgd_metaobs.py:179-183, 1036-1040): the K x K matrix of accumulated squared natural
+// parameters of the transition factor joins the resident state; NULL switches the branch off.
+int svihmm_svi_set_adagrad(svihmm_ctx* h, const double* ada_G) {
+  if (!h || !h->svi_active) return fail("svihmm_svi_set_adagrad: call svihmm_svi_begin first");
+  CK(set_device(h));
+  h->svi_adagrad = ada_G != nullptr;
+  if (!ada_G) return 0;
+  const size_t kk = (size_t)h->svi_K * h->svi_K;
+  for (size_t i = 0; i < kk; ++i)
+    if (!(ada_G[i] > 0.0 && ada_G[i] < 1.7e308)) return fail("svihmm_svi_set_adagrad: ada_G must be positive and finite");
+  void* pin = nullptr;
+  int slot = 0;
+  CK(pinned(h, kk * sizeof(double), &pin, &slot));
+  std::memcpy(pin, ada_G, kk * sizeof(double));
+  CK(pull_small(h, svi_ptr(h, 9), pin, kk * sizeof(double)));
+  return pin_release(h, slot);
+}
+int svihmm_svi_read_adagrad(svihmm_ctx* h, double* ada_G_out) {
+  if (!h || !h->svi_active || !ada_G_out) return fail("svihmm_svi_read_adagrad: bad arguments");
+  if (!h->svi_adagrad) return fail("svihmm_svi_read_adagrad: the loop runs without AdaGrad");
+  CK(set_device(h));
+  return d2h_sync_small(h, ada_G_out, svi_ptr(h, 9), (size_t)h->svi_K * h->svi_K * sizeof(double));
 }
 
 int svihmm_svi_read_elbo(svihmm_ctx* h, int32_t n, double* out_elbo, double* out_ms) {

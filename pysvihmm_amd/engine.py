@@ -450,6 +450,20 @@ class HipEngine(object):
                                                int(Lm), off, ln, int(flags), float(rho), float(bfactA),
                                                float(bfactE)), "svihmm_svi_iteration")
 
+    def svi_set_adagrad(self, ada_G):
+        """AdaGrad accumulator of the transition factor joins the resident state (reference
+        hmmsgd_metaobs.py:1036-1040); ``None`` switches back to the plain rho step."""
+        if ada_G is None:
+            L.check(self._lib.svihmm_svi_set_adagrad(self._h, None), "svihmm_svi_set_adagrad")
+            return
+        g = L.as_f64(ada_G, (self.K, self.K))
+        L.check(self._lib.svihmm_svi_set_adagrad(self._h, L.dptr(g)), "svihmm_svi_set_adagrad")
+
+    def svi_read_adagrad(self):
+        out = np.empty((self.K, self.K))
+        L.check(self._lib.svihmm_svi_read_adagrad(self._h, L.dptr(out)), "svihmm_svi_read_adagrad")
+        return out
+
     def svi_read_elbo(self, n):
         """(elbo_vec[:n], device milliseconds of each iteration); waits for the device."""
         e = np.empty(int(n)); ms = np.empty(int(n))

@@ -369,7 +369,9 @@ class VBHMM(VariationalHMMBase):
 
     def _svi_device_ok(self):
         eng = self.engine
-        if not hasattr(eng, "svi_begin") or self.adagrad or not self._niw_fastpath():
+        if not hasattr(eng, "svi_begin") or not self._niw_fastpath():
+            return False
+        if self.adagrad and not hasattr(eng, "svi_set_adagrad"):
             return False
         if any(type(e).get_vlb is not Gaussian.get_vlb for e in self.var_emit):
             return False
@@ -390,6 +392,8 @@ class VBHMM(VariationalHMMBase):
         """Device state -> the object's attributes (reference attribute names)."""
         vt, vi, mu, sg, ka, nu = self.engine.svi_read_state()
         self.var_tran, self.var_init = vt, vi
+        if self.adagrad:
+            self.ada_G = self.engine.svi_read_adagrad()
         D = self.D
         for k, G in enumerate(self.var_emit):
             G.mu_mf = mu[k]; G.sigma_mf = sg[k]
@@ -415,6 +419,8 @@ class VBHMM(VariationalHMMBase):
         fac = self._emission_arrays()
         eng.svi_begin(self.prior_tran, self.var_tran, prior, fac,
                       niw_prior_logpart(prior[1], prior[3]), maxit, vlb_logz_sign())
+        if self.adagrad:        # the accumulator of reference :1036-1040 joins the resident state
+            eng.svi_set_adagrad(self.ada_G)
         self.__dict__.pop("_pending_rows", None)
         if hasattr(eng, "on_next_mutation"):
             eng.on_next_mutation(None)

@@ -207,6 +207,8 @@ def trace_metaobs(HM, name, K, D, T, L, S, maxit, miss, seed, ctor_kw=None, infe
         orig_glob(A_inter, emit_inter)
         d["var_tran_new"] = hmm.var_tran.copy()
         d.update({"new_" + k: v for k, v in emit_arrays(hmm.var_emit).items()})
+        if getattr(hmm, "adagrad", False):
+            d["ada_G_new"] = hmm.ada_G.copy()       # (:1036-1040: the accumulated squared gradients)
         per_iter.append(d)
 
     orig_buf = hmm.intermediate_pars_buffer
@@ -242,6 +244,8 @@ def trace_metaobs(HM, name, K, D, T, L, S, maxit, miss, seed, ctor_kw=None, infe
         hmm.select_buffer = select_buffer
         rec["ctor_growBuffer"] = int(bool(ctor_kw.get("growBuffer", False)))
         rec["ctor_bufferBudget"] = int(bool(ctor_kw.get("bufferBudget", False)))
+        if ctor_kw.get("adagrad", False):
+            rec["ctor_adagrad"] = 1
         for k_, v_ in infer_kw.items():
             rec["infer_" + k_] = v_
     hmm.infer(**infer_kw)
@@ -403,7 +407,8 @@ def trace_categorical(HM, HM_asis, name, K, V, T, L, S, seed):
     print("wrote", name, "raises:", rec["cat_intermediate_raises"], rec.get("cat_intermediate_error"))
 
 
-def main():
+def main(only=None):
+    """`only`: regenerate just the fixtures whose names are given (the others stay untouched)."""
     sys.path.insert(0, REPO)
     tmp = tempfile.mkdtemp(prefix="pysvihmm_ref_")
     try:
@@ -413,8 +418,16 @@ def main():
         HM = importlib.import_module("hmmsgd_metaobs")
         CD = importlib.import_module("hmmbatchcd")
         SG = importlib.import_module("hmmbatchsgd")
-        for f in glob.glob(os.path.join(HERE, "*.npz")):
-            os.remove(f)
+        if only:
+            global trace_metaobs, trace_batch, trace_ffbs, trace_categorical
+            keep = {f.__name__: f for f in (trace_metaobs, trace_batch, trace_ffbs, trace_categorical)}
+            gate = lambda f: (lambda M, name, *a, **k: f(M, name, *a, **k) if name in only else None)
+            trace_metaobs, trace_batch, trace_categorical = (gate(keep[n]) for n in
+                                                             ("trace_metaobs", "trace_batch", "trace_categorical"))
+            trace_ffbs = lambda HB_, HM_, name, *a, **k: keep["trace_ffbs"](HB_, HM_, name, *a, **k) if name in only else None
+        else:
+            for f in glob.glob(os.path.join(HERE, "*.npz")):
+                os.remove(f)
         trace_metaobs(HM, "metaobs_K2_D2_L4", 2, 2, 200, 4, 3, 3, 0.0, SEED)
         trace_metaobs(HM, "metaobs_K4_D2_L10_mask", 4, 2, 400, 10, 4, 3, 0.1, SEED + 1)
         trace_metaobs(HM, "metaobs_K16_D8_L16", 16, 8, 600, 16, 3, 2, 0.05, SEED + 2)
@@ -435,9 +448,11 @@ def main():
                       infer_kw=dict(perIter=1, epsilon=1e-2, Lincrement=1, Lcutoff=25))
         HMA = importlib.import_module("hmmsgd_metaobs_asis")
         trace_categorical(HM, HMA, "categorical_K3_V5", 3, 5, 300, 6, 4, SEED + 10)
+        # AdaGrad-scaled transition step (hmmsgd_metaobs.py:1036-1040), round 4
+        trace_metaobs(HM, "adagrad_K4_D2", 4, 2, 400, 8, 4, 5, 0.05, SEED + 11, ctor_kw=dict(adagrad=True))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
 if __name__ == "__main__":
-    main()
+    main(only=set(sys.argv[1:]) or None)

@@ -338,3 +338,21 @@ def test_device_loop_leaves_psi_expectations_and_iteration_times():
     np.testing.assert_allclose(a.mod_tran, b.mod_tran, rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(a.mod_init, b.mod_init, rtol=1e-6, atol=1e-8)
     assert np.all(a.iter_time > 0) and np.all(a.iter_time < 0.01), a.iter_time
+
+
+@pytest.mark.parametrize("device_loop", [None, False], ids=["device_loop", "host_global_step"])
+def test_adagrad_on_gpu(device_loop):
+    """adagrad=True (reference hmmsgd_metaobs.py:1036-1040) no longer drops infer() back to the host
+    loop: the K x K accumulator lives in HBM beside var_tran (k_svi_global_step).  Against the
+    executed reference's trace (fixture adagrad_K4_D2), both routes."""
+    from tests.test_host_logic import _adagrad_model, check_adagrad_trace
+    g, K, hmm = _adagrad_model(None)
+    assert hmm._svi_device_ok()
+    hmm.infer(device_loop=device_loop)
+    assert hmm.engine.name == "hip"
+    check_adagrad_trace(g, K, hmm, 1e-6)
+    # a second infer() continues from the pulled accumulator (it went up and came back)
+    G1 = hmm.ada_G.copy()
+    hmm.maxit = 2
+    hmm.infer(device_loop=device_loop)
+    assert np.all(hmm.ada_G > G1)

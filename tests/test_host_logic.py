@@ -426,3 +426,35 @@ def test_pred_logprob_with_nan_held_out_rows_is_nan_like_the_reference():
         else:
             out.append(hmm.pred_logprob())
     assert np.isfinite(out[0]) and np.isnan(out[1])
+
+
+def _adagrad_model(engine):
+    g = np.load(os.path.join(GOLDEN, "adagrad_K4_D2.npz"))
+    K = int(g["K"])
+    hmm = hmmsgd_metaobs.VBHMM(
+        g["obs"].copy(), np.ones(K), g["prior_tran"], emit_from_fixture(g, K),
+        tau=float(g["tau"]), kappa=float(g["kappa"]), metaobs_half=int(g["L"]), mb_sz=int(g["S"]),
+        mask=g["mask"], init_tran=g["init_tran"], maxit=int(g["maxit"]), seed=int(g["seed"]),
+        adagrad=True, engine=engine)
+    return g, K, hmm
+
+
+def check_adagrad_trace(g, K, hmm, rtol):
+    np.testing.assert_allclose(hmm.var_tran, g["it_var_tran_new"][-1], rtol=rtol, atol=1e-9)
+    np.testing.assert_allclose(hmm.ada_G, g["it_ada_G_new"][-1], rtol=rtol)
+    for k in range(K):
+        np.testing.assert_allclose(hmm.var_emit[k].mu_mf, g["it_new_mu"][-1][k], rtol=rtol, atol=1e-8)
+        np.testing.assert_allclose(hmm.var_emit[k].sigma_mf, g["it_new_sigma"][-1][k], rtol=rtol, atol=1e-7)
+    np.testing.assert_allclose(hmm.elbo_vec, g["elbo_vec"], rtol=max(rtol, 1e-8))
+    np.testing.assert_allclose(hmm.var_x, g["w_var_x"][-1], rtol=rtol, atol=1e-11)
+
+
+@pytest.mark.parametrize("device_loop", [None, False], ids=["engine_loop", "host_loop"])
+def test_adagrad_matches_reference_trace(device_loop):
+    """adagrad=True (reference hmmsgd_metaobs.py:179-183, 1036-1040) against the executed reference:
+    the loop with its state inside the engine (ada_G joins var_tran there) and the host loop."""
+    g, K, hmm = _adagrad_model(OracleEngine())
+    assert int(g["ctor_adagrad"]) == 1
+    assert hmm._svi_device_ok()
+    hmm.infer(device_loop=device_loop)
+    check_adagrad_trace(g, K, hmm, 1e-9)
