@@ -762,6 +762,26 @@ def cpu_baselines(eng, L, pb, step, obs_host):
     return res
 
 
+def cpu_baseline_ffbs(obs, p1, mi_cy, logA, la_gpu, z_gpu, K1, T1):
+    """configs[1]'s CPU leg: the C port's expected log-likelihoods + forward filter in the Cython variant
+    (hmm_fast.pyx:74-93) on ONE host core, and the check of the GPU's lalpha against it (asserted)."""
+    from oracle import ref_c
+    t0 = time.perf_counter()
+    ll = ref_c.lliks_niw(obs, p1["mu"], p1["sigma"], p1["kappa"], p1["nu"])
+    t1 = time.perf_counter()
+    la = ref_c.forward(ll, mi_cy, logA)
+    t2 = time.perf_counter()
+    err = float(np.max(np.abs(la_gpu - la) / (1.0 + np.abs(la))))
+    assert err < 1e-9, "ffbs lalpha vs the C port's Cython-variant forward filter: %g" % err
+    assert z_gpu.shape == (T1,) and z_gpu.min() >= 0 and z_gpu.max() < K1
+    return {"value": T1 * K1 / (t2 - t0), "unit": "updates/s", "cores": 1, "kind": "port",
+            "ms": (t2 - t0) * 1e3, "ms_lliks": (t1 - t0) * 1e3, "ms_forward_filter": (t2 - t1) * 1e3,
+            "sample": "the whole T=1e5 sequence: expected log-likelihoods + the forward filter of "
+                      "hmm_fast.pyx:80-93 (K^2 log-add-exp per step, log(var_tran + DBL_EPSILON)) in plain C on "
+                      "one core; the O(T K) backward sampling pass is not included",
+            "gpu_lalpha_vs_port_max_rel_err": err}
+
+
 def config1_record(eng, L, with_cpu=True):
     """BASELINE configs[1]: K=16, D=8 full-covariance NIW-Gaussian HMM, T=1e5, "single-GPU E-step vs
     Cython hmm_fast": the windowed epoch step, the full-chain E-step (`full_local_update`) and
@@ -821,23 +841,7 @@ def config1_record(eng, L, with_cpu=True):
                          "note": "hmm_fast.FFBS semantics: forward filter + backward sampling, z[T] and lalpha[T,K] "
                                  "(12.8 MB) back on the host"}}
     if with_cpu:
-        from oracle import ref_c
-        t0 = time.perf_counter()
-        ll = ref_c.lliks_niw(obs, p1["mu"], p1["sigma"], p1["kappa"], p1["nu"])
-        t1 = time.perf_counter()
-        la = ref_c.forward(ll, mi_cy, logA)
-        t2 = time.perf_counter()
-        err = float(np.max(np.abs(holder["la"] - la) / (1.0 + np.abs(la))))
-        assert err < 1e-9, "ffbs lalpha vs the C port's Cython-variant forward filter: %g" % err
-        z = holder["z"]
-        assert z.shape == (T1,) and z.min() >= 0 and z.max() < K1
-        res["cpu_baseline_ffbs"] = {
-            "value": T1 * K1 / (t2 - t0), "unit": "updates/s", "cores": 1, "kind": "port",
-            "ms": (t2 - t0) * 1e3, "ms_lliks": (t1 - t0) * 1e3, "ms_forward_filter": (t2 - t1) * 1e3,
-            "sample": "the whole T=1e5 sequence: expected log-likelihoods + the forward filter of "
-                      "hmm_fast.pyx:80-93 (K^2 log-add-exp per step, log(var_tran + DBL_EPSILON)) in plain C on "
-                      "one core; the O(T K) backward sampling pass is not included",
-            "gpu_lalpha_vs_port_max_rel_err": err}
+        res["cpu_baseline_ffbs"] = cpu_baseline_ffbs(obs, p1, mi_cy, logA, holder["la"], holder["z"], K1, T1)
     return res
 
 

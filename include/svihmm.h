@@ -35,7 +35,8 @@
 extern "C" {
 #endif
 
-/* 3: svihmm_export_packed / svihmm_import_packed, svihmm_svi_set_adagrad / _read_adagrad added, slot mask
+/* 3: svihmm_export_packed / svihmm_import_packed, svihmm_svi_set_adagrad / _read_adagrad,
+ *    svihmm_svi_begin_diag / _begin_cat / _read_factors added, slot mask
  *    of svihmm_profile_enable (round 4; nothing else changed meaning).
  * 2: svihmm_get_shift added, svihmm_shift_obs no longer changes what later calls mean (the shift is
  *    the handle's business), svihmm_set_emission_diag added; 1 was rounds 1-2 (svi_*,
@@ -263,6 +264,23 @@ int svihmm_svi_begin(svihmm_ctx* h, int32_t K, int32_t D, const double* prior_tr
 int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32_t B,
                          int32_t nwin_total, int32_t Lm, int32_t inner_off, int32_t inner_len,
                          uint32_t flags, double rho, double bfactA, double bfactE);
+/* The same loop for the two families whose factors are element-wise (round 4):
+ * svihmm_svi_begin_diag: distributions.DiagonalGaussian (per dimension a normal-inverse-gamma factor;
+ *   prior_blk / factor_blk = [mu | nus | alphas | betas], each [K][D], means in the caller's
+ *   coordinates): the Gaussian branch's blend hmmsgd_metaobs.py:1050-1069 in this family's natural
+ *   parameters [nu mu, nu, 2 beta + nu mu^2, 2 alpha], theta by the device builder, ELBO term
+ *   -KL(q || prior).  (The reference dispatches on Gaussian / Categorical only: an extension.)
+ * svihmm_svi_begin_cat: Categorical emitters over ONE integer-valued observation column (D = 1),
+ *   Dirichlet factors alpha[K][V] and prior alpha0[K][V]: global step hmmsgd_metaobs.py:1071-1084 with
+ *   every window's alpha_0 + counts - 1 (:907-926), the E log theta table rebuilt on the device.
+ * svihmm_svi_iteration / svihmm_svi_read_elbo / svihmm_svi_set_adagrad work for all three;
+ * svihmm_svi_read_factors hands back the state in the family's block layout (NIW: [mu | sigma |
+ * kappa | nu]; any of the three pointers may be NULL). */
+int svihmm_svi_begin_diag(svihmm_ctx* h, int32_t K, int32_t D, const double* prior_tran, const double* var_tran,
+                          const double* prior_blk, const double* factor_blk, int32_t maxit);
+int svihmm_svi_begin_cat(svihmm_ctx* h, int32_t K, int32_t V, const double* prior_tran, const double* var_tran,
+                         const double* alpha0, const double* alpha, int32_t maxit);
+int svihmm_svi_read_factors(svihmm_ctx* h, double* var_tran, double* var_init, double* factors_out);
 /* AdaGrad-scaled transition step (hmmsgd_metaobs.py:179-183 ada_G = ones, :1036-1040
  * ada_G += nats_old^2; adaMatrix = ada_G^.25; nats_new = (1 - 1/adaMatrix) nats_old + A_up/adaMatrix):
  * after svihmm_svi_begin, svihmm_svi_set_adagrad uploads the K x K accumulator (NULL: the plain rho

@@ -325,6 +325,77 @@ class OracleEngine(object):
                          conv="pybasicbayes" if zsign > 0 else "bishop", var_init=None)
         self.K = self._svi["var_tran"].shape[0]
 
+    def svi_begin_diag(self, prior_tran, var_tran, prior, factors, maxit):
+        self._pre_mutate()
+        c = lambda a: np.array(a, dtype=np.float64)
+        self._svi = dict(prior_tran=c(prior_tran), var_tran=c(var_tran), prior=[c(a) for a in prior],
+                         mf=[c(a) for a in factors], elbo=np.full(int(maxit), np.nan), var_init=None, family="diag")
+        self.K = self._svi["var_tran"].shape[0]
+
+    def svi_begin_cat(self, prior_tran, var_tran, alpha0, alpha, maxit):
+        self._pre_mutate()
+        c = lambda a: np.array(a, dtype=np.float64)
+        self._svi = dict(prior_tran=c(prior_tran), var_tran=c(var_tran), prior=c(alpha0), mf=c(alpha),
+                         elbo=np.full(int(maxit), np.nan), var_init=None, family="cat")
+        self.K = self._svi["var_tran"].shape[0]
+
+    def svi_read_factors(self):
+        sv = self._svi
+        fam = sv.get("family", "niw")
+        fac = sv["mf"].copy() if fam == "cat" else tuple(a.copy() for a in sv["mf"])
+        return sv["var_tran"].copy(), sv["var_init"].copy(), fac
+
+    def _svi_tran_step(self, A_raw, nwin_total, rho, bfactA):
+        sv = self._svi
+        A_inter = A_raw + nwin_total * (sv["prior_tran"] - 1.)
+        if sv.get("ada_G") is not None:            # hmmsgd_metaobs.py:1036-1040
+            nats_old = sv["var_tran"] - 1.
+            sv["ada_G"] = sv["ada_G"] + nats_old ** 2
+            ada = sv["ada_G"] ** .25
+            sv["var_tran"] = ((1. - 1.0 / ada) * nats_old + (bfactA * A_inter) / ada) + 1.
+        else:
+            sv["var_tran"] = ((1. - rho) * (sv["var_tran"] - 1.) + rho * (bfactA * A_inter)) + 1.
+
+    def _svi_iteration_family(self, it, starts, nwin_total, Lm, flags, rho, bfactA, bfactE, inner):
+        """The element-wise families (hmmsgd_metaobs.py:1050-1084 with their natural parameters)."""
+        from scipy.special import digamma
+        from pysvihmm_amd.distributions import Categorical, DiagonalGaussian
+        sv = self._svi
+        K = self.K
+        if sv["family"] == "diag":
+            self.set_emission_diag(*sv["mf"])
+        else:
+            a = sv["mf"]
+            self.set_emission_cat(digamma(a) - digamma(a.sum(1))[:, None])
+        self.estep(starts, Lm, flags=flags, read=False, inner=inner)
+        self.allreduce_packed()
+        st = self._packed
+        self._svi_tran_step(st.A_raw, nwin_total, rho, bfactA)
+        vlb = 0.
+        if sv["family"] == "diag":
+            D = sv["mf"][0].shape[1]
+            new = [np.empty_like(a) for a in sv["mf"]]
+            for k in range(K):
+                n_old = DiagonalGaussian.to_natural(*[a[k] for a in sv["mf"]])
+                n_0 = DiagonalGaussian.to_natural(*[a[k] for a in sv["prior"]])
+                e = np.stack([st.xbar[k], np.full(D, st.neff[k]), st.xsq[k], np.full(D, st.neff[k])])
+                res = DiagonalGaussian.from_natural((1. - rho) * n_old + rho * (n_0 + bfactE * e))
+                for i in range(4):
+                    new[i][k] = res[i]
+                g = DiagonalGaussian(mu=res[0], sigmas=np.ones(D), mu_0=sv["prior"][0][k], nus_0=sv["prior"][1][k],
+                                     alphas_0=sv["prior"][2][k], betas_0=sv["prior"][3][k])   # (no random draws)
+                g._set_mf(*res)
+                vlb += g.get_vlb()
+            sv["mf"] = new
+        else:
+            a0 = sv["prior"]
+            inter = nwin_total * (a0 - 1.) + st.counts
+            sv["mf"] = ((1. - rho) * (sv["mf"] - 1.) + rho * bfactE * inter) + 1.
+            for k in range(K):
+                vlb += Categorical(weights=np.full(a0.shape[1], 1.0 / a0.shape[1]), alphav_0=a0[k],
+                                   alpha_mf=sv["mf"][k]).get_vlb()       # (weights given: no random draw)
+        sv["elbo"][it] = st.lb[0] + R.dirichlet_lower_bound(sv["prior_tran"], sv["var_tran"]) + vlb
+
     def svi_iteration(self, it, starts, nwin_total, Lm, flags, rho, bfactA, bfactE, inner=None):
         """hmmsgd_metaobs.py:351 .. 445 for one iteration (stationary init :413-418 by
         np.linalg.eig as the reference does, psi :502-504, the minibatch loop, global_update
@@ -334,6 +405,8 @@ class OracleEngine(object):
         sv["var_init"] = R.stationary_init(sv["var_tran"])
         mod_init, ltran = R.psi_expectations(sv["var_init"], sv["var_tran"])
         self.set_globals(mod_init, ltran)
+        if sv.get("family", "niw") != "niw":
+            return self._svi_iteration_family(it, starts, nwin_total, Lm, flags, rho, bfactA, bfactE, inner)
         self.set_emission_niw(*sv["mf"])
         self.estep(starts, Lm, flags=flags, read=False, inner=inner)
         self.allreduce_packed()

@@ -64,6 +64,9 @@ SIGNATURES = {
     "svihmm_svi_iteration": (C.c_int, [C.c_void_p, C.c_int32, _c_int64_p, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_int32, C.c_uint32, C.c_double, C.c_double, C.c_double]),
     "svihmm_svi_read_elbo": (C.c_int, [C.c_void_p, C.c_int32, _c_double_p, _c_double_p]),
+    "svihmm_svi_begin_diag": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32] + [_c_double_p] * 4 + [C.c_int32]),
+    "svihmm_svi_begin_cat": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32] + [_c_double_p] * 4 + [C.c_int32]),
+    "svihmm_svi_read_factors": (C.c_int, [C.c_void_p] + [_c_double_p] * 3),
     "svihmm_svi_set_adagrad": (C.c_int, [C.c_void_p, _c_double_p]),
     "svihmm_svi_read_adagrad": (C.c_int, [C.c_void_p, _c_double_p]),
     "svihmm_svi_read_state": (C.c_int, [C.c_void_p] + [_c_double_p] * 6),

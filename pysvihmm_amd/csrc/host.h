@@ -162,6 +162,7 @@ struct svihmm_ctx {
   // prior_logpart[K]; prior block [mu0 | sigma0 | kappa0 | nu0]; GTH scratch; elbo / event ring
   Buf svi_state, svi_prior, svi_work, commtmp;
   int svi_K = 0, svi_D = 0, svi_maxit = 0;
+  int svi_family = 0;       // 0 NIW, 1 diagonal Gaussian, 2 Categorical
   double svi_zsign = 1.0, svi_prior_const = 0.0;
   double* svi_elbo = nullptr; int svi_elbo_cap = 0;      // pinned + mapped: elbo_vec
   std::vector<hipEvent_t> svi_ev;                        // iteration boundaries (iter_time)

@@ -244,6 +244,24 @@ __global__ __launch_bounds__(64 * NWV) void k_svi_globals(
 //  niw = [mu K*D | sigma K*D*D | kappa K | nu K] (the E-step's parameter block, updated in place);
 //  prior = [mu0 K*D | sigma0 K*D*D | kappa0 K | nu0 K].
 // ------------------------------------------------------------------------------------
+// entry e of the transition factor (shared by the families' global-step kernels)
+__device__ __forceinline__ void svi_tran_step(int e, int K, const double* __restrict__ packed,
+                                              const double* __restrict__ prior_tran, double* __restrict__ var_tran,
+                                              double rho, double bA, double nwin, double* __restrict__ ada_G) {
+  if (e >= K * K) return;
+  const double a_inter = packed[e] + nwin * (prior_tran[e] - 1.0);
+  const double nat_old = var_tran[e] - 1.0;
+  if (ada_G) {
+    // AdaGrad-scaled step of the transition factor (hmmsgd_metaobs.py:1036-1040): the
+    // accumulated squared natural parameters set a per-entry step 1 / G^(1/4); rho is not used
+    const double g = ada_G[e] + nat_old * nat_old;
+    ada_G[e] = g;
+    const double am = sqrt(sqrt(g));
+    var_tran[e] = ((1.0 - 1.0 / am) * nat_old + (bA * a_inter) / am) + 1.0;
+  } else {
+    var_tran[e] = ((1.0 - rho) * nat_old + rho * (bA * a_inter)) + 1.0;
+  }
+}
 __global__ __launch_bounds__(256) void k_svi_global_step(
     const double* __restrict__ packed, const double* __restrict__ prior_tran, double* __restrict__ var_tran,
     double* __restrict__ niw, const double* __restrict__ prior, int K, int D, double rho, double bA,
@@ -255,19 +273,7 @@ __global__ __launch_bounds__(256) void k_svi_global_step(
     // the minibatch's local bound, kept for the ELBO kernel (which runs on a side stream while
     // the next E-step already rewrites `packed`)
     if (e == 0) *lb_keep = packed[(size_t)K * K + nmu + K + nsg];
-    if (e < K * K) {
-      const double a_inter = packed[e] + nwin * (prior_tran[e] - 1.0);
-      const double nat_old = var_tran[e] - 1.0;
-      if (ada_G) {
-        // AdaGrad-scaled step of the transition factor (hmmsgd_metaobs.py:1036-1040): the
-        // accumulated squared natural parameters set a per-entry step 1 / G^(1/4); rho is not used
-        const double g = ada_G[e] + nat_old * nat_old;
-        ada_G[e] = g;
-        const double am = sqrt(sqrt(g));
-        var_tran[e] = ((1.0 - 1.0 / am) * nat_old + (bA * a_inter) / am) + 1.0;
-      } else
-      var_tran[e] = ((1.0 - rho) * nat_old + rho * (bA * a_inter)) + 1.0;
-    }
+    svi_tran_step(e, K, packed, prior_tran, var_tran, rho, bA, nwin, ada_G);
     return;
   }
   const int k = blockIdx.x;
@@ -313,6 +319,22 @@ __global__ __launch_bounds__(256) void k_svi_global_step(
 //  prior_logpart[k] = invwishart_log_partitionfunction(sigma_0[k], nu_0[k]) (host, constant);
 //  zsign: +1 pybasicbayes' sign of that term, -1 Bishop's (see distributions.Gaussian.get_vlb).
 // ------------------------------------------------------------------------------------
+// Dirichlet energy + entropy of transition row i for the UPDATED var_tran (one wave)
+__device__ __forceinline__ void svi_rowterm(int i, int K, int lane, const double* __restrict__ prior_tran,
+                                            const double* __restrict__ var_tran, double* __restrict__ rowterm) {
+  double sv = 0.0;
+  for (int j = lane; j < K; j += 64) sv += var_tran[(size_t)i * K + j];
+  sv = wave_sum(sv);
+  const double dgs = digamma_d(sv + SVI_EPS);
+  double acc = 0.0;
+  for (int j = lane; j < K; j += 64) {
+    const double q = var_tran[(size_t)i * K + j], p = prior_tran[(size_t)i * K + j];
+    const double elog = digamma_d(q + SVI_EPS) - dgs;
+    acc += ((p - 1.0) - (q - 1.0)) * elog + lgamma(q + SVI_EPS);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) rowterm[i] = acc - lgamma(sv + SVI_EPS);
+}
 __global__ __launch_bounds__(64) void k_svi_vlb(
     const double* __restrict__ theta, const int* __restrict__ fab, int F, int D, int Kp,
     const double* __restrict__ niw, const double* __restrict__ logdet, const double* __restrict__ prior,
@@ -324,19 +346,7 @@ __global__ __launch_bounds__(64) void k_svi_vlb(
     // Dirichlet energy + entropy of transition row i for the UPDATED var_tran (hmmbase.
     // dirichlet_elbo, reference hmmsgd_metaobs.py:277-292) minus the prior-only constants
     // (lgamma of the prior row: added once by the host-supplied prior_const in k_svi_elbo)
-    const int i = (int)blockIdx.x - K;
-    double sv = 0.0;
-    for (int j = lane; j < K; j += 64) sv += var_tran[(size_t)i * K + j];
-    sv = wave_sum(sv);
-    const double dgs = digamma_d(sv + SVI_EPS);
-    double acc = 0.0;
-    for (int j = lane; j < K; j += 64) {
-      const double q = var_tran[(size_t)i * K + j], p = prior_tran[(size_t)i * K + j];
-      const double elog = digamma_d(q + SVI_EPS) - dgs;
-      acc += ((p - 1.0) - (q - 1.0)) * elog + lgamma(q + SVI_EPS);
-    }
-    acc = wave_sum(acc);
-    if (lane == 0) rowterm[i] = acc - lgamma(sv + SVI_EPS);
+    svi_rowterm((int)blockIdx.x - K, K, lane, prior_tran, var_tran, rowterm);
     return;
   }
   const int k = blockIdx.x;
@@ -389,4 +399,109 @@ __global__ __launch_bounds__(64) void k_svi_elbo(int K, const double* __restrict
     for (int i = 0; i < K; ++i) d += rowterm[i];
     *elbo_out = lb[0] + (d + prior_const) + v;
   }
+}
+
+
+// ------------------------------------------------------------------------------------
+//  G2' / G3': the same two steps for the families whose factors are element-wise (round 4):
+//    fam 1, diagonal Gaussian (distributions.DiagonalGaussian: per dimension a normal-inverse-gamma
+//      factor; blocks [mu | nus | alphas | betas], each [K][W = D]); packed = [A_raw | xbar K*D | neff K |
+//      xsq K*D | lb].  Blend in the natural parameters eta = [nu mu, nu, 2 beta + nu mu^2, 2 alpha]
+//      (hmmsgd_metaobs.py:1050-1069 with this family's eta): eta <- (1-rho) eta + rho (eta_0 +
+//      bE [xbar, neff, xsq, neff]); ELBO term: -KL(q || prior) summed over the dimensions
+//      (distributions.DiagonalGaussian.get_vlb).
+//    fam 2, Categorical (hmmsgd_metaobs.py:907-926, 1071-1084): Dirichlet factors alpha[K][W = V];
+//      packed = [A_raw | counts K*V | lb]; every window contributes alpha_0 + counts - 1, so
+//      alpha <- (1-rho)(alpha - 1) + rho bE (nwin (alpha_0 - 1) + counts) + 1; ELBO term as
+//      distributions.Categorical.get_vlb.
+//  grid: nem = ceil(K W / 256) element blocks + ceil(K^2 / 256) transition blocks.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_svi_global_step_simple(
+    int fam, const double* __restrict__ packed, const double* __restrict__ prior_tran,
+    double* __restrict__ var_tran, double* __restrict__ blk, const double* __restrict__ prior, int K, int W,
+    double rho, double bA, double bE, double nwin, double* __restrict__ lb_keep, double* __restrict__ ada_G,
+    int nem) {
+  const int tid = threadIdx.x;
+  const size_t n = (size_t)K * W;
+  if ((int)blockIdx.x >= nem) {
+    const int e = ((int)blockIdx.x - nem) * 256 + tid;
+    if (e == 0) *lb_keep = packed[(size_t)K * K + (fam == 1 ? 2 * n + K : n)];
+    svi_tran_step(e, K, packed, prior_tran, var_tran, rho, bA, nwin, ada_G);
+    return;
+  }
+  const size_t e = (size_t)blockIdx.x * 256 + tid;
+  if (e >= n) return;
+  if (fam == 2) {
+    const double counts = packed[(size_t)K * K + e];
+    const double inter = nwin * (prior[e] - 1.0) + counts;
+    blk[e] = ((1.0 - rho) * (blk[e] - 1.0) + (rho * bE) * inter) + 1.0;
+    return;
+  }
+  const int k = (int)(e / W);
+  const double xb = packed[(size_t)K * K + e], ne = packed[(size_t)K * K + n + k];
+  const double xs = packed[(size_t)K * K + n + K + e];
+  const double m = blk[e], nu = blk[n + e], al = blk[2 * n + e], be = blk[3 * n + e];
+  const double m0 = prior[e], nu0 = prior[n + e], al0 = prior[2 * n + e], be0 = prior[3 * n + e];
+  const double e0 = (1.0 - rho) * (nu * m) + rho * (nu0 * m0 + bE * xb);
+  const double e1 = (1.0 - rho) * nu + rho * (nu0 + bE * ne);
+  const double e2 = (1.0 - rho) * (2.0 * be + nu * m * m) + rho * ((2.0 * be0 + nu0 * m0 * m0) + bE * xs);
+  const double e3 = (1.0 - rho) * (2.0 * al) + rho * (2.0 * al0 + bE * ne);
+  const double mn = e0 / e1;
+  blk[e] = mn; blk[n + e] = e1; blk[2 * n + e] = 0.5 * e3; blk[3 * n + e] = 0.5 * (e2 - e1 * mn * mn);
+}
+
+// grid 2 K waves: [0, K) the factors' ELBO terms vlb[k], [K, 2K) the transition rows' terms
+__global__ __launch_bounds__(64) void k_svi_vlb_simple(
+    int fam, const double* __restrict__ blk, const double* __restrict__ prior, int K, int W,
+    double* __restrict__ vlb, const double* __restrict__ prior_tran, const double* __restrict__ var_tran,
+    double* __restrict__ rowterm) {
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x >= K) {
+    svi_rowterm((int)blockIdx.x - K, K, lane, prior_tran, var_tran, rowterm);
+    return;
+  }
+  const int k = blockIdx.x;
+  const size_t n = (size_t)K * W, o = (size_t)k * W;
+  if (fam == 2) {
+    double sa = 0.0, s0 = 0.0;
+    for (int v = lane; v < W; v += 64) { sa += blk[o + v]; s0 += prior[o + v]; }
+    sa = wave_sum(sa); s0 = wave_sum(s0);
+    const double dgs = digamma_d(sa);
+    double acc = 0.0;
+    for (int v = lane; v < W; v += 64) {
+      const double a = blk[o + v], a0 = prior[o + v];
+      const double el = digamma_d(a) - dgs;
+      acc += (a0 - a) * el - lgamma(a0) + lgamma(a);      // ((a0-1) - (a-1)) el - gammaln(a0) + gammaln(a)
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) vlb[k] = acc + lgamma(s0) - lgamma(sa);
+    return;
+  }
+  const double LN2PI = 1.8378770664093454836;
+  double acc = 0.0;
+  for (int d = lane; d < W; d += 64) {
+    const double m = blk[o + d], nu = blk[n + o + d], al = blk[2 * n + o + d], be = blk[3 * n + o + d];
+    const double m0 = prior[o + d], nu0 = prior[n + o + d], al0 = prior[2 * n + o + d], be0 = prior[3 * n + o + d];
+    const double elog = log(be) - digamma_d(al);          // E log sigma^2
+    const double prec = al / be;                          // E 1 / sigma^2
+    const double dm = m - m0;
+    const double pp = 0.5 * (log(nu0) - LN2PI) - (al0 + 1.5) * elog - 0.5 * nu0 * (1.0 / nu + dm * dm * prec)
+                      + al0 * log(be0) - lgamma(al0) - be0 * prec;
+    const double qq = 0.5 * (log(nu) - LN2PI) - (al + 1.5) * elog - 0.5 + al * log(be) - lgamma(al) - al;
+    acc += pp - qq;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) vlb[k] = acc;
+}
+
+// E log theta[v][k] = psi(alpha[k][v]) - psi(sum_v alpha[k][v]): the Categorical lookup table
+// (layout [V][K], see k_emission_cat) from the resident Dirichlet factors; one wave per state
+__global__ __launch_bounds__(64) void k_cat_table(const double* __restrict__ alpha, int K, int V,
+                                                  double* __restrict__ table) {
+  const int k = blockIdx.x, lane = threadIdx.x;
+  double s = 0.0;
+  for (int v = lane; v < V; v += 64) s += alpha[(size_t)k * V + v];
+  s = wave_sum(s);
+  const double dgs = digamma_d(s);
+  for (int v = lane; v < V; v += 64) table[(size_t)v * K + k] = digamma_d(alpha[(size_t)k * V + v]) - dgs;
 }

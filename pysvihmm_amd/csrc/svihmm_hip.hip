@@ -229,7 +229,7 @@ static int params_follow_centre(svihmm_ctx* h, const double* delta) {
   bool any = false;
   for (int d = 0; d < D; ++d) any = any || delta[d] != 0.0;
   const bool live = h->have_emission && !h->emis_cat && h->eD == D && h->niw.p;   // (NIW or diagonal: means lead the block)
-  const bool svi = h->svi_active && h->svi_D == D;
+  const bool svi = h->svi_active && h->svi_D == D && h->svi_family != 2;   // (Categorical: no means)
   if (!any || (!live && !svi)) return 0;
   CK(wait_side_streams(h));
   if (live) CK(drop_auto_status(h));      // this rebuild supersedes what an earlier automatic one reported
@@ -1221,13 +1221,23 @@ static int svi_globals(svihmm_ctx* h, int slot) {
 // their ELBO term vlb[] and, with elbo_it >= 0, elbo_vec[elbo_it] on the side stream -- only the
 // ELBO trace needs them, so they stay off the critical path of the iteration chain.
 static int svi_refresh_emission(svihmm_ctx* h, int elbo_it, int lb_slot, hipEvent_t after_theta = nullptr) {
-  const int K = h->svi_K, D = h->svi_D;
+  const int K = h->svi_K, D = h->svi_D, fam = h->svi_family;
   if (!h->stream3) HIPCK(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
   if (!h->svi_ec) {
     HIPCK(hipEventCreateWithFlags(&h->svi_ec, hipEventDisableTiming));
     HIPCK(hipEventCreateWithFlags(&h->svi_ed, hipEventDisableTiming));
   }
-  CK(launch_niw_to_theta(h, K, D, svi_ptr(h, 4)));
+  if (fam == 0) CK(launch_niw_to_theta(h, K, D, svi_ptr(h, 4)));
+  else if (fam == 1) CK(launch_diag_to_theta(h, K, D));
+  else {
+    // E log theta[v][k] = psi(alpha_kv) - psi(sum_v alpha_kv) (what hmmbase._push_emission uploads)
+    ProfScope ps(h, KS_MISC);
+    hipLaunchKernelGGL(k_cat_table, dim3(K), dim3(64), 0, h->stream, (const double*)h->niw.p, K, h->V,
+                       (double*)h->cat_table.p);
+    HIPCK(hipGetLastError());
+    h->eK = K; h->eD = 1; h->Kp = K > 64 ? (K + 63) / 64 * 64 : (K + 15) / 16 * 16;
+    h->have_emission = true; h->emis_cat = true; h->emis_diag = false; h->uw_valid = false;
+  }
   h->lin_stale = true;
   hipStream_t s2 = h->stream3;
   // (the iteration's end-of-iteration timing event doubles as the fork point of the ELBO kernels)
@@ -1236,11 +1246,16 @@ static int svi_refresh_emission(svihmm_ctx* h, int elbo_it, int lb_slot, hipEven
   HIPCK(hipStreamWaitEvent(s2, fork, 0));
   {
     ProfScope ps(h, KS_MISC, s2);
-    hipLaunchKernelGGL(k_svi_vlb, dim3(2 * K), dim3(64), 0, s2, (const double*)h->theta.p,
-                       (const int*)h->fab.p, h->F, D, h->Kp, (const double*)h->niw.p,
-                       (const double*)svi_ptr(h, 4), (const double*)h->svi_prior.p,
-                       (const double*)svi_ptr(h, 5), h->svi_zsign, K, svi_ptr(h, 3),
-                       (const double*)svi_ptr(h, 1), (const double*)svi_ptr(h, 0), svi_ptr(h, 6));
+    if (fam == 0)
+      hipLaunchKernelGGL(k_svi_vlb, dim3(2 * K), dim3(64), 0, s2, (const double*)h->theta.p,
+                         (const int*)h->fab.p, h->F, D, h->Kp, (const double*)h->niw.p,
+                         (const double*)svi_ptr(h, 4), (const double*)h->svi_prior.p,
+                         (const double*)svi_ptr(h, 5), h->svi_zsign, K, svi_ptr(h, 3),
+                         (const double*)svi_ptr(h, 1), (const double*)svi_ptr(h, 0), svi_ptr(h, 6));
+    else
+      hipLaunchKernelGGL(k_svi_vlb_simple, dim3(2 * K), dim3(64), 0, s2, fam, (const double*)h->niw.p,
+                         (const double*)h->svi_prior.p, K, fam == 1 ? D : h->V, svi_ptr(h, 3),
+                         (const double*)svi_ptr(h, 1), (const double*)svi_ptr(h, 0), svi_ptr(h, 6));
     if (elbo_it >= 0) {
       double* delbo = nullptr;
       HIPCK(hipHostGetDevicePointer((void**)&delbo, h->svi_elbo, 0));
@@ -1255,20 +1270,17 @@ static int svi_refresh_emission(svihmm_ctx* h, int elbo_it, int lb_slot, hipEven
   return 0;
 }
 
-int svihmm_svi_begin(svihmm_ctx* h, int32_t K, int32_t D, const double* prior_tran, const double* var_tran,
-                     const double* mu0, const double* sigma0, const double* kappa0, const double* nu0,
-                     const double* prior_logpart, const double* mu, const double* sigma,
-                     const double* kappa, const double* nu, int32_t maxit, double zsign) {
-  if (!h || K <= 0 || D <= 0 || !prior_tran || !var_tran || !mu0 || !sigma0 || !kappa0 || !nu0 ||
-      !prior_logpart || !mu || !sigma || !kappa || !nu || maxit <= 0)
-    return fail("svihmm_svi_begin: bad arguments");
+// What the three families' begin calls share: range check of the transition factor, the resident
+// state (var_tran | prior_tran | ...), the ELBO / event rings.  The caller uploads its prior / factor
+// blocks between svi_begin_common and svi_begin_finish.
+static int svi_begin_common(svihmm_ctx* h, int K, int D, const double* prior_tran, const double* var_tran,
+                            int maxit, int family) {
   if (K > 1024) return fail("svihmm_svi_begin: K > 1024 unsupported");
   if (h->D != D) return fail("svihmm_svi_begin: D does not match the resident observations");
   CK(set_device(h));
   CK(wait_side_streams(h));
   CK(drop_auto_status(h));
-  const size_t kk = (size_t)K * K, nmu = (size_t)K * D, nsg = (size_t)K * D * D;
-  const size_t nin = nmu + nsg + 2 * (size_t)K;
+  const size_t kk = (size_t)K * K;
   {
     // The global step is var_tran <- (1 - rho) var_tran + rho (1 + bA (A_raw + nwin (prior_tran - 1)))
     // with bA nwin ~ T / 2L >> 1 (quirk Q2): only for prior_tran >= 1 is every later entry bounded
@@ -1285,7 +1297,7 @@ int svihmm_svi_begin(svihmm_ctx* h, int32_t K, int32_t D, const double* prior_tr
     h->exact_log = false;
     h->f32_ok = h->svi_f32_ok;
   }
-  h->svi_K = K; h->svi_D = D; h->svi_maxit = maxit; h->svi_zsign = zsign;
+  h->svi_K = K; h->svi_D = D; h->svi_maxit = maxit; h->svi_family = family;
   {   // sum_i [lgamma(sum_j p_ij + eps) - sum_j lgamma(p_ij + eps)]: the prior-only part of the rows' energy
     double pc = 0.0;
     for (int i = 0; i < K; ++i) {
@@ -1297,28 +1309,12 @@ int svihmm_svi_begin(svihmm_ctx* h, int32_t K, int32_t D, const double* prior_tr
   }
   CK(ensure(h->svi_state, (3 * kk + 6 * (size_t)K + 16) * sizeof(double)));
   h->svi_adagrad = false;
-  CK(ensure(h->svi_prior, (nin + 8) * sizeof(double)));
-  CK(ensure(h->niw, nin * sizeof(double) + 64));
-  // one staging slot: [var_tran | prior_tran | prior_logpart | prior block | niw block]
-  const size_t tot = 2 * kk + K + 2 * nin;
   void* pin = nullptr;
   int slot = 0;
-  CK(pinned(h, tot * sizeof(double), &pin, &slot));
+  CK(pinned(h, 2 * kk * sizeof(double), &pin, &slot));
   double* hp = (double*)pin;
   std::memcpy(hp, var_tran, kk * 8); std::memcpy(hp + kk, prior_tran, kk * 8);
-  std::memcpy(hp + 2 * kk, prior_logpart, K * 8);
-  double* pp = hp + 2 * kk + K;
-  std::memcpy(pp, mu0, nmu * 8); std::memcpy(pp + nmu, sigma0, nsg * 8);
-  to_centred(h, pp, K, D);             // the loop's state lives in the resident copy's coordinates
-  std::memcpy(pp + nmu + nsg, kappa0, K * 8); std::memcpy(pp + nmu + nsg + K, nu0, K * 8);
-  double* np_ = pp + nin;
-  std::memcpy(np_, mu, nmu * 8); std::memcpy(np_ + nmu, sigma, nsg * 8);
-  to_centred(h, np_, K, D);
-  std::memcpy(np_ + nmu + nsg, kappa, K * 8); std::memcpy(np_ + nmu + nsg + K, nu, K * 8);
   CK(pull_small(h, svi_ptr(h, 0), hp, 2 * kk * 8));
-  CK(pull_small(h, svi_ptr(h, 5), hp + 2 * kk, K * 8));
-  CK(pull_small(h, h->svi_prior.p, pp, nin * 8));
-  CK(pull_small(h, h->niw.p, np_, nin * 8));
   CK(pin_release(h, slot));
   if (h->svi_elbo_cap < maxit) {
     if (h->svi_elbo) hipHostFree(h->svi_elbo);
@@ -1334,13 +1330,105 @@ int svihmm_svi_begin(svihmm_ctx* h, int32_t K, int32_t D, const double* prior_tr
   }
   h->svi_ev_begin.assign(maxit, 0);
   h->svi_last_it = -1;
+  return 0;
+}
+static int svi_begin_finish(svihmm_ctx* h) {
   HIPCK(hipStreamSynchronize(h->stream));          // (the rings below are keyed to this loop's events)
   for (auto& ss : h->svi_starts) ss.used_it = -1;
-  CK(svi_refresh_emission(h, -1, 0));   // theta of the initial factors (their vlb is not used)
+  CK(svi_refresh_emission(h, -1, 0));   // theta / table of the initial factors (their vlb is not used)
   h->svi_vi_cur = 1;
   CK(svi_globals(h, 0));             // globals of iteration 0
   h->svi_active = true;
   return 0;
+}
+// upload `n` doubles through a pinned slot into dst (asynchronous, pulled by a kernel)
+static int svi_upload(svihmm_ctx* h, void* dst, const double* a, size_t na, const double* b, size_t nb2,
+                      int centre_K, int centre_D) {
+  void* pin = nullptr;
+  int slot = 0;
+  CK(pinned(h, (na + nb2) * sizeof(double), &pin, &slot));
+  double* hp = (double*)pin;
+  std::memcpy(hp, a, na * 8);
+  if (b) std::memcpy(hp + na, b, nb2 * 8);
+  if (centre_K > 0) to_centred(h, hp, centre_K, centre_D);     // leading [K][D] block = means
+  CK(pull_small(h, dst, hp, (na + nb2) * 8));
+  return pin_release(h, slot);
+}
+
+int svihmm_svi_begin(svihmm_ctx* h, int32_t K, int32_t D, const double* prior_tran, const double* var_tran,
+                     const double* mu0, const double* sigma0, const double* kappa0, const double* nu0,
+                     const double* prior_logpart, const double* mu, const double* sigma,
+                     const double* kappa, const double* nu, int32_t maxit, double zsign) {
+  if (!h || K <= 0 || D <= 0 || !prior_tran || !var_tran || !mu0 || !sigma0 || !kappa0 || !nu0 ||
+      !prior_logpart || !mu || !sigma || !kappa || !nu || maxit <= 0)
+    return fail("svihmm_svi_begin: bad arguments");
+  CK(svi_begin_common(h, K, D, prior_tran, var_tran, maxit, 0));
+  h->svi_zsign = zsign;
+  const size_t nmu = (size_t)K * D, nsg = (size_t)K * D * D;
+  const size_t nin = nmu + nsg + 2 * (size_t)K;
+  CK(ensure(h->svi_prior, (nin + 8) * sizeof(double)));
+  CK(ensure(h->niw, nin * sizeof(double) + 64));
+  // one staging slot: [prior_logpart | prior block | niw block]
+  const size_t tot = K + 2 * nin;
+  void* pin = nullptr;
+  int slot = 0;
+  CK(pinned(h, tot * sizeof(double), &pin, &slot));
+  double* hp = (double*)pin;
+  std::memcpy(hp, prior_logpart, K * 8);
+  double* pp = hp + K;
+  std::memcpy(pp, mu0, nmu * 8); std::memcpy(pp + nmu, sigma0, nsg * 8);
+  to_centred(h, pp, K, D);             // the loop's state lives in the resident copy's coordinates
+  std::memcpy(pp + nmu + nsg, kappa0, K * 8); std::memcpy(pp + nmu + nsg + K, nu0, K * 8);
+  double* np_ = pp + nin;
+  std::memcpy(np_, mu, nmu * 8); std::memcpy(np_ + nmu, sigma, nsg * 8);
+  to_centred(h, np_, K, D);
+  std::memcpy(np_ + nmu + nsg, kappa, K * 8); std::memcpy(np_ + nmu + nsg + K, nu, K * 8);
+  CK(pull_small(h, svi_ptr(h, 5), hp, K * 8));
+  CK(pull_small(h, h->svi_prior.p, pp, nin * 8));
+  CK(pull_small(h, h->niw.p, np_, nin * 8));
+  CK(pin_release(h, slot));
+  return svi_begin_finish(h);
+}
+
+// Diagonal family (distributions.DiagonalGaussian: per dimension a normal-inverse-gamma factor):
+// blocks [mu | nus | alphas | betas], each [K][D]; the same loop with the family's natural-parameter
+// blend (hmmsgd_metaobs.py:1050-1069 in [nu mu, nu, 2 beta + nu mu^2, 2 alpha]), theta from
+// k_diag_to_theta, ELBO term -KL(q || prior) per dimension.
+int svihmm_svi_begin_diag(svihmm_ctx* h, int32_t K, int32_t D, const double* prior_tran, const double* var_tran,
+                          const double* prior_blk, const double* factor_blk, int32_t maxit) {
+  if (!h || K <= 0 || D <= 0 || !prior_tran || !var_tran || !prior_blk || !factor_blk || maxit <= 0)
+    return fail("svihmm_svi_begin_diag: bad arguments");
+  if (D > SVIHMM_DIAG_MAX_D) return fail("svihmm_svi_begin_diag: D > SVIHMM_DIAG_MAX_D");
+  CK(svi_begin_common(h, K, D, prior_tran, var_tran, maxit, 1));
+  const size_t n4 = 4 * (size_t)K * D;
+  for (size_t i = (size_t)K * D; i < n4; ++i)
+    if (!(prior_blk[i] > 0.0) || !(factor_blk[i] > 0.0)) return fail("svihmm_svi_begin_diag: nus, alphas, betas must be positive");
+  CK(ensure(h->svi_prior, (n4 + 8) * sizeof(double)));
+  CK(ensure(h->niw, n4 * sizeof(double) + 64));
+  CK(svi_upload(h, h->svi_prior.p, prior_blk, n4, nullptr, 0, K, D));
+  CK(svi_upload(h, h->niw.p, factor_blk, n4, nullptr, 0, K, D));
+  return svi_begin_finish(h);
+}
+
+// Categorical family (hmmsgd_metaobs.py:907-926, 1071-1084): Dirichlet factors alpha[K][V] over one
+// integer-valued observation column; the table E log theta is rebuilt on the device every iteration.
+int svihmm_svi_begin_cat(svihmm_ctx* h, int32_t K, int32_t V, const double* prior_tran, const double* var_tran,
+                         const double* alpha0, const double* alpha, int32_t maxit) {
+  if (!h || K <= 0 || V <= 0 || !prior_tran || !var_tran || !alpha0 || !alpha || maxit <= 0)
+    return fail("svihmm_svi_begin_cat: bad arguments");
+  if (h->D != 1) return fail("svihmm_svi_begin_cat: the resident observations must be one symbol column (D = 1)");
+  const size_t n = (size_t)K * V;
+  for (size_t i = 0; i < n; ++i)
+    if (!(alpha0[i] > 0.0) || !(alpha[i] > 0.0)) return fail("svihmm_svi_begin_cat: Dirichlet parameters must be positive");
+  CK(svi_begin_common(h, K, 1, prior_tran, var_tran, maxit, 2));
+  h->V = V;
+  CK(cat_uncentre(h));
+  CK(ensure(h->svi_prior, (n + 8) * sizeof(double)));
+  CK(ensure(h->niw, n * sizeof(double) + 64));
+  CK(ensure(h->cat_table, n * sizeof(double)));
+  CK(svi_upload(h, h->svi_prior.p, alpha0, n, nullptr, 0, 0, 0));
+  CK(svi_upload(h, h->niw.p, alpha, n, nullptr, 0, 0, 0));
+  return svi_begin_finish(h);
 }
 
 int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32_t B, int32_t nwin_total,
@@ -1349,7 +1437,7 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
   if (!h || !h->svi_active) return fail("svihmm_svi_iteration: call svihmm_svi_begin first");
   if (it < 0 || it >= h->svi_maxit) return fail("svihmm_svi_iteration: iteration index out of range");
   if (B < 0 || (B > 0 && !starts) || nwin_total < B) return fail("svihmm_svi_iteration: bad window batch");
-  if (flags & SVIHMM_USE_HOST_LLIKS) return fail("svihmm_svi_iteration: NIW emission only");
+  if (flags & SVIHMM_USE_HOST_LLIKS) return fail("svihmm_svi_iteration: device-side emission families only");
   CK(set_device(h));
   const int K = h->svi_K, D = h->svi_D;
   // start of the iteration: when the previous iteration is still running, the stream would execute
@@ -1391,11 +1479,21 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
   if (h->vlb_pending) { HIPCK(hipStreamWaitEvent(h->stream, h->svi_ed, 0)); h->vlb_pending = false; }
   {
     ProfScope ps(h, KS_MISC);
-    const unsigned nblk = (unsigned)K + (unsigned)((K * K + 255) / 256);
-    hipLaunchKernelGGL(k_svi_global_step, dim3(nblk), dim3(256), (size_t)3 * D * sizeof(double), h->stream,
-                       (const double*)h->packed.p, (const double*)svi_ptr(h, 1), svi_ptr(h, 0),
-                       (double*)h->niw.p, (const double*)h->svi_prior.p, K, D, rho, bfactA, bfactE,
-                       (double)nwin_total, svi_ptr(h, 8) + (it & 1), h->svi_adagrad ? svi_ptr(h, 9) : (double*)nullptr);
+    const unsigned ntran = (unsigned)((K * K + 255) / 256);
+    double* adag = h->svi_adagrad ? svi_ptr(h, 9) : (double*)nullptr;
+    if (h->svi_family == 0)
+      hipLaunchKernelGGL(k_svi_global_step, dim3((unsigned)K + ntran), dim3(256), (size_t)3 * D * sizeof(double), h->stream,
+                         (const double*)h->packed.p, (const double*)svi_ptr(h, 1), svi_ptr(h, 0),
+                         (double*)h->niw.p, (const double*)h->svi_prior.p, K, D, rho, bfactA, bfactE,
+                         (double)nwin_total, svi_ptr(h, 8) + (it & 1), adag);
+    else {
+      const int W = h->svi_family == 1 ? D : h->V;
+      const unsigned nem = (unsigned)(((size_t)K * W + 255) / 256);
+      hipLaunchKernelGGL(k_svi_global_step_simple, dim3(nem + ntran), dim3(256), 0, h->stream, h->svi_family,
+                         (const double*)h->packed.p, (const double*)svi_ptr(h, 1), svi_ptr(h, 0),
+                         (double*)h->niw.p, (const double*)h->svi_prior.p, K, W, rho, bfactA, bfactE,
+                         (double)nwin_total, svi_ptr(h, 8) + (it & 1), adag, (int)nem);
+    }
     HIPCK(hipGetLastError());
   }
   // the next iteration's globals, ahead of time, forked right behind the global step (its own event:
@@ -1451,6 +1549,7 @@ int svihmm_svi_read_elbo(svihmm_ctx* h, int32_t n, double* out_elbo, double* out
 int svihmm_svi_read_state(svihmm_ctx* h, double* var_tran, double* var_init, double* mu, double* sigma,
                           double* kappa, double* nu) {
   if (!h || !h->svi_active) return fail("svihmm_svi_read_state: no SVI state on the device");
+  if (h->svi_family != 0) return fail("svihmm_svi_read_state: NIW layout; this loop's family reads through svihmm_svi_read_factors");
   CK(set_device(h));
   const size_t K = h->svi_K, D = h->svi_D, nmu = K * D, nsg = K * D * D;
   const double* nw = (const double*)h->niw.p;
@@ -1465,6 +1564,25 @@ int svihmm_svi_read_state(svihmm_ctx* h, double* var_tran, double* var_init, dou
   if (h->stream3) HIPCK(hipStreamSynchronize(h->stream3));   // ELBO kernels still reading niw / theta
   h->vlb_pending = false;
   if (mu) from_centred(h, mu, (int)K, (int)D);
+  CK(check_emission_status(h));
+  return 0;
+}
+
+// The loop's state in the family's own block layout: NIW [mu | sigma | kappa | nu], diagonal
+// [mu | nus | alphas | betas] (each [K][D]), Categorical alpha[K][V]; means in the caller's coordinates.
+int svihmm_svi_read_factors(svihmm_ctx* h, double* var_tran, double* var_init, double* factors_out) {
+  if (!h || !h->svi_active) return fail("svihmm_svi_read_factors: no SVI state on the device");
+  CK(set_device(h));
+  const size_t K = h->svi_K, D = h->svi_D;
+  const size_t n = h->svi_family == 0 ? K * D + K * D * D + 2 * K : h->svi_family == 1 ? 4 * K * D : K * (size_t)h->V;
+  if (var_tran) CK(d2h(h, var_tran, svi_ptr(h, 0), K * K * 8));
+  CK(wait_globals(h));
+  if (var_init) CK(d2h(h, var_init, svi_ptr(h, h->svi_vi_cur ? 7 : 2), K * 8));
+  if (factors_out) CK(d2h(h, factors_out, h->niw.p, n * 8));
+  HIPCK(hipStreamSynchronize(h->stream));
+  if (h->stream3) HIPCK(hipStreamSynchronize(h->stream3));   // ELBO kernels still reading the factors
+  h->vlb_pending = false;
+  if (factors_out && h->svi_family != 2) from_centred(h, factors_out, (int)K, (int)D);
   CK(check_emission_status(h));
   return 0;
 }

@@ -439,6 +439,58 @@ class HipEngine(object):
         self.K, self.V = K, 0
         self.diag = False
         self._svi_shape = (K, D)
+        self._svi_family = "niw"
+
+    def svi_begin_diag(self, prior_tran, var_tran, prior, factors, maxit):
+        """The same loop for ``DiagonalGaussian`` emitters: ``prior`` / ``factors`` as
+        (mu, nus, alphas, betas), each [K, D]."""
+        self._pre_mutate()
+        var_tran = L.as_f64(var_tran)
+        K = var_tran.shape[0]
+        prior_tran = L.as_f64(prior_tran, (K, K))
+        D = np.asarray(prior[0]).shape[1]
+        pb = np.ascontiguousarray(np.stack([L.as_f64(a, (K, D)) for a in prior]))
+        fb = np.ascontiguousarray(np.stack([L.as_f64(a, (K, D)) for a in factors]))
+        L.check(self._lib.svihmm_svi_begin_diag(self._h, K, D, L.dptr(prior_tran), L.dptr(var_tran), L.dptr(pb),
+                                                L.dptr(fb), int(maxit)), "svihmm_svi_begin_diag")
+        self.K, self.V = K, 0
+        self.diag = True
+        self._svi_shape = (K, D)
+        self._svi_family = "diag"
+
+    def svi_begin_cat(self, prior_tran, var_tran, alpha0, alpha, maxit):
+        """The same loop for ``Categorical`` emitters over one symbol column: Dirichlet prior and
+        factors [K, V]."""
+        self._pre_mutate()
+        var_tran = L.as_f64(var_tran)
+        K = var_tran.shape[0]
+        prior_tran = L.as_f64(prior_tran, (K, K))
+        alpha0 = L.as_f64(alpha0); V = alpha0.shape[1]
+        alpha = L.as_f64(alpha, (K, V))
+        L.check(self._lib.svihmm_svi_begin_cat(self._h, K, V, L.dptr(prior_tran), L.dptr(var_tran), L.dptr(alpha0),
+                                               L.dptr(alpha), int(maxit)), "svihmm_svi_begin_cat")
+        self.K, self.V = K, V
+        self.diag = False
+        self._svi_shape = (K, V)
+        self._svi_family = "cat"
+
+    def svi_read_factors(self):
+        """(var_tran, var_init, factors) with ``factors`` in the loop's family layout: NIW
+        (mu, sigma, kappa, nu), diagonal (mu, nus, alphas, betas), Categorical alpha [K, V]."""
+        K, W = self._svi_shape
+        fam = getattr(self, "_svi_family", "niw")
+        n = {"niw": K * W + K * W * W + 2 * K, "diag": 4 * K * W, "cat": K * W}[fam]
+        vt, vi, blk = np.empty((K, K)), np.empty(K), np.empty(n)
+        L.check(self._lib.svihmm_svi_read_factors(self._h, L.dptr(vt), L.dptr(vi), L.dptr(blk)),
+                "svihmm_svi_read_factors")
+        if fam == "diag":
+            fac = tuple(blk.reshape(4, K, W))
+        elif fam == "cat":
+            fac = blk.reshape(K, W)
+        else:
+            o1, o2 = K * W, K * W + K * W * W
+            fac = (blk[:o1].reshape(K, W), blk[o1:o2].reshape(K, W, W), blk[o2:o2 + K], blk[o2 + K:])
+        return vt, vi, fac
 
     def svi_iteration(self, it, starts, nwin_total, Lm, flags, rho, bfactA, bfactE, inner=None):
         """Enqueue iteration ``it`` on the windows ``starts`` (asynchronous)."""

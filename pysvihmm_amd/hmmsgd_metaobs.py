@@ -28,7 +28,7 @@ from numpy import newaxis as npa
 from scipy.special import digamma
 
 from .hmmbase import VariationalHMMBase, is_niw_gaussian, is_diag_gaussian, dirichlet_elbo
-from .distributions import Gaussian, Categorical
+from .distributions import Gaussian, Categorical, DiagonalGaussian
 from . import util
 from . import _lib as L
 
@@ -367,13 +367,25 @@ class VBHMM(VariationalHMMBase):
                    "global_lower_bound", "local_lower_bound", "_minibatch_estep", "_stationary_init",
                    "_psi_expectations", "_emit_vlb", "_global_update_niw_stacked")
 
+    def _svi_family(self):
+        """Emission family the device-resident loop runs for this model (None: host loop)."""
+        if self._niw_fastpath():
+            return "niw"
+        if self._diag_fastpath():
+            return "diag"
+        if self._cat_fastpath():
+            return "cat"
+        return None
+
     def _svi_device_ok(self):
         eng = self.engine
-        if not hasattr(eng, "svi_begin") or not self._niw_fastpath():
+        fam = self._svi_family()
+        if fam is None or not hasattr(eng, {"niw": "svi_begin", "diag": "svi_begin_diag", "cat": "svi_begin_cat"}[fam]):
             return False
         if self.adagrad and not hasattr(eng, "svi_set_adagrad"):
             return False
-        if any(type(e).get_vlb is not Gaussian.get_vlb for e in self.var_emit):
+        cls = {"niw": Gaussian, "diag": DiagonalGaussian, "cat": Categorical}[fam]
+        if any(type(e).get_vlb is not cls.get_vlb for e in self.var_emit):
             return False
         for name in self._LOOP_HOOKS:
             if name in self.__dict__ or getattr(type(self), name) is not getattr(VBHMM, name):
@@ -390,10 +402,21 @@ class VBHMM(VariationalHMMBase):
 
     def _svi_pull_state(self):
         """Device state -> the object's attributes (reference attribute names)."""
-        vt, vi, mu, sg, ka, nu = self.engine.svi_read_state()
-        self.var_tran, self.var_init = vt, vi
+        fam = self._svi_family()
         if self.adagrad:
             self.ada_G = self.engine.svi_read_adagrad()
+        if fam != "niw":
+            vt, vi, fac = self.engine.svi_read_factors()
+            self.var_tran, self.var_init = vt, vi
+            for k, G in enumerate(self.var_emit):
+                if fam == "diag":
+                    G._set_mf(*[a[k].copy() for a in fac])
+                else:
+                    G._alpha_mf = fac[k].copy()
+                    G.weights = G._alpha_mf / G._alpha_mf.sum()
+            return
+        vt, vi, mu, sg, ka, nu = self.engine.svi_read_state()
+        self.var_tran, self.var_init = vt, vi
         D = self.D
         for k, G in enumerate(self.var_emit):
             G.mu_mf = mu[k]; G.sigma_mf = sg[k]
@@ -415,10 +438,21 @@ class VBHMM(VariationalHMMBase):
         mb_sz = self.mb_sz
         L_ = self.metaobs_half
         miniL = bufferL = L_
-        prior = self._prior_arrays()
-        fac = self._emission_arrays()
-        eng.svi_begin(self.prior_tran, self.var_tran, prior, fac,
-                      niw_prior_logpart(prior[1], prior[3]), maxit, vlb_logz_sign())
+        fam = self._svi_family()
+        if fam == "niw":
+            prior = self._prior_arrays()
+            fac = self._emission_arrays()
+            eng.svi_begin(self.prior_tran, self.var_tran, prior, fac,
+                          niw_prior_logpart(prior[1], prior[3]), maxit, vlb_logz_sign())
+        elif fam == "diag":
+            ve = self.var_emit
+            prior = tuple(np.array([getattr(g, n) for g in ve], dtype=np.float64)
+                          for n in ("mu_0", "nus_0", "alphas_0", "betas_0"))
+            eng.svi_begin_diag(self.prior_tran, self.var_tran, prior, self._diag_arrays(), maxit)
+        else:
+            ve = self.var_emit
+            eng.svi_begin_cat(self.prior_tran, self.var_tran, np.array([g.alphav_0 for g in ve], dtype=np.float64),
+                              np.array([g.alpha_mf for g in ve], dtype=np.float64), maxit)
         if self.adagrad:        # the accumulator of reference :1036-1040 joins the resident state
             eng.svi_set_adagrad(self.ada_G)
         self.__dict__.pop("_pending_rows", None)

@@ -130,3 +130,45 @@ def test_batchcd_categorical_on_gpu():
     for k in range(K):
         np.testing.assert_allclose(a.var_emit[k].alpha_mf, b.var_emit[k].alpha_mf, rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(a.elbo_vec, b.elbo_vec, rtol=1e-8)
+
+
+def _close_cat(a, b, K, rtol):
+    np.testing.assert_allclose(a.var_tran, b.var_tran, rtol=rtol, atol=1e-9)
+    np.testing.assert_allclose(a.elbo_vec, b.elbo_vec, rtol=max(rtol, 1e-8))
+    for k in range(K):
+        np.testing.assert_allclose(a.var_emit[k].alpha_mf, b.var_emit[k].alpha_mf, rtol=rtol, atol=1e-9)
+        np.testing.assert_allclose(a.var_emit[k].weights, b.var_emit[k].weights, rtol=rtol, atol=1e-10)
+    np.testing.assert_allclose(a.var_x, b.var_x, rtol=rtol * 10, atol=1e-11)
+
+
+@pytest.mark.parametrize("adagrad", [False, True])
+def test_categorical_engine_resident_loop_equals_host_loop(adagrad):
+    """Round 4: Categorical emitters run the SVI loop with their state inside the engine
+    (svi_begin_cat: Dirichlet blend of reference :1071-1084 with every window's alpha_0 + counts - 1,
+    E log theta table rebuilt per iteration, Dirichlet ELBO term)."""
+    K, V, T = 4, 7, 600
+    obs, mask, _ = _cat_problem(K, V, T, 1)
+    a = _make(K, V, obs, mask, OracleEngine(), adagrad=adagrad)
+    assert a._svi_family() == "cat" and a._svi_device_ok()
+    a.infer()
+    b = _make(K, V, obs, mask, OracleEngine(), adagrad=adagrad)
+    b.infer(device_loop=False)
+    _close_cat(a, b, K, 1e-10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("adagrad", [False, True])
+def test_categorical_device_loop_on_gpu(adagrad):
+    """The same on the device (k_svi_global_step_simple, k_cat_table, k_svi_vlb_simple): HIP device
+    loop == HIP host loop == oracle engine."""
+    K, V, T = 5, 9, 4000
+    obs, mask, _ = _cat_problem(K, V, T, 8)
+    a = _make(K, V, obs, mask, None, adagrad=adagrad)
+    assert a._svi_device_ok()
+    a.infer()
+    assert a.engine.name == "hip"
+    b = _make(K, V, obs, mask, None, adagrad=adagrad); b.infer(device_loop=False)
+    c = _make(K, V, obs, mask, OracleEngine(), adagrad=adagrad); c.infer(device_loop=False)
+    _close_cat(a, b, K, 1e-7)
+    _close_cat(a, c, K, 1e-6)
+    assert np.all(np.isfinite(a.iter_time)) and np.all(a.iter_time > 0)

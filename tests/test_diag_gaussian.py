@@ -138,3 +138,29 @@ def test_metaobs_and_batchsgd_diag_fused_equals_literal():
         for k in range(K):
             np.testing.assert_allclose(a.var_emit[k].mf_mu, b.var_emit[k].mf_mu, rtol=1e-8, atol=1e-9)
             np.testing.assert_allclose(a.var_emit[k].mf_betas, b.var_emit[k].mf_betas, rtol=1e-8)
+
+
+def test_metaobs_diag_engine_resident_loop_equals_host_loop():
+    """Round 4: the SVI loop keeps the diagonal family's state inside the engine too
+    (svi_begin_diag: natural-parameter blend, theta rebuild, -KL ELBO term); same trajectory as
+    the host loop, with and without AdaGrad."""
+    obs, sts, prior = _configs0(seed=5)
+    K = 4
+    for ada in (False, True):
+        runs = []
+        for dl in (None, False):
+            np.random.seed(3)
+            m = hmmsgd_metaobs.VBHMM(obs.copy(), np.ones(K), np.ones((K, K)), prior, tau=1.0, kappa=0.7,
+                                     metaobs_half=8, mb_sz=6, maxit=5, seed=4, adagrad=ada, engine=OracleEngine())
+            assert m._svi_family() == "diag" and m._svi_device_ok()
+            m.infer(device_loop=dl)
+            runs.append(m)
+        a, b = runs
+        np.testing.assert_allclose(a.elbo_vec, b.elbo_vec, rtol=1e-9)
+        np.testing.assert_allclose(a.var_tran, b.var_tran, rtol=1e-9)
+        for k in range(K):
+            for name in ("mf_mu", "mf_nus", "mf_alphas", "mf_betas"):
+                np.testing.assert_allclose(getattr(a.var_emit[k], name), getattr(b.var_emit[k], name), rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(a.var_x, b.var_x, rtol=1e-8, atol=1e-12)
+        if ada:
+            np.testing.assert_allclose(a.ada_G, b.ada_G, rtol=1e-10)

@@ -195,3 +195,36 @@ def test_configs0_classes_hip_vs_oracle_engine(cls):
             np.testing.assert_allclose(getattr(a.var_emit[k], name), getattr(b.var_emit[k], name), rtol=1e-6, atol=1e-8)
     if cls == "batchcd":
         assert a.hamming < 0.02
+
+
+@pytest.mark.parametrize("adagrad", [False, True])
+def test_diag_device_loop_on_gpu(adagrad):
+    """Round 4: the device-resident SVI loop for the diagonal family (svihmm_svi_begin_diag):
+    HIP device loop == HIP host loop == oracle engine, data far from the origin included (the
+    loop's means live in the handle's centred coordinates)."""
+    from pysvihmm_amd import hmmsgd_metaobs
+    from oracle.engine import OracleEngine
+    obs, sts, prior0 = _configs0(seed=7, T=3000)
+    K = 4
+    for off in (0.0, 250.0):
+        from pysvihmm_amd.distributions import DiagonalGaussian
+        prior = np.array([DiagonalGaussian(mu=g.mu + off, sigmas=g.sigmas, mu_0=g.mu_0 + off, nus_0=g.nus_0,
+                                           alphas_0=g.alphas_0, betas_0=g.betas_0) for g in prior0])
+        runs = []
+        for eng, dl in ((None, None), (None, False), (OracleEngine(), False)):
+            np.random.seed(3)
+            m = hmmsgd_metaobs.VBHMM(obs.copy() + off, np.ones(K), np.ones((K, K)), prior, tau=1.0, kappa=0.7,
+                                     metaobs_half=16, mb_sz=8, maxit=6, seed=4, adagrad=adagrad, engine=eng)
+            assert m._svi_family() == "diag" and m._svi_device_ok()
+            m.infer(device_loop=dl)
+            runs.append(m)
+        a, b, c = runs
+        assert a.engine.name == "hip"
+        for o, rt in ((b, 1e-7), (c, 1e-6)):
+            np.testing.assert_allclose(a.elbo_vec, o.elbo_vec, rtol=1e-7)
+            np.testing.assert_allclose(a.var_tran, o.var_tran, rtol=rt, atol=1e-9)
+            for k in range(K):
+                for name in ("mf_mu", "mf_nus", "mf_alphas", "mf_betas"):
+                    np.testing.assert_allclose(getattr(a.var_emit[k], name), getattr(o.var_emit[k], name), rtol=rt,
+                                               atol=1e-8 * (1.0 + off))
+            np.testing.assert_allclose(a.var_x, o.var_x, rtol=1e-5, atol=1e-9)
