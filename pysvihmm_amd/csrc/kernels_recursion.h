@@ -579,6 +579,13 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_mfma(
 //  t is first touched at step t+2, so its wait is a counted vmcnt a full step behind the
 //  stores (gfx9 counts loads and stores in one in-order counter).
 // ------------------------------------------------------------------------------------
+// Measurement-only knock-outs of the scaled sweeps (tools/r4_overlap_probe.py builds its own copy of
+// the library with -DSVIHMM_KO_SWEEP=n; never set in the product): bit 0 = no ah / bh stores, bit 1 =
+// no Eh loads inside the time loop.  Results are then meaningless; the launch's time shows what the
+// HBM side of the sweeps costs.
+#ifndef SVIHMM_KO_SWEEP
+#define SVIHMM_KO_SWEEP 0
+#endif
 #define LOG2E_D 1.4426950408889634074
 #define LN2_HI_D 6.93147180369123816490e-01
 #define LN2_LO_D 1.90821492927058770002e-10
@@ -797,7 +804,9 @@ __device__ __forceinline__ void fwd_lin_body(
       if (BS && !FULL) av = vj ? av : 0.0;   // streamed B has no zero columns for padded states
       sh.P[NXT][lg + 4 * r][j] = av;
       if (MODE != 2) {
+#if !(SVIHMM_KO_SWEEP & 1)
         if (FULL || vj) at[L.oE[r]] = av;
+#endif
         // LSE of step t-1: log(tot) + (h_{t-1} + K_{t-1}) ln 2, accumulated as a product
         const double mm = mant[r] * tot[r];
         ex[r] += __builtin_amdgcn_frexp_exp(mm);
@@ -808,8 +817,10 @@ __device__ __forceinline__ void fwd_lin_body(
       if (MODE != 2 && NW % 4 != 0) ht[L.oR[r]] = h[r];
     }
     if (MODE != 2 && NW % 4 == 0) ht[L.oRw] = sel4(h, wave & 3);
+#if !(SVIHMM_KO_SWEEP & 2)
 #pragma unroll
     for (int r = 0; r < 4; ++r) er[r] = E2[L.oE[r]];
+#endif
     __syncthreads();
   };
   {
@@ -943,13 +954,17 @@ __device__ __forceinline__ void bwd_lin_body(
       double bv = ldexp(acc[r], -e2);
       if (BS && !FULL) bv = vj ? bv : 0.0;
       sh.P[NXT][lg + 4 * r][j] = er[r] * bv;
+#if !(SVIHMM_KO_SWEEP & 1)
       if (FULL || vj) bt[L.oE[r]] = bv;
+#endif
       g[r] += (double)e2;
       if (NW % 4 != 0) gt[L.oR[r]] = g[r];
     }
     if (NW % 4 == 0) gt[L.oRw] = sel4(g, wave & 3);
+#if !(SVIHMM_KO_SWEEP & 2)
 #pragma unroll
     for (int r = 0; r < 4; ++r) er[r] = E2[L.oE[r]];
+#endif
     __syncthreads();
   };
   {

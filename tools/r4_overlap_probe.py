@@ -9,7 +9,8 @@
                 emission GEMM of the other): co-residency forced at kernel granularity
   q_pass        variant[15] = 2: posteriors by their own pass, statistics GEMM on plain q
                 (what the GEMM gains if ah*bh*scale left its staging code / what the pass costs)
-Per-kernel HIP-event averages are printed for the configurations that run with events."""
+Per-kernel HIP-event averages are printed for the configurations that run with events.
+`--ko` (one process per library, SVIHMM_HIP_LIB): the kernel-level knock-outs of the sweeps' HBM side."""
 import os, sys, time, json
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -57,6 +58,13 @@ def run(name, prof, variants, steps=20, reps=7):
     return out
 
 
+if "--ko" in sys.argv:
+    # run under SVIHMM_HIP_LIB=build_exp/libsvihmm_koN.so (make -C pysvihmm_amd/csrc ko KO=N: the scaled
+    # sweeps without their ah / bh stores (1), without their Eh loads (2), without both (3))
+    tag = os.path.basename(os.environ.get("SVIHMM_HIP_LIB", "product"))
+    run(tag, False, {})
+    run(tag + "+prof", True, {})
+    sys.exit(0)
 res = []
 res.append(run("base", False, {}))
 res.append(run("prof", True, {}))
