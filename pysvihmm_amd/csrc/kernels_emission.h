@@ -348,22 +348,19 @@ __global__ void k_theta_orbit(const double* __restrict__ theta, int D, int Kp, i
 // MT = row tiles per wave: 2 (128 rows per workgroup) for batches that fill the chip, 1 (64 rows,
 // round 3) for minibatches with fewer than one 128-row workgroup per CU -- the SVI iteration of 64
 // windows is 129 workgroups of 128 rows on 256 CUs.
-// NWV = waves per workgroup: 4, or 2 (round 4) for minibatches that would otherwise leave one wave per
-// SIMD -- 64 windows are 257 workgroups of 64 rows on 256 CUs: every k-step then waits out its own
-// LDS latency; 514 workgroups of 32 rows put two waves on every SIMD.
-template <int NT, int U, int MT = 2, int NWV = 4>
-__global__ __launch_bounds__(64 * NWV) void k_emission_orbit(
+template <int NT, int U, int MT = 2>
+__global__ __launch_bounds__(256) void k_emission_orbit(
     const double* __restrict__ obs, const uint8_t* __restrict__ mask,
     const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K,
     const double* __restrict__ orb, uint32_t flags, double* __restrict__ ll,
     double* __restrict__ kexp, double* __restrict__ ll0) {
-  constexpr int ROWS = 16 * NWV * MT, KP = 16 * NT, NTH = 64 * NWV;
+  constexpr int ROWS = 64 * MT, KP = 16 * NT;
   typedef typename std::conditional<MT == 2, double2, double>::type XV;   // one column of the wave's row tiles
   extern __shared__ double smem[];
   const int N = D + 1, c = D >> 2, nd = (D >> 1) + 1, nleft = (nd + 3) >> 2;
   const int LEN = D + (D >> 1) + 1;                 // slots -1 .. 3D/2 - 1 (odd count)
-  XV* xs2 = (XV*)smem;                              // [16 NWV][LEN]: MT = 2 (row r, row r + 16) pairs
-  long long* rowoff = (long long*)(xs2 + 16 * NWV * LEN);
+  XV* xs2 = (XV*)smem;                              // [64][LEN]: MT = 2 (row r, row r + 16) pairs
+  long long* rowoff = (long long*)(xs2 + 64 * LEN);
   unsigned char* bad_s = (unsigned char*)(rowoff + ROWS);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t g0 = (int64_t)blockIdx.x * ROWS;
@@ -375,7 +372,7 @@ __global__ __launch_bounds__(64 * NWV) void k_emission_orbit(
   {
     const int64_t bw0 = g0 / Lm;
     const unsigned t0 = (unsigned)(g0 - bw0 * Lm);
-    for (int r = tid; r < ROWS; r += NTH) {
+    for (int r = tid; r < ROWS; r += 256) {
       const bool valid = g0 + r < nrows;
       const unsigned x = t0 + (unsigned)(valid ? r : 0);
       const unsigned bwr = x / (unsigned)Lm;
@@ -391,7 +388,7 @@ __global__ __launch_bounds__(64 * NWV) void k_emission_orbit(
   __syncthreads();
   {
     const int sh = 32 - __builtin_clz((unsigned)(D - 1));
-    const int rpp = NTH >> sh, i = tid & ((1 << sh) - 1), rr = tid >> sh;
+    const int rpp = 256 >> sh, i = tid & ((1 << sh) - 1), rr = tid >> sh;
     constexpr int CH = 16;      // loads first, LDS writes after (see K1b)
     for (int rb = 0; rb < ROWS; rb += rpp * CH) {
       double v[CH];

@@ -206,16 +206,13 @@ int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled,
     }
     // fewer than one 128-row workgroup per CU: 64-row workgroups (variant[5] = 2: always 128)
     const int MTo = ((n + 127) / 128 < 256 && h->variant[5] != 2) ? 1 : 2;
-    // fewer than two 64-row workgroups per CU: 32-row workgroups of two waves, so that two waves share
-    // every SIMD and cover each other's LDS latency (variant[5] = 4: keep four waves)
-    const int NWo = (MTo == 1 && (n + 63) / 64 < 512 && h->variant[5] != 4) ? 2 : 4;
-    const int rows = 16 * NWo * MTo;
+    const int rows = 64 * MTo;
     const size_t lds = (size_t)rows * LEN * 8 + rows * 9;
     dim3 grid((unsigned)((n + rows - 1) / rows));
-#define EMO(NTV, UV, MTV, NWVV) hipLaunchKernelGGL((k_emission_orbit<NTV, UV, MTV, NWVV>), grid, dim3(64 * NWVV), lds, stream,  \
+#define EMO(NTV, UV, MTV) hipLaunchKernelGGL((k_emission_orbit<NTV, UV, MTV>), grid, dim3(256), lds, stream,  \
                                         (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K,               \
                                         (const double*)h->theta_orb.p, flags, out, kexp_out, ll0_out)
-#define EMOM(NTV, UV) do { if (MTo == 1 && NWo == 2) EMO(NTV, UV, 1, 2); else if (MTo == 1) EMO(NTV, UV, 1, 4); else EMO(NTV, UV, 2, 4); } while (0)
+#define EMOM(NTV, UV) do { if (MTo == 1) EMO(NTV, UV, 1); else EMO(NTV, UV, 2); } while (0)
     if (D % 16 == 0) { if (NT == 4) EMOM(4, 4); else if (NT == 3) EMOM(3, 4); else if (NT == 2) EMOM(2, 4); else EMOM(1, 4); }
     else             { if (NT == 4) EMOM(4, 2); else if (NT == 3) EMOM(3, 2); else if (NT == 2) EMOM(2, 2); else EMOM(1, 2); }
 #undef EMOM
