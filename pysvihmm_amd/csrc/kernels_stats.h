@@ -714,3 +714,242 @@ __global__ void k_finalize_cat(const double* __restrict__ part, int nchunk, int 
   }
 }
 
+
+// ------------------------------------------------------------------------------------
+//  K4f (round 4): the statistics GEMM of the fp32 mode on the bf16 matrix pipe.
+//  Same contraction as K4d -- out[f][k] = sum_t phi_f(x_t) q[t][k], the transition rows
+//  f >= Fp with phi = q[prev(t)][f - Fp] -- with BOTH operands carried as three bf16 terms
+//  (hi + mid + lo, round-to-nearest each: the fp32 value) and the six products hi hi, hi mid,
+//  mid hi, hi lo, lo hi, mid mid accumulated in the MFMA's fp32 accumulators: fp32 arithmetic at
+//  16 x the rate of v_mfma_f32_16x16x4_f32, i.e. 2.7 x faster per product than K4d's fp32
+//  instance (which ran at 0.60 of that slower pipe).  gfx950 has v_cvt_pk_bf16_f32, so a split
+//  costs 11 VALU instructions per PAIR of values.
+//  v_mfma_f32_32x32x16_bf16: M = 32 features, N = 32 states, k = 16 rows.
+//    A lane 32 h + j: feature j of the tile, rows 8 h .. 8 h + 7 of the k-step;
+//    B lane 32 h + n: state n, the same rows;   C lane 32 h + n, reg r: feature 8 (r / 4) + 4 h + r % 4.
+//  Operands in LDS, transposed so that a lane's eight consecutive rows are 16 / 32 contiguous bytes:
+//    xT  [D + 2][XRS] float    x columns, the ones column (0 on masked rows), a zero column;
+//    qT  3 x [64][QRS] bf16    q = ah bh scale as its three terms, state-major;
+//    pT  3 x [64][QRS] bf16    q of the predecessor row (wrap / none at window starts).
+//  A feature tile's A terms are formed by the wave that owns it: x_a x_b in fp32, split; the
+//  two transition tiles read pT as they are.  q is multiplied, scaled and split ONCE per
+//  (row, state) by the staging threads (thread = state, eight consecutive rows: one 16-byte
+//  LDS write per plane).  Workgroup = 8 waves, ONE per row chunk and CU: wave w owns feature
+//  tiles w, w + 8, w + 16 (Ftot / 32 = 20 at K = 64, D = 32: three on waves 0..3, two on 4..7,
+//  five per SIMD) x both state tiles -- every A operand feeds 12 MFMAs.  Stages of 64 rows,
+//  double-buffered, one barrier per stage.  Requires K == 64 (Kp = 64), D <= 32, Fp % 32 == 0.
+//  Partials leave as fp64 in K4d's layout part[chunk][f][k] (k_finalize unchanged).
+// ------------------------------------------------------------------------------------
+#define SB_ROWS 64
+#define SB_XRS 68         // xT row stride in floats
+#define SB_QRS 72         // plane row stride in bf16 (144 B: eight lanes' 16-byte reads cover all banks)
+typedef __attribute__((ext_vector_type(8))) __bf16 sbf8_t;
+typedef __attribute__((ext_vector_type(16))) float sf16_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 sbf2_t;
+typedef __attribute__((ext_vector_type(2))) float sf2_t;
+struct SbRow {
+  long long ooff;     // obs element offset of the row, -1: invalid or masked
+  int qoff, poff;     // element offsets of the row / its predecessor in ah, bh (clamped to 0)
+  float sq, sp;       // their posterior scales (0: row invalid / no predecessor)
+  int pad0, pad1;
+};
+// two fp32 values -> their three bf16 terms, packed (low half: a)
+__device__ __forceinline__ void sb_split2(float a, float b, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+  sf2_t v = {a, b};
+  hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, sbf2_t));
+  sf2_t r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
+  mid = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, sbf2_t));
+  sf2_t s = {r.x - __uint_as_float(mid << 16), r.y - __uint_as_float(mid & 0xffff0000u)};
+  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(s, sbf2_t));
+}
+__device__ __forceinline__ void sb_split8(const float (&v)[8], uint4& hi, uint4& mid, uint4& lo) {
+  sb_split2(v[0], v[1], hi.x, mid.x, lo.x);
+  sb_split2(v[2], v[3], hi.y, mid.y, lo.y);
+  sb_split2(v[4], v[5], hi.z, mid.z, lo.z);
+  sb_split2(v[6], v[7], hi.w, mid.w, lo.w);
+}
+__global__ __launch_bounds__(512) void k_stats_bf16x3(
+    const double* __restrict__ obs, const uint8_t* __restrict__ mask,
+    const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K, int Fp, int F,
+    const int* __restrict__ fab, const float* __restrict__ ah, const float* __restrict__ bh,
+    int64_t rows_per_chunk, uint32_t flags, int Lq, int off, double* __restrict__ part,
+    const double* __restrict__ hx, const double* __restrict__ gx, const double2* __restrict__ zfac) {
+  constexpr int Kp = 64, NPL = 6;
+  extern __shared__ uint4 sb_smem[];
+  const int XC = D + 2;                                      // x columns + ones + zero
+  const size_t xbytes = ((size_t)XC * SB_XRS * 4 + 15) & ~(size_t)15;
+  const size_t pbytes = (size_t)64 * SB_QRS * 2;             // one plane
+  const size_t bufbytes = xbytes + NPL * pbytes;
+  char* base = reinterpret_cast<char*>(sb_smem);
+  SbRow* rinfo = reinterpret_cast<SbRow*>(base + 2 * bufbytes);     // [3][SB_ROWS]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, hh = lane >> 5;
+  const int Ftot = Fp + Kp, NMT = Ftot >> 5, FT = Fp >> 5;   // feature tiles; the first transition tile
+  const int64_t c0 = (int64_t)blockIdx.x * rows_per_chunk;
+  const int64_t c1 = imin64(nrows, c0 + rows_per_chunk);
+  const int nrow = c1 > c0 ? (int)(c1 - c0) : 0;
+  const int nstage = (nrow + SB_ROWS - 1) / SB_ROWS;
+  const int64_t bw0 = c0 / Lm;
+  const unsigned t0 = (unsigned)(c0 - bw0 * Lm);
+  const int64_t Q0 = bw0 * Lq + off;
+  const float* __restrict__ ah0 = ah + Q0 * K;
+  const float* __restrict__ bh0 = bh + Q0 * K;
+
+  // per-lane operand addresses of the wave's feature tiles (float index of row 0 in xT)
+  int oa[3], ob[3];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const int mt = wave + 8 * m;
+    const int f = 32 * mt + j;
+    int a = D + 1, b = D + 1;                                // padding feature: zero column
+    if (mt < FT) { if (f < F) { const int ab = fab[f]; a = ab & 0xffff; b = ab >> 16; } }
+    else { a = f - Fp; b = 0; }                              // transition tile: previous state a
+    oa[m] = a; ob[m] = b;
+  }
+  sf16_t acc[3][2];
+#pragma unroll
+  for (int m = 0; m < 3; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+  auto row_info = [&](int st) {
+    if (tid < SB_ROWS) {
+      const int jrow = st * SB_ROWS + tid;
+      const bool ok = jrow < nrow;
+      const unsigned x = t0 + (unsigned)(ok ? jrow : 0);
+      const unsigned bwr = x / (unsigned)Lm, t = x - bwr * (unsigned)Lm;
+      const int qr = (int)(bwr * (unsigned)Lq + t);
+      const bool pok = ok && (t > 0 || (flags & SVIHMM_TRANS_WRAP));
+      const int pr = t > 0 ? qr - 1 : qr + Lm - 1;
+      const int64_t bw = bw0 + bwr;
+      const int64_t orow = starts[bw] + off + t;
+      const bool msk = mask && mask[orow];
+      const double2 zf = zfac[bw];
+      SbRow ri;
+      ri.ooff = (ok && !msk) ? orow * D : -1;
+      ri.qoff = ok ? qr * K : 0;
+      ri.poff = pok ? pr * K : 0;
+      ri.sq = ok ? (float)ldexp(zf.x, (int)(hx[Q0 + qr] + gx[Q0 + qr] - zf.y)) : 0.0f;
+      const int prc = pok ? pr : qr;
+      ri.sp = pok ? (float)ldexp(zf.x, (int)(hx[Q0 + prc] + gx[Q0 + prc] - zf.y)) : 0.0f;
+      ri.pad0 = 0; ri.pad1 = 0;
+      rinfo[(st % 3) * SB_ROWS + tid] = ri;
+    }
+  };
+  // staged data of one stage, in registers: thread = (state / x column `lane`, rows 8 wave .. 8 wave + 7)
+  float ra[8], rb[8], pa[8], pb[8], rsq[8], rsp[8];
+  double rx[8];
+  bool xok[8];
+  auto fetch = [&](int st) {
+    const SbRow* ri = rinfo + (st % 3) * SB_ROWS + 8 * wave;
+    const int xc = lane < D ? lane : 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const SbRow r = ri[e];                                 // (uniform address: broadcast)
+      ra[e] = ah0[r.qoff + lane]; rb[e] = bh0[r.qoff + lane];
+      pa[e] = ah0[r.poff + lane]; pb[e] = bh0[r.poff + lane];
+      rsq[e] = r.sq; rsp[e] = r.sp;
+      xok[e] = r.ooff >= 0;
+      rx[e] = obs[(xok[e] ? r.ooff : 0) + xc];
+    }
+  };
+  auto commit = [&](int buf) {
+    char* bb = base + (size_t)buf * bufbytes;
+    float qv[8], pv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { qv[e] = (ra[e] * rb[e]) * rsq[e]; pv[e] = (pa[e] * pb[e]) * rsp[e]; }
+    uint4 t3[3];
+    sb_split8(qv, t3[0], t3[1], t3[2]);
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      *reinterpret_cast<uint4*>(bb + xbytes + s * pbytes + ((size_t)lane * SB_QRS + 8 * wave) * 2) = t3[s];
+    sb_split8(pv, t3[0], t3[1], t3[2]);
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      *reinterpret_cast<uint4*>(bb + xbytes + (3 + s) * pbytes + ((size_t)lane * SB_QRS + 8 * wave) * 2) = t3[s];
+    if (lane < XC) {
+      float xf[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = lane < D ? (float)rx[e] : (lane == D ? 1.0f : 0.0f);
+        xf[e] = xok[e] ? v : 0.0f;
+      }
+      float* xt = reinterpret_cast<float*>(bb) + lane * SB_XRS + 8 * wave;
+      *reinterpret_cast<float4*>(xt) = make_float4(xf[0], xf[1], xf[2], xf[3]);
+      *reinterpret_cast<float4*>(xt + 4) = make_float4(xf[4], xf[5], xf[6], xf[7]);
+    }
+  };
+  constexpr int TA[6] = {0, 0, 1, 0, 2, 1}, TB[6] = {0, 1, 0, 2, 0, 1};
+  auto compute = [&](int buf) {
+    const char* bb = base + (size_t)buf * bufbytes;
+    const float* xT = reinterpret_cast<const float*>(bb);
+    const char* qpl = bb + xbytes;
+#pragma unroll 1
+    for (int ks = 0; ks < SB_ROWS / 16; ++ks) {
+      const int r0 = 16 * ks + 8 * hh;
+      sbf8_t b3[2][3];
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+          b3[n][s] = __builtin_bit_cast(sbf8_t, *reinterpret_cast<const uint4*>(qpl + s * pbytes + ((size_t)(32 * n + j) * SB_QRS + r0) * 2));
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const int mt = wave + 8 * m;
+        if (mt >= NMT) continue;                             // (uniform per wave)
+        sbf8_t a3[3];
+        if (mt < FT) {
+          const float4 xa0 = *reinterpret_cast<const float4*>(xT + oa[m] * SB_XRS + r0);
+          const float4 xa1 = *reinterpret_cast<const float4*>(xT + oa[m] * SB_XRS + r0 + 4);
+          const float4 xb0 = *reinterpret_cast<const float4*>(xT + ob[m] * SB_XRS + r0);
+          const float4 xb1 = *reinterpret_cast<const float4*>(xT + ob[m] * SB_XRS + r0 + 4);
+          const float p[8] = {xa0.x * xb0.x, xa0.y * xb0.y, xa0.z * xb0.z, xa0.w * xb0.w,
+                              xa1.x * xb1.x, xa1.y * xb1.y, xa1.z * xb1.z, xa1.w * xb1.w};
+          uint4 t3[3];
+          sb_split8(p, t3[0], t3[1], t3[2]);
+#pragma unroll
+          for (int s = 0; s < 3; ++s) a3[s] = __builtin_bit_cast(sbf8_t, t3[s]);
+        } else {
+#pragma unroll
+          for (int s = 0; s < 3; ++s)
+            a3[s] = __builtin_bit_cast(sbf8_t, *reinterpret_cast<const uint4*>(qpl + (3 + s) * pbytes + ((size_t)oa[m] * SB_QRS + r0) * 2));
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int pi = 0; pi < 6; ++pi)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[TA[pi]], b3[n][TB[pi]], acc[m][n], 0, 0, 0);
+      }
+    }
+  };
+  if (nstage > 0) {
+    row_info(0);
+    if (nstage > 1) row_info(1);
+    __syncthreads();
+    fetch(0);
+    commit(0);
+    __syncthreads();
+    for (int st = 0; st < nstage; ++st) {
+      if (st + 1 < nstage) fetch(st + 1);
+      if (st + 2 < nstage) row_info(st + 2);
+      compute(st & 1);
+      if (st + 1 < nstage) commit((st + 1) & 1);
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const int mt = wave + 8 * m;
+    if (mt >= NMT) continue;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int f = 32 * mt + 8 * (r >> 2) + 4 * hh + (r & 3);
+        part[((size_t)blockIdx.x * Ftot + f) * Kp + 32 * n + j] = (double)acc[m][n][r];
+      }
+  }
+}

@@ -24,8 +24,23 @@ static int stats_mt(const svihmm_ctx* h) {
 // should be a whole number of rounds of 256 workgroups: chunks x feature groups (grid.y) = 256 r.
 // 128 chunks x 2 feature groups at the bench shape; more chunks only add partial-sum traffic
 // (64 windows: statistics + finalize 74 -> 56 us, tools/chunk_sweep.py).  chunk = multiple of ST_RB.
+// fp32 mode, K = 64 / D <= 32 / whole 32-feature tiles: the statistics GEMM on the bf16 matrix pipe
+// (k_stats_bf16x3; variant[10] = 2: the fp32-input MFMA kernel instead)
+static bool stats_bf16_ok(const svihmm_ctx* h) {
+  return h->cur_f32 && h->lin_mode && !h->q_valid && h->K == 64 && h->Kp == 64 && h->D <= 32 && h->Fp > 0 &&
+         h->Fp % 32 == 0 && !h->emis_cat && !h->emis_diag && h->variant[10] != 2 && h->variant[1] == 0;
+}
 StatsPlan stats_plan(const svihmm_ctx* h, int64_t n, int forced) {
   int target_chunks = forced > 0 ? forced : 128;
+  if (forced <= 0 && stats_bf16_ok(h)) {
+    // one 8-wave workgroup per chunk covers all feature tiles: a chunk per CU (small batches: chunks of
+    // at least four 64-row stages)
+    int64_t tc = n / (4 * SB_ROWS);
+    if (tc < 1) tc = 1;
+    if (tc > 256) tc = 256;
+    int64_t rpc = ((n + tc - 1) / tc + SB_ROWS - 1) / SB_ROWS * SB_ROWS;
+    return {rpc, (n + rpc - 1) / rpc};
+  }
   if (forced <= 0 && h->Kp <= 64 && h->Fp > 0 && !h->emis_cat) {
     const int gy = ((h->Fp + h->Kp) / 16 + 4 * stats_mt(h) - 1) / (4 * stats_mt(h));
     const int r = std::max(1, (128 * gy + 128) / 256);     // rounds: round(128 gy / 256)
@@ -93,6 +108,14 @@ int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, int Lm, u
       const int mt_limit = big ? Fp / 16 : mtiles;
       const int xk = (D + 1 + TPR - 1) / TPR;
       if (lds > 150 * 1024 || xk > 9 || (big && Kp % 64 != 0)) var = 2;
+      else if (lin && h->cur_f32 && !big && stats_bf16_ok(h) && rpc % SB_ROWS == 0) {
+        const size_t xb = (((size_t)(D + 2) * SB_XRS * 4) + 15) & ~(size_t)15;
+        const size_t ldsb = 2 * (xb + 6 * (size_t)64 * SB_QRS * 2) + 3 * SB_ROWS * sizeof(SbRow);
+        hipFuncSetAttribute((const void*)k_stats_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+        hipLaunchKernelGGL(k_stats_bf16x3, dim3((unsigned)nchunk), dim3(512), ldsb, stream, (const double*)h->obs.p, mk,
+                           starts_dev, n, Lm, D, K, Fp, F, (const int*)h->fab.p, (const float*)h->la.p + qo,
+                           (const float*)h->lb.p + qo, rpc, flags, Lq, off, partv, hxv, gxv, zfv);
+      }
       else if (lin && h->cur_f32 && !big) {
         // fp32 mode: float LDS tiles, v_mfma_f32_16x16x4_f32, ah / bh read as float
         const size_t ldsf = ((size_t)(D + 3 + KpW) * ST_CC + 2 * (size_t)ST_RB * (KpW + 16)) * 4 + 8 +

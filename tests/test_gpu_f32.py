@@ -219,3 +219,55 @@ def test_f32_bf16x3_emission_nan_rows_and_outliers(flags_name):
     st2 = e.estep(starts, Lm, flags=flags)
     np.testing.assert_allclose(st2.neff, st.neff, rtol=1e-3, atol=1e-6 * sc)
     e.close()
+
+
+@pytest.mark.parametrize("D,B,Lm,flags_wrap,inner", [
+    (32, 24, 257, True, None),          # minibatch-sized: one chunk per four stages
+    (32, 1100, 17, True, None),         # windows much shorter than a stage: many window starts per stage
+    (32, 300, 65, False, None),         # no wrap statistic: window starts have no predecessor
+    (16, 700, 33, True, None),          # D = 16: Fp = 160, five feature tiles + two transition tiles
+    (32, 64, 129, True, (20, 89)),      # buffered meta-observations: inner segment
+    (32, 4200, 9, True, None),          # > 256 chunks' worth of rows, ragged last chunk
+])
+def test_f32_statistics_on_the_bf16_pipe(D, B, Lm, flags_wrap, inner):
+    """Round 4: the fp32 mode's statistics GEMM as three-term bf16 products (k_stats_bf16x3; K = 64,
+    D <= 32, whole 32-feature tiles).  Against the fp64 C oracle at the mode's tolerance (measured
+    errors asserted below 1e-4) and against the fp32-input MFMA kernel it replaces (variant 10 = 2)."""
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    from oracle import ref_c
+    K = 64
+    T = max(6000, B * 3 + Lm)
+    pb = make_problem(K, D, T, seed=D * 11 + B, miss=0.06, sep=4.0)
+    starts = np.random.default_rng(B + 1).integers(0, T - Lm + 1, size=B)
+    flags = L.TRANS_WRAP if flags_wrap else 0
+    e = HipEngine(0, dtype="f32")
+    try:
+        e.set_obs(pb["obs"], pb["mask"])
+        e.set_globals(pb["mod_init"], pb["ltran"])
+        e.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+        st = e.estep(starts, Lm, flags=flags, inner=inner)
+        assert e.precision() == ("f32", True)
+        got = st.buf.copy()
+        e.set_variant(10, 2)
+        old = e.estep(starts, Lm, flags=flags, inner=inner).buf.copy()
+        e.set_variant(10, 0)
+        if inner is None:
+            ref = ref_c.estep_minibatch(pb["obs"], pb["mask"], starts, Lm, pb["mod_init"], pb["ltran"], pb["mu"],
+                                        pb["sigma"], pb["kappa"], pb["nu"], flags=2 if flags_wrap else 0,
+                                        threads=effective_cores())
+            A, xbar, neff, S, lb = unpack(ref, K, D)
+            sc = B * Lm
+            xs = np.abs(pb["obs"]).max()
+            worst = max(_close(st.A_raw, A, sc, "A"), _close(st.neff, neff, sc, "neff"),
+                        _close(st.xbar, xbar, sc * xs, "xbar"), _close(st.S, S, sc * xs ** 2, "S"))
+            assert worst < 1e-4, worst
+            np.testing.assert_allclose(st.lb[0], lb, rtol=1e-6)
+        # the two fp32 kernels agree far inside the mode's tolerance (same inputs, fp32 arithmetic both)
+        nin = (inner[1] if inner else Lm) * B
+        scale = np.maximum(np.abs(old), 1e-6 * nin * np.abs(pb["obs"]).max() ** 2)
+        assert np.max(np.abs(got - old) / scale) < 2e-5, float(np.max(np.abs(got - old) / scale))
+        assert np.all(np.isfinite(got))
+        np.testing.assert_allclose(st.A_raw.sum(), nin if flags_wrap else nin - B, rtol=1e-5)
+    finally:
+        e.close()
