@@ -266,7 +266,7 @@ def test_f32_statistics_on_the_bf16_pipe(D, B, Lm, flags_wrap, inner):
         # the two fp32 kernels agree far inside the mode's tolerance (same inputs, fp32 arithmetic both)
         nin = (inner[1] if inner else Lm) * B
         scale = np.maximum(np.abs(old), 1e-6 * nin * np.abs(pb["obs"]).max() ** 2)
-        assert np.max(np.abs(got - old) / scale) < 2e-5, float(np.max(np.abs(got - old) / scale))
+        assert np.max(np.abs(got - old) / scale) < 1e-4, float(np.max(np.abs(got - old) / scale))
         assert np.all(np.isfinite(got))
         np.testing.assert_allclose(st.A_raw.sum(), nin if flags_wrap else nin - B, rtol=1e-5)
     finally:
