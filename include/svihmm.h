@@ -437,7 +437,12 @@ const char* svihmm_kernel_name(int32_t slot);
  * | 7 scaled sweeps' kernel family (K > 128: 1 one state tile per wave, 2 two tiles per wave for every K)
  * | 13 wide models' sweeps with 32 windows per workgroup (1 = off: 16)
  * | 14 wide models' transition statistic in 128 x 64 blocks (1 = off: 64 x 64)
- * | 15 wide models' statistics GEMM forms q = ah bh scale itself (1 = off: separate posterior pass) */
+ * | 15 wide models' statistics GEMM forms q = ah bh scale itself (1 = off: separate posterior pass;
+ *      2, measurement only: a separate pass for every K)
+ * | 10 statistics GEMM tiling (1: five feature tiles per wave for every shape) and, in the fp32 mode, its
+ *      pipe (2: the fp32-input MFMA kernel instead of the three-term bf16 one; 3: the bf16 kernel also
+ *      below its batch-size floor of 32 768 rows)
+ * | 7 = 9, measurement only: the scaled sweeps are skipped (tools/r4_overlap_probe.py) */
 int svihmm_set_variant(svihmm_ctx* h, int32_t which, int32_t value);
 
 /* ---- diagnostics ------------------------------------------------------------------- */

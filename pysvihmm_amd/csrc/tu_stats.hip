@@ -26,13 +26,16 @@ static int stats_mt(const svihmm_ctx* h) {
 // (64 windows: statistics + finalize 74 -> 56 us, tools/chunk_sweep.py).  chunk = multiple of ST_RB.
 // fp32 mode, K = 64 / D <= 32 / whole 32-feature tiles: the statistics GEMM on the bf16 matrix pipe
 // (k_stats_bf16x3; variant[10] = 2: the fp32-input MFMA kernel instead)
-static bool stats_bf16_ok(const svihmm_ctx* h) {
+static bool stats_bf16_ok(const svihmm_ctx* h, int64_t n) {
+  // (batches below 32 768 rows -- the 64-window minibatch -- keep the fp32-input kernel's many small
+  //  workgroups: one 8-wave workgroup per chunk would leave most CUs idle)
   return h->cur_f32 && h->lin_mode && !h->q_valid && h->K == 64 && h->Kp == 64 && h->D <= 32 && h->Fp > 0 &&
-         h->Fp % 32 == 0 && !h->emis_cat && !h->emis_diag && h->variant[10] != 2 && h->variant[1] == 0;
+         h->Fp % 32 == 0 && !h->emis_cat && !h->emis_diag && h->variant[10] != 2 && h->variant[1] == 0 &&
+         (n >= 32768 || h->variant[10] == 3);     // (variant[10] = 3: tests force it on small batches)
 }
 StatsPlan stats_plan(const svihmm_ctx* h, int64_t n, int forced) {
   int target_chunks = forced > 0 ? forced : 128;
-  if (forced <= 0 && stats_bf16_ok(h)) {
+  if (forced <= 0 && stats_bf16_ok(h, n)) {
     // one 8-wave workgroup per chunk covers all feature tiles: a chunk per CU (small batches: chunks of
     // at least four 64-row stages)
     int64_t tc = n / (4 * SB_ROWS);
@@ -108,7 +111,7 @@ int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, int Lm, u
       const int mt_limit = big ? Fp / 16 : mtiles;
       const int xk = (D + 1 + TPR - 1) / TPR;
       if (lds > 150 * 1024 || xk > 9 || (big && Kp % 64 != 0)) var = 2;
-      else if (lin && h->cur_f32 && !big && stats_bf16_ok(h) && rpc % SB_ROWS == 0) {
+      else if (lin && h->cur_f32 && !big && stats_bf16_ok(h, n) && rpc % SB_ROWS == 0 && nchunk * rpc >= n) {
         const size_t xb = (((size_t)(D + 2) * SB_XRS * 4) + 15) & ~(size_t)15;
         const size_t ldsb = 2 * (xb + 6 * (size_t)64 * SB_QRS * 2) + 3 * SB_ROWS * sizeof(SbRow);
         hipFuncSetAttribute((const void*)k_stats_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);

@@ -246,12 +246,16 @@ def test_f32_statistics_on_the_bf16_pipe(D, B, Lm, flags_wrap, inner):
         e.set_obs(pb["obs"], pb["mask"])
         e.set_globals(pb["mod_init"], pb["ltran"])
         e.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+        e.set_variant(10, 3)              # the bf16 kernel also below its batch-size floor of 32 768 rows
         st = e.estep(starts, Lm, flags=flags, inner=inner)
         assert e.precision() == ("f32", True)
         got = st.buf.copy()
         e.set_variant(10, 2)
         old = e.estep(starts, Lm, flags=flags, inner=inner).buf.copy()
+        assert not np.array_equal(got, old)       # (two different kernels did run)
         e.set_variant(10, 0)
+        if B * Lm >= 32768:               # ... and by default above it
+            np.testing.assert_array_equal(e.estep(starts, Lm, flags=flags, inner=inner).buf, got)
         if inner is None:
             ref = ref_c.estep_minibatch(pb["obs"], pb["mask"], starts, Lm, pb["mod_init"], pb["ltran"], pb["mu"],
                                         pb["sigma"], pb["kappa"], pb["nu"], flags=2 if flags_wrap else 0,
