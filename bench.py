@@ -581,21 +581,23 @@ def side_figures(eng, L, pb, step, barrier, obs_host, args):
         for _ in range(3):
             out32 = step()
         used = eng.precision()[1]
-        eng.profile(True); eng.profile_reset()
         blocks = []
-        for _ in range(5):
+        for _ in range(5):          # (timed without kernel events, like the headline: they cost ~0.05 ms per step)
             barrier()
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 out32 = step()
             barrier()
             blocks.append((time.perf_counter() - t0) / args.steps)
+        eng.profile(True); eng.profile_reset()
+        for _ in range(min(args.steps, 10)):
+            step()
         p32 = eng.profile_read(); eng.profile(False)
         dt32 = float(np.median(blocks))
         rows = (T // LM) * LM
         scale = np.maximum(np.abs(ref64), 1e-6 * rows)
         res["f32_mode"] = {"ms_per_step": dt32 * 1e3, "value": rows * K / dt32, "unit": "updates/s",
-                           "dtype": "f32 storage of Eh/ah/bh + f32 MFMA statistics + centred emission on bf16 MFMA (x and U as three bf16 terms, fp32 accumulators); f64 recursion arithmetic",
+                           "dtype": "f32 storage of Eh/ah/bh; centred emission AND the statistics GEMM on bf16 MFMA with every operand as three bf16 terms (fp32 accumulators = fp32 arithmetic); f64 recursion arithmetic",
                            "ran_in_f32_format": bool(used),
                            "max_rel_err_vs_f64_statistics": float(np.max(np.abs(out32.buf - ref64) / scale)),
                            "kernels_ms": {k: v[0] / v[1] for k, v in p32.items()}}
@@ -612,6 +614,22 @@ def side_figures(eng, L, pb, step, barrier, obs_host, args):
                 "note": "bf16 dense MFMA peak (MI355X_MICROARCH.md); x and U as three bf16 terms, six products in fp32 "
                         "accumulators; fp32_equivalent = the centred triangular quadratic form's K D (D+1) flop per row "
                         "(fp32-input MFMA peak: 157 TF/s)"}
+        # the statistics GEMM of the mode (k_stats_bf16x3): 20 feature tiles x 2 state tiles x 6 products of
+        # v_mfma_f32_32x32x16_bf16 per 16 rows on the bf16 pipe; 2 (F + K) K flop per row of fp32 arithmetic
+        sk = p32.get("stats")
+        if sk and sk[1] > 0 and K == 64 and D == 32:
+            sms = sk[0] / sk[1] * 1e-3
+            Fq = (D + 1) * (D + 2) // 2
+            res["f32_mode"]["roofline_stats"] = {
+                "bound": "mfma", "kernel": "k_stats_bf16x3", "achieved": rows / 16.0 * 20 * 12 * 32768.0 / sms / 1e12,
+                "peak": 2500.0, "unit": "TFLOP/s", "frac": rows / 16.0 * 20 * 12 * 32768.0 / sms / 1e12 / 2500.0,
+                "fp32_equivalent_tflops": rows * 2.0 * (Fq + K) * K / sms / 1e12,
+                "note": "bf16 dense MFMA peak; both operands as three bf16 terms, six products in fp32 accumulators; "
+                        "fp32_equivalent = 2 (F + K) K flop per row (fp32-input MFMA peak: 157 TF/s)"}
+        # the mode's tolerance (north_star: 1e-3) holds in the bench itself
+        assert res["f32_mode"]["max_rel_err_vs_f64_statistics"] < 1e-3, res["f32_mode"]["max_rel_err_vs_f64_statistics"]
+    except AssertionError:
+        raise
     except Exception as e:
         res["f32_mode"] = {"error": repr(e)}
     finally:
