@@ -590,46 +590,71 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_mfma(
 #define LN2_HI_D 6.93147180369123816490e-01
 #define LN2_LO_D 1.90821492927058770002e-10
 
-template <int NW>
+// arithmetic type of a sweep: the MFMA, its C-register <-> window map, frexp / ldexp.  double:
+// v_mfma_f64_16x16x4_f64, register r of lane group lg = window lg + 4 r; float (fp32 mode, round 4):
+// v_mfma_f32_16x16x4_f32 at twice the rate, register r = window 4 lg + r.
+typedef float float4_lv __attribute__((ext_vector_type(4)));
+template <typename T> struct LV;
+template <> struct LV<double> {
+  typedef double4_t v4;
+  static __device__ __forceinline__ v4 mma(double a, double b, v4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int crow(int lg, int r) { return lg + 4 * r; }
+  static __device__ __forceinline__ int fexp(double x) { return __builtin_amdgcn_frexp_exp(x); }
+  static __device__ __forceinline__ double ldx(double x, int e) { return ldexp(x, e); }
+};
+template <> struct LV<float> {
+  typedef float4_lv v4;
+  static __device__ __forceinline__ v4 mma(float a, float b, v4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int crow(int lg, int r) { return 4 * lg + r; }
+  static __device__ __forceinline__ int fexp(float x) { return __builtin_amdgcn_frexp_expf(x); }
+  static __device__ __forceinline__ float ldx(float x, int e) { return ldexpf(x, e); }
+};
+template <int NW, typename T = double>
 struct LinShared {
   static constexpr int PS = 16 * NW + 2;
-  double __attribute__((aligned(16))) P[2][16][PS];
+  T __attribute__((aligned(16))) P[2][16][PS];
 };
 
-template <int NW>
-__device__ __forceinline__ void lin_matmul(const LinShared<NW>& sh, int cur, int li, int lg,
-                                           const double (&Bv)[4 * NW], double4_t& acc,
-                                           double4_t& tot) {
+template <typename T> struct LPair;
+template <> struct LPair<double> { typedef double2 t; };
+template <> struct LPair<float> { typedef float2 t; };
+template <int NW, typename T>
+__device__ __forceinline__ void lin_matmul(const LinShared<NW, T>& sh, int cur, int li, int lg,
+                                           const T (&Bv)[4 * NW], typename LV<T>::v4& acc,
+                                           typename LV<T>::v4& tot) {
   constexpr int KS = 4 * NW;
-  double4_t a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
-  const double* prow = &sh.P[cur][li][2 * lg];
-  double s0 = 0.0, s1 = 0.0;
+  typedef typename LV<T>::v4 v4;
+  typedef typename LPair<T>::t T2;
+  v4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+  const T* prow = &sh.P[cur][li][2 * lg];
+  T s0 = 0, s1 = 0;
 #pragma unroll
   for (int c = 0; c < KS / 2; c += 2) {
-    const double2 x = *reinterpret_cast<const double2*>(prow + 8 * c);
-    const double2 y = *reinterpret_cast<const double2*>(prow + 8 * (c + 1));
-    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, Bv[2 * c], a0, 0, 0, 0);
-    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, Bv[2 * c + 1], a1, 0, 0, 0);
-    a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(y.x, Bv[2 * c + 2], a2, 0, 0, 0);
-    a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(y.y, Bv[2 * c + 3], a3, 0, 0, 0);
+    const T2 x = *reinterpret_cast<const T2*>(prow + 8 * c);
+    const T2 y = *reinterpret_cast<const T2*>(prow + 8 * (c + 1));
+    a0 = LV<T>::mma(x.x, Bv[2 * c], a0);
+    a1 = LV<T>::mma(x.y, Bv[2 * c + 1], a1);
+    a2 = LV<T>::mma(y.x, Bv[2 * c + 2], a2);
+    a3 = LV<T>::mma(y.y, Bv[2 * c + 3], a3);
     s0 = (c == 0) ? x.x + y.x : s0 + (x.x + y.x);
     s1 = (c == 0) ? x.y + y.y : s1 + (x.y + y.y);
   }
-  const double4_t z = {0, 0, 0, 0};
-  tot = __builtin_amdgcn_mfma_f64_16x16x4f64(s0 + s1, 1.0, z, 0, 0, 0);
+  const v4 z = {0, 0, 0, 0};
+  tot = LV<T>::mma(s0 + s1, (T)1, z);
   acc = (a0 + a1) + (a2 + a3);
 }
-template <int NW>
-__device__ __forceinline__ double4_t lin_rowsum(const LinShared<NW>& sh, int cur, int li, int lg) {
-  const double* prow = &sh.P[cur][li][2 * lg];
-  double s = 0.0;
+template <int NW, typename T>
+__device__ __forceinline__ typename LV<T>::v4 lin_rowsum(const LinShared<NW, T>& sh, int cur, int li, int lg) {
+  typedef typename LPair<T>::t T2;
+  const T* prow = &sh.P[cur][li][2 * lg];
+  T s = 0;
 #pragma unroll
   for (int c = 0; c < 2 * NW; ++c) {
-    const double2 x = *reinterpret_cast<const double2*>(prow + 8 * c);
+    const T2 x = *reinterpret_cast<const T2*>(prow + 8 * c);
     s += x.x + x.y;
   }
-  const double4_t z = {0, 0, 0, 0};
-  return __builtin_amdgcn_mfma_f64_16x16x4f64(s, 1.0, z, 0, 0, 0);
+  const typename LV<T>::v4 z = {0, 0, 0, 0};
+  return LV<T>::mma(s, (T)1, z);
 }
 
 // K > 64: the B operand (the transition matrix tile of this wave, K x 16 doubles) no longer
@@ -669,7 +694,7 @@ __device__ __forceinline__ void lin_matmul_stream(const LinShared<NW>& sh, int c
 
 // per-lane state shared by both directions.  Windows of a launch start `wstride` rows apart
 // (normal batches: wstride = Lm; chain chunks overlap their terminal row: wstride = Lm - 1).
-template <int NW, bool FULL>
+template <int NW, bool FULL, typename CT = double>
 struct LinLane {
   int lane, wave, li, lg, j, jc, b0;
   bool vj;
@@ -684,12 +709,12 @@ struct LinLane {
     b0 = bfirst;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int gw = b0 + lg + 4 * r;
+      const int gw = b0 + LV<CT>::crow(lg, r);
       gwc[r] = gw < B ? gw : B - 1;
       oR[r] = shared_rows ? 0u : (unsigned)(gwc[r] - b0) * (unsigned)wstride;
       oE[r] = oR[r] * (unsigned)K + (unsigned)jc;
     }
-    const int gww = b0 + lg + 4 * (wave & 3);
+    const int gww = b0 + LV<CT>::crow(lg, wave & 3);
     oRw = shared_rows ? 0u : (unsigned)((gww < B ? gww : B - 1) - b0) * (unsigned)wstride;
   }
 };
@@ -722,26 +747,32 @@ struct LinChain {
 // MODE 0: windows start from the initial distribution.  MODE 1: from chain.init_vec.
 // MODE 2: chunk matrices (unit initial vectors, all pseudo-windows read the chunk's rows,
 // nothing but the final matrix is stored; blockIdx.x = chunk * NW + row group).
+// CT (arithmetic type): float where the storage is float (fp32 mode: ordinary window batches, B in
+// registers); double everywhere else.
+template <int MODE, bool BS, typename ST>
+struct LinCT { typedef typename std::conditional<std::is_same<ST, float>::value && MODE == 0 && !BS, float, double>::type t; };
 template <int NW, bool FULL, int MODE, bool BS = false, typename ST = double>
 __device__ __forceinline__ void fwd_lin_body(
-    LinShared<NW>& sh, const ST* __restrict__ Eh, const double* __restrict__ kexp,
+    LinShared<NW, typename LinCT<MODE, BS, ST>::t>& sh, const ST* __restrict__ Eh, const double* __restrict__ kexp,
     const double* __restrict__ Aexp, const double* __restrict__ a0v,
     const double* __restrict__ a0e, int B, int Lm,
     int wstride, int K, ST* __restrict__ ah, double* __restrict__ hx,
     double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac,
     const LinChain& ch) {
   constexpr int KS = 4 * NW;
-  LinLane<NW, FULL> L;
+  typedef typename LinCT<MODE, BS, ST>::t CT;
+  typedef typename LV<CT>::v4 cv4;
+  LinLane<NW, FULL, CT> L;
   const int chunk = MODE == 2 ? blockIdx.x / NW : 0, rgrp = MODE == 2 ? blockIdx.x % NW : 0;
   L.init(MODE == 2 ? chunk : blockIdx.x * 16, MODE == 2 ? chunk + 1 : B, wstride, K, MODE == 2);
   const int li = L.li, lg = L.lg, j = L.j, jc = L.jc, wave = L.wave;
   const bool vj = L.vj;
-  double Bv[BS ? 1 : KS];
+  CT Bv[BS ? 1 : KS];
   if (!BS) {
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       const int k = 8 * (kk >> 1) + 2 * lg + (kk & 1);
-      Bv[BS ? 0 : kk] = (k < K && vj) ? Aexp[(size_t)k * K + jc] : 0.0;
+      Bv[BS ? 0 : kk] = (k < K && vj) ? (CT)Aexp[(size_t)k * K + jc] : (CT)0;
     }
   }
   const double* __restrict__ Bcol = Aexp + jc;
@@ -750,26 +781,27 @@ __device__ __forceinline__ void fwd_lin_body(
   ST* __restrict__ ab = ah + wrow * K;
   double* __restrict__ hb = hx + wrow;
   const int i1 = Lm > 1 ? 1 : 0, i2 = Lm > 2 ? 2 : i1;
-  double h[4], mant[4], hsum[4], ea[4], eb[4];
+  double h[4], mant[4], hsum[4];
+  CT ea[4], eb[4];
   int ex[4];
   {
-    double a0[4];
+    CT a0[4];
     if (MODE == 0) {
       // initial message and its exponent from k_lin_init (mod_init + ll_0, combined in the log domain)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        a0[r] = vj ? a0v[(size_t)L.gwc[r] * K + jc] : 0.0;
+        a0[r] = vj ? (CT)a0v[(size_t)L.gwc[r] * K + jc] : (CT)0;
         h[r] = a0e[L.gwc[r]];
       }
     } else if (MODE == 1) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        a0[r] = vj ? ch.init_vec[(size_t)L.gwc[r] * K + jc] : 0.0;
+        a0[r] = vj ? (CT)ch.init_vec[(size_t)L.gwc[r] * K + jc] : (CT)0;
         h[r] = ch.init_exp[L.gwc[r]];
       }
     } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { a0[r] = (vj && j == rgrp * 16 + lg + 4 * r) ? 1.0 : 0.0; h[r] = 0.0; }
+      for (int r = 0; r < 4; ++r) { a0[r] = (vj && j == rgrp * 16 + LV<CT>::crow(lg, r)) ? (CT)1 : (CT)0; h[r] = 0.0; }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) ea[r] = (Eb + (size_t)i1 * K)[L.oE[r]];
@@ -781,34 +813,34 @@ __device__ __forceinline__ void fwd_lin_body(
         if (NW % 4 != 0) hb[L.oR[r]] = h[r];
         if (FULL || vj) ab[L.oE[r]] = a0[r];
       }
-      sh.P[0][lg + 4 * r][j] = a0[r];
+      sh.P[0][LV<CT>::crow(lg, r)][j] = a0[r];
       mant[r] = 1.0; ex[r] = 0; hsum[r] = 0.0;
     }
     if (MODE != 2 && NW % 4 == 0) hb[L.oRw] = sel4(h, wave & 3);
   }
   __syncthreads();
   // one time step: reads P[CUR], writes P[1-CUR]; er holds Eh_t, refilled with step t+2
-  auto step = [&](const int t, auto curc, double (&er)[4]) {
+  auto step = [&](const int t, auto curc, CT (&er)[4]) {
     constexpr int CUR = decltype(curc)::value, NXT = 1 - CUR;
     const int t2 = t + 2 < Lm ? t + 2 : Lm - 1;
-    double4_t acc, tot;
+    cv4 acc, tot;
     if constexpr (BS) lin_matmul_stream<NW, FULL>(sh, CUR, li, lg, Bcol, K, acc, tot);
-    else lin_matmul<NW>(sh, CUR, li, lg, Bv, acc, tot);
+    else lin_matmul<NW, CT>(sh, CUR, li, lg, Bv, acc, tot);
     ST* __restrict__ at = ab + (size_t)t * K;
     double* __restrict__ ht = hb + t;
     const ST* __restrict__ E2 = Eb + (size_t)t2 * K;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int e2 = __builtin_amdgcn_frexp_exp(tot[r]);
-      double av = ldexp(acc[r] * er[r], -e2);
-      if (BS && !FULL) av = vj ? av : 0.0;   // streamed B has no zero columns for padded states
-      sh.P[NXT][lg + 4 * r][j] = av;
+      const int e2 = LV<CT>::fexp(tot[r]);
+      CT av = LV<CT>::ldx(acc[r] * er[r], -e2);
+      if (BS && !FULL) av = vj ? av : (CT)0;   // streamed B has no zero columns for padded states
+      sh.P[NXT][LV<CT>::crow(lg, r)][j] = av;
       if (MODE != 2) {
 #if !(SVIHMM_KO_SWEEP & 1)
         if (FULL || vj) at[L.oE[r]] = av;
 #endif
         // LSE of step t-1: log(tot) + (h_{t-1} + K_{t-1}) ln 2, accumulated as a product
-        const double mm = mant[r] * tot[r];
+        const double mm = mant[r] * (double)tot[r];
         ex[r] += __builtin_amdgcn_frexp_exp(mm);
         mant[r] = __builtin_amdgcn_frexp_mant(mm);
         hsum[r] += h[r];
@@ -839,8 +871,8 @@ __device__ __forceinline__ void fwd_lin_body(
     double* __restrict__ Mt = ch.MoutT + (size_t)chunk * Kp * K;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int i = rgrp * 16 + lg + 4 * r;
-      const double v = sh.P[last][lg + 4 * r][j];
+      const int i = rgrp * 16 + LV<CT>::crow(lg, r);
+      const double v = sh.P[last][LV<CT>::crow(lg, r)][j];
       if (vj && i < K) { Mo[(size_t)i * K + j] = v; Mt[(size_t)j * K + i] = v; }
       if (wave == 0 && li == 0 && i < K) ch.Mh[(size_t)chunk * Kp + i] = h[r];
     }
@@ -849,7 +881,7 @@ __device__ __forceinline__ void fwd_lin_body(
   // ---- epilogue: K_top = sum_t k_t and sum_t K_t = sum_t (Lm - t) k_t per window (the only
   // place the emission exponents enter), Z = sum_j alpha_{Lm-1}[j], local_lb
   {
-    double* scr = &sh.P[1 - last][0][0];     // free buffer: [0,16) K_top, [16,32) sum_t K_t
+    double* scr = reinterpret_cast<double*>(&sh.P[1 - last][0][0]);     // free buffer: [0,16) K_top, [16,32) sum_t K_t
     const double* __restrict__ kbw = kexp + wrow;
     for (int w = threadIdx.x >> 4; w < 16; w += 4 * NW) {
       const int gw = L.b0 + w;
@@ -865,18 +897,19 @@ __device__ __forceinline__ void fwd_lin_body(
       if (li == 0) { scr[w] = a; scr[16 + w] = c; }
     }
     __syncthreads();
-    const double4_t tot = lin_rowsum<NW>(sh, last, li, lg);
+    const cv4 totc = lin_rowsum<NW, CT>(sh, last, li, lg);
     if (wave == 0 && li == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int w = lg + 4 * r;
+        const int w = LV<CT>::crow(lg, r);
+        const double totr = (double)totc[r];
         const double kb4 = (MODE == 1 && ch.kbefore) ? ch.kbefore[L.gwc[r]] : 0.0;
         const double Ktop = scr[w] + kb4, KK = scr[16 + w] + kb4 * (double)Lm;
-        const double mm = mant[r] * tot[r];
+        const double mm = mant[r] * totr;
         const int exf = ex[r] + __builtin_amdgcn_frexp_exp(mm);
         const double mf = __builtin_amdgcn_frexp_mant(mm);
-        const double zm = __builtin_amdgcn_frexp_mant(tot[r]);
-        const double zexp = (double)__builtin_amdgcn_frexp_exp(tot[r]);
+        const double zm = __builtin_amdgcn_frexp_mant(totr);
+        const double zexp = (double)__builtin_amdgcn_frexp_exp(totr);
         local_lb[L.gwc[r]] = log(mf) + ((double)exf + hsum[r] + h[r] + KK) * LN2_D;
         logz[L.gwc[r]] = log(zm) + (h[r] + Ktop + zexp) * LN2_D;
         zfac[L.gwc[r]] = make_double2(1.0 / zm, h[r] + zexp);
@@ -890,20 +923,22 @@ __device__ __forceinline__ void fwd_lin_body(
 // boundary vector chain.term_vec; nothing is stored for it.
 template <int NW, bool FULL, int MODE, bool BS = false, typename ST = double>
 __device__ __forceinline__ void bwd_lin_body(
-    LinShared<NW>& sh, const ST* __restrict__ Eh, const double* __restrict__ AexpT, int B,
+    LinShared<NW, typename LinCT<MODE, BS, ST>::t>& sh, const ST* __restrict__ Eh, const double* __restrict__ AexpT, int B,
     int Lm, int wstride, int K, ST* __restrict__ bh, double* __restrict__ gx,
     const LinChain& ch) {
   constexpr int KS = 4 * NW;
-  LinLane<NW, FULL> L;
+  typedef typename LinCT<MODE, BS, ST>::t CT;
+  typedef typename LV<CT>::v4 cv4;
+  LinLane<NW, FULL, CT> L;
   L.init(blockIdx.x * 16, B, wstride, K, false);
   const int li = L.li, lg = L.lg, j = L.j, jc = L.jc, wave = L.wave;
   const bool vj = L.vj;
-  double Bv[BS ? 1 : KS];
+  CT Bv[BS ? 1 : KS];
   if (!BS) {
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       const int k = 8 * (kk >> 1) + 2 * lg + (kk & 1);
-      Bv[BS ? 0 : kk] = (k < K && vj) ? AexpT[(size_t)k * K + jc] : 0.0;
+      Bv[BS ? 0 : kk] = (k < K && vj) ? (CT)AexpT[(size_t)k * K + jc] : (CT)0;
     }
   }
   const double* __restrict__ Bcol = AexpT + jc;
@@ -913,9 +948,10 @@ __device__ __forceinline__ void bwd_lin_body(
   double* __restrict__ gb = gx + wrow;
   const int top = Lm - 1;
   const int i1 = Lm > 1 ? top - 1 : top, i2 = Lm > 2 ? top - 2 : i1;
-  double g[4], ea[4], eb[4];
+  double g[4];
+  CT ea[4], eb[4];
   {
-    double e0[4], b0v[4];
+    CT e0[4], b0v[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) e0[r] = (Eb + (size_t)top * K)[L.oE[r]];
 #pragma unroll
@@ -925,35 +961,35 @@ __device__ __forceinline__ void bwd_lin_body(
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       if (MODE == 1) {
-        b0v[r] = vj ? ch.term_vec[(size_t)L.gwc[r] * K + jc] : 0.0;
+        b0v[r] = vj ? (CT)ch.term_vec[(size_t)L.gwc[r] * K + jc] : (CT)0;
         g[r] = ch.term_exp[L.gwc[r]];
       } else {
-        b0v[r] = 1.0;
+        b0v[r] = (CT)1;
         g[r] = 0.0;
         if (NW % 4 != 0) (gb + top)[L.oR[r]] = 0.0;
         if (FULL || vj) (bb + (size_t)top * K)[L.oE[r]] = 1.0;
       }
-      sh.P[0][lg + 4 * r][j] = vj ? e0[r] * b0v[r] : 0.0;
+      sh.P[0][LV<CT>::crow(lg, r)][j] = vj ? e0[r] * b0v[r] : (CT)0;
     }
     if (MODE != 1 && NW % 4 == 0) (gb + top)[L.oRw] = 0.0;
   }
   __syncthreads();
   // one step: bh of row t from P[CUR] = Eh_{t+1} * bh_{t+1}; er holds Eh_t
-  auto step = [&](const int t, auto curc, double (&er)[4]) {
+  auto step = [&](const int t, auto curc, CT (&er)[4]) {
     constexpr int CUR = decltype(curc)::value, NXT = 1 - CUR;
     const int t2 = t >= 2 ? t - 2 : 0;
-    double4_t acc, tot;
+    cv4 acc, tot;
     if constexpr (BS) lin_matmul_stream<NW, FULL>(sh, CUR, li, lg, Bcol, K, acc, tot);
-    else lin_matmul<NW>(sh, CUR, li, lg, Bv, acc, tot);
+    else lin_matmul<NW, CT>(sh, CUR, li, lg, Bv, acc, tot);
     ST* __restrict__ bt = bb + (size_t)t * K;
     double* __restrict__ gt = gb + t;
     const ST* __restrict__ E2 = Eb + (size_t)t2 * K;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int e2 = __builtin_amdgcn_frexp_exp(tot[r]);
-      double bv = ldexp(acc[r], -e2);
-      if (BS && !FULL) bv = vj ? bv : 0.0;
-      sh.P[NXT][lg + 4 * r][j] = er[r] * bv;
+      const int e2 = LV<CT>::fexp(tot[r]);
+      CT bv = LV<CT>::ldx(acc[r], -e2);
+      if (BS && !FULL) bv = vj ? bv : (CT)0;
+      sh.P[NXT][LV<CT>::crow(lg, r)][j] = er[r] * bv;
 #if !(SVIHMM_KO_SWEEP & 1)
       if (FULL || vj) bt[L.oE[r]] = bv;
 #endif
@@ -991,8 +1027,9 @@ __global__ __launch_bounds__(64 * NW) void k_sweeps_lin(
     ST* __restrict__ ah, ST* __restrict__ bh, double* __restrict__ hx,
     double* __restrict__ gx, double* __restrict__ local_lb, double* __restrict__ logz,
     double2* __restrict__ zfac, LinChain ch) {
-  extern __shared__ double __attribute__((aligned(16))) lin_smem[];   // sizeof(LinShared<NW>)
-  LinShared<NW>& sh = *reinterpret_cast<LinShared<NW>*>(lin_smem);
+  extern __shared__ double __attribute__((aligned(16))) lin_smem[];   // sizeof(LinShared<NW>) (float P: half of it used)
+  typedef typename LinCT<(MODE == 3 ? 1 : MODE), BS, ST>::t CT;
+  LinShared<NW, CT>& sh = *reinterpret_cast<LinShared<NW, CT>*>(lin_smem);
   if (blockIdx.y == 0)
     fwd_lin_body<NW, FULL, (MODE == 3 ? 1 : MODE), BS, ST>(sh, Eh, kexp, Aexp, a0v, a0e, B,
                                                    MODE == 1 ? Lm - 1 : Lm, wstride, K, ah, hx,
