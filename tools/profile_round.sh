@@ -28,6 +28,7 @@ BENCH="python $ROOT/bench.py --steps 5 --warmup 2 --reps 2 --no-cpu-baseline --n
 { run fetch --kernel-trace --pmc FETCH_SIZE; run write --kernel-trace --pmc WRITE_SIZE; } > $OUT/${TAG}_pmc_hbm.txt
 BENCH="python $ROOT/tools/f32_profile_workload.py"
 { run fetch32 --kernel-trace --pmc FETCH_SIZE; run write32 --kernel-trace --pmc WRITE_SIZE; } > $OUT/${TAG}_pmc_hbm_f32.txt
+run sq32 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS > $OUT/${TAG}_sq_counters_f32.txt
 # configs[4] (K=256, D=64): the wide kernels alone
 BENCH="python $ROOT/tools/c5_profile_workload.py"
 run kt5 --kernel-trace --stats > $OUT/${TAG}_c5_kernel_stats.txt
@@ -35,5 +36,9 @@ run kt5 --kernel-trace --stats > $OUT/${TAG}_c5_kernel_stats.txt
 run sq5 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS > $OUT/${TAG}_c5_sq_counters.txt
 BENCH=$BENCH_ALL
 run sq --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS > $OUT/${TAG}_sq_counters.txt
+# the committed summaries bench.py reads (roofline.frac on the profiler's clock, roofline.traffic)
+cd $ROOT/tools && python kernel_stats_to_json.py $OUT/${TAG}_kernel_stats.txt > $OUT/kernel_stats.json
+python pmc_to_traffic.py $OUT/${TAG}_pmc_hbm.txt $OUT/${TAG}_pmc_hbm_f32.txt > $OUT/pmc_traffic.json
+cp $OUT/kernel_stats.json $OUT/pmc_traffic.json $ROOT/profiles/ 2>/dev/null
 cd $ROOT && python bench.py 2>/dev/null | tail -1 > $OUT/${TAG}_bench.json
 tail -c 600 $OUT/${TAG}_bench.json
