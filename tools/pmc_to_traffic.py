@@ -18,7 +18,7 @@ HEADLINE = {"emission": (r"k_emission_orbit<4, 4(, 2)?>", 7813),
             "finalize": (r"k_finalize", 161)}
 F32 = {"emission": (r"k_emission_bf16x3", 3907),
        "forward_backward": (r"k_sweeps_lin<4, true, 0, false, float>", 488),
-       "stats": (r"k_stats_bf16x3.*", 256),
+       "stats": (r"k_stats_bf16x3.*", 253),
        "finalize": (r"k_finalize", 161)}
 
 
