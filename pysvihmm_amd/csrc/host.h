@@ -184,6 +184,7 @@ struct svihmm_ctx {
   Buf shift_d;                   // the same vector on the device
   bool shifted = false;          // some component is non-zero
   bool center_pending = false;   // svihmm_alloc_obs: centre on the first block that arrives
+  bool center_deferred = false;  // uploaded / un-centred under a Categorical table: a Gaussian family that follows centres it
   int shift_epoch = 0, prior_epoch = -1;
   std::vector<double> prior_mu0; // caller-coordinate prior means of svihmm_set_emission_prior
   // precision mode (svihmm_set_precision): 0 fp64, 1 fp32 (see the header); cur_f32: the batch in

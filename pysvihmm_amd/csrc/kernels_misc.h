@@ -333,3 +333,27 @@ __global__ __launch_bounds__(256) void k_packed_shift(const double* __restrict__
   }
   dst[i] = v;
 }
+
+// column means of the finite entries of rows 0, stride, 2 stride, ... (nsamp of them): the centre of a
+// resident copy whose upload skipped the centring (a Categorical table was active); block = column
+__global__ __launch_bounds__(256) void k_col_mean(const double* __restrict__ obs, int D, int64_t stride,
+                                                  int64_t nsamp, double* __restrict__ c) {
+  __shared__ double rs[256];
+  __shared__ double rn[256];
+  const int d = blockIdx.x;
+  double s = 0.0, n = 0.0;
+  for (int64_t i = threadIdx.x; i < nsamp; i += 256) {
+    const double v = obs[(size_t)(i * stride) * D + d];
+    if (v > -1.7e308 && v < 1.7e308) { s += v; n += 1.0; }
+  }
+  rs[threadIdx.x] = s; rn[threadIdx.x] = n;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) { rs[threadIdx.x] += rs[threadIdx.x + o]; rn[threadIdx.x] += rn[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double m = rn[0] > 0.0 ? rs[0] / rn[0] : 0.0;
+    c[d] = (m > -1.7e308 && m < 1.7e308) ? m : 0.0;
+  }
+}

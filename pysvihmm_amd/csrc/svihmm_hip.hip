@@ -109,6 +109,7 @@ static int shift_rows(svihmm_ctx* h, const double* delta, int64_t row0, int64_t 
 static int store_shift(svihmm_ctx* h, const std::vector<double>& c);
 static int params_follow_centre(svihmm_ctx* h, const double* delta);
 static int drop_auto_status(svihmm_ctx* h);
+static int d2h_sync_small(svihmm_ctx* h, void* dst, const void* src, size_t bytes);
 int svihmm_set_precision(svihmm_ctx* h, int32_t mode) {
   if (!h || (mode != SVIHMM_F64 && mode != SVIHMM_F32)) return fail("svihmm_set_precision: mode must be SVIHMM_F64 or SVIHMM_F32");
   h->prec = mode;
@@ -158,11 +159,12 @@ int svihmm_set_obs(svihmm_ctx* h, const double* obs, int64_t T, int32_t D,
 // the data's spread, so that the emission GEMM's expanded quadratic form does not cancel.
 static void sample_center(const svihmm_ctx* h, const double* obs, int64_t T, int D, std::vector<double>& c) {
   c.assign((size_t)D, 0.0);
+  const_cast<svihmm_ctx*>(h)->center_deferred = false;
   if (h->variant[9] == 1 || !obs || T <= 0) return;      // variant 9 = 1: no automatic centring
   // a Categorical table is the active emission: the column holds symbol indices, which the lookup
   // kernels truncate to int -- it stays exactly as uploaded (round-3 advisor finding: set_emission_cat
   // followed by set_obs centred the symbols)
-  if (h->have_emission && h->emis_cat) return;
+  if (h->have_emission && h->emis_cat) { const_cast<svihmm_ctx*>(h)->center_deferred = true; return; }
   int64_t nsamp = ((int64_t)4 << 20) / D;
   if (nsamp > 65536) nsamp = 65536;
   if (nsamp < 16) nsamp = 16;
@@ -484,6 +486,28 @@ static void from_centred(const svihmm_ctx* h, double* mu, int K, int D) {
   for (int k = 0; k < K; ++k)
     for (int d = 0; d < D; ++d) mu[(size_t)k * D + d] += h->shift[d];
 }
+// A Categorical table was active when the resident copy was uploaded (or un-centred it): the copy
+// holds caller coordinates.  A Gaussian family that arrives now gets the centring the upload skipped:
+// column means of a strided row sample, taken on the device (k_col_mean), then the usual shift.
+static int centre_deferred(svihmm_ctx* h) {
+  if (!h->center_deferred) return 0;
+  h->center_deferred = false;
+  if (h->T <= 0 || !h->obs.p || h->shifted || h->variant[9] == 1) return 0;
+  const int D = h->D;
+  int64_t nsamp = ((int64_t)4 << 20) / D;
+  if (nsamp > 65536) nsamp = 65536;
+  if (nsamp < 16) nsamp = 16;
+  if (nsamp > h->T) nsamp = h->T;
+  const int64_t stride = h->T / nsamp;
+  CK(ensure(h->scratch, (size_t)D * sizeof(double)));
+  hipLaunchKernelGGL(k_col_mean, dim3((unsigned)D), dim3(256), 0, h->stream, (const double*)h->obs.p, D, stride,
+                     nsamp, (double*)h->scratch.p);
+  HIPCK(hipGetLastError());
+  std::vector<double> c((size_t)D, 0.0);
+  CK(d2h_sync_small(h, c.data(), h->scratch.p, (size_t)D * sizeof(double)));
+  return reset_shift(h, c, 0, h->T);
+}
+
 int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* mu,
                             const double* sigma, const double* kappa, const double* nu) {
   if (!h || K <= 0 || D <= 0 || !mu || !sigma || !kappa || !nu)
@@ -493,6 +517,7 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
                 "host and pass them with svihmm_set_lliks / SVIHMM_USE_HOST_LLIKS");
   CK(set_device(h));
   h->lin_stale = true;
+  if (h->D == D) CK(centre_deferred(h));
   const size_t nmu = (size_t)K * D, nsg = (size_t)K * D * D;
   const size_t nin = nmu + nsg + 2 * (size_t)K;
   CK(ensure(h->niw, nin * sizeof(double) + 64));
@@ -524,6 +549,7 @@ int svihmm_set_emission_diag(svihmm_ctx* h, int32_t K, int32_t D, const double* 
                 "host and pass them with svihmm_set_lliks / SVIHMM_USE_HOST_LLIKS");
   CK(set_device(h));
   h->lin_stale = true;
+  if (h->D == D) CK(centre_deferred(h));
   const size_t n = (size_t)K * D;
   CK(ensure(h->niw, 4 * n * sizeof(double) + 64));
   void* pin = nullptr;
@@ -623,6 +649,7 @@ int svihmm_niw_vlb_terms(svihmm_ctx* h, int32_t K, int32_t D, const double* mu, 
 // will read it; svihmm_shift_obs may have moved it) goes back to exact integers and stays uncentred.
 // Called when the table is set and again in front of every lookup / count launch.
 int cat_uncentre(svihmm_ctx* h) {
+  if (h->T > 0) h->center_deferred = true;     // a Gaussian family that follows centres the copy again
   if (!h->shifted || h->T <= 0) return 0;
   std::vector<double> back(h->shift.size());
   for (size_t d = 0; d < back.size(); ++d) back[d] = -h->shift[d];
@@ -1280,6 +1307,7 @@ static int svi_begin_common(svihmm_ctx* h, int K, int D, const double* prior_tra
   CK(set_device(h));
   CK(wait_side_streams(h));
   CK(drop_auto_status(h));
+  if (family != 2) CK(centre_deferred(h));
   const size_t kk = (size_t)K * K;
   {
     // The global step is var_tran <- (1 - rho) var_tran + rho (1 + bA (A_raw + nwin (prior_tran - 1)))
@@ -1720,6 +1748,7 @@ int svihmm_generate(svihmm_ctx* h, int64_t T, int32_t K, int32_t D, const double
   h->center_pending = false;
   {   // centre: the plain average of the state means (a point inside the data)
     std::vector<double> c((size_t)D, 0.0);
+    h->center_deferred = h->have_emission && h->emis_cat;
     if (h->variant[9] != 1 && !(h->have_emission && h->emis_cat)) {
       for (int k = 0; k < K; ++k)
         for (int d = 0; d < D; ++d) c[d] += means[(size_t)k * D + d] / K;

@@ -314,3 +314,39 @@ def test_categorical_table_set_before_the_observations():
                                    o.estep(starts, 40, flags=L.TRANS_WRAP).buf, rtol=1e-9, atol=1e-9)
     finally:
         e.close()
+
+
+def test_gaussian_family_after_a_categorical_table_gets_the_skipped_centring():
+    """Found by the seed-411 campaign of round 4: uploads under an active Categorical table do not centre
+    (round-3 advisor fix), so NIW factors that FOLLOW on data far from the origin met an uncentred copy
+    and tripped the range guard.  The library now takes the skipped centring when the Gaussian family
+    arrives (column means of a row sample, on the device)."""
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    from oracle import ref_c
+    from tests.helpers import make_problem
+    K, D, T, Lm = 4, 3, 3000, 33
+    pb = make_problem(K, D, T, seed=77, miss=0.04)
+    off = np.array([4.0e4, -2.5e4, 1.0e4])
+    starts = np.arange(40, dtype=np.int64) * 70
+    e = HipEngine(0)
+    try:
+        e.set_obs(np.round(np.abs(pb["obs"][:, :1])) % 5, None)          # a symbol column first
+        e.set_globals(pb["mod_init"], pb["ltran"])
+        e.set_emission_cat(np.log(np.full((K, 5), 0.2)))
+        e.set_obs(pb["obs"] + off, pb["mask"])                            # uploaded under the table: not centred
+        assert np.all(e.get_shift() == 0.0)
+        e.set_emission_niw(pb["mu"] + off, pb["sigma"], pb["kappa"], pb["nu"])
+        assert np.abs(e.get_shift() - off).max() < 20.0                   # centred now
+        st = e.estep(starts, Lm, flags=L.TRANS_WRAP)
+        ref = ref_c.estep_minibatch(pb["obs"], pb["mask"], starts, Lm, pb["mod_init"], pb["ltran"], pb["mu"],
+                                    pb["sigma"], pb["kappa"], pb["nu"], flags=2)
+        g = e.estep(starts, Lm, flags=L.TRANS_WRAP)
+        np.testing.assert_allclose(g.A_raw, ref[:K * K].reshape(K, K), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(g.neff, ref[K * K + K * D:K * K + K * D + K], rtol=1e-6, atol=1e-7)
+        # first moments in the caller's coordinates: oracle ran un-offset, so xbar = xbar_ref + neff * off
+        xb = ref[K * K:K * K + K * D].reshape(K, D) + g.neff[:, None] * off[None, :]
+        np.testing.assert_allclose(g.xbar, xb, rtol=1e-6, atol=1e-4)
+        np.testing.assert_array_equal(g.buf, st.buf)
+    finally:
+        e.close()
