@@ -348,18 +348,13 @@ __global__ void k_theta_orbit(const double* __restrict__ theta, int D, int Kp, i
 // MT = row tiles per wave: 2 (128 rows per workgroup) for batches that fill the chip, 1 (64 rows,
 // round 3) for minibatches with fewer than one 128-row workgroup per CU -- the SVI iteration of 64
 // windows is 129 workgroups of 128 rows on 256 CUs.
-// KSP (round 4): split of the feature (k) dimension over KSP groups of four waves.  Minibatch-sized
-// launches run one wave per SIMD and the launch time is ONE wave's chain of 141 dependent k-steps, each
-// with its own theta loads from L2 (every wave streams the whole 288 KB table): with KSP = 2 eight waves
-// share a 64-row tile, each group walks half of the schedule (and reads half of theta), the second
-// group's accumulators join the first's through LDS before the epilogue.
-template <int NT, int U, int MT = 2, int KSP = 1>
-__global__ __launch_bounds__(256 * KSP) void k_emission_orbit(
+template <int NT, int U, int MT = 2>
+__global__ __launch_bounds__(256) void k_emission_orbit(
     const double* __restrict__ obs, const uint8_t* __restrict__ mask,
     const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K,
     const double* __restrict__ orb, uint32_t flags, double* __restrict__ ll,
     double* __restrict__ kexp, double* __restrict__ ll0) {
-  constexpr int ROWS = 64 * MT, KP = 16 * NT, NTH = 256 * KSP;
+  constexpr int ROWS = 64 * MT, KP = 16 * NT;
   typedef typename std::conditional<MT == 2, double2, double>::type XV;   // one column of the wave's row tiles
   extern __shared__ double smem[];
   const int N = D + 1, c = D >> 2, nd = (D >> 1) + 1, nleft = (nd + 3) >> 2;
@@ -367,8 +362,7 @@ __global__ __launch_bounds__(256 * KSP) void k_emission_orbit(
   XV* xs2 = (XV*)smem;                              // [64][LEN]: MT = 2 (row r, row r + 16) pairs
   long long* rowoff = (long long*)(xs2 + 64 * LEN);
   unsigned char* bad_s = (unsigned char*)(rowoff + ROWS);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = (tid >> 6) & 3, kg = tid >> 8;      // row group of the wave; its share of the k-steps
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t g0 = (int64_t)blockIdx.x * ROWS;
   double* xs1 = (double*)xs2;
   // row r of the tile -> wave r >> 5, row tile (r >> 4) & 1, lane row r & 15
@@ -378,7 +372,7 @@ __global__ __launch_bounds__(256 * KSP) void k_emission_orbit(
   {
     const int64_t bw0 = g0 / Lm;
     const unsigned t0 = (unsigned)(g0 - bw0 * Lm);
-    for (int r = tid; r < ROWS; r += NTH) {
+    for (int r = tid; r < ROWS; r += 256) {
       const bool valid = g0 + r < nrows;
       const unsigned x = t0 + (unsigned)(valid ? r : 0);
       const unsigned bwr = x / (unsigned)Lm;
@@ -394,7 +388,7 @@ __global__ __launch_bounds__(256 * KSP) void k_emission_orbit(
   __syncthreads();
   {
     const int sh = 32 - __builtin_clz((unsigned)(D - 1));
-    const int rpp = NTH >> sh, i = tid & ((1 << sh) - 1), rr = tid >> sh;
+    const int rpp = 256 >> sh, i = tid & ((1 << sh) - 1), rr = tid >> sh;
     constexpr int CH = 16;      // loads first, LDS writes after (see K1b)
     for (int rb = 0; rb < ROWS; rb += rpp * CH) {
       double v[CH];
@@ -457,13 +451,7 @@ __global__ __launch_bounds__(256 * KSP) void k_emission_orbit(
   // blocks of U k-steps, (delta, a0) in schedule order; the B operands of block i + 1 are
   // requested before the MFMAs of block i (two register sets, loop unrolled by two blocks)
   const int nblk = nd * (c / U);
-  // this wave group's blocks [b_lo, b_hi) (even starts: the loop below runs in pairs)
-  // (KSP = 2: the split point balances blocks + leftover k-steps, which the last group takes)
-  static_assert(KSP == 1 || KSP == 2, "one or two wave groups");
-  int bsplit = ((nblk * U + nleft) / (2 * U) + 1) & ~1;
-  bsplit = bsplit > nblk ? (nblk & ~1) : bsplit;
-  const int b_lo = (KSP == 1 || kg == 0) ? 0 : bsplit, b_hi = (KSP == 1 || kg == KSP - 1) ? nblk : bsplit;
-  int bd = (b_lo * U) / c, ba = (b_lo * U) - bd * c;   // (delta, a0) of the next block to compute
+  int bd = 0, ba = 0;                                // (delta, a0) of the next block to compute
   auto block = [&](const double (&Bv)[U][NT]) {
     const XV* pa = pa0 + ba;
     const XV* pb = pa + bd;
@@ -482,16 +470,16 @@ __global__ __launch_bounds__(256 * KSP) void k_emission_orbit(
   };
   {
     double B0[U][NT], B1[U][NT];
-    loadblk(b_lo, B0);
-    for (int bi = b_lo; bi < b_hi; bi += 2) {
+    loadblk(0, B0);
+    for (int bi = 0; bi < nblk; bi += 2) {
       loadblk(bi + 1, B1);
       block(B0);
       loadblk(bi + 2, B0);
-      if (bi + 1 < b_hi) block(B1);
+      if (bi + 1 < nblk) block(B1);
     }
   }
   const double* tbs = orb + (size_t)nblk * (U * 4 * KP);
-  if (kg == KSP - 1) {
+  {
     const XV xl = rowp[N - 1];
     const XV* p2 = rowp + lg - 1;
     for (int j = 0; j < nleft; ++j) {
@@ -500,30 +488,6 @@ __global__ __launch_bounds__(256 * KSP) void k_emission_orbit(
       kstep(xl, p2[4 * j], Bv);
       tbs += (size_t)4 * KP;
     }
-  }
-  if constexpr (KSP > 1) {
-    // the other groups' partial sums: [group - 1][row wave][register][lane] behind the row tile
-    double* red = reinterpret_cast<double*>(reinterpret_cast<char*>(bad_s) + ((ROWS + 7) & ~7));
-    if (kg > 0) {
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            red[((size_t)((kg - 1) * 4 + wave) * (MT * NT * 4) + (m * NT + n) * 4 + r) * 64 + lane] = acc[m][n][r];
-    }
-    __syncthreads();
-    if (kg > 0) return;
-#pragma unroll
-    for (int g = 0; g < KSP - 1; ++g)
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            acc[m][n][r] += red[((size_t)(g * 4 + wave) * (MT * NT * 4) + (m * NT + n) * 4 + r) * 64 + lane];
   }
   double outv[MT][NT][4];
 #pragma unroll

@@ -207,18 +207,12 @@ int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled,
     // fewer than one 128-row workgroup per CU: 64-row workgroups (variant[5] = 2: always 128)
     const int MTo = ((n + 127) / 128 < 256 && h->variant[5] != 2) ? 1 : 2;
     const int rows = 64 * MTo;
-    // minibatch-sized launches (64-row workgroups): the feature dimension split over two groups of four
-    // waves (variant[5] = 4: one group)
-    const int KSo = (MTo == 1 && h->variant[5] != 4) ? 2 : 1;
-    const size_t lds = (size_t)rows * LEN * 8 + rows * 8 + ((rows + 7) & ~7) + (KSo > 1 ? (size_t)(KSo - 1) * 4 * NT * 4 * 64 * 8 : 0);
+    const size_t lds = (size_t)rows * LEN * 8 + rows * 9;
     dim3 grid((unsigned)((n + rows - 1) / rows));
-#define EMO(NTV, UV, MTV, KSV) do {                                                                          \
-    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k_emission_orbit<NTV, UV, MTV, KSV>,               \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
-    hipLaunchKernelGGL((k_emission_orbit<NTV, UV, MTV, KSV>), grid, dim3(256 * KSV), lds, stream,            \
-                       (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K,                                 \
-                       (const double*)h->theta_orb.p, flags, out, kexp_out, ll0_out); } while (0)
-#define EMOM(NTV, UV) do { if (MTo == 1 && KSo == 2) EMO(NTV, UV, 1, 2); else if (MTo == 1) EMO(NTV, UV, 1, 1); else EMO(NTV, UV, 2, 1); } while (0)
+#define EMO(NTV, UV, MTV) hipLaunchKernelGGL((k_emission_orbit<NTV, UV, MTV>), grid, dim3(256), lds, stream,  \
+                                        (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K,               \
+                                        (const double*)h->theta_orb.p, flags, out, kexp_out, ll0_out)
+#define EMOM(NTV, UV) do { if (MTo == 1) EMO(NTV, UV, 1); else EMO(NTV, UV, 2); } while (0)
     if (D % 16 == 0) { if (NT == 4) EMOM(4, 4); else if (NT == 3) EMOM(3, 4); else if (NT == 2) EMOM(2, 4); else EMOM(1, 4); }
     else             { if (NT == 4) EMOM(4, 2); else if (NT == 3) EMOM(3, 2); else if (NT == 2) EMOM(2, 2); else EMOM(1, 2); }
 #undef EMOM
