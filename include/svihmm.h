@@ -307,8 +307,8 @@ int64_t svihmm_packed_len(svihmm_ctx* h);
 
 /* ELBO bookkeeping of the SVI loop (hmmsgd_metaobs.py:273-296 global_lower_bound,
  * hmmbase.py:183-185: sum_k var_emit[k].get_vlb()): the data-dependent scalars of the NIW
- * factors' term for the given mean-field parameters (D <= 64: the width of the single-wave
- * factorisation; wider factors take the host formulas, distributions.niw_vlb_batch) --
+ * factors' term for the given mean-field parameters (D <= SVIHMM_NIW_MAX_D; D <= 64 runs the
+ * single-wave factorisation, wider factors the workgroup-per-state one the E-step uses there) --
  * out[k] = log det sigma_mf[k], out[K+k] = tr(sigma_mf[k]^-1 sigma_0[k]),
  * out[2K+k] = (mu_mf[k]-mu_0[k])' sigma_mf[k]^-1 (mu_mf[k]-mu_0[k]); the host adds the
  * closed-form parts (digamma / gammaln of nu, kappa).  The prior (mu_0[K,D], sigma_0[K,D,D])

@@ -593,7 +593,7 @@ int svihmm_niw_vlb_terms(svihmm_ctx* h, int32_t K, int32_t D, const double* mu, 
   if (!h || K <= 0 || D <= 0 || !mu || !sigma || !kappa || !nu || !out3K)
     return fail("svihmm_niw_vlb_terms: bad arguments");
   if (h->prior_K != K || h->prior_D != D) return fail("svihmm_niw_vlb_terms: call svihmm_set_emission_prior first");
-  if (D > 64) return fail("svihmm_niw_vlb_terms: D > 64 not supported (the single-wave factorisation's width)");
+  if (D > SVIHMM_NIW_MAX_D) return fail("svihmm_niw_vlb_terms: D > SVIHMM_NIW_MAX_D");
   CK(set_device(h));
   CK(upload_feature_table(h, D, K));
   const int Fp = h->Fp, Kp = h->Kp;

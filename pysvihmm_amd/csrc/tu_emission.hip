@@ -284,7 +284,15 @@ int launch_niw_vlb(svihmm_ctx* h, int K, int D, const double* dmu, const double*
   ProfScope ps(h, KS_MISC);
 #define NIWV(DM) hipLaunchKernelGGL(k_niw_to_theta_wave<DM>, dim3(K), dim3(64), 0, h->stream, dmu, dsg, dka, dnu, \
                                     K, D, Kp, th2, dstat, (double*)nullptr, ld)
-  if (D <= 8) NIWV(8); else if (D <= 16) NIWV(16); else if (D <= 32) NIWV(32); else NIWV(64);
+  if (D <= 8) NIWV(8); else if (D <= 16) NIWV(16); else if (D <= 32) NIWV(32); else if (D <= 64) NIWV(64);
+  else {
+    // D > 64: the workgroup-per-state factorisation (matrices in LDS), as the E-step uses there
+    const size_t lds = (size_t)(2 * D * (D + 1) + 2 * D) * sizeof(double);
+    if (lds > 64 * 1024)
+      hipFuncSetAttribute((const void*)k_niw_to_theta_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_niw_to_theta_generic, dim3(K), dim3(256), lds, h->stream, dmu, dsg, dka, dnu, K, D, Kp,
+                       th2, dstat, (double*)nullptr, ld);
+  }
 #undef NIWV
   hipLaunchKernelGGL(k_niw_vlb_terms, dim3(K), dim3(64), 0, h->stream, (const double*)th2,
                      (const int*)h->fab.p, h->F, D, Kp, dmu, dnu, (const double*)ld, p0, p0 + nmu, K, dout);

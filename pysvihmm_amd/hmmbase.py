@@ -269,7 +269,7 @@ class VariationalHMMBase(object, metaclass=abc.ABCMeta):
             mu0, sg0, ka0, nu0 = self._prior_arrays()
             terms = None
             eng = self.engine
-            if hasattr(eng, "niw_vlb_terms") and mu.shape[1] <= 64:
+            if hasattr(eng, "niw_vlb_terms"):
                 # log det / trace / quadratic form of sigma_mf from the device (it factorises
                 # sigma_mf for the E-step anyway): the host-side batched solve of K D x D systems
                 # costs more than the device E-step of a 64-window minibatch

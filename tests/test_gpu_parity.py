@@ -441,7 +441,7 @@ def test_obs_uploaded_in_blocks_equals_whole(eng, tmp_path):
         L.check(eng._lib.svihmm_set_obs_rows(eng._h, T - 1, 2, L.dptr(np.zeros((2, D))), None), "rows")
 
 
-@pytest.mark.parametrize("K,D", [(3, 2), (16, 8), (64, 32), (20, 64)])
+@pytest.mark.parametrize("K,D", [(3, 2), (16, 8), (64, 32), (20, 64), (12, 80), (64, 96)])
 def test_niw_vlb_terms_device_vs_host(eng, K, D):
     """svihmm_niw_vlb_terms: log det sigma_mf, tr(sigma_mf^-1 sigma_0) and the prior-mean quadratic
     form from the device's own factorisation; the ELBO term built from them equals the host
