@@ -1479,10 +1479,29 @@ __device__ __forceinline__ void wave_lin4_body(
 #pragma unroll
   for (int u = 0; u < PD; ++u) eq[u] = eclamped(1 + u);
   lp += (ptrdiff_t)PD * dstep;                  // -> row of step 1 + PD
+  // Order of a step (the wave issues in order): the mat-vec on the entering vector and its LDS write
+  // first -- they are the dependency chain --, then, in the shadow of that write and of the barrier,
+  // everything that only has to be done by the next step: the 4-level DPP reduction for the exponent,
+  // the ELBO books, and the store / exponent bookkeeping of the vector the PREVIOUS step produced
+  // (`deferred`).  With the reduction and the stores in front of the mat-vec the first FMA of every
+  // step waited ~150 cycles longer.
+  double olast = 0.0;
+  auto deferred = [&](int sp) {      // vector of step sp (>= 1): store it, keep its exponent
+    op += dstep;
+    if (valid && w == (sp & 3)) *op = olast;               // the four waves take turns storing
+    hkeep = (j == (sp & 63)) ? h : hkeep;
+    if ((sp & 63) == 63 && w == 0) xb[rowof(sp - 63 + j)] = hkeep;
+  };
   auto step = [&](int s, double et) {
     const int cur = s & 1;
-    op += dstep;
-    // exponent and bookkeeping from the entering vector (off the mat-vec's dependency chain)
+    double s0 = 0.0, s1 = 0.0;
+    fmac_row_bcast<0, true>(s0, pcur, a[0]);
+    fmac_row_bcast<1>(s1, pcur, a[1]);
+#define WL4_PAIR(N) fmac_row_bcast<N>(s0, pcur, a[N]); fmac_row_bcast<N + 1>(s1, pcur, a[N + 1]);
+    WL4_PAIR(2) WL4_PAIR(4) WL4_PAIR(6) WL4_PAIR(8) WL4_PAIR(10) WL4_PAIR(12) WL4_PAIR(14)
+#undef WL4_PAIR
+    part[cur][r][tgt] = s0 + s1;
+    __builtin_amdgcn_sched_barrier(0);
     const double tot = wave_sum_dpp(pcur);
     const int e2 = __builtin_amdgcn_frexp_exp(tot);
     if (FWD) {
@@ -1491,22 +1510,15 @@ __device__ __forceinline__ void wave_lin4_body(
       mant = __builtin_amdgcn_frexp_mant(mm);
       hsum += h;
     }
-    double s0 = 0.0, s1 = 0.0;
-    fmac_row_bcast<0, true>(s0, pcur, a[0]);
-    fmac_row_bcast<1>(s1, pcur, a[1]);
-#define WL4_PAIR(N) fmac_row_bcast<N>(s0, pcur, a[N]); fmac_row_bcast<N + 1>(s1, pcur, a[N + 1]);
-    WL4_PAIR(2) WL4_PAIR(4) WL4_PAIR(6) WL4_PAIR(8) WL4_PAIR(10) WL4_PAIR(12) WL4_PAIR(14)
-#undef WL4_PAIR
-    part[cur][r][tgt] = s0 + s1;
+    if (s > 1) deferred(s - 1);
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     const double acc = (part[cur][0][j] + part[cur][1][j]) + (part[cur][2][j] + part[cur][3][j]);
     double o;
     if (FWD) { o = ldexp(acc * et, -e2); if (!FULLK) o = valid ? o : 0.0; pcur = o; }
     else { o = ldexp(acc, -e2); if (!FULLK) o = valid ? o : 0.0; pcur = et * o; }
     h += (double)e2;
-    if (valid && w == (s & 3)) *op = o;                    // the four waves take turns storing
-    hkeep = (j == (s & 63)) ? h : hkeep;
-    if ((s & 63) == 63 && w == 0) xb[rowof(s - 63 + j)] = hkeep;
+    olast = o;
   };
   int s = 1;
   for (; s + 2 * PD <= Lm; s += PD) {           // every load of this trip: row s + u + PD <= Lm - 1
@@ -1529,6 +1541,7 @@ __device__ __forceinline__ void wave_lin4_body(
 #pragma unroll
   for (int u = 0; u < PD; ++u)
     if (s + u < Lm) step(s + u, eq[u]);
+  if (Lm > 1) deferred(Lm - 1);
   if (w != 0) return;
   {
     const int sl = Lm - 1, s0 = sl & ~63;
