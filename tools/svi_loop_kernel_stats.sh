@@ -1,3 +1,6 @@
+#!/bin/bash
+# rocprofv3 kernel statistics of the 64-window device-resident SVI loop (tools/r4_svi_probe.py):
+# the kernels of the iteration chain with their average durations.  Run on the GPU box through gpurun.
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_w
 rocprofv3 --kernel-trace --stats -d /tmp/prof_w -o w -- python $GRAFT_REPO_ROOT/tools/r4_svi_probe.py > /tmp/prof_w.log 2>&1
