@@ -410,45 +410,8 @@ int svihmm_import_packed(svihmm_ctx* h, const double* packed_in);
  * used for barriers and max-over-ranks timing. */
 int svihmm_allreduce_host(svihmm_ctx* h, double* buf, int64_t n, int32_t op);
 
-/* ---- measurement ------------------------------------------------------------------ */
-/* When enabled, every kernel launched by the handle is bracketed by HIP events on
- * the handle's stream; svihmm_profile_read returns accumulated milliseconds and
- * launch counts per kernel slot since the last reset. */
-#define SVIHMM_NKERN 12
-/* on = 0: off; 1: every slot; SVIHMM_PROF_SLOTS | (1 << slot) | ...: those slots only (an event
- * pair between two dependent kernels costs a few microseconds of dispatch -- measured 0.055 ms on
- * the 3.15 ms bench step with all slots -- so a timed region that wants one kernel's duration
- * brackets only that kernel). */
-#define SVIHMM_PROF_SLOTS 0x40000000
-int svihmm_profile_enable(svihmm_ctx* h, int32_t on);
-int svihmm_profile_reset(svihmm_ctx* h);
-int svihmm_profile_read(svihmm_ctx* h, double ms_out[SVIHMM_NKERN],
-                        int64_t count_out[SVIHMM_NKERN]);
-const char* svihmm_kernel_name(int32_t slot);
-/* Selects the kernel generation for A/B measurement (0 = default/best).
- * which 0 emission (1 VALU, 2 MFMA) | 1 statistics (1 VALU, 2 MFMA, 3 pipelined MFMA)
- * | 2 sweeps (1 wave-per-window, 2 log-domain MFMA, 3 scaled linear-domain MFMA)
- * | 3 emission row tiles per wave | 4 two-stream E-step pipeline (1 off, 2 on; default off)
- * | 6 blocked scan for one long window (B = 1, Lm >= 2048, K <= 64; 1 = off)
- * | 9 automatic centring of the resident observations at upload (1 = off: c = 0)
- * | 12 barrier-free statistics GEMM with three LDS buffers (1 = off: the double-buffered kernel)
- * | 11 svihmm_allreduce_packed forms the sum in caller coordinates also at one rank (1 = on: the
- *      multi-rank path's coordinate round trip, exercised on a single GPU)
- * | 7 scaled sweeps' kernel family (K > 128: 1 one state tile per wave, 2 two tiles per wave for every K)
- * | 13 wide models' sweeps with 32 windows per workgroup (1 = off: 16)
- * | 14 wide models' transition statistic in 128 x 64 blocks (1 = off: 64 x 64)
- * | 15 wide models' statistics GEMM forms q = ah bh scale itself (1 = off: separate posterior pass;
- *      2, measurement only: a separate pass for every K)
- * | 10 statistics GEMM tiling (1: five feature tiles per wave for every shape) and, in the fp32 mode, its
- *      pipe (2: the fp32-input MFMA kernel instead of the three-term bf16 one; 3: the bf16 kernel also
- *      below its batch-size floor of 32 768 rows)
- * | 7 = 9, measurement only: the scaled sweeps are skipped (tools/r4_overlap_probe.py) */
-int svihmm_set_variant(svihmm_ctx* h, int32_t which, int32_t value);
-
-/* ---- diagnostics ------------------------------------------------------------------- */
-/* One v_mfma_f64_16x16x4_f64 on A[16,4] x B[4,16] -> C[16,16] (operand-layout check). */
-int svihmm_selftest_mfma(svihmm_ctx* h, const double* A16x4, const double* B4x16,
-                         double* C16x16);
+/* Measurement hooks (per-kernel HIP-event timing, kernel-generation selection for A/B runs and the
+ * test suite, the MFMA operand-layout self-test) are NOT part of this boundary: include/svihmm_debug.h. */
 
 #ifdef __cplusplus
 }

@@ -105,11 +105,31 @@ class OracleEngine(object):
         self.ltran = np.array(ltran, dtype=np.float64)
         self.K = self.ltran.shape[0]
 
+    def _svi_on_upload(self, family, factors):
+        """What an emission upload does to a running device loop on libsvihmm_hip.so
+        (svihmm_set_emission_niw / _diag / _cat): a re-push of the loop's OWN family and shape
+        replaces its factors (the loop's factor block is the handle's parameter block; a
+        Categorical table upload leaves the Dirichlet factors alone), anything else ends the loop."""
+        sv = getattr(self, "_svi", None)
+        if sv is None or getattr(self, "_svi_internal", False):
+            return
+        fam = sv.get("family", "niw")
+        same = fam == family
+        if same and family == "cat":
+            same = factors[0].shape == sv["mf"].shape
+        elif same:
+            same = all(np.shape(a) == np.shape(b) for a, b in zip(factors, sv["mf"]))
+        if not same:
+            self._svi = None
+        elif family != "cat":
+            sv["mf"] = [np.array(a, dtype=np.float64) for a in factors]
+
     def set_emission_niw(self, mu, sigma, kappa, nu, check=True):
         self._pre_mutate()
         self.V = 0
         self.diag = False
         self.em = tuple(np.array(a, dtype=np.float64) for a in (mu, sigma, kappa, nu))
+        self._svi_on_upload("niw", self.em)
         for k in range(len(self.em[2])):
             np.linalg.cholesky(self.em[1][k])
 
@@ -118,6 +138,7 @@ class OracleEngine(object):
         self.V = 0
         self.diag = True
         self.emd = tuple(np.array(a, dtype=np.float64) for a in (mu, nus, alphas, betas))
+        self._svi_on_upload("diag", self.emd)
         if not all(np.all(a > 0) for a in self.emd[1:]):
             raise RuntimeError("set_emission_diag: nus / alphas / betas must be positive")
 
@@ -126,6 +147,7 @@ class OracleEngine(object):
         self.diag = False
         self.cat = np.array(logp, dtype=np.float64)
         self.V = self.cat.shape[1]
+        self._svi_on_upload("cat", (self.cat,))
 
     def set_lliks(self, lliks):
         self._pre_mutate()
@@ -362,11 +384,15 @@ class OracleEngine(object):
         from pysvihmm_amd.distributions import Categorical, DiagonalGaussian
         sv = self._svi
         K = self.K
-        if sv["family"] == "diag":
-            self.set_emission_diag(*sv["mf"])
-        else:
-            a = sv["mf"]
-            self.set_emission_cat(digamma(a) - digamma(a.sum(1))[:, None])
+        self._svi_internal = True
+        try:
+            if sv["family"] == "diag":
+                self.set_emission_diag(*sv["mf"])
+            else:
+                a = sv["mf"]
+                self.set_emission_cat(digamma(a) - digamma(a.sum(1))[:, None])
+        finally:
+            self._svi_internal = False
         self.estep(starts, Lm, flags=flags, read=False, inner=inner)
         self.allreduce_packed()
         st = self._packed
@@ -401,13 +427,19 @@ class OracleEngine(object):
         np.linalg.eig as the reference does, psi :502-504, the minibatch loop, global_update
         :1010-1069, global_lower_bound :273-296)."""
         from pysvihmm_amd.distributions import Gaussian
-        sv = self._svi
+        sv = getattr(self, "_svi", None)
+        if sv is None:
+            raise RuntimeError("svihmm_svi_iteration: call svihmm_svi_begin first")
         sv["var_init"] = R.stationary_init(sv["var_tran"])
         mod_init, ltran = R.psi_expectations(sv["var_init"], sv["var_tran"])
         self.set_globals(mod_init, ltran)
         if sv.get("family", "niw") != "niw":
             return self._svi_iteration_family(it, starts, nwin_total, Lm, flags, rho, bfactA, bfactE, inner)
-        self.set_emission_niw(*sv["mf"])
+        self._svi_internal = True
+        try:
+            self.set_emission_niw(*sv["mf"])
+        finally:
+            self._svi_internal = False
         self.estep(starts, Lm, flags=flags, read=False, inner=inner)
         self.allreduce_packed()
         st = self._packed
@@ -445,6 +477,8 @@ class OracleEngine(object):
         return self.mod_init.copy(), self.ltran.copy()
 
     def svi_read_elbo(self, n):
+        if getattr(self, "_svi", None) is None:
+            raise RuntimeError("svihmm_svi_read_elbo: bad arguments")
         return self._svi["elbo"][:n].copy(), np.zeros(n)
 
     def svi_read_state(self):

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/svihmm.h"
+#include "../../include/svihmm_debug.h"
 #include "svihmm_common.h"
 
 // ------------------------------------------------------------------------------------
@@ -102,6 +103,9 @@ struct svihmm_ctx {
   Buf uwb;                  // fp32 mode: centred factors U_k as bf16 triples + bias (k_emission_bf16x3)
   void* uw_zero_p = nullptr;
   bool uw_valid = false;    // uwb matches the NIW factors in h->niw
+  Buf uwd;                  // the same for 32 < D <= 64 / wide models (k_emission_bf16x3d: 32 KB pair records)
+  void* uwd_zero_p = nullptr; size_t uwd_zero_n = 0;
+  bool uwd_valid = false, emd_attr_set[2] = {false, false};
   bool emb_attr_set = false;
   bool emis_cat = false; int V = 0;          // Categorical emission: table [V][K] = E log theta
   bool emis_diag = false;                    // diagonal Gaussian family: 2 D + 1 features, h->niw = [mu | nus | alphas | betas]
@@ -239,6 +243,8 @@ struct StatsPlan { int64_t rpc, nchunk; };
 #define LIN_WAVE_MAX 1025
 // up to this many windows: four waves per (window, direction); 2 x 256 x 4 = 2048 waves, two per SIMD
 #define LIN_WAVE4_MAX 256
+// up to this many windows: the register-resident one-wave kernel (k_wave_linr; round 5)
+#define LIN_WAVER_MAX 256
 
 extern "C" {
 int d2h(svihmm_ctx* h, void* dst, const void* src, size_t bytes);

@@ -771,6 +771,256 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // ------------------------------------------------------------------------------------
+//  K1e (round 5): the centred bf16 x 3 emission for 32 < D <= 64 and for wide models (K > 64; any
+//  D <= 64 through this kernel's WIDE form).  Same arithmetic as K1d: ll[t][k] = c_k - |U_k x_t + b_k|^2,
+//  x and U as three bf16 terms, six products in fp32 accumulators.  U (64 components x 64 dimensions,
+//  lower triangular) is cut into 32 x 16 blocks; per state the blocks that are not identically zero are
+//      B0: comps  0..31 x dims  0..15      B1: comps 32..63 x dims  0..15
+//      B2: comps 32..63 x dims 16..31      B3: comps 32..63 x dims 32..47
+//  and the two half blocks comps 16..31 x dims 16..31 and comps 48..63 x dims 48..63, which the two
+//  states of a pair share (rows 0..15: first state, rows 16..31: second): S0, S1 -- ten MFMAs per pair
+//  and product term instead of sixteen.  Record of a pair: 3 terms x 10 blocks x 1 KB, then 2 x 64 bias
+//  floats and the two constants (EMD_REC = 32 KB, 32 chunks of 1 KB: four per wave).
+//  Workgroup = 8 waves x 32 rows (one 32-row tile per wave: six accumulators = 96 registers), ONE per
+//  CU; the pair records stream global -> LDS through two buffers (the ten blocks of a pair are read
+//  just in time, three 16-byte LDS reads in front of their six MFMAs), one barrier per pair.
+//  grid.y = group of 64 states.  WIDE: the plain log-likelihoods go out as float [rows][K] (the wide
+//  models' scaling pass and sweeps follow); otherwise (K <= 64) the scaled epilogue of K1d.
+// ------------------------------------------------------------------------------------
+constexpr int EMD_BLK = 10;
+constexpr int EMD_REC = 32768;
+constexpr int EMD_BIAS = 3 * EMD_BLK * 1024;      // byte offset of the bias floats in a record
+typedef unsigned emd_u4 __attribute__((ext_vector_type(4)));
+template <bool WIDE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_emission_bf16x3d(
+    const double* __restrict__ obs, const uint8_t* __restrict__ mask,
+    const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K,
+    const char* __restrict__ uw, uint32_t flags,
+    float* __restrict__ Eh, double* __restrict__ kexp, double* __restrict__ ll0) {
+  constexpr int ROWS = 256;
+  extern __shared__ uint4 smem4[];
+  char* stage = reinterpret_cast<char*>(smem4);                      // [2][EMD_REC]
+  float* tile_s = reinterpret_cast<float*>(stage + 2 * EMD_REC);     // [8 waves][32 rows][64 states]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t = lane & 31, hh = lane >> 5;
+  const int64_t g0 = (int64_t)blockIdx.x * ROWS;
+  const int k0 = 64 * blockIdx.y;                                    // first state of this workgroup's group
+  const int kg = K - k0 < 64 ? K - k0 : 64;                          // states in the group
+  const int npair = (kg + 1) >> 1;
+  const char* __restrict__ urec = uw + (size_t)(k0 >> 1) * EMD_REC;
+  const bool d48 = D <= 48;                                          // (uniform) no dimensions 48..63: S1 is all zero
+
+  auto stage_load = [&](int pr, int buf) {
+    const char* src = urec + (size_t)pr * EMD_REC + lane * 16;
+    char* dst = stage + buf * EMD_REC;
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) emb_glds16(src + (wave + 8 * c4) * 1024, dst + (wave + 8 * c4) * 1024);
+  };
+  stage_load(0, 0);
+
+  // ---- the lane's row: dimensions 16 c + 8 hh + e as three bf16 terms (B operands)
+  embf8_t xb[3][4];
+  int bflag;
+  {
+    const int64_t g = g0 + wave * 32 + t;
+    const bool valid = g < nrows;
+    const int64_t gg = valid ? g : 0;
+    const int64_t wi = gg / Lm;
+    const int tt = (int)(gg - wi * Lm);
+    const int64_t orow = starts[wi] + tt;
+    int bd = 0;
+    if (valid && (flags & SVIHMM_MASK_AS_NAN) && mask) bd = mask[orow] != 0;
+    const double* xp = obs + orow * D;
+    bool isnan_ = false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double v[8];
+      const int i0 = 16 * c + 8 * hh;
+      if ((D & 7) == 0) {
+        const bool ok = valid && i0 < D;
+        const double2* x2 = reinterpret_cast<const double2*>(xp + (ok ? i0 : 0));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const double2 q2 = x2[e];
+          v[2 * e] = ok ? q2.x : 0.0; v[2 * e + 1] = ok ? q2.y : 0.0;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const bool ok = valid && i0 + e < D;
+          const double x = xp[ok ? i0 + e : 0];
+          v[e] = ok ? x : 0.0;
+        }
+      }
+      uint32_t w3[3][4];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (v[e] != v[e]) { isnan_ = true; v[e] = 0.0; }
+        uint32_t t3[3];
+        bf16_split3f((float)v[e], t3);
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+          if (e & 1) w3[s3][e >> 1] |= t3[s3] << 16; else w3[s3][e >> 1] = t3[s3];
+        }
+      }
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) xb[s3][c] = emb_cast(make_uint4(w3[s3][0], w3[s3][1], w3[s3][2], w3[s3][3]));
+    }
+    int bf = bd | (isnan_ ? 1 : 0);
+    bf |= __shfl_xor(bf, 32, 64);
+    bflag = bf | ((valid && tt == 0) ? 2 : 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                                   // record 0 has landed
+
+  float* tw = tile_s + wave * 32 * 64;
+  const emf16_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  constexpr int TA[6] = {0, 0, 1, 0, 2, 1}, TB[6] = {0, 1, 0, 2, 0, 1};
+  for (int sp = 0; sp < npair; ++sp) {
+    const char* st = stage + (sp & 1) * EMD_REC;
+    emf16_t a0[2], a1[2], s0 = zero16, s1 = zero16;                  // comps 0..31 / 32..63 of the two states; shared halves
+    float cst[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 b4 = *reinterpret_cast<const float4*>(st + EMD_BIAS + (64 * u + 8 * q + 4 * hh) * 4);
+        const float4 c4 = *reinterpret_cast<const float4*>(st + EMD_BIAS + (64 * u + 32 + 8 * q + 4 * hh) * 4);
+        a0[u][4 * q] = b4.x; a0[u][4 * q + 1] = b4.y; a0[u][4 * q + 2] = b4.z; a0[u][4 * q + 3] = b4.w;
+        a1[u][4 * q] = c4.x; a1[u][4 * q + 1] = c4.y; a1[u][4 * q + 2] = c4.z; a1[u][4 * q + 3] = c4.w;
+      }
+      cst[u] = *reinterpret_cast<const float*>(st + EMD_BIAS + (128 + u) * 4);
+    }
+    // (the C++ LDS reads above sit in front of the copy: the compiler waits for an outstanding copy
+    //  before any LDS load it can see)
+    __builtin_amdgcn_sched_barrier(0);
+    stage_load(sp + 1, (sp + 1) & 1);                                // (behind the last pair: a spare record)
+    __builtin_amdgcn_sched_barrier(0);
+    // The ten blocks, software-pipelined: block i + 1's three terms are requested (16-byte LDS reads)
+    // before block i's six MFMAs.  The reads are inline asm with their own lgkmcnt waits: for a C++
+    // LDS load behind the global -> LDS copy just issued the compiler would first wait for that copy.
+    emd_u4 A[2][3];
+    const unsigned sbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)const_cast<char*>(st) + lane * 16;
+#define EMD_RD(SET, BLK) do {                                                                                   \
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(A[SET][0]) : "v"(sbase), "n"((0 * EMD_BLK + BLK) * 1024)); \
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(A[SET][1]) : "v"(sbase), "n"((1 * EMD_BLK + BLK) * 1024)); \
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(A[SET][2]) : "v"(sbase), "n"((2 * EMD_BLK + BLK) * 1024)); \
+    } while (0)
+#define EMD_WAIT(SET, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(A[SET][0]), "+v"(A[SET][1]), "+v"(A[SET][2]))
+#define EMD_MM(SET, C, ACC) do {                                                                                \
+      _Pragma("unroll") for (int pi = 0; pi < 6; ++pi)                                                          \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(embf8_t, A[SET][TA[pi]]), xb[TB[pi]][C], ACC, 0, 0, 0); \
+    } while (0)
+    EMD_RD(0, 0);
+    EMD_RD(1, 1); EMD_WAIT(0, 3); EMD_MM(0, 0, a0[0]);
+    EMD_RD(0, 2); EMD_WAIT(1, 3); EMD_MM(1, 0, a0[1]);
+    EMD_RD(1, 3); EMD_WAIT(0, 3); EMD_MM(0, 0, a1[0]);
+    EMD_RD(0, 8); EMD_WAIT(1, 3); EMD_MM(1, 0, a1[1]);
+    EMD_RD(1, 4); EMD_WAIT(0, 3); EMD_MM(0, 1, s0);
+    EMD_RD(0, 5); EMD_WAIT(1, 3); EMD_MM(1, 1, a1[0]);
+    EMD_RD(1, 6); EMD_WAIT(0, 3); EMD_MM(0, 1, a1[1]);
+    EMD_RD(0, 7); EMD_WAIT(1, 3); EMD_MM(1, 2, a1[0]);
+    if (!d48) {
+      EMD_RD(1, 9); EMD_WAIT(0, 3); EMD_MM(0, 2, a1[1]);
+      EMD_WAIT(1, 0); EMD_MM(1, 3, s1);
+    } else {
+      EMD_WAIT(0, 0); EMD_MM(0, 2, a1[1]);
+    }
+#undef EMD_RD
+#undef EMD_WAIT
+#undef EMD_MM
+    // |y|^2 of the lane half's components (registers 0..7: the block's rows 0..15, 8..15: rows 16..31)
+    float pp[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 8; r += 2) {
+        p0 = fmaf(a0[u][r], a0[u][r], p0); p1 = fmaf(a0[u][r + 1], a0[u][r + 1], p1);
+        p0 = fmaf(a1[u][r], a1[u][r], p0); p1 = fmaf(a1[u][r + 1], a1[u][r + 1], p1);
+      }
+#pragma unroll
+      for (int r = 0; r < 8; r += 2) {
+        const float y0 = a0[u][8 + r] + s0[8 * u + r], y1 = a0[u][9 + r] + s0[8 * u + r + 1];
+        const float z0 = a1[u][8 + r] + s1[8 * u + r], z1 = a1[u][9 + r] + s1[8 * u + r + 1];
+        p0 = fmaf(y0, y0, p0); p1 = fmaf(y1, y1, p1);
+        p0 = fmaf(z0, z0, p0); p1 = fmaf(z1, z1, p1);
+      }
+      pp[u] = cst[u] - (p0 + p1);
+    }
+    // the halves exchange: lanes 0..31 finish the pair's first state, lanes 32..63 its second
+    {
+      const int kl = 2 * sp + hh;
+      const float send = hh ? pp[0] : pp[1];
+      const float keep = hh ? pp[1] : pp[0];
+      const float recv = __shfl_xor(send, 32, 64);
+      tw[t * 64 + (kl ^ ((t & 15) << 2))] = keep + recv;
+    }
+    emb_step_barrier();                                              // next record landed, this one free
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- epilogue: 16 lanes per row of the wave's own tile, four adjacent states each
+  const int sg = lane & 15, rq = lane >> 4;
+  const double L2E = 1.4426950408889634074;
+  const float l2e = 1.44269504f, fbig = 3.0e38f;
+  for (int it = 0; it < 8; ++it) {
+    const int rl = it * 4 + rq;
+    const int64_t g = g0 + wave * 32 + rl;
+    const float4 v4 = *reinterpret_cast<const float4*>(tw + rl * 64 + ((4 * sg) ^ ((rl & 15) << 2)));
+    const int bf = __shfl(bflag, rl, 64);
+    float v[4] = {v4.x, v4.y, v4.z, v4.w};
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float x = v[i];
+      x = (x != x || (bf & 1)) ? 0.0f : fminf(fmaxf(x, -fbig), fbig);
+      v[i] = (WIDE || 4 * sg + i < kg) ? x : -INFINITY;
+      mx = fmaxf(mx, v[i]);
+    }
+    if (WIDE) {
+      // plain log-likelihoods of this group's states (nan_to_num'ed; rows masked as missing: 0)
+      if (g < nrows) {
+        float* orow = Eh + g * K + k0 + 4 * sg;
+        if (kg == 64 && (K & 3) == 0) *reinterpret_cast<float4*>(orow) = make_float4(v[0], v[1], v[2], v[3]);
+        else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) if (4 * sg + i < kg) orow[i] = v[i];
+        }
+        if (ll0 && (bf & 2)) {
+          double* o0 = ll0 + (g / Lm) * K + k0 + 4 * sg;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) if (4 * sg + i < kg) o0[i] = (double)v[i];
+        }
+      }
+      continue;
+    }
+    mx = row16_max_f32(mx);
+    const double kx = (fabsf(mx) < 1e30f) ? ceil((double)mx * L2E) : 0.0;
+    const float fr = (float)fma((double)mx, L2E, -kx);
+    float e[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(fmaf(v[i] - mx, l2e, fr));
+    if (g < nrows) {
+      float* orow = Eh + g * K + 4 * sg;
+      if (K == 64) *reinterpret_cast<float4*>(orow) = make_float4(e[0], e[1], e[2], e[3]);
+      else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (4 * sg + i < K) orow[i] = e[i];
+      }
+      if (sg == 0) kexp[g] = kx;
+      if (ll0 && (bf & 2)) {
+        double* o0 = ll0 + (g / Lm) * K + 4 * sg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (4 * sg + i < K) o0[i] = (double)v[i];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 //  K0: NIW mean-field factors -> theta (one workgroup per state).  Cholesky of sigma_mf,
 //      W = (nu/2) sigma^-1 = (nu/2) L^-T L^-1, E log|Lambda| (digamma), linear and constant
 //      terms of the quadratic form.  status[0] = 1 + k if sigma_k is not positive definite.
@@ -1019,6 +1269,53 @@ __global__ __launch_bounds__(64) void k_niw_to_theta_wave(
       }
     }
   }
+  if constexpr (DMAX == 64) {
+    // centred factor in the record layout of k_emission_bf16x3d (32 < D <= 64, wide models): lane
+    // 32 hh + jj writes, for both component blocks cb (component 32 cb + jj) and the four dimension
+    // blocks c (entries e = 0..7: U[comp][16 c + 8 hh + e]), the 16 bytes of the blocks that are not
+    // identically zero: B0 (cb 0, c 0), B1..B3 (cb 1, c 0..2), and its 16 rows of the half blocks the
+    // pair shares, S0 (cb 0, c 1, components 16..31) and S1 (cb 1, c 3, components 48..63)
+    if (uw) {
+      const double shn = sqrt(hn);
+      const int jj = a & 31, hh = a >> 5, u = k & 1;
+      uint4* blk = uw + (size_t)(k >> 1) * (EMD_REC / 16);
+      float* ub = reinterpret_cast<float*>(reinterpret_cast<char*>(blk) + EMD_BIAS);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (cb == 0 && c >= 2) continue;
+          const bool half = (cb == 0 && c == 1) || (cb == 1 && c == 3);
+          const int idx = cb == 0 ? (c == 0 ? u : 8) : (c < 3 ? 2 + 2 * c + u : 9);
+          const int pos = half ? 32 * hh + 16 * u + (jj - 16) : a;
+          const int comp = 32 * cb + jj;
+          uint32_t w3[3][4];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int cl = 16 * c + 8 * hh + e;
+            const double v = (comp < D && cl < D) ? shn * Ls[cl][comp] : 0.0;      // X[comp][cl]
+            uint32_t t3[3];
+            bf16_split3(v, t3);
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) {
+              if (e & 1) w3[s3][e >> 1] |= t3[s3] << 16; else w3[s3][e >> 1] = t3[s3];
+            }
+          }
+          if (!half || jj >= 16) {
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3)
+              blk[(s3 * EMD_BLK + idx) * 64 + pos] = make_uint4(w3[s3][0], w3[s3][1], w3[s3][2], w3[s3][3]);
+          }
+        }
+      }
+      double b = 0.0;
+      if (a < D) {
+#pragma unroll
+        for (int cl = 0; cl < DMAX; ++cl) b = fma(Ls[cl][a], ms[cl], b);                  // sum_c X[a][c] m_c
+      }
+      ub[64 * u + a] = (float)(-shn * b);
+    }
+  }
   double wmi = 0.0;
   const int i = a;
 #pragma unroll
@@ -1044,6 +1341,9 @@ __global__ __launch_bounds__(64) void k_niw_to_theta_wave(
     if (status && mWm > NIW_CANCEL_LIMIT) atomicMax(status, NIW_STATUS_RANGE + 1 + k);
     if constexpr (DMAX <= 32) {   // ll = cst - |U x + b|^2; each half of the wave adds its share of the squares to cst / 2
       if (uw) reinterpret_cast<float*>(uw + (size_t)(k >> 1) * (EMB_REC / 16) + EMB_BLOCKS * 64)[64 + (k & 1)] = (float)(0.5 * cst);
+    }
+    if constexpr (DMAX == 64) {
+      if (uw) reinterpret_cast<float*>(reinterpret_cast<char*>(uw + (size_t)(k >> 1) * (EMD_REC / 16)) + EMD_BIAS)[128 + (k & 1)] = (float)(0.5 * cst);
     }
   }
 }

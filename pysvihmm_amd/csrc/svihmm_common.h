@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include "../../include/svihmm.h"
+#include "../../include/svihmm_debug.h"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 #define ST_RB 32

@@ -518,6 +518,8 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
   CK(set_device(h));
   h->lin_stale = true;
   if (h->D == D) CK(centre_deferred(h));
+  // (a device loop of another family or shape kept its factors in h->niw: it ends here)
+  if (h->svi_active && !(h->svi_family == 0 && h->svi_K == K && h->svi_D == D)) h->svi_active = false;
   const size_t nmu = (size_t)K * D, nsg = (size_t)K * D * D;
   const size_t nin = nmu + nsg + 2 * (size_t)K;
   CK(ensure(h->niw, nin * sizeof(double) + 64));
@@ -562,7 +564,10 @@ int svihmm_set_emission_diag(svihmm_ctx* h, int32_t K, int32_t D, const double* 
   std::memcpy(hp + 2 * n, alphas, n * sizeof(double));
   std::memcpy(hp + 3 * n, betas, n * sizeof(double));
   if (h->vlb_pending) { HIPCK(hipStreamWaitEvent(h->stream, h->svi_ed, 0)); h->vlb_pending = false; }
-  h->svi_active = false;               // (the resident NIW state of an SVI loop lived in h->niw)
+  // a running device loop survives a re-push of ITS OWN family and shape (the loop's factor block IS
+  // h->niw: the validation hooks of infer() -- full_predprob, adaptive L, growBuffer -- re-upload the
+  // factors they just read back); any other loop's resident state is gone with this upload
+  if (!(h->svi_active && h->svi_family == 1 && h->svi_K == K && h->svi_D == D)) h->svi_active = false;
   CK(drop_auto_status(h));
   CK(pull_small(h, h->niw.p, hp, 4 * n * sizeof(double)));
   CK(pin_release(h, slot));
@@ -662,6 +667,8 @@ int svihmm_set_emission_cat(svihmm_ctx* h, int32_t K, int32_t V, const double* l
   CK(set_device(h));
   h->lin_stale = true;
   h->center_pending = false;
+  // (a device loop of another family or shape ends with this upload, as in svihmm_set_emission_niw / _diag)
+  if (h->svi_active && !(h->svi_family == 2 && h->svi_K == K && h->V == V)) h->svi_active = false;
   CK(drop_auto_status(h));
   CK(cat_uncentre(h));
   const size_t n = (size_t)K * V;
@@ -1304,6 +1311,10 @@ static int svi_begin_common(svihmm_ctx* h, int K, int D, const double* prior_tra
                             int maxit, int family) {
   if (K > 1024) return fail("svihmm_svi_begin: K > 1024 unsupported");
   if (h->D != D) return fail("svihmm_svi_begin: D does not match the resident observations");
+  // from here on the previous loop's state is being overwritten: a begin that fails half way must not
+  // leave it marked as live (svi_begin_finish sets the flag again once everything is in place)
+  h->svi_active = false;
+  h->svi_adagrad = false;
   CK(set_device(h));
   CK(wait_side_streams(h));
   CK(drop_auto_status(h));
@@ -1427,10 +1438,10 @@ int svihmm_svi_begin_diag(svihmm_ctx* h, int32_t K, int32_t D, const double* pri
   if (!h || K <= 0 || D <= 0 || !prior_tran || !var_tran || !prior_blk || !factor_blk || maxit <= 0)
     return fail("svihmm_svi_begin_diag: bad arguments");
   if (D > SVIHMM_DIAG_MAX_D) return fail("svihmm_svi_begin_diag: D > SVIHMM_DIAG_MAX_D");
-  CK(svi_begin_common(h, K, D, prior_tran, var_tran, maxit, 1));
   const size_t n4 = 4 * (size_t)K * D;
-  for (size_t i = (size_t)K * D; i < n4; ++i)
+  for (size_t i = (size_t)K * D; i < n4; ++i)       // (validated before any state is touched)
     if (!(prior_blk[i] > 0.0) || !(factor_blk[i] > 0.0)) return fail("svihmm_svi_begin_diag: nus, alphas, betas must be positive");
+  CK(svi_begin_common(h, K, D, prior_tran, var_tran, maxit, 1));
   CK(ensure(h->svi_prior, (n4 + 8) * sizeof(double)));
   CK(ensure(h->niw, n4 * sizeof(double) + 64));
   CK(svi_upload(h, h->svi_prior.p, prior_blk, n4, nullptr, 0, K, D));
@@ -1538,17 +1549,21 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
 int svihmm_svi_set_adagrad(svihmm_ctx* h, const double* ada_G) {
   if (!h || !h->svi_active) return fail("svihmm_svi_set_adagrad: call svihmm_svi_begin first");
   CK(set_device(h));
-  h->svi_adagrad = ada_G != nullptr;
-  if (!ada_G) return 0;
+  if (!ada_G) { h->svi_adagrad = false; return 0; }
   const size_t kk = (size_t)h->svi_K * h->svi_K;
+  // ada_G >= 1: the reference starts it at ones and only adds squares (hmmsgd_metaobs.py:179-183,
+  // :1036-1040), and the step's weights 1 / ada_G^.25 must stay <= 1 -- a larger weight would let
+  // var_tran leave the range svi_begin_common checked for the linear-domain recursions
   for (size_t i = 0; i < kk; ++i)
-    if (!(ada_G[i] > 0.0 && ada_G[i] < 1.7e308)) return fail("svihmm_svi_set_adagrad: ada_G must be positive and finite");
+    if (!(ada_G[i] >= 1.0 && ada_G[i] < 1.7e308)) return fail("svihmm_svi_set_adagrad: ada_G must be finite and >= 1");
   void* pin = nullptr;
   int slot = 0;
   CK(pinned(h, kk * sizeof(double), &pin, &slot));
   std::memcpy(pin, ada_G, kk * sizeof(double));
   CK(pull_small(h, svi_ptr(h, 9), pin, kk * sizeof(double)));
-  return pin_release(h, slot);
+  CK(pin_release(h, slot));
+  h->svi_adagrad = true;               // (only once the accumulator is on its way)
+  return 0;
 }
 int svihmm_svi_read_adagrad(svihmm_ctx* h, double* ada_G_out) {
   if (!h || !h->svi_active || !ada_G_out) return fail("svihmm_svi_read_adagrad: bad arguments");
@@ -1912,6 +1927,11 @@ int svihmm_profile_read(svihmm_ctx* h, double ms_out[SVIHMM_NKERN], int64_t coun
 }
 int svihmm_set_variant(svihmm_ctx* h, int32_t which, int32_t value) {
   if (!h || which < 0 || which >= 16) return fail("svihmm_set_variant: bad arguments");
+#ifndef SVIHMM_MEASURE
+  // codes under which a call's results are invalid exist in the measurement build only
+  if (which == 7 && value == 9)
+    return fail("svihmm_set_variant: measurement-only code (build with -DSVIHMM_MEASURE: make measure)");
+#endif
   h->variant[which] = value;
   return 0;
 }

@@ -24,6 +24,21 @@ static int emb_buffers(svihmm_ctx* h, uint4** uwp) {
   *uwp = (uint4*)h->uwb.p;
   return 0;
 }
+// ... and of k_emission_bf16x3d (round 5): 32 < D <= 64 at any K <= 1024, and every wide model (K > 64) with
+// D <= 64; (K / 2 + 2) records of EMD_REC bytes
+static bool emd_shape_ok(int K, int D) { return D <= 64 && K <= 1024 && (K > 64 || D > 32); }
+static int emd_buffers(svihmm_ctx* h, int K, uint4** uwp) {
+  const size_t nb = ((size_t)((K + 63) / 64 * 64) / 2 + 2) * EMD_REC;
+  CK(ensure(h->uwd, nb));
+  if (h->uwd_zero_p != h->uwd.p || h->uwd_zero_n < nb) {
+    HIPCK(hipMemsetAsync(h->uwd.p, 0, h->uwd.cap, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));
+    h->uwd_zero_p = h->uwd.p; h->uwd_zero_n = h->uwd.cap;
+    h->uwd_valid = false;
+  }
+  *uwp = (uint4*)h->uwd.p;
+  return 0;
+}
 int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out) {
   CK(upload_feature_table(h, D, K));
   const int Fp = h->Fp, Kp = h->Kp;
@@ -64,12 +79,15 @@ int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out) {
   // that follows builds them on demand)
   uint4* uwp = nullptr;
   if (h->prec == 1 && emb_shape_ok(K, D) && !h->svi_active) CK(emb_buffers(h, &uwp));
+  const bool emd = h->prec == 1 && emd_shape_ok(K, D) && !h->svi_active;   // (D <= 32 at K > 64: the 64-wide builder writes the records)
+  if (emd) CK(emd_buffers(h, K, &uwp));
   {
     ProfScope ps(h, KS_MISC);
 #define NIWW(DM) hipLaunchKernelGGL(k_niw_to_theta_wave<DM>, dim3(K), dim3(64), 0, h->stream, (const double*)dmu, \
                                     (const double*)dsg, (const double*)dka, (const double*)dnu, K, D, Kp,   \
                                     (double*)h->theta.p, dstatus, orbp, logdet_out, uwp)
-    if (D <= 8) NIWW(8);
+    if (emd) NIWW(64);
+    else if (D <= 8) NIWW(8);
     else if (D <= 16) NIWW(16);
     else if (D <= 32) NIWW(32);
     else if (D <= 64) NIWW(64);
@@ -88,7 +106,8 @@ int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out) {
   h->status_pending = true;
   h->eK = K; h->eD = D; h->have_emission = true; h->emis_cat = false; h->emis_diag = false;
   h->orb_valid = orbp != nullptr;
-  h->uw_valid = uwp != nullptr;
+  h->uw_valid = uwp != nullptr && !emd;
+  h->uwd_valid = emd;
   return 0;
 }
 
@@ -116,7 +135,7 @@ int launch_diag_to_theta(svihmm_ctx* h, int K, int D) {
     HIPCK(hipGetLastError());
   }
   h->status_pending = true;
-  h->eK = K; h->eD = D; h->have_emission = true; h->emis_cat = false; h->emis_diag = true; h->uw_valid = false;
+  h->eK = K; h->eD = D; h->have_emission = true; h->emis_cat = false; h->emis_diag = true; h->uw_valid = false; h->uwd_valid = false;
   h->orb_valid = false;
   return 0;
 }
@@ -187,6 +206,40 @@ int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled,
     hipLaunchKernelGGL(k_emission_bf16x3, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, stream,
                        (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, (const char*)uwp,
                        flags, (float*)out, kexp_out, ll0_out);
+    HIPCK(hipGetLastError());
+    return 0;
+  }
+  // fp32 mode, 32 < D <= 64 (K <= 64: scaled output) and wide models (K > 64: plain float output, the
+  // scaling pass follows): the centred bf16 x 3 kernel with 64-dimension pair records (round 5)
+  const bool wide32 = !scaled && h->cur_f32 && K > 64;
+  if (!h->emis_diag && ((scaled && (flags & SVIHMM_INT_ST32) && K <= 64) || wide32) && emd_shape_ok(K, D) && h->niw.p &&
+      h->variant[5] != 3 && min_lds == 0 && (n >= 32768 || h->variant[10] == 3)) {
+    uint4* uwp = nullptr;
+    CK(emd_buffers(h, K, &uwp));
+    if (!h->uwd_valid) {   // the mode was switched on after the parameter upload: records from the resident NIW block
+      const double* dmu = (const double*)h->niw.p;
+      const double* dsg = dmu + (size_t)K * D;
+      const double* dka = dsg + (size_t)K * D * D;
+      const double* dnu = dka + K;
+      hipLaunchKernelGGL(k_niw_to_theta_wave<64>, dim3(K), dim3(64), 0, stream, dmu, dsg, dka, dnu, K, D, Kp,
+                         (double*)nullptr, (int*)nullptr, (double*)nullptr, (double*)nullptr, uwp);
+      HIPCK(hipGetLastError());
+      h->uwd_valid = true;
+    }
+    const size_t lds = (size_t)2 * EMD_REC + (size_t)8 * 32 * 64 * 4;
+    const int wi = wide32 ? 1 : 0;
+    if (!h->emd_attr_set[wi]) {
+      if (wide32) HIPCK(hipFuncSetAttribute((const void*)k_emission_bf16x3d<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      else HIPCK(hipFuncSetAttribute((const void*)k_emission_bf16x3d<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      h->emd_attr_set[wi] = true;
+    }
+    dim3 grid((unsigned)((n + 255) / 256), wide32 ? (unsigned)((K + 63) / 64) : 1u);
+    if (wide32)
+      hipLaunchKernelGGL(k_emission_bf16x3d<true>, grid, dim3(512), lds, stream, (const double*)h->obs.p, mk, starts_dev, n, Lm,
+                         D, K, (const char*)uwp, flags, (float*)out, kexp_out, ll0_out);
+    else
+      hipLaunchKernelGGL(k_emission_bf16x3d<false>, grid, dim3(512), lds, stream, (const double*)h->obs.p, mk, starts_dev, n, Lm,
+                         D, K, (const char*)uwp, flags, (float*)out, kexp_out, ll0_out);
     HIPCK(hipGetLastError());
     return 0;
   }

@@ -505,7 +505,7 @@ class VBHMM(VariationalHMMBase):
             inner = (bufferL - L_, 2 * L_ + 1) if growBuffer else None
             eng.svi_iteration(it, starts, nwin, Lm, flags, self.lrate, bA, bE, inner=inner)
             host_fresh = False
-            loop_globals_live = True      # the handle's ltran / mod_init are this iteration's
+            loop_globals_live = True      # the handle's ltran / mod_init stem from the loop (see the hook below)
             self.cur_mo = last_mo
             last = (len(starts), Lm)
             if self.verbose:
@@ -522,7 +522,15 @@ class VBHMM(VariationalHMMBase):
                     self.pred_logprob_full_std = np.inf * np.ones(maxit)
                 # the hook uploads psi-expectations of the UPDATED state to the handle; the
                 # reference's full_local_update keeps them in locals (:1157-1159), its object still
-                # holds the last local_update's (:502-504): take those off the handle first
+                # holds the last local_update's (:502-504): take the loop's off the handle first.
+                # After the LAST iteration these are exactly the reference's (no further globals
+                # kernel exists).  Mid-loop (it < maxit - 1) svihmm_svi_iteration has already
+                # pre-launched iteration it + 1's k_svi_globals into the handle's single ltran /
+                # mod_init buffers, so mod_init / mod_tran then hold the psi-expectations of the
+                # UPDATED var_tran -- one global step ahead of reference :502-504.  Nothing on the
+                # path reads them before the next iteration overwrites them (pred_logprob_full
+                # computes its own, :1157-1159); only a caller inspecting the attributes from
+                # inside a validation hook sees the difference.
                 if loop_globals_live and hasattr(eng, "read_globals"):
                     self.mod_init, self.mod_tran = eng.read_globals()
                 tmp = self.pred_logprob_full()

@@ -9,10 +9,23 @@ from pysvihmm_amd import _lib
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
-    src = open(os.path.join(REPO, "include", "svihmm.h")).read()
+def _functions_of(header):
+    src = open(os.path.join(REPO, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(svihmm_[a-z0-9_]+)\s*\(", src)))
+
+
+def declared_functions():
+    """The drop-in boundary (svihmm.h) + the measurement / test hooks (svihmm_debug.h)."""
+    return sorted(set(_functions_of("svihmm.h")) | set(_functions_of("svihmm_debug.h")))
+
+
+def test_measurement_hooks_are_not_in_the_product_header():
+    product = set(_functions_of("svihmm.h"))
+    hooks = set(_functions_of("svihmm_debug.h"))
+    assert hooks == {"svihmm_profile_enable", "svihmm_profile_reset", "svihmm_profile_read",
+                     "svihmm_kernel_name", "svihmm_set_variant", "svihmm_selftest_mfma"}
+    assert not (product & hooks)
 
 
 def test_header_symbols_exported():

@@ -3,6 +3,7 @@ hmmbatchcd.py on CPU via gen_synthetic"): the emission class (third-party arithm
 /root/reference -> pinned to the mathematics, like tests/test_emission_formula.py), the oracle's
 restatement, and the host logic of the three classes on the oracle engine.  CPU only."""
 import numpy as np
+import pytest
 from scipy.special import gammaln
 
 from pysvihmm_amd.distributions import DiagonalGaussian
@@ -164,3 +165,49 @@ def test_metaobs_diag_engine_resident_loop_equals_host_loop():
         np.testing.assert_allclose(a.var_x, b.var_x, rtol=1e-8, atol=1e-12)
         if ada:
             np.testing.assert_allclose(a.ada_G, b.ada_G, rtol=1e-10)
+
+
+@pytest.mark.parametrize("hooks", ["full_predprob", "adaptive", "growBuffer"])
+def test_device_loop_protocol_survives_validation_hooks_on_the_oracle_engine(hooks):
+    """The host logic of the device-resident loop with mid-loop hooks that re-push the emission
+    (GPU twin: tests/test_gpu_diag.py): OracleEngine models what an upload does to a
+    running loop on libsvihmm_hip.so -- the loop's own family and shape: factors replaced, loop
+    kept; anything else: the loop ends."""
+    from tests.test_gpu_diag import _configs0
+    from pysvihmm_amd import hmmsgd_metaobs
+    from oracle.engine import OracleEngine
+    obs, sts, prior = _configs0(seed=11, T=1500)
+    K = 4
+    mask = np.random.default_rng(2).random(len(obs)) < 0.08
+    kw = dict(tau=1.0, kappa=0.7, metaobs_half=8, mb_sz=4, maxit=5, seed=4, mask=mask.copy())
+    ikw = {}
+    if hooks == "full_predprob":
+        kw["full_predprob"] = True
+    elif hooks == "adaptive":
+        ikw = dict(adaptive=True, perIter=2, epsilon=1e-3)
+    else:
+        kw["growBuffer"] = True
+        ikw = dict(perIter=2, epsilon=1e-3)
+    res = []
+    for dl in (None, False):
+        np.random.seed(3)
+        m = hmmsgd_metaobs.VBHMM(obs.copy(), np.ones(K), np.ones((K, K)), prior, engine=OracleEngine(), **kw)
+        m.infer(device_loop=dl, **ikw)
+        res.append(m)
+    np.testing.assert_allclose(res[0].elbo_vec, res[1].elbo_vec, rtol=1e-9)
+    np.testing.assert_allclose(res[0].var_tran, res[1].var_tran, rtol=1e-9)
+
+
+def test_oracle_engine_upload_of_another_family_ends_the_loop():
+    from oracle.engine import OracleEngine
+    rng = np.random.default_rng(0)
+    K, D, T = 3, 2, 200
+    e = OracleEngine()
+    e.set_obs(rng.normal(size=(T, D)))
+    blk = tuple(np.abs(rng.normal(size=(K, D))) + 0.5 for _ in range(4))
+    e.svi_begin_diag(np.ones((K, K)), np.ones((K, K)) * 2, blk, blk, 3)
+    e.set_emission_diag(*blk)                      # own family and shape: the loop lives on
+    e.svi_iteration(0, np.array([0, 50]), 2, 21, 2, 0.5, 1.0, 1.0)
+    e.set_emission_niw(rng.normal(size=(K, D)), np.tile(np.eye(D), (K, 1, 1)), np.ones(K), np.full(K, D + 2.0))
+    with pytest.raises(RuntimeError):
+        e.svi_iteration(1, np.array([0, 50]), 2, 21, 2, 0.5, 1.0, 1.0)

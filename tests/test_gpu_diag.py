@@ -228,3 +228,45 @@ def test_diag_device_loop_on_gpu(adagrad):
                     np.testing.assert_allclose(getattr(a.var_emit[k], name), getattr(o.var_emit[k], name), rtol=rt,
                                                atol=1e-8 * (1.0 + off))
             np.testing.assert_allclose(a.var_x, o.var_x, rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("hooks", ["full_predprob", "adaptive", "growBuffer"])
+def test_diag_device_loop_survives_validation_hooks(hooks):
+    """the validation hooks of infer() -- full_predprob (default schedule fires at
+    it = 0), adaptive select_L, growBuffer -- re-push the emission mid-loop through
+    svihmm_set_emission_diag, which used to end the running diagonal-family loop unconditionally:
+    the next svihmm_svi_iteration / svihmm_svi_read_elbo then failed with 'call svihmm_svi_begin
+    first'.  A re-push of the loop's own family and shape now keeps the loop (as the NIW upload always
+    did); HIP device loop == HIP host loop == oracle engine."""
+    from pysvihmm_amd import hmmsgd_metaobs
+    from oracle.engine import OracleEngine
+    obs, sts, prior = _configs0(seed=11, T=2500)
+    K = 4
+    mask = np.random.default_rng(2).random(len(obs)) < 0.08
+    kw = dict(tau=1.0, kappa=0.7, metaobs_half=10, mb_sz=6, maxit=7, seed=4, mask=mask.copy())
+    ikw = {}
+    if hooks == "full_predprob":
+        kw["full_predprob"] = True
+    elif hooks == "adaptive":
+        ikw = dict(adaptive=True, perIter=3, epsilon=1e-3)
+    else:
+        kw["growBuffer"] = True
+        ikw = dict(perIter=3, epsilon=1e-3)
+    runs = []
+    for eng, dl in ((None, None), (None, False), (OracleEngine(), None)):
+        np.random.seed(3)
+        m = hmmsgd_metaobs.VBHMM(obs.copy(), np.ones(K), np.ones((K, K)), prior, engine=eng, **kw)
+        assert m._svi_family() == "diag" and m._svi_device_ok()
+        m.infer(device_loop=dl, **ikw)
+        runs.append(m)
+    a, b, c = runs
+    assert a.engine.name == "hip"
+    assert np.all(np.isfinite(a.elbo_vec))
+    for o, rt in ((b, 1e-7), (c, 1e-6)):
+        np.testing.assert_allclose(a.elbo_vec, o.elbo_vec, rtol=1e-7)
+        np.testing.assert_allclose(a.var_tran, o.var_tran, rtol=rt, atol=1e-9)
+        for k in range(K):
+            for name in ("mf_mu", "mf_nus", "mf_alphas", "mf_betas"):
+                np.testing.assert_allclose(getattr(a.var_emit[k], name), getattr(o.var_emit[k], name), rtol=rt, atol=1e-8)
+    if hooks == "full_predprob":
+        np.testing.assert_allclose(a.pred_logprob_full_mean, c.pred_logprob_full_mean, rtol=1e-6)

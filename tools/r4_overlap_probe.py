@@ -3,7 +3,8 @@
 (parameter upload -> emission -> sweeps -> statistics -> read-back) under:
   base          the default path, HIP-event profiling off
   prof          the same with the per-kernel event pairs bench.py records
-  no_sweeps     variant[7] = 9: the sweep launch skipped (statistics on stale messages): the step
+  no_sweeps     (needs the measurement build: make -C pysvihmm_amd/csrc measure and
+                SVIHMM_HIP_LIB=build_exp/libsvihmm_measure.so) variant[7] = 9: the sweep launch skipped (statistics on stale messages): the step
                 if the sweeps cost NOTHING -- the ceiling of any overlap design
   pipeline      variant[4] = 2: the two-stream split (sweeps of one half co-resident with the
                 emission GEMM of the other): co-residency forced at kernel granularity
