@@ -84,6 +84,7 @@ struct svihmm_ctx {
   // globals
   int K = 0;
   Buf mod_init, ltran, Aexp, AexpT;
+  Buf AexpF, AexpTF;        // float copies for the fp32 mode's wide-model sweeps (256 + 16 rows, slack zeroed)
   bool have_globals = false;
   // transition expectations below the range exp() represents with headroom: every recursion goes
   // through the literal log-domain kernel (k_fb_exact); f32_ok: within the range of a float
@@ -262,6 +263,8 @@ int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_t strea
 int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out);
 int launch_posterior(svihmm_ctx* h, int B, int Lm, bool total);
 int launch_scale_ll(svihmm_ctx* h, int B, int Lm);
+int launch_scale_ll_f32(svihmm_ctx* h, int B, int Lm);
+bool f32_wide_ok(const svihmm_ctx* h, int64_t n);
 int launch_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags);
 int launch_stats_finalize(svihmm_ctx* h, int64_t nchunk, hipStream_t stream);
 int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, int Lm, uint32_t flags, StatsPlan plan, int64_t chunk_base, hipStream_t stream);

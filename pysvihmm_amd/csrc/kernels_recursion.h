@@ -1052,18 +1052,23 @@ __global__ __launch_bounds__(64 * NW) void k_sweeps_lin(
 // every wave the kernel spilled 130 registers and ran 6.7 ms on configs[4] against 6.35 ms of
 // WT = 1; with one register's books per wave 5.3 ms (WT = 1: 6.1 ms).  (Two wave groups of 124
 // registers sharing the B stream through L1 in one 1024-thread workgroup: 12.5 ms.)
-template <int NW, bool FULL, int WT = 1>
+// T = double: the fp64 kernel.  T = float (fp32 mode, round 5): Eh / ah / bh stored as float, the
+// transition matrix read from its float copy, v_mfma_f32_16x16x4_f32 (C register r of lane group lg =
+// window row 4 lg + r instead of lg + 4 r: LV<T>::crow); exponents and the local bound's books stay double.
+template <int NW, bool FULL, int WT = 1, typename T = double>
 __global__ __launch_bounds__(64 * NW) void k_sweeps_lin2(
-    const double* __restrict__ Eh, const double* __restrict__ kexp,
-    const double* __restrict__ Aexp, const double* __restrict__ AexpT,
+    const T* __restrict__ Eh, const double* __restrict__ kexp,
+    const T* __restrict__ Aexp, const T* __restrict__ AexpT,
     const double* __restrict__ a0v, const double* __restrict__ a0e, int B, int Lm, int K,
-    double* __restrict__ ah,
-    double* __restrict__ bh, double* __restrict__ hx, double* __restrict__ gx,
+    T* __restrict__ ah,
+    T* __restrict__ bh, double* __restrict__ hx, double* __restrict__ gx,
     double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac) {
   constexpr int NT = 2 * NW, KS = 4 * NT, PS = 16 * NT + 2, WR = 16 * WT;
-  static_assert(NW % 4 == 0, "a wave tracks the exponents of window rows lg + 4 (wave & 3)");
+  static_assert(NW % 4 == 0, "a wave tracks the exponents of window rows crow(lg, wave & 3)");
+  typedef typename LV<T>::v4 v4;
+  typedef typename LPair<T>::t T2;
   extern __shared__ double __attribute__((aligned(16))) lin_smem[];
-  typedef double PRow[PS];
+  typedef T PRow[PS];
   PRow* P0 = reinterpret_cast<PRow*>(lin_smem);             // P[2][WR][PS]
   auto Pb = [&](int buf) { return P0 + buf * WR; };
   const bool fwd = blockIdx.y == 0;
@@ -1075,14 +1080,14 @@ __global__ __launch_bounds__(64 * NW) void k_sweeps_lin2(
   const int jc0 = v0 ? j0 : 0, jc1 = v1 ? j1 : 0;
   const int b0 = blockIdx.x * WR;
   const size_t wrow = (size_t)b0 * Lm;
-  const double* __restrict__ Eb = Eh + wrow * K;
-  double* __restrict__ ob = (fwd ? ah : bh) + wrow * K;      // stored vector: ah (fwd) / bh (bwd)
+  const T* __restrict__ Eb = Eh + wrow * K;
+  T* __restrict__ ob = (fwd ? ah : bh) + wrow * K;      // stored vector: ah (fwd) / bh (bwd)
   double* __restrict__ xb = (fwd ? hx : gx) + wrow;          // its exponent stream
   // B operand addressing: uniform row base (scalar registers) + one 32-bit lane offset per
   // tile; rows beyond K are read from the zeroed slack the host keeps behind the matrices
-  const double* __restrict__ Bm = fwd ? Aexp : AexpT;
+  const T* __restrict__ Bm = fwd ? Aexp : AexpT;
   const int lo0 = 2 * lg * K + jc0, lo1 = 2 * lg * K + jc1;
-  auto gwin = [&](int wt, int r) { const int gw = b0 + 16 * wt + lg + 4 * r; return gw < B ? gw : B - 1; };
+  auto gwin = [&](int wt, int r) { const int gw = b0 + 16 * wt + LV<T>::crow(lg, r); return gw < B ? gw : B - 1; };
   unsigned oE[WT][4], oRw[WT];
 #pragma unroll
   for (int wt = 0; wt < WT; ++wt) {
@@ -1102,16 +1107,16 @@ __global__ __launch_bounds__(64 * NW) void k_sweeps_lin2(
     for (int wt = 0; wt < WT; ++wt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const double e0 = (Eb + ro)[oE[wt][r] + jc0], e1 = (Eb + ro)[oE[wt][r] + jc1];
+        const T e0 = (Eb + ro)[oE[wt][r] + jc0], e1 = (Eb + ro)[oE[wt][r] + jc1];
         // forward: ah_0 = the initial message of k_lin_init (stored), P = ah_0;
         // backward: bh_top = 1 (stored), P = Eh_top
         const int gw = gwin(wt, r);
-        const double s0v = fwd ? a0v[(size_t)gw * K + jc0] : 1.0;
-        const double s1v = fwd ? a0v[(size_t)gw * K + jc1] : 1.0;
+        const T s0v = fwd ? (T)a0v[(size_t)gw * K + jc0] : (T)1;
+        const T s1v = fwd ? (T)a0v[(size_t)gw * K + jc1] : (T)1;
         if (v0) (ob + ro)[oE[wt][r] + jc0] = s0v;
         if (v1) (ob + ro)[oE[wt][r] + jc1] = s1v;
-        Pb(0)[16 * wt + lg + 4 * r][j0] = v0 ? (fwd ? s0v : e0) : 0.0;
-        Pb(0)[16 * wt + lg + 4 * r][j1] = v1 ? (fwd ? s1v : e1) : 0.0;
+        Pb(0)[16 * wt + LV<T>::crow(lg, r)][j0] = v0 ? (fwd ? s0v : e0) : (T)0;
+        Pb(0)[16 * wt + LV<T>::crow(lg, r)][j1] = v1 ? (fwd ? s1v : e1) : (T)0;
       }
       h[wt] = fwd ? a0e[gwin(wt, rw)] : 0.0; mant[wt] = 1.0; hsum[wt] = 0.0;
       (xb + rowof(0))[oRw[wt]] = h[wt];
@@ -1124,38 +1129,38 @@ __global__ __launch_bounds__(64 * NW) void k_sweeps_lin2(
     const size_t ro = (size_t)t * K;
     // out[w][j] = sum_i P[w][i] M[i][j] for this wave's two state tiles and WT window tiles;
     // tot[w] = sum_i P[w][i]
-    double4_t p0[WT], p1[WT], q0[WT], q1[WT];
-    const double* pr[WT];
-    double sa[WT], sb[WT];
+    v4 p0[WT], p1[WT], q0[WT], q1[WT];
+    const T* pr[WT];
+    T sa[WT], sb[WT];
 #pragma unroll
     for (int wt = 0; wt < WT; ++wt) {
-      p0[wt] = (double4_t){0, 0, 0, 0}; p1[wt] = p0[wt]; q0[wt] = p0[wt]; q1[wt] = p0[wt];
+      p0[wt] = (v4){0, 0, 0, 0}; p1[wt] = p0[wt]; q0[wt] = p0[wt]; q1[wt] = p0[wt];
       pr[wt] = &Pb(cur)[16 * wt + li][2 * lg];
-      sa[wt] = 0.0; sb[wt] = 0.0;
+      sa[wt] = 0; sb[wt] = 0;
     }
     // A rolled loop with running pointers: fully unrolled, the compiler materialises all 256
     // lane addresses of the streamed tile as loop invariants of the time loop and spills them.
-    const double* __restrict__ pb0 = Bm + lo0;
-    const double* __restrict__ pb1 = Bm + lo1;
+    const T* __restrict__ pb0 = Bm + lo0;
+    const T* __restrict__ pb1 = Bm + lo1;
     const size_t K1 = (size_t)K, K8 = (size_t)8 * K, K9 = (size_t)9 * K, K16 = (size_t)16 * K;
 #pragma unroll 4
     for (int c = 0; c < KS / 4; ++c) {        // 4 k-steps (16 transition rows) per trip
-      const double b00 = pb0[0], b01 = pb0[K1], b02 = pb0[K8], b03 = pb0[K9];
-      const double b10 = pb1[0], b11 = pb1[K1], b12 = pb1[K8], b13 = pb1[K9];
+      const T b00 = pb0[0], b01 = pb0[K1], b02 = pb0[K8], b03 = pb0[K9];
+      const T b10 = pb1[0], b11 = pb1[K1], b12 = pb1[K8], b13 = pb1[K9];
       pb0 += K16; pb1 += K16;
 #pragma unroll
       for (int wt = 0; wt < WT; ++wt) {
-        const double2 x = *reinterpret_cast<const double2*>(pr[wt]);
-        const double2 y = *reinterpret_cast<const double2*>(pr[wt] + 8);
+        const T2 x = *reinterpret_cast<const T2*>(pr[wt]);
+        const T2 y = *reinterpret_cast<const T2*>(pr[wt] + 8);
         pr[wt] += 16;
-        p0[wt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, b00, p0[wt], 0, 0, 0);
-        q0[wt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, b10, q0[wt], 0, 0, 0);
-        p1[wt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, b01, p1[wt], 0, 0, 0);
-        q1[wt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, b11, q1[wt], 0, 0, 0);
-        p0[wt] = __builtin_amdgcn_mfma_f64_16x16x4f64(y.x, b02, p0[wt], 0, 0, 0);
-        q0[wt] = __builtin_amdgcn_mfma_f64_16x16x4f64(y.x, b12, q0[wt], 0, 0, 0);
-        p1[wt] = __builtin_amdgcn_mfma_f64_16x16x4f64(y.y, b03, p1[wt], 0, 0, 0);
-        q1[wt] = __builtin_amdgcn_mfma_f64_16x16x4f64(y.y, b13, q1[wt], 0, 0, 0);
+        p0[wt] = LV<T>::mma(x.x, b00, p0[wt]);
+        q0[wt] = LV<T>::mma(x.x, b10, q0[wt]);
+        p1[wt] = LV<T>::mma(x.y, b01, p1[wt]);
+        q1[wt] = LV<T>::mma(x.y, b11, q1[wt]);
+        p0[wt] = LV<T>::mma(y.x, b02, p0[wt]);
+        q0[wt] = LV<T>::mma(y.x, b12, q0[wt]);
+        p1[wt] = LV<T>::mma(y.y, b03, p1[wt]);
+        q1[wt] = LV<T>::mma(y.y, b13, q1[wt]);
         sa[wt] += x.x + y.x;
         sb[wt] += x.y + y.y;
       }
@@ -1164,31 +1169,31 @@ __global__ __launch_bounds__(64 * NW) void k_sweeps_lin2(
     // in front of the GEMM loop make its first operand wait for their HBM latency, and they would
     // hold 16 WT registers through the loop
     __builtin_amdgcn_sched_barrier(0);
-    double e0[WT][4], e1[WT][4];
+    T e0[WT][4], e1[WT][4];
 #pragma unroll
     for (int wt = 0; wt < WT; ++wt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) { e0[wt][r] = (Eb + ro)[oE[wt][r] + jc0]; e1[wt][r] = (Eb + ro)[oE[wt][r] + jc1]; }
     __builtin_amdgcn_sched_barrier(0);
-    const double4_t z = {0, 0, 0, 0};
+    const v4 z = {0, 0, 0, 0};
 #pragma unroll
     for (int wt = 0; wt < WT; ++wt) {
-      const double4_t tot = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[wt] + sb[wt], 1.0, z, 0, 0, 0);
-      const double4_t acc0 = p0[wt] + p1[wt], acc1 = q0[wt] + q1[wt];
-      const double totw = rw == 0 ? tot[0] : (rw == 1 ? tot[1] : (rw == 2 ? tot[2] : tot[3]));
+      const v4 tot = LV<T>::mma(sa[wt] + sb[wt], (T)1, z);
+      const v4 acc0 = p0[wt] + p1[wt], acc1 = q0[wt] + q1[wt];
+      const double totw = (double)(rw == 0 ? tot[0] : (rw == 1 ? tot[1] : (rw == 2 ? tot[2] : tot[3])));
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int e2 = __builtin_amdgcn_frexp_exp(tot[r]);
-        double o0, o1, n0, n1;      // stored value, next P value
+        const int e2 = LV<T>::fexp(tot[r]);
+        T o0, o1, n0, n1;      // stored value, next P value
         if (fwd) {
-          o0 = v0 ? ldexp(acc0[r] * e0[wt][r], -e2) : 0.0; o1 = v1 ? ldexp(acc1[r] * e1[wt][r], -e2) : 0.0;
+          o0 = v0 ? LV<T>::ldx(acc0[r] * e0[wt][r], -e2) : (T)0; o1 = v1 ? LV<T>::ldx(acc1[r] * e1[wt][r], -e2) : (T)0;
           n0 = o0; n1 = o1;
         } else {
-          o0 = v0 ? ldexp(acc0[r], -e2) : 0.0; o1 = v1 ? ldexp(acc1[r], -e2) : 0.0;
+          o0 = v0 ? LV<T>::ldx(acc0[r], -e2) : (T)0; o1 = v1 ? LV<T>::ldx(acc1[r], -e2) : (T)0;
           n0 = e0[wt][r] * o0; n1 = e1[wt][r] * o1;
         }
-        Pb(nxt)[16 * wt + lg + 4 * r][j0] = n0;
-        Pb(nxt)[16 * wt + lg + 4 * r][j1] = n1;
+        Pb(nxt)[16 * wt + LV<T>::crow(lg, r)][j0] = n0;
+        Pb(nxt)[16 * wt + LV<T>::crow(lg, r)][j1] = n1;
         if (v0) (ob + ro)[oE[wt][r] + jc0] = o0;
         if (v1) (ob + ro)[oE[wt][r] + jc1] = o1;
       }
@@ -1206,7 +1211,7 @@ __global__ __launch_bounds__(64 * NW) void k_sweeps_lin2(
   // ---- forward epilogue: K sums, Z, local_lb (as in fwd_lin_body)
   {
     const int last = (Lm - 1) & 1;
-    double* scr = &Pb(1 - last)[0][0];          // free buffer: [0, WR) K_top, [WR, 2 WR) sum_t K_t
+    double* scr = reinterpret_cast<double*>(&Pb(1 - last)[0][0]);   // free buffer (>= 2 WR doubles): [0, WR) K_top, [WR, 2 WR) sum_t K_t
     const double* __restrict__ kbw = kexp + wrow;
     for (int w = threadIdx.x >> 4; w < WR; w += 4 * NW) {
       const int gw = b0 + w;
@@ -1224,18 +1229,18 @@ __global__ __launch_bounds__(64 * NW) void k_sweeps_lin2(
     __syncthreads();
 #pragma unroll
     for (int wt = 0; wt < WT; ++wt) {
-      double sr = 0.0;
-      const double* prow = &Pb(last)[16 * wt + li][2 * lg];
+      T sr = 0;
+      const T* prow = &Pb(last)[16 * wt + li][2 * lg];
 #pragma unroll
       for (int c = 0; c < 2 * NT; ++c) {
-        const double2 x = *reinterpret_cast<const double2*>(prow + 8 * c);
+        const T2 x = *reinterpret_cast<const T2*>(prow + 8 * c);
         sr += x.x + x.y;
       }
-      const double4_t z = {0, 0, 0, 0};
-      const double4_t tot = __builtin_amdgcn_mfma_f64_16x16x4f64(sr, 1.0, z, 0, 0, 0);
-      if (wave < 4 && li == 0) {          // wave rw: window rows lg + 4 rw
-        const double totw = rw == 0 ? tot[0] : (rw == 1 ? tot[1] : (rw == 2 ? tot[2] : tot[3]));
-        const int w = 16 * wt + lg + 4 * rw;
+      const v4 z = {0, 0, 0, 0};
+      const v4 tot = LV<T>::mma(sr, (T)1, z);
+      if (wave < 4 && li == 0) {          // wave rw: window rows crow(lg, rw)
+        const double totw = (double)(rw == 0 ? tot[0] : (rw == 1 ? tot[1] : (rw == 2 ? tot[2] : tot[3])));
+        const int w = 16 * wt + LV<T>::crow(lg, rw);
         const int gw = gwin(wt, rw);
         const double Ktop = scr[w], KK = scr[WR + w];
         const double mm = mant[wt] * totw;
@@ -2209,6 +2214,35 @@ __global__ __launch_bounds__(256) void k_scale_ll(const double* __restrict__ ll,
   if (li == 0 && g < nrows) kexp[g] = kx;
 }
 
+// fp32 mode, wide models (round 5): the plain float log-likelihoods of k_emission_bf16x3d<true> -> the scaled
+// float Eh IN PLACE (a row is read completely by its 16 lanes before it is written) + the row exponents
+template <int KT>
+__global__ __launch_bounds__(256) void k_scale_ll_f32(float* __restrict__ ll, int64_t nrows, int K,
+                                                      double* __restrict__ kexp) {
+  const int li = threadIdx.x & 15;
+  const int64_t g = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int64_t gc = g < nrows ? g : nrows - 1;
+  float v[KT], mx = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < KT; ++c) {
+    const int k = li + 16 * c;
+    v[c] = k < K ? ll[gc * K + k] : -INFINITY;
+    mx = fmaxf(mx, v[c]);
+  }
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  const double kx = (fabsf(mx) < 1e30f) ? ceil((double)mx * LOG2E_D) : 0.0;
+  const float fr = (float)fma((double)mx, LOG2E_D, -kx);       // in (-1, 0], formed in double (see k_emission_bf16x3)
+#pragma unroll
+  for (int c = 0; c < KT; ++c) {
+    const int k = li + 16 * c;
+    if (k < K && g < nrows) ll[g * K + k] = __builtin_amdgcn_exp2f(fmaf(v[c] - mx, 1.44269504f, fr));
+  }
+  if (li == 0 && g < nrows) kexp[g] = kx;
+}
+__global__ __launch_bounds__(256) void k_f64_to_f32(const double* __restrict__ src, float* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = (float)src[i];
+}
 __global__ void k_sum_lb(const double* __restrict__ local_lb, int B, double* __restrict__ lb_total) {
   __shared__ double red[256];
   double acc = 0.0;

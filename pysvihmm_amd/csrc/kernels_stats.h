@@ -953,3 +953,226 @@ __global__ __launch_bounds__(512) void k_stats_bf16x3(
       }
   }
 }
+
+// ------------------------------------------------------------------------------------
+//  K4g (round 5): the same GEMM for the shapes K4f does not take -- wide models (K > 64) and
+//  D > 32 (more than 22 feature tiles).  A workgroup is (row chunk, feature group gy, state group gz
+//  of 64): it stages q for ITS 64 states, owns up to 22 feature tiles of 32 and -- when gy names a
+//  group of previous states -- the two transition tiles (previous states 64 gy .. 64 gy + 63) x its 64
+//  states, for which it stages q of the predecessor rows for THAT group.  Tile l = wave + 8 m of the
+//  workgroup's list (features first).  Everything else as K4f: three bf16 terms per operand, six
+//  products in fp32 accumulators, 64-row stages, double-buffered.  ah / bh rows have Kfull entries;
+//  partials part[chunk][Fp + Kpf][Kpf] (k_finalize's layout for wide models).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_stats_bf16x3w(
+    const double* __restrict__ obs, const uint8_t* __restrict__ mask,
+    const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K, int Kpf, int Fp, int F,
+    const int* __restrict__ fab, const float* __restrict__ ah, const float* __restrict__ bh,
+    int64_t rows_per_chunk, uint32_t flags, int Lq, int off, double* __restrict__ part,
+    const double* __restrict__ hx, const double* __restrict__ gx, const double2* __restrict__ zfac, int TPG) {
+  constexpr int NPL = 6;
+  extern __shared__ uint4 sb_smem[];
+  const int XC = D + 2;                                      // x columns + ones + zero
+  const size_t xbytes = ((size_t)XC * SB_XRS * 4 + 15) & ~(size_t)15;
+  const size_t pbytes = (size_t)64 * SB_QRS * 2;             // one plane
+  const size_t bufbytes = xbytes + NPL * pbytes;
+  char* base = reinterpret_cast<char*>(sb_smem);
+  SbRow* rinfo = reinterpret_cast<SbRow*>(base + 2 * bufbytes);     // [3][SB_ROWS]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, hh = lane >> 5;
+  const int gy = blockIdx.y, gz = blockIdx.z;
+  const int FT = (Fp + 31) >> 5;                             // (Fp is a multiple of 16: the last tile may be half padding)
+  const int ft0 = gy * TPG;
+  const int nft = ft0 >= FT ? 0 : (FT - ft0 < TPG ? FT - ft0 : TPG);    // feature tiles of this workgroup
+  const bool has_tr = 64 * gy < Kpf;                                    // ... and its two transition tiles
+  const int ntile = nft + (has_tr ? 2 : 0);
+  const int FtotF = Fp + Kpf;
+  const int ks0 = 64 * gz, kp0 = 64 * gy;
+  const int64_t c0 = (int64_t)blockIdx.x * rows_per_chunk;
+  const int64_t c1 = imin64(nrows, c0 + rows_per_chunk);
+  const int nrow = c1 > c0 ? (int)(c1 - c0) : 0;
+  const int nstage = (nrow + SB_ROWS - 1) / SB_ROWS;
+  const int64_t bw0 = c0 / Lm;
+  const unsigned t0 = (unsigned)(c0 - bw0 * Lm);
+  const int64_t Q0 = bw0 * Lq + off;
+  const float* __restrict__ ah0 = ah + Q0 * K;
+  const float* __restrict__ bh0 = bh + Q0 * K;
+  // the lane's state of the staged groups (clamped; states beyond K contribute zero)
+  const bool sq_ok = ks0 + lane < K, sp_ok = has_tr && kp0 + lane < K;
+  const int sq_c = sq_ok ? ks0 + lane : 0, sp_c = sp_ok ? kp0 + lane : 0;
+
+  int oa[3], ob[3], tkind[3];                                // tkind: 0 idle, 1 feature, 2 transition
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const int l = wave + 8 * m;
+    int a = D + 1, b = D + 1;
+    tkind[m] = l < nft ? 1 : (l < ntile ? 2 : 0);
+    if (tkind[m] == 1) {
+      const int f = 32 * (ft0 + l) + j;
+      if (f < F) { const int ab = fab[f]; a = ab & 0xffff; b = ab >> 16; }
+    } else if (tkind[m] == 2) { a = 32 * (l - nft) + j; b = 0; }   // previous state a of the staged group
+    oa[m] = a; ob[m] = b;
+  }
+  sf16_t acc[3][2];
+#pragma unroll
+  for (int m = 0; m < 3; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+  auto row_info = [&](int st) {
+    if (tid < SB_ROWS) {
+      const int jrow = st * SB_ROWS + tid;
+      const bool ok = jrow < nrow;
+      const unsigned x = t0 + (unsigned)(ok ? jrow : 0);
+      const unsigned bwr = x / (unsigned)Lm, t = x - bwr * (unsigned)Lm;
+      const int qr = (int)(bwr * (unsigned)Lq + t);
+      const bool pok = ok && (t > 0 || (flags & SVIHMM_TRANS_WRAP));
+      const int pr = t > 0 ? qr - 1 : qr + Lm - 1;
+      const int64_t bw = bw0 + bwr;
+      const int64_t orow = starts[bw] + off + t;
+      const bool msk = mask && mask[orow];
+      const double2 zf = zfac[bw];
+      SbRow ri;
+      ri.ooff = (ok && !msk) ? orow * D : -1;
+      ri.qoff = ok ? qr * K : 0;
+      ri.poff = pok ? pr * K : 0;
+      ri.sq = ok ? (float)ldexp(zf.x, (int)(hx[Q0 + qr] + gx[Q0 + qr] - zf.y)) : 0.0f;
+      const int prc = pok ? pr : qr;
+      ri.sp = pok ? (float)ldexp(zf.x, (int)(hx[Q0 + prc] + gx[Q0 + prc] - zf.y)) : 0.0f;
+      ri.pad0 = 0; ri.pad1 = 0;
+      rinfo[(st % 3) * SB_ROWS + tid] = ri;
+    }
+  };
+  float ra[8], rb[8], pa[8], pb[8], rsq[8], rsp[8];
+  double rx[8];
+  bool xok[8];
+  auto fetch = [&](int st) {
+    const SbRow* ri = rinfo + (st % 3) * SB_ROWS + 8 * wave;
+    const int xc = lane < D ? lane : 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const SbRow r = ri[e];                                 // (uniform address: broadcast)
+      ra[e] = ah0[r.qoff + sq_c]; rb[e] = bh0[r.qoff + sq_c];
+      if (has_tr) { pa[e] = ah0[r.poff + sp_c]; pb[e] = bh0[r.poff + sp_c]; }
+      rsq[e] = sq_ok ? r.sq : 0.0f; rsp[e] = sp_ok ? r.sp : 0.0f;
+      xok[e] = r.ooff >= 0;
+      rx[e] = obs[(xok[e] ? r.ooff : 0) + xc];
+    }
+  };
+  auto commit = [&](int buf) {
+    char* bb = base + (size_t)buf * bufbytes;
+    float qv[8], pv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[e] = (ra[e] * rb[e]) * rsq[e];
+    uint4 t3[3];
+    sb_split8(qv, t3[0], t3[1], t3[2]);
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      *reinterpret_cast<uint4*>(bb + xbytes + s * pbytes + ((size_t)lane * SB_QRS + 8 * wave) * 2) = t3[s];
+    if (has_tr) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pv[e] = (pa[e] * pb[e]) * rsp[e];
+      sb_split8(pv, t3[0], t3[1], t3[2]);
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        *reinterpret_cast<uint4*>(bb + xbytes + (3 + s) * pbytes + ((size_t)lane * SB_QRS + 8 * wave) * 2) = t3[s];
+    }
+    {
+      float xf[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = lane < D ? (float)rx[e] : (lane == D ? 1.0f : 0.0f);
+        xf[e] = xok[e] ? v : 0.0f;
+      }
+      if (lane < XC) {
+        float* xt = reinterpret_cast<float*>(bb) + lane * SB_XRS + 8 * wave;
+        *reinterpret_cast<float4*>(xt) = make_float4(xf[0], xf[1], xf[2], xf[3]);
+        *reinterpret_cast<float4*>(xt + 4) = make_float4(xf[4], xf[5], xf[6], xf[7]);
+      }
+      // columns 64, 65 (D = 63, 64): the ones column (0 on masked rows) and the zero column
+      const int c2 = lane + 64;
+      if (c2 < XC) {
+        float* xt = reinterpret_cast<float*>(bb) + c2 * SB_XRS + 8 * wave;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (c2 == D && xok[e]) ? 1.0f : 0.0f;
+        *reinterpret_cast<float4*>(xt) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(xt + 4) = make_float4(o[4], o[5], o[6], o[7]);
+      }
+    }
+  };
+  constexpr int TA[6] = {0, 0, 1, 0, 2, 1}, TB[6] = {0, 1, 0, 2, 0, 1};
+  auto compute = [&](int buf) {
+    const char* bb = base + (size_t)buf * bufbytes;
+    const float* xT = reinterpret_cast<const float*>(bb);
+    const char* qpl = bb + xbytes;
+#pragma unroll 1
+    for (int ks = 0; ks < SB_ROWS / 16; ++ks) {
+      const int r0 = 16 * ks + 8 * hh;
+      sbf8_t b3[2][3];
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+          b3[n][s] = __builtin_bit_cast(sbf8_t, *reinterpret_cast<const uint4*>(qpl + s * pbytes + ((size_t)(32 * n + j) * SB_QRS + r0) * 2));
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        if (tkind[m] == 0) continue;                         // (uniform per wave)
+        sbf8_t a3[3];
+        if (tkind[m] == 1) {
+          const float4 xa0 = *reinterpret_cast<const float4*>(xT + oa[m] * SB_XRS + r0);
+          const float4 xa1 = *reinterpret_cast<const float4*>(xT + oa[m] * SB_XRS + r0 + 4);
+          const float4 xb0 = *reinterpret_cast<const float4*>(xT + ob[m] * SB_XRS + r0);
+          const float4 xb1 = *reinterpret_cast<const float4*>(xT + ob[m] * SB_XRS + r0 + 4);
+          const float p[8] = {xa0.x * xb0.x, xa0.y * xb0.y, xa0.z * xb0.z, xa0.w * xb0.w,
+                              xa1.x * xb1.x, xa1.y * xb1.y, xa1.z * xb1.z, xa1.w * xb1.w};
+          uint4 t3[3];
+          sb_split8(p, t3[0], t3[1], t3[2]);
+#pragma unroll
+          for (int s = 0; s < 3; ++s) a3[s] = __builtin_bit_cast(sbf8_t, t3[s]);
+        } else {
+#pragma unroll
+          for (int s = 0; s < 3; ++s)
+            a3[s] = __builtin_bit_cast(sbf8_t, *reinterpret_cast<const uint4*>(qpl + (3 + s) * pbytes + ((size_t)oa[m] * SB_QRS + r0) * 2));
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int pi = 0; pi < 6; ++pi)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[TA[pi]], b3[n][TB[pi]], acc[m][n], 0, 0, 0);
+      }
+    }
+  };
+  if (nstage > 0 && ntile > 0) {
+    row_info(0);
+    if (nstage > 1) row_info(1);
+    __syncthreads();
+    fetch(0);
+    commit(0);
+    __syncthreads();
+    for (int st = 0; st < nstage; ++st) {
+      if (st + 1 < nstage) fetch(st + 1);
+      if (st + 2 < nstage) row_info(st + 2);
+      compute(st & 1);
+      if (st + 1 < nstage) commit((st + 1) & 1);
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    if (tkind[m] == 0) continue;
+    const int l = wave + 8 * m;
+    const int fbase = tkind[m] == 1 ? 32 * (ft0 + l) : Fp + kp0 + 32 * (l - nft);
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int f = fbase + 8 * (r >> 2) + 4 * hh + (r & 3);
+        if (tkind[m] == 1 && f >= Fp) continue;              // padding rows of the last feature tile: the transition rows start there
+        part[((size_t)blockIdx.x * FtotF + f) * Kpf + ks0 + 32 * n + j] = (double)acc[m][n][r];
+      }
+  }
+}

@@ -73,7 +73,7 @@ int svihmm_destroy(svihmm_ctx* h) {
                  &h->local_lb, &h->logz, &h->part, &h->packed, &h->scratch, &h->kexp, &h->hx, &h->gx,
                  &h->zfac, &h->llE, &h->m_ll, &h->m_la, &h->m_lb, &h->chain, &h->chain2, &h->cat_table, &h->partc, &h->theta_orb, &h->prior, &h->vlb_aux, &h->gen_z,
                  &h->svi_state, &h->svi_prior, &h->svi_work, &h->commtmp, &h->ll0, &h->a0v, &h->a0e,
-                 &h->shift_d};
+                 &h->shift_d, &h->uwb, &h->uwd, &h->AexpF, &h->AexpTF};
   for (Buf* b : bufs) release(*b);
   if (h->vlb_host) { hipHostFree(h->vlb_host); h->vlb_host = nullptr; }
   if (h->svi_elbo) { hipHostFree(h->svi_elbo); h->svi_elbo = nullptr; }
@@ -864,14 +864,19 @@ int prepare_ll(svihmm_ctx* h, const int64_t* starts, int B, int Lm, uint32_t fla
     // models take the plain kernel plus one scaling pass
     const bool two_pass = lin && (h->Kp > 64 || h->emis_cat);
     // fp32 mode: scaled messages stored as float + fp32 statistics GEMM, for what the mode
-    // covers (NIW emission, K <= 64, window batches on the scaled sweeps); everything else
-    // runs as fp64
-    h->cur_f32 = lin && h->prec == 1 && h->f32_ok && !two_pass && !use_chain(h, B, Lm);
+    // covers (NIW emission, K <= 64, window batches on the scaled sweeps; round 5: wide NIW models
+    // up to K = 256, D = 64 in large batches, f32_wide_ok); everything else runs as fp64
+    const bool wide32 = two_pass && lin && h->prec == 1 && h->f32_ok && !use_chain(h, B, Lm) &&
+                        f32_wide_ok(h, (int64_t)B * Lm);
+    h->cur_f32 = lin && h->prec == 1 && h->f32_ok && (!two_pass || wide32) && !use_chain(h, B, Lm);
     CK(launch_emission(h, B, Lm, flags, lin && !two_pass));
-    if (two_pass) CK(launch_scale_ll(h, B, Lm));
+    // wide models: plain log-likelihoods + one scaling pass (fp32 mode: float, in place in h->ll, first rows
+    // of the windows in h->ll0 -- the layout of the K <= 64 path, so eh_in_llE stays false)
+    if (wide32) CK(launch_scale_ll_f32(h, B, Lm));
+    else if (two_pass) CK(launch_scale_ll(h, B, Lm));
     h->have_host_ll = false;
   }
-  h->eh_in_llE = lin && (host_ll || h->Kp > 64 || h->emis_cat);
+  h->eh_in_llE = lin && (host_ll || (h->Kp > 64 && !h->cur_f32) || h->emis_cat);
   h->lin_mode = lin;
   h->lin_stale = false;
   h->q_valid = false;

@@ -39,6 +39,12 @@ static int emd_buffers(svihmm_ctx* h, int K, uint4** uwp) {
   *uwp = (uint4*)h->uwd.p;
   return 0;
 }
+// fp32 mode on a wide model (64 < K <= 256): NIW factors with D <= 64 in batches of at least 32 768 rows --
+// k_emission_bf16x3d<true>, k_scale_ll_f32, k_sweeps_lin2<..., float>, k_stats_bf16x3w (round 5)
+bool f32_wide_ok(const svihmm_ctx* h, int64_t n) {
+  return !h->emis_diag && !h->emis_cat && h->K > 64 && h->K <= 256 && h->D <= 64 && h->niw.p != nullptr &&
+         h->variant[5] != 3 && h->variant[10] != 2 && (n >= 32768 || h->variant[10] == 3);
+}
 int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out) {
   CK(upload_feature_table(h, D, K));
   const int Fp = h->Fp, Kp = h->Kp;
@@ -160,7 +166,7 @@ int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled,
     CK(ensure(h->kexp, (size_t)n * sizeof(double)));
     kexp_out = (double*)h->kexp.p;
   }
-  if (scaled && !ll0_out) {      // first-row log-likelihoods of every window (k_lin_init)
+  if ((scaled || (h->cur_f32 && K > 64)) && !ll0_out) {      // first-row log-likelihoods of every window (k_lin_init)
     CK(ensure(h->ll0, (size_t)B * K * sizeof(double)));
     ll0_out = (double*)h->ll0.p;
   }

@@ -195,6 +195,32 @@ int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_t strea
     const float* Ef = (const float*)h->ll.p;
     float* af = (float*)h->la.p;
     float* bf = (float*)h->lb.p;
+    if (K > 64) {
+      // wide models (round 5): k_sweeps_lin2 on v_mfma_f32_16x16x4_f32, the transition matrix streamed from
+      // its float copy (rows up to 256 + slack zeroed once per buffer, K rows converted per launch)
+      CK(launch_lin_init(h, b0, nb, Lm, stream));
+      const size_t nrow_t = 256 + 16, kk = (size_t)K * K;
+      CK(ensure(h->AexpF, nrow_t * K * sizeof(float)));
+      CK(ensure(h->AexpTF, nrow_t * K * sizeof(float)));
+      HIPCK(hipMemsetAsync((char*)h->AexpF.p + kk * 4, 0, (nrow_t * K - kk) * 4, stream));
+      HIPCK(hipMemsetAsync((char*)h->AexpTF.p + kk * 4, 0, (nrow_t * K - kk) * 4, stream));
+      hipLaunchKernelGGL(k_f64_to_f32, dim3(64), dim3(256), 0, stream, (const double*)h->Aexp.p, (float*)h->AexpF.p, kk);
+      hipLaunchKernelGGL(k_f64_to_f32, dim3(64), dim3(256), 0, stream, (const double*)h->AexpT.p, (float*)h->AexpTF.p, kk);
+      const bool w32 = 2 * ((nb + 15) / 16) > 256 && h->variant[13] != 1;
+#define SWP2F(F, WT)                                                                                          \
+  do {                                                                                                        \
+    const size_t lds = (size_t)(WT) * sizeof(LinShared<16>);                                                  \
+    dim3 g2((unsigned)((nb + 16 * (WT) - 1) / (16 * (WT))), 2);                                               \
+    hipFuncSetAttribute((const void*)k_sweeps_lin2<8, F, WT, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((k_sweeps_lin2<8, F, WT, float>), g2, dim3(512), lds, stream, Ef, kx,                  \
+                       (const float*)h->AexpF.p, (const float*)h->AexpTF.p, a0v, a0e, nb, Lm, K, af, bf, hx, gx, llb, lz, zf); \
+  } while (0)
+      if (w32) { if (K == 256) SWP2F(true, 2); else SWP2F(false, 2); }
+      else if (K == 256) SWP2F(true, 1); else SWP2F(false, 1);
+#undef SWP2F
+      HIPCK(hipGetLastError());
+      return 0;
+    }
     if (nb < LIN_WAVE_MAX && h->variant[7] != 2) {
       dim3 gw((unsigned)nb, 2);
 #define WLF(KM, FK) hipLaunchKernelGGL((k_wave_lin<KM, FK, float>), gw, dim3(64), 0, stream, Ef, kx, (const double*)h->Aexp.p, \
@@ -318,7 +344,8 @@ int ensure_q(svihmm_ctx* h, int B, int Lm, hipStream_t stream) {
 #define PQF(KT) hipLaunchKernelGGL((k_lin_posterior<KT, float>), grid, dim3(256), 0, stream, (const float*)h->la.p, \
                                    (const float*)h->lb.p, (const double*)h->hx.p, (const double*)h->gx.p,          \
                                    (const double2*)h->zfac.p, n, Lm, K, (double*)h->q.p)
-  if (h->cur_f32) { if (K <= 16) PQF(1); else if (K <= 32) PQF(2); else if (K <= 48) PQF(3); else PQF(4); }
+  if (h->cur_f32) { if (K <= 16) PQF(1); else if (K <= 32) PQF(2); else if (K <= 48) PQF(3); else if (K <= 64) PQF(4);
+                    else if (K <= 128) PQF(8); else if (K <= 192) PQF(12); else PQF(16); }
   else if (K <= 16) PQ(1); else if (K <= 32) PQ(2); else if (K <= 48) PQ(3); else if (K <= 64) PQ(4);
   else if (K <= 128) PQ(8); else if (K <= 192) PQ(12); else PQ(16);
 #undef PQ
@@ -487,6 +514,19 @@ int launch_scale_ll(svihmm_ctx* h, int B, int Lm) {
   if (K <= 16) SC(1); else if (K <= 32) SC(2); else if (K <= 48) SC(3); else if (K <= 64) SC(4);
   else if (K <= 128) SC(8); else if (K <= 192) SC(12); else SC(16);
 #undef SC
+  HIPCK(hipGetLastError());
+  return 0;
+}
+
+int launch_scale_ll_f32(svihmm_ctx* h, int B, int Lm) {
+  const int64_t n = (int64_t)B * Lm;
+  const int K = h->K;
+  CK(ensure(h->kexp, (size_t)n * sizeof(double)));
+  ProfScope ps(h, KS_EMISSION);
+  dim3 grid((unsigned)((n + 15) / 16));
+#define SCF(KT) hipLaunchKernelGGL(k_scale_ll_f32<KT>, grid, dim3(256), 0, h->stream, (float*)h->ll.p, n, K, (double*)h->kexp.p)
+  if (K <= 128) SCF(8); else if (K <= 192) SCF(12); else SCF(16);
+#undef SCF
   HIPCK(hipGetLastError());
   return 0;
 }

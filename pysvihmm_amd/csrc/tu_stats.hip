@@ -33,8 +33,33 @@ static bool stats_bf16_ok(const svihmm_ctx* h, int64_t n) {
          h->Fp % 32 == 0 && !h->emis_cat && !h->emis_diag && h->variant[10] != 2 && h->variant[1] == 0 &&
          (n >= 32768 || h->variant[10] == 3);     // (variant[10] = 3: tests force it on small batches)
 }
+// ... and k_stats_bf16x3w (round 5) for what that kernel does not take: wide models (64 < K <= 256) and more
+// than 22 feature tiles (D > 32); D <= 64 (two stage buffers of x^T + six planes in 160 KB of LDS)
+static int bw_feature_groups(const svihmm_ctx* h) {
+  const int FT = (h->Fp + 31) / 32, NGz = (h->Kp + 63) / 64;
+  return std::max(NGz, (FT + 21) / 22);
+}
+static size_t bw_lds(const svihmm_ctx* h) {
+  const size_t xb = (((size_t)(h->D + 2) * SB_XRS * 4) + 15) & ~(size_t)15;
+  return 2 * (xb + 6 * (size_t)64 * SB_QRS * 2) + 3 * SB_ROWS * sizeof(SbRow);
+}
+static bool stats_bf16w_ok(const svihmm_ctx* h, int64_t n) {
+  // (a wide model that runs in the fp32 format has no other statistics kernel: no batch-size floor there)
+  return h->cur_f32 && h->lin_mode && !h->q_valid && h->K <= 256 && h->Kp % 64 == 0 && h->Fp > 0 && !h->emis_cat &&
+         !h->emis_diag && h->variant[10] != 2 && h->variant[1] == 0 && bw_lds(h) <= 160 * 1024 &&
+         (h->K > 64 || ((h->Fp + 31) / 32 + 2 > 24 && (n >= 32768 || h->variant[10] == 3)));
+}
 StatsPlan stats_plan(const svihmm_ctx* h, int64_t n, int forced) {
   int target_chunks = forced > 0 ? forced : 128;
+  if (forced <= 0 && !stats_bf16_ok(h, n) && stats_bf16w_ok(h, n)) {
+    // chunks x feature groups x state groups = whole rounds of 256 one-per-CU workgroups, >= 32 chunks
+    const int per_chunk = bw_feature_groups(h) * ((h->Kp + 63) / 64);
+    const int R = std::max(1, (32 * per_chunk + 255) / 256);
+    int64_t tc = std::max(1, 256 * R / per_chunk);
+    if (tc > n / (4 * SB_ROWS)) tc = std::max<int64_t>(1, n / (4 * SB_ROWS));
+    int64_t rpc = ((n + tc - 1) / tc + SB_ROWS - 1) / SB_ROWS * SB_ROWS;
+    return {rpc, (n + rpc - 1) / rpc};
+  }
   if (forced <= 0 && stats_bf16_ok(h, n)) {
     // one 8-wave workgroup per chunk covers all feature tiles: a chunk per CU (small batches: chunks of
     // at least four 64-row stages)
@@ -53,7 +78,8 @@ StatsPlan stats_plan(const svihmm_ctx* h, int64_t n, int forced) {
     target_chunks = std::max(1, 256 * r * per_cu / gy);
   }
   int64_t rpc = (n + target_chunks - 1) / target_chunks;
-  rpc = (rpc + ST_RB - 1) / ST_RB * ST_RB;
+  const int rb = (stats_bf16_ok(h, n) || stats_bf16w_ok(h, n)) ? SB_ROWS : ST_RB;     // (a forced chunk count: the bf16 kernels' stage)
+  rpc = (rpc + rb - 1) / rb * rb;
   return {rpc, (n + rpc - 1) / rpc};
 }
 // partial statistics of windows [b0, b0+nb) (inner segment [off, off+Lm) of each window of
@@ -94,11 +120,13 @@ int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, int Lm, u
       // K > 64: state groups of 64 in grid.z for the emission-statistics tiles; the K x K
       // transition tiles (which need q[t-1] of ALL states as operand rows) go to k_stats_mfma.
       const bool big = Kp > 64;
+      const bool bw = lin && h->cur_f32 && !stats_bf16_ok(h, n) && stats_bf16w_ok(h, n) && rpc % SB_ROWS == 0 && nchunk * rpc >= n;
+      if (h->cur_f32 && big && !bw) return fail("internal: fp32-mode batch of a wide model without its statistics kernel");
       // wide models, scaled sweeps: the feature launch leaves q = ah bh scale behind for the
       // transition-block launch (whose little matrix work per staged row cannot carry two more
       // operand streams: 3.3 against 2.4 ms on configs[4])
       double* qoutv = nullptr;
-      if (big && lin) {
+      if (big && lin && !bw) {
         CK(ensure(h->q, (size_t)h->curB * Lq * K * sizeof(double)));
         qoutv = (double*)h->q.p + qo;
       }
@@ -110,7 +138,17 @@ int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, int Lm, u
       const int mtiles = Ftot / 16;
       const int mt_limit = big ? Fp / 16 : mtiles;
       const int xk = (D + 1 + TPR - 1) / TPR;
-      if (lds > 150 * 1024 || xk > 9 || (big && Kp % 64 != 0)) var = 2;
+      if (bw) {
+        const int KpF = (Kp + 63) / 64 * 64, NGf = bw_feature_groups(h), FT = (Fp + 31) / 32;
+        const int TPG = (FT + NGf - 1) / NGf;
+        const size_t ldsb = bw_lds(h);
+        if (KpF != Kp) return fail("internal: wide fp32 statistics need states padded in groups of 64");
+        hipFuncSetAttribute((const void*)k_stats_bf16x3w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+        hipLaunchKernelGGL(k_stats_bf16x3w, dim3((unsigned)nchunk, NGf, KpF / 64), dim3(512), ldsb, stream, (const double*)h->obs.p, mk,
+                           starts_dev, n, Lm, D, K, KpF, Fp, F, (const int*)h->fab.p, (const float*)h->la.p + qo,
+                           (const float*)h->lb.p + qo, rpc, flags, Lq, off, partv, hxv, gxv, zfv, TPG);
+      }
+      else if (lds > 150 * 1024 || xk > 9 || (big && Kp % 64 != 0)) var = 2;
       else if (lin && h->cur_f32 && !big && stats_bf16_ok(h, n) && rpc % SB_ROWS == 0 && nchunk * rpc >= n) {
         const size_t xb = (((size_t)(D + 2) * SB_XRS * 4) + 15) & ~(size_t)15;
         const size_t ldsb = 2 * (xb + 6 * (size_t)64 * SB_QRS * 2) + 3 * SB_ROWS * sizeof(SbRow);
