@@ -895,13 +895,48 @@ def wide_model(eng, L):
     nstep = n + 1                       # steps since profile_reset (one warm-up + n timed)
     F = (Dw + 1) * (Dw + 2) // 2
     fl = rows * (2.0 * F * Kw + 2.0 * (F + Kw) * Kw + 2 * 2.0 * Kw * Kw)
-    return {"ms": dt * 1e3, "value": rows * Kw / dt, "unit": "updates/s", "tflops": fl / dt / 1e12,
-            "K": Kw, "D": Dw, "T": T, "Lm": LM, "windows_per_step": Bw,
-            "kernels_ms": {k: v[0] / nstep for k, v in prof.items()},
-            "kernel_launches_per_step": {k: v[1] / nstep for k, v in prof.items()},
-            "note": "configs[4] epoch sweep, fp64; tflops = algorithmic MFMA flops (emission 2FK + statistics "
-                    "2(F+K)K + sweeps 4K^2 per row) / wall; kernels_ms = device time per STEP summed over the "
-                    "slot's launches (emission = GEMM + scaling pass, stats = feature + transition blocks)"}
+    rec = {"ms": dt * 1e3, "value": rows * Kw / dt, "unit": "updates/s", "tflops": fl / dt / 1e12,
+           "K": Kw, "D": Dw, "T": T, "Lm": LM, "windows_per_step": Bw,
+           "kernels_ms": {k: v[0] / nstep for k, v in prof.items()},
+           "kernel_launches_per_step": {k: v[1] / nstep for k, v in prof.items()},
+           "roofline": {"bound": "mfma", "kernel": "whole step (fp64 MFMA kernels)", "achieved": fl / dt / 1e12,
+                        "peak": 78.6, "unit": "TFLOP/s", "frac": fl / dt / 1e12 / 78.6},
+           "note": "configs[4] epoch sweep, fp64; tflops = algorithmic MFMA flops (emission 2FK + statistics "
+                   "2(F+K)K + sweeps 4K^2 per row) / wall; kernels_ms = device time per STEP summed over the "
+                   "slot's launches (emission = GEMM + scaling pass, stats = feature + transition blocks)"}
+    # the same step in the fp32 mode (round 5: k_emission_bf16x3d, k_scale_ll_f32, k_sweeps_lin2<float>,
+    # k_stats_bf16x3w); north_star's fp32 tolerance asserted against the fp64 statistics of this run
+    try:
+        ref64 = out.buf.copy()
+        eng.set_precision("f32")
+        o32 = one()
+        used = eng.precision()[1]
+        eng.profile(True); eng.profile_reset()
+        dt32 = median_time(one, eng.sync, n, warm=1)
+        p32 = eng.profile_read(); eng.profile(False)
+        scale = np.maximum(np.abs(ref64), 1e-6 * rows)
+        err = float(np.max(np.abs(o32.buf - ref64) / scale))
+        # bf16 MFMA work issued: emission 60 v_mfma_f32_32x32x16_bf16 per pair of states and 32-row tile, statistics
+        # (68 feature + 8 transition tiles) x 8 state tiles x 6 per 16 rows; fp32-equivalent = the arithmetic the
+        # mode replaces: K D (D + 1) + 2 (F + K) K + 4 K^2 flop per row
+        bf_em = rows / 32.0 * (Kw / 2) * 60 * 32768.0
+        bf_st = rows / 16.0 * ((F + 31) // 32 + Kw // 32) * (Kw // 32) * 6 * 32768.0
+        kms = {k: v[0] / nstep for k, v in p32.items()}
+        rec["f32_mode"] = {"ms": dt32 * 1e3, "value": rows * Kw / dt32, "unit": "updates/s", "ran_in_f32_format": bool(used),
+                           "max_rel_err_vs_f64_statistics": err, "kernels_ms": kms,
+                           "fp32_equivalent_tflops": rows * (Kw * Dw * (Dw + 1.0) + 2.0 * (F + Kw) * Kw + 4.0 * Kw * Kw) / dt32 / 1e12,
+                           "roofline": {"bound": "mfma", "kernel": "k_emission_bf16x3d + k_stats_bf16x3w (bf16 pipe)",
+                                        "achieved": (bf_em + bf_st) / ((kms.get("emission", 0) + kms.get("stats", 0)) * 1e-3 + 1e-30) / 1e12,
+                                        "peak": 2500.0, "unit": "TFLOP/s",
+                                        "frac": (bf_em + bf_st) / ((kms.get("emission", 0) + kms.get("stats", 0)) * 1e-3 + 1e-30) / 1e12 / 2500.0}}
+        assert err < 1e-3, err
+    except AssertionError:
+        raise
+    except Exception as e:
+        rec["f32_mode"] = {"error": repr(e)}
+    finally:
+        eng.set_precision("f64")
+    return rec
 
 
 if __name__ == "__main__":

@@ -275,3 +275,53 @@ def test_f32_statistics_on_the_bf16_pipe(D, B, Lm, flags_wrap, inner):
         np.testing.assert_allclose(st.A_raw.sum(), nin if flags_wrap else nin - B, rtol=1e-5)
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("K,D,B,Lm", [(256, 64, 208, 257), (200, 48, 260, 129), (130, 40, 300, 129), (128, 32, 200, 257),
+                                      (64, 64, 160, 257), (64, 48, 300, 129), (33, 40, 280, 129)])
+def test_f32_wide_models_and_d_above_32_vs_fp64_oracle(K, D, B, Lm):
+    """Round 5: the fp32 mode at the shapes it did not reach -- wide models
+    (64 < K <= 256: k_emission_bf16x3d<WIDE> + k_scale_ll_f32 + k_sweeps_lin2<float> + k_stats_bf16x3w,
+    ragged K included) and D in {40, 48, 64} at K <= 64 (k_emission_bf16x3d; K = 64: k_stats_bf16x3w) --
+    against the fp64 C oracle: the mode's 1e-3 (canary 1e-4), the batch really ran in the fp32 format."""
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    from oracle import ref_c
+    T = max(6000, B * 3 + Lm)
+    pb = make_problem(K, D, T, seed=K + D, miss=0.05, sep=4.0)
+    starts = np.random.default_rng(B).integers(0, T - Lm + 1, size=B)
+    e = HipEngine(0, dtype="f32")
+    try:
+        e.set_obs(pb["obs"], pb["mask"])
+        e.set_globals(pb["mod_init"], pb["ltran"])
+        e.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+        st = e.estep(starts, Lm, flags=L.TRANS_WRAP)
+        assert e.precision() == ("f32", True)
+        ref = ref_c.estep_minibatch(pb["obs"], pb["mask"], starts, Lm, pb["mod_init"], pb["ltran"], pb["mu"],
+                                    pb["sigma"], pb["kappa"], pb["nu"], flags=2, threads=effective_cores())
+        A, xbar, neff, S, lb = unpack(ref, K, D)
+        sc = B * Lm
+        xs = np.abs(pb["obs"]).max()
+        worst = max(_close(st.A_raw, A, sc, "A"), _close(st.neff, neff, sc, "neff"),
+                    _close(st.xbar, xbar, sc * xs, "xbar"), _close(st.S, S, sc * xs ** 2, "S"))
+        assert worst < 1e-4, worst
+        np.testing.assert_allclose(st.lb[0], lb, rtol=1e-6)
+        for b in (0, B - 1):
+            x = pb["obs"][starts[b]:starts[b] + Lm].copy()
+            ll = ref_c.lliks_niw(x, pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+            q, _ = ref_c.posterior(ref_c.forward(ll, pb["mod_init"], pb["ltran"]), ref_c.backward(ll, pb["ltran"]))
+            got = e.read_rows("var_x", b * Lm, Lm)
+            assert np.abs(got - q).max() < 1e-4
+            assert np.abs(got.sum(1) - 1.0).max() < 1e-5
+        # the inner-segment statistic of buffered windows on the same kernels, against the fp64 device path
+        inner = (3, Lm - 7)
+        st2 = e.estep(starts, Lm, flags=L.TRANS_WRAP, inner=inner)
+        assert e.precision()[1]
+        e.set_precision("f64")
+        ref2 = e.estep(starts, Lm, flags=L.TRANS_WRAP, inner=inner)
+        sc2 = B * inner[1]
+        for a, b_, s_, w in ((st2.A_raw, ref2.A_raw, sc2, "A"), (st2.neff, ref2.neff, sc2, "neff"),
+                             (st2.xbar, ref2.xbar, sc2 * xs, "xbar"), (st2.S, ref2.S, sc2 * xs ** 2, "S")):
+            _close(a, b_, s_, "inner " + w)
+    finally:
+        e.close()

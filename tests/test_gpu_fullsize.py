@@ -220,5 +220,28 @@ def test_config5_k256_d64_t1e6_epoch_sweep():
         np.testing.assert_allclose(got.neff, neff, rtol=1e-6, atol=1e-10 * sc)
         np.testing.assert_allclose(got.S, S, rtol=1e-6, atol=1e-8 * sc)
         np.testing.assert_allclose(got.lb[0], lb, rtol=1e-10)
+        # ---- the same configuration in the fp32 mode (round 5: k_emission_bf16x3d<WIDE>, k_scale_ll_f32,
+        #      k_sweeps_lin2<float>, k_stats_bf16x3w): north_star's 1e-3 against the fp64 C oracle on the 208
+        #      spread windows, against the fp64 epoch step on all 3891, posteriors of the 6 windows
+        def close32(a, b, scale, what):
+            err = np.abs(a - b) / (np.abs(b) + 1e-6 * scale)
+            assert err.max() < 1e-3, (what, float(err.max()))
+        xs = float(np.abs(obs[:n]).max())
+        e.set_precision("f32")
+        g32 = e.estep(sel, Lm, flags=L.TRANS_WRAP)
+        assert e.precision() == ("f32", True)
+        for a, b, sc_, w in ((g32.A_raw, A, sc, "A"), (g32.neff, neff, sc, "neff"), (g32.xbar, xbar, sc * xs, "xbar"),
+                             (g32.S, S, sc * xs * xs, "S")):
+            close32(a, b, sc_, "sample " + w)
+        np.testing.assert_allclose(g32.lb[0], lb, rtol=1e-6)
+        s32 = e.estep(starts, Lm, flags=L.TRANS_WRAP)
+        assert e.precision() == ("f32", True)
+        assert np.all(np.isfinite(s32.buf)) and abs(s32.A_raw.sum() / n - 1.0) < 1e-5
+        for a, b, sc_, w in ((s32.A_raw, st.A_raw, n, "A"), (s32.neff, st.neff, n, "neff"), (s32.xbar, st.xbar, n * xs, "xbar"),
+                             (s32.S, st.S, n * xs * xs, "S")):
+            close32(a, b, sc_, "epoch " + w)
+        np.testing.assert_allclose(s32.lb[0], st.lb[0], rtol=1e-6)
+        for b, q in qs.items():
+            assert np.abs(e.read_rows("var_x", b * Lm, Lm) - q).max() < 1e-4
     finally:
         e.close()
