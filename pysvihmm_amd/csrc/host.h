@@ -174,6 +174,7 @@ struct svihmm_ctx {
   std::vector<int> svi_ev_begin;                         // event that marks the start of iteration it
   int svi_last_it = -1;
   bool svi_active = false, svi_f32_ok = true, svi_adagrad = false;
+  double svi_vmin = 0.0;    // host-side lower bound of var_tran's entries (plain rho steps with prior_tran >= 1 only raise it)
   hipEvent_t svi_ea = nullptr, svi_eb = nullptr, globals_ev = nullptr;   // side-stream globals kernel
   hipEvent_t svi_ec = nullptr, svi_ed = nullptr;   // theta ready / side-stream ELBO kernels done
   hipStream_t stream3 = nullptr;                   // the ELBO kernels' own stream

@@ -1338,6 +1338,7 @@ static int svi_begin_common(svihmm_ctx* h, int K, int D, const double* prior_tra
       return fail("svihmm_svi_begin: prior_tran below 1 or var_tran below SVIHMM_SVI_MIN_PSEUDOCOUNT may need the "
                   "log-domain recursion mid-loop: run the loop through svihmm_set_globals + svihmm_estep_minibatch");
     h->svi_f32_ok = vmin > 0.05;      // psi(0.05) - 28 > SVIHMM_LTRAN_F32_MIN
+    h->svi_vmin = vmin;
     h->exact_log = false;
     h->f32_ok = h->svi_f32_ok;
   }
@@ -1544,6 +1545,15 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
   // forked behind theta together with the ELBO kernels it competes with the next emission GEMM,
   // ends after that GEMM, and a stream wait that really has to block wakes up ~20 us late -- measured
   // 0.272 against 0.25 ms per iteration)
+  // Lower bound of var_tran after this step, kept on the host: the plain step is
+  // v <- (1 - rho) v + rho (1 + bA (A_raw + nwin (prior_tran - 1))) with prior_tran >= 1 and A_raw >= 0,
+  // so every entry is >= (1 - rho) bound + rho.  A loop that started below the fp32 mode's range for
+  // E[log A] (a class's default initial var_tran of 1/K) enters it after its first steps (rho_0 = 1 for
+  // tau = 1) instead of running fp64 to the end.  AdaGrad's element-wise weights give no such bound.
+  if (!h->svi_adagrad && rho >= 0.0 && rho <= 1.0) {
+    h->svi_vmin = (1.0 - rho) * h->svi_vmin + rho;
+    h->svi_f32_ok = h->svi_vmin > 0.05;
+  }
   if (it + 1 < h->svi_maxit) CK(svi_globals(h, h->svi_vi_cur ^ 1));
   CK(svi_refresh_emission(h, it, it & 1, h->svi_ev[2 * it + 1]));
   return 0;

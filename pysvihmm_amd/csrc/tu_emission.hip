@@ -84,7 +84,7 @@ int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out) {
   // device-resident SVI loop: its minibatches stay below that kernel's batch size, and a large batch
   // that follows builds them on demand)
   uint4* uwp = nullptr;
-  if (h->prec == 1 && emb_shape_ok(K, D) && !h->svi_active) CK(emb_buffers(h, &uwp));
+  if (h->prec == 1 && emb_shape_ok(K, D) && (!h->svi_active || h->variant[5] == 4)) CK(emb_buffers(h, &uwp));
   const bool emd = h->prec == 1 && emd_shape_ok(K, D) && !h->svi_active;   // (D <= 32 at K > 64: the 64-wide builder writes the records)
   if (emd) CK(emd_buffers(h, K, &uwp));
   {
@@ -189,7 +189,7 @@ int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled,
   // fp32 mode, large batches of a NIW model with K <= 64, D <= 32: the centred bf16 x 3 kernel
   // (variant[5] = 3: the fp64 feature GEMM also in this mode)
   if (!h->emis_diag && scaled && (flags & SVIHMM_INT_ST32) && emb_shape_ok(K, D) && h->niw.p &&
-      h->variant[5] != 3 && min_lds == 0 && (n + 127) / 128 >= 256) {
+      h->variant[5] != 3 && min_lds == 0 && ((n + 127) / 128 >= 256 || h->variant[5] == 4)) {
     uint4* uwp = nullptr;
     CK(emb_buffers(h, &uwp));
     if (!h->uw_valid) {   // the mode was switched on after the parameter upload: factors from the resident NIW block

@@ -35,6 +35,10 @@ static bool stats_bf16_ok(const svihmm_ctx* h, int64_t n) {
 }
 // ... and k_stats_bf16x3w (round 5) for what that kernel does not take: wide models (64 < K <= 256) and more
 // than 22 feature tiles (D > 32); D <= 64 (two stage buffers of x^T + six planes in 160 KB of LDS)
+// feature groups (grid.y): each owns up to 22 feature tiles + (the first Kp / 64 of them) two transition tiles.
+// (Measured on configs[4], 68 feature tiles: five groups of 14 + 2 -- two full rounds of the 8 waves each
+//  instead of four of 17 + 2 = three ragged rounds -- ran 8.5 against 7.8 ms: every group restages q and
+//  re-forms its A terms, which costs more than the idle slots.)
 static int bw_feature_groups(const svihmm_ctx* h) {
   const int FT = (h->Fp + 31) / 32, NGz = (h->Kp + 63) / 64;
   return std::max(NGz, (FT + 21) / 22);

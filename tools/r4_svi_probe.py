@@ -13,6 +13,9 @@ rs, tran, means, chols = bench.true_process(0)
 eng.generate(tran, means, chols, bench.T, seed=bench.SEED)
 obs = eng.read_generated(want_sts=False)[0]
 for kv in sys.argv[1:]:
+    if kv == "f32":
+        eng.set_precision("f32")
+        continue
     eng.set_variant(int(kv.split(":")[0]), int(kv.split(":")[1]))
 for rep in range(3):
     r = bench.svi_iteration(eng, obs)

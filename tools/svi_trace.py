@@ -10,7 +10,7 @@ rows = list(c.execute("select name, start, end, grid_x*grid_y*grid_z/(workgroup_
                       "from kernels order by start"))
 idx = [i for i, r in enumerate(rows) if "k_svi_elbo" in r[0]]
 # an iteration of the 64-window loop: contains a k_wave_lin4 launch
-sel = [(a, b) for a, b in zip(idx, idx[1:]) if any("k_wave_lin4" in r[0] for r in rows[a:b])]
+sel = [(a, b) for a, b in zip(idx, idx[1:]) if any("k_wave_lin" in r[0] for r in rows[a:b])]
 a, b = sel[len(sel) // 2]
 t0 = rows[a][2]
 last_end = t0
