@@ -142,22 +142,66 @@ def rank_envs(n, port, base=None):
     return envs
 
 
+def error_record(n_gpus, msg, **extra):
+    """The ONE JSON line of a run that could not produce a measurement: same leading keys as a result
+    line, value null, and the reason -- so that a failed N-GPU run leaves a record instead of nothing."""
+    rec = {"metric": "obs-state updates/sec (T*K/s) per SVI E-step, K=64 Gaussian HMM", "value": None,
+           "unit": "updates/s", "n_gpus": n_gpus, "higher_is_better": True, "error": msg}
+    rec.update(extra)
+    return rec
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU)
-    ourselves; rank 0's stdout (the JSON line) passes through.  Exit code = worst child."""
+    ourselves; rank 0's stdout (the JSON line) passes through.  Exit code = worst child.  A rank that
+    dies takes the job down (its peers would wait in a collective for ever): the others get
+    SVIHMM_PEER_GRACE_S seconds (default 20), then SIGTERM; if rank 0 printed no JSON line the launcher
+    prints the error record with every rank's exit code."""
     from pysvihmm_amd.engine import device_count
     ndev = device_count()
     if ndev < args.gpus:
         sys.stderr.write("bench.py: --gpus %d but only %d HIP device(s) visible\n" % (args.gpus, ndev))
+        print(json.dumps(error_record(args.gpus, "--gpus %d but only %d HIP device(s) visible" % (args.gpus, ndev))))
         return 2
     procs = []
     for r, env in enumerate(rank_envs(args.gpus, free_port())):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    import threading
+    seen = {"json": False}
+
+    def pump():
+        for line in procs[0].stdout:
+            if line.lstrip().startswith("{"):
+                seen["json"] = True
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    grace = float(os.environ.get("SVIHMM_PEER_GRACE_S", "20"))
+    failed_at = None
+    while any(p.poll() is None for p in procs):
+        if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
+            failed_at = time.time()
+        if failed_at is not None and time.time() - failed_at > grace:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.05)
+    codes = []
     for p in procs:
-        p.wait()
-        rc = rc or p.returncode
+        try:
+            codes.append(p.wait(timeout=15))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            codes.append(p.wait())
+    th.join(timeout=5)
+    rc = next((c for c in codes if c), 0)
+    if not seen["json"]:
+        print(json.dumps(error_record(args.gpus, "no result line from rank 0", rank_exit_codes=codes)))
+        sys.stdout.flush()
+        rc = rc or 1
     return rc
 
 
@@ -198,7 +242,27 @@ def headline_record(args, strong, world, ranks_seen, have_comm, block, per_rank,
         prof_src = kj.get("_note", "").split("source ")[-1] or None
     except Exception:
         pass
-    achieved_prof = flops[dom] / (prof_us * 1e-6) / 1e12 if prof_us else None
+    # the committed profile is only quoted when it still describes THIS build: same kernel function as the one
+    # the run dispatched (svihmm_last_kernel_name) and an average duration within 10 % of the live HIP-event
+    # figure; otherwise the line says "stale" and carries the live figure
+    prof_kernel = None
+    stale = None
+    try:
+        prof_kernel = kj.get(dom, {}).get("kernel")
+    except Exception:
+        pass
+    live_kernel = (side or {}).get("_dispatched", {}).get(dom)
+    ev_us = kern[dom]["ms_per_launch"] * 1e3
+    if prof_us:
+        if live_kernel and prof_kernel and live_kernel != prof_kernel:
+            stale = "profile is of %s, this run dispatched %s" % (prof_kernel, live_kernel)
+        elif abs(prof_us - ev_us) > 0.10 * ev_us:
+            stale = "profile average %.1f us differs from this run's HIP-event average %.1f us by more than 10 %%" % (prof_us, ev_us)
+    if stale:
+        prof_us_used = None
+    else:
+        prof_us_used = prof_us
+    achieved_prof = flops[dom] / (prof_us_used * 1e-6) / 1e12 if prof_us_used else None
     # algorithmic HBM bytes of the whole step: obs read once + packed stats out
     alg_bytes = rows * D * 8.0 + packed_size(K, D) * 8.0
     step_flops = sum(flops.values())
@@ -228,9 +292,12 @@ def headline_record(args, strong, world, ranks_seen, have_comm, block, per_rank,
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved,
                      "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_PEAK_TFLOPS,
-                     "frac_source": ("rocprofv3 --kernel-trace --stats average of the kernel, %s (%.1f us)"
-                                     % (prof_src, prof_us)) if achieved_prof else
+                     "frac_source": ("rocprofv3 --kernel-trace --stats average of the kernel, %s (%.1f us); checked against "
+                                     "this run: same kernel function, HIP-event average %.1f us" % (prof_src, prof_us, ev_us))
+                                    if achieved_prof else
+                                    ("stale: %s -- frac is this run's HIP-event figure" % stale) if stale else
                                     "HIP events of this run (no profiles/kernel_stats.json)",
+                     "kernel_function": live_kernel or prof_kernel,
                      "achieved_events": achieved_ev, "frac_events": achieved_ev / FP64_PEAK_TFLOPS,
                      "whole_step_frac": step_flops / (ms_per_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                      "traffic": traffic,
@@ -257,7 +324,7 @@ def headline_record(args, strong, world, ranks_seen, have_comm, block, per_rank,
         res["allreduce"] = {"ms_per_step": kern["allreduce"]["ms_per_launch"], "bytes": packed_size(K, D) * 8,
                             "note": "ncclAllReduce(sum, f64) of the packed statistics on the handle's stream "
                                     "(HIP events around the call)"}
-    res.update(side)
+    res.update({k: v for k, v in (side or {}).items() if not k.startswith("_")})
     return res
 
 
@@ -361,6 +428,32 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    # A rank that fails (communicator init, a device error, a peer that went away and made the launcher
+    # terminate us) still leaves ONE JSON line on rank 0's stdout: the error record.
+    state = {"printed": False}
+    if rank == 0 and world > 1:
+        import signal
+
+        def on_term(signum, frame):
+            if not state["printed"]:
+                print(json.dumps(error_record(args.gpus, "terminated by the launcher (signal %d): a peer rank failed "
+                                                         "or the job was cancelled" % signum)))
+                sys.stdout.flush()
+            os._exit(143)
+        signal.signal(signal.SIGTERM, on_term)
+    try:
+        run_rank(args, state)
+    except BaseException as e:
+        if rank == 0 and not state["printed"] and not isinstance(e, KeyboardInterrupt):
+            msg = str(e) if isinstance(e, SystemExit) else repr(e)
+            print(json.dumps(error_record(args.gpus, msg, rank=rank)))
+            sys.stdout.flush()
+        raise
+
+
+def run_rank(args, state):
+    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
@@ -380,7 +473,8 @@ def main():
     ranks_seen = 1
     if use_comm:
         from pysvihmm_amd.comm import RcclComm, file_uid_exchange
-        ex = file_uid_exchange(rank)
+        # bounded rendezvous: a rank that never shows up must not hold the others past the driver's patience
+        ex = file_uid_exchange(rank, timeout=float(os.environ.get("SVIHMM_RENDEZVOUS_TIMEOUT", "90")))
         comm = RcclComm(eng, rank, world, ex)
         ranks_seen = eng.comm_count()
         if ranks_seen != world:
@@ -448,6 +542,9 @@ def main():
         block[r] = time.perf_counter() - t0
     prof = eng.profile_read()
     eng.profile(False)
+    dispatched = {}
+    if hasattr(eng, "last_kernel"):
+        dispatched = {dom_slot: eng.last_kernel(dom_slot)}
     # the other kernels of the step: a short separate pass with every slot bracketed (outside the
     # timed region; the dominant kernel keeps its timed-region figure)
     eng.profile(True)
@@ -473,6 +570,7 @@ def main():
     side = {}
     if world == 1 and not args.no_side:
         side = side_figures(eng, L, pb, step, barrier, obs_host, args)
+    side["_dispatched"] = dispatched
     if comm is not None and not strong and not args.no_strong:
         # the other partitioning of DESIGN 6, measured in the same job: ONE sequence on every GPU
         # (rank 0's), the epoch's windows and the S=64 minibatch dealt round-robin over the ranks
@@ -483,6 +581,7 @@ def main():
                               gen_ms, side)
         print(json.dumps(res))
         sys.stdout.flush()
+        state["printed"] = True
     if comm is not None:
         comm.barrier(eng)
         if rank == 0:
@@ -568,8 +667,23 @@ def side_figures(eng, L, pb, step, barrier, obs_host, args):
         barrier()
         blocks.append((time.perf_counter() - t0) / n64)
     dt64 = float(np.median(blocks))
+    fl64 = sum(algorithmic_flops(64 * LM).values())
+    eng.profile(True); eng.profile_reset()
+    for _ in range(10):
+        step(st64)
+    p64 = eng.profile_read(); eng.profile(False)
+    k64 = {k: v[0] / v[1] for k, v in p64.items()}
+    f64k = algorithmic_flops(64 * LM)
     res["minibatch_s64"] = {"windows": 64, "ms_per_step": dt64 * 1e3, "value": 64 * LM * K / dt64,
-                            "unit": "updates/s", "note": "E-step + statistics of 64 windows (engine calls only)"}
+                            "unit": "updates/s", "note": "E-step + statistics of 64 windows (engine calls only)",
+                            "kernels_ms": k64,
+                            "roofline": {"bound": "mfma", "kernel": "whole step (emission + sweeps + statistics)",
+                                         "achieved": fl64 / dt64 / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                         "frac": fl64 / dt64 / 1e12 / FP64_PEAK_TFLOPS,
+                                         "per_kernel_frac": {k: f64k[k] / (k64[k] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
+                                                             for k in f64k if k in k64},
+                                         "note": "algorithmic fp64 flop of 64 windows x 257 rows / wall; a 257-step dependent "
+                                                 "chain at one wave per SIMD: latency-, not throughput-bound (DESIGN 7 item 4)"}}
 
     # 1b. the same epoch step in the fp32 mode (scaled messages stored as float, statistics GEMM on
     #     v_mfma_f32_16x16x4_f32, emission as the centred quadratic form on the bf16 matrix pipe with
@@ -671,6 +785,26 @@ def side_figures(eng, L, pb, step, barrier, obs_host, args):
             res["svi_iteration_s64"] = svi_iteration(eng, obs_host)
         except Exception as e:       # a side figure must not take the headline down
             res["svi_iteration_s64"] = {"error": repr(e)}
+        # the same loop in the fp32 mode (the loop enters the fp32 format once var_tran's lower bound allows:
+        # from its second iteration for the class's default initialisation); final state compared with the
+        # fp64 run's at the mode's tolerance
+        try:
+            eng.set_precision("f32")
+            r32 = svi_iteration(eng, obs_host)
+            r32["ran_in_f32_format"] = bool(eng.precision()[1])
+            r64 = res["svi_iteration_s64"]
+            if "_final" in r64 and "_final" in r32:
+                a, b = r32.pop("_final"), r64["_final"]
+                r32["max_rel_err_vs_f64_final_var_tran"] = float(np.max(np.abs(a - b) / (np.abs(b) + 1e-6 * np.abs(b).max())))
+                assert r32["max_rel_err_vs_f64_final_var_tran"] < 1e-3, r32["max_rel_err_vs_f64_final_var_tran"]
+            res["svi_iteration_s64_f32"] = r32
+        except AssertionError:
+            raise
+        except Exception as e:
+            res["svi_iteration_s64_f32"] = {"error": repr(e)}
+        finally:
+            eng.set_precision("f64")
+            res.get("svi_iteration_s64", {}).pop("_final", None)
         eng.set_obs(obs_host, None)
         after = step().buf
         drift = float(np.max(np.abs(after - before) / (1e-9 + np.abs(before))))
@@ -713,8 +847,14 @@ def svi_iteration(eng, obs_host):
     hmm = t2s[-1][1]
     per_it = (t2 - t1) / (n2 - n1)
     assert np.all(np.isfinite(hmm.elbo_vec))
+    fl = sum(algorithmic_flops(64 * LM).values())
     return {"ms": per_it * 1e3, "value": 64 * LM * K / per_it, "unit": "updates/s",
             "iter_time_median_ms": float(np.median(hmm.iter_time[5:]) * 1e3),
+            "_final": hmm.var_tran.copy(),
+            "roofline": {"bound": "mfma", "kernel": "whole iteration (E-step kernels' algorithmic flop / wall)",
+                         "achieved": fl / per_it / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": fl / per_it / 1e12 / FP64_PEAK_TFLOPS,
+                         "note": "nine dependent launches on a 257-step chain: latency-bound (DESIGN 7 item 4)"},
             "note": "hmmsgd_metaobs.VBHMM.infer, mb_sz=64, L=128: wall per iteration (minibatch sampling + "
                     "E-step + global step + ELBO), from infer(maxit=%d) - infer(maxit=%d); iter_time = "
                     "E-step + global step as the reference clocks it" % (n2, n1)}

@@ -32,6 +32,10 @@ int svihmm_profile_reset(svihmm_ctx* h);
 int svihmm_profile_read(svihmm_ctx* h, double ms_out[SVIHMM_NKERN],
                         int64_t count_out[SVIHMM_NKERN]);
 const char* svihmm_kernel_name(int32_t slot);
+/* The kernel function the slot's LAST launch dispatched, as rocprofv3 prints it (e.g.
+ * "k_stats_mfma4<5, 2, 2, 3, true, false, double, double, 3>"; "" when unknown): bench.py checks it against
+ * the kernel name in the committed profile before it quotes that profile's duration. */
+const char* svihmm_last_kernel_name(svihmm_ctx* h, int32_t slot);
 /* Selects the kernel generation for A/B measurement (0 = default/best).
  * which 0 emission (1 VALU, 2 MFMA) | 1 statistics (1 VALU, 2 MFMA, 3 pipelined MFMA)
  * | 2 sweeps (1 wave-per-window, 2 log-domain MFMA, 3 scaled linear-domain MFMA)

@@ -103,6 +103,7 @@ SIGNATURES = {
     "svihmm_profile_reset": (C.c_int, [C.c_void_p]),
     "svihmm_profile_read": (C.c_int, [C.c_void_p, _c_double_p, _c_int64_p]),
     "svihmm_kernel_name": (C.c_char_p, [C.c_int32]),
+    "svihmm_last_kernel_name": (C.c_char_p, [C.c_void_p, C.c_int32]),
     "svihmm_set_variant": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "svihmm_selftest_mfma": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, _c_double_p]),
 }

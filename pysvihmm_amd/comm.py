@@ -46,7 +46,7 @@ class RcclComm(object):
         engine.allreduce_host(np.zeros(1))
 
 
-def file_uid_exchange(rank, tag=None, timeout=300.0, directory=None):
+def file_uid_exchange(rank, tag=None, timeout=None, directory=None):
     """Single-node rendezvous without torch: rank 0 publishes the 128-byte ncclUniqueId
     in a file named after the launcher's pid (all workers of one ``torch.distributed.run``
     share the parent pid) and MASTER_PORT; the other ranks poll for it.  Returns a
@@ -54,6 +54,8 @@ def file_uid_exchange(rank, tag=None, timeout=300.0, directory=None):
     import os
     import tempfile
     import time
+    if timeout is None:     # (bounded by default: SVIHMM_RENDEZVOUS_TIMEOUT seconds, 120 when unset)
+        timeout = float(os.environ.get("SVIHMM_RENDEZVOUS_TIMEOUT", "120"))
     if tag is None:
         tag = "%s_%s_%s" % (os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid(),
                             os.environ.get("MASTER_PORT", "0"))

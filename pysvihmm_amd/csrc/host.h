@@ -162,6 +162,7 @@ struct svihmm_ctx {
   std::vector<Pending> pending;
   std::vector<hipEvent_t> pool;
   double ms[SVIHMM_NKERN] = {0};
+  const char* last_kernel[SVIHMM_NKERN] = {nullptr};   // name of the kernel the slot's last launch dispatched (svihmm_last_kernel_name)
   int64_t cnt[SVIHMM_NKERN] = {0};
   // device-resident SVI loop (svihmm_svi_*): var_tran | prior_tran | var_init | vlb[K] | logdet[K] |
   // prior_logpart[K]; prior block [mu0 | sigma0 | kappa0 | nu0]; GTH scratch; elbo / event ring

@@ -1940,6 +1940,10 @@ int svihmm_profile_read(svihmm_ctx* h, double ms_out[SVIHMM_NKERN], int64_t coun
   for (int i = 0; i < SVIHMM_NKERN; ++i) { ms_out[i] = h->ms[i]; count_out[i] = h->cnt[i]; }
   return 0;
 }
+const char* svihmm_last_kernel_name(svihmm_ctx* h, int32_t slot) {
+  if (!h || slot < 0 || slot >= SVIHMM_NKERN || !h->last_kernel[slot]) return "";
+  return h->last_kernel[slot];
+}
 int svihmm_set_variant(svihmm_ctx* h, int32_t which, int32_t value) {
   if (!h || which < 0 || which >= 16) return fail("svihmm_set_variant: bad arguments");
 #ifndef SVIHMM_MEASURE

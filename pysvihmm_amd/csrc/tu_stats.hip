@@ -147,6 +147,7 @@ int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, int Lm, u
         const int TPG = (FT + NGf - 1) / NGf;
         const size_t ldsb = bw_lds(h);
         if (KpF != Kp) return fail("internal: wide fp32 statistics need states padded in groups of 64");
+        h->last_kernel[KS_STATS] = "k_stats_bf16x3w";
         hipFuncSetAttribute((const void*)k_stats_bf16x3w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
         hipLaunchKernelGGL(k_stats_bf16x3w, dim3((unsigned)nchunk, NGf, KpF / 64), dim3(512), ldsb, stream, (const double*)h->obs.p, mk,
                            starts_dev, n, Lm, D, K, KpF, Fp, F, (const int*)h->fab.p, (const float*)h->la.p + qo,
@@ -156,6 +157,7 @@ int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, int Lm, u
       else if (lin && h->cur_f32 && !big && stats_bf16_ok(h, n) && rpc % SB_ROWS == 0 && nchunk * rpc >= n) {
         const size_t xb = (((size_t)(D + 2) * SB_XRS * 4) + 15) & ~(size_t)15;
         const size_t ldsb = 2 * (xb + 6 * (size_t)64 * SB_QRS * 2) + 3 * SB_ROWS * sizeof(SbRow);
+        h->last_kernel[KS_STATS] = "k_stats_bf16x3";
         hipFuncSetAttribute((const void*)k_stats_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
         hipLaunchKernelGGL(k_stats_bf16x3, dim3((unsigned)nchunk), dim3(512), ldsb, stream, (const double*)h->obs.p, mk,
                            starts_dev, n, Lm, D, K, Fp, F, (const int*)h->fab.p, (const float*)h->la.p + qo,
@@ -169,6 +171,7 @@ int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, int Lm, u
         dim3 grid((unsigned)nchunk, (mt_limit + 4 * MTs - 1) / (4 * MTs), 1);
 #define ST3F(MTV, NTW, NS, XKV)                                                                   \
   do {                                                                                           \
+    h->last_kernel[KS_STATS] = "k_stats_mfma4<" #MTV ", " #NTW ", " #NS ", " #XKV ", true, false, float, float, 2>"; \
     if (ldsf > 64 * 1024)                                                                        \
       hipFuncSetAttribute((const void*)k_stats_mfma4<MTV, NTW, NS, XKV, true, false, float, float>, \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);                \
@@ -198,6 +201,7 @@ int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, int Lm, u
         if (tb) {
 #define ST3TL(XKV, LN)                                                                                         \
   do {                                                                                                         \
+    h->last_kernel[KS_STATS] = "k_stats_mfma4<5, 2, 2, " #XKV ", " #LN ", false, double, double, 3>";          \
     hipFuncSetAttribute((const void*)k_stats_mfma4<5, 2, 2, XKV, LN, false, double, double, 3>,                \
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);                                \
     hipLaunchKernelGGL((k_stats_mfma4<5, 2, 2, XKV, LN, false, double, double, 3>), grid, dim3(512), lds3,     \
@@ -211,6 +215,7 @@ int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, int Lm, u
         } else {
 #define ST3L(MTV, NTW, NS, XKV, LN)                                                               \
   do {                                                                                           \
+    h->last_kernel[KS_STATS] = "k_stats_mfma4<" #MTV ", " #NTW ", " #NS ", " #XKV ", " #LN ", false, double, double, 2>"; \
     if (lds > 64 * 1024)                                                                         \
       hipFuncSetAttribute((const void*)k_stats_mfma4<MTV, NTW, NS, XKV, LN>,                     \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \

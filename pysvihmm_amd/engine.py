@@ -595,6 +595,11 @@ class HipEngine(object):
         names = [self._lib.svihmm_kernel_name(i).decode() for i in range(L.NKERN)]
         return {n: (float(m), int(c)) for n, m, c in zip(names, ms, cnt) if c > 0}
 
+    def last_kernel(self, slot_name):
+        """Name of the kernel function the slot's last launch dispatched ("" when not recorded)."""
+        names = [self._lib.svihmm_kernel_name(i).decode() for i in range(L.NKERN)]
+        return self._lib.svihmm_last_kernel_name(self._h, names.index(slot_name)).decode()
+
     def set_variant(self, which, value):
         idx = {"emission": 0, "stats": 1, "fb": 2, "emission_mt": 3, "pipeline": 4, "emission_orbit": 5, "chain": 6}[which] if isinstance(which, str) else which
         L.check(self._lib.svihmm_set_variant(self._h, idx, int(value)), "set_variant")
