@@ -25,4 +25,13 @@ for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
     e.estep(st, LM, flags=L.TRANS_WRAP, read=False)
     out = e.read_packed()
 assert abs(out.A_raw.sum() / (len(st) * LM) - 1.0) < 1e-9
+# round 5: the same step in the fp32 mode (k_emission_bf16x3d<true>, k_scale_ll_f32, k_sweeps_lin2<..., float>,
+# k_stats_bf16x3w) -- its kernels carry other names, so one trace holds both
+e.set_precision("f32")
+for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
+    e.set_globals(pw["mod_init"], pw["ltran"])
+    e.set_emission_niw(pw["mu"], pw["sigma"], pw["kappa"], pw["nu"], check=False)
+    e.estep(st, LM, flags=L.TRANS_WRAP, read=False)
+    out = e.read_packed()
+assert e.precision()[1] and abs(out.A_raw.sum() / (len(st) * LM) - 1.0) < 1e-5
 e.close()

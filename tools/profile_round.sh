@@ -37,8 +37,8 @@ run sq5 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CY
 BENCH=$BENCH_ALL
 run sq --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS > $OUT/${TAG}_sq_counters.txt
 # the committed summaries bench.py reads (roofline.frac on the profiler's clock, roofline.traffic)
-cd $ROOT/tools && python kernel_stats_to_json.py $OUT/${TAG}_kernel_stats.txt > $OUT/kernel_stats.json
-python pmc_to_traffic.py $OUT/${TAG}_pmc_hbm.txt $OUT/${TAG}_pmc_hbm_f32.txt > $OUT/pmc_traffic.json
+cd $ROOT/tools && python kernel_stats_to_json.py $OUT/${TAG}_kernel_stats.txt | sed "s#$OUT/#profiles/#g" > $OUT/kernel_stats.json
+python pmc_to_traffic.py $OUT/${TAG}_pmc_hbm.txt $OUT/${TAG}_pmc_hbm_f32.txt | sed "s#$OUT/#profiles/#g" > $OUT/pmc_traffic.json
 cp $OUT/kernel_stats.json $OUT/pmc_traffic.json $ROOT/profiles/ 2>/dev/null
 cd $ROOT && python bench.py 2>/dev/null | tail -1 > $OUT/${TAG}_bench.json
 tail -c 600 $OUT/${TAG}_bench.json
