@@ -37,7 +37,7 @@ const char* svihmm_kernel_name(int32_t slot);
  * the kernel name in the committed profile before it quotes that profile's duration. */
 const char* svihmm_last_kernel_name(svihmm_ctx* h, int32_t slot);
 /* Selects the kernel generation for A/B measurement (0 = default/best).
- * which 0 emission (1 VALU, 2 MFMA) | 1 statistics (1 VALU, 2 MFMA, 3 pipelined MFMA)
+ * which 0 (unused since round 5: the VALU emission generation is gone) | 1 statistics (2 double-buffered MFMA, else the pipelined MFMA kernels)
  * | 2 sweeps (1 wave-per-window, 2 log-domain MFMA, 3 scaled linear-domain MFMA)
  * | 3 emission row tiles per wave | 4 two-stream E-step pipeline (1 off, 2 on; default off)
  * | 6 blocked scan for one long window (B = 1, Lm >= 2048, K <= 64; 1 = off)
@@ -53,8 +53,8 @@ const char* svihmm_last_kernel_name(svihmm_ctx* h, int32_t slot);
  * | 10 statistics GEMM tiling (1: five feature tiles per wave for every shape) and, in the fp32 mode, its
  *      pipe (2: the fp32-input MFMA kernel instead of the three-term bf16 one; 3: the bf16 kernel also
  *      below its batch-size floor of 32 768 rows)
- * | 7 = 4: the four-wave minibatch sweep k_wave_lin4 instead of the register-resident k_wave_linr (round 5);
- *      5: k_wave_linr with fp32 arithmetic in the fp32 mode
+ * | 7 = 3: the LDS-broadcast one-wave minibatch sweep k_wave_lin instead of the register-resident k_wave_linr (fp64)
+ *      / the four-wave k_wave_lin4 (fp32 mode)
  * Codes that make results INVALID exist only in a -DSVIHMM_MEASURE build of the library (make measure):
  * | 7 = 9: the scaled sweeps are skipped, the statistics read stale messages (tools/r4_overlap_probe.py);
  *   a product build rejects them with an error. */

@@ -35,56 +35,6 @@ __device__ __forceinline__ void bf16_split3(double v, uint32_t (&t)[3]) {
 }
 
 // ------------------------------------------------------------------------------------
-//  K1a: emission, VALU outer-product form (generic fallback).  lane = row.
-//       grid (ceil(n/128), Kp/16), block 128, LDS (D+1)*129*8 bytes.
-// ------------------------------------------------------------------------------------
-#define EM_R 128
-__global__ __launch_bounds__(EM_R) void k_emission_outer(
-    const double* __restrict__ obs, const uint8_t* __restrict__ mask,
-    const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K, int Kp,
-    const double* __restrict__ theta, uint32_t flags, double* __restrict__ ll) {
-  extern __shared__ double xs[];  // [(D+1)][EM_R+1], transposed
-  const int S = EM_R + 1;
-  const int tid = threadIdx.x;
-  const int64_t g0 = (int64_t)blockIdx.x * EM_R;
-  const int k0 = blockIdx.y * 16;
-  for (int e = tid; e < EM_R * D; e += EM_R) {
-    int r = e / D, i = e - r * D;
-    int64_t g = g0 + r;
-    double v = 0.0;
-    if (g < nrows) v = obs[obs_row(starts, Lm, g) * D + i];
-    xs[i * S + r] = v;
-  }
-  xs[D * S + tid] = 1.0;
-  __syncthreads();
-  const int64_t g = g0 + tid;
-  bool bad = false;
-  if (g < nrows && (flags & SVIHMM_MASK_AS_NAN) && mask)
-    bad = mask[obs_row(starts, Lm, g)] != 0;
-  double acc[16];
-#pragma unroll
-  for (int kk = 0; kk < 16; ++kk) acc[kk] = 0.0;
-  const double* th = theta + k0;
-  int f = 0;
-  for (int a = 0; a <= D; ++a) {
-    const double xa = xs[a * S + tid];
-    bad |= (xa != xa);
-    for (int b = a; b <= D; ++b) {
-      const double phi = xa * xs[b * S + tid];
-      const double* row = th + (size_t)f * Kp;
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) acc[kk] = fma(phi, row[kk], acc[kk]);
-      ++f;
-    }
-  }
-  if (g < nrows) {
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk)
-      if (k0 + kk < K) ll[g * K + k0 + kk] = bad ? 0.0 : nan_to_num(acc[kk]);
-  }
-}
-
-// ------------------------------------------------------------------------------------
 //  K1b: emission as an fp64 MFMA GEMM  ll[rows x K] = Phi[rows x Fp] * theta[Fp x Kp]
 //       with Phi generated on the fly from x rows staged in LDS.
 //       v_mfma_f64_16x16x4_f64: A lane l -> A[i=l&15][k=l>>4]; B lane l -> B[k=l>>4][j=l&15];

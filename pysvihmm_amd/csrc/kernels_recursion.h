@@ -1769,12 +1769,10 @@ __device__ __forceinline__ void wave_linr_body(
     __builtin_amdgcn_wave_barrier();
   };
   constexpr int PD = 12;
-  const ST* __restrict__ lp = ep + dstep;
   auto eclamped = [&](int s) { return ep[(ptrdiff_t)(s < Lm ? s : Lm - 1) * dstep + jc]; };
   CT eq[PD];
 #pragma unroll
   for (int u = 0; u < PD; ++u) eq[u] = eclamped(1 + u);
-  lp += (ptrdiff_t)PD * dstep;
   auto step = [&](int s, CT et) {
     CT p0 = 0, p1 = 0, p2 = 0, p3 = 0;
     int ef = wlr_expfield(pcur);                // (the exponent comes from the ENTERING vector: off the chain)
@@ -1824,22 +1822,13 @@ __device__ __forceinline__ void wave_linr_body(
     }
   };
   int s = 1;
-  for (; s + 2 * PD <= Lm; s += PD) {
-#pragma unroll
-    for (int u = 0; u < PD; ++u) {
-      const CT et = eq[u];
-#if !(WLR_KO & 8)
-      eq[u] = lp[jc];
-#endif
-      lp += dstep;
-      step(s + u, et);
-    }
-  }
   for (; s + PD <= Lm; s += PD) {
 #pragma unroll
     for (int u = 0; u < PD; ++u) {
       const CT et = eq[u];
-      eq[u] = eclamped(s + u + PD);
+#if !(WLR_KO & 8)
+      eq[u] = eclamped(s + u + PD);           // (uniform row arithmetic: scalar instructions)
+#endif
       step(s + u, et);
     }
   }

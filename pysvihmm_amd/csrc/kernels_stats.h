@@ -3,69 +3,6 @@
 #pragma once
 
 // ------------------------------------------------------------------------------------
-//  K4a: statistics, VALU outer-product form (generic fallback).  One wave per
-//       (row chunk, 16-feature chunk, 64-state chunk); lane = state.
-//       feature f < Fp : phi = x~_a x~_b (0 on masked rows);  f >= Fp : phi = q[prev][f-Fp]
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_stats_outer(
-    const double* __restrict__ obs, const uint8_t* __restrict__ mask,
-    const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K, int Kp,
-    int Fp, int F, const int* __restrict__ fab, const double* __restrict__ q,
-    int64_t rows_per_chunk, uint32_t flags, int Lq, int off, double* __restrict__ part) {
-  // rows g enumerate (window b, inner step t<Lm); q row = b*Lq+off+t, obs row = starts[b]+off+t
-  const int lane = threadIdx.x;
-  const int f0 = blockIdx.y * 16;
-  const int k = blockIdx.z * 64 + lane;
-  const int Ftot = Fp + Kp;
-  const int64_t g0 = (int64_t)blockIdx.x * rows_per_chunk;
-  const int64_t g1 = imin64(nrows, g0 + rows_per_chunk);
-  double acc[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.0;
-  const bool is_trans = f0 >= Fp;
-  for (int64_t g = g0; g < g1; ++g) {
-    const int64_t bwin = g / Lm;
-    const int64_t t = g - bwin * Lm;
-    const int64_t qrow = bwin * Lq + off + t;
-    const double qk = (k < K) ? q[qrow * K + k] : 0.0;
-    if (!is_trans) {
-      const int64_t orow = starts[bwin] + off + t;
-      if (mask && mask[orow]) continue;
-      const double* x = obs + orow * D;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int f = f0 + i;
-        double phi = 0.0;
-        if (f < F) {
-          const int ab = fab[f];
-          const int a = ab & 0xffff, b = ab >> 16;
-          const double xa = (a < D) ? x[a] : 1.0;
-          const double xb = (b < D) ? x[b] : 1.0;
-          phi = xa * xb;
-        }
-        acc[i] = fma(phi, qk, acc[i]);
-      }
-    } else {
-      int64_t gp;
-      if (t > 0) gp = qrow - 1;
-      else if (flags & SVIHMM_TRANS_WRAP) gp = qrow + Lm - 1;
-      else continue;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int ii = f0 - Fp + i;
-        const double phi = (ii < K) ? q[gp * K + ii] : 0.0;
-        acc[i] = fma(phi, qk, acc[i]);
-      }
-    }
-  }
-  if (k < Kp) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-      part[((size_t)blockIdx.x * Ftot + f0 + i) * Kp + k] = acc[i];
-  }
-}
-
-// ------------------------------------------------------------------------------------
 //  K4b: statistics as an fp64 MFMA GEMM  out[Ftot x Kp] = Phi^T[Ftot x rows] * q[rows x Kp]
 //       Per workgroup: 4 waves, each MT m-tiles (16 features) x NT n-tiles (16 states);
 //       rows of the chunk staged through LDS in blocks of ST_RB.

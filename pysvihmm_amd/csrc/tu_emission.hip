@@ -249,10 +249,8 @@ int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled,
     HIPCK(hipGetLastError());
     return 0;
   }
-  int var = h->variant[0];
-  if (var == 0 || scaled) var = 2;
+  int var = 2;      // (the VALU outer-product generation of round 1 is gone: variant[0] is ignored)
   // scaled output, D % 8 == 0: the address-free orbit schedule (variant[5] = 1 keeps K1b)
-  if (h->emis_diag) var = 2;    // table-driven GEMM only (the VALU fallback assumes the triangular order)
   if (!h->emis_diag && scaled && K <= 64 && D >= 8 && D <= 40 && D % 8 == 0 && h->variant[5] != 1 && min_lds == 0) {
     const int NT = Kp / 16, LEN = D + D / 2 + 1;
     const int nks = (D / 4) * (D / 2 + 1) + (D / 2 + 1 + 3) / 4;
@@ -288,8 +286,8 @@ int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled,
     if (lds < min_lds) lds = min_lds;   // occupancy cap: leave LDS for co-resident sweep workgroups
     if (lds > 150 * 1024 && scaled) return fail("emission: D too large for the scaled sweeps");
     if (lds > 150 * 1024 && h->emis_diag) return fail("emission: D too large for the diagonal family's kernel");
-    if (lds > 150 * 1024) var = 1;
-    else {
+    if (lds > 150 * 1024) return fail("emission: D too large for the LDS-staged GEMM kernel");
+    {
       const int ntile = Kp / 16;
       int NT = (ntile % 4 == 0) ? 4 : (ntile % 2 == 0) ? 2 : 1;
       // wide models: eight state tiles per wave -- every generated A operand feeds 8 instead of 4
@@ -319,16 +317,6 @@ int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled,
       }
 #undef EMM_LAUNCH
     }
-  }
-  if (var == 1) {
-    const size_t lds = (size_t)(D + 1) * (EM_R + 1) * 8;
-    if (lds > 160 * 1024) return fail("emission: D too large for the LDS-staged kernels");
-    if (lds > 64 * 1024)
-      hipFuncSetAttribute((const void*)k_emission_outer, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    dim3 grid((unsigned)((n + EM_R - 1) / EM_R), Kp / 16);
-    hipLaunchKernelGGL(k_emission_outer, grid, dim3(EM_R), lds, stream,
-                       (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K,
-                       Kp, (const double*)h->theta.p, flags, out);
   }
   HIPCK(hipGetLastError());
   return 0;

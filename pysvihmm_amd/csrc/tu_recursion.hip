@@ -229,14 +229,11 @@ int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_t strea
 #define WL4F(KM) hipLaunchKernelGGL((k_wave_lin4<KM, float>), gw, dim3(256), 0, stream, Ef, kx, (const double*)h->Aexp.p, \
                                     (const double*)h->AexpT.p, mi, l0, l0s, Lm, K, af, bf, hx, gx, \
                                     llb, lz, zf)
-      // (round 5: the register-resident one-wave kernel k_wave_linr computes in the storage type; with
-      //  fp32 arithmetic over 257 steps the statistics drift to 1.2e-4 of the fp64 oracle -- inside the
-      //  mode's 1e-3 but above this suite's 1e-4 canary -- for 8 % of the launch, so the fp32 mode keeps
-      //  the four-wave kernel, which computes in fp64 on float storage; variant[7] = 5 selects it)
-      if (K > 16 && nb <= LIN_WAVER_MAX && Lm <= (1 << 20) && h->variant[7] == 5)
-        hipLaunchKernelGGL((k_wave_linr<float>), gw, dim3(64), 0, stream, Ef, kx, (const double*)h->Aexp.p,
-                           (const double*)h->AexpT.p, mi, l0, l0s, Lm, K, af, bf, hx, gx, llb, lz, zf);
-      else if (K > 16 && nb <= LIN_WAVE4_MAX && h->variant[7] != 3) { WL4F(64); }
+      // (round 5: the register-resident one-wave kernel k_wave_linr of the fp64 path was also built with fp32
+      //  arithmetic: 278 against 303 ns per step, but over 257 steps the statistics drift to 1.2e-4 of the fp64
+      //  oracle -- inside the mode's 1e-3, above this suite's 1e-4 canary; the fp32 mode keeps the four-wave
+      //  kernel, which computes in fp64 on float storage)
+      if (K > 16 && nb <= LIN_WAVE4_MAX && h->variant[7] != 3) { WL4F(64); }
       else if (K <= 16) WLF(16, false); else if (K <= 32) WLF(32, false);
       else if (K == 64) WLF(64, true); else WLF(64, false);
 #undef WLF
@@ -265,17 +262,12 @@ int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_t strea
                                       gx, llb, lz, zf)
     // up to a few hundred windows the chip is far from full with one wave per (window,
     // direction): split each window's source states over four waves (variant[7] = 3: off)
-    if (K > 16 && nb <= LIN_WAVER_MAX && Lm <= (1 << 20) && h->variant[7] != 3 && h->variant[7] != 4) {
-      // (round 5) one wave per (window, direction), mat-vec in registers (variant[7] = 4: the four-wave kernel)
+    // minibatch-sized batches, K > 16 (round 5): one wave per (window, direction) with the mat-vec in registers
+    // (k_wave_linr; it replaces round 3's four-wave k_wave_lin4<64, double>: 316 against 319 ns per step with a
+    // quarter of the waves and no LDS exchange; variant[7] = 3: the LDS-broadcast one-wave kernel below)
+    if (K > 16 && nb <= LIN_WAVER_MAX && Lm <= (1 << 20) && h->variant[7] != 3) {
       hipLaunchKernelGGL((k_wave_linr<double>), gw, dim3(64), 0, stream, Eh, kx, (const double*)h->Aexp.p,
                          (const double*)h->AexpT.p, mi, l0, l0s, Lm, K, ah, bh, hx, gx, llb, lz, zf);
-    }
-    else if (K > 16 && nb <= LIN_WAVE4_MAX && h->variant[7] != 3) {
-#define WL4(KM) hipLaunchKernelGGL((k_wave_lin4<KM>), gw, dim3(256), 0, stream, Eh, kx, (const double*)h->Aexp.p, \
-                                   (const double*)h->AexpT.p, mi, l0, l0s, Lm, K, ah, bh, hx,  \
-                                   gx, llb, lz, zf)
-      WL4(64);
-#undef WL4
     }
     else if (K <= 16) WL(16, false); else if (K <= 32) WL(32, false);
     else if (K == 64) WL(64, true); else WL(64, false);

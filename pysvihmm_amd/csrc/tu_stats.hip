@@ -97,7 +97,7 @@ int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, int Lm, u
   const uint8_t* mk = h->have_mask ? (const uint8_t*)h->mask.p : nullptr;
   const int64_t* starts_dev = (const int64_t*)h->starts.p + b0;
   int var = h->variant[1];
-  if (var == 0) var = 3;
+  if (var != 2) var = 3;      // (2: the double-buffered generation; the VALU generation of round 1 is gone)
   if (var == 3) {   // feasibility of the pipelined kernel (same test as below)
     const int KpW = Kp > 64 ? 64 : Kp;
     const int TPR = 8 * ((KpW / 16 == 4) ? 2 : 1);
@@ -278,8 +278,8 @@ int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, int Lm, u
       const int MT = 3;
       const int DS = (D + 2) | 1;
       const size_t lds = ((size_t)ST_RB * DS + (size_t)ST_RB * (16 * NT + 1) + (size_t)ST_RB * (Kp + 1)) * 8;
-      if (lds > 150 * 1024) var = 1;
-      else {
+      if (lds > 150 * 1024) return fail("statistics: D too large for the LDS-staged GEMM kernels");
+      {
         const int mtiles = Ftot / 16;
         dim3 grid((unsigned)nchunk, (mtiles + 4 * MT - 1) / (4 * MT), ntile / NT);
 #define ST_LAUNCH(NTV)                                                                        \
@@ -295,12 +295,6 @@ int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, int Lm, u
         if (NT == 4) ST_LAUNCH(4); else if (NT == 2) ST_LAUNCH(2); else ST_LAUNCH(1);
 #undef ST_LAUNCH
       }
-    }
-    if (var == 1) {
-      dim3 grid((unsigned)nchunk, Ftot / 16, (Kp + 63) / 64);
-      hipLaunchKernelGGL(k_stats_outer, grid, dim3(64), 0, stream, (const double*)h->obs.p, mk,
-                         starts_dev, n, Lm, D, K, Kp, Fp, F,
-                         (const int*)h->fab.p, qv, rpc, flags, Lq, off, partv);
     }
     HIPCK(hipGetLastError());
   }

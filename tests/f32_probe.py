@@ -1,6 +1,6 @@
 """Round 5: fp32-mode E-step against the fp64 C oracle at shapes the mode did not reach before
 (D > 32, K > 64): max relative deviation of the packed statistics (tolerance of the mode: 1e-3) and
-the kernels' HIP-event times.  usage: r5_f32_probe.py K D B Lm [variant=value ...]"""
+the kernels' HIP-event times.  usage: python tests/f32_probe.py K D B Lm [variant=value ...]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

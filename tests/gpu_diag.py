@@ -51,7 +51,7 @@ def main():
             eng.set_globals(pb["mod_init"], pb["ltran"])
             eng.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
             ref_ll = np.stack([ref_c.lliks_niw(pb["obs"][s:s + Lm], pb["mu"], pb["sigma"], pb["kappa"], pb["nu"]) for s in starts])
-            for ev in (1, 2):
+            for ev in (2,):
                 eng.set_variant("emission", ev)
                 ll = eng.loglik(starts, Lm)
                 print("  emission var %d: max abs err %.3g (|ll| max %.3g)" % (ev, np.abs(ll - ref_ll).max(), np.abs(ref_ll).max()))
@@ -64,7 +64,7 @@ def main():
             print("  var_x err %.3g  local_lb rel %.3g" % (np.abs(r["var_x"] - q).max(), relerr(r["local_lb"], lbs)))
             ref = ref_c.estep_minibatch(pb["obs"], pb["mask"], starts, Lm, pb["mod_init"], pb["ltran"], pb["mu"], pb["sigma"], pb["kappa"], pb["nu"], flags=2)
             A, xbar, neff, S, lbt = unpack(ref, K, D)
-            for sv in (1, 2, 3):
+            for sv in (2, 3):
                 eng.set_variant("stats", sv)
                 st = eng.estep(starts, Lm, flags=L.TRANS_WRAP)
                 print("  stats var %d: A %.3g xbar %.3g neff %.3g S %.3g lb %.3g (abs, scale %d)" % (

@@ -82,7 +82,7 @@ def test_chain_batch_statistics_vs_oracle(eng, K, D, T):
                                        (64, 9000, 3, 1.5), (16, 6000, 8, 14.0), (33, 4000, 16, 9.0),
                                        # wide models (round 3): k_ffbs_paths_wide, k_lalpha_fix_wide
                                        (80, 3000, 3, 1.5), (130, 2600, 3, 3.0), (256, 2500, 4, 12.0),
-                                       (200, 70001, 3, 4.0)])
+                                       (200, 30001, 3, 4.0)])
 def test_ffbs_long_chain_blocked(K, T, D, sep):
     """FFBS of a long chain (hmm_fast.pyx:43-124): forward filter through the blocked scan
     (lalpha from the scaled messages) and backward sampling by composition of the per-row draw

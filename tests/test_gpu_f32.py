@@ -325,3 +325,60 @@ def test_f32_wide_models_and_d_above_32_vs_fp64_oracle(K, D, B, Lm):
             _close(a, b_, s_, "inner " + w)
     finally:
         e.close()
+
+
+def test_f32_s64_minibatch_vs_fp64_oracle():
+    """The literal configs[2] minibatch (64 windows of 257 rows, K = 64, D = 32) in the fp32 mode against the
+    fp64 C oracle: below the bf16 kernels' batch-size floor the mode runs the fp64 feature GEMM in front of
+    float storage, the four-wave sweep (fp64 arithmetic on float messages) and the fp32-input statistics GEMM."""
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    from oracle import ref_c
+    K, D, B, Lm, T = 64, 32, 64, 257, 40000
+    pb = make_problem(K, D, T, seed=64, miss=0.0, sep=4.0)
+    starts = (np.arange(B, dtype=np.int64) * (T // B)) % (T - Lm)
+    e = HipEngine(0, dtype="f32")
+    try:
+        e.set_obs(pb["obs"], None)
+        e.set_globals(pb["mod_init"], pb["ltran"])
+        e.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+        st = e.estep(starts, Lm, flags=L.TRANS_WRAP)
+        assert e.precision() == ("f32", True)
+        ref = ref_c.estep_minibatch(pb["obs"], None, starts, Lm, pb["mod_init"], pb["ltran"], pb["mu"], pb["sigma"],
+                                    pb["kappa"], pb["nu"], flags=2, threads=effective_cores())
+        A, xbar, neff, S, lb = unpack(ref, K, D)
+        sc = B * Lm
+        xs = np.abs(pb["obs"]).max()
+        worst = max(_close(st.A_raw, A, sc, "A"), _close(st.neff, neff, sc, "neff"),
+                    _close(st.xbar, xbar, sc * xs, "xbar"), _close(st.S, S, sc * xs ** 2, "S"))
+        assert worst < 1e-4, worst
+        np.testing.assert_allclose(st.lb[0], lb, rtol=1e-6)
+    finally:
+        e.close()
+
+
+def test_f32_device_loop_enters_the_fp32_format_and_tracks_the_fp64_loop():
+    """Round 5: a loop whose initial var_tran (the class's 1/K) lies below the mode's range for E[log A] used to
+    run fp64 to its end; the host-side lower bound of var_tran lets it enter the fp32 format after its first
+    steps.  Final state against the fp64 loop at the mode's tolerance."""
+    from pysvihmm_amd import hmmsgd_metaobs
+    from pysvihmm_amd.distributions import Gaussian
+    K, D, T = 8, 4, 6000
+    pb = make_problem(K, D, T, seed=5, miss=0.0, sep=5.0)
+    obs = pb["obs"]
+    np.random.seed(0)
+    prior = np.array([Gaussian(mu_0=obs.mean(0), sigma_0=0.75 * np.cov(obs.T), kappa_0=0.01, nu_0=D + 2) for _ in range(K)])
+    res = {}
+    for dt in ("f64", "f32"):
+        np.random.seed(1)
+        m = hmmsgd_metaobs.VBHMM(obs.copy(), np.ones(K), np.ones((K, K)), prior, tau=1.0, kappa=0.7, metaobs_half=32,
+                                 mb_sz=16, maxit=12, seed=2, dtype=dt)
+        assert m._svi_device_ok()
+        m.infer()
+        res[dt] = (m.var_tran.copy(), np.array([g.mu_mf for g in m.var_emit]), m.elbo_vec.copy(), m.engine.precision())
+    assert res["f64"][3] == ("f64", False)
+    assert res["f32"][3] == ("f32", True)
+    a, b = res["f32"], res["f64"]
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-3, atol=1e-3 * np.abs(b[0]).max())
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-3, atol=1e-3 * np.abs(b[1]).max())
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-3)

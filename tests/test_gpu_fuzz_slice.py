@@ -31,7 +31,7 @@ def test_statistics_cases(eng):
     from oracle import ref_c
     eng.set_precision("f64")
     rng = np.random.default_rng(31)
-    for i in range(12):
+    for i in range(8):
         fuzz_gpu.run_case(eng, L, ref_c, fuzz_gpu.draw_case(rng), 3100000 + i)
 
 
@@ -47,7 +47,7 @@ def test_api_and_class_cases(eng):
 
 # ---- the campaign itself, time-boxed: every leg of tests/fuzz_gpu.py through its
 # own driver (main: case drawing, failure accounting, engine re-creation after a hard error), fixed
-# seed, 12 s per leg = 60 s in all.  A failure prints the leg's seed for `fuzz_gpu.py --replay`.
+# seed, 8 s per leg = 40 s in all.  A failure prints the leg's seed for `fuzz_gpu.py --replay`.
 LEGS = {"statistics": ["--cases", "100000", "--chains", "0"],
         "chains": ["--cases", "0", "--chains", "1000"],
         "api": ["--cases", "0", "--chains", "0", "--api", "100000"],
@@ -58,7 +58,7 @@ LEGS = {"statistics": ["--cases", "100000", "--chains", "0"],
 @pytest.mark.parametrize("leg", sorted(LEGS))
 def test_campaign_leg_time_boxed(leg, capsys):
     from tests import fuzz_gpu
-    rc = fuzz_gpu.main(["--seed", "404", "--seconds", "12"] + LEGS[leg])
+    rc = fuzz_gpu.main(["--seed", "404", "--seconds", "8"] + LEGS[leg])
     out = capsys.readouterr().out
     assert rc == 0, out[-3000:]
     import re

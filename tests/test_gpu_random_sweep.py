@@ -117,7 +117,7 @@ def test_svi_loop_sweep(case):
     np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-5 if f32 else 1e-9)
 
 
-@pytest.mark.parametrize("case", [(300, 4, 33, 20, 3.0, 0.1, False, False), (512, 8, 17, 200, 20.0, 0.0, False, True),
+@pytest.mark.parametrize("case", [(300, 4, 33, 20, 3.0, 0.1, False, False), (512, 8, 17, 96, 20.0, 0.0, False, True),
                                   (1024, 2, 9, 3, 3.0, 0.1, False, False), (300, 3, 257, 4, 3.0, 0.0, True, False)],
                          ids=lambda c: "K%d_D%d_Lm%d_B%d" % c[:4])
 def test_models_beyond_256_states(case):

@@ -110,7 +110,12 @@ def test_bench_refuses_more_gpus_than_visible():
     env.pop("WORLD_SIZE", None)
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n + 1)], cwd=REPO,
                        env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode != 0 and "{" not in r.stdout
+    # (round 5: a refused or failed multi-rank run still leaves ONE JSON line, the error record)
+    import json
+    lines = [l for l in r.stdout.splitlines() if l.lstrip().startswith("{")]
+    assert r.returncode != 0 and len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["value"] is None and "HIP device" in rec["error"] and rec["n_gpus"] == n + 1
 
 
 def test_allreduce_in_caller_coordinates_rehearsal(tmp_path):

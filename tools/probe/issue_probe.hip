@@ -129,6 +129,43 @@ __global__ __launch_bounds__(64) void t_swap(float* o) {
   o[128 + threadIdx.x] = (float)(x + y);
 }
 
+// grid-wide barrier across one workgroup per CU (what a single cooperative kernel per SVI iteration would
+// pay between its phases): sense-reversing counter in HBM/L2, agent-scope atomics, thread 0 of every
+// workgroup arrives and spins, the rest wait at s_barrier
+__global__ __launch_bounds__(256) void t_grid_barrier(unsigned* ctr, int nwg, int iters, double* o) {
+  unsigned target = 0;
+  double v = o[threadIdx.x];
+  for (int i = 0; i < iters; ++i) {
+    target += (unsigned)nwg;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+    v += 1.0;
+  }
+  o[256 + threadIdx.x] = v;
+}
+static double run_grid_barrier(int nwg, int nthreads) {
+  unsigned* ctr; double* d;
+  CK(hipMalloc(&ctr, 64)); CK(hipMalloc(&d, 1 << 16));
+  const int iters = 2000;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  double best = 1e30;
+  for (int rep = 0; rep < 3; ++rep) {
+    CK(hipMemset(ctr, 0, 64));
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(t_grid_barrier, dim3(nwg), dim3(nthreads), 0, 0, ctr, nwg, iters, d);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+    best = ms < best ? ms : best;
+  }
+  return 1e6 * best / iters;
+}
+
 template <typename F, typename T>
 static double run(F kern, T* buf, int nthreads, int ninstr) {
   hipEvent_t e0, e1;
@@ -161,5 +198,7 @@ int main() {
   printf("v_permlane32_swap     %.3f\n", run(t_swap, f, 64, 64));
   printf("LDS write + barrier + read, 1 wave   %.1f ns per round trip\n", run(t_lds_rt<1>, d, 64, 1));
   printf("LDS write + barrier + read, 4 waves  %.1f ns per round trip\n", run(t_lds_rt<4>, d, 256, 1));
+  printf("grid barrier (counter in L2, one 256-thread workgroup per CU):  64 workgroups %.0f ns, 128: %.0f ns, 256: %.0f ns\n",
+         run_grid_barrier(64, 256), run_grid_barrier(128, 256), run_grid_barrier(256, 256));
   return 0;
 }

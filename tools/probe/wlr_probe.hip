@@ -59,7 +59,7 @@ int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 64, Lm = argc > 2 ? atoi(argv[2]) : 257;
   for (int which = 0; which < 2; ++which) {
     if (run<double>(B, Lm, which, 200)) return 1;
-    if (run<float>(B, Lm, which, 200)) return 1;
+    if (run<float>(B, Lm, which, 200)) return 1;        // (k_wave_linr<float>: fp32 arithmetic, not used by the product)
   }
   return 0;
 }
