@@ -122,6 +122,20 @@ def run_case(e, L, ref_c, case, seed):
     np.testing.assert_allclose(g[2], r[2], rtol=2e-3, atol=2e-4 * sc, err_msg="f32 neff")
     np.testing.assert_allclose(g[1], r[1], rtol=2e-3, atol=2e-4 * sc * xs, err_msg="f32 xbar")
     np.testing.assert_allclose(g[4], r[4], rtol=1e-4, atol=1e-2, err_msg="f32 lb")
+    # the same with the bf16 kernels' batch-size floors lifted (round 5): the centred emission kernels
+    # (k_emission_bf16x3 / k_emission_bf16x3d), the bf16 statistics kernels and -- from 192 windows -- the whole
+    # wide-model path (k_scale_ll_f32, k_sweeps_lin2<float>, k_stats_bf16x3w) on this case's ragged shape
+    e.set_precision("f32"); e.set_variant(10, 3); e.set_variant(5, 4)
+    try:
+        st = e.estep(starts, Lm, flags=L.TRANS_WRAP)
+    finally:
+        e.set_variant(10, 0); e.set_variant(5, 0); e.set_precision("f64")
+    assert np.all(np.isfinite(st.buf)), "f32 (bf16 kernels): non-finite statistics"
+    g = unpack(st.buf, K, D)
+    np.testing.assert_allclose(g[0], r[0], rtol=2e-3, atol=2e-4 * sc, err_msg="f32/bf16 A_raw")
+    np.testing.assert_allclose(g[2], r[2], rtol=2e-3, atol=2e-4 * sc, err_msg="f32/bf16 neff")
+    np.testing.assert_allclose(g[1], r[1], rtol=2e-3, atol=2e-4 * sc * xs, err_msg="f32/bf16 xbar")
+    np.testing.assert_allclose(g[4], r[4], rtol=1e-4, atol=1e-2, err_msg="f32/bf16 lb")
     # inner segment (buffered meta-observations)
     if Lm >= 3:
         off = int(rng.integers(0, Lm // 2))

@@ -177,8 +177,9 @@ def test_f32_bf16x3_emission_large_batch(K, D, B, Lm, off, sep):
     e.close(); e3.close()
 
 
+@pytest.mark.parametrize("K,D", [(40, 20), (48, 48), (64, 40), (130, 24), (256, 64)])
 @pytest.mark.parametrize("flags_name", ["TRANS_WRAP", "MASK_AS_NAN"])
-def test_f32_bf16x3_emission_nan_rows_and_outliers(flags_name):
+def test_f32_bf16x3_emission_nan_rows_and_outliers(flags_name, K, D):
     """Rows with NaN entries (log-likelihood 0 for every state, hmmbase.py:220), the missing-data flag and
     a row 1e6 standard deviations away from every state, in a batch large enough for k_emission_bf16x3:
     the fp32 mode's statistics stay within its tolerance of the fp64 oracle and nothing non-finite
@@ -186,7 +187,9 @@ def test_f32_bf16x3_emission_nan_rows_and_outliers(flags_name):
     from pysvihmm_amd.engine import HipEngine
     from pysvihmm_amd import _lib as L
     from oracle import ref_c
-    K, D, B, Lm = 40, 20, 520, 64
+    # (40, 20): k_emission_bf16x3; (48, 48), (64, 40): k_emission_bf16x3d (round 5; K = 64: k_stats_bf16x3w);
+    # (130, 24), (256, 64): the wide path (k_emission_bf16x3d<WIDE>, k_scale_ll_f32, k_sweeps_lin2<float>, k_stats_bf16x3w)
+    B, Lm = 520, 64
     T = 6000
     pb = make_problem(K, D, T, seed=11, miss=0.05, sep=2.0)
     obs = pb["obs"].copy()
