@@ -1055,7 +1055,10 @@ __global__ __launch_bounds__(64 * NW) void k_sweeps_lin(
 // T = double: the fp64 kernel.  T = float (fp32 mode, round 5): Eh / ah / bh stored as float, the
 // transition matrix read from its float copy, v_mfma_f32_16x16x4_f32 (C register r of lane group lg =
 // window row 4 lg + r instead of lg + 4 r: LV<T>::crow); exponents and the local bound's books stay double.
-template <int NW, bool FULL, int WT = 1, typename T = double>
+// BREG (fp32 only): the wave's share of the transition matrix -- K rows x its 32 columns = 128 floats per lane --
+// stays in registers for the whole sweep instead of being streamed from L2 every step (in fp64 that share is the
+// whole register file, which is why the kernel streams; as floats it fits beside the accumulators).
+template <int NW, bool FULL, int WT = 1, typename T = double, bool BREG = false>
 __global__ __launch_bounds__(64 * NW) void k_sweeps_lin2(
     const T* __restrict__ Eh, const double* __restrict__ kexp,
     const T* __restrict__ Aexp, const T* __restrict__ AexpT,
@@ -1122,6 +1125,19 @@ __global__ __launch_bounds__(64 * NW) void k_sweeps_lin2(
       (xb + rowof(0))[oRw[wt]] = h[wt];
     }
   }
+  // BREG: rows 2 lg + {0, 1, 8, 9} + 16 c of the wave's two column tiles (rows beyond K: zero)
+  T breg0[BREG ? KS / 4 : 1][4], breg1[BREG ? KS / 4 : 1][4];
+  if (BREG) {
+#pragma unroll
+    for (int c = 0; c < KS / 4; ++c) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int row = 2 * lg + 16 * c + (u & 1) + 8 * (u >> 1);
+        breg0[c][u] = (v0 && row < K) ? Bm[(size_t)row * K + jc0] : (T)0;
+        breg1[c][u] = (v1 && row < K) ? Bm[(size_t)row * K + jc1] : (T)0;
+      }
+    }
+  }
   __syncthreads();
   for (int s = 1; s < Lm; ++s) {
     const int cur = (s - 1) & 1, nxt = s & 1;
@@ -1143,6 +1159,29 @@ __global__ __launch_bounds__(64 * NW) void k_sweeps_lin2(
     const T* __restrict__ pb0 = Bm + lo0;
     const T* __restrict__ pb1 = Bm + lo1;
     const size_t K1 = (size_t)K, K8 = (size_t)8 * K, K9 = (size_t)9 * K, K16 = (size_t)16 * K;
+    auto ktrip = [&](T b00, T b01, T b02, T b03, T b10, T b11, T b12, T b13) {
+#pragma unroll
+      for (int wt = 0; wt < WT; ++wt) {
+        const T2 x = *reinterpret_cast<const T2*>(pr[wt]);
+        const T2 y = *reinterpret_cast<const T2*>(pr[wt] + 8);
+        pr[wt] += 16;
+        p0[wt] = LV<T>::mma(x.x, b00, p0[wt]);
+        q0[wt] = LV<T>::mma(x.x, b10, q0[wt]);
+        p1[wt] = LV<T>::mma(x.y, b01, p1[wt]);
+        q1[wt] = LV<T>::mma(x.y, b11, q1[wt]);
+        p0[wt] = LV<T>::mma(y.x, b02, p0[wt]);
+        q0[wt] = LV<T>::mma(y.x, b12, q0[wt]);
+        p1[wt] = LV<T>::mma(y.y, b03, p1[wt]);
+        q1[wt] = LV<T>::mma(y.y, b13, q1[wt]);
+        sa[wt] += x.x + y.x;
+        sb[wt] += x.y + y.y;
+      }
+    };
+    if (BREG) {
+#pragma unroll
+      for (int c = 0; c < KS / 4; ++c)
+        ktrip(breg0[c][0], breg0[c][1], breg0[c][2], breg0[c][3], breg1[c][0], breg1[c][1], breg1[c][2], breg1[c][3]);
+    } else
 #pragma unroll 4
     for (int c = 0; c < KS / 4; ++c) {        // 4 k-steps (16 transition rows) per trip
       const T b00 = pb0[0], b01 = pb0[K1], b02 = pb0[K8], b03 = pb0[K9];

@@ -206,13 +206,15 @@ int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_t strea
       HIPCK(hipMemsetAsync((char*)h->AexpTF.p + kk * 4, 0, (nrow_t * K - kk) * 4, stream));
       hipLaunchKernelGGL(k_f64_to_f32, dim3(64), dim3(256), 0, stream, (const double*)h->Aexp.p, (float*)h->AexpF.p, kk);
       hipLaunchKernelGGL(k_f64_to_f32, dim3(64), dim3(256), 0, stream, (const double*)h->AexpT.p, (float*)h->AexpTF.p, kk);
-      const bool w32 = 2 * ((nb + 15) / 16) > 256 && h->variant[13] != 1;
+      // 16 windows per workgroup: with two window tiles per wave the 128 resident transition values + the
+      // second tile's accumulators spill (4.0 ms on configs[4]; one tile: 3.17; the streamed kernel 3.70)
+      const bool w32 = false;
 #define SWP2F(F, WT)                                                                                          \
   do {                                                                                                        \
     const size_t lds = (size_t)(WT) * sizeof(LinShared<16>);                                                  \
     dim3 g2((unsigned)((nb + 16 * (WT) - 1) / (16 * (WT))), 2);                                               \
-    hipFuncSetAttribute((const void*)k_sweeps_lin2<8, F, WT, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL((k_sweeps_lin2<8, F, WT, float>), g2, dim3(512), lds, stream, Ef, kx,                  \
+    hipFuncSetAttribute((const void*)k_sweeps_lin2<8, F, WT, float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((k_sweeps_lin2<8, F, WT, float, true>), g2, dim3(512), lds, stream, Ef, kx,            \
                        (const float*)h->AexpF.p, (const float*)h->AexpTF.p, a0v, a0e, nb, Lm, K, af, bf, hx, gx, llb, lz, zf); \
   } while (0)
       if (w32) { if (K == 256) SWP2F(true, 2); else SWP2F(false, 2); }
