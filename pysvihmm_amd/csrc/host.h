@@ -122,6 +122,8 @@ struct svihmm_ctx {
   // events (an event record between two kernels of the chain costs ~7 us of dispatch)
   struct StartSlot { void* p = nullptr; size_t cap = 0; int used_it = -1; };
   StartSlot svi_starts[8];
+  const int64_t* starts_pending = nullptr;   // device-visible pinned slot whose pull into h->starts is still owed
+  int starts_pending_n = 0;
   int svi_upload_it = -1;
   int* pin_status = nullptr;                 // pinned: NIW factorisation status (lazy check)
   double* mirror = nullptr; size_t mirror_cap = 0;   // pinned + mapped copy of `packed`
@@ -277,6 +279,7 @@ StatsPlan stats_plan(const svihmm_ctx* h, int64_t n, int forced = 0);
 int upload_feature_table(svihmm_ctx* h, int D, int K, bool diag = false);
 bool use_chain(const svihmm_ctx* h, int B, int Lm);
 int wait_globals(svihmm_ctx* h);
+int ensure_starts_pulled(svihmm_ctx* h);
 int cat_uncentre(svihmm_ctx* h);
 int launch_fb_chain(svihmm_ctx* h, int Lm, bool total);
 int launch_niw_vlb(svihmm_ctx* h, int K, int D, const double* dmu, const double* dsg, const double* dka,

@@ -303,8 +303,14 @@ __global__ __launch_bounds__(256) void k_emission_orbit(
     const double* __restrict__ obs, const uint8_t* __restrict__ mask,
     const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K,
     const double* __restrict__ orb, uint32_t flags, double* __restrict__ ll,
-    double* __restrict__ kexp, double* __restrict__ ll0) {
+    double* __restrict__ kexp, double* __restrict__ ll0,
+    int64_t* __restrict__ starts_copy = nullptr, int nstarts = 0) {
   constexpr int ROWS = 64 * MT, KP = 16 * NT;
+  // SVI loop (round 5): `starts` is the host's pinned, device-visible slot -- the window starts are read over
+  // PCIe here once (a separate k_pull launch in front of this kernel cost 6 us + a 7 us dispatch gap on the
+  // iteration's critical path); workgroup 0 leaves the device copy the statistics kernel reads
+  if (starts_copy && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < nstarts; i += 256) starts_copy[i] = starts[i];
   typedef typename std::conditional<MT == 2, double2, double>::type XV;   // one column of the wave's row tiles
   extern __shared__ double smem[];
   const int N = D + 1, c = D >> 2, nd = (D >> 1) + 1, nleft = (nd + 3) >> 2;

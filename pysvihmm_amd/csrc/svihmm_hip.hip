@@ -732,8 +732,19 @@ static int pull_small(svihmm_ctx* h, void* dst, const void* pin, size_t bytes) {
   return 0;
 }
 
+int ensure_starts_pulled(svihmm_ctx* h) {
+  if (!h->starts_pending) return 0;
+  void* dst = h->starts.p;
+  const int64_t* src = h->starts_pending;
+  h->starts_pending = nullptr;
+  hipLaunchKernelGGL(k_pull, dim3(1), dim3(256), 0, h->stream, (const unsigned long long*)src,
+                     (unsigned long long*)dst, (size_t)h->starts_pending_n);
+  HIPCK(hipGetLastError());
+  return 0;
+}
 static int upload_starts(svihmm_ctx* h, const int64_t* starts, int B) {
   CK(ensure(h->starts, (size_t)B * sizeof(int64_t)));
+  h->starts_pending = nullptr;
   const size_t nb = (size_t)B * sizeof(int64_t);
   if (h->svi_upload_it >= 0 && nb <= (size_t)1 << 20) {
     svihmm_ctx::StartSlot& ss = h->svi_starts[h->svi_upload_it % 8];
@@ -746,7 +757,11 @@ static int upload_starts(svihmm_ctx* h, const int64_t* starts, int B) {
       ss.cap = nb + 4096;
     }
     std::memcpy(ss.p, starts, nb);
-    CK(pull_small(h, h->starts.p, ss.p, nb));
+    // the pull is owed, not launched: the orbit-schedule emission kernel reads the slot itself and leaves the
+    // device copy behind (launch_emission); every other consumer pays it first (ensure_starts_pulled)
+    void* dpin = nullptr;
+    HIPCK(hipHostGetDevicePointer(&dpin, ss.p, 0));
+    h->starts_pending = (const int64_t*)dpin; h->starts_pending_n = B;
     ss.used_it = h->svi_upload_it;
   } else if (nb <= (size_t)4 << 20) {   // through a pinned slot: no host-side wait for the stream
     void* pin = nullptr;

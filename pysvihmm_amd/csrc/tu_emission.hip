@@ -161,7 +161,14 @@ int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled,
     CK(ensure(h->ll, (size_t)n * K * sizeof(double)));
     out = (double*)h->ll.p;
   }
-  if (!starts_dev) starts_dev = (const int64_t*)h->starts.p;
+  // window starts whose pull is still owed (SVI loop, upload_starts): the orbit kernel below takes them from
+  // the pinned slot itself and leaves the device copy behind; every other kernel gets the device copy first
+  const bool own_starts = starts_dev == nullptr;
+  auto device_starts = [&]() -> int {
+    if (own_starts) { CK(ensure_starts_pulled(h)); starts_dev = (const int64_t*)h->starts.p; }
+    return 0;
+  };
+  if (!own_starts) CK(ensure_starts_pulled(h));
   if (scaled && !kexp_out) {
     CK(ensure(h->kexp, (size_t)n * sizeof(double)));
     kexp_out = (double*)h->kexp.p;
@@ -176,6 +183,7 @@ int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled,
   ProfScope ps(h, KS_EMISSION, stream);
   if (h->emis_cat) {   // table lookup (scaled output: the caller adds the k_scale_ll pass)
     if (scaled) return fail("internal: Categorical emission has no fused scaled output");
+    CK(device_starts());
     if (h->shifted) {          // (a shift moved the symbol column after the table was set)
       if (stream != h->stream) return fail("internal: Categorical lookup on a side stream over a centred column");
       CK(cat_uncentre(h));
@@ -191,6 +199,7 @@ int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled,
   if (!h->emis_diag && scaled && (flags & SVIHMM_INT_ST32) && emb_shape_ok(K, D) && h->niw.p &&
       h->variant[5] != 3 && min_lds == 0 && ((n + 127) / 128 >= 256 || h->variant[5] == 4)) {
     uint4* uwp = nullptr;
+    CK(device_starts());
     CK(emb_buffers(h, &uwp));
     if (!h->uw_valid) {   // the mode was switched on after the parameter upload: factors from the resident NIW block
       const double* dmu = (const double*)h->niw.p;
@@ -221,6 +230,7 @@ int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled,
   if (!h->emis_diag && ((scaled && (flags & SVIHMM_INT_ST32) && K <= 64) || wide32) && emd_shape_ok(K, D) && h->niw.p &&
       h->variant[5] != 3 && min_lds == 0 && (n >= 32768 || h->variant[10] == 3)) {
     uint4* uwp = nullptr;
+    CK(device_starts());
     CK(emd_buffers(h, K, &uwp));
     if (!h->uwd_valid) {   // the mode was switched on after the parameter upload: records from the resident NIW block
       const double* dmu = (const double*)h->niw.p;
@@ -254,6 +264,12 @@ int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled,
   if (!h->emis_diag && scaled && K <= 64 && D >= 8 && D <= 40 && D % 8 == 0 && h->variant[5] != 1 && min_lds == 0) {
     const int NT = Kp / 16, LEN = D + D / 2 + 1;
     const int nks = (D / 4) * (D / 2 + 1) + (D / 2 + 1 + 3) / 4;
+    const int64_t* pend = nullptr;
+    int pend_n = 0;
+    if (own_starts && h->starts_pending && h->starts_pending_n == B && stream == h->stream) {
+      pend = h->starts_pending; pend_n = B; h->starts_pending = nullptr;
+      starts_dev = pend;
+    } else CK(device_starts());
     if (!h->orb_valid) {
       CK(ensure(h->theta_orb, (size_t)nks * 4 * Kp * sizeof(double)));
       hipLaunchKernelGGL(k_theta_orbit, dim3(nks * 4), dim3(64), 0, stream, (const double*)h->theta.p,
@@ -268,7 +284,8 @@ int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled,
     dim3 grid((unsigned)((n + rows - 1) / rows));
 #define EMO(NTV, UV, MTV) hipLaunchKernelGGL((k_emission_orbit<NTV, UV, MTV>), grid, dim3(256), lds, stream,  \
                                         (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K,               \
-                                        (const double*)h->theta_orb.p, flags, out, kexp_out, ll0_out)
+                                        (const double*)h->theta_orb.p, flags, out, kexp_out, ll0_out,               \
+                                        pend ? (int64_t*)h->starts.p : (int64_t*)nullptr, pend_n)
 #define EMOM(NTV, UV) do { if (MTo == 1) EMO(NTV, UV, 1); else EMO(NTV, UV, 2); } while (0)
     if (D % 16 == 0) { if (NT == 4) EMOM(4, 4); else if (NT == 3) EMOM(3, 4); else if (NT == 2) EMOM(2, 4); else EMOM(1, 4); }
     else             { if (NT == 4) EMOM(4, 2); else if (NT == 3) EMOM(3, 2); else if (NT == 2) EMOM(2, 2); else EMOM(1, 2); }
@@ -277,6 +294,7 @@ int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled,
     HIPCK(hipGetLastError());
     return 0;
   }
+  CK(device_starts());
   if (var == 2) {
     const int DS = (D + 2) | 1;
     int MT = h->variant[3] > 0 ? h->variant[3] : 2;
