@@ -519,15 +519,18 @@ __device__ __forceinline__ void emb_step_barrier() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// MT = row tiles of 32 per wave: 2 (large batches: 256-row workgroups, two per CU) or 1 (round 5, batches with
+// fewer than one 256-row workgroup per CU -- the 64-window minibatch: 128-row workgroups, half the chain per pair)
+template <int MT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_emission_bf16x3(
     const double* __restrict__ obs, const uint8_t* __restrict__ mask,
     const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K,
     const char* __restrict__ uw, uint32_t flags,
     float* __restrict__ Eh, double* __restrict__ kexp, double* __restrict__ ll0) {
-  constexpr int ROWS = 256;
+  constexpr int ROWS = 128 * MT, WR = 32 * MT;            // rows per workgroup / per wave
   extern __shared__ uint4 smem4[];
   char* stage = reinterpret_cast<char*>(smem4);                      // [EMB_REC]: one pair record
-  float* tile_s = reinterpret_cast<float*>(stage + EMB_REC);         // [4 waves][64 rows][64 states]
+  float* tile_s = reinterpret_cast<float*>(stage + EMB_REC);         // [4 waves][WR rows][64 states]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int t = lane & 31, hh = lane >> 5;
@@ -548,11 +551,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   stage_load(0);
 
   // ---- the lane's two rows: dimensions 16 c + 8 hh + e as three bf16 terms (B operands)
-  embf8_t xb[2][3][2];
-  int bflag[2];
+  embf8_t xb[MT][3][2];
+  int bflag[MT];
 #pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const int r = wave * 64 + m * 32 + t;
+  for (int m = 0; m < MT; ++m) {
+    const int r = wave * WR + m * 32 + t;
     const int64_t g = g0 + r;
     const bool valid = g < nrows;
     const int64_t gg = valid ? g : 0;
@@ -606,7 +609,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   // One step per pair: operands LDS -> registers, barrier (the buffer is free), the next record's copy
   // on its way under this pair's 36 MFMAs, barrier (it has landed).
-  float* tw = tile_s + wave * 64 * 64;
+  float* tw = tile_s + wave * WR * 64;
   const emf16_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int sp = 0; sp < npair; ++sp) {
     embf8_t a[3][3];
@@ -631,11 +634,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __builtin_amdgcn_sched_barrier(0);
     stage_load(sp + 1);                                              // (behind the last pair: a spare record)
     __builtin_amdgcn_sched_barrier(0);
-    emf16_t acc[2][3];                                               // [row tile][k, k', upper components of both]
+    emf16_t acc[MT][3];                                              // [row tile][k, k', upper components of both]
     // the six products: (U term, x term)
     constexpr int TA[6] = {0, 0, 1, 0, 2, 1}, TB[6] = {0, 1, 0, 2, 0, 1};
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < MT; ++m) {
       acc[m][0] = bv[0]; acc[m][1] = bv[1]; acc[m][2] = zero16;
 #pragma unroll
       for (int pi = 0; pi < 6; ++pi) {
@@ -647,9 +650,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __builtin_amdgcn_sched_barrier(0);
     // |y|^2 of the lane half's components: registers 0..7 are components 0..15 (dims 0..15 only),
     // registers 8..15 components 16..31 = the state's own block + its half of the shared block
-    float pp[2][2];
+    float pp[2][MT];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < MT; ++m) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         // (scalar v_fmac_f32: the packed form, v_pk_add_f32 / v_pk_fma_f32 on register pairs, measured
@@ -670,7 +673,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // the halves exchange: lanes 0..31 finish the pair's first state, lanes 32..63 its second
     const int kl = 2 * sp + hh;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < MT; ++m) {
       const float send = hh ? pp[0][m] : pp[1][m];
       const float keep = hh ? pp[1][m] : pp[0][m];
       const float recv = __shfl_xor(send, 32, 64);
@@ -687,9 +690,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int sg = lane & 15, rq = lane >> 4;
   const double L2E = 1.4426950408889634074;
   const float l2e = 1.44269504f, fbig = 3.0e38f;
-  for (int it = 0; it < 16; ++it) {
+  for (int it = 0; it < 8 * MT; ++it) {
     const int rl = it * 4 + rq;
-    const int64_t g = g0 + wave * 64 + rl;
+    const int64_t g = g0 + wave * WR + rl;
     const float4 v4 = *reinterpret_cast<const float4*>(tw + rl * 64 + ((4 * sg) ^ ((rl & 15) << 2)));
     const int bf = __shfl(bflag[it >> 3], rl & 31, 64);
     float v[4] = {v4.x, v4.y, v4.z, v4.w};

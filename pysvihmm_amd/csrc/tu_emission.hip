@@ -84,7 +84,8 @@ int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out) {
   // device-resident SVI loop: its minibatches stay below that kernel's batch size, and a large batch
   // that follows builds them on demand)
   uint4* uwp = nullptr;
-  if (h->prec == 1 && emb_shape_ok(K, D) && (!h->svi_active || h->variant[5] == 4)) CK(emb_buffers(h, &uwp));
+  // (also inside the device-resident SVI loop since round 5: its 64-window minibatches take the 128-row form of the kernel)
+  if (h->prec == 1 && emb_shape_ok(K, D)) CK(emb_buffers(h, &uwp));
   const bool emd = h->prec == 1 && emd_shape_ok(K, D) && !h->svi_active;   // (D <= 32 at K > 64: the 64-wide builder writes the records)
   if (emd) CK(emd_buffers(h, K, &uwp));
   {
@@ -197,7 +198,7 @@ int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled,
   // fp32 mode, large batches of a NIW model with K <= 64, D <= 32: the centred bf16 x 3 kernel
   // (variant[5] = 3: the fp64 feature GEMM also in this mode)
   if (!h->emis_diag && scaled && (flags & SVIHMM_INT_ST32) && emb_shape_ok(K, D) && h->niw.p &&
-      h->variant[5] != 3 && min_lds == 0 && ((n + 127) / 128 >= 256 || h->variant[5] == 4)) {
+      h->variant[5] != 3 && min_lds == 0 && (n >= 8192 || h->variant[5] == 4)) {
     uint4* uwp = nullptr;
     CK(device_starts());
     CK(emb_buffers(h, &uwp));
@@ -213,14 +214,24 @@ int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled,
       HIPCK(hipGetLastError());
       h->uw_valid = true;
     }
-    const size_t lds = (size_t)EMB_REC + (size_t)4 * 64 * 64 * 4;         // two workgroups per CU
+    // fewer than one 256-row workgroup per CU (the 64-window minibatch): 128-row workgroups, one row tile per wave
+    const int MTe = (n + 255) / 256 >= 256 ? 2 : 1;
+    const size_t lds = (size_t)EMB_REC + (size_t)4 * (32 * MTe) * 64 * 4;  // MT = 2: two workgroups per CU
     if (!h->emb_attr_set) {   // (per handle = per device)
-      HIPCK(hipFuncSetAttribute((const void*)k_emission_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIPCK(hipFuncSetAttribute((const void*)k_emission_bf16x3<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)((size_t)EMB_REC + (size_t)4 * 64 * 64 * 4)));
+      HIPCK(hipFuncSetAttribute((const void*)k_emission_bf16x3<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)((size_t)EMB_REC + (size_t)4 * 32 * 64 * 4)));
       h->emb_attr_set = true;
     }
-    hipLaunchKernelGGL(k_emission_bf16x3, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, stream,
-                       (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, (const char*)uwp,
-                       flags, (float*)out, kexp_out, ll0_out);
+    if (MTe == 2)
+      hipLaunchKernelGGL(k_emission_bf16x3<2>, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, stream,
+                         (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, (const char*)uwp,
+                         flags, (float*)out, kexp_out, ll0_out);
+    else
+      hipLaunchKernelGGL(k_emission_bf16x3<1>, dim3((unsigned)((n + 127) / 128)), dim3(256), lds, stream,
+                         (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, (const char*)uwp,
+                         flags, (float*)out, kexp_out, ll0_out);
     HIPCK(hipGetLastError());
     return 0;
   }

@@ -49,7 +49,9 @@ static size_t bw_lds(const svihmm_ctx* h) {
 }
 static bool stats_bf16w_ok(const svihmm_ctx* h, int64_t n) {
   // (a wide model that runs in the fp32 format has no other statistics kernel: no batch-size floor there)
-  return h->cur_f32 && h->lin_mode && !h->q_valid && h->K <= 256 && h->Kp % 64 == 0 && h->Fp > 0 && !h->emis_cat &&
+  // (D <= 64: the kernel stages x columns 0..63 from the observations and treats columns 64, 65 as the ones / zero
+  //  columns -- found by the fuzz at K = 64, D = 79 with the floors lifted)
+  return h->cur_f32 && h->lin_mode && !h->q_valid && h->K <= 256 && h->D <= 64 && h->Kp % 64 == 0 && h->Fp > 0 && !h->emis_cat &&
          !h->emis_diag && h->variant[10] != 2 && h->variant[1] == 0 && bw_lds(h) <= 160 * 1024 &&
          (h->K > 64 || ((h->Fp + 31) / 32 + 2 > 24 && (n >= 32768 || h->variant[10] == 3)));
 }

@@ -32,10 +32,10 @@ int main(int argc, char** argv) {
   CKH(hipMemcpy(dst, starts.data(), B * 8, hipMemcpyHostToDevice));
   CKH(hipMemcpy(duw, uwh.data(), nb, hipMemcpyHostToDevice));
   const size_t lds = (size_t)EMB_REC + (size_t)4 * 64 * 64 * 4;
-  CKH(hipFuncSetAttribute((const void*)k_emission_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  CKH(hipFuncSetAttribute((const void*)k_emission_bf16x3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   auto launch = [&]() {
-    hipLaunchKernelGGL(k_emission_bf16x3, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, 0, dobs, (const uint8_t*)nullptr,
+    hipLaunchKernelGGL(k_emission_bf16x3<2>, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, 0, dobs, (const uint8_t*)nullptr,
                        dst, n, Lm, D, K, (const char*)duw, 0x10000u, dEh, dkexp, dll0);
   };
   for (int i = 0; i < 3; ++i) launch();
