@@ -526,8 +526,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const double* __restrict__ obs, const uint8_t* __restrict__ mask,
     const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K,
     const char* __restrict__ uw, uint32_t flags,
-    float* __restrict__ Eh, double* __restrict__ kexp, double* __restrict__ ll0) {
+    float* __restrict__ Eh, double* __restrict__ kexp, double* __restrict__ ll0,
+    int64_t* __restrict__ starts_copy = nullptr, int nstarts = 0) {
   constexpr int ROWS = 128 * MT, WR = 32 * MT;            // rows per workgroup / per wave
+  // (SVI loop: `starts` is the host's pinned slot, see k_emission_orbit; workgroup 0 leaves the device copy)
+  if (starts_copy && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < nstarts; i += 256) starts_copy[i] = starts[i];
   extern __shared__ uint4 smem4[];
   char* stage = reinterpret_cast<char*>(smem4);                      // [EMB_REC]: one pair record
   float* tile_s = reinterpret_cast<float*>(stage + EMB_REC);         // [4 waves][WR rows][64 states]

@@ -200,7 +200,12 @@ int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled,
   if (!h->emis_diag && scaled && (flags & SVIHMM_INT_ST32) && emb_shape_ok(K, D) && h->niw.p &&
       h->variant[5] != 3 && min_lds == 0 && (n >= 8192 || h->variant[5] == 4)) {
     uint4* uwp = nullptr;
-    CK(device_starts());
+    const int64_t* pend = nullptr;
+    int pend_n = 0;
+    if (own_starts && h->starts_pending && h->starts_pending_n == B && stream == h->stream) {
+      pend = h->starts_pending; pend_n = B; h->starts_pending = nullptr;
+      starts_dev = pend;
+    } else CK(device_starts());
     CK(emb_buffers(h, &uwp));
     if (!h->uw_valid) {   // the mode was switched on after the parameter upload: factors from the resident NIW block
       const double* dmu = (const double*)h->niw.p;
@@ -227,11 +232,11 @@ int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled,
     if (MTe == 2)
       hipLaunchKernelGGL(k_emission_bf16x3<2>, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, stream,
                          (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, (const char*)uwp,
-                         flags, (float*)out, kexp_out, ll0_out);
+                         flags, (float*)out, kexp_out, ll0_out, pend ? (int64_t*)h->starts.p : (int64_t*)nullptr, pend_n);
     else
       hipLaunchKernelGGL(k_emission_bf16x3<1>, dim3((unsigned)((n + 127) / 128)), dim3(256), lds, stream,
                          (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, (const char*)uwp,
-                         flags, (float*)out, kexp_out, ll0_out);
+                         flags, (float*)out, kexp_out, ll0_out, pend ? (int64_t*)h->starts.p : (int64_t*)nullptr, pend_n);
     HIPCK(hipGetLastError());
     return 0;
   }

@@ -39,8 +39,12 @@ static bool stats_bf16_ok(const svihmm_ctx* h, int64_t n) {
 // (Measured on configs[4], 68 feature tiles: five groups of 14 + 2 -- two full rounds of the 8 waves each
 //  instead of four of 17 + 2 = three ragged rounds -- ran 8.5 against 7.8 ms: every group restages q and
 //  re-forms its A terms, which costs more than the idle slots.)
-static int bw_feature_groups(const svihmm_ctx* h) {
+// Small batches (below the large-batch kernels' floor: the 64-window minibatch): six feature tiles per group, so that
+// a workgroup's list is one round of its eight waves and the launch has chunks x groups >= ~200 workgroups of four
+// stages each instead of ~50 (k_stats_bf16x3 with its floor lifted: 47 us; the fp32-input MFMA kernel: 30 us).
+static int bw_feature_groups(const svihmm_ctx* h, int64_t n) {
   const int FT = (h->Fp + 31) / 32, NGz = (h->Kp + 63) / 64;
+  if (n < 32768) return std::max(NGz, (FT + 5) / 6);
   return std::max(NGz, (FT + 21) / 22);
 }
 static size_t bw_lds(const svihmm_ctx* h) {
@@ -53,13 +57,14 @@ static bool stats_bf16w_ok(const svihmm_ctx* h, int64_t n) {
   //  columns -- found by the fuzz at K = 64, D = 79 with the floors lifted)
   return h->cur_f32 && h->lin_mode && !h->q_valid && h->K <= 256 && h->D <= 64 && h->Kp % 64 == 0 && h->Fp > 0 && !h->emis_cat &&
          !h->emis_diag && h->variant[10] != 2 && h->variant[1] == 0 && bw_lds(h) <= 160 * 1024 &&
-         (h->K > 64 || ((h->Fp + 31) / 32 + 2 > 24 && (n >= 32768 || h->variant[10] == 3)));
+         (h->K > 64 || ((h->Fp + 31) / 32 + 2 > 24 && (n >= 32768 || h->variant[10] == 3)) ||
+          (n >= 8192 && n < 32768 && h->variant[10] != 3));      // (minibatch-sized batches at K = 64: the six-tile groups)
 }
 StatsPlan stats_plan(const svihmm_ctx* h, int64_t n, int forced) {
   int target_chunks = forced > 0 ? forced : 128;
   if (forced <= 0 && !stats_bf16_ok(h, n) && stats_bf16w_ok(h, n)) {
     // chunks x feature groups x state groups = whole rounds of 256 one-per-CU workgroups, >= 32 chunks
-    const int per_chunk = bw_feature_groups(h) * ((h->Kp + 63) / 64);
+    const int per_chunk = bw_feature_groups(h, n) * ((h->Kp + 63) / 64);
     const int R = std::max(1, (32 * per_chunk + 255) / 256);
     int64_t tc = std::max(1, 256 * R / per_chunk);
     if (tc > n / (4 * SB_ROWS)) tc = std::max<int64_t>(1, n / (4 * SB_ROWS));
@@ -145,7 +150,7 @@ int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, int Lm, u
       const int mt_limit = big ? Fp / 16 : mtiles;
       const int xk = (D + 1 + TPR - 1) / TPR;
       if (bw) {
-        const int KpF = (Kp + 63) / 64 * 64, NGf = bw_feature_groups(h), FT = (Fp + 31) / 32;
+        const int KpF = (Kp + 63) / 64 * 64, NGf = bw_feature_groups(h, n), FT = (Fp + 31) / 32;
         const int TPG = (FT + NGf - 1) / NGf;
         const size_t ldsb = bw_lds(h);
         if (KpF != Kp) return fail("internal: wide fp32 statistics need states padded in groups of 64");
