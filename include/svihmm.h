@@ -87,7 +87,7 @@ int svihmm_sync(svihmm_ctx* h);
  *   forward / backward messages are STORED as fp32 (half the HBM traffic of the sweeps) and the
  *   expected-sufficient-statistics GEMM runs on v_mfma_f32_16x16x4_f32 (twice the matrix rate),
  *   each row chunk accumulated in fp32 and the chunks reduced in fp64.  The emission quadratic
- *   form of large batches (>= 32768 rows, D <= 32) is evaluated CENTRED, c_k - |U_k x + b_k|^2 with
+ *   form of batches from 8192 rows (D <= 32; from 32768 rows at D <= 64) is evaluated CENTRED, c_k - |U_k x + b_k|^2 with
  *   U_k = sqrt(nu_k/2) L_k^-1, on the bf16 matrix pipe: x and U_k as three bf16 terms each (= the
  *   values to fp32 accuracy), six products into fp32 accumulators (round 3; the expanded feature
  *   form of the fp64 kernels cancels ~1e5 : 1, which fp32 cannot carry -- smaller batches and

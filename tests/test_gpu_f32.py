@@ -332,8 +332,8 @@ def test_f32_wide_models_and_d_above_32_vs_fp64_oracle(K, D, B, Lm):
 
 def test_f32_s64_minibatch_vs_fp64_oracle():
     """The literal configs[2] minibatch (64 windows of 257 rows, K = 64, D = 32) in the fp32 mode against the
-    fp64 C oracle: below the bf16 kernels' batch-size floor the mode runs the fp64 feature GEMM in front of
-    float storage, the four-wave sweep (fp64 arithmetic on float messages) and the fp32-input statistics GEMM."""
+    fp64 C oracle: the 128-row form of the centred bf16 emission kernel (k_emission_bf16x3<1>), the four-wave
+    sweep (fp64 arithmetic on float messages) and the bf16 statistics kernel with six-tile feature groups."""
     from pysvihmm_amd.engine import HipEngine
     from pysvihmm_amd import _lib as L
     from oracle import ref_c
