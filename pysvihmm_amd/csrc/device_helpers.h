@@ -172,3 +172,37 @@ __device__ __forceinline__ double digamma_d(double x) {
 __device__ __forceinline__ int feat_index_d(int a, int b, int D) {
   return a * (D + 1) - a * (a - 1) / 2 + (b - a);
 }
+
+// ------------------------------------------------------------------------------------
+//  Device-side dependencies of the resident SVI loop (round 5).  A stream-order event between two kernels
+//  of an iteration's chain costs ~7 us of dispatch (record) or 4-10 us (a wait that was satisfied long
+//  before); the loop's cross-stream edges -- global step -> globals kernel, globals -> sweeps, theta ->
+//  ELBO kernels, ELBO kernels -> next global step -- and its timing marks are therefore carried by
+//  monotonic counters in HBM: a producer's workgroups ARRIVE (agent-scope release) when their stores are
+//  done, a consumer's workgroups GATE on the expected total (agent-scope acquire; bounded spin -- a
+//  timeout raises the status word instead of hanging the queue), side streams start their kernels behind a
+//  one-wave k_svi_gate so that nothing squats on a CU while it waits, and the iteration boundaries are
+//  wall_clock64() stamps written by the kernels themselves.
+// ------------------------------------------------------------------------------------
+#define SVI_SYNC_TIMEOUT (1 << 22)
+#define SVI_SYNC_SPINS (1 << 21)          // x ~1 us of s_sleep: ~2 s, then the gate gives up
+__device__ __forceinline__ void svi_gate(const SviSync& sy) {
+  if (!sy.gate) return;
+  if (threadIdx.x == 0) {
+    int n = 0;
+    while (__hip_atomic_load(sy.gate, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < sy.gate_tgt) {
+      __builtin_amdgcn_s_sleep(16);
+      if (++n > SVI_SYNC_SPINS) { if (sy.status) atomicMax(sy.status, SVI_SYNC_TIMEOUT); break; }
+    }
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void svi_arrive(const SviSync& sy) {
+  if (!sy.arrive) return;
+  __syncthreads();                         // every thread's stores are issued and waited for (workgroup scope)
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const unsigned before = __hip_atomic_fetch_add(sy.arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (sy.stamp && before + 1u == sy.stamp_at) *sy.stamp = wall_clock64();
+  }
+}

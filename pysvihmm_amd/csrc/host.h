@@ -182,6 +182,16 @@ struct svihmm_ctx {
   hipEvent_t svi_ec = nullptr, svi_ed = nullptr;   // theta ready / side-stream ELBO kernels done
   hipStream_t stream3 = nullptr;                   // the ELBO kernels' own stream
   bool vlb_pending = false;
+  // device-side dependencies of the loop (round 5, device_helpers.h): counters [step | globals | theta | side] in
+  // HBM with the totals the host expects, the status word of the gates, iteration stamps in mapped host memory
+  Buf svi_sync;
+  unsigned tgt_step = 0, tgt_glob = 0, tgt_theta = 0, tgt_side = 0;
+  bool svi_flags = false;          // this loop runs on counters instead of stream-order events
+  int* svi_status_dev = nullptr;   // device address of pin_status[1]: a gate that gave up
+  bool in_svi_estep = false;       // estep_core is running for svihmm_svi_iteration
+  unsigned long long* svi_ts = nullptr; unsigned long long* svi_ts_dev = nullptr; int svi_ts_cap = 0;   // pinned + mapped: [2 it] begin, [2 it + 1] end (wall_clock64)
+  SviSync theta_sy = {nullptr, 0u, nullptr, nullptr, nullptr};   // what the next theta-builder launch arrives on
+  double wall_clock_khz = 0.0;
   bool svi_globals_ready = false;   // Aexp / mod_init / var_init[slot] of the NEXT iteration are computed (or in flight)
   int svi_globals_slot = 0, svi_vi_cur = 0;   // var_init slot the pending globals write / the last iteration used
   // The resident observations are kept centred: obs_dev[t] = obs_caller[t] - shift.  The shift is

@@ -1619,9 +1619,11 @@ __global__ __launch_bounds__(256) void k_wave_lin4(
     const double* __restrict__ mod_init, const double* __restrict__ ll0, size_t l0stride, int Lm,
     int K, ST* __restrict__ ah,
     ST* __restrict__ bh, double* __restrict__ hx, double* __restrict__ gx,
-    double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac) {
+    double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac,
+    SviSync sy = SviSync{nullptr, 0u, nullptr, nullptr, nullptr}) {
   static_assert(KMAX == 64, "lane = state, four source blocks of 16");
   __shared__ double part[2][4][64];             // [step parity][source block][target], double-buffered
+  svi_gate(sy);                                 // (SVI loop: the globals kernel of the side stream has arrived)
   if (blockIdx.y == 0) {
     if (K == 64) wave_lin4_body<true, true, ST>(Eh, kexp, Aexp, mod_init, ll0, l0stride, Lm, K, ah, hx, local_lb, logz, zfac, part);
     else wave_lin4_body<true, false, ST>(Eh, kexp, Aexp, mod_init, ll0, l0stride, Lm, K, ah, hx, local_lb, logz, zfac, part);
@@ -1906,8 +1908,10 @@ __global__ __launch_bounds__(64) void k_wave_linr(
     const double* __restrict__ mod_init, const double* __restrict__ ll0, size_t l0stride, int Lm,
     int K, ST* __restrict__ ah,
     ST* __restrict__ bh, double* __restrict__ hx, double* __restrict__ gx,
-    double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac) {
+    double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac,
+    SviSync sy = SviSync{nullptr, 0u, nullptr, nullptr, nullptr}) {
   __shared__ WlrRing<ST> ring;
+  svi_gate(sy);                                 // (SVI loop: the globals kernel of the side stream has arrived)
   if (blockIdx.y == 0) {
     if (K == 64) wave_linr_body<true, true, ST>(Eh, kexp, Aexp, mod_init, ll0, l0stride, Lm, K, ah, hx, local_lb, logz, zfac, ring);
     else wave_linr_body<true, false, ST>(Eh, kexp, Aexp, mod_init, ll0, l0stride, Lm, K, ah, hx, local_lb, logz, zfac, ring);

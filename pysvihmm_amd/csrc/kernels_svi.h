@@ -76,7 +76,7 @@ struct GthBack<0> {
 };
 
 template <bool LDSW, int NWV>
-__global__ __launch_bounds__(64 * NWV) void k_svi_globals(
+__device__ __forceinline__ void k_svi_globals_body(
     const double* __restrict__ var_tran, int K, double* __restrict__ work_g,
     double* __restrict__ ltran, double* __restrict__ Aexp, double* __restrict__ AexpT,
     double* __restrict__ var_init, double* __restrict__ mod_init) {
@@ -231,6 +231,15 @@ __global__ __launch_bounds__(64 * NWV) void k_svi_globals(
     mod_init[k] = digamma_d(v + SVI_EPS) - dsum;
   }
 }
+template <bool LDSW, int NWV>
+__global__ __launch_bounds__(64 * NWV) void k_svi_globals(
+    const double* __restrict__ var_tran, int K, double* __restrict__ work_g,
+    double* __restrict__ ltran, double* __restrict__ Aexp, double* __restrict__ AexpT,
+    double* __restrict__ var_init, double* __restrict__ mod_init, SviSync sy) {
+  svi_gate(sy);
+  k_svi_globals_body<LDSW, NWV>(var_tran, K, work_g, ltran, Aexp, AexpT, var_init, mod_init);
+  svi_arrive(sy);
+}
 
 // ------------------------------------------------------------------------------------
 //  G2: natural-gradient global step (hmmsgd_metaobs.py:1010-1069, util.py:28-60) from the packed
@@ -262,7 +271,7 @@ __device__ __forceinline__ void svi_tran_step(int e, int K, const double* __rest
     var_tran[e] = ((1.0 - rho) * nat_old + rho * (bA * a_inter)) + 1.0;
   }
 }
-__global__ __launch_bounds__(256) void k_svi_global_step(
+__device__ __forceinline__ void k_svi_global_step_body(
     const double* __restrict__ packed, const double* __restrict__ prior_tran, double* __restrict__ var_tran,
     double* __restrict__ niw, const double* __restrict__ prior, int K, int D, double rho, double bA,
     double bE, double nwin, double* __restrict__ lb_keep, double* __restrict__ ada_G) {
@@ -310,6 +319,14 @@ __global__ __launch_bounds__(256) void k_svi_global_step(
   for (int a = tid; a < D; a += 256) mu[a] = mn[a];
   if (tid == 0) { kap[k] = e2; nu[k] = e4 - 2 - D; }
 }
+__global__ __launch_bounds__(256) void k_svi_global_step(
+    const double* __restrict__ packed, const double* __restrict__ prior_tran, double* __restrict__ var_tran,
+    double* __restrict__ niw, const double* __restrict__ prior, int K, int D, double rho, double bA,
+    double bE, double nwin, double* __restrict__ lb_keep, double* __restrict__ ada_G, SviSync sy) {
+  svi_gate(sy);
+  k_svi_global_step_body(packed, prior_tran, var_tran, niw, prior, K, D, rho, bA, bE, nwin, lb_keep, ada_G);
+  svi_arrive(sy);
+}
 
 // ------------------------------------------------------------------------------------
 //  G3: the NIW factors' term of global_lower_bound (hmmsgd_metaobs.py:294 sum_k get_vlb();
@@ -335,7 +352,7 @@ __device__ __forceinline__ void svi_rowterm(int i, int K, int lane, const double
   acc = wave_sum(acc);
   if (lane == 0) rowterm[i] = acc - lgamma(sv + SVI_EPS);
 }
-__global__ __launch_bounds__(64) void k_svi_vlb(
+__device__ __forceinline__ void k_svi_vlb_body(
     const double* __restrict__ theta, const int* __restrict__ fab, int F, int D, int Kp,
     const double* __restrict__ niw, const double* __restrict__ logdet, const double* __restrict__ prior,
     const double* __restrict__ prior_logpart, double zsign, int K, double* __restrict__ vlb,
@@ -383,6 +400,16 @@ __global__ __launch_bounds__(64) void k_svi_vlb(
     vlb[k] = p_avgengy + q_entropy;
   }
 }
+__global__ __launch_bounds__(64) void k_svi_vlb(
+    const double* __restrict__ theta, const int* __restrict__ fab, int F, int D, int Kp,
+    const double* __restrict__ niw, const double* __restrict__ logdet, const double* __restrict__ prior,
+    const double* __restrict__ prior_logpart, double zsign, int K, double* __restrict__ vlb,
+    const double* __restrict__ prior_tran, const double* __restrict__ var_tran,
+    double* __restrict__ rowterm, SviSync sy) {
+  svi_gate(sy);
+  k_svi_vlb_body(theta, fab, F, D, Kp, niw, logdet, prior, prior_logpart, zsign, K, vlb, prior_tran, var_tran, rowterm);
+  svi_arrive(sy);
+}
 
 // ------------------------------------------------------------------------------------
 //  G4: elbo_vec[it] = lb + global_lower_bound()  (hmmsgd_metaobs.py:436-445, 273-296):
@@ -390,7 +417,7 @@ __global__ __launch_bounds__(64) void k_svi_vlb(
 //  (rowterm[i] from k_svi_vlb + prior_const = sum_i [lgamma(sum_j p_ij + eps) - sum_j lgamma(p_ij
 //  + eps)], a constant of the prior computed once by the host) + sum_k vlb[k]; fixed order.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_svi_elbo(int K, const double* __restrict__ vlb,
+__device__ __forceinline__ void k_svi_elbo_body(int K, const double* __restrict__ vlb,
                                                  const double* __restrict__ rowterm, double prior_const,
                                                  const double* __restrict__ lb, double* __restrict__ elbo_out) {
   if (threadIdx.x == 0) {
@@ -399,6 +426,13 @@ __global__ __launch_bounds__(64) void k_svi_elbo(int K, const double* __restrict
     for (int i = 0; i < K; ++i) d += rowterm[i];
     *elbo_out = lb[0] + (d + prior_const) + v;
   }
+}
+__global__ __launch_bounds__(64) void k_svi_elbo(int K, const double* __restrict__ vlb,
+                                                 const double* __restrict__ rowterm, double prior_const,
+                                                 const double* __restrict__ lb, double* __restrict__ elbo_out, SviSync sy) {
+  svi_gate(sy);
+  k_svi_elbo_body(K, vlb, rowterm, prior_const, lb, elbo_out);
+  svi_arrive(sy);
 }
 
 
@@ -416,7 +450,7 @@ __global__ __launch_bounds__(64) void k_svi_elbo(int K, const double* __restrict
 //      distributions.Categorical.get_vlb.
 //  grid: nem = ceil(K W / 256) element blocks + ceil(K^2 / 256) transition blocks.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_svi_global_step_simple(
+__device__ __forceinline__ void k_svi_global_step_simple_body(
     int fam, const double* __restrict__ packed, const double* __restrict__ prior_tran,
     double* __restrict__ var_tran, double* __restrict__ blk, const double* __restrict__ prior, int K, int W,
     double rho, double bA, double bE, double nwin, double* __restrict__ lb_keep, double* __restrict__ ada_G,
@@ -449,9 +483,18 @@ __global__ __launch_bounds__(256) void k_svi_global_step_simple(
   const double mn = e0 / e1;
   blk[e] = mn; blk[n + e] = e1; blk[2 * n + e] = 0.5 * e3; blk[3 * n + e] = 0.5 * (e2 - e1 * mn * mn);
 }
+__global__ __launch_bounds__(256) void k_svi_global_step_simple(
+    int fam, const double* __restrict__ packed, const double* __restrict__ prior_tran,
+    double* __restrict__ var_tran, double* __restrict__ blk, const double* __restrict__ prior, int K, int W,
+    double rho, double bA, double bE, double nwin, double* __restrict__ lb_keep, double* __restrict__ ada_G,
+    int nem, SviSync sy) {
+  svi_gate(sy);
+  k_svi_global_step_simple_body(fam, packed, prior_tran, var_tran, blk, prior, K, W, rho, bA, bE, nwin, lb_keep, ada_G, nem);
+  svi_arrive(sy);
+}
 
 // grid 2 K waves: [0, K) the factors' ELBO terms vlb[k], [K, 2K) the transition rows' terms
-__global__ __launch_bounds__(64) void k_svi_vlb_simple(
+__device__ __forceinline__ void k_svi_vlb_simple_body(
     int fam, const double* __restrict__ blk, const double* __restrict__ prior, int K, int W,
     double* __restrict__ vlb, const double* __restrict__ prior_tran, const double* __restrict__ var_tran,
     double* __restrict__ rowterm) {
@@ -493,10 +536,18 @@ __global__ __launch_bounds__(64) void k_svi_vlb_simple(
   acc = wave_sum(acc);
   if (lane == 0) vlb[k] = acc;
 }
+__global__ __launch_bounds__(64) void k_svi_vlb_simple(
+    int fam, const double* __restrict__ blk, const double* __restrict__ prior, int K, int W,
+    double* __restrict__ vlb, const double* __restrict__ prior_tran, const double* __restrict__ var_tran,
+    double* __restrict__ rowterm, SviSync sy) {
+  svi_gate(sy);
+  k_svi_vlb_simple_body(fam, blk, prior, K, W, vlb, prior_tran, var_tran, rowterm);
+  svi_arrive(sy);
+}
 
 // E log theta[v][k] = psi(alpha[k][v]) - psi(sum_v alpha[k][v]): the Categorical lookup table
 // (layout [V][K], see k_emission_cat) from the resident Dirichlet factors; one wave per state
-__global__ __launch_bounds__(64) void k_cat_table(const double* __restrict__ alpha, int K, int V,
+__device__ __forceinline__ void k_cat_table_body(const double* __restrict__ alpha, int K, int V,
                                                   double* __restrict__ table) {
   const int k = blockIdx.x, lane = threadIdx.x;
   double s = 0.0;
@@ -505,3 +556,15 @@ __global__ __launch_bounds__(64) void k_cat_table(const double* __restrict__ alp
   const double dgs = digamma_d(s);
   for (int v = lane; v < V; v += 64) table[(size_t)v * K + k] = digamma_d(alpha[(size_t)k * V + v]) - dgs;
 }
+__global__ __launch_bounds__(64) void k_cat_table(const double* __restrict__ alpha, int K, int V,
+                                                  double* __restrict__ table, SviSync sy) {
+  svi_gate(sy);
+  k_cat_table_body(alpha, K, V, table);
+  svi_arrive(sy);
+}
+
+// one wave that waits for a counter: what a side stream runs in front of a kernel whose inputs another stream
+// produces (instead of hipStreamWaitEvent on an event recorded between two kernels of the main chain)
+__global__ __launch_bounds__(64) void k_svi_gate(SviSync sy) { svi_gate(sy); }
+// iteration-begin stamp when the loop does not run back to back (first iteration, after a host-side hook)
+__global__ __launch_bounds__(64) void k_svi_stamp(unsigned long long* ts) { if (threadIdx.x == 0) *ts = wall_clock64(); }

@@ -14,3 +14,13 @@ __device__ __forceinline__ int64_t imin64(int64_t a, int64_t b) { return a < b ?
 // status word of the NIW / diagonal theta builders: 1 + k = factor k not positive definite,
 // NIW_STATUS_RANGE + 1 + k = factor k too far from the data centre (kernels_emission.h)
 #define NIW_STATUS_RANGE (1 << 20)
+
+// device-side dependency of the resident SVI loop (device_helpers.h: svi_gate / svi_arrive); passed by value
+struct SviSync {
+  const unsigned* gate;        // wait until *gate >= gate_tgt before touching the inputs (nullptr: no wait)
+  unsigned gate_tgt;
+  unsigned* arrive;            // += 1 per workgroup when its outputs are written (nullptr: none)
+  int* status;                 // raised to SVI_SYNC_TIMEOUT when a gate gives up
+  unsigned long long* stamp;   // the workgroup whose arrival brings *arrive to stamp_at stores wall_clock64() here
+  unsigned stamp_at;           //   (the kernel's last workgroup; nullptr: none)
+};

@@ -73,7 +73,7 @@ int svihmm_destroy(svihmm_ctx* h) {
                  &h->local_lb, &h->logz, &h->part, &h->packed, &h->scratch, &h->kexp, &h->hx, &h->gx,
                  &h->zfac, &h->llE, &h->m_ll, &h->m_la, &h->m_lb, &h->chain, &h->chain2, &h->cat_table, &h->partc, &h->theta_orb, &h->prior, &h->vlb_aux, &h->gen_z,
                  &h->svi_state, &h->svi_prior, &h->svi_work, &h->commtmp, &h->ll0, &h->a0v, &h->a0e,
-                 &h->shift_d, &h->uwb, &h->uwd, &h->AexpF, &h->AexpTF};
+                 &h->shift_d, &h->uwb, &h->uwd, &h->AexpF, &h->AexpTF, &h->svi_sync};
   for (Buf* b : bufs) release(*b);
   if (h->vlb_host) { hipHostFree(h->vlb_host); h->vlb_host = nullptr; }
   if (h->svi_elbo) { hipHostFree(h->svi_elbo); h->svi_elbo = nullptr; }
@@ -91,6 +91,7 @@ int svihmm_destroy(svihmm_ctx* h) {
   for (auto& ps : h->pins) { if (ps.p) hipHostFree(ps.p); if (ps.ev) hipEventDestroy(ps.ev); }
   for (auto& ss : h->svi_starts) if (ss.p) hipHostFree(ss.p);
   if (h->pin_status) hipHostFree(h->pin_status);
+  if (h->svi_ts) hipHostFree(h->svi_ts);
   if (h->mirror) hipHostFree(h->mirror);
   hipStreamDestroy(h->stream);
   delete h;
@@ -748,7 +749,13 @@ static int upload_starts(svihmm_ctx* h, const int64_t* starts, int B) {
   const size_t nb = (size_t)B * sizeof(int64_t);
   if (h->svi_upload_it >= 0 && nb <= (size_t)1 << 20) {
     svihmm_ctx::StartSlot& ss = h->svi_starts[h->svi_upload_it % 8];
-    if (ss.used_it >= 0 && 2 * ss.used_it + 1 < (int)h->svi_ev.size())
+    if (ss.used_it >= 0 && h->svi_flags && h->svi_ts && 2 * ss.used_it + 1 < h->svi_ts_cap) {
+      // (eight iterations back: long complete -- its end stamp is there; bounded wait, then the stream itself)
+      volatile unsigned long long* ts = &h->svi_ts[2 * ss.used_it + 1];
+      int spins = 0;
+      while (*ts == 0 && ++spins < 200000) { for (volatile int w = 0; w < 50; ++w) {} }
+      if (*ts == 0) HIPCK(hipStreamSynchronize(h->stream));
+    } else if (ss.used_it >= 0 && 2 * ss.used_it + 1 < (int)h->svi_ev.size())
       HIPCK(hipEventSynchronize(h->svi_ev[2 * ss.used_it + 1]));   // (eight iterations back: long complete)
     if (nb > ss.cap) {
       if (ss.p) hipHostFree(ss.p);
@@ -813,6 +820,9 @@ int wait_globals(svihmm_ctx* h) {
 // The SVI loop's side streams may still read what a host upload is about to rewrite: the ELBO
 // kernels (stream3) read niw / theta / logdet / var_tran, the globals kernel (stream2) var_tran.
 static int wait_side_streams(svihmm_ctx* h) {
+  // (flags mode, inside the loop's E-step: the sweeps gate on the globals counter -- or take the event themselves,
+  //  launch_fb_lin_range -- and the global step gates on the ELBO kernels' counter)
+  if (h->svi_flags && h->in_svi_estep) return 0;
   CK(wait_globals(h));
   if (h->vlb_pending) { HIPCK(hipStreamWaitEvent(h->stream, h->svi_ed, 0)); h->vlb_pending = false; }
   return 0;
@@ -829,6 +839,7 @@ static int run_fb(svihmm_ctx* h, int B, int Lm, int var, bool want_lb, bool tota
     return launch_fb_lin(h, B, Lm, total);
   }
   h->have_lb = (var != 2) || want_lb;
+  if (h->svi_flags && h->in_svi_estep) CK(wait_globals(h));    // (the log-domain kernels take no gate)
   if (var == 2) return launch_fb_fused(h, B, Lm, want_lb, total);
   CK(launch_fb(h, B, Lm, 0, 2));
   return launch_posterior(h, B, Lm, total);
@@ -1217,6 +1228,23 @@ static double* svi_ptr(svihmm_ctx* h, int which) {
 #ifndef SVI_GW
 #define SVI_GW 8      // wavefronts of the k_svi_globals workgroups
 #endif
+// counters of the loop's device-side dependencies (host.h): [0] global-step workgroups, [1] globals-kernel
+// workgroups, [2] theta-builder workgroups, [3] ELBO side-chain workgroups; the gates' status word is slot 1 of the
+// mapped status block (slot 0: the theta builders')
+static unsigned* svi_cnt(svihmm_ctx* h, int which) { return (unsigned*)h->svi_sync.p + 16 * which; }
+static int* svi_gate_status(svihmm_ctx* h) {
+  int* d = nullptr;
+  if (h->pin_status && hipHostGetDevicePointer((void**)&d, h->pin_status, 0) == hipSuccess) return d + 1;
+  return nullptr;
+}
+static unsigned long long* svi_stamp_dev(svihmm_ctx* h, int idx) { return h->svi_ts_dev ? h->svi_ts_dev + idx : nullptr; }
+static int svi_launch_gate(svihmm_ctx* h, hipStream_t st, int which, unsigned tgt) {
+  if (tgt == 0) return 0;
+  SviSync sy = {svi_cnt(h, which), tgt, nullptr, h->svi_status_dev, nullptr};
+  hipLaunchKernelGGL(k_svi_gate, dim3(1), dim3(64), 0, st, sy);
+  HIPCK(hipGetLastError());
+  return 0;
+}
 static int svi_globals(svihmm_ctx* h, int slot) {
   const int K = h->svi_K;
   double* vi_out = svi_ptr(h, slot ? 7 : 2);
@@ -1237,8 +1265,15 @@ static int svi_globals(svihmm_ctx* h, int slot) {
     HIPCK(hipEventCreateWithFlags(&h->svi_eb, hipEventDisableTiming));
   }
   hipStream_t s2 = h->stream2;
-  HIPCK(hipEventRecord(h->svi_ea, h->stream));
-  HIPCK(hipStreamWaitEvent(s2, h->svi_ea, 0));
+  SviSync gsy = {nullptr, 0u, nullptr, nullptr, nullptr};
+  if (h->svi_flags) { gsy.arrive = svi_cnt(h, 1); h->tgt_glob += (unsigned)(K + 1); }
+  if (h->svi_flags && h->tgt_step > 0) {
+    // no event on the main stream: the side stream waits for the global steps launched so far in a one-wave gate
+    CK(svi_launch_gate(h, s2, 0, h->tgt_step));
+  } else {         // (svi_begin: behind the uploads of the main stream)
+    HIPCK(hipEventRecord(h->svi_ea, h->stream));
+    HIPCK(hipStreamWaitEvent(s2, h->svi_ea, 0));
+  }
   if (h->slack_a != h->Aexp.p || h->slack_t != h->AexpT.p || h->slack_k != K) {
     HIPCK(hipMemsetAsync((char*)h->Aexp.p + kk, 0, slack, s2));
     HIPCK(hipMemsetAsync((char*)h->AexpT.p + kk, 0, slack, s2));
@@ -1254,11 +1289,11 @@ static int svi_globals(svihmm_ctx* h, int slot) {
         hipFuncSetAttribute((const void*)k_svi_globals<true, SVI_GW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)work);
       hipLaunchKernelGGL((k_svi_globals<true, SVI_GW>), dim3(K + 1), dim3(64 * SVI_GW), work, s2, (const double*)svi_ptr(h, 0), K,
                          (double*)nullptr, (double*)h->ltran.p, (double*)h->Aexp.p, (double*)h->AexpT.p,
-                         vi_out, (double*)h->mod_init.p);
+                         vi_out, (double*)h->mod_init.p, gsy);
     } else {
       hipLaunchKernelGGL((k_svi_globals<false, SVI_GW>), dim3(K + 1), dim3(64 * SVI_GW), 0, s2, (const double*)svi_ptr(h, 0), K,
                          (double*)h->svi_work.p, (double*)h->ltran.p, (double*)h->Aexp.p, (double*)h->AexpT.p,
-                         vi_out, (double*)h->mod_init.p);
+                         vi_out, (double*)h->mod_init.p, gsy);
     }
     HIPCK(hipGetLastError());
   }
@@ -1281,23 +1316,40 @@ static int svi_refresh_emission(svihmm_ctx* h, int elbo_it, int lb_slot, hipEven
     HIPCK(hipEventCreateWithFlags(&h->svi_ec, hipEventDisableTiming));
     HIPCK(hipEventCreateWithFlags(&h->svi_ed, hipEventDisableTiming));
   }
+  // flags mode: the builder's K workgroups arrive on the theta counter (the ELBO kernels' gate) and workgroup 0
+  // stamps the end of the iteration
+  SviSync tsy = {nullptr, 0u, nullptr, nullptr, nullptr};
+  if (h->svi_flags) {
+    tsy.arrive = svi_cnt(h, 2);
+    h->tgt_theta += (unsigned)K;
+    if (elbo_it >= 0) { tsy.stamp = svi_stamp_dev(h, 2 * elbo_it + 1); tsy.stamp_at = h->tgt_theta; }
+  }
+  h->theta_sy = tsy;
   if (fam == 0) CK(launch_niw_to_theta(h, K, D, svi_ptr(h, 4)));
   else if (fam == 1) CK(launch_diag_to_theta(h, K, D));
   else {
     // E log theta[v][k] = psi(alpha_kv) - psi(sum_v alpha_kv) (what hmmbase._push_emission uploads)
     ProfScope ps(h, KS_MISC);
     hipLaunchKernelGGL(k_cat_table, dim3(K), dim3(64), 0, h->stream, (const double*)h->niw.p, K, h->V,
-                       (double*)h->cat_table.p);
+                       (double*)h->cat_table.p, tsy);
     HIPCK(hipGetLastError());
     h->eK = K; h->eD = 1; h->Kp = K > 64 ? (K + 63) / 64 * 64 : (K + 15) / 16 * 16;
     h->have_emission = true; h->emis_cat = true; h->emis_diag = false; h->uw_valid = false;
   }
+  h->theta_sy = SviSync{nullptr, 0u, nullptr, nullptr, nullptr};
   h->lin_stale = true;
   hipStream_t s2 = h->stream3;
-  // (the iteration's end-of-iteration timing event doubles as the fork point of the ELBO kernels)
-  hipEvent_t fork = after_theta ? after_theta : h->svi_ec;
-  HIPCK(hipEventRecord(fork, h->stream));
-  HIPCK(hipStreamWaitEvent(s2, fork, 0));
+  SviSync vsy = {nullptr, 0u, nullptr, nullptr, nullptr};
+  if (h->svi_flags) {
+    CK(svi_launch_gate(h, s2, 2, h->tgt_theta));
+    vsy.arrive = svi_cnt(h, 3);
+    h->tgt_side += (unsigned)(2 * K) + (elbo_it >= 0 ? 1u : 0u);
+  } else {
+    // (the iteration's end-of-iteration timing event doubles as the fork point of the ELBO kernels)
+    hipEvent_t fork = after_theta ? after_theta : h->svi_ec;
+    HIPCK(hipEventRecord(fork, h->stream));
+    HIPCK(hipStreamWaitEvent(s2, fork, 0));
+  }
   {
     ProfScope ps(h, KS_MISC, s2);
     if (fam == 0)
@@ -1305,17 +1357,17 @@ static int svi_refresh_emission(svihmm_ctx* h, int elbo_it, int lb_slot, hipEven
                          (const int*)h->fab.p, h->F, D, h->Kp, (const double*)h->niw.p,
                          (const double*)svi_ptr(h, 4), (const double*)h->svi_prior.p,
                          (const double*)svi_ptr(h, 5), h->svi_zsign, K, svi_ptr(h, 3),
-                         (const double*)svi_ptr(h, 1), (const double*)svi_ptr(h, 0), svi_ptr(h, 6));
+                         (const double*)svi_ptr(h, 1), (const double*)svi_ptr(h, 0), svi_ptr(h, 6), vsy);
     else
       hipLaunchKernelGGL(k_svi_vlb_simple, dim3(2 * K), dim3(64), 0, s2, fam, (const double*)h->niw.p,
                          (const double*)h->svi_prior.p, K, fam == 1 ? D : h->V, svi_ptr(h, 3),
-                         (const double*)svi_ptr(h, 1), (const double*)svi_ptr(h, 0), svi_ptr(h, 6));
+                         (const double*)svi_ptr(h, 1), (const double*)svi_ptr(h, 0), svi_ptr(h, 6), vsy);
     if (elbo_it >= 0) {
       double* delbo = nullptr;
       HIPCK(hipHostGetDevicePointer((void**)&delbo, h->svi_elbo, 0));
       hipLaunchKernelGGL(k_svi_elbo, dim3(1), dim3(64), 0, s2, K, (const double*)svi_ptr(h, 3),
                          (const double*)svi_ptr(h, 6), h->svi_prior_const, (const double*)svi_ptr(h, 8) + lb_slot,
-                         delbo + elbo_it);
+                         delbo + elbo_it, vsy);
     }
     HIPCK(hipGetLastError());
   }
@@ -1383,6 +1435,35 @@ static int svi_begin_common(svihmm_ctx* h, int K, int D, const double* prior_tra
     h->svi_elbo_cap = maxit;
   }
   for (int i = 0; i < maxit; ++i) h->svi_elbo[i] = NAN;
+  // device-side dependencies (variant[0] = 1: the stream-event choreography of rounds 2-4 instead)
+  h->svi_flags = h->variant[0] != 1;
+  h->tgt_step = h->tgt_glob = h->tgt_theta = h->tgt_side = 0;
+  if (h->svi_flags) {
+    // (begin is cold: the counters are zeroed with every stream idle, so no gate of this loop can see a
+    //  previous loop's counts)
+    CK(ensure(h->svi_sync, 4 * 64));
+    HIPCK(hipStreamSynchronize(h->stream));
+    HIPCK(hipMemset(h->svi_sync.p, 0, 4 * 64));
+    if (h->svi_ts_cap < 2 * maxit) {
+      if (h->svi_ts) hipHostFree(h->svi_ts);
+      h->svi_ts = nullptr; h->svi_ts_dev = nullptr; h->svi_ts_cap = 0;
+      HIPCK(hipHostMalloc((void**)&h->svi_ts, (size_t)2 * maxit * sizeof(unsigned long long) + 64, hipHostMallocMapped));
+      h->svi_ts_cap = 2 * maxit;
+      HIPCK(hipHostGetDevicePointer((void**)&h->svi_ts_dev, h->svi_ts, 0));
+    }
+    std::memset(h->svi_ts, 0, (size_t)2 * maxit * sizeof(unsigned long long));
+    if (!h->pin_status) {
+      HIPCK(hipHostMalloc((void**)&h->pin_status, 64, hipHostMallocMapped));
+      std::memset(h->pin_status, 0, 64);
+    }
+    h->pin_status[1] = 0;
+    h->svi_status_dev = svi_gate_status(h);
+    if (h->wall_clock_khz <= 0.0) {
+      int khz = 0;
+      if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device) != hipSuccess || khz <= 0) khz = 100000;
+      h->wall_clock_khz = (double)khz;
+    }
+  }
   while ((int)h->svi_ev.size() < 2 * maxit) {      // [2 it]: first launch of iteration it, [2 it + 1]: its last
     hipEvent_t e;
     HIPCK(hipEventCreate(&e));
@@ -1504,7 +1585,16 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
   // this marker right behind that iteration's end marker -- the end marker serves as both
   if ((int)h->svi_ev_begin.size() < h->svi_maxit) h->svi_ev_begin.resize(h->svi_maxit, 0);
   h->svi_ev_begin[it] = 2 * it;
-  if (it > 0 && h->svi_last_it == it - 1 && hipEventQuery(h->svi_ev[2 * it - 1]) == hipErrorNotReady)
+  if (h->svi_flags) {
+    // (stamps instead of events: the previous iteration's end stamp -- written by its theta builder into mapped
+    //  host memory -- is still 0 while that iteration runs)
+    if (it > 0 && h->svi_last_it == it - 1 && *(volatile unsigned long long*)&h->svi_ts[2 * it - 1] == 0)
+      h->svi_ev_begin[it] = 2 * it - 1;
+    else {
+      hipLaunchKernelGGL(k_svi_stamp, dim3(1), dim3(64), 0, h->stream, svi_stamp_dev(h, 2 * it));
+      HIPCK(hipGetLastError());
+    }
+  } else if (it > 0 && h->svi_last_it == it - 1 && hipEventQuery(h->svi_ev[2 * it - 1]) == hipErrorNotReady)
     h->svi_ev_begin[it] = 2 * it - 1;
   else
     HIPCK(hipEventRecord(h->svi_ev[2 * it], h->stream));
@@ -1517,7 +1607,9 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
   flags &= ~(uint32_t)SVIHMM_SVI_KEEP_WINDOW;
   if (B > 0) {
     h->svi_upload_it = it;
+    h->in_svi_estep = true;
     const int rc = estep_core(h, starts, B, Lm, inner_off, inner_len, flags);
+    h->in_svi_estep = false;
     h->svi_upload_it = -1;
     if (rc) return rc;
     // the last window's log-domain rows are rebuilt on demand from the CURRENT parameters:
@@ -1533,10 +1625,15 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
     ProfScope ps(h, KS_ALLREDUCE);
     CK(allreduce_packed_dev(h));
   }
-  CK(wait_globals(h));     // (an empty shard ran no sweeps)
+  CK(wait_globals(h));     // (an empty shard ran no sweeps; a gated sweep kernel has cleared the event)
   // the previous iteration's ELBO kernels (their own stream) read var_tran / theta / logdet,
-  // which this global step and the NIW kernel after it rewrite (normally long finished)
-  if (h->vlb_pending) { HIPCK(hipStreamWaitEvent(h->stream, h->svi_ed, 0)); h->vlb_pending = false; }
+  // which this global step and the NIW kernel after it rewrite (normally long finished): flags mode gates the
+  // step kernel on their counter, the event mode waits for their event
+  SviSync ssy = {nullptr, 0u, nullptr, nullptr, nullptr};
+  if (h->svi_flags) {
+    ssy.gate = svi_cnt(h, 3); ssy.gate_tgt = h->tgt_side; ssy.arrive = svi_cnt(h, 0); ssy.status = h->svi_status_dev;
+    if (h->tgt_side == 0) ssy.gate = nullptr;
+  } else if (h->vlb_pending) { HIPCK(hipStreamWaitEvent(h->stream, h->svi_ed, 0)); h->vlb_pending = false; }
   {
     ProfScope ps(h, KS_MISC);
     const unsigned ntran = (unsigned)((K * K + 255) / 256);
@@ -1545,16 +1642,18 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
       hipLaunchKernelGGL(k_svi_global_step, dim3((unsigned)K + ntran), dim3(256), (size_t)3 * D * sizeof(double), h->stream,
                          (const double*)h->packed.p, (const double*)svi_ptr(h, 1), svi_ptr(h, 0),
                          (double*)h->niw.p, (const double*)h->svi_prior.p, K, D, rho, bfactA, bfactE,
-                         (double)nwin_total, svi_ptr(h, 8) + (it & 1), adag);
+                         (double)nwin_total, svi_ptr(h, 8) + (it & 1), adag, ssy);
     else {
       const int W = h->svi_family == 1 ? D : h->V;
       const unsigned nem = (unsigned)(((size_t)K * W + 255) / 256);
       hipLaunchKernelGGL(k_svi_global_step_simple, dim3(nem + ntran), dim3(256), 0, h->stream, h->svi_family,
                          (const double*)h->packed.p, (const double*)svi_ptr(h, 1), svi_ptr(h, 0),
                          (double*)h->niw.p, (const double*)h->svi_prior.p, K, W, rho, bfactA, bfactE,
-                         (double)nwin_total, svi_ptr(h, 8) + (it & 1), adag, (int)nem);
+                         (double)nwin_total, svi_ptr(h, 8) + (it & 1), adag, (int)nem, ssy);
     }
     HIPCK(hipGetLastError());
+    if (h->svi_flags) h->tgt_step += (h->svi_family == 0 ? (unsigned)K + ntran
+                                                          : (unsigned)(((size_t)K * (h->svi_family == 1 ? D : h->V) + 255) / 256) + ntran);
   }
   // the next iteration's globals, ahead of time, forked right behind the global step (its own event:
   // forked behind theta together with the ELBO kernels it competes with the next emission GEMM,
@@ -1609,9 +1708,20 @@ int svihmm_svi_read_elbo(svihmm_ctx* h, int32_t n, double* out_elbo, double* out
   if (h->stream2) HIPCK(hipStreamSynchronize(h->stream2));
   if (h->stream3) HIPCK(hipStreamSynchronize(h->stream3));
   CK(check_emission_status(h));
+  if (h->svi_flags && h->pin_status && h->pin_status[1] != 0) {
+    h->pin_status[1] = 0;
+    h->svi_active = false;
+    return fail("svihmm_svi_read_elbo: a device-side dependency of the loop was not met within its bound (a kernel "
+                "of the loop did not run); the loop's state is not usable -- SVIHMM_VARIANT=0:1 runs the loop on stream events");
+  }
   for (int i = 0; i < n; ++i) {
     if (out_elbo) out_elbo[i] = h->svi_elbo[i];
-    if (out_ms) {
+    if (out_ms && h->svi_flags) {
+      // device wall-clock stamps: begin (k_svi_stamp, or the previous iteration's end) to the theta builder's end
+      const int bi = (int)h->svi_ev_begin.size() > i ? h->svi_ev_begin[i] : 2 * i;
+      const unsigned long long t0 = h->svi_ts[bi], t1 = h->svi_ts[2 * i + 1];
+      out_ms[i] = (t0 && t1 && t1 >= t0) ? (double)(t1 - t0) / h->wall_clock_khz : NAN;
+    } else if (out_ms) {
       float ms = 0.f;
       out_ms[i] = hipEventElapsedTime(&ms, h->svi_ev[(int)h->svi_ev_begin.size() > i ? h->svi_ev_begin[i] : 2 * i], h->svi_ev[2 * i + 1]) == hipSuccess ? (double)ms : NAN;
     }

@@ -92,7 +92,7 @@ int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out) {
     ProfScope ps(h, KS_MISC);
 #define NIWW(DM) hipLaunchKernelGGL(k_niw_to_theta_wave<DM>, dim3(K), dim3(64), 0, h->stream, (const double*)dmu, \
                                     (const double*)dsg, (const double*)dka, (const double*)dnu, K, D, Kp,   \
-                                    (double*)h->theta.p, dstatus, orbp, logdet_out, uwp)
+                                    (double*)h->theta.p, dstatus, orbp, logdet_out, uwp, h->theta_sy)
     if (emd) NIWW(64);
     else if (D <= 8) NIWW(8);
     else if (D <= 16) NIWW(16);
@@ -104,7 +104,7 @@ int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out) {
         hipFuncSetAttribute((const void*)k_niw_to_theta_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(k_niw_to_theta_generic, dim3(K), dim3(256), lds, h->stream, (const double*)dmu,
                          (const double*)dsg, (const double*)dka, (const double*)dnu, K, D, Kp,
-                         (double*)h->theta.p, dstatus, orbp, logdet_out);
+                         (double*)h->theta.p, dstatus, orbp, logdet_out, h->theta_sy);
     }
 #undef NIWW
     HIPCK(hipGetLastError());
@@ -138,7 +138,7 @@ int launch_diag_to_theta(svihmm_ctx* h, int K, int D) {
   {
     ProfScope ps(h, KS_MISC);
     hipLaunchKernelGGL(k_diag_to_theta, dim3(K), dim3(64), 0, h->stream, p, p + n, p + 2 * n, p + 3 * n, K, D, Kp,
-                       (double*)h->theta.p, dstatus);
+                       (double*)h->theta.p, dstatus, h->theta_sy);
     HIPCK(hipGetLastError());
   }
   h->status_pending = true;
@@ -293,7 +293,22 @@ int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled,
       HIPCK(hipGetLastError());
       h->orb_valid = true;
     }
-    // fewer than one 128-row workgroup per CU: 64-row workgroups (variant[5] = 2: always 128)
+    // minibatches (fewer than 32768 rows): 16-row workgroups, the four waves split the k-steps
+    // (k_emission_orbit_ks; variant[5] = 5: the 64-row form of round 3, 2: always 128 rows)
+    if ((n + 127) / 128 < 256 && h->variant[5] != 2 && h->variant[5] != 5) {
+      const int R0 = 3 * NT * 256 > 16 * LEN + 1 ? 3 * NT * 256 : ((16 * LEN + 1) & ~1);
+      const size_t lds = (size_t)(R0 + 16 * NT + 16) * 8 + 16;
+      dim3 grid((unsigned)((n + 15) / 16));
+#define EMK(NTV) hipLaunchKernelGGL((k_emission_orbit_ks<NTV>), grid, dim3(256), lds, stream,                      \
+                                    (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K,                          \
+                                    (const double*)h->theta_orb.p, flags, out, kexp_out, ll0_out,                  \
+                                    pend ? (int64_t*)h->starts.p : (int64_t*)nullptr, pend_n)
+      if (NT == 4) EMK(4); else if (NT == 3) EMK(3); else if (NT == 2) EMK(2); else EMK(1);
+#undef EMK
+      HIPCK(hipGetLastError());
+      return 0;
+    }
+    // fewer than one 128-row workgroup per CU: 64-row workgroups
     const int MTo = ((n + 127) / 128 < 256 && h->variant[5] != 2) ? 1 : 2;
     const int rows = 64 * MTo;
     const size_t lds = (size_t)rows * LEN * 8 + rows * 9;

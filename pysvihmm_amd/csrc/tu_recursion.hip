@@ -160,10 +160,30 @@ static int launch_lin_init(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_t st
   HIPCK(hipGetLastError());
   return 0;
 }
+// minibatch-sized batches, 16 < K <= 64: the kernels that split one window over one wave's registers (fp64,
+// k_wave_linr) or four waves (fp32 storage, k_wave_lin4)
+static bool minibatch_wave_kernel(const svihmm_ctx* h, int K, int nb, int Lm) {
+  if (K <= 16 || K > 64 || nb >= LIN_WAVE_MAX || h->variant[7] == 2 || h->variant[7] == 3) return false;
+  return h->cur_f32 ? nb <= LIN_WAVE4_MAX : (nb <= LIN_WAVER_MAX && Lm <= (1 << 20));
+}
+// SVI loop on counters (svihmm_hip.hip, svi_globals): those two kernels wait for the side stream's globals
+// kernel themselves -- no stream-order event in front of them
+static SviSync sweep_gate(svihmm_ctx* h, hipStream_t stream) {
+  SviSync sy = {nullptr, 0u, nullptr, nullptr, nullptr};
+  if (h->svi_flags && h->in_svi_estep && h->globals_ev && stream == h->stream && h->svi_sync.p) {
+    sy.gate = (const unsigned*)h->svi_sync.p + 16;
+    sy.gate_tgt = h->tgt_glob;
+    sy.status = h->svi_status_dev;
+    h->globals_ev = nullptr;
+  }
+  return sy;
+}
 // both sweeps over windows [b0, b0+nb) of the current batch on `stream` (buffers ensured):
 // one launch, blockIdx.y = direction
 int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_t stream) {
   const int K = h->K;
+  const bool wave_kernel = minibatch_wave_kernel(h, K, nb, Lm);
+  if (h->svi_flags && h->in_svi_estep && stream == h->stream && !wave_kernel) CK(wait_globals(h));
   // measurement only (tools/r4_overlap_probe.py): variant[7] = 9 skips the sweep launch -- the
   // statistics then read the previous step's messages; bounds what hiding the sweeps could give
 #ifdef SVIHMM_MEASURE
@@ -230,12 +250,12 @@ int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_t strea
                                        gx, llb, lz, zf)
 #define WL4F(KM) hipLaunchKernelGGL((k_wave_lin4<KM, float>), gw, dim3(256), 0, stream, Ef, kx, (const double*)h->Aexp.p, \
                                     (const double*)h->AexpT.p, mi, l0, l0s, Lm, K, af, bf, hx, gx, \
-                                    llb, lz, zf)
+                                    llb, lz, zf, gsy)
       // (round 5: the register-resident one-wave kernel k_wave_linr of the fp64 path was also built with fp32
       //  arithmetic: 278 against 303 ns per step, but over 257 steps the statistics drift to 1.2e-4 of the fp64
       //  oracle -- inside the mode's 1e-3, above this suite's 1e-4 canary; the fp32 mode keeps the four-wave
       //  kernel, which computes in fp64 on float storage)
-      if (K > 16 && nb <= LIN_WAVE4_MAX && h->variant[7] != 3) { WL4F(64); }
+      if (wave_kernel) { const SviSync gsy = sweep_gate(h, stream); WL4F(64); }
       else if (K <= 16) WLF(16, false); else if (K <= 32) WLF(32, false);
       else if (K == 64) WLF(64, true); else WLF(64, false);
 #undef WLF
@@ -267,9 +287,10 @@ int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_t strea
     // minibatch-sized batches, K > 16 (round 5): one wave per (window, direction) with the mat-vec in registers
     // (k_wave_linr; it replaces round 3's four-wave k_wave_lin4<64, double>: 316 against 319 ns per step with a
     // quarter of the waves and no LDS exchange; variant[7] = 3: the LDS-broadcast one-wave kernel below)
-    if (K > 16 && nb <= LIN_WAVER_MAX && Lm <= (1 << 20) && h->variant[7] != 3) {
+    if (wave_kernel) {
+      const SviSync gsy = sweep_gate(h, stream);
       hipLaunchKernelGGL((k_wave_linr<double>), gw, dim3(64), 0, stream, Eh, kx, (const double*)h->Aexp.p,
-                         (const double*)h->AexpT.p, mi, l0, l0s, Lm, K, ah, bh, hx, gx, llb, lz, zf);
+                         (const double*)h->AexpT.p, mi, l0, l0s, Lm, K, ah, bh, hx, gx, llb, lz, zf, gsy);
     }
     else if (K <= 16) WL(16, false); else if (K <= 32) WL(32, false);
     else if (K == 64) WL(64, true); else WL(64, false);
@@ -483,7 +504,10 @@ int launch_fb_chain(svihmm_ctx* h, int Lm, bool total) {
 
 int launch_fb_lin(svihmm_ctx* h, int B, int Lm, bool total) {
   if (!h->have_globals) return fail("no globals: call svihmm_set_globals");
-  if (use_chain(h, B, Lm)) return launch_fb_chain(h, Lm, total);
+  if (use_chain(h, B, Lm)) {
+    if (h->svi_flags && h->in_svi_estep) CK(wait_globals(h));    // (the chain kernels take no gate)
+    return launch_fb_chain(h, Lm, total);
+  }
   CK(ensure_fb_lin(h, B, Lm));
   CK(launch_fb_lin_range(h, 0, B, Lm, h->stream));
   if (total) h->lb_pending = B;   // summed by k_finalize's extra workgroup (or flush_lb)
