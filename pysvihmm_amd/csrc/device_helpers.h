@@ -185,15 +185,17 @@ __device__ __forceinline__ int feat_index_d(int a, int b, int D) {
 //  wall_clock64() stamps written by the kernels themselves.
 // ------------------------------------------------------------------------------------
 #define SVI_SYNC_TIMEOUT (1 << 22)
-#define SVI_SYNC_SPINS (1 << 21)          // x ~1 us of s_sleep: ~2 s, then the gate gives up
+#define SVI_SYNC_SPINS (1 << 21)          // x ~1 us per poll (sleep + load): a few seconds, then the gate gives up
 __device__ __forceinline__ void svi_gate(const SviSync& sy) {
   if (!sy.gate) return;
   if (threadIdx.x == 0) {
+    // (relaxed polls, one acquire fence at the end: an acquire load invalidates the caches on every poll)
     int n = 0;
-    while (__hip_atomic_load(sy.gate, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < sy.gate_tgt) {
-      __builtin_amdgcn_s_sleep(16);
+    while (__hip_atomic_load(sy.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sy.gate_tgt) {
+      __builtin_amdgcn_s_sleep(4);
       if (++n > SVI_SYNC_SPINS) { if (sy.status) atomicMax(sy.status, SVI_SYNC_TIMEOUT); break; }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
 }
@@ -201,7 +203,7 @@ __device__ __forceinline__ void svi_arrive(const SviSync& sy) {
   if (!sy.arrive) return;
   __syncthreads();                         // every thread's stores are issued and waited for (workgroup scope)
   if (threadIdx.x == 0) {
-    __threadfence();
+    // (release: the workgroup's stores -- ordered before this thread by the barrier -- are written back first)
     const unsigned before = __hip_atomic_fetch_add(sy.arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     if (sy.stamp && before + 1u == sy.stamp_at) *sy.stamp = wall_clock64();
   }

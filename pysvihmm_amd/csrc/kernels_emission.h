@@ -1378,11 +1378,13 @@ __device__ __forceinline__ void k_niw_to_theta_wave_body(
   if (a < DMAX) ms[a] = va ? mu[(size_t)k * D + a] : 0.0;
   // ---- right-looking Cholesky; padded rows/columns form an identity block
   bool bad = false;
+  double rdv[DMAX];                       // 1 / L[j][j] (uniform): the triangular inverse multiplies by it
 #pragma unroll
   for (int j = 0; j < DMAX; ++j) {
     const double djj = __shfl(A[j], j, 64);
     bad |= !(djj > 0.0);
     const double d = sqrt(djj), rd = 1.0 / d;
+    rdv[j] = rd;
     const double l = (a == j) ? d : A[j] * rd;
     A[j] = l;
     col[a] = l;
@@ -1415,7 +1417,7 @@ __device__ __forceinline__ void k_niw_to_theta_wave_body(
     double s = (r == c) ? 1.0 : 0.0;
 #pragma unroll
     for (int j = 0; j < r; ++j) s = fma(-Ls[r][j], X[j], s);   // X[j] = 0 for j < c
-    X[r] = (r >= c) ? s / Ls[r][r] : 0.0;
+    X[r] = (r >= c) ? s * rdv[r] : 0.0;
   }
   __syncthreads();
   if (a < DMAX) {
@@ -1514,6 +1516,15 @@ __device__ __forceinline__ void k_niw_to_theta_wave_body(
   }
   double wmi = 0.0;
   const int i = a;
+  // theta_store's index arithmetic, once per lane and per column instead of once per entry (the kernel is one
+  // wave issuing ~8000 instructions in a row; the per-entry divisions were a third of them).  Canonical row of
+  // the pair (i, j): fbase + j; orbit row: with S4 = 4 c Kp and t4(a) = 4 (a mod c) + a / c,
+  //   j - i <= D/2:  (t4(i) Kp + kk - i S4) + j S4        j - i > D/2:  (i S4 + kk) + (N - j) S4 + t4(j) Kp
+  const int Nn = D + 1, cq = (D >> 2) > 0 ? (D >> 2) : 1, S4 = 4 * cq * Kp;
+  const int kk = (k & 15) * (Kp >> 4) + (k >> 4);
+  const int t4 = 4 * (a % cq) + a / cq;
+  const int fbase = (a * (D + 1) - a * (a - 1) / 2 - a) * Kp + k;
+  const int oA = t4 * Kp + kk - a * S4, oB = a * S4 + kk;
 #pragma unroll
   for (int j = 0; j < DMAX; ++j) {
     double s = 0.0;
@@ -1521,10 +1532,24 @@ __device__ __forceinline__ void k_niw_to_theta_wave_body(
     for (int r = j; r < DMAX; ++r) s = fma(X[r], Ls[j][r], s);  // X[r][i] * X[r][j]; zero for r < max(i,j)
     const double w = hn * s;
     wmi = fma(w, ms[j], wmi);
-    if (theta && va && j >= i && j < D)
-      theta_store(theta, orb, i, j, D, Kp, k, (i == j) ? -w : -2.0 * w);
+    if (theta && va && j >= i && j < D) {
+      const double tv = (i == j) ? -w : -2.0 * w;
+      theta[fbase + j * Kp] = tv;
+      if (orb) {
+        const int t4j = __builtin_amdgcn_readlane(t4, j);
+        orb[(j - i <= (D >> 1)) ? oA + j * S4 : oB + (Nn - j) * S4 + t4j * Kp] = tv;
+      }
+    }
   }
-  if (theta && va) theta_store(theta, orb, i, D, D, Kp, k, 2.0 * wmi);
+  if (theta && va) {                      // the linear term (i, D): column D is the orbit's leftover block
+    const double tv = 2.0 * wmi;
+    theta[fbase + D * Kp] = tv;
+    if (orb) {
+      const int dl = i + 1;
+      orb[(D - i <= (D >> 1)) ? oA + D * S4
+                              : (4 * (cq * ((D >> 1) + 1) + (dl >> 2)) + (dl & 3)) * Kp + kk] = tv;
+    }
+  }
   // ---- constant term
   double dgm = va ? digamma_d(0.5 * (nu[k] - a)) : 0.0;
   double mWm = va ? ms[a < DMAX ? a : 0] * wmi : 0.0;

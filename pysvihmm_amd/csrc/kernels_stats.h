@@ -561,23 +561,37 @@ __global__ void k_finalize(const double* __restrict__ part, int nchunk, int D, i
     if (threadIdx.x == 0) packed[(size_t)K * K + (size_t)K * D + K + (size_t)K * D * (diag ? 1 : D)] = red[0];
     return;
   }
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)Ftot * Kp) return;
-  const int f = idx / Kp, k = idx - (int64_t)f * Kp;
-  if (k >= K) return;
-  // fixed summation order (4 interleaved partial sums) -> bit-reproducible
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  // 64 outputs per workgroup, wave q sums the chunks c = q (mod 4) of the whole groups of four (the tail goes
+  // to wave 0): the four interleaved partial sums of rounds 1-4 -- same additions in the same order, bit for
+  // bit -- with four times the loads in flight (the minibatch's ~100 chunks on 40 960 threads were
+  // latency-bound: 12 us of the 64-window iteration)
+  __shared__ double fsum[4][64];
+  const int q = threadIdx.x >> 6;
+  const int64_t idx = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const bool live = idx < (int64_t)Ftot * Kp;
+  const int f = live ? (int)(idx / Kp) : 0, k = live ? (int)(idx - (int64_t)f * Kp) : 0;
   const size_t stride = (size_t)Ftot * Kp;
-  const double* pp = part + (size_t)f * Kp + k;
-  int c = 0;
-  for (; c + 4 <= nchunk; c += 4) {
-    s0 += pp[(size_t)c * stride];
-    s1 += pp[(size_t)(c + 1) * stride];
-    s2 += pp[(size_t)(c + 2) * stride];
-    s3 += pp[(size_t)(c + 3) * stride];
+  {
+    const double* pp = part + (size_t)f * Kp + k;
+    const int n4 = nchunk & ~3;
+    double sq = 0.0;
+    if (live && k < K) {
+      int c = q;
+      for (; c + 12 < n4; c += 16) {
+        const double v0 = pp[(size_t)c * stride], v1 = pp[(size_t)(c + 4) * stride];
+        const double v2 = pp[(size_t)(c + 8) * stride], v3 = pp[(size_t)(c + 12) * stride];
+        sq += v0; sq += v1; sq += v2; sq += v3;
+      }
+      for (; c < n4; c += 4) sq += pp[(size_t)c * stride];
+      if (q == 0)
+        for (c = n4; c < nchunk; ++c) sq += pp[(size_t)c * stride];
+    }
+    fsum[q][threadIdx.x & 63] = sq;
   }
-  for (; c < nchunk; ++c) s0 += pp[(size_t)c * stride];
-  const double s = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (q != 0 || !live || k >= K) return;
+  const int ln = threadIdx.x & 63;
+  const double s = (fsum[0][ln] + fsum[1][ln]) + (fsum[2][ln] + fsum[3][ln]);
   double* A = packed;
   double* xbar = A + (size_t)K * K;
   double* neff = xbar + (size_t)K * D;

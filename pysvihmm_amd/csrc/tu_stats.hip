@@ -313,7 +313,7 @@ int launch_stats_finalize(svihmm_ctx* h, int64_t nchunk, hipStream_t stream) {
   const int64_t tot = (int64_t)(Fp + Kp) * Kp;
   const int lbB = h->lb_pending;     // deferred ELBO total of the scaled sweeps rides along
   h->lb_pending = 0;
-  hipLaunchKernelGGL(k_finalize, dim3((unsigned)((tot + 255) / 256) + (lbB ? 1 : 0)), dim3(256), 0, stream,
+  hipLaunchKernelGGL(k_finalize, dim3((unsigned)((tot + 63) / 64) + (lbB ? 1 : 0)), dim3(256), 0, stream,
                      (const double*)h->part.p, (int)nchunk, D, K, Kp, Fp, F,
                      (const int*)h->fab.p, (double*)h->packed.p,
                      (const double*)(lbB ? h->local_lb.p : nullptr), lbB, h->emis_diag ? 1 : 0);

@@ -601,7 +601,9 @@ class HipEngine(object):
         return self._lib.svihmm_last_kernel_name(self._h, names.index(slot_name)).decode()
 
     def set_variant(self, which, value):
-        idx = {"emission": 0, "stats": 1, "fb": 2, "emission_mt": 3, "pipeline": 4, "emission_orbit": 5, "chain": 6}[which] if isinstance(which, str) else which
+        # ("svi_loop" = 1: the resident SVI loop on stream events instead of device-side counters; it shares
+        #  slot 0 with the retired "emission" choice, whose values the library ignores)
+        idx = {"emission": 0, "svi_loop": 0, "stats": 1, "fb": 2, "emission_mt": 3, "pipeline": 4, "emission_orbit": 5, "chain": 6}[which] if isinstance(which, str) else which
         L.check(self._lib.svihmm_set_variant(self._h, idx, int(value)), "set_variant")
 
     def selftest_mfma(self, A, B):

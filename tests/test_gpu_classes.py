@@ -272,6 +272,51 @@ def test_svi_iteration_engine_level(K, D, B, Lm):
     np.testing.assert_allclose(qa, qb, rtol=1e-6, atol=1e-11)
 
 
+@pytest.mark.parametrize("K,D,B,Lm", [(64, 8, 9, 33), (100, 3, 6, 17), (20, 5, 210, 9)])
+def test_svi_loop_on_counters_equals_the_stream_event_loop(K, D, B, Lm):
+    """The resident loop orders its streams with device-side counters (gated kernels: the minibatch sweeps wait
+    for the globals kernel themselves, the global step for the ELBO kernels) -- round 5; variant "svi_loop" = 1
+    keeps the stream-event choreography of rounds 2-4.  Same kernels on the same data in the same order: the
+    variational state and the ELBO trace must agree bit for bit, and both report per-iteration times.  K = 64
+    takes the gated wave kernel, K = 100 / B = 210 sweeps that take the globals event instead."""
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd.distributions import niw_prior_logpart
+    from pysvihmm_amd import _lib as L
+    from tests.helpers import make_problem
+    T, nit = 4000, 9
+    pb = make_problem(K, D, T, seed=K + D)
+    rng = np.random.default_rng(K)
+    prior_tran = 1.0 + rng.random((K, K))
+    mu0 = np.tile(pb["obs"].mean(0), (K, 1)) + 0.1 * rng.normal(size=(K, D))
+    sg0 = np.tile(0.75 * np.cov(pb["obs"].T).reshape(D, D), (K, 1, 1))
+    ka0, nu0 = np.full(K, 0.01), np.full(K, D + 2.0)
+    bA, bE = (T - 2 * 8 - 1) / (2. * 8 * B), (T - 2 * 8 - 1) / ((2. * 8 + 1) * B)
+    res = []
+    for events in (0, 1):
+        eng = HipEngine(0)
+        try:
+            eng.set_variant("svi_loop", events)
+            eng.set_obs(pb["obs"], pb["mask"])
+            eng.svi_begin(prior_tran, pb["var_tran"], (mu0, sg0, ka0, nu0),
+                          (pb["mu"], pb["sigma"], pb["kappa"], pb["nu"]), niw_prior_logpart(sg0, nu0), nit, 1.0)
+            r2 = np.random.default_rng(5)
+            for it in range(nit):
+                starts = r2.integers(0, T - Lm, size=B)
+                eng.svi_iteration(it, starts, B, Lm, L.TRANS_WRAP, (it + 1.0) ** -0.7, bA, bE)
+                if it == 4:
+                    eng.svi_read_elbo(it + 1)          # a mid-loop read drains every stream and the loop goes on
+            elbo, ms = eng.svi_read_elbo(nit)
+            res.append((eng.svi_read_state(), elbo, ms))
+        finally:
+            eng.close()
+    (sa, ea, ma), (sb, eb, mb) = res
+    for n, a, b in zip(("var_tran", "var_init", "mu", "sigma", "kappa", "nu"), sa, sb):
+        np.testing.assert_array_equal(a, b, err_msg=n)
+    np.testing.assert_array_equal(ea, eb)
+    assert np.all(np.isfinite(ea))
+    assert np.all(ma > 0) and np.all(ma < 50) and np.all(mb > 0) and np.all(mb < 50), (ma, mb)
+
+
 @pytest.mark.parametrize("K,D,Lm,S", [(1, 1, 3, 2), (2, 1, 1, 5), (3, 2, 5, 1), (7, 40, 9, 4)])
 def test_device_loop_edge_shapes(K, D, Lm, S):
     """Degenerate shapes through the device-resident loop vs the oracle engine: a single state
