@@ -187,6 +187,8 @@ __device__ __forceinline__ int feat_index_d(int a, int b, int D) {
 #define SVI_SYNC_TIMEOUT (1 << 22)
 #define SVI_SYNC_SPINS (1 << 21)          // x ~1 us per poll (sleep + load): a few seconds, then the gate gives up
 __device__ __forceinline__ void svi_gate(const SviSync& sy) {
+  if (sy.early && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0)
+    __hip_atomic_fetch_add(sy.early, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (!sy.gate) return;
   if (threadIdx.x == 0) {
     // (relaxed polls, one acquire fence at the end: an acquire load invalidates the caches on every poll)

@@ -188,6 +188,11 @@ struct svihmm_ctx {
   unsigned tgt_step = 0, tgt_glob = 0, tgt_theta = 0, tgt_side = 0;
   bool svi_flags = false;          // this loop runs on counters instead of stream-order events
   int* svi_status_dev = nullptr;   // device address of pin_status[1]: a gate that gave up
+  // ELBO kernels of iteration it, launched during the host call of iteration it + 1 behind its sweeps' gate
+  // (they then run beside the sweeps' 128 waves instead of beside the emission GEMM)
+  bool elbo_pending = false; int elbo_pend_it = -1, elbo_pend_slot = 0;
+  unsigned tgt_early = 0;          // sweep launches that signal their start (counter 4)
+  bool sweep_signalled = false;    // this E-step's sweep launch does
   bool in_svi_estep = false;       // estep_core is running for svihmm_svi_iteration
   unsigned long long* svi_ts = nullptr; unsigned long long* svi_ts_dev = nullptr; int svi_ts_cap = 0;   // pinned + mapped: [2 it] begin, [2 it + 1] end (wall_clock64)
   SviSync theta_sy = {nullptr, 0u, nullptr, nullptr, nullptr};   // what the next theta-builder launch arrives on
@@ -289,6 +294,7 @@ StatsPlan stats_plan(const svihmm_ctx* h, int64_t n, int forced = 0);
 int upload_feature_table(svihmm_ctx* h, int D, int K, bool diag = false);
 bool use_chain(const svihmm_ctx* h, int B, int Lm);
 int wait_globals(svihmm_ctx* h);
+int svi_flush_elbo(svihmm_ctx* h);
 int ensure_starts_pulled(svihmm_ctx* h);
 int cat_uncentre(svihmm_ctx* h);
 int launch_fb_chain(svihmm_ctx* h, int Lm, bool total);

@@ -23,4 +23,6 @@ struct SviSync {
   int* status;                 // raised to SVI_SYNC_TIMEOUT when a gate gives up
   unsigned long long* stamp;   // the workgroup whose arrival brings *arrive to stamp_at stores wall_clock64() here
   unsigned stamp_at;           //   (the kernel's last workgroup; nullptr: none)
+  unsigned* early;             // += 1 by the kernel's first workgroup as soon as it runs ("my predecessors on the
+                               //   stream are done": the deferred ELBO kernels' gate; nullptr: none)
 };

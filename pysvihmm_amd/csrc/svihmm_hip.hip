@@ -823,6 +823,7 @@ static int wait_side_streams(svihmm_ctx* h) {
   // (flags mode, inside the loop's E-step: the sweeps gate on the globals counter -- or take the event themselves,
   //  launch_fb_lin_range -- and the global step gates on the ELBO kernels' counter)
   if (h->svi_flags && h->in_svi_estep) return 0;
+  CK(svi_flush_elbo(h));
   CK(wait_globals(h));
   if (h->vlb_pending) { HIPCK(hipStreamWaitEvent(h->stream, h->svi_ed, 0)); h->vlb_pending = false; }
   return 0;
@@ -1309,7 +1310,9 @@ static int svi_globals(svihmm_ctx* h, int slot) {
 // theta + log det for the factors now in h->niw (main stream: the next emission GEMM needs theta);
 // their ELBO term vlb[] and, with elbo_it >= 0, elbo_vec[elbo_it] on the side stream -- only the
 // ELBO trace needs them, so they stay off the critical path of the iteration chain.
-static int svi_refresh_emission(svihmm_ctx* h, int elbo_it, int lb_slot, hipEvent_t after_theta = nullptr) {
+static int svi_launch_elbo(svihmm_ctx* h, int elbo_it, int lb_slot, bool behind_sweeps, hipEvent_t after_theta);
+static int svi_refresh_emission(svihmm_ctx* h, int elbo_it, int lb_slot, hipEvent_t after_theta = nullptr,
+                                bool defer_elbo = false) {
   const int K = h->svi_K, D = h->svi_D, fam = h->svi_family;
   if (!h->stream3) HIPCK(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
   if (!h->svi_ec) {
@@ -1338,10 +1341,25 @@ static int svi_refresh_emission(svihmm_ctx* h, int elbo_it, int lb_slot, hipEven
   }
   h->theta_sy = SviSync{nullptr, 0u, nullptr, nullptr, nullptr};
   h->lin_stale = true;
+#ifdef SVIHMM_MEASURE
+  if (h->variant[0] == 9) return 0;    // measurement only: no ELBO kernels at all
+#endif
+  if (h->svi_flags && defer_elbo && elbo_it >= 0) {
+    // launched by the next svihmm_svi_iteration behind its sweeps (svi_launch_elbo), or by whoever needs them first
+    h->elbo_pending = true; h->elbo_pend_it = elbo_it; h->elbo_pend_slot = lb_slot;
+    return 0;
+  }
+  return svi_launch_elbo(h, elbo_it, lb_slot, false, after_theta);
+}
+// The ELBO terms of the factors now in h->niw / theta (side stream).  `behind_sweeps`: additionally gated on the
+// start of the sweep launch that carries counter 4.
+static int svi_launch_elbo(svihmm_ctx* h, int elbo_it, int lb_slot, bool behind_sweeps, hipEvent_t after_theta) {
+  const int K = h->svi_K, D = h->svi_D, fam = h->svi_family;
   hipStream_t s2 = h->stream3;
   SviSync vsy = {nullptr, 0u, nullptr, nullptr, nullptr};
   if (h->svi_flags) {
     CK(svi_launch_gate(h, s2, 2, h->tgt_theta));
+    if (behind_sweeps) CK(svi_launch_gate(h, s2, 4, h->tgt_early));
     vsy.arrive = svi_cnt(h, 3);
     h->tgt_side += (unsigned)(2 * K) + (elbo_it >= 0 ? 1u : 0u);
   } else {
@@ -1374,6 +1392,12 @@ static int svi_refresh_emission(svihmm_ctx* h, int elbo_it, int lb_slot, hipEven
   HIPCK(hipEventRecord(h->svi_ed, s2));
   h->vlb_pending = true;
   return 0;
+}
+// deferred ELBO kernels, now and ungated: somebody is about to wait for the side stream or to rewrite what they read
+int svi_flush_elbo(svihmm_ctx* h) {
+  if (!h->elbo_pending) return 0;
+  h->elbo_pending = false;
+  return svi_launch_elbo(h, h->elbo_pend_it, h->elbo_pend_slot, false, nullptr);
 }
 
 // What the three families' begin calls share: range check of the transition factor, the resident
@@ -1437,13 +1461,14 @@ static int svi_begin_common(svihmm_ctx* h, int K, int D, const double* prior_tra
   for (int i = 0; i < maxit; ++i) h->svi_elbo[i] = NAN;
   // device-side dependencies (variant[0] = 1: the stream-event choreography of rounds 2-4 instead)
   h->svi_flags = h->variant[0] != 1;
-  h->tgt_step = h->tgt_glob = h->tgt_theta = h->tgt_side = 0;
+  h->tgt_step = h->tgt_glob = h->tgt_theta = h->tgt_side = h->tgt_early = 0;
+  h->elbo_pending = false;
   if (h->svi_flags) {
     // (begin is cold: the counters are zeroed with every stream idle, so no gate of this loop can see a
     //  previous loop's counts)
-    CK(ensure(h->svi_sync, 4 * 64));
+    CK(ensure(h->svi_sync, 8 * 64));
     HIPCK(hipStreamSynchronize(h->stream));
-    HIPCK(hipMemset(h->svi_sync.p, 0, 4 * 64));
+    HIPCK(hipMemset(h->svi_sync.p, 0, 8 * 64));
     if (h->svi_ts_cap < 2 * maxit) {
       if (h->svi_ts) hipHostFree(h->svi_ts);
       h->svi_ts = nullptr; h->svi_ts_dev = nullptr; h->svi_ts_cap = 0;
@@ -1608,9 +1633,15 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
   if (B > 0) {
     h->svi_upload_it = it;
     h->in_svi_estep = true;
+    h->sweep_signalled = false;
     const int rc = estep_core(h, starts, B, Lm, inner_off, inner_len, flags);
     h->in_svi_estep = false;
     h->svi_upload_it = -1;
+    // the previous iteration's ELBO kernels: behind this iteration's sweeps when their launch signals its start
+    if (rc == 0 && h->elbo_pending) {
+      h->elbo_pending = false;
+      CK(svi_launch_elbo(h, h->elbo_pend_it, h->elbo_pend_slot, h->sweep_signalled, nullptr));
+    }
     if (rc) return rc;
     // the last window's log-domain rows are rebuilt on demand from the CURRENT parameters:
     // do it now, before the global step replaces them
@@ -1625,6 +1656,7 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
     ProfScope ps(h, KS_ALLREDUCE);
     CK(allreduce_packed_dev(h));
   }
+  CK(svi_flush_elbo(h));   // (an empty shard, or an E-step that failed over to an ungated path)
   CK(wait_globals(h));     // (an empty shard ran no sweeps; a gated sweep kernel has cleared the event)
   // the previous iteration's ELBO kernels (their own stream) read var_tran / theta / logdet,
   // which this global step and the NIW kernel after it rewrite (normally long finished): flags mode gates the
@@ -1669,7 +1701,7 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
     h->svi_f32_ok = h->svi_vmin > 0.05;
   }
   if (it + 1 < h->svi_maxit) CK(svi_globals(h, h->svi_vi_cur ^ 1));
-  CK(svi_refresh_emission(h, it, it & 1, h->svi_ev[2 * it + 1]));
+  CK(svi_refresh_emission(h, it, it & 1, h->svi_ev[2 * it + 1], it + 1 < h->svi_maxit));
   return 0;
 }
 
@@ -1704,6 +1736,7 @@ int svihmm_svi_read_adagrad(svihmm_ctx* h, double* ada_G_out) {
 int svihmm_svi_read_elbo(svihmm_ctx* h, int32_t n, double* out_elbo, double* out_ms) {
   if (!h || !h->svi_active || n < 0 || n > h->svi_maxit) return fail("svihmm_svi_read_elbo: bad arguments");
   CK(set_device(h));
+  CK(svi_flush_elbo(h));
   HIPCK(hipStreamSynchronize(h->stream));
   if (h->stream2) HIPCK(hipStreamSynchronize(h->stream2));
   if (h->stream3) HIPCK(hipStreamSynchronize(h->stream3));

@@ -169,12 +169,18 @@ static bool minibatch_wave_kernel(const svihmm_ctx* h, int K, int nb, int Lm) {
 // SVI loop on counters (svihmm_hip.hip, svi_globals): those two kernels wait for the side stream's globals
 // kernel themselves -- no stream-order event in front of them
 static SviSync sweep_gate(svihmm_ctx* h, hipStream_t stream) {
-  SviSync sy = {nullptr, 0u, nullptr, nullptr, nullptr};
+  SviSync sy = {nullptr, 0u, nullptr, nullptr, nullptr, 0u, nullptr};
   if (h->svi_flags && h->in_svi_estep && h->globals_ev && stream == h->stream && h->svi_sync.p) {
     sy.gate = (const unsigned*)h->svi_sync.p + 16;
     sy.gate_tgt = h->tgt_glob;
     sy.status = h->svi_status_dev;
     h->globals_ev = nullptr;
+  }
+  if (h->svi_flags && h->in_svi_estep && stream == h->stream && h->svi_sync.p && h->elbo_pending) {
+    // the deferred ELBO kernels of the previous iteration start with these sweeps (svihmm_svi_iteration)
+    sy.early = (unsigned*)h->svi_sync.p + 16 * 4;
+    ++h->tgt_early;
+    h->sweep_signalled = true;
   }
   return sy;
 }
