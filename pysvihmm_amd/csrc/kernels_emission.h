@@ -735,38 +735,44 @@ __device__ __forceinline__ void emb_step_barrier() {
 
 // MT = row tiles of 32 per wave: 2 (large batches: 256-row workgroups, two per CU) or 1 (round 5, batches with
 // fewer than one 256-row workgroup per CU -- the 64-window minibatch: 128-row workgroups, half the chain per pair)
-template <int MT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_emission_bf16x3(
+// NH = groups of four waves that split the state pairs of the same 128 rows (minibatch form, MT = 1: the chain of
+// a wave is npair / NH steps instead of npair, the groups' waves share the SIMDs and fill each other's VALU
+// phases; each group stages its own pair record, every wave finishes the rows / NH of its tile in the epilogue)
+template <int MT, int NH, int RW>
+__device__ __forceinline__ void emission_bf16x3_body(
     const double* __restrict__ obs, const uint8_t* __restrict__ mask,
     const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K,
     const char* __restrict__ uw, uint32_t flags,
     float* __restrict__ Eh, double* __restrict__ kexp, double* __restrict__ ll0,
-    int64_t* __restrict__ starts_copy = nullptr, int nstarts = 0) {
-  constexpr int ROWS = 128 * MT, WR = 32 * MT;            // rows per workgroup / per wave
+    int64_t* __restrict__ starts_copy, int nstarts) {
+  constexpr int ROWS = 32 * RW * MT, WR = 32 * MT;        // rows per workgroup / per wave
   // (SVI loop: `starts` is the host's pinned slot, see k_emission_orbit; workgroup 0 leaves the device copy)
   if (starts_copy && blockIdx.x == 0)
-    for (int i = threadIdx.x; i < nstarts; i += 256) starts_copy[i] = starts[i];
+    for (int i = threadIdx.x; i < nstarts; i += 64 * RW * NH) starts_copy[i] = starts[i];
   extern __shared__ uint4 smem4[];
-  char* stage = reinterpret_cast<char*>(smem4);                      // [EMB_REC]: one pair record
-  float* tile_s = reinterpret_cast<float*>(stage + EMB_REC);         // [4 waves][WR rows][64 states]
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = wv % RW, sh = wv / RW;                            // row wave, pair group
+  char* stage = reinterpret_cast<char*>(smem4) + sh * EMB_REC;       // [NH][EMB_REC]: one pair record per group
+  float* tile_s = reinterpret_cast<float*>(reinterpret_cast<char*>(smem4) + NH * EMB_REC);   // [RW waves][WR rows][64 states]
   const int t = lane & 31, hh = lane >> 5;
   const int64_t g0 = (int64_t)blockIdx.x * ROWS;
   const int npair = (K + 1) >> 1;
+  const int nh = (npair + NH - 1) / NH, sp0 = sh * nh;               // this group's pairs: [sp0, sp0 + nh)
 
-  // pair record p -> the LDS buffer, branch-free: every wave issues three 1 KB copies (chunks wave,
-  // 4 + wave and min(8 + wave, 9); the last chunk is copied by waves 1..3 alike)
-  const int ch3 = (8 + wave < 9 ? 8 + wave : 9) * 1024;
+  // pair record p -> the group's LDS buffer, branch-free: the group's RW waves issue ceil(10 / RW) 1 KB copies each
+  // (chunks wave, RW + wave, ..., clamped to the last chunk, which some waves copy alike)
   auto stage_load = [&](int pr) {
 #if !(defined(EMB_KO) && (EMB_KO & 2))
     const char* src = uw + (size_t)pr * EMB_REC + lane * 16;
-    emb_glds16(src + wave * 1024, stage + wave * 1024);
-    emb_glds16(src + (4 + wave) * 1024, stage + (4 + wave) * 1024);
-    emb_glds16(src + ch3, stage + ch3);
+#pragma unroll
+    for (int c = 0; c < (10 + RW - 1) / RW; ++c) {
+      const int ch = (wave + c * RW < 9 ? wave + c * RW : 9) * 1024;
+      emb_glds16(src + ch, stage + ch);
+    }
 #endif
   };
-  stage_load(0);
+  stage_load(sp0);
 
   // ---- the lane's two rows: dimensions 16 c + 8 hh + e as three bf16 terms (B operands)
   embf8_t xb[MT][3][2];
@@ -829,7 +835,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // on its way under this pair's 36 MFMAs, barrier (it has landed).
   float* tw = tile_s + wave * WR * 64;
   const emf16_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int sp = 0; sp < npair; ++sp) {
+  for (int si = 0; si < nh; ++si) {
+    const int sp = sp0 + si;
     embf8_t a[3][3];
     emf16_t bv[2];
     float cst[2];
@@ -896,19 +903,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const float keep = hh ? pp[1][m] : pp[0][m];
       const float recv = __shfl_xor(send, 32, 64);
       const int r = m * 32 + t;
-      tw[r * 64 + (kl ^ ((r & 15) << 2))] = keep + recv;
+      if (NH == 1 || sp < npair) tw[r * 64 + (kl ^ ((r & 15) << 2))] = keep + recv;
     }
     emb_step_barrier();
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  if constexpr (NH == 1) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    __syncthreads();                                                 // the other groups' columns of the tile
+  }
 
   // ---- scaled epilogue: Eh = exp(ll) 2^-k, k = ceil(max_j ll / ln 2); 16 lanes per row of the
   //      wave's own tile, four adjacent states each
   const int sg = lane & 15, rq = lane >> 4;
   const double L2E = 1.4426950408889634074;
   const float l2e = 1.44269504f, fbig = 3.0e38f;
-  for (int it = 0; it < 8 * MT; ++it) {
+  for (int it = sh * (8 * MT / NH); it < (sh + 1) * (8 * MT / NH); ++it) {
     const int rl = it * 4 + rq;
     const int64_t g = g0 + wave * WR + rl;
     const float4 v4 = *reinterpret_cast<const float4*>(tw + rl * 64 + ((4 * sg) ^ ((rl & 15) << 2)));
@@ -945,6 +956,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
   }
+}
+template <int MT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_emission_bf16x3(
+    const double* __restrict__ obs, const uint8_t* __restrict__ mask,
+    const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K,
+    const char* __restrict__ uw, uint32_t flags,
+    float* __restrict__ Eh, double* __restrict__ kexp, double* __restrict__ ll0,
+    int64_t* __restrict__ starts_copy = nullptr, int nstarts = 0) {
+  emission_bf16x3_body<MT, 1, 4>(obs, mask, starts, nrows, Lm, D, K, uw, flags, Eh, kexp, ll0, starts_copy, nstarts);
+}
+template <int NH, int RW>
+__global__ __launch_bounds__(64 * RW * NH) void k_emission_bf16x3h(
+    const double* __restrict__ obs, const uint8_t* __restrict__ mask,
+    const int64_t* __restrict__ starts, int64_t nrows, int Lm, int D, int K,
+    const char* __restrict__ uw, uint32_t flags,
+    float* __restrict__ Eh, double* __restrict__ kexp, double* __restrict__ ll0,
+    int64_t* __restrict__ starts_copy = nullptr, int nstarts = 0) {
+  emission_bf16x3_body<1, NH, RW>(obs, mask, starts, nrows, Lm, D, K, uw, flags, Eh, kexp, ll0, starts_copy, nstarts);
 }
 
 // ------------------------------------------------------------------------------------

@@ -233,10 +233,22 @@ int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled,
       hipLaunchKernelGGL(k_emission_bf16x3<2>, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, stream,
                          (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, (const char*)uwp,
                          flags, (float*)out, kexp_out, ll0_out, pend ? (int64_t*)h->starts.p : (int64_t*)nullptr, pend_n);
-    else
+    else if (h->variant[5] == 8)        // (one group of four waves: the form of the round's first half)
       hipLaunchKernelGGL(k_emission_bf16x3<1>, dim3((unsigned)((n + 127) / 128)), dim3(256), lds, stream,
                          (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, (const char*)uwp,
                          flags, (float*)out, kexp_out, ll0_out, pend ? (int64_t*)h->starts.p : (int64_t*)nullptr, pend_n);
+    else {
+      // minibatches: the state pairs of a row tile split over groups of waves on different SIMDs -- 32-row
+      // workgroups of four one-wave groups up to ~2 tiles per CU (the 64-window minibatch: 514 workgroups, 22 us
+      // against 26 for the 128-row form; 30 windows: 12), 64-row workgroups of two two-wave groups above
+      // (tools/probe/emb_probe.hip)
+#define EMH(NHV, RWV) hipLaunchKernelGGL((k_emission_bf16x3h<NHV, RWV>), dim3((unsigned)((n + 32 * RWV - 1) / (32 * RWV))), \
+                         dim3(64 * (NHV) * (RWV)), (size_t)(NHV) * EMB_REC + (size_t)(RWV) * 32 * 64 * 4, stream,      \
+                         (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K, (const char*)uwp,                       \
+                         flags, (float*)out, kexp_out, ll0_out, pend ? (int64_t*)h->starts.p : (int64_t*)nullptr, pend_n)
+      if ((n + 31) / 32 <= 520) EMH(4, 1); else EMH(2, 2);
+#undef EMH
+    }
     HIPCK(hipGetLastError());
     return 0;
   }
