@@ -1745,14 +1745,14 @@ template <typename CT> struct WlrBias;
 template <> struct WlrBias<double> { static constexpr int v = 1022; };
 template <> struct WlrBias<float> { static constexpr int v = 126; };
 template <typename CT> struct WlrRing { CT v[64][65]; };      // [step & 63][state]: a lane later sums ITS step's row
-template <bool FWD, bool FULLK, typename ST>
+template <bool FWD, bool FULLK, typename ST, typename CT>
 __device__ __forceinline__ void wave_linr_body(
     const ST* __restrict__ Eh, const double* __restrict__ kexp,
     const double* __restrict__ Am, const double* __restrict__ mod_init,
     const double* __restrict__ ll0, size_t l0stride, int Lm, int K, ST* __restrict__ out,
     double* __restrict__ xout, double* __restrict__ local_lb, double* __restrict__ logz,
-    double2* __restrict__ zfac, WlrRing<ST>& ring) {
-  typedef ST CT;                                // arithmetic type of the mat-vec = storage type
+    double2* __restrict__ zfac, WlrRing<CT>& ring) {
+  // (CT = arithmetic type of the mat-vec; ST = storage type of Eh and of the messages)
   const int b = blockIdx.x, j = threadIdx.x;
   const int r = j >> 4, c = j & 15;
   const bool valid = FULLK || j < K;
@@ -1901,7 +1901,7 @@ __device__ __forceinline__ void wave_linr_body(
     zfac[b] = make_double2(1.0 / zm, hd + zexp);
   }
 }
-template <typename ST = double>
+template <typename ST = double, typename CT = ST>
 __global__ __launch_bounds__(64) void k_wave_linr(
     const ST* __restrict__ Eh, const double* __restrict__ kexp,
     const double* __restrict__ Aexp, const double* __restrict__ AexpT,
@@ -1910,14 +1910,14 @@ __global__ __launch_bounds__(64) void k_wave_linr(
     ST* __restrict__ bh, double* __restrict__ hx, double* __restrict__ gx,
     double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac,
     SviSync sy = SviSync{nullptr, 0u, nullptr, nullptr, nullptr}) {
-  __shared__ WlrRing<ST> ring;
+  __shared__ WlrRing<CT> ring;
   svi_gate(sy);                                 // (SVI loop: the globals kernel of the side stream has arrived)
   if (blockIdx.y == 0) {
-    if (K == 64) wave_linr_body<true, true, ST>(Eh, kexp, Aexp, mod_init, ll0, l0stride, Lm, K, ah, hx, local_lb, logz, zfac, ring);
-    else wave_linr_body<true, false, ST>(Eh, kexp, Aexp, mod_init, ll0, l0stride, Lm, K, ah, hx, local_lb, logz, zfac, ring);
+    if (K == 64) wave_linr_body<true, true, ST, CT>(Eh, kexp, Aexp, mod_init, ll0, l0stride, Lm, K, ah, hx, local_lb, logz, zfac, ring);
+    else wave_linr_body<true, false, ST, CT>(Eh, kexp, Aexp, mod_init, ll0, l0stride, Lm, K, ah, hx, local_lb, logz, zfac, ring);
   } else {
-    if (K == 64) wave_linr_body<false, true, ST>(Eh, kexp, AexpT, mod_init, ll0, l0stride, Lm, K, bh, gx, local_lb, logz, zfac, ring);
-    else wave_linr_body<false, false, ST>(Eh, kexp, AexpT, mod_init, ll0, l0stride, Lm, K, bh, gx, local_lb, logz, zfac, ring);
+    if (K == 64) wave_linr_body<false, true, ST, CT>(Eh, kexp, AexpT, mod_init, ll0, l0stride, Lm, K, bh, gx, local_lb, logz, zfac, ring);
+    else wave_linr_body<false, false, ST, CT>(Eh, kexp, AexpT, mod_init, ll0, l0stride, Lm, K, bh, gx, local_lb, logz, zfac, ring);
   }
 }
 

@@ -1733,6 +1733,16 @@ int svihmm_svi_read_adagrad(svihmm_ctx* h, double* ada_G_out) {
   return d2h_sync_small(h, ada_G_out, svi_ptr(h, 9), (size_t)h->svi_K * h->svi_K * sizeof(double));
 }
 
+// after a synchronisation of the main stream: did a gate of the loop give up (device_helpers.h, svi_gate)?
+static int svi_gate_check(svihmm_ctx* h) {
+  if (h->svi_flags && h->pin_status && h->pin_status[1] != 0) {
+    h->pin_status[1] = 0;
+    h->svi_active = false;
+    return fail("SVI loop: a device-side dependency was not met within its bound (a kernel of the loop did not "
+                "run); the loop's state is not usable -- variant 0 = 1 runs the loop on stream events");
+  }
+  return 0;
+}
 int svihmm_svi_read_elbo(svihmm_ctx* h, int32_t n, double* out_elbo, double* out_ms) {
   if (!h || !h->svi_active || n < 0 || n > h->svi_maxit) return fail("svihmm_svi_read_elbo: bad arguments");
   CK(set_device(h));
@@ -1741,12 +1751,7 @@ int svihmm_svi_read_elbo(svihmm_ctx* h, int32_t n, double* out_elbo, double* out
   if (h->stream2) HIPCK(hipStreamSynchronize(h->stream2));
   if (h->stream3) HIPCK(hipStreamSynchronize(h->stream3));
   CK(check_emission_status(h));
-  if (h->svi_flags && h->pin_status && h->pin_status[1] != 0) {
-    h->pin_status[1] = 0;
-    h->svi_active = false;
-    return fail("svihmm_svi_read_elbo: a device-side dependency of the loop was not met within its bound (a kernel "
-                "of the loop did not run); the loop's state is not usable -- SVIHMM_VARIANT=0:1 runs the loop on stream events");
-  }
+  CK(svi_gate_check(h));
   for (int i = 0; i < n; ++i) {
     if (out_elbo) out_elbo[i] = h->svi_elbo[i];
     if (out_ms && h->svi_flags) {
@@ -1779,6 +1784,7 @@ int svihmm_svi_read_state(svihmm_ctx* h, double* var_tran, double* var_init, dou
   HIPCK(hipStreamSynchronize(h->stream));
   if (h->stream3) HIPCK(hipStreamSynchronize(h->stream3));   // ELBO kernels still reading niw / theta
   h->vlb_pending = false;
+  CK(svi_gate_check(h));
   if (mu) from_centred(h, mu, (int)K, (int)D);
   CK(check_emission_status(h));
   return 0;
@@ -1798,6 +1804,7 @@ int svihmm_svi_read_factors(svihmm_ctx* h, double* var_tran, double* var_init, d
   HIPCK(hipStreamSynchronize(h->stream));
   if (h->stream3) HIPCK(hipStreamSynchronize(h->stream3));   // ELBO kernels still reading the factors
   h->vlb_pending = false;
+  CK(svi_gate_check(h));
   if (factors_out && h->svi_family != 2) from_centred(h, factors_out, (int)K, (int)D);
   CK(check_emission_status(h));
   return 0;

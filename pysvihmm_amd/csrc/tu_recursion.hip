@@ -261,7 +261,13 @@ int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_t strea
       //  arithmetic: 278 against 303 ns per step, but over 257 steps the statistics drift to 1.2e-4 of the fp64
       //  oracle -- inside the mode's 1e-3, above this suite's 1e-4 canary; the fp32 mode keeps the four-wave
       //  kernel, which computes in fp64 on float storage)
-      if (wave_kernel) { const SviSync gsy = sweep_gate(h, stream); WL4F(64); }
+      if (wave_kernel && nb <= LIN_WAVER_MAX && Lm <= (1 << 20) && h->variant[7] != 4) {
+        // (round 5, second half: the one-wave register-resident kernel with fp64 arithmetic on the float storage)
+        const SviSync gsy = sweep_gate(h, stream);
+        hipLaunchKernelGGL((k_wave_linr<float, double>), gw, dim3(64), 0, stream, Ef, kx, (const double*)h->Aexp.p,
+                           (const double*)h->AexpT.p, mi, l0, l0s, Lm, K, af, bf, hx, gx, llb, lz, zf, gsy);
+      }
+      else if (wave_kernel) { const SviSync gsy = sweep_gate(h, stream); WL4F(64); }
       else if (K <= 16) WLF(16, false); else if (K <= 32) WLF(32, false);
       else if (K == 64) WLF(64, true); else WLF(64, false);
 #undef WLF
