@@ -260,7 +260,7 @@ int svihmm_estep_minibatch_ex(svihmm_ctx* h, const int64_t* starts, int32_t B,
  * svihmm_svi_read_elbo: elbo_vec[0..n) and the device time of each iteration in ms (device clock:
  *   from the iteration's first kernel -- or the end of the previous iteration when the loop runs back
  *   to back -- to the last workgroup of its theta builder; either may be NULL).  The loop orders its
- *   streams with device-side counters; a dependency that is not met within a few seconds (a kernel of
+ *   streams with device-side counters; a dependency that is not met within a minute (a kernel of
  *   the loop never ran) makes this call fail and ends the loop.  svihmm_svi_read_state: current var_tran [K,K], var_init [K] (the stationary vector
  *   of the last iteration, quirk Q5), NIW factors; any pointer may be NULL. */
 int svihmm_svi_begin(svihmm_ctx* h, int32_t K, int32_t D, const double* prior_tran,

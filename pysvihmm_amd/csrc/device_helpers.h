@@ -179,23 +179,30 @@ __device__ __forceinline__ int feat_index_d(int a, int b, int D) {
 //  before); the loop's cross-stream edges -- global step -> globals kernel, globals -> sweeps, theta ->
 //  ELBO kernels, ELBO kernels -> next global step -- and its timing marks are therefore carried by
 //  monotonic counters in HBM: a producer's workgroups ARRIVE (agent-scope release) when their stores are
-//  done, a consumer's workgroups GATE on the expected total (agent-scope acquire; bounded spin -- a
-//  timeout raises the status word instead of hanging the queue), side streams start their kernels behind a
+//  done, a consumer's workgroups GATE on the expected total (agent-scope acquire; bounded spin -- after
+//  60 s a timeout raises the status word instead of hanging the queue), side streams start their kernels behind a
 //  one-wave k_svi_gate so that nothing squats on a CU while it waits, and the iteration boundaries are
 //  wall_clock64() stamps written by the kernels themselves.
 // ------------------------------------------------------------------------------------
 #define SVI_SYNC_TIMEOUT (1 << 22)
-#define SVI_SYNC_SPINS (1 << 21)          // x ~1 us per poll (sleep + load): a few seconds, then the gate gives up
+// a gate gives up after this many ticks of the 100 MHz device wall clock (60 s: a gate launched early legitimately
+// waits for as long as the iteration in front of it runs -- tens of ms for an epoch-sized "minibatch" of a wide model)
+#define SVI_SYNC_TICKS 6000000000ull
 __device__ __forceinline__ void svi_gate(const SviSync& sy) {
   if (sy.early && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0)
     __hip_atomic_fetch_add(sy.early, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (!sy.gate) return;
   if (threadIdx.x == 0) {
     // (relaxed polls, one acquire fence at the end: an acquire load invalidates the caches on every poll)
-    int n = 0;
+    const unsigned long long t0 = wall_clock64();
+    unsigned n = 0;
     while (__hip_atomic_load(sy.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sy.gate_tgt) {
-      __builtin_amdgcn_s_sleep(4);
-      if (++n > SVI_SYNC_SPINS) { if (sy.status) atomicMax(sy.status, SVI_SYNC_TIMEOUT); break; }
+      if (++n < 256u) { __builtin_amdgcn_s_sleep(4); continue; }       // ~0.1 us naps first, ~2 us later
+      __builtin_amdgcn_s_sleep(64);
+      if ((n & 255u) == 0u && wall_clock64() - t0 > SVI_SYNC_TICKS) {
+        if (sy.status) atomicMax(sy.status, SVI_SYNC_TIMEOUT);
+        break;
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }

@@ -1,7 +1,8 @@
-"""Orbit-schedule emission GEMM (k_emission_orbit: the scaled E-step emission for D % 8 == 0,
-K <= 64) against the C oracle and against the table-driven kernel it replaces, over every
-state-tile count (NT = 1..4, ragged K), every supported D, masked (missing) rows and row counts
-that are not a multiple of the 128-row tile."""
+"""Orbit-schedule emission GEMM (the scaled E-step emission for D % 8 == 0, K <= 64) against the C oracle and
+against the table-driven kernel it replaces, over every state-tile count (NT = 1..4, ragged K), every
+supported D, masked (missing) rows and row counts that are not a multiple of any tile -- in all three forms:
+k_emission_orbit_ks (16-row workgroups, k-steps split over the waves: what batches below 32 768 rows take),
+k_emission_orbit<.., 1> (64-row workgroups) and k_emission_orbit<.., 2> (128-row workgroups: large batches)."""
 import numpy as np
 import pytest
 
@@ -42,6 +43,10 @@ def test_orbit_vs_oracle_and_table(eng, K, D):
         scale = np.abs(ref).max()
         np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-11 * scale)
         np.testing.assert_allclose(a, ref, rtol=1e-6, atol=1e-9 * scale)
+        for form in (5, 2):                  # the row-tile forms on the same batch
+            eng.set_variant("emission_orbit", form)
+            c = eng.estep(starts, Lm, flags=flags).buf.copy()
+            np.testing.assert_allclose(c, a, rtol=1e-9, atol=1e-11 * scale, err_msg="form %d" % form)
     eng.set_variant("emission_orbit", 0)
 
 

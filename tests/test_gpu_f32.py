@@ -330,18 +330,26 @@ def test_f32_wide_models_and_d_above_32_vs_fp64_oracle(K, D, B, Lm):
         e.close()
 
 
-def test_f32_s64_minibatch_vs_fp64_oracle():
+@pytest.mark.parametrize("B,form", [(64, 0), (64, 8), (100, 0), (31, 0)],
+                         ids=["64w_32row_groups", "64w_128row", "100w_64row_groups", "31w_below_floor"])
+def test_f32_s64_minibatch_vs_fp64_oracle(B, form):
     """The literal configs[2] minibatch (64 windows of 257 rows, K = 64, D = 32) in the fp32 mode against the
-    fp64 C oracle: the 128-row form of the centred bf16 emission kernel (k_emission_bf16x3<1>), the four-wave
-    sweep (fp64 arithmetic on float messages) and the bf16 statistics kernel with six-tile feature groups."""
+    fp64 C oracle: the minibatch forms of the centred bf16 emission kernel -- k_emission_bf16x3h<4, 1> (32-row
+    workgroups, the state pairs split over four one-wave groups; up to ~2 tiles per CU), <2, 2> (64-row
+    workgroups, two two-wave groups: 100 windows) and the 128-row k_emission_bf16x3<1> (variant 5 = 8) --, the
+    one-wave register-resident sweep with fp64 arithmetic on float messages (k_wave_linr<float, double>) and the
+    bf16 statistics kernel with six-tile feature groups.  31 windows lie below the bf16 kernels' 8192-row floor: the
+    fp32 format with the fp64 feature GEMM writing float Eh (k_emission_orbit_ks) and the fp32-input MFMA statistics."""
     from pysvihmm_amd.engine import HipEngine
     from pysvihmm_amd import _lib as L
     from oracle import ref_c
-    K, D, B, Lm, T = 64, 32, 64, 257, 40000
+    K, D, Lm, T = 64, 32, 257, 40000
     pb = make_problem(K, D, T, seed=64, miss=0.0, sep=4.0)
     starts = (np.arange(B, dtype=np.int64) * (T // B)) % (T - Lm)
     e = HipEngine(0, dtype="f32")
     try:
+        if form:
+            e.set_variant("emission_orbit", form)
         e.set_obs(pb["obs"], None)
         e.set_globals(pb["mod_init"], pb["ltran"])
         e.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
