@@ -840,13 +840,14 @@ def svi_iteration(eng, obs_host):
         hmm.infer()
         return time.perf_counter() - t0, hmm
     run(5)
-    # (the call's fixed part -- uploads, the final read-back -- is ~12 ms with a few ms of jitter: 240 iterations
-    #  between the two lengths keep it below 0.01 ms per iteration; tools/svi_wall_vs_device.py shows the wall
-    #  time linear in maxit with the device's own per-iteration times as slope)
-    n1, n2 = 70, 310
-    t1 = min(run(n1)[0] for _ in range(3))
+    # (the call's fixed part -- uploads, the final read-back -- is ~12 ms and jitters by several ms from call to
+    #  call: 2000 iterations between the two lengths and medians instead of minima keep that below 0.003 ms per
+    #  iteration; tools/svi_wall_vs_device.py shows the wall time linear in maxit with the device's own
+    #  per-iteration times as slope.  Rounds 2-5 differenced infer(70) - infer(10): +-0.02 ms of noise.)
+    n1, n2 = 100, 2100
+    t1 = float(np.median([run(n1)[0] for _ in range(3)]))
     t2s = [run(n2) for _ in range(3)]
-    t2 = min(t[0] for t in t2s)
+    t2 = float(np.median([t[0] for t in t2s]))
     hmm = t2s[-1][1]
     per_it = (t2 - t1) / (n2 - n1)
     assert np.all(np.isfinite(hmm.elbo_vec))

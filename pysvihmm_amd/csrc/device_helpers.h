@@ -196,7 +196,8 @@ __device__ __forceinline__ void svi_gate(const SviSync& sy) {
     // (relaxed polls, one acquire fence at the end: an acquire load invalidates the caches on every poll)
     const unsigned long long t0 = wall_clock64();
     unsigned n = 0;
-    while (__hip_atomic_load(sy.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sy.gate_tgt) {
+    // (counters and targets are 32-bit and only ever grow: compared by their signed difference, so a long loop may wrap them)
+    while ((int)(__hip_atomic_load(sy.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - sy.gate_tgt) < 0) {
       if (++n < 256u) { __builtin_amdgcn_s_sleep(4); continue; }       // ~0.1 us naps first, ~2 us later
       __builtin_amdgcn_s_sleep(64);
       if ((n & 255u) == 0u && wall_clock64() - t0 > SVI_SYNC_TICKS) {

@@ -185,13 +185,14 @@ struct svihmm_ctx {
   // device-side dependencies of the loop (round 5, device_helpers.h): counters [step | globals | theta | side] in
   // HBM with the totals the host expects, the status word of the gates, iteration stamps in mapped host memory
   Buf svi_sync;
-  unsigned tgt_step = 0, tgt_glob = 0, tgt_theta = 0, tgt_side = 0;
+  // (64-bit on the host, their low 32 bits on the device: the counters wrap, svi_gate compares signed differences)
+  unsigned long long tgt_step = 0, tgt_glob = 0, tgt_theta = 0, tgt_side = 0;
   bool svi_flags = false;          // this loop runs on counters instead of stream-order events
   int* svi_status_dev = nullptr;   // device address of pin_status[1]: a gate that gave up
   // ELBO kernels of iteration it, launched during the host call of iteration it + 1 behind its sweeps' gate
   // (they then run beside the sweeps' 128 waves instead of beside the emission GEMM)
   bool elbo_pending = false; int elbo_pend_it = -1, elbo_pend_slot = 0;
-  unsigned tgt_early = 0;          // sweep launches that signal their start (counter 4)
+  unsigned long long tgt_early = 0;   // sweep launches that signal their start (counter 4)
   bool sweep_signalled = false;    // this E-step's sweep launch does
   bool in_svi_estep = false;       // estep_core is running for svihmm_svi_iteration
   unsigned long long* svi_ts = nullptr; unsigned long long* svi_ts_dev = nullptr; int svi_ts_cap = 0;   // pinned + mapped: [2 it] begin, [2 it + 1] end (wall_clock64)

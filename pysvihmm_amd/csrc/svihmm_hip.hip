@@ -1239,9 +1239,9 @@ static int* svi_gate_status(svihmm_ctx* h) {
   return nullptr;
 }
 static unsigned long long* svi_stamp_dev(svihmm_ctx* h, int idx) { return h->svi_ts_dev ? h->svi_ts_dev + idx : nullptr; }
-static int svi_launch_gate(svihmm_ctx* h, hipStream_t st, int which, unsigned tgt) {
+static int svi_launch_gate(svihmm_ctx* h, hipStream_t st, int which, unsigned long long tgt) {
   if (tgt == 0) return 0;
-  SviSync sy = {svi_cnt(h, which), tgt, nullptr, h->svi_status_dev, nullptr};
+  SviSync sy = {svi_cnt(h, which), (unsigned)tgt, nullptr, h->svi_status_dev, nullptr};
   hipLaunchKernelGGL(k_svi_gate, dim3(1), dim3(64), 0, st, sy);
   HIPCK(hipGetLastError());
   return 0;
@@ -1325,7 +1325,7 @@ static int svi_refresh_emission(svihmm_ctx* h, int elbo_it, int lb_slot, hipEven
   if (h->svi_flags) {
     tsy.arrive = svi_cnt(h, 2);
     h->tgt_theta += (unsigned)K;
-    if (elbo_it >= 0) { tsy.stamp = svi_stamp_dev(h, 2 * elbo_it + 1); tsy.stamp_at = h->tgt_theta; }
+    if (elbo_it >= 0) { tsy.stamp = svi_stamp_dev(h, 2 * elbo_it + 1); tsy.stamp_at = (unsigned)h->tgt_theta; }
   }
   h->theta_sy = tsy;
   if (fam == 0) CK(launch_niw_to_theta(h, K, D, svi_ptr(h, 4)));
@@ -1489,7 +1489,8 @@ static int svi_begin_common(svihmm_ctx* h, int K, int D, const double* prior_tra
       h->wall_clock_khz = (double)khz;
     }
   }
-  while ((int)h->svi_ev.size() < 2 * maxit) {      // [2 it]: first launch of iteration it, [2 it + 1]: its last
+  // (event choreography only: the counter loop times its iterations with device stamps)
+  while (!h->svi_flags && (int)h->svi_ev.size() < 2 * maxit) {      // [2 it]: first launch of iteration it, [2 it + 1]: its last
     hipEvent_t e;
     HIPCK(hipEventCreate(&e));
     h->svi_ev.push_back(e);
@@ -1663,7 +1664,7 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
   // step kernel on their counter, the event mode waits for their event
   SviSync ssy = {nullptr, 0u, nullptr, nullptr, nullptr};
   if (h->svi_flags) {
-    ssy.gate = svi_cnt(h, 3); ssy.gate_tgt = h->tgt_side; ssy.arrive = svi_cnt(h, 0); ssy.status = h->svi_status_dev;
+    ssy.gate = svi_cnt(h, 3); ssy.gate_tgt = (unsigned)h->tgt_side; ssy.arrive = svi_cnt(h, 0); ssy.status = h->svi_status_dev;
     if (h->tgt_side == 0) ssy.gate = nullptr;
   } else if (h->vlb_pending) { HIPCK(hipStreamWaitEvent(h->stream, h->svi_ed, 0)); h->vlb_pending = false; }
   {
@@ -1701,7 +1702,7 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
     h->svi_f32_ok = h->svi_vmin > 0.05;
   }
   if (it + 1 < h->svi_maxit) CK(svi_globals(h, h->svi_vi_cur ^ 1));
-  CK(svi_refresh_emission(h, it, it & 1, h->svi_ev[2 * it + 1], it + 1 < h->svi_maxit));
+  CK(svi_refresh_emission(h, it, it & 1, h->svi_flags ? (hipEvent_t) nullptr : h->svi_ev[2 * it + 1], it + 1 < h->svi_maxit));
   return 0;
 }
 

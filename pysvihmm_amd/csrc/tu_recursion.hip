@@ -172,7 +172,7 @@ static SviSync sweep_gate(svihmm_ctx* h, hipStream_t stream) {
   SviSync sy = {nullptr, 0u, nullptr, nullptr, nullptr, 0u, nullptr};
   if (h->svi_flags && h->in_svi_estep && h->globals_ev && stream == h->stream && h->svi_sync.p) {
     sy.gate = (const unsigned*)h->svi_sync.p + 16;
-    sy.gate_tgt = h->tgt_glob;
+    sy.gate_tgt = (unsigned)h->tgt_glob;
     sy.status = h->svi_status_dev;
     h->globals_ev = nullptr;
   }
