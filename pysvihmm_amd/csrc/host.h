@@ -188,6 +188,7 @@ struct svihmm_ctx {
   // (64-bit on the host, their low 32 bits on the device: the counters wrap, svi_gate compares signed differences)
   unsigned long long tgt_step = 0, tgt_glob = 0, tgt_theta = 0, tgt_side = 0;
   bool svi_flags = false;          // this loop runs on counters instead of stream-order events
+  int svi_concurrent = -1;         // -1 not probed; 1: kernels of two streams run side by side (svi_probe_concurrency)
   int* svi_status_dev = nullptr;   // device address of pin_status[1]: a gate that gave up
   // ELBO kernels of iteration it, launched during the host call of iteration it + 1 behind its sweeps' gate
   // (they then run beside the sweeps' 128 waves instead of beside the emission GEMM)

@@ -566,5 +566,22 @@ __global__ __launch_bounds__(64) void k_cat_table(const double* __restrict__ alp
 // one wave that waits for a counter: what a side stream runs in front of a kernel whose inputs another stream
 // produces (instead of hipStreamWaitEvent on an event recorded between two kernels of the main chain)
 __global__ __launch_bounds__(64) void k_svi_gate(SviSync sy) { svi_gate(sy); }
+// Can a kernel of one stream run while a kernel of another stream spins?  (svi_begin_common: a tool that lets one
+// kernel at a time onto the device -- rocprofv3 --pmc, AMD_SERIALIZE_KERNEL -- may dispatch a gate before the
+// kernel it waits for and then never lets that kernel in; the loop falls back to stream events there.)  The waiter
+// reports that it runs, then waits up to `ticks` of the device wall clock for the setter's flag.
+__global__ __launch_bounds__(64) void k_svi_probe_wait(const unsigned* flag, unsigned* started, unsigned* result,
+                                                       unsigned long long ticks) {
+  if (threadIdx.x != 0) return;
+  __hip_atomic_store(started, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  const unsigned long long t0 = wall_clock64();
+  unsigned seen = 0;
+  while (!(seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) && wall_clock64() - t0 < ticks)
+    __builtin_amdgcn_s_sleep(8);
+  __hip_atomic_store(result, seen ? 1u : 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ __launch_bounds__(64) void k_svi_probe_set(unsigned* flag) {
+  if (threadIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
 // iteration-begin stamp when the loop does not run back to back (first iteration, after a host-side hook)
 __global__ __launch_bounds__(64) void k_svi_stamp(unsigned long long* ts) { if (threadIdx.x == 0) *ts = wall_clock64(); }

@@ -1246,6 +1246,30 @@ static int svi_launch_gate(svihmm_ctx* h, hipStream_t st, int which, unsigned lo
   HIPCK(hipGetLastError());
   return 0;
 }
+// One-time probe per handle (see k_svi_probe_wait): the waiter goes first and the setter is launched only once
+// the waiter reports that it is running, so the outcome does not depend on which queue a serialising tool serves
+// first.  ~30 us where kernels overlap, 2 ms where they do not.
+static int svi_probe_concurrency(svihmm_ctx* h) {
+  if (h->svi_concurrent >= 0) return 0;
+  if (!h->stream2) HIPCK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+  unsigned* pin = reinterpret_cast<unsigned*>(h->pin_status);      // words 2, 3: started / result (mapped)
+  unsigned* dpin = nullptr;
+  HIPCK(hipHostGetDevicePointer((void**)&dpin, pin, 0));
+  unsigned* flag = svi_cnt(h, 6);
+  volatile unsigned* vp = pin;
+  vp[2] = 0; vp[3] = 2;
+  HIPCK(hipMemset(flag, 0, sizeof(unsigned)));
+  hipLaunchKernelGGL(k_svi_probe_wait, dim3(1), dim3(64), 0, h->stream2, (const unsigned*)flag, dpin + 2, dpin + 3,
+                     200000ull);
+  HIPCK(hipGetLastError());
+  for (int spin = 0; spin < 2000000 && vp[2] == 0; ++spin) { for (volatile int w = 0; w < 20; ++w) {} }
+  hipLaunchKernelGGL(k_svi_probe_set, dim3(1), dim3(64), 0, h->stream, flag);
+  HIPCK(hipGetLastError());
+  HIPCK(hipStreamSynchronize(h->stream2));
+  HIPCK(hipStreamSynchronize(h->stream));
+  h->svi_concurrent = vp[3] == 1 ? 1 : 0;
+  return 0;
+}
 static int svi_globals(svihmm_ctx* h, int slot) {
   const int K = h->svi_K;
   double* vi_out = svi_ptr(h, slot ? 7 : 2);
@@ -1483,6 +1507,10 @@ static int svi_begin_common(svihmm_ctx* h, int K, int D, const double* prior_tra
     }
     h->pin_status[1] = 0;
     h->svi_status_dev = svi_gate_status(h);
+    // a device that runs one kernel at a time (a counter-collecting profiler, serialised launches) cannot carry
+    // spinning gates: stream events there
+    CK(svi_probe_concurrency(h));
+    if (h->svi_concurrent != 1) h->svi_flags = false;
     if (h->wall_clock_khz <= 0.0) {
       int khz = 0;
       if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device) != hipSuccess || khz <= 0) khz = 100000;

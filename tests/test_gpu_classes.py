@@ -317,6 +317,61 @@ def test_svi_loop_on_counters_equals_the_stream_event_loop(K, D, B, Lm):
     assert np.all(ma > 0) and np.all(ma < 50) and np.all(mb > 0) and np.all(mb < 50), (ma, mb)
 
 
+_SERIAL_LOOP = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from pysvihmm_amd.engine import HipEngine
+from pysvihmm_amd.distributions import niw_prior_logpart
+from pysvihmm_amd import _lib as L
+from tests.helpers import make_problem
+K, D, B, Lm, T, nit = 64, 8, 9, 33, 4000, 6
+pb = make_problem(K, D, T, seed=K + D)
+rng = np.random.default_rng(K)
+prior_tran = 1.0 + rng.random((K, K))
+mu0 = np.tile(pb["obs"].mean(0), (K, 1)) + 0.1 * rng.normal(size=(K, D))
+sg0 = np.tile(0.75 * np.cov(pb["obs"].T).reshape(D, D), (K, 1, 1))
+ka0, nu0 = np.full(K, 0.01), np.full(K, D + 2.0)
+eng = HipEngine(0)
+eng.set_obs(pb["obs"], pb["mask"])
+eng.svi_begin(prior_tran, pb["var_tran"], (mu0, sg0, ka0, nu0), (pb["mu"], pb["sigma"], pb["kappa"], pb["nu"]),
+              niw_prior_logpart(sg0, nu0), nit, 1.0)
+r2 = np.random.default_rng(5)
+for it in range(nit):
+    eng.svi_iteration(it, r2.integers(0, T - Lm, size=B), B, Lm, L.TRANS_WRAP, (it + 1.0) ** -0.7, 7.0, 6.5)
+elbo, ms = eng.svi_read_elbo(nit)
+st = eng.svi_read_state()
+eng.close()
+np.savez(sys.argv[2], elbo=elbo, ms=ms, var_tran=st[0], mu=st[2], sigma=st[3])
+"""
+
+
+def test_svi_loop_falls_back_to_stream_events_when_kernels_are_serialised(tmp_path):
+    """A tool that lets one kernel at a time onto the device (rocprofv3 --pmc, AMD_SERIALIZE_KERNEL=3) cannot carry
+    the loop's spinning gates -- a gate dispatched ahead of the kernel it waits for would keep that kernel out
+    until its 60 s bound.  svihmm_svi_begin probes whether a kernel of a second stream runs beside a spinning one
+    (k_svi_probe_wait / _set) and takes the stream-event choreography when it does not: the serialised process
+    must finish promptly with the same numbers as the unserialised one."""
+    import subprocess, sys, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "serial_loop.py"
+    script.write_text(_SERIAL_LOOP)
+    outs = []
+    for serial in (False, True):
+        env = dict(os.environ)
+        env.pop("AMD_SERIALIZE_KERNEL", None)
+        if serial:
+            env["AMD_SERIALIZE_KERNEL"] = "3"
+        out = tmp_path / ("serial.npz" if serial else "plain.npz")
+        t0 = time.time()
+        subprocess.run([sys.executable, str(script), root, str(out)], check=True, env=env, timeout=240, cwd=root)
+        assert time.time() - t0 < 120, "the loop stalled on a gate"
+        outs.append(np.load(out))
+    a, b = outs
+    for k in ("elbo", "var_tran", "mu", "sigma"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert np.all(a["ms"] > 0) and np.all(b["ms"] > 0)
+
+
 @pytest.mark.parametrize("K,D,Lm,S", [(1, 1, 3, 2), (2, 1, 1, 5), (3, 2, 5, 1), (7, 40, 9, 4)])
 def test_device_loop_edge_shapes(K, D, Lm, S):
     """Degenerate shapes through the device-resident loop vs the oracle engine: a single state
