@@ -1650,7 +1650,7 @@ __global__ __launch_bounds__(256) void k_wave_lin4(
 //  product stay double.
 // ------------------------------------------------------------------------------------
 #ifndef WLR_KO
-#define WLR_KO 0      // measurement knock-outs of k_wave_linr (tools/probe/wlr_probe.hip); 0 in the product
+#define WLR_KO 0      // measurement knock-outs / add-ons of k_wave_linr (tools/probe/wlr_probe.hip); 0 in the product
 #endif
 typedef unsigned wr_u2 __attribute__((ext_vector_type(2)));
 template <int N, bool FIRST = false>
@@ -1861,6 +1861,14 @@ __device__ __forceinline__ void wave_linr_body(
       xb[rowof(s - 63 + j)] = (double)hkeep;
       if (FWD) ring_flush(64);
     }
+#if WLR_KO & 48
+    // measurement only (tools/probe/wlr_probe.hip): what publishing the sweep's progress would cost -- an
+    // agent-scope release every 32 (bit 16) or 16 (bit 32) steps + one relaxed store of the step
+    if ((s & ((WLR_KO & 32) ? 15 : 31)) == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (j == 0) __hip_atomic_store(reinterpret_cast<int*>(zfac + b) + (FWD ? 0 : 1), s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#endif
   };
   int s = 1;
   for (; s + PD <= Lm; s += PD) {
