@@ -2,7 +2,8 @@
 // B windows of Lm rows, K = 64, random scaled inputs.  HIP events around REPS launches; tools only.
 //   hipcc ... [-DWLR_KO=<bits>] -o wlr_probe wlr_probe.hip ; wlr_probe [B Lm which]
 // WLR_KO (k_wave_linr only): 1 = one DPP FMA per accumulator instead of 16, 2 = exponent fixed at 0,
-// 4 = no message stores, 8 = no Eh loads in the loop.
+// 4 = no message stores, 8 = no Eh loads in the loop; add-ons: 16 / 32 = an agent-scope release + progress store
+// every 32 / 16 steps (what publishing the sweep's progress to a consumer kernel would cost).
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>
@@ -36,7 +37,7 @@ int run(int B, int Lm, int which, int reps) {
   CKH(hipMemcpy(dl0, l0.data(), (size_t)B * K * 8, hipMemcpyHostToDevice));
   auto launch = [&]() {
     if (which == 0)
-      hipLaunchKernelGGL((k_wave_linr<ST>), dim3(B, 2), dim3(64), 0, 0, dE, dk, dA, dAT, dmi, dl0, (size_t)K, Lm, K, da, db, dhx, dgx, dlb, dlz, dzf);
+      hipLaunchKernelGGL((k_wave_linr<ST, ST>), dim3(B, 2), dim3(64), 0, 0, dE, dk, dA, dAT, dmi, dl0, (size_t)K, Lm, K, da, db, dhx, dgx, dlb, dlz, dzf);
     else
       hipLaunchKernelGGL((k_wave_lin4<64, ST>), dim3(B, 2), dim3(256), 0, 0, dE, dk, dA, dAT, dmi, dl0, (size_t)K, Lm, K, da, db, dhx, dgx, dlb, dlz, dzf);
   };
