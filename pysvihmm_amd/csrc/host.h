@@ -124,6 +124,10 @@ struct svihmm_ctx {
   StartSlot svi_starts[8];
   const int64_t* starts_pending = nullptr;   // device-visible pinned slot whose pull into h->starts is still owed
   int starts_pending_n = 0;
+  // synchronous E-step calls (statistics read back before the call returns): the starts go through ONE mapped slot
+  // that the emission kernel reads itself -- free again once the call's final synchronisation has passed
+  bool starts_sync_call = false, starts_slot_inflight = false;
+  void* starts_slot = nullptr; size_t starts_slot_cap = 0;
   int svi_upload_it = -1;
   int* pin_status = nullptr;                 // pinned: NIW factorisation status (lazy check)
   double* mirror = nullptr; size_t mirror_cap = 0;   // pinned + mapped copy of `packed`

@@ -92,6 +92,7 @@ int svihmm_destroy(svihmm_ctx* h) {
   for (auto& ss : h->svi_starts) if (ss.p) hipHostFree(ss.p);
   if (h->pin_status) hipHostFree(h->pin_status);
   if (h->svi_ts) hipHostFree(h->svi_ts);
+  if (h->starts_slot) hipHostFree(h->starts_slot);
   if (h->mirror) hipHostFree(h->mirror);
   hipStreamDestroy(h->stream);
   delete h;
@@ -770,6 +771,21 @@ static int upload_starts(svihmm_ctx* h, const int64_t* starts, int B) {
     HIPCK(hipHostGetDevicePointer(&dpin, ss.p, 0));
     h->starts_pending = (const int64_t*)dpin; h->starts_pending_n = B;
     ss.used_it = h->svi_upload_it;
+  } else if (h->starts_sync_call && nb <= (size_t)1 << 20) {
+    // (svihmm_estep_minibatch with a read-back: as in the SVI loop the pull is owed, not launched -- a k_pull launch
+    //  and the slot's release event in front of the emission kernel are ~10 us of a 64-window step)
+    if (h->starts_slot_inflight) { HIPCK(hipStreamSynchronize(h->stream)); h->starts_slot_inflight = false; }
+    if (nb > h->starts_slot_cap) {
+      if (h->starts_slot) hipHostFree(h->starts_slot);
+      h->starts_slot = nullptr; h->starts_slot_cap = 0;
+      HIPCK(hipHostMalloc(&h->starts_slot, nb + 4096, hipHostMallocMapped));
+      h->starts_slot_cap = nb + 4096;
+    }
+    std::memcpy(h->starts_slot, starts, nb);
+    void* dpin = nullptr;
+    HIPCK(hipHostGetDevicePointer(&dpin, h->starts_slot, 0));
+    h->starts_pending = (const int64_t*)dpin; h->starts_pending_n = B;
+    h->starts_slot_inflight = true;
   } else if (nb <= (size_t)4 << 20) {   // through a pinned slot: no host-side wait for the stream
     void* pin = nullptr;
     int slot = 0;
@@ -1198,10 +1214,14 @@ int svihmm_estep_minibatch_ex(svihmm_ctx* h, const int64_t* starts, int32_t B, i
     }
     return 0;
   }
-  CK(estep_core(h, starts, B, Lm, inner_off, inner_len, flags));
+  h->starts_sync_call = out_packed != nullptr && h->variant[9] != 2;    // (variant 9 = 2: the k_pull route)
+  const int rc = estep_core(h, starts, B, Lm, inner_off, inner_len, flags);
+  h->starts_sync_call = false;
+  if (rc) return rc;
   CK(launch_mirror(h));
   if (out_packed) {
     CK(read_packed_host(h, out_packed));
+    h->starts_slot_inflight = false;      // (the stream is idle: the slot's readers are done)
     CK(check_emission_status(h));
   }
   return 0;

@@ -102,6 +102,7 @@ int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, int Lm, u
   const int64_t n = (int64_t)nb * Lm;
   const int64_t rpc = plan.rpc, nchunk = plan.nchunk;
   const uint8_t* mk = h->have_mask ? (const uint8_t*)h->mask.p : nullptr;
+  CK(ensure_starts_pulled(h));    // (an E-step without an emission launch -- host lliks -- still owes the device copy)
   const int64_t* starts_dev = (const int64_t*)h->starts.p + b0;
   int var = h->variant[1];
   if (var != 2) var = 3;      // (2: the double-buffered generation; the VALU generation of round 1 is gone)
@@ -336,6 +337,7 @@ static int launch_stats_cat(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint3
   const int64_t n = (int64_t)B * Lm;
   hipStream_t stream = h->stream;
   CK(ensure_q(h, h->curB, Lq, stream));
+  CK(ensure_starts_pulled(h));
   const StatsPlan plan = stats_plan(h, n);
   const int64_t rpcc = (n + 1023) / 1024 > 64 ? (n + 1023) / 1024 : 64;
   const int nchunkc = (int)((n + rpcc - 1) / rpcc);
