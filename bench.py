@@ -157,8 +157,19 @@ def launch_ranks(args):
     dies takes the job down (its peers would wait in a collective for ever): the others get
     SVIHMM_PEER_GRACE_S seconds (default 20), then SIGTERM; if rank 0 printed no JSON line the launcher
     prints the error record with every rank's exit code."""
-    from pysvihmm_amd.engine import device_count
-    ndev = device_count()
+    # (first contact with a new box: a missing / unloadable libsvihmm_hip.so or a HIP runtime that reports no
+    #  device must still leave the ONE JSON line, not a traceback)
+    try:
+        from pysvihmm_amd.engine import device_count
+        ndev = device_count()
+    except BaseException as e:
+        if isinstance(e, KeyboardInterrupt):
+            raise
+        msg = "cannot count HIP devices: %r" % (e,)
+        sys.stderr.write("bench.py: %s\n" % msg)
+        print(json.dumps(error_record(args.gpus, msg + " -- 0 HIP device(s) usable")))
+        sys.stdout.flush()
+        return 2
     if ndev < args.gpus:
         sys.stderr.write("bench.py: --gpus %d but only %d HIP device(s) visible\n" % (args.gpus, ndev))
         print(json.dumps(error_record(args.gpus, "--gpus %d but only %d HIP device(s) visible" % (args.gpus, ndev))))
@@ -266,6 +277,11 @@ def headline_record(args, strong, world, ranks_seen, have_comm, block, per_rank,
     # algorithmic HBM bytes of the whole step: obs read once + packed stats out
     alg_bytes = rows * D * 8.0 + packed_size(K, D) * 8.0
     step_flops = sum(flops.values())
+    # bytes one launch of the dominant kernel has to move: statistics = obs + ah + bh rows in, 128 x (F' + K) x K
+    # partial sums out; emission = obs in, Eh out; sweeps = Eh in, ah + bh out
+    kern_alg_bytes = {"stats": rows * (D + 2 * K) * 8.0 + 128 * 640 * K * 8.0,
+                      "emission": rows * (D + K) * 8.0,
+                      "forward_backward": rows * 3 * K * 8.0}.get(dom, alg_bytes)
     # roofline.frac is the figure a reader recomputes from profiles/ (rocprofv3's average of the
     # dominant kernel); the live HIP-event figure of THIS run is frac_events.  Without a committed
     # profile set the live figure is all there is.
@@ -300,16 +316,23 @@ def headline_record(args, strong, world, ranks_seen, have_comm, block, per_rank,
                      "kernel_function": live_kernel or prof_kernel,
                      "achieved_events": achieved_ev, "frac_events": achieved_ev / FP64_PEAK_TFLOPS,
                      "whole_step_frac": step_flops / (ms_per_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                     # two scopes, each with its own pair: `traffic` / `traffic_ratio` = the dominant kernel's HBM
+                     # bytes per launch (PMC counters) over the bytes that launch has to move (its inputs obs + ah + bh
+                     # once, its partials out); `traffic_step` / `traffic_ratio_step` = all kernels of one step over
+                     # the step's algorithmic bytes (obs in once + packed statistics out)
                      "traffic": traffic,
-                     "traffic_ratio": (step_traffic / alg_bytes) if step_traffic else None,
+                     "traffic_ratio": (traffic / kern_alg_bytes) if traffic else None,
+                     "traffic_scope": "dominant kernel, bytes per launch; *_step: whole step (all kernels)",
+                     "traffic_step": step_traffic,
+                     "traffic_ratio_step": (step_traffic / alg_bytes) if step_traffic else None,
                      "clock": "frac: the profiler's clock (reproducible from profiles/); frac_events: HIP events "
                               "around every launch of the kernel in the timed region (%d launches; a few %% "
                               "shorter than under the profiler; only this kernel is bracketed there, the other "
                               "entries of `kernels` come from a short separate pass); whole_step_frac: algorithmic "
                               "flop of emission + sweeps + statistics / ms_per_step / peak" % nlaunch,
                      "note": "fp64: v_mfma_f64_16x16x4_f64; peak = MI355X datasheet fp64 "
-                             "(matrix = vector = 78.6 TF); traffic_ratio = counter bytes per step / "
-                             "algorithmic bytes (%s)" % pmc_src},
+                             "(matrix = vector = 78.6 TF); traffic_ratio = counter bytes / "
+                             "algorithmic bytes of the same scope (%s)" % pmc_src},
         "roofline_hbm": {"bound": "hbm", "achieved": alg_bytes / (ms_per_step * 1e-3) / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -325,7 +348,48 @@ def headline_record(args, strong, world, ranks_seen, have_comm, block, per_rank,
                             "note": "ncclAllReduce(sum, f64) of the packed statistics on the handle's stream "
                                     "(HIP events around the call)"}
     res.update({k: v for k, v in (side or {}).items() if not k.startswith("_")})
+    res["roofline"]["regimes"] = regimes(side or {})
     return res
+
+
+def regimes(side):
+    """Numbers only, under `roofline` (the driver's record keeps sub-keys of `roofline` and `config`): the
+    other regimes the side figures measure -- the literal minibatch = 64 E-step, the S=64 SVI iteration through
+    the class surface (fp64 and fp32 mode), the fp32-mode epoch step, configs[4]; ms per step / iteration and the
+    fraction of the fp64 peak (fp32-mode entries: of the bf16 dense peak for the kernels named in the side
+    record), plus the wall time of ONE infer(maxit=100) call with its fixed part broken down."""
+    def num(x):
+        return float(x) if isinstance(x, (int, float)) and np.isfinite(x) else None
+    out = {}
+    r = side.get("minibatch_s64") or {}
+    if "ms_per_step" in r:
+        out["minibatch_s64"] = {"ms": num(r["ms_per_step"]), "frac": num(r.get("roofline", {}).get("frac"))}
+    for key in ("svi_iteration_s64", "svi_iteration_s64_f32"):
+        r = side.get(key) or {}
+        if "ms" in r:
+            out[key] = {"ms": num(r["ms"]), "frac": num(r.get("roofline", {}).get("frac")),
+                        "iter_time_median_ms": num(r.get("iter_time_median_ms"))}
+            if "infer_wall_ms_maxit100" in r:
+                out[key]["infer_wall_ms_maxit100"] = num(r["infer_wall_ms_maxit100"])
+                out[key]["infer_wall_breakdown_ms"] = {k: num(v) for k, v in (r.get("infer_wall_breakdown_ms") or {}).items()}
+            if "max_rel_err_vs_f64_final_var_tran" in r:
+                out[key]["max_rel_err_vs_f64"] = num(r["max_rel_err_vs_f64_final_var_tran"])
+    r = side.get("f32_mode") or {}
+    if "ms_per_step" in r:
+        out["f32_mode"] = {"ms": num(r["ms_per_step"]),
+                           "frac_bf16_emission": num(r.get("roofline_emission", {}).get("frac")),
+                           "frac_bf16_stats": num(r.get("roofline_stats", {}).get("frac")),
+                           "max_rel_err_vs_f64": num(r.get("max_rel_err_vs_f64_statistics"))}
+    r = side.get("c5_k256_d64") or {}
+    if "ms" in r:
+        out["c5_k256_d64"] = {"ms": num(r["ms"]), "frac": num(r.get("roofline", {}).get("frac")),
+                              "f32_ms": num((r.get("f32_mode") or {}).get("ms")),
+                              "f32_max_rel_err_vs_f64": num((r.get("f32_mode") or {}).get("max_rel_err_vs_f64_statistics"))}
+    r = side.get("c2_k16_d8") or {}
+    if "epoch_step" in r:
+        out["c2_k16_d8"] = {"epoch_ms": num(r["epoch_step"]["ms"]), "full_chain_ms": num(r["full_chain_estep"]["ms"]),
+                            "ffbs_ms": num(r["ffbs_fast"]["ms"])}
+    return out
 
 
 REQUIRED = {"metric": str, "value": float, "unit": str, "n_gpus": int, "steps": int, "warmup": int,
@@ -845,7 +909,12 @@ def svi_iteration(eng, obs_host):
     #  iteration; tools/svi_wall_vs_device.py shows the wall time linear in maxit with the device's own
     #  per-iteration times as slope.  Rounds 2-5 differenced infer(70) - infer(10): +-0.02 ms of noise.)
     n1, n2 = 100, 2100
-    t1 = float(np.median([run(n1)[0] for _ in range(3)]))
+    r1 = [run(n1) for _ in range(3)]
+    t1 = float(np.median([t[0] for t in r1]))
+    # the call a user of the reference's default maxit = 100 sees, and where its fixed part goes
+    wall_keys = ("upload_obs", "svi_begin", "submit_iterations", "wait_and_read_state", "last_window")
+    wall100 = {k: float(np.median([getattr(t[1], "infer_wall_ms", {}).get(k, 0.0) for t in r1])) for k in wall_keys}
+    wall100["iterations_device"] = float(np.median([np.sum(t[1].iter_time) * 1e3 for t in r1]))
     t2s = [run(n2) for _ in range(3)]
     t2 = float(np.median([t[0] for t in t2s]))
     hmm = t2s[-1][1]
@@ -854,6 +923,13 @@ def svi_iteration(eng, obs_host):
     fl = sum(algorithmic_flops(64 * LM).values())
     return {"ms": per_it * 1e3, "value": 64 * LM * K / per_it, "unit": "updates/s",
             "iter_time_median_ms": float(np.median(hmm.iter_time[5:]) * 1e3),
+            "infer_wall_ms_maxit100": t1 * 1e3, "infer_wall_breakdown_ms": wall100,
+            "infer_wall_note": "one infer(maxit=100) call, median of 3: upload_obs = the reference's unconditional re-read "
+                               "of self.obs (256 MB pageable host -> HBM; `assume_obs_unchanged = True` skips it), svi_begin = "
+                               "prior / factor uploads + first theta + globals, submit_iterations = host time of the 100 "
+                               "svihmm_svi_iteration calls (the device runs behind), wait_and_read_state = rest of the device "
+                               "time + state / ELBO read-back, last_window = lliks / lalpha / lbeta / var_x of the last window; "
+                               "iterations_device = sum of iter_time (device stamps)",
             "_final": hmm.var_tran.copy(),
             "roofline": {"bound": "mfma", "kernel": "whole iteration (E-step kernels' algorithmic flop / wall)",
                          "achieved": fl / per_it / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -881,7 +957,7 @@ def cpu_baselines(eng, L, pb, step, obs_host):
     chk = step(starts[:nwin])
     err = float(np.max(np.abs(chk.buf - ref) / (1e-9 + np.abs(ref))))
     res["cpu_baseline"] = {
-        "value": nwin * LM * K / cdt, "unit": "updates/s", "cores": 1, "kind": "port",
+        "value": nwin * LM * K / cdt, "unit": "updates/s", "cores": 1, "kind": "port", "port_kind": "c_port",
         "sample": "first %d of the %d windows of the same workload (%.1f s); plain-C restatement of the "
                   "reference's single-threaded K^2 log-add-exp recursions; the container may use %d of "
                   "the host's %d hardware threads" % (nwin, B, cdt, ncore, nhw),
@@ -894,7 +970,7 @@ def cpu_baselines(eng, L, pb, step, obs_host):
     ref_all = ref_c.estep_minibatch(obs_host, None, starts[:nwin_all], LM, *par, flags=2, threads=nthr)
     adt = time.perf_counter() - t0
     res["cpu_baseline_all_cores"] = {
-        "value": nwin_all * LM * K / adt, "unit": "updates/s", "cores": nthr, "kind": "port",
+        "value": nwin_all * LM * K / adt, "unit": "updates/s", "cores": nthr, "kind": "port", "port_kind": "c_port",
         "sample": "first %d windows (%.1f s), OpenMP over windows on %d threads = the container's CPU "
                   "quota (host: %d hardware threads)" % (nwin_all, adt, nthr, nhw)}
     if nwin_all >= B:
@@ -919,6 +995,7 @@ def cpu_baselines(eng, L, pb, step, obs_host):
     ndt = time.perf_counter() - t0
     res["cpu_baseline_numpy"] = {
         "value": nwin_np * LM * K / ndt, "unit": "updates/s", "cores": 1, "kind": "port",
+        "port_kind": "numpy_restatement (reference expressions: SURVEY 8(d)(i)'s 'reference CPU path')",
         "sample": "first %d windows (%.1f s); NumPy restatement of the reference's local_update + "
                   "intermediate_pars expressions (np.logaddexp.reduce folds, np.outer loop)" % (nwin_np, ndt)}
     return res

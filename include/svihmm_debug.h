@@ -37,7 +37,11 @@ const char* svihmm_kernel_name(int32_t slot);
  * the kernel name in the committed profile before it quotes that profile's duration. */
 const char* svihmm_last_kernel_name(svihmm_ctx* h, int32_t slot);
 /* Selects the kernel generation for A/B measurement (0 = default/best).
- * which 0 (unused since round 5: the VALU emission generation is gone) | 1 statistics (2 double-buffered MFMA, else the pipelined MFMA kernels)
+ * which 0 the resident SVI loop's dependency mechanism (0: device-side counters where kernels of two streams run
+ *      side by side, else stream events; 1: stream events; 2: counters, and the loop behaves as if the device stopped
+ *      running kernels concurrently at iteration 3 -- exercises the mid-loop switch to stream events; 3: counters, one gate
+ *      of iteration 3 waits for a count that never comes with a 2 ms bound -- exercises the bounded-wait recovery)
+ * | 1 statistics (2 double-buffered MFMA, else the pipelined MFMA kernels)
  * | 2 sweeps (1 wave-per-window, 2 log-domain MFMA, 3 scaled linear-domain MFMA)
  * | 3 emission row tiles per wave | 4 two-stream E-step pipeline (1 off, 2 on; default off)
  * | 6 blocked scan for one long window (B = 1, Lm >= 2048, K <= 64; 1 = off)
@@ -59,6 +63,9 @@ const char* svihmm_last_kernel_name(svihmm_ctx* h, int32_t slot);
  * | 7 = 9: the scaled sweeps are skipped, the statistics read stale messages (tools/r4_overlap_probe.py);
  *   a product build rejects them with an error. */
 int svihmm_set_variant(svihmm_ctx* h, int32_t which, int32_t value);
+/* How often the current device-resident SVI loop left its device-side counters for stream events mid-way
+ * (a gate's bounded wait ran out and the lost iterations were replayed, or the debug variants 0 = 2 / 3). */
+int svihmm_svi_recoveries(svihmm_ctx* h, int32_t* out);
 
 /* ---- diagnostics ------------------------------------------------------------------- */
 /* One v_mfma_f64_16x16x4_f64 on A[16,4] x B[4,16] -> C[16,16] (operand-layout check). */

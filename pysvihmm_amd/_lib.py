@@ -105,6 +105,7 @@ SIGNATURES = {
     "svihmm_kernel_name": (C.c_char_p, [C.c_int32]),
     "svihmm_last_kernel_name": (C.c_char_p, [C.c_void_p, C.c_int32]),
     "svihmm_set_variant": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "svihmm_svi_recoveries": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "svihmm_selftest_mfma": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, _c_double_p]),
 }
 

@@ -185,29 +185,58 @@ __device__ __forceinline__ int feat_index_d(int a, int b, int D) {
 //  wall_clock64() stamps written by the kernels themselves.
 // ------------------------------------------------------------------------------------
 #define SVI_SYNC_TIMEOUT (1 << 22)
-// a gate gives up after this many ticks of the 100 MHz device wall clock (60 s: a gate launched early legitimately
-// waits for as long as the iteration in front of it runs -- tens of ms for an epoch-sized "minibatch" of a wide model)
+// upper limit of a gate's bound in ticks of the 100 MHz device wall clock (60 s).  The host passes each gate its own
+// bound (SviSync::ticks): a gate launched early legitimately waits for as long as the iteration in front of it
+// runs, so the bound follows the loop's measured iteration period (svihmm_hip.hip, svi_gate_ticks) -- 64 periods,
+// at least 50 ms, and this limit while no period is known yet.
 #define SVI_SYNC_TICKS 6000000000ull
-__device__ __forceinline__ void svi_gate(const SviSync& sy) {
+// Returns true when the kernel may run its body (uniform over the workgroup).  false: the loop is dead -- this gate
+// or an earlier one gave up; the caller skips the body but still arrives, so that nothing behind it waits.
+__device__ __forceinline__ bool svi_gate(const SviSync& sy) {
   if (sy.early && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0)
     __hip_atomic_fetch_add(sy.early, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (!sy.gate) return;
+  if (!sy.gate && !sy.dead) return true;
+  int failed = 0;
   if (threadIdx.x == 0) {
     // (relaxed polls, one acquire fence at the end: an acquire load invalidates the caches on every poll)
-    const unsigned long long t0 = wall_clock64();
-    unsigned n = 0;
-    // (counters and targets are 32-bit and only ever grow: compared by their signed difference, so a long loop may wrap them)
-    while ((int)(__hip_atomic_load(sy.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - sy.gate_tgt) < 0) {
-      if (++n < 256u) { __builtin_amdgcn_s_sleep(4); continue; }       // ~0.1 us naps first, ~2 us later
-      __builtin_amdgcn_s_sleep(64);
-      if ((n & 255u) == 0u && wall_clock64() - t0 > SVI_SYNC_TICKS) {
-        if (sy.status) atomicMax(sy.status, SVI_SYNC_TIMEOUT);
-        break;
+    // (the first poll and the flag travel together: one L2 round trip on the path that finds the count already there)
+    unsigned seen = sy.gate ? __hip_atomic_load(sy.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    if (sy.dead && __hip_atomic_load(sy.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) failed = 1;
+    if (sy.gate && !failed) {
+      const unsigned long long t0 = wall_clock64();
+      const unsigned long long bound = sy.ticks ? sy.ticks : SVI_SYNC_TICKS;
+      unsigned n = 0;
+      // (counters and targets are 32-bit and only ever grow: compared by their signed difference, so a long loop may wrap them)
+      for (; (int)(seen - sy.gate_tgt) < 0; seen = __hip_atomic_load(sy.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        if (++n < 256u) { __builtin_amdgcn_s_sleep(4); continue; }       // ~0.1 us naps first, ~2 us later
+        __builtin_amdgcn_s_sleep(64);
+        if ((n & 63u) == 0u) {
+          if (sy.dead && __hip_atomic_load(sy.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { failed = 1; break; }
+          if (wall_clock64() - t0 > bound) {
+            if (sy.dead) __hip_atomic_store(sy.dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (sy.status) atomicMax(sy.status, SVI_SYNC_TIMEOUT);
+            failed = 1;
+            break;
+          }
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
-  __syncthreads();
+  return __syncthreads_or(failed) == 0;
+}
+// a kernel on the read-after-write path of the loop's state that could not run: the iteration poison_val stands for
+// (and every later one) must not reach the state
+__device__ __forceinline__ void svi_poison(const SviSync& sy) {
+  if (sy.poison && threadIdx.x == 0) atomicMax(sy.poison, sy.poison_val);
+}
+// the global-step kernels: skip from the poisoned iteration on (uniform: see SviSync::poison); the kernel's own gate
+// guards a write-after-read hazard only (the previous iteration's ELBO kernels still reading what the step rewrites),
+// so a gate that gives up does not stop the step -- it costs that iteration's ELBO entry, not the state
+__device__ __forceinline__ bool svi_step_gate(const SviSync& sy) {
+  if (sy.poison && __hip_atomic_load(sy.poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+  (void)svi_gate(sy);
+  return true;
 }
 __device__ __forceinline__ void svi_arrive(const SviSync& sy) {
   if (!sy.arrive) return;

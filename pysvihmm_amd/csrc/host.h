@@ -75,9 +75,20 @@ enum { KS_EMISSION = 0, KS_FB, KS_POSTERIOR, KS_STATS, KS_FINALIZE, KS_FFBS, KS_
 
 struct Pending { int slot; hipEvent_t e0, e1; };
 
+// one svihmm_svi_iteration call, kept until the iteration is known to have reached the loop's state (the host runs at
+// most eight iterations ahead of the device: the window-start ring): what svi_recover replays on stream events
+struct SviLogEntry {
+  int it = -1, B = 0, nwin = 0, Lm = 0, off = 0, len = 0;
+  uint32_t flags = 0;
+  double rho = 0.0, bA = 0.0, bE = 0.0, vmin_before = 0.0;
+  bool f32_ok_before = true;
+  std::vector<int64_t> starts;
+};
 struct svihmm_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  // the device's shape (svihmm_create): launch-shape thresholds tuned on the 256-CU MI355X scale with it (cu_scaled)
+  int ncu = 256, waves_per_cu = 32;
   // data
   int64_t T = 0; int D = 0; bool have_mask = false;
   Buf obs, mask;
@@ -198,6 +209,15 @@ struct svihmm_ctx {
   // (they then run beside the sweeps' 128 waves instead of beside the emission GEMM)
   bool elbo_pending = false; int elbo_pend_it = -1, elbo_pend_slot = 0;
   unsigned long long tgt_early = 0;   // sweep launches that signal their start (counter 4)
+  // bounded waits + recovery (round 6): gate bound from the measured iteration period, the iterations in flight,
+  // which iterations were timed by stream events (after a mid-loop switch away from the counters)
+  unsigned long long svi_period_ticks = 0;   // longest iteration seen so far (device stamps), 0: none yet
+  unsigned long long svi_ticks = 0;          // bound the gates launched now carry (svi_gate_ticks)
+  SviLogEntry svi_log[16];
+  std::vector<char> svi_it_events;
+  int svi_cur_it = -1;               // iteration whose E-step is being launched (poison value of its sweeps)
+  bool svi_replaying = false;
+  int svi_recoveries = 0;            // times this loop left the counters mid-way (svihmm_svi_recoveries)
   bool sweep_signalled = false;    // this E-step's sweep launch does
   bool in_svi_estep = false;       // estep_core is running for svihmm_svi_iteration
   unsigned long long* svi_ts = nullptr; unsigned long long* svi_ts_dev = nullptr; int svi_ts_cap = 0;   // pinned + mapped: [2 it] begin, [2 it + 1] end (wall_clock64)
@@ -261,16 +281,21 @@ inline int set_device(svihmm_ctx* h) {
   return 0;
 }
 
+// a count tuned on the 256 compute units of one MI355X, for this device (CPX partitions, other parts)
+inline int64_t cu_scaled(const svihmm_ctx* h, int64_t v) {
+  const int64_t r = (v * h->ncu + 128) / 256;
+  return r < 1 ? 1 : r;
+}
 struct StatsPlan { int64_t rpc, nchunk; };
 // up to this many windows the wave-per-window scaled sweep beats the MFMA one (which is
 // latency-bound at ~0.9 us per step however few windows it gets): 2 x 1024 waves are resident
-// at once (190 VGPRs: two per SIMD); measured (tools/sweep_crossover.py, K = 64, Lm = 257)
+// at once on 256 CUs (190 VGPRs: two per SIMD); measured (tools/sweep_crossover.py, K = 64, Lm = 257)
 // 0.16 ms at 64 .. 0.19 ms at 1024 windows against 0.23 .. 0.25 ms, 0.33 against 0.26 ms at 1399
-#define LIN_WAVE_MAX 1025
-// up to this many windows: four waves per (window, direction); 2 x 256 x 4 = 2048 waves, two per SIMD
-#define LIN_WAVE4_MAX 256
+inline int lin_wave_max(const svihmm_ctx* h) { return 4 * h->ncu + 1; }
+// up to this many windows: four waves per (window, direction); 2 x 256 x 4 = 2048 waves, two per SIMD of 256 CUs
+inline int lin_wave4_max(const svihmm_ctx* h) { return h->ncu; }
 // up to this many windows: the register-resident one-wave kernel (k_wave_linr; round 5)
-#define LIN_WAVER_MAX 256
+inline int lin_waver_max(const svihmm_ctx* h) { return h->ncu; }
 
 extern "C" {
 int d2h(svihmm_ctx* h, void* dst, const void* src, size_t bytes);
@@ -290,6 +315,7 @@ int launch_posterior(svihmm_ctx* h, int B, int Lm, bool total);
 int launch_scale_ll(svihmm_ctx* h, int B, int Lm);
 int launch_scale_ll_f32(svihmm_ctx* h, int B, int Lm);
 bool f32_wide_ok(const svihmm_ctx* h, int64_t n);
+bool stats_bf16w_shape_ok(const svihmm_ctx* h, int64_t n);
 int launch_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags);
 int launch_stats_finalize(svihmm_ctx* h, int64_t nchunk, hipStream_t stream);
 int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, int Lm, uint32_t flags, StatsPlan plan, int64_t chunk_base, hipStream_t stream);

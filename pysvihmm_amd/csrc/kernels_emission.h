@@ -1274,8 +1274,7 @@ __global__ __launch_bounds__(64) void k_diag_to_theta(
     const double* __restrict__ betas, int K, int D, int Kp, double* __restrict__ theta,
     int* __restrict__ status,
     SviSync sy = SviSync{nullptr, 0u, nullptr, nullptr, nullptr}) {
-  svi_gate(sy);
-  k_diag_to_theta_body(mu, nus, alphas, betas, K, D, Kp, theta, status);
+  if (svi_gate(sy)) k_diag_to_theta_body(mu, nus, alphas, betas, K, D, Kp, theta, status);
   svi_arrive(sy);
 }
 
@@ -1378,8 +1377,7 @@ __global__ __launch_bounds__(256) void k_niw_to_theta_generic(
     double* __restrict__ theta, int* __restrict__ status, double* __restrict__ orb,
     double* __restrict__ logdet_out,
     SviSync sy = SviSync{nullptr, 0u, nullptr, nullptr, nullptr}) {
-  svi_gate(sy);
-  k_niw_to_theta_generic_body(mu, sigma, kappa, nu, K, D, Kp, theta, status, orb, logdet_out);
+  if (svi_gate(sy)) k_niw_to_theta_generic_body(mu, sigma, kappa, nu, K, D, Kp, theta, status, orb, logdet_out);
   svi_arrive(sy);
 }
 
@@ -1616,8 +1614,7 @@ __global__ __launch_bounds__(64) void k_niw_to_theta_wave(
     double* __restrict__ theta, int* __restrict__ status, double* __restrict__ orb,
     double* __restrict__ logdet_out, uint4* __restrict__ uw = nullptr,
     SviSync sy = SviSync{nullptr, 0u, nullptr, nullptr, nullptr}) {
-  svi_gate(sy);
-  k_niw_to_theta_wave_body<DMAX>(mu, sigma, kappa, nu, K, D, Kp, theta, status, orb, logdet_out, uw);
+  if (svi_gate(sy)) k_niw_to_theta_wave_body<DMAX>(mu, sigma, kappa, nu, K, D, Kp, theta, status, orb, logdet_out, uw);
   svi_arrive(sy);
 }
 

@@ -1623,7 +1623,7 @@ __global__ __launch_bounds__(256) void k_wave_lin4(
     SviSync sy = SviSync{nullptr, 0u, nullptr, nullptr, nullptr}) {
   static_assert(KMAX == 64, "lane = state, four source blocks of 16");
   __shared__ double part[2][4][64];             // [step parity][source block][target], double-buffered
-  svi_gate(sy);                                 // (SVI loop: the globals kernel of the side stream has arrived)
+  if (!svi_gate(sy)) { svi_poison(sy); return; }   // (SVI loop: the globals kernel of the side stream has arrived)
   if (blockIdx.y == 0) {
     if (K == 64) wave_lin4_body<true, true, ST>(Eh, kexp, Aexp, mod_init, ll0, l0stride, Lm, K, ah, hx, local_lb, logz, zfac, part);
     else wave_lin4_body<true, false, ST>(Eh, kexp, Aexp, mod_init, ll0, l0stride, Lm, K, ah, hx, local_lb, logz, zfac, part);
@@ -1919,7 +1919,7 @@ __global__ __launch_bounds__(64) void k_wave_linr(
     double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac,
     SviSync sy = SviSync{nullptr, 0u, nullptr, nullptr, nullptr}) {
   __shared__ WlrRing<CT> ring;
-  svi_gate(sy);                                 // (SVI loop: the globals kernel of the side stream has arrived)
+  if (!svi_gate(sy)) { svi_poison(sy); return; }   // (SVI loop: the globals kernel of the side stream has arrived)
   if (blockIdx.y == 0) {
     if (K == 64) wave_linr_body<true, true, ST, CT>(Eh, kexp, Aexp, mod_init, ll0, l0stride, Lm, K, ah, hx, local_lb, logz, zfac, ring);
     else wave_linr_body<true, false, ST, CT>(Eh, kexp, Aexp, mod_init, ll0, l0stride, Lm, K, ah, hx, local_lb, logz, zfac, ring);

@@ -236,8 +236,10 @@ __global__ __launch_bounds__(64 * NWV) void k_svi_globals(
     const double* __restrict__ var_tran, int K, double* __restrict__ work_g,
     double* __restrict__ ltran, double* __restrict__ Aexp, double* __restrict__ AexpT,
     double* __restrict__ var_init, double* __restrict__ mod_init, SviSync sy) {
-  svi_gate(sy);
-  k_svi_globals_body<LDSW, NWV>(var_tran, K, work_g, ltran, Aexp, AexpT, var_init, mod_init);
+  // (skipped -- the loop is dead, its gate kernel gave up -- the iteration these globals are for is poisoned; the
+  //  kernel still arrives so that nothing waits for it)
+  if (svi_gate(sy)) k_svi_globals_body<LDSW, NWV>(var_tran, K, work_g, ltran, Aexp, AexpT, var_init, mod_init);
+  else svi_poison(sy);
   svi_arrive(sy);
 }
 
@@ -323,8 +325,7 @@ __global__ __launch_bounds__(256) void k_svi_global_step(
     const double* __restrict__ packed, const double* __restrict__ prior_tran, double* __restrict__ var_tran,
     double* __restrict__ niw, const double* __restrict__ prior, int K, int D, double rho, double bA,
     double bE, double nwin, double* __restrict__ lb_keep, double* __restrict__ ada_G, SviSync sy) {
-  svi_gate(sy);
-  k_svi_global_step_body(packed, prior_tran, var_tran, niw, prior, K, D, rho, bA, bE, nwin, lb_keep, ada_G);
+  if (svi_step_gate(sy)) k_svi_global_step_body(packed, prior_tran, var_tran, niw, prior, K, D, rho, bA, bE, nwin, lb_keep, ada_G);
   svi_arrive(sy);
 }
 
@@ -406,8 +407,7 @@ __global__ __launch_bounds__(64) void k_svi_vlb(
     const double* __restrict__ prior_logpart, double zsign, int K, double* __restrict__ vlb,
     const double* __restrict__ prior_tran, const double* __restrict__ var_tran,
     double* __restrict__ rowterm, SviSync sy) {
-  svi_gate(sy);
-  k_svi_vlb_body(theta, fab, F, D, Kp, niw, logdet, prior, prior_logpart, zsign, K, vlb, prior_tran, var_tran, rowterm);
+  if (svi_gate(sy)) k_svi_vlb_body(theta, fab, F, D, Kp, niw, logdet, prior, prior_logpart, zsign, K, vlb, prior_tran, var_tran, rowterm);
   svi_arrive(sy);
 }
 
@@ -430,8 +430,7 @@ __device__ __forceinline__ void k_svi_elbo_body(int K, const double* __restrict_
 __global__ __launch_bounds__(64) void k_svi_elbo(int K, const double* __restrict__ vlb,
                                                  const double* __restrict__ rowterm, double prior_const,
                                                  const double* __restrict__ lb, double* __restrict__ elbo_out, SviSync sy) {
-  svi_gate(sy);
-  k_svi_elbo_body(K, vlb, rowterm, prior_const, lb, elbo_out);
+  if (svi_gate(sy)) k_svi_elbo_body(K, vlb, rowterm, prior_const, lb, elbo_out);
   svi_arrive(sy);
 }
 
@@ -488,8 +487,7 @@ __global__ __launch_bounds__(256) void k_svi_global_step_simple(
     double* __restrict__ var_tran, double* __restrict__ blk, const double* __restrict__ prior, int K, int W,
     double rho, double bA, double bE, double nwin, double* __restrict__ lb_keep, double* __restrict__ ada_G,
     int nem, SviSync sy) {
-  svi_gate(sy);
-  k_svi_global_step_simple_body(fam, packed, prior_tran, var_tran, blk, prior, K, W, rho, bA, bE, nwin, lb_keep, ada_G, nem);
+  if (svi_step_gate(sy)) k_svi_global_step_simple_body(fam, packed, prior_tran, var_tran, blk, prior, K, W, rho, bA, bE, nwin, lb_keep, ada_G, nem);
   svi_arrive(sy);
 }
 
@@ -540,8 +538,7 @@ __global__ __launch_bounds__(64) void k_svi_vlb_simple(
     int fam, const double* __restrict__ blk, const double* __restrict__ prior, int K, int W,
     double* __restrict__ vlb, const double* __restrict__ prior_tran, const double* __restrict__ var_tran,
     double* __restrict__ rowterm, SviSync sy) {
-  svi_gate(sy);
-  k_svi_vlb_simple_body(fam, blk, prior, K, W, vlb, prior_tran, var_tran, rowterm);
+  if (svi_gate(sy)) k_svi_vlb_simple_body(fam, blk, prior, K, W, vlb, prior_tran, var_tran, rowterm);
   svi_arrive(sy);
 }
 
@@ -558,8 +555,7 @@ __device__ __forceinline__ void k_cat_table_body(const double* __restrict__ alph
 }
 __global__ __launch_bounds__(64) void k_cat_table(const double* __restrict__ alpha, int K, int V,
                                                   double* __restrict__ table, SviSync sy) {
-  svi_gate(sy);
-  k_cat_table_body(alpha, K, V, table);
+  if (svi_gate(sy)) k_cat_table_body(alpha, K, V, table);
   svi_arrive(sy);
 }
 

@@ -25,4 +25,15 @@ struct SviSync {
   unsigned stamp_at;           //   (the kernel's last workgroup; nullptr: none)
   unsigned* early;             // += 1 by the kernel's first workgroup as soon as it runs ("my predecessors on the
                                //   stream are done": the deferred ELBO kernels' gate; nullptr: none)
+  unsigned* dead;              // HBM flag of the loop: non-zero once a gate has given up -- every later gate returns at
+                               //   once and its kernel skips its body, so the loop's state stays at the last completed
+                               //   global step and the queue drains in microseconds (nullptr: not checked)
+  unsigned long long ticks;    // bound of this gate's wait in ticks of the device wall clock (0: SVI_SYNC_TICKS)
+  unsigned* poison;            // HBM word of the loop: 0, or SVI_POISON_BASE - it of the EARLIEST iteration `it` whose E-step ran
+                               //   on inputs that were not there (its sweeps' gate gave up / its globals kernel was skipped).
+                               //   Raised (atomicMax) by those kernels with poison_val; read by the global-step kernels, which
+                               //   skip from that iteration on -- they follow the sweeps in stream order, so every workgroup of
+                               //   a step sees the same value and the loop's state freezes at a whole iteration
+  unsigned poison_val;
 };
+#define SVI_POISON_BASE 0x7fffffffu

@@ -55,6 +55,13 @@ int svihmm_create(int device_id, svihmm_ctx** out) {
   h->device = device_id;
   HIPCK(hipSetDevice(device_id));
   HIPCK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  {   // the device's shape, once: batch-size thresholds and workgroup rounds are expressed through it (host.h, cu_scaled)
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && v > 0) h->ncu = v;
+    v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxThreadsPerMultiProcessor, device_id) == hipSuccess && v >= 64)
+      h->waves_per_cu = v / 64;
+  }
   *out = h;
   return 0;
 }
@@ -536,6 +543,9 @@ int svihmm_set_emission_niw(svihmm_ctx* h, int32_t K, int32_t D, const double* m
   std::memcpy(hp + nmu, sigma, nsg * sizeof(double));
   std::memcpy(hp + nmu + nsg, kappa, K * sizeof(double));
   std::memcpy(hp + nmu + nsg + K, nu, K * sizeof(double));
+  // (a live loop whose own family and shape are re-pushed: the previous iteration's ELBO kernels may still be
+  //  deferred -- they read the factors this upload rewrites, so they go first)
+  if (h->svi_active) CK(svi_flush_elbo(h));
   if (h->vlb_pending) { HIPCK(hipStreamWaitEvent(h->stream, h->svi_ed, 0)); h->vlb_pending = false; }
   CK(drop_auto_status(h));
   CK(pull_small(h, dmu, hp, nin * sizeof(double)));
@@ -565,6 +575,7 @@ int svihmm_set_emission_diag(svihmm_ctx* h, int32_t K, int32_t D, const double* 
   std::memcpy(hp + n, nus, n * sizeof(double));
   std::memcpy(hp + 2 * n, alphas, n * sizeof(double));
   std::memcpy(hp + 3 * n, betas, n * sizeof(double));
+  if (h->svi_active) CK(svi_flush_elbo(h));      // (as in svihmm_set_emission_niw)
   if (h->vlb_pending) { HIPCK(hipStreamWaitEvent(h->stream, h->svi_ed, 0)); h->vlb_pending = false; }
   // a running device loop survives a re-push of ITS OWN family and shape (the loop's factor block IS
   // h->niw: the validation hooks of infer() -- full_predprob, adaptive L, growBuffer -- re-upload the
@@ -671,6 +682,8 @@ int svihmm_set_emission_cat(svihmm_ctx* h, int32_t K, int32_t V, const double* l
   h->center_pending = false;
   // (a device loop of another family or shape ends with this upload, as in svihmm_set_emission_niw / _diag)
   if (h->svi_active && !(h->svi_family == 2 && h->svi_K == K && h->V == V)) h->svi_active = false;
+  if (h->svi_active) CK(svi_flush_elbo(h));      // (as in svihmm_set_emission_niw)
+  if (h->vlb_pending) { HIPCK(hipStreamWaitEvent(h->stream, h->svi_ed, 0)); h->vlb_pending = false; }
   CK(drop_auto_status(h));
   CK(cat_uncentre(h));
   const size_t n = (size_t)K * V;
@@ -811,14 +824,14 @@ static int pick_fb(const svihmm_ctx* h, int B, int Lm, bool want_logs) {
     if (var == 2) var = 1;
     // one long chain: blocked scan (its messages convert to logs row by row, see materialise);
     // large batches: scaled sweeps unless the logs themselves are wanted
-    if (var == 0) var = (use_chain(h, B, Lm) || (B >= 192 && !want_logs)) ? 3 : 1;
+    if (var == 0) var = (use_chain(h, B, Lm) || (B >= cu_scaled(h, 192) && !want_logs)) ? 3 : 1;
     if (var == 3 && !use_chain(h, B, Lm) && (size_t)16 * Lm * h->K * sizeof(double) >= ((size_t)1 << 32)) var = 1;
     return var;
   }
-  if (var == 0) var = want_logs ? (use_chain(h, B, Lm) ? 3 : B >= 192 ? 2 : 1) : 3;   // no logs wanted: scaled sweeps at any batch size; logs of one long chain: blocked scan + conversion
+  if (var == 0) var = want_logs ? (use_chain(h, B, Lm) ? 3 : B >= cu_scaled(h, 192) ? 2 : 1) : 3;   // no logs wanted: scaled sweeps at any batch size; logs of one long chain: blocked scan + conversion
   // the scaled sweeps address a workgroup's 16 windows with 32-bit byte offsets
   // (the wave-per-window kernel of small batches uses 64-bit row offsets)
-  if (var == 3 && !use_chain(h, B, Lm) && !(B < LIN_WAVE_MAX && h->variant[7] != 2) &&
+  if (var == 3 && !use_chain(h, B, Lm) && !(B < lin_wave_max(h) && h->variant[7] != 2) &&
       (size_t)16 * Lm * h->K * sizeof(double) >= ((size_t)1 << 32)) var = 2;
   return var;
 }
@@ -1259,38 +1272,65 @@ static int* svi_gate_status(svihmm_ctx* h) {
   return nullptr;
 }
 static unsigned long long* svi_stamp_dev(svihmm_ctx* h, int idx) { return h->svi_ts_dev ? h->svi_ts_dev + idx : nullptr; }
+// What every gate of the loop carries (flags mode): the status word in mapped host memory, the loop's dead flag
+// (counter slot 7) and the bound of its wait.  Counter slots: [0] global-step workgroups, [1] globals-kernel
+// workgroups, [2] theta-builder workgroups, [3] ELBO side chain, [4] sweep launches that signalled their start,
+// [5] the poison word (SviSync::poison), [6] the concurrency probe's flag, [7] dead.
+static SviSync svi_sy(svihmm_ctx* h) {
+  SviSync sy = {};
+  if (h->svi_flags) { sy.status = h->svi_status_dev; sy.dead = svi_cnt(h, 7); sy.ticks = h->svi_ticks; }
+  return sy;
+}
+// Bound of a gate's wait.  A gate waits for work submitted earlier in host order, and the in-order side streams keep
+// it from starting more than one iteration ahead of what it waits for: 64 measured iteration periods (at least 50 ms)
+// once the device stamps of a finished iteration are there, 2 s before that, plus 20 us per row of the batch in
+// flight (adaptive windows / buffers grow between two measurements); never more than SVI_SYNC_TICKS (60 s).
+static unsigned long long svi_gate_ticks(const svihmm_ctx* h, int64_t rows) {
+  const double khz = h->wall_clock_khz > 0.0 ? h->wall_clock_khz : 100000.0;
+  double t = h->svi_period_ticks ? std::fmax(64.0 * (double)h->svi_period_ticks, 50.0 * khz) : 2000.0 * khz;
+  t += 0.02 * (double)rows * khz;
+  return t < (double)SVI_SYNC_TICKS ? (unsigned long long)t : SVI_SYNC_TICKS;
+}
 static int svi_launch_gate(svihmm_ctx* h, hipStream_t st, int which, unsigned long long tgt) {
   if (tgt == 0) return 0;
-  SviSync sy = {svi_cnt(h, which), (unsigned)tgt, nullptr, h->svi_status_dev, nullptr};
+  SviSync sy = svi_sy(h);
+  sy.gate = svi_cnt(h, which); sy.gate_tgt = (unsigned)tgt;
   hipLaunchKernelGGL(k_svi_gate, dim3(1), dim3(64), 0, st, sy);
   HIPCK(hipGetLastError());
   return 0;
 }
-// One-time probe per handle (see k_svi_probe_wait): the waiter goes first and the setter is launched only once
-// the waiter reports that it is running, so the outcome does not depend on which queue a serialising tool serves
-// first.  ~30 us where kernels overlap, 2 ms where they do not.
+// One-time probe per handle (see k_svi_probe_wait), for each of the loop's two side streams against the main one:
+// the waiter goes first and the setter is launched only once the waiter reports that it is running, so the outcome
+// does not depend on which queue a serialising tool serves first.  ~30 us per stream where kernels overlap, 2 ms
+// where they do not.
 static int svi_probe_concurrency(svihmm_ctx* h) {
   if (h->svi_concurrent >= 0) return 0;
   if (!h->stream2) HIPCK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+  if (!h->stream3) HIPCK(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
   unsigned* pin = reinterpret_cast<unsigned*>(h->pin_status);      // words 2, 3: started / result (mapped)
   unsigned* dpin = nullptr;
   HIPCK(hipHostGetDevicePointer((void**)&dpin, pin, 0));
   unsigned* flag = svi_cnt(h, 6);
   volatile unsigned* vp = pin;
-  vp[2] = 0; vp[3] = 2;
-  HIPCK(hipMemset(flag, 0, sizeof(unsigned)));
-  hipLaunchKernelGGL(k_svi_probe_wait, dim3(1), dim3(64), 0, h->stream2, (const unsigned*)flag, dpin + 2, dpin + 3,
-                     200000ull);
-  HIPCK(hipGetLastError());
-  for (int spin = 0; spin < 2000000 && vp[2] == 0; ++spin) { for (volatile int w = 0; w < 20; ++w) {} }
-  hipLaunchKernelGGL(k_svi_probe_set, dim3(1), dim3(64), 0, h->stream, flag);
-  HIPCK(hipGetLastError());
-  HIPCK(hipStreamSynchronize(h->stream2));
-  HIPCK(hipStreamSynchronize(h->stream));
-  h->svi_concurrent = vp[3] == 1 ? 1 : 0;
+  int ok = 1;
+  hipStream_t side[2] = {h->stream2, h->stream3};
+  for (int i = 0; i < 2 && ok; ++i) {
+    vp[2] = 0; vp[3] = 2;
+    HIPCK(hipMemset(flag, 0, sizeof(unsigned)));
+    hipLaunchKernelGGL(k_svi_probe_wait, dim3(1), dim3(64), 0, side[i], (const unsigned*)flag, dpin + 2, dpin + 3,
+                       200000ull);
+    HIPCK(hipGetLastError());
+    for (int spin = 0; spin < 2000000 && vp[2] == 0; ++spin) { for (volatile int w = 0; w < 20; ++w) {} }
+    hipLaunchKernelGGL(k_svi_probe_set, dim3(1), dim3(64), 0, h->stream, flag);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(side[i]));
+    HIPCK(hipStreamSynchronize(h->stream));
+    ok = vp[3] == 1 ? 1 : 0;
+  }
+  h->svi_concurrent = ok;
   return 0;
 }
-static int svi_globals(svihmm_ctx* h, int slot) {
+static int svi_globals(svihmm_ctx* h, int slot, int for_it) {
   const int K = h->svi_K;
   double* vi_out = svi_ptr(h, slot ? 7 : 2);
   const size_t kk = (size_t)K * K * sizeof(double);
@@ -1310,8 +1350,12 @@ static int svi_globals(svihmm_ctx* h, int slot) {
     HIPCK(hipEventCreateWithFlags(&h->svi_eb, hipEventDisableTiming));
   }
   hipStream_t s2 = h->stream2;
-  SviSync gsy = {nullptr, 0u, nullptr, nullptr, nullptr};
-  if (h->svi_flags) { gsy.arrive = svi_cnt(h, 1); h->tgt_glob += (unsigned)(K + 1); }
+  // (a globals kernel that finds the loop dead does not run: the iteration its output is for is poisoned)
+  SviSync gsy = svi_sy(h);
+  if (h->svi_flags) {
+    gsy.arrive = svi_cnt(h, 1); h->tgt_glob += (unsigned)(K + 1);
+    gsy.poison = svi_cnt(h, 5); gsy.poison_val = SVI_POISON_BASE - (unsigned)(for_it < 0 ? 0 : for_it);
+  }
   if (h->svi_flags && h->tgt_step > 0) {
     // no event on the main stream: the side stream waits for the global steps launched so far in a one-wave gate
     CK(svi_launch_gate(h, s2, 0, h->tgt_step));
@@ -1365,7 +1409,7 @@ static int svi_refresh_emission(svihmm_ctx* h, int elbo_it, int lb_slot, hipEven
   }
   // flags mode: the builder's K workgroups arrive on the theta counter (the ELBO kernels' gate) and workgroup 0
   // stamps the end of the iteration
-  SviSync tsy = {nullptr, 0u, nullptr, nullptr, nullptr};
+  SviSync tsy = {};
   if (h->svi_flags) {
     tsy.arrive = svi_cnt(h, 2);
     h->tgt_theta += (unsigned)K;
@@ -1383,7 +1427,7 @@ static int svi_refresh_emission(svihmm_ctx* h, int elbo_it, int lb_slot, hipEven
     h->eK = K; h->eD = 1; h->Kp = K > 64 ? (K + 63) / 64 * 64 : (K + 15) / 16 * 16;
     h->have_emission = true; h->emis_cat = true; h->emis_diag = false; h->uw_valid = false;
   }
-  h->theta_sy = SviSync{nullptr, 0u, nullptr, nullptr, nullptr};
+  h->theta_sy = SviSync{};
   h->lin_stale = true;
 #ifdef SVIHMM_MEASURE
   if (h->variant[0] == 9) return 0;    // measurement only: no ELBO kernels at all
@@ -1400,7 +1444,9 @@ static int svi_refresh_emission(svihmm_ctx* h, int elbo_it, int lb_slot, hipEven
 static int svi_launch_elbo(svihmm_ctx* h, int elbo_it, int lb_slot, bool behind_sweeps, hipEvent_t after_theta) {
   const int K = h->svi_K, D = h->svi_D, fam = h->svi_family;
   hipStream_t s2 = h->stream3;
-  SviSync vsy = {nullptr, 0u, nullptr, nullptr, nullptr};
+  // (the ELBO kernels follow their gate kernels in stream order: when a gate gave up they find the loop dead and
+  //  leave the iteration's entry NaN -- svi_recover computes it again where the state still allows)
+  SviSync vsy = svi_sy(h);
   if (h->svi_flags) {
     CK(svi_launch_gate(h, s2, 2, h->tgt_theta));
     if (behind_sweeps) CK(svi_launch_gate(h, s2, 4, h->tgt_early));
@@ -1507,6 +1553,9 @@ static int svi_begin_common(svihmm_ctx* h, int K, int D, const double* prior_tra
   h->svi_flags = h->variant[0] != 1;
   h->tgt_step = h->tgt_glob = h->tgt_theta = h->tgt_side = h->tgt_early = 0;
   h->elbo_pending = false;
+  h->svi_period_ticks = 0; h->svi_cur_it = -1; h->svi_replaying = false; h->svi_recoveries = 0;
+  for (auto& e : h->svi_log) e.it = -1;
+  h->svi_it_events.assign(maxit, (char)0);
   if (h->svi_flags) {
     // (begin is cold: the counters are zeroed with every stream idle, so no gate of this loop can see a
     //  previous loop's counts)
@@ -1536,6 +1585,7 @@ static int svi_begin_common(svihmm_ctx* h, int K, int D, const double* prior_tra
       if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device) != hipSuccess || khz <= 0) khz = 100000;
       h->wall_clock_khz = (double)khz;
     }
+    h->svi_ticks = svi_gate_ticks(h, 0);
   }
   // (event choreography only: the counter loop times its iterations with device stamps)
   while (!h->svi_flags && (int)h->svi_ev.size() < 2 * maxit) {      // [2 it]: first launch of iteration it, [2 it + 1]: its last
@@ -1552,7 +1602,7 @@ static int svi_begin_finish(svihmm_ctx* h) {
   for (auto& ss : h->svi_starts) ss.used_it = -1;
   CK(svi_refresh_emission(h, -1, 0));   // theta / table of the initial factors (their vlb is not used)
   h->svi_vi_cur = 1;
-  CK(svi_globals(h, 0));             // globals of iteration 0
+  CK(svi_globals(h, 0, 0));          // globals of iteration 0
   h->svi_active = true;
   return 0;
 }
@@ -1646,6 +1696,66 @@ int svihmm_svi_begin_cat(svihmm_ctx* h, int32_t K, int32_t V, const double* prio
   return svi_begin_finish(h);
 }
 
+static int svi_iteration_impl(svihmm_ctx* h, int32_t it, const int64_t* starts, int32_t B, int32_t nwin_total,
+                              int32_t Lm, int32_t inner_off, int32_t inner_len, uint32_t flags, double rho,
+                              double bfactA, double bfactE);
+// Leave the counters in the middle of a loop and carry on with the stream-event choreography (round 6).  Two
+// callers: a gate of the loop gave up (the status word is set: a tool that serialises kernels attached after
+// svihmm_svi_begin's probe, another process time-slicing the device, a partition too small for the loop's
+// kernels side by side), or the host decides to (`clean`: debug variant 0 = 2).  When a gate gave up the loop is
+// dead on the device: every later gate returned at once, the E-steps whose inputs were missing poisoned their
+// iteration and the global steps from that iteration on did not run (device_helpers.h) -- the loop's state is the
+// one after iteration p - 1, whole.  The iterations from p on are replayed from the host's log (the host runs at
+// most eight iterations ahead: the window-start ring), the last applied iteration's ELBO entry is formed again
+// if its kernels were caught by the shutdown.  The event loop computes bit for bit what the counter loop does
+// (tests/test_gpu_classes.py::test_svi_loop_on_counters_equals_the_stream_event_loop).
+static int svi_recover(svihmm_ctx* h, bool clean) {
+  if (!h->svi_flags) return 0;
+  if (clean) CK(svi_flush_elbo(h));
+  HIPCK(hipStreamSynchronize(h->stream));
+  if (h->stream2) HIPCK(hipStreamSynchronize(h->stream2));
+  if (h->stream3) HIPCK(hipStreamSynchronize(h->stream3));
+  unsigned poison = 0;
+  HIPCK(hipMemcpy(&poison, svi_cnt(h, 5), sizeof(unsigned), hipMemcpyDeviceToHost));
+  const int submitted = h->svi_last_it;                     // last iteration handed to the device
+  const int p = poison ? (int)(SVI_POISON_BASE - poison) : submitted + 1;   // first iteration that did not reach the state
+  HIPCK(hipMemset(h->svi_sync.p, 0, 8 * 64));
+  h->pin_status[1] = 0;
+  h->tgt_step = h->tgt_glob = h->tgt_theta = h->tgt_side = h->tgt_early = 0;
+  h->elbo_pending = false; h->vlb_pending = false; h->globals_ev = nullptr;
+  h->svi_flags = false;
+  ++h->svi_recoveries;
+  while ((int)h->svi_ev.size() < 2 * h->svi_maxit) {
+    hipEvent_t e;
+    HIPCK(hipEventCreate(&e));
+    h->svi_ev.push_back(e);
+  }
+  if (p > submitted + 1 || p < 0) return fail("SVI loop: inconsistent poison word after a gate gave up");
+  // the ELBO entry of the last iteration that did reach the state: its kernels may have found the loop dead
+  if (p >= 1 && std::isnan(h->svi_elbo[p - 1])) CK(svi_launch_elbo(h, p - 1, (p - 1) & 1, false, nullptr));
+  if (p > submitted) return 0;                              // nothing was lost: the next iteration's globals are in place
+  // replay iterations p .. submitted
+  for (int j = p; j <= submitted; ++j)
+    if (h->svi_log[j % 16].it != j) return fail("SVI loop: iteration " + std::to_string(j) + " is no longer in the replay log");
+  h->svi_globals_ready = false;                             // (the globals on the device stem from a skipped kernel)
+  h->svi_last_it = p - 1;
+  h->svi_vmin = h->svi_log[p % 16].vmin_before;
+  h->svi_f32_ok = h->svi_log[p % 16].f32_ok_before;
+  h->svi_replaying = true;
+  int rc = 0;
+  for (int j = p; j <= submitted && rc == 0; ++j) {
+    const SviLogEntry& e = h->svi_log[j % 16];
+    rc = svi_iteration_impl(h, e.it, e.starts.data(), e.B, e.nwin, e.Lm, e.off, e.len, e.flags, e.rho, e.bA, e.bE);
+  }
+  h->svi_replaying = false;
+  return rc;
+}
+int svihmm_svi_recoveries(svihmm_ctx* h, int32_t* out) {
+  if (!h || !out) return fail("svihmm_svi_recoveries: bad arguments");
+  *out = h->svi_recoveries;
+  return 0;
+}
+
 int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32_t B, int32_t nwin_total,
                          int32_t Lm, int32_t inner_off, int32_t inner_len, uint32_t flags, double rho,
                          double bfactA, double bfactE) {
@@ -1654,7 +1764,35 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
   if (B < 0 || (B > 0 && !starts) || nwin_total < B) return fail("svihmm_svi_iteration: bad window batch");
   if (flags & SVIHMM_USE_HOST_LLIKS) return fail("svihmm_svi_iteration: device-side emission families only");
   CK(set_device(h));
+  if (h->svi_flags) {
+    // a gate of the loop gave up since the last call (mapped status word: a plain host read)
+    if (h->pin_status && *(volatile int*)&h->pin_status[1] != 0) CK(svi_recover(h, false));
+    else if (h->variant[0] == 2 && it == 3) CK(svi_recover(h, true));     // (debug: "concurrency lost" between two iterations)
+  }
+  if (h->svi_flags) {
+    // the iteration period, from the device stamps of an iteration that is certainly complete (eight back)
+    const int j = it - 8;
+    if (j >= 0 && (int)h->svi_ev_begin.size() > j && h->svi_ts) {
+      const unsigned long long t0 = h->svi_ts[h->svi_ev_begin[j]], t1 = h->svi_ts[2 * j + 1];
+      if (t0 && t1 > t0 && t1 - t0 > h->svi_period_ticks) h->svi_period_ticks = t1 - t0;
+    }
+    h->svi_ticks = svi_gate_ticks(h, (int64_t)B * Lm);
+  }
+  {
+    SviLogEntry& e = h->svi_log[it % 16];
+    e.it = it; e.B = B; e.nwin = nwin_total; e.Lm = Lm; e.off = inner_off; e.len = inner_len; e.flags = flags;
+    e.rho = rho; e.bA = bfactA; e.bE = bfactE; e.vmin_before = h->svi_vmin; e.f32_ok_before = h->svi_f32_ok;
+    e.starts.assign(starts, starts + (B > 0 ? B : 0));
+  }
+  return svi_iteration_impl(h, it, starts, B, nwin_total, Lm, inner_off, inner_len, flags, rho, bfactA, bfactE);
+}
+static int svi_iteration_impl(svihmm_ctx* h, int32_t it, const int64_t* starts, int32_t B, int32_t nwin_total,
+                              int32_t Lm, int32_t inner_off, int32_t inner_len, uint32_t flags, double rho,
+                              double bfactA, double bfactE) {
   const int K = h->svi_K, D = h->svi_D;
+  h->svi_cur_it = it;
+  if ((int)h->svi_it_events.size() < h->svi_maxit) h->svi_it_events.resize(h->svi_maxit, (char)0);
+  h->svi_it_events[it] = h->svi_flags ? (char)0 : (char)1;
   // start of the iteration: when the previous iteration is still running, the stream would execute
   // this marker right behind that iteration's end marker -- the end marker serves as both
   if ((int)h->svi_ev_begin.size() < h->svi_maxit) h->svi_ev_begin.resize(h->svi_maxit, 0);
@@ -1674,7 +1812,7 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
     HIPCK(hipEventRecord(h->svi_ev[2 * it], h->stream));
   (void)hipGetLastError();            // (hipErrorNotReady is not an error here)
   h->svi_last_it = it;
-  if (!h->svi_globals_ready) CK(svi_globals(h, h->svi_vi_cur ^ 1));   // (a host set_globals came in between)
+  if (!h->svi_globals_ready) CK(svi_globals(h, h->svi_vi_cur ^ 1, it));   // (a host set_globals came in between)
   h->svi_vi_cur = h->svi_globals_slot;
   h->svi_globals_ready = false;       // consumed by this iteration's sweeps
   const bool keep = (flags & SVIHMM_SVI_KEEP_WINDOW) != 0;
@@ -1705,19 +1843,32 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
     ProfScope ps(h, KS_ALLREDUCE);
     CK(allreduce_packed_dev(h));
   }
+  const bool flushed_now = h->elbo_pending;
   CK(svi_flush_elbo(h));   // (an empty shard, or an E-step that failed over to an ungated path)
   CK(wait_globals(h));     // (an empty shard ran no sweeps; a gated sweep kernel has cleared the event)
   // the previous iteration's ELBO kernels (their own stream) read var_tran / theta / logdet,
   // which this global step and the NIW kernel after it rewrite (normally long finished): flags mode gates the
   // step kernel on their counter, the event mode waits for their event
-  SviSync ssy = {nullptr, 0u, nullptr, nullptr, nullptr};
+  const unsigned ntran = (unsigned)((K * K + 255) / 256);
+  const unsigned step_grid = h->svi_family == 0 ? (unsigned)K + ntran
+                                                : (unsigned)(((size_t)K * (h->svi_family == 1 ? D : h->V) + 255) / 256) + ntran;
+  SviSync ssy = svi_sy(h);
   if (h->svi_flags) {
-    ssy.gate = svi_cnt(h, 3); ssy.gate_tgt = (unsigned)h->tgt_side; ssy.arrive = svi_cnt(h, 0); ssy.status = h->svi_status_dev;
+    ssy.gate = svi_cnt(h, 3); ssy.gate_tgt = (unsigned)h->tgt_side; ssy.arrive = svi_cnt(h, 0);
+    ssy.poison = svi_cnt(h, 5);
     if (h->tgt_side == 0) ssy.gate = nullptr;
+    // A gated grid must leave room for what it waits for.  The step's workgroups all spin in their gate: a grid
+    // that can hold half the device's wave slots (K beyond ~600), or ELBO kernels that were enqueued only just now
+    // (svi_flush_elbo above: they may not be resident yet), could keep those kernels off the device -- the stream
+    // waits for their event instead (recorded in both modes, svi_launch_elbo).
+    const bool big = (size_t)step_grid * 4 > (size_t)h->ncu * h->waves_per_cu / 2;
+    if (ssy.gate && (big || flushed_now) && h->vlb_pending) {
+      HIPCK(hipStreamWaitEvent(h->stream, h->svi_ed, 0));
+      ssy.gate = nullptr;
+    }
   } else if (h->vlb_pending) { HIPCK(hipStreamWaitEvent(h->stream, h->svi_ed, 0)); h->vlb_pending = false; }
   {
     ProfScope ps(h, KS_MISC);
-    const unsigned ntran = (unsigned)((K * K + 255) / 256);
     double* adag = h->svi_adagrad ? svi_ptr(h, 9) : (double*)nullptr;
     if (h->svi_family == 0)
       hipLaunchKernelGGL(k_svi_global_step, dim3((unsigned)K + ntran), dim3(256), (size_t)3 * D * sizeof(double), h->stream,
@@ -1733,8 +1884,7 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
                          (double)nwin_total, svi_ptr(h, 8) + (it & 1), adag, (int)nem, ssy);
     }
     HIPCK(hipGetLastError());
-    if (h->svi_flags) h->tgt_step += (h->svi_family == 0 ? (unsigned)K + ntran
-                                                          : (unsigned)(((size_t)K * (h->svi_family == 1 ? D : h->V) + 255) / 256) + ntran);
+    if (h->svi_flags) h->tgt_step += step_grid;
   }
   // the next iteration's globals, ahead of time, forked right behind the global step (its own event:
   // forked behind theta together with the ELBO kernels it competes with the next emission GEMM,
@@ -1749,7 +1899,7 @@ int svihmm_svi_iteration(svihmm_ctx* h, int32_t it, const int64_t* starts, int32
     h->svi_vmin = (1.0 - rho) * h->svi_vmin + rho;
     h->svi_f32_ok = h->svi_vmin > 0.05;
   }
-  if (it + 1 < h->svi_maxit) CK(svi_globals(h, h->svi_vi_cur ^ 1));
+  if (it + 1 < h->svi_maxit) CK(svi_globals(h, h->svi_vi_cur ^ 1, it + 1));
   CK(svi_refresh_emission(h, it, it & 1, h->svi_flags ? (hipEvent_t) nullptr : h->svi_ev[2 * it + 1], it + 1 < h->svi_maxit));
   return 0;
 }
@@ -1782,28 +1932,29 @@ int svihmm_svi_read_adagrad(svihmm_ctx* h, double* ada_G_out) {
   return d2h_sync_small(h, ada_G_out, svi_ptr(h, 9), (size_t)h->svi_K * h->svi_K * sizeof(double));
 }
 
-// after a synchronisation of the main stream: did a gate of the loop give up (device_helpers.h, svi_gate)?
-static int svi_gate_check(svihmm_ctx* h) {
-  if (h->svi_flags && h->pin_status && h->pin_status[1] != 0) {
-    h->pin_status[1] = 0;
-    h->svi_active = false;
-    return fail("SVI loop: a device-side dependency was not met within its bound (a kernel of the loop did not "
-                "run); the loop's state is not usable -- variant 0 = 1 runs the loop on stream events");
+// Everything the loop has in flight is complete and has reached the loop's state: pending ELBO kernels launched,
+// all three streams idle and -- when a gate of the loop gave up on the way -- the lost iterations replayed on stream
+// events (svi_recover).  Every read of the loop's results starts here.
+static int svi_settle(svihmm_ctx* h) {
+  CK(svi_flush_elbo(h));
+  for (int pass = 0; pass < 2; ++pass) {
+    HIPCK(hipStreamSynchronize(h->stream));
+    if (h->stream2) HIPCK(hipStreamSynchronize(h->stream2));
+    if (h->stream3) HIPCK(hipStreamSynchronize(h->stream3));
+    if (!(h->svi_flags && h->pin_status && h->pin_status[1] != 0)) break;
+    CK(svi_recover(h, false));
   }
   return 0;
 }
 int svihmm_svi_read_elbo(svihmm_ctx* h, int32_t n, double* out_elbo, double* out_ms) {
   if (!h || !h->svi_active || n < 0 || n > h->svi_maxit) return fail("svihmm_svi_read_elbo: bad arguments");
   CK(set_device(h));
-  CK(svi_flush_elbo(h));
-  HIPCK(hipStreamSynchronize(h->stream));
-  if (h->stream2) HIPCK(hipStreamSynchronize(h->stream2));
-  if (h->stream3) HIPCK(hipStreamSynchronize(h->stream3));
+  CK(svi_settle(h));
   CK(check_emission_status(h));
-  CK(svi_gate_check(h));
   for (int i = 0; i < n; ++i) {
     if (out_elbo) out_elbo[i] = h->svi_elbo[i];
-    if (out_ms && h->svi_flags) {
+    // (per iteration: a loop that left the counters mid-way timed its later iterations with events)
+    if (out_ms && !((int)h->svi_it_events.size() > i && h->svi_it_events[i])) {
       // device wall-clock stamps: begin (k_svi_stamp, or the previous iteration's end) to the theta builder's end
       const int bi = (int)h->svi_ev_begin.size() > i ? h->svi_ev_begin[i] : 2 * i;
       const unsigned long long t0 = h->svi_ts[bi], t1 = h->svi_ts[2 * i + 1];
@@ -1821,6 +1972,7 @@ int svihmm_svi_read_state(svihmm_ctx* h, double* var_tran, double* var_init, dou
   if (!h || !h->svi_active) return fail("svihmm_svi_read_state: no SVI state on the device");
   if (h->svi_family != 0) return fail("svihmm_svi_read_state: NIW layout; this loop's family reads through svihmm_svi_read_factors");
   CK(set_device(h));
+  CK(svi_settle(h));
   const size_t K = h->svi_K, D = h->svi_D, nmu = K * D, nsg = K * D * D;
   const double* nw = (const double*)h->niw.p;
   if (var_tran) CK(d2h(h, var_tran, svi_ptr(h, 0), K * K * 8));
@@ -1833,7 +1985,6 @@ int svihmm_svi_read_state(svihmm_ctx* h, double* var_tran, double* var_init, dou
   HIPCK(hipStreamSynchronize(h->stream));
   if (h->stream3) HIPCK(hipStreamSynchronize(h->stream3));   // ELBO kernels still reading niw / theta
   h->vlb_pending = false;
-  CK(svi_gate_check(h));
   if (mu) from_centred(h, mu, (int)K, (int)D);
   CK(check_emission_status(h));
   return 0;
@@ -1844,6 +1995,7 @@ int svihmm_svi_read_state(svihmm_ctx* h, double* var_tran, double* var_init, dou
 int svihmm_svi_read_factors(svihmm_ctx* h, double* var_tran, double* var_init, double* factors_out) {
   if (!h || !h->svi_active) return fail("svihmm_svi_read_factors: no SVI state on the device");
   CK(set_device(h));
+  CK(svi_settle(h));
   const size_t K = h->svi_K, D = h->svi_D;
   const size_t n = h->svi_family == 0 ? K * D + K * D * D + 2 * K : h->svi_family == 1 ? 4 * K * D : K * (size_t)h->V;
   if (var_tran) CK(d2h(h, var_tran, svi_ptr(h, 0), K * K * 8));
@@ -1853,7 +2005,6 @@ int svihmm_svi_read_factors(svihmm_ctx* h, double* var_tran, double* var_init, d
   HIPCK(hipStreamSynchronize(h->stream));
   if (h->stream3) HIPCK(hipStreamSynchronize(h->stream3));   // ELBO kernels still reading the factors
   h->vlb_pending = false;
-  CK(svi_gate_check(h));
   if (factors_out && h->svi_family != 2) from_centred(h, factors_out, (int)K, (int)D);
   CK(check_emission_status(h));
   return 0;

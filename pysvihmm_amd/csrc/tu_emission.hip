@@ -41,9 +41,12 @@ static int emd_buffers(svihmm_ctx* h, int K, uint4** uwp) {
 }
 // fp32 mode on a wide model (64 < K <= 256): NIW factors with D <= 64 in batches of at least 32 768 rows --
 // k_emission_bf16x3d<true>, k_scale_ll_f32, k_sweeps_lin2<..., float>, k_stats_bf16x3w (round 5)
+// (the statistics side of the same decision is stats_bf16w_shape_ok, tu_stats.hip: a batch enters the fp32 format
+//  only when BOTH ends have their kernel -- otherwise it runs fp64, as the header promises)
 bool f32_wide_ok(const svihmm_ctx* h, int64_t n) {
   return !h->emis_diag && !h->emis_cat && h->K > 64 && h->K <= 256 && h->D <= 64 && h->niw.p != nullptr &&
-         h->variant[5] != 3 && h->variant[10] != 2 && (n >= 32768 || h->variant[10] == 3);
+         h->variant[5] != 3 && h->variant[10] != 2 && (n >= cu_scaled(h, 32768) || h->variant[10] == 3) &&
+         stats_bf16w_shape_ok(h, n);
 }
 int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out) {
   CK(upload_feature_table(h, D, K));
@@ -256,7 +259,7 @@ int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled,
   // scaling pass follows): the centred bf16 x 3 kernel with 64-dimension pair records (round 5)
   const bool wide32 = !scaled && h->cur_f32 && K > 64;
   if (!h->emis_diag && ((scaled && (flags & SVIHMM_INT_ST32) && K <= 64) || wide32) && emd_shape_ok(K, D) && h->niw.p &&
-      h->variant[5] != 3 && min_lds == 0 && (n >= 32768 || h->variant[10] == 3)) {
+      h->variant[5] != 3 && min_lds == 0 && (n >= cu_scaled(h, 32768) || h->variant[10] == 3)) {
     uint4* uwp = nullptr;
     CK(device_starts());
     CK(emd_buffers(h, K, &uwp));

@@ -163,17 +163,26 @@ static int launch_lin_init(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_t st
 // minibatch-sized batches, 16 < K <= 64: the kernels that split one window over one wave's registers (fp64,
 // k_wave_linr) or four waves (fp32 storage, k_wave_lin4)
 static bool minibatch_wave_kernel(const svihmm_ctx* h, int K, int nb, int Lm) {
-  if (K <= 16 || K > 64 || nb >= LIN_WAVE_MAX || h->variant[7] == 2 || h->variant[7] == 3) return false;
-  return h->cur_f32 ? nb <= LIN_WAVE4_MAX : (nb <= LIN_WAVER_MAX && Lm <= (1 << 20));
+  if (K <= 16 || K > 64 || nb >= lin_wave_max(h) || h->variant[7] == 2 || h->variant[7] == 3) return false;
+  return h->cur_f32 ? nb <= lin_wave4_max(h) : (nb <= lin_waver_max(h) && Lm <= (1 << 20));
 }
 // SVI loop on counters (svihmm_hip.hip, svi_globals): those two kernels wait for the side stream's globals
 // kernel themselves -- no stream-order event in front of them
 static SviSync sweep_gate(svihmm_ctx* h, hipStream_t stream) {
-  SviSync sy = {nullptr, 0u, nullptr, nullptr, nullptr, 0u, nullptr};
+  SviSync sy = {};
   if (h->svi_flags && h->in_svi_estep && h->globals_ev && stream == h->stream && h->svi_sync.p) {
     sy.gate = (const unsigned*)h->svi_sync.p + 16;
     sy.gate_tgt = (unsigned)h->tgt_glob;
     sy.status = h->svi_status_dev;
+    // (sweeps that cannot get their globals poison their iteration: the global step behind them does not run)
+    sy.dead = (unsigned*)h->svi_sync.p + 16 * 7;
+    sy.ticks = h->svi_ticks;
+    sy.poison = (unsigned*)h->svi_sync.p + 16 * 5;
+    sy.poison_val = SVI_POISON_BASE - (unsigned)(h->svi_cur_it < 0 ? 0 : h->svi_cur_it);
+    if (h->variant[0] == 3 && h->svi_cur_it == 3) {      // (debug: a count that never comes, 2 ms bound -- svi_recover's test)
+      sy.gate_tgt += 1000u;
+      sy.ticks = (unsigned long long)(2.0 * (h->wall_clock_khz > 0.0 ? h->wall_clock_khz : 100000.0));
+    }
     h->globals_ev = nullptr;
   }
   if (h->svi_flags && h->in_svi_estep && stream == h->stream && h->svi_sync.p && h->elbo_pending) {
@@ -249,7 +258,7 @@ int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_t strea
       HIPCK(hipGetLastError());
       return 0;
     }
-    if (nb < LIN_WAVE_MAX && h->variant[7] != 2) {
+    if (nb < lin_wave_max(h) && h->variant[7] != 2) {
       dim3 gw((unsigned)nb, 2);
 #define WLF(KM, FK) hipLaunchKernelGGL((k_wave_lin<KM, FK, float>), gw, dim3(64), 0, stream, Ef, kx, (const double*)h->Aexp.p, \
                                        (const double*)h->AexpT.p, mi, l0, l0s, Lm, K, af, bf, hx,   \
@@ -261,7 +270,7 @@ int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_t strea
       //  arithmetic: 278 against 303 ns per step, but over 257 steps the statistics drift to 1.2e-4 of the fp64
       //  oracle -- inside the mode's 1e-3, above this suite's 1e-4 canary; the fp32 mode keeps the four-wave
       //  kernel, which computes in fp64 on float storage)
-      if (wave_kernel && nb <= LIN_WAVER_MAX && Lm <= (1 << 20) && h->variant[7] != 4) {
+      if (wave_kernel && nb <= lin_waver_max(h) && Lm <= (1 << 20) && h->variant[7] != 4) {
         // (round 5, second half: the one-wave register-resident kernel with fp64 arithmetic on the float storage)
         const SviSync gsy = sweep_gate(h, stream);
         hipLaunchKernelGGL((k_wave_linr<float, double>), gw, dim3(64), 0, stream, Ef, kx, (const double*)h->Aexp.p,
@@ -288,7 +297,7 @@ int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_t strea
     HIPCK(hipGetLastError());
     return 0;
   }
-  if (K <= 64 && nb < LIN_WAVE_MAX && h->variant[7] != 2) {
+  if (K <= 64 && nb < lin_wave_max(h) && h->variant[7] != 2) {
     // small batches: one wavefront per (window, direction)
     dim3 gw((unsigned)nb, 2);
 #define WL(KM, FK) hipLaunchKernelGGL((k_wave_lin<KM, FK>), gw, dim3(64), 0, stream, Eh, kx, (const double*)h->Aexp.p, \

@@ -31,7 +31,7 @@ static bool stats_bf16_ok(const svihmm_ctx* h, int64_t n) {
   //  workgroups: one 8-wave workgroup per chunk would leave most CUs idle)
   return h->cur_f32 && h->lin_mode && !h->q_valid && h->K == 64 && h->Kp == 64 && h->D <= 32 && h->Fp > 0 &&
          h->Fp % 32 == 0 && !h->emis_cat && !h->emis_diag && h->variant[10] != 2 && h->variant[1] == 0 &&
-         (n >= 32768 || h->variant[10] == 3);     // (variant[10] = 3: tests force it on small batches)
+         (n >= cu_scaled(h, 32768) || h->variant[10] == 3);     // (variant[10] = 3: tests force it on small batches)
 }
 // ... and k_stats_bf16x3w (round 5) for what that kernel does not take: wide models (64 < K <= 256) and more
 // than 22 feature tiles (D > 32); D <= 64 (two stage buffers of x^T + six planes in 160 KB of LDS)
@@ -44,29 +44,36 @@ static bool stats_bf16_ok(const svihmm_ctx* h, int64_t n) {
 // stages each instead of ~50 (k_stats_bf16x3 with its floor lifted: 47 us; the fp32-input MFMA kernel: 30 us).
 static int bw_feature_groups(const svihmm_ctx* h, int64_t n) {
   const int FT = (h->Fp + 31) / 32, NGz = (h->Kp + 63) / 64;
-  if (n < 32768) return std::max(NGz, (FT + 5) / 6);
+  if (n < cu_scaled(h, 32768)) return std::max(NGz, (FT + 5) / 6);
   return std::max(NGz, (FT + 21) / 22);
 }
 static size_t bw_lds(const svihmm_ctx* h) {
   const size_t xb = (((size_t)(h->D + 2) * SB_XRS * 4) + 15) & ~(size_t)15;
   return 2 * (xb + 6 * (size_t)64 * SB_QRS * 2) + 3 * SB_ROWS * sizeof(SbRow);
 }
-static bool stats_bf16w_ok(const svihmm_ctx* h, int64_t n) {
+// the part of the test that does not depend on the batch in flight: prepare_ll decides with it whether a wide model's
+// batch may enter the fp32 format at all (f32_wide_ok, tu_emission.hip) -- ONE predicate, so the emission / sweep side
+// can never commit to float for a batch this side has no kernel for
+bool stats_bf16w_shape_ok(const svihmm_ctx* h, int64_t n) {
   // (a wide model that runs in the fp32 format has no other statistics kernel: no batch-size floor there)
   // (D <= 64: the kernel stages x columns 0..63 from the observations and treats columns 64, 65 as the ones / zero
   //  columns -- found by the fuzz at K = 64, D = 79 with the floors lifted)
-  return h->cur_f32 && h->lin_mode && !h->q_valid && h->K <= 256 && h->D <= 64 && h->Kp % 64 == 0 && h->Fp > 0 && !h->emis_cat &&
+  return h->K <= 256 && h->D <= 64 && h->Kp % 64 == 0 && h->Fp > 0 && !h->emis_cat &&
          !h->emis_diag && h->variant[10] != 2 && h->variant[1] == 0 && bw_lds(h) <= 160 * 1024 &&
-         (h->K > 64 || ((h->Fp + 31) / 32 + 2 > 24 && (n >= 32768 || h->variant[10] == 3)) ||
-          (n >= 8192 && n < 32768 && h->variant[10] != 3));      // (minibatch-sized batches at K = 64: the six-tile groups)
+         (h->K > 64 || ((h->Fp + 31) / 32 + 2 > 24 && (n >= cu_scaled(h, 32768) || h->variant[10] == 3)) ||
+          (n >= cu_scaled(h, 8192) && n < cu_scaled(h, 32768) && h->variant[10] != 3));      // (minibatch-sized batches at K = 64: the six-tile groups)
+}
+static bool stats_bf16w_ok(const svihmm_ctx* h, int64_t n) {
+  return h->cur_f32 && h->lin_mode && !h->q_valid && stats_bf16w_shape_ok(h, n);
 }
 StatsPlan stats_plan(const svihmm_ctx* h, int64_t n, int forced) {
-  int target_chunks = forced > 0 ? forced : 128;
+  int target_chunks = forced > 0 ? forced : (int)cu_scaled(h, 128);
   if (forced <= 0 && !stats_bf16_ok(h, n) && stats_bf16w_ok(h, n)) {
     // chunks x feature groups x state groups = whole rounds of 256 one-per-CU workgroups, >= 32 chunks
     const int per_chunk = bw_feature_groups(h, n) * ((h->Kp + 63) / 64);
-    const int R = std::max(1, (32 * per_chunk + 255) / 256);
-    int64_t tc = std::max(1, 256 * R / per_chunk);
+    const int ncu = h->ncu;
+    const int R = std::max(1, (32 * per_chunk + ncu - 1) / ncu);
+    int64_t tc = std::max(1, ncu * R / per_chunk);
     if (tc > n / (4 * SB_ROWS)) tc = std::max<int64_t>(1, n / (4 * SB_ROWS));
     int64_t rpc = ((n + tc - 1) / tc + SB_ROWS - 1) / SB_ROWS * SB_ROWS;
     return {rpc, (n + rpc - 1) / rpc};
@@ -76,17 +83,18 @@ StatsPlan stats_plan(const svihmm_ctx* h, int64_t n, int forced) {
     // at least four 64-row stages)
     int64_t tc = n / (4 * SB_ROWS);
     if (tc < 1) tc = 1;
-    if (tc > 256) tc = 256;
+    if (tc > h->ncu) tc = h->ncu;
     int64_t rpc = ((n + tc - 1) / tc + SB_ROWS - 1) / SB_ROWS * SB_ROWS;
     return {rpc, (n + rpc - 1) / rpc};
   }
   if (forced <= 0 && h->Kp <= 64 && h->Fp > 0 && !h->emis_cat) {
     const int gy = ((h->Fp + h->Kp) / 16 + 4 * stats_mt(h) - 1) / (4 * stats_mt(h));
-    const int r = std::max(1, (128 * gy + 128) / 256);     // rounds: round(128 gy / 256)
+    const int ncu = h->ncu;
+    const int r = std::max(1, (ncu / 2 * gy + ncu / 2) / ncu);     // rounds: round((CUs / 2) gy / CUs)
     // one state tile (K <= 16): the 4-wave workgroups are small enough for two per CU, and the
     // launch is latency- rather than MFMA-bound (K = 16, D = 32: 0.61 -> 0.46 ms); wider models: one
     const int per_cu = (h->Kp == 16 && n >= (int64_t)1 << 18) ? 2 : 1;   // (small batches: more chunks only add partial sums)
-    target_chunks = std::max(1, 256 * r * per_cu / gy);
+    target_chunks = std::max(1, ncu * r * per_cu / gy);
   }
   int64_t rpc = (n + target_chunks - 1) / target_chunks;
   const int rb = (stats_bf16_ok(h, n) || stats_bf16w_ok(h, n)) ? SB_ROWS : ST_RB;     // (a forced chunk count: the bf16 kernels' stage)

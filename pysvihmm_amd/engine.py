@@ -522,6 +522,12 @@ class HipEngine(object):
         L.check(self._lib.svihmm_svi_read_elbo(self._h, int(n), L.dptr(e), L.dptr(ms)), "svihmm_svi_read_elbo")
         return e, ms
 
+    def svi_recoveries(self):
+        """How often the current loop left its device-side counters for stream events mid-way (svihmm_debug.h)."""
+        n = C.c_int32()
+        L.check(self._lib.svihmm_svi_recoveries(self._h, C.byref(n)), "svihmm_svi_recoveries")
+        return int(n.value)
+
     def svi_read_state(self):
         """Current (var_tran, var_init, mu, sigma, kappa, nu); waits for the device."""
         K, D = self._svi_shape
@@ -601,9 +607,9 @@ class HipEngine(object):
         return self._lib.svihmm_last_kernel_name(self._h, names.index(slot_name)).decode()
 
     def set_variant(self, which, value):
-        # ("svi_loop" = 1: the resident SVI loop on stream events instead of device-side counters; it shares
-        #  slot 0 with the retired "emission" choice, whose values the library ignores)
-        idx = {"emission": 0, "svi_loop": 0, "stats": 1, "fb": 2, "emission_mt": 3, "pipeline": 4, "emission_orbit": 5, "chain": 6}[which] if isinstance(which, str) else which
+        # ("svi_loop", slot 0 -- 1: the resident SVI loop on stream events instead of device-side counters;
+        #  include/svihmm_debug.h lists every slot)
+        idx = {"svi_loop": 0, "stats": 1, "fb": 2, "emission_mt": 3, "pipeline": 4, "emission_orbit": 5, "chain": 6}[which] if isinstance(which, str) else which
         L.check(self._lib.svihmm_set_variant(self._h, idx, int(value)), "set_variant")
 
     def selftest_mfma(self, A, B):

@@ -275,14 +275,21 @@ class VBHMM(VariationalHMMBase):
         # (the reference reads self.obs afresh in every call: so does this one.  Opt-in
         #  `self.assume_obs_unchanged = True` skips the upload while hmmbase._obs_fingerprint's
         #  sampled probe finds the buffer unchanged -- 256 MB at T = 1e6)
+        # wall-clock marks of the call's fixed part (not a reference attribute; bench.py reports it):
+        # obs upload | svi_begin | host submission of the iterations | wait + state read-back | last window
+        wall = self.infer_wall_ms = {}
+        t_mark = time.perf_counter()
         if not self._obs_unchanged():
             self._obs_dirty = True
         self._upload_obs()
+        wall["upload_obs"] = (time.perf_counter() - t_mark) * 1e3
 
         if fused and device_loop is not False and self._svi_device_ok():
             # variational state resident in HBM for the whole loop (engine.svi_*)
             self._infer_device(adaptive, perIter, epsilon, minHalfL, avgResidual, Lincrement, Lcutoff)
+            t_mark = time.perf_counter()
             self._resolve_pending()
+            wall["last_window"] = wall.get("last_window", 0.0) + (time.perf_counter() - t_mark) * 1e3
             self.metaobs_fun = None
             return
 
@@ -439,6 +446,8 @@ class VBHMM(VariationalHMMBase):
         L_ = self.metaobs_half
         miniL = bufferL = L_
         fam = self._svi_family()
+        wall = self.__dict__.setdefault("infer_wall_ms", {})
+        t_mark = time.perf_counter()
         if fam == "niw":
             prior = self._prior_arrays()
             fac = self._emission_arrays()
@@ -460,6 +469,8 @@ class VBHMM(VariationalHMMBase):
             eng.on_next_mutation(None)
         host_fresh = True            # the object's attributes equal the device state
         T = self.T
+        wall["svi_begin"] = (time.perf_counter() - t_mark) * 1e3
+        t_mark = time.perf_counter()
         # quirk Q3: batch factors from the CONSTRUCTOR's L and S, whatever the windows are
         bA = (T - 2 * self.metaobs_half - 1) / (2. * self.metaobs_half * self.mb_sz)
         bE = (T - 2 * self.metaobs_half - 1) / ((2. * self.metaobs_half + 1.) * self.mb_sz)
@@ -537,11 +548,15 @@ class VBHMM(VariationalHMMBase):
                 loop_globals_live = False
                 self.pred_logprob_full_mean[it] = np.nanmean(tmp)
                 self.pred_logprob_full_std[it] = np.nanstd(tmp)
+        wall["submit_iterations"] = (time.perf_counter() - t_mark) * 1e3
+        t_mark = time.perf_counter()
         if not host_fresh:
             self._svi_pull_state()
         e, ms = eng.svi_read_elbo(maxit)
         self.elbo_vec[:] = e
         self.iter_time[:] = ms * 1e-3
+        wall["wait_and_read_state"] = (time.perf_counter() - t_mark) * 1e3
+        t_mark = time.perf_counter()
         # the reference leaves the last local_update's psi-expectations on the object (:502-504).
         # (A validation hook after the last iteration has overwritten the handle's copy: they were
         #  read before it ran.  The loop always runs to maxit, so no globals kernel of a further
@@ -551,6 +566,7 @@ class VBHMM(VariationalHMMBase):
         if "_pending_rows" not in self.__dict__ and "_val_done" not in self.__dict__:
             self._register_last_window(eng, last)
         self.__dict__.pop("_val_done", None)
+        wall["last_window"] = (time.perf_counter() - t_mark) * 1e3
 
     def _register_last_window(self, eng, last):
         """lliks / lalpha / lbeta / var_x of the last window of the last minibatch, fetched from

@@ -51,10 +51,8 @@ def main():
             eng.set_globals(pb["mod_init"], pb["ltran"])
             eng.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
             ref_ll = np.stack([ref_c.lliks_niw(pb["obs"][s:s + Lm], pb["mu"], pb["sigma"], pb["kappa"], pb["nu"]) for s in starts])
-            for ev in (2,):
-                eng.set_variant("emission", ev)
-                ll = eng.loglik(starts, Lm)
-                print("  emission var %d: max abs err %.3g (|ll| max %.3g)" % (ev, np.abs(ll - ref_ll).max(), np.abs(ref_ll).max()))
+            ll = eng.loglik(starts, Lm)
+            print("  emission: max abs err %.3g (|ll| max %.3g)" % (np.abs(ll - ref_ll).max(), np.abs(ref_ll).max()))
             r = eng.forward_backward(starts, Lm)
             la = np.stack([ref_c.forward(ref_ll[b], pb["mod_init"], pb["ltran"]) for b in range(B)])
             lb = np.stack([ref_c.backward(ref_ll[b], pb["ltran"]) for b in range(B)])
@@ -70,7 +68,7 @@ def main():
                 print("  stats var %d: A %.3g xbar %.3g neff %.3g S %.3g lb %.3g (abs, scale %d)" % (
                     sv, np.abs(st.A_raw - A).max(), np.abs(st.xbar - xbar).max(), np.abs(st.neff - neff).max(),
                     np.abs(st.S - S).max(), abs(st.lb[0] - lbt), B * Lm))
-            eng.set_variant("emission", 0); eng.set_variant("stats", 0)
+            eng.set_variant("stats", 0)
         except Exception:
             traceback.print_exc()
 
@@ -87,7 +85,7 @@ def main():
         for B in (64, 3891):
             starts = (np.arange(B, dtype=np.int64) * Lm) % (T - Lm)
             for ev, sv, fv in ((2, 3, 2), (2, 2, 2), (2, 2, 1)):
-                eng.set_variant("emission", ev); eng.set_variant("stats", sv); eng.set_variant("fb", fv)
+                eng.set_variant("stats", sv); eng.set_variant("fb", fv)
                 eng.estep(starts, Lm, read=False); eng.sync()
                 eng.profile(True); eng.profile_reset()
                 t0 = time.time()

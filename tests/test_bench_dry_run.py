@@ -86,3 +86,21 @@ def test_self_launch_refusal_prints_the_error_record():
                        text=True, timeout=120)
     rec = json.loads([l for l in p.stdout.splitlines() if l.lstrip().startswith("{")][-1])
     assert rec["value"] is None and "HIP device" in rec["error"]
+
+
+def test_self_launch_without_the_built_library_prints_the_error_record():
+    """first contact with a box whose libsvihmm_hip.so is missing (or does not load) -- the
+    launcher's preamble raises before any rank exists; the ONE JSON line is still there."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["SVIHMM_HIP_LIB"] = "/nonexistent/libsvihmm_hip.so"
+    for gpus in ("2", "1"):
+        p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", gpus, "--steps", "1", "--warmup", "0"],
+                           env=env, capture_output=True, text=True, timeout=120)
+        assert p.returncode != 0
+        lines = [l for l in p.stdout.splitlines() if l.lstrip().startswith("{")]
+        assert len(lines) == 1, p.stdout + p.stderr
+        rec = json.loads(lines[0])
+        assert rec["value"] is None and rec["n_gpus"] == int(gpus) and "error" in rec

@@ -317,6 +317,91 @@ def test_svi_loop_on_counters_equals_the_stream_event_loop(K, D, B, Lm):
     assert np.all(ma > 0) and np.all(ma < 50) and np.all(mb > 0) and np.all(mb < 50), (ma, mb)
 
 
+def _loop_run(mode, K, D, B, Lm, T=4000, nit=12, repush_at=None):
+    """One resident loop on a fresh handle; mode = variant "svi_loop" (0 counters, 1 stream events, 2 counters +
+    a clean switch to events before iteration 3, 3 counters + a gate of iteration 3 that gives up after 2 ms)."""
+    import time
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd.distributions import niw_prior_logpart
+    from pysvihmm_amd import _lib as L
+    from tests.helpers import make_problem
+    pb = make_problem(K, D, T, seed=K + D)
+    rng = np.random.default_rng(K)
+    prior_tran = 1.0 + rng.random((K, K))
+    mu0 = np.tile(pb["obs"].mean(0), (K, 1)) + 0.1 * rng.normal(size=(K, D))
+    sg0 = np.tile(0.75 * np.cov(pb["obs"].T).reshape(D, D), (K, 1, 1))
+    ka0, nu0 = np.full(K, 0.01), np.full(K, D + 2.0)
+    bA, bE = (T - 2 * 8 - 1) / (2. * 8 * B), (T - 2 * 8 - 1) / ((2. * 8 + 1) * B)
+    eng = HipEngine(0)
+    try:
+        eng.set_variant("svi_loop", mode)
+        eng.set_obs(pb["obs"], pb["mask"])
+        eng.svi_begin(prior_tran, pb["var_tran"], (mu0, sg0, ka0, nu0),
+                      (pb["mu"], pb["sigma"], pb["kappa"], pb["nu"]), niw_prior_logpart(sg0, nu0), nit, 1.0)
+        r2 = np.random.default_rng(5)
+        t0 = time.time()
+        for it in range(nit):
+            eng.svi_iteration(it, r2.integers(0, T - Lm, size=B), B, Lm, L.TRANS_WRAP, (it + 1.0) ** -0.7, bA, bE)
+            if repush_at is not None and it == repush_at:
+                # different factors of the loop's own family and shape, with NO read in front (a read would launch
+                # the deferred ELBO kernels itself)
+                eng.set_emission_niw(pb["mu"] + 0.25, pb["sigma"] * 1.5, pb["kappa"], pb["nu"])
+        elbo, ms = eng.svi_read_elbo(nit)
+        st = eng.svi_read_state()
+        wall = time.time() - t0
+        return st, elbo, ms, eng.svi_recoveries(), wall
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("K,D,B,Lm", [(64, 8, 9, 33), (20, 5, 210, 9)])
+def test_svi_loop_switches_to_stream_events_mid_loop(K, D, B, Lm):
+    """VERDICT r5 next #6a: a loop that started on device-side counters carries on with the stream-event
+    choreography from an iteration boundary on (what a serialising tool attaching AFTER svihmm_svi_begin's probe
+    needs; emulated by the debug variant 0 = 2, which makes the host take that decision before iteration 3):
+    promptly, with the state, the ELBO trace and per-iteration times of an undisturbed loop -- bit for bit."""
+    ref = _loop_run(0, K, D, B, Lm)
+    sw = _loop_run(2, K, D, B, Lm)
+    assert ref[3] == 0 and sw[3] == 1
+    assert sw[4] < 1.0, "the switch stalled: %.2f s" % sw[4]
+    for n, a, b in zip(("var_tran", "var_init", "mu", "sigma", "kappa", "nu"), ref[0], sw[0]):
+        np.testing.assert_array_equal(a, b, err_msg=n)
+    np.testing.assert_array_equal(ref[1], sw[1])
+    assert np.all(np.isfinite(sw[1])) and np.all(sw[2] > 0) and np.all(sw[2] < 50), sw[2]
+
+
+def test_svi_loop_recovers_when_a_gate_gives_up():
+    """VERDICT r5 next #6 / ADVICE r5 low 3: a device-side dependency that is never met (debug variant 0 = 3: the
+    sweeps of iteration 3 wait for a count that does not come, bound 2 ms) must not cost maxit x 60 s nor the
+    loop's state: the gate gives up after its bound, the loop goes dead on the device (later gates return at once,
+    the poisoned iteration's global step and every later one do not run), the host finds the status word at its
+    next call, replays the lost iterations on stream events -- and the results are those of an undisturbed loop."""
+    K, D, B, Lm = 64, 8, 9, 33
+    ref = _loop_run(0, K, D, B, Lm)
+    rec = _loop_run(3, K, D, B, Lm)
+    assert rec[3] == 1, "no recovery took place"
+    assert rec[4] < 1.0, "the recovery stalled: %.2f s" % rec[4]
+    for n, a, b in zip(("var_tran", "var_init", "mu", "sigma", "kappa", "nu"), ref[0], rec[0]):
+        np.testing.assert_array_equal(a, b, err_msg=n)
+    np.testing.assert_array_equal(ref[1], rec[1])
+    assert np.all(np.isfinite(rec[1]))
+
+
+def test_factors_pushed_mid_loop_do_not_reach_the_pending_elbo_entry():
+    """svihmm_set_emission_niw on a live loop of the same family and shape (infer()'s
+    validation hooks) used to rewrite the factors while the previous iteration's ELBO kernels were still deferred
+    (counter mode): elbo_vec[it] then came from the pushed factors.  The entry points launch the deferred kernels
+    first now; both modes give the same trace, the entry of the iteration in front of the push included."""
+    K, D, B, Lm = 64, 8, 9, 33
+    a = _loop_run(0, K, D, B, Lm, nit=8, repush_at=4)
+    b = _loop_run(1, K, D, B, Lm, nit=8, repush_at=4)
+    undisturbed = _loop_run(0, K, D, B, Lm, nit=8)
+    np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_array_equal(a[1][:5], undisturbed[1][:5])     # entries 0..4 predate the push
+    for n, x, y in zip(("var_tran", "var_init", "mu", "sigma", "kappa", "nu"), a[0], b[0]):
+        np.testing.assert_array_equal(x, y, err_msg=n)
+
+
 _SERIAL_LOOP = r"""
 import sys, numpy as np
 sys.path.insert(0, sys.argv[1])

@@ -36,13 +36,11 @@ def test_mfma_f64_operand_layout(eng):
 
 
 @pytest.mark.parametrize("path", META, ids=[os.path.basename(p)[:-4] for p in META])
-@pytest.mark.parametrize("evar", [2], ids=["em_mfma"])
-def test_golden_windows(eng, path, evar):
+def test_golden_windows(eng, path):
     """Per-window intermediates vs the executed reference."""
     from pysvihmm_amd import _lib as L
     g = np.load(path)
     K, Lm = int(g["K"]), 2 * int(g["L"]) + 1
-    eng.set_variant("emission", evar)
     eng.set_obs(g["obs"], g["mask"])
     wpi = int(g["windows_per_iter"])
     for it in range(int(g["maxit"])):
@@ -63,7 +61,7 @@ def test_golden_windows(eng, path, evar):
             np.testing.assert_allclose(r["lbeta"], g["w_lbeta"][sl], rtol=1e-10, atol=1e-9)
             np.testing.assert_allclose(r["var_x"], g["w_var_x"][sl], rtol=RTOL, atol=1e-12)
             np.testing.assert_allclose(r["local_lb"], g["w_local_lb"][sl], rtol=1e-12)
-    eng.set_variant("emission", 0); eng.set_variant("fb", 0)
+    eng.set_variant("fb", 0)
 
 
 @pytest.mark.parametrize("path", META, ids=[os.path.basename(p)[:-4] for p in META])
@@ -182,7 +180,7 @@ def test_random_vs_c_oracle(eng, case, var):
         np.testing.assert_allclose(st.xbar, xbar, rtol=RTOL, atol=1e-8 * scale)
         np.testing.assert_allclose(st.S, S, rtol=RTOL, atol=1e-7 * scale)
         np.testing.assert_allclose(st.lb[0], lb, rtol=1e-9)
-    eng.set_variant("emission", 0); eng.set_variant("stats", 0); eng.set_variant("fb", 0)
+    eng.set_variant("stats", 0); eng.set_variant("fb", 0)
 
 
 def test_nan_rows_and_all_masked(eng):
