@@ -316,14 +316,27 @@ __global__ __launch_bounds__(256) void k_emission_orbit(
   const int N = D + 1, c = D >> 2, nd = (D >> 1) + 1, nleft = (nd + 3) >> 2;
   const int LEN = D + (D >> 1) + 1;                 // slots -1 .. 3D/2 - 1 (odd count)
   XV* xs2 = (XV*)smem;                              // [64][LEN]: MT = 2 (row r, row r + 16) pairs
-  long long* rowoff = (long long*)(xs2 + 64 * LEN);
+  // LDS banking (round 6; tools/probe/lds_probe.hip patterns 30 / 31): a ds_read_b128 is served in 16-lane groups that
+  // mix the lane rows 0-3, 12-15 of one lane group with rows 4-11 of the next, whose operands start c = D / 4 slots
+  // further.  At D = 32 (c = 8, row pitch 49 = 1 mod 16 slots) rows li and li + 8 of neighbouring groups met on one
+  // bank in EVERY read (twice the LDS cycles, SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE): every second block of
+  // eight rows starts eight slots later now (EO_SHIFT), which moves its reads onto the banks the other block leaves
+  // free.  D = 64 (c = 16) never conflicted; the other widths keep the plain pitch.
+#ifdef SVIHMM_AB_EMIS_OLD       // (A/B builds only)
+  const int SHIFT8 = 0;
+#else
+  const int SHIFT8 = (MT == 2 && c == 8) ? 8 : 0;
+#endif
+#define EO_SHIFT(ROW) (SHIFT8 * ((ROW) >> 3))      // ROW = 16 wave + lane row
+  long long* rowoff = (long long*)(xs2 + 64 * LEN + 8 * SHIFT8);
   unsigned char* bad_s = (unsigned char*)(rowoff + ROWS);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t g0 = (int64_t)blockIdx.x * ROWS;
   double* xs1 = (double*)xs2;
   // row r of the tile -> wave r >> 5, row tile (r >> 4) & 1, lane row r & 15
   auto slot = [&](int r, int idx) {
-    return MT == 2 ? ((((r >> 5) * 16 + (r & 15)) * LEN + idx + 1) << 1) + ((r >> 4) & 1) : r * LEN + idx + 1;
+    return MT == 2 ? ((((r >> 5) * 16 + (r & 15)) * LEN + EO_SHIFT((r >> 5) * 16 + (r & 15)) + idx + 1) << 1) + ((r >> 4) & 1)
+                   : r * LEN + idx + 1;
   };
   {
     const int64_t bw0 = g0 / Lm;
@@ -376,7 +389,8 @@ __global__ __launch_bounds__(256) void k_emission_orbit(
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[m][n] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
-  const XV* rowp = xs2 + (wave * 16 + li) * LEN + 1;           // slot 0 of this lane's row (pair)
+  const XV* rowp = xs2 + (wave * 16 + li) * LEN + EO_SHIFT(wave * 16 + li) + 1;   // slot 0 of this lane's row (pair)
+#undef EO_SHIFT
   const XV* pa0 = rowp + c * lg;
   const unsigned loff = (unsigned)(lg * KP + li * NT);         // lane part of the theta address
   auto kstep = [&](const XV xa, const XV xb, const double (&Bv)[NT]) {

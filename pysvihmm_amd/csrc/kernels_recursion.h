@@ -618,20 +618,41 @@ struct LinShared {
 template <typename T> struct LPair;
 template <> struct LPair<double> { typedef double2 t; };
 template <> struct LPair<float> { typedef float2 t; };
+// Which source state k lane group lg feeds into k-slot kk of a step's mat-vec (kk = 0 .. 4 NW - 1; the A operand
+// P[window][k] and the B operand A[k][target] only have to agree).  Four state tiles (K = 64, the bench shape; round 6):
+// k = 32 (lg & 1) + 16 (lg >> 1) + kk -- each lane group reads 16 CONSECUTIVE entries of the window's row, and the groups
+// lg = 0 / 1 (2 / 3), which one LDS pass of a ds_read_b128 (ds_read_b64 for float) serves together, start 32 entries
+// apart: with the odd slot stride of P's rows the pass touches every bank once.  Rounds 2-5 interleaved the groups
+// (k = 8 (kk >> 1) + 2 lg + (kk & 1)): lanes of lg = 0 and lg = 1 met on one bank in every pass, and every operand read
+// took twice its LDS cycles (tools/probe/lds_probe.hip patterns 20 / 21, profiles/r06a_lds_probe_pmc.txt).  The other
+// tile counts keep the interleaved order (their rows are too short for the 32-entry distance).
+template <int NW>
+__device__ __forceinline__ int lin_kslot(int lg, int kk) {
+#ifdef SVIHMM_AB_KSLOT_OLD      // (A/B builds only: the interleaved order of rounds 2-5)
+  return 8 * (kk >> 1) + 2 * lg + (kk & 1);
+#else
+  return NW == 4 ? 32 * (lg & 1) + 16 * (lg >> 1) + kk : 8 * (kk >> 1) + 2 * lg + (kk & 1);
+#endif
+}
 template <int NW, typename T>
 __device__ __forceinline__ void lin_matmul(const LinShared<NW, T>& sh, int cur, int li, int lg,
                                            const T (&Bv)[4 * NW], typename LV<T>::v4& acc,
                                            typename LV<T>::v4& tot) {
   constexpr int KS = 4 * NW;
+#ifdef SVIHMM_AB_KSLOT_OLD
+  constexpr int PSTEP = 8;
+#else
+  constexpr int PSTEP = NW == 4 ? 2 : 8;        // distance of two consecutive k-slot pairs in the row
+#endif
   typedef typename LV<T>::v4 v4;
   typedef typename LPair<T>::t T2;
   v4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
-  const T* prow = &sh.P[cur][li][2 * lg];
+  const T* prow = &sh.P[cur][li][lin_kslot<NW>(lg, 0)];
   T s0 = 0, s1 = 0;
 #pragma unroll
   for (int c = 0; c < KS / 2; c += 2) {
-    const T2 x = *reinterpret_cast<const T2*>(prow + 8 * c);
-    const T2 y = *reinterpret_cast<const T2*>(prow + 8 * (c + 1));
+    const T2 x = *reinterpret_cast<const T2*>(prow + PSTEP * c);
+    const T2 y = *reinterpret_cast<const T2*>(prow + PSTEP * (c + 1));
     a0 = LV<T>::mma(x.x, Bv[2 * c], a0);
     a1 = LV<T>::mma(x.y, Bv[2 * c + 1], a1);
     a2 = LV<T>::mma(y.x, Bv[2 * c + 2], a2);
@@ -771,7 +792,7 @@ __device__ __forceinline__ void fwd_lin_body(
   if (!BS) {
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
-      const int k = 8 * (kk >> 1) + 2 * lg + (kk & 1);
+      const int k = lin_kslot<NW>(lg, kk);
       Bv[BS ? 0 : kk] = (k < K && vj) ? (CT)Aexp[(size_t)k * K + jc] : (CT)0;
     }
   }
@@ -937,7 +958,7 @@ __device__ __forceinline__ void bwd_lin_body(
   if (!BS) {
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
-      const int k = 8 * (kk >> 1) + 2 * lg + (kk & 1);
+      const int k = lin_kslot<NW>(lg, kk);
       Bv[BS ? 0 : kk] = (k < K && vj) ? (CT)AexpT[(size_t)k * K + jc] : (CT)0;
     }
   }

@@ -157,10 +157,11 @@ __global__ __launch_bounds__(256) void k_stats_mfma(
 //  instructions per 80-MFMA stage on address arithmetic, 64-bit divisions and predicated
 //  copies.  Here (~170 per stage):
 //   * the A-operand tile is stored column-major, both LDS buffers interleaved, the 32 stage
-//     rows permuted:  element (buffer u, row r, column c) at  c*67 + u*33 + (r&3)*8 + (r>>2),
+//     rows permuted:  element (buffer u, row r, column c) at  c*67 + u*33 + ST_SLOT(r&3) + (r>>2),
 //     so the operand of k-step ks for lane (li, lg) is  base(lane, m) + [u*33 + ks]  -- one
 //     VGPR per (m-tile, factor) computed once per kernel, everything else an immediate, and
-//     a wave's 64 reads spread over all banks (column stride 67 = 3 mod 32, lg stride 8);
+//     the 32 lanes of an LDS pass spread over all bank pairs (column stride 67 = 3 mod 32, the
+//     slots of lg = 0 / 1 and of lg = 2 / 3 sixteen apart: ST_SLOT, round 6);
 //   * row bookkeeping is 32-bit arithmetic relative to the chunk start (one unsigned
 //     division per row instead of a 64-bit one); q rows become 32-bit element offsets
 //     from a per-thread base pointer;
@@ -179,6 +180,26 @@ struct StRow4 {
 };
 #define ST_CS 33            // row slots per buffer per column (32 + 1 pad)
 #define ST_CC (2 * ST_CS + 1)  // column stride (both buffers + 1 pad): 67
+// LDS banking of the two operand tiles (round 6; tools/probe/lds_probe.hip, profiles/r06a_lds_probe_pmc.txt).  A wave's
+// ds_read_b64 is served in two groups of 32 lanes on 64 four-byte banks, i.e. the 32 eight-byte words of lanes
+// (li = 0..15, lg = 0, 1) -- and of (li, lg = 2, 3) -- must fall on 32 different bank pairs.  Rounds 1-5 laid both
+// tiles out for 16-lane groups (row stride of the q tile Kp + 1, the four k-rows of a k-step eight row slots apart
+// in a column): conflict-free within one lg, but lg = 0 and 1 collided on 8 (A operand) / 15 (B operand) of the 32
+// pairs and every operand read took twice its LDS cycles (SQ_LDS_BANK_CONFLICT = SQ_LDS_IDX_ACTIVE / 2).  Now:
+//   q tile: row stride = 16 (mod 32) words, so lg = 1 lands on the pairs lg = 0 leaves free;
+//   A tile: the row slot of (lg, ks) is 16 (lg & 1) + 8 (lg >> 1) + ks -- with an odd column stride (67 / 101) the
+//   sixteen columns of a feature tile cover sixteen pairs m .. m + 15 in multiples of the stride, and the same columns
+//   sixteen slots further the other sixteen.
+#ifdef SVIHMM_AB_STATS_OLD      // (A/B builds only: the layout of rounds 1-5)
+#define ST_QS(KP) ((KP) + 1)
+#define ST_SLOT(LG) (8 * (LG))
+#else
+#define ST_QS(KP) ((((KP) + 15) / 32) * 32 + 16)
+#define ST_SLOT(LG) (16 * ((LG) & 1) + 8 * ((LG) >> 1))
+#endif
+// the 128 x 64 transition blocks of wide models (TRONLY, two q[prev] groups per workgroup) fill the LDS with the
+// three-buffer loop: their q tile keeps the Kp + 1 stride (161 KB; 172 KB with ST_QS)
+#define ST_QS_TR(KP, MT) ((MT) >= 2 ? (KP) + 1 : ST_QS(KP))
 
 // TRONLY (K > 64): only the transition statistic sum_t q[t-1, pbase + i] q[t, kbase + j] of
 // one (64 MT) x 64 block of (previous state, state) pairs: blockIdx.y = previous-state group,
@@ -229,10 +250,9 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
   constexpr int NWV = 4 * NSPLIT;          // waves of the workgroup
   constexpr int NT = NTW * NSPLIT;
   constexpr int Kp = 16 * NT;
-  // q tile row stride: the four k-rows (lg) of a B-operand read must fall on different banks --
-  // one double apart for 8-byte words (16 lanes per LDS pass), 16 floats apart for 4-byte words
-  // (32 lanes per pass: lg = 0, 1 -> banks li, 16 + li)
-  constexpr int QS = sizeof(CT) == 4 ? Kp + 16 : Kp + 1;
+  // q tile row stride: the k-rows lg = 0, 1 (and 2, 3) of a B-operand read are served in one LDS pass of 32 lanes
+  // and must fall on different banks: 16 words apart modulo the 32 (ST_QS)
+  constexpr int QS = TRONLY ? ST_QS_TR(Kp, MT) : ST_QS(Kp);
   constexpr int TPR = 8 * NSPLIT;          // staging threads per row (block / 32)
   constexpr int QK = Kp / TPR;             // q columns per staging thread (exact)
   static_assert(QK * TPR == Kp, "staging split");
@@ -258,7 +278,7 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
   const bool need_x = !TRONLY && wg_m0 < Fp;
   const bool need_qp = TRONLY || (wg_m1 > Fp && mt_limit * 16 > Fp);
   const int sr = tid / TPR, sc = tid % TPR;   // staging role: row sr, columns sc + TPR*k
-  const int psr = (sr & 3) * 8 + (sr >> 2);   // permuted row slot
+  const int psr = ST_SLOT(sr & 3) + (sr >> 2);   // row slot of row sr = 4 ks + lg (see ST_SLOT)
 
   // A-operand element index of buffer 0, k-step 0 (buffer u, k-step ks: + u*33 + ks)
   int oa[MT], ob[MT];
@@ -269,7 +289,7 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
     if (TRONLY) { if (f < Kp * PG && pbase + f < K) { fa = QP0 + f; fb = ONE; } }
     else if (f < F) { const int ab = fab[f]; fa = ab & 0xffff; fb = ab >> 16; }
     else if (f >= Fp && f - Fp < K && mt_limit * 16 > Fp) { fa = QP0 + (f - Fp); fb = ONE; }
-    oa[m] = fa * CC + lg * 8; ob[m] = fb * CC + lg * 8;
+    oa[m] = fa * CC + ST_SLOT(lg); ob[m] = fb * CC + ST_SLOT(lg);
   }
   const int obq = lg * QS + nt0 * 16 + li;   // B operand: qs[(4ks+lg)*QS + (nt0+n)*16 + li]
   typename MF<CT>::v4 acc[MT][NTW];

@@ -310,7 +310,7 @@ int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled,
     }
     // minibatches (fewer than 32768 rows): 16-row workgroups, the four waves split the k-steps
     // (k_emission_orbit_ks; variant[5] = 5: the 64-row form of round 3, 2: always 128 rows)
-    if ((n + 127) / 128 < 256 && h->variant[5] != 2 && h->variant[5] != 5) {
+    if ((n + 127) / 128 < h->ncu && h->variant[5] != 2 && h->variant[5] != 5) {
       const int R0 = 3 * NT * 256 > 16 * LEN + 1 ? 3 * NT * 256 : ((16 * LEN + 1) & ~1);
       const size_t lds = (size_t)(R0 + 16 * NT + 16) * 8 + 16;
       dim3 grid((unsigned)((n + 15) / 16));
@@ -324,9 +324,10 @@ int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled,
       return 0;
     }
     // fewer than one 128-row workgroup per CU: 64-row workgroups
-    const int MTo = ((n + 127) / 128 < 256 && h->variant[5] != 2) ? 1 : 2;
+    const int MTo = ((n + 127) / 128 < h->ncu && h->variant[5] != 2) ? 1 : 2;
     const int rows = 64 * MTo;
-    const size_t lds = (size_t)rows * LEN * 8 + rows * 9;
+    // (+ 1 KB at D = 32 with two row tiles per wave: every second block of eight rows starts eight slots later, EO_SHIFT)
+    const size_t lds = (size_t)rows * LEN * 8 + rows * 9 + ((MTo == 2 && D == 32) ? 1024 : 0);
     dim3 grid((unsigned)((n + rows - 1) / rows));
 #define EMO(NTV, UV, MTV) hipLaunchKernelGGL((k_emission_orbit<NTV, UV, MTV>), grid, dim3(256), lds, stream,  \
                                         (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K,               \

@@ -117,7 +117,7 @@ int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, int Lm, u
   if (var == 3) {   // feasibility of the pipelined kernel (same test as below)
     const int KpW = Kp > 64 ? 64 : Kp;
     const int TPR = 8 * ((KpW / 16 == 4) ? 2 : 1);
-    const size_t lds = ((size_t)(D + 3 + KpW) * ST_CC + 2 * (size_t)ST_RB * (KpW + 1)) * 8 + 4 * ST_RB * sizeof(StRow4);
+    const size_t lds = ((size_t)(D + 3 + KpW) * ST_CC + 2 * (size_t)ST_RB * ST_QS(KpW)) * 8 + 4 * ST_RB * sizeof(StRow4);
     if (lds > 150 * 1024 || (D + 1 + TPR - 1) / TPR > 9 || (Kp > 64 && Kp % 64 != 0)) var = 2;
   }
   // scaled sweeps: the pipelined kernel forms q = ah * bh * scale itself; the others read var_x
@@ -154,7 +154,7 @@ int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, int Lm, u
       const int KpW = 16 * NTt;
       const int NSPLIT = (NTt == 4) ? 2 : 1;
       const int TPR = 8 * NSPLIT;
-      const size_t lds = ((size_t)(D + 3 + KpW) * ST_CC + 2 * (size_t)ST_RB * (KpW + 1)) * 8 + 4 * ST_RB * sizeof(StRow4);
+      const size_t lds = ((size_t)(D + 3 + KpW) * ST_CC + 2 * (size_t)ST_RB * ST_QS(KpW)) * 8 + 4 * ST_RB * sizeof(StRow4);
       const int mtiles = Ftot / 16;
       const int mt_limit = big ? Fp / 16 : mtiles;
       const int xk = (D + 1 + TPR - 1) / TPR;
@@ -181,7 +181,7 @@ int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, int Lm, u
       }
       else if (lin && h->cur_f32 && !big) {
         // fp32 mode: float LDS tiles, v_mfma_f32_16x16x4_f32, ah / bh read as float
-        const size_t ldsf = ((size_t)(D + 3 + KpW) * ST_CC + 2 * (size_t)ST_RB * (KpW + 16)) * 4 + 8 +
+        const size_t ldsf = ((size_t)(D + 3 + KpW) * ST_CC + 2 * (size_t)ST_RB * ST_QS(KpW)) * 4 + 8 +
                             4 * ST_RB * sizeof(StRow4);
         const int MTs = stats_mt(h);
         dim3 grid((unsigned)nchunk, (mt_limit + 4 * MTs - 1) / (4 * MTs), 1);
@@ -211,7 +211,7 @@ int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, int Lm, u
         dim3 grid((unsigned)nchunk, (mt_limit + 4 * MTs - 1) / (4 * MTs), big ? Kp / 64 : 1);
         // four state tiles, five feature tiles per wave, scaled sweeps (the K = 64 epoch shapes): the
         // barrier-free stage loop with three LDS buffers, where they fit (D <= 55)
-        const size_t lds3 = ((size_t)(D + 3 + KpW) * (3 * ST_CS + 2) + 3 * (size_t)ST_RB * (KpW + 1)) * 8 +
+        const size_t lds3 = ((size_t)(D + 3 + KpW) * (3 * ST_CS + 2) + 3 * (size_t)ST_RB * ST_QS(KpW)) * 8 +
                             4 * ST_RB * sizeof(StRow4) + 16;
         const bool tb = NTt == 4 && MTs == 5 && lds3 <= 160 * 1024 && h->variant[12] != 1;
         if (tb) {
@@ -257,8 +257,8 @@ int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, int Lm, u
           // k-step instead of 2 on 4; variant[14] = 1: one)
           const int MTt = (Kp % 128 == 0 && h->variant[14] != 1) ? 2 : 1;
           dim3 g2((unsigned)nchunk, Kp / (64 * MTt), Kp / 64);
-          const size_t ldt = ((size_t)(2 + 64 * MTt) * ST_CC + 2 * (size_t)ST_RB * 65) * 8 + 4 * ST_RB * sizeof(StRow4);
-          const size_t ldt3 = ((size_t)(2 + 64 * MTt) * (3 * ST_CS + 2) + 3 * (size_t)ST_RB * 65) * 8 +
+          const size_t ldt = ((size_t)(2 + 64 * MTt) * ST_CC + 2 * (size_t)ST_RB * ST_QS_TR(64, MTt)) * 8 + 4 * ST_RB * sizeof(StRow4);
+          const size_t ldt3 = ((size_t)(2 + 64 * MTt) * (3 * ST_CS + 2) + 3 * (size_t)ST_RB * ST_QS_TR(64, MTt)) * 8 +
                               4 * ST_RB * sizeof(StRow4) + 16;
 #define STT(MTV, LN)                                                                              \
   do {                                                                                           \
@@ -355,7 +355,7 @@ static int launch_stats_cat(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint3
   const uint8_t* mk = h->have_mask ? (const uint8_t*)h->mask.p : nullptr;
   {
     ProfScope ps(h, KS_STATS, stream);
-    const size_t lds = ((size_t)(D + 3 + 64) * ST_CC + 2 * (size_t)ST_RB * 65) * 8 + 4 * ST_RB * sizeof(StRow4);
+    const size_t lds = ((size_t)(D + 3 + 64) * ST_CC + 2 * (size_t)ST_RB * ST_QS_TR(64, 1)) * 8 + 4 * ST_RB * sizeof(StRow4);
     hipFuncSetAttribute((const void*)k_stats_mfma4<1, 2, 2, 1, false, true>,
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 g2((unsigned)plan.nchunk, KpT / 64, KpT / 64);
