@@ -483,7 +483,9 @@ class OracleEngine(object):
 
     def svi_read_state(self):
         sv = self._svi
-        return (sv["var_tran"].copy(), sv["var_init"].copy()) + tuple(a.copy() for a in sv["mf"])
+        # (before the first iteration: the stationary vector of the initial var_tran, as the device loop's begin computes it)
+        vi = sv["var_init"] if sv["var_init"] is not None else R.stationary_init(sv["var_tran"])
+        return (sv["var_tran"].copy(), np.array(vi, dtype=np.float64)) + tuple(a.copy() for a in sv["mf"])
 
     # -- multi-process (host all-reduce through an injected communicator)
     def allreduce_packed(self):

@@ -313,15 +313,13 @@ def run_api_case(e, L, seed):
     return what
 
 
-def run_class_case(e, seed):
-    """The reference's three classes end to end (small problems, a few iterations), HIP engine vs
-    oracle engine: hmmsgd_metaobs with random options (mask, full_predprob, growBuffer,
-    adaptive, noverlap sampler, host / device loop), hmmbatchcd, hmmbatchsgd."""
-    from oracle.engine import OracleEngine
+def class_case(seed):
+    """The class-level case of `seed`: (kind, K, D, T, obs, mask, opts, infer_kw, what, model) with model(engine) ->
+    a fresh instance of the drawn class on that engine (run_class_case; tests/test_gpu_tiny_windows.py replays the
+    recorded deviating seeds through it)."""
     from pysvihmm_amd import hmmsgd_metaobs, hmmbatchcd, hmmbatchsgd
     from pysvihmm_amd.distributions import Gaussian
     rng = np.random.default_rng(seed)
-    e.set_precision("f64")     # (a call sequence before may have left the shared handle in the fp32 mode)
     K = int(rng.choice([2, 3, 5, 8, 17]))
     D = int(rng.choice([1, 2, 3, 8]))
     T = int(rng.choice([300, 700, 1500]))
@@ -354,6 +352,17 @@ def run_class_case(e, seed):
             return hmmbatchcd.VBHMM(obs.copy(), np.ones(K), np.ones((K, K)), prior, mask=m, maxit=3, engine=engine)
         return hmmbatchsgd.VBHMM(obs.copy(), np.ones(K), np.ones((K, K)), prior, tau=1.0, kappa=0.7, mask=m, maxit=3,
                                  engine=engine)
+    return dict(kind=kind, K=K, D=D, T=T, obs=obs, mask=mask, opts=opts, infer_kw=infer_kw, what=what, model=model)
+
+
+def run_class_case(e, seed):
+    """The reference's three classes end to end (small problems, a few iterations), HIP engine vs
+    oracle engine: hmmsgd_metaobs with random options (mask, full_predprob, growBuffer,
+    adaptive, noverlap sampler, host / device loop), hmmbatchcd, hmmbatchsgd."""
+    from oracle.engine import OracleEngine
+    e.set_precision("f64")     # (a call sequence before may have left the shared handle in the fp32 mode)
+    c = class_case(seed)
+    kind, K, opts, infer_kw, what, model = c["kind"], c["K"], c["opts"], c["infer_kw"], c["what"], c["model"]
     a, b = model(e), model(OracleEngine())
     a.infer(**infer_kw)
     b.infer(**infer_kw)
