@@ -218,6 +218,12 @@ struct svihmm_ctx {
   int svi_cur_it = -1;               // iteration whose E-step is being launched (poison value of its sweeps)
   bool svi_replaying = false;
   int svi_recoveries = 0;            // times this loop left the counters mid-way (svihmm_svi_recoveries)
+  // fused sweep + statistics launch (tu_fused.hip): band counters with their running targets, cached readiness orders
+  Buf pipe_cnt;
+  unsigned pipe_tgt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  struct PipeTab { Buf buf; int Lq = -1, off = -1, Lm = -1, NS = -1; bool wrap = false; unsigned long long stamp = 0; };
+  PipeTab pipe_tabs[8];
+  unsigned long long pipe_stamp = 0;
   bool sweep_signalled = false;    // this E-step's sweep launch does
   bool in_svi_estep = false;       // estep_core is running for svihmm_svi_iteration
   unsigned long long* svi_ts = nullptr; unsigned long long* svi_ts_dev = nullptr; int svi_ts_cap = 0;   // pinned + mapped: [2 it] begin, [2 it + 1] end (wall_clock64)
@@ -330,6 +336,9 @@ int svi_flush_elbo(svihmm_ctx* h);
 int ensure_starts_pulled(svihmm_ctx* h);
 int cat_uncentre(svihmm_ctx* h);
 int launch_fb_chain(svihmm_ctx* h, int Lm, bool total);
+bool sweep_stats_ok(const svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags);
+int launch_sweep_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags);
+SviSync sweep_gate(svihmm_ctx* h, hipStream_t stream);
 int launch_niw_vlb(svihmm_ctx* h, int K, int D, const double* dmu, const double* dsg, const double* dka,
                    const double* dnu, double* th2, int* dstat, double* ld, const double* p0, double* dout);
 }

@@ -1,0 +1,397 @@
+// kernels_fused.h -- the minibatch E-step's sweeps and statistics as ONE launch (round 6; VERDICT r5 next #1a).
+//
+// A minibatch of S = 64 windows keeps 128 sweep waves busy for 257 dependent steps (~76 us) while 7/8 of the chip
+// idles, and its statistics GEMM (~40 us, 206 one-per-CU workgroups) can only start when the sweeps are over -- it needs
+// alpha_t AND beta_t of a row.  But row t has both once the forward sweep has passed t and the backward sweep Lm - 1 - t:
+// the middle rows at HALF the sweep time, the rows next to a window's ends only at the very end.  This kernel puts both
+// kinds of workgroup into one grid:
+//
+//   workgroups [0, nsw)            sweep workgroups: the four waves run k_wave_linr's body (kernels_wave_linr.h) for
+//                                  window 4 (b >> 1) + w in direction b & 1 (K = 64 only).  A sweep wave
+//                                  PUBLISHES its progress: when it has stored the row of step thr[i] it adds one to
+//                                  band counter i (agent-scope release);
+//   workgroups [nsw, nsw + nst)    statistics workgroups (chunk c, feature group g): the five-tile-per-wave fp64 MFMA
+//                                  GEMM of k_stats_mfma4 with its rows taken in READINESS ORDER: stage s of every chunk
+//                                  draws 32 rows from band s -- the rows of all windows whose order index (distance from
+//                                  the window's middle) lies in [s Lb, (s + 1) Lb) -- and starts when band counter s
+//                                  shows that all 2 B sweeps have passed the band's threshold.
+//
+// All workgroups are resident at once (one per CU: the host launches the kernel only when nsw + nst fits the device,
+// with CUs to spare for the loop's side streams) and the sweep workgroups have the lower indices, so they are placed
+// first: a statistics workgroup never waits for a sweep that has no CU.  No cross-stream edge, no host round trip:
+// the pipelining lives inside one launch and works the same under a profiler that serialises kernels.
+//
+// Posteriors: the statistics kernels of rounds 1-5 formed q_t = ah_t bh_t 2^(hx + gx - zexp) / zmant with the window's
+// normaliser Z -- which the forward sweep only knows at its END.  Here every row normalises itself,
+// q_t[j] = ah_t[j] bh_t[j] / sum_j ah_t[j] bh_t[j]  (the sum IS Z for every t; the binary exponents cancel), a 16-lane
+// DPP sum per staged row.  Same quantity, rounded differently in the last place.
+//
+// Statistics stage = 32 rows x (40 tiles of 16 features) x 64 states, 80 MFMAs per wave: ~1.1 us of matrix pipe; the
+// readiness bands of a 257-row window are 7.7 us apart at five stages (0.3 us per sweep step), so a stage -- gate, 2 us
+// of loads, LDS, 8 k-steps -- is long done when the next band opens: no software pipelining across stages, one LDS
+// buffer, two barriers per stage.  What is left behind the sweeps is the last band's stage and the epilogue.
+#pragma once
+#include "kernels_stats_layout.h"
+#include "kernels_wave_linr.h"
+
+#define PIPE_MAX_STAGES WLR_MAX_BANDS
+struct PipePlan {
+  int nsw;                          // sweep workgroups (wpb windows of one direction each)
+  int wpb;                          // active sweep waves per workgroup (4)
+  int exp;                          // measurement only (SVIHMM_PIPE_EXP): 1 statistics workgroups leave at once, 2 they sleep
+                                    // 120 us on the clock and leave, 3 they take their gates but skip loads and k-steps
+  int nchunk, ngrp;                 // statistics chunks x feature groups of 20 tiles = statistics workgroups
+  int NS, Lb;                       // stages per chunk = readiness bands; rows of a window per band
+  unsigned tgt[PIPE_MAX_STAGES];    // band counter value that says "all 2 B sweeps are past this band"
+  const int* ord;                   // [len]: inner row of readiness order o (host table: stable sort by need)
+  WlrPub pub;
+  const WlrPub* pubg;               // the same record in global memory (the sweep role is a function: it cannot read kernel arguments)
+  unsigned long long* dbg;          // measurement only (SVIHMM_PIPE_DBG): wall-clock stamps, nullptr in normal runs --
+                                    // [workgroup][16]: sweep workgroups (wave 0) begin / end; statistics workgroups begin,
+                                    // then per stage the gate's opening and the end of its k-steps
+};
+struct PipeRow {
+  long long ooff;   // obs element offset (row * D), -1: out of range or masked
+  int qoff;         // element offset of the row in ah / bh, -1: out of range
+  int poff;         // predecessor row's
+  int pok;
+  int pad_;
+};
+
+// ---- statistics workgroup ------------------------------------------------------------------------------------
+// Four waves (one per SIMD, 256-thread workgroups: every wave of the kernel may use the SIMD's whole register file --
+// the sweep body needs 274 registers, and under the 256 of a 512-thread workgroup it spilled into its step loop or lost
+// half its prefetch depth).  Wave mg owns MT = 5 feature tiles x all four state tiles (Kp = 64): 160 accumulator
+// registers, 160 MFMAs per stage on 14 LDS operand reads per k-step.  LDS: A tile rb[C][CC1] (column-major, one buffer:
+// CC1 = 33 row slots), q tile qs[32][80], row records of all stages.
+#define PIPE_CC1 33
+// sum over the eight lanes that stage one row (quad_perm xor 1, xor 2, row_half_mirror)
+__device__ __forceinline__ double pipe_row8_sum(double v) {
+  v += dpp_mov_f64<0xB1>(v);
+  v += dpp_mov_f64<0x4E>(v);
+  v += dpp_mov_f64<0x141>(v);
+  return v;
+}
+template <int XK, typename ST>
+__device__ __forceinline__ void pipe_stats_body(
+    double* __restrict__ smem, const double* __restrict__ obs, const uint8_t* __restrict__ mask,
+    const int64_t* __restrict__ starts, int B, int Lm, int Lq, int off, int D, int K, int Fp, int F,
+    const int* __restrict__ fab, const ST* __restrict__ ah, const ST* __restrict__ bh, uint32_t flags,
+    double* __restrict__ part, double* __restrict__ lbpart, const PipePlan& pl, const int chunk, const int fg) {
+  const bool lb_here = fg == 0 && lbpart != nullptr;
+  constexpr int MT = 5, NTW = 4, Kp = 64, QS = ST_QS(64), TPR = 8, QK = 8, CC = PIPE_CC1;
+  const int ZERO = D + 1, ONE = ZERO + 1, QP0 = ZERO + 2;
+  const int C = QP0 + Kp;
+  double* rb0 = smem;                               // [C][CC]
+  double* qs0 = rb0 + C * CC;                       // [32][QS]
+  PipeRow* rinfo = reinterpret_cast<PipeRow*>(qs0 + ST_RB * QS);   // [NS][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int mg = wave;
+  const int Ftot = Fp + Kp, mtiles = Ftot / 16;
+  const int mt0 = (fg * 4 + mg) * MT, nt0 = 0;
+  const int wg_m0 = fg * 4 * MT * 16, wg_m1 = wg_m0 + 4 * MT * 16;
+  const bool need_x = wg_m0 < Fp;
+  const bool need_qp = wg_m1 > Fp;
+  const int sr = tid / TPR, sc = tid % TPR;         // staging role: row sr, columns sc + 8 k
+  const int psr = ST_SLOT(sr & 3) + (sr >> 2);      // row slot of row sr = 4 ks + lg
+  const int NS = pl.NS, Lb = pl.Lb;
+
+  // ---- row records of every stage, up front (nothing here depends on the sweeps): thread (s, r)
+  for (int i = tid; i < 32 * NS; i += 256) {
+    const int s = i >> 5, rr = i & 31;
+    const int y = chunk * 32 + rr;
+    const int w = y / Lb, oo = s * Lb + (y - w * Lb);
+    const bool ok = w < B && oo < Lm;
+    const int t = ok ? pl.ord[oo] : 0;
+    const int64_t start = starts[ok ? w : 0];
+    const int64_t orow = start + off + t;
+    const uint8_t m = (ok && mask) ? mask[orow] : (uint8_t)0;
+    const int qrow = (ok ? w : 0) * Lq + off + t;
+    const bool pok = ok && (t > 0 || (flags & SVIHMM_TRANS_WRAP));
+    PipeRow ri;
+    ri.ooff = (ok && !m) ? orow * D : -1;
+    ri.qoff = ok ? qrow * K : -1;
+    ri.poff = (t > 0 ? qrow - 1 : qrow + Lm - 1) * K;
+    ri.pok = pok ? 1 : 0;
+    ri.pad_ = 0;
+    rinfo[i] = ri;
+  }
+  // A-operand element index (k-step 0)
+  int oa[MT], ob[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int f = (mt0 + m) * 16 + li;
+    int fa = ZERO, fb = ZERO;
+    if (f < F) { const int ab = fab[f]; fa = ab & 0xffff; fb = ab >> 16; }
+    else if (f >= Fp && f - Fp < K) { fa = QP0 + (f - Fp); fb = ONE; }
+    oa[m] = fa * CC + ST_SLOT(lg); ob[m] = fb * CC + ST_SLOT(lg);
+  }
+  const int obq = lg * QS + nt0 * 16 + li;
+  double4_t acc[MT][NTW];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) acc[m][n] = (double4_t){0, 0, 0, 0};
+  int xcc[XK], xwi[XK];
+#pragma unroll
+  for (int k = 0; k < XK; ++k) {
+    const int c = sc + TPR * k;
+    xcc[k] = c < D ? c : D - 1;
+    xwi[k] = (c <= D ? c : ZERO) * CC + psr;        // beyond the ones slot: rewrite ZERO with 0.0
+  }
+  const int qwi = sr * QS + sc;
+  const int pwi = (QP0 + sc) * CC + psr;
+  if (sc == 0) { rb0[ZERO * CC + psr] = 0.0; rb0[ONE * CC + psr] = 1.0; }
+  const ST* __restrict__ athr = ah + sc;
+  const ST* __restrict__ bthr = bh + sc;
+
+  unsigned long long* dbg = pl.dbg ? pl.dbg + (size_t)blockIdx.x * 32 : nullptr;
+  const unsigned long long t_begin = wall_clock64();
+  unsigned long long t_open0 = 0;
+  if (dbg && tid == 0) dbg[0] = t_begin;
+  // ---- the stage loop.  Stage s: gate (band s published by all sweeps) -> fetch its 32 rows into registers -> normalise,
+  //      commit to LDS -> 8 k-steps.  While the workgroup runs behind the sweeps (the first band opens at 60 % of the
+  //      sweep, later ones every ~7 us) every gate is a real wait; once it lags -- a stage costs 3 us of loads + 2 us of
+  //      matrix pipe -- the next band is usually open already: it is looked at without waiting after the commit, and
+  //      its rows are requested BEFORE the k-steps of the current stage, so loads and matrix work overlap.
+  int* lflag = reinterpret_cast<int*>(rinfo + NS * 32);       // [0] "next band is open" (written by thread 0)
+  double* lred = reinterpret_cast<double*>(lflag + 2);         // [4] per-wave sums of the local bound's terms
+  double rx[XK], va[QK], vb[QK], pa[QK], pb[QK];
+  bool okx = false, okq = false, okp = false;
+  double lbp = 0.0;
+  auto band_open = [&](int s) {
+    return (int)(__hip_atomic_load(pl.pub.cnt + 16 * s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - pl.tgt[s]) >= 0;
+  };
+  auto fetch = [&](int s) {
+    // (no acquire fence: the sweeps store their rows with agent-scope atomic stores, these are the matching loads)
+    const PipeRow ri = rinfo[s * 32 + sr];
+    okx = ri.ooff >= 0; okq = ri.qoff >= 0; okp = ri.pok != 0;
+    if (need_x) {
+      const double* __restrict__ xo = obs + (okx ? ri.ooff : 0);
+#pragma unroll
+      for (int k = 0; k < XK; ++k) rx[k] = xo[xcc[k]];
+    }
+    {
+      const int o = okq ? ri.qoff : 0;
+#pragma unroll
+      for (int k = 0; k < QK; ++k) {
+        va[k] = (double)__hip_atomic_load(athr + o + TPR * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        vb[k] = (double)__hip_atomic_load(bthr + o + TPR * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (need_qp) {
+      const int o = okp ? ri.poff : 0;
+#pragma unroll
+      for (int k = 0; k < QK; ++k) {
+        pa[k] = (double)__hip_atomic_load(athr + o + TPR * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pb[k] = (double)__hip_atomic_load(bthr + o + TPR * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
+  auto commit = [&]() {
+    // self-normalised posteriors (columns >= K of a ragged model read a neighbour's entries: masked)
+    double vq[QK], vp[QK], sq = 0.0, sp = 0.0, sa = 0.0;
+#pragma unroll
+    for (int k = 0; k < QK; ++k) {
+      const bool live = sc + TPR * k < K;
+      vq[k] = (okq && live) ? va[k] * vb[k] : 0.0;
+      sq += vq[k];
+      sa += (okq && live) ? va[k] : 0.0;
+    }
+    sq = pipe_row8_sum(sq);
+    const double iq = sq > 0.0 ? 1.0 / sq : 0.0;
+    if (lb_here) {                                   // the local bound's term of this row: log sum_j ah_t[j]
+      sa = pipe_row8_sum(sa);
+      if (okq && sc == 0) lbp += fast_log(sa);
+    }
+    if (need_qp) {
+#pragma unroll
+      for (int k = 0; k < QK; ++k) {
+        const bool live = sc + TPR * k < K;
+        vp[k] = (okp && live) ? pa[k] * pb[k] : 0.0;
+        sp += vp[k];
+      }
+      sp = pipe_row8_sum(sp);
+    }
+    const double ip = sp > 0.0 ? 1.0 / sp : 0.0;
+    if (need_x) {
+#pragma unroll
+      for (int k = 0; k < XK; ++k) {
+        const int c = sc + TPR * k;
+        const double v = c < D ? rx[k] : (c == D ? 1.0 : 0.0);
+        rb0[xwi[k]] = okx ? v : 0.0;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < QK; ++k) qs0[qwi + TPR * k] = vq[k] * iq;
+    if (need_qp) {
+#pragma unroll
+      for (int k = 0; k < QK; ++k) rb0[pwi + TPR * k * CC] = vp[k] * ip;
+    }
+  };
+  bool have = false;                                 // the registers hold the rows of the stage about to start
+  for (int s = 0; s < NS; ++s) {
+    if (!have) {
+      // ---- gate: every sweep has stored the rows of band s (bounded like the loop's other gates: a count that never
+      //      comes must not hang the queue; the statistics of such a launch are garbage and its sweeps poisoned the step)
+      if (tid == 0) {
+        // Polling discipline (measured, tools/r6_fused_trace.py): 208 workgroups polling one counter every 0.2 us
+        // saturate its memory channel.  The first band is polled every ~1.7 us; its opening time gives the sweeps'
+        // pace, later bands are slept for (clock reads only) until a microsecond before their predicted opening and
+        // then polled every ~0.4 us.
+        if (s > 0 && t_open0 > t_begin) {
+          const unsigned long long pred = t_begin + (t_open0 - t_begin) * (unsigned long long)pl.pub.thr[s] / (unsigned long long)(pl.pub.thr[0] > 0 ? pl.pub.thr[0] : 1);
+          while (wall_clock64() + 100ull < pred) __builtin_amdgcn_s_sleep(32);
+        }
+        if (!band_open(s)) {
+          const unsigned long long t0 = wall_clock64();
+          unsigned n = 0;
+          while (!band_open(s)) {
+            if (s == 0) __builtin_amdgcn_s_sleep(64); else __builtin_amdgcn_s_sleep(16);
+            if ((++n & 1023u) == 0u && wall_clock64() - t0 > SVI_SYNC_TICKS) break;
+          }
+        }
+        if (s == 0) t_open0 = wall_clock64();
+      }
+      __syncthreads();                               // (also: every wave is through the previous stage's k-steps)
+      if (dbg && tid == 0) dbg[1 + 2 * s] = wall_clock64();
+      if (pl.exp == 3) { if (dbg && tid == 0) dbg[2 + 2 * s] = wall_clock64(); continue; }
+      fetch(s);
+    } else {
+      __syncthreads();                               // every wave is through the previous stage's k-steps
+      if (dbg && tid == 0) dbg[1 + 2 * s] = wall_clock64();
+    }
+    if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (tid == 0) dbg[14 + 2 * s] = wall_clock64(); }
+    commit();
+    if (tid == 0) lflag[0] = (s + 1 < NS && band_open(s + 1)) ? 1 : 0;
+    __syncthreads();
+    if (dbg && tid == 0) dbg[15 + 2 * s] = wall_clock64();
+    have = lflag[0] != 0;
+    if (have) fetch(s + 1);
+    // ---- 8 k-steps, the LDS reads of k-step ks + 1 issued before the MFMAs of k-step ks
+    {
+      const double* qs = qs0 + obq;
+      double Bv[NTW], Ax[MT], Ay[MT];
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) Bv[n] = qs[n * 16];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) { Ax[m] = rb0[oa[m]]; Ay[m] = rb0[ob[m]]; }
+#pragma unroll
+      for (int ks = 0; ks < ST_RB / 4; ++ks) {
+        double Bn[NTW], Axn[MT], Ayn[MT];
+        if (ks + 1 < ST_RB / 4) {
+#pragma unroll
+          for (int n = 0; n < NTW; ++n) Bn[n] = qs[(ks + 1) * 4 * QS + n * 16];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) { Axn[m] = rb0[oa[m] + ks + 1]; Ayn[m] = rb0[ob[m] + ks + 1]; }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const double A = Ax[m] * Ay[m];
+#pragma unroll
+          for (int n = 0; n < NTW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(A, Bv[n], acc[m][n], 0, 0, 0);
+        }
+        if (ks + 1 < ST_RB / 4) {
+#pragma unroll
+          for (int n = 0; n < NTW; ++n) Bv[n] = Bn[n];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) { Ax[m] = Axn[m]; Ay[m] = Ayn[m]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (dbg && tid == 0) dbg[2 + 2 * s] = wall_clock64();
+  }
+  // ---- the chunk's share of sum_t log(sum_j ah_t[j]) (first feature group only: every row once)
+  if (lb_here) {
+    const double w = wave_sum_dpp(lbp);
+    if (lane == 0) lred[wave] = w;
+    __syncthreads();
+    if (tid == 0) lbpart[chunk] = (lred[0] + lred[1]) + (lred[2] + lred[3]);
+  }
+  // ---- partial sums of the chunk: part[chunk][f][k]
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = (mt0 + m) * 16 + lg + 4 * r;
+      if (f < Ftot && (mt0 + m) < mtiles) {
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+          part[((size_t)chunk * Ftot + f) * Kp + (nt0 + n) * 16 + li] = acc[m][n][r];
+      }
+    }
+  }
+}
+
+// LDS of the kernel
+inline size_t pipe_lds_bytes(int D, int NS) {
+  // (statistics: tiles + row records + flag / reduction words; the sweep workgroups use no LDS since the row sums of
+  //  the local bound moved to the statistics side)
+  return ((size_t)(D + 3 + 64) * PIPE_CC1 + (size_t)ST_RB * ST_QS(64)) * 8 + (size_t)NS * 32 * sizeof(PipeRow) + 64;
+}
+
+// 256-thread workgroups: four waves, one per SIMD, each with the SIMD's whole register file (512).  Both roles are
+// inlined into the kernel body -- the sweep's row arithmetic wants the kernel's pointer arguments where they are: in
+// scalar registers, known to be global (as a non-inlined function it took them as flat pointers in vector registers:
+// flat loads / stores with 64-bit vector address arithmetic in every step; with eight-wave workgroups, i.e. 256
+// registers, the inlined roles spilled 100-400 registers).
+// The statistics role alone is a separate (non-inlined) function: inlined beside the sweep bodies the allocator sees the
+// union of all live ranges and spills 40-140 registers; as a function it gets its own allocation.  It finds the
+// workgroup's dynamic LDS itself (a pointer argument would make every LDS access a flat one).
+template <int XK, typename ST>
+__device__ __attribute__((noinline)) void pipe_stats_role(
+    const double* __restrict__ obs, const uint8_t* __restrict__ mask, const int64_t* __restrict__ starts, int B, int Lm,
+    int Lq, int off, int D, int K, int Fp, int F, const int* __restrict__ fab, const ST* __restrict__ ah,
+    const ST* __restrict__ bh, uint32_t flags, double* __restrict__ part, double* __restrict__ lbpart, const PipePlan* pl,
+    int chunk, int fg) {
+  extern __shared__ double smem_role[];
+  pipe_stats_body<XK, ST>(smem_role, obs, mask, starts, B, Lm, Lq, off, D, K, Fp, F, fab, ah, bh, flags, part, lbpart, *pl, chunk, fg);
+}
+template <int XK, typename ST>
+__global__ __launch_bounds__(256) void k_sweep_stats(
+    // sweeps (k_wave_linr's arguments)
+    const ST* __restrict__ Eh, const double* __restrict__ kexp, const double* __restrict__ Aexp,
+    const double* __restrict__ AexpT, const double* __restrict__ mod_init, const double* __restrict__ ll0,
+    size_t l0stride, int Lq, int K, ST* __restrict__ ah, ST* __restrict__ bh, double* __restrict__ hx,
+    double* __restrict__ gx, double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac,
+    SviSync sy,
+    // statistics
+    const double* __restrict__ obs, const uint8_t* __restrict__ mask, const int64_t* __restrict__ starts, int B,
+    int Lm, int off, int D, int Fp, int F, const int* __restrict__ fab, uint32_t flags, double* __restrict__ part,
+    PipePlan pl) {
+  extern __shared__ double smem[];
+  const int bx = blockIdx.x;
+  if (bx < pl.nsw) {
+    // ---- sweep workgroup
+    // (SVI loop: the globals kernel of the side stream has arrived -- the gate ends in a workgroup barrier, so all
+    //  four waves take it before those without a window leave)
+    const bool go = svi_gate(sy);
+    // (a workgroup's four waves run ONE direction -- even workgroups forward, odd backward, four windows each: the
+    //  unrolled step loops of the two directions are 40 + 75 KB of code, more than a CU's instruction cache holds)
+    const int wave = threadIdx.x >> 6, j = threadIdx.x & 63;
+    const int b = pl.wpb * (bx >> 1) + wave;
+    const bool fwd = (bx & 1) == 0;
+    if (wave >= pl.wpb || b >= B) return;
+    if (!go) {
+      // the loop is dead (device_helpers.h): the iteration is poisoned, and every band is published so that no
+      // statistics workgroup waits for a sweep that will not run
+      if (threadIdx.x == 0) svi_poison(sy);
+      if (j == 0)
+        for (int i = 0; i < pl.pub.nb; ++i) __hip_atomic_fetch_add(pl.pub.cnt + 16 * i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    WlrRing<double>& ring = *reinterpret_cast<WlrRing<double>*>(smem);     // (not touched by the publishing variant of the body)
+    if (pl.dbg && threadIdx.x == 0) pl.dbg[(size_t)bx * 32] = wall_clock64();
+    if (fwd) wave_linr_body<true, true, ST, double, true>(Eh, kexp, Aexp, mod_init, ll0, l0stride, Lq, K, ah, hx, local_lb, logz, zfac, ring, b, j, &pl.pub);
+    else wave_linr_body<false, true, ST, double, true>(Eh, kexp, AexpT, mod_init, ll0, l0stride, Lq, K, bh, gx, local_lb, logz, zfac, ring, b, j, &pl.pub);
+    if (pl.dbg && threadIdx.x == 0) pl.dbg[(size_t)bx * 32 + 1] = wall_clock64();
+    return;
+  }
+  const int sb = bx - pl.nsw;
+  if (pl.exp == 1) return;
+  if (pl.exp == 2) { const unsigned long long t0 = wall_clock64(); while (wall_clock64() - t0 < 12000ull) __builtin_amdgcn_s_sleep(64); return; }
+  pipe_stats_role<XK, ST>(obs, mask, starts, B, Lm, Lq, off, D, K, Fp, F, fab, ah, bh, flags, part, local_lb + B, &pl,
+                          sb / pl.ngrp, sb % pl.ngrp);
+}

@@ -231,7 +231,9 @@ __global__ void k_fb_exact(const double* __restrict__ ll, const double* __restri
 //  reduction on the critical path.  sum_t LSE_j lalpha (quirk Q4) is accumulated as a
 //  running (mantissa, exponent) product of the per-step sums.
 // ------------------------------------------------------------------------------------
+#ifndef LN2_D
 #define LN2_D 0.69314718055994530942
+#endif
 
 template <int NW>
 struct FbShared {
@@ -586,29 +588,7 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_mfma(
 #ifndef SVIHMM_KO_SWEEP
 #define SVIHMM_KO_SWEEP 0
 #endif
-#define LOG2E_D 1.4426950408889634074
-#define LN2_HI_D 6.93147180369123816490e-01
-#define LN2_LO_D 1.90821492927058770002e-10
-
-// arithmetic type of a sweep: the MFMA, its C-register <-> window map, frexp / ldexp.  double:
-// v_mfma_f64_16x16x4_f64, register r of lane group lg = window lg + 4 r; float (fp32 mode, round 4):
-// v_mfma_f32_16x16x4_f32 at twice the rate, register r = window 4 lg + r.
-typedef float float4_lv __attribute__((ext_vector_type(4)));
-template <typename T> struct LV;
-template <> struct LV<double> {
-  typedef double4_t v4;
-  static __device__ __forceinline__ v4 mma(double a, double b, v4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-  static __device__ __forceinline__ int crow(int lg, int r) { return lg + 4 * r; }
-  static __device__ __forceinline__ int fexp(double x) { return __builtin_amdgcn_frexp_exp(x); }
-  static __device__ __forceinline__ double ldx(double x, int e) { return ldexp(x, e); }
-};
-template <> struct LV<float> {
-  typedef float4_lv v4;
-  static __device__ __forceinline__ v4 mma(float a, float b, v4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-  static __device__ __forceinline__ int crow(int lg, int r) { return 4 * lg + r; }
-  static __device__ __forceinline__ int fexp(float x) { return __builtin_amdgcn_frexp_expf(x); }
-  static __device__ __forceinline__ float ldx(float x, int e) { return ldexpf(x, e); }
-};
+#include "kernels_wave_linr.h"
 template <int NW, typename T = double>
 struct LinShared {
   static constexpr int PS = 16 * NW + 2;
@@ -1332,19 +1312,6 @@ __global__ __launch_bounds__(64 * NW) void k_sweeps_lin2(
 // vmcnt instead of a full drain per step.  The exponent stream is written 64 steps at a time
 // (lane s & 63 keeps h_s; one coalesced store per 64 steps): 64 lanes storing one address
 // every step serialise in the memory pipeline.
-// Initial message of a window, lane = state (K <= 64): lalpha_0 = mod_init + ll_0 combined in the
-// log domain (see k_lin_init), scaled by its own binary exponent H; returns a0[j], sets
-// h0 = H - k0 (k0: the emission exponent of the window's first row).
-__device__ __forceinline__ double lin_init_lane(const double* __restrict__ mod_init,
-                                                const double* __restrict__ l0, int jc, bool valid,
-                                                double k0, double& h0) {
-  const double v = valid ? mod_init[jc] + l0[jc] : -INFINITY;
-  const double m = wave_max(v);
-  const double H = (m > -1e300 && m < 1e300) ? ceil(m * LOG2E_D) : 0.0;
-  h0 = H - k0;
-  return valid ? exp(fma(-H, LN2_LO_D, fma(-H, LN2_HI_D, v))) : 0.0;
-}
-
 template <int KMAX, bool FULLK, typename ST = double>
 __global__ __launch_bounds__(64) void k_wave_lin(
     const ST* __restrict__ Eh, const double* __restrict__ kexp,
@@ -1651,302 +1618,6 @@ __global__ __launch_bounds__(256) void k_wave_lin4(
   } else {
     if (K == 64) wave_lin4_body<false, true, ST>(Eh, kexp, AexpT, mod_init, ll0, l0stride, Lm, K, bh, gx, local_lb, logz, zfac, part);
     else wave_lin4_body<false, false, ST>(Eh, kexp, AexpT, mod_init, ll0, l0stride, Lm, K, bh, gx, local_lb, logz, zfac, part);
-  }
-}
-
-// ------------------------------------------------------------------------------------
-//  K2g (round 5), minibatch-sized batches: ONE wavefront per (window, direction) with the whole
-//  mat-vec in registers -- no LDS round trip and no workgroup barrier on the 257-step chain.
-//  Lane l = 16 r + c holds state l of the entering vector.  It forms the partial sums of the FOUR
-//  targets 16 q + c (q = 0..3) over its source block [16 r, 16 r + 16): 64 DPP FMAs whose source
-//  operand is a row broadcast of the wave's own registers (row_newbcast:N = lane 16 r + N), four
-//  independent chains.  The four rows' partials of a target meet through the two lane-swap
-//  instructions gfx950 has (v_permlane32_swap: upper half of one register <-> lower half of another;
-//  v_permlane16_swap: odd rows <-> even rows): swap(P0, P2), swap(P1, P3), two adds, swap, one add --
-//  and lane 16 r + c holds the finished sum of target 16 r + c, i.e. the next entering vector in
-//  place.  A step of k_wave_lin4 was 16 FMAs + an LDS round trip + a barrier between four waves
-//  (~740 cycles); this one is ~110 instructions of one wave.  Same inputs / outputs as k_wave_lin4;
-//  the 64-term sum is associated as 4 blocks x 16, blocks (r, r + 2) first.
-//  fp32 mode (ST = float): the same step on v_fmac_f32_dpp; exponents and the local bound's running
-//  product stay double.
-// ------------------------------------------------------------------------------------
-#ifndef WLR_KO
-#define WLR_KO 0      // measurement knock-outs / add-ons of k_wave_linr (tools/probe/wlr_probe.hip); 0 in the product
-#endif
-typedef unsigned wr_u2 __attribute__((ext_vector_type(2)));
-template <int N, bool FIRST = false>
-__device__ __forceinline__ void fmac_row_bcast(float& acc, float p, float a) {
-  if (FIRST)
-    asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-                 : "+v"(acc) : "v"(p), "v"(a), "n"(N));
-  else
-    asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-                 : "+v"(acc) : "v"(p), "v"(a), "n"(N));
-}
-// lanes 0..31: x(l) + x(l + 32);  lanes 32..63: y(l - 32) + y(l)
-__device__ __forceinline__ double swap_add32(double x, double y) {
-  const wr_u2 lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
-  const wr_u2 hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
-  return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
-}
-__device__ __forceinline__ float swap_add32(float x, float y) {
-  const wr_u2 v = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-  return __uint_as_float(v.x) + __uint_as_float(v.y);
-}
-// even rows: x(l) + x(l + 16);  odd rows: y(l - 16) + y(l)
-__device__ __forceinline__ double swap_add16(double x, double y) {
-  const wr_u2 lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
-  const wr_u2 hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
-  return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
-}
-__device__ __forceinline__ float swap_add16(float x, float y) {
-  const wr_u2 v = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-  return __uint_as_float(v.x) + __uint_as_float(v.y);
-}
-// One eighth of a step's mat-vec: the DPP FMAs of sources N0, N0 + 1 into the four target accumulators.
-// One asm statement per group, so that the exponent reduction's instructions can be placed between the
-// groups by hand (a lone wave issues in order: what matters is the instruction count, and that no
-// dependent pair sits back to back).
-template <int N0, bool FIRST>
-__device__ __forceinline__ void wlr_fma2(double& p0, double& p1, double& p2, double& p3, double pc,
-                                         double a00, double a10, double a20, double a30,
-                                         double a01, double a11, double a21, double a31) {
-#define WLR_F(ACC, CO, NN) "v_fmac_f64_dpp %" #ACC ", %4, %" #CO " row_newbcast:%" #NN " row_mask:0xf bank_mask:0xf\n\t"
-  if (FIRST)
-    asm volatile("s_nop 1\n\t" WLR_F(0, 5, 13) WLR_F(1, 6, 13) WLR_F(2, 7, 13) WLR_F(3, 8, 13)
-                 WLR_F(0, 9, 14) WLR_F(1, 10, 14) WLR_F(2, 11, 14) WLR_F(3, 12, 14)
-                 : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3)
-                 : "v"(pc), "v"(a00), "v"(a10), "v"(a20), "v"(a30), "v"(a01), "v"(a11), "v"(a21), "v"(a31),
-                   "n"(N0), "n"(N0 + 1));
-  else
-    asm volatile(WLR_F(0, 5, 13) WLR_F(1, 6, 13) WLR_F(2, 7, 13) WLR_F(3, 8, 13)
-                 WLR_F(0, 9, 14) WLR_F(1, 10, 14) WLR_F(2, 11, 14) WLR_F(3, 12, 14)
-                 : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3)
-                 : "v"(pc), "v"(a00), "v"(a10), "v"(a20), "v"(a30), "v"(a01), "v"(a11), "v"(a21), "v"(a31),
-                   "n"(N0), "n"(N0 + 1));
-#undef WLR_F
-}
-template <int N0, bool FIRST>
-__device__ __forceinline__ void wlr_fma2(float& p0, float& p1, float& p2, float& p3, float pc,
-                                         float a00, float a10, float a20, float a30,
-                                         float a01, float a11, float a21, float a31) {
-#define WLR_F(ACC, CO, NN) "v_fmac_f32_dpp %" #ACC ", %4, %" #CO " row_newbcast:%" #NN " row_mask:0xf bank_mask:0xf\n\t"
-  if (FIRST)
-    asm volatile("s_nop 1\n\t" WLR_F(0, 5, 13) WLR_F(1, 6, 13) WLR_F(2, 7, 13) WLR_F(3, 8, 13)
-                 WLR_F(0, 9, 14) WLR_F(1, 10, 14) WLR_F(2, 11, 14) WLR_F(3, 12, 14)
-                 : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3)
-                 : "v"(pc), "v"(a00), "v"(a10), "v"(a20), "v"(a30), "v"(a01), "v"(a11), "v"(a21), "v"(a31),
-                   "n"(N0), "n"(N0 + 1));
-  else
-    asm volatile(WLR_F(0, 5, 13) WLR_F(1, 6, 13) WLR_F(2, 7, 13) WLR_F(3, 8, 13)
-                 WLR_F(0, 9, 14) WLR_F(1, 10, 14) WLR_F(2, 11, 14) WLR_F(3, 12, 14)
-                 : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3)
-                 : "v"(pc), "v"(a00), "v"(a10), "v"(a20), "v"(a30), "v"(a01), "v"(a11), "v"(a21), "v"(a31),
-                   "n"(N0), "n"(N0 + 1));
-#undef WLR_F
-}
-// The normalising exponent: a uniform integer e with  sum_j p[j] 2^-e  in [1/2, 64) -- the largest
-// biased exponent field of the vector's entries (zeros and denormals count as the smallest), as frexp's
-// exponent.  32-bit DPP max: four steps inside the rows of 16, row_bcast:15 / :31 across them, one
-// v_readlane of lane 63: eight instructions against ~26 for the fp64 wave sum whose exponent the other
-// sweep kernels use (any integer keeps the books exact; the vector only has to stay in range).  The
-// steps are separate asm statements: the caller places them between the groups of the mat-vec.
-__device__ __forceinline__ int wlr_expfield(double v) { return (__double2hiint(v) >> 20) & 0x7ff; }
-__device__ __forceinline__ int wlr_expfield(float v) { return (int)((__float_as_uint(v) >> 23) & 0xff); }
-template <int STEP>
-__device__ __forceinline__ void wlr_emax(int& e) {
-  if (STEP == 0) asm volatile("v_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(e));
-  if (STEP == 1) asm volatile("v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(e));
-  if (STEP == 2) asm volatile("v_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(e));
-  if (STEP == 3) asm volatile("v_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(e));
-  if (STEP == 4) asm volatile("v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(e));
-  if (STEP == 5) asm volatile("v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(e));
-}
-template <typename CT> struct WlrBias;
-template <> struct WlrBias<double> { static constexpr int v = 1022; };
-template <> struct WlrBias<float> { static constexpr int v = 126; };
-template <typename CT> struct WlrRing { CT v[64][65]; };      // [step & 63][state]: a lane later sums ITS step's row
-template <bool FWD, bool FULLK, typename ST, typename CT>
-__device__ __forceinline__ void wave_linr_body(
-    const ST* __restrict__ Eh, const double* __restrict__ kexp,
-    const double* __restrict__ Am, const double* __restrict__ mod_init,
-    const double* __restrict__ ll0, size_t l0stride, int Lm, int K, ST* __restrict__ out,
-    double* __restrict__ xout, double* __restrict__ local_lb, double* __restrict__ logz,
-    double2* __restrict__ zfac, WlrRing<CT>& ring) {
-  // (CT = arithmetic type of the mat-vec; ST = storage type of Eh and of the messages)
-  const int b = blockIdx.x, j = threadIdx.x;
-  const int r = j >> 4, c = j & 15;
-  const bool valid = FULLK || j < K;
-  const int jc = valid ? j : 0;
-  CT a[4][16];                                  // a[q][N] = A[16 r + N][16 q + c] (fwd) / A[16 q + c][16 r + N] (bwd)
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int src = 16 * r + i, tgt = 16 * q + c;
-      a[q][i] = (FULLK || (tgt < K && src < K)) ? (CT)Am[(size_t)src * K + tgt] : (CT)0;
-    }
-  const size_t wrow = (size_t)b * Lm;
-  const ptrdiff_t dstep = FWD ? (ptrdiff_t)K : -(ptrdiff_t)K;
-  const size_t row0 = FWD ? 0 : (size_t)(Lm - 1);
-  // uniform row pointers (scalar registers) + the lane's column: loads and stores take base + offset
-  const ST* __restrict__ ep = Eh + (wrow + row0) * K;       // Eh row of sweep step 0
-  ST* __restrict__ op = out + (wrow + row0) * K;
-  double* __restrict__ xb = xout + wrow;
-  auto rowof = [&](int s) { return FWD ? s : Lm - 1 - s; };
-  // exponent books: h = the current vector's binary exponent (an exact integer: |h| <= ~1100 Lm),
-  // hsum = sum of the h of all vectors so far, lbacc = this lane's share of sum_t log(sum_j ah_t[j])
-  int h = 0;
-  long long hsum = 0;
-  double lbacc = 0.0;
-  CT pcur;
-  {
-    CT o;
-    if (FWD) {
-      double h0;
-      o = (CT)lin_init_lane(mod_init, ll0 + (size_t)b * l0stride, jc, valid, kexp[wrow], h0);
-      h = __builtin_amdgcn_readfirstlane((int)h0);
-      pcur = o;
-      ring.v[0][j] = o;
-    } else {
-      const CT e0 = ep[jc];
-      o = valid ? (CT)1 : (CT)0;
-      pcur = valid ? e0 : (CT)0;
-    }
-    if (valid) op[jc] = o;
-  }
-  int hkeep = h;                                // lane (s & 63) keeps the exponent of sweep step s
-  // the local bound's terms of the vectors in ring rows [0, n): lane t sums row t
-  auto ring_flush = [&](int n) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-#pragma unroll
-    for (int i = 0; i < 64; i += 4) {
-      t0 += (double)ring.v[j][i]; t1 += (double)ring.v[j][i + 1];
-      t2 += (double)ring.v[j][i + 2]; t3 += (double)ring.v[j][i + 3];
-    }
-    const double tot = (t0 + t1) + (t2 + t3);
-    if (j < n) lbacc += fast_log(tot);
-    __builtin_amdgcn_wave_barrier();
-  };
-  constexpr int PD = 12;
-  auto eclamped = [&](int s) { return ep[(ptrdiff_t)(s < Lm ? s : Lm - 1) * dstep + jc]; };
-  CT eq[PD];
-#pragma unroll
-  for (int u = 0; u < PD; ++u) eq[u] = eclamped(1 + u);
-  auto step = [&](int s, CT et) {
-    CT p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-    int ef = wlr_expfield(pcur);                // (the exponent comes from the ENTERING vector: off the chain)
-#define WLR_G(N0, FI) wlr_fma2<N0, FI>(p0, p1, p2, p3, pcur, a[0][N0], a[1][N0], a[2][N0], a[3][N0], \
-                                       a[0][N0 + 1], a[1][N0 + 1], a[2][N0 + 1], a[3][N0 + 1]);
-    WLR_G(0, true)
-#if !(WLR_KO & 1)
-    wlr_emax<0>(ef);
-    WLR_G(2, false)
-    wlr_emax<1>(ef);
-    WLR_G(4, false)
-    wlr_emax<2>(ef);
-    WLR_G(6, false)
-    wlr_emax<3>(ef);
-    WLR_G(8, false)
-    wlr_emax<4>(ef);
-    WLR_G(10, false)
-    wlr_emax<5>(ef);
-    WLR_G(12, false)
-    WLR_G(14, false)
-#else
-    wlr_emax<0>(ef); wlr_emax<1>(ef); wlr_emax<2>(ef); wlr_emax<3>(ef); wlr_emax<4>(ef); wlr_emax<5>(ef);
-#endif
-#undef WLR_G
-#if WLR_KO & 2
-    const int e2 = 0;
-#else
-    const int em = __builtin_amdgcn_readlane(ef, 63);
-    const int e2 = em ? em - WlrBias<CT>::v : 0;
-#endif
-    const CT q0 = swap_add32(p0, p2), q1 = swap_add32(p1, p3);
-    const CT acc = swap_add16(q0, q1);
-    if (FWD) hsum += h;
-    CT o;
-    if (FWD) { o = LV<CT>::ldx(acc * et, -e2); if (!FULLK) o = valid ? o : (CT)0; pcur = o; }
-    else { o = LV<CT>::ldx(acc, -e2); if (!FULLK) o = valid ? o : (CT)0; pcur = et * o; }
-    h += e2;
-    op += dstep;
-#if !(WLR_KO & 4)
-    if (FULLK || valid) op[jc] = o;
-#endif
-    hkeep = (j == (s & 63)) ? h : hkeep;
-    if (FWD) ring.v[s & 63][j] = o;
-    if ((s & 63) == 63) {                       // uniform
-      xb[rowof(s - 63 + j)] = (double)hkeep;
-      if (FWD) ring_flush(64);
-    }
-#if WLR_KO & 48
-    // measurement only (tools/probe/wlr_probe.hip): what publishing the sweep's progress would cost -- an
-    // agent-scope release every 32 (bit 16) or 16 (bit 32) steps + one relaxed store of the step
-    if ((s & ((WLR_KO & 32) ? 15 : 31)) == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      if (j == 0) __hip_atomic_store(reinterpret_cast<int*>(zfac + b) + (FWD ? 0 : 1), s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#endif
-  };
-  int s = 1;
-  for (; s + PD <= Lm; s += PD) {
-#pragma unroll
-    for (int u = 0; u < PD; ++u) {
-      const CT et = eq[u];
-#if !(WLR_KO & 8)
-      eq[u] = eclamped(s + u + PD);           // (uniform row arithmetic: scalar instructions)
-#endif
-      step(s + u, et);
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < PD; ++u)
-    if (s + u < Lm) step(s + u, eq[u]);
-  {
-    const int sl = Lm - 1, s0 = sl & ~63;
-    if ((sl & 63) != 63 && s0 + j <= sl) xb[rowof(s0 + j)] = (double)hkeep;
-    if (FWD && (sl & 63) != 63) ring_flush((sl & 63) + 1);
-  }
-  if (!FWD) return;
-  double ks = 0.0, kk = 0.0;
-  for (int t = j; t < Lm; t += 64) {
-    const double kv = kexp[wrow + t];
-    ks += kv;
-    kk += kv * (double)(Lm - t);
-  }
-  ks = wave_sum_dpp(ks);
-  kk = wave_sum_dpp(kk);
-  lbacc = wave_sum_dpp(lbacc);
-  const double tot = wave_sum_dpp((double)pcur);
-  if (j == 0) {
-    const double zm = __builtin_amdgcn_frexp_mant(tot);
-    const double zexp = (double)__builtin_amdgcn_frexp_exp(tot);
-    const double hd = (double)h;
-    local_lb[b] = lbacc + ((double)hsum + hd + kk) * LN2_D;
-    logz[b] = log(zm) + (hd + ks + zexp) * LN2_D;
-    zfac[b] = make_double2(1.0 / zm, hd + zexp);
-  }
-}
-template <typename ST = double, typename CT = ST>
-__global__ __launch_bounds__(64) void k_wave_linr(
-    const ST* __restrict__ Eh, const double* __restrict__ kexp,
-    const double* __restrict__ Aexp, const double* __restrict__ AexpT,
-    const double* __restrict__ mod_init, const double* __restrict__ ll0, size_t l0stride, int Lm,
-    int K, ST* __restrict__ ah,
-    ST* __restrict__ bh, double* __restrict__ hx, double* __restrict__ gx,
-    double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac,
-    SviSync sy = SviSync{nullptr, 0u, nullptr, nullptr, nullptr}) {
-  __shared__ WlrRing<CT> ring;
-  if (!svi_gate(sy)) { svi_poison(sy); return; }   // (SVI loop: the globals kernel of the side stream has arrived)
-  if (blockIdx.y == 0) {
-    if (K == 64) wave_linr_body<true, true, ST, CT>(Eh, kexp, Aexp, mod_init, ll0, l0stride, Lm, K, ah, hx, local_lb, logz, zfac, ring);
-    else wave_linr_body<true, false, ST, CT>(Eh, kexp, Aexp, mod_init, ll0, l0stride, Lm, K, ah, hx, local_lb, logz, zfac, ring);
-  } else {
-    if (K == 64) wave_linr_body<false, true, ST, CT>(Eh, kexp, AexpT, mod_init, ll0, l0stride, Lm, K, bh, gx, local_lb, logz, zfac, ring);
-    else wave_linr_body<false, false, ST, CT>(Eh, kexp, AexpT, mod_init, ll0, l0stride, Lm, K, bh, gx, local_lb, logz, zfac, ring);
   }
 }
 

@@ -80,7 +80,9 @@ int svihmm_destroy(svihmm_ctx* h) {
                  &h->local_lb, &h->logz, &h->part, &h->packed, &h->scratch, &h->kexp, &h->hx, &h->gx,
                  &h->zfac, &h->llE, &h->m_ll, &h->m_la, &h->m_lb, &h->chain, &h->chain2, &h->cat_table, &h->partc, &h->theta_orb, &h->prior, &h->vlb_aux, &h->gen_z,
                  &h->svi_state, &h->svi_prior, &h->svi_work, &h->commtmp, &h->ll0, &h->a0v, &h->a0e,
-                 &h->shift_d, &h->uwb, &h->uwd, &h->AexpF, &h->AexpTF, &h->svi_sync};
+                 &h->shift_d, &h->uwb, &h->uwd, &h->AexpF, &h->AexpTF, &h->svi_sync, &h->pipe_cnt,
+                 &h->pipe_tabs[0].buf, &h->pipe_tabs[1].buf, &h->pipe_tabs[2].buf, &h->pipe_tabs[3].buf,
+                 &h->pipe_tabs[4].buf, &h->pipe_tabs[5].buf, &h->pipe_tabs[6].buf, &h->pipe_tabs[7].buf};
   for (Buf* b : bufs) release(*b);
   if (h->vlb_host) { hipHostFree(h->vlb_host); h->vlb_host = nullptr; }
   if (h->svi_elbo) { hipHostFree(h->svi_elbo); h->svi_elbo = nullptr; }
@@ -1194,8 +1196,15 @@ static int estep_core(svihmm_ctx* h, const int64_t* starts, int B, int Lm, int i
     CK(estep_pipelined(h, starts, B, Lm, inner_off, inner_len, flags));
   } else {
     CK(prepare_ll(h, starts, B, Lm, flags, true, var == 3));
-    CK(run_fb(h, B, Lm, var, (flags & SVIHMM_KEEP_LBETA) != 0, true));
-    CK(launch_stats(h, B, Lm, inner_off, inner_len, flags));
+    if (var == 3 && sweep_stats_ok(h, B, Lm, inner_off, inner_len, flags)) {
+      // minibatch-sized batches of the five-tile shapes: sweeps and statistics in one launch, the statistics'
+      // stages behind the sweeps' published progress (tu_fused.hip)
+      CK(wait_side_streams(h));
+      CK(launch_sweep_stats(h, B, Lm, inner_off, inner_len, flags));
+    } else {
+      CK(run_fb(h, B, Lm, var, (flags & SVIHMM_KEEP_LBETA) != 0, true));
+      CK(launch_stats(h, B, Lm, inner_off, inner_len, flags));
+    }
     CK(flush_lb(h, h->stream));   // no-op when k_finalize carried the ELBO total
   }
   h->have_packed = true;

@@ -1,0 +1,179 @@
+// tu_fused.hip -- the minibatch E-step's sweeps + statistics as one launch (kernels_fused.h): plan and launcher.
+// One of the translation units of libsvihmm_hip.so (see host.h).
+#include "host.h"
+#include "device_helpers.h"
+#include "kernels_fused.h"
+
+#include <algorithm>
+
+extern "C" {
+
+// the statistics GEMM tiling this batch would take as a launch of its own must be the five-tile one the fused kernel's
+// statistics workgroups implement (tu_stats.hip, stats_mt: K = 64 with D >= 25, i.e. at least 17 tiles that pad less
+// in groups of 20 than in groups of 16)
+static bool five_tile_shape(const svihmm_ctx* h) {
+  const int Kp = h->Kp, Fp = h->Fp, D = h->D;
+  if (Kp != 64 || h->variant[10] != 0) return false;
+  const int xk = (D + 1 + 15) / 16, mt = (Fp + Kp) / 16;
+  if ((D + 1 + 7) / 8 > 9) return false;         // (the fused kernel's statistics stage: eight threads per row, <= 9 x columns each)
+  if (xk > 3) return true;
+  if (mt <= 16) return false;
+  return !((mt + 15) / 16 * 16 < (mt + 19) / 20 * 20);
+}
+// stages per chunk: the fewest (>= 3: something to hide; <= 12) with which sweep + statistics workgroups are all
+// resident at once and leave CUs for the loop's side-stream kernels; 0: does not fit
+static int pipe_wpb() { const char* e = std::getenv("SVIHMM_PIPE_WPB"); const int v = e ? std::atoi(e) : 4; return v >= 1 && v <= 4 ? v : 4; }
+static int pipe_stages(const svihmm_ctx* h, int B, int Lm, int ngrp, int* nchunk_out, int* Lb_out) {
+  const int wpb = pipe_wpb();
+  const int nsw = 2 * ((B + wpb - 1) / wpb);
+  for (int ns = 3; ns <= PIPE_MAX_STAGES; ++ns) {
+    if (ns > Lm) break;
+    const int Lb = (Lm + ns - 1) / ns;
+    const int64_t nchunk = ((int64_t)B * Lb + 31) / 32;
+    if (nsw + nchunk * ngrp <= h->ncu - 8) { *nchunk_out = (int)nchunk; *Lb_out = Lb; return ns; }
+  }
+  return 0;
+}
+// Does this batch take the fused launch?  (prepare_ll has run: lin_mode / cur_f32 describe the batch in flight.)
+bool sweep_stats_ok(const svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags) {
+  const int K = h->K;
+  if (h->variant[4] == 1 || h->variant[1] != 0 || h->variant[2] == 1 || h->variant[2] == 2 || h->variant[7] != 0 ||
+      h->variant[8] != 0 || h->variant[15] != 0)
+    return false;
+  if ((flags & SVIHMM_USE_HOST_LLIKS) || h->emis_cat || h->emis_diag || !h->lin_mode || h->q_valid || h->eh_in_llE) return false;
+  if (K != 64 || h->Fp <= 0 || !five_tile_shape(h)) return false;      // (the sweep workgroups run the all-lanes-valid body)
+  if (B < 1 || B > lin_waver_max(h) || Lq > (1 << 20) || use_chain(h, B, Lq)) return false;
+  if (off != 0 || Lm != Lq) return false;      // (the local bound covers the whole window: its log terms come from the statistics rows)
+  if ((int64_t)B * Lq * K >= ((int64_t)1 << 31)) return false;
+  if (pipe_lds_bytes(h->D, PIPE_MAX_STAGES) > 150 * 1024) return false;
+  const int ngrp = ((h->Fp + 64) / 16 + 19) / 20;
+  int nchunk = 0, Lb = 0;
+  return pipe_stages(h, B, Lm, ngrp, &nchunk, &Lb) > 0;
+}
+
+// readiness order of the inner rows of a window (cached per (Lq, off, Lm, wrap)): row t of the inner segment has both
+// messages -- its own and its predecessor's, which the transition statistic multiplies -- once both sweeps have done
+// need(t) = max over {t, pred(t)} of max(t_full, Lq - 1 - t_full) steps
+static int pipe_order(svihmm_ctx* h, int Lq, int off, int Lm, bool wrap, int NS, int Lb, WlrPub* pub, const int** ord_dev,
+                      const WlrPub** pub_dev) {
+  std::vector<int> need((size_t)Lm), idx((size_t)Lm);
+  auto n1 = [&](int t) { const int tf = off + t; return std::max(tf, Lq - 1 - tf); };
+  for (int t = 0; t < Lm; ++t) {
+    int n = n1(t);
+    if (t > 0) n = std::max(n, n1(t - 1));
+    else if (wrap) n = std::max(n, n1(Lm - 1));
+    need[t] = n; idx[t] = t;
+  }
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return need[a] < need[b]; });
+  pub->nb = NS;
+  for (int s = 0; s < NS; ++s) pub->thr[s] = need[idx[std::min((s + 1) * Lb, Lm) - 1]];
+  // cache of device tables: [order | publication record] per (Lq, off, Lm, wrap, NS); a table stays untouched while
+  // launches that read it may be in flight
+  const size_t pub_off = ((size_t)Lm * sizeof(int) + 15) & ~(size_t)15;
+  for (auto& e : h->pipe_tabs)
+    if (e.buf.p && e.Lq == Lq && e.off == off && e.Lm == Lm && e.wrap == wrap && e.NS == NS) {
+      e.stamp = ++h->pipe_stamp;
+      *ord_dev = (const int*)e.buf.p; *pub_dev = (const WlrPub*)((const char*)e.buf.p + pub_off);
+      return 0;
+    }
+  svihmm_ctx::PipeTab* slot = nullptr;
+  for (auto& e : h->pipe_tabs) if (!e.buf.p) { slot = &e; break; }
+  if (!slot) {
+    slot = &h->pipe_tabs[0];
+    for (auto& e : h->pipe_tabs) if (e.stamp < slot->stamp) slot = &e;
+    HIPCK(hipStreamSynchronize(h->stream));           // (the evicted table's readers are done)
+  }
+  CK(ensure(slot->buf, pub_off + sizeof(WlrPub)));
+  std::vector<char> img(pub_off + sizeof(WlrPub), 0);
+  std::memcpy(img.data(), idx.data(), (size_t)Lm * sizeof(int));
+  std::memcpy(img.data() + pub_off, pub, sizeof(WlrPub));
+  HIPCK(hipMemcpy(slot->buf.p, img.data(), img.size(), hipMemcpyHostToDevice));
+  slot->Lq = Lq; slot->off = off; slot->Lm = Lm; slot->wrap = wrap; slot->NS = NS; slot->stamp = ++h->pipe_stamp;
+  *ord_dev = (const int*)slot->buf.p; *pub_dev = (const WlrPub*)((const char*)slot->buf.p + pub_off);
+  return 0;
+}
+
+// sweeps of the B windows of length Lq + statistics over their inner segments [off, off + Lm) + finalize
+int launch_sweep_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags) {
+  if (!h->have_globals) return fail("no globals: call svihmm_set_globals");
+  const int K = h->K, D = h->D, Fp = h->Fp, F = h->F;
+  const int ngrp = ((Fp + 64) / 16 + 19) / 20;
+  PipePlan pl = {};
+  pl.wpb = pipe_wpb();
+  pl.exp = std::getenv("SVIHMM_PIPE_EXP") ? std::atoi(std::getenv("SVIHMM_PIPE_EXP")) : 0;
+  pl.nsw = 2 * ((B + pl.wpb - 1) / pl.wpb);
+  pl.ngrp = ngrp;
+  pl.NS = pipe_stages(h, B, Lm, ngrp, &pl.nchunk, &pl.Lb);
+  if (pl.NS <= 0) return fail("internal: fused sweep + statistics launch does not fit (sweep_stats_ok)");
+  CK(ensure_fb_lin(h, B, Lq));
+  CK(ensure(h->local_lb, (size_t)(B + pl.nchunk) * sizeof(double)));     // [B] exponent books per window | [nchunk] the chunks' log terms
+  CK(ensure_stats(h, pl.nchunk));
+  CK(ensure_starts_pulled(h));
+  if (!h->pipe_cnt.p) {
+    CK(ensure(h->pipe_cnt, PIPE_MAX_STAGES * 64));
+    HIPCK(hipMemset(h->pipe_cnt.p, 0, PIPE_MAX_STAGES * 64));
+  }
+  pl.pub.cnt = (unsigned*)h->pipe_cnt.p;
+  CK(pipe_order(h, Lq, off, Lm, (flags & SVIHMM_TRANS_WRAP) != 0, pl.NS, pl.Lb, &pl.pub, &pl.ord, &pl.pubg));
+  for (int s = 0; s < pl.NS; ++s) {
+    h->pipe_tgt[s] += 2u * (unsigned)B;            // (monotonic counters: compared by signed difference on the device)
+    pl.tgt[s] = h->pipe_tgt[s];
+  }
+  if (std::getenv("SVIHMM_PIPE_DBG")) {     // measurement only (tools/r6_fused_trace.py)
+    CK(ensure(h->scratch, (size_t)(pl.nsw + pl.nchunk * pl.ngrp) * 32 * 8));
+    HIPCK(hipMemsetAsync(h->scratch.p, 0, (size_t)(pl.nsw + pl.nchunk * pl.ngrp) * 32 * 8, h->stream));
+    pl.dbg = (unsigned long long*)h->scratch.p;
+    pl.pub.dbgw = pl.dbg;
+  }
+  h->m_nb = 0;
+  h->have_lb = true;
+  const size_t lds = std::max(pipe_lds_bytes(D, pl.NS), (size_t)84 * 1024);     // (> 80 KB: one workgroup per CU)
+  const SviSync gsy = sweep_gate(h, h->stream);
+  const void* Ehv = h->ll.p;
+  const double* kx = (const double*)h->kexp.p;
+  const double* mi = (const double*)h->mod_init.p;
+  const double* l0 = (const double*)h->ll0.p;
+  const uint8_t* mk = h->have_mask ? (const uint8_t*)h->mask.p : nullptr;
+  const int xk = (D + 1 + 7) / 8;
+  const dim3 grid((unsigned)(pl.nsw + pl.nchunk * pl.ngrp));
+  {
+    ProfScope ps(h, KS_FB, h->stream);
+#define FZ(XKV, STT)                                                                                                     \
+  do {                                                                                                                   \
+    h->last_kernel[KS_FB] = "k_sweep_stats<" #XKV ", " #STT ">";                                                         \
+    hipFuncSetAttribute((const void*)k_sweep_stats<XKV, STT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+    hipLaunchKernelGGL((k_sweep_stats<XKV, STT>), grid, dim3(256), lds, h->stream, (const STT*)Ehv, kx,                  \
+                       (const double*)h->Aexp.p, (const double*)h->AexpT.p, mi, l0, (size_t)K, Lq, K, (STT*)h->la.p,     \
+                       (STT*)h->lb.p, (double*)h->hx.p, (double*)h->gx.p, (double*)h->local_lb.p, (double*)h->logz.p,    \
+                       (double2*)h->zfac.p, gsy, (const double*)h->obs.p, mk, (const int64_t*)h->starts.p, B, Lm, off, D, \
+                       Fp, F, (const int*)h->fab.p, flags, (double*)h->part.p, pl);                                      \
+  } while (0)
+#define FZX(STT) do { if (xk <= 5) FZ(5, STT); else FZ(9, STT); } while (0)
+    if (h->cur_f32) FZX(float); else FZX(double);
+#undef FZX
+#undef FZ
+    HIPCK(hipGetLastError());
+  }
+  if (pl.dbg) {      // measurement only: the launch's stamps as text
+    HIPCK(hipStreamSynchronize(h->stream));
+    std::vector<unsigned long long> st((size_t)grid.x * 32);
+    HIPCK(hipMemcpy(st.data(), pl.dbg, st.size() * 8, hipMemcpyDeviceToHost));
+    if (FILE* f = std::fopen(std::getenv("SVIHMM_PIPE_DBG"), "w")) {
+      unsigned long long t0 = ~0ull;
+      for (unsigned i = 0; i < grid.x; ++i) if (st[(size_t)i * 32] && st[(size_t)i * 32] < t0) t0 = st[(size_t)i * 32];
+      std::fprintf(f, "# nsw %d nchunk %d ngrp %d NS %d Lb %d thr", pl.nsw, pl.nchunk, pl.ngrp, pl.NS, pl.Lb);
+      for (int s = 0; s < pl.NS; ++s) std::fprintf(f, " %d", pl.pub.thr[s]);
+      std::fprintf(f, "\n");
+      for (unsigned i = 0; i < grid.x; ++i) {
+        std::fprintf(f, "%u", i);
+        for (int k = 0; k < (i < (unsigned)pl.nsw ? 13 : 14 + 2 * pl.NS); ++k) { const unsigned long long v = st[(size_t)i * 32 + k]; std::fprintf(f, " %.2f", v ? (double)(v - t0) * 0.01 : -1.0); }
+        std::fprintf(f, "\n");
+      }
+      std::fclose(f);
+    }
+  }
+  h->lb_pending = B + pl.nchunk;     // the windows' exponent books + the chunks' log terms: summed by k_finalize's extra workgroup
+  return launch_stats_finalize(h, pl.nchunk, h->stream);
+}
+
+}  // extern "C"

@@ -168,7 +168,7 @@ static bool minibatch_wave_kernel(const svihmm_ctx* h, int K, int nb, int Lm) {
 }
 // SVI loop on counters (svihmm_hip.hip, svi_globals): those two kernels wait for the side stream's globals
 // kernel themselves -- no stream-order event in front of them
-static SviSync sweep_gate(svihmm_ctx* h, hipStream_t stream) {
+SviSync sweep_gate(svihmm_ctx* h, hipStream_t stream) {
   SviSync sy = {};
   if (h->svi_flags && h->in_svi_estep && h->globals_ev && stream == h->stream && h->svi_sync.p) {
     sy.gate = (const unsigned*)h->svi_sync.p + 16;

@@ -1,0 +1,48 @@
+"""round 6: wall-clock stamps of one fused sweep + statistics launch (SVIHMM_PIPE_DBG): when the sweep workgroups run,
+when each statistics stage's gate opens and when its k-steps end."""
+import sys, os
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from pysvihmm_amd.engine import HipEngine
+from pysvihmm_amd import _lib as L
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from _workload import bench_problem
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+e = HipEngine(0)
+pb = bench_problem(e)
+LM, T = bench.LM, bench.T
+st = (np.arange(B, dtype=np.int64) * (T // B)) % (T - LM)
+e.set_globals(pb["mod_init"], pb["ltran"]); e.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+for _ in range(5):
+    e.estep(st, LM, flags=L.TRANS_WRAP, read=False)
+e.sync()
+path = "/tmp/pipe_dbg.txt"
+os.environ["SVIHMM_PIPE_DBG"] = path
+e.estep(st, LM, flags=L.TRANS_WRAP, read=False)
+e.sync()
+del os.environ["SVIHMM_PIPE_DBG"]
+lines = open(path).read().splitlines()
+print(lines[0])
+hdr = lines[0].split()
+nsw, NS = int(hdr[2]), int(hdr[8])
+raw = [[float(x) for x in l.split()[1:]] for l in lines[1:]]
+W = max(len(r) for r in raw)
+rows = np.array([r + [-1.0] * (W - len(r)) for r in raw])
+sw = rows[:nsw]
+if sw.shape[1] >= 13:
+    print("sweep wave 0 of each workgroup, mean stamps (us): step 63 / 127 / 191 / 255, chain done, function end")
+    for name, sel in (("fwd", sw[0::2]), ("bwd", sw[1::2])):
+        print("  %s: %s | %.1f | %.1f" % (name, " ".join("%.1f" % sel[:, 2 + 2 * q].mean() for q in range(4)), sel[:, 12].mean(), sel[:, 1].mean()))
+print("sweep workgroups: begin %.1f .. %.1f us, end %.1f .. %.1f us (fwd even / bwd odd: fwd end mean %.1f, bwd end mean %.1f)" % (
+    sw[:, 0].min(), sw[:, 0].max(), sw[:, 1].min(), sw[:, 1].max(), sw[0::2, 1].mean(), sw[1::2, 1].mean()))
+stt = rows[nsw:]
+print("statistics workgroups: begin %.1f .. %.1f" % (stt[:, 0].min(), stt[:, 0].max()))
+for s in range(NS):
+    g, d = stt[:, 1 + 2 * s], stt[:, 2 + 2 * s]
+    extra = ""
+    if stt.shape[1] > 15 + 2 * s:
+        extra = "; rows arrived +%.1f, committed +%.1f, k-steps +%.1f" % ((stt[:, 14 + 2 * s] - g).mean(), (stt[:, 15 + 2 * s] - stt[:, 14 + 2 * s]).mean(), (d - stt[:, 15 + 2 * s]).mean())
+    print("  stage %d: gate opens %.1f .. %.1f (mean %.1f), k-steps end %.1f .. %.1f (mean %.1f)%s" % (s, g.min(), g.max(), g.mean(), d.min(), d.max(), d.mean(), extra))
+e.close()
