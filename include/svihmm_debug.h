@@ -43,7 +43,9 @@ const char* svihmm_last_kernel_name(svihmm_ctx* h, int32_t slot);
  *      of iteration 3 waits for a count that never comes with a 2 ms bound -- exercises the bounded-wait recovery)
  * | 1 statistics (2 double-buffered MFMA, else the pipelined MFMA kernels)
  * | 2 sweeps (1 wave-per-window, 2 log-domain MFMA, 3 scaled linear-domain MFMA)
- * | 3 emission row tiles per wave | 4 two-stream E-step pipeline (1 off, 2 on; default off)
+ * | 3 emission row tiles per wave | 4 E-step launch structure (0: sweeps + statistics of minibatch-sized K = 64 batches in one
+ *      fused launch where that is ahead, else one launch after the other; 1: never fused; 2: the two-stream pipeline of
+ *      round 2; 3: the fused launch for every batch it can take, whatever its size or precision mode)
  * | 6 blocked scan for one long window (B = 1, Lm >= 2048, K <= 64; 1 = off)
  * | 9 automatic centring of the resident observations at upload (1 = off: c = 0)
  * | 12 barrier-free statistics GEMM with three LDS buffers (1 = off: the double-buffered kernel)

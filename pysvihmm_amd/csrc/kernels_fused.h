@@ -82,9 +82,10 @@ __device__ __forceinline__ void pipe_stats_body(
   constexpr int MT = 5, NTW = 4, Kp = 64, QS = ST_QS(64), TPR = 8, QK = 8, CC = PIPE_CC1;
   const int ZERO = D + 1, ONE = ZERO + 1, QP0 = ZERO + 2;
   const int C = QP0 + Kp;
-  double* rb0 = smem;                               // [C][CC]
-  double* qs0 = rb0 + C * CC;                       // [32][QS]
-  PipeRow* rinfo = reinterpret_cast<PipeRow*>(qs0 + ST_RB * QS);   // [NS][32]
+  const int TB = C * CC + ST_RB * QS;               // doubles of one tile buffer: A tile [C][CC] | q tile [32][QS]
+  double* rb0 = smem;                               // buffer u at rb0 + u TB
+  double* qs0 = rb0 + C * CC;
+  PipeRow* rinfo = reinterpret_cast<PipeRow*>(smem + 2 * TB);      // [NS][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int mg = wave;
@@ -142,21 +143,23 @@ __device__ __forceinline__ void pipe_stats_body(
   }
   const int qwi = sr * QS + sc;
   const int pwi = (QP0 + sc) * CC + psr;
-  if (sc == 0) { rb0[ZERO * CC + psr] = 0.0; rb0[ONE * CC + psr] = 1.0; }
+  if (sc == 0) { rb0[ZERO * CC + psr] = 0.0; rb0[ONE * CC + psr] = 1.0; rb0[TB + ZERO * CC + psr] = 0.0; rb0[TB + ONE * CC + psr] = 1.0; }
   const ST* __restrict__ athr = ah + sc;
   const ST* __restrict__ bthr = bh + sc;
 
   unsigned long long* dbg = pl.dbg ? pl.dbg + (size_t)blockIdx.x * 32 : nullptr;
-  const unsigned long long t_begin = wall_clock64();
-  unsigned long long t_open0 = 0;
-  if (dbg && tid == 0) dbg[0] = t_begin;
-  // ---- the stage loop.  Stage s: gate (band s published by all sweeps) -> fetch its 32 rows into registers -> normalise,
-  //      commit to LDS -> 8 k-steps.  While the workgroup runs behind the sweeps (the first band opens at 60 % of the
-  //      sweep, later ones every ~7 us) every gate is a real wait; once it lags -- a stage costs 3 us of loads + 2 us of
-  //      matrix pipe -- the next band is usually open already: it is looked at without waiting after the commit, and
-  //      its rows are requested BEFORE the k-steps of the current stage, so loads and matrix work overlap.
-  int* lflag = reinterpret_cast<int*>(rinfo + NS * 32);       // [0] "next band is open" (written by thread 0)
-  double* lred = reinterpret_cast<double*>(lflag + 2);         // [4] per-wave sums of the local bound's terms
+  if (dbg && tid == 0) dbg[0] = wall_clock64();
+  // ---- the stage loop, double-buffered.  Stage s = 8 k-steps (160 MFMAs per wave: 4.3 us of the fp64 matrix pipe) on the
+  //      32 rows of band s in LDS buffer s & 1.  The rows of band s + 1 are requested as soon as that band is open --
+  //      thread 0 looks at its counter between k-steps and raises a flag in LDS, every thread tests the flag at the same
+  //      places and issues its loads itself -- so their ~2 us of memory latency run beside the matrix work; whoever has
+  //      not seen the flag by the end of the k-steps waits for it there.  Then normalise + commit into the other buffer,
+  //      one barrier, next stage.  (Measured first with one buffer and gate -> loads -> commit -> k-steps in sequence:
+  //      8.4 us per stage against bands 7.7 us apart -- the statistics fell further behind with every stage and ended
+  //      20 us after the sweeps.)
+  volatile int* lflag = reinterpret_cast<volatile int*>(rinfo + NS * 32);   // [s]: band s is open (written by thread 0)
+  double* lred = reinterpret_cast<double*>(const_cast<int*>(lflag) + PIPE_MAX_STAGES + 2);   // [4] per-wave sums of the local bound's terms
+  if (tid < PIPE_MAX_STAGES) lflag[tid] = 0;
   double rx[XK], va[QK], vb[QK], pa[QK], pb[QK];
   bool okx = false, okq = false, okp = false;
   double lbp = 0.0;
@@ -189,7 +192,9 @@ __device__ __forceinline__ void pipe_stats_body(
       }
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](int u) {
+    double* rbu = rb0 + u * TB;
+    double* qsu = qs0 + u * TB;
     // self-normalised posteriors (columns >= K of a ragged model read a neighbour's entries: masked)
     double vq[QK], vp[QK], sq = 0.0, sp = 0.0, sa = 0.0;
 #pragma unroll
@@ -220,71 +225,80 @@ __device__ __forceinline__ void pipe_stats_body(
       for (int k = 0; k < XK; ++k) {
         const int c = sc + TPR * k;
         const double v = c < D ? rx[k] : (c == D ? 1.0 : 0.0);
-        rb0[xwi[k]] = okx ? v : 0.0;
+        rbu[xwi[k]] = okx ? v : 0.0;
       }
     }
 #pragma unroll
-    for (int k = 0; k < QK; ++k) qs0[qwi + TPR * k] = vq[k] * iq;
+    for (int k = 0; k < QK; ++k) qsu[qwi + TPR * k] = vq[k] * iq;
     if (need_qp) {
 #pragma unroll
-      for (int k = 0; k < QK; ++k) rb0[pwi + TPR * k * CC] = vp[k] * ip;
+      for (int k = 0; k < QK; ++k) rbu[pwi + TPR * k * CC] = vp[k] * ip;
     }
   };
-  bool have = false;                                 // the registers hold the rows of the stage about to start
-  for (int s = 0; s < NS; ++s) {
-    if (!have) {
-      // ---- gate: every sweep has stored the rows of band s (bounded like the loop's other gates: a count that never
-      //      comes must not hang the queue; the statistics of such a launch are garbage and its sweeps poisoned the step)
-      if (tid == 0) {
-        // Polling discipline (measured, tools/r6_fused_trace.py): 208 workgroups polling one counter every 0.2 us
-        // saturate its memory channel.  The first band is polled every ~1.7 us; its opening time gives the sweeps'
-        // pace, later bands are slept for (clock reads only) until a microsecond before their predicted opening and
-        // then polled every ~0.4 us.
-        if (s > 0 && t_open0 > t_begin) {
-          const unsigned long long pred = t_begin + (t_open0 - t_begin) * (unsigned long long)pl.pub.thr[s] / (unsigned long long)(pl.pub.thr[0] > 0 ? pl.pub.thr[0] : 1);
-          while (wall_clock64() + 100ull < pred) __builtin_amdgcn_s_sleep(32);
+  // every thread: wait until band s is flagged open (thread 0 does the looking: bounded like the loop's other gates --
+  // a count that never comes must not hang the queue; the statistics of such a launch are garbage, its sweeps poisoned
+  // the step).  Polling discipline (measured): 208 workgroups polling one counter every 0.2 us saturate its memory
+  // channel; the first band is polled every ~1.7 us, later ones every ~0.4 us.
+  auto wait_band = [&](int s) {
+    // (wave-uniform on purpose: with lane 0 polling in one branch and lanes 1..63 of the same wave spinning on the flag
+    //  in the other, the wave never gets back to lane 0 -- all lanes of wave 0 read the counter, one request)
+    if (wave == 0) {
+      if (!lflag[s]) {
+        const unsigned long long t0 = wall_clock64();
+        unsigned n = 0;
+        while (!band_open(s)) {
+          if (s == 0) __builtin_amdgcn_s_sleep(64); else __builtin_amdgcn_s_sleep(16);
+          if ((++n & 1023u) == 0u && wall_clock64() - t0 > SVI_SYNC_TICKS) break;
         }
-        if (!band_open(s)) {
-          const unsigned long long t0 = wall_clock64();
-          unsigned n = 0;
-          while (!band_open(s)) {
-            if (s == 0) __builtin_amdgcn_s_sleep(64); else __builtin_amdgcn_s_sleep(16);
-            if ((++n & 1023u) == 0u && wall_clock64() - t0 > SVI_SYNC_TICKS) break;
-          }
-        }
-        if (s == 0) t_open0 = wall_clock64();
+        if (lane == 0) lflag[s] = 1;
       }
-      __syncthreads();                               // (also: every wave is through the previous stage's k-steps)
-      if (dbg && tid == 0) dbg[1 + 2 * s] = wall_clock64();
-      if (pl.exp == 3) { if (dbg && tid == 0) dbg[2 + 2 * s] = wall_clock64(); continue; }
-      fetch(s);
     } else {
-      __syncthreads();                               // every wave is through the previous stage's k-steps
-      if (dbg && tid == 0) dbg[1 + 2 * s] = wall_clock64();
+      while (!lflag[s]) __builtin_amdgcn_s_sleep(2);
     }
-    if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (tid == 0) dbg[14 + 2 * s] = wall_clock64(); }
-    commit();
-    if (tid == 0) lflag[0] = (s + 1 < NS && band_open(s + 1)) ? 1 : 0;
-    __syncthreads();
-    if (dbg && tid == 0) dbg[15 + 2 * s] = wall_clock64();
-    have = lflag[0] != 0;
-    if (have) fetch(s + 1);
-    // ---- 8 k-steps, the LDS reads of k-step ks + 1 issued before the MFMAs of k-step ks
+  };
+  __syncthreads();                                   // row records and flags are in place
+  wait_band(0);
+  if (dbg && tid == 0) dbg[1] = wall_clock64();
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  for (int s = 0; s < NS; ++s) {
+    if (pl.exp == 3) {                                // (measurement: gates only)
+      if (dbg && tid == 0) dbg[2 + 2 * s] = wall_clock64();
+      if (s + 1 < NS) { wait_band(s + 1); if (dbg && tid == 0) dbg[3 + 2 * s] = wall_clock64(); }
+      continue;
+    }
+    const bool more = s + 1 < NS;
+    bool issued = false;
+    unsigned seen = 0;                                // thread 0: the band counter as last read (asynchronously)
+    const unsigned* cnt_next = pl.pub.cnt + 16 * (more ? s + 1 : s);
+    const unsigned tgt_next = pl.tgt[more ? s + 1 : s];
+    // ---- 8 k-steps on buffer s & 1, the LDS reads of k-step ks + 1 issued before the MFMAs of k-step ks
     {
-      const double* qs = qs0 + obq;
+      const double* rbu = rb0 + (s & 1) * TB;
+      const double* qs = qs0 + (s & 1) * TB + obq;
       double Bv[NTW], Ax[MT], Ay[MT];
 #pragma unroll
       for (int n = 0; n < NTW; ++n) Bv[n] = qs[n * 16];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) { Ax[m] = rb0[oa[m]]; Ay[m] = rb0[ob[m]]; }
+      for (int m = 0; m < MT; ++m) { Ax[m] = rbu[oa[m]]; Ay[m] = rbu[ob[m]]; }
 #pragma unroll
       for (int ks = 0; ks < ST_RB / 4; ++ks) {
+        // the next band: thread 0 reads its counter (the value is looked at one k-step later: no wait on the load),
+        // everybody tests the flag
+        // (twice per stage only: the flag is an LDS read, and waiting for it also waits for the operand reads in flight)
+        if (more && !issued && (ks == 1 || ks == 4)) {
+          if (tid == 0 && !lflag[s + 1] && (int)(seen - tgt_next) >= 0) lflag[s + 1] = 1;
+          if (lflag[s + 1]) { fetch(s + 1); issued = true; if (dbg && tid == 0) dbg[14 + 2 * s] = wall_clock64(); }
+        }
+        if (more && !issued && (ks == 0 || ks == 3) && tid == 0)
+          seen = __hip_atomic_load(cnt_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         double Bn[NTW], Axn[MT], Ayn[MT];
         if (ks + 1 < ST_RB / 4) {
 #pragma unroll
           for (int n = 0; n < NTW; ++n) Bn[n] = qs[(ks + 1) * 4 * QS + n * 16];
 #pragma unroll
-          for (int m = 0; m < MT; ++m) { Axn[m] = rb0[oa[m] + ks + 1]; Ayn[m] = rb0[ob[m] + ks + 1]; }
+          for (int m = 0; m < MT; ++m) { Axn[m] = rbu[oa[m] + ks + 1]; Ayn[m] = rbu[ob[m] + ks + 1]; }
         }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -302,6 +316,13 @@ __device__ __forceinline__ void pipe_stats_body(
       }
     }
     if (dbg && tid == 0) dbg[2 + 2 * s] = wall_clock64();
+    if (more) {
+      if (!issued) { wait_band(s + 1); fetch(s + 1); if (dbg && tid == 0) dbg[14 + 2 * s] = wall_clock64(); }
+      if (dbg && tid == 0) dbg[3 + 2 * s] = wall_clock64();
+      commit((s + 1) & 1);
+      __syncthreads();                               // buffer (s + 1) & 1 complete; everybody is through buffer s & 1
+      if (dbg && tid == 0) dbg[15 + 2 * s] = wall_clock64();
+    }
   }
   // ---- the chunk's share of sum_t log(sum_j ah_t[j]) (first feature group only: every row once)
   if (lb_here) {
@@ -329,7 +350,8 @@ __device__ __forceinline__ void pipe_stats_body(
 inline size_t pipe_lds_bytes(int D, int NS) {
   // (statistics: tiles + row records + flag / reduction words; the sweep workgroups use no LDS since the row sums of
   //  the local bound moved to the statistics side)
-  return ((size_t)(D + 3 + 64) * PIPE_CC1 + (size_t)ST_RB * ST_QS(64)) * 8 + (size_t)NS * 32 * sizeof(PipeRow) + 64;
+  return 2 * ((size_t)(D + 3 + 64) * PIPE_CC1 + (size_t)ST_RB * ST_QS(64)) * 8 + (size_t)NS * 32 * sizeof(PipeRow) +
+         (PIPE_MAX_STAGES + 2) * sizeof(int) + 4 * sizeof(double) + 64;
 }
 
 // 256-thread workgroups: four waves, one per SIMD, each with the SIMD's whole register file (512).  Both roles are

@@ -42,6 +42,11 @@ bool sweep_stats_ok(const svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_
     return false;
   if ((flags & SVIHMM_USE_HOST_LLIKS) || h->emis_cat || h->emis_diag || !h->lin_mode || h->q_valid || h->eh_in_llE) return false;
   if (K != 64 || h->Fp <= 0 || !five_tile_shape(h)) return false;      // (the sweep workgroups run the all-lanes-valid body)
+  // (measured, tools/r6_fused_check.py: from ~16 windows on the fused launch is ahead of sweeps + statistics one after the
+  //  other -- 169 against 178 us at 64 windows --, below that the statistics launch is too short to be worth hiding; the
+  //  fp32 mode keeps its own statistics kernel on the bf16 pipe (29 us: the fused fp64 stages end later than that);
+  //  variant 4 = 3 forces the fused launch for every batch it can take -- tests)
+  if (h->variant[4] != 3 && (B < 16 || h->cur_f32)) return false;
   if (B < 1 || B > lin_waver_max(h) || Lq > (1 << 20) || use_chain(h, B, Lq)) return false;
   if (off != 0 || Lm != Lq) return false;      // (the local bound covers the whole window: its log terms come from the statistics rows)
   if ((int64_t)B * Lq * K >= ((int64_t)1 << 31)) return false;

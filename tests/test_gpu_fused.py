@@ -1,0 +1,103 @@
+"""The fused sweep + statistics launch (kernels_fused.h, round 6) against the C oracle and against the separate
+launches it replaces: every shape class it takes -- one window to a quarter of the device, windows of 3 to 300 rows
+(bands thinner than a stage, stages mostly padding), masks, no wrap-around, the fp32 storage format -- with the
+fused path forced (variant "pipeline" = 3) and switched off (= 1)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(K, D, T, seed, miss=0.05):
+    from tests.helpers import make_problem
+    return make_problem(K, D, T, seed=seed, miss=miss)
+
+
+@pytest.mark.parametrize("B,Lm,D,wrap", [(1, 257, 32, True), (9, 33, 32, True), (64, 257, 32, True), (23, 3, 32, False),
+                                         (100, 65, 40, True), (130, 9, 48, True), (5, 300, 32, False)])
+def test_fused_launch_vs_oracle_and_separate_launches(B, Lm, D, wrap):
+    from oracle import ref_c
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    K, T = 64, 6000
+    pb = _problem(K, D, T, seed=B + Lm + D)
+    starts = np.random.default_rng(B).integers(0, T - Lm + 1, size=B)
+    flags = L.TRANS_WRAP if wrap else 0
+    eng = HipEngine(0)
+    try:
+        eng.set_obs(pb["obs"], pb["mask"])
+        eng.set_globals(pb["mod_init"], pb["ltran"])
+        eng.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+        res = {}
+        for mode in (1, 3):
+            eng.set_variant("pipeline", mode)
+            res[mode] = eng.estep(starts, Lm, flags=flags).buf.copy()
+            res[mode, "kernel"] = eng.last_kernel("forward_backward")
+        eng.set_variant("pipeline", 0)
+    finally:
+        eng.close()
+    assert "k_sweep_stats" in res[3, "kernel"], res[3, "kernel"]
+    assert "k_sweep_stats" not in res[1, "kernel"]
+    ref = ref_c.estep_minibatch(pb["obs"], pb["mask"], starts, Lm, pb["mod_init"], pb["ltran"], pb["mu"], pb["sigma"],
+                                pb["kappa"], pb["nu"], flags=2 if wrap else 0)
+    scale = np.maximum(np.abs(ref), 1e-9 * B * Lm)
+    assert np.max(np.abs(res[3] - ref) / scale) < 1e-6, "fused vs oracle"
+    assert np.max(np.abs(res[3] - res[1]) / scale) < 1e-9, "fused vs separate launches"
+
+
+def test_fused_launch_in_the_fp32_format():
+    """fp32 mode with the fused launch forced: float messages, fp64 statistics stages -- within the mode's 1e-3."""
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    K, D, T, B, Lm = 64, 32, 6000, 40, 129
+    pb = _problem(K, D, T, seed=3, miss=0.0)
+    starts = np.random.default_rng(1).integers(0, T - Lm + 1, size=B)
+    eng = HipEngine(0)
+    try:
+        eng.set_obs(pb["obs"], None)
+        eng.set_globals(pb["mod_init"], pb["ltran"])
+        eng.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+        ref = eng.estep(starts, Lm, flags=L.TRANS_WRAP).buf.copy()
+        eng.set_precision("f32")
+        eng.set_variant("pipeline", 3)
+        out = eng.estep(starts, Lm, flags=L.TRANS_WRAP).buf.copy()
+        used, kern = eng.precision()[1], eng.last_kernel("forward_backward")
+        eng.set_variant("pipeline", 0)
+        eng.set_precision("f64")
+    finally:
+        eng.close()
+    assert used and "k_sweep_stats" in kern and "float" in kern, (used, kern)
+    scale = np.maximum(np.abs(ref), 1e-6 * B * Lm)
+    assert np.max(np.abs(out - ref) / scale) < 1e-3
+
+
+def test_fused_launch_inside_the_resident_loop_matches_the_separate_launches():
+    """The device-resident SVI loop at the S = 64 shape class (K = 64, 24 windows) with the fused launch and without:
+    same state and ELBO trace to rounding (the fused statistics normalise every row by its own sum)."""
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd.distributions import niw_prior_logpart
+    from pysvihmm_amd import _lib as L
+    K, D, T, B, Lm, nit = 64, 32, 6000, 24, 65, 6
+    pb = _problem(K, D, T, seed=11, miss=0.0)
+    rng = np.random.default_rng(K)
+    prior_tran = 1.0 + rng.random((K, K))
+    mu0 = np.tile(pb["obs"].mean(0), (K, 1)) + 0.1 * rng.normal(size=(K, D))
+    sg0 = np.tile(0.75 * np.cov(pb["obs"].T).reshape(D, D), (K, 1, 1))
+    ka0, nu0 = np.full(K, 0.01), np.full(K, D + 2.0)
+    res = []
+    for mode in (1, 3):
+        eng = HipEngine(0)
+        try:
+            eng.set_variant("pipeline", mode)
+            eng.set_obs(pb["obs"], None)
+            eng.svi_begin(prior_tran, pb["var_tran"], (mu0, sg0, ka0, nu0), (pb["mu"], pb["sigma"], pb["kappa"], pb["nu"]),
+                          niw_prior_logpart(sg0, nu0), nit, 1.0)
+            r2 = np.random.default_rng(5)
+            for it in range(nit):
+                eng.svi_iteration(it, r2.integers(0, T - Lm, size=B), B, Lm, L.TRANS_WRAP, (it + 1.0) ** -0.7, 3.0, 2.5)
+            res.append((eng.svi_read_state(), eng.svi_read_elbo(nit)[0]))
+        finally:
+            eng.close()
+    for n, a, b in zip(("var_tran", "var_init", "mu", "sigma", "kappa", "nu"), res[0][0], res[1][0]):
+        np.testing.assert_allclose(a, b, rtol=1e-7, atol=1e-9, err_msg=n)
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-9)

@@ -39,10 +39,11 @@ print("sweep workgroups: begin %.1f .. %.1f us, end %.1f .. %.1f us (fwd even / 
     sw[:, 0].min(), sw[:, 0].max(), sw[:, 1].min(), sw[:, 1].max(), sw[0::2, 1].mean(), sw[1::2, 1].mean()))
 stt = rows[nsw:]
 print("statistics workgroups: begin %.1f .. %.1f" % (stt[:, 0].min(), stt[:, 0].max()))
+print("  band 0 open (first rows requested): %.1f .. %.1f (mean %.1f)" % (stt[:, 1].min(), stt[:, 1].max(), stt[:, 1].mean()))
 for s in range(NS):
-    g, d = stt[:, 1 + 2 * s], stt[:, 2 + 2 * s]
-    extra = ""
-    if stt.shape[1] > 15 + 2 * s:
-        extra = "; rows arrived +%.1f, committed +%.1f, k-steps +%.1f" % ((stt[:, 14 + 2 * s] - g).mean(), (stt[:, 15 + 2 * s] - stt[:, 14 + 2 * s]).mean(), (d - stt[:, 15 + 2 * s]).mean())
-    print("  stage %d: gate opens %.1f .. %.1f (mean %.1f), k-steps end %.1f .. %.1f (mean %.1f)%s" % (s, g.min(), g.max(), g.mean(), d.min(), d.max(), d.mean(), extra))
+    d = stt[:, 2 + 2 * s]
+    line = "  stage %d: k-steps end %.1f .. %.1f (mean %.1f)" % (s, d.min(), d.max(), d.mean())
+    if s + 1 < NS and stt.shape[1] > 15 + 2 * s:
+        line += "; rows of stage %d requested at %.1f (mean), committed at %.1f" % (s + 1, stt[:, 14 + 2 * s].mean(), stt[:, 15 + 2 * s].mean())
+    print(line)
 e.close()
