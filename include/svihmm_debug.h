@@ -52,7 +52,8 @@ const char* svihmm_last_kernel_name(svihmm_ctx* h, int32_t slot);
  * | 11 svihmm_allreduce_packed forms the sum in caller coordinates also at one rank (1 = on: the
  *      multi-rank path's coordinate round trip, exercised on a single GPU)
  * | 7 scaled sweeps' kernel family (K > 128: 1 one state tile per wave, 2 two tiles per wave for every K)
- * | 13 wide models' sweeps with 32 windows per workgroup (1 = off: 16)
+ * | 13 wide models' sweeps with 32 windows per workgroup (1 = off: 16); 2: NIW -> theta for 16 < D <= 32 by the builder that
+ *      leaves half the wave idle (rounds 2-5) instead of k_niw_to_theta_wave32s -- same results bit for bit
  * | 14 wide models' transition statistic in 128 x 64 blocks (1 = off: 64 x 64)
  * | 15 wide models' statistics GEMM forms q = ah bh scale itself (1 = off: separate posterior pass;
  *      2: a separate pass for every K -- valid results, slower)

@@ -234,9 +234,12 @@ __device__ __forceinline__ void svi_poison(const SviSync& sy) {
 // guards a write-after-read hazard only (the previous iteration's ELBO kernels still reading what the step rewrites),
 // so a gate that gives up does not stop the step -- it costs that iteration's ELBO entry, not the state
 __device__ __forceinline__ bool svi_step_gate(const SviSync& sy) {
-  if (sy.poison && __hip_atomic_load(sy.poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+  // (the poison word is requested by every thread up front and looked at AFTER the gate: its round trip rides with the
+  //  gate's own loads instead of standing in front of them -- 3 us of a 6 us kernel otherwise)
+  unsigned poisoned = 0u;
+  if (sy.poison) poisoned = __hip_atomic_load(sy.poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   (void)svi_gate(sy);
-  return true;
+  return poisoned == 0u;
 }
 __device__ __forceinline__ void svi_arrive(const SviSync& sy) {
   if (!sy.arrive) return;
@@ -245,5 +248,24 @@ __device__ __forceinline__ void svi_arrive(const SviSync& sy) {
     // (release: the workgroup's stores -- ordered before this thread by the barrier -- are written back first)
     const unsigned before = __hip_atomic_fetch_add(sy.arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     if (sy.stamp && before + 1u == sy.stamp_at) *sy.stamp = wall_clock64();
+  }
+}
+
+// entry e of the transition factor (shared by the families' global-step kernels)
+__device__ __forceinline__ void svi_tran_step(int e, int K, const double* __restrict__ packed,
+                                              const double* __restrict__ prior_tran, double* __restrict__ var_tran,
+                                              double rho, double bA, double nwin, double* __restrict__ ada_G) {
+  if (e >= K * K) return;
+  const double a_inter = packed[e] + nwin * (prior_tran[e] - 1.0);
+  const double nat_old = var_tran[e] - 1.0;
+  if (ada_G) {
+    // AdaGrad-scaled step of the transition factor (hmmsgd_metaobs.py:1036-1040): the
+    // accumulated squared natural parameters set a per-entry step 1 / G^(1/4); rho is not used
+    const double g = ada_G[e] + nat_old * nat_old;
+    ada_G[e] = g;
+    const double am = sqrt(sqrt(g));
+    var_tran[e] = ((1.0 - 1.0 / am) * nat_old + (bA * a_inter) / am) + 1.0;
+  } else {
+    var_tran[e] = ((1.0 - rho) * nat_old + rho * (bA * a_inter)) + 1.0;
   }
 }

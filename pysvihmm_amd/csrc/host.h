@@ -293,6 +293,12 @@ inline int64_t cu_scaled(const svihmm_ctx* h, int64_t v) {
   return r < 1 ? 1 : r;
 }
 struct StatsPlan { int64_t rpc, nchunk; };
+// the natural-gradient step's arguments when it rides in the theta builder's launch (k_svi_step_theta32s, kernels_svi_theta.h)
+struct SviStepArgs {
+  const double* packed; const double* prior_tran; double* var_tran; const double* prior;
+  double rho, bA, bE, nwin; double* lb_keep; double* ada_G;
+  SviSync sy;          // the step's gate / poison / arrival
+};
 // up to this many windows the wave-per-window scaled sweep beats the MFMA one (which is
 // latency-bound at ~0.9 us per step however few windows it gets): 2 x 1024 waves are resident
 // at once on 256 CUs (190 VGPRs: two per SIMD); measured (tools/sweep_crossover.py, K = 64, Lm = 257)
@@ -316,7 +322,8 @@ int launch_fb(svihmm_ctx* h, int B, int Lm, int dir0, int ndir, const double* ll
 int launch_fb_fused(svihmm_ctx* h, int B, int Lm, bool want_lb, bool total);
 int launch_fb_lin(svihmm_ctx* h, int B, int Lm, bool total);
 int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_t stream);
-int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out);
+int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out, const SviStepArgs* step = nullptr);
+bool step_theta_ok(const svihmm_ctx* h, int K, int D);
 int launch_posterior(svihmm_ctx* h, int B, int Lm, bool total);
 int launch_scale_ll(svihmm_ctx* h, int B, int Lm);
 int launch_scale_ll_f32(svihmm_ctx* h, int B, int Lm);

@@ -1621,6 +1621,286 @@ __device__ __forceinline__ void k_niw_to_theta_wave_body(
     }
   }
 }
+// D <= 32 (round 6): the same factorisation with BOTH halves of the wave at work.  The one-wave builder above leaves
+// lanes 32..63 idle at DMAX = 32 -- and it is 25 us of the S = 64 iteration's critical path (one wave per state, ~6900
+// dependent-ish instructions).  Here lane (r = a & 31, h = a >> 5) owns the columns b = 2 i + h of row r in the Cholesky
+// sweep (half the rank-one updates and LDS broadcasts per column step) and the columns j = 2 jj + h of row r in the Gram
+// product W = (nu / 2) X'X (half the dot products); the triangular inverse runs in both halves alike (32 columns, one
+// per lane: nothing to split).  Every ELEMENT goes through the same operations in the same order as above -- the
+// products of a row with the mean are summed in column order from LDS -- so theta, log det and the status word come
+// out bit for bit the same (tests/test_emission_formula.py pins them to SciPy; tests/test_gpu_theta_split.py compares
+// the two builders directly).
+__device__ __forceinline__ void k_niw_to_theta_wave32s_body(
+    const double* __restrict__ mu, const double* __restrict__ sigma,
+    const double* __restrict__ kappa, const double* __restrict__ nu, int K, int D, int Kp,
+    double* __restrict__ theta, int* __restrict__ status, double* __restrict__ orb,
+    double* __restrict__ logdet_out, uint4* __restrict__ uw) {
+  constexpr int DMAX = 32;
+  __shared__ double col[64];
+  __shared__ double Ls[DMAX][DMAX + 1];    // L (row-major), later X = L^-1 stored as Ls[c][r]
+  __shared__ double Wr[DMAX][DMAX + 1];    // W rows
+  __shared__ double ms[DMAX];
+  const int k = blockIdx.x, a = threadIdx.x, hh = a >> 5, r_ = a & 31;
+  const bool vr = r_ < D, va = a < D;
+  const double* Sg = sigma + (size_t)k * D * D;
+  double Ah[16];                           // A[r_][2 i + hh]
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int b = 2 * i + hh;
+    Ah[i] = (vr && b < D) ? Sg[(size_t)r_ * D + b] : (r_ == b ? 1.0 : 0.0);
+  }
+  if (a < DMAX) ms[a] = va ? mu[(size_t)k * D + a] : 0.0;
+  // ---- right-looking Cholesky; padded rows/columns form an identity block
+  bool bad = false;
+  double rdv[DMAX];
+#pragma unroll
+  for (int j = 0; j < DMAX; ++j) {
+    const double djj = __shfl(Ah[j >> 1], j + 32 * (j & 1), 64);     // A[j][j]: row j, half j & 1
+    bad |= !(djj > 0.0);
+    double d, rd;
+    {
+      const double y0 = __builtin_amdgcn_rsq(djj);
+      double g = djj * y0, hf = 0.5 * y0;
+      double r = fma(-g, hf, 0.5);
+      g = fma(g, r, g); hf = fma(hf, r, hf);
+      r = fma(-g, hf, 0.5);
+      g = fma(g, r, g); hf = fma(hf, r, hf);
+      g = fma(fma(-g, g, djj), hf, g);
+      d = g; rd = hf + hf;
+    }
+    rdv[j] = rd;
+    if (hh == (j & 1)) {
+      const double lo = (r_ == j) ? d : Ah[j >> 1] * rd;
+      Ah[j >> 1] = lo;
+      col[r_] = lo;
+    }
+    __syncthreads();
+    const double l = col[r_];
+    const double* cb = col + hh;
+    if ((j & 1) == 0) {                    // column j + 1 = 2 (j / 2) + 1: the odd half's entry of slot j / 2
+      const double t = fma(-l, col[j + 1 < DMAX ? j + 1 : j], Ah[j >> 1]);
+      Ah[j >> 1] = hh ? t : Ah[j >> 1];
+    }
+#pragma unroll
+    for (int i = (j >> 1) + 1; i < 16; ++i) Ah[i] = fma(-l, cb[2 * i], Ah[i]);   // upper part: unused garbage
+    __syncthreads();
+  }
+  if (bad) {   // uniform: djj is a broadcast value
+    if (a == 0 && status) atomicMax(status, 1 + k);
+    return;
+  }
+  double logdet;
+  {   // the diagonal element of row r_ lives in half r_ & 1: handed to lane r_ through LDS
+    double dgh = 1.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dgh = ((r_ >> 1) == i) ? Ah[i] : dgh;
+    if (hh == (r_ & 1)) col[r_] = dgh;
+    __syncthreads();
+    logdet = va ? log(col[a < DMAX ? a : 0]) : 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) Ls[r_][2 * i + hh] = Ah[i];
+  __syncthreads();
+  // ---- X = L^-1, column c = r_ (both halves compute it): X[r][c] = -(sum_{j=c}^{r-1} L[r][j] X[j][c]) / L[r][r]
+  double X[DMAX];
+  const int c = r_;
+#pragma unroll
+  for (int r = 0; r < DMAX; ++r) {
+    double s = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int j = 0; j < r; ++j) s = fma(-Ls[r][j], X[j], s);   // X[j] = 0 for j < c
+    X[r] = (r >= c) ? s * rdv[r] : 0.0;
+  }
+  __syncthreads();
+  if (a < DMAX) {
+#pragma unroll
+    for (int r = 0; r < DMAX; ++r) Ls[a][r] = X[r];            // Ls[c][r] = X[r][c]
+  }
+  __syncthreads();
+  const double hn = 0.5 * nu[k];
+  if (uw) {
+    // centred factor for the fp32-mode emission kernel (see k_niw_to_theta_wave_body: same record, same values)
+    const double shn = sqrt(hn);
+    const int j = a & 31, u = k & 1;
+    uint4* blk = uw + (size_t)(k >> 1) * (EMB_REC / 16);
+    float* ub = reinterpret_cast<float*>(blk + EMB_BLOCKS * 64);
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      uint32_t w3[3][4];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int cl = 16 * cc + 8 * hh + e;
+        const double v = (j < D && cl < D) ? shn * Ls[cl < DMAX ? cl : 0][j < DMAX ? j : 0] : 0.0;   // X[j][cl]
+        uint32_t t3[3];
+        bf16_split3(v, t3);
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+          if (e & 1) w3[s3][e >> 1] |= t3[s3] << 16; else w3[s3][e >> 1] = t3[s3];
+        }
+      }
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) {
+        const uint4 q = make_uint4(w3[s3][0], w3[s3][1], w3[s3][2], w3[s3][3]);
+        if (cc == 0) blk[(s3 * 3 + u) * 64 + a] = q;
+        else if (j >= 16) blk[(s3 * 3 + 2) * 64 + 32 * hh + 16 * u + (j - 16)] = q;
+      }
+    }
+    if (a < 32) {
+      double b = 0.0;
+      if (a < D) {
+#pragma unroll
+        for (int cl = 0; cl < DMAX; ++cl) b = fma(Ls[cl][a < DMAX ? a : 0], ms[cl], b);
+      }
+      ub[32 * u + a] = (float)(-shn * b);
+    }
+  }
+  // ---- W = (nu/2) X^T X: lane (i = r_, hh) forms W[i][j] for the columns j = 2 jj + hh
+  const int i = r_;
+  const int Nn = D + 1, cq = (D >> 2) > 0 ? (D >> 2) : 1, S4 = 4 * cq * Kp;
+  const int kk = (k & 15) * (Kp >> 4) + (k >> 4);
+  const int t4 = 4 * (i % cq) + i / cq;
+  const int fbase = (i * (D + 1) - i * (i - 1) / 2 - i) * Kp + k;
+  const int oA = t4 * Kp + kk - i * S4, oB = i * S4 + kk;
+#pragma unroll
+  for (int jj = 0; jj < 16; ++jj) {
+    const int j = 2 * jj + hh;
+    const double* lj = &Ls[0][0] + j * (DMAX + 1);
+    double s = 0.0;
+    {
+      const double t = fma(X[2 * jj], lj[2 * jj], 0.0);       // r = 2 jj: part of the sum for the even column only
+      s = hh ? 0.0 : t;
+    }
+#pragma unroll
+    for (int r = 2 * jj + 1; r < DMAX; ++r) s = fma(X[r], lj[r], s);   // X[r][i] * X[r][j]; zero for r < max(i,j)
+    const double w = hn * s;
+    Wr[i][j] = w;
+    if (theta && vr && j >= i && j < D) {
+      const double tv = (i == j) ? -w : -2.0 * w;
+      theta[fbase + j * Kp] = tv;
+      if (orb) {
+        const int t4j = 4 * (j % cq) + j / cq;
+        orb[(j - i <= (D >> 1)) ? oA + j * S4 : oB + (Nn - j) * S4 + t4j * Kp] = tv;
+      }
+    }
+  }
+  __syncthreads();
+  double wmi = 0.0;
+  if (a < DMAX) {
+#pragma unroll
+    for (int j = 0; j < DMAX; ++j) wmi = fma(Wr[a][j], ms[j], wmi);
+  }
+  if (theta && va) {                      // the linear term (i, D): column D is the orbit's leftover block
+    const double tv = 2.0 * wmi;
+    theta[fbase + D * Kp] = tv;
+    if (orb) {
+      const int dl = i + 1;
+      orb[(D - i <= (D >> 1)) ? oA + D * S4
+                              : (4 * (cq * ((D >> 1) + 1) + (dl >> 2)) + (dl & 3)) * Kp + kk] = tv;
+    }
+  }
+  // ---- constant term
+  double dgm = va ? digamma_d(0.5 * (nu[k] - a)) : 0.0;
+  double mWm = va ? ms[a < DMAX ? a : 0] * wmi : 0.0;
+  logdet = wave_sum(logdet); dgm = wave_sum(dgm); mWm = wave_sum(mWm);
+  if (a == 0) {
+    const double llt = D * log(2.0) + dgm - 2.0 * logdet;
+    const double cst = 0.5 * llt - D / (2.0 * kappa[k]) - 0.5 * D * 1.8378770664093454835606594728112;
+    if (theta) theta_store(theta, orb, D, D, D, Kp, k, cst - mWm);
+    if (logdet_out) logdet_out[k] = 2.0 * logdet;
+    if (status && mWm > NIW_CANCEL_LIMIT) atomicMax(status, NIW_STATUS_RANGE + 1 + k);
+    if (uw) reinterpret_cast<float*>(uw + (size_t)(k >> 1) * (EMB_REC / 16) + EMB_BLOCKS * 64)[64 + (k & 1)] = (float)(0.5 * cst);
+  }
+}
+// The natural-gradient global step of the resident SVI loop AND the theta builder in one launch (round 6; VERDICT r5
+// next #1b): workgroup k < K updates NIW factor k (hmmsgd_metaobs.py:1048-1069, util.py:28-60 -- the expressions of
+// k_svi_global_step, kernels_svi.h, term by term) with the sigma' entries already where the split Cholesky wants them
+// (lane (r, h): columns 2 i + h of row r), writes the factor back for the ELBO kernels and the next step, arrives on the
+// step counter (the side stream's globals kernel may go), and carries straight on into the factorisation; workgroups
+// K .. K + ceil(K^2 / 64) - 1 update the transition factor.  One kernel boundary and the 6-9 us step kernel less on the
+// iteration's chain; the separate kernels remain for every other family / shape.
+__global__ __launch_bounds__(64) void k_svi_step_theta32s(
+    const double* __restrict__ packed, const double* __restrict__ prior_tran, double* __restrict__ var_tran,
+    double* __restrict__ niw, const double* __restrict__ prior, int K, int D, double rho, double bA, double bE,
+    double nwin, double* __restrict__ lb_keep, double* __restrict__ ada_G, SviSync ssy,
+    int Kp, double* __restrict__ theta, int* __restrict__ status, double* __restrict__ orb,
+    double* __restrict__ logdet_out, uint4* __restrict__ uw, SviSync tsy) {
+  const size_t nmu = (size_t)K * D, nsg = (size_t)K * D * D;
+  const int a = threadIdx.x;
+  const bool go = svi_step_gate(ssy);
+  if ((int)blockIdx.x >= K) {
+    if (go) {
+      const int e = ((int)blockIdx.x - K) * 64 + a;
+      if (e == 0) *lb_keep = packed[(size_t)K * K + nmu + K + nsg];
+      svi_tran_step(e, K, packed, prior_tran, var_tran, rho, bA, nwin, ada_G);
+    }
+    svi_arrive(ssy);
+    return;
+  }
+  const int k = blockIdx.x;
+  double* mu = niw + (size_t)k * D;
+  double* sg = niw + nmu + (size_t)k * D * D;
+  double* kap = niw + nmu + nsg;
+  double* nu = kap + K;
+  if (go) {
+    __shared__ double mo[32], mn[32], m0[32];
+    const int hh = a >> 5, r_ = a & 31;
+    const double* mu0 = prior + (size_t)k * D;
+    const double* sg0 = prior + nmu + (size_t)k * D * D;
+    const double ka0 = prior[nmu + nsg + k], nu0 = prior[nmu + nsg + K + k];
+    const double* xbar = packed + (size_t)K * K + (size_t)k * D;
+    const double neff = packed[(size_t)K * K + nmu + k];
+    const double* S = packed + (size_t)K * K + nmu + K + (size_t)k * D * D;
+    const double ka = kap[k], nuo = nu[k];
+    const int ac = a < D ? a : 0;
+    const double m_ld = mu[ac], p_ld = mu0[ac], x_ld = xbar[ac];
+    const double e2 = (1.0 - rho) * ka + rho * (ka0 + bE * neff);                        // kappa'
+    const double e4 = (1.0 - rho) * (nuo + 2 + D) + rho * ((nu0 + 2 + D) + bE * neff);
+    if (a < D) {
+      const double m = m_ld, p = p_ld;
+      mo[a] = m; m0[a] = p;
+      mn[a] = ((1.0 - rho) * (ka * m) + rho * (ka0 * p + bE * x_ld)) / e2;               // mu' = e1 / e2
+    }
+    __syncthreads();
+    {
+      // (all 48 loads of the lane's 16 entries in flight at once -- clamped addresses, the stores predicated: one
+      //  memory round trip instead of one per entry)
+      const int rr = r_ < D ? r_ : 0;
+      double vs[16], v0[16], vS[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int b = 2 * i + hh, e = rr * D + (b < D ? b : 0);
+        vs[i] = sg[e]; v0[i] = sg0[e]; vS[i] = S[e];
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int b = 2 * i + hh, bc = b < D ? b : 0;
+        const double e3o = vs[i] + (mo[rr] * mo[bc]) * ka;
+        const double e3p = v0[i] + (m0[rr] * m0[bc]) * ka0;
+        const double e3 = (1.0 - rho) * e3o + rho * (e3p + bE * vS[i]);
+        if (r_ < D && b < D) sg[rr * D + b] = e3 - (mn[rr] * mn[bc]) * e2;                  // sigma'
+      }
+    }
+    __syncthreads();
+    if (a < D) mu[a] = mn[a];
+    if (a == 0) { kap[k] = e2; nu[k] = e4 - 2 - D; }
+  }
+  // (only the transition workgroups arrive on the step counter: what waits on it -- the side stream's globals kernel, 60 us
+  //  that must be over before the next sweeps -- needs var_tran alone and should not wait for the K factor updates)
+  // theta from the factor just written (this workgroup's own stores, in program order)
+  __syncthreads();
+  k_niw_to_theta_wave32s_body(niw, niw + nmu, kap, nu, K, D, Kp, theta, status, orb, logdet_out, uw);
+  svi_arrive(tsy);
+}
+// SPLIT: 0 the one-wave-half builder above, 1 both halves (D <= 32 only)
+__global__ __launch_bounds__(64) void k_niw_to_theta_wave32s(
+    const double* __restrict__ mu, const double* __restrict__ sigma,
+    const double* __restrict__ kappa, const double* __restrict__ nu, int K, int D, int Kp,
+    double* __restrict__ theta, int* __restrict__ status, double* __restrict__ orb,
+    double* __restrict__ logdet_out, uint4* __restrict__ uw = nullptr,
+    SviSync sy = SviSync{nullptr, 0u, nullptr, nullptr, nullptr}) {
+  if (svi_gate(sy)) k_niw_to_theta_wave32s_body(mu, sigma, kappa, nu, K, D, Kp, theta, status, orb, logdet_out, uw);
+  svi_arrive(sy);
+}
 template <int DMAX>
 __global__ __launch_bounds__(64) void k_niw_to_theta_wave(
     const double* __restrict__ mu, const double* __restrict__ sigma,

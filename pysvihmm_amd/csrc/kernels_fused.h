@@ -384,6 +384,12 @@ __global__ __launch_bounds__(256) void k_sweep_stats(
     int Lm, int off, int D, int Fp, int F, const int* __restrict__ fab, uint32_t flags, double* __restrict__ part,
     PipePlan pl) {
   extern __shared__ double smem[];
+  // Nobody else on this kernel's SIMDs: naming the last accumulation register makes the kernel's register block the whole
+  // file (512 per lane), so no wave of another kernel fits beside a sweep or a statistics wave.  In the resident SVI loop
+  // the ELBO kernels of the previous iteration and the next iteration's globals kernel run on side streams at this
+  // time; spread over this kernel's CUs they took issue slots from the 257-step chain and the matrix work (trace:
+  // k_svi_vlb 104 us instead of 20, this kernel 109 instead of 100) -- they belong on the CUs the launch leaves free.
+  asm volatile("" ::: "a255");
   const int bx = blockIdx.x;
   if (bx < pl.nsw) {
     // ---- sweep workgroup

@@ -255,24 +255,6 @@ __global__ __launch_bounds__(64 * NWV) void k_svi_globals(
 //  niw = [mu K*D | sigma K*D*D | kappa K | nu K] (the E-step's parameter block, updated in place);
 //  prior = [mu0 K*D | sigma0 K*D*D | kappa0 K | nu0 K].
 // ------------------------------------------------------------------------------------
-// entry e of the transition factor (shared by the families' global-step kernels)
-__device__ __forceinline__ void svi_tran_step(int e, int K, const double* __restrict__ packed,
-                                              const double* __restrict__ prior_tran, double* __restrict__ var_tran,
-                                              double rho, double bA, double nwin, double* __restrict__ ada_G) {
-  if (e >= K * K) return;
-  const double a_inter = packed[e] + nwin * (prior_tran[e] - 1.0);
-  const double nat_old = var_tran[e] - 1.0;
-  if (ada_G) {
-    // AdaGrad-scaled step of the transition factor (hmmsgd_metaobs.py:1036-1040): the
-    // accumulated squared natural parameters set a per-entry step 1 / G^(1/4); rho is not used
-    const double g = ada_G[e] + nat_old * nat_old;
-    ada_G[e] = g;
-    const double am = sqrt(sqrt(g));
-    var_tran[e] = ((1.0 - 1.0 / am) * nat_old + (bA * a_inter) / am) + 1.0;
-  } else {
-    var_tran[e] = ((1.0 - rho) * nat_old + rho * (bA * a_inter)) + 1.0;
-  }
-}
 __device__ __forceinline__ void k_svi_global_step_body(
     const double* __restrict__ packed, const double* __restrict__ prior_tran, double* __restrict__ var_tran,
     double* __restrict__ niw, const double* __restrict__ prior, int K, int D, double rho, double bA,

@@ -1409,7 +1409,7 @@ static int svi_globals(svihmm_ctx* h, int slot, int for_it) {
 // ELBO trace needs them, so they stay off the critical path of the iteration chain.
 static int svi_launch_elbo(svihmm_ctx* h, int elbo_it, int lb_slot, bool behind_sweeps, hipEvent_t after_theta);
 static int svi_refresh_emission(svihmm_ctx* h, int elbo_it, int lb_slot, hipEvent_t after_theta = nullptr,
-                                bool defer_elbo = false) {
+                                bool defer_elbo = false, const SviStepArgs* step = nullptr) {
   const int K = h->svi_K, D = h->svi_D, fam = h->svi_family;
   if (!h->stream3) HIPCK(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
   if (!h->svi_ec) {
@@ -1425,7 +1425,7 @@ static int svi_refresh_emission(svihmm_ctx* h, int elbo_it, int lb_slot, hipEven
     if (elbo_it >= 0) { tsy.stamp = svi_stamp_dev(h, 2 * elbo_it + 1); tsy.stamp_at = (unsigned)h->tgt_theta; }
   }
   h->theta_sy = tsy;
-  if (fam == 0) CK(launch_niw_to_theta(h, K, D, svi_ptr(h, 4)));
+  if (fam == 0) CK(launch_niw_to_theta(h, K, D, svi_ptr(h, 4), step));
   else if (fam == 1) CK(launch_diag_to_theta(h, K, D));
   else {
     // E log theta[v][k] = psi(alpha_kv) - psi(sum_v alpha_kv) (what hmmbase._push_emission uploads)
@@ -1858,7 +1858,9 @@ static int svi_iteration_impl(svihmm_ctx* h, int32_t it, const int64_t* starts, 
   // the previous iteration's ELBO kernels (their own stream) read var_tran / theta / logdet,
   // which this global step and the NIW kernel after it rewrite (normally long finished): flags mode gates the
   // step kernel on their counter, the event mode waits for their event
-  const unsigned ntran = (unsigned)((K * K + 255) / 256);
+  // (NIW factors of 17 .. 32 dimensions: the step rides in the theta builder's launch -- k_svi_step_theta32s)
+  const bool merged = h->svi_family == 0 && step_theta_ok(h, K, D);
+  const unsigned ntran = merged ? (unsigned)((K * K + 63) / 64) : (unsigned)((K * K + 255) / 256);
   const unsigned step_grid = h->svi_family == 0 ? (unsigned)K + ntran
                                                 : (unsigned)(((size_t)K * (h->svi_family == 1 ? D : h->V) + 255) / 256) + ntran;
   SviSync ssy = svi_sy(h);
@@ -1870,15 +1872,19 @@ static int svi_iteration_impl(svihmm_ctx* h, int32_t it, const int64_t* starts, 
     // that can hold half the device's wave slots (K beyond ~600), or ELBO kernels that were enqueued only just now
     // (svi_flush_elbo above: they may not be resident yet), could keep those kernels off the device -- the stream
     // waits for their event instead (recorded in both modes, svi_launch_elbo).
-    const bool big = (size_t)step_grid * 4 > (size_t)h->ncu * h->waves_per_cu / 2;
+    const bool big = (size_t)step_grid * (merged ? 1 : 4) > (size_t)h->ncu * h->waves_per_cu / 2;
     if (ssy.gate && (big || flushed_now) && h->vlb_pending) {
       HIPCK(hipStreamWaitEvent(h->stream, h->svi_ed, 0));
       ssy.gate = nullptr;
     }
   } else if (h->vlb_pending) { HIPCK(hipStreamWaitEvent(h->stream, h->svi_ed, 0)); h->vlb_pending = false; }
-  {
+  double* adag = h->svi_adagrad ? svi_ptr(h, 9) : (double*)nullptr;
+  SviStepArgs sargs = {(const double*)h->packed.p, (const double*)svi_ptr(h, 1), svi_ptr(h, 0), (const double*)h->svi_prior.p,
+                       rho, bfactA, bfactE, (double)nwin_total, svi_ptr(h, 8) + (it & 1), adag, ssy};
+  if (merged) {
+    if (h->svi_flags) h->tgt_step += ntran;          // (the merged kernel's transition workgroups: see k_svi_step_theta32s)
+  } else {
     ProfScope ps(h, KS_MISC);
-    double* adag = h->svi_adagrad ? svi_ptr(h, 9) : (double*)nullptr;
     if (h->svi_family == 0)
       hipLaunchKernelGGL(k_svi_global_step, dim3((unsigned)K + ntran), dim3(256), (size_t)3 * D * sizeof(double), h->stream,
                          (const double*)h->packed.p, (const double*)svi_ptr(h, 1), svi_ptr(h, 0),
@@ -1907,6 +1913,12 @@ static int svi_iteration_impl(svihmm_ctx* h, int32_t it, const int64_t* starts, 
   if (!h->svi_adagrad && rho >= 0.0 && rho <= 1.0) {
     h->svi_vmin = (1.0 - rho) * h->svi_vmin + rho;
     h->svi_f32_ok = h->svi_vmin > 0.05;
+  }
+  if (merged) {
+    // step + theta in one launch FIRST: the globals kernel's gate must wait for work submitted earlier in host order
+    CK(svi_refresh_emission(h, it, it & 1, h->svi_flags ? (hipEvent_t) nullptr : h->svi_ev[2 * it + 1], it + 1 < h->svi_maxit, &sargs));
+    if (it + 1 < h->svi_maxit) CK(svi_globals(h, h->svi_vi_cur ^ 1, it + 1));
+    return 0;
   }
   if (it + 1 < h->svi_maxit) CK(svi_globals(h, h->svi_vi_cur ^ 1, it + 1));
   CK(svi_refresh_emission(h, it, it & 1, h->svi_flags ? (hipEvent_t) nullptr : h->svi_ev[2 * it + 1], it + 1 < h->svi_maxit));

@@ -48,7 +48,11 @@ bool f32_wide_ok(const svihmm_ctx* h, int64_t n) {
          h->variant[5] != 3 && h->variant[10] != 2 && (n >= cu_scaled(h, 32768) || h->variant[10] == 3) &&
          stats_bf16w_shape_ok(h, n);
 }
-int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out) {
+// the step may ride in the theta builder's launch: NIW family, the split builder's widths, plain fp64 / fp32 records alike
+bool step_theta_ok(const svihmm_ctx* h, int K, int D) {
+  return D > 16 && D <= 32 && h->variant[13] != 2 && h->variant[13] != 3 && !(h->prec == 1 && emd_shape_ok(K, D) && !h->svi_active);
+}
+int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out, const SviStepArgs* step) {
   CK(upload_feature_table(h, D, K));
   const int Fp = h->Fp, Kp = h->Kp;
   const size_t nmu = (size_t)K * D, nsg = (size_t)K * D * D;
@@ -96,9 +100,21 @@ int launch_niw_to_theta(svihmm_ctx* h, int K, int D, double* logdet_out) {
 #define NIWW(DM) hipLaunchKernelGGL(k_niw_to_theta_wave<DM>, dim3(K), dim3(64), 0, h->stream, (const double*)dmu, \
                                     (const double*)dsg, (const double*)dka, (const double*)dnu, K, D, Kp,   \
                                     (double*)h->theta.p, dstatus, orbp, logdet_out, uwp, h->theta_sy)
-    if (emd) NIWW(64);
+    if (step && !emd && step_theta_ok(h, K, D)) {
+      const unsigned ntr = (unsigned)((K * K + 63) / 64);
+      hipLaunchKernelGGL(k_svi_step_theta32s, dim3((unsigned)K + ntr), dim3(64), 0, h->stream, step->packed, step->prior_tran,
+                         step->var_tran, (double*)dmu, step->prior, K, D, step->rho, step->bA, step->bE, step->nwin,
+                         step->lb_keep, step->ada_G, step->sy, Kp, (double*)h->theta.p, dstatus, orbp, logdet_out, uwp,
+                         h->theta_sy);
+    }
+    else if (step) return fail("internal: step_theta_ok and launch_niw_to_theta disagree");
+    else if (emd) NIWW(64);
     else if (D <= 8) NIWW(8);
     else if (D <= 16) NIWW(16);
+    else if (D > 16 && D <= 32 && h->variant[13] != 2)     // (both halves of the wave at work: round 6; variant 13 = 2: the older builder)
+      hipLaunchKernelGGL(k_niw_to_theta_wave32s, dim3(K), dim3(64), 0, h->stream, (const double*)dmu, (const double*)dsg,
+                         (const double*)dka, (const double*)dnu, K, D, Kp, (double*)h->theta.p, dstatus, orbp, logdet_out,
+                         uwp, h->theta_sy);
     else if (D <= 32) NIWW(32);
     else if (D <= 64) NIWW(64);
     else {

@@ -351,7 +351,7 @@ int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_t strea
   } while (0)
     // more 16-window workgroups than CUs: 32 windows per workgroup share the streamed transition
     // tile (variant[13] = 1: off)
-    const bool w32 = 2 * ((nb + 15) / 16) > 256 && h->variant[13] != 1;     // 256 CUs
+    const bool w32 = 2 * ((nb + 15) / 16) > h->ncu && h->variant[13] != 1;     // more workgroups than CUs
     // 128 < K <= 192: twelve waves of one state tile (three per SIMD; the eight two-tile waves would
     // run four empty tiles: 4.85 against 6.1 ms at K = 192, D = 32, T = 1e6).  variant[7] = 1: one
     // tile per wave for every K, 2: two tiles per wave for every K

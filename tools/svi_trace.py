@@ -10,7 +10,7 @@ rows = list(c.execute("select name, start, end, grid_x*grid_y*grid_z/(workgroup_
                       "from kernels order by start"))
 idx = [i for i, r in enumerate(rows) if "k_svi_elbo" in r[0]]
 # an iteration of the 64-window loop: contains a k_wave_lin4 launch
-sel = [(a, b) for a, b in zip(idx, idx[1:]) if any("k_wave_lin" in r[0] for r in rows[a:b])]
+sel = [(a, b) for a, b in zip(idx, idx[1:]) if any(("k_wave_lin" in r[0] or "k_sweep_stats" in r[0]) for r in rows[a:b])]
 # (bench.py runs several loops -- fp64, fp32 mode -- and other work in between: take the iteration of median
 #  SPAN among those that look like steady-state iterations, not the middle one of the list)
 sel = [ab for ab in sel if rows[ab[1]][2] - rows[ab[0]][2] < 2e6] or sel
