@@ -45,7 +45,9 @@ const char* svihmm_last_kernel_name(svihmm_ctx* h, int32_t slot);
  * | 2 sweeps (1 wave-per-window, 2 log-domain MFMA, 3 scaled linear-domain MFMA)
  * | 3 emission row tiles per wave | 4 E-step launch structure (0: sweeps + statistics of minibatch-sized K = 64 batches in one
  *      fused launch where that is ahead, else one launch after the other; 1: never fused; 2: the two-stream pipeline of
- *      round 2; 3: the fused launch for every batch it can take, whatever its size or precision mode)
+ *      round 2; 3: the fused launch for every batch it can take, whatever its size or precision mode, WITH the emission
+ *      tiles computed inside it where the batch's emission kernel is the 16-row fp64 one (D % 8 == 0, D <= 32) -- tests;
+ *      4: as 0; 5: as 0 plus the emission tiles inside the launch -- measured, not ahead: tu_fused.hip, sweep_emission_ok)
  * | 6 blocked scan for one long window (B = 1, Lm >= 2048, K <= 64; 1 = off)
  * | 9 automatic centring of the resident observations at upload (1 = off: c = 0)
  * | 12 barrier-free statistics GEMM with three LDS buffers (1 = off: the double-buffered kernel)
@@ -53,7 +55,9 @@ const char* svihmm_last_kernel_name(svihmm_ctx* h, int32_t slot);
  *      multi-rank path's coordinate round trip, exercised on a single GPU)
  * | 7 scaled sweeps' kernel family (K > 128: 1 one state tile per wave, 2 two tiles per wave for every K)
  * | 13 wide models' sweeps with 32 windows per workgroup (1 = off: 16); 2: NIW -> theta for 16 < D <= 32 by the builder that
- *      leaves half the wave idle (rounds 2-5) instead of k_niw_to_theta_wave32s -- same results bit for bit
+ *      leaves half the wave idle (rounds 2-5) instead of k_niw_to_theta_wave32s -- same results bit for bit; 3: the
+ *      split builder, but the resident loop's global step stays a launch of its own (k_svi_global_step, not merged
+ *      into k_svi_step_theta32s)
  * | 14 wide models' transition statistic in 128 x 64 blocks (1 = off: 64 x 64)
  * | 15 wide models' statistics GEMM forms q = ah bh scale itself (1 = off: separate posterior pass;
  *      2: a separate pass for every K -- valid results, slower)

@@ -221,7 +221,13 @@ struct svihmm_ctx {
   // fused sweep + statistics launch (tu_fused.hip): band counters with their running targets, cached readiness orders
   Buf pipe_cnt;
   unsigned pipe_tgt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  struct PipeTab { Buf buf; int Lq = -1, off = -1, Lm = -1, NS = -1; bool wrap = false; unsigned long long stamp = 0; };
+  struct PipeTab { Buf buf; int Lq = -1, off = -1, Lm = -1, NS = -1, B = -1, nst = -1; bool wrap = false; unsigned long long stamp = 0; };
+  unsigned em_tgt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // emission rounds inside the fused launch: counter targets (monotonic)
+  // An emission launch held back for the fused E-step kernel (launch_emission with em_defer_req set has done everything
+  // but the launch: buffers, theta orbit, the pending window starts); launch_emission_deferred sends it after all
+  bool em_defer_req = false;
+  struct EmDeferred { bool active = false; const int64_t* starts = nullptr; int64_t* starts_copy = nullptr; int nstarts = 0;
+                      int B = 0, Lm = 0; uint32_t flags = 0; double* out = nullptr; double* kexp = nullptr; double* ll0 = nullptr; } em_def;
   PipeTab pipe_tabs[8];
   unsigned long long pipe_stamp = 0;
   bool sweep_signalled = false;    // this E-step's sweep launch does
@@ -343,6 +349,8 @@ int svi_flush_elbo(svihmm_ctx* h);
 int ensure_starts_pulled(svihmm_ctx* h);
 int cat_uncentre(svihmm_ctx* h);
 int launch_fb_chain(svihmm_ctx* h, int Lm, bool total);
+int launch_emission_deferred(svihmm_ctx* h);
+bool sweep_emission_ok(const svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags);
 bool sweep_stats_ok(const svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags);
 int launch_sweep_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags);
 SviSync sweep_gate(svihmm_ctx* h, hipStream_t stream);

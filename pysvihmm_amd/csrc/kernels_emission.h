@@ -486,6 +486,7 @@ __global__ __launch_bounds__(256) void k_emission_orbit(
 #ifndef EMO_KO
 #define EMO_KO 0      // measurement knock-outs (tools/probe/emo_probe.hip): 1 no k-steps, 2 no theta loads, 4 no exp
 #endif
+#include "kernels_emission_ks.h"
 template <int NT>
 __global__ __launch_bounds__(256) void k_emission_orbit_ks(
     const double* __restrict__ obs, const uint8_t* __restrict__ mask,
@@ -493,195 +494,10 @@ __global__ __launch_bounds__(256) void k_emission_orbit_ks(
     const double* __restrict__ orb, uint32_t flags, double* __restrict__ ll,
     double* __restrict__ kexp, double* __restrict__ ll0,
     int64_t* __restrict__ starts_copy, int nstarts) {
-  constexpr int KP = 16 * NT;
   if (starts_copy && blockIdx.x == 0)       // (SVI loop: see k_emission_orbit)
     for (int i = threadIdx.x; i < nstarts; i += 256) starts_copy[i] = starts[i];
   extern __shared__ double smem[];
-  const int N = D + 1, c = D >> 2, nd = (D >> 1) + 1, nleft = (nd + 3) >> 2;
-  const int LEN = D + (D >> 1) + 1;                 // slots -1 .. 3D/2 - 1 (odd count)
-  // [0, R0) doubles: the rows (16 x LEN), later the partial sums (3 NT 256); then the small arrays
-  double* xs = smem;
-  double* red = smem;                               // [dest tile][source slot 0..2][r][lane]
-  const int R0 = 3 * NT * 256 > 16 * LEN + 1 ? 3 * NT * 256 : ((16 * LEN + 1) & ~1);
-  double* mxs = smem + R0;                          // [NT][16] per-tile row maxima
-  long long* rowoff = (long long*)(mxs + 16 * NT);
-  unsigned char* bad_s = (unsigned char*)(rowoff + 16);
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t g0 = (int64_t)blockIdx.x * 16;
-  if (tid < 16) {
-    const int r = tid;
-    const int64_t bw0 = g0 / Lm;
-    const unsigned t0 = (unsigned)(g0 - bw0 * Lm);
-    const bool valid = g0 + r < nrows;
-    const unsigned x = t0 + (unsigned)(valid ? r : 0);
-    const unsigned bwr = x / (unsigned)Lm;
-    const int64_t orow = starts[bw0 + bwr] + (x - bwr * (unsigned)Lm);
-    unsigned char bd = 0;
-    if (valid && (flags & SVIHMM_MASK_AS_NAN) && mask) bd = mask[orow] != 0;
-    rowoff[r] = valid ? orow * D : -1;
-    bad_s[r] = bd | ((valid && x == bwr * (unsigned)Lm) ? 2 : 0);   // bit 1: step 0 of its window
-    xs[r * LEN] = 1.0;
-    xs[r * LEN + D + 1] = 1.0;
-  }
-  __syncthreads();
-  {
-    const int sh = 32 - __builtin_clz((unsigned)(D - 1));
-    for (int e = tid; e < (16 << sh); e += 256) {
-      const int r = e >> sh, i = e & ((1 << sh) - 1);
-      const long long o = rowoff[r];
-      if (i < D) {
-        double v = o >= 0 ? obs[o + i] : 0.0;
-        if (v != v) { bad_s[r] |= 1; v = 0.0; }     // (every writer ORs the same bit)
-        xs[r * LEN + i + 1] = v;
-        if (i + N <= LEN - 2) xs[r * LEN + i + N + 1] = v;
-      }
-    }
-  }
-  __syncthreads();
-
-  const int li = lane & 15, lg = lane >> 4;
-  double4_t acc[NT];
-#pragma unroll
-  for (int n = 0; n < NT; ++n) acc[n] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  const double* rowp = xs + li * LEN + 1;                      // slot 0 of this lane's row
-  const double* pa0 = rowp + c * lg;
-  const double* p2 = rowp + lg - 1;
-  const double xl = rowp[N - 1];
-  const double* tl = orb + (unsigned)(lg * KP + li * NT);      // lane part of the theta address
-  // this wave's k-steps: [s0, s1) of the schedule's nmain = c nd orbit steps followed by nleft leftover steps
-  const int nmain = c * nd, S = nmain + nleft;
-#if EMO_KO & 1
-  const int s0 = 0, s1 = 0;
-#else
-  const int s0 = (S * wave) >> 2, s1 = (S * (wave + 1)) >> 2;
-#endif
-  auto loadB = [&](int s, double (&Bv)[NT]) {
-    const double* trow = tl + (size_t)(s < S ? s : S - 1) * (4 * KP);
-#if EMO_KO & 2
-#pragma unroll
-    for (int n = 0; n < NT; ++n) Bv[n] = (double)(s + n) * 1e-3;
-    (void)trow;
-#else
-    if constexpr (NT % 2 == 0) {
-#pragma unroll
-      for (int n = 0; n < NT; n += 2) {
-        const double2 t = *reinterpret_cast<const double2*>(trow + n);
-        Bv[n] = t.x; Bv[n + 1] = t.y;
-      }
-    } else {
-#pragma unroll
-      for (int n = 0; n < NT; ++n) Bv[n] = trow[n];
-    }
-#endif
-  };
-  int sd = s0 / c, sa = s0 - sd * c;                 // (delta, a0) of the next main step
-  // blocks of four k-steps: the block's eight LDS operands first, then its 4 NT MFMAs; the B operands of block
-  // i + 1 are requested before the MFMAs of block i (two register sets, loop unrolled by two blocks)
-  auto block = [&](int s, const double (&Bv)[4][NT]) {
-    double xa[4], xb[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (s + u < nmain) {
-        xa[u] = pa0[sa]; xb[u] = pa0[sa + sd];
-        if (++sa == c) { sa = 0; ++sd; }
-      } else {
-        const int jl = s + u - nmain < nleft ? s + u - nmain : nleft - 1;
-        xa[u] = xl; xb[u] = p2[4 * jl];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const double A = (s + u < s1) ? xa[u] * xb[u] : 0.0;        // (past the wave's range: adds B x 0)
-#pragma unroll
-      for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(A, Bv[u][n], acc[n], 0, 0, 0);
-    }
-  };
-  auto loadblk = [&](int s, double (&Bv)[4][NT]) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) loadB(s + u, Bv[u]);
-  };
-  {
-    double B0[4][NT], B1[4][NT];
-    loadblk(s0, B0);
-    for (int s = s0; s < s1; s += 8) {
-      loadblk(s + 4, B1);
-      block(s, B0);
-      loadblk(s + 8, B0);
-      if (s + 4 < s1) block(s + 4, B1);
-    }
-  }
-  // partial sums: wave w keeps state tile w and leaves the other tiles for their owners
-  __syncthreads();                                   // (the rows are no longer needed: red overlays xs)
-#pragma unroll
-  for (int n = 0; n < NT; ++n)
-    if (n != wave) {
-      const int slot = wave < n ? wave : wave - 1;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red[((n * 3 + slot) * 4 + r) * 64 + lane] = acc[n][r];
-    }
-  __syncthreads();
-  double own[4] = {0.0, 0.0, 0.0, 0.0};
-  if (wave < NT) {
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-      if (n == wave) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) own[r] = acc[n][r];
-      }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      double sum = 0.0;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {                  // source waves in index order
-        const int slot = w < wave ? w : w - 1;
-        const double pv = (w == wave) ? own[r] : red[((wave * 3 + slot) * 4 + r) * 64 + lane];
-        sum = (w == 0) ? pv : sum + pv;
-      }
-      own[r] = sum;
-    }
-  }
-  // epilogue: emission_scaled_epilogue with the row maximum taken over the workgroup's waves
-  ExpConsts ek;
-  exp_consts_init(ek);
-  double big = 1.7976931348623157e308, l2e = 1.4426950408889634074;
-  asm volatile("" : "+v"(big));
-  asm volatile("" : "+v"(l2e));
-  const int k = wave * 16 + li;
-  const int st32 = (flags >> 16) & 1;
-  double v[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int rl = lg + 4 * r;
-    const bool bdr = (bad_s[rl] & 1) != 0;
-    double x = own[r];
-    x = fmax_raw(-big, x);
-    x = -fmax_raw(-big, -x);
-    x = (own[r] != own[r] || bdr) ? 0.0 : x;
-    v[r] = (wave < NT && k < K) ? x : -INFINITY;
-    const double mx = row16_max(v[r]);
-    if (li == 0 && wave < NT) mxs[wave * 16 + rl] = mx;
-  }
-  __syncthreads();
-  if (wave >= NT) return;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int rl = lg + 4 * r;
-    const int64_t g = g0 + rl;
-    double mx = mxs[rl];
-#pragma unroll
-    for (int w = 1; w < NT; ++w) mx = fmax_raw(mx, mxs[w * 16 + rl]);
-    const double kx = (mx > -1e300 && mx < 1e300) ? ceil(mx * l2e) : 0.0;
-#if EMO_KO & 4
-    const double e = v[r] - kx;
-#else
-    const double e = fast_exp_k(fma(kx, ek.c[13], fma(kx, ek.c[12], v[r])), ek);
-#endif
-    if (g < nrows && k < K) {
-      if (st32) reinterpret_cast<float*>(ll)[g * K + k] = (float)e; else ll[g * K + k] = e;
-    }
-    if (wave == 0 && li == 0 && g < nrows) kexp[g] = kx;
-    if (ll0 && (bad_s[rl] & 2) && g < nrows && k < K) ll0[(g / Lm) * K + k] = v[r];
-  }
+  emission_orbit_ks_body<NT, false>(smem, obs, mask, starts, nrows, Lm, D, K, orb, flags, ll, kexp, ll0, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------

@@ -33,8 +33,10 @@
 #pragma once
 #include "kernels_stats_layout.h"
 #include "kernels_wave_linr.h"
+#include "kernels_emission_ks.h"
 
 #define PIPE_MAX_STAGES WLR_MAX_BANDS
+#define PIPE_AS1(T) __attribute__((address_space(1))) T*
 struct PipePlan {
   int nsw;                          // sweep workgroups (wpb windows of one direction each)
   int wpb;                          // active sweep waves per workgroup (4)
@@ -44,8 +46,12 @@ struct PipePlan {
   int NS, Lb;                       // stages per chunk = readiness bands; rows of a window per band
   unsigned tgt[PIPE_MAX_STAGES];    // band counter value that says "all 2 B sweeps are past this band"
   const int* ord;                   // [len]: inner row of readiness order o (host table: stable sort by need)
+  // emission inside the launch (EMW instantiation): the 16-row tiles of the batch in outside-in priority order; statistics
+  // workgroup sb computes tiles em_tiles[r nst + sb], r = 0 .. em_nround - 1, and adds one to the round's counter after each
+  const int* em_tiles;
+  int em_ntile, em_nround;
+  int64_t* starts_copy;             // SVI loop: the window starts are read from the pinned slot; the device copy is left here
   WlrPub pub;
-  const WlrPub* pubg;               // the same record in global memory (the sweep role is a function: it cannot read kernel arguments)
   unsigned long long* dbg;          // measurement only (SVIHMM_PIPE_DBG): wall-clock stamps, nullptr in normal runs --
                                     // [workgroup][16]: sweep workgroups (wave 0) begin / end; statistics workgroups begin,
                                     // then per stage the gate's opening and the end of its k-steps
@@ -77,7 +83,8 @@ __device__ __forceinline__ void pipe_stats_body(
     double* __restrict__ smem, const double* __restrict__ obs, const uint8_t* __restrict__ mask,
     const int64_t* __restrict__ starts, int B, int Lm, int Lq, int off, int D, int K, int Fp, int F,
     const int* __restrict__ fab, const ST* __restrict__ ah, const ST* __restrict__ bh, uint32_t flags,
-    double* __restrict__ part, double* __restrict__ lbpart, const PipePlan& pl, const int chunk, const int fg) {
+    double* __restrict__ part, double* __restrict__ lbpart, const PipePlan& pl, const int* __restrict__ ord,
+    const unsigned* bcnt, PIPE_AS1(unsigned long long) dbg0, const int chunk, const int fg) {
   const bool lb_here = fg == 0 && lbpart != nullptr;
   constexpr int MT = 5, NTW = 4, Kp = 64, QS = ST_QS(64), TPR = 8, QK = 8, CC = PIPE_CC1;
   const int ZERO = D + 1, ONE = ZERO + 1, QP0 = ZERO + 2;
@@ -98,14 +105,22 @@ __device__ __forceinline__ void pipe_stats_body(
   const int psr = ST_SLOT(sr & 3) + (sr >> 2);      // row slot of row sr = 4 ks + lg
   const int NS = pl.NS, Lb = pl.Lb;
 
-  // ---- row records of every stage, up front (nothing here depends on the sweeps): thread (s, r)
+  // ---- row records of every stage, up front (nothing here depends on the sweeps): thread (s, r).  The chunk's 32 rows per
+  //      stage lie in at most 33 windows, the same for every stage: their starts go through LDS (in the SVI loop `starts`
+  //      is the pinned slot the host wrote: one read per window, not one per row record, crosses the bus)
+  volatile int* lflag = reinterpret_cast<volatile int*>(rinfo + NS * 32);   // [s]: band s is open (written by thread 0)
+  double* lred = reinterpret_cast<double*>(const_cast<int*>(lflag) + PIPE_MAX_STAGES + 2);   // [4] per-wave sums of the local bound's terms
+  int64_t* wst = reinterpret_cast<int64_t*>(lred + 4);                       // [34]
+  const int w0 = (chunk * 32) / Lb;
+  if (tid < 34) wst[tid] = starts[w0 + tid < B ? w0 + tid : 0];
+  __syncthreads();
   for (int i = tid; i < 32 * NS; i += 256) {
     const int s = i >> 5, rr = i & 31;
     const int y = chunk * 32 + rr;
     const int w = y / Lb, oo = s * Lb + (y - w * Lb);
     const bool ok = w < B && oo < Lm;
-    const int t = ok ? pl.ord[oo] : 0;
-    const int64_t start = starts[ok ? w : 0];
+    const int t = ok ? ord[oo] : 0;
+    const int64_t start = wst[ok ? w - w0 : 0];
     const int64_t orow = start + off + t;
     const uint8_t m = (ok && mask) ? mask[orow] : (uint8_t)0;
     const int qrow = (ok ? w : 0) * Lq + off + t;
@@ -147,7 +162,8 @@ __device__ __forceinline__ void pipe_stats_body(
   const ST* __restrict__ athr = ah + sc;
   const ST* __restrict__ bthr = bh + sc;
 
-  unsigned long long* dbg = pl.dbg ? pl.dbg + (size_t)blockIdx.x * 32 : nullptr;
+  // (stamps through a pointer declared global: a FLAT store may alias LDS, and every LDS read behind one would wait for it)
+  PIPE_AS1(unsigned long long) dbg = dbg0 ? dbg0 + (size_t)blockIdx.x * 32 : nullptr;
   if (dbg && tid == 0) dbg[0] = wall_clock64();
   // ---- the stage loop, double-buffered.  Stage s = 8 k-steps (160 MFMAs per wave: 4.3 us of the fp64 matrix pipe) on the
   //      32 rows of band s in LDS buffer s & 1.  The rows of band s + 1 are requested as soon as that band is open --
@@ -157,14 +173,12 @@ __device__ __forceinline__ void pipe_stats_body(
   //      one barrier, next stage.  (Measured first with one buffer and gate -> loads -> commit -> k-steps in sequence:
   //      8.4 us per stage against bands 7.7 us apart -- the statistics fell further behind with every stage and ended
   //      20 us after the sweeps.)
-  volatile int* lflag = reinterpret_cast<volatile int*>(rinfo + NS * 32);   // [s]: band s is open (written by thread 0)
-  double* lred = reinterpret_cast<double*>(const_cast<int*>(lflag) + PIPE_MAX_STAGES + 2);   // [4] per-wave sums of the local bound's terms
   if (tid < PIPE_MAX_STAGES) lflag[tid] = 0;
   double rx[XK], va[QK], vb[QK], pa[QK], pb[QK];
   bool okx = false, okq = false, okp = false;
   double lbp = 0.0;
   auto band_open = [&](int s) {
-    return (int)(__hip_atomic_load(pl.pub.cnt + 16 * s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - pl.tgt[s]) >= 0;
+    return (int)(__hip_atomic_load(bcnt + 16 * s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - pl.tgt[s]) >= 0;
   };
   auto fetch = [&](int s) {
     // (no acquire fence: the sweeps store their rows with agent-scope atomic stores, these are the matching loads)
@@ -271,7 +285,7 @@ __device__ __forceinline__ void pipe_stats_body(
     const bool more = s + 1 < NS;
     bool issued = false;
     unsigned seen = 0;                                // thread 0: the band counter as last read (asynchronously)
-    const unsigned* cnt_next = pl.pub.cnt + 16 * (more ? s + 1 : s);
+    const unsigned* cnt_next = bcnt + 16 * (more ? s + 1 : s);
     const unsigned tgt_next = pl.tgt[more ? s + 1 : s];
     // ---- 8 k-steps on buffer s & 1, the LDS reads of k-step ks + 1 issued before the MFMAs of k-step ks
     {
@@ -351,7 +365,7 @@ inline size_t pipe_lds_bytes(int D, int NS) {
   // (statistics: tiles + row records + flag / reduction words; the sweep workgroups use no LDS since the row sums of
   //  the local bound moved to the statistics side)
   return 2 * ((size_t)(D + 3 + 64) * PIPE_CC1 + (size_t)ST_RB * ST_QS(64)) * 8 + (size_t)NS * 32 * sizeof(PipeRow) +
-         (PIPE_MAX_STAGES + 2) * sizeof(int) + 4 * sizeof(double) + 64;
+         (PIPE_MAX_STAGES + 2) * sizeof(int) + 4 * sizeof(double) + 34 * sizeof(int64_t) + 64;
 }
 
 // 256-thread workgroups: four waves, one per SIMD, each with the SIMD's whole register file (512).  Both roles are
@@ -361,17 +375,49 @@ inline size_t pipe_lds_bytes(int D, int NS) {
 // registers, the inlined roles spilled 100-400 registers).
 // The statistics role alone is a separate (non-inlined) function: inlined beside the sweep bodies the allocator sees the
 // union of all live ranges and spills 40-140 registers; as a function it gets its own allocation.  It finds the
-// workgroup's dynamic LDS itself (a pointer argument would make every LDS access a flat one).
+// workgroup's dynamic LDS itself (a pointer argument would make every LDS access a flat one), and its global pointers are
+// declared in the global address space (generic parameters made every load of the stage loop a flat one).
 template <int XK, typename ST>
 __device__ __attribute__((noinline)) void pipe_stats_role(
-    const double* __restrict__ obs, const uint8_t* __restrict__ mask, const int64_t* __restrict__ starts, int B, int Lm,
-    int Lq, int off, int D, int K, int Fp, int F, const int* __restrict__ fab, const ST* __restrict__ ah,
-    const ST* __restrict__ bh, uint32_t flags, double* __restrict__ part, double* __restrict__ lbpart, const PipePlan* pl,
-    int chunk, int fg) {
+    PIPE_AS1(const double) obs, PIPE_AS1(const uint8_t) mask, PIPE_AS1(const int64_t) starts, int B, int Lm,
+    int Lq, int off, int D, int K, int Fp, int F, PIPE_AS1(const int) fab, PIPE_AS1(const ST) ah,
+    PIPE_AS1(const ST) bh, uint32_t flags, PIPE_AS1(double) part, PIPE_AS1(double) lbpart, PIPE_AS1(const int) ord,
+    PIPE_AS1(const unsigned) bcnt, PIPE_AS1(unsigned long long) dbg, const PipePlan* pl, int chunk, int fg) {
   extern __shared__ double smem_role[];
-  pipe_stats_body<XK, ST>(smem_role, obs, mask, starts, B, Lm, Lq, off, D, K, Fp, F, fab, ah, bh, flags, part, lbpart, *pl, chunk, fg);
+  pipe_stats_body<XK, ST>(smem_role, (const double*)obs, (const uint8_t*)mask, (const int64_t*)starts, B, Lm, Lq, off, D, K, Fp, F,
+                          (const int*)fab, (const ST*)ah, (const ST*)bh, flags, (double*)part, (double*)lbpart, *pl, (const int*)ord,
+                          (const unsigned*)bcnt, dbg, chunk, fg);
 }
-template <int XK, typename ST>
+// The emission role of a statistics workgroup: k_emission_orbit_ks's tile (kernels_emission.h: the same arithmetic, bit for
+// bit) with its results stored coherently, one arrival per tile.  A function of its own for the same reason as the
+// statistics role; its pointer parameters are declared in the global address space, which gives the inlined body its global -- not flat -- accesses back.
+__device__ __attribute__((noinline)) void pipe_emission_role(
+    PIPE_AS1(const double) obs_, PIPE_AS1(const uint8_t) mask_, PIPE_AS1(const int64_t) starts_, int64_t nrows, int Lm,
+    int D, int K, PIPE_AS1(const double) orb_, uint32_t flags, PIPE_AS1(double) ll_, PIPE_AS1(double) kexp_,
+    PIPE_AS1(double) ll0_, PIPE_AS1(const int) tiles_, PIPE_AS1(unsigned) cnt_, PIPE_AS1(unsigned long long) dbg0,
+    const PipePlan* pl, int sb, int nst) {
+  extern __shared__ double smem_em[];
+  const double* __restrict__ obs = (const double*)obs_;
+  const uint8_t* __restrict__ mask = (const uint8_t*)mask_;
+  const int64_t* __restrict__ starts = (const int64_t*)starts_;
+  const double* __restrict__ orb = (const double*)orb_;
+  double* __restrict__ ll = (double*)ll_;
+  double* __restrict__ kexp = (double*)kexp_;
+  double* __restrict__ ll0 = (double*)ll0_;
+  const int* __restrict__ tiles = (const int*)tiles_;
+  unsigned* cnt = (unsigned*)cnt_;
+  PIPE_AS1(unsigned long long) dbg = dbg0 ? dbg0 + (size_t)blockIdx.x * 32 : nullptr;
+  if (dbg && threadIdx.x == 0) dbg[28] = wall_clock64();
+  if (sb == 0 && pl->starts_copy) {
+    PIPE_AS1(int64_t) sc = (PIPE_AS1(int64_t))pl->starts_copy;
+    const int B = (int)(nrows / Lm);
+    for (int i = threadIdx.x; i < B; i += 256) sc[i] = starts[i];
+  }
+  emission_orbit_ks_rounds<4>(smem_em, obs, mask, starts, nrows, Lm, D, K, orb, flags, ll, kexp, ll0, tiles, pl->em_ntile,
+                              pl->em_nround, nst, sb, cnt, dbg);
+  if (dbg && threadIdx.x == 0) dbg[29] = wall_clock64();
+}
+template <int XK, typename ST, bool EMW = false>
 __global__ __launch_bounds__(256) void k_sweep_stats(
     // sweeps (k_wave_linr's arguments)
     const ST* __restrict__ Eh, const double* __restrict__ kexp, const double* __restrict__ Aexp,
@@ -382,7 +428,9 @@ __global__ __launch_bounds__(256) void k_sweep_stats(
     // statistics
     const double* __restrict__ obs, const uint8_t* __restrict__ mask, const int64_t* __restrict__ starts, int B,
     int Lm, int off, int D, int Fp, int F, const int* __restrict__ fab, uint32_t flags, double* __restrict__ part,
-    PipePlan pl) {
+    PipePlan pl,
+    // emission (EMW only: Eh, kexp, ll0 above are then this launch's own products)
+    const double* __restrict__ orb, uint32_t eflags) {
   extern __shared__ double smem[];
   // Nobody else on this kernel's SIMDs: naming the last accumulation register makes the kernel's register block the whole
   // file (512 per lane), so no wave of another kernel fits beside a sweep or a statistics wave.  In the resident SVI loop
@@ -412,14 +460,26 @@ __global__ __launch_bounds__(256) void k_sweep_stats(
     }
     WlrRing<double>& ring = *reinterpret_cast<WlrRing<double>*>(smem);     // (not touched by the publishing variant of the body)
     if (pl.dbg && threadIdx.x == 0) pl.dbg[(size_t)bx * 32] = wall_clock64();
-    if (fwd) wave_linr_body<true, true, ST, double, true>(Eh, kexp, Aexp, mod_init, ll0, l0stride, Lq, K, ah, hx, local_lb, logz, zfac, ring, b, j, &pl.pub);
-    else wave_linr_body<false, true, ST, double, true>(Eh, kexp, AexpT, mod_init, ll0, l0stride, Lq, K, bh, gx, local_lb, logz, zfac, ring, b, j, &pl.pub);
+    if (fwd) wave_linr_body<true, true, ST, double, true, EMW>(Eh, kexp, Aexp, mod_init, ll0, l0stride, Lq, K, ah, hx, local_lb, logz, zfac, ring, b, j, &pl.pub);
+    else wave_linr_body<false, true, ST, double, true, EMW>(Eh, kexp, AexpT, mod_init, ll0, l0stride, Lq, K, bh, gx, local_lb, logz, zfac, ring, b, j, &pl.pub);
     if (pl.dbg && threadIdx.x == 0) pl.dbg[(size_t)bx * 32 + 1] = wall_clock64();
     return;
   }
   const int sb = bx - pl.nsw;
   if (pl.exp == 1) return;
   if (pl.exp == 2) { const unsigned long long t0 = wall_clock64(); while (wall_clock64() - t0 < 12000ull) __builtin_amdgcn_s_sleep(64); return; }
-  pipe_stats_role<XK, ST>(obs, mask, starts, B, Lm, Lq, off, D, K, Fp, F, fab, ah, bh, flags, part, local_lb + B, &pl,
-                          sb / pl.ngrp, sb % pl.ngrp);
+  if constexpr (EMW) {
+    if constexpr (sizeof(ST) == 8)
+      pipe_emission_role((PIPE_AS1(const double))obs, (PIPE_AS1(const uint8_t))mask, (PIPE_AS1(const int64_t))starts, (int64_t)B * Lq,
+                         Lq, D, K, (PIPE_AS1(const double))orb, eflags, (PIPE_AS1(double)) const_cast<double*>(reinterpret_cast<const double*>(Eh)),
+                         (PIPE_AS1(double)) const_cast<double*>(kexp), (PIPE_AS1(double)) const_cast<double*>(ll0),
+                         (PIPE_AS1(const int))pl.em_tiles, (PIPE_AS1(unsigned)) const_cast<unsigned*>(pl.pub.em_cnt),
+                         (PIPE_AS1(unsigned long long))pl.dbg, &pl, sb,
+                         pl.nchunk * pl.ngrp);
+    __syncthreads();                                 // (the roles share the workgroup's LDS)
+  }
+  pipe_stats_role<XK, ST>((PIPE_AS1(const double))obs, (PIPE_AS1(const uint8_t))mask, (PIPE_AS1(const int64_t))starts, B, Lm, Lq, off, D,
+                          K, Fp, F, (PIPE_AS1(const int))fab, (PIPE_AS1(const ST))ah, (PIPE_AS1(const ST))bh, flags,
+                          (PIPE_AS1(double))part, (PIPE_AS1(double))(local_lb + B), (PIPE_AS1(const int))pl.ord,
+                          (PIPE_AS1(const unsigned))pl.pub.cnt, (PIPE_AS1(unsigned long long))pl.dbg, &pl, sb / pl.ngrp, sb % pl.ngrp);
 }

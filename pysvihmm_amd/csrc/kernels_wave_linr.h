@@ -32,10 +32,13 @@ template <> struct LV<float> {
 // Initial message of a window, lane = state (K <= 64): lalpha_0 = mod_init + ll_0 combined in the
 // log domain (see k_lin_init), scaled by its own binary exponent H; returns a0[j], sets
 // h0 = H - k0 (k0: the emission exponent of the window's first row).
+// (COH: l0 was written by another workgroup of the SAME launch with agent-scope stores -- kernels_fused.h)
+template <bool COH = false>
 __device__ __forceinline__ double lin_init_lane(const double* __restrict__ mod_init,
                                                 const double* __restrict__ l0, int jc, bool valid,
                                                 double k0, double& h0) {
-  const double v = valid ? mod_init[jc] + l0[jc] : -INFINITY;
+  const double l0v = COH ? __hip_atomic_load(l0 + jc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : l0[jc];
+  const double v = valid ? mod_init[jc] + l0v : -INFINITY;
   const double m = wave_max(v);
   const double H = (m > -1e300 && m < 1e300) ? ceil(m * LOG2E_D) : 0.0;
   h0 = H - k0;
@@ -158,13 +161,23 @@ template <typename CT> struct WlrRing { CT v[64][65]; };      // [step & 63][sta
 // the wave has stored the row of sweep step thr[i] it adds one to counter i (agent-scope release in front: the rows
 // are visible to whoever sees the count).  Both directions use the same step thresholds.
 #define WLR_MAX_BANDS 12
+#ifndef PIPE_PD
+#define PIPE_PD 12
+#endif
 struct WlrPub {
   unsigned* cnt;                // counter of band i at cnt + 16 i (64 bytes apart)
   int nb;                       // bands
   int thr[WLR_MAX_BANDS];       // ascending sweep-step thresholds
   unsigned long long* dbgw;     // measurement only: per sweep workgroup 32 stamps (wave 0), nullptr in normal runs
+  // the other direction (EMW variant of the body): the emission rows are produced INSIDE the launch, by the statistics
+  // workgroups before their first band opens, in rounds of outside-in priority min(t, Lm - 1 - t); round i is complete
+  // when counter em_cnt + 16 i has reached em_tgt[i], and then every row of priority <= em_thr[i] is there
+  const unsigned* em_cnt;
+  int em_n;                     // rounds (0: the rows were written by an earlier launch)
+  int em_thr[WLR_MAX_BANDS];    // ascending; the last round's is INT_MAX
+  unsigned em_tgt[WLR_MAX_BANDS];
 };
-template <bool FWD, bool FULLK, typename ST, typename CT, bool PUB = false>
+template <bool FWD, bool FULLK, typename ST, typename CT, bool PUB = false, bool EMW = false>
 __device__ __forceinline__ void wave_linr_body(
     const ST* __restrict__ Eh, const double* __restrict__ kexp,
     const double* __restrict__ Am, const double* __restrict__ mod_init,
@@ -187,6 +200,37 @@ __device__ __forceinline__ void wave_linr_body(
     }
   };
   if constexpr (PUB) pub_next = pub->nb > 0 ? pub->thr[0] : 0x7fffffff;
+  // EMW: which emission rows are there.  em_lim = every row of priority <= em_lim is complete (rounds [0, em_r) seen).
+  // The sweep requests Eh rows 2 PD steps ahead of their use; the round counter is read asynchronously -- requested at
+  // the head of a block of PD steps, looked at behind it -- and only a sweep that has caught up with the emission
+  // rounds waits (bounded like every gate of the loop: a round that never completes must not hang the queue).
+  int em_r = 0, em_lim = EMW ? -1 : 0x7fffffff;
+  unsigned em_seen_v = 0;
+  auto em_wait = [&](int need) {
+    if constexpr (EMW) {
+      while (em_lim < need && em_r < pub->em_n) {
+        const unsigned tgt = pub->em_tgt[em_r];
+        const unsigned long long t0 = wall_clock64();
+        unsigned n = 0;
+        while ((int)(__builtin_amdgcn_readfirstlane(__hip_atomic_load(pub->em_cnt + 16 * em_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - tgt) < 0) {
+          __builtin_amdgcn_s_sleep(8);
+          if ((++n & 1023u) == 0u && wall_clock64() - t0 > SVI_SYNC_TICKS) break;
+        }
+        em_lim = __builtin_amdgcn_readfirstlane(pub->em_thr[em_r]);
+        ++em_r;
+      }
+    }
+  };
+  const int em_half = (Lm - 1) >> 1;              // the largest priority there is
+  auto em_need = [&](int srow) { return srow < em_half ? srow : em_half; };
+  auto eload = [&](const ST* p) -> CT {
+    if constexpr (EMW) return (CT)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return (CT)*p;
+  };
+  auto kload = [&](const double* p) -> double {
+    if constexpr (EMW) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+  };
   const int r = j >> 4, c = j & 15;
   const bool valid = FULLK || j < K;
   const int jc = valid ? j : 0;
@@ -212,16 +256,18 @@ __device__ __forceinline__ void wave_linr_body(
   long long hsum = 0;
   double lbacc = 0.0;
   CT pcur;
+  constexpr int PD = PUB ? PIPE_PD : 12;
+  em_wait(em_need(PD));                         // row 0 (ll0, kexp, Eh of the backward sweep) and the first PD rows
   {
     CT o;
     if (FWD) {
       double h0;
-      o = (CT)lin_init_lane(mod_init, ll0 + (size_t)b * l0stride, jc, valid, kexp[wrow], h0);
+      o = (CT)lin_init_lane<EMW>(mod_init, ll0 + (size_t)b * l0stride, jc, valid, kload(kexp + wrow), h0);
       h = __builtin_amdgcn_readfirstlane((int)h0);
       pcur = o;
       if constexpr (!PUB) ring.v[0][j] = o;
     } else {
-      const CT e0 = ep[jc];
+      const CT e0 = eload(ep + jc);
       o = valid ? (CT)1 : (CT)0;
       pcur = valid ? e0 : (CT)0;
     }
@@ -248,11 +294,7 @@ __device__ __forceinline__ void wave_linr_body(
   };
   // (rows of Eh requested ahead of their step: 12 where the wave has the SIMD's whole register file -- the stand-alone
   //  kernel --, 6 inside the fused kernel's 256-register budget, where 12 spilled into the step loop)
-#ifndef PIPE_PD
-#define PIPE_PD 12
-#endif
-  constexpr int PD = PUB ? PIPE_PD : 12;
-  auto eclamped = [&](int s) { return ep[(ptrdiff_t)(s < Lm ? s : Lm - 1) * dstep + jc]; };
+  auto eclamped = [&](int s) { return eload(ep + (ptrdiff_t)(s < Lm ? s : Lm - 1) * dstep + jc); };
   CT eq[PD];
 #pragma unroll
   for (int u = 0; u < PD; ++u) eq[u] = eclamped(1 + u);
@@ -324,7 +366,11 @@ __device__ __forceinline__ void wave_linr_body(
 #endif
   };
   int s = 1;
+  em_wait(em_need(2 * PD));                      // the first block requests rows PD + 1 .. 2 PD
   for (; s + PD <= Lm; s += PD) {
+    if constexpr (EMW) {
+      if (em_r < pub->em_n) em_seen_v = __hip_atomic_load(pub->em_cnt + 16 * em_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #pragma unroll
     for (int u = 0; u < PD; ++u) {
       const CT et = eq[u];
@@ -339,10 +385,19 @@ __device__ __forceinline__ void wave_linr_body(
     // step s - 2 here, ~PD steps (2 us) behind its real position, and never waits for its own stores: the bands open a
     // little later, the 257-step chain does not stall.  (The last rows are published after the drain below.)
     publish(s - 2);
+    if constexpr (EMW) {
+      if (em_r < pub->em_n) {
+        if ((int)(__builtin_amdgcn_readfirstlane(em_seen_v) - pub->em_tgt[em_r]) >= 0) { em_lim = __builtin_amdgcn_readfirstlane(pub->em_thr[em_r]); ++em_r; }
+        // (tried: the same test in front of every step's request instead of once per block -- 23 steps less lookahead; the
+        //  branch in the unrolled step loop cost the chain 0.53 us a step instead of 0.31)
+        em_wait(em_need(s + 3 * PD - 1));       // the next block requests rows up to (s + PD) + 2 PD - 1
+      }
+    }
   }
 #pragma unroll
   for (int u = 0; u < PD; ++u)
     if (s + u < Lm) step(s + u, eq[u]);
+  em_wait(em_half);                             // (short windows: the epilogue reads kexp of every row)
   if constexpr (PUB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   publish(0x7ffffffe);                          // (whatever is left: nobody may wait for a band the sweep never names)
   {
@@ -357,7 +412,7 @@ __device__ __forceinline__ void wave_linr_body(
   if (!FWD) return;
   double ks = 0.0, kk = 0.0;
   for (int t = j; t < Lm; t += 64) {
-    const double kv = kexp[wrow + t];
+    const double kv = kload(kexp + wrow + t);
     ks += kv;
     kk += kv * (double)(Lm - t);
   }

@@ -1195,8 +1195,15 @@ static int estep_core(svihmm_ctx* h, const int64_t* starts, int B, int Lm, int i
   if (use_pipeline(h, B, Lm, var, flags)) {
     CK(estep_pipelined(h, starts, B, Lm, inner_off, inner_len, flags));
   } else {
-    CK(prepare_ll(h, starts, B, Lm, flags, true, var == 3));
-    if (var == 3 && sweep_stats_ok(h, B, Lm, inner_off, inner_len, flags)) {
+    // (the fused launch below can compute the emission tiles itself: launch_emission then does everything but launch)
+    h->em_def.active = false;
+    h->em_defer_req = var == 3 && sweep_emission_ok(h, B, Lm, inner_off, inner_len, flags);
+    const int prc = prepare_ll(h, starts, B, Lm, flags, true, var == 3);
+    h->em_defer_req = false;
+    if (prc) { h->em_def.active = false; return prc; }
+    const bool fused = var == 3 && sweep_stats_ok(h, B, Lm, inner_off, inner_len, flags);
+    if (!fused) CK(launch_emission_deferred(h));
+    if (fused) {
       // minibatch-sized batches of the five-tile shapes: sweeps and statistics in one launch, the statistics'
       // stages behind the sweeps' published progress (tu_fused.hip)
       CK(wait_side_streams(h));

@@ -166,6 +166,27 @@ int launch_diag_to_theta(svihmm_ctx* h, int K, int D) {
   return 0;
 }
 
+// the emission launch launch_emission held back for the fused E-step kernel, sent as a launch of its own after all
+// (the batch did not take the fused kernel)
+int launch_emission_deferred(svihmm_ctx* h) {
+  if (!h->em_def.active) return 0;
+  const svihmm_ctx::EmDeferred d = h->em_def;
+  h->em_def.active = false;
+  const int D = h->D, K = h->K;
+  const int NT = 4, LEN = D + D / 2 + 1;
+  const int64_t n = (int64_t)d.B * d.Lm;
+  const int R0 = 3 * NT * 256 > 16 * LEN + 1 ? 3 * NT * 256 : ((16 * LEN + 1) & ~1);
+  const size_t lds = (size_t)(R0 + 16 * NT + 16) * 8 + 16;
+  const uint8_t* mk = h->have_mask ? (const uint8_t*)h->mask.p : nullptr;
+  ProfScope ps(h, KS_EMISSION, h->stream);
+  hipLaunchKernelGGL((k_emission_orbit_ks<4>), dim3((unsigned)((n + 15) / 16)), dim3(256), lds, h->stream,
+                     (const double*)h->obs.p, mk, d.starts, n, d.Lm, D, K, (const double*)h->theta_orb.p, d.flags, d.out,
+                     d.kexp, d.ll0, d.starts_copy, d.nstarts);
+  HIPCK(hipGetLastError());
+  return 0;
+}
+
+
 // scaled: write (Eh, kexp) for the linear-domain sweeps instead of ll (K <= 64 only).
 // starts_dev / out: window starts and destination (default: the handle's buffers).
 int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled,
@@ -330,6 +351,14 @@ int launch_emission(svihmm_ctx* h, int B, int Lm, uint32_t flags, bool scaled,
       const int R0 = 3 * NT * 256 > 16 * LEN + 1 ? 3 * NT * 256 : ((16 * LEN + 1) & ~1);
       const size_t lds = (size_t)(R0 + 16 * NT + 16) * 8 + 16;
       dim3 grid((unsigned)((n + 15) / 16));
+      if (h->em_defer_req && NT == 4 && stream == h->stream && out == (double*)h->ll.p && !(flags & SVIHMM_INT_ST32)) {
+        // the fused E-step kernel computes these tiles itself (tu_fused.hip); everything but the launch is done
+        h->em_def.active = true;
+        h->em_def.starts = starts_dev; h->em_def.starts_copy = pend ? (int64_t*)h->starts.p : nullptr; h->em_def.nstarts = pend_n;
+        h->em_def.B = B; h->em_def.Lm = Lm; h->em_def.flags = flags;
+        h->em_def.out = out; h->em_def.kexp = kexp_out; h->em_def.ll0 = ll0_out;
+        return 0;
+      }
 #define EMK(NTV) hipLaunchKernelGGL((k_emission_orbit_ks<NTV>), grid, dim3(256), lds, stream,                      \
                                     (const double*)h->obs.p, mk, starts_dev, n, Lm, D, K,                          \
                                     (const double*)h->theta_orb.p, flags, out, kexp_out, ll0_out,                  \

@@ -35,32 +35,62 @@ static int pipe_stages(const svihmm_ctx* h, int B, int Lm, int ngrp, int* nchunk
   return 0;
 }
 // Does this batch take the fused launch?  (prepare_ll has run: lin_mode / cur_f32 describe the batch in flight.)
-bool sweep_stats_ok(const svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags) {
+// the part of the test that does not depend on what prepare_ll decides for the batch
+static bool fused_shape_ok(const svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags, int* nst_out) {
   const int K = h->K;
   if (h->variant[4] == 1 || h->variant[1] != 0 || h->variant[2] == 1 || h->variant[2] == 2 || h->variant[7] != 0 ||
       h->variant[8] != 0 || h->variant[15] != 0)
     return false;
-  if ((flags & SVIHMM_USE_HOST_LLIKS) || h->emis_cat || h->emis_diag || !h->lin_mode || h->q_valid || h->eh_in_llE) return false;
+  if ((flags & SVIHMM_USE_HOST_LLIKS) || h->emis_cat || h->emis_diag) return false;
   if (K != 64 || h->Fp <= 0 || !five_tile_shape(h)) return false;      // (the sweep workgroups run the all-lanes-valid body)
-  // (measured, tools/r6_fused_check.py: from ~16 windows on the fused launch is ahead of sweeps + statistics one after the
-  //  other -- 169 against 178 us at 64 windows --, below that the statistics launch is too short to be worth hiding; the
-  //  fp32 mode keeps its own statistics kernel on the bf16 pipe (29 us: the fused fp64 stages end later than that);
-  //  variant 4 = 3 forces the fused launch for every batch it can take -- tests)
-  if (h->variant[4] != 3 && (B < 16 || h->cur_f32)) return false;
   if (B < 1 || B > lin_waver_max(h) || Lq > (1 << 20) || use_chain(h, B, Lq)) return false;
   if (off != 0 || Lm != Lq) return false;      // (the local bound covers the whole window: its log terms come from the statistics rows)
   if ((int64_t)B * Lq * K >= ((int64_t)1 << 31)) return false;
   if (pipe_lds_bytes(h->D, PIPE_MAX_STAGES) > 150 * 1024) return false;
   const int ngrp = ((h->Fp + 64) / 16 + 19) / 20;
   int nchunk = 0, Lb = 0;
-  return pipe_stages(h, B, Lm, ngrp, &nchunk, &Lb) > 0;
+  if (pipe_stages(h, B, Lm, ngrp, &nchunk, &Lb) <= 0) return false;
+  *nst_out = nchunk * ngrp;
+  return true;
+}
+bool sweep_stats_ok(const svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags) {
+  int nst = 0;
+  if (!fused_shape_ok(h, B, Lq, off, Lm, flags, &nst)) return false;
+  if (!h->lin_mode || h->q_valid || h->eh_in_llE) return false;
+  // (measured, tools/r6_fused_check.py: from ~16 windows on the fused launch is ahead of sweeps + statistics one after the
+  //  other -- 169 against 178 us at 64 windows --, below that the statistics launch is too short to be worth hiding; the
+  //  fp32 mode keeps its own statistics kernel on the bf16 pipe (29 us: the fused fp64 stages end later than that);
+  //  variant 4 = 3 forces the fused launch for every batch it can take -- tests)
+  if (h->variant[4] != 3 && (B < 16 || h->cur_f32)) return false;
+  return true;
+}
+// Will the fused launch of this batch also compute the emission tiles (asked BEFORE prepare_ll; launch_emission holds
+// its launch back only on the fp64 minibatch path whose tile the fused kernel carries)?
+// OFF unless asked for (variant 4 = 3: everything the kernel can take, tests; 5: the automatic thresholds + emission).
+// Measured at 64 windows (tools/r6_fused_trace.py, r6_fused_check.py, r4_svi_probe.py; profiles/r06g_*): the statistics
+// workgroups finish the 1028 tiles 46 - 55 us into the launch (first tile 15 us: 295 KB of theta operands per workgroup,
+// 61 MB through the L2s; then 8.5 us a tile against 3.9 us of matrix work -- one wave per SIMD hides nothing) and the
+// sweeps, gated round by round, end at 123 us: exactly where 39 us of emission kernel + 84 us of sweeps end.  E-step call
+// 170 against 168 us, resident loop 0.190 against 0.185 ms.  The stand-alone emission kernel turned out to be bound by
+// the same L2 traffic (every tile re-reads the 270 KB orbit: 277 MB in 39 us = 7.1 TB/s), not by latency.
+bool sweep_emission_ok(const svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags) {
+  int nst = 0;
+  if ((h->variant[4] != 3 && h->variant[4] != 5) || h->variant[5] != 0 || !fused_shape_ok(h, B, Lq, off, Lm, flags, &nst)) return false;
+  if (h->prec == 1 && h->f32_ok) return false;           // (fp32 mode: its own emission kernel on the bf16 pipe)
+  if (h->D > 32 || h->D % 8 != 0) return false;          // (the resident theta operands of the tile: <= 144 k-steps)
+  if (h->variant[4] != 3 && B < 16) return false;
+  const int64_t ntile = ((int64_t)B * Lq + 15) / 16;
+  return (ntile + nst - 1) / nst <= WLR_MAX_BANDS;
 }
 
 // readiness order of the inner rows of a window (cached per (Lq, off, Lm, wrap)): row t of the inner segment has both
 // messages -- its own and its predecessor's, which the transition statistic multiplies -- once both sweeps have done
 // need(t) = max over {t, pred(t)} of max(t_full, Lq - 1 - t_full) steps
-static int pipe_order(svihmm_ctx* h, int Lq, int off, int Lm, bool wrap, int NS, int Lb, WlrPub* pub, const int** ord_dev,
-                      const WlrPub** pub_dev) {
+// + the emission tiles of the batch (16 consecutive rows of the [B Lq] row space) in outside-in order: a tile's priority
+// is the smallest min(t, Lq - 1 - t) of its rows -- the sweep step at which the first of them is needed; rounds of nst
+// tiles; em_thr[r] = every row of priority <= em_thr[r] lies in a tile of rounds 0 .. r
+static int pipe_order(svihmm_ctx* h, int B, int nst, int Lq, int off, int Lm, bool wrap, int NS, int Lb, WlrPub* pub,
+                      const int** ord_dev, const int** tiles_dev, int* ntile_out, int* nround_out) {
   std::vector<int> need((size_t)Lm), idx((size_t)Lm);
   auto n1 = [&](int t) { const int tf = off + t; return std::max(tf, Lq - 1 - tf); };
   for (int t = 0; t < Lm; ++t) {
@@ -72,13 +102,32 @@ static int pipe_order(svihmm_ctx* h, int Lq, int off, int Lm, bool wrap, int NS,
   std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return need[a] < need[b]; });
   pub->nb = NS;
   for (int s = 0; s < NS; ++s) pub->thr[s] = need[idx[std::min((s + 1) * Lb, Lm) - 1]];
-  // cache of device tables: [order | publication record] per (Lq, off, Lm, wrap, NS); a table stays untouched while
+  const int64_t nrows = (int64_t)B * Lq;
+  const int ntile = (int)((nrows + 15) / 16), nround = (ntile + nst - 1) / nst;
+  std::vector<int> tprio((size_t)ntile), tidx((size_t)ntile);
+  for (int i = 0; i < ntile; ++i) {
+    int p = 0x7fffffff;
+    for (int64_t g = (int64_t)i * 16; g < std::min<int64_t>((int64_t)i * 16 + 16, nrows); ++g) {
+      const int t = (int)(g % Lq);
+      p = std::min(p, std::min(t, Lq - 1 - t));
+    }
+    tprio[i] = p; tidx[i] = i;
+  }
+  std::stable_sort(tidx.begin(), tidx.end(), [&](int a, int b) { return tprio[a] < tprio[b]; });
+  *ntile_out = ntile; *nround_out = nround;
+  pub->em_n = 0;
+  if (nround <= WLR_MAX_BANDS) {
+    pub->em_n = nround;
+    for (int r = 0; r < nround; ++r)
+      pub->em_thr[r] = (r + 1) * nst < ntile ? tprio[tidx[(size_t)(r + 1) * nst]] - 1 : 0x7fffffff;
+  }
+  // cache of device tables: [order | tiles] per (B, nst, Lq, off, Lm, wrap, NS); a table stays untouched while
   // launches that read it may be in flight
-  const size_t pub_off = ((size_t)Lm * sizeof(int) + 15) & ~(size_t)15;
+  const size_t til_off = ((size_t)Lm * sizeof(int) + 15) & ~(size_t)15;
   for (auto& e : h->pipe_tabs)
-    if (e.buf.p && e.Lq == Lq && e.off == off && e.Lm == Lm && e.wrap == wrap && e.NS == NS) {
+    if (e.buf.p && e.Lq == Lq && e.off == off && e.Lm == Lm && e.wrap == wrap && e.NS == NS && e.B == B && e.nst == nst) {
       e.stamp = ++h->pipe_stamp;
-      *ord_dev = (const int*)e.buf.p; *pub_dev = (const WlrPub*)((const char*)e.buf.p + pub_off);
+      *ord_dev = (const int*)e.buf.p; *tiles_dev = (const int*)((const char*)e.buf.p + til_off);
       return 0;
     }
   svihmm_ctx::PipeTab* slot = nullptr;
@@ -88,13 +137,14 @@ static int pipe_order(svihmm_ctx* h, int Lq, int off, int Lm, bool wrap, int NS,
     for (auto& e : h->pipe_tabs) if (e.stamp < slot->stamp) slot = &e;
     HIPCK(hipStreamSynchronize(h->stream));           // (the evicted table's readers are done)
   }
-  CK(ensure(slot->buf, pub_off + sizeof(WlrPub)));
-  std::vector<char> img(pub_off + sizeof(WlrPub), 0);
+  CK(ensure(slot->buf, til_off + (size_t)ntile * sizeof(int)));
+  std::vector<char> img(til_off + (size_t)ntile * sizeof(int), 0);
   std::memcpy(img.data(), idx.data(), (size_t)Lm * sizeof(int));
-  std::memcpy(img.data() + pub_off, pub, sizeof(WlrPub));
+  std::memcpy(img.data() + til_off, tidx.data(), (size_t)ntile * sizeof(int));
   HIPCK(hipMemcpy(slot->buf.p, img.data(), img.size(), hipMemcpyHostToDevice));
-  slot->Lq = Lq; slot->off = off; slot->Lm = Lm; slot->wrap = wrap; slot->NS = NS; slot->stamp = ++h->pipe_stamp;
-  *ord_dev = (const int*)slot->buf.p; *pub_dev = (const WlrPub*)((const char*)slot->buf.p + pub_off);
+  slot->Lq = Lq; slot->off = off; slot->Lm = Lm; slot->wrap = wrap; slot->NS = NS; slot->B = B; slot->nst = nst;
+  slot->stamp = ++h->pipe_stamp;
+  *ord_dev = (const int*)slot->buf.p; *tiles_dev = (const int*)((const char*)slot->buf.p + til_off);
   return 0;
 }
 
@@ -114,16 +164,34 @@ int launch_sweep_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t f
   CK(ensure(h->local_lb, (size_t)(B + pl.nchunk) * sizeof(double)));     // [B] exponent books per window | [nchunk] the chunks' log terms
   CK(ensure_stats(h, pl.nchunk));
   CK(ensure_starts_pulled(h));
-  if (!h->pipe_cnt.p) {
-    CK(ensure(h->pipe_cnt, PIPE_MAX_STAGES * 64));
-    HIPCK(hipMemset(h->pipe_cnt.p, 0, PIPE_MAX_STAGES * 64));
+  if (!h->pipe_cnt.p) {      // [band counters | emission round counters], 64 bytes apart
+    CK(ensure(h->pipe_cnt, 2 * PIPE_MAX_STAGES * 64));
+    HIPCK(hipMemset(h->pipe_cnt.p, 0, 2 * PIPE_MAX_STAGES * 64));
   }
   pl.pub.cnt = (unsigned*)h->pipe_cnt.p;
-  CK(pipe_order(h, Lq, off, Lm, (flags & SVIHMM_TRANS_WRAP) != 0, pl.NS, pl.Lb, &pl.pub, &pl.ord, &pl.pubg));
+  pl.pub.em_cnt = (const unsigned*)h->pipe_cnt.p + 16 * PIPE_MAX_STAGES;
+  const int nst = pl.nchunk * pl.ngrp;
+  CK(pipe_order(h, B, nst, Lq, off, Lm, (flags & SVIHMM_TRANS_WRAP) != 0, pl.NS, pl.Lb, &pl.pub, &pl.ord, &pl.em_tiles,
+                &pl.em_ntile, &pl.em_nround));
   for (int s = 0; s < pl.NS; ++s) {
     h->pipe_tgt[s] += 2u * (unsigned)B;            // (monotonic counters: compared by signed difference on the device)
     pl.tgt[s] = h->pipe_tgt[s];
   }
+  // the emission tiles inside this launch?  (launch_emission held its launch back: everything else is in place)
+  const svihmm_ctx::EmDeferred ed = h->em_def;
+  const bool emw = ed.active;
+  h->em_def.active = false;
+  if (emw) {
+    if (ed.B != B || ed.Lm != Lq || pl.pub.em_n <= 0 || h->cur_f32) return fail("internal: deferred emission does not match the fused launch");
+    for (int r = 0; r < pl.em_nround; ++r) {
+      h->em_tgt[r] += (unsigned)std::min(nst, pl.em_ntile - r * nst);
+      pl.pub.em_tgt[r] = h->em_tgt[r];
+    }
+    pl.starts_copy = ed.starts_copy;
+  } else {
+    pl.pub.em_n = 0; pl.em_nround = 0;
+  }
+  const int64_t* starts_arg = emw ? ed.starts : (const int64_t*)h->starts.p;
   if (std::getenv("SVIHMM_PIPE_DBG")) {     // measurement only (tools/r6_fused_trace.py)
     CK(ensure(h->scratch, (size_t)(pl.nsw + pl.nchunk * pl.ngrp) * 32 * 8));
     HIPCK(hipMemsetAsync(h->scratch.p, 0, (size_t)(pl.nsw + pl.nchunk * pl.ngrp) * 32 * 8, h->stream));
@@ -132,7 +200,11 @@ int launch_sweep_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t f
   }
   h->m_nb = 0;
   h->have_lb = true;
-  const size_t lds = std::max(pipe_lds_bytes(D, pl.NS), (size_t)84 * 1024);     // (> 80 KB: one workgroup per CU)
+  size_t lds = std::max(pipe_lds_bytes(D, pl.NS), (size_t)84 * 1024);     // (> 80 KB: one workgroup per CU)
+  {                           // (the emission tile's LDS: tu_emission.hip, k_emission_orbit_ks)
+    const int LEN = D + D / 2 + 1, R0 = 3 * 4 * 256 > 16 * LEN + 1 ? 3 * 4 * 256 : ((16 * LEN + 1) & ~1);
+    if (emw) lds = std::max(lds, (size_t)(R0 + 16 * 4) * 8 + (size_t)pl.em_nround * 16 * 9 + 64);    // (+ the tiles' row records)
+  }
   const SviSync gsy = sweep_gate(h, h->stream);
   const void* Ehv = h->ll.p;
   const double* kx = (const double*)h->kexp.p;
@@ -143,18 +215,19 @@ int launch_sweep_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t f
   const dim3 grid((unsigned)(pl.nsw + pl.nchunk * pl.ngrp));
   {
     ProfScope ps(h, KS_FB, h->stream);
-#define FZ(XKV, STT)                                                                                                     \
+#define FZ(XKV, STT, EMV)                                                                                                \
   do {                                                                                                                   \
-    h->last_kernel[KS_FB] = "k_sweep_stats<" #XKV ", " #STT ">";                                                         \
-    hipFuncSetAttribute((const void*)k_sweep_stats<XKV, STT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
-    hipLaunchKernelGGL((k_sweep_stats<XKV, STT>), grid, dim3(256), lds, h->stream, (const STT*)Ehv, kx,                  \
+    h->last_kernel[KS_FB] = "k_sweep_stats<" #XKV ", " #STT ", " #EMV ">";                                               \
+    hipFuncSetAttribute((const void*)k_sweep_stats<XKV, STT, EMV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((k_sweep_stats<XKV, STT, EMV>), grid, dim3(256), lds, h->stream, (const STT*)Ehv, kx,             \
                        (const double*)h->Aexp.p, (const double*)h->AexpT.p, mi, l0, (size_t)K, Lq, K, (STT*)h->la.p,     \
                        (STT*)h->lb.p, (double*)h->hx.p, (double*)h->gx.p, (double*)h->local_lb.p, (double*)h->logz.p,    \
-                       (double2*)h->zfac.p, gsy, (const double*)h->obs.p, mk, (const int64_t*)h->starts.p, B, Lm, off, D, \
-                       Fp, F, (const int*)h->fab.p, flags, (double*)h->part.p, pl);                                      \
+                       (double2*)h->zfac.p, gsy, (const double*)h->obs.p, mk, starts_arg, B, Lm, off, D,                 \
+                       Fp, F, (const int*)h->fab.p, flags, (double*)h->part.p, pl, (const double*)h->theta_orb.p,        \
+                       ed.flags);                                                                                        \
   } while (0)
-#define FZX(STT) do { if (xk <= 5) FZ(5, STT); else FZ(9, STT); } while (0)
-    if (h->cur_f32) FZX(float); else FZX(double);
+#define FZX(STT, EMV) do { if (xk <= 5) FZ(5, STT, EMV); else FZ(9, STT, EMV); } while (0)
+    if (h->cur_f32) FZX(float, false); else if (emw) FZX(double, true); else FZX(double, false);
 #undef FZX
 #undef FZ
     HIPCK(hipGetLastError());
@@ -171,7 +244,7 @@ int launch_sweep_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t f
       std::fprintf(f, "\n");
       for (unsigned i = 0; i < grid.x; ++i) {
         std::fprintf(f, "%u", i);
-        for (int k = 0; k < (i < (unsigned)pl.nsw ? 13 : 14 + 2 * pl.NS); ++k) { const unsigned long long v = st[(size_t)i * 32 + k]; std::fprintf(f, " %.2f", v ? (double)(v - t0) * 0.01 : -1.0); }
+        for (int k = 0; k < 32; ++k) { const unsigned long long v = st[(size_t)i * 32 + k]; std::fprintf(f, " %.2f", v ? (double)(v - t0) * 0.01 : -1.0); }
         std::fprintf(f, "\n");
       }
       std::fclose(f);

@@ -1,7 +1,9 @@
-"""The fused sweep + statistics launch (kernels_fused.h, round 6) against the C oracle and against the separate
-launches it replaces: every shape class it takes -- one window to a quarter of the device, windows of 3 to 300 rows
-(bands thinner than a stage, stages mostly padding), masks, no wrap-around, the fp32 storage format -- with the
-fused path forced (variant "pipeline" = 3) and switched off (= 1)."""
+"""The fused E-step launch (kernels_fused.h, round 6: sweeps + statistics, and the emission tiles where the batch's
+emission kernel is the 16-row minibatch one) against the C oracle and against the separate launches it replaces: every
+shape class it takes -- one window to a quarter of the device, windows of 3 to 300 rows (bands thinner than a stage,
+stages mostly padding, emission rounds of one tile), masks, no wrap-around, the fp32 storage format -- with the fused
+path forced (variant "pipeline" = 3), forced without the emission tiles (= 4 keeps the emission kernel; with < 16 windows
+that is the separate path) and switched off (= 1)."""
 import numpy as np
 import pytest
 
@@ -29,7 +31,7 @@ def test_fused_launch_vs_oracle_and_separate_launches(B, Lm, D, wrap):
         eng.set_globals(pb["mod_init"], pb["ltran"])
         eng.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
         res = {}
-        for mode in (1, 3):
+        for mode in (1, 3, 4, 3):
             eng.set_variant("pipeline", mode)
             res[mode] = eng.estep(starts, Lm, flags=flags).buf.copy()
             res[mode, "kernel"] = eng.last_kernel("forward_backward")
@@ -38,6 +40,14 @@ def test_fused_launch_vs_oracle_and_separate_launches(B, Lm, D, wrap):
         eng.close()
     assert "k_sweep_stats" in res[3, "kernel"], res[3, "kernel"]
     assert "k_sweep_stats" not in res[1, "kernel"]
+    # the emission tiles ride in the launch where the batch's emission kernel is the 16-row one and its theta operands
+    # fit a wave's registers (D % 8 == 0, D <= 32)
+    assert ("true>" in res[3, "kernel"]) == (D <= 32), res[3, "kernel"]
+    if B >= 16:
+        # same sweeps and statistics with the emission kernel as a launch of its own: the tile arithmetic is the same
+        # code, so the statistics agree bit for bit -- a row read before its tile was complete would show here
+        assert "k_sweep_stats" in res[4, "kernel"] and "false>" in res[4, "kernel"], res[4, "kernel"]
+        assert np.array_equal(res[3], res[4]), float(np.max(np.abs(res[3] - res[4])))
     ref = ref_c.estep_minibatch(pb["obs"], pb["mask"], starts, Lm, pb["mod_init"], pb["ltran"], pb["mu"], pb["sigma"],
                                 pb["kappa"], pb["nu"], flags=2 if wrap else 0)
     scale = np.maximum(np.abs(ref), 1e-9 * B * Lm)
@@ -85,7 +95,7 @@ def test_fused_launch_inside_the_resident_loop_matches_the_separate_launches():
     sg0 = np.tile(0.75 * np.cov(pb["obs"].T).reshape(D, D), (K, 1, 1))
     ka0, nu0 = np.full(K, 0.01), np.full(K, D + 2.0)
     res = []
-    for mode in (1, 3):
+    for mode in (1, 3, 4):
         eng = HipEngine(0)
         try:
             eng.set_variant("pipeline", mode)
@@ -101,3 +111,8 @@ def test_fused_launch_inside_the_resident_loop_matches_the_separate_launches():
     for n, a, b in zip(("var_tran", "var_init", "mu", "sigma", "kappa", "nu"), res[0][0], res[1][0]):
         np.testing.assert_allclose(a, b, rtol=1e-7, atol=1e-9, err_msg=n)
     np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-9)
+    # emission tiles inside the launch (3) or as the launch of their own (4): the same arithmetic, bit for bit -- in the
+    # loop the emission buffers are REUSED every iteration, so a stale row (last iteration's, from a cache) would show
+    for n, a, b in zip(("var_tran", "var_init", "mu", "sigma", "kappa", "nu"), res[1][0], res[2][0]):
+        assert np.array_equal(a, b), n
+    assert np.array_equal(res[1][1], res[2][1])

@@ -14,6 +14,8 @@ e = HipEngine(0)
 pb = bench_problem(e)
 LM, T = bench.LM, bench.T
 st = (np.arange(B, dtype=np.int64) * (T // B)) % (T - LM)
+if len(sys.argv) > 2:
+    e.set_variant("pipeline", int(sys.argv[2]))
 e.set_globals(pb["mod_init"], pb["ltran"]); e.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
 for _ in range(5):
     e.estep(st, LM, flags=L.TRANS_WRAP, read=False)
@@ -38,6 +40,13 @@ if sw.shape[1] >= 13:
 print("sweep workgroups: begin %.1f .. %.1f us, end %.1f .. %.1f us (fwd even / bwd odd: fwd end mean %.1f, bwd end mean %.1f)" % (
     sw[:, 0].min(), sw[:, 0].max(), sw[:, 1].min(), sw[:, 1].max(), sw[0::2, 1].mean(), sw[1::2, 1].mean()))
 stt = rows[nsw:]
+if stt.shape[1] >= 32 and stt[:, 29].max() > 0:
+    v = lambda c: stt[:, c][stt[:, c] > 0]
+    if stt[:, 23].max() > 0:
+        print("second tile of a workgroup, mean stamps: rows + previous stores retired %.2f | arrival of the previous tile sent %.2f | k-steps done %.2f | stores issued %.2f" % (
+            v(23).mean(), v(30).mean(), v(26).mean(), v(12).mean()))
+    print("emission role of the statistics workgroups: begin %.1f .. %.1f, first tile done %.1f .. %.1f (mean %.1f), second %.1f .. %.1f (mean %.1f), all rounds done %.1f .. %.1f (mean %.1f)" % (
+        v(28).min(), v(28).max(), v(30).min(), v(30).max(), v(30).mean(), v(31).min(), v(31).max(), v(31).mean(), v(29).min(), v(29).max(), v(29).mean()))
 print("statistics workgroups: begin %.1f .. %.1f" % (stt[:, 0].min(), stt[:, 0].max()))
 print("  band 0 open (first rows requested): %.1f .. %.1f (mean %.1f)" % (stt[:, 1].min(), stt[:, 1].max(), stt[:, 1].mean()))
 for s in range(NS):
