@@ -66,7 +66,6 @@ __device__ __forceinline__ void emission_orbit_ks_body(
   const double* rowp = xs + li * LEN + 1;                      // slot 0 of this lane's row
   const double* pa0 = rowp + c * lg;
   const double* p2 = rowp + lg - 1;
-  const double xl = rowp[N - 1];
   const double* tl = orb + (unsigned)(lg * KP + li * NT);      // lane part of the theta address
   // this wave's k-steps: [s0, s1) of the schedule's nmain = c nd orbit steps followed by nleft leftover steps
   const int nmain = c * nd, S = nmain + nleft;
@@ -96,18 +95,25 @@ __device__ __forceinline__ void emission_orbit_ks_body(
   };
   int sd = s0 / c, sa = s0 - sd * c;                 // (delta, a0) of the next main step
   // blocks of four k-steps: the block's eight LDS operands first, then its 4 NT MFMAs; the B operands of block
-  // i + 1 are requested before the MFMAs of block i (two register sets, loop unrolled by two blocks)
+  // i + 1 are requested before the MFMAs of block i (two register sets, loop unrolled by two blocks).
+  // Round 6: the two LDS operand addresses of a k-step are SELECTED (main step / leftover step), the (uniform) position
+  // in the feature schedule is stepped with scalar selects -- the branch per k-step this loop had cost a lone wave 7.1
+  // against 5.0 us for its 36 k-steps (kernels_fused.h's emission role, same loop) and here it shared the SIMD's issue
+  // port with three other waves' MFMAs.  Same operands, same order: bit-identical.
+  const double* pxl = rowp + (N - 1);
   auto block = [&](int s, const double (&Bv)[4][NT]) {
     double xa[4], xb[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      if (s + u < nmain) {
-        xa[u] = pa0[sa]; xb[u] = pa0[sa + sd];
-        if (++sa == c) { sa = 0; ++sd; }
-      } else {
-        const int jl = s + u - nmain < nleft ? s + u - nmain : nleft - 1;
-        xa[u] = xl; xb[u] = p2[4 * jl];
-      }
+      const bool mainstep = s + u < nmain;
+      int jl = s + u - nmain;
+      jl = jl < 0 ? 0 : (jl < nleft ? jl : nleft - 1);
+      const double* pa = mainstep ? pa0 + sa : pxl;
+      const double* pb = mainstep ? pa0 + sa + sd : p2 + 4 * jl;
+      xa[u] = *pa; xb[u] = *pb;
+      const bool wrap = sa + 1 == c;
+      sa = wrap ? 0 : sa + 1;
+      sd += wrap ? 1 : 0;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
