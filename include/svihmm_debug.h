@@ -7,6 +7,11 @@
  * binary IS the product binary; knobs that change what a call computes in a way that makes its results
  * invalid (skipped launches, knocked-out loads / stores) are compiled only with -DSVIHMM_MEASURE
  * (make -C pysvihmm_amd/csrc measure -> build_exp/libsvihmm_measure.so, never shipped).
+ *
+ * Versioning: SVIHMM_ABI_VERSION / svihmm_abi_version() cover include/svihmm.h ONLY (the symbols a caller of the
+ * product binds; 3 since the hooks below left that header in round 5).  This header is not a stable interface: it
+ * changes with the library build (round 6 added svihmm_svi_recoveries and variant codes 0 = 2 / 3, 4 = 3 / 5, 13 = 3),
+ * and its only users are the repository's own tests, bench.py and tools/, which travel with the library.
  */
 #ifndef SVIHMM_DEBUG_H
 #define SVIHMM_DEBUG_H

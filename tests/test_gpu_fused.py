@@ -116,3 +116,44 @@ def test_fused_launch_inside_the_resident_loop_matches_the_separate_launches():
     for n, a, b in zip(("var_tran", "var_init", "mu", "sigma", "kappa", "nu"), res[1][0], res[2][0]):
         assert np.array_equal(a, b), n
     assert np.array_equal(res[1][1], res[2][1])
+
+
+def test_fused_launch_on_random_shapes_vs_oracle():
+    """Fixed-seed sweep over what the fused launch's plan depends on: feature count (five-tile shapes of K = 64 and their
+    neighbours that fall back), windows from 1 to 150, window lengths from 3 rows (bands thinner than a stage) to 300,
+    masks, wrap-around on / off -- forced (variant 3: emission tiles inside where the shape allows) and automatic."""
+    from oracle import ref_c
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    rng = np.random.default_rng(20260930)
+    K, T = 64, 4000
+    taken = 0
+    for case in range(22):
+        D = int(rng.choice([25, 28, 31, 32, 33, 40, 48, 56, 64]))
+        Lm = int(rng.choice([3, 4, 9, 33, 64, 129, 257, 300]))
+        B = int(rng.choice([1, 2, 16, 17, 40, 64, 100, 150]))
+        B = max(1, min(B, 8000 // Lm))
+        wrap = bool(rng.integers(2))
+        miss = float(rng.choice([0.0, 0.1]))
+        mode = int(rng.choice([3, 3, 0]))
+        pb = _problem(K, D, T, seed=1000 + case, miss=miss)
+        starts = rng.integers(0, T - Lm + 1, size=B)
+        flags = L.TRANS_WRAP if wrap else 0
+        eng = HipEngine(0)
+        try:
+            eng.set_obs(pb["obs"], pb["mask"])
+            eng.set_globals(pb["mod_init"], pb["ltran"])
+            eng.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+            eng.set_variant("pipeline", mode)
+            out = eng.estep(starts, Lm, flags=flags).buf.copy()
+            kern = eng.last_kernel("forward_backward")
+            eng.set_variant("pipeline", 0)
+        finally:
+            eng.close()
+        taken += "k_sweep_stats" in kern
+        ref = ref_c.estep_minibatch(pb["obs"], pb["mask"], starts, Lm, pb["mod_init"], pb["ltran"], pb["mu"], pb["sigma"],
+                                    pb["kappa"], pb["nu"], flags=2 if wrap else 0)
+        scale = np.maximum(np.abs(ref), 1e-9 * B * Lm)
+        err = float(np.max(np.abs(out - ref) / scale))
+        assert err < 1e-6, (case, D, Lm, B, wrap, miss, mode, kern, err)
+    assert taken >= 8, taken       # (the sweep is about the fused launch: most shapes must have taken it)
