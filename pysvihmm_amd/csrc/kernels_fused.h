@@ -1,35 +1,50 @@
-// kernels_fused.h -- the minibatch E-step's sweeps and statistics as ONE launch (round 6; VERDICT r5 next #1a).
+// kernels_fused.h -- the minibatch E-step's sweeps and statistics as ONE launch (round 6; VERDICT r5 next #1a; DESIGN 4
+// "The S = 64 iteration").
 //
-// A minibatch of S = 64 windows keeps 128 sweep waves busy for 257 dependent steps (~76 us) while 7/8 of the chip
+// A minibatch of S = 64 windows keeps 128 sweep waves busy for 257 dependent steps (~80 us) while 7/8 of the chip
 // idles, and its statistics GEMM (~40 us, 206 one-per-CU workgroups) can only start when the sweeps are over -- it needs
 // alpha_t AND beta_t of a row.  But row t has both once the forward sweep has passed t and the backward sweep Lm - 1 - t:
 // the middle rows at HALF the sweep time, the rows next to a window's ends only at the very end.  This kernel puts both
-// kinds of workgroup into one grid:
+// kinds of workgroup into one grid of 256-thread workgroups (every wave has its SIMD's whole register file):
 //
 //   workgroups [0, nsw)            sweep workgroups: the four waves run k_wave_linr's body (kernels_wave_linr.h) for
-//                                  window 4 (b >> 1) + w in direction b & 1 (K = 64 only).  A sweep wave
-//                                  PUBLISHES its progress: when it has stored the row of step thr[i] it adds one to
-//                                  band counter i (agent-scope release);
-//   workgroups [nsw, nsw + nst)    statistics workgroups (chunk c, feature group g): the five-tile-per-wave fp64 MFMA
-//                                  GEMM of k_stats_mfma4 with its rows taken in READINESS ORDER: stage s of every chunk
-//                                  draws 32 rows from band s -- the rows of all windows whose order index (distance from
-//                                  the window's middle) lies in [s Lb, (s + 1) Lb) -- and starts when band counter s
+//                                  windows wpb (b >> 1) + w in direction b & 1 (K = 64 only; one direction per workgroup:
+//                                  the two unrolled step loops together do not fit a CU's instruction cache).  A sweep
+//                                  wave PUBLISHES its progress: once per block of 12 steps it adds one to the counter of
+//                                  every band whose threshold it has passed -- two steps behind its real position, so that
+//                                  the rows it names have retired through the wave's in-order memory counter: no fence;
+//   workgroups [nsw, nsw + nst)    statistics workgroups (chunk c, feature group g): four waves x five feature tiles x all
+//                                  four state tiles of the fp64 MFMA GEMM, rows taken in READINESS ORDER: stage s of every
+//                                  chunk draws 32 rows from band s -- the rows of its windows whose order index (distance
+//                                  from the window's middle) lies in [s Lb, (s + 1) Lb) -- and starts when band counter s
 //                                  shows that all 2 B sweeps have passed the band's threshold.
 //
-// All workgroups are resident at once (one per CU: the host launches the kernel only when nsw + nst fits the device,
-// with CUs to spare for the loop's side streams) and the sweep workgroups have the lower indices, so they are placed
-// first: a statistics workgroup never waits for a sweep that has no CU.  No cross-stream edge, no host round trip:
-// the pipelining lives inside one launch and works the same under a profiler that serialises kernels.
+// All workgroups are resident at once (one per CU: the host asks for > 80 KB of LDS and launches the kernel only when
+// nsw + nst fits the device with CUs to spare for the loop's side streams) and the sweep workgroups have the lower
+// indices, so they are placed first: a statistics workgroup never waits for a sweep that has no CU.  No cross-stream
+// edge, no host round trip: the pipelining lives inside one launch and works the same under a profiler that serialises
+// kernels.
+//
+// Coherence without fences: the sweeps store their rows with agent-scope atomic stores (written through), the statistics
+// read them with agent-scope atomic loads.  (Measured alternatives: an acquire fence in every statistics wave halved the
+// sweeps' speed, a release fence per band in the sweep costs 2 us of drained prefetch queue each.)
 //
 // Posteriors: the statistics kernels of rounds 1-5 formed q_t = ah_t bh_t 2^(hx + gx - zexp) / zmant with the window's
 // normaliser Z -- which the forward sweep only knows at its END.  Here every row normalises itself,
-// q_t[j] = ah_t[j] bh_t[j] / sum_j ah_t[j] bh_t[j]  (the sum IS Z for every t; the binary exponents cancel), a 16-lane
-// DPP sum per staged row.  Same quantity, rounded differently in the last place.
+// q_t[j] = ah_t[j] bh_t[j] / sum_j ah_t[j] bh_t[j]  (the sum IS Z for every t; the binary exponents cancel), a DPP sum
+// over the eight lanes that stage a row.  Same quantity, rounded differently in the last place.  The local bound's
+// sum_t log sum_j ah_t[j] is formed from the same staged rows (lbpart), which takes the row-sum ring and its flushes out
+// of the sweep's chain.
 //
-// Statistics stage = 32 rows x (40 tiles of 16 features) x 64 states, 80 MFMAs per wave: ~1.1 us of matrix pipe; the
-// readiness bands of a 257-row window are 7.7 us apart at five stages (0.3 us per sweep step), so a stage -- gate, 2 us
-// of loads, LDS, 8 k-steps -- is long done when the next band opens: no software pipelining across stages, one LDS
-// buffer, two barriers per stage.  What is left behind the sweeps is the last band's stage and the epilogue.
+// A statistics stage = 160 MFMAs per wave = 4.3 us of the fp64 matrix pipe at one wave per SIMD, 8.5 us with its loads and
+// LDS commits; the readiness bands of a 257-row window are 7.7 us apart at five stages.  The stages are double-buffered:
+// the rows of band s + 1 are requested as soon as its counter shows it open (looked at between k-steps), so the memory
+// latency runs beside the matrix work.  What is left behind the sweeps is the last band's stage and the epilogue.
+//
+// EMW instantiation (off by default, tu_fused.hip: sweep_emission_ok): the statistics workgroups first compute the batch's
+// emission tiles (kernels_emission_ks.h: emission_orbit_ks_rounds), in outside-in priority order and in rounds with one
+// arrival counter each; the sweeps then read Eh / kexp / ll0 coherently and take a round's gate before they request rows
+// of its priority levels.
 #pragma once
 #include "kernels_stats_layout.h"
 #include "kernels_wave_linr.h"
@@ -68,8 +83,8 @@ struct PipeRow {
 // Four waves (one per SIMD, 256-thread workgroups: every wave of the kernel may use the SIMD's whole register file --
 // the sweep body needs 274 registers, and under the 256 of a 512-thread workgroup it spilled into its step loop or lost
 // half its prefetch depth).  Wave mg owns MT = 5 feature tiles x all four state tiles (Kp = 64): 160 accumulator
-// registers, 160 MFMAs per stage on 14 LDS operand reads per k-step.  LDS: A tile rb[C][CC1] (column-major, one buffer:
-// CC1 = 33 row slots), q tile qs[32][80], row records of all stages.
+// registers, 160 MFMAs per stage on 14 LDS operand reads per k-step.  LDS: two buffers of { A tile rb[C][CC1]
+// (column-major, CC1 = 33 row slots), q tile qs[32][80] }, the row records of all stages, flags.
 #define PIPE_CC1 33
 // sum over the eight lanes that stage one row (quad_perm xor 1, xor 2, row_half_mirror)
 __device__ __forceinline__ double pipe_row8_sum(double v) {

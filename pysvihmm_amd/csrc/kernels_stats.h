@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256 * NSPLIT) void k_stats_mfma4(
   constexpr int Kp = 16 * NT;
   // q tile row stride: the k-rows lg = 0, 1 (and 2, 3) of a B-operand read are served in one LDS pass of 32 lanes
   // and must fall on different banks: 16 words apart modulo the 32 (ST_QS)
-  constexpr int QS = TRONLY ? ST_QS_TR(Kp, MT) : ST_QS(Kp);
+  constexpr int QS = TRONLY ? ST_QS_TR(Kp, MT) : (NB == 3 ? ST_QS3(Kp, XK) : ST_QS(Kp));
   constexpr int TPR = 8 * NSPLIT;          // staging threads per row (block / 32)
   constexpr int QK = Kp / TPR;             // q columns per staging thread (exact)
   static_assert(QK * TPR == Kp, "staging split");

@@ -27,3 +27,7 @@
 // three-buffer loop: their q tile keeps the Kp + 1 stride (161 KB; 172 KB with ST_QS)
 #define ST_QS_TR(KP, MT) ((MT) >= 2 ? (KP) + 1 : ST_QS(KP))
 
+// the barrier-free three-buffer loop at XK >= 5 (48 <= D: 131 columns at D = 64) has 161 KB of LDS with the Kp + 1 stride
+// and would not fit with ST_QS (172 KB) -- it would fall back to the double-buffered kernel: 20.9 instead of 19.2 ms on
+// configs[4] (measured, profiles/r06z_c5_kernel_stats.txt against r05j's).  Those shapes keep the old stride.
+#define ST_QS3(KP, XK) ((XK) >= 5 ? (KP) + 1 : ST_QS(KP))

@@ -211,7 +211,8 @@ int launch_stats_range(svihmm_ctx* h, int b0, int nb, int Lq, int off, int Lm, u
         dim3 grid((unsigned)nchunk, (mt_limit + 4 * MTs - 1) / (4 * MTs), big ? Kp / 64 : 1);
         // four state tiles, five feature tiles per wave, scaled sweeps (the K = 64 epoch shapes): the
         // barrier-free stage loop with three LDS buffers, where they fit (D <= 55)
-        const size_t lds3 = ((size_t)(D + 3 + KpW) * (3 * ST_CS + 2) + 3 * (size_t)ST_RB * ST_QS(KpW)) * 8 +
+        const int xk3 = xk <= 1 ? 1 : xk <= 3 ? 3 : xk <= 5 ? 5 : 9;      // (the XK instance ST3T picks below)
+        const size_t lds3 = ((size_t)(D + 3 + KpW) * (3 * ST_CS + 2) + 3 * (size_t)ST_RB * ST_QS3(KpW, xk3)) * 8 +
                             4 * ST_RB * sizeof(StRow4) + 16;
         const bool tb = NTt == 4 && MTs == 5 && lds3 <= 160 * 1024 && h->variant[12] != 1;
         if (tb) {
