@@ -238,6 +238,10 @@ __global__ __launch_bounds__(64 * NWV) void k_svi_globals(
     double* __restrict__ var_init, double* __restrict__ mod_init, SviSync sy) {
   // (skipped -- the loop is dead, its gate kernel gave up -- the iteration these globals are for is poisoned; the
   //  kernel still arrives so that nothing waits for it)
+  // (round 6: this kernel runs on a side stream BESIDE the emission GEMM of the main stream, whose waves share its
+  //  SIMDs, and the minibatch sweeps gate on it: the elimination's 64 dependent steps ended 2.7 us after the emission
+  //  kernel -- profiles/r06z_svi_iteration_trace.txt.  Its few waves take issue priority over their neighbours.)
+  __builtin_amdgcn_s_setprio(3);
   if (svi_gate(sy)) k_svi_globals_body<LDSW, NWV>(var_tran, K, work_g, ltran, Aexp, AexpT, var_init, mod_init);
   else svi_poison(sy);
   svi_arrive(sy);
@@ -383,14 +387,51 @@ __device__ __forceinline__ void k_svi_vlb_body(
     vlb[k] = p_avgengy + q_entropy;
   }
 }
+// Round 6: in the counter choreography the ELBO total (k_svi_elbo below) rides in this launch -- the workgroup that
+// arrives LAST on the side counter (its value then equals `at`) forms it.  Why: beside the fused sweep + statistics
+// launch, which fills 240 CUs for ~110 us, the 2 K one-wave workgroups of this kernel are handed to the shader engines
+// round-robin and those bound for an engine without a free CU wait for that launch to END; a second one-workgroup
+// kernel behind them (12-15 us of launch + a dependent-load chain) then ended AFTER the main stream's finalize, and the
+// next global step -- which may not overwrite the factors before these kernels have read them -- waited 2-3 us for it
+// every iteration (profiles/r06z_svi_iteration_trace.txt).  Same sums in the same order as k_svi_elbo_body.
+struct SviElboTail {
+  double* out;                 // nullptr: no total in this launch
+  const double* lb;
+  double prior_const;
+  unsigned at;                 // value of the arrival counter once every workgroup of the launch has arrived
+};
+__device__ __forceinline__ void svi_arrive_elbo(const SviSync& sy, bool go, const SviElboTail& et, int K,
+                                                const double* __restrict__ vlb, const double* __restrict__ rowterm) {
+  if (!sy.arrive) return;
+  __shared__ int last_s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned before = __hip_atomic_fetch_add(sy.arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (sy.stamp && before + 1u == sy.stamp_at) *sy.stamp = wall_clock64();
+    last_s = (et.out != nullptr && go && before + 1u == et.at) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!last_s || threadIdx.x >= 64) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // the other workgroups' terms (released by their arrivals)
+  const int lane = threadIdx.x;
+  double v = 0.0, d = 0.0;
+  for (int base = 0; base < K; base += 64) {               // k ascending, one add per term: k_svi_elbo_body's order
+    const double x = base + lane < K ? __hip_atomic_load(vlb + base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    const double y = base + lane < K ? __hip_atomic_load(rowterm + base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    const int n = K - base < 64 ? K - base : 64;
+    for (int j = 0; j < n; ++j) { v += __shfl(x, j, 64); d += __shfl(y, j, 64); }
+  }
+  if (lane == 0) *et.out = et.lb[0] + (d + et.prior_const) + v;
+}
 __global__ __launch_bounds__(64) void k_svi_vlb(
     const double* __restrict__ theta, const int* __restrict__ fab, int F, int D, int Kp,
     const double* __restrict__ niw, const double* __restrict__ logdet, const double* __restrict__ prior,
     const double* __restrict__ prior_logpart, double zsign, int K, double* __restrict__ vlb,
     const double* __restrict__ prior_tran, const double* __restrict__ var_tran,
-    double* __restrict__ rowterm, SviSync sy) {
-  if (svi_gate(sy)) k_svi_vlb_body(theta, fab, F, D, Kp, niw, logdet, prior, prior_logpart, zsign, K, vlb, prior_tran, var_tran, rowterm);
-  svi_arrive(sy);
+    double* __restrict__ rowterm, SviSync sy, SviElboTail et) {
+  const bool go = svi_gate(sy);
+  if (go) k_svi_vlb_body(theta, fab, F, D, Kp, niw, logdet, prior, prior_logpart, zsign, K, vlb, prior_tran, var_tran, rowterm);
+  svi_arrive_elbo(sy, go, et, K, vlb, rowterm);
 }
 
 // ------------------------------------------------------------------------------------
@@ -519,9 +560,10 @@ __device__ __forceinline__ void k_svi_vlb_simple_body(
 __global__ __launch_bounds__(64) void k_svi_vlb_simple(
     int fam, const double* __restrict__ blk, const double* __restrict__ prior, int K, int W,
     double* __restrict__ vlb, const double* __restrict__ prior_tran, const double* __restrict__ var_tran,
-    double* __restrict__ rowterm, SviSync sy) {
-  if (svi_gate(sy)) k_svi_vlb_simple_body(fam, blk, prior, K, W, vlb, prior_tran, var_tran, rowterm);
-  svi_arrive(sy);
+    double* __restrict__ rowterm, SviSync sy, SviElboTail et) {
+  const bool go = svi_gate(sy);
+  if (go) k_svi_vlb_simple_body(fam, blk, prior, K, W, vlb, prior_tran, var_tran, rowterm);
+  svi_arrive_elbo(sy, go, et, K, vlb, rowterm);
 }
 
 // E log theta[v][k] = psi(alpha[k][v]) - psi(sum_v alpha[k][v]): the Categorical lookup table

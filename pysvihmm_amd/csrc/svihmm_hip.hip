@@ -1467,7 +1467,7 @@ static int svi_launch_elbo(svihmm_ctx* h, int elbo_it, int lb_slot, bool behind_
     CK(svi_launch_gate(h, s2, 2, h->tgt_theta));
     if (behind_sweeps) CK(svi_launch_gate(h, s2, 4, h->tgt_early));
     vsy.arrive = svi_cnt(h, 3);
-    h->tgt_side += (unsigned)(2 * K) + (elbo_it >= 0 ? 1u : 0u);
+    h->tgt_side += (unsigned)(2 * K);       // (the ELBO total rides in the last-arriving workgroup: kernels_svi.h)
   } else {
     // (the iteration's end-of-iteration timing event doubles as the fork point of the ELBO kernels)
     hipEvent_t fork = after_theta ? after_theta : h->svi_ec;
@@ -1476,19 +1476,22 @@ static int svi_launch_elbo(svihmm_ctx* h, int elbo_it, int lb_slot, bool behind_
   }
   {
     ProfScope ps(h, KS_MISC, s2);
+    double* delbo = nullptr;
+    if (elbo_it >= 0) HIPCK(hipHostGetDevicePointer((void**)&delbo, h->svi_elbo, 0));
+    const bool tail = h->svi_flags && elbo_it >= 0;
+    const SviElboTail et = {tail ? delbo + elbo_it : (double*)nullptr, (const double*)svi_ptr(h, 8) + lb_slot,
+                            h->svi_prior_const, (unsigned)h->tgt_side};
     if (fam == 0)
       hipLaunchKernelGGL(k_svi_vlb, dim3(2 * K), dim3(64), 0, s2, (const double*)h->theta.p,
                          (const int*)h->fab.p, h->F, D, h->Kp, (const double*)h->niw.p,
                          (const double*)svi_ptr(h, 4), (const double*)h->svi_prior.p,
                          (const double*)svi_ptr(h, 5), h->svi_zsign, K, svi_ptr(h, 3),
-                         (const double*)svi_ptr(h, 1), (const double*)svi_ptr(h, 0), svi_ptr(h, 6), vsy);
+                         (const double*)svi_ptr(h, 1), (const double*)svi_ptr(h, 0), svi_ptr(h, 6), vsy, et);
     else
       hipLaunchKernelGGL(k_svi_vlb_simple, dim3(2 * K), dim3(64), 0, s2, fam, (const double*)h->niw.p,
                          (const double*)h->svi_prior.p, K, fam == 1 ? D : h->V, svi_ptr(h, 3),
-                         (const double*)svi_ptr(h, 1), (const double*)svi_ptr(h, 0), svi_ptr(h, 6), vsy);
-    if (elbo_it >= 0) {
-      double* delbo = nullptr;
-      HIPCK(hipHostGetDevicePointer((void**)&delbo, h->svi_elbo, 0));
+                         (const double*)svi_ptr(h, 1), (const double*)svi_ptr(h, 0), svi_ptr(h, 6), vsy, et);
+    if (elbo_it >= 0 && !tail) {      // (stream-event choreography: no arrival counter to tell the last workgroup by)
       hipLaunchKernelGGL(k_svi_elbo, dim3(1), dim3(64), 0, s2, K, (const double*)svi_ptr(h, 3),
                          (const double*)svi_ptr(h, 6), h->svi_prior_const, (const double*)svi_ptr(h, 8) + lb_slot,
                          delbo + elbo_it, vsy);

@@ -22,7 +22,15 @@ static bool five_tile_shape(const svihmm_ctx* h) {
 }
 // stages per chunk: the fewest (>= 3: something to hide; <= 12) with which sweep + statistics workgroups are all
 // resident at once and leave CUs for the loop's side-stream kernels; 0: does not fit
-static int pipe_wpb() { const char* e = std::getenv("SVIHMM_PIPE_WPB"); const int v = e ? std::atoi(e) : 4; return v >= 1 && v <= 4 ? v : 4; }
+// (measurement knobs, read once: SVIHMM_PIPE_WPB = active sweep waves per workgroup, SVIHMM_PIPE_EXP = PipePlan::exp)
+static int pipe_wpb() {
+  static const int v = [] { const char* e = std::getenv("SVIHMM_PIPE_WPB"); const int x = e ? std::atoi(e) : 4; return x >= 1 && x <= 4 ? x : 4; }();
+  return v;
+}
+static int pipe_exp() {
+  static const int v = [] { const char* e = std::getenv("SVIHMM_PIPE_EXP"); return e ? std::atoi(e) : 0; }();
+  return v;
+}
 static int pipe_stages(const svihmm_ctx* h, int B, int Lm, int ngrp, int* nchunk_out, int* Lb_out) {
   const int wpb = pipe_wpb();
   const int nsw = 2 * ((B + wpb - 1) / wpb);
@@ -155,7 +163,7 @@ int launch_sweep_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t f
   const int ngrp = ((Fp + 64) / 16 + 19) / 20;
   PipePlan pl = {};
   pl.wpb = pipe_wpb();
-  pl.exp = std::getenv("SVIHMM_PIPE_EXP") ? std::atoi(std::getenv("SVIHMM_PIPE_EXP")) : 0;
+  pl.exp = pipe_exp();
   pl.nsw = 2 * ((B + pl.wpb - 1) / pl.wpb);
   pl.ngrp = ngrp;
   pl.NS = pipe_stages(h, B, Lm, ngrp, &pl.nchunk, &pl.Lb);

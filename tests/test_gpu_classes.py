@@ -354,7 +354,7 @@ def _loop_run(mode, K, D, B, Lm, T=4000, nit=12, repush_at=None):
         eng.close()
 
 
-@pytest.mark.parametrize("K,D,B,Lm", [(64, 8, 9, 33), (20, 5, 210, 9)])
+@pytest.mark.parametrize("K,D,B,Lm", [(64, 8, 9, 33), (20, 5, 210, 9), (64, 32, 24, 65)])
 def test_svi_loop_switches_to_stream_events_mid_loop(K, D, B, Lm):
     """VERDICT r5 next #6a: a loop that started on device-side counters carries on with the stream-event
     choreography from an iteration boundary on (what a serialising tool attaching AFTER svihmm_svi_begin's probe
@@ -370,13 +370,16 @@ def test_svi_loop_switches_to_stream_events_mid_loop(K, D, B, Lm):
     assert np.all(np.isfinite(sw[1])) and np.all(sw[2] > 0) and np.all(sw[2] < 50), sw[2]
 
 
-def test_svi_loop_recovers_when_a_gate_gives_up():
+@pytest.mark.parametrize("K,D,B,Lm", [(64, 8, 9, 33), (64, 32, 24, 65)])
+def test_svi_loop_recovers_when_a_gate_gives_up(K, D, B, Lm):
     """VERDICT r5 next #6 / ADVICE r5 low 3: a device-side dependency that is never met (debug variant 0 = 3: the
     sweeps of iteration 3 wait for a count that does not come, bound 2 ms) must not cost maxit x 60 s nor the
     loop's state: the gate gives up after its bound, the loop goes dead on the device (later gates return at once,
     the poisoned iteration's global step and every later one do not run), the host finds the status word at its
-    next call, replays the lost iterations on stream events -- and the results are those of an undisturbed loop."""
-    K, D, B, Lm = 64, 8, 9, 33
+    next call, replays the lost iterations on stream events -- and the results are those of an undisturbed loop.
+    Second shape: the round-6 kernels of the S = 64 class -- the sweep workgroups of the fused sweep + statistics launch
+    take the gate (they poison the iteration and open every band for the statistics workgroups), the global step rides
+    in the theta builder's launch."""
     ref = _loop_run(0, K, D, B, Lm)
     rec = _loop_run(3, K, D, B, Lm)
     assert rec[3] == 1, "no recovery took place"

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Timeline of one device-resident SVI iteration from a rocprofv3 kernel trace (rocpd .db) of
-tools/svi_e2e.py: kernels between two consecutive k_svi_elbo launches of the 64-window loop."""
+tools/svi_e2e.py: kernels between two consecutive end-of-iteration markers of the 64-window loop (k_svi_elbo; since
+round 6 the ELBO total rides in k_svi_vlb's last workgroup when the loop runs on device-side counters: k_finalize then)."""
 import re
 import sqlite3
 import sys
@@ -9,6 +10,8 @@ c = sqlite3.connect(sys.argv[1])
 rows = list(c.execute("select name, start, end, grid_x*grid_y*grid_z/(workgroup_x*workgroup_y*workgroup_z) "
                       "from kernels order by start"))
 idx = [i for i, r in enumerate(rows) if "k_svi_elbo" in r[0]]
+if len(idx) < 8:
+    idx = [i for i, r in enumerate(rows) if r[0].startswith("k_finalize")]
 # an iteration of the 64-window loop: contains a k_wave_lin4 launch
 sel = [(a, b) for a, b in zip(idx, idx[1:]) if any(("k_wave_lin" in r[0] or "k_sweep_stats" in r[0]) for r in rows[a:b])]
 # (bench.py runs several loops -- fp64, fp32 mode -- and other work in between: take the iteration of median
