@@ -41,7 +41,7 @@ const char* svihmm_kernel_name(int32_t slot);
  * "k_stats_mfma4<5, 2, 2, 3, true, false, double, double, 3>"; "" when unknown): bench.py checks it against
  * the kernel name in the committed profile before it quotes that profile's duration. */
 const char* svihmm_last_kernel_name(svihmm_ctx* h, int32_t slot);
-/* Selects the kernel generation for A/B measurement (0 = default/best).
+/* Selects the kernel generation for A/B measurement (0 = default/best; which < 24).
  * which 0 the resident SVI loop's dependency mechanism (0: device-side counters where kernels of two streams run
  *      side by side, else stream events; 1: stream events; 2: counters, and the loop behaves as if the device stopped
  *      running kernels concurrently at iteration 3 -- exercises the mid-loop switch to stream events; 3: counters, one gate
@@ -63,6 +63,9 @@ const char* svihmm_last_kernel_name(svihmm_ctx* h, int32_t slot);
  *      leaves half the wave idle (rounds 2-5) instead of k_niw_to_theta_wave32s -- same results bit for bit; 3: the
  *      split builder, but the resident loop's global step stays a launch of its own (k_svi_global_step, not merged
  *      into k_svi_step_theta32s)
+ * | 16 the register-resident minibatch sweep (k_wave_linr, the sweep workgroups of k_sweep_stats) re-normalises its vector
+ *      every fourth step where the transition expectations lie inside a float's range (1 = off: every step; same
+ *      results bit for bit)
  * | 14 wide models' transition statistic in 128 x 64 blocks (1 = off: 64 x 64)
  * | 15 wide models' statistics GEMM forms q = ah bh scale itself (1 = off: separate posterior pass;
  *      2: a separate pass for every K -- valid results, slower)

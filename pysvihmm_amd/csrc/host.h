@@ -169,7 +169,7 @@ struct svihmm_ctx {
   // [2] sweeps (0 auto,1 wave,2 log-MFMA,3 scaled) [3] emission row tiles
   // [4] two-stream E-step pipeline (0 auto,1 off,2 on)
   // [8] row chunks of the statistics GEMM (0 = automatic)
-  int variant[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int variant[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   // second stream + events of the pipelined E-step (created on first use)
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_em[2] = {nullptr, nullptr}, ev_sw[2] = {nullptr, nullptr};

@@ -432,7 +432,7 @@ __device__ __attribute__((noinline)) void pipe_emission_role(
                               pl->em_nround, nst, sb, cnt, dbg);
   if (dbg && threadIdx.x == 0) dbg[29] = wall_clock64();
 }
-template <int XK, typename ST, bool EMW = false>
+template <int XK, typename ST, bool EMW = false, int RN = 1>
 __global__ __launch_bounds__(256) void k_sweep_stats(
     // sweeps (k_wave_linr's arguments)
     const ST* __restrict__ Eh, const double* __restrict__ kexp, const double* __restrict__ Aexp,
@@ -475,8 +475,8 @@ __global__ __launch_bounds__(256) void k_sweep_stats(
     }
     WlrRing<double>& ring = *reinterpret_cast<WlrRing<double>*>(smem);     // (not touched by the publishing variant of the body)
     if (pl.dbg && threadIdx.x == 0) pl.dbg[(size_t)bx * 32] = wall_clock64();
-    if (fwd) wave_linr_body<true, true, ST, double, true, EMW>(Eh, kexp, Aexp, mod_init, ll0, l0stride, Lq, K, ah, hx, local_lb, logz, zfac, ring, b, j, &pl.pub);
-    else wave_linr_body<false, true, ST, double, true, EMW>(Eh, kexp, AexpT, mod_init, ll0, l0stride, Lq, K, bh, gx, local_lb, logz, zfac, ring, b, j, &pl.pub);
+    if (fwd) wave_linr_body<true, true, ST, double, true, EMW, RN>(Eh, kexp, Aexp, mod_init, ll0, l0stride, Lq, K, ah, hx, local_lb, logz, zfac, ring, b, j, &pl.pub);
+    else wave_linr_body<false, true, ST, double, true, EMW, RN>(Eh, kexp, AexpT, mod_init, ll0, l0stride, Lq, K, bh, gx, local_lb, logz, zfac, ring, b, j, &pl.pub);
     if (pl.dbg && threadIdx.x == 0) pl.dbg[(size_t)bx * 32 + 1] = wall_clock64();
     return;
   }

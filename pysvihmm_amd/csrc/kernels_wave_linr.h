@@ -104,7 +104,7 @@ __device__ __forceinline__ void wlr_fma2(double& p0, double& p1, double& p2, dou
                                          double a01, double a11, double a21, double a31) {
 #define WLR_F(ACC, CO, NN) "v_fmac_f64_dpp %" #ACC ", %4, %" #CO " row_newbcast:%" #NN " row_mask:0xf bank_mask:0xf\n\t"
   if (FIRST)
-    asm volatile("s_nop 1\n\t" WLR_F(0, 5, 13) WLR_F(1, 6, 13) WLR_F(2, 7, 13) WLR_F(3, 8, 13)
+    asm volatile("s_nop 4\n\t" WLR_F(0, 5, 13) WLR_F(1, 6, 13) WLR_F(2, 7, 13) WLR_F(3, 8, 13)
                  WLR_F(0, 9, 14) WLR_F(1, 10, 14) WLR_F(2, 11, 14) WLR_F(3, 12, 14)
                  : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3)
                  : "v"(pc), "v"(a00), "v"(a10), "v"(a20), "v"(a30), "v"(a01), "v"(a11), "v"(a21), "v"(a31),
@@ -123,7 +123,7 @@ __device__ __forceinline__ void wlr_fma2(float& p0, float& p1, float& p2, float&
                                          float a01, float a11, float a21, float a31) {
 #define WLR_F(ACC, CO, NN) "v_fmac_f32_dpp %" #ACC ", %4, %" #CO " row_newbcast:%" #NN " row_mask:0xf bank_mask:0xf\n\t"
   if (FIRST)
-    asm volatile("s_nop 1\n\t" WLR_F(0, 5, 13) WLR_F(1, 6, 13) WLR_F(2, 7, 13) WLR_F(3, 8, 13)
+    asm volatile("s_nop 4\n\t" WLR_F(0, 5, 13) WLR_F(1, 6, 13) WLR_F(2, 7, 13) WLR_F(3, 8, 13)
                  WLR_F(0, 9, 14) WLR_F(1, 10, 14) WLR_F(2, 11, 14) WLR_F(3, 12, 14)
                  : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3)
                  : "v"(pc), "v"(a00), "v"(a10), "v"(a20), "v"(a30), "v"(a01), "v"(a11), "v"(a21), "v"(a31),
@@ -142,8 +142,21 @@ __device__ __forceinline__ void wlr_fma2(float& p0, float& p1, float& p2, float&
 // v_readlane of lane 63: eight instructions against ~26 for the fp64 wave sum whose exponent the other
 // sweep kernels use (any integer keeps the books exact; the vector only has to stay in range).  The
 // steps are separate asm statements: the caller places them between the groups of the mat-vec.
-__device__ __forceinline__ int wlr_expfield(double v) { return (__double2hiint(v) >> 20) & 0x7ff; }
-__device__ __forceinline__ int wlr_expfield(float v) { return (int)((__float_as_uint(v) >> 23) & 0xff); }
+// (asm volatile: the field is consumed by the DPP instructions of wlr_emax, which the compiler's hazard recogniser does
+//  not see inside inline asm -- a VALU write needs two wait states before a DPP read of the same register.  As plain
+//  C++ the extraction was free to sink right in front of the first v_max_i32_dpp (it did once the call became
+//  conditional: round 6, RN) and the reduction then read the register's previous contents.  As a volatile statement
+//  it stays where it is written: in front of the step's first group of eight FMAs.)
+__device__ __forceinline__ int wlr_expfield(double v) {
+  int e;
+  asm volatile("v_bfe_u32 %0, %1, 20, 11" : "=v"(e) : "v"(__double2hiint(v)));
+  return e;
+}
+__device__ __forceinline__ int wlr_expfield(float v) {
+  int e;
+  asm volatile("v_bfe_u32 %0, %1, 23, 8" : "=v"(e) : "v"(__float_as_uint(v)));
+  return e;
+}
 template <int STEP>
 __device__ __forceinline__ void wlr_emax(int& e) {
   if (STEP == 0) asm volatile("v_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(e));
@@ -177,7 +190,15 @@ struct WlrPub {
   int em_thr[WLR_MAX_BANDS];    // ascending; the last round's is INT_MAX
   unsigned em_tgt[WLR_MAX_BANDS];
 };
-template <bool FWD, bool FULLK, typename ST, typename CT, bool PUB = false, bool EMW = false>
+// RN (round 6): the vector is re-normalised every RN-th step only (RN divides 12).  The normalising exponent -- six DPP
+// max steps, a v_readlane, two v_ldexp and the books -- is ~18 of a step's ~115 instructions, and fp64 has the range to
+// go without it for a few steps when no transition expectation lies below SVIHMM_LTRAN_F32_MIN = -60 nats (the host's
+// f32_ok): a step shrinks the vector's largest entry by at most 2^-88 (the transition factor and the emission row's
+// maximum >= 1/2), the normalisation lags one step, so with RN = 4 a stored vector's largest entry stays above 2^-440
+// and the consumers' product ah bh above 2^-880 -- RN = 6 would not leave that product inside fp64.  Scaling by powers of
+// two is exact: the stored mantissas and every statistic are those of RN = 1 bit for bit; the local bound (a sum of
+// logarithms of the differently scaled sums + the exponent books) agrees to rounding.
+template <bool FWD, bool FULLK, typename ST, typename CT, bool PUB = false, bool EMW = false, int RN = 1>
 __device__ __forceinline__ void wave_linr_body(
     const ST* __restrict__ Eh, const double* __restrict__ kexp,
     const double* __restrict__ Am, const double* __restrict__ mod_init,
@@ -298,24 +319,25 @@ __device__ __forceinline__ void wave_linr_body(
   CT eq[PD];
 #pragma unroll
   for (int u = 0; u < PD; ++u) eq[u] = eclamped(1 + u);
-  auto step = [&](int s, CT et) {
+  static_assert(RN == 1 || RN == 2 || RN == 3 || RN == 4 || RN == 6 || RN == 12, "RN divides the unroll depth");
+  auto step = [&](int s, CT et, const bool rn) {      // rn: a compile-time constant after unrolling (see the loops)
     CT p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-    int ef = wlr_expfield(pcur);                // (the exponent comes from the ENTERING vector: off the chain)
+    int ef = rn ? wlr_expfield(pcur) : 0;       // (the exponent comes from the ENTERING vector: off the chain)
 #define WLR_G(N0, FI) wlr_fma2<N0, FI>(p0, p1, p2, p3, pcur, a[0][N0], a[1][N0], a[2][N0], a[3][N0], \
                                        a[0][N0 + 1], a[1][N0 + 1], a[2][N0 + 1], a[3][N0 + 1]);
     WLR_G(0, true)
 #if !(WLR_KO & 1)
-    wlr_emax<0>(ef);
+    if (rn) wlr_emax<0>(ef);
     WLR_G(2, false)
-    wlr_emax<1>(ef);
+    if (rn) wlr_emax<1>(ef);
     WLR_G(4, false)
-    wlr_emax<2>(ef);
+    if (rn) wlr_emax<2>(ef);
     WLR_G(6, false)
-    wlr_emax<3>(ef);
+    if (rn) wlr_emax<3>(ef);
     WLR_G(8, false)
-    wlr_emax<4>(ef);
+    if (rn) wlr_emax<4>(ef);
     WLR_G(10, false)
-    wlr_emax<5>(ef);
+    if (rn) wlr_emax<5>(ef);
     WLR_G(12, false)
     WLR_G(14, false)
 #else
@@ -325,16 +347,19 @@ __device__ __forceinline__ void wave_linr_body(
 #if WLR_KO & 2
     const int e2 = 0;
 #else
-    const int em = __builtin_amdgcn_readlane(ef, 63);
-    const int e2 = em ? em - WlrBias<CT>::v : 0;
+    int e2 = 0;
+    if (rn) {
+      const int em = __builtin_amdgcn_readlane(ef, 63);
+      e2 = em ? em - WlrBias<CT>::v : 0;
+    }
 #endif
     const CT q0 = swap_add32(p0, p2), q1 = swap_add32(p1, p3);
     const CT acc = swap_add16(q0, q1);
     if (FWD) hsum += h;
     CT o;
-    if (FWD) { o = LV<CT>::ldx(acc * et, -e2); if (!FULLK) o = valid ? o : (CT)0; pcur = o; }
-    else { o = LV<CT>::ldx(acc, -e2); if (!FULLK) o = valid ? o : (CT)0; pcur = et * o; }
-    h += e2;
+    if (FWD) { o = rn ? LV<CT>::ldx(acc * et, -e2) : acc * et; if (!FULLK) o = valid ? o : (CT)0; pcur = o; }
+    else { o = rn ? LV<CT>::ldx(acc, -e2) : acc; if (!FULLK) o = valid ? o : (CT)0; pcur = et * o; }
+    if (rn) h += e2;
     op += dstep;
 #if !(WLR_KO & 4)
     // (PUB: agent-scope atomic store = written through to where every CU of the device reads it coherently; "complete"
@@ -377,7 +402,7 @@ __device__ __forceinline__ void wave_linr_body(
 #if !(WLR_KO & 8)
       eq[u] = eclamped(s + u + PD);           // (uniform row arithmetic: scalar instructions)
 #endif
-      step(s + u, et);
+      step(s + u, et, RN == 1 || (1 + u) % RN == 0);      // (s = 1 mod 12: step s + u re-normalises iff RN | s + u)
     }
     // Progress, once per block of PD steps.  Which rows are complete?  Loads and stores of a wave retire through ONE
     // in-order counter: the last step of this block waited for the Eh row requested PD steps earlier, and everything
@@ -396,7 +421,7 @@ __device__ __forceinline__ void wave_linr_body(
   }
 #pragma unroll
   for (int u = 0; u < PD; ++u)
-    if (s + u < Lm) step(s + u, eq[u]);
+    if (s + u < Lm) step(s + u, eq[u], RN == 1 || (1 + u) % RN == 0);
   em_wait(em_half);                             // (short windows: the epilogue reads kexp of every row)
   if constexpr (PUB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   publish(0x7ffffffe);                          // (whatever is left: nobody may wait for a band the sweep never names)
@@ -429,7 +454,7 @@ __device__ __forceinline__ void wave_linr_body(
     zfac[b] = make_double2(1.0 / zm, hd + zexp);
   }
 }
-template <typename ST = double, typename CT = ST>
+template <typename ST = double, typename CT = ST, int RN = 1>
 __global__ __launch_bounds__(64) void k_wave_linr(
     const ST* __restrict__ Eh, const double* __restrict__ kexp,
     const double* __restrict__ Aexp, const double* __restrict__ AexpT,
@@ -441,11 +466,11 @@ __global__ __launch_bounds__(64) void k_wave_linr(
   __shared__ WlrRing<CT> ring;
   if (!svi_gate(sy)) { svi_poison(sy); return; }   // (SVI loop: the globals kernel of the side stream has arrived)
   if (blockIdx.y == 0) {
-    if (K == 64) wave_linr_body<true, true, ST, CT>(Eh, kexp, Aexp, mod_init, ll0, l0stride, Lm, K, ah, hx, local_lb, logz, zfac, ring, blockIdx.x, threadIdx.x);
-    else wave_linr_body<true, false, ST, CT>(Eh, kexp, Aexp, mod_init, ll0, l0stride, Lm, K, ah, hx, local_lb, logz, zfac, ring, blockIdx.x, threadIdx.x);
+    if (K == 64) wave_linr_body<true, true, ST, CT, false, false, RN>(Eh, kexp, Aexp, mod_init, ll0, l0stride, Lm, K, ah, hx, local_lb, logz, zfac, ring, blockIdx.x, threadIdx.x);
+    else wave_linr_body<true, false, ST, CT, false, false, RN>(Eh, kexp, Aexp, mod_init, ll0, l0stride, Lm, K, ah, hx, local_lb, logz, zfac, ring, blockIdx.x, threadIdx.x);
   } else {
-    if (K == 64) wave_linr_body<false, true, ST, CT>(Eh, kexp, AexpT, mod_init, ll0, l0stride, Lm, K, bh, gx, local_lb, logz, zfac, ring, blockIdx.x, threadIdx.x);
-    else wave_linr_body<false, false, ST, CT>(Eh, kexp, AexpT, mod_init, ll0, l0stride, Lm, K, bh, gx, local_lb, logz, zfac, ring, blockIdx.x, threadIdx.x);
+    if (K == 64) wave_linr_body<false, true, ST, CT, false, false, RN>(Eh, kexp, AexpT, mod_init, ll0, l0stride, Lm, K, bh, gx, local_lb, logz, zfac, ring, blockIdx.x, threadIdx.x);
+    else wave_linr_body<false, false, ST, CT, false, false, RN>(Eh, kexp, AexpT, mod_init, ll0, l0stride, Lm, K, bh, gx, local_lb, logz, zfac, ring, blockIdx.x, threadIdx.x);
   }
 }
 

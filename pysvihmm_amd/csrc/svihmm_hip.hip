@@ -2341,7 +2341,7 @@ const char* svihmm_last_kernel_name(svihmm_ctx* h, int32_t slot) {
   return h->last_kernel[slot];
 }
 int svihmm_set_variant(svihmm_ctx* h, int32_t which, int32_t value) {
-  if (!h || which < 0 || which >= 16) return fail("svihmm_set_variant: bad arguments");
+  if (!h || which < 0 || which >= 24) return fail("svihmm_set_variant: bad arguments");
 #ifndef SVIHMM_MEASURE
   // codes under which a call's results are invalid exist in the measurement build only
   if (which == 7 && value == 9)

@@ -223,19 +223,24 @@ int launch_sweep_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t f
   const dim3 grid((unsigned)(pl.nsw + pl.nchunk * pl.ngrp));
   {
     ProfScope ps(h, KS_FB, h->stream);
-#define FZ(XKV, STT, EMV)                                                                                                \
+#define FZ(XKV, STT, EMV, RNV)                                                                                           \
   do {                                                                                                                   \
-    h->last_kernel[KS_FB] = "k_sweep_stats<" #XKV ", " #STT ", " #EMV ">";                                               \
-    hipFuncSetAttribute((const void*)k_sweep_stats<XKV, STT, EMV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL((k_sweep_stats<XKV, STT, EMV>), grid, dim3(256), lds, h->stream, (const STT*)Ehv, kx,             \
+    h->last_kernel[KS_FB] = "k_sweep_stats<" #XKV ", " #STT ", " #EMV ", " #RNV ">";                                     \
+    hipFuncSetAttribute((const void*)k_sweep_stats<XKV, STT, EMV, RNV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((k_sweep_stats<XKV, STT, EMV, RNV>), grid, dim3(256), lds, h->stream, (const STT*)Ehv, kx,        \
                        (const double*)h->Aexp.p, (const double*)h->AexpT.p, mi, l0, (size_t)K, Lq, K, (STT*)h->la.p,     \
                        (STT*)h->lb.p, (double*)h->hx.p, (double*)h->gx.p, (double*)h->local_lb.p, (double*)h->logz.p,    \
                        (double2*)h->zfac.p, gsy, (const double*)h->obs.p, mk, starts_arg, B, Lm, off, D,                 \
                        Fp, F, (const int*)h->fab.p, flags, (double*)h->part.p, pl, (const double*)h->theta_orb.p,        \
                        ed.flags);                                                                                        \
   } while (0)
-#define FZX(STT, EMV) do { if (xk <= 5) FZ(5, STT, EMV); else FZ(9, STT, EMV); } while (0)
-    if (h->cur_f32) FZX(float, false); else if (emw) FZX(double, true); else FZX(double, false);
+#define FZX(STT, EMV, RNV) do { if (xk <= 5) FZ(5, STT, EMV, RNV); else FZ(9, STT, EMV, RNV); } while (0)
+    // (fp64 messages, transition expectations inside a float's range: the sweeps re-normalise every fourth step --
+    //  kernels_wave_linr.h, RN; variant 16 = 1 keeps every step)
+    const bool rn4 = !h->cur_f32 && h->f32_ok && h->variant[16] != 1;
+    if (h->cur_f32) FZX(float, false, 1);
+    else if (emw) { if (rn4) FZX(double, true, 4); else FZX(double, true, 1); }
+    else { if (rn4) FZX(double, false, 4); else FZX(double, false, 1); }
 #undef FZX
 #undef FZ
     HIPCK(hipGetLastError());

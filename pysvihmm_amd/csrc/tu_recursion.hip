@@ -310,8 +310,14 @@ int launch_fb_lin_range(svihmm_ctx* h, int b0, int nb, int Lm, hipStream_t strea
     // quarter of the waves and no LDS exchange; variant[7] = 3: the LDS-broadcast one-wave kernel below)
     if (wave_kernel) {
       const SviSync gsy = sweep_gate(h, stream);
-      hipLaunchKernelGGL((k_wave_linr<double>), gw, dim3(64), 0, stream, Eh, kx, (const double*)h->Aexp.p,
-                         (const double*)h->AexpT.p, mi, l0, l0s, Lm, K, ah, bh, hx, gx, llb, lz, zf, gsy);
+      // (transition expectations inside a float's range: re-normalised every fourth step -- kernels_wave_linr.h, RN;
+      //  variant 16 = 1: every step)
+      if (h->f32_ok && h->variant[16] != 1)
+        hipLaunchKernelGGL((k_wave_linr<double, double, 4>), gw, dim3(64), 0, stream, Eh, kx, (const double*)h->Aexp.p,
+                           (const double*)h->AexpT.p, mi, l0, l0s, Lm, K, ah, bh, hx, gx, llb, lz, zf, gsy);
+      else
+        hipLaunchKernelGGL((k_wave_linr<double>), gw, dim3(64), 0, stream, Eh, kx, (const double*)h->Aexp.p,
+                           (const double*)h->AexpT.p, mi, l0, l0s, Lm, K, ah, bh, hx, gx, llb, lz, zf, gsy);
     }
     else if (K <= 16) WL(16, false); else if (K <= 32) WL(32, false);
     else if (K == 64) WL(64, true); else WL(64, false);

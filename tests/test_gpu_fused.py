@@ -42,11 +42,11 @@ def test_fused_launch_vs_oracle_and_separate_launches(B, Lm, D, wrap):
     assert "k_sweep_stats" not in res[1, "kernel"]
     # the emission tiles ride in the launch where the batch's emission kernel is the 16-row one and its theta operands
     # fit a wave's registers (D % 8 == 0, D <= 32)
-    assert ("true>" in res[3, "kernel"]) == (D <= 32), res[3, "kernel"]
+    assert (", true" in res[3, "kernel"]) == (D <= 32), res[3, "kernel"]
     if B >= 16:
         # same sweeps and statistics with the emission kernel as a launch of its own: the tile arithmetic is the same
         # code, so the statistics agree bit for bit -- a row read before its tile was complete would show here
-        assert "k_sweep_stats" in res[4, "kernel"] and "false>" in res[4, "kernel"], res[4, "kernel"]
+        assert "k_sweep_stats" in res[4, "kernel"] and ", false" in res[4, "kernel"], res[4, "kernel"]
         assert np.array_equal(res[3], res[4]), float(np.max(np.abs(res[3] - res[4])))
     ref = ref_c.estep_minibatch(pb["obs"], pb["mask"], starts, Lm, pb["mod_init"], pb["ltran"], pb["mu"], pb["sigma"],
                                 pb["kappa"], pb["nu"], flags=2 if wrap else 0)
@@ -157,3 +157,39 @@ def test_fused_launch_on_random_shapes_vs_oracle():
         err = float(np.max(np.abs(out - ref) / scale))
         assert err < 1e-6, (case, D, Lm, B, wrap, miss, mode, kern, err)
     assert taken >= 8, taken       # (the sweep is about the fused launch: most shapes must have taken it)
+
+
+@pytest.mark.parametrize("B,Lm,pipeline", [(9, 257, 0), (40, 129, 0), (64, 257, 3)])
+def test_renormalising_every_fourth_step_changes_nothing(B, Lm, pipeline):
+    """The register-resident sweep (stand-alone below 16 windows, inside the fused launch above) re-normalises its
+    vector every fourth step where the transition expectations lie inside a float's range (variant 16 = 1: every
+    step).  Scaling by powers of two is exact, so statistics and local bound must agree BIT FOR BIT -- also with
+    transition expectations at the edge of that range (-59 nats: a step may shrink the vector by 2^-85)."""
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    K, D, T = 64, 32, 6000
+    pb = _problem(K, D, T, seed=B + Lm, miss=0.05)
+    rng = np.random.default_rng(B)
+    starts = rng.integers(0, T - Lm + 1, size=B)
+    for edge in (False, True):
+        ltran = pb["ltran"].copy()
+        if edge:      # a third of the transitions at the edge of the range, the diagonal kept
+            m = (rng.random((K, K)) < 0.33) & ~np.eye(K, dtype=bool)
+            ltran[m] = -59.0
+        out = {}
+        for every in (0, 1):
+            eng = HipEngine(0)
+            try:
+                eng.set_variant(16, every)
+                eng.set_variant("pipeline", pipeline)
+                eng.set_obs(pb["obs"], pb["mask"])
+                eng.set_globals(pb["mod_init"], ltran)
+                eng.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+                out[every] = eng.estep(starts, Lm, flags=L.TRANS_WRAP).buf.copy()
+                kern = eng.last_kernel("forward_backward")
+            finally:
+                eng.close()
+        assert np.all(np.isfinite(out[0])), (edge, kern)
+        # (statistics: bit for bit; the local bound is a sum of logarithms of differently scaled -- equal -- sums: rounding)
+        assert np.array_equal(out[0][:-1], out[1][:-1]), (edge, kern, float(np.max(np.abs(out[0] - out[1]))))
+        assert abs(out[0][-1] - out[1][-1]) <= 1e-13 * abs(out[1][-1]), (edge, kern, out[0][-1], out[1][-1])
