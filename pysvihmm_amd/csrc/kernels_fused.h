@@ -315,7 +315,11 @@ __device__ __forceinline__ void pipe_stats_body(
       for (int ks = 0; ks < ST_RB / 4; ++ks) {
         // the next band: thread 0 reads its counter (the value is looked at one k-step later: no wait on the load),
         // everybody tests the flag
-        // (twice per stage only: the flag is an LDS read, and waiting for it also waits for the operand reads in flight)
+        // (twice per stage only: the flag is an LDS read, and waiting for it also waits for the operand reads in flight.
+        //  Measured, round 6: three looks per stage -- a band that opens 0.2 us after the second look costs the stage
+        //  its prefetch -- made the stages slower (k-steps of stage 1 end at 72.2 instead of 69.6 us); committing the
+        //  prefetched rows inside the k-loop, in the shadow of its last MFMAs, changed nothing: for stages 1-3 the band
+        //  opens during or after the stage's own k-steps, the fetch comes behind them)
         if (more && !issued && (ks == 1 || ks == 4)) {
           if (tid == 0 && !lflag[s + 1] && (int)(seen - tgt_next) >= 0) lflag[s + 1] = 1;
           if (lflag[s + 1]) { fetch(s + 1); issued = true; if (dbg && tid == 0) dbg[14 + 2 * s] = wall_clock64(); }
