@@ -319,7 +319,7 @@ __device__ __forceinline__ void wave_linr_body(
   CT eq[PD];
 #pragma unroll
   for (int u = 0; u < PD; ++u) eq[u] = eclamped(1 + u);
-  static_assert(RN == 1 || RN == 2 || RN == 3 || RN == 4 || RN == 6 || RN == 12, "RN divides the unroll depth");
+  static_assert(RN >= 1 && PD % RN == 0, "RN divides the unroll depth");
   auto step = [&](int s, CT et, const bool rn) {      // rn: a compile-time constant after unrolling (see the loops)
     CT p0 = 0, p1 = 0, p2 = 0, p3 = 0;
     int ef = rn ? wlr_expfield(pcur) : 0;       // (the exponent comes from the ENTERING vector: off the chain)
@@ -402,7 +402,7 @@ __device__ __forceinline__ void wave_linr_body(
 #if !(WLR_KO & 8)
       eq[u] = eclamped(s + u + PD);           // (uniform row arithmetic: scalar instructions)
 #endif
-      step(s + u, et, RN == 1 || (1 + u) % RN == 0);      // (s = 1 mod 12: step s + u re-normalises iff RN | s + u)
+      step(s + u, et, RN == 1 || (1 + u) % RN == 0);      // (s = 1 mod PD: step s + u re-normalises iff RN | s + u)
     }
     // Progress, once per block of PD steps.  Which rows are complete?  Loads and stores of a wave retire through ONE
     // in-order counter: the last step of this block waited for the Eh row requested PD steps earlier, and everything
