@@ -747,7 +747,7 @@ def side_figures(eng, L, pb, step, barrier, obs_host, args):
                                          "per_kernel_frac": {k: f64k[k] / (k64[k] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
                                                              for k in f64k if k in k64},
                                          "note": "algorithmic fp64 flop of 64 windows x 257 rows / wall; a 257-step dependent "
-                                                 "chain at one wave per SIMD: latency-, not throughput-bound (DESIGN 4, "The S = 64 iteration")"}}
+                                                 "chain at one wave per SIMD: latency-, not throughput-bound (DESIGN 4, 'The S = 64 iteration')"}}
 
     # 1b. the same epoch step in the fp32 mode (scaled messages stored as float, statistics GEMM on
     #     v_mfma_f32_16x16x4_f32, emission as the centred quadratic form on the bf16 matrix pipe with
@@ -934,7 +934,7 @@ def svi_iteration(eng, obs_host):
             "roofline": {"bound": "mfma", "kernel": "whole iteration (E-step kernels' algorithmic flop / wall)",
                          "achieved": fl / per_it / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": fl / per_it / 1e12 / FP64_PEAK_TFLOPS,
-                         "note": "five dependent launches on a 257-step chain: latency-bound ("The S = 64 iteration")"},
+                         "note": "five dependent launches on a 257-step chain: latency-bound (DESIGN 4, 'The S = 64 iteration')"},
             "note": "hmmsgd_metaobs.VBHMM.infer, mb_sz=64, L=128: wall per iteration (minibatch sampling + "
                     "E-step + global step + ELBO), from infer(maxit=%d) - infer(maxit=%d); iter_time = "
                     "E-step + global step as the reference clocks it" % (n2, n1)}
