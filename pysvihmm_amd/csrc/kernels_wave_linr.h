@@ -3,6 +3,7 @@
 // round 6: the fused sweep + statistics kernel of tu_stats.hip (kernels_fused.h) runs the same body in its sweep
 // workgroups.  Device templates and inline functions only -- safe to include from several translation units.
 #pragma once
+#include <type_traits>
 #ifndef LN2_D
 #define LN2_D 0.69314718055994530942
 #endif
@@ -320,6 +321,8 @@ __device__ __forceinline__ void wave_linr_body(
 #pragma unroll
   for (int u = 0; u < PD; ++u) eq[u] = eclamped(1 + u);
   static_assert(RN >= 1 && PD % RN == 0, "RN divides the unroll depth");
+  constexpr bool LAZY = RN > 1 && 64 % RN == 0;
+  ST* opl = op + jc;                            // the lane's own output pointer: one 64-bit add per step
   auto step = [&](int s, CT et, const bool rn) {      // rn: a compile-time constant after unrolling (see the loops)
     CT p0 = 0, p1 = 0, p2 = 0, p3 = 0;
     int ef = rn ? wlr_expfield(pcur) : 0;       // (the exponent comes from the ENTERING vector: off the chain)
@@ -355,12 +358,15 @@ __device__ __forceinline__ void wave_linr_body(
 #endif
     const CT q0 = swap_add32(p0, p2), q1 = swap_add32(p1, p3);
     const CT acc = swap_add16(q0, q1);
-    if (FWD) hsum += h;
+    // (LAZY: h only changes at re-normalising steps, so the books of the RN - 1 steps before one are written there)
+    if constexpr (!LAZY) { if (FWD) hsum += h; }
+    else { if (FWD && rn) hsum += (long long)RN * h; }
+    const int h_old = h;
     CT o;
     if (FWD) { o = rn ? LV<CT>::ldx(acc * et, -e2) : acc * et; if (!FULLK) o = valid ? o : (CT)0; pcur = o; }
     else { o = rn ? LV<CT>::ldx(acc, -e2) : acc; if (!FULLK) o = valid ? o : (CT)0; pcur = et * o; }
     if (rn) h += e2;
-    op += dstep;
+    opl += dstep;
 #if !(WLR_KO & 4)
     // (PUB: agent-scope atomic store = written through to where every CU of the device reads it coherently; "complete"
     //  then means "visible", and the statistics workgroups read the row with agent-scope atomic loads -- no cache
@@ -368,14 +374,19 @@ __device__ __forceinline__ void wave_linr_body(
     //  acquire fence in every statistics wave halved the sweeps' speed (208 workgroups x 8 waves invalidating the L2s
     //  at every band); a release fence per band in the sweep wave drains its prefetch queue: 2 us each)
 #ifdef PIPE_PLAIN_STORES
-    if (FULLK || valid) op[jc] = o;
+    if (FULLK || valid) *opl = o;
 #else
-    if (FULLK || valid) { if constexpr (PUB) __hip_atomic_store(&op[jc], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else op[jc] = o; }
+    if (FULLK || valid) { if constexpr (PUB) __hip_atomic_store(opl, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *opl = o; }
 #endif
 #endif
-    hkeep = (j == (s & 63)) ? h : hkeep;
+    if constexpr (!LAZY) hkeep = (j == (s & 63)) ? h : hkeep;
+    else if (rn) {                              // lanes of steps s - RN + 1 .. s - 1: the old book; lane of step s: the new one
+      hkeep = ((unsigned)(j - ((s - RN + 1) & 63)) < (unsigned)(RN - 1)) ? h_old : hkeep;
+      hkeep = (j == (s & 63)) ? h : hkeep;
+    }
     if (FWD && !PUB) ring.v[s & 63][j] = o;
     if ((s & 63) == 63) {                       // uniform
+      if constexpr (LAZY) hkeep = (j > 64 - RN) ? h : hkeep;      // (steps s - RN + 2 .. s lie behind the last re-normalisation)
       if constexpr (PUB) { if (pub->dbgw && threadIdx.x == 0) pub->dbgw[(size_t)blockIdx.x * 32 + 2 + 2 * (s >> 6)] = wall_clock64(); }
       xb[rowof(s - 63 + j)] = (double)hkeep;
       if (FWD && !PUB) ring_flush(64);
@@ -392,7 +403,11 @@ __device__ __forceinline__ void wave_linr_body(
   };
   int s = 1;
   em_wait(em_need(2 * PD));                      // the first block requests rows PD + 1 .. 2 PD
-  for (; s + PD <= Lm; s += PD) {
+  // Blocks whose requests all lie inside the window (INNER) take the row pointer as a running scalar; only the last one
+  // or two clamp the row index (the clamp's 64-bit scalar multiply cost every step nine scalar instructions).
+  const ST* enext = ep + (ptrdiff_t)(1 + PD) * dstep + jc;      // the lane's entry of the first request of block s = 1
+  auto run_block = [&](auto inner_c) {
+    constexpr bool INNER = decltype(inner_c)::value;
     if constexpr (EMW) {
       if (em_r < pub->em_n) em_seen_v = __hip_atomic_load(pub->em_cnt + 16 * em_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -400,7 +415,8 @@ __device__ __forceinline__ void wave_linr_body(
     for (int u = 0; u < PD; ++u) {
       const CT et = eq[u];
 #if !(WLR_KO & 8)
-      eq[u] = eclamped(s + u + PD);           // (uniform row arithmetic: scalar instructions)
+      if constexpr (INNER) { eq[u] = eload(enext); enext += dstep; }
+      else eq[u] = eclamped(s + u + PD);
 #endif
       step(s + u, et, RN == 1 || (1 + u) % RN == 0);      // (s = 1 mod PD: step s + u re-normalises iff RN | s + u)
     }
@@ -418,15 +434,22 @@ __device__ __forceinline__ void wave_linr_body(
         em_wait(em_need(s + 3 * PD - 1));       // the next block requests rows up to (s + PD) + 2 PD - 1
       }
     }
-  }
+  };
+  // (only where a workgroup runs ONE direction -- the fused kernel: with both directions in one kernel, as in k_wave_linr,
+  //  the second copy of the unrolled block pushes the step loops out of the instruction cache: fp32-mode iteration 0.168 ->
+  //  0.177 ms, measured)
+  if constexpr (PUB) { for (; s + 2 * PD <= Lm; s += PD) run_block(std::true_type{}); }
+  for (; s + PD <= Lm; s += PD) run_block(std::false_type{});
 #pragma unroll
   for (int u = 0; u < PD; ++u)
     if (s + u < Lm) step(s + u, eq[u], RN == 1 || (1 + u) % RN == 0);
   em_wait(em_half);                             // (short windows: the epilogue reads kexp of every row)
   if constexpr (PUB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   publish(0x7ffffffe);                          // (whatever is left: nobody may wait for a band the sweep never names)
+  if constexpr (LAZY) { if (FWD) hsum += (long long)((Lm - 1) % RN) * h; }     // the steps behind the last re-normalisation
   {
     const int sl = Lm - 1, s0 = sl & ~63;
+    if constexpr (LAZY) hkeep = (s0 + j > sl - sl % RN && s0 + j <= sl) ? h : hkeep;
     if ((sl & 63) != 63 && s0 + j <= sl) xb[rowof(s0 + j)] = (double)hkeep;
     if (FWD && !PUB && (sl & 63) != 63) ring_flush((sl & 63) + 1);
   }
