@@ -323,6 +323,9 @@ __device__ __forceinline__ void wave_linr_body(
   static_assert(RN >= 1 && PD % RN == 0, "RN divides the unroll depth");
   constexpr bool LAZY = RN > 1 && 64 % RN == 0;
   ST* opl = op + jc;                            // the lane's own output pointer: one 64-bit add per step
+  // (tried: two accumulator sets, the next step's zeroed between this step's last FMA group and the lane swaps, where the
+  //  compiler pads four s_nop after the asm it cannot look into -- it moved the zeroing back in front of the next FMAs
+  //  and, with a scheduling barrier to pin it, padded eight)
   auto step = [&](int s, CT et, const bool rn) {      // rn: a compile-time constant after unrolling (see the loops)
     CT p0 = 0, p1 = 0, p2 = 0, p3 = 0;
     int ef = rn ? wlr_expfield(pcur) : 0;       // (the exponent comes from the ENTERING vector: off the chain)
@@ -379,18 +382,29 @@ __device__ __forceinline__ void wave_linr_body(
     if (FULLK || valid) { if constexpr (PUB) __hip_atomic_store(opl, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *opl = o; }
 #endif
 #endif
-    if constexpr (!LAZY) hkeep = (j == (s & 63)) ? h : hkeep;
-    else if (rn) {                              // lanes of steps s - RN + 1 .. s - 1: the old book; lane of step s: the new one
-      hkeep = ((unsigned)(j - ((s - RN + 1) & 63)) < (unsigned)(RN - 1)) ? h_old : hkeep;
+    if constexpr (!LAZY) {
       hkeep = (j == (s & 63)) ? h : hkeep;
-    }
-    if (FWD && !PUB) ring.v[s & 63][j] = o;
-    if ((s & 63) == 63) {                       // uniform
-      if constexpr (LAZY) hkeep = (j > 64 - RN) ? h : hkeep;      // (steps s - RN + 2 .. s lie behind the last re-normalisation)
-      if constexpr (PUB) { if (pub->dbgw && threadIdx.x == 0) pub->dbgw[(size_t)blockIdx.x * 32 + 2 + 2 * (s >> 6)] = wall_clock64(); }
-      xb[rowof(s - 63 + j)] = (double)hkeep;
-      if (FWD && !PUB) ring_flush(64);
-      if constexpr (PUB) { if (pub->dbgw && threadIdx.x == 0) pub->dbgw[(size_t)blockIdx.x * 32 + 3 + 2 * (s >> 6)] = wall_clock64(); }
+      if (FWD && !PUB) ring.v[s & 63][j] = o;
+      if ((s & 63) == 63) {                     // uniform: the books (and the ring's rows) of steps s - 63 .. s
+        if constexpr (PUB) { if (pub->dbgw && threadIdx.x == 0) pub->dbgw[(size_t)blockIdx.x * 32 + 2 + 2 * (s >> 6)] = wall_clock64(); }
+        xb[rowof(s - 63 + j)] = (double)hkeep;
+        if (FWD && !PUB) ring_flush(64);
+        if constexpr (PUB) { if (pub->dbgw && threadIdx.x == 0) pub->dbgw[(size_t)blockIdx.x * 32 + 3 + 2 * (s >> 6)] = wall_clock64(); }
+      }
+    } else {
+      // LAZY: the books only change at re-normalising steps, so the lanes of steps s - RN + 1 .. s - 1 get the old book
+      // HERE, the 64-step flush rides in the re-normalising step that opens the next group of 64 (one test per RN
+      // steps instead of four scalar instructions in every step), and then the lane of step s gets the new book
+      if (rn) {
+        hkeep = ((unsigned)(j - ((s - RN + 1) & 63)) < (unsigned)(RN - 1)) ? h_old : hkeep;
+        if ((s & 63) == 0) {                    // uniform: steps s - 64 .. s - 1 are complete
+          if constexpr (PUB) { if (pub->dbgw && threadIdx.x == 0) pub->dbgw[(size_t)blockIdx.x * 32 + 2 * (s >> 6)] = wall_clock64(); }
+          xb[rowof(s - 64 + j)] = (double)hkeep;
+          if (FWD && !PUB) ring_flush(64);      // (before this step's vector takes ring row 0)
+        }
+        hkeep = (j == (s & 63)) ? h : hkeep;
+      }
+      if (FWD && !PUB) ring.v[s & 63][j] = o;
     }
 #if WLR_KO & 48
     // measurement only (tools/probe/wlr_probe.hip): what publishing the sweep's progress would cost -- an
@@ -450,8 +464,9 @@ __device__ __forceinline__ void wave_linr_body(
   {
     const int sl = Lm - 1, s0 = sl & ~63;
     if constexpr (LAZY) hkeep = (s0 + j > sl - sl % RN && s0 + j <= sl) ? h : hkeep;
-    if ((sl & 63) != 63 && s0 + j <= sl) xb[rowof(s0 + j)] = (double)hkeep;
-    if (FWD && !PUB && (sl & 63) != 63) ring_flush((sl & 63) + 1);
+    // (LAZY: a full last group is flushed here as well -- no re-normalising step follows it)
+    if ((LAZY || (sl & 63) != 63) && s0 + j <= sl) xb[rowof(s0 + j)] = (double)hkeep;
+    if (FWD && !PUB && (LAZY || (sl & 63) != 63)) ring_flush((sl & 63) + 1);
   }
   // (PUB variant: no row-sum ring, no flushes inside the chain -- the terms sum_t log(sum_j ah_t[j]) of the local bound are
   //  formed by the statistics workgroups of the fused kernel, which read every stored vector anyway (kernels_fused.h);
