@@ -265,11 +265,14 @@ __device__ __forceinline__ void wave_linr_body(
       a[q][i] = (FULLK || (tgt < K && src < K)) ? (CT)Am[(size_t)src * K + tgt] : (CT)0;
     }
   const size_t wrow = (size_t)b * Lm;
-  const ptrdiff_t dstep = FWD ? (ptrdiff_t)K : -(ptrdiff_t)K;
+  // (FULLK: the row stride is the constant 64 -- the unrolled block's stores and row requests become immediate offsets
+  //  from one pointer per block instead of a 64-bit vector add per step)
+  const ptrdiff_t KS = FULLK ? (ptrdiff_t)64 : (ptrdiff_t)K;
+  const ptrdiff_t dstep = FWD ? KS : -KS;
   const size_t row0 = FWD ? 0 : (size_t)(Lm - 1);
   // uniform row pointers (scalar registers) + the lane's column: loads and stores take base + offset
-  const ST* __restrict__ ep = Eh + (wrow + row0) * K;       // Eh row of sweep step 0
-  ST* __restrict__ op = out + (wrow + row0) * K;
+  const ST* __restrict__ ep = Eh + (wrow + row0) * KS;      // Eh row of sweep step 0
+  ST* __restrict__ op = out + (wrow + row0) * KS;
   double* __restrict__ xb = xout + wrow;
   auto rowof = [&](int s) { return FWD ? s : Lm - 1 - s; };
   // exponent books: h = the current vector's binary exponent (an exact integer: |h| <= ~1100 Lm),
