@@ -52,7 +52,9 @@ const char* svihmm_last_kernel_name(svihmm_ctx* h, int32_t slot);
  *      fused launch where that is ahead, else one launch after the other; 1: never fused; 2: the two-stream pipeline of
  *      round 2; 3: the fused launch for every batch it can take, whatever its size or precision mode, WITH the emission
  *      tiles computed inside it where the batch's emission kernel is the 16-row fp64 one (D % 8 == 0, D <= 32) -- tests;
- *      4: as 0; 5: as 0 plus the emission tiles inside the launch -- measured, not ahead: tu_fused.hip, sweep_emission_ok)
+ *      4: as 0; 5: as 0 plus the emission tiles inside the launch -- measured, not ahead: tu_fused.hip, sweep_emission_ok;
+ *      6: as 0, but the fp32 mode keeps float messages + its bf16 statistics kernel for minibatch-sized batches instead of
+ *      the fused launch on fp64 messages behind float emission rows)
  * | 6 blocked scan for one long window (B = 1, Lm >= 2048, K <= 64; 1 = off)
  * | 9 automatic centring of the resident observations at upload (1 = off: c = 0)
  * | 12 barrier-free statistics GEMM with three LDS buffers (1 = off: the double-buffered kernel)

@@ -225,6 +225,10 @@ struct svihmm_ctx {
   unsigned em_tgt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // emission rounds inside the fused launch: counter targets (monotonic)
   // An emission launch held back for the fused E-step kernel (launch_emission with em_defer_req set has done everything
   // but the launch: buffers, theta orbit, the pending window starts); launch_emission_deferred sends it after all
+  // fp32 mode, minibatch-sized batch bound for the fused sweep + statistics launch: the emission kernel of the mode writes
+  // float Eh (eh_float), the messages and the statistics stay fp64 (cur_f32 = false) -- the fused fp64 stages behind a
+  // sweep that re-normalises every fourth step end earlier than float messages + the bf16 statistics kernel behind it
+  bool f32_fused_req = false, eh_float = false;
   bool em_defer_req = false;
   struct EmDeferred { bool active = false; const int64_t* starts = nullptr; int64_t* starts_copy = nullptr; int nstarts = 0;
                       int B = 0, Lm = 0; uint32_t flags = 0; double* out = nullptr; double* kexp = nullptr; double* ll0 = nullptr; } em_def;
@@ -351,6 +355,7 @@ int cat_uncentre(svihmm_ctx* h);
 int launch_fb_chain(svihmm_ctx* h, int Lm, bool total);
 int launch_emission_deferred(svihmm_ctx* h);
 bool sweep_emission_ok(const svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags);
+bool sweep_mixed_ok(const svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags);
 bool sweep_stats_ok(const svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags);
 int launch_sweep_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags);
 SviSync sweep_gate(svihmm_ctx* h, hipStream_t stream);

@@ -436,10 +436,10 @@ __device__ __attribute__((noinline)) void pipe_emission_role(
                               pl->em_nround, nst, sb, cnt, dbg);
   if (dbg && threadIdx.x == 0) dbg[29] = wall_clock64();
 }
-template <int XK, typename ST, bool EMW = false, int RN = 1>
+template <int XK, typename ST, bool EMW = false, int RN = 1, typename SE = ST>
 __global__ __launch_bounds__(256) void k_sweep_stats(
-    // sweeps (k_wave_linr's arguments)
-    const ST* __restrict__ Eh, const double* __restrict__ kexp, const double* __restrict__ Aexp,
+    // sweeps (k_wave_linr's arguments; SE: storage type of Eh where it is not the messages' -- fp32 mode with fp64 messages)
+    const SE* __restrict__ Eh, const double* __restrict__ kexp, const double* __restrict__ Aexp,
     const double* __restrict__ AexpT, const double* __restrict__ mod_init, const double* __restrict__ ll0,
     size_t l0stride, int Lq, int K, ST* __restrict__ ah, ST* __restrict__ bh, double* __restrict__ hx,
     double* __restrict__ gx, double* __restrict__ local_lb, double* __restrict__ logz, double2* __restrict__ zfac,
@@ -479,8 +479,8 @@ __global__ __launch_bounds__(256) void k_sweep_stats(
     }
     WlrRing<double>& ring = *reinterpret_cast<WlrRing<double>*>(smem);     // (not touched by the publishing variant of the body)
     if (pl.dbg && threadIdx.x == 0) pl.dbg[(size_t)bx * 32] = wall_clock64();
-    if (fwd) wave_linr_body<true, true, ST, double, true, EMW, RN>(Eh, kexp, Aexp, mod_init, ll0, l0stride, Lq, K, ah, hx, local_lb, logz, zfac, ring, b, j, &pl.pub);
-    else wave_linr_body<false, true, ST, double, true, EMW, RN>(Eh, kexp, AexpT, mod_init, ll0, l0stride, Lq, K, bh, gx, local_lb, logz, zfac, ring, b, j, &pl.pub);
+    if (fwd) wave_linr_body<true, true, ST, double, true, EMW, RN, SE>(Eh, kexp, Aexp, mod_init, ll0, l0stride, Lq, K, ah, hx, local_lb, logz, zfac, ring, b, j, &pl.pub);
+    else wave_linr_body<false, true, ST, double, true, EMW, RN, SE>(Eh, kexp, AexpT, mod_init, ll0, l0stride, Lq, K, bh, gx, local_lb, logz, zfac, ring, b, j, &pl.pub);
     if (pl.dbg && threadIdx.x == 0) pl.dbg[(size_t)bx * 32 + 1] = wall_clock64();
     return;
   }
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256) void k_sweep_stats(
   if (pl.exp == 1) return;
   if (pl.exp == 2) { const unsigned long long t0 = wall_clock64(); while (wall_clock64() - t0 < 12000ull) __builtin_amdgcn_s_sleep(64); return; }
   if constexpr (EMW) {
-    if constexpr (sizeof(ST) == 8)
+    if constexpr (sizeof(SE) == 8)
       pipe_emission_role((PIPE_AS1(const double))obs, (PIPE_AS1(const uint8_t))mask, (PIPE_AS1(const int64_t))starts, (int64_t)B * Lq,
                          Lq, D, K, (PIPE_AS1(const double))orb, eflags, (PIPE_AS1(double)) const_cast<double*>(reinterpret_cast<const double*>(Eh)),
                          (PIPE_AS1(double)) const_cast<double*>(kexp), (PIPE_AS1(double)) const_cast<double*>(ll0),

@@ -199,9 +199,11 @@ struct WlrPub {
 // and the consumers' product ah bh above 2^-880 -- RN = 6 would not leave that product inside fp64.  Scaling by powers of
 // two is exact: the stored mantissas and every statistic are those of RN = 1 bit for bit; the local bound (a sum of
 // logarithms of the differently scaled sums + the exponent books) agrees to rounding.
-template <bool FWD, bool FULLK, typename ST, typename CT, bool PUB = false, bool EMW = false, int RN = 1>
+// SE: storage type of the emission rows Eh where it differs from the messages' (fp32 mode inside the fused kernel: float Eh
+// from the bf16 emission kernel, fp64 messages).
+template <bool FWD, bool FULLK, typename ST, typename CT, bool PUB = false, bool EMW = false, int RN = 1, typename SE = ST>
 __device__ __forceinline__ void wave_linr_body(
-    const ST* __restrict__ Eh, const double* __restrict__ kexp,
+    const SE* __restrict__ Eh, const double* __restrict__ kexp,
     const double* __restrict__ Am, const double* __restrict__ mod_init,
     const double* __restrict__ ll0, size_t l0stride, int Lm, int K, ST* __restrict__ out,
     double* __restrict__ xout, double* __restrict__ local_lb, double* __restrict__ logz,
@@ -245,7 +247,7 @@ __device__ __forceinline__ void wave_linr_body(
   };
   const int em_half = (Lm - 1) >> 1;              // the largest priority there is
   auto em_need = [&](int srow) { return srow < em_half ? srow : em_half; };
-  auto eload = [&](const ST* p) -> CT {
+  auto eload = [&](const SE* p) -> CT {
     if constexpr (EMW) return (CT)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else return (CT)*p;
   };
@@ -271,7 +273,7 @@ __device__ __forceinline__ void wave_linr_body(
   const ptrdiff_t dstep = FWD ? KS : -KS;
   const size_t row0 = FWD ? 0 : (size_t)(Lm - 1);
   // uniform row pointers (scalar registers) + the lane's column: loads and stores take base + offset
-  const ST* __restrict__ ep = Eh + (wrow + row0) * KS;      // Eh row of sweep step 0
+  const SE* __restrict__ ep = Eh + (wrow + row0) * KS;      // Eh row of sweep step 0
   ST* __restrict__ op = out + (wrow + row0) * KS;
   double* __restrict__ xb = xout + wrow;
   auto rowof = [&](int s) { return FWD ? s : Lm - 1 - s; };
@@ -422,7 +424,7 @@ __device__ __forceinline__ void wave_linr_body(
   em_wait(em_need(2 * PD));                      // the first block requests rows PD + 1 .. 2 PD
   // Blocks whose requests all lie inside the window (INNER) take the row pointer as a running scalar; only the last one
   // or two clamp the row index (the clamp's 64-bit scalar multiply cost every step nine scalar instructions).
-  const ST* enext = ep + (ptrdiff_t)(1 + PD) * dstep + jc;      // the lane's entry of the first request of block s = 1
+  const SE* enext = ep + (ptrdiff_t)(1 + PD) * dstep + jc;      // the lane's entry of the first request of block s = 1
   auto run_block = [&](auto inner_c) {
     constexpr bool INNER = decltype(inner_c)::value;
     if constexpr (EMW) {

@@ -129,7 +129,7 @@ int svihmm_set_precision(svihmm_ctx* h, int32_t mode) {
 int svihmm_get_precision(svihmm_ctx* h, int32_t* mode_out, int32_t* last_batch_f32_out) {
   if (!h) return fail("svihmm_get_precision: NULL handle");
   if (mode_out) *mode_out = h->prec;
-  if (last_batch_f32_out) *last_batch_f32_out = h->cur_f32 ? 1 : 0;
+  if (last_batch_f32_out) *last_batch_f32_out = (h->cur_f32 || h->eh_float) ? 1 : 0;
   return 0;
 }
 int svihmm_sync(svihmm_ctx* h) {
@@ -913,6 +913,7 @@ int prepare_ll(svihmm_ctx* h, const int64_t* starts, int B, int Lm, uint32_t fla
   CK(check_windows(h, starts, B, Lm, !host_ll || need_obs_for_stats));
   if (starts) CK(upload_starts(h, starts, B));
   h->cur_f32 = false;
+  h->eh_float = false;
   if (host_ll) {
     if (!h->have_host_ll || h->hostB != B || h->hostLm != Lm)
       return fail("SVIHMM_USE_HOST_LLIKS: no uploaded lliks of shape [B,Lm,K]");
@@ -928,6 +929,10 @@ int prepare_ll(svihmm_ctx* h, const int64_t* starts, int B, int Lm, uint32_t fla
                         f32_wide_ok(h, (int64_t)B * Lm);
     h->cur_f32 = lin && h->prec == 1 && h->f32_ok && (!two_pass || wide32) && !use_chain(h, B, Lm);
     CK(launch_emission(h, B, Lm, flags, lin && !two_pass));
+    if (h->cur_f32 && !two_pass && h->f32_fused_req) {     // (float Eh is written; from here on the batch is an fp64 one)
+      h->eh_float = true;
+      h->cur_f32 = false;
+    }
     // wide models: plain log-likelihoods + one scaling pass (fp32 mode: float, in place in h->ll, first rows
     // of the windows in h->ll0 -- the layout of the K <= 64 path, so eh_in_llE stays false)
     if (wide32) CK(launch_scale_ll_f32(h, B, Lm));
@@ -1198,10 +1203,13 @@ static int estep_core(svihmm_ctx* h, const int64_t* starts, int B, int Lm, int i
     // (the fused launch below can compute the emission tiles itself: launch_emission then does everything but launch)
     h->em_def.active = false;
     h->em_defer_req = var == 3 && sweep_emission_ok(h, B, Lm, inner_off, inner_len, flags);
+    h->f32_fused_req = var == 3 && sweep_mixed_ok(h, B, Lm, inner_off, inner_len, flags);
     const int prc = prepare_ll(h, starts, B, Lm, flags, true, var == 3);
     h->em_defer_req = false;
+    h->f32_fused_req = false;
     if (prc) { h->em_def.active = false; return prc; }
     const bool fused = var == 3 && sweep_stats_ok(h, B, Lm, inner_off, inner_len, flags);
+    if (h->eh_float && !fused) return fail("internal: float emission rows without the fused launch that reads them");
     if (!fused) CK(launch_emission_deferred(h));
     if (fused) {
       // minibatch-sized batches of the five-tile shapes: sweeps and statistics in one launch, the statistics'

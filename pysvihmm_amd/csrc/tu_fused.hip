@@ -72,6 +72,14 @@ bool sweep_stats_ok(const svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_
   if (h->variant[4] != 3 && (B < 16 || h->cur_f32)) return false;
   return true;
 }
+// fp32 mode: will this batch take the fused launch with float emission rows and fp64 messages (asked BEFORE prepare_ll)?
+// The same thresholds as the fp64 batch's; variant 4 = 6: never (the mode's own sweep + bf16 statistics kernels).
+bool sweep_mixed_ok(const svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t flags) {
+  int nst = 0;
+  if (h->prec != 1 || !h->f32_ok || h->variant[4] == 6 || h->variant[4] == 3) return false;
+  if (!fused_shape_ok(h, B, Lq, off, Lm, flags, &nst)) return false;
+  return B >= 16;
+}
 // Will the fused launch of this batch also compute the emission tiles (asked BEFORE prepare_ll; launch_emission holds
 // its launch back only on the fp64 minibatch path whose tile the fused kernel carries)?
 // OFF unless asked for (variant 4 = 3: everything the kernel can take, tests; 5: the automatic thresholds + emission).
@@ -235,12 +243,30 @@ int launch_sweep_stats(svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_t f
                        ed.flags);                                                                                        \
   } while (0)
 #define FZX(STT, EMV, RNV) do { if (xk <= 5) FZ(5, STT, EMV, RNV); else FZ(9, STT, EMV, RNV); } while (0)
+#define FZM(XKV, RNV)                                                                                                    \
+  do {                                                                                                                   \
+    h->last_kernel[KS_FB] = "k_sweep_stats<" #XKV ", double, false, " #RNV ", float>";                                   \
+    hipFuncSetAttribute((const void*)k_sweep_stats<XKV, double, false, RNV, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((k_sweep_stats<XKV, double, false, RNV, float>), grid, dim3(256), lds, h->stream, (const float*)Ehv, kx, \
+                       (const double*)h->Aexp.p, (const double*)h->AexpT.p, mi, l0, (size_t)K, Lq, K, (double*)h->la.p, \
+                       (double*)h->lb.p, (double*)h->hx.p, (double*)h->gx.p, (double*)h->local_lb.p, (double*)h->logz.p, \
+                       (double2*)h->zfac.p, gsy, (const double*)h->obs.p, mk, starts_arg, B, Lm, off, D,                 \
+                       Fp, F, (const int*)h->fab.p, flags, (double*)h->part.p, pl, (const double*)h->theta_orb.p,        \
+                       ed.flags);                                                                                        \
+  } while (0)
+#define FZXM(RNV) do { if (xk <= 5) FZM(5, RNV); else FZM(9, RNV); } while (0)
     // (fp64 messages, transition expectations inside a float's range: the sweeps re-normalise every fourth step --
     //  kernels_wave_linr.h, RN; variant 16 = 1 keeps every step)
     const bool rn4 = !h->cur_f32 && h->f32_ok && h->variant[16] != 1;
-    if (h->cur_f32) FZX(float, false, 1);
+    if (h->eh_float) {       // fp32 mode: float emission rows, fp64 messages and statistics
+      if (emw || h->cur_f32) return fail("internal: mixed-format fused launch in the wrong state");
+      if (rn4) FZXM(4); else FZXM(1);
+    }
+    else if (h->cur_f32) FZX(float, false, 1);
     else if (emw) { if (rn4) FZX(double, true, 4); else FZX(double, true, 1); }
     else { if (rn4) FZX(double, false, 4); else FZX(double, false, 1); }
+#undef FZXM
+#undef FZM
 #undef FZX
 #undef FZ
     HIPCK(hipGetLastError());

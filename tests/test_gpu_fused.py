@@ -193,3 +193,37 @@ def test_renormalising_every_fourth_step_changes_nothing(B, Lm, pipeline):
         # (statistics: bit for bit; the local bound is a sum of logarithms of differently scaled -- equal -- sums: rounding)
         assert np.array_equal(out[0][:-1], out[1][:-1]), (edge, kern, float(np.max(np.abs(out[0] - out[1]))))
         assert abs(out[0][-1] - out[1][-1]) <= 1e-13 * abs(out[1][-1]), (edge, kern, out[0][-1], out[1][-1])
+
+
+def test_f32_mode_minibatch_takes_the_fused_launch_with_fp64_messages():
+    """fp32 mode, minibatch-sized batch: the mode's bf16 emission kernel writes float emission rows, sweeps and
+    statistics run as the fused launch on fp64 messages (k_sweep_stats<..., double, ..., float>) -- reported as the fp32
+    format, within the mode's tolerance of the fp64 statistics (closer than the float-message path: variant 4 = 6)."""
+    from pysvihmm_amd.engine import HipEngine
+    from pysvihmm_amd import _lib as L
+    K, D, T, B, Lm = 64, 32, 40000, 64, 257
+    pb = _problem(K, D, T, seed=64, miss=0.0)
+    starts = (np.arange(B, dtype=np.int64) * (T // B)) % (T - Lm)
+    out = {}
+    for mode, prec in ((0, "f64"), (0, "f32"), (6, "f32")):
+        eng = HipEngine(0)
+        try:
+            eng.set_precision(prec)
+            eng.set_variant("pipeline", mode)
+            eng.set_obs(pb["obs"], None)
+            eng.set_globals(pb["mod_init"], pb["ltran"])
+            eng.set_emission_niw(pb["mu"], pb["sigma"], pb["kappa"], pb["nu"])
+            out[mode, prec] = (eng.estep(starts, Lm, flags=L.TRANS_WRAP).buf.copy(), eng.last_kernel("forward_backward"),
+                               eng.precision())
+        finally:
+            eng.close()
+    ref = out[0, "f64"][0]
+    scale = np.maximum(np.abs(ref), 1e-6 * B * Lm)
+    kern = out[0, "f32"][1]
+    assert "k_sweep_stats" in kern and kern.endswith("float>") and ", double," in kern, kern
+    assert out[0, "f32"][2] == ("f32", True)
+    assert "k_sweep_stats" not in out[6, "f32"][1] and out[6, "f32"][2] == ("f32", True)
+    e_mixed = float(np.max(np.abs(out[0, "f32"][0] - ref) / scale))
+    e_float = float(np.max(np.abs(out[6, "f32"][0] - ref) / scale))
+    assert e_mixed < 1e-3 and e_float < 1e-3, (e_mixed, e_float)
+    assert e_mixed <= e_float * 1.5, (e_mixed, e_float)
