@@ -1238,7 +1238,7 @@ __device__ __forceinline__ void k_niw_to_theta_wave_body(
   double rdv[DMAX];                       // 1 / L[j][j] (uniform): the triangular inverse multiplies by it
 #pragma unroll
   for (int j = 0; j < DMAX; ++j) {
-    const double djj = __shfl(A[j], j, 64);
+    const double djj = readlane_f64(A[j], j);
     bad |= !(djj > 0.0);
     // sqrt and reciprocal sqrt together: v_rsq_f64 + two coupled Newton steps (g -> sqrt x, hh -> 1 / (2 sqrt x))
     // and a last correction of g: ~12 instructions in place of the ~40 of sqrt() and a division
@@ -1471,7 +1471,7 @@ __device__ __forceinline__ void k_niw_to_theta_wave32s_body(
   double rdv[DMAX];
 #pragma unroll
   for (int j = 0; j < DMAX; ++j) {
-    const double djj = __shfl(Ah[j >> 1], j + 32 * (j & 1), 64);     // A[j][j]: row j, half j & 1
+    const double djj = readlane_f64(Ah[j >> 1], j + 32 * (j & 1));   // A[j][j]: row j, half j & 1
     bad |= !(djj > 0.0);
     double d, rd;
     {
