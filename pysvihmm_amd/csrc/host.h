@@ -221,7 +221,8 @@ struct svihmm_ctx {
   // fused sweep + statistics launch (tu_fused.hip): band counters with their running targets, cached readiness orders
   Buf pipe_cnt;
   unsigned pipe_tgt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  struct PipeTab { Buf buf; int Lq = -1, off = -1, Lm = -1, NS = -1, B = -1, nst = -1; bool wrap = false; unsigned long long stamp = 0; };
+  struct PipeTab { Buf buf; int Lq = -1, off = -1, Lm = -1, NS = -1, B = -1, nst = -1; bool wrap = false; unsigned long long stamp = 0;
+                   int thr[12], em_thr[12], em_n = 0, ntile = 0, nround = 0; };    // (host copies of what the plan needs: a hit costs no sort)
   unsigned em_tgt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // emission rounds inside the fused launch: counter targets (monotonic)
   // An emission launch held back for the fused E-step kernel (launch_emission with em_defer_req set has done everything
   // but the launch: buffers, theta orbit, the pending window starts); launch_emission_deferred sends it after all

@@ -66,9 +66,10 @@ bool sweep_stats_ok(const svihmm_ctx* h, int B, int Lq, int off, int Lm, uint32_
   if (!fused_shape_ok(h, B, Lq, off, Lm, flags, &nst)) return false;
   if (!h->lin_mode || h->q_valid || h->eh_in_llE) return false;
   // (measured, tools/r6_fused_check.py: from ~16 windows on the fused launch is ahead of sweeps + statistics one after the
-  //  other -- 169 against 178 us at 64 windows --, below that the statistics launch is too short to be worth hiding; the
-  //  fp32 mode keeps its own statistics kernel on the bf16 pipe (29 us: the fused fp64 stages end later than that);
-  //  variant 4 = 3 forces the fused launch for every batch it can take -- tests)
+  //  other -- 161 against 171 us at 64 windows --, below that the statistics launch is too short to be worth hiding;
+  //  float MESSAGES (cur_f32) keep the mode's own sweep + bf16 statistics kernels -- the fp32 mode's minibatches come
+  //  here as fp64 batches behind float emission rows (sweep_mixed_ok); variant 4 = 3 forces the fused launch for every
+  //  batch it can take -- tests)
   if (h->variant[4] != 3 && (B < 16 || h->cur_f32)) return false;
   return true;
 }
@@ -107,6 +108,20 @@ bool sweep_emission_ok(const svihmm_ctx* h, int B, int Lq, int off, int Lm, uint
 // tiles; em_thr[r] = every row of priority <= em_thr[r] lies in a tile of rounds 0 .. r
 static int pipe_order(svihmm_ctx* h, int B, int nst, int Lq, int off, int Lm, bool wrap, int NS, int Lb, WlrPub* pub,
                       const int** ord_dev, const int** tiles_dev, int* ntile_out, int* nround_out) {
+  // cache of device tables: [order | tiles] per (B, nst, Lq, off, Lm, wrap, NS), with the host's copies of the thresholds;
+  // a table stays untouched while launches that read it may be in flight.  (The lookup comes first: the two sorts below
+  // are ~20 us of host time, and the resident loop calls this once per iteration.)
+  const size_t til_off = ((size_t)Lm * sizeof(int) + 15) & ~(size_t)15;
+  static_assert(WLR_MAX_BANDS == 12, "PipeTab's threshold arrays");
+  for (auto& e : h->pipe_tabs)
+    if (e.buf.p && e.Lq == Lq && e.off == off && e.Lm == Lm && e.wrap == wrap && e.NS == NS && e.B == B && e.nst == nst) {
+      e.stamp = ++h->pipe_stamp;
+      pub->nb = NS;
+      for (int i = 0; i < WLR_MAX_BANDS; ++i) { pub->thr[i] = e.thr[i]; pub->em_thr[i] = e.em_thr[i]; }
+      pub->em_n = e.em_n; *ntile_out = e.ntile; *nround_out = e.nround;
+      *ord_dev = (const int*)e.buf.p; *tiles_dev = (const int*)((const char*)e.buf.p + til_off);
+      return 0;
+    }
   std::vector<int> need((size_t)Lm), idx((size_t)Lm);
   auto n1 = [&](int t) { const int tf = off + t; return std::max(tf, Lq - 1 - tf); };
   for (int t = 0; t < Lm; ++t) {
@@ -137,15 +152,6 @@ static int pipe_order(svihmm_ctx* h, int B, int nst, int Lq, int off, int Lm, bo
     for (int r = 0; r < nround; ++r)
       pub->em_thr[r] = (r + 1) * nst < ntile ? tprio[tidx[(size_t)(r + 1) * nst]] - 1 : 0x7fffffff;
   }
-  // cache of device tables: [order | tiles] per (B, nst, Lq, off, Lm, wrap, NS); a table stays untouched while
-  // launches that read it may be in flight
-  const size_t til_off = ((size_t)Lm * sizeof(int) + 15) & ~(size_t)15;
-  for (auto& e : h->pipe_tabs)
-    if (e.buf.p && e.Lq == Lq && e.off == off && e.Lm == Lm && e.wrap == wrap && e.NS == NS && e.B == B && e.nst == nst) {
-      e.stamp = ++h->pipe_stamp;
-      *ord_dev = (const int*)e.buf.p; *tiles_dev = (const int*)((const char*)e.buf.p + til_off);
-      return 0;
-    }
   svihmm_ctx::PipeTab* slot = nullptr;
   for (auto& e : h->pipe_tabs) if (!e.buf.p) { slot = &e; break; }
   if (!slot) {
@@ -160,6 +166,8 @@ static int pipe_order(svihmm_ctx* h, int B, int nst, int Lq, int off, int Lm, bo
   HIPCK(hipMemcpy(slot->buf.p, img.data(), img.size(), hipMemcpyHostToDevice));
   slot->Lq = Lq; slot->off = off; slot->Lm = Lm; slot->wrap = wrap; slot->NS = NS; slot->B = B; slot->nst = nst;
   slot->stamp = ++h->pipe_stamp;
+  for (int i = 0; i < WLR_MAX_BANDS; ++i) { slot->thr[i] = i < NS ? pub->thr[i] : 0; slot->em_thr[i] = i < pub->em_n ? pub->em_thr[i] : 0; }
+  slot->em_n = pub->em_n; slot->ntile = ntile; slot->nround = nround;
   *ord_dev = (const int*)slot->buf.p; *tiles_dev = (const int*)((const char*)slot->buf.p + til_off);
   return 0;
 }
